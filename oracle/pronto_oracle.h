@@ -1,0 +1,143 @@
+/*
+ * pronto_oracle.h -- CPU restatement of Pronto's RBIS/RBIM EKF hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product: only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library, and only as
+ * the checker / the timed CPU baseline.  The product path (pronto_amd/, include/) never links it.
+ *
+ * PARITY UNPINNED: the reference has no tests, golden vectors or fixtures for this path
+ *  and cannot be compiled here (Eigen3, eigen_utils, lcm, libbot2 absent), so this
+ * restatement is pinned only by (i) analytic known-answer tests and (ii) an independent numpy
+ * restatement (oracle/numpy_restatement.py) agreeing to <=1e-12.
+ *
+ * Dense, op-for-op with the reference (all paths relative to /root/reference):
+ *   state-estimator/src/mav_state_est/rbis.cpp:12-227          filter maths
+ *   state-estimator/src/mav_state_est/rbis_update_interface.cpp:23-107   update objects
+ *   state-estimator/src/mav_state_est/sensor_handlers.cpp:612-724        scan-matcher mapping
+ *   motion_estimate/src/mav_est_legodo/rbis_legodo_common.cpp:34-169     leg-odometry measurement
+ *   motion_estimate/src/mav_est_fovis/rbis_fovis_update.cpp:199-305      VO pose composition
+ *   pronto-utils/src/conversions/pronto_conversions_lcm.hpp:38-87        getDeltaAsVelocity
+ *   pronto-utils/src/pronto_math/pronto_math.cpp:25-61                   euler<->quat
+ *
+ * Third-party semantics NOT IN THE REFERENCE TREE (un-vendored pod `eigen-utils`, no version pinned;
+ * Eigen3 for Quaternion/AngleAxis/LDLT/determinant) are restated from their published algorithms and
+ * are explicit, overridable constants here (po_set_constants):
+ *   g_vec       = -g * z_hat, g = 9.80665   (eigen_utils `g_val`; SURVEY recalled 9.8 -- see DESIGN.md)
+ *   chiToQuat() folds chi into quat when |chi| > 1e-6, else leaves chi in vec
+ *   addState(d): vec += d.vec; chiToQuat(); quat = quat * d.quat
+ *   RigidBodyState(vec) ctor: quat = I; chiToQuat()
+ *   subtractQuats(q1,q2) = axis*wrap_pi(angle) of q2^-1 * q1
+ */
+#ifndef PRONTO_ORACLE_H
+#define PRONTO_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PO_N 21 /* RBIS::rbis_num_states, rbis.hpp:23 */
+
+/* state vector layout (eigen_utils::RigidBodyState enum + rbis.hpp:22-24) */
+enum {
+  PO_ANGVEL = 0, PO_VEL = 3, PO_CHI = 6, PO_POS = 9, PO_ACC = 12, PO_BASIC = 15,
+  PO_GYRO_BIAS = 15, PO_ACCEL_BIAS = 18
+};
+
+typedef struct {
+  double vec[PO_N];
+  double quat[4]; /* w, x, y, z */
+  int64_t utime;
+} po_rbis;
+
+typedef struct {
+  double m[PO_N * PO_N]; /* column-major, as Eigen's default and rbis.cpp:300 Map<RBIM> */
+} po_rbim;
+
+void po_set_constants(double g, double chi_tol);
+void po_get_constants(double *g, double *chi_tol);
+
+/* ---- eigen_utils / Eigen primitives ---- */
+void po_rbis_zero(po_rbis *s);                         /* RBIS(): vec=0, quat=I, utime=0 */
+void po_rbis_from_vec(po_rbis *s, const double *vec);  /* RBIS(vec): quat=I then chiToQuat */
+void po_chi_to_quat(po_rbis *s);
+void po_add_state(po_rbis *s, const po_rbis *d);
+void po_subtract_quats(const double *q1, const double *q2, double *out3);
+void po_quat_mul(const double *a, const double *b, double *out);
+void po_quat_rotate(const double *q, const double *v, double *out);     /* q * v          */
+void po_quat_inv_rotate(const double *q, const double *v, double *out); /* q.inverse() * v */
+void po_quat_to_rot(const double *q, double *R /* 3x3 row-major */);
+
+/* ---- rbis.cpp ---- */
+void po_get_imu_linearization(const po_rbis *state, po_rbim *Ac);                 /* rbis.cpp:12-35  */
+void po_ins_update_state(const double *gyro, const double *accel, double dt, po_rbis *state); /* :37-75 */
+void po_ins_update_covariance(double q_gyro, double q_accel, double q_gyro_bias, double q_accel_bias,
+                              const po_rbis *state, po_rbim *cov, double dt);    /* rbis.cpp:77-122 */
+/* rbis.cpp:124-143; R is m x m col-major, C is m x 21 col-major, K is 21 x m col-major */
+double po_matrix_measurement_k_dcov(int m, const double *R, const double *C, const po_rbim *cov,
+                                    const double *z_resid, po_rbim *dcov, double *K);
+double po_indexed_measurement(int m, const double *z, const double *R, const int *idx, const po_rbis *state,
+                              const po_rbim *cov, po_rbis *dstate, po_rbim *dcov); /* rbis.cpp:160-178 */
+double po_indexed_plus_orientation_measurement(int m, const double *z, const double *quat, const double *R,
+                                               const int *idx, const po_rbis *state, const po_rbim *cov,
+                                               po_rbis *dstate, po_rbim *dcov);    /* rbis.cpp:189-217 */
+void po_apply_delta(const po_rbis *prior, const po_rbim *prior_cov, const po_rbis *dstate, const po_rbim *dcov,
+                    po_rbis *post, po_rbim *post_cov);                             /* rbis.cpp:219-227 */
+/* rbis.cpp:234-266 (RTS smoother step; SURVEY 8f, exercised by oracle self-tests only for now) */
+void po_ekf_smoothing_step(const po_rbis *next_state_pred, const po_rbim *next_cov_pred, const po_rbis *next_state,
+                           const po_rbim *next_cov, double dt, po_rbis *cur_state, po_rbim *cur_cov);
+
+/* ---- rbis_update_interface.cpp: updateFilter() of each update object ---- */
+void po_imu_process_step(const double *gyro, const double *accel, double dt, double q_gyro, double q_accel,
+                         double q_gyro_bias, double q_accel_bias, const po_rbis *prior, const po_rbim *prior_cov,
+                         double prior_ll, po_rbis *post, po_rbim *post_cov, double *post_ll); /* :30-52 */
+void po_indexed_update(int m, const int *idx, const double *z, const double *R, const po_rbis *prior,
+                       const po_rbim *prior_cov, double prior_ll, po_rbis *post, po_rbim *post_cov,
+                       double *post_ll);                                                     /* :54-95 */
+void po_indexed_orient_update(int m, const int *idx, const double *z, const double *R, const double *quat,
+                              const po_rbis *prior, const po_rbim *prior_cov, double prior_ll, po_rbis *post,
+                              po_rbim *post_cov, double *post_ll);                           /* :97-107 */
+
+/* ---- measurement formers (handlers' arithmetic) ---- */
+void po_euler_to_quat(double roll, double pitch, double yaw, double *q);    /* pronto_math.cpp:25-50 */
+void po_quat_to_euler(const double *q, double *rpy);                        /* pronto_math.cpp:53-61 */
+/* pronto_conversions_lcm.hpp:38-87: delta (t[3], q[4]) over dt_us -> velocity transform */
+void po_delta_as_velocity(const double *t, const double *q, int64_t dt_us, double *t_vel, double *q_vel);
+/* rbis_legodo_common.cpp:110-169.  mode: 0 lin_rate, 1 lin_rot_rate, 2 pos_and_lin_rate.
+ * r[5] = {r_xyz, r_vxyz, r_vang, r_vxyz_uncertain, r_vang_uncertain}.
+ * returns m (3 or 6) and fills idx[m], z[m], Rdiag[m]. */
+int po_legodo_create_measurement(int mode, const double *r, const double *pos_t, const double *delta_t,
+                                 const double *delta_q, int64_t utime, int64_t prev_utime, int pos_status,
+                                 float delta_status, int *idx, double *z, double *Rdiag);
+/* rbis_fovis_update.cpp:199-223,299-305: T1 = T0(pos0,quat0) * (t,q); z = T1.translation, q_meas = T1.rot */
+void po_fovis_compose(const double *pos0, const double *quat0, const double *t, const double *q, double *z3,
+                      double *q_meas);
+
+/* ---- batch drivers (fixtures + CPU baseline).  All arrays SoA with the filter index fastest. ----
+ * State SoA: vec[21][B], quat[4][B], cov[441][B] (col-major index c*21+r), ll[B].
+ * IMU block per step: gyro[3][B], accel[3][B], dt[B]  (7*B doubles)
+ * legodo block per step: z[3][B], Rdiag[3][B]          (6*B doubles), mask[B] (uint8, 0 = handler returned NULL)
+ */
+typedef struct {
+  int B;
+  double *vec;  /* [21][B] */
+  double *quat; /* [4][B]  */
+  double *cov;  /* [441][B] */
+  double *ll;   /* [B] */
+} po_batch;
+
+void po_batch_predict(po_batch *s, const double *imu_block, const double *q4 /* qg,qa,qbg,qba */, int nthreads);
+void po_batch_update_indexed(po_batch *s, int m, const int *idx, const double *z /* [m][B] */,
+                             const double *Rdiag /* [m][B] */, const double *quat_meas /* [4][B] or NULL */,
+                             const uint8_t *mask /* [B] or NULL */, int nthreads);
+/* T steps of predict + legodo m=3 (idx 3,4,5); returns seconds spent in the step loop */
+double po_batch_run_legodo(po_batch *s, int T, const double *imu_stream /* [T][7][B] */,
+                           const double *lo_stream /* [T][6][B] */, const uint8_t *mask_stream /* [T][B] or NULL */,
+                           const double *q4, int nthreads);
+int po_max_threads(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
