@@ -1,0 +1,154 @@
+/*
+ * pronto_batch.h -- C ABI of the batched RBIS/RBIM EKF hot path on MI355X (gfx950).
+ *
+ * This is the drop-in boundary for ONE path of openhumanoids/pronto: the propagate-and-correct loop
+ * (RBISUpdateInterface::updateFilter of the IMU / indexed / indexed+orientation / reset updates, driven
+ * by MavStateEstimator::addUpdate), batched over B independent filters.  Each entry point names the
+ * reference interface it replaces (paths relative to the reference tree).  The reference has no FFI
+ * today -- its boundary is C++; INTEGRATION.md shows the binding a maintainer would add,
+ * and pronto_amd/csrc/mav_state_est_batch.hpp keeps the reference's class names on top of this ABI.
+ *
+ * Conventions
+ *  - All functions return PB_OK (0) or an error code; they never throw and never exit().
+ *    pb_last_error() gives the text of the last failure on that context.
+ *  - The caller owns every buffer it passes; the context owns the device state.
+ *  - One context is driven from one host thread at a time (the reference is single-threaded,
+ *    lcm_front_end.cpp:223-229); distinct contexts (one per GPU) may be driven concurrently.
+ *  - Batched arrays are SoA with the FILTER INDEX FASTEST: element (c, b) of an array [C][B] is at c*B + b.
+ *  - `mem` says where the caller's buffers live: PB_HOST (staged through an internal pinned buffer, PCIe
+ *    inclusive) or PB_DEVICE (HBM-resident; the kernels read them in place).
+ *  - fp64 throughout.  State layout is RBIS's (rbis.hpp:22-30): vec = [omega(0-2) v_body(3-5) chi(6-8)
+ *    pos(9-11) accel(12-14) | gyro_bias(15-17) accel_bias(18-20)], quat = (w,x,y,z), n_states = 15 keeps
+ *    the first 15 (bias states and their covariance pinned to 0).
+ *  - The covariance is stored symmetric-packed on the device; the reference does not symmetrise P
+ *    (rbis.cpp:118,226) so results agree to rounding, not bit for bit (tolerances in tests/).
+ */
+#ifndef PRONTO_BATCH_H
+#define PRONTO_BATCH_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pb_ctx pb_ctx;
+
+enum pb_status {
+  PB_OK = 0,
+  PB_ERR_ARG = 1,         /* bad argument (NULL, size, index out of range, unsupported m) */
+  PB_ERR_HIP = 2,         /* a HIP runtime call failed; see pb_last_error */
+  PB_ERR_NO_DEVICE = 3,   /* no gfx950 device / HIP extension unusable: there is NO CPU fallback */
+  PB_ERR_STATE = 4        /* call order (e.g. step before reset, unknown snapshot slot) */
+};
+
+enum pb_mem { PB_HOST = 0, PB_DEVICE = 1 };
+
+/* how the measurement covariance R is passed to pb_update_indexed* */
+enum pb_rkind {
+  PB_R_DIAG_BROADCAST = 0, /* host double[m], same for every filter (handlers' cov_* members)       */
+  PB_R_DIAG = 1,           /* [m][B]      per-filter diagonal (legodo certain/uncertain switch)       */
+  PB_R_FULL = 2            /* [m*m][B]    per-filter full symmetric R, column-major (indexed_measurement_t) */
+};
+
+/* sensor ids, RBISUpdateInterface::sensor_enum (rbis_update_interface.hpp:10-12) */
+enum pb_sensor {
+  PB_SENSOR_INS = 0, PB_SENSOR_GPS, PB_SENSOR_VICON, PB_SENSOR_LASER, PB_SENSOR_LASER_GPF, PB_SENSOR_SCAN_MATCHER,
+  PB_SENSOR_OPTICAL_FLOW, PB_SENSOR_RESET, PB_SENSOR_INVALID, PB_SENSOR_RGBD, PB_SENSOR_FOVIS, PB_SENSOR_LEGODO,
+  PB_SENSOR_POSE_MEAS, PB_SENSOR_ALTIMETER, PB_SENSOR_AIRSPEED, PB_SENSOR_SIDESLIP, PB_SENSOR_INIT_MESSAGE,
+  PB_SENSOR_VIEWER, PB_SENSOR_YAWLOCK
+};
+
+/* ---- lifetime ------------------------------------------------------------------------------------- */
+
+/* Replaces MavStateEstimator::MavStateEstimator (mav_state_est.cpp:12-22) for B filters.
+ * n_states in {15, 21}; device = HIP device ordinal; n_snapshots = history slots for pb_snapshot (>= 0). */
+int pb_create(pb_ctx **out, int n_states, int batch, int device, int n_snapshots);
+int pb_destroy(pb_ctx *ctx);
+const char *pb_last_error(const pb_ctx *ctx); /* ctx may be NULL: last error of a failed pb_create */
+
+/* Launch on an existing hipStream_t (e.g. torch's current stream); NULL = the context's own stream. */
+int pb_set_stream(pb_ctx *ctx, void *hip_stream);
+/* eigen_utils constants that are not in the reference tree (g_vec magnitude, chiToQuat tolerance). */
+int pb_set_constants(pb_ctx *ctx, double g, double chi_tol);
+int pb_sync(pb_ctx *ctx);
+int pb_batch(const pb_ctx *ctx);
+int pb_n_states(const pb_ctx *ctx);
+
+/* device memory helpers for hosts without torch (hipMalloc / hipMemcpy on the context's device) */
+int pb_malloc(pb_ctx *ctx, uint64_t bytes, void **dev_ptr);
+int pb_free(pb_ctx *ctx, void *dev_ptr);
+int pb_memcpy_h2d(pb_ctx *ctx, void *dev_dst, const void *host_src, uint64_t bytes);
+int pb_memcpy_d2h(pb_ctx *ctx, void *host_dst, const void *dev_src, uint64_t bytes);
+
+/* ---- update objects (rbis_update_interface.hpp) ----------------------------------------------------- */
+
+/* RBISResetUpdate::updateFilter (rbis_update_interface.cpp:23-28): posterior <- (state, cov), loglik <- 0.
+ * vec [n][B], quat [4][B], cov [n*n][B] (full, column-major; the lower triangle is taken) -- or, with
+ * broadcast != 0, vec [n], quat [4], cov [n*n] applied to every filter (host memory only). */
+int pb_reset(pb_ctx *ctx, const double *vec, const double *quat, const double *cov, int broadcast, int mem);
+
+/* RBISIMUProcessStep::updateFilter (rbis_update_interface.cpp:30-52 -> rbis.cpp:37-122).
+ * imu_block [7][B] = gyro xyz, accelerometer xyz (body frame, as InsHandler hands them over,
+ * sensor_handlers.cpp:226-251), dt.  q = {q_gyro, q_accel, q_gyro_bias, q_accel_bias} (host). */
+int pb_predict(pb_ctx *ctx, const double *imu_block, const double q[4], int mem);
+
+/* RBISIndexedMeasurement::updateFilter (rbis_update_interface.cpp:54-95 -> rbis.cpp:160-178,124-143,219-227).
+ * m in 1..6; idx host int[m] (state indices < n_states, distinct); z [m][B]; R per r_kind;
+ * mask [B] uint8 or NULL: 0 = "handler returned NULL for this filter" (lcm_front_end.hpp:156) -> no update. */
+int pb_update_indexed(pb_ctx *ctx, int m, const int *idx, const double *z, const double *R, int r_kind,
+                      const uint8_t *mask, int mem);
+
+/* RBISIndexedPlusOrientationMeasurement::updateFilter (rbis_update_interface.cpp:97-107 -> rbis.cpp:189-217).
+ * quat_meas [4][B] (w,x,y,z).  z entries at chi indices (6..8) are ignored, as in the reference. */
+int pb_update_indexed_orient(pb_ctx *ctx, int m, const int *idx, const double *z, const double *R, int r_kind,
+                             const double *quat_meas, const uint8_t *mask, int mem);
+
+/* Fused hot step = RBISIMUProcessStep then RBISIndexedMeasurement(idx = velocityInds = {3,4,5}) as produced
+ * by LegOdoCommon::createMeasurement in mode lin_rate (rbis_legodo_common.cpp:153-156): ONE launch and ONE
+ * round trip of the state through HBM (BASELINE.json's "predict+update step").
+ * lo_block [6][B] = z xyz, Rdiag xyz; mask as above. */
+int pb_step_legodo(pb_ctx *ctx, const double *imu_block, const double *lo_block, const uint8_t *mask,
+                   const double q[4], int mem);
+
+/* n_steps consecutive fused steps from HBM-resident streams: imu_stream [n_steps][7][B],
+ * lo_stream [n_steps][6][B], mask_stream [n_steps][B] or NULL (device pointers).  One launch per step (the
+ * posterior is materialised in HBM after every message, as MavStateEstimator::addUpdate does,
+ * mav_state_est.cpp:50-70).  If elapsed_ms != NULL the call brackets the launches with HIP events on the
+ * context's stream, synchronises, and returns the device time. */
+int pb_run_legodo(pb_ctx *ctx, int n_steps, const double *imu_stream, const double *lo_stream,
+                  const uint8_t *mask_stream, const double q[4], float *elapsed_ms);
+
+/* ---- history look-up used by FovisHandler (rbis_fovis_update.cpp:184-223) ------------------------------ */
+
+/* remember the head posterior's (position, quat) in `slot` (the reference finds it again by
+ * history.updateMap.lower_bound(prev_timestamp)) */
+int pb_snapshot(pb_ctx *ctx, int slot);
+/* T1 = T0(slot) * (t, q): z_out [3][B] = T1.translation, quat_out [4][B] = T1.rotation (device buffers) */
+int pb_compose_delta(pb_ctx *ctx, int slot, const double *t, const double *q, double *z_out, double *quat_out,
+                     int mem);
+
+/* ---- estimator queries (mav_state_est.hpp:20-22) -------------------------------------------------------- */
+
+/* MavStateEstimator::getHeadState + getMeasurementsLogLikelihood for filters [first, first+count):
+ * vec_out [n][count], quat_out [4][count], cov_out [n*n][count] full column-major (as rbis.cpp:300 Map<RBIM>),
+ * ll_out [count]; any of them may be NULL. */
+int pb_get_head(pb_ctx *ctx, int first, int count, double *vec_out, double *quat_out, double *cov_out,
+                double *ll_out, int mem);
+/* rbisCreateFilterStateMessageCPP (rbis.cpp:287-304) for one filter: quat[4], state[21], cov[441] (host). */
+int pb_get_filter_state(pb_ctx *ctx, int filter, double quat[4], double state[21], double cov[441]);
+/* per-shard run summary for the end-of-run all-reduce:
+ * out[0] = sum loglik, out[1] = sum |vec| + |quat| (checksum), out[2] = max | |quat|^2 - 1 |,
+ * out[3] = number of non-finite state entries. */
+int pb_summary(pb_ctx *ctx, double out[4]);
+/* head utime bookkeeping (posterior_state.utime = update->utime, mav_state_est.cpp:60) */
+int pb_set_utime(pb_ctx *ctx, int64_t utime);
+int64_t pb_get_utime(const pb_ctx *ctx);
+
+/* library identification: "pronto_batch <version> gfx950" */
+const char *pb_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PRONTO_BATCH_H */

@@ -1,0 +1,97 @@
+"""Build / load libpronto_batch.so (the C ABI of include/pronto_batch.h).
+
+There is no CPU fallback: if the shared library is missing or no gfx950 device is visible, the
+product path raises.  The library is kept IN-TREE (pronto_amd/lib/) so it travels with the repo
+snapshot and shows up as a loaded native module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(_HERE, "lib", "libpronto_batch.so")
+HEADER = os.path.join(os.path.dirname(_HERE), "include", "pronto_batch.h")
+
+PB_OK, PB_ERR_ARG, PB_ERR_HIP, PB_ERR_NO_DEVICE, PB_ERR_STATE = range(5)
+PB_HOST, PB_DEVICE = 0, 1
+PB_R_DIAG_BROADCAST, PB_R_DIAG, PB_R_FULL = 0, 1, 2
+
+
+def sources():
+    return [os.path.join(CSRC, f) for f in ("pronto_batch.hip", "rbis_kernels.hpp", "rbis_device.hpp")] + [HEADER]
+
+
+def is_stale():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    return any(os.path.getmtime(s) > t for s in sources())
+
+
+def build(force=False):
+    """hipcc --offload-arch=gfx950 -shared (cross-compiles without a GPU)."""
+    if force or is_stale():
+        subprocess.check_call(["make", "-C", CSRC, "-s"] + (["-B"] if force else []))
+    return LIB_PATH
+
+
+_lib = None
+
+_dp = C.POINTER(C.c_double)
+_SIGS = {
+    "pb_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int]),
+    "pb_destroy": (C.c_int, [C.c_void_p]),
+    "pb_last_error": (C.c_char_p, [C.c_void_p]),
+    "pb_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "pb_set_constants": (C.c_int, [C.c_void_p, C.c_double, C.c_double]),
+    "pb_sync": (C.c_int, [C.c_void_p]),
+    "pb_batch": (C.c_int, [C.c_void_p]),
+    "pb_n_states": (C.c_int, [C.c_void_p]),
+    "pb_malloc": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]),
+    "pb_free": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "pb_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
+    "pb_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
+    "pb_reset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    "pb_predict": (C.c_int, [C.c_void_p, C.c_void_p, _dp, C.c_int]),
+    "pb_update_indexed": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_void_p, C.c_void_p, C.c_int,
+                                    C.c_void_p, C.c_int]),
+    "pb_update_indexed_orient": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_void_p, C.c_void_p, C.c_int,
+                                           C.c_void_p, C.c_void_p, C.c_int]),
+    "pb_step_legodo": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, _dp, C.c_int]),
+    "pb_run_legodo": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, _dp, C.POINTER(C.c_float)]),
+    "pb_snapshot": (C.c_int, [C.c_void_p, C.c_int]),
+    "pb_compose_delta": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "pb_get_head": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "pb_get_filter_state": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _dp]),
+    "pb_summary": (C.c_int, [C.c_void_p, _dp]),
+    "pb_set_utime": (C.c_int, [C.c_void_p, C.c_int64]),
+    "pb_get_utime": (C.c_int64, [C.c_void_p]),
+    "pb_version": (C.c_char_p, []),
+}
+
+
+def exported_names():
+    return sorted(_SIGS)
+
+
+def load():
+    """dlopen the library and bind every symbol the header declares; raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "pronto_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
+    try:  # share torch's HIP runtime when torch is present (same soname, libamdhip64.so.7)
+        import torch  # noqa: F401
+    except Exception:
+        pass
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export it
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib

@@ -1,0 +1,178 @@
+"""Thin Python binding of the C ABI (include/pronto_batch.h) -- test/bench plumbing, not the product.
+
+`BatchEstimator` mirrors the reference's estimator entry points for B filters at once
+(state-estimator/src/mav_state_est/mav_state_est.hpp:20-22: addUpdate / getHeadState /
+getMeasurementsLogLikelihood) by forwarding to pb_* one-to-one.  Arrays may be numpy (host, staged over
+PCIe) or torch CUDA tensors (HBM-resident, read in place).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import PB_DEVICE, PB_HOST, PB_R_DIAG, PB_R_DIAG_BROADCAST, PB_R_FULL
+
+
+class PbError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("pronto_batch error %d: %s" % (code, msg))
+        self.code = code
+
+
+def _is_torch(a):
+    return type(a).__module__.startswith("torch")
+
+
+def _ptr(a, dtype=np.float64):
+    """(pointer, mem) of a numpy array or a torch tensor; None -> (NULL, None)."""
+    if a is None:
+        return None, None
+    if _is_torch(a):
+        import torch
+        want = {np.float64: torch.float64, np.uint8: torch.uint8}[dtype]
+        if a.dtype != want or not a.is_contiguous():
+            raise TypeError("expected a contiguous %s tensor" % want)
+        return C.c_void_p(a.data_ptr()), (PB_DEVICE if a.is_cuda else PB_HOST)
+    if not isinstance(a, np.ndarray) or a.dtype != dtype or not a.flags["C_CONTIGUOUS"]:
+        raise TypeError("expected a C-contiguous numpy array of %s" % np.dtype(dtype))
+    return C.c_void_p(a.ctypes.data), PB_HOST
+
+
+def _same_mem(*mems):
+    ms = {m for m in mems if m is not None}
+    if len(ms) != 1:
+        raise ValueError("all buffers of one call must live in the same memory space")
+    return ms.pop()
+
+
+class BatchEstimator:
+    def __init__(self, batch, n_states=15, device=0, n_snapshots=1):
+        self._L = _lib.load()
+        h = C.c_void_p()
+        rc = self._L.pb_create(C.byref(h), n_states, batch, device, n_snapshots)
+        if rc:
+            raise PbError(rc, (self._L.pb_last_error(None) or b"").decode())
+        self._h = h
+        self.B, self.n, self.device = batch, n_states, device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.pb_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def _chk(self, rc):
+        if rc:
+            raise PbError(rc, (self._L.pb_last_error(self._h) or b"").decode())
+
+    # --- plumbing ---
+    def set_stream(self, stream_ptr):
+        self._chk(self._L.pb_set_stream(self._h, C.c_void_p(stream_ptr)))
+
+    def set_constants(self, g, chi_tol):
+        self._chk(self._L.pb_set_constants(self._h, g, chi_tol))
+
+    def sync(self):
+        self._chk(self._L.pb_sync(self._h))
+
+    # --- update objects ---
+    def reset(self, vec, quat, cov, broadcast=False):
+        """RBISResetUpdate.  vec [n,B], quat [4,B], cov [n,n,B] indexed [row,col,b] (or [n],[4],[n,n] broadcast)."""
+        if _is_torch(cov):
+            cov_cm = cov.transpose(0, 1).contiguous()
+        else:
+            cov_cm = np.ascontiguousarray(np.swapaxes(cov, 0, 1))  # column-major flat index c*n+r
+        pv, m1 = _ptr(vec)
+        pq, m2 = _ptr(quat)
+        pc, m3 = _ptr(cov_cm)
+        self._chk(self._L.pb_reset(self._h, pv, pq, pc, int(broadcast), _same_mem(m1, m2, m3)))
+
+    def predict(self, imu_block, q4):
+        p, m = _ptr(imu_block)
+        q = (C.c_double * 4)(*q4)
+        self._chk(self._L.pb_predict(self._h, p, q, m))
+
+    def _r(self, R, m):
+        if isinstance(R, (list, tuple)) or (isinstance(R, np.ndarray) and R.ndim == 1):
+            arr = np.ascontiguousarray(R, dtype=np.float64)
+            assert arr.shape == (m,)
+            return arr, C.c_void_p(arr.ctypes.data), PB_R_DIAG_BROADCAST, None
+        p, mem = _ptr(R)
+        kind = PB_R_DIAG if R.shape[0] == m and len(R.shape) == 2 else PB_R_FULL
+        return R, p, kind, mem
+
+    def update_indexed(self, idx, z, R, mask=None, quat_meas=None):
+        """RBISIndexedMeasurement / RBISIndexedPlusOrientationMeasurement.  z [m,B];
+        R: length-m list (broadcast diag), [m,B] per-filter diag, or [m*m,B] full column-major."""
+        m = len(idx)
+        ia = (C.c_int * m)(*[int(i) for i in idx])
+        pz, mz = _ptr(z)
+        _keep, pr, kind, mr = self._r(R, m)
+        pm, mm = _ptr(mask, np.uint8)
+        if quat_meas is None:
+            self._chk(self._L.pb_update_indexed(self._h, m, ia, pz, pr, kind, pm, _same_mem(mz, mr, mm)))
+        else:
+            pq, mq = _ptr(quat_meas)
+            self._chk(self._L.pb_update_indexed_orient(self._h, m, ia, pz, pr, kind, pq, pm, _same_mem(mz, mr, mm, mq)))
+
+    def step_legodo(self, imu_block, lo_block, mask, q4):
+        pi, m1 = _ptr(imu_block)
+        pl, m2 = _ptr(lo_block)
+        pm, m3 = _ptr(mask, np.uint8)
+        q = (C.c_double * 4)(*q4)
+        self._chk(self._L.pb_step_legodo(self._h, pi, pl, pm, q, _same_mem(m1, m2, m3)))
+
+    def run_legodo(self, imu_stream, lo_stream, mask_stream, q4, timed=False):
+        """n_steps fused steps from device-resident streams [T,7,B], [T,6,B], [T,B]; returns device ms if timed."""
+        T = imu_stream.shape[0]
+        pi, m1 = _ptr(imu_stream)
+        pl, m2 = _ptr(lo_stream)
+        pm, m3 = _ptr(mask_stream, np.uint8)
+        if _same_mem(m1, m2, m3) != PB_DEVICE:
+            raise ValueError("run_legodo needs device-resident streams")
+        q = (C.c_double * 4)(*q4)
+        ms = C.c_float(0)
+        self._chk(self._L.pb_run_legodo(self._h, T, pi, pl, pm, q, C.byref(ms) if timed else None))
+        return ms.value if timed else None
+
+    # --- fovis history ---
+    def snapshot(self, slot=0):
+        self._chk(self._L.pb_snapshot(self._h, slot))
+
+    def compose_delta(self, slot, t, q, z_out, quat_out):
+        pt, m1 = _ptr(t)
+        pq, m2 = _ptr(q)
+        pz, m3 = _ptr(z_out)
+        po_, m4 = _ptr(quat_out)
+        if m3 != PB_DEVICE or m4 != PB_DEVICE:
+            raise ValueError("compose_delta outputs must be device tensors")
+        self._chk(self._L.pb_compose_delta(self._h, slot, pt, pq, pz, po_, _same_mem(m1, m2)))
+
+    # --- queries ---
+    def get_head(self, first=0, count=None, want_cov=True):
+        """getHeadState: (vec [n,c], quat [4,c], cov [n,n,c] indexed [row,col,b] or None, ll [c]) as numpy."""
+        count = self.B - first if count is None else count
+        n = self.n
+        vec = np.empty((n, count))
+        quat = np.empty((4, count))
+        ll = np.empty(count)
+        cov = np.empty((n, n, count)) if want_cov else None
+        self._chk(self._L.pb_get_head(self._h, first, count, C.c_void_p(vec.ctypes.data), C.c_void_p(quat.ctypes.data),
+                                      C.c_void_p(cov.ctypes.data) if want_cov else None, C.c_void_p(ll.ctypes.data),
+                                      PB_HOST))
+        if want_cov:
+            cov = np.swapaxes(cov, 0, 1)  # stored [col,row,b] -> [row,col,b]
+        return vec, quat, cov, ll
+
+    def filter_state(self, b):
+        q = (C.c_double * 4)()
+        s = (C.c_double * 21)()
+        c = (C.c_double * 441)()
+        self._chk(self._L.pb_get_filter_state(self._h, b, q, s, c))
+        return np.array(q), np.array(s), np.array(c).reshape(21, 21).T  # cov col-major -> [row,col]
+
+    def summary(self):
+        out = (C.c_double * 4)()
+        self._chk(self._L.pb_summary(self._h, out))
+        return np.array(out)

@@ -1,0 +1,511 @@
+// pronto_batch.hip -- host side of the C ABI declared in include/pronto_batch.h: context, staging, launches.
+// The kernels live in rbis_kernels.hpp, the per-filter arithmetic in rbis_device.hpp.
+// There is no CPU path here: without a gfx950 device pb_create fails with PB_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+
+#include "../../include/pronto_batch.h"
+#include "rbis_kernels.hpp"
+
+using namespace pb;
+
+#define PB_VERSION_STR "pronto_batch 0.1 gfx950"
+
+// ------------------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------------------
+
+struct pb_ctx {
+  int ns = 0, B = 0, dev = 0, nsnap = 0, nc = 0;
+  long stride = 0;
+  hipStream_t stream = nullptr, own_stream = nullptr;
+  double *st = nullptr, *snaps = nullptr, *d_small = nullptr;
+  void *stage = nullptr;
+  size_t stage_bytes = 0;
+  Consts k{ 9.80665, 1e-6 };
+  int64_t utime = 0;
+  bool have_state = false;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  char err[512] = { 0 };
+};
+
+static thread_local char g_create_err[512] = "";
+
+static int fail(pb_ctx *c, int code, const char *fmt, ...)
+{
+  char *dst = c ? c->err : g_create_err;
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(dst, 512, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIPCHK(c, call)                                                                               \
+  do {                                                                                                \
+    hipError_t e_ = (call);                                                                           \
+    if (e_ != hipSuccess) return fail((c), PB_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
+  } while (0)
+
+static inline int nblk(int n) { return (n + 63) / 64; }
+
+extern "C" const char *pb_version(void) { return PB_VERSION_STR; }
+
+extern "C" const char *pb_last_error(const pb_ctx *ctx) { return ctx ? ctx->err : g_create_err; }
+
+extern "C" int pb_create(pb_ctx **out, int n_states, int batch, int device, int n_snapshots)
+{
+  if (!out) return fail(nullptr, PB_ERR_ARG, "pb_create: out is NULL");
+  *out = nullptr;
+  if (n_states != 15 && n_states != 21) return fail(nullptr, PB_ERR_ARG, "pb_create: n_states must be 15 or 21");
+  if (batch <= 0 || n_snapshots < 0) return fail(nullptr, PB_ERR_ARG, "pb_create: bad batch / n_snapshots");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(nullptr, PB_ERR_NO_DEVICE, "pb_create: no HIP device visible (this library has no CPU fallback)");
+  if (device < 0 || device >= ndev) return fail(nullptr, PB_ERR_ARG, "pb_create: device %d out of range", device);
+  hipDeviceProp_t prop;
+  HIPCHK(nullptr, hipGetDeviceProperties(&prop, device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(nullptr, PB_ERR_NO_DEVICE, "pb_create: device %d is %s; kernels are built for gfx950 only", device,
+                prop.gcnArchName);
+  pb_ctx *c = new (std::nothrow) pb_ctx();
+  if (!c) return fail(nullptr, PB_ERR_ARG, "pb_create: out of host memory");
+  c->ns = n_states;
+  c->B = batch;
+  c->dev = device;
+  c->nsnap = n_snapshots;
+  c->stride = ((long) batch + 63) / 64 * 64;
+  c->nc = (n_states == 15) ? Lay<15>::NC : Lay<21>::NC;
+  // the kernels address the state through one 32-bit-ranged buffer descriptor (rbis_kernels.hpp)
+  if ((unsigned long long) c->nc * (unsigned long long) c->stride * 8ull >= (1ull << 32)) {
+    delete c;
+    return fail(nullptr, PB_ERR_ARG, "pb_create: batch %d too large for one context (state must stay below 4 GiB; "
+                "split the batch over several contexts)", batch);
+  }
+#define CRCHK(call)                                                                                 \
+  do {                                                                                              \
+    hipError_t e_ = (call);                                                                         \
+    if (e_ != hipSuccess) {                                                                         \
+      fail(nullptr, PB_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_));                      \
+      pb_destroy(c);                                                                                \
+      return PB_ERR_HIP;                                                                            \
+    }                                                                                               \
+  } while (0)
+  CRCHK(hipSetDevice(device));
+  CRCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+  c->stream = c->own_stream;
+  CRCHK(hipMalloc((void **) &c->st, sizeof(double) * c->nc * c->stride));
+  CRCHK(hipMemsetAsync(c->st, 0, sizeof(double) * c->nc * c->stride, c->stream));
+  if (n_snapshots > 0) {
+    CRCHK(hipMalloc((void **) &c->snaps, sizeof(double) * 7 * c->stride * n_snapshots));
+    CRCHK(hipMemsetAsync(c->snaps, 0, sizeof(double) * 7 * c->stride * n_snapshots, c->stream));
+  }
+  CRCHK(hipMalloc((void **) &c->d_small, sizeof(double) * 1024));
+  CRCHK(hipEventCreate(&c->ev0));
+  CRCHK(hipEventCreate(&c->ev1));
+  CRCHK(hipStreamSynchronize(c->stream));
+#undef CRCHK
+  *out = c;
+  return PB_OK;
+}
+
+extern "C" int pb_destroy(pb_ctx *c)
+{
+  if (!c) return PB_OK;
+  (void) hipSetDevice(c->dev);
+  if (c->stream) (void) hipStreamSynchronize(c->stream);
+  if (c->st) (void) hipFree(c->st);
+  if (c->snaps) (void) hipFree(c->snaps);
+  if (c->d_small) (void) hipFree(c->d_small);
+  if (c->stage) (void) hipFree(c->stage);
+  if (c->ev0) (void) hipEventDestroy(c->ev0);
+  if (c->ev1) (void) hipEventDestroy(c->ev1);
+  if (c->own_stream) (void) hipStreamDestroy(c->own_stream);
+  delete c;
+  return PB_OK;
+}
+
+extern "C" int pb_set_stream(pb_ctx *c, void *s)
+{
+  if (!c) return PB_ERR_ARG;
+  c->stream = s ? (hipStream_t) s : c->own_stream;
+  return PB_OK;
+}
+
+extern "C" int pb_set_constants(pb_ctx *c, double g, double chi_tol)
+{
+  if (!c) return PB_ERR_ARG;
+  if (!(g > 0) || !(chi_tol >= 0)) return fail(c, PB_ERR_ARG, "pb_set_constants: g must be > 0 and chi_tol >= 0");
+  c->k.g = g;
+  c->k.chi_tol = chi_tol;
+  return PB_OK;
+}
+
+extern "C" int pb_sync(pb_ctx *c)
+{
+  if (!c) return PB_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->dev));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return PB_OK;
+}
+
+extern "C" int pb_batch(const pb_ctx *c) { return c ? c->B : -1; }
+extern "C" int pb_n_states(const pb_ctx *c) { return c ? c->ns : -1; }
+
+extern "C" int pb_malloc(pb_ctx *c, uint64_t bytes, void **p)
+{
+  if (!c || !p) return PB_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->dev));
+  HIPCHK(c, hipMalloc(p, bytes));
+  return PB_OK;
+}
+extern "C" int pb_free(pb_ctx *c, void *p)
+{
+  if (!c) return PB_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->dev));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipFree(p));
+  return PB_OK;
+}
+extern "C" int pb_memcpy_h2d(pb_ctx *c, void *d, const void *h, uint64_t bytes)
+{
+  if (!c || (!d && bytes) || (!h && bytes)) return PB_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->dev));
+  HIPCHK(c, hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return PB_OK;
+}
+extern "C" int pb_memcpy_d2h(pb_ctx *c, void *h, const void *d, uint64_t bytes)
+{
+  if (!c || (!d && bytes) || (!h && bytes)) return PB_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->dev));
+  HIPCHK(c, hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return PB_OK;
+}
+
+// staging area for PB_HOST inputs/outputs: a device buffer the host blocks are copied into
+static int stage_reserve(pb_ctx *c, size_t bytes)
+{
+  if (bytes <= c->stage_bytes) return PB_OK;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (c->stage) HIPCHK(c, hipFree(c->stage));
+  c->stage = nullptr;
+  c->stage_bytes = 0;
+  HIPCHK(c, hipMalloc(&c->stage, bytes));
+  c->stage_bytes = bytes;
+  return PB_OK;
+}
+
+// Resolve up to 4 caller buffers: device pointers pass through; host buffers are packed into the staging area.
+struct Part {
+  const void *src;
+  size_t bytes;
+  const void *dev;
+};
+static int stage_in(pb_ctx *c, int mem, Part *parts, int n)
+{
+  if (mem == PB_DEVICE) {
+    for (int i = 0; i < n; i++) parts[i].dev = parts[i].src;
+    return PB_OK;
+  }
+  if (mem != PB_HOST) return fail(c, PB_ERR_ARG, "mem must be PB_HOST or PB_DEVICE");
+  size_t tot = 0;
+  for (int i = 0; i < n; i++) tot += (parts[i].bytes + 255) / 256 * 256;
+  int rc = stage_reserve(c, tot);
+  if (rc) return rc;
+  size_t off = 0;
+  for (int i = 0; i < n; i++) {
+    if (parts[i].src) {
+      HIPCHK(c, hipMemcpyAsync((char *) c->stage + off, parts[i].src, parts[i].bytes, hipMemcpyHostToDevice, c->stream));
+      parts[i].dev = (char *) c->stage + off;
+    } else {
+      parts[i].dev = nullptr;
+    }
+    off += (parts[i].bytes + 255) / 256 * 256;
+  }
+  return PB_OK;
+}
+
+#define ENTER(c)                                       \
+  if (!(c)) return PB_ERR_ARG;                         \
+  HIPCHK((c), hipSetDevice((c)->dev))
+
+#define NEED_STATE(c) \
+  if (!(c)->have_state) return fail((c), PB_ERR_STATE, "%s before pb_reset", __func__)
+
+#define LAUNCHCHK(c) HIPCHK((c), hipGetLastError())
+
+extern "C" int pb_reset(pb_ctx *c, const double *vec, const double *quat, const double *cov, int broadcast, int mem)
+{
+  ENTER(c);
+  if (!vec || !quat || !cov) return fail(c, PB_ERR_ARG, "pb_reset: NULL input");
+  const int n = c->ns, B = c->B;
+  if (broadcast) {
+    if (mem != PB_HOST) return fail(c, PB_ERR_ARG, "pb_reset: broadcast inputs must be host memory");
+    double comp[Lay<21>::NC];
+    const int off_q = n, off_ll = n + 4, off_p = n + 5;
+    for (int i = 0; i < n; i++) comp[i] = vec[i];
+    for (int i = 0; i < 4; i++) comp[off_q + i] = quat[i];
+    comp[off_ll] = 0.0;
+    for (int i = 0; i < n; i++)
+      for (int j = 0; j <= i; j++) comp[off_p + pk(i, j)] = cov[j * n + i];
+    HIPCHK(c, hipMemcpyAsync(c->d_small, comp, sizeof(double) * c->nc, hipMemcpyHostToDevice, c->stream));
+    k_reset_bcast<<<nblk(B), 64, 0, c->stream>>>(c->st, c->stride, B, c->nc, c->d_small);
+    LAUNCHCHK(c);
+    HIPCHK(c, hipStreamSynchronize(c->stream));  // comp is a stack buffer
+  } else {
+    Part p[3] = { { vec, sizeof(double) * n * B, 0 }, { quat, sizeof(double) * 4 * B, 0 },
+                  { cov, sizeof(double) * n * n * B, 0 } };
+    int rc = stage_in(c, mem, p, 3);
+    if (rc) return rc;
+    if (n == 15)
+      k_reset<15><<<nblk(B), 64, 0, c->stream>>>(c->st, c->stride, B, (const double *) p[0].dev, (const double *) p[1].dev, (const double *) p[2].dev);
+    else
+      k_reset<21><<<nblk(B), 64, 0, c->stream>>>(c->st, c->stride, B, (const double *) p[0].dev, (const double *) p[1].dev, (const double *) p[2].dev);
+    LAUNCHCHK(c);
+  }
+  c->have_state = true;
+  return PB_OK;
+}
+
+template <bool UPDATE>
+static int launch_step(pb_ctx *c, const double *imu, const double *lo, const uint8_t *mask, const double q[4])
+{
+  const int B = c->B;
+  if (c->ns == 15)
+    k_step<15, UPDATE><<<nblk(B), 64, 0, c->stream>>>(c->st, c->stride, B, imu, lo, mask, q[0], q[1], q[2], q[3], c->k);
+  else
+    k_step<21, UPDATE><<<nblk(B), 64, 0, c->stream>>>(c->st, c->stride, B, imu, lo, mask, q[0], q[1], q[2], q[3], c->k);
+  LAUNCHCHK(c);
+  return PB_OK;
+}
+
+extern "C" int pb_predict(pb_ctx *c, const double *imu_block, const double q[4], int mem)
+{
+  ENTER(c);
+  NEED_STATE(c);
+  if (!imu_block || !q) return fail(c, PB_ERR_ARG, "pb_predict: NULL input");
+  Part p[1] = { { imu_block, sizeof(double) * 7 * c->B, 0 } };
+  int rc = stage_in(c, mem, p, 1);
+  if (rc) return rc;
+  return launch_step<false>(c, (const double *) p[0].dev, nullptr, nullptr, q);
+}
+
+extern "C" int pb_step_legodo(pb_ctx *c, const double *imu_block, const double *lo_block, const uint8_t *mask,
+                              const double q[4], int mem)
+{
+  ENTER(c);
+  NEED_STATE(c);
+  if (!imu_block || !lo_block || !q) return fail(c, PB_ERR_ARG, "pb_step_legodo: NULL input");
+  Part p[3] = { { imu_block, sizeof(double) * 7 * c->B, 0 }, { lo_block, sizeof(double) * 6 * c->B, 0 },
+                { mask, (size_t) c->B, 0 } };
+  int rc = stage_in(c, mem, p, 3);
+  if (rc) return rc;
+  return launch_step<true>(c, (const double *) p[0].dev, (const double *) p[1].dev, (const uint8_t *) p[2].dev, q);
+}
+
+extern "C" int pb_run_legodo(pb_ctx *c, int n_steps, const double *imu_stream, const double *lo_stream,
+                             const uint8_t *mask_stream, const double q[4], float *elapsed_ms)
+{
+  ENTER(c);
+  NEED_STATE(c);
+  if (n_steps < 0 || !imu_stream || !lo_stream || !q) return fail(c, PB_ERR_ARG, "pb_run_legodo: bad argument");
+  const size_t B = (size_t) c->B;
+  if (elapsed_ms) HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+  for (int s = 0; s < n_steps; s++) {
+    int rc = launch_step<true>(c, imu_stream + (size_t) s * 7 * B, lo_stream + (size_t) s * 6 * B,
+                               mask_stream ? mask_stream + (size_t) s * B : nullptr, q);
+    if (rc) return rc;
+  }
+  if (elapsed_ms) {
+    HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+    HIPCHK(c, hipEventSynchronize(c->ev1));
+    HIPCHK(c, hipEventElapsedTime(elapsed_ms, c->ev0, c->ev1));
+  }
+  return PB_OK;
+}
+
+template <int NS, int M>
+static void launch_update_m(pb_ctx *c, const int *idx, const double *z, const double *R, int rkind, const double *rb,
+                            const double *qm, const uint8_t *mask)
+{
+  IdxArg<M> ia;
+  DiagArg<M> da;
+  for (int i = 0; i < M; i++) {
+    ia.v[i] = idx[i];
+    da.v[i] = rb ? rb[i] : 0.0;
+  }
+  if (qm)
+    k_update<NS, M, true><<<nblk(c->B), 64, 0, c->stream>>>(c->st, c->stride, c->B, ia, z, R, rkind, da, qm, mask, c->k);
+  else
+    k_update<NS, M, false><<<nblk(c->B), 64, 0, c->stream>>>(c->st, c->stride, c->B, ia, z, R, rkind, da, qm, mask, c->k);
+}
+
+template <int NS>
+static int launch_update(pb_ctx *c, int m, const int *idx, const double *z, const double *R, int rkind,
+                         const double *rb, const double *qm, const uint8_t *mask)
+{
+  switch (m) {
+    case 1: launch_update_m<NS, 1>(c, idx, z, R, rkind, rb, qm, mask); break;
+    case 2: launch_update_m<NS, 2>(c, idx, z, R, rkind, rb, qm, mask); break;
+    case 3: launch_update_m<NS, 3>(c, idx, z, R, rkind, rb, qm, mask); break;
+    case 4: launch_update_m<NS, 4>(c, idx, z, R, rkind, rb, qm, mask); break;
+    case 5: launch_update_m<NS, 5>(c, idx, z, R, rkind, rb, qm, mask); break;
+    case 6: launch_update_m<NS, 6>(c, idx, z, R, rkind, rb, qm, mask); break;
+    default: return fail(c, PB_ERR_ARG, "update: m must be 1..6");
+  }
+  LAUNCHCHK(c);
+  return PB_OK;
+}
+
+static int update_common(pb_ctx *c, int m, const int *idx, const double *z, const double *R, int rkind,
+                         const double *qm, bool orient, const uint8_t *mask, int mem)
+{
+  ENTER(c);
+  NEED_STATE(c);
+  if (m < 1 || m > 6) return fail(c, PB_ERR_ARG, "update: m must be 1..6 (got %d)", m);
+  if (!idx || !z || !R) return fail(c, PB_ERR_ARG, "update: NULL input");
+  if (orient && !qm) return fail(c, PB_ERR_ARG, "update: quat_meas is NULL");
+  for (int i = 0; i < m; i++) {
+    if (idx[i] < 0 || idx[i] >= c->ns) return fail(c, PB_ERR_ARG, "update: index %d out of range for n_states=%d", idx[i], c->ns);
+    for (int j = 0; j < i; j++)
+      if (idx[i] == idx[j]) return fail(c, PB_ERR_ARG, "update: duplicate index %d", idx[i]);
+  }
+  const size_t B = (size_t) c->B;
+  size_t rbytes;
+  const double *rb = nullptr;
+  if (rkind == PB_R_DIAG_BROADCAST) { rb = R; rbytes = 0; }
+  else if (rkind == PB_R_DIAG) rbytes = sizeof(double) * m * B;
+  else if (rkind == PB_R_FULL) rbytes = sizeof(double) * m * m * B;
+  else return fail(c, PB_ERR_ARG, "update: bad r_kind %d", rkind);
+  Part p[4] = { { z, sizeof(double) * m * B, 0 }, { rb ? nullptr : R, rbytes, 0 },
+                { orient ? qm : nullptr, sizeof(double) * 4 * B, 0 }, { mask, B, 0 } };
+  int rc = stage_in(c, mem, p, 4);
+  if (rc) return rc;
+  if (c->ns == 15)
+    return launch_update<15>(c, m, idx, (const double *) p[0].dev, (const double *) p[1].dev, rkind, rb,
+                             (const double *) p[2].dev, (const uint8_t *) p[3].dev);
+  return launch_update<21>(c, m, idx, (const double *) p[0].dev, (const double *) p[1].dev, rkind, rb,
+                           (const double *) p[2].dev, (const uint8_t *) p[3].dev);
+}
+
+extern "C" int pb_update_indexed(pb_ctx *c, int m, const int *idx, const double *z, const double *R, int r_kind,
+                                 const uint8_t *mask, int mem)
+{
+  return update_common(c, m, idx, z, R, r_kind, nullptr, false, mask, mem);
+}
+
+extern "C" int pb_update_indexed_orient(pb_ctx *c, int m, const int *idx, const double *z, const double *R,
+                                        int r_kind, const double *quat_meas, const uint8_t *mask, int mem)
+{
+  return update_common(c, m, idx, z, R, r_kind, quat_meas, true, mask, mem);
+}
+
+extern "C" int pb_snapshot(pb_ctx *c, int slot)
+{
+  ENTER(c);
+  NEED_STATE(c);
+  if (slot < 0 || slot >= c->nsnap) return fail(c, PB_ERR_STATE, "pb_snapshot: slot %d of %d", slot, c->nsnap);
+  double *snap = c->snaps + (size_t) slot * 7 * c->stride;
+  if (c->ns == 15) k_snapshot<15><<<nblk(c->B), 64, 0, c->stream>>>(c->st, c->stride, c->B, snap);
+  else k_snapshot<21><<<nblk(c->B), 64, 0, c->stream>>>(c->st, c->stride, c->B, snap);
+  LAUNCHCHK(c);
+  return PB_OK;
+}
+
+extern "C" int pb_compose_delta(pb_ctx *c, int slot, const double *t, const double *q, double *z_out,
+                                double *quat_out, int mem)
+{
+  ENTER(c);
+  if (slot < 0 || slot >= c->nsnap) return fail(c, PB_ERR_STATE, "pb_compose_delta: slot %d of %d", slot, c->nsnap);
+  if (!t || !q || !z_out || !quat_out) return fail(c, PB_ERR_ARG, "pb_compose_delta: NULL argument");
+  Part p[2] = { { t, sizeof(double) * 3 * c->B, 0 }, { q, sizeof(double) * 4 * c->B, 0 } };
+  int rc = stage_in(c, mem, p, 2);
+  if (rc) return rc;
+  const double *snap = c->snaps + (size_t) slot * 7 * c->stride;
+  k_compose<<<nblk(c->B), 64, 0, c->stream>>>(snap, c->stride, c->B, (const double *) p[0].dev, (const double *) p[1].dev, z_out, quat_out);
+  LAUNCHCHK(c);
+  return PB_OK;
+}
+
+extern "C" int pb_get_head(pb_ctx *c, int first, int count, double *vec_out, double *quat_out, double *cov_out,
+                           double *ll_out, int mem)
+{
+  ENTER(c);
+  NEED_STATE(c);
+  if (first < 0 || count < 0 || (long) first + count > c->B) return fail(c, PB_ERR_ARG, "pb_get_head: range [%d,+%d) outside batch %d", first, count, c->B);
+  if (count == 0) return PB_OK;
+  const int n = c->ns;
+  double *dv = vec_out, *dq = quat_out, *dc = cov_out, *dl = ll_out;
+  size_t o_v = 0, o_q = 0, o_c = 0, o_l = 0;
+  if (mem == PB_HOST) {
+    size_t tot = 0;
+    o_v = tot; tot += vec_out ? sizeof(double) * n * count : 0;
+    o_q = tot; tot += quat_out ? sizeof(double) * 4 * count : 0;
+    o_c = tot; tot += cov_out ? sizeof(double) * n * n * count : 0;
+    o_l = tot; tot += ll_out ? sizeof(double) * count : 0;
+    int rc = stage_reserve(c, tot ? tot : 8);
+    if (rc) return rc;
+    char *s = (char *) c->stage;
+    dv = vec_out ? (double *) (s + o_v) : nullptr;
+    dq = quat_out ? (double *) (s + o_q) : nullptr;
+    dc = cov_out ? (double *) (s + o_c) : nullptr;
+    dl = ll_out ? (double *) (s + o_l) : nullptr;
+  } else if (mem != PB_DEVICE) {
+    return fail(c, PB_ERR_ARG, "mem must be PB_HOST or PB_DEVICE");
+  }
+  if (n == 15) k_get_head<15><<<nblk(count), 64, 0, c->stream>>>(c->st, c->stride, first, count, dv, dq, dc, dl);
+  else k_get_head<21><<<nblk(count), 64, 0, c->stream>>>(c->st, c->stride, first, count, dv, dq, dc, dl);
+  LAUNCHCHK(c);
+  if (mem == PB_HOST) {
+    if (vec_out) HIPCHK(c, hipMemcpyAsync(vec_out, dv, sizeof(double) * n * count, hipMemcpyDeviceToHost, c->stream));
+    if (quat_out) HIPCHK(c, hipMemcpyAsync(quat_out, dq, sizeof(double) * 4 * count, hipMemcpyDeviceToHost, c->stream));
+    if (cov_out) HIPCHK(c, hipMemcpyAsync(cov_out, dc, sizeof(double) * n * n * count, hipMemcpyDeviceToHost, c->stream));
+    if (ll_out) HIPCHK(c, hipMemcpyAsync(ll_out, dl, sizeof(double) * count, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  return PB_OK;
+}
+
+extern "C" int pb_get_filter_state(pb_ctx *c, int filter, double quat[4], double state[21], double cov[441])
+{
+  if (!c || !quat || !state || !cov) return PB_ERR_ARG;
+  const int n = c->ns;
+  double v[21], P[441];
+  int rc = pb_get_head(c, filter, 1, v, quat, P, nullptr, PB_HOST);
+  if (rc) return rc;
+  memset(state, 0, sizeof(double) * 21);
+  memset(cov, 0, sizeof(double) * 441);
+  for (int i = 0; i < n; i++) state[i] = v[i];
+  for (int col = 0; col < n; col++)
+    for (int r = 0; r < n; r++) cov[col * 21 + r] = P[col * n + r];
+  return PB_OK;
+}
+
+extern "C" int pb_summary(pb_ctx *c, double out[4])
+{
+  ENTER(c);
+  NEED_STATE(c);
+  if (!out) return PB_ERR_ARG;
+  HIPCHK(c, hipMemsetAsync(c->d_small, 0, sizeof(double) * 4, c->stream));
+  if (c->ns == 15) k_summary<15><<<nblk(c->B), 64, 0, c->stream>>>(c->st, c->stride, c->B, c->d_small);
+  else k_summary<21><<<nblk(c->B), 64, 0, c->stream>>>(c->st, c->stride, c->B, c->d_small);
+  LAUNCHCHK(c);
+  HIPCHK(c, hipMemcpyAsync(out, c->d_small, sizeof(double) * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return PB_OK;
+}
+
+extern "C" int pb_set_utime(pb_ctx *c, int64_t utime)
+{
+  if (!c) return PB_ERR_ARG;
+  c->utime = utime;
+  return PB_OK;
+}
+extern "C" int64_t pb_get_utime(const pb_ctx *c) { return c ? c->utime : 0; }

@@ -1,0 +1,330 @@
+// rbis_kernels.hpp -- gfx950 kernels of the batched RBIS EKF (included by pronto_batch.hip only).
+//
+// Data layout in HBM: st[NC][stride] doubles per context, component-major with the filter index fastest
+// (stride = batch rounded up to 64); components = vec[n] | quat[4] | loglik | P packed lower [n(n+1)/2].
+// One lane owns one filter, so every global access of a wave is one fully coalesced 512-byte row segment.
+//
+// Addressing: component base (wave-uniform, SGPRs) + one per-lane 32-bit byte offset, i.e. the
+// `global_load/store v, v_off, s[base:base+1]` form; no per-access 64-bit VGPR address is materialised
+// (that cost ~700 instructions and ~60 VGPRs in the first version of k_step).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/pronto_batch.h"
+#include "rbis_device.hpp"
+
+namespace pb {
+
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+
+// 128-bit buffer descriptor over [p, p+bytes): out-of-range lanes read 0 / drop their stores (hardware check)
+__device__ __forceinline__ rsrc_t mkbuf(const void *p, unsigned bytes)
+{
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, bytes, 0x00020000);
+}
+// buffer_load_dwordx2 v, v_off, s[rsrc], s_off offen : voff = per-lane byte offset, soff = uniform component offset
+__device__ __forceinline__ double ldg(rsrc_t r, unsigned soff, unsigned voff)
+{
+  return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+}
+__device__ __forceinline__ void stg(rsrc_t r, unsigned soff, unsigned voff, double v)
+{
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, v), r, voff, soff, 0);
+}
+
+struct IdxVel {
+  static constexpr Idx<3> value = { { 3, 4, 5 } };
+};
+
+// RBISIMUProcessStep::updateFilter [+ RBISIndexedMeasurement::updateFilter with idx = {3,4,5}, diagonal R]
+// (rbis_update_interface.cpp:30-52, :54-95).  The BASELINE hot step: 2*(n+4+1+n(n+1)/2)*8 + 56 + 48 bytes/filter.
+template <int NS, bool UPDATE>
+__global__ __launch_bounds__(64, 1) void k_step(double *__restrict__ st, long stride, int B,
+                                                const double *__restrict__ imu, const double *__restrict__ lo,
+                                                const uint8_t *__restrict__ mask, double qg, double qa, double qbg,
+                                                double qba, Consts k)
+{
+  using L = Lay<NS>;
+  const unsigned b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= (unsigned) B) return;
+  const unsigned bo = b * 8u;
+  const unsigned s8 = (unsigned) stride * 8u, B8 = (unsigned) B * 8u;  // host guarantees NC*stride*8 < 2^32
+  const rsrc_t rs = mkbuf(st, (unsigned) L::NC * s8);
+  const rsrc_t ri = mkbuf(imu, 7u * B8);
+  const rsrc_t rl = mkbuf(lo, UPDATE ? 6u * B8 : 0u);
+  double x[NS], q[4], ll, P[L::NP];
+#pragma unroll
+  for (int i = 0; i < NS; i++) x[i] = ldg(rs, (L::OFF_VEC + i) * s8, bo);
+#pragma unroll
+  for (int i = 0; i < 4; i++) q[i] = ldg(rs, (L::OFF_QUAT + i) * s8, bo);
+  ll = ldg(rs, L::OFF_LL * s8, bo);
+#pragma unroll
+  for (int i = 0; i < L::NP; i++) P[i] = ldg(rs, (L::OFF_P + i) * s8, bo);
+  double gyro[3], accel[3];
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    gyro[i] = ldg(ri, i * B8, bo);
+    accel[i] = ldg(ri, (3 + i) * B8, bo);
+  }
+  const double dt = ldg(ri, 6u * B8, bo);
+  double z[3], rd[3];
+  bool upd = false;
+  if constexpr (UPDATE) {
+    upd = (mask == nullptr) || (mask[b] != 0);
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      z[i] = ldg(rl, i * B8, bo);
+      rd[i] = ldg(rl, (3 + i) * B8, bo);
+    }
+  }
+  imu_process_step<NS>(x, q, P, gyro, accel, dt, qg, qa, qbg, qba, k);
+  bool stored = false;
+  if constexpr (UPDATE) {
+    if (upd) {
+      double resid[3], S[6];
+#pragma unroll
+      for (int i = 0; i < 3; i++) resid[i] = z[i] - x[3 + i];  // rbis.cpp:170
+#pragma unroll
+      for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j <= i; j++) S[pk(i, j)] = P[pk(3 + i, 3 + j)] + (i == j ? rd[i] : 0.0);  // rbis.cpp:134-135
+      measurement_update<NS, 3>(x, q, P, ll, resid, S, IdxVel{}, k,
+                                [rs, s8, bo](int pi, double v) { stg(rs, (L::OFF_P + pi) * s8, bo, v); });
+      stored = true;
+    }
+  }
+  if (!stored) {
+#pragma unroll
+    for (int i = 0; i < L::NP; i++) stg(rs, (L::OFF_P + i) * s8, bo, P[i]);
+  }
+#pragma unroll
+  for (int i = 0; i < NS; i++) stg(rs, (L::OFF_VEC + i) * s8, bo, x[i]);
+#pragma unroll
+  for (int i = 0; i < 4; i++) stg(rs, (L::OFF_QUAT + i) * s8, bo, q[i]);
+  stg(rs, L::OFF_LL * s8, bo, ll);
+}
+
+template <int M>
+struct IdxArg {
+  int v[M];
+};
+template <int M>
+struct DiagArg {
+  double v[M];
+};
+
+// Generic RBISIndexedMeasurement / RBISIndexedPlusOrientationMeasurement::updateFilter with a RUNTIME index list
+// (rbis_update_interface.cpp:54-107).  The m gathered columns P[:, idx] (wave-uniform component addresses) and x
+// live in registers; P itself is streamed through once (load, rank-m downdate, store).
+template <int NS, int M, bool ORIENT>
+__global__ __launch_bounds__(64, 1) void k_update(double *__restrict__ st, long stride, int B, IdxArg<M> idx,
+                                                  const double *__restrict__ z, const double *__restrict__ R,
+                                                  int rkind, DiagArg<M> rb, const double *__restrict__ qmeas,
+                                                  const uint8_t *__restrict__ mask, Consts k)
+{
+  using L = Lay<NS>;
+  const unsigned b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= (unsigned) B) return;
+  if (mask != nullptr && mask[b] == 0) return;  // handler returned NULL for this filter
+  const unsigned bo = b * 8u;
+  const unsigned s8 = (unsigned) stride * 8u, B8 = (unsigned) B * 8u;
+  const rsrc_t rs = mkbuf(st, (unsigned) L::NC * s8);
+  const rsrc_t rz = mkbuf(z, (unsigned) M * B8);
+  const rsrc_t rR = mkbuf(R, rkind == PB_R_DIAG ? (unsigned) M * B8 : (rkind == PB_R_FULL ? (unsigned) (M * M) * B8 : 0u));
+  const rsrc_t rq = mkbuf(qmeas, ORIENT ? 4u * B8 : 0u);
+  double x[NS], q[4];
+#pragma unroll
+  for (int i = 0; i < NS; i++) x[i] = ldg(rs, (L::OFF_VEC + i) * s8, bo);
+#pragma unroll
+  for (int i = 0; i < 4; i++) q[i] = ldg(rs, (L::OFF_QUAT + i) * s8, bo);
+  double ll = ldg(rs, L::OFF_LL * s8, bo);
+
+  // residual (rbis.cpp:169-172 / :199-208)
+  double resid[M];
+  double dq[3] = { 0, 0, 0 };
+  if constexpr (ORIENT) {
+    const double qm[4] = { ldg(rq, 0u, bo), ldg(rq, B8, bo), ldg(rq, 2u * B8, bo), ldg(rq, 3u * B8, bo) };
+    subtract_quats(qm, q, dq);
+  }
+#pragma unroll
+  for (int kk = 0; kk < M; kk++) {
+    const int ii = idx.v[kk];
+    const double xi = ldg(rs, (L::OFF_VEC + ii) * s8, bo);  // runtime index: re-read instead of x[ii]
+    double r = ldg(rz, kk * B8, bo) - xi;
+    if constexpr (ORIENT) {
+      if (ii >= 6 && ii <= 8) r = (ii == 6) ? dq[0] : (ii == 7 ? dq[1] : dq[2]);
+    }
+    resid[kk] = r;
+  }
+  // S = R + P[idx, idx]
+  double S[M * (M + 1) / 2], d[M];
+#pragma unroll
+  for (int i = 0; i < M; i++)
+#pragma unroll
+    for (int j = 0; j <= i; j++) {
+      double r;
+      if (rkind == PB_R_DIAG_BROADCAST) r = (i == j) ? rb.v[i] : 0.0;
+      else if (rkind == PB_R_DIAG) r = (i == j) ? ldg(rR, i * B8, bo) : 0.0;
+      else r = ldg(rR, (j * M + i) * B8, bo);
+      S[pk(i, j)] = r + ldg(rs, (L::OFF_P + pk(idx.v[i], idx.v[j])) * s8, bo);
+    }
+  ldlt<M>(S, d);
+  double y[M], id[M], yd[M], lli = 0.0;
+#pragma unroll
+  for (int kk = 0; kk < M; kk++) {
+    double s = resid[kk];
+#pragma unroll
+    for (int j = 0; j < kk; j++) s -= S[pk(kk, j)] * y[j];
+    y[kk] = s;
+    id[kk] = 1.0 / d[kk];
+    yd[kk] = s * id[kk];
+    lli -= log(d[kk]) + s * s * id[kk];
+  }
+  ll += lli;
+  // W = P[:, idx] L^-T
+  double W[NS][M];
+#pragma unroll
+  for (int i = 0; i < NS; i++) {
+#pragma unroll
+    for (int kk = 0; kk < M; kk++) {
+      double s = ldg(rs, (L::OFF_P + pk(i, idx.v[kk])) * s8, bo);
+#pragma unroll
+      for (int j = 0; j < kk; j++) s -= W[i][j] * S[pk(kk, j)];
+      W[i][kk] = s;
+    }
+  }
+  double dx[NS];
+#pragma unroll
+  for (int i = 0; i < NS; i++) {
+    double s = 0.0, wd[M];
+#pragma unroll
+    for (int kk = 0; kk < M; kk++) {
+      s = (kk == 0) ? W[i][0] * yd[0] : fma(W[i][kk], yd[kk], s);
+      wd[kk] = W[i][kk] * id[kk];
+    }
+    dx[i] = s;
+#pragma unroll
+    for (int j = 0; j <= i; j++) {
+      double acc = ldg(rs, (L::OFF_P + pk(i, j)) * s8, bo);
+#pragma unroll
+      for (int kk = 0; kk < M; kk++) acc = fma(-wd[kk], W[j][kk], acc);
+      stg(rs, (L::OFF_P + pk(i, j)) * s8, bo, acc);
+    }
+  }
+  add_delta<NS>(x, q, dx, k.chi_tol);
+#pragma unroll
+  for (int i = 0; i < NS; i++) stg(rs, (L::OFF_VEC + i) * s8, bo, x[i]);
+#pragma unroll
+  for (int i = 0; i < 4; i++) stg(rs, (L::OFF_QUAT + i) * s8, bo, q[i]);
+  stg(rs, L::OFF_LL * s8, bo, ll);
+}
+
+// RBISResetUpdate::updateFilter, per-filter inputs: vec [n][B], quat [4][B], cov [n*n][B] column-major
+template <int NS>
+__global__ void k_reset(double *__restrict__ st, long stride, int B, const double *__restrict__ vec,
+                        const double *__restrict__ quat, const double *__restrict__ cov)
+{
+  using L = Lay<NS>;
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  for (int i = 0; i < NS; i++) st[(long) (L::OFF_VEC + i) * stride + b] = vec[(long) i * B + b];
+  for (int i = 0; i < 4; i++) st[(long) (L::OFF_QUAT + i) * stride + b] = quat[(long) i * B + b];
+  st[(long) L::OFF_LL * stride + b] = 0.0;
+  for (int i = 0; i < NS; i++)
+    for (int j = 0; j <= i; j++) st[(long) (L::OFF_P + pk(i, j)) * stride + b] = cov[(long) (j * NS + i) * B + b];
+}
+
+// broadcast reset: comp [NC] already packed on the host
+__global__ void k_reset_bcast(double *__restrict__ st, long stride, int B, int NC, const double *__restrict__ comp)
+{
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  for (int c = 0; c < NC; c++) st[(long) c * stride + b] = comp[c];
+}
+
+template <int NS>
+__global__ void k_get_head(const double *__restrict__ st, long stride, int first, int count, double *vec_out,
+                           double *quat_out, double *cov_out, double *ll_out)
+{
+  using L = Lay<NS>;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= count) return;
+  const int b = first + t;
+  if (vec_out)
+    for (int i = 0; i < NS; i++) vec_out[(long) i * count + t] = st[(long) (L::OFF_VEC + i) * stride + b];
+  if (quat_out)
+    for (int i = 0; i < 4; i++) quat_out[(long) i * count + t] = st[(long) (L::OFF_QUAT + i) * stride + b];
+  if (ll_out) ll_out[t] = st[(long) L::OFF_LL * stride + b];
+  if (cov_out)
+    for (int c = 0; c < NS; c++)
+      for (int r = 0; r < NS; r++)
+        cov_out[(long) (c * NS + r) * count + t] = st[(long) (L::OFF_P + pk(r, c)) * stride + b];
+}
+
+// (position, quat) of the head posterior -> snapshot slot [7][stride]
+template <int NS>
+__global__ void k_snapshot(const double *__restrict__ st, long stride, int B, double *__restrict__ snap)
+{
+  using L = Lay<NS>;
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  for (int i = 0; i < 3; i++) snap[(long) i * stride + b] = st[(long) (L::OFF_VEC + 9 + i) * stride + b];
+  for (int i = 0; i < 4; i++) snap[(long) (3 + i) * stride + b] = st[(long) (L::OFF_QUAT + i) * stride + b];
+}
+
+// T1 = T0 * (t, q)   (rbis_fovis_update.cpp:219-223)
+__global__ void k_compose(const double *__restrict__ snap, long stride, int B, const double *__restrict__ t,
+                          const double *__restrict__ q, double *__restrict__ z_out, double *__restrict__ q_out)
+{
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const double p0[3] = { snap[b], snap[stride + b], snap[2 * stride + b] };
+  const double q0[4] = { snap[3 * stride + b], snap[4 * stride + b], snap[5 * stride + b], snap[6 * stride + b] };
+  const double tt[3] = { t[b], t[(long) B + b], t[2L * B + b] };
+  const double qq[4] = { q[b], q[(long) B + b], q[2L * B + b], q[3L * B + b] };
+  double R[9], o[4];
+  quat_to_rot(q0, R);
+  for (int i = 0; i < 3; i++)
+    z_out[(long) i * B + b] = p0[i] + (R[3 * i] * tt[0] + R[3 * i + 1] * tt[1] + R[3 * i + 2] * tt[2]);
+  quat_mul(q0, qq, o);
+  for (int i = 0; i < 4; i++) q_out[(long) i * B + b] = o[i];
+}
+
+template <int NS>
+__global__ void k_summary(const double *__restrict__ st, long stride, int B, double *__restrict__ out)
+{
+  using L = Lay<NS>;
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  double s_ll = 0, s_abs = 0, qdev = 0, nonfin = 0;
+  if (b < B) {
+    s_ll = st[(long) L::OFF_LL * stride + b];
+    double qn = 0;
+    for (int i = 0; i < NS + 4; i++) {
+      const double v = st[(long) i * stride + b];
+      s_abs += fabs(v);
+      if (!isfinite(v)) nonfin += 1;
+      if (i >= NS) qn += v * v;
+    }
+    for (int i = 0; i < L::NP; i++)
+      if (!isfinite(st[(long) (L::OFF_P + i) * stride + b])) nonfin += 1;
+    if (!isfinite(s_ll)) nonfin += 1;
+    qdev = fabs(qn - 1.0);
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    s_ll += __shfl_down(s_ll, off);
+    s_abs += __shfl_down(s_abs, off);
+    nonfin += __shfl_down(nonfin, off);
+    qdev = fmax(qdev, __shfl_down(qdev, off));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(&out[0], s_ll);
+    atomicAdd(&out[1], s_abs);
+    atomicMax((unsigned long long *) &out[2], (unsigned long long) __double_as_longlong(qdev));
+    atomicAdd(&out[3], nonfin);
+  }
+}
+
+}  // namespace pb

@@ -1,0 +1,105 @@
+// host_harness.cpp -- TEST-ONLY: compiles pronto_amd/csrc/rbis_device.hpp (the per-lane arithmetic the HIP kernels
+// run) with g++ so that `-m "not gpu"` tests can check that arithmetic against the oracle in a container without
+// a GPU.  It is NOT part of the product: libpronto_batch.so contains no host path and pronto_amd/ never loads this.
+// The glue below mirrors k_step / k_update in rbis_kernels.hpp.
+#include <cstdint>
+#include <cstring>
+
+#include "../pronto_amd/csrc/rbis_device.hpp"
+
+using namespace pb;
+
+struct IdxVel { static constexpr Idx<3> value = { { 3, 4, 5 } }; };
+struct IdxPosChi { static constexpr Idx<6> value = { { 9, 10, 11, 6, 7, 8 } }; };
+struct IdxPosYaw { static constexpr Idx<4> value = { { 9, 10, 11, 8 } }; };
+
+template <int NS>
+static void load(const double *st, long stride, int b, double (&x)[NS], double (&q)[4], double &ll,
+                 double (&P)[Lay<NS>::NP])
+{
+  using L = Lay<NS>;
+  for (int i = 0; i < NS; i++) x[i] = st[(L::OFF_VEC + i) * stride + b];
+  for (int i = 0; i < 4; i++) q[i] = st[(L::OFF_QUAT + i) * stride + b];
+  ll = st[L::OFF_LL * stride + b];
+  for (int i = 0; i < L::NP; i++) P[i] = st[(L::OFF_P + i) * stride + b];
+}
+template <int NS>
+static void store(double *st, long stride, int b, const double (&x)[NS], const double (&q)[4], double ll,
+                  const double (&P)[Lay<NS>::NP])
+{
+  using L = Lay<NS>;
+  for (int i = 0; i < NS; i++) st[(L::OFF_VEC + i) * stride + b] = x[i];
+  for (int i = 0; i < 4; i++) st[(L::OFF_QUAT + i) * stride + b] = q[i];
+  st[L::OFF_LL * stride + b] = ll;
+  for (int i = 0; i < L::NP; i++) st[(L::OFF_P + i) * stride + b] = P[i];
+}
+
+template <int NS>
+static void step(double *st, long stride, int B, const double *imu, const double *lo, const uint8_t *mask,
+                 const double *q4, double g, double tol, int do_update)
+{
+  Consts k{ g, tol };
+  for (int b = 0; b < B; b++) {
+    double x[NS], q[4], ll, P[Lay<NS>::NP];
+    load<NS>(st, stride, b, x, q, ll, P);
+    const double gyro[3] = { imu[b], imu[B + b], imu[2 * B + b] };
+    const double accel[3] = { imu[3 * B + b], imu[4 * B + b], imu[5 * B + b] };
+    imu_process_step<NS>(x, q, P, gyro, accel, imu[6 * B + b], q4[0], q4[1], q4[2], q4[3], k);
+    if (do_update && (!mask || mask[b])) {
+      double resid[3], S[6];
+      for (int i = 0; i < 3; i++) resid[i] = lo[i * B + b] - x[3 + i];
+      for (int i = 0; i < 3; i++)
+        for (int j = 0; j <= i; j++) S[pk(i, j)] = P[pk(3 + i, 3 + j)] + (i == j ? lo[(3 + i) * B + b] : 0.0);
+      measurement_update<NS, 3>(x, q, P, ll, resid, S, IdxVel{}, k);
+    }
+    store<NS>(st, stride, b, x, q, ll, P);
+  }
+}
+
+// compile-time-index orientation update (VO position_orient / scan-match position_yaw)
+template <int NS, int M, typename IDXT>
+static void update_orient(double *st, long stride, int B, const double *z, const double *rdiag, const double *qm,
+                          double g, double tol)
+{
+  Consts k{ g, tol };
+  constexpr Idx<M> idx = IDXT::value;
+  for (int b = 0; b < B; b++) {
+    double x[NS], q[4], ll, P[Lay<NS>::NP];
+    load<NS>(st, stride, b, x, q, ll, P);
+    const double qmeas[4] = { qm[b], qm[B + b], qm[2 * B + b], qm[3 * B + b] };
+    double dq[3];
+    subtract_quats(qmeas, q, dq);
+    double resid[M], S[M * (M + 1) / 2];
+    for (int i = 0; i < M; i++) {
+      const int ii = idx.v[i];
+      resid[i] = (ii >= 6 && ii <= 8) ? dq[ii - 6] : z[i * B + b] - x[ii];
+    }
+    for (int i = 0; i < M; i++)
+      for (int j = 0; j <= i; j++) S[pk(i, j)] = P[pk(idx.v[i], idx.v[j])] + (i == j ? rdiag[i * B + b] : 0.0);
+    measurement_update<NS, M>(x, q, P, ll, resid, S, IDXT{}, k);
+    store<NS>(st, stride, b, x, q, ll, P);
+  }
+}
+
+extern "C" {
+int hh_nc(int ns) { return ns == 15 ? Lay<15>::NC : Lay<21>::NC; }
+int hh_pk(int i, int j) { return pk(i, j); }
+void hh_step(int ns, double *st, long stride, int B, const double *imu, const double *lo, const uint8_t *mask,
+             const double *q4, double g, double tol, int do_update)
+{
+  if (ns == 15) step<15>(st, stride, B, imu, lo, mask, q4, g, tol, do_update);
+  else step<21>(st, stride, B, imu, lo, mask, q4, g, tol, do_update);
+}
+void hh_update_vo(int ns, double *st, long stride, int B, const double *z, const double *rdiag, const double *qm,
+                  double g, double tol)
+{
+  if (ns == 15) update_orient<15, 6, IdxPosChi>(st, stride, B, z, rdiag, qm, g, tol);
+  else update_orient<21, 6, IdxPosChi>(st, stride, B, z, rdiag, qm, g, tol);
+}
+void hh_update_posyaw(int ns, double *st, long stride, int B, const double *z, const double *rdiag, const double *qm,
+                      double g, double tol)
+{
+  if (ns == 15) update_orient<15, 4, IdxPosYaw>(st, stride, B, z, rdiag, qm, g, tol);
+  else update_orient<21, 4, IdxPosYaw>(st, stride, B, z, rdiag, qm, g, tol);
+}
+}

@@ -1,0 +1,393 @@
+"""Parity of the HIP path (through the C ABI) against the oracle -- run with `-m gpu` on an MI355X.
+
+Tolerances (fp64; the HIP path uses the block structure of F and a rank-m downdate, the oracle is dense):
+  per-run relative error <= 1e-9 on vec / quat / P / loglik blocks (observed ~1e-13), far inside the
+  <=1e-5 pose/velocity bound of BASELINE.json.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from util import embed21, pad_z, random_spd, rel, run_config
+
+from pronto_amd.synth import Workload
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-9
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def pa():
+    import torch
+    assert torch.cuda.is_available(), "-m gpu tests need a GPU"
+    from pronto_amd import _lib
+    _lib.build()
+    from pronto_amd import batch
+    return batch
+
+
+def make_pair(pa, oracle, w, dense_p0=None, n_snapshots=1):
+    vec, quat, P0 = w.initial_state()
+    if dense_p0:
+        P0 = P0 + random_spd(w.n, w.B, 0.03, dense_p0)
+    if w.n == 21:
+        vec[15:18], vec[18:21] = 0.5 * w.bg, 0.5 * w.ba
+    v21, P21 = embed21(vec, P0)
+    ob = oracle.OracleBatch(v21, quat, P21)
+    est = pa.BatchEstimator(w.B, n_states=w.n, device=0, n_snapshots=n_snapshots)
+    est.set_constants(*oracle.constants())
+    est.reset(vec, quat, P0)
+    return est, ob
+
+
+def check(est, ob, tol=TOL):
+    n = est.n
+    v, q, P, ll = est.get_head()
+    errs = dict(vec=rel(v, ob.vec[:n]), quat=rel(q, ob.quat), cov=rel(P, ob.cov[:n, :n]), ll=rel(ll, ob.ll))
+    assert max(errs.values()) < tol, errs
+    return errs
+
+
+@pytest.mark.parametrize("n,B", [(15, 1), (15, 300), (21, 130)])
+def test_fused_step_host_buffers(pa, oracle, n, B):
+    """pb_step_legodo with PB_HOST blocks, ragged batch sizes (not a multiple of the wave), masks + uncertain R."""
+    w = Workload(B, n_states=n)
+    est, ob = make_pair(pa, oracle, w, dense_p0=3)
+    q4 = w.process_noise()
+    for k in range(120):
+        imu = w.imu_block(k)
+        lo, mask = w.legodo_block(k)
+        est.step_legodo(imu, lo, mask, q4)
+        ob.predict(imu, q4)
+        ob.update_indexed([3, 4, 5], lo[0:3], lo[3:6], mask=mask)
+    check(est, ob)
+
+
+@pytest.mark.parametrize("n", [15, 21])
+def test_separate_calls_equal_fused(pa, oracle, n):
+    """pb_predict + pb_update_indexed (generic kernel, runtime idx) == pb_step_legodo == oracle."""
+    B = 192
+    w = Workload(B, n_states=n)
+    est_f, ob = make_pair(pa, oracle, w)
+    est_s, _ = make_pair(pa, oracle, w)
+    q4 = w.process_noise()
+    for k in range(60):
+        imu = w.imu_block(k)
+        lo, mask = w.legodo_block(k)
+        est_f.step_legodo(imu, lo, mask, q4)
+        est_s.predict(imu, q4)
+        est_s.update_indexed([3, 4, 5], np.ascontiguousarray(lo[0:3]), np.ascontiguousarray(lo[3:6]), mask=mask)
+        ob.predict(imu, q4)
+        ob.update_indexed([3, 4, 5], lo[0:3], lo[3:6], mask=mask)
+    check(est_f, ob)
+    check(est_s, ob)
+    vf, qf, Pf, lf = est_f.get_head()
+    vs, qs, Ps, ls = est_s.get_head()
+    assert rel(vf, vs) < 1e-12 and rel(Pf, Ps) < 1e-12 and rel(lf, ls) < 1e-12
+
+
+@pytest.mark.parametrize("n", [15, 21])
+@pytest.mark.parametrize("m", [1, 2, 3, 4, 5, 6])
+def test_generic_update_every_m(pa, oracle, n, m):
+    """k_update<NS,M,ORIENT>: random distinct index lists, the three R encodings, with and without orientation."""
+    B = 100
+    rng = np.random.default_rng(100 * n + m)
+    w = Workload(B, n_states=n)
+    est, ob = make_pair(pa, oracle, w, dense_p0=5)
+    q4 = w.process_noise()
+    for trial in range(4):
+        imu = w.imu_block(trial)
+        est.predict(imu, q4)
+        ob.predict(imu, q4)
+        idx = [int(i) for i in rng.choice(n, size=m, replace=False)]
+        z = np.ascontiguousarray(ob.vec[idx] + 0.05 * rng.normal(size=(m, B)))
+        mask = (rng.random(B) > 0.2).astype(np.uint8)
+        orient = trial % 2 == 1
+        qm = None
+        if orient:
+            d = 0.02 * rng.normal(size=(3, B))
+            from oracle import numpy_restatement as nr
+            qm = np.ascontiguousarray(nr.quat_mul(ob.quat.T, nr.quat_exp(d.T)[0]).T)
+        kind = trial % 3
+        if kind == 0:      # broadcast diagonal
+            rb = list(0.01 + 0.05 * rng.random(m))
+            Rd = np.tile(np.array(rb)[:, None], (1, B))
+            est.update_indexed(idx, z, rb, mask=mask, quat_meas=qm)
+            ob.update_indexed(idx, z, Rd, quat_meas=qm, mask=mask)
+        elif kind == 1:    # per-filter diagonal
+            Rd = np.ascontiguousarray(0.01 + 0.05 * rng.random((m, B)))
+            est.update_indexed(idx, z, Rd, mask=mask, quat_meas=qm)
+            ob.update_indexed(idx, z, Rd, quat_meas=qm, mask=mask)
+        else:              # per-filter full R with a diagonal matrix in it (the oracle driver takes diagonals)
+            Rd = 0.01 + 0.05 * rng.random((m, B))
+            Rf = np.zeros((m * m, B))
+            for i in range(m):
+                Rf[i * m + i] = Rd[i]
+            # (for m = 1 a [1,B] array is a diagonal and a full R at once)
+            est.update_indexed(idx, z, np.ascontiguousarray(Rf), mask=mask, quat_meas=qm)
+            ob.update_indexed(idx, z, Rd, quat_meas=qm, mask=mask)
+    check(est, ob)
+
+
+def test_full_r_offdiagonal(pa, oracle):
+    """PB_R_FULL with a genuinely non-diagonal R against the oracle's single-filter entry point."""
+    import ctypes as C
+    B, n, m = 70, 15, 3
+    rng = np.random.default_rng(9)
+    w = Workload(B, n_states=n)
+    est, ob = make_pair(pa, oracle, w, dense_p0=6)
+    idx = [9, 4, 7]
+    z = np.ascontiguousarray(ob.vec[idx] + 0.05 * rng.normal(size=(m, B)))
+    A = rng.normal(size=(B, m, m)) * 0.1
+    R = np.einsum("bij,bkj->bik", A, A) + 0.01 * np.eye(m)
+    Rf = np.ascontiguousarray(np.transpose(R, (2, 1, 0)).reshape(m * m, B))  # [c*m+r, b]
+    est.update_indexed(idx, z, Rf)
+    L = oracle.lib()
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    exp_v, exp_P, exp_ll = np.zeros((21, B)), np.zeros((21, 21, B)), np.zeros(B)
+    for b in range(B):
+        x, Pm = oracle.Rbis(), oracle.Rbim()
+        for i in range(21):
+            x.vec[i] = ob.vec[i, b]
+        for i in range(4):
+            x.quat[i] = ob.quat[i, b]
+        Pm.m[:] = list(np.ascontiguousarray(ob.cov[:, :, b].T).ravel())
+        ll = C.c_double(0)
+        zz = np.ascontiguousarray(z[:, b])
+        Rb = np.ascontiguousarray(R[b].T).ravel()
+        ia = (C.c_int * m)(*idx)
+        L.po_indexed_update(m, ia, dp(zz), dp(Rb), C.byref(x), C.byref(Pm), 0.0, C.byref(x), C.byref(Pm), C.byref(ll))
+        exp_v[:, b] = x.vec[:]
+        exp_P[:, :, b] = np.array(Pm.m[:]).reshape(21, 21).T
+        exp_ll[b] = ll.value
+    v, q, P, ll = est.get_head()
+    assert rel(v, exp_v[:n]) < TOL and rel(P, exp_P[:n, :n]) < TOL and rel(ll, exp_ll) < TOL
+
+
+def test_config3_vo_with_history_snapshot(pa, oracle):
+    """BASELINE config 3 in miniature: predict + legodo every step, FovisHandler position_orient every 32nd step
+    with T0 taken from the filter's own posterior at the previous VO time (pb_snapshot / pb_compose_delta)."""
+    import ctypes as C
+    import torch
+    from oracle import numpy_restatement as nr
+    B, n, T = 256, 15, 200
+    w = Workload(B, n_states=n)
+    est, ob = make_pair(pa, oracle, w, n_snapshots=2)
+    q4 = w.process_noise()
+    dev = torch.device("cuda:0")
+    z_out = torch.empty((3, B), dtype=torch.float64, device=dev)
+    q_out = torch.empty((4, B), dtype=torch.float64, device=dev)
+    L = oracle.lib()
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    est.snapshot(1)
+    snap_pos, snap_quat = ob.vec[9:12].copy(), ob.quat.copy()
+    tr_prev = w.truth(w.time_s(0))
+    for k in range(T):
+        imu = w.imu_block(k)
+        lo, mask = w.legodo_block(k)
+        est.step_legodo(imu, lo, mask, q4)
+        ob.predict(imu, q4)
+        ob.update_indexed([3, 4, 5], lo[0:3], lo[3:6], mask=mask)
+        if k % 32 == 31:
+            # VO delta = truth motion between the two keyframes (+ noise via vo_block's pose)
+            zt, qt, Rd = w.vo_block(k)
+            Rp = nr.rot_of_quat(tr_prev["quat"].T)
+            t_delta = np.ascontiguousarray(np.einsum("bji,jb->ib", Rp, zt - tr_prev["pos"]))
+            qpc = tr_prev["quat"].T * np.array([1, -1, -1, -1.0])
+            q_delta = np.ascontiguousarray(nr.quat_mul(qpc, qt.T).T)
+            # HIP path: compose on the device, feed the device outputs straight into the m=6 update
+            est.compose_delta(1, t_delta, q_delta, z_out, q_out)
+            z6 = torch.zeros((6, B), dtype=torch.float64, device=dev)
+            z6[0:3] = z_out
+            est.update_indexed([9, 10, 11, 6, 7, 8], z6, torch.from_numpy(Rd).to(dev), quat_meas=q_out)
+            # oracle: po_fovis_compose per filter, then the m=6 orientation update
+            zc, qc = np.zeros((3, B)), np.zeros((4, B))
+            for b in range(B):
+                p0 = np.ascontiguousarray(snap_pos[:, b]); q0 = np.ascontiguousarray(snap_quat[:, b])
+                tt = np.ascontiguousarray(t_delta[:, b]); qq = np.ascontiguousarray(q_delta[:, b])
+                zo, qo = np.zeros(3), np.zeros(4)
+                L.po_fovis_compose(dp(p0), dp(q0), dp(tt), dp(qq), dp(zo), dp(qo))
+                zc[:, b], qc[:, b] = zo, qo
+            assert rel(z_out.cpu().numpy(), zc) < 1e-12 and rel(q_out.cpu().numpy(), qc) < 1e-12
+            ob.update_indexed([9, 10, 11, 6, 7, 8], pad_z(zc, 6), Rd, quat_meas=qc)
+            # new keyframe
+            est.snapshot(1)
+            snap_pos, snap_quat = ob.vec[9:12].copy(), ob.quat.copy()
+            tr_prev = w.truth(w.time_s(k + 1))
+    check(est, ob)
+    tr = w.truth(w.time_s(T))
+    assert np.abs(ob.vec[9:12] - tr["pos"]).max() < 0.5
+
+
+def test_config5_n21_scanmatch(pa, oracle):
+    """BASELINE config 5 in miniature: 21-state filter, legodo every step, scan-match position_yaw (m=4) every 25th."""
+    B, n, T = 128, 21, 150
+    w = Workload(B, n_states=n)
+    est, ob = make_pair(pa, oracle, w)
+    run_config(est, w, T, sm_every=25)
+    run_config(ob, w, T, sm_every=25)
+    check(est, ob)
+
+
+@pytest.mark.parametrize("name", ["n15_legodo", "n15_legodo_vo", "n21_legodo_scanmatch"])
+def test_against_golden_fixtures(pa, oracle, name):
+    """HIP path vs the committed golden trajectories (no oracle call: fixtures only)."""
+    gold = np.load(os.path.join(GOLD, name + ".npz"))
+    n, B, T, stride, vo, sm = (int(v) for v in gold["meta"][:6])
+    w = Workload(B, n_states=n)
+    vec, quat, P0 = w.initial_state()
+    est = pa.BatchEstimator(B, n_states=n)
+    est.set_constants(float(gold["meta"][6]), float(gold["meta"][7]))
+    est.reset(vec, quat, P0)
+    for s in range(T // stride):
+        run_config(est, w, stride, vo_every=vo, sm_every=sm, k0=s * stride)
+        v, q, P, ll = est.get_head()
+        assert rel(v, gold["vec"][s][:n]) < TOL
+        assert rel(q, gold["quat"][s]) < TOL
+        assert rel(np.stack([P[i, i] for i in range(n)]), gold["pdiag"][s][:n]) < TOL
+        assert rel(P[3:6, 6:12], gold["pvv"][s]) < TOL
+        assert rel(ll, gold["ll"][s]) < TOL
+    # BASELINE.json's bound: pose / velocity within 1e-5 relative of the reference CPU filter
+    assert rel(v[9:12], gold["vec"][-1][9:12]) < 1e-5 and rel(v[3:6], gold["vec"][-1][3:6]) < 1e-5
+
+
+def test_long_run_10k_steps(pa, oracle):
+    """16 filters x 10 000 steps through pb_run_legodo against the golden long run."""
+    import torch
+    gold = np.load(os.path.join(GOLD, "n15_long.npz"))
+    n, B, T, stride = (int(v) for v in gold["meta"][:4])
+    w = Workload(B, n_states=n)
+    vec, quat, P0 = w.initial_state()
+    est = pa.BatchEstimator(B, n_states=n)
+    est.set_constants(float(gold["meta"][6]), float(gold["meta"][7]))
+    est.reset(vec, quat, P0)
+    dev = torch.device("cuda:0")
+    q4 = w.process_noise()
+    for s in range(T // stride):
+        imu, lo, mask = w.streams(s * stride, stride)
+        est.run_legodo(torch.from_numpy(imu).to(dev), torch.from_numpy(lo).to(dev), torch.from_numpy(mask).to(dev), q4)
+        v, q, P, ll = est.get_head()
+        assert rel(v, gold["vec"][s][:n]) < 1e-8 and rel(q, gold["quat"][s]) < 1e-8
+        assert rel(np.stack([P[i, i] for i in range(n)]), gold["pdiag"][s][:n]) < 1e-8
+        assert rel(ll, gold["ll"][s]) < 1e-8
+
+
+def test_full_size_64k_sampled_parity_and_properties(pa, oracle):
+    """BASELINE config 2 at full size (65 536 filters): device-resident streams, one launch per step.
+    Size-independent properties: (a) every filter's result is independent of the batch around it (a sampled
+    sub-batch replayed alone gives the same bits), (b) sampled filters match the oracle, (c) everything finite,
+    quaternions unit, (d) replays are bit-reproducible (checksum of checksums)."""
+    import torch
+    B, n, T = 65536, 15, 40
+    w = Workload(B, n_states=n)
+    vec, quat, P0 = w.initial_state()
+    q4 = w.process_noise()
+    imu, lo, mask = w.streams(0, T)
+    dev = torch.device("cuda:0")
+    d_imu, d_lo, d_mask = (torch.from_numpy(a).to(dev) for a in (imu, lo, mask))
+    sums = []
+    for rep in range(2):
+        est = pa.BatchEstimator(B, n_states=n)
+        est.set_constants(*oracle.constants())
+        est.reset(vec, quat, P0)
+        est.run_legodo(d_imu, d_lo, d_mask, q4)
+        sums.append(est.summary())
+        if rep == 0:
+            v, q, P, ll = est.get_head()
+        est.close()
+    assert np.array_equal(sums[0], sums[1])                       # (d)
+    assert sums[0][3] == 0 and sums[0][2] < 1e-12                  # (c) finite, |q|^2 = 1
+    assert np.all(np.isfinite(v)) and np.all(np.isfinite(P)) and np.all(np.isfinite(ll))
+    assert np.isclose(sums[0][0], ll.sum(), rtol=1e-12)
+    sel = np.concatenate([np.arange(0, 64), np.arange(32700, 32764), np.arange(B - 128, B)])
+    # (b) oracle on the sampled filters
+    v21, P21 = embed21(vec[:, sel], P0[:, :, sel])
+    ob = oracle.OracleBatch(v21, quat[:, sel], P21)
+    ob.run_legodo(np.ascontiguousarray(imu[:, :, sel]), np.ascontiguousarray(lo[:, :, sel]),
+                  np.ascontiguousarray(mask[:, sel]), q4)
+    assert rel(v[:, sel], ob.vec[:n]) < TOL and rel(q[:, sel], ob.quat) < TOL
+    assert rel(P[:, :, sel], ob.cov[:n, :n]) < TOL and rel(ll[sel], ob.ll) < TOL
+    # (a) the same filters alone in a small batch: bit-identical
+    est = pa.BatchEstimator(len(sel), n_states=n)
+    est.set_constants(*oracle.constants())
+    est.reset(np.ascontiguousarray(vec[:, sel]), np.ascontiguousarray(quat[:, sel]), np.ascontiguousarray(P0[:, :, sel]))
+    est.run_legodo(torch.from_numpy(np.ascontiguousarray(imu[:, :, sel])).to(dev),
+                   torch.from_numpy(np.ascontiguousarray(lo[:, :, sel])).to(dev),
+                   torch.from_numpy(np.ascontiguousarray(mask[:, sel])).to(dev), q4)
+    v2, q2, P2, ll2 = est.get_head()
+    assert np.array_equal(v2, v[:, sel]) and np.array_equal(P2, P[:, :, sel]) and np.array_equal(ll2, ll[sel])
+
+
+def test_kats_through_the_abi(pa, oracle):
+    """Stationary and constant-yaw-rate KATs (SURVEY.md 8c i, ii) on the HIP path itself."""
+    g, tol = oracle.constants()
+    B = 64
+    est = pa.BatchEstimator(B, n_states=15)
+    est.set_constants(g, tol)
+    quat = np.zeros(4); quat[0] = 1
+    est.reset(np.zeros(15), quat, np.zeros((15, 15)), broadcast=True)
+    imu = np.zeros((7, B))
+    imu[2] = 0.7
+    imu[5] = g
+    imu[6] = 1e-3
+    for _ in range(500):
+        est.predict(imu, [0, 0, 0, 0])
+    v, q, P, ll = est.get_head()
+    ang = 0.7 * 1e-3 * 500
+    assert np.allclose(q[0], np.cos(ang / 2), atol=1e-13) and np.allclose(q[3], np.sin(ang / 2), atol=1e-13)
+    assert np.max(np.abs(v[3:6])) < 1e-13 and np.max(np.abs(v[9:12])) < 1e-13
+    assert np.max(np.abs(P)) == 0.0 and np.all(ll == 0)
+
+
+def test_error_behaviour_and_wire_layout(pa, oracle):
+    """Error codes instead of exit()/exceptions in the library; rbisCreateFilterStateMessageCPP layout."""
+    B = 10
+    est = pa.BatchEstimator(B, n_states=15)
+    w = Workload(B, n_states=15)
+    imu = w.imu_block(0)
+    with pytest.raises(pa.PbError) as e:
+        est.predict(imu, [0, 0, 0, 0])          # before reset
+    assert e.value.code == 4
+    vec, quat, P0 = w.initial_state()
+    est.reset(vec, quat, P0 + random_spd(15, B, 0.02, 1))
+    z = np.zeros((1, B))
+    for bad in ([15], [-1]):
+        with pytest.raises(pa.PbError) as e:
+            est.update_indexed(bad, z, [0.1])
+        assert e.value.code == 1
+    with pytest.raises(pa.PbError):
+        est.update_indexed([3, 3], np.zeros((2, B)), [0.1, 0.1])    # duplicate index
+    with pytest.raises(pa.PbError):
+        est.update_indexed(list(range(7)), np.zeros((7, B)), [0.1] * 7)  # m > 6
+    with pytest.raises(pa.PbError) as e:
+        est.snapshot(5)
+    assert e.value.code == 4
+    v, q, P, ll = est.get_head()
+    qq, s21, c21 = est.filter_state(3)
+    assert np.array_equal(qq, q[:, 3]) and np.array_equal(s21[:15], v[:, 3]) and np.all(s21[15:] == 0)
+    assert np.array_equal(c21[:15, :15], P[:, :, 3]) and np.all(c21[15:] == 0)
+    # empty range and partial range queries
+    v2, q2, P2, l2 = est.get_head(first=4, count=3)
+    assert np.array_equal(v2, v[:, 4:7]) and np.array_equal(P2, P[:, :, 4:7])
+
+
+def test_torch_stream_interop(pa, oracle):
+    """Kernels launched on torch's current stream read torch-allocated HBM in place (no staging copy)."""
+    import torch
+    B, n = 512, 15
+    w = Workload(B, n_states=n)
+    est, ob = make_pair(pa, oracle, w)
+    est.set_stream(torch.cuda.current_stream().cuda_stream)
+    q4 = w.process_noise()
+    dev = torch.device("cuda:0")
+    for k in range(10):
+        imu = w.imu_block(k)
+        lo, mask = w.legodo_block(k)
+        est.step_legodo(torch.from_numpy(imu).to(dev), torch.from_numpy(lo).to(dev), torch.from_numpy(mask).to(dev), q4)
+        ob.predict(imu, q4)
+        ob.update_indexed([3, 4, 5], lo[0:3], lo[3:6], mask=mask)
+    torch.cuda.synchronize()
+    check(est, ob)

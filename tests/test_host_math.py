@@ -1,0 +1,99 @@
+"""The kernels' per-lane arithmetic (pronto_amd/csrc/rbis_device.hpp), compiled for the host by the test-only
+harness, against the oracle.  Catches maths errors in a container without a GPU; the real parity tests are the
+-m gpu ones, which run the same header through hipcc and the C ABI."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from util import embed21, pad_z, random_spd, rel
+
+from pronto_amd.synth import Workload
+
+DP = C.POINTER(C.c_double)
+
+
+def P(a):
+    return a.ctypes.data_as(DP)
+
+
+def pack(H, ns, vec, quat, cov, ll):
+    B = vec.shape[1]
+    st = np.zeros((H.hh_nc(ns), B))
+    st[:ns] = vec[:ns]
+    st[ns:ns + 4] = quat
+    st[ns + 4] = ll
+    for i in range(ns):
+        for j in range(i + 1):
+            st[ns + 5 + H.hh_pk(i, j)] = cov[i, j]
+    return st
+
+
+def unpack(H, ns, st):
+    B = st.shape[1]
+    cov = np.zeros((ns, ns, B))
+    for i in range(ns):
+        for j in range(i + 1):
+            cov[i, j] = cov[j, i] = st[ns + 5 + H.hh_pk(i, j)]
+    return st[:ns], st[ns:ns + 4], cov, st[ns + 4]
+
+
+@pytest.mark.parametrize("ns", [15, 21])
+def test_structured_math_matches_dense_oracle(oracle, harness, ns):
+    H = harness
+    g, tol = oracle.constants()
+    B, T = 32, 400
+    w = Workload(B, n_states=ns)
+    vec, quat, P0 = w.initial_state()
+    P0 = P0 + random_spd(ns, B, 0.03, 11)   # dense P0: exercises the omega/accel cross blocks too
+    if ns == 21:
+        vec[15:18], vec[18:21] = 0.5 * w.bg, 0.5 * w.ba
+    v21, P21 = embed21(vec, P0)
+    ob = oracle.OracleBatch(v21, quat, P21)
+    st = pack(H, ns, vec, quat, P0, np.zeros(B))
+    q4 = w.process_noise()
+    gd, td = C.c_double(g), C.c_double(tol)
+    for k in range(T):
+        imu = w.imu_block(k)
+        lo, mask = w.legodo_block(k)
+        ob.predict(imu, q4)
+        ob.update_indexed([3, 4, 5], lo[0:3], lo[3:6], mask=mask)
+        H.hh_step(ns, P(st), C.c_long(B), B, P(imu), P(lo), mask.ctypes.data_as(C.c_void_p), P(q4), gd, td, 1)
+        if k % 32 == 31:
+            z, qm, Rd = w.vo_block(k)
+            zz, qm = pad_z(z, 6), np.ascontiguousarray(qm)
+            ob.update_indexed([9, 10, 11, 6, 7, 8], zz, Rd, quat_meas=qm)
+            H.hh_update_vo(ns, P(st), C.c_long(B), B, P(zz), P(Rd), P(qm), gd, td)
+        if k % 25 == 24:
+            z, qm, Rd = w.scanmatch_block(k)
+            zz, qm = pad_z(z, 4), np.ascontiguousarray(qm)
+            ob.update_indexed([9, 10, 11, 8], zz, Rd, quat_meas=qm)
+            H.hh_update_posyaw(ns, P(st), C.c_long(B), B, P(zz), P(Rd), P(qm), gd, td)
+    v, q, cov, ll = unpack(H, ns, st)
+    # tolerance: fp64 reassociation only (structured vs dense), accumulated over 400 steps
+    assert rel(v, ob.vec[:ns]) < 1e-11
+    assert rel(q, ob.quat) < 1e-11
+    assert rel(cov, ob.cov[:ns, :ns]) < 1e-11
+    assert rel(ll, ob.ll) < 1e-11
+
+
+def test_predict_only_and_masked_lanes(oracle, harness):
+    H = harness
+    g, tol = oracle.constants()
+    B, ns = 16, 15
+    w = Workload(B, n_states=ns)
+    vec, quat, P0 = w.initial_state()
+    v21, P21 = embed21(vec, P0)
+    ob = oracle.OracleBatch(v21, quat, P21)
+    st = pack(H, ns, vec, quat, P0, np.zeros(B))
+    q4 = w.process_noise()
+    mask = (np.arange(B) % 2).astype(np.uint8)   # every other filter's handler "returned NULL"
+    for k in range(20):
+        imu = w.imu_block(k)
+        lo, _ = w.legodo_block(k)
+        ob.predict(imu, q4)
+        ob.update_indexed([3, 4, 5], lo[0:3], lo[3:6], mask=mask)
+        H.hh_step(ns, P(st), C.c_long(B), B, P(imu), P(lo), mask.ctypes.data_as(C.c_void_p), P(q4), C.c_double(g), C.c_double(tol), 1)
+    v, q, cov, ll = unpack(H, ns, st)
+    assert rel(v, ob.vec[:ns]) < 1e-12 and rel(cov, ob.cov[:ns, :ns]) < 1e-12
+    assert np.all(ll[mask == 0] == 0.0) and np.all(ll[mask == 1] != 0.0)

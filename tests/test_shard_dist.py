@@ -1,0 +1,77 @@
+"""Multi-rank path on CPU: world_size-2 gloo (the N>1 bench path uses the same helpers over RCCL)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from pronto_amd.shard import allreduce_summary, shard_range
+from pronto_amd.synth import Workload
+
+
+def test_shard_range_partitions_exactly():
+    for total in (0, 1, 7, 64, 65536, 262144, 1000003):
+        for world in (1, 2, 3, 8):
+            rs = [shard_range(total, r, world) for r in range(world)]
+            assert rs[0][0] == 0 and rs[-1][1] == total
+            assert all(a[1] == b[0] for a, b in zip(rs, rs[1:]))
+            sizes = [b - a for a, b in rs]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_range(10, 2, 2)
+
+
+def test_workload_shards_are_slices_of_the_global_workload():
+    """Counter-based generator: rank r's shard is bit-identical to the slice of the single-GPU workload."""
+    B = 96
+    full = Workload(B, n_states=15)
+    imu_f, lo_f, mk_f = full.streams(3, 4)
+    v_f, q_f, P_f = full.initial_state()
+    for r in range(2):
+        b0, b1 = shard_range(B, r, 2)
+        w = Workload(b1 - b0, b0=b0, n_states=15)
+        imu, lo, mk = w.streams(3, 4)
+        assert np.array_equal(imu, imu_f[:, :, b0:b1]) and np.array_equal(lo, lo_f[:, :, b0:b1])
+        assert np.array_equal(mk, mk_f[:, b0:b1])
+        v, q, P = w.initial_state()
+        assert np.array_equal(v, v_f[:, b0:b1]) and np.array_equal(P, P_f[:, :, b0:b1])
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    b0, b1 = shard_range(1001, rank, world)
+    local = [float(b1 - b0), 10.0 * (rank + 1), 1e-15 * (rank + 1), float(rank)]
+    out = allreduce_summary(local, dist)
+    t = torch.tensor([0.5 + rank])          # the bench's max-over-ranks timing reduction
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.barrier()
+    q.put((rank, out.tolist(), t.item()))
+    dist.destroy_process_group()
+
+
+def test_summary_allreduce_world2_gloo():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in ps)
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, out, tmax in res:
+        assert out == [1001.0, 30.0, 2e-15, 1.0]
+        assert tmax == 1.5
+
+
+def test_single_process_is_identity():
+    assert allreduce_summary([1.0, 2.0, 3.0, 4.0]).tolist() == [1.0, 2.0, 3.0, 4.0]
