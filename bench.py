@@ -52,7 +52,7 @@ def cpu_baseline(n, dt_us, target_s, est_cls):
 
     sec, _, _ = run(4 * threads)  # calibration
     rate = 4 * threads * T / max(sec, 1e-9)
-    Bs = int(max(4 * threads, min(16384, rate * target_s / T)))
+    Bs = int(max(4 * threads, min(262144, rate * target_s / T)))
     Bs = (Bs + threads - 1) // threads * threads
     sec, ob, (w, vec, quat, P0, imu, lo, mask) = run(Bs)
     out = {"value": Bs * T / sec, "unit": "steps/s", "cores": threads, "kind": "port",

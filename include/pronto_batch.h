@@ -141,6 +141,10 @@ int pb_get_filter_state(pb_ctx *ctx, int filter, double quat[4], double state[21
  * out[0] = sum loglik, out[1] = sum |vec| + |quat| (checksum), out[2] = max | |quat|^2 - 1 |,
  * out[3] = number of non-finite state entries. */
 int pb_summary(pb_ctx *ctx, double out[4]);
+/* Measurement aid (not on the reference path): `reps` plain copies of the whole state array with k_step's exact
+ * access pattern (8 bytes/lane buffer loads and stores), to calibrate rocprofv3's FETCH_SIZE / WRITE_SIZE on a
+ * known byte count and to measure this box's achievable copy rate.  elapsed_ms = HIP-event time of the reps. */
+int pb_calib_copy(pb_ctx *ctx, int reps, float *elapsed_ms);
 /* head utime bookkeeping (posterior_state.utime = update->utime, mav_state_est.cpp:60) */
 int pb_set_utime(pb_ctx *ctx, int64_t utime);
 int64_t pb_get_utime(const pb_ctx *ctx);

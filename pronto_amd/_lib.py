@@ -10,7 +10,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(_HERE, "lib", "libpronto_batch.so")
+LIB_PATH = os.environ.get("PRONTO_BATCH_LIB") or os.path.join(_HERE, "lib", "libpronto_batch.so")  # env: A/B builds
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "pronto_batch.h")
 
 PB_OK, PB_ERR_ARG, PB_ERR_HIP, PB_ERR_NO_DEVICE, PB_ERR_STATE = range(5)
@@ -65,6 +65,7 @@ _SIGS = {
     "pb_get_head": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "pb_get_filter_state": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _dp]),
     "pb_summary": (C.c_int, [C.c_void_p, _dp]),
+    "pb_calib_copy": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float)]),
     "pb_set_utime": (C.c_int, [C.c_void_p, C.c_int64]),
     "pb_get_utime": (C.c_int64, [C.c_void_p]),
     "pb_version": (C.c_char_p, []),

@@ -172,6 +172,12 @@ class BatchEstimator:
         self._chk(self._L.pb_get_filter_state(self._h, b, q, s, c))
         return np.array(q), np.array(s), np.array(c).reshape(21, 21).T  # cov col-major -> [row,col]
 
+    def calib_copy(self, reps=10):
+        """device ms for `reps` plain copies of the state array (counter calibration / copy-rate probe)."""
+        ms = C.c_float(0)
+        self._chk(self._L.pb_calib_copy(self._h, reps, C.byref(ms)))
+        return ms.value
+
     def summary(self):
         out = (C.c_double * 4)()
         self._chk(self._L.pb_summary(self._h, out))

@@ -15,6 +15,11 @@
 #include "../../include/pronto_batch.h"
 #include "rbis_device.hpp"
 
+// workgroup size of the hot kernel (one wave per SIMD either way; 64 = one wave per workgroup)
+#ifndef PB_STEP_BLOCK
+#define PB_STEP_BLOCK 64
+#endif
+
 namespace pb {
 
 typedef unsigned v2u __attribute__((ext_vector_type(2)));
@@ -42,7 +47,7 @@ struct IdxVel {
 // RBISIMUProcessStep::updateFilter [+ RBISIndexedMeasurement::updateFilter with idx = {3,4,5}, diagonal R]
 // (rbis_update_interface.cpp:30-52, :54-95).  The BASELINE hot step: 2*(n+4+1+n(n+1)/2)*8 + 56 + 48 bytes/filter.
 template <int NS, bool UPDATE>
-__global__ __launch_bounds__(64, 1) void k_step(double *__restrict__ st, long stride, int B,
+__global__ __launch_bounds__(PB_STEP_BLOCK, 1) void k_step(double *__restrict__ st, long stride, int B,
                                                 const double *__restrict__ imu, const double *__restrict__ lo,
                                                 const uint8_t *__restrict__ mask, double qg, double qa, double qbg,
                                                 double qba, Consts k)
@@ -81,22 +86,20 @@ __global__ __launch_bounds__(64, 1) void k_step(double *__restrict__ st, long st
     }
   }
   imu_process_step<NS>(x, q, P, gyro, accel, dt, qg, qa, qbg, qba, k);
-  bool stored = false;
   if constexpr (UPDATE) {
-    if (upd) {
-      double resid[3], S[6];
+    // Predicated, not branched: lanes whose handler returned NULL (mask 0) run the same stream with D^-1 = 0 and a
+    // benign R, so the wave stores whole rows (see measurement_update).
+    double resid[3], S[6];
 #pragma unroll
-      for (int i = 0; i < 3; i++) resid[i] = z[i] - x[3 + i];  // rbis.cpp:170
+    for (int i = 0; i < 3; i++) resid[i] = upd ? z[i] - x[3 + i] : 0.0;  // rbis.cpp:170
 #pragma unroll
-      for (int i = 0; i < 3; i++)
+    for (int i = 0; i < 3; i++)
 #pragma unroll
-        for (int j = 0; j <= i; j++) S[pk(i, j)] = P[pk(3 + i, 3 + j)] + (i == j ? rd[i] : 0.0);  // rbis.cpp:134-135
-      measurement_update<NS, 3>(x, q, P, ll, resid, S, IdxVel{}, k,
-                                [rs, s8, bo](int pi, double v) { stg(rs, (L::OFF_P + pi) * s8, bo, v); });
-      stored = true;
-    }
-  }
-  if (!stored) {
+      for (int j = 0; j <= i; j++)
+        S[pk(i, j)] = P[pk(3 + i, 3 + j)] + (i == j ? (upd ? rd[i] : 1.0) : 0.0);  // rbis.cpp:134-135
+    measurement_update<NS, 3>(x, q, P, ll, resid, S, IdxVel{}, k,
+                              [rs, s8, bo](int pi, double v) { stg(rs, (L::OFF_P + pi) * s8, bo, v); }, upd);
+  } else {
 #pragma unroll
     for (int i = 0; i < L::NP; i++) stg(rs, (L::OFF_P + i) * s8, bo, P[i]);
   }
@@ -319,11 +322,30 @@ __global__ void k_summary(const double *__restrict__ st, long stride, int B, dou
     nonfin += __shfl_down(nonfin, off);
     qdev = fmax(qdev, __shfl_down(qdev, off));
   }
+  // one partial per wave, reduced on the host in wave order: bit-reproducible (float atomics are not)
   if ((threadIdx.x & 63) == 0) {
-    atomicAdd(&out[0], s_ll);
-    atomicAdd(&out[1], s_abs);
-    atomicMax((unsigned long long *) &out[2], (unsigned long long) __double_as_longlong(qdev));
-    atomicAdd(&out[3], nonfin);
+    double *o = out + 4L * blockIdx.x;
+    o[0] = s_ll; o[1] = s_abs; o[2] = qdev; o[3] = nonfin;
+  }
+}
+
+// Counter calibration: a plain copy with EXACTLY the access pattern of k_step (buffer_load/store_dwordx2, 8 bytes
+// per lane, component-major rows of `stride` doubles), so that rocprofv3's FETCH_SIZE / WRITE_SIZE can be scaled
+// on a known byte count (MI355X_MICROARCH.md section HBM: widths other than 16 B/lane are uncalibrated).
+__global__ __launch_bounds__(64, 1) void k_calib_copy(const double *__restrict__ src, double *__restrict__ dst,
+                                                      long stride, int B, int ncomp)
+{
+  const unsigned b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= (unsigned) B) return;
+  const unsigned bo = b * 8u, s8 = (unsigned) stride * 8u;
+  const rsrc_t ri = mkbuf(src, (unsigned) ncomp * s8), ro = mkbuf(dst, (unsigned) ncomp * s8);
+  for (int c0 = 0; c0 < ncomp; c0 += 20) {
+    double v[20];
+#pragma unroll
+    for (int i = 0; i < 20; i++) v[i] = (c0 + i < ncomp) ? ldg(ri, (unsigned) (c0 + i) * s8, bo) : 0.0;
+#pragma unroll
+    for (int i = 0; i < 20; i++)
+      if (c0 + i < ncomp) stg(ro, (unsigned) (c0 + i) * s8, bo, v[i]);
   }
 }
 
