@@ -1,0 +1,809 @@
+// mav_state_est_batch.hpp -- host-side C++ mirror of Pronto's plugin / update-object API for B filters at once,
+// header-only on top of the C ABI (include/pronto_batch.h).  Same namespace, class and method names, argument
+// meaning and error conventions as the reference for THIS path, so handler code reads like the reference's:
+//
+//   RBISUpdateInterface + RBISResetUpdate / RBISIMUProcessStep / RBISIndexedMeasurement /
+//   RBISIndexedPlusOrientationMeasurement          state-estimator/src/mav_state_est/rbis_update_interface.hpp:8-120
+//   MavStateEstimator::addUpdate / getHeadState / getMeasurementsLogLikelihood   mav_state_est.hpp:10-25, .cpp:28-96
+//   InsHandler, ScanMatcherHandler, IndexedMeasurementHandler, GpsHandler        sensor_handlers.hpp:22-167
+//   LegOdoCommon (+ a LegOdoHandler fed by leg-odometry deltas)                  mav_est_legodo/rbis_legodo_common.hpp
+//   FovisHandler                                                                 mav_est_fovis/rbis_fovis_update.cpp:6-312
+//   SensorHandler<Msg,Handler> dispatch (downsample gate, utime_offset, roll_forward)   lcm_front_end.hpp:139-203
+//
+// What changes, and why: every message type carries B filters' worth of data (SoA, filter index fastest, host or
+// device memory); RBIS/RBIM are batched host containers; updateFilter() applies itself to the estimator's
+// device-resident posterior instead of taking prior/posterior by value (the posterior of 65 536 filters is 73 MB --
+// it stays in HBM).  BotParam is a key/value map with the reference's key names; *_or_fail keep libbot's behaviour
+// (message on stderr, exit(1)).  LCM, BotFrames and the leg kinematics are outside this path.
+//
+// Throughput note: a handler that transforms inputs on the host (frame rotation in InsHandler, delta->velocity in
+// LegOdoCommon) costs O(B) host work per message; bulk replays pre-stage body-frame blocks in HBM and use
+// pb_run_legodo (see bench.py).  The handlers skip the host pass entirely when the transform is the identity.
+#pragma once
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <memory>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/pronto_batch.h"
+
+namespace MavStateEst {
+
+// ---------------------------------------------------------------------------------------------------------------
+// libbot stand-ins (bot_param, bot_core math) -- same names and semantics as the calls in the reference
+// ---------------------------------------------------------------------------------------------------------------
+struct BotParam {
+  std::map<std::string, std::string> kv;
+  void set(const std::string &k, const std::string &v) { kv[k] = v; }
+  void set(const std::string &k, double v)
+  {
+    char b[64];
+    snprintf(b, sizeof b, "%.17g", v);
+    kv[k] = b;
+  }
+  // "-O key=value|key=value" overrides (fusion.cpp:98-99, lcm_front_end.cpp:62-68)
+  void applyOverrides(const std::string &s)
+  {
+    size_t p = 0;
+    while (p < s.size()) {
+      size_t e = s.find('|', p);
+      if (e == std::string::npos) e = s.size();
+      std::string kvp = s.substr(p, e - p);
+      size_t eq = kvp.find('=');
+      if (eq != std::string::npos) kv[kvp.substr(0, eq)] = kvp.substr(eq + 1);
+      p = e + 1;
+    }
+  }
+};
+
+inline const std::string &bot_param_get_raw_or_fail(BotParam *p, const char *key)
+{
+  auto it = p->kv.find(key);
+  if (it == p->kv.end()) {
+    fprintf(stderr, "ERROR: BotParam: could not get param value for key '%s'\n", key);
+    exit(1);  // libbot bot_param_get_*_or_fail behaviour
+  }
+  return it->second;
+}
+inline double bot_param_get_double_or_fail(BotParam *p, const char *key) { return atof(bot_param_get_raw_or_fail(p, key).c_str()); }
+inline int64_t bot_param_get_int_or_fail(BotParam *p, const char *key) { return atoll(bot_param_get_raw_or_fail(p, key).c_str()); }
+inline bool bot_param_get_boolean_or_fail(BotParam *p, const char *key)
+{
+  const std::string &v = bot_param_get_raw_or_fail(p, key);
+  return v == "true" || v == "1" || v == "True";
+}
+inline std::string bot_param_get_str_or_fail(BotParam *p, const char *key) { return bot_param_get_raw_or_fail(p, key); }
+inline double bot_sq(double a) { return a * a; }
+inline double bot_to_radians(double d) { return d * (M_PI / 180.0); }
+
+struct BotTrans {
+  double rot_quat[4] = { 1, 0, 0, 0 };
+  double trans_vec[3] = { 0, 0, 0 };
+  bool isIdentityRotation() const { return rot_quat[0] == 1 && rot_quat[1] == 0 && rot_quat[2] == 0 && rot_quat[3] == 0; }
+};
+// libbot bot_quat_rotate_to (restated in-tree at pronto-utils/src/pronto_complementary/complementary_test.cpp:49-59)
+inline void bot_quat_rotate_to(const double rot[4], const double v[3], double r[3])
+{
+  double ab = rot[0] * rot[1], ac = rot[0] * rot[2], ad = rot[0] * rot[3];
+  double nbb = -rot[1] * rot[1], bc = rot[1] * rot[2], bd = rot[1] * rot[3];
+  double ncc = -rot[2] * rot[2], cd = rot[2] * rot[3], ndd = -rot[3] * rot[3];
+  r[0] = 2 * ((ncc + ndd) * v[0] + (bc - ad) * v[1] + (ac + bd) * v[2]) + v[0];
+  r[1] = 2 * ((ad + bc) * v[0] + (nbb + ndd) * v[1] + (cd - ab) * v[2]) + v[1];
+  r[2] = 2 * ((bd - ac) * v[0] + (ab + cd) * v[1] + (nbb + ncc) * v[2]) + v[2];
+}
+inline void bot_trans_apply_vec(const BotTrans *t, const double v[3], double r[3])
+{
+  bot_quat_rotate_to(t->rot_quat, v, r);
+  r[0] += t->trans_vec[0]; r[1] += t->trans_vec[1]; r[2] += t->trans_vec[2];
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// batched RBIS / RBIM (rbis.hpp:19-123): host containers, SoA with the filter index fastest
+// ---------------------------------------------------------------------------------------------------------------
+struct RBIS {
+  enum { angular_velocity_ind = 0, velocity_ind = 3, chi_ind = 6, position_ind = 9, acceleration_ind = 12,
+         basic_num_states = 15, gyro_bias_ind = 15, accel_bias_ind = 18, rbis_num_states = 21 };
+  int n = 0, B = 0;
+  int64_t utime = 0;
+  std::vector<double> vec;   // [n][B]
+  std::vector<double> quat;  // [4][B]  (w,x,y,z)
+  RBIS() {}
+  RBIS(int n_states, int batch) : n(n_states), B(batch), vec((size_t) n_states * batch, 0.0), quat((size_t) 4 * batch, 0.0)
+  {
+    for (int b = 0; b < B; b++) quat[b] = 1.0;
+  }
+  double &operator()(int i, int b) { return vec[(size_t) i * B + b]; }
+  double operator()(int i, int b) const { return vec[(size_t) i * B + b]; }
+  double &q(int i, int b) { return quat[(size_t) i * B + b]; }
+  double q(int i, int b) const { return quat[(size_t) i * B + b]; }
+  static std::vector<int> positionInds() { return { 9, 10, 11 }; }
+  static std::vector<int> velocityInds() { return { 3, 4, 5 }; }
+  static std::vector<int> chiInds() { return { 6, 7, 8 }; }
+  static std::vector<int> angularVelocityInds() { return { 0, 1, 2 }; }
+};
+
+struct RBIM {
+  int n = 0, B = 0;
+  std::vector<double> m;  // [n*n][B], column-major per filter (Map<RBIM>, rbis.cpp:300)
+  RBIM() {}
+  RBIM(int n_states, int batch) : n(n_states), B(batch), m((size_t) n_states * n_states * batch, 0.0) {}
+  double &operator()(int r, int c, int b) { return m[((size_t) c * n + r) * B + b]; }
+  double operator()(int r, int c, int b) const { return m[((size_t) c * n + r) * B + b]; }
+};
+
+// a batched array handed over by a message: pointer + where it lives
+struct BatchArray {
+  const double *p = nullptr;
+  int mem = PB_HOST;
+  BatchArray() {}
+  BatchArray(const double *ptr, int m) : p(ptr), mem(m) {}
+};
+
+class MavStateEstimator;
+
+// ---------------------------------------------------------------------------------------------------------------
+// update objects (rbis_update_interface.hpp)
+// ---------------------------------------------------------------------------------------------------------------
+class RBISUpdateInterface {
+public:
+  typedef enum {
+    ins, gps, vicon, laser, laser_gpf, scan_matcher, optical_flow, reset, invalid, rgbd, fovis, legodo, pose_meas,
+    altimeter, airspeed, sideslip, init_message, viewer, yawlock
+  } sensor_enum;
+  int64_t utime;
+  sensor_enum sensor_id;
+  RBISUpdateInterface(sensor_enum sensor_id_, int64_t utime_) : utime(utime_), sensor_id(sensor_id_) {}
+  virtual ~RBISUpdateInterface() {}
+  // Applies this update to the estimator's device-resident posterior (prior = previous posterior,
+  // mav_state_est.cpp:55-57).  Returns a pb_status; the posterior/loglikelihood stay on the device.
+  virtual int updateFilter(pb_ctx *ctx) = 0;
+  static const char *sensor_enum_string(sensor_enum s)
+  {
+    static const char *names[] = { "ins", "gps", "vicon", "laser", "laser_gpf", "scan_matcher", "optic_flow", "reset",
+                                   "invalid", "rgbd", "fovis", "legodo", "pose_meas", "altimeter", "airspeed",
+                                   "sideslip", "init_message", "viewer", "yawlock" };
+    return names[(int) s];
+  }
+};
+
+class RBISResetUpdate : public RBISUpdateInterface {
+public:
+  RBIS reset_state;
+  RBIM reset_cov;
+  RBISResetUpdate(const RBIS &state, const RBIM &cov, sensor_enum sensor_id_, int64_t utime)
+      : RBISUpdateInterface(sensor_id_, utime), reset_state(state), reset_cov(cov) {}
+  int updateFilter(pb_ctx *ctx) override
+  {
+    return pb_reset(ctx, reset_state.vec.data(), reset_state.quat.data(), reset_cov.m.data(), 0, PB_HOST);
+  }
+};
+
+class RBISIMUProcessStep : public RBISUpdateInterface {
+public:
+  // gyro xyz | accelerometer xyz | dt as ONE block [7][B] (body frame), owned when built on the host
+  std::vector<double> owned;
+  BatchArray imu_block;
+  double q_gyro, q_accel, q_gyro_bias, q_accel_bias;
+  RBISIMUProcessStep(BatchArray imu_block_, double q_gyro_, double q_accel_, double q_gyro_bias_, double q_accel_bias_,
+                     int64_t utime)
+      : RBISUpdateInterface(ins, utime), imu_block(imu_block_), q_gyro(q_gyro_), q_accel(q_accel_),
+        q_gyro_bias(q_gyro_bias_), q_accel_bias(q_accel_bias_) {}
+  RBISIMUProcessStep(std::vector<double> &&block, double q_gyro_, double q_accel_, double q_gyro_bias_,
+                     double q_accel_bias_, int64_t utime)
+      : RBISUpdateInterface(ins, utime), owned(std::move(block)), imu_block(owned.data(), PB_HOST), q_gyro(q_gyro_),
+        q_accel(q_accel_), q_gyro_bias(q_gyro_bias_), q_accel_bias(q_accel_bias_) {}
+  int updateFilter(pb_ctx *ctx) override
+  {
+    const double q[4] = { q_gyro, q_accel, q_gyro_bias, q_accel_bias };
+    return pb_predict(ctx, imu_block.p, q, imu_block.mem);
+  }
+};
+
+class RBISIndexedMeasurement : public RBISUpdateInterface {
+public:
+  std::vector<int> index;
+  std::vector<double> owned_z, owned_R;
+  std::vector<uint8_t> owned_mask;
+  BatchArray measurement;           // [m][B]
+  const double *measurement_cov;    // per r_kind
+  int r_kind, cov_mem;
+  const uint8_t *mask = nullptr;    // [B]; 0 = this filter's handler returned NULL (lcm_front_end.hpp:156)
+  RBISIndexedMeasurement(const std::vector<int> &index_, BatchArray measurement_, const double *measurement_cov_,
+                         int r_kind_, const uint8_t *mask_, sensor_enum sensor_id_, int64_t utime)
+      : RBISUpdateInterface(sensor_id_, utime), index(index_), measurement(measurement_),
+        measurement_cov(measurement_cov_), r_kind(r_kind_), cov_mem(measurement_.mem), mask(mask_) {}
+  // host-built measurement: takes ownership of z [m][B], R (per r_kind) and mask
+  RBISIndexedMeasurement(const std::vector<int> &index_, std::vector<double> &&z, std::vector<double> &&R, int r_kind_,
+                         std::vector<uint8_t> &&mask_, sensor_enum sensor_id_, int64_t utime)
+      : RBISUpdateInterface(sensor_id_, utime), index(index_), owned_z(std::move(z)), owned_R(std::move(R)),
+        owned_mask(std::move(mask_)), measurement(owned_z.data(), PB_HOST), measurement_cov(owned_R.data()),
+        r_kind(r_kind_), cov_mem(PB_HOST), mask(owned_mask.empty() ? nullptr : owned_mask.data()) {}
+  int updateFilter(pb_ctx *ctx) override
+  {
+    return pb_update_indexed(ctx, (int) index.size(), index.data(), measurement.p, measurement_cov, r_kind, mask,
+                             measurement.mem);
+  }
+};
+
+class RBISIndexedPlusOrientationMeasurement : public RBISIndexedMeasurement {
+public:
+  std::vector<double> owned_q;
+  BatchArray orientation;  // [4][B]
+  RBISIndexedPlusOrientationMeasurement(const std::vector<int> &index_, BatchArray measurement_,
+                                        const double *measurement_cov_, int r_kind_, BatchArray orientation_,
+                                        const uint8_t *mask_, sensor_enum sensor_id_, int64_t utime)
+      : RBISIndexedMeasurement(index_, measurement_, measurement_cov_, r_kind_, mask_, sensor_id_, utime),
+        orientation(orientation_) {}
+  RBISIndexedPlusOrientationMeasurement(const std::vector<int> &index_, std::vector<double> &&z, std::vector<double> &&R,
+                                        int r_kind_, std::vector<double> &&quat, std::vector<uint8_t> &&mask_,
+                                        sensor_enum sensor_id_, int64_t utime)
+      : RBISIndexedMeasurement(index_, std::move(z), std::move(R), r_kind_, std::move(mask_), sensor_id_, utime),
+        owned_q(std::move(quat)), orientation(owned_q.data(), PB_HOST) {}
+  int updateFilter(pb_ctx *ctx) override
+  {
+    return pb_update_indexed_orient(ctx, (int) index.size(), index.data(), measurement.p, measurement_cov, r_kind,
+                                    orientation.p, mask, measurement.mem);
+  }
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// MavStateEstimator (mav_state_est.hpp / .cpp): in-order path.  Out-of-order replay is SURVEY.md 8f rank 1.
+// ---------------------------------------------------------------------------------------------------------------
+class MavStateEstimator {
+public:
+  int64_t utime_history_span;
+  pb_ctx *ctx = nullptr;
+  int n = 0, B = 0;
+  int64_t head_utime = 0;
+  int last_status = PB_OK;
+  std::vector<RBISUpdateInterface *> unprocessed;  // added with roll_forward == false (mav_state_est.cpp:39-42)
+
+  MavStateEstimator(RBISResetUpdate *init_state, BotParam *param, int device = 0, int n_snapshots = 2)
+  {
+    utime_history_span = bot_param_get_int_or_fail(param, "state_estimator.utime_history_span");
+    n = init_state->reset_state.n;
+    B = init_state->reset_state.B;
+    int rc = pb_create(&ctx, n, B, device, n_snapshots);
+    if (rc != PB_OK) {
+      fprintf(stderr, "MavStateEstimator: %s\n", pb_last_error(nullptr));
+      exit(1);  // the reference's constructor cannot fail softly either (bot_param_get_int_or_fail)
+    }
+    last_status = init_state->updateFilter(ctx);  // "apply update from zero... should reset the state" (:16)
+    head_utime = init_state->utime;
+    pb_set_utime(ctx, head_utime);
+    delete init_state;  // the history owned it (update_history.cpp:5-13)
+  }
+  ~MavStateEstimator()
+  {
+    for (auto *u : unprocessed) delete u;
+    pb_destroy(ctx);
+  }
+  MavStateEstimator(const MavStateEstimator &) = delete;
+  MavStateEstimator &operator=(const MavStateEstimator &) = delete;
+
+  // Takes ownership of `update` (the reference's history deletes it, update_history.cpp:12,36,52).
+  void addUpdate(RBISUpdateInterface *update, bool roll_forward)
+  {
+    if (update == nullptr) return;
+    if (update->utime < head_utime) {
+      // update_history.cpp:28-39: an update older than the (here: one-element) history is discarded
+      fprintf(stderr, "error: update type %s had timestamp %jd, which was before the head (%jd)\ndiscarding update!\n",
+              RBISUpdateInterface::sensor_enum_string(update->sensor_id), (intmax_t) update->utime, (intmax_t) head_utime);
+      delete update;
+      return;
+    }
+    // keep the unprocessed queue time-ordered (multimap insert semantics: equal keys keep arrival order)
+    auto it = unprocessed.end();
+    while (it != unprocessed.begin() && (*(it - 1))->utime > update->utime) --it;
+    unprocessed.insert(it, update);
+    if (!roll_forward) return;
+    for (auto *u : unprocessed) {
+      int rc = u->updateFilter(ctx);
+      if (rc != PB_OK) {
+        last_status = rc;
+        fprintf(stderr, "MavStateEstimator::addUpdate: %s update failed: %s\n",
+                RBISUpdateInterface::sensor_enum_string(u->sensor_id), pb_last_error(ctx));
+      }
+      head_utime = u->utime;  // posterior_state.utime = update->utime (:60)
+      delete u;
+    }
+    unprocessed.clear();
+    pb_set_utime(ctx, head_utime);
+  }
+
+  void getHeadState(RBIS &head_state, RBIM &head_cov)
+  {
+    head_state = RBIS(n, B);
+    head_cov = RBIM(n, B);
+    last_status = pb_get_head(ctx, 0, B, head_state.vec.data(), head_state.quat.data(), head_cov.m.data(), nullptr, PB_HOST);
+    head_state.utime = head_utime;
+  }
+  std::vector<double> getMeasurementsLogLikelihood()
+  {
+    std::vector<double> ll(B);
+    last_status = pb_get_head(ctx, 0, B, nullptr, nullptr, nullptr, ll.data(), PB_HOST);
+    return ll;
+  }
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// messages (batched stand-ins for the LCM types at the seam; every array is [k][B])
+// ---------------------------------------------------------------------------------------------------------------
+namespace msgs {
+struct ins_t {               // bot_core::ins_t
+  int64_t utime;
+  BatchArray gyro, accel;    // [3][B] each, sensor frame
+};
+struct kvh_raw_imu_t {       // the newest packet of bot_core::kvh_raw_imu_batch_t (atlas_filter == false path)
+  int64_t utime;
+  BatchArray delta_rotation, linear_acceleration;  // [3][B]
+  double raw_dt;             // (raw_imu[0].utime - raw_imu[1].utime) * 1E-6
+};
+struct legodo_delta_t {      // what leg_estimate hands to LegOdoCommon::createMeasurement
+  int64_t utime, prev_utime;
+  const double *position;        // [3][B] pelvis position (may be NULL unless mode pos_and_lin_rate), host
+  const double *delta_trans;     // [3][B] translation of the pelvis delta over (prev_utime, utime], host
+  const double *delta_quat;      // [4][B] rotation of the delta (NULL = identity), host
+  const int *position_status;    // [B] or NULL (= valid)
+  const float *delta_status;     // [B]: < 0 skip (leg_estimate.hpp:84-93), < 0.5 certain, else uncertain
+};
+struct update_t {            // pronto::update_t (fovis)
+  int64_t timestamp, prev_timestamp;
+  const uint8_t *estimate_valid;   // [B] or NULL: estimate_status == ESTIMATE_VALID
+  BatchArray translation, rotation;  // [3][B], [4][B]
+};
+struct pose_t {              // bot_core::pose_t
+  int64_t utime;
+  BatchArray pos, vel, orientation;  // [3][B], [3][B], [4][B]
+};
+struct indexed_measurement_t {  // pronto::indexed_measurement_t
+  int64_t utime;
+  std::vector<int> z_indices;
+  BatchArray z_effective;      // [m][B]
+  const double *R_effective;   // [m*m][B] column-major, same memory space as z_effective
+};
+struct gps_data_t {
+  int64_t utime;
+  const uint8_t *has_lock;     // [B]: gps_lock >= 3
+  BatchArray xyz_pos;
+};
+}  // namespace msgs
+
+// ---------------------------------------------------------------------------------------------------------------
+// handlers
+// ---------------------------------------------------------------------------------------------------------------
+class InsHandler {
+public:
+  std::string channel;
+  BotTrans ins_to_body;
+  double cov_accel, cov_gyro, cov_accel_bias, cov_gyro_bias, dt;
+  bool atlas_filter, accel_bias_update_online, gyro_bias_update_online;
+  int64_t prev_utime_atlas = 0;
+
+  InsHandler(BotParam *_param, const BotTrans *ins_to_body_ = nullptr)
+  {
+    channel = bot_param_get_str_or_fail(_param, "state_estimator.ins.channel");
+    cov_gyro = bot_sq(bot_to_radians(bot_param_get_double_or_fail(_param, "state_estimator.ins.q_gyro")));          // :18-19
+    cov_accel = bot_sq(bot_param_get_double_or_fail(_param, "state_estimator.ins.q_accel"));                        // :20-21
+    cov_gyro_bias = bot_sq(bot_to_radians(bot_param_get_double_or_fail(_param, "state_estimator.ins.q_gyro_bias")));  // :22-23
+    cov_accel_bias = bot_sq(bot_param_get_double_or_fail(_param, "state_estimator.ins.q_accel_bias"));              // :24-25
+    dt = bot_param_get_double_or_fail(_param, "state_estimator.ins.timestep_dt");                                  // :27
+    atlas_filter = bot_param_get_boolean_or_fail(_param, "state_estimator.ins.atlas_filter");
+    accel_bias_update_online = bot_param_get_boolean_or_fail(_param, "state_estimator.ins.accel_bias_update_online");
+    if (!accel_bias_update_online) cov_accel_bias = 0.0;                                                          // :70-72
+    gyro_bias_update_online = bot_param_get_boolean_or_fail(_param, "state_estimator.ins.gyro_bias_update_online");
+    if (!gyro_bias_update_online) cov_gyro_bias = 0.0;                                                            // :89-91
+    if (ins_to_body_) ins_to_body = *ins_to_body_;
+    if (atlas_filter) {
+      fprintf(stderr, "InsHandler: state_estimator.ins.atlas_filter=true (KVH de-dup + notch cascade) is not on this "
+                      "path yet (SURVEY.md 8f rank 3)\n");
+      exit(1);
+    }
+  }
+
+  // Microstrain path (sensor_handlers.cpp:96-131): rotate accel and gyro into the body frame, dt = param
+  RBISUpdateInterface *processMessage(const msgs::ins_t *msg, MavStateEstimator *est)
+  {
+    return build(msg->gyro, msg->accel, 1.0, false, dt, msg->utime, est->B);
+  }
+  // Atlas KVH path without the notch (sensor_handlers.cpp:199-252): gyro = delta_rotation/raw_dt, accel through the
+  // full ins_to_body transform (rotation + translation, :227), dt from message timestamps (:239-249)
+  RBISUpdateInterface *processMessageAtlas(const msgs::kvh_raw_imu_t *msg, MavStateEstimator *est)
+  {
+    double integration_dt = (prev_utime_atlas == 0) ? dt : (msg->utime - prev_utime_atlas) * 1E-6;
+    if (integration_dt > 0.1) fprintf(stdout, "dt was : %f - there is an issue with timestamps\n", integration_dt);
+    prev_utime_atlas = msg->utime;
+    return build(msg->delta_rotation, msg->linear_acceleration, 1.0 / msg->raw_dt, true, integration_dt, msg->utime, est->B);
+  }
+
+private:
+  RBISUpdateInterface *build(BatchArray gyro, BatchArray accel, double gyro_scale, bool accel_translate, double dt_,
+                             int64_t utime, int B)
+  {
+    if (gyro.mem != PB_HOST || accel.mem != PB_HOST) {
+      fprintf(stderr, "InsHandler: sensor-frame inputs must be host arrays (frame rotation is a host pass)\n");
+      return nullptr;
+    }
+    std::vector<double> blk((size_t) 7 * B);
+    const bool ident = ins_to_body.isIdentityRotation();
+    for (int b = 0; b < B; b++) {
+      double g[3] = { gyro.p[b] * gyro_scale, gyro.p[(size_t) B + b] * gyro_scale, gyro.p[(size_t) 2 * B + b] * gyro_scale };
+      double a[3] = { accel.p[b], accel.p[(size_t) B + b], accel.p[(size_t) 2 * B + b] };
+      double gb[3], ab[3];
+      if (ident) {
+        memcpy(gb, g, sizeof g);
+        memcpy(ab, a, sizeof a);
+      } else {
+        bot_quat_rotate_to(ins_to_body.rot_quat, g, gb);
+        bot_quat_rotate_to(ins_to_body.rot_quat, a, ab);
+      }
+      if (accel_translate)
+        for (int i = 0; i < 3; i++) ab[i] += ins_to_body.trans_vec[i];
+      for (int i = 0; i < 3; i++) {
+        blk[(size_t) i * B + b] = gb[i];
+        blk[(size_t) (3 + i) * B + b] = ab[i];
+      }
+      blk[(size_t) 6 * B + b] = dt_;
+    }
+    return new RBISIMUProcessStep(std::move(blk), cov_gyro, cov_accel, cov_gyro_bias, cov_accel_bias, utime);
+  }
+};
+
+// pronto_math.cpp:25-61 and pronto_conversions_lcm.hpp:38-87
+inline void quat_to_euler(const double q[4], double &roll, double &pitch, double &yaw)
+{
+  const double q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+  roll = atan2(2 * (q0 * q1 + q2 * q3), 1 - 2 * (q1 * q1 + q2 * q2));
+  pitch = asin(2 * (q0 * q2 - q3 * q1));
+  yaw = atan2(2 * (q0 * q3 + q1 * q2), 1 - 2 * (q2 * q2 + q3 * q3));
+}
+
+class LegOdoCommon {
+public:
+  typedef enum { MODE_LIN_RATE, MODE_ROT_RATE, MODE_LIN_AND_ROT_RATE, MODE_POSITION_AND_LIN_RATE } LegOdoCommonMode;
+  LegOdoCommonMode mode_;
+  double R_legodo_xyz_, R_legodo_vxyz_, R_legodo_vang_, R_legodo_vxyz_uncertain_, R_legodo_vang_uncertain_;
+
+  explicit LegOdoCommon(BotParam *param)
+  {
+    std::string mode_str = bot_param_get_str_or_fail(param, "state_estimator.legodo.mode");
+    if (mode_str == "lin_rot_rate") mode_ = MODE_LIN_AND_ROT_RATE;
+    else if (mode_str == "lin_rate") mode_ = MODE_LIN_RATE;
+    else if (mode_str == "pos_and_lin_rate") mode_ = MODE_POSITION_AND_LIN_RATE;
+    else {
+      fprintf(stdout, "Legodo not understood! [LegOdoCommon].\n");  // rbis_legodo_common.cpp:19-21 (mode_ left unset there)
+      mode_ = MODE_LIN_RATE;
+    }
+    R_legodo_xyz_ = bot_param_get_double_or_fail(param, "state_estimator.legodo.r_xyz");
+    R_legodo_vxyz_ = bot_param_get_double_or_fail(param, "state_estimator.legodo.r_vxyz");
+    R_legodo_vang_ = bot_param_get_double_or_fail(param, "state_estimator.legodo.r_vang");
+    R_legodo_vxyz_uncertain_ = bot_param_get_double_or_fail(param, "state_estimator.legodo.r_vxyz_uncertain");
+    R_legodo_vang_uncertain_ = bot_param_get_double_or_fail(param, "state_estimator.legodo.r_vang_uncertain");
+  }
+
+  // getCovariance (rbis_legodo_common.cpp:34-88) for one filter: fills Rdiag[m], z_indices; returns m
+  int getCovariance(LegOdoCommonMode mode_current, bool delta_certain, double *Rdiag, std::vector<int> &z_indices) const
+  {
+    const double rv = delta_certain ? R_legodo_vxyz_ : R_legodo_vxyz_uncertain_;
+    const double ra = delta_certain ? R_legodo_vang_ : R_legodo_vang_uncertain_;
+    if (mode_current == MODE_LIN_AND_ROT_RATE) {
+      for (int i = 0; i < 3; i++) { Rdiag[i] = bot_sq(rv); Rdiag[3 + i] = bot_sq(ra); }
+      z_indices = { 3, 4, 5, 0, 1, 2 };
+      return 6;
+    } else if (mode_current == MODE_POSITION_AND_LIN_RATE) {
+      for (int i = 0; i < 3; i++) { Rdiag[i] = bot_sq(R_legodo_xyz_); Rdiag[3 + i] = bot_sq(rv); }
+      z_indices = { 9, 10, 11, 3, 4, 5 };
+      return 6;
+    }
+    for (int i = 0; i < 3; i++) Rdiag[i] = bot_sq(rv);
+    z_indices = { 3, 4, 5 };
+    return 3;
+  }
+
+  // createMeasurement (rbis_legodo_common.cpp:110-169) for B filters.  Filters whose delta status is < 0 (the
+  // handler's "return NULL", rbis_legodo_update.cpp:242-255) get mask 0.  In mode pos_and_lin_rate the reference
+  // falls back to lin_rate per message when the position is invalid (:118-122); a batch cannot change m per filter,
+  // so such filters keep m = 6 with an uninformative (1e12) position variance -- K for those rows is ~0.
+  RBISUpdateInterface *createMeasurement(const msgs::legodo_delta_t *msg, int B) const
+  {
+    const double elapsed = (double) (msg->utime - msg->prev_utime) * 1E-6;  // pronto_conversions_lcm.hpp:45
+    const int m = (mode_ == MODE_LIN_RATE) ? 3 : 6;
+    std::vector<double> z((size_t) m * B), R((size_t) m * B);
+    std::vector<uint8_t> mask(B);
+    std::vector<int> idx;
+    for (int b = 0; b < B; b++) {
+      const float st = msg->delta_status ? msg->delta_status[b] : 0.f;
+      mask[b] = st >= 0;
+      const bool certain = st < 0.5;                                        // :124-129
+      double Rd[6];
+      getCovariance(mode_, certain, Rd, idx);
+      double vel[3];
+      for (int i = 0; i < 3; i++) vel[i] = msg->delta_trans[(size_t) i * B + b] / elapsed;   // getDeltaAsVelocity :73
+      if (mode_ == MODE_LIN_RATE) {
+        for (int i = 0; i < 3; i++) { z[(size_t) i * B + b] = vel[i]; R[(size_t) i * B + b] = Rd[i]; }
+      } else if (mode_ == MODE_LIN_AND_ROT_RATE) {
+        double q[4] = { 1, 0, 0, 0 }, rpy[3];
+        if (msg->delta_quat) for (int i = 0; i < 4; i++) q[i] = msg->delta_quat[(size_t) i * B + b];
+        quat_to_euler(q, rpy[0], rpy[1], rpy[2]);                           // :141-147
+        for (int i = 0; i < 3; i++) {
+          z[(size_t) i * B + b] = vel[i];
+          z[(size_t) (3 + i) * B + b] = rpy[i] / (((double) msg->utime - msg->prev_utime) / 1000000);
+          R[(size_t) i * B + b] = Rd[i];
+          R[(size_t) (3 + i) * B + b] = Rd[3 + i];
+        }
+      } else {
+        const bool pos_ok = !msg->position_status || msg->position_status[b];
+        for (int i = 0; i < 3; i++) {
+          z[(size_t) i * B + b] = msg->position ? msg->position[(size_t) i * B + b] : 0.0;
+          z[(size_t) (3 + i) * B + b] = vel[i];
+          R[(size_t) i * B + b] = pos_ok ? Rd[i] : 1e12;
+          R[(size_t) (3 + i) * B + b] = Rd[3 + i];
+        }
+      }
+    }
+    return new RBISIndexedMeasurement(idx, std::move(z), std::move(R), PB_R_DIAG, std::move(mask),
+                                      RBISUpdateInterface::legodo, msg->utime);
+  }
+};
+
+// LegOdoHandler::processMessage (rbis_legodo_update.cpp:206-280) minus the kinematics: leg_estimate (KDL forward
+// kinematics + contact classifier, out of scope) is the producer of msgs::legodo_delta_t.
+class LegOdoHandler {
+public:
+  LegOdoCommon *leg_odo_common_;
+  int zero_initial_velocity;  // rbis_legodo_update.cpp:265-269: report zero velocity for the first N ticks
+  explicit LegOdoHandler(BotParam *param) : leg_odo_common_(new LegOdoCommon(param)), zero_initial_velocity(0)
+  {
+    auto it = param->kv.find("state_estimator.legodo.zero_initial_velocity");
+    if (it != param->kv.end()) zero_initial_velocity = atoi(it->second.c_str());
+  }
+  ~LegOdoHandler() { delete leg_odo_common_; }
+  RBISUpdateInterface *processMessage(const msgs::legodo_delta_t *msg, MavStateEstimator *est)
+  {
+    if (zero_initial_velocity > 0) {
+      zero_initial_velocity--;
+      std::vector<double> zero((size_t) 3 * est->B, 0.0);
+      msgs::legodo_delta_t m2 = *msg;
+      m2.delta_trans = zero.data();
+      return leg_odo_common_->createMeasurement(&m2, est->B);
+    }
+    return leg_odo_common_->createMeasurement(msg, est->B);
+  }
+};
+
+class ScanMatcherHandler {
+public:
+  typedef enum { MODE_POSITION, MODE_POSITION_YAW, MODE_VELOCITY, MODE_VELOCITY_YAW, MODE_YAW } ScanMatchingMode;
+  ScanMatchingMode mode;
+  std::vector<int> z_indices;
+  std::vector<double> cov_scan_match;  // diagonal
+
+  explicit ScanMatcherHandler(BotParam *param)
+  {
+    std::string mode_str = bot_param_get_str_or_fail(param, "state_estimator.scan_matcher.mode");
+    if (mode_str == "position") mode = MODE_POSITION;
+    else if (mode_str == "position_yaw") mode = MODE_POSITION_YAW;
+    else if (mode_str == "velocity") mode = MODE_VELOCITY;
+    else if (mode_str == "velocity_yaw") mode = MODE_VELOCITY_YAW;
+    else if (mode_str == "yaw") mode = MODE_YAW;
+    else mode = MODE_VELOCITY;  // sensor_handlers.cpp:636-639
+    if (mode == MODE_POSITION || mode == MODE_POSITION_YAW) {
+      double rxy = bot_param_get_double_or_fail(param, "state_estimator.scan_matcher.r_pxy");
+      double rz = bot_param_get_double_or_fail(param, "state_estimator.scan_matcher.r_pz");
+      cov_scan_match = { bot_sq(rxy), bot_sq(rxy), bot_sq(rz) };
+      z_indices = RBIS::positionInds();
+    } else if (mode == MODE_YAW) {
+      double ry = bot_param_get_double_or_fail(param, "state_estimator.scan_matcher.r_yaw");
+      cov_scan_match = { bot_sq(bot_to_radians(ry)) };
+      z_indices = { RBIS::chi_ind + 2 };
+    } else {
+      double rxy = bot_param_get_double_or_fail(param, "state_estimator.scan_matcher.r_vxy");
+      double rz = bot_param_get_double_or_fail(param, "state_estimator.scan_matcher.r_vz");
+      cov_scan_match = { bot_sq(rxy), bot_sq(rxy), bot_sq(rz) };
+      z_indices = RBIS::velocityInds();
+    }
+    if (mode == MODE_POSITION_YAW || mode == MODE_VELOCITY_YAW) {
+      double ry = bot_param_get_double_or_fail(param, "state_estimator.scan_matcher.r_yaw");
+      cov_scan_match.push_back(bot_sq(bot_to_radians(ry)));
+      z_indices.push_back(RBIS::chi_ind + 2);
+    }
+  }
+
+  // sensor_handlers.cpp:689-724.  For the *_yaw modes z is [4][B] whose 4th row is ignored (chi index), so the
+  // message's pos/vel block is used in place when it already has 4 rows of storage; otherwise it is padded on the host.
+  RBISUpdateInterface *processMessage(const msgs::pose_t *msg, MavStateEstimator *est)
+  {
+    const int B = est->B;
+    if (mode == MODE_POSITION)
+      return new RBISIndexedMeasurement(RBIS::positionInds(), msg->pos, cov_scan_match.data(), PB_R_DIAG_BROADCAST, nullptr,
+                                        RBISUpdateInterface::scan_matcher, msg->utime);
+    if (mode == MODE_VELOCITY)
+      return new RBISIndexedMeasurement(RBIS::velocityInds(), msg->vel, cov_scan_match.data(), PB_R_DIAG_BROADCAST, nullptr,
+                                        RBISUpdateInterface::scan_matcher, msg->utime);
+    const BatchArray src = (mode == MODE_POSITION_YAW) ? msg->pos : msg->vel;
+    const int m = (int) z_indices.size();
+    if (src.mem != PB_HOST && mode != MODE_YAW) {
+      fprintf(stderr, "ScanMatcherHandler: *_yaw modes take host pos/vel arrays\n");
+      return nullptr;
+    }
+    std::vector<double> z((size_t) m * B, 0.0);
+    if (mode != MODE_YAW) memcpy(z.data(), src.p, sizeof(double) * 3 * B);
+    std::vector<double> q((size_t) 4 * B);
+    if (msg->orientation.mem != PB_HOST) {
+      fprintf(stderr, "ScanMatcherHandler: orientation must be a host array\n");
+      return nullptr;
+    }
+    memcpy(q.data(), msg->orientation.p, sizeof(double) * 4 * B);
+    std::vector<double> R(cov_scan_match);
+    return new RBISIndexedPlusOrientationMeasurement(z_indices, std::move(z), std::move(R), PB_R_DIAG_BROADCAST, std::move(q),
+                                                     std::vector<uint8_t>(), RBISUpdateInterface::scan_matcher, msg->utime);
+  }
+};
+
+class IndexedMeasurementHandler {
+public:
+  explicit IndexedMeasurementHandler(RBISUpdateInterface::sensor_enum this_sensor) : indexed_sensor(this_sensor) {}
+  RBISUpdateInterface *processMessage(const msgs::indexed_measurement_t *msg, MavStateEstimator *)
+  {
+    return new RBISIndexedMeasurement(msg->z_indices, msg->z_effective, msg->R_effective, PB_R_FULL, nullptr, indexed_sensor,
+                                      msg->utime);  // sensor_handlers.cpp:560-566
+  }
+private:
+  RBISUpdateInterface::sensor_enum indexed_sensor;
+};
+
+class GpsHandler {
+public:
+  std::vector<double> cov_xyz;  // diagonal
+  explicit GpsHandler(BotParam *_param)
+  {
+    double rxy = bot_param_get_double_or_fail(_param, "state_estimator.gps.r_xy");
+    double rz = bot_param_get_double_or_fail(_param, "state_estimator.gps.r_z");
+    cov_xyz = { rxy * rxy, rxy * rxy, rz * rz };
+  }
+  RBISUpdateInterface *processMessage(const msgs::gps_data_t *msg, MavStateEstimator *)
+  {
+    return new RBISIndexedMeasurement(RBIS::positionInds(), msg->xyz_pos, cov_xyz.data(), PB_R_DIAG_BROADCAST, msg->has_lock,
+                                      RBISUpdateInterface::gps, msg->utime);  // sensor_handlers.cpp:374-381
+  }
+};
+
+class FovisHandler {
+public:
+  typedef enum { MODE_VELOCITY, MODE_VELOCITY_ROTATION_RATE, MODE_POSITION, MODE_POSITION_ORIENT } FovisMode;
+  FovisMode mode;
+  std::vector<int> z_indices;
+  std::vector<double> cov_fovis;  // diagonal
+  int64_t prev_t0_body_utime_ = 0;
+  int slot;                       // device snapshot slot holding the filter posterior at prev_timestamp
+  double *d_q = nullptr, *d_z6 = nullptr;  // device scratch: composed orientation [4][B], z [6][B] (rows 3-5 zero)
+  pb_ctx *owner = nullptr;
+
+  explicit FovisHandler(BotParam *param, int snapshot_slot = 0) : slot(snapshot_slot)
+  {
+    std::string mode_str = bot_param_get_str_or_fail(param, "state_estimator.fovis.mode");
+    if (mode_str == "velocity_rotation_rate") mode = MODE_VELOCITY_ROTATION_RATE;
+    else if (mode_str == "velocity") mode = MODE_VELOCITY;
+    else if (mode_str == "position") mode = MODE_POSITION;
+    else if (mode_str == "position_orient") mode = MODE_POSITION_ORIENT;
+    else {
+      fprintf(stdout, "FOVIS mode not understood %s, exiting\n", mode_str.c_str());
+      exit(-1);  // rbis_fovis_update.cpp:36-38
+    }
+    if (mode == MODE_VELOCITY || mode == MODE_VELOCITY_ROTATION_RATE) {
+      double r = bot_param_get_double_or_fail(param, "state_estimator.fovis.r_vxyz");
+      cov_fovis = { bot_sq(r), bot_sq(r), bot_sq(r) };
+      z_indices = RBIS::velocityInds();
+      if (mode == MODE_VELOCITY_ROTATION_RATE) {
+        double ra = bot_param_get_double_or_fail(param, "state_estimator.fovis.r_vang");
+        for (int i = 0; i < 3; i++) cov_fovis.push_back(bot_sq(ra));
+        for (int i : RBIS::angularVelocityInds()) z_indices.push_back(i);
+      }
+    } else {
+      double r = bot_param_get_double_or_fail(param, "state_estimator.fovis.r_pxyz");
+      cov_fovis = { bot_sq(r), bot_sq(r), bot_sq(r) };
+      z_indices = RBIS::positionInds();
+      if (mode == MODE_POSITION_ORIENT) {
+        double rc = bot_param_get_double_or_fail(param, "state_estimator.fovis.r_chi");  // NOT deg->rad (:99-102)
+        for (int i = 0; i < 3; i++) cov_fovis.push_back(bot_sq(rc));
+        for (int i : RBIS::chiInds()) z_indices.push_back(i);
+      }
+    }
+  }
+  ~FovisHandler()
+  {
+    if (owner) {
+      pb_free(owner, d_q);
+      pb_free(owner, d_z6);
+    }
+  }
+
+  // The estimator calls this when the posterior at a future `prev_timestamp` is the head: the device-side
+  // replacement of history.updateMap.lower_bound(prev_timestamp) (rbis_fovis_update.cpp:184-207).
+  void markKeyframe(MavStateEstimator *est) { pb_snapshot(est->ctx, slot); prev_t0_body_utime_ = est->head_utime; }
+
+  RBISUpdateInterface *processMessage(const msgs::update_t *msg, MavStateEstimator *est)
+  {
+    const int B = est->B;
+    if (mode == MODE_VELOCITY_ROTATION_RATE) {
+      fprintf(stdout, "FovisHandler Mode not supported, exiting\n");  // :276-285
+      return nullptr;
+    }
+    if (mode == MODE_VELOCITY) {
+      if (msg->translation.mem != PB_HOST) return nullptr;
+      const double elapsed = (double) (msg->timestamp - msg->prev_timestamp) * 1E-6;
+      std::vector<double> z((size_t) 3 * B);
+      for (size_t i = 0; i < z.size(); i++) z[i] = msg->translation.p[i] / elapsed;
+      std::vector<uint8_t> mask;
+      if (msg->estimate_valid) mask.assign(msg->estimate_valid, msg->estimate_valid + B);
+      return new RBISIndexedMeasurement(RBIS::velocityInds(), std::move(z), std::vector<double>(cov_fovis), PB_R_DIAG_BROADCAST,
+                                        std::move(mask), RBISUpdateInterface::fovis, msg->timestamp);
+    }
+    // position / position_orient: T1 = T0(posterior at prev_timestamp) * (t, q)
+    const double diff = (double) (prev_t0_body_utime_ - msg->prev_timestamp) * 1E-6;
+    if (diff > 0.025 || diff < -0.025) {
+      fprintf(stdout, "FOIVS: time difference for VO delta root pose is too great (%fsec). Will not use\n", diff);  // :186-189
+      return nullptr;
+    }
+    if (!owner) {
+      owner = est->ctx;
+      pb_malloc(owner, sizeof(double) * 4 * B, (void **) &d_q);
+      pb_malloc(owner, sizeof(double) * 6 * B, (void **) &d_z6);
+      std::vector<double> zero((size_t) 6 * B, 0.0);
+      pb_memcpy_h2d(owner, d_z6, zero.data(), sizeof(double) * 6 * B);
+    }
+    if (pb_compose_delta(est->ctx, slot, msg->translation.p, msg->rotation.p, d_z6, d_q, msg->translation.mem) != PB_OK) {
+      fprintf(stderr, "FovisHandler: %s\n", pb_last_error(est->ctx));
+      return nullptr;
+    }
+    if (mode == MODE_POSITION)
+      return new RBISIndexedMeasurement(RBIS::positionInds(), BatchArray(d_z6, PB_DEVICE), cov_fovis.data(), PB_R_DIAG_BROADCAST,
+                                        nullptr, RBISUpdateInterface::fovis, msg->timestamp);
+    // rows 3..5 of d_z6 stay zero: z at chi indices is ignored (rbis.cpp:203-205)
+    return new RBISIndexedPlusOrientationMeasurement(z_indices, BatchArray(d_z6, PB_DEVICE), cov_fovis.data(), PB_R_DIAG_BROADCAST,
+                                                     BatchArray(d_q, PB_DEVICE), nullptr, RBISUpdateInterface::fovis,
+                                                     msg->timestamp);
+  }
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// dispatch: LCMFrontEnd::addSensor / SensorHandler::lcm_message_handler without LCM (lcm_front_end.hpp:82-94,139-203)
+// ---------------------------------------------------------------------------------------------------------------
+class FrontEnd {
+public:
+  BotParam *param;
+  MavStateEstimator *state_estimator = nullptr;
+  explicit FrontEnd(BotParam *p) : param(p) {}
+  void setStateEstimator(MavStateEstimator *e) { state_estimator = e; }
+
+  template <class MsgT, class HandlerT>
+  std::function<void(const MsgT *)> addSensor(const std::string &sensor_prefix,
+                                              RBISUpdateInterface *(HandlerT::*handler_function)(const MsgT *, MavStateEstimator *),
+                                              HandlerT *handler)
+  {
+    const std::string pre = "state_estimator." + sensor_prefix;
+    const int downsample_factor = (int) bot_param_get_int_or_fail(param, (pre + ".downsample_factor").c_str());
+    const bool roll_forward = bot_param_get_boolean_or_fail(param, (pre + ".roll_forward_on_receive").c_str());
+    const int64_t utime_delay = bot_param_get_int_or_fail(param, (pre + ".utime_offset").c_str());
+    auto counter = std::make_shared<int64_t>(0);
+    return [=](const MsgT *msg) {
+      if (state_estimator == nullptr) return;
+      if ((*counter)++ % downsample_factor != 0) return;                     // :147
+      RBISUpdateInterface *update = (handler->*handler_function)(msg, state_estimator);
+      if (update != nullptr) {
+        update->utime -= utime_delay;                                        // :157
+        state_estimator->addUpdate(update, roll_forward);                    // :158
+      }
+    };
+  }
+};
+
+}  // namespace MavStateEst
