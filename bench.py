@@ -168,7 +168,7 @@ def main():
             "config": {"workload": "64k batched 15-state filters, IMU predict + 3-DoF leg-odom update, 1 MI355X"
                        if (n == 15 and Bper == 65536) else
                        "%d batched %d-state filters per GPU, IMU predict + 3-DoF leg-odom update" % (Bper, n),
-                       "batch_per_gpu": Bper, "n_states": n, "imu_dt_us": dt_us, "kernel": "k_step<%d,true>" % n,
+                       "batch_per_gpu": Bper, "n_states": n, "imu_dt_us": dt_us, "kernel": est.hot_kernel(),
                        "launches_per_step": 1, "bytes_per_filter_step": bps, "parallelism": "filter-range split x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
@@ -180,7 +180,7 @@ def main():
         if os.path.exists(tr):
             try:
                 rec = json.load(open(tr))
-                key = "k_step<%d,true>@%d" % (n, B)
+                key = "%s@%d" % (est.hot_kernel(), B)
                 if key in rec:
                     out["roofline"]["traffic"] = rec[key]["hbm_bytes_per_launch"]
             except Exception:

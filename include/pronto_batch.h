@@ -72,6 +72,9 @@ int pb_set_stream(pb_ctx *ctx, void *hip_stream);
 /* eigen_utils constants that are not in the reference tree (g_vec magnitude, chiToQuat tolerance). */
 int pb_set_constants(pb_ctx *ctx, double g, double chi_tol);
 int pb_sync(pb_ctx *ctx);
+/* name (as rocprofv3 prints it, without the pb:: prefix) of the kernel pb_step_legodo / pb_run_legodo launch for
+ * this context: "k_step<15,true>", "k_step_coop<15,true>" or "k_step_coop<21,true>" */
+const char *pb_hot_kernel(const pb_ctx *ctx);
 int pb_batch(const pb_ctx *ctx);
 int pb_n_states(const pb_ctx *ctx);
 

@@ -46,6 +46,7 @@ _SIGS = {
     "pb_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "pb_set_constants": (C.c_int, [C.c_void_p, C.c_double, C.c_double]),
     "pb_sync": (C.c_int, [C.c_void_p]),
+    "pb_hot_kernel": (C.c_char_p, [C.c_void_p]),
     "pb_batch": (C.c_int, [C.c_void_p]),
     "pb_n_states": (C.c_int, [C.c_void_p]),
     "pb_malloc": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]),

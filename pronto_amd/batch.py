@@ -76,6 +76,9 @@ class BatchEstimator:
     def sync(self):
         self._chk(self._L.pb_sync(self._h))
 
+    def hot_kernel(self):
+        return self._L.pb_hot_kernel(self._h).decode()
+
     # --- update objects ---
     def reset(self, vec, quat, cov, broadcast=False):
         """RBISResetUpdate.  vec [n,B], quat [4,B], cov [n,n,B] indexed [row,col,b] (or [n],[4],[n,n] broadcast)."""

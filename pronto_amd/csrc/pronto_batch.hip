@@ -30,6 +30,7 @@ struct pb_ctx {
   Consts k{ 9.80665, 1e-6 };
   int64_t utime = 0;
   bool have_state = false;
+  bool coop15 = false;  // PRONTO_BATCH_COOP15=1: run the 15-state step on the two-wave cooperative kernel (A/B switch)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   char err[512] = { 0 };
 };
@@ -79,6 +80,13 @@ extern "C" int pb_create(pb_ctx **out, int n_states, int batch, int device, int 
   c->B = batch;
   c->dev = device;
   c->nsnap = n_snapshots;
+  {
+    // 15-state hot kernel: the two-wave cooperative mapping (2 waves/SIMD, reads and writes interleave) measured
+    // 3-20 % faster up to 256k filters, the one-lane-per-filter k_step 3-5 % faster beyond (profiles/).
+    // PRONTO_BATCH_COOP15=0/1 forces one of them (A/B runs and tests).
+    const char *e = getenv("PRONTO_BATCH_COOP15");
+    c->coop15 = e ? (e[0] == '1') : (batch <= 393216);
+  }
   c->stride = ((long) batch + 63) / 64 * 64;
   c->nc = (n_states == 15) ? Lay<15>::NC : Lay<21>::NC;
   // the kernels address the state through one 32-bit-ranged buffer descriptor (rbis_kernels.hpp)
@@ -154,6 +162,12 @@ extern "C" int pb_sync(pb_ctx *c)
   return PB_OK;
 }
 
+extern "C" const char *pb_hot_kernel(const pb_ctx *c)
+{
+  if (!c) return "";
+  if (c->ns == 21) return "k_step_coop<21,true>";
+  return c->coop15 ? "k_step_coop<15,true>" : "k_step<15,true>";
+}
 extern "C" int pb_batch(const pb_ctx *c) { return c ? c->B : -1; }
 extern "C" int pb_n_states(const pb_ctx *c) { return c ? c->ns : -1; }
 
@@ -278,20 +292,14 @@ template <bool UPDATE>
 static int launch_step(pb_ctx *c, const double *imu, const double *lo, const uint8_t *mask, const double q[4])
 {
   const int B = c->B;
-  if (c->ns == 15) {
+  if (c->ns == 15 && c->coop15) {
+    k_step_coop<15, UPDATE><<<nblk(B), 128, 0, c->stream>>>(c->st, c->stride, B, imu, lo, mask, q[0], q[1], q[2], q[3], c->k);
+  } else if (c->ns == 15) {
     k_step<15, UPDATE><<<(B + PB_STEP_BLOCK - 1) / PB_STEP_BLOCK, PB_STEP_BLOCK, 0, c->stream>>>(c->st, c->stride, B, imu, lo, mask, q[0], q[1], q[2], q[3], c->k);
   } else {
-    // n = 21: 231 packed covariance entries do not fit one lane's registers next to the update temporaries (the
-    // fused instantiation spills ~200 VGPRs and is not built); predict and the generic streaming update run as
-    // two launches until the 21-state kernel gets its own mapping (DESIGN.md "n = 21").
-    k_step<21, false><<<nblk(B), 64, 0, c->stream>>>(c->st, c->stride, B, imu, nullptr, nullptr, q[0], q[1], q[2], q[3], c->k);
-    if (UPDATE) {
-      LAUNCHCHK(c);
-      IdxArg<3> ia = { { 3, 4, 5 } };
-      DiagArg<3> da = { { 0, 0, 0 } };
-      k_update<21, 3, false><<<nblk(B), 64, 0, c->stream>>>(c->st, c->stride, B, ia, lo, lo + 3 * (size_t) B, PB_R_DIAG, da,
-                                                            nullptr, mask, c->k);
-    }
+    // n = 21: 231 packed covariance entries do not fit one lane's registers; the step runs on the two-wave
+    // cooperative kernel (rbis_coop.hpp): one launch, one state round trip.
+    k_step_coop<21, UPDATE><<<nblk(B), 128, 0, c->stream>>>(c->st, c->stride, B, imu, lo, mask, q[0], q[1], q[2], q[3], c->k);
   }
   LAUNCHCHK(c);
   return PB_OK;

@@ -1,0 +1,397 @@
+// rbis_coop.hpp -- the predict(+update) step split over TWO cooperating waves per 64 filters.
+//
+// Why: a 21-state filter has 231 packed covariance entries = 462 registers per lane before any temporary; one lane
+// per filter cannot hold it (k_step<21,*> spills to scratch).  The process model gives a natural cut
+// (rbis.cpp:12-35): in the order p = {omega, accel} (passive: identity rows/cols of Ad, never a source),
+// c = {v, chi, Delta} (dynamic core), b = {gyro bias, accel bias},
+//
+//        | I   0     0   |          P'_cc = G P_(cb)(cb) G^T,  P'_cb = F_cc P_cb + F_cb P_bb,  P'_bb = P_bb + Q_b dt
+//   Ad = | 0  F_cc  F_cb | ,        P'_cp = F_cc P_cp + F_cb P_bp,   P'_bp = P_bp,   P'_pp = P_pp (+ overwrites)
+//        | 0   0     I   |          (G = [F_cc F_cb])
+//
+// so the (c,b) x (c,b) sub-matrix evolves by itself and the p-panels only consume F.  Role C (wave 0 of the
+// workgroup) owns the (c,b) sub-matrix, the state and the quaternion; role P (wave 1) owns P_cp, P_bp, P_pp and the
+// omega/accel entries of x.  A measurement on core states (legodo idx 3..5) needs ONE hand-off: role C publishes the
+// LDL^T factors and its rows of W = P[:,idx] L^-T through LDS, both waves meet at one barrier, then each downdates
+// and stores its own entries.  No lane divergence, no cross-lane traffic, whole-row (512 B) global accesses.
+//
+// The role bodies are PB_HD templates over load/store/exchange functors so that tests/host_harness.cpp can run the
+// two roles back to back on the CPU against the oracle.
+#pragma once
+
+#include "rbis_device.hpp"
+
+namespace pb {
+
+template <int NS>
+struct Coop {
+  static constexpr bool HB = (NS == 21);            // has bias states
+  static constexpr int NSC = HB ? 15 : 9;           // role C sub-state: v chi Delta [bg ba]
+  static constexpr int NPC = NSC * (NSC + 1) / 2;
+  static constexpr int NB_ = HB ? 6 : 0;            // bias states
+  static constexpr int NXCH = 9 + 3 * NSC;          // LDS hand-off doubles per filter: L(3) id(3) yd(3) W_c,b
+  // sub index -> full state index
+  PB_HD static constexpr int fullc(int s) { return s < 9 ? 3 + s : 15 + (s - 9); }
+  // passive index 0..5 -> full state index (omega 0..2, accel 12..14)
+  PB_HD static constexpr int fullp(int p) { return p < 3 ? p : 12 + (p - 3); }
+};
+
+// blocks of Ac*dt about the prior state (rbis.cpp:12-35), shared by both roles
+struct ProcBlocks {
+  double a_mw[3];  // -skew(w) dt      = hat(a_mw)
+  double a_g[3];   // skew(R^T g) dt   = hat(a_g)
+  double a_mv[3];  // -skew(v) dt      = hat(a_mv)
+  double A_R[9];   // R dt
+  double A_RV[9];  // -R skew(v) dt
+  double v[3];
+};
+
+template <int NS>
+PB_HD void make_proc_blocks(const double (&xp)[NS], const double (&qp)[4], double dt, const Consts &k, ProcBlocks &pb_)
+{
+  double R[9];
+  quat_to_rot(qp, R);
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    pb_.v[i] = xp[3 + i];
+    pb_.a_mw[i] = -(xp[i] * dt);
+    pb_.a_g[i] = (-k.g * R[6 + i]) * dt;
+    pb_.a_mv[i] = -(xp[3 + i] * dt);
+  }
+  const double vd[3] = { xp[3] * dt, xp[4] * dt, xp[5] * dt };
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    pb_.A_R[3 * i + 0] = R[3 * i + 0] * dt;
+    pb_.A_R[3 * i + 1] = R[3 * i + 1] * dt;
+    pb_.A_R[3 * i + 2] = R[3 * i + 2] * dt;
+    pb_.A_RV[3 * i + 0] = -(R[3 * i + 1] * vd[2] - R[3 * i + 2] * vd[1]);
+    pb_.A_RV[3 * i + 1] = -(R[3 * i + 2] * vd[0] - R[3 * i + 0] * vd[2]);
+    pb_.A_RV[3 * i + 2] = -(R[3 * i + 0] * vd[1] - R[3 * i + 1] * vd[0]);
+  }
+}
+
+// hat(a) * X for a 3x3 block X (row-major), accumulated into Y
+PB_HD void hat_mul_acc(const double (&a)[3], const double (&X)[9], double (&Y)[9])
+{
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    Y[0 + c] += a[1] * X[6 + c] - a[2] * X[3 + c];
+    Y[3 + c] += a[2] * X[0 + c] - a[0] * X[6 + c];
+    Y[6 + c] += a[0] * X[3 + c] - a[1] * X[0 + c];
+  }
+}
+PB_HD void mat_mul_acc(const double (&A)[9], const double (&X)[9], double (&Y)[9])
+{
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+      Y[3 * r + c] += A[3 * r] * X[c] + A[3 * r + 1] * X[3 + c] + A[3 * r + 2] * X[6 + c];
+}
+
+struct StepInputs {
+  double gyro[3], accel[3], dt;
+  double z[3], rd[3];
+  bool upd;
+  double qg, qa, qbg, qba;
+};
+
+// ------------------------------------------------------------------------------------------------------------
+// role C: (c,b) sub-matrix, state, quaternion, log-likelihood
+//   LD(comp) -> double, ST(comp, v), XW(slot, v) writes the hand-off, SYNC() is the workgroup barrier
+// ------------------------------------------------------------------------------------------------------------
+template <int NS, bool UPDATE, class LD, class ST, class XW, class SYNC>
+PB_HD void coop_role_core(LD ld, ST st, XW xw, SYNC sync, const StepInputs &in, const Consts &k)
+{
+  using L = Lay<NS>;
+  using C = Coop<NS>;
+  constexpr int NSC = C::NSC;
+  double x[NS], q[4], ll;
+#pragma unroll
+  for (int i = 0; i < NS; i++) x[i] = ld(L::OFF_VEC + i);
+#pragma unroll
+  for (int i = 0; i < 4; i++) q[i] = ld(L::OFF_QUAT + i);
+  ll = ld(L::OFF_LL);
+  double Pc[C::NPC];
+#pragma unroll
+  for (int i = 0; i < NSC; i++)
+#pragma unroll
+    for (int j = 0; j <= i; j++) Pc[pk(i, j)] = ld(L::OFF_P + pk(C::fullc(i), C::fullc(j)));
+
+  // ---- covariance propagate on the sub-matrix (blocks: v=0 chi=1 Delta=2 bg=3 ba=4) ----
+  ProcBlocks f;
+  make_proc_blocks<NS>(x, q, in.dt, k, f);
+  {
+    const int src[2] = { 0, 1 };
+    const int kind[2] = { 0, 0 };
+    double A[2][9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) { A[0][i] = f.A_R[i]; A[1][i] = f.A_RV[i]; }
+    RowOp<NSC, 2, 2>::apply(Pc, src, kind, A);  // E3: row Delta
+  }
+  if constexpr (C::HB) {
+    const int src[4] = { 0, 1, 3, 4 };
+    const int kind[4] = { 1, 1, 1, 2 };
+    double A[4][9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) { A[0][i] = f.a_mw[i % 3]; A[1][i] = f.a_g[i % 3]; A[2][i] = f.a_mv[i % 3]; A[3][i] = -in.dt; }
+    RowOp<NSC, 0, 4>::apply(Pc, src, kind, A);  // E1: row v
+    const int src2[2] = { 1, 3 };
+    const int kind2[2] = { 1, 2 };
+    double A2[2][9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) { A2[0][i] = f.a_mw[i % 3]; A2[1][i] = -in.dt; }
+    RowOp<NSC, 1, 2>::apply(Pc, src2, kind2, A2);  // E2: row chi
+  } else {
+    const int src[2] = { 0, 1 };
+    const int kind[2] = { 1, 1 };
+    double A[2][9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) { A[0][i] = f.a_mw[i % 3]; A[1][i] = f.a_g[i % 3]; }
+    RowOp<NSC, 0, 2>::apply(Pc, src, kind, A);
+    const int src2[1] = { 1 };
+    const int kind2[1] = { 1 };
+    double A2[1][9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) A2[0][i] = f.a_mw[i % 3];
+    RowOp<NSC, 1, 1>::apply(Pc, src2, kind2, A2);
+  }
+  // Qd (closed form of rbis.cpp:91-116) on sub indices: v 0..2, chi 3..5, bg 9..11, ba 12..14
+  {
+    const double qgd = in.qg * in.dt, qad = in.qa * in.dt;
+    const double vv = f.v[0] * f.v[0] + f.v[1] * f.v[1] + f.v[2] * f.v[2];
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+      for (int c = 0; c <= r; c++) Pc[pk(r, c)] += qgd * ((r == c ? vv : 0.0) - f.v[r] * f.v[c]) + (r == c ? qad : 0.0);
+    const double m[9] = { 0, f.v[2], -f.v[1], -f.v[2], 0, f.v[0], f.v[1], -f.v[0], 0 };
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+      for (int c = 0; c < 3; c++)
+        if (r != c) Pc[pk(3 + r, c)] += qgd * m[3 * r + c];
+#pragma unroll
+    for (int r = 0; r < 3; r++) Pc[pk(3 + r, 3 + r)] += qgd;
+    if constexpr (C::HB) {
+#pragma unroll
+      for (int r = 0; r < 3; r++) {
+        Pc[pk(9 + r, 9 + r)] += in.qbg * in.dt;
+        Pc[pk(12 + r, 12 + r)] += in.qba * in.dt;
+      }
+    }
+  }
+  // ---- state propagate (rbis.cpp:37-75); omega/accel entries are role P's to store ----
+  ins_update_state<NS>(x, q, in.gyro, in.accel, in.dt, k);
+
+  if constexpr (UPDATE) {
+    // S = R + P[v,v]; unpivoted LDL^T; y = L^-1 r  (rbis.cpp:124-143)
+    double resid[3], S[6], d[3], y[3], id[3], yd[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) resid[i] = in.upd ? in.z[i] - x[3 + i] : 0.0;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+      for (int j = 0; j <= i; j++) S[pk(i, j)] = Pc[pk(i, j)] + (i == j ? (in.upd ? in.rd[i] : 1.0) : 0.0);
+    ldlt<3>(S, d);
+    double lli = 0.0;
+#pragma unroll
+    for (int kk = 0; kk < 3; kk++) {
+      double s = resid[kk];
+#pragma unroll
+      for (int j = 0; j < kk; j++) s -= S[pk(kk, j)] * y[j];
+      y[kk] = in.upd ? s : 0.0;
+      id[kk] = in.upd ? 1.0 / d[kk] : 0.0;
+      yd[kk] = y[kk] * id[kk];
+      lli -= log(d[kk]) + s * s * id[kk];
+    }
+    if (in.upd) ll += lli;
+    double W[NSC][3];
+#pragma unroll
+    for (int i = 0; i < NSC; i++)
+#pragma unroll
+      for (int kk = 0; kk < 3; kk++) {
+        double s = Pc[pk(i, kk)];
+#pragma unroll
+        for (int j = 0; j < kk; j++) s -= W[i][j] * S[pk(kk, j)];
+        W[i][kk] = s;
+      }
+    // hand-off to role P
+    xw(0, S[pk(1, 0)]); xw(1, S[pk(2, 0)]); xw(2, S[pk(2, 1)]);
+#pragma unroll
+    for (int kk = 0; kk < 3; kk++) { xw(3 + kk, id[kk]); xw(6 + kk, yd[kk]); }
+#pragma unroll
+    for (int i = 0; i < NSC; i++)
+#pragma unroll
+      for (int kk = 0; kk < 3; kk++) xw(9 + 3 * i + kk, W[i][kk]);
+    sync();
+    // downdate + store own entries, dx for own states
+    double dfull[NS];
+#pragma unroll
+    for (int i = 0; i < NS; i++) dfull[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < NSC; i++) {
+      double wd[3];
+#pragma unroll
+      for (int kk = 0; kk < 3; kk++) wd[kk] = W[i][kk] * id[kk];
+      dfull[C::fullc(i)] = fma(W[i][2], yd[2], fma(W[i][1], yd[1], W[i][0] * yd[0]));
+#pragma unroll
+      for (int j = 0; j <= i; j++) {
+        double acc = Pc[pk(i, j)];
+#pragma unroll
+        for (int kk = 0; kk < 3; kk++) acc = fma(-wd[kk], W[j][kk], acc);
+        st(L::OFF_P + pk(C::fullc(i), C::fullc(j)), acc);
+      }
+    }
+    if (in.upd) add_delta<NS>(x, q, dfull, k.chi_tol);
+  } else {
+#pragma unroll
+    for (int i = 0; i < NSC; i++)
+#pragma unroll
+      for (int j = 0; j <= i; j++) st(L::OFF_P + pk(C::fullc(i), C::fullc(j)), Pc[pk(i, j)]);
+    // role P reads the PRIOR x and quat: it must have consumed them before they are overwritten below (in the
+    // UPDATE flavour the hand-off barrier above already orders this)
+    sync();
+  }
+#pragma unroll
+  for (int i = 0; i < NSC; i++) st(L::OFF_VEC + C::fullc(i), x[C::fullc(i)]);
+#pragma unroll
+  for (int i = 0; i < 4; i++) st(L::OFF_QUAT + i, q[i]);
+  st(L::OFF_LL, ll);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// role P: passive panels P_cp, P_bp, P_pp and the omega / accel entries of x.   XR(slot) reads the hand-off.
+// ------------------------------------------------------------------------------------------------------------
+template <int NS, bool UPDATE, class LD, class ST, class XR, class SYNC>
+PB_HD void coop_role_passive(LD ld, ST st, XR xr, SYNC sync, const StepInputs &in, const Consts &k)
+{
+  using L = Lay<NS>;
+  using C = Coop<NS>;
+  double x[NS], q[4];
+#pragma unroll
+  for (int i = 0; i < NS; i++) x[i] = ld(L::OFF_VEC + i);
+#pragma unroll
+  for (int i = 0; i < 4; i++) q[i] = ld(L::OFF_QUAT + i);
+  // X[sb][J] = 3x3 block P(state block sb, passive block J), row-major; sb: v chi Delta [bg ba]; J: omega, accel
+  constexpr int NSB = C::HB ? 5 : 3;
+  double X[NSB][2][9];
+#pragma unroll
+  for (int sb = 0; sb < NSB; sb++)
+#pragma unroll
+    for (int J = 0; J < 2; J++)
+#pragma unroll
+      for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) X[sb][J][3 * r + c] = ld(L::OFF_P + pk(C::fullc(3 * sb + r), C::fullp(3 * J + c)));
+  double Ppp[21];
+#pragma unroll
+  for (int i = 0; i < 6; i++)
+#pragma unroll
+    for (int j = 0; j <= i; j++) Ppp[pk(i, j)] = ld(L::OFF_P + pk(C::fullp(i), C::fullp(j)));
+
+  ProcBlocks f;
+  make_proc_blocks<NS>(x, q, in.dt, k, f);
+  // panel propagate: all right-hand sides use the ORIGINAL blocks (Ad = E2 E1 E3)
+#pragma unroll
+  for (int J = 0; J < 2; J++) {
+    double nD[9], nV[9], nC[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) { nD[i] = X[2][J][i]; nV[i] = X[0][J][i]; nC[i] = X[1][J][i]; }
+    mat_mul_acc(f.A_R, X[0][J], nD);
+    mat_mul_acc(f.A_RV, X[1][J], nD);
+    hat_mul_acc(f.a_mw, X[0][J], nV);
+    hat_mul_acc(f.a_g, X[1][J], nV);
+    hat_mul_acc(f.a_mw, X[1][J], nC);
+    if constexpr (C::HB) {
+      hat_mul_acc(f.a_mv, X[3][J], nV);
+#pragma unroll
+      for (int i = 0; i < 9; i++) {
+        nV[i] -= in.dt * X[4][J][i];
+        nC[i] -= in.dt * X[3][J][i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 9; i++) { X[2][J][i] = nD[i]; X[0][J][i] = nV[i]; X[1][J][i] = nC[i]; }
+  }
+  // rbis.cpp:120-121: overwrite the omega and accel diagonal blocks (the [accel,omega] block is untouched)
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+#pragma unroll
+    for (int c = 0; c <= r; c++) {
+      Ppp[pk(r, c)] = (r == c) ? in.qg : 0.0;
+      Ppp[pk(3 + r, 3 + c)] = (r == c) ? in.qa : 0.0;
+    }
+  // rbis.cpp:50-51
+  double xp[6];
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    xp[i] = in.gyro[i] - (C::HB ? x[15 + i] : 0.0);
+    xp[3 + i] = in.accel[i] - (C::HB ? x[18 + i] : 0.0);
+  }
+
+  if constexpr (!UPDATE) sync();  // pairs with role C's barrier before it overwrites x / quat
+  if constexpr (UPDATE) {
+    sync();
+    const double L10 = xr(0), L20 = xr(1), L21 = xr(2);
+    double id[3], yd[3];
+#pragma unroll
+    for (int kk = 0; kk < 3; kk++) { id[kk] = xr(3 + kk); yd[kk] = xr(6 + kk); }
+    // W_p = P'[p, v] L^-T : P'(p_i, v_k) = X[v][J][k][c]
+    double Wp[6][3];
+#pragma unroll
+    for (int pi = 0; pi < 6; pi++) {
+      const double c0 = X[0][pi / 3][0 * 3 + pi % 3], c1 = X[0][pi / 3][1 * 3 + pi % 3], c2 = X[0][pi / 3][2 * 3 + pi % 3];
+      Wp[pi][0] = c0;
+      Wp[pi][1] = c1 - Wp[pi][0] * L10;
+      Wp[pi][2] = c2 - Wp[pi][0] * L20 - Wp[pi][1] * L21;
+      xp[pi] += fma(Wp[pi][2], yd[2], fma(Wp[pi][1], yd[1], Wp[pi][0] * yd[0]));
+    }
+    // downdate (c,p) and (b,p) panels with role C's rows of W
+#pragma unroll
+    for (int sb = 0; sb < NSB; sb++)
+#pragma unroll
+      for (int r = 0; r < 3; r++) {
+        double wd[3];
+#pragma unroll
+        for (int kk = 0; kk < 3; kk++) wd[kk] = xr(9 + 3 * (3 * sb + r) + kk) * id[kk];
+#pragma unroll
+        for (int J = 0; J < 2; J++)
+#pragma unroll
+          for (int c = 0; c < 3; c++) {
+            double acc = X[sb][J][3 * r + c];
+#pragma unroll
+            for (int kk = 0; kk < 3; kk++) acc = fma(-wd[kk], Wp[3 * J + c][kk], acc);
+            X[sb][J][3 * r + c] = acc;
+          }
+      }
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+      double wd[3];
+#pragma unroll
+      for (int kk = 0; kk < 3; kk++) wd[kk] = Wp[i][kk] * id[kk];
+#pragma unroll
+      for (int j = 0; j <= i; j++) {
+        double acc = Ppp[pk(i, j)];
+#pragma unroll
+        for (int kk = 0; kk < 3; kk++) acc = fma(-wd[kk], Wp[j][kk], acc);
+        Ppp[pk(i, j)] = acc;
+      }
+    }
+  }
+#pragma unroll
+  for (int sb = 0; sb < NSB; sb++)
+#pragma unroll
+    for (int J = 0; J < 2; J++)
+#pragma unroll
+      for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) st(L::OFF_P + pk(C::fullc(3 * sb + r), C::fullp(3 * J + c)), X[sb][J][3 * r + c]);
+#pragma unroll
+  for (int i = 0; i < 6; i++)
+#pragma unroll
+    for (int j = 0; j <= i; j++) st(L::OFF_P + pk(C::fullp(i), C::fullp(j)), Ppp[pk(i, j)]);
+#pragma unroll
+  for (int i = 0; i < 6; i++) st(L::OFF_VEC + C::fullp(i), xp[i]);
+}
+
+}  // namespace pb

@@ -13,6 +13,7 @@
 #include <stdint.h>
 
 #include "../../include/pronto_batch.h"
+#include "rbis_coop.hpp"
 #include "rbis_device.hpp"
 
 // workgroup size of the hot kernel (one wave per SIMD either way; 64 = one wave per workgroup)
@@ -326,6 +327,49 @@ __global__ void k_summary(const double *__restrict__ st, long stride, int B, dou
   if ((threadIdx.x & 63) == 0) {
     double *o = out + 4L * blockIdx.x;
     o[0] = s_ll; o[1] = s_abs; o[2] = qdev; o[3] = nonfin;
+  }
+}
+
+// Two-wave cooperative step (rbis_coop.hpp): 128-thread workgroups, wave 0 = role C (dynamic core sub-matrix, state,
+// quaternion), wave 1 = role P (passive omega/accel panels) for the SAME 64 filters; one LDS hand-off + one barrier.
+// This is the 21-state hot kernel (231 packed entries do not fit one lane) and an alternative mapping for n = 15.
+// No lane returns before the barrier: lanes past the batch end work on the zero-initialised padding columns of the
+// state array (stride is the batch rounded up to 64) and on bounds-checked (zero) inputs.
+template <int NS, bool UPDATE>
+__global__ __launch_bounds__(128, 1) void k_step_coop(double *__restrict__ st, long stride, int B,
+                                                      const double *__restrict__ imu, const double *__restrict__ lo,
+                                                      const uint8_t *__restrict__ mask, double qg, double qa,
+                                                      double qbg, double qba, Consts k)
+{
+  using L = Lay<NS>;
+  using C = Coop<NS>;
+  __shared__ double xch[UPDATE ? C::NXCH : 1][64];
+  const int role = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
+  const unsigned lane = threadIdx.x & 63u;
+  const unsigned b = blockIdx.x * 64u + lane;
+  const unsigned bo = b * 8u;
+  const unsigned s8 = (unsigned) stride * 8u, B8 = (unsigned) B * 8u;
+  const rsrc_t rs = mkbuf(st, (unsigned) L::NC * s8);
+  const rsrc_t ri = mkbuf(imu, 7u * B8);
+  const rsrc_t rl = mkbuf(lo, UPDATE ? 6u * B8 : 0u);
+  StepInputs in;
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    in.gyro[i] = ldg(ri, i * B8, bo);
+    in.accel[i] = ldg(ri, (3 + i) * B8, bo);
+    in.z[i] = UPDATE ? ldg(rl, i * B8, bo) : 0.0;
+    in.rd[i] = UPDATE ? ldg(rl, (3 + i) * B8, bo) : 1.0;
+  }
+  in.dt = ldg(ri, 6u * B8, bo);
+  in.upd = UPDATE && (b < (unsigned) B) && (mask == nullptr || mask[b] != 0);
+  in.qg = qg; in.qa = qa; in.qbg = qbg; in.qba = qba;
+  auto ld = [rs, s8, bo](int comp) { return ldg(rs, (unsigned) comp * s8, bo); };
+  auto stf = [rs, s8, bo](int comp, double v) { stg(rs, (unsigned) comp * s8, bo, v); };
+  auto sync = []() { __syncthreads(); };
+  if (role == 0) {
+    coop_role_core<NS, UPDATE>(ld, stf, [lane](int s, double v) { xch[s][lane] = v; }, sync, in, k);
+  } else {
+    coop_role_passive<NS, UPDATE>(ld, stf, [lane](int s) { return xch[s][lane]; }, sync, in, k);
   }
 }
 

@@ -1,0 +1,29 @@
+"""PCIe-inclusive rate of the hot step when the boundary hands over HOST buffers (pb_step_legodo, PB_HOST):
+each step stages 104 B/filter over PCIe before the launch.  Reported in DESIGN.md; never bench.py's `value`."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+
+from pronto_amd.batch import BatchEstimator  # noqa: E402
+from pronto_amd.synth import Workload  # noqa: E402
+
+B, T = 65536, 60
+w = Workload(B, n_states=15)
+vec, quat, P0 = w.initial_state()
+imu, lo, mask = w.streams(0, T)
+q4 = w.process_noise()
+est = BatchEstimator(B, n_states=15)
+est.reset(vec, quat, P0)
+for k in range(10):
+    est.step_legodo(imu[k], lo[k], mask[k], q4)
+est.sync()
+t0 = time.perf_counter()
+for k in range(10, T):
+    est.step_legodo(imu[k], lo[k], mask[k], q4)
+est.sync()
+dt = time.perf_counter() - t0
+print("PCIe-inclusive: %d filters x %d steps from pageable host blocks: %.3e steps/s, %.3f ms/step, %.1f GB/s over PCIe"
+      % (B, T - 10, B * (T - 10) / dt, dt / (T - 10) * 1e3, 105 * B * (T - 10) / dt / 1e9))

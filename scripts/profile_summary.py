@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Condense gpurun_out/prof_<tag> (scripts/profile.sh) into the tracked files under profiles/:
+  profiles/<tag>_kernel_stats.csv, <tag>_kernel_stats_n21.csv   rocprofv3 --kernel-trace --stats summaries (verbatim)
+  profiles/<tag>_pmc.json    FETCH_SIZE / WRITE_SIZE medians per launch, scaled by the calibration copy
+                             (MI355X_MICROARCH.md section HBM: FETCH_SIZE x2 on gfx950; verified here, not assumed)
+  profiles/traffic.json      what bench.py reports as roofline.traffic (keyed "<kernel>@<batch>")
+usage: profile_summary.py <tag>
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import re
+import shutil
+import statistics
+import sys
+
+tag = sys.argv[1]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(root, "gpurun_out", "prof_" + tag)
+out = os.path.join(root, "profiles")
+os.makedirs(out, exist_ok=True)
+
+
+def counters(d):
+    by = collections.defaultdict(list)
+    for f in glob.glob(os.path.join(src, d, "*", "*counter_collection.csv")):
+        for r in csv.DictReader(open(f)):
+            name = re.sub(r"\s+", "", r["Kernel_Name"].split("(")[0].replace("void ", "").replace("pb::", ""))
+            by[(name, r["Counter_Name"])].append(float(r["Counter_Value"]))
+    return by
+
+
+for d, name in (("trace64k", "_kernel_stats.csv"), ("trace64k_n21", "_kernel_stats_n21.csv")):
+    ks = glob.glob(os.path.join(src, d, "*", "*kernel_stats.csv"))
+    if ks:
+        shutil.copy(ks[0], os.path.join(out, tag + name))
+for name in ("trace64k.json", "trace64k_n21.json", "bench1m.json", "calib_plain.txt"):
+    p = os.path.join(src, name)
+    if os.path.exists(p):
+        shutil.copy(p, os.path.join(out, tag + "_" + name))
+
+known = 140 * (1 << 20) * 8
+kf = statistics.median(counters("calib_FETCH_SIZE")[("k_calib_copy", "FETCH_SIZE")]) * 1024
+kw = statistics.median(counters("calib_WRITE_SIZE")[("k_calib_copy", "WRITE_SIZE")]) * 1024
+fs, ws = known / kf, known / kw
+res = {"units": "bytes per launch (median over launches)",
+       "calibration": {"kernel": "k_calib_copy (1M filters x 140 components, 8 B/lane buffer loads+stores)",
+                       "known_read_bytes": known, "known_write_bytes": known, "FETCH_SIZE_bytes_raw": kf,
+                       "WRITE_SIZE_bytes_raw": kw, "fetch_scale": fs, "write_scale": ws},
+       "runs": {}}
+traffic = {}
+for run, B, bps in (("pmc64k", 65536, 2344), ("pmc1m", 1 << 20, 2344), ("pmc64k_n21", 65536, 4216)):
+    f, w = counters(run + "_FETCH_SIZE"), counters(run + "_WRITE_SIZE")
+    for (k, c), v in list(f.items()):
+        if not k.startswith("k_step"):
+            continue
+        rd = statistics.median(v) * 1024 * fs
+        wr = statistics.median(w[(k, "WRITE_SIZE")]) * 1024 * ws
+        res["runs"]["%s %s" % (run, k)] = {"batch": B, "hbm_read_bytes": rd, "hbm_write_bytes": wr, "hbm_bytes": rd + wr,
+                                           "algorithmic_bytes": bps * B, "traffic_over_algorithmic": (rd + wr) / (bps * B),
+                                           "launches": len(v)}
+        traffic["%s@%d" % (k, B)] = {"hbm_bytes_per_launch": rd + wr, "read": rd, "write": wr, "source": tag}
+json.dump(res, open(os.path.join(out, tag + "_pmc.json"), "w"), indent=1)
+json.dump(traffic, open(os.path.join(out, "traffic.json"), "w"), indent=1)
+for k, v in res["runs"].items():
+    print("%-40s read %.1f MB write %.1f MB = %.3f x algorithmic" % (k, v["hbm_read_bytes"] / 1e6, v["hbm_write_bytes"] / 1e6, v["traffic_over_algorithmic"]))
+for f in sorted(glob.glob(os.path.join(out, tag + "_kernel_stats*.csv"))):
+    for r in csv.DictReader(open(f)):
+        if "k_step" in r["Name"]:
+            print(os.path.basename(f), r["Name"].split("(")[0], "calls", r["Calls"], "avg_ns", r["AverageNs"])

@@ -103,3 +103,47 @@ void hh_update_posyaw(int ns, double *st, long stride, int B, const double *z, c
   else update_orient<21, 4, IdxPosYaw>(st, stride, B, z, rdiag, qm, g, tol);
 }
 }
+
+// ---- two-wave cooperative step (rbis_coop.hpp): the two roles run back to back on a snapshot of the filter's
+// column, with a plain array standing in for the LDS hand-off; stores are applied after both roles have read. ----
+#include "../pronto_amd/csrc/rbis_coop.hpp"
+
+template <int NS>
+static void step_coop(double *st, long stride, int B, const double *imu, const double *lo, const uint8_t *mask,
+                      const double *q4, double g, double tol, int do_update)
+{
+  Consts k{ g, tol };
+  constexpr int NC = Lay<NS>::NC;
+  for (int b = 0; b < B; b++) {
+    double in_col[NC], out_col[NC], xch[Coop<NS>::NXCH];
+    for (int c = 0; c < NC; c++) in_col[c] = out_col[c] = st[c * stride + b];
+    StepInputs in;
+    for (int i = 0; i < 3; i++) {
+      in.gyro[i] = imu[i * B + b];
+      in.accel[i] = imu[(3 + i) * B + b];
+      in.z[i] = do_update ? lo[i * B + b] : 0.0;
+      in.rd[i] = do_update ? lo[(3 + i) * B + b] : 1.0;
+    }
+    in.dt = imu[6 * B + b];
+    in.upd = do_update && (!mask || mask[b]);
+    in.qg = q4[0]; in.qa = q4[1]; in.qbg = q4[2]; in.qba = q4[3];
+    auto ld = [&](int c) { return in_col[c]; };
+    auto stf = [&](int c, double v) { out_col[c] = v; };
+    auto sync = []() {};
+    if (do_update) {
+      coop_role_core<NS, true>(ld, stf, [&](int s, double v) { xch[s] = v; }, sync, in, k);
+      coop_role_passive<NS, true>(ld, stf, [&](int s) { return xch[s]; }, sync, in, k);
+    } else {
+      coop_role_core<NS, false>(ld, stf, [&](int s, double v) { xch[s] = v; }, sync, in, k);
+      coop_role_passive<NS, false>(ld, stf, [&](int s) { return xch[s]; }, sync, in, k);
+    }
+    for (int c = 0; c < NC; c++) st[c * stride + b] = out_col[c];
+  }
+}
+
+extern "C" void hh_step_coop(int ns, double *st, long stride, int B, const double *imu, const double *lo,
+                             const uint8_t *mask, const double *q4, double g, double tol, int do_update)
+{
+  if (ns == 15) step_coop<15>(st, stride, B, imu, lo, mask, q4, g, tol, do_update);
+  else step_coop<21>(st, stride, B, imu, lo, mask, q4, g, tol, do_update);
+}

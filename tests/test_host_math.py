@@ -77,6 +77,36 @@ def test_structured_math_matches_dense_oracle(oracle, harness, ns):
     assert rel(ll, ob.ll) < 1e-11
 
 
+@pytest.mark.parametrize("ns", [15, 21])
+@pytest.mark.parametrize("upd", [1, 0])
+def test_cooperative_roles_match_oracle(oracle, harness, ns, upd):
+    """rbis_coop.hpp: role C (core sub-matrix) + role P (passive panels) with the LDS hand-off replaced by an array."""
+    H = harness
+    g, tol = oracle.constants()
+    B, T = 24, 150
+    w = Workload(B, n_states=ns)
+    vec, quat, P0 = w.initial_state()
+    P0 = P0 + random_spd(ns, B, 0.03, 5)
+    if ns == 21:
+        vec[15:18], vec[18:21] = 0.5 * w.bg, 0.5 * w.ba
+    v21, P21 = embed21(vec, P0)
+    ob = oracle.OracleBatch(v21, quat, P21)
+    st = pack(H, ns, vec, quat, P0, np.zeros(B))
+    q4 = w.process_noise()
+    for k in range(T):
+        imu = w.imu_block(k)
+        lo, mask = w.legodo_block(k)
+        ob.predict(imu, q4)
+        if upd:
+            ob.update_indexed([3, 4, 5], lo[0:3], lo[3:6], mask=mask)
+        H.hh_step_coop(ns, P(st), C.c_long(B), B, P(imu), P(lo), mask.ctypes.data_as(C.c_void_p), P(q4),
+                       C.c_double(g), C.c_double(tol), upd)
+    v, q, cov, ll = unpack(H, ns, st)
+    assert rel(v, ob.vec[:ns]) < 1e-11 and rel(q, ob.quat) < 1e-11 and rel(cov, ob.cov[:ns, :ns]) < 1e-11
+    if upd:
+        assert rel(ll, ob.ll) < 1e-11
+
+
 def test_predict_only_and_masked_lanes(oracle, harness):
     H = harness
     g, tol = oracle.constants()
