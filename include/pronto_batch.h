@@ -131,6 +131,18 @@ int pb_snapshot(pb_ctx *ctx, int slot);
 int pb_compose_delta(pb_ctx *ctx, int slot, const double *t, const double *q, double *z_out, double *quat_out,
                      int mem);
 
+/* ---- posterior checkpoints for roll-forward replay (mav_state_est.cpp:28-80, update_history.cpp) ------------ */
+
+/* The reference keeps every update's posterior (RBIS + RBIM, 3.7 KB) in a multimap so that a delayed measurement can
+ * be inserted at its timestamp and everything after it re-applied.  Here the posterior of the WHOLE batch after a
+ * chosen update is saved device-to-device into one of n_slots checkpoint slots (each = the full state array:
+ * 73 MB for 64k 15-state filters -- sized for 288 GB of HBM); the time-ordered bookkeeping and the replay loop live
+ * on the host (MavStateEstimator in mav_state_est_batch.hpp).  pb_history_reserve may be called again to resize
+ * (contents are lost). */
+int pb_history_reserve(pb_ctx *ctx, int n_slots);
+int pb_state_save(pb_ctx *ctx, int slot);      /* slot <- head posterior (state, cov, loglik) */
+int pb_state_restore(pb_ctx *ctx, int slot);   /* head posterior <- slot */
+
 /* ---- estimator queries (mav_state_est.hpp:20-22) -------------------------------------------------------- */
 
 /* MavStateEstimator::getHeadState + getMeasurementsLogLikelihood for filters [first, first+count):

@@ -255,8 +255,29 @@ public:
 };
 
 // ---------------------------------------------------------------------------------------------------------------
-// MavStateEstimator (mav_state_est.hpp / .cpp): in-order path.  Out-of-order replay is SURVEY.md 8f rank 1.
+// updateHistory + MavStateEstimator (update_history.hpp:12-36, mav_state_est.hpp / .cpp:12-96)
+//
+// The reference stores every update's posterior inside the update object; a delayed measurement is inserted at
+// its timestamp and everything from there on is re-applied (mav_state_est.cpp:28-80).  Here the posterior of the
+// whole batch lives on the device, so the history keeps, per update, an optional CHECKPOINT slot
+// (pb_state_save) instead; a replay restores the newest checkpoint at or before the insertion point and re-applies
+// the updates after it.  checkpoint_every = 1 is the reference's "posterior per update"; larger values trade HBM
+// (73 MB per slot for 64k 15-state filters) for longer replays.  With history_slots = 0 the estimator is in-order
+// only: an update older than the head is discarded like one older than the history (update_history.cpp:28-39).
+// Updates in the history own their host payloads; device payloads they point to must outlive the window.
 // ---------------------------------------------------------------------------------------------------------------
+class updateHistory {
+public:
+  typedef std::multimap<int64_t, RBISUpdateInterface *> historyMap;
+  typedef historyMap::iterator historyMapIterator;
+  typedef std::pair<int64_t, RBISUpdateInterface *> historyPair;
+  historyMap updateMap;
+  ~updateHistory()
+  {
+    for (auto &kv : updateMap) delete kv.second;  // update_history.cpp:9-14
+  }
+};
+
 class MavStateEstimator {
 public:
   int64_t utime_history_span;
@@ -264,28 +285,43 @@ public:
   int n = 0, B = 0;
   int64_t head_utime = 0;
   int last_status = PB_OK;
-  std::vector<RBISUpdateInterface *> unprocessed;  // added with roll_forward == false (mav_state_est.cpp:39-42)
+  updateHistory history;
+  updateHistory::historyMapIterator unprocessed_updates_start;
+  // checkpoint bookkeeping (this build's addition; keys state_estimator.history_slots / history_checkpoint_every)
+  int history_slots = 0, checkpoint_every = 1, since_checkpoint = 0;
+  std::map<RBISUpdateInterface *, int> checkpoint_of;
+  std::vector<int> free_slots;
+  RBISUpdateInterface *device_head = nullptr;  // the update whose posterior the device currently holds
+  int64_t replayed_updates = 0;                // statistics: updates re-applied because of late arrivals
 
   MavStateEstimator(RBISResetUpdate *init_state, BotParam *param, int device = 0, int n_snapshots = 2)
   {
     utime_history_span = bot_param_get_int_or_fail(param, "state_estimator.utime_history_span");
+    auto opt = [&](const char *k, int dflt) {
+      auto it = param->kv.find(k);
+      return it == param->kv.end() ? dflt : atoi(it->second.c_str());
+    };
+    history_slots = opt("state_estimator.history_slots", 0);
+    checkpoint_every = opt("state_estimator.history_checkpoint_every", 1);
+    if (checkpoint_every < 1) checkpoint_every = 1;
     n = init_state->reset_state.n;
     B = init_state->reset_state.B;
     int rc = pb_create(&ctx, n, B, device, n_snapshots);
+    if (rc == PB_OK && history_slots > 0) rc = pb_history_reserve(ctx, history_slots);
     if (rc != PB_OK) {
-      fprintf(stderr, "MavStateEstimator: %s\n", pb_last_error(nullptr));
+      fprintf(stderr, "MavStateEstimator: %s\n", pb_last_error(rc == PB_OK ? nullptr : ctx));
       exit(1);  // the reference's constructor cannot fail softly either (bot_param_get_int_or_fail)
     }
+    for (int i = history_slots - 1; i >= 0; i--) free_slots.push_back(i);
     last_status = init_state->updateFilter(ctx);  // "apply update from zero... should reset the state" (:16)
     head_utime = init_state->utime;
     pb_set_utime(ctx, head_utime);
-    delete init_state;  // the history owned it (update_history.cpp:5-13)
+    history.updateMap.insert(updateHistory::historyPair(init_state->utime, init_state));  // update_history.cpp:5-8
+    device_head = init_state;
+    if (history_slots > 0) save_checkpoint(init_state);
+    unprocessed_updates_start = history.updateMap.end();
   }
-  ~MavStateEstimator()
-  {
-    for (auto *u : unprocessed) delete u;
-    pb_destroy(ctx);
-  }
+  ~MavStateEstimator() { pb_destroy(ctx); }
   MavStateEstimator(const MavStateEstimator &) = delete;
   MavStateEstimator &operator=(const MavStateEstimator &) = delete;
 
@@ -293,30 +329,54 @@ public:
   void addUpdate(RBISUpdateInterface *update, bool roll_forward)
   {
     if (update == nullptr) return;
-    if (update->utime < head_utime) {
-      // update_history.cpp:28-39: an update older than the (here: one-element) history is discarded
-      fprintf(stderr, "error: update type %s had timestamp %jd, which was before the head (%jd)\ndiscarding update!\n",
-              RBISUpdateInterface::sensor_enum_string(update->sensor_id), (intmax_t) update->utime, (intmax_t) head_utime);
+    auto &map = history.updateMap;
+    // update_history.cpp:16-42: insert by time (equal keys keep arrival order); too old -> discard
+    const int64_t oldest = (history_slots > 0) ? map.begin()->first : head_utime;
+    if (update->utime < oldest) {
+      fprintf(stderr, "error: update type %s had timestamp %jd, which was before the first in history (%jd)\ndiscarding update!\n",
+              RBISUpdateInterface::sensor_enum_string(update->sensor_id), (intmax_t) update->utime, (intmax_t) oldest);
       delete update;
       return;
     }
-    // keep the unprocessed queue time-ordered (multimap insert semantics: equal keys keep arrival order)
-    auto it = unprocessed.end();
-    while (it != unprocessed.begin() && (*(it - 1))->utime > update->utime) --it;
-    unprocessed.insert(it, update);
+    auto added_it = map.insert(map.end(), updateHistory::historyPair(update->utime, update));
+    if (unprocessed_updates_start == map.end() || added_it->first < unprocessed_updates_start->first)
+      unprocessed_updates_start = added_it;                                   // mav_state_est.cpp:33-40
     if (!roll_forward) return;
-    for (auto *u : unprocessed) {
+
+    // The prior of the first unprocessed update is the posterior of the update before it (:45-57).  If the device
+    // does not hold that posterior (late arrival), restore the newest checkpoint at or before it and replay.
+    auto prev_it = unprocessed_updates_start;
+    --prev_it;
+    auto current_it = unprocessed_updates_start;
+    if (prev_it->second != device_head) {
+      auto origin = prev_it;
+      while (checkpoint_of.find(origin->second) == checkpoint_of.end()) --origin;  // begin() always has one
+      last_status = pb_state_restore(ctx, checkpoint_of[origin->second]);
+      current_it = origin;
+      ++current_it;
+      for (auto it = current_it; it != unprocessed_updates_start; ++it) replayed_updates++;
+      for (auto it = unprocessed_updates_start; it != map.end(); ++it)
+        if (it != added_it) replayed_updates++;
+      // checkpoints after the insertion point are stale now
+      for (auto it = current_it; it != map.end(); ++it) drop_checkpoint(it->second);
+      since_checkpoint = 0;
+    }
+    while (current_it != map.end()) {
+      RBISUpdateInterface *u = current_it->second;
       int rc = u->updateFilter(ctx);
       if (rc != PB_OK) {
         last_status = rc;
         fprintf(stderr, "MavStateEstimator::addUpdate: %s update failed: %s\n",
                 RBISUpdateInterface::sensor_enum_string(u->sensor_id), pb_last_error(ctx));
       }
+      device_head = u;
       head_utime = u->utime;  // posterior_state.utime = update->utime (:60)
-      delete u;
+      if (history_slots > 0 && ++since_checkpoint >= checkpoint_every) save_checkpoint(u);
+      ++current_it;
     }
-    unprocessed.clear();
     pb_set_utime(ctx, head_utime);
+    clearHistoryBeforeUtime(head_utime - utime_history_span);                 // :72-77
+    unprocessed_updates_start = map.end();
   }
 
   void getHeadState(RBIS &head_state, RBIM &head_cov)
@@ -331,6 +391,59 @@ public:
     std::vector<double> ll(B);
     last_status = pb_get_head(ctx, 0, B, nullptr, nullptr, nullptr, ll.data(), PB_HOST);
     return ll;
+  }
+
+private:
+  void drop_checkpoint(RBISUpdateInterface *u)
+  {
+    auto it = checkpoint_of.find(u);
+    if (it != checkpoint_of.end()) {
+      free_slots.push_back(it->second);
+      checkpoint_of.erase(it);
+    }
+  }
+  void save_checkpoint(RBISUpdateInterface *u)
+  {
+    if (free_slots.empty()) {
+      // pool exhausted: the window shrinks to what the pool covers -- drop everything before the second-oldest
+      // checkpoint (begin() must keep one: it is the prior of the oldest replayable update)
+      auto &map = history.updateMap;
+      auto it = map.begin();
+      ++it;
+      while (it != map.end() && checkpoint_of.find(it->second) == checkpoint_of.end()) ++it;
+      if (it == map.end() || it->second == u) return;  // nothing to recycle: skip this checkpoint
+      erase_before(it);
+    }
+    const int slot = free_slots.back();
+    free_slots.pop_back();
+    int rc = pb_state_save(ctx, slot);
+    if (rc != PB_OK) last_status = rc;
+    checkpoint_of[u] = slot;
+    since_checkpoint = 0;
+  }
+  void erase_before(updateHistory::historyMapIterator keep)
+  {
+    auto &map = history.updateMap;
+    for (auto it = map.begin(); it != keep; ++it) {
+      drop_checkpoint(it->second);
+      delete it->second;
+    }
+    map.erase(map.begin(), keep);
+  }
+  // update_history.cpp:44-55, with the extra rule that the new first element must hold a checkpoint
+  void clearHistoryBeforeUtime(int64_t utime)
+  {
+    auto &map = history.updateMap;
+    if (history_slots == 0) {  // in-order only: keep just the head
+      auto last = map.end();
+      --last;
+      erase_before(last);
+      return;
+    }
+    auto keep = map.begin();
+    for (auto it = map.begin(); it != map.end() && it->first <= utime; ++it)
+      if (checkpoint_of.find(it->second) != checkpoint_of.end()) keep = it;
+    if (keep != map.begin()) erase_before(keep);
   }
 };
 

@@ -25,6 +25,8 @@ struct pb_ctx {
   long stride = 0;
   hipStream_t stream = nullptr, own_stream = nullptr;
   double *st = nullptr, *snaps = nullptr, *d_small = nullptr;
+  double *hist = nullptr;  // posterior checkpoint slots (pb_history_reserve)
+  int nhist = 0;
   void *stage = nullptr;
   size_t stage_bytes = 0;
   Consts k{ 9.80665, 1e-6 };
@@ -129,6 +131,7 @@ extern "C" int pb_destroy(pb_ctx *c)
   if (c->stream) (void) hipStreamSynchronize(c->stream);
   if (c->st) (void) hipFree(c->st);
   if (c->snaps) (void) hipFree(c->snaps);
+  if (c->hist) (void) hipFree(c->hist);
   if (c->d_small) (void) hipFree(c->d_small);
   if (c->stage) (void) hipFree(c->stage);
   if (c->ev0) (void) hipEventDestroy(c->ev0);
@@ -537,6 +540,36 @@ extern "C" int pb_summary(pb_ctx *c, double out[4])
   free(h);
   return PB_OK;
 }
+
+extern "C" int pb_history_reserve(pb_ctx *c, int n_slots)
+{
+  ENTER(c);
+  if (n_slots < 0) return fail(c, PB_ERR_ARG, "pb_history_reserve: n_slots < 0");
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (c->hist) HIPCHK(c, hipFree(c->hist));
+  c->hist = nullptr;
+  c->nhist = 0;
+  if (n_slots == 0) return PB_OK;
+  const size_t bytes = sizeof(double) * (size_t) c->nc * c->stride;
+  hipError_t e = hipMalloc((void **) &c->hist, bytes * n_slots);
+  if (e != hipSuccess)
+    return fail(c, PB_ERR_HIP, "pb_history_reserve: %d slots x %zu bytes: %s", n_slots, bytes, hipGetErrorString(e));
+  c->nhist = n_slots;
+  return PB_OK;
+}
+
+static int hist_copy(pb_ctx *c, int slot, bool save)
+{
+  ENTER(c);
+  NEED_STATE(c);
+  if (slot < 0 || slot >= c->nhist) return fail(c, PB_ERR_STATE, "checkpoint slot %d of %d", slot, c->nhist);
+  const size_t n = (size_t) c->nc * c->stride;
+  double *h = c->hist + (size_t) slot * n;
+  HIPCHK(c, hipMemcpyAsync(save ? h : c->st, save ? c->st : h, sizeof(double) * n, hipMemcpyDeviceToDevice, c->stream));
+  return PB_OK;
+}
+extern "C" int pb_state_save(pb_ctx *c, int slot) { return hist_copy(c, slot, true); }
+extern "C" int pb_state_restore(pb_ctx *c, int slot) { return hist_copy(c, slot, false); }
 
 extern "C" int pb_calib_copy(pb_ctx *c, int reps, float *elapsed_ms)
 {

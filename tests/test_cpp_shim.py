@@ -1,5 +1,6 @@
 """The C++ mirror of the reference API (pronto_amd/csrc/mav_state_est_batch.hpp): it compiles and links against the
-C ABI everywhere; on a GPU the miniature se-fusion in tests/cpp/test_shim.cpp must agree with the oracle."""
+C ABI everywhere; on a GPU the miniature se-fusion in tests/cpp/test_shim.cpp and the delayed-measurement replay in
+tests/cpp/test_history.cpp must agree with the oracle."""
 import os
 import subprocess
 
@@ -8,27 +9,28 @@ import pytest
 from pronto_amd import _lib
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-EXE = os.path.join(ROOT, "tests", "build", "test_shim")
 
 
-def build_exe(oracle):
+def build_exe(oracle, name="test_shim"):
     _lib.build()
-    os.makedirs(os.path.dirname(EXE), exist_ok=True)
-    src = os.path.join(ROOT, "tests", "cpp", "test_shim.cpp")
+    exe = os.path.join(ROOT, "tests", "build", name)
+    os.makedirs(os.path.dirname(exe), exist_ok=True)
+    src = os.path.join(ROOT, "tests", "cpp", name + ".cpp")
     deps = [src, os.path.join(ROOT, "pronto_amd", "csrc", "mav_state_est_batch.hpp"),
             os.path.join(ROOT, "include", "pronto_batch.h"), _lib.LIB_PATH]
-    if os.path.exists(EXE) and all(os.path.getmtime(EXE) >= os.path.getmtime(d) for d in deps):
-        return EXE
-    cmd = ["g++", "-O1", "-std=c++17", "-Wall", "-Werror=return-type", "-o", EXE, src,
+    if os.path.exists(exe) and all(os.path.getmtime(exe) >= os.path.getmtime(d) for d in deps):
+        return exe
+    cmd = ["g++", "-O1", "-std=c++17", "-Wall", "-Werror=return-type", "-o", exe, src,
            "-L" + os.path.dirname(_lib.LIB_PATH), "-lpronto_batch", "-L" + os.path.join(ROOT, "oracle", "build"),
            "-lpronto_oracle", "-L/opt/rocm/lib", "-Wl,-rpath," + os.path.dirname(_lib.LIB_PATH),
            "-Wl,-rpath," + os.path.join(ROOT, "oracle", "build"), "-Wl,-rpath,/opt/rocm/lib"]
     subprocess.check_call(cmd)
-    return EXE
+    return exe
 
 
-def test_shim_compiles_and_links(oracle):
-    exe = build_exe(oracle)
+@pytest.mark.parametrize("name", ["test_shim", "test_history"])
+def test_shim_compiles_and_links(oracle, name):
+    exe = build_exe(oracle, name)
     out = subprocess.run(["ldd", exe], capture_output=True, text=True).stdout
     assert "libpronto_batch.so" in out and "not found" not in out.split("libpronto_batch.so")[1].split("\n")[0]
 
@@ -41,3 +43,16 @@ def test_shim_matches_oracle_on_gpu(oracle, n):
     print(r.stdout, r.stderr)
     assert r.returncode == 0 and "PASS" in r.stdout, r.stdout + r.stderr
     assert "discarding update" in r.stderr  # the late update was rejected like update_history.cpp:28-39
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("checkpoint_every,delay", [(1, 0), (1, 7), (4, 13)])
+def test_delayed_measurements_replay_equals_in_order(oracle, checkpoint_every, delay):
+    """measurements arriving `delay` steps late are inserted at their timestamp and everything
+    after them is re-applied from the nearest posterior checkpoint (mav_state_est.cpp:28-80); the head must equal an
+    in-order pass (the oracle).  Dense and sparse checkpointing agree."""
+    exe = build_exe(oracle, "test_history")
+    r = subprocess.run([exe, str(checkpoint_every), str(delay)], capture_output=True, text=True, timeout=300)
+    print(r.stdout, r.stderr)
+    assert r.returncode == 0 and "PASS" in r.stdout, r.stdout + r.stderr
+    assert "before the first in history" in r.stderr  # the too-old fix was discarded (update_history.cpp:28-39)
