@@ -40,16 +40,17 @@ def cpu_baseline(n, dt_us, target_s, est_cls):
     threads = po.lib().po_max_threads()
     T = 100
 
-    def run(Bs):
+    def run(Bs, nthreads=threads):
         w = Workload(Bs, n_states=n, dt_us=dt_us)
         vec, quat, P0 = w.initial_state()
         v21 = np.zeros((21, Bs)); v21[:n] = vec
         P21 = np.zeros((21, 21, Bs)); P21[:n, :n] = P0
         ob = po.OracleBatch(v21, quat, P21)
         imu, lo, mask = w.streams(0, T)
-        sec = ob.run_legodo(imu, lo, mask, w.process_noise(), nthreads=threads)
+        sec = ob.run_legodo(imu, lo, mask, w.process_noise(), nthreads=nthreads)
         return sec, ob, (w, vec, quat, P0, imu, lo, mask)
 
+    sec1, _, _ = run(256, nthreads=1)  # BASELINE.md section 4 "cpu-dense-1t"
     sec, _, _ = run(4 * threads)  # calibration
     rate = 4 * threads * T / max(sec, 1e-9)
     Bs = int(max(4 * threads, min(262144, rate * target_s / T)))
@@ -57,7 +58,8 @@ def cpu_baseline(n, dt_us, target_s, est_cls):
     sec, ob, (w, vec, quat, P0, imu, lo, mask) = run(Bs)
     out = {"value": Bs * T / sec, "unit": "steps/s", "cores": threads, "kind": "port",
            "sample": "%d filters x %d steps of the same synthetic workload, dense 21-state oracle "
-                     "(oracle/pronto_oracle.c, gcc -O2 -fopenmp), %.1f s" % (Bs, T, sec)}
+                     "(oracle/pronto_oracle.c, gcc -O2 -fopenmp), %.1f s" % (Bs, T, sec),
+           "value_1thread": 256 * T / sec1}
     # parity of the HIP path on the very same sample
     import torch
     est = est_cls(Bs, n_states=n, device=torch.cuda.current_device())

@@ -131,6 +131,17 @@ int pb_snapshot(pb_ctx *ctx, int slot);
 int pb_compose_delta(pb_ctx *ctx, int slot, const double *t, const double *q, double *z_out, double *quat_out,
                      int mem);
 
+/* ---- IMU front end of the Atlas path (InsHandler::doFilter, sensor_handlers.cpp:29-42,154-162) ---------------- */
+
+/* Three cascaded 2nd-order IIR notches (iir_notch.cpp:3-61) at notch_freq * 2^i, i = 0..2, per accelerometer axis and
+ * per filter.  pb_imu_notch_init allocates/zeroes the per-filter filter state and fixes the coefficients
+ * (state_estimator.ins.atlas_filter_freq, fs = 1000 in the reference). */
+int pb_imu_notch_init(pb_ctx *ctx, double notch_freq, double fs);
+/* Filters n_packets consecutive NEW packets (oldest first) accel_packets [n_packets][3][B]; accel_out [3][B] receives
+ * the newest filtered sample (what processMessageAtlas feeds to the process step, sensor_handlers.cpp:191-196).
+ * accel_out must be device memory when mem == PB_DEVICE, host memory when PB_HOST. */
+int pb_imu_notch(pb_ctx *ctx, int n_packets, const double *accel_packets, double *accel_out, int mem);
+
 /* ---- posterior checkpoints for roll-forward replay (mav_state_est.cpp:28-80, update_history.cpp) ------------ */
 
 /* The reference keeps every update's posterior (RBIS + RBIM, 3.7 KB) in a multimap so that a delayed measurement can

@@ -33,6 +33,24 @@ class Rbim(C.Structure):
     _fields_ = [("m", C.c_double * (N * N))]
 
 
+class Notch(C.Structure):
+    _fields_ = [("b", C.c_double * 3), ("a", C.c_double * 3), ("x", C.c_double * 2), ("y", C.c_double * 2)]
+
+
+def notch_cascade_run(acc, notch_freq, fs=1000.0):
+    """Oracle run of InsHandler::doFilter over a packet stream acc [T,3] -> filtered [T,3] (one filter)."""
+    L = lib()
+    filt = (Notch * 9)()
+    L.po_notch_cascade_init(filt, notch_freq, fs)
+    out = np.empty_like(acc)
+    v = (C.c_double * 3)()
+    for t in range(acc.shape[0]):
+        v[0], v[1], v[2] = acc[t]
+        L.po_notch_cascade(filt, v)
+        out[t] = v[0], v[1], v[2]
+    return out
+
+
 class Batch(C.Structure):
     _fields_ = [("B", C.c_int), ("vec", C.c_void_p), ("quat", C.c_void_p), ("cov", C.c_void_p),
                 ("ll", C.c_void_p)]
@@ -80,6 +98,11 @@ def lib():
         L.po_batch_run_legodo.argtypes = [C.POINTER(Batch), C.c_int, dp, dp, C.c_void_p, dp, C.c_int]
         L.po_batch_run_legodo.restype = C.c_double
         L.po_max_threads.restype = C.c_int
+        L.po_notch_cascade_init.argtypes = [C.POINTER(Notch), C.c_double, C.c_double]
+        L.po_notch_cascade.argtypes = [C.POINTER(Notch), dp]
+        L.po_notch_init.argtypes = [C.POINTER(Notch), C.c_double, C.c_double]
+        L.po_notch_process.argtypes = [C.POINTER(Notch), C.c_double]
+        L.po_notch_process.restype = C.c_double
         _lib = L
     return _lib
 

@@ -668,6 +668,51 @@ void po_fovis_compose(const double *pos0, const double *quat0, const double *t, 
 }
 
 /* ------------------------------------------------------------------------------------------- */
+/* IMU front end                                                                               */
+/* ------------------------------------------------------------------------------------------- */
+
+void po_notch_init(po_notch *f, double notch_freq, double fs)
+{
+  /* iir_notch.cpp:3-32 */
+  double Wo = notch_freq / (fs / 2);
+  double BW = Wo;
+  double Ab = fabs(10 * log10(.5));
+  BW = BW * M_PI;
+  Wo = Wo * M_PI;
+  double Gb = pow(10, -Ab / 20.);
+  double beta = (sqrt(1.0 - Gb * Gb) / Gb) * tan(BW / 2.0);
+  double gain = 1 / (1 + beta);
+  f->b[0] = gain * 1.0; f->b[1] = gain * (-2.0 * cos(Wo)); f->b[2] = gain * 1;
+  f->a[0] = 1.0; f->a[1] = -2 * gain * cos(Wo); f->a[2] = 2 * gain - 1;
+  f->x[0] = f->x[1] = f->y[0] = f->y[1] = 0;
+}
+
+double po_notch_process(po_notch *f, double input)
+{
+  /* iir_notch.cpp:34-61: output = [input x0 x1].b - [0 y0 y1].a */
+  double xb = input * f->b[0] + f->x[0] * f->b[1] + f->x[1] * f->b[2];
+  double ya = 0 * f->a[0] + f->y[0] * f->a[1] + f->y[1] * f->a[2];
+  double output = xb - ya;
+  f->x[1] = f->x[0]; f->x[0] = input;
+  f->y[1] = f->y[0]; f->y[0] = output;
+  return output;
+}
+
+void po_notch_cascade_init(po_notch *filt9, double notch_freq, double fs)
+{
+  /* sensor_handlers.cpp:29-42: IIRNotch(notch_freq*pow(2,i), fs), i = 0..2, for x, y, z */
+  for (int ax = 0; ax < 3; ax++)
+    for (int i = 0; i < 3; i++) po_notch_init(&filt9[ax * 3 + i], notch_freq * pow(2, i), fs);
+}
+
+void po_notch_cascade(po_notch *filt9, double *acc3)
+{
+  /* sensor_handlers.cpp:154-162 */
+  for (int i = 0; i < 3; i++)
+    for (int ax = 0; ax < 3; ax++) acc3[ax] = po_notch_process(&filt9[ax * 3 + i], acc3[ax]);
+}
+
+/* ------------------------------------------------------------------------------------------- */
 /* batch drivers                                                                               */
 /* ------------------------------------------------------------------------------------------- */
 

@@ -114,6 +114,18 @@ int po_legodo_create_measurement(int mode, const double *r, const double *pos_t,
 void po_fovis_compose(const double *pos0, const double *quat0, const double *t, const double *q, double *z3,
                       double *q_meas);
 
+/* ---- IMU front end: estimate_tools/src/estimate_tools/iir_notch.cpp:3-61 (2nd-order IIR notch) ---- */
+typedef struct {
+  double b[3], a[3]; /* num, den */
+  double x[2], y[2]; /* carried inputs / outputs */
+} po_notch;
+void po_notch_init(po_notch *f, double notch_freq, double fs);   /* iir_notch.cpp:3-32 */
+double po_notch_process(po_notch *f, double input);              /* iir_notch.cpp:34-61 */
+/* InsHandler::doFilter (sensor_handlers.cpp:154-162): cascade of 3 notches (freq * 2^i) per accelerometer axis.
+ * filt is po_notch[3 axes][3 stages]; acc is filtered in place. */
+void po_notch_cascade_init(po_notch *filt9, double notch_freq, double fs);
+void po_notch_cascade(po_notch *filt9, double *acc3);
+
 /* ---- batch drivers (fixtures + CPU baseline).  All arrays SoA with the filter index fastest. ----
  * State SoA: vec[21][B], quat[4][B], cov[441][B] (col-major index c*21+r), ll[B].
  * IMU block per step: gyro[3][B], accel[3][B], dt[B]  (7*B doubles)

@@ -79,6 +79,16 @@ class BatchEstimator:
     def hot_kernel(self):
         return self._L.pb_hot_kernel(self._h).decode()
 
+    # --- IMU front end ---
+    def imu_notch_init(self, notch_freq, fs=1000.0):
+        self._chk(self._L.pb_imu_notch_init(self._h, notch_freq, fs))
+
+    def imu_notch(self, accel_packets, accel_out):
+        """accel_packets [n_packets,3,B] oldest first -> accel_out [3,B] (newest filtered sample)."""
+        pi, m1 = _ptr(accel_packets)
+        po_, m2 = _ptr(accel_out)
+        self._chk(self._L.pb_imu_notch(self._h, accel_packets.shape[0], pi, po_, _same_mem(m1, m2)))
+
     # --- update objects ---
     def reset(self, vec, quat, cov, broadcast=False):
         """RBISResetUpdate.  vec [n,B], quat [4,B], cov [n,n,B] indexed [row,col,b] (or [n],[4],[n,n] broadcast)."""

@@ -488,7 +488,68 @@ struct gps_data_t {
   const uint8_t *has_lock;     // [B]: gps_lock >= 3
   BatchArray xyz_pos;
 };
+struct kvh_raw_imu_packet_t {  // bot_core::kvh_raw_imu_t
+  int64_t utime, packet_count;
+  const double *delta_rotation, *linear_acceleration;  // [3][B] host arrays
+};
+struct kvh_raw_imu_batch_t {   // bot_core::kvh_raw_imu_batch_t: raw_imu[0] is the NEWEST packet, as on the wire
+  int64_t utime;
+  std::vector<kvh_raw_imu_packet_t> raw_imu;
+};
 }  // namespace msgs
+
+// estimate_tools/src/estimate_tools/imu_stream.hpp:10-37, imu_stream.cpp:62-98: KVH batch messages repeat packets
+// (1 kHz packets in ~333 Hz batches); only packets with a packet_count above the last one seen are new.
+struct IMUPacket {
+  int64_t utime_raw, utime_batch, utime, utime_delta, packet_count;
+  const double *delta_rotation, *linear_acceleration;  // [3][B]
+};
+struct IMUBatch {
+  int64_t utime;
+  std::vector<IMUPacket> packets;      // new packets, [0] oldest ... [end] newest
+  std::vector<IMUPacket> packets_old;  // packets already seen in an earlier message
+};
+class IMUStream {
+public:
+  IMUStream() : last_packet_(-1), last_packet_utime_(0), counter_(0) {}
+  IMUBatch convertFromLCMBatch(const msgs::kvh_raw_imu_batch_t *msg)
+  {
+    if (!msg->raw_imu.empty() && msg->raw_imu[0].packet_count < last_packet_) {
+      fprintf(stdout, "Detected time skip, resetting IMUStream\n");  // imu_stream.cpp:63-68
+      last_packet_ = -1;
+      last_packet_utime_ = 0;
+      counter_ = 0;
+    }
+    IMUBatch batch;
+    batch.utime = msg->utime;
+    for (int i = (int) msg->raw_imu.size() - 1; i >= 0; i--) {  // oldest first (:76)
+      const auto &m = msg->raw_imu[i];
+      IMUPacket raw;
+      raw.utime_raw = m.utime;
+      raw.utime_batch = msg->utime;
+      raw.utime = m.utime;
+      raw.packet_count = m.packet_count;
+      raw.delta_rotation = m.delta_rotation;
+      raw.linear_acceleration = m.linear_acceleration;
+      if (m.packet_count > last_packet_) {
+        raw.utime_delta = m.utime - last_packet_utime_;
+        batch.packets.push_back(raw);
+        last_packet_ = m.packet_count;
+        last_packet_utime_ = m.utime;
+      } else {
+        raw.utime_delta = m.utime - (-m.utime);  // "deliberately obfuscate the delta field" (:87-88)
+        batch.packets_old.push_back(raw);
+      }
+    }
+    counter_++;
+    return batch;
+  }
+  int getNumberBatchSinceReset() const { return counter_; }
+
+private:
+  int64_t last_packet_, last_packet_utime_;
+  int counter_;
+};
 
 // ---------------------------------------------------------------------------------------------------------------
 // handlers
@@ -515,12 +576,47 @@ public:
     gyro_bias_update_online = bot_param_get_boolean_or_fail(_param, "state_estimator.ins.gyro_bias_update_online");
     if (!gyro_bias_update_online) cov_gyro_bias = 0.0;                                                            // :89-91
     if (ins_to_body_) ins_to_body = *ins_to_body_;
-    if (atlas_filter) {
-      fprintf(stderr, "InsHandler: state_estimator.ins.atlas_filter=true (KVH de-dup + notch cascade) is not on this "
-                      "path yet (SURVEY.md 8f rank 3)\n");
-      exit(1);
-    }
+    notch_freq = atlas_filter ? bot_param_get_double_or_fail(_param, "state_estimator.ins.atlas_filter_freq") : 0.0;  // :31
   }
+
+  // Atlas KVH path WITH the front end (sensor_handlers.cpp:173-197): de-duplicate the batch message, run every NEW
+  // packet through the 3-stage notch cascade (on the device: pb_imu_notch), use the newest filtered packet.
+  RBISUpdateInterface *processMessageAtlas(const msgs::kvh_raw_imu_batch_t *msg, MavStateEstimator *est)
+  {
+    const int B = est->B;
+    if (!atlas_filter) {
+      // :199-204: newest packet unfiltered, raw_dt from the two newest packets
+      if (msg->raw_imu.size() < 2) return nullptr;
+      msgs::kvh_raw_imu_t m{ msg->utime, BatchArray(msg->raw_imu[0].delta_rotation, PB_HOST),
+                             BatchArray(msg->raw_imu[0].linear_acceleration, PB_HOST),
+                             (msg->raw_imu[0].utime - msg->raw_imu[1].utime) * 1E-6 };
+      return processMessageAtlasPacket(&m, est);
+    }
+    if (!notch_initialised) {
+      if (pb_imu_notch_init(est->ctx, notch_freq, 1000) != PB_OK) {  // fs = 1000 (:32)
+        fprintf(stderr, "InsHandler: %s\n", pb_last_error(est->ctx));
+        exit(1);
+      }
+      notch_initialised = true;
+    }
+    IMUBatch batch = imu_data_.convertFromLCMBatch(msg);
+    if (batch.packets.empty()) return nullptr;  // :181-187 "happens all the time at 1kHz"
+    const size_t np = batch.packets.size();
+    std::vector<double> acc((size_t) np * 3 * B), filt((size_t) 3 * B);
+    for (size_t p = 0; p < np; p++) memcpy(&acc[p * 3 * B], batch.packets[p].linear_acceleration, sizeof(double) * 3 * B);
+    if (pb_imu_notch(est->ctx, (int) np, acc.data(), filt.data(), PB_HOST) != PB_OK) {
+      fprintf(stderr, "InsHandler: %s\n", pb_last_error(est->ctx));
+      return nullptr;
+    }
+    const IMUPacket &p = batch.packets.back();  // the most recent filtered packet (:191-196)
+    msgs::kvh_raw_imu_t m{ msg->utime, BatchArray(p.delta_rotation, PB_HOST), BatchArray(filt.data(), PB_HOST),
+                           p.utime_delta * 1E-6 };
+    return processMessageAtlasPacket(&m, est);
+  }
+
+  double notch_freq = 0.0;
+  bool notch_initialised = false;
+  IMUStream imu_data_;
 
   // Microstrain path (sensor_handlers.cpp:96-131): rotate accel and gyro into the body frame, dt = param
   RBISUpdateInterface *processMessage(const msgs::ins_t *msg, MavStateEstimator *est)
@@ -529,7 +625,7 @@ public:
   }
   // Atlas KVH path without the notch (sensor_handlers.cpp:199-252): gyro = delta_rotation/raw_dt, accel through the
   // full ins_to_body transform (rotation + translation, :227), dt from message timestamps (:239-249)
-  RBISUpdateInterface *processMessageAtlas(const msgs::kvh_raw_imu_t *msg, MavStateEstimator *est)
+  RBISUpdateInterface *processMessageAtlasPacket(const msgs::kvh_raw_imu_t *msg, MavStateEstimator *est)
   {
     double integration_dt = (prev_utime_atlas == 0) ? dt : (msg->utime - prev_utime_atlas) * 1E-6;
     if (integration_dt > 0.1) fprintf(stdout, "dt was : %f - there is an issue with timestamps\n", integration_dt);

@@ -27,6 +27,9 @@ struct pb_ctx {
   double *st = nullptr, *snaps = nullptr, *d_small = nullptr;
   double *hist = nullptr;  // posterior checkpoint slots (pb_history_reserve)
   int nhist = 0;
+  double *notch = nullptr;  // IMU notch cascade state [36][stride] (pb_imu_notch_init)
+  NotchCoef notch_coef;
+  bool notch_ready = false;
   void *stage = nullptr;
   size_t stage_bytes = 0;
   Consts k{ 9.80665, 1e-6 };
@@ -132,6 +135,7 @@ extern "C" int pb_destroy(pb_ctx *c)
   if (c->st) (void) hipFree(c->st);
   if (c->snaps) (void) hipFree(c->snaps);
   if (c->hist) (void) hipFree(c->hist);
+  if (c->notch) (void) hipFree(c->notch);
   if (c->d_small) (void) hipFree(c->d_small);
   if (c->stage) (void) hipFree(c->stage);
   if (c->ev0) (void) hipEventDestroy(c->ev0);
@@ -538,6 +542,63 @@ extern "C" int pb_summary(pb_ctx *c, double out[4])
     out[3] += h[4 * i + 3];
   }
   free(h);
+  return PB_OK;
+}
+
+extern "C" int pb_imu_notch_init(pb_ctx *c, double notch_freq, double fs)
+{
+  ENTER(c);
+  if (!(notch_freq > 0) || !(fs > 0) || notch_freq * 4 >= fs / 2)
+    return fail(c, PB_ERR_ARG, "pb_imu_notch_init: need 0 < 4*notch_freq < fs/2 (got %g, %g)", notch_freq, fs);
+  if (!c->notch) HIPCHK(c, hipMalloc((void **) &c->notch, sizeof(double) * 36 * c->stride));
+  HIPCHK(c, hipMemsetAsync(c->notch, 0, sizeof(double) * 36 * c->stride, c->stream));
+  for (int i = 0; i < 3; i++) {
+    // IIRNotch::IIRNotch + secondOrderNotch (iir_notch.cpp:3-32), notch_freq * 2^i (sensor_handlers.cpp:33-41)
+    double Wo = (notch_freq * pow(2, i)) / (fs / 2);
+    double BW = Wo;
+    const double Ab = fabs(10 * log10(.5));
+    BW = BW * M_PI;
+    Wo = Wo * M_PI;
+    const double Gb = pow(10, -Ab / 20.);
+    const double beta = (sqrt(1.0 - Gb * Gb) / Gb) * tan(BW / 2.0);
+    const double gain = 1 / (1 + beta);
+    c->notch_coef.b[i][0] = gain * 1.0;
+    c->notch_coef.b[i][1] = gain * (-2.0 * cos(Wo));
+    c->notch_coef.b[i][2] = gain * 1;
+    c->notch_coef.a[i][0] = 1.0;
+    c->notch_coef.a[i][1] = -2 * gain * cos(Wo);
+    c->notch_coef.a[i][2] = 2 * gain - 1;
+  }
+  c->notch_ready = true;
+  return PB_OK;
+}
+
+extern "C" int pb_imu_notch(pb_ctx *c, int n_packets, const double *accel_packets, double *accel_out, int mem)
+{
+  ENTER(c);
+  if (!c->notch_ready) return fail(c, PB_ERR_STATE, "pb_imu_notch before pb_imu_notch_init");
+  if (n_packets < 0 || (n_packets > 0 && (!accel_packets || !accel_out))) return fail(c, PB_ERR_ARG, "pb_imu_notch: bad argument");
+  if (n_packets == 0) return PB_OK;
+  const size_t B = (size_t) c->B;
+  Part p[2] = { { accel_packets, sizeof(double) * 3 * B * n_packets, 0 }, { nullptr, sizeof(double) * 3 * B, 0 } };
+  double *d_out = accel_out;
+  if (mem == PB_HOST) {
+    int rc = stage_reserve(c, (p[0].bytes + 255) / 256 * 256 + p[1].bytes);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->stage, accel_packets, p[0].bytes, hipMemcpyHostToDevice, c->stream));
+    p[0].dev = c->stage;
+    d_out = (double *) ((char *) c->stage + (p[0].bytes + 255) / 256 * 256);
+  } else if (mem == PB_DEVICE) {
+    p[0].dev = accel_packets;
+  } else {
+    return fail(c, PB_ERR_ARG, "mem must be PB_HOST or PB_DEVICE");
+  }
+  k_notch<<<nblk(c->B), 64, 0, c->stream>>>(c->notch, c->stride, c->B, n_packets, (const double *) p[0].dev, d_out, c->notch_coef);
+  LAUNCHCHK(c);
+  if (mem == PB_HOST) {
+    HIPCHK(c, hipMemcpyAsync(accel_out, d_out, sizeof(double) * 3 * B, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
   return PB_OK;
 }
 

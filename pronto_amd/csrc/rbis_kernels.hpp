@@ -373,6 +373,53 @@ __global__ __launch_bounds__(128, 1) void k_step_coop(double *__restrict__ st, l
   }
 }
 
+// IMU front end (InsHandler::doFilter, sensor_handlers.cpp:154-162 + iir_notch.cpp:34-61): cascade of three 2nd-order
+// IIR notches per accelerometer axis, one filter per lane, n_packets consecutive packets per call (a KVH batch message
+// carries ~3 new 1 kHz packets; all are filtered, the newest filtered one feeds the predict).  State per filter:
+// [axis][stage]{x0,x1,y0,y1} = 36 doubles in nst[36][stride].  Bytes: 24 B in per packet + 576 B state per call + 24 B out.
+struct NotchCoef {
+  double b[3][3], a[3][3];  // [stage][tap]
+};
+__global__ void k_notch(double *__restrict__ nst, long stride, int B, int n_packets, const double *__restrict__ acc_in,
+                        double *__restrict__ acc_out, NotchCoef k)
+{
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  double s[3][3][4];
+#pragma unroll
+  for (int ax = 0; ax < 3; ax++)
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+      for (int t = 0; t < 4; t++) s[ax][i][t] = nst[(long) ((ax * 3 + i) * 4 + t) * stride + b];
+  double v[3] = { 0, 0, 0 };
+  for (int p = 0; p < n_packets; p++) {
+#pragma unroll
+    for (int ax = 0; ax < 3; ax++) v[ax] = acc_in[((long) p * 3 + ax) * B + b];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+      for (int ax = 0; ax < 3; ax++) {
+        const double in = v[ax];
+        const double xb = in * k.b[i][0] + s[ax][i][0] * k.b[i][1] + s[ax][i][1] * k.b[i][2];
+        const double ya = s[ax][i][2] * k.a[i][1] + s[ax][i][3] * k.a[i][2];
+        const double out = xb - ya;
+        s[ax][i][1] = s[ax][i][0]; s[ax][i][0] = in;
+        s[ax][i][3] = s[ax][i][2]; s[ax][i][2] = out;
+        v[ax] = out;
+      }
+  }
+#pragma unroll
+  for (int ax = 0; ax < 3; ax++)
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+      for (int t = 0; t < 4; t++) nst[(long) ((ax * 3 + i) * 4 + t) * stride + b] = s[ax][i][t];
+  if (n_packets > 0)
+#pragma unroll
+    for (int ax = 0; ax < 3; ax++) acc_out[(long) ax * B + b] = v[ax];
+}
+
 // Counter calibration: a plain copy with EXACTLY the access pattern of k_step (buffer_load/store_dwordx2, 8 bytes
 // per lane, component-major rows of `stride` doubles), so that rocprofv3's FETCH_SIZE / WRITE_SIZE can be scaled
 // on a known byte count (MI355X_MICROARCH.md section HBM: widths other than 16 B/lane are uncalibrated).

@@ -100,7 +100,8 @@ int main(int argc, char **argv)
         lacc[i * B + b] = 0.5 * nrand() + (i == 2 ? g : 0.0);
       }
     }
-    msgs::kvh_raw_imu_t imu{ utime, BatchArray(drot.data(), PB_HOST), BatchArray(lacc.data(), PB_HOST), 0.001 };
+    // a KVH batch message: newest packet first, then the previous one (raw_dt = their utime difference, :202)
+    msgs::kvh_raw_imu_batch_t imu{ utime, { { utime, k + 1, drot.data(), lacc.data() }, { utime - 1000, k, drot.data(), lacc.data() } } };
     on_ins(&imu);
     {  // oracle: the same handler arithmetic, one filter at a time
       const double dt = (prev_ins_utime == 0) ? 0.001 : (utime - prev_ins_utime) * 1E-6;

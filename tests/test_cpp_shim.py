@@ -28,7 +28,16 @@ def build_exe(oracle, name="test_shim"):
     return exe
 
 
-@pytest.mark.parametrize("name", ["test_shim", "test_history"])
+@pytest.mark.gpu
+def test_atlas_imu_front_end_on_gpu(oracle):
+    """KVH batch de-dup + device notch cascade + process step through InsHandler::processMessageAtlas vs the oracle."""
+    exe = build_exe(oracle, "test_atlas_imu")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    print(r.stdout, r.stderr)
+    assert r.returncode == 0 and "PASS" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("name", ["test_shim", "test_history", "test_atlas_imu"])
 def test_shim_compiles_and_links(oracle, name):
     exe = build_exe(oracle, name)
     out = subprocess.run(["ldd", exe], capture_output=True, text=True).stdout

@@ -391,3 +391,44 @@ def test_torch_stream_interop(pa, oracle):
         ob.update_indexed([3, 4, 5], lo[0:3], lo[3:6], mask=mask)
     torch.cuda.synchronize()
     check(est, ob)
+
+
+@pytest.mark.parametrize("n,vo,sm", [(15, 32, 0), (21, 0, 25)])
+def test_full_size_configs_3_and_5_sampled_parity(pa, oracle, n, vo, sm):
+    """BASELINE configs 3 (n=15, +VO m=6 every 32nd step) and 5 (n=21, +scan-match m=4 every 25th) at the full
+    65 536 filters with device-resident inputs; 192 sampled filters against the oracle, everything finite."""
+    import torch
+    B, T = 65536, 64
+    w = Workload(B, n_states=n)
+    vec, quat, P0 = w.initial_state()
+    q4 = w.process_noise()
+    dev = torch.device("cuda:0")
+    est = pa.BatchEstimator(B, n_states=n)
+    est.set_constants(*oracle.constants())
+    est.reset(vec, quat, P0)
+    sel = np.concatenate([np.arange(0, 64), np.arange(30000, 30064), np.arange(B - 64, B)])
+    v21, P21 = embed21(vec[:, sel], P0[:, :, sel])
+    ob = oracle.OracleBatch(v21, quat[:, sel], P21)
+    up = lambda a, dt=None: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    for k in range(T):
+        imu = w.imu_block(k)
+        lo, mask = w.legodo_block(k)
+        est.step_legodo(up(imu), up(lo), up(mask), q4)
+        ob.predict(np.ascontiguousarray(imu[:, sel]), q4)
+        ob.update_indexed([3, 4, 5], np.ascontiguousarray(lo[0:3, sel]), np.ascontiguousarray(lo[3:6, sel]),
+                          mask=np.ascontiguousarray(mask[sel]))
+        if vo and k % vo == vo - 1:
+            z, qm, Rd = w.vo_block(k)
+            est.update_indexed([9, 10, 11, 6, 7, 8], up(pad_z(z, 6)), up(Rd), quat_meas=up(qm))
+            ob.update_indexed([9, 10, 11, 6, 7, 8], pad_z(z[:, sel], 6), np.ascontiguousarray(Rd[:, sel]),
+                              quat_meas=np.ascontiguousarray(qm[:, sel]))
+        if sm and k % sm == sm - 1:
+            z, qm, Rd = w.scanmatch_block(k)
+            est.update_indexed([9, 10, 11, 8], up(pad_z(z, 4)), up(Rd), quat_meas=up(qm))
+            ob.update_indexed([9, 10, 11, 8], pad_z(z[:, sel], 4), np.ascontiguousarray(Rd[:, sel]),
+                              quat_meas=np.ascontiguousarray(qm[:, sel]))
+    s = est.summary()
+    assert s[3] == 0 and s[2] < 1e-12
+    v, q, P, ll = est.get_head()
+    assert rel(v[:, sel], ob.vec[:n]) < TOL and rel(q[:, sel], ob.quat) < TOL
+    assert rel(P[:, :, sel], ob.cov[:n, :n]) < TOL and rel(ll[sel], ob.ll) < TOL
