@@ -131,6 +131,19 @@ int pb_snapshot(pb_ctx *ctx, int slot);
 int pb_compose_delta(pb_ctx *ctx, int slot, const double *t, const double *q, double *z_out, double *quat_out,
                      int mem);
 
+/* ---- noise identification / parameter sweeps (state-estimator/src/noise_id/noise_id.cpp:9-65) ------------------ */
+
+/* Per-filter process noise: q_block [4][B] (device memory) = q_gyro, q_accel, q_gyro_bias, q_accel_bias of every
+ * filter, used by all following pb_predict / pb_step_legodo / pb_run_legodo calls instead of their scalar q; NULL
+ * switches back.  This is what lets ONE batch carry the windows x candidate-noise grid of a noise-ID run
+ * (sampleProcessForward, noise_id.cpp:9-42: by linearity rolled_cov - start_window_cov is the predict chain from P = 0). */
+int pb_set_process_noise_block(pb_ctx *ctx, const double *q_block_dev);
+/* Window likelihood pieces (noise_id.cpp:37-38,44-65): e = head (-) truth with chi = Log(truth.quat^-1 * quat); over
+ * the m <= 9 active indices: out3 [3][B] = log det P_aa, e_a^T P_aa^-1 e_a, -0.5*(m log 2pi + logdet + maha).
+ * truth_vec [n][B], truth_quat [4][B]; err_out [n][B] or NULL. */
+int pb_window_nll(pb_ctx *ctx, int m, const int *idx, const double *truth_vec, const double *truth_quat, double *out3,
+                  double *err_out, int mem);
+
 /* ---- IMU front end of the Atlas path (InsHandler::doFilter, sensor_handlers.cpp:29-42,154-162) ---------------- */
 
 /* Three cascaded 2nd-order IIR notches (iir_notch.cpp:3-61) at notch_freq * 2^i, i = 0..2, per accelerometer axis and

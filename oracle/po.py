@@ -51,6 +51,25 @@ def notch_cascade_run(acc, notch_freq, fs=1000.0):
     return out
 
 
+def noise_id_window(truth_vec, truth_quat, start_cov, dt, q_gyro, q_accel, idx):
+    """Oracle sampleProcessForward + likelihood pieces for ONE window (noise_id.cpp:19-40,52-58).
+    truth_vec [N+1,21], truth_quat [N+1,4], start_cov [21,21] -> (err [21], cov [21,21], logdet, maha, loglike)."""
+    L = lib()
+    N1 = truth_vec.shape[0]
+    tr = (Rbis * N1)()
+    for k in range(N1):
+        tr[k].vec[:] = list(truth_vec[k])
+        tr[k].quat[:] = list(truth_quat[k])
+    sc = Rbim()
+    sc.m[:] = list(np.ascontiguousarray(start_cov.T).ravel())
+    err, cov = Rbis(), Rbim()
+    L.po_noise_id_window(N1 - 1, tr, C.byref(sc), dt, q_gyro, q_accel, C.byref(err), C.byref(cov))
+    ia = (C.c_int * len(idx))(*idx)
+    ld, mh = C.c_double(), C.c_double()
+    ll = L.po_loglike_pieces(len(idx), ia, C.byref(err), C.byref(cov), C.byref(ld), C.byref(mh))
+    return np.array(err.vec[:]), np.array(cov.m[:]).reshape(21, 21).T, ld.value, mh.value, ll
+
+
 class Batch(C.Structure):
     _fields_ = [("B", C.c_int), ("vec", C.c_void_p), ("quat", C.c_void_p), ("cov", C.c_void_p),
                 ("ll", C.c_void_p)]
@@ -98,6 +117,10 @@ def lib():
         L.po_batch_run_legodo.argtypes = [C.POINTER(Batch), C.c_int, dp, dp, C.c_void_p, dp, C.c_int]
         L.po_batch_run_legodo.restype = C.c_double
         L.po_max_threads.restype = C.c_int
+        L.po_noise_id_window.argtypes = [C.c_int, C.POINTER(Rbis), C.POINTER(Rbim), C.c_double, C.c_double, C.c_double,
+                                         C.POINTER(Rbis), C.POINTER(Rbim)]
+        L.po_loglike_pieces.argtypes = [C.c_int, ip, C.POINTER(Rbis), C.POINTER(Rbim), dp, dp]
+        L.po_loglike_pieces.restype = C.c_double
         L.po_notch_cascade_init.argtypes = [C.POINTER(Notch), C.c_double, C.c_double]
         L.po_notch_cascade.argtypes = [C.POINTER(Notch), dp]
         L.po_notch_init.argtypes = [C.POINTER(Notch), C.c_double, C.c_double]

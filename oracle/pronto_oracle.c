@@ -713,6 +713,53 @@ void po_notch_cascade(po_notch *filt9, double *acc3)
 }
 
 /* ------------------------------------------------------------------------------------------- */
+/* noise identification                                                                        */
+/* ------------------------------------------------------------------------------------------- */
+
+void po_noise_id_window(int Nw, const po_rbis *truth, const po_rbim *start_cov, double dt, double q_gyro, double q_accel,
+                        po_rbis *err_out, po_rbim *cov_out)
+{
+  /* noise_id.cpp:19-40 */
+  po_rbis rolled = truth[0];
+  po_rbim start_window_cov = *start_cov, rolled_cov = *start_cov;
+  for (int ii = 0; ii < Nw; ii++) {
+    po_ins_update_covariance(q_gyro, q_accel, 0, 0, &rolled, &rolled_cov, dt);      /* :24 */
+    po_ins_update_covariance(0, 0, 0, 0, &rolled, &start_window_cov, dt);           /* :25 */
+    po_ins_update_state(truth[ii].vec + PO_ANGVEL, truth[ii].vec + PO_ACC, dt, &rolled); /* :26 */
+  }
+  /* rolled_state.subtractState(truth[N]); quatToChi()  (:37-38) */
+  double qi[4], qr[4], chi[3];
+  const double ident[4] = { 1, 0, 0, 0 };
+  for (int i = 0; i < N; i++) rolled.vec[i] -= truth[Nw].vec[i];
+  quat_inverse(truth[Nw].quat, qi);
+  po_quat_mul(qi, rolled.quat, qr);
+  po_subtract_quats(qr, ident, chi);
+  for (int i = 0; i < 3; i++) rolled.vec[PO_CHI + i] = chi[i];
+  rolled.quat[0] = 1; rolled.quat[1] = rolled.quat[2] = rolled.quat[3] = 0;
+  *err_out = rolled;
+  for (int i = 0; i < N * N; i++) cov_out->m[i] = rolled_cov.m[i] - start_window_cov.m[i];  /* :40 */
+}
+
+double po_loglike_pieces(int m, const int *idx, const po_rbis *err, const po_rbim *cov, double *logdet, double *maha)
+{
+  /* noise_id.cpp:52-58: cov_active = cov(idx, idx), error_active = err(idx) */
+  double S[MMAX * MMAX], LD[MMAX * MMAX], e[MMAX], sol[MMAX];
+  int perm[MMAX];
+  for (int c = 0; c < m; c++)
+    for (int r = 0; r < m; r++) S[c * m + r] = cov->m[IDX(idx[r], idx[c])];
+  for (int i = 0; i < m; i++) e[i] = sol[i] = err->vec[idx[i]];
+  memcpy(LD, S, sizeof(double) * m * m);
+  ldlt_factor(m, LD, perm);
+  ldlt_solve(m, LD, perm, sol);
+  double q = 0;
+  for (int i = 0; i < m; i++) q += e[i] * sol[i];
+  const double ld = log(lu_det(m, S));
+  if (logdet) *logdet = ld;
+  if (maha) *maha = q;
+  return -0.5 * (m * log(2 * M_PI) + ld + q);
+}
+
+/* ------------------------------------------------------------------------------------------- */
 /* batch drivers                                                                               */
 /* ------------------------------------------------------------------------------------------- */
 

@@ -126,6 +126,16 @@ double po_notch_process(po_notch *f, double input);              /* iir_notch.cp
 void po_notch_cascade_init(po_notch *filt9, double notch_freq, double fs);
 void po_notch_cascade(po_notch *filt9, double *acc3);
 
+/* ---- noise identification: state-estimator/src/noise_id/noise_id.cpp:9-65 ---- */
+/* sampleProcessForward for ONE window of N steps (noise_id.cpp:19-40): truth[0..N] are the logged filter states
+ * (truth[k].vec holds omega and accel, which drive the roll-forward, :26); start_cov = logged covariance at truth[0].
+ * err_out = rolled (-) truth[N] with chi = Log(quat difference) (:37-38); cov_out = rolled_cov - start_window_cov (:40). */
+void po_noise_id_window(int N, const po_rbis *truth, const po_rbim *start_cov, double dt, double q_gyro, double q_accel,
+                        po_rbis *err_out, po_rbim *cov_out);
+/* the pieces of loglike_normalized (eigen_utils [NOT IN TREE]) over the active indices (noise_id.cpp:52-58):
+ * log det cov_active and e^T cov_active^-1 e.  Returns -0.5*(m log 2pi + logdet + maha), the usual convention. */
+double po_loglike_pieces(int m, const int *idx, const po_rbis *err, const po_rbim *cov, double *logdet, double *maha);
+
 /* ---- batch drivers (fixtures + CPU baseline).  All arrays SoA with the filter index fastest. ----
  * State SoA: vec[21][B], quat[4][B], cov[441][B] (col-major index c*21+r), ll[B].
  * IMU block per step: gyro[3][B], accel[3][B], dt[B]  (7*B doubles)

@@ -63,6 +63,9 @@ _SIGS = {
     "pb_run_legodo": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, _dp, C.POINTER(C.c_float)]),
     "pb_snapshot": (C.c_int, [C.c_void_p, C.c_int]),
     "pb_compose_delta": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "pb_set_process_noise_block": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "pb_window_nll": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                C.c_int]),
     "pb_imu_notch_init": (C.c_int, [C.c_void_p, C.c_double, C.c_double]),
     "pb_imu_notch": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
     "pb_history_reserve": (C.c_int, [C.c_void_p, C.c_int]),

@@ -79,6 +79,31 @@ class BatchEstimator:
     def hot_kernel(self):
         return self._L.pb_hot_kernel(self._h).decode()
 
+    # --- noise identification ---
+    def set_process_noise_block(self, q_block):
+        """q_block: torch CUDA tensor [4,B] (kept alive by the caller) or None."""
+        if q_block is None:
+            self._chk(self._L.pb_set_process_noise_block(self._h, None))
+            return
+        p, m = _ptr(q_block)
+        if m != PB_DEVICE:
+            raise ValueError("the process-noise block must be device memory")
+        self._chk(self._L.pb_set_process_noise_block(self._h, p))
+
+    def window_nll(self, idx, truth_vec, truth_quat, want_err=False):
+        """(logdet, maha, nll) [3,B] (+ error vector [n,B]) of head (-) truth over the active indices."""
+        m = len(idx)
+        ia = (C.c_int * m)(*[int(i) for i in idx])
+        out = np.empty((3, self.B))
+        err = np.empty((self.n, self.B)) if want_err else None
+        pv, m1 = _ptr(truth_vec)
+        pq, m2 = _ptr(truth_quat)
+        if _same_mem(m1, m2) != PB_HOST:
+            raise ValueError("window_nll takes host truth arrays")
+        self._chk(self._L.pb_window_nll(self._h, m, ia, pv, pq, C.c_void_p(out.ctypes.data),
+                                        C.c_void_p(err.ctypes.data) if want_err else None, PB_HOST))
+        return (out, err) if want_err else out
+
     # --- IMU front end ---
     def imu_notch_init(self, notch_freq, fs=1000.0):
         self._chk(self._L.pb_imu_notch_init(self._h, notch_freq, fs))

@@ -545,6 +545,69 @@ extern "C" int pb_summary(pb_ctx *c, double out[4])
   return PB_OK;
 }
 
+extern "C" int pb_set_process_noise_block(pb_ctx *c, const double *q_block_dev)
+{
+  if (!c) return PB_ERR_ARG;
+  c->k.qblk = q_block_dev;  // [4][B] device memory, or NULL to go back to the scalar q of each call
+  return PB_OK;
+}
+
+template <int NS>
+static int launch_nll(pb_ctx *c, int m, const int *idx, const double *tv, const double *tq, double *out, double *err)
+{
+#define NLL_CASE(M)                                                                                         \
+  case M: {                                                                                                 \
+    IdxArg<M> ia;                                                                                           \
+    for (int i = 0; i < M; i++) ia.v[i] = idx[i];                                                           \
+    k_window_nll<NS, M><<<nblk(c->B), 64, 0, c->stream>>>(c->st, c->stride, c->B, ia, tv, tq, out, err);    \
+  } break;
+  switch (m) {
+    NLL_CASE(1) NLL_CASE(2) NLL_CASE(3) NLL_CASE(4) NLL_CASE(5) NLL_CASE(6) NLL_CASE(7) NLL_CASE(8) NLL_CASE(9)
+    default: return fail(c, PB_ERR_ARG, "pb_window_nll: m must be 1..9");
+  }
+#undef NLL_CASE
+  LAUNCHCHK(c);
+  return PB_OK;
+}
+
+extern "C" int pb_window_nll(pb_ctx *c, int m, const int *idx, const double *truth_vec, const double *truth_quat,
+                             double *out3, double *err_out, int mem)
+{
+  ENTER(c);
+  NEED_STATE(c);
+  if (m < 1 || m > 9 || !idx || !truth_vec || !truth_quat || !out3) return fail(c, PB_ERR_ARG, "pb_window_nll: bad argument");
+  for (int i = 0; i < m; i++) {
+    if (idx[i] < 0 || idx[i] >= c->ns) return fail(c, PB_ERR_ARG, "pb_window_nll: index %d out of range", idx[i]);
+    for (int j = 0; j < i; j++)
+      if (idx[i] == idx[j]) return fail(c, PB_ERR_ARG, "pb_window_nll: duplicate index %d", idx[i]);
+  }
+  const size_t B = (size_t) c->B, n = (size_t) c->ns;
+  const double *tv = truth_vec, *tq = truth_quat;
+  double *d_out = out3, *d_err = err_out;
+  if (mem == PB_HOST) {
+    const size_t o1 = sizeof(double) * n * B, o2 = o1 + sizeof(double) * 4 * B, o3 = o2 + sizeof(double) * 3 * B;
+    int rc = stage_reserve(c, o3 + sizeof(double) * n * B);
+    if (rc) return rc;
+    char *s = (char *) c->stage;
+    HIPCHK(c, hipMemcpyAsync(s, truth_vec, o1, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(s + o1, truth_quat, sizeof(double) * 4 * B, hipMemcpyHostToDevice, c->stream));
+    tv = (const double *) s;
+    tq = (const double *) (s + o1);
+    d_out = (double *) (s + o2);
+    d_err = err_out ? (double *) (s + o3) : nullptr;
+  } else if (mem != PB_DEVICE) {
+    return fail(c, PB_ERR_ARG, "mem must be PB_HOST or PB_DEVICE");
+  }
+  int rc = (c->ns == 15) ? launch_nll<15>(c, m, idx, tv, tq, d_out, d_err) : launch_nll<21>(c, m, idx, tv, tq, d_out, d_err);
+  if (rc) return rc;
+  if (mem == PB_HOST) {
+    HIPCHK(c, hipMemcpyAsync(out3, d_out, sizeof(double) * 3 * B, hipMemcpyDeviceToHost, c->stream));
+    if (err_out) HIPCHK(c, hipMemcpyAsync(err_out, d_err, sizeof(double) * n * B, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  return PB_OK;
+}
+
 extern "C" int pb_imu_notch_init(pb_ctx *c, double notch_freq, double fs)
 {
   ENTER(c);

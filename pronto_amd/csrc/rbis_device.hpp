@@ -50,6 +50,9 @@ enum { BW = 0, BV = 1, BCHI = 2, BPOS = 3, BACC = 4, BBG = 5, BBA = 6 };
 struct Consts {
   double g;        // |g_vec| (eigen_utils g_val)
   double chi_tol;  // chiToQuat fold tolerance
+  // optional per-filter process noise [4][B] = q_gyro, q_accel, q_gyro_bias, q_accel_bias (device memory); used by
+  // parameter sweeps / noise identification (noise_id.cpp:9-42) where every filter of the batch carries its own q
+  const double *qblk = nullptr;
 };
 
 // ------------------------------------------------------------------------------------------------------------

@@ -86,6 +86,10 @@ __global__ __launch_bounds__(PB_STEP_BLOCK, 1) void k_step(double *__restrict__ 
       rd[i] = ldg(rl, (3 + i) * B8, bo);
     }
   }
+  if (k.qblk != nullptr) {  // per-filter process noise (wave-uniform branch)
+    const rsrc_t rq = mkbuf(k.qblk, 4u * B8);
+    qg = ldg(rq, 0u, bo); qa = ldg(rq, B8, bo); qbg = ldg(rq, 2u * B8, bo); qba = ldg(rq, 3u * B8, bo);
+  }
   imu_process_step<NS>(x, q, P, gyro, accel, dt, qg, qa, qbg, qba, k);
   if constexpr (UPDATE) {
     // Predicated, not branched: lanes whose handler returned NULL (mask 0) run the same stream with D^-1 = 0 and a
@@ -363,6 +367,10 @@ __global__ __launch_bounds__(128, 1) void k_step_coop(double *__restrict__ st, l
   in.dt = ldg(ri, 6u * B8, bo);
   in.upd = UPDATE && (b < (unsigned) B) && (mask == nullptr || mask[b] != 0);
   in.qg = qg; in.qa = qa; in.qbg = qbg; in.qba = qba;
+  if (k.qblk != nullptr) {  // per-filter process noise (wave-uniform branch)
+    const rsrc_t rq = mkbuf(k.qblk, 4u * B8);
+    in.qg = ldg(rq, 0u, bo); in.qa = ldg(rq, B8, bo); in.qbg = ldg(rq, 2u * B8, bo); in.qba = ldg(rq, 3u * B8, bo);
+  }
   auto ld = [rs, s8, bo](int comp) { return ldg(rs, (unsigned) comp * s8, bo); };
   auto stf = [rs, s8, bo](int comp, double v) { stg(rs, (unsigned) comp * s8, bo, v); };
   auto sync = []() { __syncthreads(); };
@@ -371,6 +379,58 @@ __global__ __launch_bounds__(128, 1) void k_step_coop(double *__restrict__ st, l
   } else {
     coop_role_passive<NS, UPDATE>(ld, stf, [lane](int s) { return xch[s][lane]; }, sync, in, k);
   }
+}
+
+// Noise identification (state-estimator/src/noise_id/noise_id.cpp:37-38,44-65): window error e = head (-) truth with
+// chi = Log(truth.quat^-1 * quat), then over the m active indices log det P_aa and e_a^T P_aa^-1 e_a (the two pieces of
+// eigen_utils' loglike_normalized).  out [3][B] = logdet, mahalanobis^2, -0.5*(m log 2pi + logdet + maha).
+// err_out [NS][B] (optional) receives the full error vector.  Runtime index list, gathered like k_update.
+template <int NS, int M>
+__global__ void k_window_nll(const double *__restrict__ st, long stride, int B, IdxArg<M> idx,
+                             const double *__restrict__ tvec, const double *__restrict__ tquat, double *__restrict__ out,
+                             double *__restrict__ err_out)
+{
+  using L = Lay<NS>;
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  double q[4], tq[4], dchi[3];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    q[i] = st[(long) (L::OFF_QUAT + i) * stride + b];
+    tq[i] = tquat[(long) i * B + b];
+  }
+  subtract_quats(q, tq, dchi);
+  if (err_out != nullptr) {
+    for (int i = 0; i < NS; i++) {
+      double e = st[(long) (L::OFF_VEC + i) * stride + b] - tvec[(long) i * B + b];
+      if (i >= 6 && i <= 8) e = dchi[i - 6];
+      err_out[(long) i * B + b] = e;
+    }
+  }
+  double e[M], S[M * (M + 1) / 2], d[M];
+#pragma unroll
+  for (int kk = 0; kk < M; kk++) {
+    const int ii = idx.v[kk];
+    double v = st[(long) (L::OFF_VEC + ii) * stride + b] - tvec[(long) ii * B + b];
+    if (ii >= 6 && ii <= 8) v = (ii == 6) ? dchi[0] : (ii == 7 ? dchi[1] : dchi[2]);
+    e[kk] = v;
+#pragma unroll
+    for (int j = 0; j <= kk; j++) S[pk(kk, j)] = st[(long) (L::OFF_P + pk(ii, idx.v[j])) * stride + b];
+  }
+  ldlt<M>(S, d);
+  double logdet = 0.0, maha = 0.0, y[M];
+#pragma unroll
+  for (int kk = 0; kk < M; kk++) {
+    double s = e[kk];
+#pragma unroll
+    for (int j = 0; j < kk; j++) s -= S[pk(kk, j)] * y[j];
+    y[kk] = s;
+    logdet += log(d[kk]);
+    maha += s * s / d[kk];
+  }
+  out[b] = logdet;
+  out[(long) B + b] = maha;
+  out[2L * B + b] = -0.5 * (M * 1.8378770664093453 + logdet + maha);  // log(2 pi)
 }
 
 // IMU front end (InsHandler::doFilter, sensor_handlers.cpp:154-162 + iir_notch.cpp:34-61): cascade of three 2nd-order
