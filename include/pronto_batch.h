@@ -167,6 +167,13 @@ int pb_history_reserve(pb_ctx *ctx, int n_slots);
 int pb_state_save(pb_ctx *ctx, int slot);      /* slot <- head posterior (state, cov, loglik) */
 int pb_state_restore(pb_ctx *ctx, int slot);   /* head posterior <- slot */
 
+/* ekfSmoothingStep (rbis.cpp:234-266), one backward step of MavStateEstimator::EKFSmoothBackwardsPass
+ * (mav_state_est.cpp:98-189), on checkpoint slots:
+ *   slot_next_pred = posterior of the INS update at k+1 (prediction), slot_next = smoothed (or, for the last step,
+ *   filtered) posterior at k+1, slot_cur = filtered posterior at k; slot_out <- smoothed posterior at k.
+ * slot_out may be slot_cur (in place) but not one of the k+1 slots.  dt as passed to EKFSmoothBackwardsPass. */
+int pb_smooth_step(pb_ctx *ctx, int slot_next_pred, int slot_next, int slot_cur, int slot_out, double dt);
+
 /* ---- estimator queries (mav_state_est.hpp:20-22) -------------------------------------------------------- */
 
 /* MavStateEstimator::getHeadState + getMeasurementsLogLikelihood for filters [first, first+count):

@@ -19,7 +19,8 @@ PB_R_DIAG_BROADCAST, PB_R_DIAG, PB_R_FULL = 0, 1, 2
 
 
 def sources():
-    return [os.path.join(CSRC, f) for f in ("pronto_batch.hip", "rbis_kernels.hpp", "rbis_device.hpp")] + [HEADER]
+    return [os.path.join(CSRC, f) for f in ("pronto_batch.hip", "rbis_kernels.hpp", "rbis_coop.hpp", "rbis_smooth.hpp",
+                                            "rbis_device.hpp")] + [HEADER]
 
 
 def is_stale():
@@ -71,6 +72,7 @@ _SIGS = {
     "pb_history_reserve": (C.c_int, [C.c_void_p, C.c_int]),
     "pb_state_save": (C.c_int, [C.c_void_p, C.c_int]),
     "pb_state_restore": (C.c_int, [C.c_void_p, C.c_int]),
+    "pb_smooth_step": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double]),
     "pb_get_head": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "pb_get_filter_state": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _dp]),
     "pb_summary": (C.c_int, [C.c_void_p, _dp]),

@@ -79,6 +79,19 @@ class BatchEstimator:
     def hot_kernel(self):
         return self._L.pb_hot_kernel(self._h).decode()
 
+    # --- posterior checkpoints, RTS smoother ---
+    def history_reserve(self, n_slots):
+        self._chk(self._L.pb_history_reserve(self._h, n_slots))
+
+    def state_save(self, slot):
+        self._chk(self._L.pb_state_save(self._h, slot))
+
+    def state_restore(self, slot):
+        self._chk(self._L.pb_state_restore(self._h, slot))
+
+    def smooth_step(self, slot_next_pred, slot_next, slot_cur, slot_out, dt):
+        self._chk(self._L.pb_smooth_step(self._h, slot_next_pred, slot_next, slot_cur, slot_out, dt))
+
     # --- noise identification ---
     def set_process_noise_block(self, q_block):
         """q_block: torch CUDA tensor [4,B] (kept alive by the caller) or None."""

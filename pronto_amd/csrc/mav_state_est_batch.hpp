@@ -393,6 +393,59 @@ public:
     return ll;
   }
 
+  // EKFSmoothBackwardsPass (mav_state_est.cpp:98-189): walk the history backwards; at every INS update k apply
+  // ekfSmoothingStep with  next_pred = posterior of INS_{k+1},  next = smoothed posterior of step k+1 (for the newest
+  // step: its last measurement's posterior),  cur = posterior of the last measurement that followed INS_k (or INS_k's
+  // own when none did).  Needs a checkpoint on every update of the window (history_checkpoint_every = 1) and two
+  // spare checkpoint slots.  The reference overwrites the updates' posteriors with the smoothed ones for later
+  // republishing; here on_smoothed(utime of INS_k, slot) is called newest-first with a slot that holds the smoothed
+  // posterior until the next call (pb_state_restore(slot) + getHeadState reads it).  Returns the number of steps.
+  int EKFSmoothBackwardsPass(double dt, const std::function<void(int64_t, int)> &on_smoothed)
+  {
+    auto &map = history.updateMap;
+    if (free_slots.size() < 2) {
+      fprintf(stderr, "EKFSmoothBackwardsPass: needs 2 free checkpoint slots (state_estimator.history_slots)\n");
+      return -1;
+    }
+    const int spare[2] = { free_slots[free_slots.size() - 1], free_slots[free_slots.size() - 2] };
+    // time-ordered list of (update, slot); every update must be checkpointed
+    std::vector<std::pair<RBISUpdateInterface *, int>> seq;
+    for (auto &kv : map) {
+      auto it = checkpoint_of.find(kv.second);
+      if (it == checkpoint_of.end()) {
+        fprintf(stderr, "EKFSmoothBackwardsPass: update at %jd has no checkpoint (set history_checkpoint_every = 1)\n",
+                (intmax_t) kv.first);
+        return -1;
+      }
+      seq.push_back({ kv.second, it->second });
+    }
+    // indices of INS updates, and for each the slot of the filtered posterior of its step
+    std::vector<int> ins;
+    for (int i = 0; i < (int) seq.size(); i++)
+      if (seq[i].first->sensor_id == RBISUpdateInterface::ins) ins.push_back(i);
+    if (ins.size() < 2) return 0;
+    auto filt_slot = [&](int j) {  // last update before the next INS (or the end)
+      const int stop = (j + 1 < (int) ins.size()) ? ins[j + 1] : (int) seq.size();
+      return seq[stop - 1].second;
+    };
+    int next_pred = seq[ins.back()].second, next = filt_slot((int) ins.size() - 1), steps = 0;
+    for (int j = (int) ins.size() - 2; j >= 0; j--) {
+      const int out = spare[steps & 1];
+      int rc = pb_smooth_step(ctx, next_pred, next, filt_slot(j), out, dt);
+      if (rc != PB_OK) {
+        last_status = rc;
+        fprintf(stderr, "EKFSmoothBackwardsPass: %s\n", pb_last_error(ctx));
+        return -1;
+      }
+      if (on_smoothed) on_smoothed(seq[ins[j]].first->utime, out);
+      next = out;
+      next_pred = seq[ins[j]].second;
+      steps++;
+    }
+    device_head = nullptr;  // callers may have restored slots into the head: force a restore on the next replay
+    return steps;
+  }
+
 private:
   void drop_checkpoint(RBISUpdateInterface *u)
   {

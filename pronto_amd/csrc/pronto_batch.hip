@@ -11,6 +11,7 @@
 
 #include "../../include/pronto_batch.h"
 #include "rbis_kernels.hpp"
+#include "rbis_smooth.hpp"
 
 using namespace pb;
 
@@ -694,6 +695,31 @@ static int hist_copy(pb_ctx *c, int slot, bool save)
 }
 extern "C" int pb_state_save(pb_ctx *c, int slot) { return hist_copy(c, slot, true); }
 extern "C" int pb_state_restore(pb_ctx *c, int slot) { return hist_copy(c, slot, false); }
+
+extern "C" int pb_smooth_step(pb_ctx *c, int slot_next_pred, int slot_next, int slot_cur, int slot_out, double dt)
+{
+  ENTER(c);
+  const int s[4] = { slot_next_pred, slot_next, slot_cur, slot_out };
+  for (int i = 0; i < 4; i++)
+    if (s[i] < 0 || s[i] >= c->nhist) return fail(c, PB_ERR_STATE, "pb_smooth_step: checkpoint slot %d of %d", s[i], c->nhist);
+  if (slot_out == slot_next_pred || slot_out == slot_next)
+    return fail(c, PB_ERR_ARG, "pb_smooth_step: slot_out may alias slot_cur only");
+  const size_t n = (size_t) c->nc * c->stride;
+  const double *np_ = c->hist + (size_t) slot_next_pred * n, *ns_ = c->hist + (size_t) slot_next * n;
+  const double *cu = c->hist + (size_t) slot_cur * n;
+  double *out = c->hist + (size_t) slot_out * n;
+  if (c->ns == 15) {
+    using S = SmoothCfg<15>;
+    k_smooth_step<15><<<(c->B + S::F - 1) / S::F, S::THREADS, sizeof(double) * S::PER_FILTER * S::F, c->stream>>>(
+        np_, ns_, cu, out, c->stride, c->B, dt, c->k);
+  } else {
+    using S = SmoothCfg<21>;
+    k_smooth_step<21><<<(c->B + S::F - 1) / S::F, S::THREADS, sizeof(double) * S::PER_FILTER * S::F, c->stream>>>(
+        np_, ns_, cu, out, c->stride, c->B, dt, c->k);
+  }
+  LAUNCHCHK(c);
+  return PB_OK;
+}
 
 extern "C" int pb_calib_copy(pb_ctx *c, int reps, float *elapsed_ms)
 {

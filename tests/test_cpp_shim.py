@@ -37,7 +37,18 @@ def test_atlas_imu_front_end_on_gpu(oracle):
     assert r.returncode == 0 and "PASS" in r.stdout, r.stdout + r.stderr
 
 
-@pytest.mark.parametrize("name", ["test_shim", "test_history", "test_atlas_imu"])
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [15, 21])
+def test_smooth_backwards_pass_on_gpu(oracle, n):
+    """EKFSmoothBackwardsPass (mav_state_est.cpp:98-189) through the shim vs the oracle's backward recursion, steps with
+    and without a measurement after the INS update."""
+    exe = build_exe(oracle, "test_smooth_pass")
+    r = subprocess.run([exe, str(n)], capture_output=True, text=True, timeout=300)
+    print(r.stdout, r.stderr)
+    assert r.returncode == 0 and "PASS" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("name", ["test_shim", "test_history", "test_atlas_imu", "test_smooth_pass"])
 def test_shim_compiles_and_links(oracle, name):
     exe = build_exe(oracle, name)
     out = subprocess.run(["ldd", exe], capture_output=True, text=True).stdout

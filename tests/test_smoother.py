@@ -1,0 +1,119 @@
+"""RTS smoother (rbis.cpp:234-266 + the backward pass of mav_state_est.cpp:98-189): the device
+kernel k_smooth_step on posterior checkpoints against the oracle's dense restatement po_ekf_smoothing_step.
+
+Tolerance: the step inverts P^-_{k+1} (condition number up to ~1e7 here: variances from 1e-8 to 0.25); both sides use
+LDL^T with the same diagonal pivoting, so they differ by summation order only -- 1e-7 relative is the bound used."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from util import embed21, rel
+
+from pronto_amd.synth import Workload
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-7
+
+
+def oracle_forward(oracle, w, n, T, B):
+    """Forward pass with the oracle, keeping (pred, filtered) posteriors of every step (INS update, then legodo)."""
+    vec, quat, P0 = w.initial_state()
+    v21, P21 = embed21(vec, P0)
+    ob = oracle.OracleBatch(v21, quat, P21)
+    q4 = w.process_noise()
+    hist = []
+    for k in range(T):
+        imu = w.imu_block(k)
+        lo, mask = w.legodo_block(k)
+        ob.predict(imu, q4)
+        pred = (ob.vec.copy(), ob.quat.copy(), ob.cov.copy())
+        ob.update_indexed([3, 4, 5], lo[0:3], lo[3:6], mask=mask)
+        hist.append((pred, (ob.vec.copy(), ob.quat.copy(), ob.cov.copy())))
+    return hist
+
+
+def oracle_smooth_step(oracle, nxt_pred, nxt, cur, dt):
+    L = oracle.lib()
+    B = cur[0].shape[1]
+    out_v, out_q, out_P = cur[0].copy(), cur[1].copy(), cur[2].copy()
+
+    def mk(v, q, b):
+        s = oracle.Rbis()
+        s.vec[:] = list(v[:, b])
+        s.quat[:] = list(q[:, b])
+        return s
+
+    def mkP(P, b):
+        m = oracle.Rbim()
+        m.m[:] = list(np.ascontiguousarray(P[:, :, b].T).ravel())
+        return m
+    for b in range(B):
+        sp, Pp = mk(nxt_pred[0], nxt_pred[1], b), mkP(nxt_pred[2], b)
+        sn, Pn = mk(nxt[0], nxt[1], b), mkP(nxt[2], b)
+        sc, Pc = mk(cur[0], cur[1], b), mkP(cur[2], b)
+        L.po_ekf_smoothing_step(C.byref(sp), C.byref(Pp), C.byref(sn), C.byref(Pn), dt, C.byref(sc), C.byref(Pc))
+        out_v[:, b] = sc.vec[:]
+        out_q[:, b] = sc.quat[:]
+        out_P[:, :, b] = np.array(Pc.m[:]).reshape(21, 21).T
+    return out_v, out_q, out_P
+
+
+@pytest.mark.parametrize("n", [15, 21])
+def test_backward_pass_matches_oracle(oracle, n):
+    """Forward pass on the GPU with a checkpoint after every update (INS and legodo), then the backward recursion of
+    EKFSmoothBackwardsPass with pb_smooth_step; the same recursion with the oracle on the oracle's forward pass."""
+    from pronto_amd.batch import BatchEstimator
+    B, T, dt = 37, 24, 1e-3
+    w = Workload(B, n_states=n)
+    hist = oracle_forward(oracle, w, n, T, B)
+    est = BatchEstimator(B, n_states=n)
+    est.set_constants(*oracle.constants())
+    vec, quat, P0 = w.initial_state()
+    est.reset(vec, quat, P0)
+    est.history_reserve(2 * T + 2)
+    q4 = w.process_noise()
+    for k in range(T):
+        imu = w.imu_block(k)
+        lo, mask = w.legodo_block(k)
+        est.predict(imu, q4)
+        est.state_save(2 * k)            # posterior of the INS update (the "pred" of step k)
+        est.update_indexed([3, 4, 5], np.ascontiguousarray(lo[0:3]), np.ascontiguousarray(lo[3:6]), mask=mask)
+        est.state_save(2 * k + 1)        # filtered posterior of step k
+    S = [2 * T, 2 * T + 1]               # ping-pong slots for the smoothed posterior
+    # backward recursion: next = filtered(T-1), next_pred = pred(T-1)
+    nxt_slot, nxt_o = 2 * (T - 1) + 1, hist[T - 1][1]
+    for k in range(T - 2, -1, -1):
+        out_slot = S[k % 2]
+        est.smooth_step(2 * (k + 1), nxt_slot, 2 * k + 1, out_slot, dt)
+        nxt_o = oracle_smooth_step(oracle, hist[k + 1][0], nxt_o, hist[k][1], dt)
+        nxt_slot = out_slot
+        est.state_restore(out_slot)
+        v, q, P, ll = est.get_head()
+        assert rel(v, nxt_o[0][:n]) < TOL and rel(q, nxt_o[1]) < TOL, (k, rel(v, nxt_o[0][:n]))
+        assert rel(P, nxt_o[2][:n, :n]) < TOL, (k, rel(P, nxt_o[2][:n, :n]))
+        # smoothing never increases the uncertainty: P_filtered - P_smoothed is PSD
+        d = hist[k][1][2][:n, :n, 0] - P[:, :, 0]
+        assert np.linalg.eigvalsh(0.5 * (d + d.T)).min() > -1e-9 * np.abs(hist[k][1][2]).max()
+
+
+def test_smooth_step_identity_when_next_equals_prediction(oracle):
+    """If the smoothed next state equals its prediction there is nothing to propagate back: out == cur."""
+    from pronto_amd.batch import BatchEstimator
+    B, n = 70, 15
+    w = Workload(B, n_states=n)
+    vec, quat, P0 = w.initial_state()
+    est = BatchEstimator(B, n_states=n)
+    est.reset(vec, quat, P0)
+    est.history_reserve(3)
+    est.state_save(0)
+    est.predict(w.imu_block(0), w.process_noise())
+    est.state_save(1)
+    est.smooth_step(1, 1, 0, 2, 1e-3)
+    est.state_restore(0)
+    v0, q0, P0_, _ = est.get_head()
+    est.state_restore(2)
+    v2, q2, P2, _ = est.get_head()
+    assert rel(v2, v0) < 1e-12 and rel(q2, q0) < 1e-12 and rel(P2, P0_) < 1e-12
+    with pytest.raises(Exception):
+        est.smooth_step(1, 1, 0, 1, 1e-3)    # out must not alias a k+1 slot
