@@ -67,8 +67,11 @@ int pb_create(pb_ctx **out, int n_states, int batch, int device, int n_snapshots
 int pb_destroy(pb_ctx *ctx);
 const char *pb_last_error(const pb_ctx *ctx); /* ctx may be NULL: last error of a failed pb_create */
 
-/* Launch on an existing hipStream_t (e.g. torch's current stream); NULL = the context's own stream. */
+/* A new context launches on its own non-blocking stream.  pb_set_stream switches to an existing hipStream_t, taken
+ * literally: NULL is the null stream (torch's default stream) -- use the stream that PRODUCES the device buffers you
+ * pass, otherwise nothing orders their producer kernels before these launches.  pb_use_own_stream switches back. */
 int pb_set_stream(pb_ctx *ctx, void *hip_stream);
+int pb_use_own_stream(pb_ctx *ctx);
 /* eigen_utils constants that are not in the reference tree (g_vec magnitude, chiToQuat tolerance). */
 int pb_set_constants(pb_ctx *ctx, double g, double chi_tol);
 int pb_sync(pb_ctx *ctx);
@@ -121,6 +124,14 @@ int pb_step_legodo(pb_ctx *ctx, const double *imu_block, const double *lo_block,
  * context's stream, synchronises, and returns the device time. */
 int pb_run_legodo(pb_ctx *ctx, int n_steps, const double *imu_stream, const double *lo_stream,
                   const uint8_t *mask_stream, const double q[4], float *elapsed_ms);
+
+/* Time-fused replay of the same streams: steps_per_launch consecutive steps per kernel launch with the state and
+ * covariance resident in registers; the posterior is written to HBM once per launch instead of once per message.  Same
+ * arithmetic as pb_run_legodo, NOT the plugin semantics (no per-message posterior): meant for parameter sweeps and
+ * likelihood evaluation over log segments (state-estimator/python/param_sweep.py:39-52).  15-state filters only.
+ * Accounting differs from the T = 1 path (104 + 2240/T bytes per filter-step): see DESIGN.md section 6. */
+int pb_replay_legodo_fused(pb_ctx *ctx, int n_steps, int steps_per_launch, const double *imu_stream,
+                           const double *lo_stream, const uint8_t *mask_stream, const double q[4], float *elapsed_ms);
 
 /* ---- history look-up used by FovisHandler (rbis_fovis_update.cpp:184-223) ------------------------------ */
 

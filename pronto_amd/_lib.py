@@ -45,6 +45,7 @@ _SIGS = {
     "pb_destroy": (C.c_int, [C.c_void_p]),
     "pb_last_error": (C.c_char_p, [C.c_void_p]),
     "pb_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "pb_use_own_stream": (C.c_int, [C.c_void_p]),
     "pb_set_constants": (C.c_int, [C.c_void_p, C.c_double, C.c_double]),
     "pb_sync": (C.c_int, [C.c_void_p]),
     "pb_hot_kernel": (C.c_char_p, [C.c_void_p]),
@@ -62,6 +63,8 @@ _SIGS = {
                                            C.c_void_p, C.c_void_p, C.c_int]),
     "pb_step_legodo": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, _dp, C.c_int]),
     "pb_run_legodo": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, _dp, C.POINTER(C.c_float)]),
+    "pb_replay_legodo_fused": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, _dp,
+                                         C.POINTER(C.c_float)]),
     "pb_snapshot": (C.c_int, [C.c_void_p, C.c_int]),
     "pb_compose_delta": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "pb_set_process_noise_block": (C.c_int, [C.c_void_p, C.c_void_p]),

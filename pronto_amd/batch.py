@@ -54,6 +54,14 @@ class BatchEstimator:
             raise PbError(rc, (self._L.pb_last_error(None) or b"").decode())
         self._h = h
         self.B, self.n, self.device = batch, n_states, device
+        # Launch on torch's current stream of that device (usually the null stream): device tensors handed to this
+        # object are produced by torch kernels/copies on that stream, so stream order makes them visible.
+        try:
+            import torch
+            if torch.cuda.is_available():
+                self.set_stream(torch.cuda.current_stream(device).cuda_stream)
+        except ImportError:
+            pass
 
     def close(self):
         if getattr(self, "_h", None):
@@ -68,7 +76,11 @@ class BatchEstimator:
 
     # --- plumbing ---
     def set_stream(self, stream_ptr):
+        """hipStream_t handle, taken literally (0 = the null stream = torch's default stream)."""
         self._chk(self._L.pb_set_stream(self._h, C.c_void_p(stream_ptr)))
+
+    def use_own_stream(self):
+        self._chk(self._L.pb_use_own_stream(self._h))
 
     def set_constants(self, g, chi_tol):
         self._chk(self._L.pb_set_constants(self._h, g, chi_tol))
@@ -185,6 +197,19 @@ class BatchEstimator:
         q = (C.c_double * 4)(*q4)
         ms = C.c_float(0)
         self._chk(self._L.pb_run_legodo(self._h, T, pi, pl, pm, q, C.byref(ms) if timed else None))
+        return ms.value if timed else None
+
+    def replay_legodo_fused(self, imu_stream, lo_stream, mask_stream, q4, steps_per_launch, timed=False):
+        """Time-fused replay (P resident in registers for steps_per_launch steps); same results as run_legodo."""
+        T = imu_stream.shape[0]
+        pi, m1 = _ptr(imu_stream)
+        pl, m2 = _ptr(lo_stream)
+        pm, m3 = _ptr(mask_stream, np.uint8)
+        if _same_mem(m1, m2, m3) != PB_DEVICE:
+            raise ValueError("replay_legodo_fused needs device-resident streams")
+        q = (C.c_double * 4)(*q4)
+        ms = C.c_float(0)
+        self._chk(self._L.pb_replay_legodo_fused(self._h, T, steps_per_launch, pi, pl, pm, q, C.byref(ms) if timed else None))
         return ms.value if timed else None
 
     # --- fovis history ---

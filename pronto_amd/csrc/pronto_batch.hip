@@ -149,7 +149,14 @@ extern "C" int pb_destroy(pb_ctx *c)
 extern "C" int pb_set_stream(pb_ctx *c, void *s)
 {
   if (!c) return PB_ERR_ARG;
-  c->stream = s ? (hipStream_t) s : c->own_stream;
+  c->stream = (hipStream_t) s;  // literal handle: NULL is the (legacy) null stream, which is torch's default stream
+  return PB_OK;
+}
+
+extern "C" int pb_use_own_stream(pb_ctx *c)
+{
+  if (!c) return PB_ERR_ARG;
+  c->stream = c->own_stream;
   return PB_OK;
 }
 
@@ -349,6 +356,33 @@ extern "C" int pb_run_legodo(pb_ctx *c, int n_steps, const double *imu_stream, c
     int rc = launch_step<true>(c, imu_stream + (size_t) s * 7 * B, lo_stream + (size_t) s * 6 * B,
                                mask_stream ? mask_stream + (size_t) s * B : nullptr, q);
     if (rc) return rc;
+  }
+  if (elapsed_ms) {
+    HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+    HIPCHK(c, hipEventSynchronize(c->ev1));
+    HIPCHK(c, hipEventElapsedTime(elapsed_ms, c->ev0, c->ev1));
+  }
+  return PB_OK;
+}
+
+extern "C" int pb_replay_legodo_fused(pb_ctx *c, int n_steps, int steps_per_launch, const double *imu_stream,
+                                      const double *lo_stream, const uint8_t *mask_stream, const double q[4],
+                                      float *elapsed_ms)
+{
+  ENTER(c);
+  NEED_STATE(c);
+  if (c->ns != 15) return fail(c, PB_ERR_ARG, "pb_replay_legodo_fused: only the 15-state filter has a time-fused kernel");
+  if (n_steps < 0 || steps_per_launch < 1 || !imu_stream || !lo_stream || !q)
+    return fail(c, PB_ERR_ARG, "pb_replay_legodo_fused: bad argument");
+  const size_t B = (size_t) c->B;
+  if (elapsed_ms) HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+  for (int s = 0; s < n_steps; s += steps_per_launch) {
+    const int T = (n_steps - s < steps_per_launch) ? n_steps - s : steps_per_launch;
+    k_replay_fused<15><<<nblk(c->B), 64, 0, c->stream>>>(c->st, c->stride, c->B, T, imu_stream + (size_t) s * 7 * B,
+                                                         lo_stream + (size_t) s * 6 * B,
+                                                         mask_stream ? mask_stream + (size_t) s * B : nullptr, q[0], q[1],
+                                                         q[2], q[3], c->k);
+    LAUNCHCHK(c);
   }
   if (elapsed_ms) {
     HIPCHK(c, hipEventRecord(c->ev1, c->stream));

@@ -115,6 +115,80 @@ __global__ __launch_bounds__(PB_STEP_BLOCK, 1) void k_step(double *__restrict__ 
   stg(rs, L::OFF_LL * s8, bo, ll);
 }
 
+// Time-fused replay: T consecutive predict+update steps per launch with the state and P resident in registers; only the
+// 104 B/filter of inputs stream from HBM per step, the posterior is materialised once per launch.  This is NOT the plugin
+// path (MavStateEstimator::addUpdate publishes a posterior per message) but what a parameter sweep or a likelihood
+// evaluation over a log segment wants (param_sweep.py:39-52).  Accounting: 104 + 2240/T bytes per filter-step, so the
+// bound moves from HBM to fp64 VALU issue; bench.py reports it separately (never as the headline value).
+// Inputs of step t+1 are prefetched while step t computes (one wave per SIMD: nothing else hides their latency).
+template <int NS>
+__global__ __launch_bounds__(64, 1) void k_replay_fused(double *__restrict__ st, long stride, int B, int T,
+                                                        const double *__restrict__ imu, const double *__restrict__ lo,
+                                                        const uint8_t *__restrict__ mask, double qg, double qa, double qbg,
+                                                        double qba, Consts k)
+{
+  using L = Lay<NS>;
+  const unsigned b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= (unsigned) B) return;
+  const unsigned bo = b * 8u;
+  const unsigned s8 = (unsigned) stride * 8u, B8 = (unsigned) B * 8u;
+  const rsrc_t rs = mkbuf(st, (unsigned) L::NC * s8);
+  double x[NS], q[4], ll, P[L::NP];
+#pragma unroll
+  for (int i = 0; i < NS; i++) x[i] = ldg(rs, (L::OFF_VEC + i) * s8, bo);
+#pragma unroll
+  for (int i = 0; i < 4; i++) q[i] = ldg(rs, (L::OFF_QUAT + i) * s8, bo);
+  ll = ldg(rs, L::OFF_LL * s8, bo);
+#pragma unroll
+  for (int i = 0; i < L::NP; i++) P[i] = ldg(rs, (L::OFF_P + i) * s8, bo);
+  if (k.qblk != nullptr) {
+    const rsrc_t rq = mkbuf(k.qblk, 4u * B8);
+    qg = ldg(rq, 0u, bo); qa = ldg(rq, B8, bo); qbg = ldg(rq, 2u * B8, bo); qba = ldg(rq, 3u * B8, bo);
+  }
+  // step-t input blocks are [7][B] / [6][B] / [B] slabs of the streams; 64-bit slab base, 32-bit offsets inside
+  double in[13], nx[13] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+  bool upd, nupd = false;
+  auto fetch = [&](int t, double (&dst)[13], bool &u) {
+    const rsrc_t ri = mkbuf(imu + (size_t) t * 7 * B, 7u * B8);
+    const rsrc_t rl = mkbuf(lo + (size_t) t * 6 * B, 6u * B8);
+#pragma unroll
+    for (int i = 0; i < 7; i++) dst[i] = ldg(ri, i * B8, bo);
+#pragma unroll
+    for (int i = 0; i < 6; i++) dst[7 + i] = ldg(rl, i * B8, bo);
+    u = (mask == nullptr) || (mask[(size_t) t * B + b] != 0);
+  };
+  fetch(0, in, upd);
+  for (int t = 0; t < T; t++) {
+#ifdef PB_REPLAY_PREFETCH
+    if (t + 1 < T) fetch(t + 1, nx, nupd);
+#else
+    if (t > 0) fetch(t, in, upd);
+#endif
+    const double gyro[3] = { in[0], in[1], in[2] }, accel[3] = { in[3], in[4], in[5] };
+    imu_process_step<NS>(x, q, P, gyro, accel, in[6], qg, qa, qbg, qba, k);
+    double resid[3], S[6];
+#pragma unroll
+    for (int i = 0; i < 3; i++) resid[i] = upd ? in[7 + i] - x[3 + i] : 0.0;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+      for (int j = 0; j <= i; j++) S[pk(i, j)] = P[pk(3 + i, 3 + j)] + (i == j ? (upd ? in[10 + i] : 1.0) : 0.0);
+    measurement_update<NS, 3>(x, q, P, ll, resid, S, IdxVel{}, k, NoSink(), upd);
+#ifdef PB_REPLAY_PREFETCH
+#pragma unroll
+    for (int i = 0; i < 13; i++) in[i] = nx[i];
+    upd = nupd;
+#endif
+  }
+#pragma unroll
+  for (int i = 0; i < L::NP; i++) stg(rs, (L::OFF_P + i) * s8, bo, P[i]);
+#pragma unroll
+  for (int i = 0; i < NS; i++) stg(rs, (L::OFF_VEC + i) * s8, bo, x[i]);
+#pragma unroll
+  for (int i = 0; i < 4; i++) stg(rs, (L::OFF_QUAT + i) * s8, bo, q[i]);
+  stg(rs, L::OFF_LL * s8, bo, ll);
+}
+
 template <int M>
 struct IdxArg {
   int v[M];

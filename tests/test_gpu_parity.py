@@ -380,17 +380,54 @@ def test_torch_stream_interop(pa, oracle):
     B, n = 512, 15
     w = Workload(B, n_states=n)
     est, ob = make_pair(pa, oracle, w)
-    est.set_stream(torch.cuda.current_stream().cuda_stream)
     q4 = w.process_noise()
     dev = torch.device("cuda:0")
-    for k in range(10):
+    side = torch.cuda.Stream()
+    for k in range(12):
         imu = w.imu_block(k)
         lo, mask = w.legodo_block(k)
-        est.step_legodo(torch.from_numpy(imu).to(dev), torch.from_numpy(lo).to(dev), torch.from_numpy(mask).to(dev), q4)
+        if k % 2:   # a non-default torch stream: inputs are PRODUCED by torch kernels on it, the step follows in stream order
+            with torch.cuda.stream(side):
+                est.set_stream(side.cuda_stream)
+                d_imu = torch.from_numpy(imu).to(dev, non_blocking=True) * 1.0
+                d_lo = torch.from_numpy(lo).to(dev, non_blocking=True) + 0.0
+                d_mask = torch.from_numpy(mask).to(dev, non_blocking=True).clone()
+                est.step_legodo(d_imu, d_lo, d_mask, q4)
+            side.synchronize()
+        else:       # the default (null) stream, handle 0
+            est.set_stream(torch.cuda.current_stream().cuda_stream)
+            est.step_legodo(torch.from_numpy(imu).to(dev) * 1.0, torch.from_numpy(lo).to(dev), torch.from_numpy(mask).to(dev), q4)
+            torch.cuda.current_stream().synchronize()
         ob.predict(imu, q4)
         ob.update_indexed([3, 4, 5], lo[0:3], lo[3:6], mask=mask)
+    est.use_own_stream()
     torch.cuda.synchronize()
     check(est, ob)
+
+
+@pytest.mark.parametrize("T_fuse", [1, 7, 64])
+def test_time_fused_replay_equals_per_step_path(pa, oracle, T_fuse):
+    """pb_replay_legodo_fused (state resident in registers for T steps) gives the per-message path's results and
+    matches the oracle; ragged last launch (50 steps in chunks of 7), masks, uncertain R."""
+    import torch
+    B, n, T = 1000, 15, 50
+    w = Workload(B, n_states=n)
+    imu, lo, mask = w.streams(0, T)
+    dev = torch.device("cuda:0")
+    d = [torch.from_numpy(a).to(dev) for a in (imu, lo, mask)]
+    q4 = w.process_noise()
+    est_f, ob = make_pair(pa, oracle, w)
+    est_s, _ = make_pair(pa, oracle, w)
+    est_f.replay_legodo_fused(d[0], d[1], d[2], q4, T_fuse)
+    est_s.run_legodo(d[0], d[1], d[2], q4)
+    ob.run_legodo(imu, lo, mask, q4)
+    check(est_f, ob)
+    vf, qf, Pf, lf = est_f.get_head()
+    vs, qs, Ps, ls = est_s.get_head()
+    assert rel(vf, vs) < 1e-12 and rel(qf, qs) < 1e-12 and rel(Pf, Ps) < 1e-12 and rel(lf, ls) < 1e-12
+    est21 = pa.BatchEstimator(8, n_states=21)
+    with pytest.raises(pa.PbError):
+        est21.replay_legodo_fused(d[0], d[1], d[2], q4, 4)   # 15-state only (and before reset)
 
 
 @pytest.mark.parametrize("n,vo,sm", [(15, 32, 0), (21, 0, 25)])
