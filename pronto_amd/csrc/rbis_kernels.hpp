@@ -198,9 +198,38 @@ struct DiagArg {
   double v[M];
 };
 
+// rows [R0, R1) of the packed covariance: issue ALL their loads, then downdate and store them.  (Interleaving a load
+// and a store per entry serialises on the load latency: the compiler may not hoist a load above a possibly aliasing
+// store; that version of k_update ran at 0.33-0.45 of the HBM roofline.)
+template <int NS, int M, int R0, int R1>
+__device__ __forceinline__ void downdate_rows(rsrc_t rs, unsigned s8, unsigned bo, const double (&W)[NS][M],
+                                              const double (&id)[M])
+{
+  using L = Lay<NS>;
+  constexpr int CNT = (R1 * (R1 + 1) - R0 * (R0 + 1)) / 2;
+  constexpr int P0 = R0 * (R0 + 1) / 2;
+  double buf[CNT];
+#pragma unroll
+  for (int e = 0; e < CNT; e++) buf[e] = ldg(rs, (L::OFF_P + P0 + e) * s8, bo);
+#pragma unroll
+  for (int i = R0; i < R1; i++) {
+    double wd[M];
+#pragma unroll
+    for (int kk = 0; kk < M; kk++) wd[kk] = W[i][kk] * id[kk];
+#pragma unroll
+    for (int j = 0; j <= i; j++) {
+      double acc = buf[pk(i, j) - P0];
+#pragma unroll
+      for (int kk = 0; kk < M; kk++) acc = fma(-wd[kk], W[j][kk], acc);
+      stg(rs, (L::OFF_P + pk(i, j)) * s8, bo, acc);
+    }
+  }
+}
+
 // Generic RBISIndexedMeasurement / RBISIndexedPlusOrientationMeasurement::updateFilter with a RUNTIME index list
 // (rbis_update_interface.cpp:54-107).  The m gathered columns P[:, idx] (wave-uniform component addresses) and x
-// live in registers; P itself is streamed through once (load, rank-m downdate, store).
+// live in registers; P itself is streamed through once in row chunks (load a chunk, rank-m downdate, store it).
+// The skip mask is predicated like in k_step: every lane stores whole rows with D^-1 = 0 for skipped filters.
 template <int NS, int M, bool ORIENT>
 __global__ __launch_bounds__(64, 1) void k_update(double *__restrict__ st, long stride, int B, IdxArg<M> idx,
                                                   const double *__restrict__ z, const double *__restrict__ R,
@@ -210,7 +239,7 @@ __global__ __launch_bounds__(64, 1) void k_update(double *__restrict__ st, long 
   using L = Lay<NS>;
   const unsigned b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= (unsigned) B) return;
-  if (mask != nullptr && mask[b] == 0) return;  // handler returned NULL for this filter
+  const bool upd = (mask == nullptr) || (mask[b] != 0);  // 0 = handler returned NULL for this filter
   const unsigned bo = b * 8u;
   const unsigned s8 = (unsigned) stride * 8u, B8 = (unsigned) B * 8u;
   const rsrc_t rs = mkbuf(st, (unsigned) L::NC * s8);
@@ -223,6 +252,12 @@ __global__ __launch_bounds__(64, 1) void k_update(double *__restrict__ st, long 
 #pragma unroll
   for (int i = 0; i < 4; i++) q[i] = ldg(rs, (L::OFF_QUAT + i) * s8, bo);
   double ll = ldg(rs, L::OFF_LL * s8, bo);
+  // gather the measured columns first: all these loads are in flight together
+  double W[NS][M];
+#pragma unroll
+  for (int i = 0; i < NS; i++)
+#pragma unroll
+    for (int kk = 0; kk < M; kk++) W[i][kk] = ldg(rs, (L::OFF_P + pk(i, idx.v[kk])) * s8, bo);
 
   // residual (rbis.cpp:169-172 / :199-208)
   double resid[M];
@@ -239,7 +274,7 @@ __global__ __launch_bounds__(64, 1) void k_update(double *__restrict__ st, long 
     if constexpr (ORIENT) {
       if (ii >= 6 && ii <= 8) r = (ii == 6) ? dq[0] : (ii == 7 ? dq[1] : dq[2]);
     }
-    resid[kk] = r;
+    resid[kk] = upd ? r : 0.0;
   }
   // S = R + P[idx, idx]
   double S[M * (M + 1) / 2], d[M];
@@ -251,6 +286,7 @@ __global__ __launch_bounds__(64, 1) void k_update(double *__restrict__ st, long 
       if (rkind == PB_R_DIAG_BROADCAST) r = (i == j) ? rb.v[i] : 0.0;
       else if (rkind == PB_R_DIAG) r = (i == j) ? ldg(rR, i * B8, bo) : 0.0;
       else r = ldg(rR, (j * M + i) * B8, bo);
+      if (!upd) r = (i == j) ? 1.0 : 0.0;  // benign R for skipped filters (their R block may hold anything)
       S[pk(i, j)] = r + ldg(rs, (L::OFF_P + pk(idx.v[i], idx.v[j])) * s8, bo);
     }
   ldlt<M>(S, d);
@@ -261,18 +297,17 @@ __global__ __launch_bounds__(64, 1) void k_update(double *__restrict__ st, long 
 #pragma unroll
     for (int j = 0; j < kk; j++) s -= S[pk(kk, j)] * y[j];
     y[kk] = s;
-    id[kk] = 1.0 / d[kk];
+    id[kk] = upd ? 1.0 / d[kk] : 0.0;
     yd[kk] = s * id[kk];
     lli -= log(d[kk]) + s * s * id[kk];
   }
-  ll += lli;
-  // W = P[:, idx] L^-T
-  double W[NS][M];
+  if (upd) ll += lli;
+  // W = P[:, idx] L^-T  (in place on the gathered columns)
 #pragma unroll
   for (int i = 0; i < NS; i++) {
 #pragma unroll
     for (int kk = 0; kk < M; kk++) {
-      double s = ldg(rs, (L::OFF_P + pk(i, idx.v[kk])) * s8, bo);
+      double s = W[i][kk];
 #pragma unroll
       for (int j = 0; j < kk; j++) s -= W[i][j] * S[pk(kk, j)];
       W[i][kk] = s;
@@ -281,22 +316,29 @@ __global__ __launch_bounds__(64, 1) void k_update(double *__restrict__ st, long 
   double dx[NS];
 #pragma unroll
   for (int i = 0; i < NS; i++) {
-    double s = 0.0, wd[M];
+    double s = 0.0;
 #pragma unroll
-    for (int kk = 0; kk < M; kk++) {
-      s = (kk == 0) ? W[i][0] * yd[0] : fma(W[i][kk], yd[kk], s);
-      wd[kk] = W[i][kk] * id[kk];
-    }
+    for (int kk = 0; kk < M; kk++) s = (kk == 0) ? W[i][0] * yd[0] : fma(W[i][kk], yd[kk], s);
     dx[i] = s;
-#pragma unroll
-    for (int j = 0; j <= i; j++) {
-      double acc = ldg(rs, (L::OFF_P + pk(i, j)) * s8, bo);
-#pragma unroll
-      for (int kk = 0; kk < M; kk++) acc = fma(-wd[kk], W[j][kk], acc);
-      stg(rs, (L::OFF_P + pk(i, j)) * s8, bo, acc);
-    }
   }
-  add_delta<NS>(x, q, dx, k.chi_tol);
+  // chunk sizes keep (chunk + W) inside the register file: W is NS x M doubles
+  if constexpr (NS == 15 && M <= 4) {
+    downdate_rows<NS, M, 0, 15>(rs, s8, bo, W, id);
+  } else if constexpr (NS == 15) {
+    downdate_rows<NS, M, 0, 11>(rs, s8, bo, W, id);
+    downdate_rows<NS, M, 11, 15>(rs, s8, bo, W, id);
+  } else if constexpr (M <= 4) {
+    downdate_rows<NS, M, 0, 12>(rs, s8, bo, W, id);
+    downdate_rows<NS, M, 12, 17>(rs, s8, bo, W, id);
+    downdate_rows<NS, M, 17, 21>(rs, s8, bo, W, id);
+  } else {
+    downdate_rows<NS, M, 0, 9>(rs, s8, bo, W, id);
+    downdate_rows<NS, M, 9, 13>(rs, s8, bo, W, id);
+    downdate_rows<NS, M, 13, 16>(rs, s8, bo, W, id);
+    downdate_rows<NS, M, 16, 19>(rs, s8, bo, W, id);
+    downdate_rows<NS, M, 19, 21>(rs, s8, bo, W, id);
+  }
+  if (upd) add_delta<NS>(x, q, dx, k.chi_tol);
 #pragma unroll
   for (int i = 0; i < NS; i++) stg(rs, (L::OFF_VEC + i) * s8, bo, x[i]);
 #pragma unroll
