@@ -37,7 +37,8 @@ def cpu_baseline(n, dt_us, target_s, est_cls):
     the HIP path is run on the same sample to report the parity of what was just timed."""
     from oracle import po
     from pronto_amd.synth import Workload
-    threads = po.lib().po_max_threads()
+    # a GPU box gives one GPU's job a 16-core CPU share whatever nproc says: more OpenMP threads only oversubscribe it
+    threads = max(1, min(po.lib().po_max_threads(), int(os.environ.get("PRONTO_CPU_THREADS", "16"))))
     T = 100
 
     def run(Bs, nthreads=threads):

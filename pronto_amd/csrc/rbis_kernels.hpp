@@ -4,9 +4,10 @@
 // (stride = batch rounded up to 64); components = vec[n] | quat[4] | loglik | P packed lower [n(n+1)/2].
 // One lane owns one filter, so every global access of a wave is one fully coalesced 512-byte row segment.
 //
-// Addressing: component base (wave-uniform, SGPRs) + one per-lane 32-bit byte offset, i.e. the
-// `global_load/store v, v_off, s[base:base+1]` form; no per-access 64-bit VGPR address is materialised
-// (that cost ~700 instructions and ~60 VGPRs in the first version of k_step).
+// Addressing: one 128-bit buffer descriptor per array, the component offset in an SGPR (soffset) and ONE per-lane
+// 32-bit byte offset shared by every access: `buffer_load/store_dwordx2 v, v_off, s[rsrc], s_off offen`.  No per-access
+// 64-bit VGPR address is materialised (flat addressing cost ~700 instructions, ~60 VGPRs and 164 spilled registers in the
+// first version of k_step).
 #pragma once
 
 #include <hip/hip_runtime.h>

@@ -365,6 +365,13 @@ def test_error_behaviour_and_wire_layout(pa, oracle):
     with pytest.raises(pa.PbError) as e:
         est.snapshot(5)
     assert e.value.code == 4
+    with pytest.raises(pa.PbError) as e:
+        pa.BatchEstimator(3_000_000, n_states=21)      # 257 components x 3M filters x 8 B > 4 GiB per context
+    assert e.value.code == 1 and "too large" in str(e.value)
+    for call in (lambda: est.state_save(0), lambda: est.smooth_step(0, 1, 2, 3, 1e-3)):
+        with pytest.raises(pa.PbError) as e:
+            call()                                      # no checkpoint slots reserved
+        assert e.value.code == 4
     v, q, P, ll = est.get_head()
     qq, s21, c21 = est.filter_state(3)
     assert np.array_equal(qq, q[:, 3]) and np.array_equal(s21[:15], v[:, 3]) and np.all(s21[15:] == 0)
