@@ -53,6 +53,8 @@ struct Consts {
   // optional per-filter process noise [4][B] = q_gyro, q_accel, q_gyro_bias, q_accel_bias (device memory); used by
   // parameter sweeps / noise identification (noise_id.cpp:9-42) where every filter of the batch carries its own q
   const double *qblk = nullptr;
+  // k_step_coop: 1 = give each of the 8 XCDs one contiguous filter range (workgroups are dealt round-robin to XCDs)
+  int xcd_remap = 0;
 };
 
 // ------------------------------------------------------------------------------------------------------------

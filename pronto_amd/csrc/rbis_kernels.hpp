@@ -42,6 +42,18 @@ __device__ __forceinline__ void stg(rsrc_t r, unsigned soff, unsigned voff, doub
   __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, v), r, voff, soff, 0);
 }
 
+// Workgroups are dealt round-robin to the 8 XCDs.  With k.xcd_remap each XCD walks one contiguous filter range
+// (bijective for any grid size) instead of every 8th 512-byte segment of each component row (host picks).
+__device__ __forceinline__ unsigned xcd_workgroup(const Consts &k)
+{
+  unsigned wg = blockIdx.x;
+  if (k.xcd_remap) {
+    const unsigned nq = gridDim.x >> 3, nr = gridDim.x & 7u, xcd = blockIdx.x & 7u, rank = blockIdx.x >> 3;
+    wg = (xcd < nr ? xcd * (nq + 1u) : nr * (nq + 1u) + (xcd - nr) * nq) + rank;
+  }
+  return wg;
+}
+
 struct IdxVel {
   static constexpr Idx<3> value = { { 3, 4, 5 } };
 };
@@ -55,7 +67,7 @@ __global__ __launch_bounds__(PB_STEP_BLOCK, 1) void k_step(double *__restrict__ 
                                                 double qba, Consts k)
 {
   using L = Lay<NS>;
-  const unsigned b = blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned b = xcd_workgroup(k) * blockDim.x + threadIdx.x;
   if (b >= (unsigned) B) return;
   const unsigned bo = b * 8u;
   const unsigned s8 = (unsigned) stride * 8u, B8 = (unsigned) B * 8u;  // host guarantees NC*stride*8 < 2^32
@@ -238,7 +250,7 @@ __global__ __launch_bounds__(64, 1) void k_update(double *__restrict__ st, long 
                                                   const uint8_t *__restrict__ mask, Consts k)
 {
   using L = Lay<NS>;
-  const unsigned b = blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned b = xcd_workgroup(k) * blockDim.x + threadIdx.x;
   if (b >= (unsigned) B) return;
   const bool upd = (mask == nullptr) || (mask[b] != 0);  // 0 = handler returned NULL for this filter
   const unsigned bo = b * 8u;
@@ -467,7 +479,8 @@ __global__ __launch_bounds__(128, 1) void k_step_coop(double *__restrict__ st, l
   __shared__ double xch[UPDATE ? C::NXCH : 1][64];
   const int role = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
   const unsigned lane = threadIdx.x & 63u;
-  const unsigned b = blockIdx.x * 64u + lane;
+  const unsigned wg = xcd_workgroup(k);
+  const unsigned b = wg * 64u + lane;
   const unsigned bo = b * 8u;
   const unsigned s8 = (unsigned) stride * 8u, B8 = (unsigned) B * 8u;
   const rsrc_t rs = mkbuf(st, (unsigned) L::NC * s8);
