@@ -37,6 +37,7 @@ struct pb_ctx {
   int64_t utime = 0;
   bool have_state = false;
   bool coop15 = false;  // PRONTO_BATCH_COOP15=1: run the 15-state step on the two-wave cooperative kernel (A/B switch)
+  int mem_hint = 0;     // MH_* cache policy of the step kernels' state round trip (PRONTO_BATCH_MEMHINT=0/1/2 forces it)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   char err[512] = { 0 };
 };
@@ -101,6 +102,15 @@ extern "C" int pb_create(pb_ctx **out, int n_states, int batch, int device, int 
     // (3-15 % slower beyond).  PRONTO_BATCH_XCD=0/1 forces it either way for A/B runs.
     const char *e = getenv("PRONTO_BATCH_XCD");
     c->k.xcd_remap = e ? (e[0] == '1') : (n_states == 15 || (long) c->nc * c->stride * 8 <= (160L << 20));
+    // Cache policy of the state round trip (rbis_kernels.hpp MemHint), measured on both step kernels: a state that
+    // fits the XCDs' L2s (< ~48 MB) wants the default policy (sc1 stores 7 % slower at 32k x 15 states); up to ~1.3x
+    // the 256 MB memory-side cache sc1 stores are 1-4 % faster; beyond, non-temporal loads+stores are 7-15 % faster
+    // (1M filters: 469 -> 417 us) and 10-40 % SLOWER if used on a cache-sized state.  PRONTO_BATCH_MEMHINT=0/1/2 forces.
+    const long state_bytes = (long) c->nc * c->stride * 8;
+    const char *h = getenv("PRONTO_BATCH_MEMHINT");
+    c->mem_hint = h ? (h[0] - '0')
+                    : (state_bytes < (48L << 20) ? MH_DEFAULT : state_bytes < (340L << 20) ? MH_STORE_SC1 : MH_STREAM_NT);
+    if (c->mem_hint < 0 || c->mem_hint > 2) c->mem_hint = MH_DEFAULT;
   }
   // the kernels address the state through one 32-bit-ranged buffer descriptor (rbis_kernels.hpp)
   if ((unsigned long long) c->nc * (unsigned long long) c->stride * 8ull >= (1ull << 32)) {
@@ -310,18 +320,28 @@ extern "C" int pb_reset(pb_ctx *c, const double *vec, const double *quat, const 
   return PB_OK;
 }
 
-template <bool UPDATE>
-static int launch_step(pb_ctx *c, const double *imu, const double *lo, const uint8_t *mask, const double q[4])
+template <bool UPDATE, int MH>
+static void launch_step_mh(pb_ctx *c, const double *imu, const double *lo, const uint8_t *mask, const double q[4])
 {
   const int B = c->B;
   if (c->ns == 15 && c->coop15) {
-    k_step_coop<15, UPDATE><<<nblk(B), 128, 0, c->stream>>>(c->st, c->stride, B, imu, lo, mask, q[0], q[1], q[2], q[3], c->k);
+    k_step_coop<15, UPDATE, MH><<<nblk(B), 128, 0, c->stream>>>(c->st, c->stride, B, imu, lo, mask, q[0], q[1], q[2], q[3], c->k);
   } else if (c->ns == 15) {
-    k_step<15, UPDATE><<<(B + PB_STEP_BLOCK - 1) / PB_STEP_BLOCK, PB_STEP_BLOCK, 0, c->stream>>>(c->st, c->stride, B, imu, lo, mask, q[0], q[1], q[2], q[3], c->k);
+    k_step<15, UPDATE, MH><<<(B + PB_STEP_BLOCK - 1) / PB_STEP_BLOCK, PB_STEP_BLOCK, 0, c->stream>>>(c->st, c->stride, B, imu, lo, mask, q[0], q[1], q[2], q[3], c->k);
   } else {
     // n = 21: 231 packed covariance entries do not fit one lane's registers; the step runs on the two-wave
     // cooperative kernel (rbis_coop.hpp): one launch, one state round trip.
-    k_step_coop<21, UPDATE><<<nblk(B), 128, 0, c->stream>>>(c->st, c->stride, B, imu, lo, mask, q[0], q[1], q[2], q[3], c->k);
+    k_step_coop<21, UPDATE, MH><<<nblk(B), 128, 0, c->stream>>>(c->st, c->stride, B, imu, lo, mask, q[0], q[1], q[2], q[3], c->k);
+  }
+}
+
+template <bool UPDATE>
+static int launch_step(pb_ctx *c, const double *imu, const double *lo, const uint8_t *mask, const double q[4])
+{
+  switch (c->mem_hint) {  // cache policy of the state round trip, chosen in pb_create from the state size
+  case MH_STORE_SC1: launch_step_mh<UPDATE, MH_STORE_SC1>(c, imu, lo, mask, q); break;
+  case MH_STREAM_NT: launch_step_mh<UPDATE, MH_STREAM_NT>(c, imu, lo, mask, q); break;
+  default: launch_step_mh<UPDATE, MH_DEFAULT>(c, imu, lo, mask, q); break;
   }
   LAUNCHCHK(c);
   return PB_OK;
@@ -399,6 +419,16 @@ extern "C" int pb_replay_legodo_fused(pb_ctx *c, int n_steps, int steps_per_laun
   return PB_OK;
 }
 
+template <int NS, int M, int MH>
+static void launch_update_mh(pb_ctx *c, const IdxArg<M> &ia, const DiagArg<M> &da, const double *z, const double *R,
+                             int rkind, const double *qm, const uint8_t *mask)
+{
+  if (qm)
+    k_update<NS, M, true, MH><<<nblk(c->B), 64, 0, c->stream>>>(c->st, c->stride, c->B, ia, z, R, rkind, da, qm, mask, c->k);
+  else
+    k_update<NS, M, false, MH><<<nblk(c->B), 64, 0, c->stream>>>(c->st, c->stride, c->B, ia, z, R, rkind, da, qm, mask, c->k);
+}
+
 template <int NS, int M>
 static void launch_update_m(pb_ctx *c, const int *idx, const double *z, const double *R, int rkind, const double *rb,
                             const double *qm, const uint8_t *mask)
@@ -409,10 +439,11 @@ static void launch_update_m(pb_ctx *c, const int *idx, const double *z, const do
     ia.v[i] = idx[i];
     da.v[i] = rb ? rb[i] : 0.0;
   }
-  if (qm)
-    k_update<NS, M, true><<<nblk(c->B), 64, 0, c->stream>>>(c->st, c->stride, c->B, ia, z, R, rkind, da, qm, mask, c->k);
-  else
-    k_update<NS, M, false><<<nblk(c->B), 64, 0, c->stream>>>(c->st, c->stride, c->B, ia, z, R, rkind, da, qm, mask, c->k);
+  switch (c->mem_hint) {
+  case MH_STORE_SC1: launch_update_mh<NS, M, MH_STORE_SC1>(c, ia, da, z, R, rkind, qm, mask); break;
+  case MH_STREAM_NT: launch_update_mh<NS, M, MH_STREAM_NT>(c, ia, da, z, R, rkind, qm, mask); break;
+  default: launch_update_mh<NS, M, MH_DEFAULT>(c, ia, da, z, R, rkind, qm, mask); break;
+  }
 }
 
 template <int NS>

@@ -33,14 +33,27 @@ __device__ __forceinline__ rsrc_t mkbuf(const void *p, unsigned bytes)
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, bytes, 0x00020000);
 }
 // buffer_load_dwordx2 v, v_off, s[rsrc], s_off offen : voff = per-lane byte offset, soff = uniform component offset
+// AUX = cache-policy bits of the instruction (gfx940+: 1 = sc0, 2 = nt, 16 = sc1)
+template <int AUX = 0>
 __device__ __forceinline__ double ldg(rsrc_t r, unsigned soff, unsigned voff)
 {
-  return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+  return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, AUX));
 }
+template <int AUX = 0>
 __device__ __forceinline__ void stg(rsrc_t r, unsigned soff, unsigned voff, double v)
 {
-  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, v), r, voff, soff, 0);
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, v), r, voff, soff, AUX);
 }
+
+// Memory hint of the state round trip in the step kernels (template parameter MH), picked by the host from the state
+// size.  Measured with an in-place streaming copy of the same layout: while the state fits the 256 MB
+// memory-side cache, stores with sc1 (write through the XCD's L2) are 3-5 % faster; far beyond it, non-temporal loads
+// AND stores are ~5 % faster; in between neither helps.
+enum { MH_DEFAULT = 0, MH_STORE_SC1 = 1, MH_STREAM_NT = 2 };
+template <int MH> struct MemHint {
+  static constexpr int LA = (MH == MH_STREAM_NT) ? 2 : 0;
+  static constexpr int SA = (MH == MH_STORE_SC1) ? 16 : (MH == MH_STREAM_NT) ? 2 : 0;
+};
 
 // Workgroups are dealt round-robin to the 8 XCDs.  With k.xcd_remap each XCD walks one contiguous filter range
 // (bijective for any grid size) instead of every 8th 512-byte segment of each component row (host picks).
@@ -60,13 +73,14 @@ struct IdxVel {
 
 // RBISIMUProcessStep::updateFilter [+ RBISIndexedMeasurement::updateFilter with idx = {3,4,5}, diagonal R]
 // (rbis_update_interface.cpp:30-52, :54-95).  The BASELINE hot step: 2*(n+4+1+n(n+1)/2)*8 + 56 + 48 bytes/filter.
-template <int NS, bool UPDATE>
+template <int NS, bool UPDATE, int MH = MH_DEFAULT>
 __global__ __launch_bounds__(PB_STEP_BLOCK, 1) void k_step(double *__restrict__ st, long stride, int B,
                                                 const double *__restrict__ imu, const double *__restrict__ lo,
                                                 const uint8_t *__restrict__ mask, double qg, double qa, double qbg,
                                                 double qba, Consts k)
 {
   using L = Lay<NS>;
+  constexpr int LA = MemHint<MH>::LA, SA = MemHint<MH>::SA;
   const unsigned b = xcd_workgroup(k) * blockDim.x + threadIdx.x;
   if (b >= (unsigned) B) return;
   const unsigned bo = b * 8u;
@@ -76,12 +90,12 @@ __global__ __launch_bounds__(PB_STEP_BLOCK, 1) void k_step(double *__restrict__ 
   const rsrc_t rl = mkbuf(lo, UPDATE ? 6u * B8 : 0u);
   double x[NS], q[4], ll, P[L::NP];
 #pragma unroll
-  for (int i = 0; i < NS; i++) x[i] = ldg(rs, (L::OFF_VEC + i) * s8, bo);
+  for (int i = 0; i < NS; i++) x[i] = ldg<LA>(rs, (L::OFF_VEC + i) * s8, bo);
 #pragma unroll
-  for (int i = 0; i < 4; i++) q[i] = ldg(rs, (L::OFF_QUAT + i) * s8, bo);
-  ll = ldg(rs, L::OFF_LL * s8, bo);
+  for (int i = 0; i < 4; i++) q[i] = ldg<LA>(rs, (L::OFF_QUAT + i) * s8, bo);
+  ll = ldg<LA>(rs, L::OFF_LL * s8, bo);
 #pragma unroll
-  for (int i = 0; i < L::NP; i++) P[i] = ldg(rs, (L::OFF_P + i) * s8, bo);
+  for (int i = 0; i < L::NP; i++) P[i] = ldg<LA>(rs, (L::OFF_P + i) * s8, bo);
   double gyro[3], accel[3];
 #pragma unroll
   for (int i = 0; i < 3; i++) {
@@ -116,16 +130,16 @@ __global__ __launch_bounds__(PB_STEP_BLOCK, 1) void k_step(double *__restrict__ 
       for (int j = 0; j <= i; j++)
         S[pk(i, j)] = P[pk(3 + i, 3 + j)] + (i == j ? (upd ? rd[i] : 1.0) : 0.0);  // rbis.cpp:134-135
     measurement_update<NS, 3>(x, q, P, ll, resid, S, IdxVel{}, k,
-                              [rs, s8, bo](int pi, double v) { stg(rs, (L::OFF_P + pi) * s8, bo, v); }, upd);
+                              [rs, s8, bo](int pi, double v) { stg<SA>(rs, (L::OFF_P + pi) * s8, bo, v); }, upd);
   } else {
 #pragma unroll
-    for (int i = 0; i < L::NP; i++) stg(rs, (L::OFF_P + i) * s8, bo, P[i]);
+    for (int i = 0; i < L::NP; i++) stg<SA>(rs, (L::OFF_P + i) * s8, bo, P[i]);
   }
 #pragma unroll
-  for (int i = 0; i < NS; i++) stg(rs, (L::OFF_VEC + i) * s8, bo, x[i]);
+  for (int i = 0; i < NS; i++) stg<SA>(rs, (L::OFF_VEC + i) * s8, bo, x[i]);
 #pragma unroll
-  for (int i = 0; i < 4; i++) stg(rs, (L::OFF_QUAT + i) * s8, bo, q[i]);
-  stg(rs, L::OFF_LL * s8, bo, ll);
+  for (int i = 0; i < 4; i++) stg<SA>(rs, (L::OFF_QUAT + i) * s8, bo, q[i]);
+  stg<SA>(rs, L::OFF_LL * s8, bo, ll);
 }
 
 // Time-fused replay: T consecutive predict+update steps per launch with the state and P resident in registers; only the
@@ -214,7 +228,7 @@ struct DiagArg {
 // rows [R0, R1) of the packed covariance: issue ALL their loads, then downdate and store them.  (Interleaving a load
 // and a store per entry serialises on the load latency: the compiler may not hoist a load above a possibly aliasing
 // store; that version of k_update ran at 0.33-0.45 of the HBM roofline.)
-template <int NS, int M, int R0, int R1>
+template <int NS, int M, int R0, int R1, int MH>
 __device__ __forceinline__ void downdate_rows(rsrc_t rs, unsigned s8, unsigned bo, const double (&W)[NS][M],
                                               const double (&id)[M])
 {
@@ -223,7 +237,7 @@ __device__ __forceinline__ void downdate_rows(rsrc_t rs, unsigned s8, unsigned b
   constexpr int P0 = R0 * (R0 + 1) / 2;
   double buf[CNT];
 #pragma unroll
-  for (int e = 0; e < CNT; e++) buf[e] = ldg(rs, (L::OFF_P + P0 + e) * s8, bo);
+  for (int e = 0; e < CNT; e++) buf[e] = ldg<MemHint<MH>::LA>(rs, (L::OFF_P + P0 + e) * s8, bo);
 #pragma unroll
   for (int i = R0; i < R1; i++) {
     double wd[M];
@@ -234,7 +248,7 @@ __device__ __forceinline__ void downdate_rows(rsrc_t rs, unsigned s8, unsigned b
       double acc = buf[pk(i, j) - P0];
 #pragma unroll
       for (int kk = 0; kk < M; kk++) acc = fma(-wd[kk], W[j][kk], acc);
-      stg(rs, (L::OFF_P + pk(i, j)) * s8, bo, acc);
+      stg<MemHint<MH>::SA>(rs, (L::OFF_P + pk(i, j)) * s8, bo, acc);
     }
   }
 }
@@ -243,7 +257,9 @@ __device__ __forceinline__ void downdate_rows(rsrc_t rs, unsigned s8, unsigned b
 // (rbis_update_interface.cpp:54-107).  The m gathered columns P[:, idx] (wave-uniform component addresses) and x
 // live in registers; P itself is streamed through once in row chunks (load a chunk, rank-m downdate, store it).
 // The skip mask is predicated like in k_step: every lane stores whole rows with D^-1 = 0 for skipped filters.
-template <int NS, int M, bool ORIENT>
+// MH: the gathered columns are read with the default policy (they are read again by the row stream), the row stream's
+// loads and every store carry the hint.
+template <int NS, int M, bool ORIENT, int MH = MH_DEFAULT>
 __global__ __launch_bounds__(64, 1) void k_update(double *__restrict__ st, long stride, int B, IdxArg<M> idx,
                                                   const double *__restrict__ z, const double *__restrict__ R,
                                                   int rkind, DiagArg<M> rb, const double *__restrict__ qmeas,
@@ -336,27 +352,28 @@ __global__ __launch_bounds__(64, 1) void k_update(double *__restrict__ st, long 
   }
   // chunk sizes keep (chunk + W) inside the register file: W is NS x M doubles
   if constexpr (NS == 15 && M <= 4) {
-    downdate_rows<NS, M, 0, 15>(rs, s8, bo, W, id);
+    downdate_rows<NS, M, 0, 15, MH>(rs, s8, bo, W, id);
   } else if constexpr (NS == 15) {
-    downdate_rows<NS, M, 0, 11>(rs, s8, bo, W, id);
-    downdate_rows<NS, M, 11, 15>(rs, s8, bo, W, id);
+    downdate_rows<NS, M, 0, 11, MH>(rs, s8, bo, W, id);
+    downdate_rows<NS, M, 11, 15, MH>(rs, s8, bo, W, id);
   } else if constexpr (M <= 4) {
-    downdate_rows<NS, M, 0, 12>(rs, s8, bo, W, id);
-    downdate_rows<NS, M, 12, 17>(rs, s8, bo, W, id);
-    downdate_rows<NS, M, 17, 21>(rs, s8, bo, W, id);
+    downdate_rows<NS, M, 0, 12, MH>(rs, s8, bo, W, id);
+    downdate_rows<NS, M, 12, 17, MH>(rs, s8, bo, W, id);
+    downdate_rows<NS, M, 17, 21, MH>(rs, s8, bo, W, id);
   } else {
-    downdate_rows<NS, M, 0, 9>(rs, s8, bo, W, id);
-    downdate_rows<NS, M, 9, 13>(rs, s8, bo, W, id);
-    downdate_rows<NS, M, 13, 16>(rs, s8, bo, W, id);
-    downdate_rows<NS, M, 16, 19>(rs, s8, bo, W, id);
-    downdate_rows<NS, M, 19, 21>(rs, s8, bo, W, id);
+    downdate_rows<NS, M, 0, 9, MH>(rs, s8, bo, W, id);
+    downdate_rows<NS, M, 9, 13, MH>(rs, s8, bo, W, id);
+    downdate_rows<NS, M, 13, 16, MH>(rs, s8, bo, W, id);
+    downdate_rows<NS, M, 16, 19, MH>(rs, s8, bo, W, id);
+    downdate_rows<NS, M, 19, 21, MH>(rs, s8, bo, W, id);
   }
   if (upd) add_delta<NS>(x, q, dx, k.chi_tol);
+  constexpr int SA = MemHint<MH>::SA;
 #pragma unroll
-  for (int i = 0; i < NS; i++) stg(rs, (L::OFF_VEC + i) * s8, bo, x[i]);
+  for (int i = 0; i < NS; i++) stg<SA>(rs, (L::OFF_VEC + i) * s8, bo, x[i]);
 #pragma unroll
-  for (int i = 0; i < 4; i++) stg(rs, (L::OFF_QUAT + i) * s8, bo, q[i]);
-  stg(rs, L::OFF_LL * s8, bo, ll);
+  for (int i = 0; i < 4; i++) stg<SA>(rs, (L::OFF_QUAT + i) * s8, bo, q[i]);
+  stg<SA>(rs, L::OFF_LL * s8, bo, ll);
 }
 
 // RBISResetUpdate::updateFilter, per-filter inputs: vec [n][B], quat [4][B], cov [n*n][B] column-major
@@ -468,7 +485,7 @@ __global__ void k_summary(const double *__restrict__ st, long stride, int B, dou
 // This is the 21-state hot kernel (231 packed entries do not fit one lane) and an alternative mapping for n = 15.
 // No lane returns before the barrier: lanes past the batch end work on the zero-initialised padding columns of the
 // state array (stride is the batch rounded up to 64) and on bounds-checked (zero) inputs.
-template <int NS, bool UPDATE>
+template <int NS, bool UPDATE, int MH = MH_DEFAULT>
 __global__ __launch_bounds__(128, 1) void k_step_coop(double *__restrict__ st, long stride, int B,
                                                       const double *__restrict__ imu, const double *__restrict__ lo,
                                                       const uint8_t *__restrict__ mask, double qg, double qa,
@@ -501,8 +518,8 @@ __global__ __launch_bounds__(128, 1) void k_step_coop(double *__restrict__ st, l
     const rsrc_t rq = mkbuf(k.qblk, 4u * B8);
     in.qg = ldg(rq, 0u, bo); in.qa = ldg(rq, B8, bo); in.qbg = ldg(rq, 2u * B8, bo); in.qba = ldg(rq, 3u * B8, bo);
   }
-  auto ld = [rs, s8, bo](int comp) { return ldg(rs, (unsigned) comp * s8, bo); };
-  auto stf = [rs, s8, bo](int comp, double v) { stg(rs, (unsigned) comp * s8, bo, v); };
+  auto ld = [rs, s8, bo](int comp) { return ldg<MemHint<MH>::LA>(rs, (unsigned) comp * s8, bo); };
+  auto stf = [rs, s8, bo](int comp, double v) { stg<MemHint<MH>::SA>(rs, (unsigned) comp * s8, bo, v); };
   auto sync = []() { __syncthreads(); };
   if (role == 0) {
     coop_role_core<NS, UPDATE>(ld, stf, [lane](int s, double v) { xch[s][lane] = v; }, sync, in, k);

@@ -476,3 +476,40 @@ def test_full_size_configs_3_and_5_sampled_parity(pa, oracle, n, vo, sm):
     v, q, P, ll = est.get_head()
     assert rel(v[:, sel], ob.vec[:n]) < TOL and rel(q[:, sel], ob.quat) < TOL
     assert rel(P[:, :, sel], ob.cov[:n, :n]) < TOL and rel(ll[sel], ob.ll) < TOL
+
+
+@pytest.mark.parametrize("n,B,coop", [(15, 1000, "1"), (15, 715, "1"), (15, 715, "0"), (21, 700, "1")])
+def test_every_kernel_variant_is_bit_identical(pa, oracle, n, B, coop, monkeypatch):
+    """pb_create picks the step kernel (one-lane / two-wave), the workgroup order (XCD-contiguous or not) and the cache
+    policy of the state round trip (default / sc1 stores / non-temporal) from the batch size, so the small batches of the
+    other tests never reach most variants.  Force every combination on ragged grids (16, 12 and 11 workgroups: remainder
+    0, 4 and 3 over the 8 XCDs): each step kernel is checked against the oracle, and workgroup order and cache policy
+    must not change a single bit."""
+    w = Workload(B, n_states=n)
+    q4 = w.process_noise()
+    vo, sm = (7, 0) if n == 15 else (0, 7)
+    monkeypatch.setenv("PRONTO_BATCH_COOP15", coop)
+    ref = None
+    for xcd in ("0", "1"):
+        for hint in ("0", "1", "2"):
+            monkeypatch.setenv("PRONTO_BATCH_XCD", xcd)
+            monkeypatch.setenv("PRONTO_BATCH_MEMHINT", hint)
+            est, ob = make_pair(pa, oracle, w, dense_p0=5)
+            assert ("coop" in est.hot_kernel()) == (coop == "1")
+            for k in range(30):  # fused step kernel
+                lo, mask = w.legodo_block(k)
+                est.step_legodo(w.imu_block(k), lo, mask, q4)
+            run_config(est, w, 30, vo_every=vo, sm_every=sm, k0=30)  # predict-only kernel + k_update m = 3, 4 / 6
+            head = est.get_head()
+            if ref is None:
+                for k in range(30):
+                    lo, mask = w.legodo_block(k)
+                    ob.predict(w.imu_block(k), q4)
+                    ob.update_indexed([3, 4, 5], lo[0:3], lo[3:6], mask=mask)
+                run_config(ob, w, 30, vo_every=vo, sm_every=sm, k0=30)
+                check(est, ob)
+                ref = head
+            else:
+                for a, b in zip(head, ref):
+                    assert np.array_equal(a, b), (xcd, hint)
+            est.close()
