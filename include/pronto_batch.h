@@ -76,7 +76,8 @@ int pb_use_own_stream(pb_ctx *ctx);
 int pb_set_constants(pb_ctx *ctx, double g, double chi_tol);
 int pb_sync(pb_ctx *ctx);
 /* name (as rocprofv3 prints it, without the pb:: prefix) of the kernel pb_step_legodo / pb_run_legodo launch for
- * this context: "k_step<15,true>", "k_step_coop<15,true>" or "k_step_coop<21,true>" */
+ * this context: "k_step<15,true,H>", "k_step_coop<15,true,H>" or "k_step_coop<21,true,H>"; H = 0/1/2 is the cache
+ * policy of the state round trip the library picked from the state size (default / sc1 stores / non-temporal) */
 const char *pb_hot_kernel(const pb_ctx *ctx);
 int pb_batch(const pb_ctx *ctx);
 int pb_n_states(const pb_ctx *ctx);

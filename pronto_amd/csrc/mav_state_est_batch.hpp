@@ -21,6 +21,7 @@
 // pb_run_legodo (see bench.py).  The handlers skip the host pass entirely when the transform is the identity.
 #pragma once
 
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -34,6 +35,7 @@
 #include <vector>
 
 #include "../../include/pronto_batch.h"
+#include "pronto_wire.hpp"
 
 namespace MavStateEst {
 
@@ -947,6 +949,7 @@ public:
   int64_t prev_t0_body_utime_ = 0;
   int slot;                       // device snapshot slot holding the filter posterior at prev_timestamp
   double *d_q = nullptr, *d_z6 = nullptr;  // device scratch: composed orientation [4][B], z [6][B] (rows 3-5 zero)
+  uint8_t *d_valid = nullptr;              // device copy of msg->estimate_valid [B]
   pb_ctx *owner = nullptr;
 
   explicit FovisHandler(BotParam *param, int snapshot_slot = 0) : slot(snapshot_slot)
@@ -985,6 +988,7 @@ public:
     if (owner) {
       pb_free(owner, d_q);
       pb_free(owner, d_z6);
+      pb_free(owner, d_valid);
     }
   }
 
@@ -995,6 +999,12 @@ public:
   RBISUpdateInterface *processMessage(const msgs::update_t *msg, MavStateEstimator *est)
   {
     const int B = est->B;
+    // estimate_status != ESTIMATE_VALID -> NULL (:160-164); per filter that is a mask, and NULL when no filter is valid
+    if (msg->estimate_valid != nullptr && std::find_if(msg->estimate_valid, msg->estimate_valid + B,
+                                                       [](uint8_t v) { return v != 0; }) == msg->estimate_valid + B) {
+      fprintf(stdout, "FovisHandler: FOVIS failure, not integrating this measurement\n");
+      return nullptr;
+    }
     if (mode == MODE_VELOCITY_ROTATION_RATE) {
       fprintf(stdout, "FovisHandler Mode not supported, exiting\n");  // :276-285
       return nullptr;
@@ -1019,6 +1029,7 @@ public:
       owner = est->ctx;
       pb_malloc(owner, sizeof(double) * 4 * B, (void **) &d_q);
       pb_malloc(owner, sizeof(double) * 6 * B, (void **) &d_z6);
+      pb_malloc(owner, (size_t) B, (void **) &d_valid);
       std::vector<double> zero((size_t) 6 * B, 0.0);
       pb_memcpy_h2d(owner, d_z6, zero.data(), sizeof(double) * 6 * B);
     }
@@ -1026,12 +1037,17 @@ public:
       fprintf(stderr, "FovisHandler: %s\n", pb_last_error(est->ctx));
       return nullptr;
     }
+    const uint8_t *valid = nullptr;  // the composed z / q live on the device, so does the mask that goes with them
+    if (msg->estimate_valid != nullptr) {
+      pb_memcpy_h2d(owner, d_valid, msg->estimate_valid, (size_t) B);
+      valid = d_valid;
+    }
     if (mode == MODE_POSITION)
       return new RBISIndexedMeasurement(RBIS::positionInds(), BatchArray(d_z6, PB_DEVICE), cov_fovis.data(), PB_R_DIAG_BROADCAST,
-                                        nullptr, RBISUpdateInterface::fovis, msg->timestamp);
+                                        valid, RBISUpdateInterface::fovis, msg->timestamp);
     // rows 3..5 of d_z6 stay zero: z at chi indices is ignored (rbis.cpp:203-205)
     return new RBISIndexedPlusOrientationMeasurement(z_indices, BatchArray(d_z6, PB_DEVICE), cov_fovis.data(), PB_R_DIAG_BROADCAST,
-                                                     BatchArray(d_q, PB_DEVICE), nullptr, RBISUpdateInterface::fovis,
+                                                     BatchArray(d_q, PB_DEVICE), valid, RBISUpdateInterface::fovis,
                                                      msg->timestamp);
   }
 };
@@ -1066,6 +1082,133 @@ public:
       }
     };
   }
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// wire side (pronto_wire.hpp): publish the head of one filter, replay a recorded LCM log into the batch
+// ---------------------------------------------------------------------------------------------------------------
+
+// rbisCreateFilterStateMessageCPP (rbis.cpp:287-304) for filter b: always rbis_num_states = 21 entries and the full
+// 21 x 21 column-major covariance; a 15-state batch publishes zero bias entries like the reference run with q_bias = 0.
+inline pronto_wire::filter_state_t rbisCreateFilterStateMessageCPP(const RBIS &state, const RBIM &cov, int b)
+{
+  pronto_wire::filter_state_t msg;
+  msg.utime = state.utime;
+  msg.num_states = RBIS::rbis_num_states;
+  msg.num_cov_elements = msg.num_states * msg.num_states;
+  for (int i = 0; i < 4; i++) msg.quat[i] = state.q(i, b);
+  msg.state.assign((size_t) msg.num_states, 0.0);
+  msg.cov.assign((size_t) msg.num_cov_elements, 0.0);
+  for (int i = 0; i < state.n; i++) msg.state[(size_t) i] = state(i, b);
+  for (int c = 0; c < cov.n; c++)
+    for (int r = 0; r < cov.n; r++) msg.cov[(size_t) c * msg.num_states + r] = cov(r, c, b);
+  return msg;
+}
+
+// LCMFrontEnd::publishState (lcm_front_end.cpp:144-157), filter-state half: appends the head of the chosen filters
+// to an LCM log on `state_estimator.filter_state_channel` when `state_estimator.publish_filter_state` is set.
+class FilterStatePublisher {
+public:
+  std::string filter_state_channel;
+  bool publish_filter_state;
+  FilterStatePublisher(BotParam *param, pronto_wire::LogWriter *log, std::vector<int> filters)
+      : filter_state_channel(bot_param_get_str_or_fail(param, "state_estimator.filter_state_channel")),
+        publish_filter_state(bot_param_get_boolean_or_fail(param, "state_estimator.publish_filter_state")),
+        log_(log), filters_(std::move(filters)) {}
+  // one channel per filter beyond the first so that a reader can tell them apart: CHANNEL, CHANNEL_1, CHANNEL_2 ...
+  void publishHead(MavStateEstimator *est)
+  {
+    if (!publish_filter_state || log_ == nullptr) return;
+    RBIS s;
+    RBIM c;
+    est->getHeadState(s, c);
+    std::vector<uint8_t> buf;
+    for (size_t k = 0; k < filters_.size(); k++) {
+      rbisCreateFilterStateMessageCPP(s, c, filters_[k]).encode(buf);
+      log_->write(s.utime, k == 0 ? filter_state_channel : filter_state_channel + "_" + std::to_string(k), buf);
+    }
+  }
+private:
+  pronto_wire::LogWriter *log_;
+  std::vector<int> filters_;
+};
+
+// Log replay (lcm_front_end.cpp:223-229 handle loop, reading a recorded segment instead of the network): events are
+// dispatched in file order to the subscribed channels.  One recorded robot feeds EVERY filter of the batch -- the
+// batch differs in parameters / initial state, not in data (param_sweep.py:39-52) -- so a decoded message is
+// broadcast into [m][B] host blocks and handed to the same callback LCMFrontEnd::addSensor returns.
+class LogPlayer {
+public:
+  explicit LogPlayer(int batch) : B_(batch) {}
+  void subscribeRaw(const std::string &channel, std::function<void(const pronto_wire::LogEvent &)> cb)
+  {
+    subs_[channel] = std::move(cb);
+  }
+  void subscribeIndexedMeasurement(const std::string &channel, std::function<void(const msgs::indexed_measurement_t *)> cb)
+  {
+    subs_[channel] = [this, cb](const pronto_wire::LogEvent &ev) {
+      pronto_wire::indexed_measurement_t w;
+      if (w.decode(ev.data.data(), ev.data.size()) < 0 || w.measured_cov_dim != w.measured_dim * w.measured_dim) {
+        n_bad_++;
+        return;
+      }
+      const int m = w.measured_dim;
+      z_.resize((size_t) m * B_);
+      R_.resize((size_t) m * m * B_);
+      for (int i = 0; i < m; i++) std::fill_n(z_.begin() + (size_t) i * B_, B_, w.z_effective[(size_t) i]);
+      for (int i = 0; i < m * m; i++) std::fill_n(R_.begin() + (size_t) i * B_, B_, w.R_effective[(size_t) i]);
+      msgs::indexed_measurement_t msg;
+      msg.utime = w.utime;
+      msg.z_indices.assign(w.z_indices.begin(), w.z_indices.end());
+      msg.z_effective = BatchArray(z_.data(), PB_HOST);
+      msg.R_effective = R_.data();
+      cb(&msg);
+    };
+  }
+  void subscribeUpdate(const std::string &channel, std::function<void(const msgs::update_t *)> cb)
+  {
+    subs_[channel] = [this, cb](const pronto_wire::LogEvent &ev) {
+      pronto_wire::update_t w;
+      if (w.decode(ev.data.data(), ev.data.size()) < 0) {
+        n_bad_++;
+        return;
+      }
+      t_.resize((size_t) 3 * B_);
+      q_.resize((size_t) 4 * B_);
+      valid_.assign((size_t) B_, (uint8_t) (w.estimate_status == pronto_wire::update_t::ESTIMATE_VALID));
+      for (int i = 0; i < 3; i++) std::fill_n(t_.begin() + (size_t) i * B_, B_, w.translation[i]);
+      for (int i = 0; i < 4; i++) std::fill_n(q_.begin() + (size_t) i * B_, B_, w.rotation[i]);
+      msgs::update_t msg;
+      msg.timestamp = w.timestamp;
+      msg.prev_timestamp = w.prev_timestamp;
+      msg.estimate_valid = valid_.data();
+      msg.translation = BatchArray(t_.data(), PB_HOST);
+      msg.rotation = BatchArray(q_.data(), PB_HOST);
+      cb(&msg);
+    };
+  }
+  // returns the number of events dispatched, or -1 if the file cannot be opened
+  int64_t run(const std::string &path)
+  {
+    pronto_wire::LogReader rd(path);
+    if (!rd.good()) return -1;
+    pronto_wire::LogEvent ev;
+    int64_t n = 0;
+    while (rd.next(ev)) {
+      auto it = subs_.find(ev.channel);
+      if (it == subs_.end()) continue;
+      it->second(ev);
+      n++;
+    }
+    return n;
+  }
+  int64_t undecodable() const { return n_bad_; }
+private:
+  int B_;
+  int64_t n_bad_ = 0;
+  std::map<std::string, std::function<void(const pronto_wire::LogEvent &)>> subs_;
+  std::vector<double> z_, R_, t_, q_;
+  std::vector<uint8_t> valid_;
 };
 
 }  // namespace MavStateEst

@@ -197,8 +197,10 @@ extern "C" int pb_sync(pb_ctx *c)
 extern "C" const char *pb_hot_kernel(const pb_ctx *c)
 {
   if (!c) return "";
-  if (c->ns == 21) return "k_step_coop<21,true>";
-  return c->coop15 ? "k_step_coop<15,true>" : "k_step<15,true>";
+  static const char *const names[3][3] = { { "k_step_coop<21,true,0>", "k_step_coop<21,true,1>", "k_step_coop<21,true,2>" },
+                                           { "k_step_coop<15,true,0>", "k_step_coop<15,true,1>", "k_step_coop<15,true,2>" },
+                                           { "k_step<15,true,0>", "k_step<15,true,1>", "k_step<15,true,2>" } };
+  return names[c->ns == 21 ? 0 : (c->coop15 ? 1 : 2)][c->mem_hint];
 }
 extern "C" int pb_batch(const pb_ctx *c) { return c ? c->B : -1; }
 extern "C" int pb_n_states(const pb_ctx *c) { return c ? c->ns : -1; }

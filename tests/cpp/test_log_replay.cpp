@@ -1,0 +1,222 @@
+// test_log_replay.cpp -- a recorded segment (LCM event log) replayed into the batch through the C++ shim's LogPlayer,
+// the way se-fusion replays a log for a parameter sweep (param_sweep.py:39-52): ONE robot's messages feed every filter,
+// the filters differ in their initial state.  The log carries pronto::indexed_measurement_t (channel GPF_MEASUREMENT,
+// m = 3 with a full R) and pronto::update_t (KINECT_REL_ODOMETRY, VO position_orient); the IMU travels on a raw test
+// channel (7 big-endian doubles) because bot_core::ins_t's schema is not in the reference tree.  Every event is applied to
+// the oracle filter by filter; afterwards the head is published as pronto::filter_state_t into a second log, read back
+// and compared with getHeadState.  Exit code 0 + "PASS".  Needs a GPU.
+#include <cinttypes>
+#include <cstdio>
+#include <vector>
+
+#include "../../oracle/pronto_oracle.h"
+#include "../../pronto_amd/csrc/mav_state_est_batch.hpp"
+
+using namespace MavStateEst;
+
+static uint64_t rng_state = 0x4C434D4C4F47ULL;
+static double urand()
+{
+  rng_state = rng_state * 6364136223846793005ULL + 1442695040888963407ULL;
+  return ((rng_state >> 11) + 0.5) / 9007199254740992.0;
+}
+static double nrand() { return sqrt(-2 * log(urand())) * cos(2 * M_PI * urand()); }
+
+int main(int argc, char **argv)
+{
+  const std::string dir = argc > 1 ? argv[1] : "/tmp";
+  const std::string in_log = dir + "/segment.lcmlog", out_log = dir + "/published.lcmlog";
+  const int n = 15, B = 96, T = 100;
+  double g;
+  po_get_constants(&g, nullptr);
+
+  // ---- record the segment ----
+  {
+    pronto_wire::LogWriter log(in_log);
+    if (!log.good()) { printf("cannot write %s\nFAIL\n", in_log.c_str()); return 1; }
+    std::vector<uint8_t> buf;
+    int64_t key_utime = 0;
+    for (int k = 0; k < T; k++) {
+      const int64_t utime = (int64_t) (k + 1) * 1000;
+      pronto_wire::Writer w;
+      for (int i = 0; i < 3; i++) w.f64(0.3 * sin(0.02 * k + i) + 0.01 * nrand());
+      for (int i = 0; i < 3; i++) w.f64(0.3 * nrand() + (i == 2 ? g : 0.0));
+      w.f64(0.001);
+      log.write(utime, "IMU_TICK", w.buf);
+      if (k % 7 == 3) log.write(utime, "SOMETHING_ELSE", std::vector<uint8_t>(11, 0x5A));
+      if (k % 4 == 3) {
+        pronto_wire::indexed_measurement_t im;
+        im.utime = utime;
+        im.state_utime = utime - 1000;
+        im.measured_dim = 3;
+        im.z_indices = { 3, 4, 5 };
+        for (int i = 0; i < 3; i++) im.z_effective.push_back(0.2 * nrand());
+        im.measured_cov_dim = 9;
+        const double R[9] = { 0.012, 0.002, -0.001, 0.002, 0.011, 0.003, -0.001, 0.003, 0.014 };
+        im.R_effective.assign(R, R + 9);
+        im.encode(buf);
+        log.write(utime, "GPF_MEASUREMENT", buf);
+      }
+      if (k % 25 == 24) {
+        pronto_wire::update_t up;
+        up.timestamp = utime;
+        up.prev_timestamp = key_utime;
+        double dq[4];
+        po_euler_to_quat(0.01 * nrand(), 0.01 * nrand(), 0.02 * nrand(), dq);
+        for (int i = 0; i < 3; i++) up.translation[i] = 0.02 * nrand();
+        for (int i = 0; i < 4; i++) up.rotation[i] = dq[i];
+        up.estimate_status = (k == 49) ? pronto_wire::update_t::ESTIMATE_DEGENERATE : pronto_wire::update_t::ESTIMATE_VALID;
+        up.encode(buf);
+        log.write(utime, "KINECT_REL_ODOMETRY", buf);
+        key_utime = utime;
+      }
+    }
+  }
+
+  // ---- the estimator, configured with the reference's keys ----
+  BotParam param;
+  param.set("state_estimator.utime_history_span", "1000000");
+  param.set("state_estimator.ins.channel", "IMU_TICK");
+  param.set("state_estimator.ins.q_gyro", 0.5);
+  param.set("state_estimator.ins.q_accel", 0.1);
+  param.set("state_estimator.ins.q_gyro_bias", 0.0);
+  param.set("state_estimator.ins.q_accel_bias", 0.0);
+  param.set("state_estimator.ins.timestep_dt", 0.001);
+  param.set("state_estimator.ins.atlas_filter", "false");
+  param.set("state_estimator.ins.accel_bias_update_online", "false");
+  param.set("state_estimator.ins.gyro_bias_update_online", "false");
+  param.applyOverrides("state_estimator.fovis.mode=position_orient|state_estimator.fovis.r_pxyz=0.02|state_estimator.fovis.r_chi=0.01");
+  param.set("state_estimator.filter_state_channel", "STATE_ESTIMATOR_STATE");
+  param.set("state_estimator.publish_filter_state", "true");
+  for (const char *s : { "ins", "gpf", "fovis" }) {
+    param.set(std::string("state_estimator.") + s + ".downsample_factor", "1");
+    param.set(std::string("state_estimator.") + s + ".roll_forward_on_receive", "true");
+    param.set(std::string("state_estimator.") + s + ".utime_offset", "0");
+  }
+  RBIS x0(n, B);
+  RBIM P0(n, B);
+  std::vector<po_rbis> ox(B);
+  std::vector<po_rbim> oP(B);
+  std::vector<double> oll(B, 0.0);
+  for (int b = 0; b < B; b++) {
+    double q[4];
+    po_euler_to_quat(0.1 * (urand() - 0.5), 0.1 * (urand() - 0.5), 6.0 * (urand() - 0.5), q);
+    po_rbis_zero(&ox[b]);
+    memset(&oP[b], 0, sizeof(po_rbim));
+    for (int i = 0; i < 4; i++) { x0.q(i, b) = q[i]; ox[b].quat[i] = q[i]; }
+    for (int i = 0; i < 3; i++) { x0(3 + i, b) = 0.2 * nrand(); ox[b].vec[3 + i] = x0(3 + i, b); }
+    const double sig[15] = { 0, 0, 0, .15, .15, .15, .05, .05, .05, .5, .5, .5, 0, 0, 0 };
+    for (int i = 0; i < n; i++) { P0(i, i, b) = sig[i] * sig[i] * (1.0 + 0.01 * b); oP[b].m[i * 21 + i] = P0(i, i, b); }
+  }
+  BotTrans ins_to_body;
+  InsHandler ins_handler(&param, &ins_to_body);
+  IndexedMeasurementHandler gpf_handler(RBISUpdateInterface::laser_gpf);
+  FovisHandler fovis_handler(&param, 0);
+  FrontEnd front_end(&param);
+  auto on_ins = front_end.addSensor("ins", &InsHandler::processMessage, &ins_handler);
+  auto on_gpf = front_end.addSensor("gpf", &IndexedMeasurementHandler::processMessage, &gpf_handler);
+  auto on_fovis = front_end.addSensor("fovis", &FovisHandler::processMessage, &fovis_handler);
+  MavStateEstimator est(new RBISResetUpdate(x0, P0, RBISUpdateInterface::reset, 0), &param, 0);
+  front_end.setStateEstimator(&est);
+  fovis_handler.markKeyframe(&est);
+  std::vector<po_rbis> key = ox;
+  const double q4[4] = { ins_handler.cov_gyro, ins_handler.cov_accel, ins_handler.cov_gyro_bias, ins_handler.cov_accel_bias };
+
+  // ---- replay: every subscription applies the event to the batch AND to the oracle ----
+  LogPlayer player(B);
+  std::vector<double> gy(3 * B), ac(3 * B);
+  int n_imu = 0, n_gpf = 0, n_vo = 0, n_vo_invalid = 0;
+  player.subscribeRaw("IMU_TICK", [&](const pronto_wire::LogEvent &ev) {
+    pronto_wire::Reader r(ev.data.data(), ev.data.size());
+    double v[7];
+    r.f64s(v, 7);
+    for (int i = 0; i < 3; i++)
+      for (int b = 0; b < B; b++) { gy[i * B + b] = v[i]; ac[i * B + b] = v[3 + i]; }
+    msgs::ins_t m{ ev.timestamp, BatchArray(gy.data(), PB_HOST), BatchArray(ac.data(), PB_HOST) };
+    on_ins(&m);
+    for (int b = 0; b < B; b++) po_imu_process_step(v, v + 3, 0.001, q4[0], q4[1], q4[2], q4[3], &ox[b], &oP[b], oll[b], &ox[b], &oP[b], &oll[b]);
+    n_imu++;
+  });
+  player.subscribeIndexedMeasurement("GPF_MEASUREMENT", [&](const msgs::indexed_measurement_t *m) {
+    on_gpf(m);
+    const int mm = (int) m->z_indices.size();
+    for (int b = 0; b < B; b++) {
+      double z[6], R[36];
+      for (int i = 0; i < mm; i++) z[i] = m->z_effective.p[(size_t) i * B + b];
+      for (int i = 0; i < mm * mm; i++) R[i] = m->R_effective[(size_t) i * B + b];
+      po_indexed_update(mm, m->z_indices.data(), z, R, &ox[b], &oP[b], oll[b], &ox[b], &oP[b], &oll[b]);
+    }
+    n_gpf++;
+  });
+  player.subscribeUpdate("KINECT_REL_ODOMETRY", [&](const msgs::update_t *m) {
+    on_fovis(m);
+    n_vo++;
+    if (!m->estimate_valid[0]) {  // rbis_fovis_update.cpp:165-171: anything but ESTIMATE_VALID is dropped
+      n_vo_invalid++;
+    } else {
+      for (int b = 0; b < B; b++) {
+        double t3[3] = { m->translation.p[b], m->translation.p[B + b], m->translation.p[2 * B + b] };
+        double q[4] = { m->rotation.p[b], m->rotation.p[B + b], m->rotation.p[2 * B + b], m->rotation.p[3 * B + b] };
+        double z[6] = { 0 }, qm[4], R[36] = { 0 };
+        po_fovis_compose(key[b].vec + 9, key[b].quat, t3, q, z, qm);
+        const int idx[6] = { 9, 10, 11, 6, 7, 8 };
+        for (int i = 0; i < 6; i++) R[i * 6 + i] = (i < 3) ? 0.02 * 0.02 : 0.01 * 0.01;
+        po_indexed_orient_update(6, idx, z, R, qm, &ox[b], &oP[b], oll[b], &ox[b], &oP[b], &oll[b]);
+      }
+    }
+    fovis_handler.markKeyframe(&est);
+    key = ox;
+  });
+  const int64_t dispatched = player.run(in_log);
+
+  // ---- compare the head with the oracle ----
+  RBIS head;
+  RBIM cov;
+  est.getHeadState(head, cov);
+  std::vector<double> ll = est.getMeasurementsLogLikelihood();
+  double ev = 0, eq = 0, eP = 0, el = 0, sv = 0, sP = 0, sl = 0;
+  for (int b = 0; b < B; b++) {
+    for (int i = 0; i < n; i++) { ev = fmax(ev, fabs(head(i, b) - ox[b].vec[i])); sv = fmax(sv, fabs(ox[b].vec[i])); }
+    for (int i = 0; i < 4; i++) eq = fmax(eq, fabs(head.q(i, b) - ox[b].quat[i]));
+    for (int c = 0; c < n; c++)
+      for (int r = 0; r < n; r++) { eP = fmax(eP, fabs(cov(r, c, b) - oP[b].m[c * 21 + r])); sP = fmax(sP, fabs(oP[b].m[c * 21 + r])); }
+    el = fmax(el, fabs(ll[b] - oll[b]));
+    sl = fmax(sl, fabs(oll[b]));
+  }
+  printf("replayed %" PRId64 " events (imu %d, gpf %d, vo %d of which %d not valid, undecodable %" PRId64 "): rel err vec %.2e "
+         "quat %.2e cov %.2e ll %.2e (status %d)\n", dispatched, n_imu, n_gpf, n_vo, n_vo_invalid, player.undecodable(),
+         ev / sv, eq, eP / sP, el / sl, est.last_status);
+  bool ok = est.last_status == PB_OK && dispatched == n_imu + n_gpf + n_vo && n_imu == T && n_gpf == T / 4 && n_vo == T / 25 &&
+            n_vo_invalid == 1 && player.undecodable() == 0 && head.utime == (int64_t) T * 1000 && ev / sv < 1e-9 && eq < 1e-9 &&
+            eP / sP < 1e-9 && el / sl < 1e-9;
+
+  // ---- publish the head of three filters, read the log back: bit-exact against getHeadState ----
+  {
+    pronto_wire::LogWriter out(out_log);
+    FilterStatePublisher pub(&param, &out, { 0, 17, B - 1 });
+    pub.publishHead(&est);
+  }
+  {
+    pronto_wire::LogReader rd(out_log);
+    pronto_wire::LogEvent e;
+    const int which[3] = { 0, 17, B - 1 };
+    const char *chan[3] = { "STATE_ESTIMATOR_STATE", "STATE_ESTIMATOR_STATE_1", "STATE_ESTIMATOR_STATE_2" };
+    int seen = 0;
+    while (rd.next(e)) {
+      pronto_wire::filter_state_t fs;
+      const int b = which[seen < 3 ? seen : 0];
+      bool good = seen < 3 && e.channel == chan[seen] && e.timestamp == head.utime && e.data.size() == 3752 &&
+                  fs.decode(e.data.data(), e.data.size()) == 3752 && fs.utime == head.utime && fs.num_states == 21 &&
+                  fs.num_cov_elements == 441;
+      for (int i = 0; good && i < 4; i++) good = fs.quat[i] == head.q(i, b);
+      for (int i = 0; good && i < 21; i++) good = fs.state[(size_t) i] == (i < n ? head(i, b) : 0.0);
+      for (int c = 0; good && c < 21; c++)
+        for (int r = 0; good && r < 21; r++) good = fs.cov[(size_t) c * 21 + r] == ((r < n && c < n) ? cov(r, c, b) : 0.0);
+      if (!good) { printf("published filter_state_t %d differs from the head\n", seen); ok = false; }
+      seen++;
+    }
+    if (seen != 3) { printf("expected 3 published states, read %d\n", seen); ok = false; }
+  }
+  printf(ok ? "PASS\n" : "FAIL\n");
+  return ok ? 0 : 1;
+}

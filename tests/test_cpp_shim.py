@@ -17,6 +17,7 @@ def build_exe(oracle, name="test_shim"):
     os.makedirs(os.path.dirname(exe), exist_ok=True)
     src = os.path.join(ROOT, "tests", "cpp", name + ".cpp")
     deps = [src, os.path.join(ROOT, "pronto_amd", "csrc", "mav_state_est_batch.hpp"),
+            os.path.join(ROOT, "pronto_amd", "csrc", "pronto_wire.hpp"),
             os.path.join(ROOT, "include", "pronto_batch.h"), _lib.LIB_PATH]
     if os.path.exists(exe) and all(os.path.getmtime(exe) >= os.path.getmtime(d) for d in deps):
         return exe
@@ -48,7 +49,18 @@ def test_smooth_backwards_pass_on_gpu(oracle, n):
     assert r.returncode == 0 and "PASS" in r.stdout, r.stdout + r.stderr
 
 
-@pytest.mark.parametrize("name", ["test_shim", "test_history", "test_atlas_imu", "test_smooth_pass"])
+@pytest.mark.gpu
+def test_lcm_log_replay_and_filter_state_publishing_on_gpu(oracle, tmp_path):
+    """A recorded LCM event log (pronto::indexed_measurement_t, pronto::update_t, raw IMU ticks, foreign channels)
+    replayed into the batch through LogPlayer + the reference's handlers vs the oracle; the head published as
+    pronto::filter_state_t and read back bit-exactly (pronto_wire.hpp)."""
+    exe = build_exe(oracle, "test_log_replay")
+    r = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=300)
+    print(r.stdout, r.stderr)
+    assert r.returncode == 0 and "PASS" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("name", ["test_shim", "test_history", "test_atlas_imu", "test_smooth_pass", "test_log_replay"])
 def test_shim_compiles_and_links(oracle, name):
     exe = build_exe(oracle, name)
     out = subprocess.run(["ldd", exe], capture_output=True, text=True).stdout
