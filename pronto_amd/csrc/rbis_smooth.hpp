@@ -20,6 +20,9 @@
 
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+#include <utility>
+
 #include "rbis_device.hpp"
 
 namespace pb {
@@ -272,6 +275,318 @@ __global__ __launch_bounds__(SmoothCfg<NS>::THREADS) void k_smooth_step(const do
       for (int i = 0; i < 4; i++) out[(long) (L::OFF_QUAT + i) * stride + b] = o[i];
       out[(long) L::OFF_LL * stride + b] = cur[(long) L::OFF_LL * stride + bb];
     }
+  }
+}
+
+// =================================================================================================================
+// k_smooth_step16<NS> (NS <= 15): the same step with the factorisation and the substitutions in REGISTERS.
+//
+// The LDS kernel above is a chain of dependent LDS round trips (PMC: 65 % of wave time waiting, ~180 k cycles per
+// wave) at 1.75 waves per SIMD, and its row-per-lane global loads touch 16 component rows x 4 filters per instruction.
+// Here:
+//   * one DPP row (16 lanes) owns one filter, lane r owns matrix row r; values cross lanes with `row_newbcast:n`
+//     (broadcast lane n of every 16-lane row: VALU latency, no LDS) and `row_ror` butterflies (pivot arg-max);
+//   * pivoted LDL^T without physical swaps: at step kk the pivot p is the largest remaining |A_ii| (Eigen's rule, ties
+//     to the smallest CURRENT position so the pivot sequence equals Eigen's with its swaps); lane r takes c_r = A[r][p]
+//     from its own row (A is symmetric: the pivot row A[p][j] is the column c_j held by lane j), l_r = c_r / d, and
+//     updates its whole row with broadcasts of c_j.  L is kept as L[r][kk] (rows by lane, columns in pivot order);
+//   * forward/backward substitution of the lane's own right-hand side (column r of T = Ad P_k) against L published
+//     once to LDS -- read-only broadcast reads that pipeline, nothing dependent on an LDS write; the solution is kept
+//     indexed by ROW, so no permutation is ever applied or undone;
+//   * P^s_row = P_row + (g_row D) G^T with D (packed) and the gain G read as LDS broadcasts;
+//   * 16 filters per 256-thread workgroup: every checkpoint is staged through LDS with filter-fastest (128-byte)
+//     global accesses instead of 4-filter (32-byte) fragments that four different XCDs each fetched.
+// Run-time register indexing (A[r][p], x[p]) is a compare/select chain: VALU work, no memory.
+// =================================================================================================================
+template <int NS>
+struct Smooth16Cfg {
+  static constexpr int F = 16, THREADS = 256;
+  static constexpr int NC = Lay<NS>::NC, PITCH = NC | 1;  // odd pitch: conflict-free filter-fastest staging
+  static constexpr int MAT = NS * NS, NPK = NS * (NS + 1) / 2, DPITCH = NPK | 1;
+  static constexpr int U_DOUBLES = (F * PITCH > F * MAT) ? F * PITCH : F * MAT;  // staging buffer, later L then G
+  static constexpr int LDS_DOUBLES = U_DOUBLES + F * DPITCH;
+};
+
+// compile-time loop: fn(std::integral_constant<int, 0>) ... fn(std::integral_constant<int, N-1>); DPP controls are
+// instruction immediates, so a lane number coming from a loop has to be a template argument
+template <class Fn, int... I>
+__device__ __forceinline__ void static_for_impl(Fn &&fn, std::integer_sequence<int, I...>)
+{
+  (fn(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class Fn>
+__device__ __forceinline__ void static_for(Fn &&fn)
+{
+  static_for_impl(fn, std::make_integer_sequence<int, N>{});
+}
+
+// End of one unrolled step.  Two compiler behaviours each cost hundreds of registers (the first build used 512 + 2 KB of
+// scratch): the scheduler hoists every later step's LDS reads to the top, and GVN keeps a loaded L / D entry alive in a
+// register until its next use in a later phase (L is read by the forward AND the backward substitution, D(a,b) = D(b,a)
+// by two columns).  The scheduling barrier stops the first, the memory clobber makes the re-read a real LDS read.
+__device__ __forceinline__ void step_fence()
+{
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int LANE>
+__device__ __forceinline__ double row_bcast(double v)  // value of lane LANE of this lane's 16-lane row
+{
+  // mov_dpp (no "old" operand): every lane has a valid source under row_newbcast / row_ror, so nothing needs the
+  // zero-initialised destination + hazard nop that update_dpp(0, ...) costs per move
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x150 + LANE, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x150 + LANE, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+template <int S>
+__device__ __forceinline__ int row_ror_i(int v) { return __builtin_amdgcn_mov_dpp(v, 0x120 + S, 0xF, 0xF, true); }
+template <int S>
+__device__ __forceinline__ double row_ror_d(double v)
+{
+  return __hiloint2double(row_ror_i<S>(__double2hiint(v)), row_ror_i<S>(__double2loint(v)));
+}
+template <int NS>
+__device__ __forceinline__ double reg_select(const double (&a)[NS], int p)
+{
+  // a[p] for a run-time p with a in registers.  Written as mask-and-or on the bit patterns, NOT as a chain of
+  // `(p == j) ? a[j] : r`: the compiler folds a select of two array loads into one load through a selected pointer,
+  // which pins the whole array in scratch memory (seen in the first build: 2.2 KB of scratch per lane).
+  unsigned lo = 0u, hi = 0u;
+#pragma unroll
+  for (int j = 0; j < NS; j++) {
+    const unsigned m = (p == j) ? 0xFFFFFFFFu : 0u;
+    lo |= m & (unsigned) __double2loint(a[j]);
+    hi |= m & (unsigned) __double2hiint(a[j]);
+  }
+  return __hiloint2double((int) hi, (int) lo);
+}
+
+// one butterfly stage of the pivot search: keep the larger |d|, on ties the smaller current position
+template <int S>
+__device__ __forceinline__ void pivot_stage(double &cv, double &cs, int &cpos, int &clane)
+{
+  const double ov = row_ror_d<S>(cv), os = row_ror_d<S>(cs);
+  const int opos = row_ror_i<S>(cpos), olane = row_ror_i<S>(clane);
+  const bool take = (ov > cv) || (ov == cv && opos < cpos);
+  cv = take ? ov : cv;
+  cs = take ? os : cs;
+  cpos = take ? opos : cpos;
+  clane = take ? olane : clane;
+}
+
+template <int NS>
+__global__ __launch_bounds__(256) void k_smooth_step16(const double *__restrict__ next_pred,
+                                                       const double *__restrict__ next_sm,
+                                                       const double *__restrict__ cur, double *__restrict__ out,
+                                                       long stride, int B, double dt, Consts k)
+{
+  static_assert(NS <= 15, "one 16-lane DPP row per filter");
+  using L = Lay<NS>;
+  using C = Smooth16Cfg<NS>;
+  constexpr int PITCH = C::PITCH, MAT = C::MAT, DPITCH = C::DPITCH;
+  extern __shared__ double lds[];
+  double *U = lds, *DP = lds + C::U_DOUBLES;
+  const int t = threadIdx.x;
+  const int f = t >> 4, r = t & 15;      // compute mapping: filter slot f (one DPP row), matrix row r
+  const int sf = t & 15, sc = t >> 4;    // staging mapping: filter fastest
+  const long b0 = (long) blockIdx.x * C::F;
+  const long sb = (b0 + sf < B) ? b0 + sf : (long) B - 1;  // slots past the batch end shadow the last filter
+  const bool row = r < NS;
+  const int rr = row ? r : NS - 1;
+  double *Uf = U + f * PITCH;
+  auto stage = [&](const double *src) {
+#pragma unroll 4
+    for (int c = sc; c < L::NC; c += 16) U[sf * PITCH + c] = src[(long) c * stride + sb];
+  };
+
+  // ---- 1. operands through LDS: P^- row, D = P^s - P^- (packed, LDS), residual, P_k row, prior state ----
+  double am[NS], prow[NS];
+  stage(next_pred);
+  __syncthreads();
+  double qp[4];
+#pragma unroll
+  for (int j = 0; j < NS; j++) am[j] = Uf[L::OFF_P + pk_rt(rr, j)];
+#pragma unroll
+  for (int i = 0; i < 4; i++) qp[i] = Uf[L::OFF_QUAT + i];
+  const double xpr = Uf[L::OFF_VEC + rr];
+  __syncthreads();
+  stage(next_sm);
+  __syncthreads();
+  double res;
+  {
+#pragma unroll
+    for (int j = 0; j < NS; j++)
+      if (row && j <= rr) DP[f * DPITCH + pk_rt(rr, j)] = Uf[L::OFF_P + pk_rt(rr, j)] - am[j];
+    double qs[4], dchi[3];
+#pragma unroll
+    for (int i = 0; i < 4; i++) qs[i] = Uf[L::OFF_QUAT + i];
+    subtract_quats(qs, qp, dchi);  // chi = Log(q^-^-1 q^s)   (rbis.cpp:259-261)
+    res = Uf[L::OFF_VEC + rr] - xpr;
+    if (rr >= 6 && rr <= 8) res = (rr == 6) ? dchi[0] : (rr == 7 ? dchi[1] : dchi[2]);
+    if (!row) res = 0.0;
+  }
+  __syncthreads();
+  stage(cur);
+  __syncthreads();
+  double w[3], v[3], q[4];
+#pragma unroll
+  for (int j = 0; j < NS; j++) prow[j] = Uf[L::OFF_P + pk_rt(rr, j)];
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    w[i] = Uf[L::OFF_VEC + i];
+    v[i] = Uf[L::OFF_VEC + 3 + i];
+  }
+#pragma unroll
+  for (int i = 0; i < 4; i++) q[i] = Uf[L::OFF_QUAT + i];
+  const double xcur = Uf[L::OFF_VEC + rr], llcur = Uf[L::OFF_LL];
+  double chi_cur[3];
+#pragma unroll
+  for (int i = 0; i < 3; i++) chi_cur[i] = Uf[L::OFF_VEC + 6 + i];
+  __syncthreads();  // the staging buffer is free: U now holds L, later the gain
+
+  // ---- 2. x = column r of T = Ad P_k = Ad (row r of P_k)^T, Ad = I + dt Ac (rbis.cpp:12-35) ----
+  double x[NS];
+  {
+    double R[9];
+    quat_to_rot(q, R);
+    const double gb[3] = { -k.g * R[6], -k.g * R[7], -k.g * R[8] };
+    const double pv[3] = { prow[3], prow[4], prow[5] }, pc[3] = { prow[6], prow[7], prow[8] };
+#pragma unroll
+    for (int i = 0; i < NS; i++) x[i] = prow[i];
+    const double wxpv[3] = { w[1] * pv[2] - w[2] * pv[1], w[2] * pv[0] - w[0] * pv[2], w[0] * pv[1] - w[1] * pv[0] };
+    const double gxpc[3] = { gb[1] * pc[2] - gb[2] * pc[1], gb[2] * pc[0] - gb[0] * pc[2], gb[0] * pc[1] - gb[1] * pc[0] };
+    const double wxpc[3] = { w[1] * pc[2] - w[2] * pc[1], w[2] * pc[0] - w[0] * pc[2], w[0] * pc[1] - w[1] * pc[0] };
+    const double vxpc[3] = { v[1] * pc[2] - v[2] * pc[1], v[2] * pc[0] - v[0] * pc[2], v[0] * pc[1] - v[1] * pc[0] };
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      const double av = -wxpv[i] + gxpc[i], ac = -wxpc[i];
+      const double ad = R[3 * i] * (pv[0] - vxpc[0]) + R[3 * i + 1] * (pv[1] - vxpc[1]) + R[3 * i + 2] * (pv[2] - vxpc[2]);
+      x[3 + i] = fma(dt, av, x[3 + i]);
+      x[6 + i] = fma(dt, ac, x[6 + i]);
+      x[9 + i] = fma(dt, ad, x[9 + i]);
+    }
+  }
+
+  // ---- 3. pivoted LDL^T of P^-, rows in registers ----
+  double dv[NS];
+  int piv[NS];
+  double *Lf = U + f * MAT;
+  {
+    bool done = !row;            // lane 15 is never a candidate
+    int pos = r;                 // current position of this row under Eigen's swaps (tie-break only)
+    double dg = reg_select<NS>(am, rr);
+    static_for<NS>([&](auto KK) {
+      constexpr int kk = decltype(KK)::value;
+      double cv = done ? -1.0 : fabs(dg), cs = dg;
+      int cpos = pos, clane = r;
+      pivot_stage<1>(cv, cs, cpos, clane);
+      pivot_stage<2>(cv, cs, cpos, clane);
+      pivot_stage<4>(cv, cs, cpos, clane);
+      pivot_stage<8>(cv, cs, cpos, clane);
+      const int p = clane;       // pivot row (= lane), identical in the 16 lanes of the row
+      const double d = cs;
+      piv[kk] = p;
+      dv[kk] = d;
+      // Eigen swaps position kk with the pivot's position: the row sitting at kk inherits the pivot's old position
+      if (!done && pos == kk) pos = cpos;
+      const double c = reg_select<NS>(am, p);  // A[r][p]: this row's entry in the pivot column (= A[p][r])
+      const double l = (!done && r != p && fabs(d) > 0.0) ? c / d : 0.0;
+      static_for<NS>([&](auto J) {
+        constexpr int j = decltype(J)::value;
+        am[j] = fma(-l, row_bcast<j>(c), am[j]);  // A[r][j] -= l_r A[p][j], with A[p][j] = c_j of lane j
+      });
+      dg = fma(-l, c, dg);
+      if (row) Lf[rr * NS + kk] = l;  // 0 for the pivot row itself and for rows pivoted earlier
+      done = done || (r == p);
+      step_fence();
+    });
+  }
+  group_sync();  // L (rows by lane, columns in pivot order) is published; from here it is only read
+
+  // ---- 4. A y = x for this lane's column: forward in pivot order, D^-1, backward; solution indexed by row ----
+  double z[NS];
+  static_for<NS>([&](auto KK) {
+    constexpr int kk = decltype(KK)::value;
+    const double zk = reg_select<NS>(x, piv[kk]);
+    z[kk] = zk;
+#pragma unroll
+    for (int i = 0; i < NS; i++) x[i] = fma(-Lf[i * NS + kk], zk, x[i]);  // L[i][kk] = 0 for rows pivoted at or before kk
+    step_fence();
+  });
+#pragma unroll
+  for (int kk = 0; kk < NS; kk++) z[kk] = (fabs(dv[kk]) > 5.562684646268003e-309) ? z[kk] / dv[kk] : 0.0;  // Eigen: 1/highest
+  double gain[NS];
+#pragma unroll
+  for (int i = 0; i < NS; i++) gain[i] = 0.0;
+  static_for<NS>([&](auto KR) {
+    constexpr int kk = NS - 1 - decltype(KR)::value;
+    double s = z[kk];
+#pragma unroll
+    for (int i = 0; i < NS; i++) s = fma(-Lf[i * NS + kk], gain[i], s);  // rows pivoted after kk are solved, the rest hold 0
+    const int p = piv[kk];
+#pragma unroll
+    for (int i = 0; i < NS; i++) gain[i] = (p == i) ? s : gain[i];
+    step_fence();
+  });
+  // gain[i] = ((P^-)^-1 T[:,r])_i = G[r][i], row r of the smoother gain
+  group_sync();  // every lane of the row is done reading L
+  if (row) {
+#pragma unroll
+    for (int i = 0; i < NS; i++) Lf[rr * NS + i] = gain[i];
+  }
+  group_sync();
+
+  // ---- 5. P^s_row = P_row + (g D) G^T ----
+  {
+    const double *Df = DP + f * DPITCH;
+#pragma unroll
+    for (int bcol = 0; bcol < NS; bcol++) {
+      double ub = 0.0;
+#pragma unroll
+      for (int a = 0; a < NS; a++) ub = fma(gain[a], Df[pk(a, bcol)], ub);
+#pragma unroll
+      for (int m = 0; m < NS; m++) prow[m] = fma(ub, Lf[m * NS + bcol], prow[m]);
+      step_fence();
+    }
+  }
+  // ---- 6. state: dx = G resid; cur.addState(RBIS(dx))  (rbis.cpp:263-265) ----
+  double dx = 0.0;
+  static_for<NS>([&](auto A) {
+    constexpr int a = decltype(A)::value;
+    dx = fma(gain[a], row_bcast<a>(res), dx);
+  });
+  const double dx6 = row_bcast<6>(dx), dx7 = row_bcast<7>(dx), dx8 = row_bcast<8>(dx);
+  __syncthreads();  // all four waves are done with L / G: the buffer becomes the output staging area
+  // Unconditional stores with a selected ADDRESS (entries this lane does not own go to a private dummy slot behind the
+  // staging layout): with the stores inside `if (row && m <= rr)` the compiler sinks all 450 multiply-adds of step 5
+  // into that block, below the barrier, and keeps every LDS operand they need alive (or spilled) until then.
+  static_assert(C::U_DOUBLES >= C::F * PITCH + C::THREADS, "dummy slots behind the staging layout");
+  const int dummy = C::F * PITCH + t;
+#pragma unroll
+  for (int m = 0; m < NS; m++) U[(row && m <= rr) ? f * PITCH + L::OFF_P + pk_rt(rr, m) : dummy] = prow[m];
+  U[(row && !(rr >= 6 && rr <= 8)) ? f * PITCH + L::OFF_VEC + rr : dummy] = xcur + dx;
+  if (r == 0) {
+    double dchi[3] = { dx6, dx7, dx8 };
+    double dq[4] = { 1.0, 0.0, 0.0, 0.0 };
+    fold_chi(dchi, dq, k.chi_tol);  // RBIS(vec) constructor
+    double chi[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) chi[i] = chi_cur[i] + dchi[i];
+    double qq[4] = { q[0], q[1], q[2], q[3] };
+    fold_chi(chi, qq, k.chi_tol);
+    double o[4];
+    quat_mul(qq, dq, o);
+#pragma unroll
+    for (int i = 0; i < 3; i++) Uf[L::OFF_VEC + 6 + i] = chi[i];
+#pragma unroll
+    for (int i = 0; i < 4; i++) Uf[L::OFF_QUAT + i] = o[i];
+    Uf[L::OFF_LL] = llcur;
+  }
+  __syncthreads();
+  if (b0 + sf < B) {
+#pragma unroll 4
+    for (int c = sc; c < L::NC; c += 16) out[(long) c * stride + b0 + sf] = U[sf * PITCH + c];
   }
 }
 
