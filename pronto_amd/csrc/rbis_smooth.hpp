@@ -304,7 +304,7 @@ struct Smooth16Cfg {
   static constexpr int NC = Lay<NS>::NC, PITCH = NC | 1;  // odd pitch: conflict-free filter-fastest staging
   static constexpr int MAT = NS * NS, NPK = NS * (NS + 1) / 2, DPITCH = NPK | 1;
   static constexpr int U_DOUBLES = (F * PITCH > F * MAT) ? F * PITCH : F * MAT;  // staging buffer, later L then G
-  static constexpr int LDS_DOUBLES = U_DOUBLES + F * DPITCH;
+  static constexpr int LDS_DOUBLES = U_DOUBLES + F * DPITCH + F * 16;  // + one pivot-row buffer per filter
 };
 
 // compile-time loop: fn(std::integral_constant<int, 0>) ... fn(std::integral_constant<int, N-1>); DPP controls are
@@ -362,17 +362,15 @@ __device__ __forceinline__ double reg_select(const double (&a)[NS], int p)
   return __hiloint2double((int) hi, (int) lo);
 }
 
-// one butterfly stage of the pivot search: keep the larger |d|, on ties the smaller current position
+// one butterfly stage of the pivot search: keep the larger |d|, on ties the smaller key (= current position * 16 + lane)
 template <int S>
-__device__ __forceinline__ void pivot_stage(double &cv, double &cs, int &cpos, int &clane)
+__device__ __forceinline__ void pivot_stage(double &cs, int &key)
 {
-  const double ov = row_ror_d<S>(cv), os = row_ror_d<S>(cs);
-  const int opos = row_ror_i<S>(cpos), olane = row_ror_i<S>(clane);
-  const bool take = (ov > cv) || (ov == cv && opos < cpos);
-  cv = take ? ov : cv;
+  const double os = row_ror_d<S>(cs);
+  const int okey = row_ror_i<S>(key);
+  const bool take = (fabs(os) > fabs(cs)) || (fabs(os) == fabs(cs) && okey < key);
   cs = take ? os : cs;
-  cpos = take ? opos : cpos;
-  clane = take ? olane : clane;
+  key = take ? okey : key;
 }
 
 template <int NS>
@@ -410,6 +408,7 @@ __global__ __launch_bounds__(256) void k_smooth_step16(const double *__restrict_
 #pragma unroll
   for (int i = 0; i < 4; i++) qp[i] = Uf[L::OFF_QUAT + i];
   const double xpr = Uf[L::OFF_VEC + rr];
+  double dg = Uf[L::OFF_P + pk_rt(rr, rr)];  // own diagonal entry, carried through the factorisation
   __syncthreads();
   stage(next_sm);
   __syncthreads();
@@ -468,74 +467,94 @@ __global__ __launch_bounds__(256) void k_smooth_step16(const double *__restrict_
     }
   }
 
-  // ---- 3. pivoted LDL^T of P^-, rows in registers ----
-  double dv[NS];
+  // ---- 3. pivoted LDL^T of P^-: rows in registers, the pivot row goes round through LDS ----
+  double inv[NS], Lr[NS];
   int piv[NS];
-  double *Lf = U + f * MAT;
+  double *Lf = U + f * MAT;                                      // per-filter n x n scratch: x, then L, then the gain
+  double *Rf = lds + C::U_DOUBLES + C::F * DPITCH + f * 16;      // pivot row of the current step
+  int mypos = 0;                                                  // pivot position of this lane's row
   {
     bool done = !row;            // lane 15 is never a candidate
     int pos = r;                 // current position of this row under Eigen's swaps (tie-break only)
-    double dg = reg_select<NS>(am, rr);
     static_for<NS>([&](auto KK) {
       constexpr int kk = decltype(KK)::value;
-      double cv = done ? -1.0 : fabs(dg), cs = dg;
-      int cpos = pos, clane = r;
-      pivot_stage<1>(cv, cs, cpos, clane);
-      pivot_stage<2>(cv, cs, cpos, clane);
-      pivot_stage<4>(cv, cs, cpos, clane);
-      pivot_stage<8>(cv, cs, cpos, clane);
-      const int p = clane;       // pivot row (= lane), identical in the 16 lanes of the row
-      const double d = cs;
+      double cs = done ? 0.0 : dg;
+      int key = done ? (256 + r) : (pos * 16 + r);
+      pivot_stage<1>(cs, key);
+      pivot_stage<2>(cs, key);
+      pivot_stage<4>(cs, key);
+      pivot_stage<8>(cs, key);
+      const int p = key & 15;    // pivot row (= lane), identical in the 16 lanes of the row
+      const bool is_p = (r == p);
       piv[kk] = p;
-      dv[kk] = d;
+      inv[kk] = (fabs(cs) > 5.562684646268003e-309) ? 1.0 / cs : 0.0;  // Eigen's solve() tolerance: 1/highest
       // Eigen swaps position kk with the pivot's position: the row sitting at kk inherits the pivot's old position
-      if (!done && pos == kk) pos = cpos;
-      const double c = reg_select<NS>(am, p);  // A[r][p]: this row's entry in the pivot column (= A[p][r])
-      const double l = (!done && r != p && fabs(d) > 0.0) ? c / d : 0.0;
-      static_for<NS>([&](auto J) {
-        constexpr int j = decltype(J)::value;
-        am[j] = fma(-l, row_bcast<j>(c), am[j]);  // A[r][j] -= l_r A[p][j], with A[p][j] = c_j of lane j
-      });
+      if (!done && pos == kk) pos = key >> 4;
+      if (is_p) {
+#pragma unroll
+        for (int j = 0; j < NS; j++) Rf[j] = am[j];
+        mypos = kk;
+      }
+      group_sync();
+      const double c = Rf[rr];                                   // A[p][r] (= A[r][p])
+      const double l = (done || is_p) ? 0.0 : c * inv[kk];
+#pragma unroll
+      for (int j = 0; j < NS; j++) am[j] = fma(-l, Rf[j], am[j]);  // A[r][j] -= l_r A[p][j]
       dg = fma(-l, c, dg);
-      if (row) Lf[rr * NS + kk] = l;  // 0 for the pivot row itself and for rows pivoted earlier
-      done = done || (r == p);
+      Lr[kk] = l;                // 0 for the pivot row itself and for rows pivoted earlier
+      done = done || is_p;
+      group_sync();
       step_fence();
     });
   }
-  group_sync();  // L (rows by lane, columns in pivot order) is published; from here it is only read
 
-  // ---- 4. A y = x for this lane's column: forward in pivot order, D^-1, backward; solution indexed by row ----
+  // ---- 4. A y = x for this lane's column.  Run-time indices become run-time LDS ADDRESSES: x goes to pivot order
+  //         through LDS, L is published as the unit lower-triangular factor in pivot order (row mypos = this lane's
+  //         L row), so both substitutions are compile-time triangular loops over read-only broadcast reads ----
+  // (publishing stores are unconditional with a selected address -- lane 15 writes the unused 16th slot of the pivot-row
+  //  buffer -- because the compiler sinks whatever feeds a store inside `if (row)` into that block, see step 6)
   double z[NS];
+  double *const mine = row ? Lf + rr * NS : Rf + 15;
+  const int one = row ? 1 : 0;
+#pragma unroll
+  for (int i = 0; i < NS; i++) mine[one * i] = x[i];
+  group_sync();
+#pragma unroll
+  for (int kk = 0; kk < NS; kk++) z[kk] = Lf[rr * NS + piv[kk]];
+  group_sync();
+  {
+    double *const lrow = row ? Lf + mypos * NS : Rf + 15;
+#pragma unroll
+    for (int kk = 0; kk < NS; kk++) lrow[one * kk] = Lr[kk];
+  }
+  group_sync();
   static_for<NS>([&](auto KK) {
     constexpr int kk = decltype(KK)::value;
-    const double zk = reg_select<NS>(x, piv[kk]);
-    z[kk] = zk;
+    double s = z[kk];
 #pragma unroll
-    for (int i = 0; i < NS; i++) x[i] = fma(-Lf[i * NS + kk], zk, x[i]);  // L[i][kk] = 0 for rows pivoted at or before kk
-    step_fence();
+    for (int m = 0; m < kk; m++) s = fma(-Lf[kk * NS + m], z[m], s);
+    z[kk] = s;
+    if constexpr (kk == 4 || kk == 8 || kk == 11 || kk == NS - 1) step_fence();
   });
 #pragma unroll
-  for (int kk = 0; kk < NS; kk++) z[kk] = (fabs(dv[kk]) > 5.562684646268003e-309) ? z[kk] / dv[kk] : 0.0;  // Eigen: 1/highest
-  double gain[NS];
-#pragma unroll
-  for (int i = 0; i < NS; i++) gain[i] = 0.0;
+  for (int kk = 0; kk < NS; kk++) z[kk] *= inv[kk];
   static_for<NS>([&](auto KR) {
     constexpr int kk = NS - 1 - decltype(KR)::value;
     double s = z[kk];
 #pragma unroll
-    for (int i = 0; i < NS; i++) s = fma(-Lf[i * NS + kk], gain[i], s);  // rows pivoted after kk are solved, the rest hold 0
-    const int p = piv[kk];
-#pragma unroll
-    for (int i = 0; i < NS; i++) gain[i] = (p == i) ? s : gain[i];
-    step_fence();
+    for (int m = kk + 1; m < NS; m++) s = fma(-Lf[m * NS + kk], z[m], s);
+    z[kk] = s;
+    if constexpr (kk == 10 || kk == 6 || kk == 3 || kk == 0) step_fence();
   });
-  // gain[i] = ((P^-)^-1 T[:,r])_i = G[r][i], row r of the smoother gain
   group_sync();  // every lane of the row is done reading L
-  if (row) {
+  // z[kk] = ((P^-)^-1 T[:,r])_{piv[kk]} = G[r][piv[kk]]: row r of the smoother gain, back in row order
 #pragma unroll
-    for (int i = 0; i < NS; i++) Lf[rr * NS + i] = gain[i];
-  }
+  for (int kk = 0; kk < NS; kk++) mine[one * piv[kk]] = z[kk];
   group_sync();
+  double gain[NS];
+#pragma unroll
+  for (int i = 0; i < NS; i++) gain[i] = Lf[rr * NS + i];
+  step_fence();
 
   // ---- 5. P^s_row = P_row + (g D) G^T ----
   {
