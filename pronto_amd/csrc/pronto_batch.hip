@@ -38,7 +38,7 @@ struct pb_ctx {
   bool have_state = false;
   bool coop15 = false;  // PRONTO_BATCH_COOP15=1: run the 15-state step on the two-wave cooperative kernel (A/B switch)
   int mem_hint = 0;     // MH_* cache policy of the step kernels' state round trip (PRONTO_BATCH_MEMHINT=0/1/2 forces it)
-  bool smooth_lds = false;  // PRONTO_BATCH_SMOOTH_LDS=1: 15-state smoother on the LDS kernel instead of the register one
+  bool smooth_lds = false;  // PRONTO_BATCH_SMOOTH_LDS=1: smoother on the first (LDS-resident) kernel, for A/B runs
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   char err[512] = { 0 };
 };
@@ -785,10 +785,16 @@ extern "C" int pb_smooth_step(pb_ctx *c, int slot_next_pred, int slot_next, int 
   const double *np_ = c->hist + (size_t) slot_next_pred * n, *ns_ = c->hist + (size_t) slot_next * n;
   const double *cu = c->hist + (size_t) slot_cur * n;
   double *out = c->hist + (size_t) slot_out * n;
-  if (c->ns == 15 && !c->smooth_lds) {
-    using S = Smooth16Cfg<15>;  // factorisation in registers (one DPP row per filter), 16 filters per workgroup
-    k_smooth_step16<15><<<(c->B + S::F - 1) / S::F, S::THREADS, sizeof(double) * S::LDS_DOUBLES, c->stream>>>(
-        np_, ns_, cu, out, c->stride, c->B, dt, c->k);
+  if (!c->smooth_lds) {  // factorisation in registers, run-time indices as LDS addresses (rbis_smooth.hpp)
+    if (c->ns == 15) {
+      using S = SmoothRegCfg<15>;
+      k_smooth_reg<15><<<(c->B + S::F - 1) / S::F, S::THREADS, sizeof(double) * S::LDS_DOUBLES, c->stream>>>(
+          np_, ns_, cu, out, c->stride, c->B, dt, c->k);
+    } else {
+      using S = SmoothRegCfg<21>;
+      k_smooth_reg<21><<<(c->B + S::F - 1) / S::F, S::THREADS, sizeof(double) * S::LDS_DOUBLES, c->stream>>>(
+          np_, ns_, cu, out, c->stride, c->B, dt, c->k);
+    }
   } else if (c->ns == 15) {
     using S = SmoothCfg<15>;
     k_smooth_step<15><<<(c->B + S::F - 1) / S::F, S::THREADS, sizeof(double) * S::PER_FILTER * S::F, c->stream>>>(

@@ -279,36 +279,42 @@ __global__ __launch_bounds__(SmoothCfg<NS>::THREADS) void k_smooth_step(const do
 }
 
 // =================================================================================================================
-// k_smooth_step16<NS> (NS <= 15): the same step with the factorisation and the substitutions in REGISTERS.
+// k_smooth_reg<NS>: the same step with the factorisation in REGISTERS and every run-time index turned into an LDS
+// ADDRESS.  This is the kernel pb_smooth_step launches; k_smooth_step above is kept as the A/B reference
+// (PRONTO_BATCH_SMOOTH_LDS=1).
 //
-// The LDS kernel above is a chain of dependent LDS round trips (PMC: 65 % of wave time waiting, ~180 k cycles per
-// wave) at 1.75 waves per SIMD, and its row-per-lane global loads touch 16 component rows x 4 filters per instruction.
-// Here:
-//   * one DPP row (16 lanes) owns one filter, lane r owns matrix row r; values cross lanes with `row_newbcast:n`
-//     (broadcast lane n of every 16-lane row: VALU latency, no LDS) and `row_ror` butterflies (pivot arg-max);
-//   * pivoted LDL^T without physical swaps: at step kk the pivot p is the largest remaining |A_ii| (Eigen's rule, ties
-//     to the smallest CURRENT position so the pivot sequence equals Eigen's with its swaps); lane r takes c_r = A[r][p]
-//     from its own row (A is symmetric: the pivot row A[p][j] is the column c_j held by lane j), l_r = c_r / d, and
-//     updates its whole row with broadcasts of c_j.  L is kept as L[r][kk] (rows by lane, columns in pivot order);
-//   * forward/backward substitution of the lane's own right-hand side (column r of T = Ad P_k) against L published
-//     once to LDS -- read-only broadcast reads that pipeline, nothing dependent on an LDS write; the solution is kept
-//     indexed by ROW, so no permutation is ever applied or undone;
-//   * P^s_row = P_row + (g_row D) G^T with D (packed) and the gain G read as LDS broadcasts;
-//   * 16 filters per 256-thread workgroup: every checkpoint is staged through LDS with filter-fastest (128-byte)
-//     global accesses instead of 4-filter (32-byte) fragments that four different XCDs each fetched.
-// Run-time register indexing (A[r][p], x[p]) is a compare/select chain: VALU work, no memory.
+// The LDS kernel is a chain of dependent LDS read-modify-write round trips (PMC: 65 % of wave time waiting, ~180 k
+// cycles per wave) at 1.75 waves per SIMD, and its row-per-lane global loads touch 16 component rows x 4 filters per
+// instruction, each 128-byte line fetched by four workgroups on four XCDs.  Here:
+//   * G = 16 (n = 15) or 32 (n = 21) lanes own one filter, lane r owns matrix row r, 256-thread workgroups of 16 / 8
+//     filters; every checkpoint is staged through LDS with filter-fastest global accesses;
+//   * pivoted LDL^T without swaps: rows stay in their lanes' registers.  Step kk: butterfly arg-max of the remaining
+//     |A_ii| (DPP row rotations; Eigen's rule, ties to the smallest CURRENT position so that the pivot sequence is
+//     Eigen's with its swaps), the pivot lane writes its row to LDS, every lane reads it back (broadcast), takes
+//     l_r = A[p][r] / d and updates its row.  One LDS round trip per step, nothing is read-modify-written in LDS;
+//   * no run-time register index anywhere: x is put in pivot order by reading LDS at address piv[kk]; L is published as
+//     the unit lower-triangular factor in pivot order (lane r writes row mypos), so forward and backward substitution
+//     are compile-time triangular loops over read-only broadcast reads; the gain row goes back to row order the same way;
+//   * P^s_row = P_row + (g_row D) G^T with D (packed) and the gain G read as LDS broadcasts.
+// Three compiler behaviours had to be fenced off, each worth hundreds of registers (the first build: 512 + 2 KB scratch):
+// select chains over a register array are turned into a load through a selected POINTER (array pinned in scratch);
+// values that only feed a store inside `if (row)` are sunk into that block below everything (their LDS operands stay
+// live); LDS reads of later steps are hoisted / kept alive for a later re-read (step_fence).
 // =================================================================================================================
 template <int NS>
-struct Smooth16Cfg {
-  static constexpr int F = 16, THREADS = 256;
+struct SmoothRegCfg {
+  static constexpr int G = (NS <= 16) ? 16 : 32;  // lanes per filter
+  static constexpr int THREADS = 256, F = THREADS / G;
   static constexpr int NC = Lay<NS>::NC, PITCH = NC | 1;  // odd pitch: conflict-free filter-fastest staging
   static constexpr int MAT = NS * NS, NPK = NS * (NS + 1) / 2, DPITCH = NPK | 1;
-  static constexpr int U_DOUBLES = (F * PITCH > F * MAT) ? F * PITCH : F * MAT;  // staging buffer, later L then G
-  static constexpr int LDS_DOUBLES = U_DOUBLES + F * DPITCH + F * 16;  // + one pivot-row buffer per filter
+  static constexpr int U_DOUBLES = (F * PITCH > F * MAT) ? F * PITCH : F * MAT;  // staging, then x, L, the gain
+  // small per-filter buffer: [0,24) pivot row of the current step (slot NS = dummy for the padding lanes),
+  // [24,48) reciprocal pivots, [48,72) residual, then dx
+  static constexpr int RB = 96, RB_INV = 24, RB_RES = 48, RB_DX = 72;
+  static constexpr int LDS_DOUBLES = F * RB + U_DOUBLES + F * DPITCH;
 };
 
-// compile-time loop: fn(std::integral_constant<int, 0>) ... fn(std::integral_constant<int, N-1>); DPP controls are
-// instruction immediates, so a lane number coming from a loop has to be a template argument
+// compile-time loop: fn(std::integral_constant<int, 0>) ... fn(std::integral_constant<int, N-1>)
 template <class Fn, int... I>
 __device__ __forceinline__ void static_for_impl(Fn &&fn, std::integer_sequence<int, I...>)
 {
@@ -320,25 +326,15 @@ __device__ __forceinline__ void static_for(Fn &&fn)
   static_for_impl(fn, std::make_integer_sequence<int, N>{});
 }
 
-// End of one unrolled step.  Two compiler behaviours each cost hundreds of registers (the first build used 512 + 2 KB of
-// scratch): the scheduler hoists every later step's LDS reads to the top, and GVN keeps a loaded L / D entry alive in a
-// register until its next use in a later phase (L is read by the forward AND the backward substitution, D(a,b) = D(b,a)
-// by two columns).  The scheduling barrier stops the first, the memory clobber makes the re-read a real LDS read.
+// End of one unrolled step: the scheduling barrier keeps later steps' LDS reads from being hoisted to the top, the
+// memory clobber makes a re-read in a later phase a real LDS read instead of a value kept in a register since its first use.
 __device__ __forceinline__ void step_fence()
 {
   asm volatile("" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int LANE>
-__device__ __forceinline__ double row_bcast(double v)  // value of lane LANE of this lane's 16-lane row
-{
-  // mov_dpp (no "old" operand): every lane has a valid source under row_newbcast / row_ror, so nothing needs the
-  // zero-initialised destination + hazard nop that update_dpp(0, ...) costs per move
-  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x150 + LANE, 0xF, 0xF, true);
-  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x150 + LANE, 0xF, 0xF, true);
-  return __hiloint2double(hi, lo);
-}
+// DPP row rotation inside each 16-lane row (mov_dpp has no "old" operand: every lane has a valid source)
 template <int S>
 __device__ __forceinline__ int row_ror_i(int v) { return __builtin_amdgcn_mov_dpp(v, 0x120 + S, 0xF, 0xF, true); }
 template <int S>
@@ -346,57 +342,49 @@ __device__ __forceinline__ double row_ror_d(double v)
 {
   return __hiloint2double(row_ror_i<S>(__double2hiint(v)), row_ror_i<S>(__double2loint(v)));
 }
-template <int NS>
-__device__ __forceinline__ double reg_select(const double (&a)[NS], int p)
+// one butterfly stage of the pivot search: keep the larger |d|, on ties the smaller key (= current position * 32 + lane)
+__device__ __forceinline__ void pivot_take(double &cs, int &key, double os, int okey)
 {
-  // a[p] for a run-time p with a in registers.  Written as mask-and-or on the bit patterns, NOT as a chain of
-  // `(p == j) ? a[j] : r`: the compiler folds a select of two array loads into one load through a selected pointer,
-  // which pins the whole array in scratch memory (seen in the first build: 2.2 KB of scratch per lane).
-  unsigned lo = 0u, hi = 0u;
-#pragma unroll
-  for (int j = 0; j < NS; j++) {
-    const unsigned m = (p == j) ? 0xFFFFFFFFu : 0u;
-    lo |= m & (unsigned) __double2loint(a[j]);
-    hi |= m & (unsigned) __double2hiint(a[j]);
-  }
-  return __hiloint2double((int) hi, (int) lo);
-}
-
-// one butterfly stage of the pivot search: keep the larger |d|, on ties the smaller key (= current position * 16 + lane)
-template <int S>
-__device__ __forceinline__ void pivot_stage(double &cs, int &key)
-{
-  const double os = row_ror_d<S>(cs);
-  const int okey = row_ror_i<S>(key);
-  const bool take = (fabs(os) > fabs(cs)) || (fabs(os) == fabs(cs) && okey < key);
+  // bitwise, not short-circuit: `||` / `&&` became two branches per stage
+  const bool take = (fabs(os) > fabs(cs)) | ((fabs(os) == fabs(cs)) & (okey < key));
   cs = take ? os : cs;
   key = take ? okey : key;
 }
+template <int S>
+__device__ __forceinline__ void pivot_stage(double &cs, int &key)
+{
+  pivot_take(cs, key, row_ror_d<S>(cs), row_ror_i<S>(key));
+}
 
 template <int NS>
-__global__ __launch_bounds__(256) void k_smooth_step16(const double *__restrict__ next_pred,
-                                                       const double *__restrict__ next_sm,
-                                                       const double *__restrict__ cur, double *__restrict__ out,
-                                                       long stride, int B, double dt, Consts k)
+__global__ __launch_bounds__(256) void k_smooth_reg(const double *__restrict__ next_pred,
+                                                    const double *__restrict__ next_sm,
+                                                    const double *__restrict__ cur, double *__restrict__ out,
+                                                    long stride, int B, double dt, Consts k)
 {
-  static_assert(NS <= 15, "one 16-lane DPP row per filter");
   using L = Lay<NS>;
-  using C = Smooth16Cfg<NS>;
-  constexpr int PITCH = C::PITCH, MAT = C::MAT, DPITCH = C::DPITCH;
+  using C = SmoothRegCfg<NS>;
+  constexpr int G = C::G, F = C::F, PITCH = C::PITCH, MAT = C::MAT, DPITCH = C::DPITCH;
+  static_assert(NS < 24 && C::U_DOUBLES >= F * PITCH + C::THREADS, "buffer slots");
   extern __shared__ double lds[];
-  double *U = lds, *DP = lds + C::U_DOUBLES;
+  double *U = lds + F * C::RB, *DP = U + C::U_DOUBLES;  // [small buffers | staging / x / L / gain | D packed]
   const int t = threadIdx.x;
-  const int f = t >> 4, r = t & 15;      // compute mapping: filter slot f (one DPP row), matrix row r
-  const int sf = t & 15, sc = t >> 4;    // staging mapping: filter fastest
-  const long b0 = (long) blockIdx.x * C::F;
+  const int f = t / G, r = t % G;        // compute mapping: filter slot f, matrix row r
+  const int sf = t % F, sc = t / F;      // staging mapping: filter fastest
+  const long b0 = (long) blockIdx.x * F;
   const long sb = (b0 + sf < B) ? b0 + sf : (long) B - 1;  // slots past the batch end shadow the last filter
-  const bool row = r < NS;
+  const bool row = r < NS;               // padding lanes mirror row NS-1 and write only dummy slots
   const int rr = row ? r : NS - 1;
-  double *Uf = U + f * PITCH;
+  double *Uf = U + f * PITCH;            // this filter in the staging layout
+  double *Lf = U + f * MAT;              // this filter's n x n scratch: L by rows, x, L in pivot order, the gain
+  double *Rf = lds + f * C::RB;          // this filter's small buffer
   auto stage = [&](const double *src) {
 #pragma unroll 4
-    for (int c = sc; c < L::NC; c += 16) U[sf * PITCH + c] = src[(long) c * stride + sb];
+    for (int c = sc; c < L::NC; c += G) U[sf * PITCH + c] = src[(long) c * stride + sb];
   };
+  int poff[NS];                          // packed offsets of this lane's row
+#pragma unroll
+  for (int j = 0; j < NS; j++) poff[j] = L::OFF_P + pk_rt(rr, j);
 
   // ---- 1. operands through LDS: P^- row, D = P^s - P^- (packed, LDS), residual, P_k row, prior state ----
   double am[NS], prow[NS];
@@ -404,33 +392,47 @@ __global__ __launch_bounds__(256) void k_smooth_step16(const double *__restrict_
   __syncthreads();
   double qp[4];
 #pragma unroll
-  for (int j = 0; j < NS; j++) am[j] = Uf[L::OFF_P + pk_rt(rr, j)];
+  for (int j = 0; j < NS; j++) am[j] = Uf[poff[j]];
 #pragma unroll
   for (int i = 0; i < 4; i++) qp[i] = Uf[L::OFF_QUAT + i];
   const double xpr = Uf[L::OFF_VEC + rr];
   double dg = Uf[L::OFF_P + pk_rt(rr, rr)];  // own diagonal entry, carried through the factorisation
+  if constexpr (NS == 21) {  // bias-block fix (rbis.cpp:244-251): P^- bias-bias block <- I when a variance is < 1e-11
+    bool fix_g = false, fix_a = false;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      fix_g = fix_g | (Uf[L::OFF_P + pk(15 + i, 15 + i)] < .00000000001);
+      fix_a = fix_a | (Uf[L::OFF_P + pk(18 + i, 18 + i)] < .00000000001);
+    }
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      am[15 + j] = (fix_g & (rr >= 15) & (rr < 18)) ? ((rr - 15 == j) ? 1.0 : 0.0) : am[15 + j];
+      am[18 + j] = (fix_a & (rr >= 18) & (rr < 21)) ? ((rr - 18 == j) ? 1.0 : 0.0) : am[18 + j];
+    }
+    dg = ((fix_g & (rr >= 15) & (rr < 18)) | (fix_a & (rr >= 18) & (rr < 21))) ? 1.0 : dg;
+  }
   __syncthreads();
   stage(next_sm);
   __syncthreads();
-  double res;
   {
+    double *const drow = DP + f * DPITCH;
 #pragma unroll
-    for (int j = 0; j < NS; j++)
-      if (row && j <= rr) DP[f * DPITCH + pk_rt(rr, j)] = Uf[L::OFF_P + pk_rt(rr, j)] - am[j];
+    for (int j = 0; j < NS; j++)  // D = P^s - P^- (after the bias fix, like the reference), lower triangle only
+      if (row && j <= rr) drow[poff[j] - L::OFF_P] = Uf[poff[j]] - am[j];
     double qs[4], dchi[3];
 #pragma unroll
     for (int i = 0; i < 4; i++) qs[i] = Uf[L::OFF_QUAT + i];
     subtract_quats(qs, qp, dchi);  // chi = Log(q^-^-1 q^s)   (rbis.cpp:259-261)
-    res = Uf[L::OFF_VEC + rr] - xpr;
+    double res = Uf[L::OFF_VEC + rr] - xpr;
     if (rr >= 6 && rr <= 8) res = (rr == 6) ? dchi[0] : (rr == 7 ? dchi[1] : dchi[2]);
-    if (!row) res = 0.0;
+    Rf[row ? C::RB_RES + rr : NS] = res;
   }
   __syncthreads();
   stage(cur);
   __syncthreads();
   double w[3], v[3], q[4];
 #pragma unroll
-  for (int j = 0; j < NS; j++) prow[j] = Uf[L::OFF_P + pk_rt(rr, j)];
+  for (int j = 0; j < NS; j++) prow[j] = Uf[poff[j]];
 #pragma unroll
   for (int i = 0; i < 3; i++) {
     w[i] = Uf[L::OFF_VEC + i];
@@ -442,111 +444,118 @@ __global__ __launch_bounds__(256) void k_smooth_step16(const double *__restrict_
   double chi_cur[3];
 #pragma unroll
   for (int i = 0; i < 3; i++) chi_cur[i] = Uf[L::OFF_VEC + 6 + i];
-  __syncthreads();  // the staging buffer is free: U now holds L, later the gain
+  __syncthreads();  // the staging buffer is free from here
 
-  // ---- 2. x = column r of T = Ad P_k = Ad (row r of P_k)^T, Ad = I + dt Ac (rbis.cpp:12-35) ----
-  double x[NS];
-  {
-    double R[9];
-    quat_to_rot(q, R);
-    const double gb[3] = { -k.g * R[6], -k.g * R[7], -k.g * R[8] };
-    const double pv[3] = { prow[3], prow[4], prow[5] }, pc[3] = { prow[6], prow[7], prow[8] };
-#pragma unroll
-    for (int i = 0; i < NS; i++) x[i] = prow[i];
-    const double wxpv[3] = { w[1] * pv[2] - w[2] * pv[1], w[2] * pv[0] - w[0] * pv[2], w[0] * pv[1] - w[1] * pv[0] };
-    const double gxpc[3] = { gb[1] * pc[2] - gb[2] * pc[1], gb[2] * pc[0] - gb[0] * pc[2], gb[0] * pc[1] - gb[1] * pc[0] };
-    const double wxpc[3] = { w[1] * pc[2] - w[2] * pc[1], w[2] * pc[0] - w[0] * pc[2], w[0] * pc[1] - w[1] * pc[0] };
-    const double vxpc[3] = { v[1] * pc[2] - v[2] * pc[1], v[2] * pc[0] - v[0] * pc[2], v[0] * pc[1] - v[1] * pc[0] };
-#pragma unroll
-    for (int i = 0; i < 3; i++) {
-      const double av = -wxpv[i] + gxpc[i], ac = -wxpc[i];
-      const double ad = R[3 * i] * (pv[0] - vxpc[0]) + R[3 * i + 1] * (pv[1] - vxpc[1]) + R[3 * i + 2] * (pv[2] - vxpc[2]);
-      x[3 + i] = fma(dt, av, x[3 + i]);
-      x[6 + i] = fma(dt, ac, x[6 + i]);
-      x[9 + i] = fma(dt, ad, x[9 + i]);
-    }
-  }
-
-  // ---- 3. pivoted LDL^T of P^-: rows in registers, the pivot row goes round through LDS ----
-  double inv[NS], Lr[NS];
+  // ---- 2. pivoted LDL^T of P^-: rows in registers, the pivot row goes round through LDS ----
   int piv[NS];
-  double *Lf = U + f * MAT;                                      // per-filter n x n scratch: x, then L, then the gain
-  double *Rf = lds + C::U_DOUBLES + C::F * DPITCH + f * 16;      // pivot row of the current step
-  int mypos = 0;                                                  // pivot position of this lane's row
+  int mypos = 0;                 // pivot position of this lane's row
+  double *const mine = row ? Lf + rr * NS : Rf + NS;  // this lane's row of the n x n scratch (padding lanes: dummy slot)
+  const int one = row ? 1 : 0;
   {
-    bool done = !row;            // lane 15 is never a candidate
+    bool done = !row;            // padding lanes are never candidates
     int pos = r;                 // current position of this row under Eigen's swaps (tie-break only)
     static_for<NS>([&](auto KK) {
       constexpr int kk = decltype(KK)::value;
       double cs = done ? 0.0 : dg;
-      int key = done ? (256 + r) : (pos * 16 + r);
+      int key = done ? ((1 << 20) + r) : (pos * 32 + r);
       pivot_stage<1>(cs, key);
       pivot_stage<2>(cs, key);
       pivot_stage<4>(cs, key);
       pivot_stage<8>(cs, key);
-      const int p = key & 15;    // pivot row (= lane), identical in the 16 lanes of the row
+      if constexpr (G == 32) pivot_take(cs, key, __shfl_xor(cs, 16), __shfl_xor(key, 16));
+      const int p = key & 31;    // pivot row (= lane of the group), identical in all lanes of the group
       const bool is_p = (r == p);
       piv[kk] = p;
-      inv[kk] = (fabs(cs) > 5.562684646268003e-309) ? 1.0 / cs : 0.0;  // Eigen's solve() tolerance: 1/highest
+      const double inv = (fabs(cs) > 5.562684646268003e-309) ? 1.0 / cs : 0.0;  // Eigen's solve() tolerance: 1/highest
       // Eigen swaps position kk with the pivot's position: the row sitting at kk inherits the pivot's old position
-      if (!done && pos == kk) pos = key >> 4;
+      if (!done && pos == kk) pos = key >> 5;
       if (is_p) {
 #pragma unroll
         for (int j = 0; j < NS; j++) Rf[j] = am[j];
+        Rf[C::RB_INV + kk] = inv;
         mypos = kk;
       }
       group_sync();
       const double c = Rf[rr];                                   // A[p][r] (= A[r][p])
-      const double l = (done || is_p) ? 0.0 : c * inv[kk];
+      const double l = (done || is_p) ? 0.0 : c * inv;
 #pragma unroll
       for (int j = 0; j < NS; j++) am[j] = fma(-l, Rf[j], am[j]);  // A[r][j] -= l_r A[p][j]
       dg = fma(-l, c, dg);
-      Lr[kk] = l;                // 0 for the pivot row itself and for rows pivoted earlier
+      mine[one * kk] = l;        // L[r][kk]: 0 for the pivot row itself and for rows pivoted earlier
       done = done || is_p;
       group_sync();
       step_fence();
     });
   }
 
-  // ---- 4. A y = x for this lane's column.  Run-time indices become run-time LDS ADDRESSES: x goes to pivot order
-  //         through LDS, L is published as the unit lower-triangular factor in pivot order (row mypos = this lane's
-  //         L row), so both substitutions are compile-time triangular loops over read-only broadcast reads ----
-  // (publishing stores are unconditional with a selected address -- lane 15 writes the unused 16th slot of the pivot-row
-  //  buffer -- because the compiler sinks whatever feeds a store inside `if (row)` into that block, see step 6)
+  // ---- 3. right-hand side: x = column r of T = Ad P_k = Ad (row r of P_k)^T, Ad = I + dt Ac (rbis.cpp:12-35) ----
   double z[NS];
-  double *const mine = row ? Lf + rr * NS : Rf + 15;
-  const int one = row ? 1 : 0;
-#pragma unroll
-  for (int i = 0; i < NS; i++) mine[one * i] = x[i];
-  group_sync();
-#pragma unroll
-  for (int kk = 0; kk < NS; kk++) z[kk] = Lf[rr * NS + piv[kk]];
-  group_sync();
   {
-    double *const lrow = row ? Lf + mypos * NS : Rf + 15;
+    double R[9];
+    quat_to_rot(q, R);
+    const double gb[3] = { -k.g * R[6], -k.g * R[7], -k.g * R[8] };
+    const double pv[3] = { prow[3], prow[4], prow[5] }, pc[3] = { prow[6], prow[7], prow[8] };
 #pragma unroll
-    for (int kk = 0; kk < NS; kk++) lrow[one * kk] = Lr[kk];
+    for (int i = 0; i < NS; i++) z[i] = prow[i];
+    // v rows: -w x p_v + g_b x p_chi [- v x p_bg - p_ba];  chi rows: -w x p_chi [- p_bg];  Delta rows: R p_v - R (v x p_chi)
+    const double wxpv[3] = { w[1] * pv[2] - w[2] * pv[1], w[2] * pv[0] - w[0] * pv[2], w[0] * pv[1] - w[1] * pv[0] };
+    const double gxpc[3] = { gb[1] * pc[2] - gb[2] * pc[1], gb[2] * pc[0] - gb[0] * pc[2], gb[0] * pc[1] - gb[1] * pc[0] };
+    const double wxpc[3] = { w[1] * pc[2] - w[2] * pc[1], w[2] * pc[0] - w[0] * pc[2], w[0] * pc[1] - w[1] * pc[0] };
+    const double vxpc[3] = { v[1] * pc[2] - v[2] * pc[1], v[2] * pc[0] - v[0] * pc[2], v[0] * pc[1] - v[1] * pc[0] };
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      double av = -wxpv[i] + gxpc[i], ac = -wxpc[i];
+      if constexpr (NS == 21) {
+        const double pbg[3] = { prow[15], prow[16], prow[17] };
+        const double vxpbg = (i == 0) ? v[1] * pbg[2] - v[2] * pbg[1] : (i == 1 ? v[2] * pbg[0] - v[0] * pbg[2] : v[0] * pbg[1] - v[1] * pbg[0]);
+        av += -vxpbg - prow[18 + i];
+        ac += -pbg[i];
+      }
+      const double ad = R[3 * i] * (pv[0] - vxpc[0]) + R[3 * i + 1] * (pv[1] - vxpc[1]) + R[3 * i + 2] * (pv[2] - vxpc[2]);
+      z[3 + i] = fma(dt, av, z[3 + i]);
+      z[6 + i] = fma(dt, ac, z[6 + i]);
+      z[9 + i] = fma(dt, ad, z[9 + i]);
+    }
   }
-  group_sync();
+
+  // ---- 4. A y = x.  (Publishing stores are unconditional with a selected address -- padding lanes write a dummy slot --
+  //         because whatever only feeds a store inside `if (row)` is sunk into that block, see step 6.) ----
+  {
+    double lrow[NS];             // park this lane's L row while the scratch carries x
+#pragma unroll
+    for (int kk = 0; kk < NS; kk++) lrow[kk] = mine[one * kk];
+    group_sync();
+#pragma unroll
+    for (int i = 0; i < NS; i++) mine[one * i] = z[i];
+    group_sync();
+#pragma unroll
+    for (int kk = 0; kk < NS; kk++) z[kk] = Lf[rr * NS + piv[kk]];  // x in pivot order
+    group_sync();
+    double *const prow_l = row ? Lf + mypos * NS : Rf + NS;
+#pragma unroll
+    for (int kk = 0; kk < NS; kk++) prow_l[one * kk] = lrow[kk];     // L in pivot order: unit lower triangular
+    group_sync();
+  }
   static_for<NS>([&](auto KK) {
     constexpr int kk = decltype(KK)::value;
     double s = z[kk];
 #pragma unroll
     for (int m = 0; m < kk; m++) s = fma(-Lf[kk * NS + m], z[m], s);
     z[kk] = s;
-    if constexpr (kk == 4 || kk == 8 || kk == 11 || kk == NS - 1) step_fence();
+    if constexpr (kk % 4 == 3 || kk == NS - 1) step_fence();
   });
 #pragma unroll
-  for (int kk = 0; kk < NS; kk++) z[kk] *= inv[kk];
+  for (int kk = 0; kk < NS; kk++) z[kk] *= Rf[C::RB_INV + kk];
+  step_fence();
   static_for<NS>([&](auto KR) {
     constexpr int kk = NS - 1 - decltype(KR)::value;
     double s = z[kk];
 #pragma unroll
     for (int m = kk + 1; m < NS; m++) s = fma(-Lf[m * NS + kk], z[m], s);
     z[kk] = s;
-    if constexpr (kk == 10 || kk == 6 || kk == 3 || kk == 0) step_fence();
+    if constexpr (kk % 4 == 0) step_fence();
   });
-  group_sync();  // every lane of the row is done reading L
+  group_sync();  // every lane of the group is done reading L
   // z[kk] = ((P^-)^-1 T[:,r])_{piv[kk]} = G[r][piv[kk]]: row r of the smoother gain, back in row order
 #pragma unroll
   for (int kk = 0; kk < NS; kk++) mine[one * piv[kk]] = z[kk];
@@ -571,22 +580,19 @@ __global__ __launch_bounds__(256) void k_smooth_step16(const double *__restrict_
   }
   // ---- 6. state: dx = G resid; cur.addState(RBIS(dx))  (rbis.cpp:263-265) ----
   double dx = 0.0;
-  static_for<NS>([&](auto A) {
-    constexpr int a = decltype(A)::value;
-    dx = fma(gain[a], row_bcast<a>(res), dx);
-  });
-  const double dx6 = row_bcast<6>(dx), dx7 = row_bcast<7>(dx), dx8 = row_bcast<8>(dx);
-  __syncthreads();  // all four waves are done with L / G: the buffer becomes the output staging area
-  // Unconditional stores with a selected ADDRESS (entries this lane does not own go to a private dummy slot behind the
-  // staging layout): with the stores inside `if (row && m <= rr)` the compiler sinks all 450 multiply-adds of step 5
-  // into that block, below the barrier, and keeps every LDS operand they need alive (or spilled) until then.
-  static_assert(C::U_DOUBLES >= C::F * PITCH + C::THREADS, "dummy slots behind the staging layout");
-  const int dummy = C::F * PITCH + t;
 #pragma unroll
-  for (int m = 0; m < NS; m++) U[(row && m <= rr) ? f * PITCH + L::OFF_P + pk_rt(rr, m) : dummy] = prow[m];
+  for (int a = 0; a < NS; a++) dx = fma(gain[a], Rf[C::RB_RES + a], dx);
+  Rf[row ? C::RB_DX + rr : NS] = dx;
+  __syncthreads();  // all waves are done with L / G: the buffer becomes the output staging area
+  // Unconditional stores with a selected ADDRESS (entries this lane does not own go to a private dummy slot behind the
+  // staging layout): with the stores inside `if (row && m <= rr)` the compiler sinks all the multiply-adds of step 5
+  // into that block, below the barrier, and keeps every LDS operand they need alive (or spilled) until then.
+  const int dummy = F * PITCH + t;
+#pragma unroll
+  for (int m = 0; m < NS; m++) U[(row && m <= rr) ? f * PITCH + poff[m] : dummy] = prow[m];
   U[(row && !(rr >= 6 && rr <= 8)) ? f * PITCH + L::OFF_VEC + rr : dummy] = xcur + dx;
   if (r == 0) {
-    double dchi[3] = { dx6, dx7, dx8 };
+    double dchi[3] = { Rf[C::RB_DX + 6], Rf[C::RB_DX + 7], Rf[C::RB_DX + 8] };
     double dq[4] = { 1.0, 0.0, 0.0, 0.0 };
     fold_chi(dchi, dq, k.chi_tol);  // RBIS(vec) constructor
     double chi[3];
@@ -605,7 +611,7 @@ __global__ __launch_bounds__(256) void k_smooth_step16(const double *__restrict_
   __syncthreads();
   if (b0 + sf < B) {
 #pragma unroll 4
-    for (int c = sc; c < L::NC; c += 16) out[(long) c * stride + b0 + sf] = U[sf * PITCH + c];
+    for (int c = sc; c < L::NC; c += G) out[(long) c * stride + b0 + sf] = U[sf * PITCH + c];
   }
 }
 
