@@ -38,6 +38,7 @@ struct pb_ctx {
   bool have_state = false;
   bool coop15 = false;  // PRONTO_BATCH_COOP15=1: run the 15-state step on the two-wave cooperative kernel (A/B switch)
   int mem_hint = 0;     // MH_* cache policy of the step kernels' state round trip (PRONTO_BATCH_MEMHINT=0/1/2 forces it)
+  bool smooth_attr = false;  // dynamic-LDS limit of the smoother kernels raised on this device
   bool smooth_lds = false;  // PRONTO_BATCH_SMOOTH_LDS=1: smoother on the first (LDS-resident) kernel, for A/B runs
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   char err[512] = { 0 };
@@ -786,6 +787,13 @@ extern "C" int pb_smooth_step(pb_ctx *c, int slot_next_pred, int slot_next, int 
   const double *cu = c->hist + (size_t) slot_cur * n;
   double *out = c->hist + (size_t) slot_out * n;
   if (!c->smooth_lds) {  // factorisation in registers, run-time indices as LDS addresses (rbis_smooth.hpp)
+    if (!c->smooth_attr) {  // more than the default 64 KB of dynamic LDS per workgroup
+      HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_smooth_reg<15>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int) (sizeof(double) * SmoothRegCfg<15>::LDS_DOUBLES)));
+      HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_smooth_reg<21>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int) (sizeof(double) * SmoothRegCfg<21>::LDS_DOUBLES)));
+      c->smooth_attr = true;
+    }
     if (c->ns == 15) {
       using S = SmoothRegCfg<15>;
       k_smooth_reg<15><<<(c->B + S::F - 1) / S::F, S::THREADS, sizeof(double) * S::LDS_DOUBLES, c->stream>>>(

@@ -306,13 +306,35 @@ struct SmoothRegCfg {
   static constexpr int G = (NS <= 16) ? 16 : 32;  // lanes per filter
   static constexpr int THREADS = 256, F = THREADS / G;
   static constexpr int NC = Lay<NS>::NC, PITCH = NC | 1;  // odd pitch: conflict-free filter-fastest staging
-  static constexpr int MAT = NS * NS, NPK = NS * (NS + 1) / 2, DPITCH = NPK | 1;
-  static constexpr int U_DOUBLES = (F * PITCH > F * MAT) ? F * PITCH : F * MAT;  // staging, then x, L, the gain
-  // small per-filter buffer: [0,24) pivot row of the current step (slot NS = dummy for the padding lanes),
-  // [24,48) reciprocal pivots, [48,72) residual, then dx
-  static constexpr int RB = 96, RB_INV = 24, RB_RES = 48, RB_DX = 72;
-  static constexpr int LDS_DOUBLES = F * RB + U_DOUBLES + F * DPITCH;
+  // Strides = 2 (mod 4) doubles, i.e. 4 (mod 8) dwords, everywhere a stride separates things that are accessed together:
+  //  * row pitch PG of the n x n scratch matrices: even, so rows are 16-byte aligned and are read with ds_read_b128
+  //    (16 B per lane in 4 LDS cycles; the compiler's ds_read2_b64 for the same bytes takes 16), and NOT a multiple of
+  //    16 dwords, so the lanes of a group reading or writing one COLUMN (lane = row) fall on distinct banks -- a pitch
+  //    of 16 doubles for n = 15 made every such access a 16-way conflict (PMC: half of all LDS cycles);
+  //  * per-filter strides: the 64/G filters of one wave read their rows as 16-byte broadcasts at the same time; with
+  //    4 (mod 8) dwords between them their 4-bank groups never coincide.
+  static constexpr int bank_stride(int x) { return (x % 4 == 2) ? x : x + ((6 - x % 4) % 4); }
+  static constexpr int PG = bank_stride(NS), MATP = NS * PG;
+  static constexpr int U_PER = bank_stride((PITCH + 1 > MATP) ? PITCH + 1 : MATP);  // staging, then L, x, L, L^T, gain^T
+  static constexpr int U_DOUBLES = F * U_PER;
+  static constexpr int D_PER = bank_stride(MATP);  // D = P^s - P^- (full, row pitch PG)
+  // small per-filter buffer of four RBW-wide slots: pivot row of the current step (entry NS = dummy for the padding
+  // lanes), reciprocal pivots, residual, dx
+  static constexpr int RBW = (NS + 2) & ~1, RB_INV = RBW, RB_RES = 2 * RBW, RB_DX = 3 * RBW, RB = bank_stride(4 * RBW);
+  static constexpr int LDS_DOUBLES = F * RB + U_DOUBLES + F * D_PER;
 };
+
+typedef double d2_t __attribute__((ext_vector_type(2)));
+// 16-byte LDS access: p must be an even number of doubles from the (16-byte aligned) start of LDS
+__device__ __forceinline__ d2_t lds_ld2(const double *p)
+{
+  return *reinterpret_cast<const d2_t *>(__builtin_assume_aligned(p, 16));
+}
+__device__ __forceinline__ void lds_st2(double *p, double a, double b)
+{
+  d2_t v = { a, b };
+  *reinterpret_cast<d2_t *>(__builtin_assume_aligned(p, 16)) = v;
+}
 
 // compile-time loop: fn(std::integral_constant<int, 0>) ... fn(std::integral_constant<int, N-1>)
 template <class Fn, int... I>
@@ -357,16 +379,16 @@ __device__ __forceinline__ void pivot_stage(double &cs, int &key)
 }
 
 template <int NS>
-__global__ __launch_bounds__(256) void k_smooth_reg(const double *__restrict__ next_pred,
+__global__ __launch_bounds__(256, 2) void k_smooth_reg(const double *__restrict__ next_pred,
                                                     const double *__restrict__ next_sm,
                                                     const double *__restrict__ cur, double *__restrict__ out,
                                                     long stride, int B, double dt, Consts k)
 {
   using L = Lay<NS>;
   using C = SmoothRegCfg<NS>;
-  constexpr int G = C::G, F = C::F, PITCH = C::PITCH, MAT = C::MAT, DPITCH = C::DPITCH;
+  constexpr int G = C::G, F = C::F, PITCH = C::PITCH, PG = C::PG, MATP = C::MATP;
   static_assert(NS < 24 && C::U_DOUBLES >= F * PITCH + C::THREADS, "buffer slots");
-  extern __shared__ double lds[];
+  extern __shared__ __attribute__((aligned(16))) double lds[];
   double *U = lds + F * C::RB, *DP = U + C::U_DOUBLES;  // [small buffers | staging / x / L / gain | D packed]
   const int t = threadIdx.x;
   const int f = t / G, r = t % G;        // compute mapping: filter slot f, matrix row r
@@ -376,7 +398,8 @@ __global__ __launch_bounds__(256) void k_smooth_reg(const double *__restrict__ n
   const bool row = r < NS;               // padding lanes mirror row NS-1 and write only dummy slots
   const int rr = row ? r : NS - 1;
   double *Uf = U + f * PITCH;            // this filter in the staging layout
-  double *Lf = U + f * MAT;              // this filter's n x n scratch: L by rows, x, L in pivot order, the gain
+  double *Lf = U + f * C::U_PER;         // this filter's n x n scratch (row pitch PG)
+  double *Df = DP + f * C::D_PER;        // this filter's D = P^s - P^-
   double *Rf = lds + f * C::RB;          // this filter's small buffer
   auto stage = [&](const double *src) {
 #pragma unroll 4
@@ -415,10 +438,12 @@ __global__ __launch_bounds__(256) void k_smooth_reg(const double *__restrict__ n
   stage(next_sm);
   __syncthreads();
   {
-    double *const drow = DP + f * DPITCH;
+    // D = P^s - P^- (after the bias fix, like the reference): every lane its full row, bitwise symmetric because both
+    // (r,j) and (j,r) subtract the same two packed entries
+    double *const drow = row ? Df + rr * PG : Rf;  // padding lanes: the pivot-row buffer is not in use yet
 #pragma unroll
-    for (int j = 0; j < NS; j++)  // D = P^s - P^- (after the bias fix, like the reference), lower triangle only
-      if (row && j <= rr) drow[poff[j] - L::OFF_P] = Uf[poff[j]] - am[j];
+    for (int j = 0; j + 1 < NS; j += 2) lds_st2(drow + j, Uf[poff[j]] - am[j], Uf[poff[j + 1]] - am[j + 1]);
+    if (NS & 1) drow[NS - 1] = Uf[poff[NS - 1]] - am[NS - 1];
     double qs[4], dchi[3];
 #pragma unroll
     for (int i = 0; i < 4; i++) qs[i] = Uf[L::OFF_QUAT + i];
@@ -449,7 +474,7 @@ __global__ __launch_bounds__(256) void k_smooth_reg(const double *__restrict__ n
   // ---- 2. pivoted LDL^T of P^-: rows in registers, the pivot row goes round through LDS ----
   int piv[NS];
   int mypos = 0;                 // pivot position of this lane's row
-  double *const mine = row ? Lf + rr * NS : Rf + NS;  // this lane's row of the n x n scratch (padding lanes: dummy slot)
+  double *const mine = row ? Lf + rr * PG : Rf + NS;  // this lane's row of the n x n scratch (padding lanes: dummy slot)
   const int one = row ? 1 : 0;
   {
     bool done = !row;            // padding lanes are never candidates
@@ -471,7 +496,8 @@ __global__ __launch_bounds__(256) void k_smooth_reg(const double *__restrict__ n
       if (!done && pos == kk) pos = key >> 5;
       if (is_p) {
 #pragma unroll
-        for (int j = 0; j < NS; j++) Rf[j] = am[j];
+        for (int j = 0; j + 1 < NS; j += 2) lds_st2(Rf + j, am[j], am[j + 1]);
+        if (NS & 1) Rf[NS - 1] = am[NS - 1];
         Rf[C::RB_INV + kk] = inv;
         mypos = kk;
       }
@@ -479,7 +505,11 @@ __global__ __launch_bounds__(256) void k_smooth_reg(const double *__restrict__ n
       const double c = Rf[rr];                                   // A[p][r] (= A[r][p])
       const double l = (done || is_p) ? 0.0 : c * inv;
 #pragma unroll
-      for (int j = 0; j < NS; j++) am[j] = fma(-l, Rf[j], am[j]);  // A[r][j] -= l_r A[p][j]
+      for (int j = 0; j < NS; j += 2) {                          // A[r][j] -= l_r A[p][j]
+        const d2_t pr = lds_ld2(Rf + j);
+        am[j] = fma(-l, pr.x, am[j]);
+        if (j + 1 < NS) am[j + 1] = fma(-l, pr.y, am[j + 1]);
+      }
       dg = fma(-l, c, dg);
       mine[one * kk] = l;        // L[r][kk]: 0 for the pivot row itself and for rows pivoted earlier
       done = done || is_p;
@@ -520,63 +550,89 @@ __global__ __launch_bounds__(256) void k_smooth_reg(const double *__restrict__ n
 
   // ---- 4. A y = x.  (Publishing stores are unconditional with a selected address -- padding lanes write a dummy slot --
   //         because whatever only feeds a store inside `if (row)` is sunk into that block, see step 6.) ----
+  double lrow[NS];               // this lane's L row, parked while the scratch carries x
+#pragma unroll
+  for (int kk = 0; kk < NS; kk++) lrow[kk] = mine[one * kk];
+  group_sync();
+#pragma unroll
+  for (int i = 0; i < NS; i++) mine[one * i] = z[i];
+  group_sync();
+#pragma unroll
+  for (int kk = 0; kk < NS; kk++) z[kk] = Lf[rr * PG + piv[kk]];   // x in pivot order
+  group_sync();
   {
-    double lrow[NS];             // park this lane's L row while the scratch carries x
+    double *const lp = row ? Lf + mypos * PG : Rf + NS;
 #pragma unroll
-    for (int kk = 0; kk < NS; kk++) lrow[kk] = mine[one * kk];
-    group_sync();
-#pragma unroll
-    for (int i = 0; i < NS; i++) mine[one * i] = z[i];
-    group_sync();
-#pragma unroll
-    for (int kk = 0; kk < NS; kk++) z[kk] = Lf[rr * NS + piv[kk]];  // x in pivot order
-    group_sync();
-    double *const prow_l = row ? Lf + mypos * NS : Rf + NS;
-#pragma unroll
-    for (int kk = 0; kk < NS; kk++) prow_l[one * kk] = lrow[kk];     // L in pivot order: unit lower triangular
-    group_sync();
+    for (int kk = 0; kk < NS; kk++) lp[one * kk] = lrow[kk];       // L in pivot order: unit lower triangular, by rows
   }
-  static_for<NS>([&](auto KK) {
+  group_sync();
+  static_for<NS>([&](auto KK) {  // forward: z[kk] -= sum_{m<kk} L[kk][m] z[m], row kk read 16 bytes at a time
     constexpr int kk = decltype(KK)::value;
     double s = z[kk];
 #pragma unroll
-    for (int m = 0; m < kk; m++) s = fma(-Lf[kk * NS + m], z[m], s);
+    for (int m = 0; m < kk; m += 2) {
+      const d2_t lv = lds_ld2(Lf + kk * PG + m);
+      s = fma(-lv.x, z[m], s);
+      if (m + 1 < kk) s = fma(-lv.y, z[m + 1], s);
+    }
     z[kk] = s;
     if constexpr (kk % 4 == 3 || kk == NS - 1) step_fence();
   });
 #pragma unroll
   for (int kk = 0; kk < NS; kk++) z[kk] *= Rf[C::RB_INV + kk];
-  step_fence();
-  static_for<NS>([&](auto KR) {
+  group_sync();  // every lane of the group is done reading L by rows
+  {
+    const int col = row ? mypos : NS;  // padding lanes: the pad column of an even pitch, or the dummy slot
+    double *const lt = (row || PG > NS) ? Lf + col : Rf + NS;
+    const int step = (row || PG > NS) ? PG : 0;
+#pragma unroll
+    for (int kk = 0; kk < NS; kk++) lt[step * kk] = lrow[kk];       // L^T by rows: Lt[kk][m] = L[m][kk]
+  }
+  group_sync();
+  static_for<NS>([&](auto KR) {  // backward: z[kk] -= sum_{m>kk} L[m][kk] z[m]
     constexpr int kk = NS - 1 - decltype(KR)::value;
     double s = z[kk];
 #pragma unroll
-    for (int m = kk + 1; m < NS; m++) s = fma(-Lf[m * NS + kk], z[m], s);
+    for (int m = (kk + 1) & ~1; m < NS; m += 2) {
+      const d2_t lv = lds_ld2(Lf + kk * PG + m);
+      if (m > kk) s = fma(-lv.x, z[m], s);
+      if (m + 1 < NS) s = fma(-lv.y, z[m + 1], s);
+    }
     z[kk] = s;
     if constexpr (kk % 4 == 0) step_fence();
   });
-  group_sync();  // every lane of the group is done reading L
-  // z[kk] = ((P^-)^-1 T[:,r])_{piv[kk]} = G[r][piv[kk]]: row r of the smoother gain, back in row order
+  group_sync();  // every lane of the group is done reading L^T
+  // z[kk] = ((P^-)^-1 T[:,r])_{piv[kk]} = G[r][piv[kk]]; published TRANSPOSED (Gt[i][r] = G[r][i]) so that step 5
+  // reads a row, and read back in row order for this lane's own gain row
+  {
+    double *const gt = row ? Lf + rr : Rf + NS;
+    const int step = row ? PG : 0;
 #pragma unroll
-  for (int kk = 0; kk < NS; kk++) mine[one * piv[kk]] = z[kk];
+    for (int kk = 0; kk < NS; kk++) gt[step * piv[kk]] = z[kk];
+  }
   group_sync();
   double gain[NS];
 #pragma unroll
-  for (int i = 0; i < NS; i++) gain[i] = Lf[rr * NS + i];
+  for (int i = 0; i < NS; i++) gain[i] = Lf[i * PG + rr];
   step_fence();
 
-  // ---- 5. P^s_row = P_row + (g D) G^T ----
-  {
-    const double *Df = DP + f * DPITCH;
+  // ---- 5. P^s_row = P_row + (g D) G^T: row bcol of D (symmetric) and row bcol of Gt, 16 bytes at a time ----
 #pragma unroll
-    for (int bcol = 0; bcol < NS; bcol++) {
-      double ub = 0.0;
+  for (int bcol = 0; bcol < NS; bcol++) {
+    double ub = 0.0;
 #pragma unroll
-      for (int a = 0; a < NS; a++) ub = fma(gain[a], Df[pk(a, bcol)], ub);
-#pragma unroll
-      for (int m = 0; m < NS; m++) prow[m] = fma(ub, Lf[m * NS + bcol], prow[m]);
-      step_fence();
+    for (int a = 0; a < NS; a += 2) {
+      const d2_t dvv = lds_ld2(Df + bcol * PG + a);
+      ub = fma(gain[a], dvv.x, ub);
+      if (a + 1 < NS) ub = fma(gain[a + 1], dvv.y, ub);
     }
+#pragma unroll
+    for (int m = 0; m < NS; m += 2) {
+      const d2_t gv = lds_ld2(Lf + bcol * PG + m);
+      prow[m] = fma(ub, gv.x, prow[m]);
+      if (m + 1 < NS) prow[m + 1] = fma(ub, gv.y, prow[m + 1]);
+    }
+    step_fence();
   }
   // ---- 6. state: dx = G resid; cur.addState(RBIS(dx))  (rbis.cpp:263-265) ----
   double dx = 0.0;
