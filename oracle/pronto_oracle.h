@@ -84,7 +84,7 @@ double po_indexed_plus_orientation_measurement(int m, const double *z, const dou
                                                po_rbis *dstate, po_rbim *dcov);    /* rbis.cpp:189-217 */
 void po_apply_delta(const po_rbis *prior, const po_rbim *prior_cov, const po_rbis *dstate, const po_rbim *dcov,
                     po_rbis *post, po_rbim *post_cov);                             /* rbis.cpp:219-227 */
-/* rbis.cpp:234-266 (RTS smoother step; SURVEY 8f, exercised by oracle self-tests only for now) */
+/* rbis.cpp:234-266 (RTS smoother step; SURVEY 8f rank 2: checks pb_smooth_step in tests/test_smoother.py, tests/cpp/test_smooth_pass.cpp) */
 void po_ekf_smoothing_step(const po_rbis *next_state_pred, const po_rbim *next_cov_pred, const po_rbis *next_state,
                            const po_rbim *next_cov, double dt, po_rbis *cur_state, po_rbim *cur_cov);
 

@@ -6,7 +6,11 @@
 //
 // Unlike the forward step this IS dense n x n work (an SPD solve with n right-hand sides and two dense products,
 // ~40 kflop per 21-state filter against ~8 KB of state: ~5 flop/B, at the fp64 balance point), so one lane per filter
-// is the wrong shape.  Mapping: a GROUP of G = 16 (n=15) or 32 (n=21) lanes owns one filter, lane r owns matrix row r,
+// is the wrong shape.  Two kernels, same mapping idea (a GROUP of G = 16 / 32 lanes owns one filter, lane r owns row r):
+//   k_smooth_reg   (second half of this file) -- the one pb_smooth_step launches: factorisation in registers, 2.6-2.7x
+//                  faster than the first;
+//   k_smooth_step  (below) -- the first version, everything resident in LDS; kept as the A/B reference
+//                  (PRONTO_BATCH_SMOOTH_LDS=1).  Its structure:
 // 4 filters per workgroup.  A group never spans a wave, and a wave's LDS operations execute in order, so the steps
 // below are separated by wave-local ordering only -- no workgroup barrier anywhere.
 //   1. lane r: row r of P_k stays in registers; row r of P^- (bias-fixed) and of D = P^s - P^- go to LDS

@@ -1,4 +1,4 @@
-"""Throughput of the RTS smoother step kernel (k_smooth_step) at BASELINE batch size: 64k filters, wall clock around back-to-back launches + sync."""
+"""Throughput of the RTS smoother step kernel (pb_smooth_step) at BASELINE batch size: 64k filters, wall clock around back-to-back launches + sync."""
 import os
 import sys
 
@@ -33,5 +33,5 @@ for n in (15, 21):
     est.sync()
     ms = (time.perf_counter() - t0) / reps * 1e3
     nbytes = (3 * (n * (n + 1) // 2 + n + 4) + (n * (n + 1) // 2 + n + 5)) * 8
-    print("k_smooth_step<%d>: %d filters, %.1f us/step, %.3e filter-steps/s, %.0f GB/s algorithmic (%d B/filter)"
+    print("smoother step (pb_smooth_step), n=%d: %d filters, %.1f us/step, %.3e filter-steps/s, %.0f GB/s algorithmic (%d B/filter)"
           % (n, B, ms * 1e3, B / (ms * 1e-3), nbytes * B / (ms * 1e-3) / 1e9, nbytes))
