@@ -48,7 +48,27 @@ def generate(name):
     return out
 
 
+SMOOTHER_CASES = {"smoother_n15": (15, 8, 24, 1e-3), "smoother_n21": (21, 8, 24, 1e-3)}  # n, B, T, dt
+
+
+def generate_smoother(name):
+    """Smoothed posterior at the first and the middle step of a T-step forward pass + backward recursion."""
+    from smoother_ref import oracle_backward_pass
+    n, B, T, dt = SMOOTHER_CASES[name]
+    w = Workload(B, n_states=n)
+    res = oracle_backward_pass(po, w, n, T, B, dt, keep=(0, T // 2))
+    g, tol = po.constants()
+    out = {"meta": np.array([n, B, T, dt, g, tol])}
+    for tag, k in (("first", 0), ("mid", T // 2)):
+        out["vec_" + tag], out["quat_" + tag], out["cov_" + tag] = res[k]
+    return out
+
+
 if __name__ == "__main__":
+    for name in SMOOTHER_CASES:
+        out = generate_smoother(name)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+        print(name, {k: v.shape for k, v in out.items()})
     for name in CASES:
         out = generate(name)
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)

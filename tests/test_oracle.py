@@ -288,3 +288,18 @@ def test_golden_trajectories(oracle, name):
     tr = w.truth(w.time_s(T))
     assert np.abs(ob.vec[9:12] - tr["pos"]).max() < (0.25 if vo or sm else 1.5)
     assert np.abs(ob.vec[3:6] - tr["vel_b"]).max() < 0.3
+
+
+@pytest.mark.parametrize("n", [15, 21])
+def test_golden_smoother(oracle, n):
+    """The oracle's backward recursion reproduces the committed smoother fixtures on this machine."""
+    from smoother_ref import oracle_backward_pass
+    gold = np.load(os.path.join(GOLD, "smoother_n%d.npz" % n))
+    nn, B, T = (int(v) for v in gold["meta"][:3])
+    assert nn == n and (gold["meta"][4], gold["meta"][5]) == oracle.constants()
+    res = oracle_backward_pass(oracle, Workload(B, n_states=n), n, T, B, float(gold["meta"][3]), keep=(0, T // 2))
+    for tag, k in (("first", 0), ("mid", T // 2)):
+        for got, name in zip(res[k], ("vec_", "quat_", "cov_")):
+            assert rel(got, gold[name + tag]) < 1e-10
+    # smoothing shrinks the position uncertainty of the first step
+    assert np.all(gold["cov_first"][9, 9] > 0)

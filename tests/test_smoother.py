@@ -3,60 +3,18 @@ kernel k_smooth_step on posterior checkpoints against the oracle's dense restate
 
 Tolerance: the step inverts P^-_{k+1} (condition number up to ~1e7 here: variances from 1e-8 to 0.25); both sides use
 LDL^T with the same diagonal pivoting, so they differ by summation order only -- 1e-7 relative is the bound used."""
-import ctypes as C
+import os
 
 import numpy as np
 import pytest
 
-from util import embed21, rel
+from smoother_ref import oracle_backward_pass, oracle_forward, oracle_smooth_step
+from util import rel
 
 from pronto_amd.synth import Workload
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-7
-
-
-def oracle_forward(oracle, w, n, T, B):
-    """Forward pass with the oracle, keeping (pred, filtered) posteriors of every step (INS update, then legodo)."""
-    vec, quat, P0 = w.initial_state()
-    v21, P21 = embed21(vec, P0)
-    ob = oracle.OracleBatch(v21, quat, P21)
-    q4 = w.process_noise()
-    hist = []
-    for k in range(T):
-        imu = w.imu_block(k)
-        lo, mask = w.legodo_block(k)
-        ob.predict(imu, q4)
-        pred = (ob.vec.copy(), ob.quat.copy(), ob.cov.copy())
-        ob.update_indexed([3, 4, 5], lo[0:3], lo[3:6], mask=mask)
-        hist.append((pred, (ob.vec.copy(), ob.quat.copy(), ob.cov.copy())))
-    return hist
-
-
-def oracle_smooth_step(oracle, nxt_pred, nxt, cur, dt):
-    L = oracle.lib()
-    B = cur[0].shape[1]
-    out_v, out_q, out_P = cur[0].copy(), cur[1].copy(), cur[2].copy()
-
-    def mk(v, q, b):
-        s = oracle.Rbis()
-        s.vec[:] = list(v[:, b])
-        s.quat[:] = list(q[:, b])
-        return s
-
-    def mkP(P, b):
-        m = oracle.Rbim()
-        m.m[:] = list(np.ascontiguousarray(P[:, :, b].T).ravel())
-        return m
-    for b in range(B):
-        sp, Pp = mk(nxt_pred[0], nxt_pred[1], b), mkP(nxt_pred[2], b)
-        sn, Pn = mk(nxt[0], nxt[1], b), mkP(nxt[2], b)
-        sc, Pc = mk(cur[0], cur[1], b), mkP(cur[2], b)
-        L.po_ekf_smoothing_step(C.byref(sp), C.byref(Pp), C.byref(sn), C.byref(Pn), dt, C.byref(sc), C.byref(Pc))
-        out_v[:, b] = sc.vec[:]
-        out_q[:, b] = sc.quat[:]
-        out_P[:, :, b] = np.array(Pc.m[:]).reshape(21, 21).T
-    return out_v, out_q, out_P
 
 
 @pytest.mark.parametrize("n", [15, 21])
@@ -117,3 +75,39 @@ def test_smooth_step_identity_when_next_equals_prediction(oracle):
     assert rel(v2, v0) < 1e-12 and rel(q2, q0) < 1e-12 and rel(P2, P0_) < 1e-12
     with pytest.raises(Exception):
         est.smooth_step(1, 1, 0, 1, 1e-3)    # out must not alias a k+1 slot
+
+
+@pytest.mark.parametrize("n", [15, 21])
+def test_backward_pass_matches_golden_fixture(oracle, n):
+    """The committed smoother fixtures (tests/golden/smoother_n*.npz, written by make_golden.py from the oracle): forward
+    pass + full backward recursion on the GPU, compared at the two stored steps."""
+    from pronto_amd.batch import BatchEstimator
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "smoother_n%d.npz" % n))
+    nn, B, T = (int(v) for v in gold["meta"][:3])
+    dt = float(gold["meta"][3])
+    assert nn == n and (gold["meta"][4], gold["meta"][5]) == oracle.constants()
+    w = Workload(B, n_states=n)
+    est = BatchEstimator(B, n_states=n)
+    est.set_constants(*oracle.constants())
+    vec, quat, P0 = w.initial_state()
+    est.reset(vec, quat, P0)
+    est.history_reserve(2 * T + 2)
+    q4 = w.process_noise()
+    for k in range(T):
+        lo, mask = w.legodo_block(k)
+        est.predict(w.imu_block(k), q4)
+        est.state_save(2 * k)
+        est.update_indexed([3, 4, 5], np.ascontiguousarray(lo[0:3]), np.ascontiguousarray(lo[3:6]), mask=mask)
+        est.state_save(2 * k + 1)
+    nxt_slot = 2 * (T - 1) + 1
+    for k in range(T - 2, -1, -1):
+        out_slot = 2 * T + (k % 2)
+        est.smooth_step(2 * (k + 1), nxt_slot, 2 * k + 1, out_slot, dt)
+        nxt_slot = out_slot
+        if k in (T // 2, 0):
+            tag = "mid" if k == T // 2 and k != 0 else "first"
+            est.state_restore(out_slot)
+            v, q, P, ll = est.get_head()
+            assert rel(v, gold["vec_" + tag][:n]) < TOL and rel(q, gold["quat_" + tag]) < TOL
+            assert rel(P, gold["cov_" + tag][:n, :n]) < TOL
+    est.close()
