@@ -164,8 +164,12 @@ def main():
         raise SystemExit("bench.py: no GPU visible; the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # PRONTO_BENCH_FORCE_DIST=1 takes the torch.distributed / RCCL path with a single rank too (a rehearsal of the N > 1
+    # code on a one-GPU box; launch through torch.distributed.run so that the rendezvous variables exist)
+    use_dist = world > 1 or os.environ.get("PRONTO_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     n, K, W = args.n_states, args.steps, args.warmup
@@ -196,7 +200,7 @@ def main():
     est.sync()
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier(device_ids=[local_rank])
 
     # ---- warmup (untimed) ----
@@ -212,11 +216,11 @@ def main():
     barrier()
     t1 = time.perf_counter()
     wall = torch.tensor([t1 - t0, ev_ms * 1e-3], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(wall, op=dist.ReduceOp.MAX)
     wall_s, ev_s = float(wall[0]), float(wall[1])
 
-    summary = allreduce_summary(est.summary(), dist if world > 1 else None, dev)
+    summary = allreduce_summary(est.summary(), dist if use_dist else None, dev)
 
     fused = None
     if args.fused > 0 and n == 15:
@@ -268,7 +272,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(n, dt_us, args.cpu_seconds, BatchEstimator)
         print(json.dumps(out), flush=True)
     est.close()
-    if world > 1:
+    if use_dist:
         dist.barrier(device_ids=[local_rank])
         dist.destroy_process_group()
 
