@@ -17,6 +17,7 @@
  *  - Batched arrays are SoA with the FILTER INDEX FASTEST: element (c, b) of an array [C][B] is at c*B + b.
  *  - `mem` says where the caller's buffers live: PB_HOST (staged through an internal pinned buffer, PCIe
  *    inclusive) or PB_DEVICE (HBM-resident; the kernels read them in place).
+ *    PB_HOST_BROADCAST: host memory with ONE value per row, the same message for every filter (see enum pb_mem).
  *  - fp64 throughout.  State layout is RBIS's (rbis.hpp:22-30): vec = [omega(0-2) v_body(3-5) chi(6-8)
  *    pos(9-11) accel(12-14) | gyro_bias(15-17) accel_bias(18-20)], quat = (w,x,y,z), n_states = 15 keeps
  *    the first 15 (bias states and their covariance pinned to 0).
@@ -42,7 +43,15 @@ enum pb_status {
   PB_ERR_STATE = 4        /* call order (e.g. step before reset, unknown snapshot slot) */
 };
 
-enum pb_mem { PB_HOST = 0, PB_DEVICE = 1 };
+enum pb_mem {
+  PB_HOST = 0,   /* caller's buffers are host memory, [rows][B] */
+  PB_DEVICE = 1, /* caller's buffers are device memory, [rows][B] */
+  /* host memory holding ONE value per row ([rows] doubles): the same message for every filter of the batch, the batch
+   * differing in parameters / initial state only (the reference's own batch use: state-estimator/python/param_sweep.py:39-52
+   * replays one log per parameter set).  The rows are expanded on the device; nothing of batch size crosses PCIe.
+   * Accepted by pb_predict, pb_update_indexed(_orient), pb_step_legodo and pb_compose_delta; mask must be NULL. */
+  PB_HOST_BROADCAST = 2
+};
 
 /* how the measurement covariance R is passed to pb_update_indexed* */
 enum pb_rkind {

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("PRONTO_BATCH_LIB") or os.path.join(_HERE, "lib", "lib
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "pronto_batch.h")
 
 PB_OK, PB_ERR_ARG, PB_ERR_HIP, PB_ERR_NO_DEVICE, PB_ERR_STATE = range(5)
-PB_HOST, PB_DEVICE = 0, 1
+PB_HOST, PB_DEVICE, PB_HOST_BROADCAST = 0, 1, 2
 PB_R_DIAG_BROADCAST, PB_R_DIAG, PB_R_FULL = 0, 1, 2
 
 

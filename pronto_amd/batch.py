@@ -10,7 +10,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import PB_DEVICE, PB_HOST, PB_R_DIAG, PB_R_DIAG_BROADCAST, PB_R_FULL
+from ._lib import PB_DEVICE, PB_HOST, PB_HOST_BROADCAST, PB_R_DIAG, PB_R_DIAG_BROADCAST, PB_R_FULL
 
 
 class PbError(RuntimeError):
@@ -36,6 +36,15 @@ def _ptr(a, dtype=np.float64):
     if not isinstance(a, np.ndarray) or a.dtype != dtype or not a.flags["C_CONTIGUOUS"]:
         raise TypeError("expected a C-contiguous numpy array of %s" % np.dtype(dtype))
     return C.c_void_p(a.ctypes.data), PB_HOST
+
+
+def _ptr_block(a):
+    """Like _ptr for a [rows, B] data block; a 1-D numpy array of `rows` values means ONE message for every filter of the
+    batch (PB_HOST_BROADCAST: expanded on the device, nothing of batch size crosses PCIe)."""
+    if isinstance(a, np.ndarray) and a.ndim == 1:
+        p, _ = _ptr(a)
+        return p, PB_HOST_BROADCAST
+    return _ptr(a)
 
 
 def _same_mem(*mems):
@@ -152,13 +161,15 @@ class BatchEstimator:
         self._chk(self._L.pb_reset(self._h, pv, pq, pc, int(broadcast), _same_mem(m1, m2, m3)))
 
     def predict(self, imu_block, q4):
-        p, m = _ptr(imu_block)
+        p, m = _ptr_block(imu_block)
         q = (C.c_double * 4)(*q4)
         self._chk(self._L.pb_predict(self._h, p, q, m))
 
     def _r(self, R, m):
         if isinstance(R, (list, tuple)) or (isinstance(R, np.ndarray) and R.ndim == 1):
             arr = np.ascontiguousarray(R, dtype=np.float64)
+            if arr.shape == (m * m,) and m > 1:  # one full column-major R for every filter
+                return arr, C.c_void_p(arr.ctypes.data), PB_R_FULL, PB_HOST_BROADCAST
             assert arr.shape == (m,)
             return arr, C.c_void_p(arr.ctypes.data), PB_R_DIAG_BROADCAST, None
         p, mem = _ptr(R)
@@ -170,18 +181,18 @@ class BatchEstimator:
         R: length-m list (broadcast diag), [m,B] per-filter diag, or [m*m,B] full column-major."""
         m = len(idx)
         ia = (C.c_int * m)(*[int(i) for i in idx])
-        pz, mz = _ptr(z)
+        pz, mz = _ptr_block(z)
         _keep, pr, kind, mr = self._r(R, m)
         pm, mm = _ptr(mask, np.uint8)
         if quat_meas is None:
             self._chk(self._L.pb_update_indexed(self._h, m, ia, pz, pr, kind, pm, _same_mem(mz, mr, mm)))
         else:
-            pq, mq = _ptr(quat_meas)
+            pq, mq = _ptr_block(quat_meas)
             self._chk(self._L.pb_update_indexed_orient(self._h, m, ia, pz, pr, kind, pq, pm, _same_mem(mz, mr, mm, mq)))
 
     def step_legodo(self, imu_block, lo_block, mask, q4):
-        pi, m1 = _ptr(imu_block)
-        pl, m2 = _ptr(lo_block)
+        pi, m1 = _ptr_block(imu_block)
+        pl, m2 = _ptr_block(lo_block)
         pm, m3 = _ptr(mask, np.uint8)
         q = (C.c_double * 4)(*q4)
         self._chk(self._L.pb_step_legodo(self._h, pi, pl, pm, q, _same_mem(m1, m2, m3)))
@@ -217,8 +228,8 @@ class BatchEstimator:
         self._chk(self._L.pb_snapshot(self._h, slot))
 
     def compose_delta(self, slot, t, q, z_out, quat_out):
-        pt, m1 = _ptr(t)
-        pq, m2 = _ptr(q)
+        pt, m1 = _ptr_block(t)
+        pq, m2 = _ptr_block(q)
         pz, m3 = _ptr(z_out)
         po_, m4 = _ptr(quat_out)
         if m3 != PB_DEVICE or m4 != PB_DEVICE:

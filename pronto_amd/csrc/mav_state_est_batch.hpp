@@ -199,8 +199,8 @@ public:
       : RBISUpdateInterface(ins, utime), imu_block(imu_block_), q_gyro(q_gyro_), q_accel(q_accel_),
         q_gyro_bias(q_gyro_bias_), q_accel_bias(q_accel_bias_) {}
   RBISIMUProcessStep(std::vector<double> &&block, double q_gyro_, double q_accel_, double q_gyro_bias_,
-                     double q_accel_bias_, int64_t utime)
-      : RBISUpdateInterface(ins, utime), owned(std::move(block)), imu_block(owned.data(), PB_HOST), q_gyro(q_gyro_),
+                     double q_accel_bias_, int64_t utime, int mem = PB_HOST)  // PB_HOST_BROADCAST: block is [7]
+      : RBISUpdateInterface(ins, utime), owned(std::move(block)), imu_block(owned.data(), mem), q_gyro(q_gyro_),
         q_accel(q_accel_), q_gyro_bias(q_gyro_bias_), q_accel_bias(q_accel_bias_) {}
   int updateFilter(pb_ctx *ctx) override
   {
@@ -692,10 +692,13 @@ private:
   RBISUpdateInterface *build(BatchArray gyro, BatchArray accel, double gyro_scale, bool accel_translate, double dt_,
                              int64_t utime, int B)
   {
-    if (gyro.mem != PB_HOST || accel.mem != PB_HOST) {
+    if (gyro.mem == PB_DEVICE || accel.mem == PB_DEVICE || gyro.mem != accel.mem) {
       fprintf(stderr, "InsHandler: sensor-frame inputs must be host arrays (frame rotation is a host pass)\n");
       return nullptr;
     }
+    // PB_HOST_BROADCAST: one IMU for every filter -> rotate once, hand a [7] block over (expanded on the device)
+    const int mem = gyro.mem;
+    if (mem == PB_HOST_BROADCAST) B = 1;
     std::vector<double> blk((size_t) 7 * B);
     const bool ident = ins_to_body.isIdentityRotation();
     for (int b = 0; b < B; b++) {
@@ -717,7 +720,7 @@ private:
       }
       blk[(size_t) 6 * B + b] = dt_;
     }
-    return new RBISIMUProcessStep(std::move(blk), cov_gyro, cov_accel, cov_gyro_bias, cov_accel_bias, utime);
+    return new RBISIMUProcessStep(std::move(blk), cov_gyro, cov_accel, cov_gyro_bias, cov_accel_bias, utime, mem);
   }
 };
 
@@ -915,10 +918,21 @@ public:
 class IndexedMeasurementHandler {
 public:
   explicit IndexedMeasurementHandler(RBISUpdateInterface::sensor_enum this_sensor) : indexed_sensor(this_sensor) {}
-  RBISUpdateInterface *processMessage(const msgs::indexed_measurement_t *msg, MavStateEstimator *)
+  RBISUpdateInterface *processMessage(const msgs::indexed_measurement_t *msg, MavStateEstimator *est)
   {
-    return new RBISIndexedMeasurement(msg->z_indices, msg->z_effective, msg->R_effective, PB_R_FULL, nullptr, indexed_sensor,
-                                      msg->utime);  // sensor_handlers.cpp:560-566
+    // sensor_handlers.cpp:576-582.  Like the reference's update object, ours owns a copy of host data (it may be
+    // re-applied later from the history); device blocks stay where they are.
+    const int m = (int) msg->z_indices.size();
+    if (msg->z_effective.mem == PB_DEVICE)
+      return new RBISIndexedMeasurement(msg->z_indices, msg->z_effective, msg->R_effective, PB_R_FULL, nullptr, indexed_sensor,
+                                        msg->utime);
+    const size_t per = (msg->z_effective.mem == PB_HOST_BROADCAST) ? 1 : (size_t) est->B;
+    std::vector<double> z(msg->z_effective.p, msg->z_effective.p + (size_t) m * per);
+    std::vector<double> R(msg->R_effective, msg->R_effective + (size_t) m * m * per);
+    auto *u = new RBISIndexedMeasurement(msg->z_indices, std::move(z), std::move(R), PB_R_FULL, std::vector<uint8_t>(),
+                                         indexed_sensor, msg->utime);
+    u->measurement.mem = u->cov_mem = msg->z_effective.mem;
+    return u;
   }
 private:
   RBISUpdateInterface::sensor_enum indexed_sensor;
@@ -1010,14 +1024,17 @@ public:
       return nullptr;
     }
     if (mode == MODE_VELOCITY) {
-      if (msg->translation.mem != PB_HOST) return nullptr;
+      if (msg->translation.mem == PB_DEVICE) return nullptr;
       const double elapsed = (double) (msg->timestamp - msg->prev_timestamp) * 1E-6;
-      std::vector<double> z((size_t) 3 * B);
+      const bool bcast = msg->translation.mem == PB_HOST_BROADCAST;
+      std::vector<double> z((size_t) 3 * (bcast ? 1 : B));
       for (size_t i = 0; i < z.size(); i++) z[i] = msg->translation.p[i] / elapsed;
       std::vector<uint8_t> mask;
-      if (msg->estimate_valid) mask.assign(msg->estimate_valid, msg->estimate_valid + B);
-      return new RBISIndexedMeasurement(RBIS::velocityInds(), std::move(z), std::vector<double>(cov_fovis), PB_R_DIAG_BROADCAST,
-                                        std::move(mask), RBISUpdateInterface::fovis, msg->timestamp);
+      if (msg->estimate_valid && !bcast) mask.assign(msg->estimate_valid, msg->estimate_valid + B);
+      auto *u = new RBISIndexedMeasurement(RBIS::velocityInds(), std::move(z), std::vector<double>(cov_fovis), PB_R_DIAG_BROADCAST,
+                                           std::move(mask), RBISUpdateInterface::fovis, msg->timestamp);
+      if (bcast) u->measurement.mem = PB_HOST_BROADCAST;
+      return u;
     }
     // position / position_orient: T1 = T0(posterior at prev_timestamp) * (t, q)
     const double diff = (double) (prev_t0_body_utime_ - msg->prev_timestamp) * 1E-6;
@@ -1038,7 +1055,7 @@ public:
       return nullptr;
     }
     const uint8_t *valid = nullptr;  // the composed z / q live on the device, so does the mask that goes with them
-    if (msg->estimate_valid != nullptr) {
+    if (msg->estimate_valid != nullptr && msg->translation.mem != PB_HOST_BROADCAST) {  // broadcast: all valid here
       pb_memcpy_h2d(owner, d_valid, msg->estimate_valid, (size_t) B);
       valid = d_valid;
     }
@@ -1135,8 +1152,9 @@ private:
 
 // Log replay (lcm_front_end.cpp:223-229 handle loop, reading a recorded segment instead of the network): events are
 // dispatched in file order to the subscribed channels.  One recorded robot feeds EVERY filter of the batch -- the
-// batch differs in parameters / initial state, not in data (param_sweep.py:39-52) -- so a decoded message is
-// broadcast into [m][B] host blocks and handed to the same callback LCMFrontEnd::addSensor returns.
+// batch differs in parameters / initial state, not in data (param_sweep.py:39-52) -- so a decoded message is handed to
+// the callback LCMFrontEnd::addSensor returns as PB_HOST_BROADCAST blocks ([rows] values, expanded on the device:
+// nothing of batch size is built on the host or crosses PCIe).
 class LogPlayer {
 public:
   explicit LogPlayer(int batch) : B_(batch) {}
@@ -1152,16 +1170,12 @@ public:
         n_bad_++;
         return;
       }
-      const int m = w.measured_dim;
-      z_.resize((size_t) m * B_);
-      R_.resize((size_t) m * m * B_);
-      for (int i = 0; i < m; i++) std::fill_n(z_.begin() + (size_t) i * B_, B_, w.z_effective[(size_t) i]);
-      for (int i = 0; i < m * m; i++) std::fill_n(R_.begin() + (size_t) i * B_, B_, w.R_effective[(size_t) i]);
+      // one recorded message for every filter: hand the [m] / [m*m] values over as PB_HOST_BROADCAST blocks
       msgs::indexed_measurement_t msg;
       msg.utime = w.utime;
       msg.z_indices.assign(w.z_indices.begin(), w.z_indices.end());
-      msg.z_effective = BatchArray(z_.data(), PB_HOST);
-      msg.R_effective = R_.data();
+      msg.z_effective = BatchArray(w.z_effective.data(), PB_HOST_BROADCAST);
+      msg.R_effective = w.R_effective.data();
       cb(&msg);
     };
   }
@@ -1173,17 +1187,14 @@ public:
         n_bad_++;
         return;
       }
-      t_.resize((size_t) 3 * B_);
-      q_.resize((size_t) 4 * B_);
-      valid_.assign((size_t) B_, (uint8_t) (w.estimate_status == pronto_wire::update_t::ESTIMATE_VALID));
-      for (int i = 0; i < 3; i++) std::fill_n(t_.begin() + (size_t) i * B_, B_, w.translation[i]);
-      for (int i = 0; i < 4; i++) std::fill_n(q_.begin() + (size_t) i * B_, B_, w.rotation[i]);
+      // estimate_status != ESTIMATE_VALID for the one robot = for every filter: an all-zero per-filter mask
+      if (w.estimate_status != pronto_wire::update_t::ESTIMATE_VALID) valid_.assign((size_t) B_, (uint8_t) 0);
       msgs::update_t msg;
       msg.timestamp = w.timestamp;
       msg.prev_timestamp = w.prev_timestamp;
-      msg.estimate_valid = valid_.data();
-      msg.translation = BatchArray(t_.data(), PB_HOST);
-      msg.rotation = BatchArray(q_.data(), PB_HOST);
+      msg.estimate_valid = (w.estimate_status == pronto_wire::update_t::ESTIMATE_VALID) ? nullptr : valid_.data();
+      msg.translation = BatchArray(w.translation, PB_HOST_BROADCAST);
+      msg.rotation = BatchArray(w.rotation, PB_HOST_BROADCAST);
       cb(&msg);
     };
   }
@@ -1207,7 +1218,6 @@ private:
   int B_;
   int64_t n_bad_ = 0;
   std::map<std::string, std::function<void(const pronto_wire::LogEvent &)>> subs_;
-  std::vector<double> z_, R_, t_, q_;
   std::vector<uint8_t> valid_;
 };
 

@@ -266,14 +266,26 @@ static int stage_in(pb_ctx *c, int mem, Part *parts, int n)
     for (int i = 0; i < n; i++) parts[i].dev = parts[i].src;
     return PB_OK;
   }
-  if (mem != PB_HOST) return fail(c, PB_ERR_ARG, "mem must be PB_HOST or PB_DEVICE");
+  if (mem != PB_HOST && mem != PB_HOST_BROADCAST) return fail(c, PB_ERR_ARG, "mem must be PB_HOST, PB_DEVICE or PB_HOST_BROADCAST");
   size_t tot = 0;
   for (int i = 0; i < n; i++) tot += (parts[i].bytes + 255) / 256 * 256;
   int rc = stage_reserve(c, tot);
   if (rc) return rc;
   size_t off = 0;
   for (int i = 0; i < n; i++) {
-    if (parts[i].src) {
+    if (parts[i].src && mem == PB_HOST_BROADCAST) {
+      // One value per ROW, the same for every filter (one robot's message feeding a whole parameter sweep): the rows are
+      // expanded on the device, nothing of batch size crosses PCIe.  A mask (bytes == B) cannot be broadcast.
+      const size_t rows = parts[i].bytes / (sizeof(double) * (size_t) c->B);
+      if (rows * sizeof(double) * (size_t) c->B != parts[i].bytes || rows == 0 || rows > (size_t) RowVals::MAX)
+        return fail(c, PB_ERR_ARG, "PB_HOST_BROADCAST: only blocks of 1..%d double rows can be broadcast (pass mask = NULL)",
+                    RowVals::MAX);
+      RowVals v;
+      memcpy(v.v, parts[i].src, rows * sizeof(double));
+      k_fill_rows<<<nblk(c->B), 64, 0, c->stream>>>((double *) ((char *) c->stage + off), (int) rows, c->B, v);
+      HIPCHK(c, hipGetLastError());
+      parts[i].dev = (char *) c->stage + off;
+    } else if (parts[i].src) {
       HIPCHK(c, hipMemcpyAsync((char *) c->stage + off, parts[i].src, parts[i].bytes, hipMemcpyHostToDevice, c->stream));
       parts[i].dev = (char *) c->stage + off;
     } else {
@@ -485,6 +497,7 @@ static int update_common(pb_ctx *c, int m, const int *idx, const double *z, cons
   const size_t B = (size_t) c->B;
   size_t rbytes;
   const double *rb = nullptr;
+  if (mem == PB_HOST_BROADCAST && rkind == PB_R_DIAG) rkind = PB_R_DIAG_BROADCAST;  // the same thing, without a fill
   if (rkind == PB_R_DIAG_BROADCAST) { rb = R; rbytes = 0; }
   else if (rkind == PB_R_DIAG) rbytes = sizeof(double) * m * B;
   else if (rkind == PB_R_FULL) rbytes = sizeof(double) * m * m * B;

@@ -528,6 +528,18 @@ __global__ __launch_bounds__(128, 1) void k_step_coop(double *__restrict__ st, l
   }
 }
 
+// PB_HOST_BROADCAST inputs: dst [rows][B] <- one value per row (pronto_batch.hip stage_in)
+struct RowVals {
+  static constexpr int MAX = 36;  // the largest block of one call: a full 6 x 6 measurement covariance
+  double v[MAX];
+};
+__global__ void k_fill_rows(double *__restrict__ dst, int rows, int B, RowVals vals)
+{
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  for (int r = 0; r < rows; r++) dst[(long) r * B + b] = vals.v[r];
+}
+
 // Noise identification (state-estimator/src/noise_id/noise_id.cpp:37-38,44-65): window error e = head (-) truth with
 // chi = Log(truth.quat^-1 * quat), then over the m active indices log det P_aa and e_a^T P_aa^-1 e_a (the two pieces of
 // eigen_utils' loglike_normalized).  out [3][B] = logdet, mahalanobis^2, -0.5*(m log 2pi + logdet + maha).

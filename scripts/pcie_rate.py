@@ -27,3 +27,19 @@ est.sync()
 dt = time.perf_counter() - t0
 print("PCIe-inclusive: %d filters x %d steps from pageable host blocks: %.3e steps/s, %.3f ms/step, %.1f GB/s over PCIe"
       % (B, T - 10, B * (T - 10) / dt, dt / (T - 10) * 1e3, 105 * B * (T - 10) / dt / 1e9))
+
+# the same loop when ONE robot's stream feeds every filter (parameter sweep, LogPlayer): PB_HOST_BROADCAST blocks of
+# [7] + [6] values, expanded on the device -- no batch-sized PCIe traffic, one small fill launch per block
+est.reset(vec, quat, P0)
+imu1 = np.ascontiguousarray(imu[:, :, 0])
+lo1 = np.ascontiguousarray(lo[:, :, 0])
+for k in range(10):
+    est.step_legodo(imu1[k], lo1[k], None, q4)
+est.sync()
+t0 = time.perf_counter()
+for k in range(10, T):
+    est.step_legodo(imu1[k], lo1[k], None, q4)
+est.sync()
+dt = time.perf_counter() - t0
+print("broadcast (one message for all filters): %d filters x %d steps: %.3e steps/s, %.3f ms/step"
+      % (B, T - 10, B * (T - 10) / dt, dt / (T - 10) * 1e3))

@@ -124,15 +124,13 @@ int main(int argc, char **argv)
 
   // ---- replay: every subscription applies the event to the batch AND to the oracle ----
   LogPlayer player(B);
-  std::vector<double> gy(3 * B), ac(3 * B);
   int n_imu = 0, n_gpf = 0, n_vo = 0, n_vo_invalid = 0;
   player.subscribeRaw("IMU_TICK", [&](const pronto_wire::LogEvent &ev) {
     pronto_wire::Reader r(ev.data.data(), ev.data.size());
     double v[7];
     r.f64s(v, 7);
-    for (int i = 0; i < 3; i++)
-      for (int b = 0; b < B; b++) { gy[i * B + b] = v[i]; ac[i * B + b] = v[3 + i]; }
-    msgs::ins_t m{ ev.timestamp, BatchArray(gy.data(), PB_HOST), BatchArray(ac.data(), PB_HOST) };
+    // one IMU for every filter: [3] + [3] values as PB_HOST_BROADCAST blocks, expanded on the device
+    msgs::ins_t m{ ev.timestamp, BatchArray(v, PB_HOST_BROADCAST), BatchArray(v + 3, PB_HOST_BROADCAST) };
     on_ins(&m);
     for (int b = 0; b < B; b++) po_imu_process_step(v, v + 3, 0.001, q4[0], q4[1], q4[2], q4[3], &ox[b], &oP[b], oll[b], &ox[b], &oP[b], &oll[b]);
     n_imu++;
@@ -140,23 +138,19 @@ int main(int argc, char **argv)
   player.subscribeIndexedMeasurement("GPF_MEASUREMENT", [&](const msgs::indexed_measurement_t *m) {
     on_gpf(m);
     const int mm = (int) m->z_indices.size();
-    for (int b = 0; b < B; b++) {
-      double z[6], R[36];
-      for (int i = 0; i < mm; i++) z[i] = m->z_effective.p[(size_t) i * B + b];
-      for (int i = 0; i < mm * mm; i++) R[i] = m->R_effective[(size_t) i * B + b];
-      po_indexed_update(mm, m->z_indices.data(), z, R, &ox[b], &oP[b], oll[b], &ox[b], &oP[b], &oll[b]);
-    }
+    if (m->z_effective.mem != PB_HOST_BROADCAST) { printf("LogPlayer did not broadcast\n"); exit(1); }
+    for (int b = 0; b < B; b++)
+      po_indexed_update(mm, m->z_indices.data(), m->z_effective.p, m->R_effective, &ox[b], &oP[b], oll[b], &ox[b], &oP[b], &oll[b]);
     n_gpf++;
   });
   player.subscribeUpdate("KINECT_REL_ODOMETRY", [&](const msgs::update_t *m) {
     on_fovis(m);
     n_vo++;
-    if (!m->estimate_valid[0]) {  // rbis_fovis_update.cpp:165-171: anything but ESTIMATE_VALID is dropped
+    if (m->estimate_valid && !m->estimate_valid[0]) {  // rbis_fovis_update.cpp:160-164: anything but ESTIMATE_VALID is dropped
       n_vo_invalid++;
     } else {
       for (int b = 0; b < B; b++) {
-        double t3[3] = { m->translation.p[b], m->translation.p[B + b], m->translation.p[2 * B + b] };
-        double q[4] = { m->rotation.p[b], m->rotation.p[B + b], m->rotation.p[2 * B + b], m->rotation.p[3 * B + b] };
+        const double *t3 = m->translation.p, *q = m->rotation.p;  // broadcast blocks: [3], [4]
         double z[6] = { 0 }, qm[4], R[36] = { 0 };
         po_fovis_compose(key[b].vec + 9, key[b].quat, t3, q, z, qm);
         const int idx[6] = { 9, 10, 11, 6, 7, 8 };

@@ -513,3 +513,70 @@ def test_every_kernel_variant_is_bit_identical(pa, oracle, n, B, coop, monkeypat
                 for a, b in zip(head, ref):
                     assert np.array_equal(a, b), (xcd, hint)
             est.close()
+
+
+@pytest.mark.parametrize("n", [15, 21])
+def test_broadcast_inputs_equal_replicated_blocks(pa, oracle, n):
+    """PB_HOST_BROADCAST: one message for every filter of the batch (a parameter sweep replaying one robot's log) passed
+    as [rows] host values must give bit-identical results to the same values replicated into [rows, B] blocks; a mask
+    cannot be broadcast."""
+    import torch
+    B = 333
+    w = Workload(B, n_states=n)
+    vec, quat, P0 = w.initial_state()
+    P0 = P0 + random_spd(n, B, 0.03, 11)
+    ests = []
+    for _ in range(2):
+        e = pa.BatchEstimator(B, n_states=n, n_snapshots=1)
+        e.set_constants(*oracle.constants())
+        e.reset(vec, quat, P0)
+        e.snapshot(0)
+        ests.append(e)
+    rep, bc = ests
+    rng = np.random.default_rng(5)
+    q4 = w.process_noise()
+    dev = torch.device("cuda:0")
+    tile = lambda a: np.ascontiguousarray(np.repeat(np.asarray(a, dtype=np.float64)[:, None], B, axis=1))
+    for k in range(40):
+        imu = np.concatenate([0.3 * rng.standard_normal(3), [0.1, -0.2, 9.8] + 0.2 * rng.standard_normal(3), [1e-3]])
+        lo = np.concatenate([0.2 * rng.standard_normal(3), [0.01, 0.02, 0.015]])
+        if k % 2:
+            rep.step_legodo(tile(imu), tile(lo), None, q4)
+            bc.step_legodo(imu, lo, None, q4)
+        else:
+            rep.predict(tile(imu), q4)
+            bc.predict(imu, q4)
+        if k % 5 == 4:   # m = 3 with one full R for everybody
+            z = 0.2 * rng.standard_normal(3)
+            A = rng.standard_normal((3, 3))
+            R = np.ascontiguousarray((A @ A.T * 0.01 + 0.01 * np.eye(3)).T.ravel())
+            rep.update_indexed([3, 4, 5], tile(z), tile(R))
+            bc.update_indexed([3, 4, 5], z, R)
+        if k % 8 == 7:   # VO: compose on the device from a broadcast delta, then the m = 6 orientation update
+            t = 0.02 * rng.standard_normal(3)
+            dq = np.array([1.0, 0.01, -0.02, 0.015]); dq /= np.linalg.norm(dq)
+            outs = []
+            for e, tt, qq in ((rep, tile(t), tile(dq)), (bc, t, dq)):
+                zo = torch.zeros((6, B), dtype=torch.float64, device=dev)
+                qo = torch.empty((4, B), dtype=torch.float64, device=dev)
+                e.compose_delta(0, tt, qq, zo[0:3], qo)
+                e.update_indexed([9, 10, 11, 6, 7, 8], zo, [4e-4] * 3 + [1e-4] * 3, quat_meas=qo)
+                e.snapshot(0)
+                outs.append((zo.cpu().numpy(), qo.cpu().numpy()))
+            assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+        if k % 10 == 9:  # scan-match style: broadcast z and quat_meas, broadcast diagonal R
+            z4 = np.concatenate([0.1 * rng.standard_normal(3), [0.0]])
+            qm = np.array([0.99, 0.0, 0.0, 0.14]); qm /= np.linalg.norm(qm)
+            rep.update_indexed([9, 10, 11, 8], tile(z4), [0.0025] * 3 + [3e-4], quat_meas=tile(qm))
+            bc.update_indexed([9, 10, 11, 8], z4, [0.0025] * 3 + [3e-4], quat_meas=qm)
+    for a, b in zip(rep.get_head(), bc.get_head()):
+        assert np.array_equal(a, b)
+    with pytest.raises(ValueError):  # the binding refuses to mix a per-filter mask with broadcast blocks ...
+        bc.step_legodo(imu, lo, np.ones(B, dtype=np.uint8), q4)
+    import ctypes as C
+    from pronto_amd._lib import PB_HOST_BROADCAST
+    m8 = np.ones(B, dtype=np.uint8)  # ... and so does the C ABI
+    rc = bc._L.pb_step_legodo(bc._h, C.c_void_p(imu.ctypes.data), C.c_void_p(lo.ctypes.data), C.c_void_p(m8.ctypes.data),
+                              (C.c_double * 4)(*q4), PB_HOST_BROADCAST)
+    assert rc != 0 and b"BROADCAST" in bc._L.pb_last_error(bc._h)
+    rep.close(); bc.close()
