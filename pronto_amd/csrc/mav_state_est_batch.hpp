@@ -1122,6 +1122,44 @@ inline pronto_wire::filter_state_t rbisCreateFilterStateMessageCPP(const RBIS &s
   return msg;
 }
 
+// InitMessageHandler (rbis_initializer.cpp:162-184): a pronto::filter_state_t resets the estimator on the fly -- the
+// reference's checkpoint / resume mechanism (what FilterStatePublisher writes can be read back here).
+// RBIS(msg) (rbis.hpp:69-78): vec <- state[0..n), quat <- msg.quat.  The RigidBodyState(vec) constructor folds a chi beyond
+// the tolerance into its own quaternion before msg.quat overwrites that quaternion, i.e. such a chi is dropped; published
+// heads carry chi = 0 anyway.
+class InitMessageHandler {
+public:
+  double chi_tol = 1e-6;  // eigen_utils' chiToQuat tolerance: the same constant as pb_set_constants' chi_tol
+  // one message for every filter of the batch
+  RBISUpdateInterface *processMessage(const pronto_wire::filter_state_t *msg, MavStateEstimator *est)
+  {
+    return processMessages(std::vector<pronto_wire::filter_state_t>((size_t) est->B, *msg), est);
+  }
+  // one message per filter (msgs.size() == batch): resume a whole batch from what was published
+  RBISUpdateInterface *processMessages(const std::vector<pronto_wire::filter_state_t> &msgs, MavStateEstimator *est)
+  {
+    const int n = est->n, B = est->B;
+    if ((int) msgs.size() != B) return nullptr;
+    RBIS x(n, B);
+    RBIM P(n, B);
+    for (int b = 0; b < B; b++) {
+      const pronto_wire::filter_state_t &m = msgs[(size_t) b];
+      if (m.num_states != RBIS::rbis_num_states || m.num_cov_elements != m.num_states * m.num_states) {
+        fprintf(stderr, "error, constructed RBIS from rbis_filter_state_t of wrong size\n");  // rbis.hpp:72-74
+        return nullptr;
+      }
+      for (int i = 0; i < n; i++) x(i, b) = m.state[(size_t) i];
+      const double chi2 = x(6, b) * x(6, b) + x(7, b) * x(7, b) + x(8, b) * x(8, b);
+      if (chi2 > chi_tol * chi_tol) x(6, b) = x(7, b) = x(8, b) = 0.0;
+      for (int i = 0; i < 4; i++) x.q(i, b) = m.quat[i];
+      for (int c = 0; c < n; c++)
+        for (int r = 0; r < n; r++) P(r, c, b) = m.cov[(size_t) c * m.num_states + r];
+    }
+    x.utime = msgs[0].utime;
+    return new RBISResetUpdate(x, P, RBISUpdateInterface::init_message, msgs[0].utime);
+  }
+};
+
 // LCMFrontEnd::publishState (lcm_front_end.cpp:144-157), filter-state half: appends the head of the chosen filters
 // to an LCM log on `state_estimator.filter_state_channel` when `state_estimator.publish_filter_state` is set.
 class FilterStatePublisher {

@@ -211,6 +211,56 @@ int main(int argc, char **argv)
     }
     if (seen != 3) { printf("expected 3 published states, read %d\n", seen); ok = false; }
   }
+  // ---- resume: a second, 3-filter estimator initialised from the published messages (InitMessageHandler), one more
+  //      IMU + GPF step on both: the resumed filters must stay bit-identical to filters 0, 17, B-1 of the original ----
+  {
+    std::vector<pronto_wire::filter_state_t> msgs;
+    pronto_wire::LogReader rd(out_log);
+    pronto_wire::LogEvent e;
+    while (rd.next(e)) {
+      pronto_wire::filter_state_t fs;
+      if (fs.decode(e.data.data(), e.data.size()) > 0) msgs.push_back(fs);
+    }
+    RBIS z0(n, 3);
+    RBIM zP(n, 3);
+    MavStateEstimator est2(new RBISResetUpdate(z0, zP, RBISUpdateInterface::reset, 0), &param, 0);
+    InitMessageHandler init_handler;
+    RBISUpdateInterface *reset = init_handler.processMessages(msgs, &est2);
+    if (reset == nullptr) { printf("InitMessageHandler refused the published messages\n"); ok = false; }
+    else {
+      est2.addUpdate(reset, true);
+      FrontEnd fe2(&param);
+      fe2.setStateEstimator(&est2);
+      InsHandler ins2(&param, &ins_to_body);
+      IndexedMeasurementHandler gpf2(RBISUpdateInterface::laser_gpf);
+      auto on_ins2 = fe2.addSensor("ins", &InsHandler::processMessage, &ins2);
+      auto on_gpf2 = fe2.addSensor("gpf", &IndexedMeasurementHandler::processMessage, &gpf2);
+      const double v[6] = { 0.11, -0.07, 0.23, 0.3, -0.2, g };
+      const double zz[3] = { 0.05, -0.02, 0.01 }, RR[9] = { 0.012, 0.002, -0.001, 0.002, 0.011, 0.003, -0.001, 0.003, 0.014 };
+      const int64_t t1 = head.utime + 1000;
+      msgs::ins_t im{ t1, BatchArray(v, PB_HOST_BROADCAST), BatchArray(v + 3, PB_HOST_BROADCAST) };
+      msgs::indexed_measurement_t gm;
+      gm.utime = t1;
+      gm.z_indices = { 3, 4, 5 };
+      gm.z_effective = BatchArray(zz, PB_HOST_BROADCAST);
+      gm.R_effective = RR;
+      on_ins(&im); on_gpf(&gm);
+      on_ins2(&im); on_gpf2(&gm);
+      RBIS h1, h2;
+      RBIM c1, c2;
+      est.getHeadState(h1, c1);
+      est2.getHeadState(h2, c2);
+      const int which[3] = { 0, 17, B - 1 };
+      bool same = h1.utime == h2.utime && h2.utime == t1;
+      for (int k = 0; same && k < 3; k++) {
+        for (int i = 0; same && i < n; i++) same = h2(i, k) == h1(i, which[k]);
+        for (int i = 0; same && i < 4; i++) same = h2.q(i, k) == h1.q(i, which[k]);
+        for (int c = 0; same && c < n; c++)
+          for (int r = 0; same && r < n; r++) same = c2(r, c, k) == c1(r, c, which[k]);
+      }
+      if (!same) { printf("resumed filters diverge from the originals\n"); ok = false; }
+    }
+  }
   printf(ok ? "PASS\n" : "FAIL\n");
   return ok ? 0 : 1;
 }
