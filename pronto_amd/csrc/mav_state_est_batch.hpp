@@ -846,6 +846,24 @@ public:
   }
 };
 
+// The reference's update objects own their measurement (Eigen copies in their constructors); so do ours for host data,
+// which the history may re-apply long after the message buffer is gone.  Device blocks are referenced, not copied: the
+// caller keeps them alive for utime_history_span.  cov_diag must outlive the update (handlers are app-lifetime singletons).
+inline RBISIndexedMeasurement *makeIndexedMeasurement(const std::vector<int> &idx, BatchArray z, int B,
+                                                      const std::vector<double> &cov_diag, const uint8_t *mask,
+                                                      RBISUpdateInterface::sensor_enum sensor, int64_t utime)
+{
+  if (z.mem == PB_DEVICE) return new RBISIndexedMeasurement(idx, z, cov_diag.data(), PB_R_DIAG_BROADCAST, mask, sensor, utime);
+  const size_t per = (z.mem == PB_HOST_BROADCAST) ? 1 : (size_t) B;
+  std::vector<double> zc(z.p, z.p + idx.size() * per);
+  std::vector<uint8_t> mc;
+  if (mask != nullptr && z.mem == PB_HOST) mc.assign(mask, mask + B);
+  auto *u = new RBISIndexedMeasurement(idx, std::move(zc), std::vector<double>(cov_diag), PB_R_DIAG_BROADCAST, std::move(mc), sensor,
+                                       utime);
+  u->measurement.mem = z.mem;
+  return u;
+}
+
 class ScanMatcherHandler {
 public:
   typedef enum { MODE_POSITION, MODE_POSITION_YAW, MODE_VELOCITY, MODE_VELOCITY_YAW, MODE_YAW } ScanMatchingMode;
@@ -890,28 +908,27 @@ public:
   {
     const int B = est->B;
     if (mode == MODE_POSITION)
-      return new RBISIndexedMeasurement(RBIS::positionInds(), msg->pos, cov_scan_match.data(), PB_R_DIAG_BROADCAST, nullptr,
-                                        RBISUpdateInterface::scan_matcher, msg->utime);
+      return makeIndexedMeasurement(RBIS::positionInds(), msg->pos, B, cov_scan_match, nullptr, RBISUpdateInterface::scan_matcher,
+                                    msg->utime);
     if (mode == MODE_VELOCITY)
-      return new RBISIndexedMeasurement(RBIS::velocityInds(), msg->vel, cov_scan_match.data(), PB_R_DIAG_BROADCAST, nullptr,
-                                        RBISUpdateInterface::scan_matcher, msg->utime);
+      return makeIndexedMeasurement(RBIS::velocityInds(), msg->vel, B, cov_scan_match, nullptr, RBISUpdateInterface::scan_matcher,
+                                    msg->utime);
     const BatchArray src = (mode == MODE_POSITION_YAW) ? msg->pos : msg->vel;
     const int m = (int) z_indices.size();
-    if (src.mem != PB_HOST && mode != MODE_YAW) {
-      fprintf(stderr, "ScanMatcherHandler: *_yaw modes take host pos/vel arrays\n");
+    const int omem = msg->orientation.mem;
+    if (omem == PB_DEVICE || (mode != MODE_YAW && src.mem != omem)) {
+      fprintf(stderr, "ScanMatcherHandler: *_yaw modes take host (or host-broadcast) pos/vel and orientation arrays\n");
       return nullptr;
     }
-    std::vector<double> z((size_t) m * B, 0.0);
-    if (mode != MODE_YAW) memcpy(z.data(), src.p, sizeof(double) * 3 * B);
-    std::vector<double> q((size_t) 4 * B);
-    if (msg->orientation.mem != PB_HOST) {
-      fprintf(stderr, "ScanMatcherHandler: orientation must be a host array\n");
-      return nullptr;
-    }
-    memcpy(q.data(), msg->orientation.p, sizeof(double) * 4 * B);
+    const size_t per = (omem == PB_HOST_BROADCAST) ? 1 : (size_t) B;
+    std::vector<double> z((size_t) m * per, 0.0);
+    if (mode != MODE_YAW) memcpy(z.data(), src.p, sizeof(double) * 3 * per);
+    std::vector<double> q(msg->orientation.p, msg->orientation.p + 4 * per);
     std::vector<double> R(cov_scan_match);
-    return new RBISIndexedPlusOrientationMeasurement(z_indices, std::move(z), std::move(R), PB_R_DIAG_BROADCAST, std::move(q),
-                                                     std::vector<uint8_t>(), RBISUpdateInterface::scan_matcher, msg->utime);
+    auto *u = new RBISIndexedPlusOrientationMeasurement(z_indices, std::move(z), std::move(R), PB_R_DIAG_BROADCAST, std::move(q),
+                                                        std::vector<uint8_t>(), RBISUpdateInterface::scan_matcher, msg->utime);
+    u->measurement.mem = u->orientation.mem = omem;
+    return u;
   }
 };
 
@@ -947,10 +964,10 @@ public:
     double rz = bot_param_get_double_or_fail(_param, "state_estimator.gps.r_z");
     cov_xyz = { rxy * rxy, rxy * rxy, rz * rz };
   }
-  RBISUpdateInterface *processMessage(const msgs::gps_data_t *msg, MavStateEstimator *)
+  RBISUpdateInterface *processMessage(const msgs::gps_data_t *msg, MavStateEstimator *est)
   {
-    return new RBISIndexedMeasurement(RBIS::positionInds(), msg->xyz_pos, cov_xyz.data(), PB_R_DIAG_BROADCAST, msg->has_lock,
-                                      RBISUpdateInterface::gps, msg->utime);  // sensor_handlers.cpp:374-381
+    return makeIndexedMeasurement(RBIS::positionInds(), msg->xyz_pos, est->B, cov_xyz, msg->has_lock, RBISUpdateInterface::gps,
+                                  msg->utime);  // sensor_handlers.cpp:374-381
   }
 };
 
