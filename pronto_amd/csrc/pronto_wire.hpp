@@ -310,7 +310,13 @@ private:
 
 class LogReader {
 public:
-  explicit LogReader(const std::string &path) : f_(fopen(path.c_str(), "rb")) {}
+  explicit LogReader(const std::string &path) : f_(fopen(path.c_str(), "rb"))
+  {
+    if (f_ && fseek(f_, 0, SEEK_END) == 0) {
+      size_ = ftell(f_);
+      fseek(f_, 0, SEEK_SET);
+    }
+  }
   ~LogReader() { if (f_) fclose(f_); }
   LogReader(const LogReader &) = delete;
   LogReader &operator=(const LogReader &) = delete;
@@ -335,6 +341,8 @@ public:
     ev.timestamp = r.i64();
     const int32_t clen = r.i32(), dlen = r.i32();
     if (clen < 0 || clen > 1000 || dlen < 0) return false;  // eventlog.c rejects channel names > 1000
+    // a damaged length field must not turn into a multi-gigabyte allocation: the payload cannot outrun the file
+    if (size_ >= 0 && (long) clen + (long) dlen > size_ - ftell(f_)) return false;
     ev.channel.resize((size_t) clen);
     if (clen && fread(&ev.channel[0], 1, (size_t) clen, f_) != (size_t) clen) return false;
     ev.data.resize((size_t) dlen);
@@ -343,6 +351,7 @@ public:
   }
 private:
   FILE *f_;
+  long size_ = -1;
 };
 
 }  // namespace pronto_wire
