@@ -7,12 +7,24 @@ import numpy as np
 from util import embed21
 
 
-def oracle_forward(oracle, w, n, T, B):
-    """Forward pass with the oracle, keeping (pred, filtered) posteriors of every step (INS update, then legodo)."""
+def start_of(w, zero_bias=False):
+    """(vec, quat, P0, q4) of a run; zero_bias: a 21-state filter whose bias states are switched off (zero variance,
+    zero process noise) -- the case the smoother's bias-block fix exists for (rbis.cpp:244-251)."""
     vec, quat, P0 = w.initial_state()
+    q4 = w.process_noise()
+    if zero_bias:
+        P0[15:, :, :] = 0.0
+        P0[:, 15:, :] = 0.0
+        vec[15:] = 0.0
+        q4 = np.array([q4[0], q4[1], 0.0, 0.0])
+    return vec, quat, P0, q4
+
+
+def oracle_forward(oracle, w, n, T, B, zero_bias=False):
+    """Forward pass with the oracle, keeping (pred, filtered) posteriors of every step (INS update, then legodo)."""
+    vec, quat, P0, q4 = start_of(w, zero_bias)
     v21, P21 = embed21(vec, P0)
     ob = oracle.OracleBatch(v21, quat, P21)
-    q4 = w.process_noise()
     hist = []
     for k in range(T):
         imu = w.imu_block(k)

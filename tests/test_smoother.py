@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from smoother_ref import oracle_backward_pass, oracle_forward, oracle_smooth_step
+from smoother_ref import oracle_backward_pass, oracle_forward, oracle_smooth_step, start_of
 from util import rel
 
 from pronto_amd.synth import Workload
@@ -17,20 +17,19 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-7
 
 
-@pytest.mark.parametrize("n", [15, 21])
-def test_backward_pass_matches_oracle(oracle, n):
+@pytest.mark.parametrize("n,zero_bias", [(15, False), (21, False), (21, True)])
+def test_backward_pass_matches_oracle(oracle, n, zero_bias):
     """Forward pass on the GPU with a checkpoint after every update (INS and legodo), then the backward recursion of
     EKFSmoothBackwardsPass with pb_smooth_step; the same recursion with the oracle on the oracle's forward pass."""
     from pronto_amd.batch import BatchEstimator
     B, T, dt = 37, 24, 1e-3
     w = Workload(B, n_states=n)
-    hist = oracle_forward(oracle, w, n, T, B)
+    hist = oracle_forward(oracle, w, n, T, B, zero_bias)
     est = BatchEstimator(B, n_states=n)
     est.set_constants(*oracle.constants())
-    vec, quat, P0 = w.initial_state()
+    vec, quat, P0, q4 = start_of(w, zero_bias)  # zero_bias: P^-'s bias blocks are exactly 0 -> replaced by I in the solve
     est.reset(vec, quat, P0)
     est.history_reserve(2 * T + 2)
-    q4 = w.process_noise()
     for k in range(T):
         imu = w.imu_block(k)
         lo, mask = w.legodo_block(k)
