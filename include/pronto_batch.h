@@ -15,8 +15,8 @@
  *  - One context is driven from one host thread at a time (the reference is single-threaded,
  *    lcm_front_end.cpp:223-229); distinct contexts (one per GPU) may be driven concurrently.
  *  - Batched arrays are SoA with the FILTER INDEX FASTEST: element (c, b) of an array [C][B] is at c*B + b.
- *  - `mem` says where the caller's buffers live: PB_HOST (staged through an internal pinned buffer, PCIe
- *    inclusive) or PB_DEVICE (HBM-resident; the kernels read them in place).
+ *  - `mem` says where the caller's buffers live: PB_HOST (copied into an internal device staging area on the
+ *    context's stream, PCIe inclusive) or PB_DEVICE (HBM-resident; the kernels read them in place).
  *    PB_HOST_BROADCAST: host memory with ONE value per row, the same message for every filter (see enum pb_mem).
  *  - fp64 throughout.  State layout is RBIS's (rbis.hpp:22-30): vec = [omega(0-2) v_body(3-5) chi(6-8)
  *    pos(9-11) accel(12-14) | gyro_bias(15-17) accel_bias(18-20)], quat = (w,x,y,z), n_states = 15 keeps
