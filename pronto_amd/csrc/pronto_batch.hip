@@ -396,6 +396,29 @@ extern "C" int pb_run_legodo(pb_ctx *c, int n_steps, const double *imu_stream, c
   NEED_STATE(c);
   if (n_steps < 0 || !imu_stream || !lo_stream || !q) return fail(c, PB_ERR_ARG, "pb_run_legodo: bad argument");
   const size_t B = (size_t) c->B;
+  // Experiment switch: PRONTO_BATCH_GRAPH=1 captures the n_steps launches into a HIP graph and times
+  // ONE replay of it (capture and instantiation excluded).  Needs a capturable stream (pb_use_own_stream).
+  static const bool want_graph = getenv("PRONTO_BATCH_GRAPH") && getenv("PRONTO_BATCH_GRAPH")[0] == '1';
+  if (want_graph && c->stream != nullptr && n_steps > 1) {
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+    for (int s = 0; s < n_steps; s++) {
+      int rc = launch_step<true>(c, imu_stream + (size_t) s * 7 * B, lo_stream + (size_t) s * 6 * B,
+                                 mask_stream ? mask_stream + (size_t) s * B : nullptr, q);
+      if (rc) return rc;
+    }
+    HIPCHK(c, hipStreamEndCapture(c->stream, &graph));
+    HIPCHK(c, hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    HIPCHK(c, hipGraphLaunch(exec, c->stream));
+    HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+    HIPCHK(c, hipEventSynchronize(c->ev1));
+    if (elapsed_ms) HIPCHK(c, hipEventElapsedTime(elapsed_ms, c->ev0, c->ev1));
+    (void) hipGraphExecDestroy(exec);
+    (void) hipGraphDestroy(graph);
+    return PB_OK;
+  }
   if (elapsed_ms) HIPCHK(c, hipEventRecord(c->ev0, c->stream));
   for (int s = 0; s < n_steps; s++) {
     int rc = launch_step<true>(c, imu_stream + (size_t) s * 7 * B, lo_stream + (size_t) s * 6 * B,
