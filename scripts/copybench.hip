@@ -1,0 +1,45 @@
+// copybench.hip -- measurement aid: streaming copy of a state array with the step kernels' exact layout and access pattern
+// (component-major, 8 B/lane buffer loads/stores), in place and out of place, with the cache-policy hints and the
+// XCD-contiguous workgroup order.  This is the memory system's ceiling the EKF step is compared with in DESIGN.md 6.
+//   hipcc -O3 --offload-arch=gfx950 -o copybench scripts/copybench.hip && ./copybench > profiles/rNN_copybench.txt
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t mkbuf(const void*p, unsigned bytes){ return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p),0,bytes,0x00020000);}
+template<int DEPTH, int LA, int SA, bool XCD> __global__ __launch_bounds__(64) void copyA(const double* src, double* dst, long stride, int B, int nc){
+  unsigned wg=blockIdx.x;
+  if(XCD){ unsigned nq=gridDim.x>>3,nr=gridDim.x&7u,x=blockIdx.x&7u,r=blockIdx.x>>3; wg=(x<nr? x*(nq+1u): nr*(nq+1u)+(x-nr)*nq)+r; }
+  unsigned b=wg*64u+threadIdx.x; if(b>=(unsigned)B) return; unsigned bo=b*8u, s8=(unsigned)stride*8u;
+  rsrc_t ri=mkbuf(src,(unsigned)nc*s8), ro=mkbuf(dst,(unsigned)nc*s8);
+  for(int c0=0;c0<nc;c0+=DEPTH){ v2u v[DEPTH];
+#pragma unroll
+    for(int i=0;i<DEPTH;i++) v[i]=__builtin_amdgcn_raw_buffer_load_b64(ri,bo,(unsigned)(c0+i)*s8,LA);
+#pragma unroll
+    for(int i=0;i<DEPTH;i++){ v[i].x+=1u; __builtin_amdgcn_raw_buffer_store_b64(v[i],ro,bo,(unsigned)(c0+i)*s8,SA);}
+  }
+}
+#define CK(x) do{hipError_t e=(x); if(e!=hipSuccess){printf("err %s line %d\n",hipGetErrorString(e),__LINE__); return 1;}}while(0)
+template<class F> float timeit(F f,int reps){ hipEvent_t a,b; hipEventCreate(&a);hipEventCreate(&b); f(); f(); hipDeviceSynchronize(); hipEventRecord(a); for(int i=0;i<reps;i++) f(); hipEventRecord(b); hipEventSynchronize(b); float ms; hipEventElapsedTime(&ms,a,b); return ms/reps; }
+int main(){
+  const int nc=140;
+  for(int B : {65536, 196608, 262144, 1<<20}){
+    long stride=B; size_t bytes=(size_t)nc*stride*8; double *s,*d; CK(hipMalloc(&s,bytes)); CK(hipMalloc(&d,bytes)); CK(hipMemset(s,1,bytes)); CK(hipMemset(d,0,bytes));
+    auto rep=[&](const char*name,float ms){ printf("B=%8d %-34s %9.1f us  %7.1f GB/s (r+w)\n",B,name,ms*1e3,2.0*bytes/(ms*1e-3)/1e9); fflush(stdout); };
+    int reps = B>100000? 20: 100; int g=(B+63)/64;
+#define RUN(NAME,D,LA,SA,X,DST) rep(NAME, timeit([&]{ copyA<D,LA,SA,X><<<g,64>>>(s,DST,stride,B,nc);},reps))
+    RUN("out-of-place d35",35,0,0,false,d);
+    RUN("out-of-place d35 xcd",35,0,0,true,d);
+    RUN("in-place d35",35,0,0,false,s);
+    RUN("in-place d35 xcd",35,0,0,true,s);
+    RUN("in-place d35 xcd st-nt",35,0,2,true,s);
+    RUN("in-place d35 xcd ld-nt st-nt",35,2,2,true,s);
+    RUN("in-place d35 xcd ld-nt",35,2,0,true,s);
+    RUN("in-place d35 xcd st-sc1",35,0,16,true,s);
+    RUN("in-place d35 xcd st-sc0sc1",35,0,17,true,s);
+    RUN("in-place d70 xcd",70,0,0,true,s);
+    RUN("in-place d70 xcd st-nt",70,0,2,true,s);
+    hipFree(s);hipFree(d);
+  }
+  return 0;
+}
