@@ -186,6 +186,13 @@ int pb_imu_notch(pb_ctx *ctx, int n_packets, const double *accel_packets, double
  * (contents are lost). */
 int pb_history_reserve(pb_ctx *ctx, int n_slots);
 int pb_state_save(pb_ctx *ctx, int slot);      /* slot <- head posterior (state, cov, loglik) */
+/* Checkpoint without a copy: the NEXT update (pb_predict / pb_update_indexed* / pb_step_legodo) reads the head and
+ * writes its posterior straight into checkpoint `slot`, which then IS the head (pb_state_save(slot) becomes a no-op).
+ * The step moves the same bytes either way, so a forward pass that keeps every posterior -- what the reference's
+ * history does by value (mav_state_est.cpp:55-61) and what the smoother needs -- costs no more than one that keeps none.
+ * A saved posterior is never modified afterwards: an update that finds the head in a slot and has no output slot of its
+ * own writes back into the context's array; pb_state_restore and pb_reset always land there.  slot = -1 cancels. */
+int pb_set_output_slot(pb_ctx *ctx, int slot);
 int pb_state_restore(pb_ctx *ctx, int slot);   /* head posterior <- slot */
 
 /* ekfSmoothingStep (rbis.cpp:234-266), one backward step of MavStateEstimator::EKFSmoothBackwardsPass

@@ -74,6 +74,7 @@ _SIGS = {
     "pb_imu_notch": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
     "pb_history_reserve": (C.c_int, [C.c_void_p, C.c_int]),
     "pb_state_save": (C.c_int, [C.c_void_p, C.c_int]),
+    "pb_set_output_slot": (C.c_int, [C.c_void_p, C.c_int]),
     "pb_state_restore": (C.c_int, [C.c_void_p, C.c_int]),
     "pb_smooth_step": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double]),
     "pb_get_head": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),

@@ -104,6 +104,11 @@ class BatchEstimator:
     def history_reserve(self, n_slots):
         self._chk(self._L.pb_history_reserve(self._h, n_slots))
 
+    def set_output_slot(self, slot):
+        """The next update writes its posterior straight into checkpoint `slot` (which becomes the head): a checkpoint
+        per update without a copy.  -1 cancels."""
+        self._chk(self._L.pb_set_output_slot(self._h, int(slot)))
+
     def state_save(self, slot):
         self._chk(self._L.pb_state_save(self._h, slot))
 

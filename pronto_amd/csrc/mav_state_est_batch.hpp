@@ -365,6 +365,10 @@ public:
     }
     while (current_it != map.end()) {
       RBISUpdateInterface *u = current_it->second;
+      // a checkpointed update writes its posterior straight into the checkpoint slot (no copy afterwards)
+      int slot = -1;
+      if (history_slots > 0 && ++since_checkpoint >= checkpoint_every && (slot = reserve_slot(u)) >= 0)
+        pb_set_output_slot(ctx, slot);
       int rc = u->updateFilter(ctx);
       if (rc != PB_OK) {
         last_status = rc;
@@ -373,7 +377,13 @@ public:
       }
       device_head = u;
       head_utime = u->utime;  // posterior_state.utime = update->utime (:60)
-      if (history_slots > 0 && ++since_checkpoint >= checkpoint_every) save_checkpoint(u);
+      if (slot >= 0) {
+        pb_set_output_slot(ctx, -1);
+        rc = pb_state_save(ctx, slot);  // a no-op when the update wrote there; a copy for updates that cannot (reset)
+        if (rc != PB_OK) last_status = rc;
+        checkpoint_of[u] = slot;
+        since_checkpoint = 0;
+      }
       ++current_it;
     }
     pb_set_utime(ctx, head_utime);
@@ -457,7 +467,8 @@ private:
       checkpoint_of.erase(it);
     }
   }
-  void save_checkpoint(RBISUpdateInterface *u)
+  // a free checkpoint slot for update u, recycling the oldest part of the window when the pool is exhausted; -1 = none
+  int reserve_slot(RBISUpdateInterface *u)
   {
     if (free_slots.empty()) {
       // pool exhausted: the window shrinks to what the pool covers -- drop everything before the second-oldest
@@ -466,11 +477,17 @@ private:
       auto it = map.begin();
       ++it;
       while (it != map.end() && checkpoint_of.find(it->second) == checkpoint_of.end()) ++it;
-      if (it == map.end() || it->second == u) return;  // nothing to recycle: skip this checkpoint
+      if (it == map.end() || it->second == u) return -1;  // nothing to recycle: skip this checkpoint
       erase_before(it);
     }
     const int slot = free_slots.back();
     free_slots.pop_back();
+    return slot;
+  }
+  void save_checkpoint(RBISUpdateInterface *u)
+  {
+    const int slot = reserve_slot(u);
+    if (slot < 0) return;
     int rc = pb_state_save(ctx, slot);
     if (rc != PB_OK) last_status = rc;
     checkpoint_of[u] = slot;

@@ -25,7 +25,10 @@ struct pb_ctx {
   int ns = 0, B = 0, dev = 0, nsnap = 0, nc = 0;
   long stride = 0;
   hipStream_t stream = nullptr, own_stream = nullptr;
-  double *st = nullptr, *snaps = nullptr, *d_small = nullptr;
+  double *st = nullptr;       // the HEAD posterior: st_base, or a checkpoint slot an update wrote its posterior into
+  double *st_base = nullptr;  // the context's own state array
+  int out_slot = -1;          // pb_set_output_slot: where the next update writes (then that slot is the head)
+  double *snaps = nullptr, *d_small = nullptr;
   double *hist = nullptr;  // posterior checkpoint slots (pb_history_reserve)
   int nhist = 0;
   double *notch = nullptr;  // IMU notch cascade state [36][stride] (pb_imu_notch_init)
@@ -63,6 +66,25 @@ static int fail(pb_ctx *c, int code, const char *fmt, ...)
   } while (0)
 
 static inline int nblk(int n) { return (n + 63) / 64; }
+
+// Where an update writes its posterior.  Normally in place.  With pb_set_output_slot the posterior goes straight into a
+// checkpoint slot (a checkpoint per update without a copy: the step moves the same bytes either way).  If the head IS a
+// checkpoint slot and no output slot was named, the update writes back into the context's own array, so a saved
+// posterior is never modified.
+static inline double *update_target(pb_ctx *c);
+static inline void update_done(pb_ctx *c, double *target);
+static int detach_head(pb_ctx *c, bool keep_contents);
+
+static inline double *update_target(pb_ctx *c)
+{
+  if (c->out_slot >= 0) return c->hist + (size_t) c->out_slot * (size_t) c->nc * c->stride;
+  return (c->st != c->st_base) ? c->st_base : c->st;
+}
+static inline void update_done(pb_ctx *c, double *target)
+{
+  c->st = target;
+  c->out_slot = -1;
+}
 
 extern "C" const char *pb_version(void) { return PB_VERSION_STR; }
 
@@ -134,7 +156,8 @@ extern "C" int pb_create(pb_ctx **out, int n_states, int batch, int device, int 
   CRCHK(hipSetDevice(device));
   CRCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
   c->stream = c->own_stream;
-  CRCHK(hipMalloc((void **) &c->st, sizeof(double) * c->nc * c->stride));
+  CRCHK(hipMalloc((void **) &c->st_base, sizeof(double) * c->nc * c->stride));
+  c->st = c->st_base;
   CRCHK(hipMemsetAsync(c->st, 0, sizeof(double) * c->nc * c->stride, c->stream));
   if (n_snapshots > 0) {
     CRCHK(hipMalloc((void **) &c->snaps, sizeof(double) * 7 * c->stride * n_snapshots));
@@ -154,7 +177,7 @@ extern "C" int pb_destroy(pb_ctx *c)
   if (!c) return PB_OK;
   (void) hipSetDevice(c->dev);
   if (c->stream) (void) hipStreamSynchronize(c->stream);
-  if (c->st) (void) hipFree(c->st);
+  if (c->st_base) (void) hipFree(c->st_base);
   if (c->snaps) (void) hipFree(c->snaps);
   if (c->hist) (void) hipFree(c->hist);
   if (c->notch) (void) hipFree(c->notch);
@@ -309,6 +332,8 @@ extern "C" int pb_reset(pb_ctx *c, const double *vec, const double *quat, const 
 {
   ENTER(c);
   if (!vec || !quat || !cov) return fail(c, PB_ERR_ARG, "pb_reset: NULL input");
+  c->st = c->st_base;  // a reset always lands in the context's own array (a checkpoint the head lived in stays intact)
+  c->out_slot = -1;
   const int n = c->ns, B = c->B;
   if (broadcast) {
     if (mem != PB_HOST) return fail(c, PB_ERR_ARG, "pb_reset: broadcast inputs must be host memory");
@@ -339,29 +364,31 @@ extern "C" int pb_reset(pb_ctx *c, const double *vec, const double *quat, const 
 }
 
 template <bool UPDATE, int MH>
-static void launch_step_mh(pb_ctx *c, const double *imu, const double *lo, const uint8_t *mask, const double q[4])
+static void launch_step_mh(pb_ctx *c, double *out, const double *imu, const double *lo, const uint8_t *mask, const double q[4])
 {
   const int B = c->B;
   if (c->ns == 15 && c->coop15) {
-    k_step_coop<15, UPDATE, MH><<<nblk(B), 128, 0, c->stream>>>(c->st, c->stride, B, imu, lo, mask, q[0], q[1], q[2], q[3], c->k);
+    k_step_coop<15, UPDATE, MH><<<nblk(B), 128, 0, c->stream>>>(c->st, out, c->stride, B, imu, lo, mask, q[0], q[1], q[2], q[3], c->k);
   } else if (c->ns == 15) {
-    k_step<15, UPDATE, MH><<<(B + PB_STEP_BLOCK - 1) / PB_STEP_BLOCK, PB_STEP_BLOCK, 0, c->stream>>>(c->st, c->stride, B, imu, lo, mask, q[0], q[1], q[2], q[3], c->k);
+    k_step<15, UPDATE, MH><<<(B + PB_STEP_BLOCK - 1) / PB_STEP_BLOCK, PB_STEP_BLOCK, 0, c->stream>>>(c->st, out, c->stride, B, imu, lo, mask, q[0], q[1], q[2], q[3], c->k);
   } else {
     // n = 21: 231 packed covariance entries do not fit one lane's registers; the step runs on the two-wave
     // cooperative kernel (rbis_coop.hpp): one launch, one state round trip.
-    k_step_coop<21, UPDATE, MH><<<nblk(B), 128, 0, c->stream>>>(c->st, c->stride, B, imu, lo, mask, q[0], q[1], q[2], q[3], c->k);
+    k_step_coop<21, UPDATE, MH><<<nblk(B), 128, 0, c->stream>>>(c->st, out, c->stride, B, imu, lo, mask, q[0], q[1], q[2], q[3], c->k);
   }
 }
 
 template <bool UPDATE>
 static int launch_step(pb_ctx *c, const double *imu, const double *lo, const uint8_t *mask, const double q[4])
 {
+  double *out = update_target(c);
   switch (c->mem_hint) {  // cache policy of the state round trip, chosen in pb_create from the state size
-  case MH_STORE_SC1: launch_step_mh<UPDATE, MH_STORE_SC1>(c, imu, lo, mask, q); break;
-  case MH_STREAM_NT: launch_step_mh<UPDATE, MH_STREAM_NT>(c, imu, lo, mask, q); break;
-  default: launch_step_mh<UPDATE, MH_DEFAULT>(c, imu, lo, mask, q); break;
+  case MH_STORE_SC1: launch_step_mh<UPDATE, MH_STORE_SC1>(c, out, imu, lo, mask, q); break;
+  case MH_STREAM_NT: launch_step_mh<UPDATE, MH_STREAM_NT>(c, out, imu, lo, mask, q); break;
+  default: launch_step_mh<UPDATE, MH_DEFAULT>(c, out, imu, lo, mask, q); break;
   }
   LAUNCHCHK(c);
+  update_done(c, out);
   return PB_OK;
 }
 
@@ -443,6 +470,10 @@ extern "C" int pb_replay_legodo_fused(pb_ctx *c, int n_steps, int steps_per_laun
   if (n_steps < 0 || steps_per_launch < 1 || !imu_stream || !lo_stream || !q)
     return fail(c, PB_ERR_ARG, "pb_replay_legodo_fused: bad argument");
   const size_t B = (size_t) c->B;
+  {
+    int rc = detach_head(c, true);  // this kernel works in place: never on a checkpoint slot
+    if (rc) return rc;
+  }
   if (elapsed_ms) HIPCHK(c, hipEventRecord(c->ev0, c->stream));
   for (int s = 0; s < n_steps; s += steps_per_launch) {
     const int T = (n_steps - s < steps_per_launch) ? n_steps - s : steps_per_launch;
@@ -464,10 +495,12 @@ template <int NS, int M, int MH>
 static void launch_update_mh(pb_ctx *c, const IdxArg<M> &ia, const DiagArg<M> &da, const double *z, const double *R,
                              int rkind, const double *qm, const uint8_t *mask)
 {
+  double *out = update_target(c);
   if (qm)
-    k_update<NS, M, true, MH><<<nblk(c->B), 64, 0, c->stream>>>(c->st, c->stride, c->B, ia, z, R, rkind, da, qm, mask, c->k);
+    k_update<NS, M, true, MH><<<nblk(c->B), 64, 0, c->stream>>>(c->st, out, c->stride, c->B, ia, z, R, rkind, da, qm, mask, c->k);
   else
-    k_update<NS, M, false, MH><<<nblk(c->B), 64, 0, c->stream>>>(c->st, c->stride, c->B, ia, z, R, rkind, da, qm, mask, c->k);
+    k_update<NS, M, false, MH><<<nblk(c->B), 64, 0, c->stream>>>(c->st, out, c->stride, c->B, ia, z, R, rkind, da, qm, mask, c->k);
+  update_done(c, out);
 }
 
 template <int NS, int M>
@@ -780,10 +813,24 @@ extern "C" int pb_imu_notch(pb_ctx *c, int n_packets, const double *accel_packet
   return PB_OK;
 }
 
+// the head goes back to the context's own array (copying it there if it currently lives in a checkpoint slot)
+static int detach_head(pb_ctx *c, bool keep_contents)
+{
+  if (c->st != c->st_base) {
+    if (keep_contents)
+      HIPCHK(c, hipMemcpyAsync(c->st_base, c->st, sizeof(double) * (size_t) c->nc * c->stride, hipMemcpyDeviceToDevice, c->stream));
+    c->st = c->st_base;
+  }
+  c->out_slot = -1;
+  return PB_OK;
+}
+
 extern "C" int pb_history_reserve(pb_ctx *c, int n_slots)
 {
   ENTER(c);
   if (n_slots < 0) return fail(c, PB_ERR_ARG, "pb_history_reserve: n_slots < 0");
+  int rc = detach_head(c, true);
+  if (rc) return rc;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (c->hist) HIPCHK(c, hipFree(c->hist));
   c->hist = nullptr;
@@ -793,22 +840,44 @@ extern "C" int pb_history_reserve(pb_ctx *c, int n_slots)
   hipError_t e = hipMalloc((void **) &c->hist, bytes * n_slots);
   if (e != hipSuccess)
     return fail(c, PB_ERR_HIP, "pb_history_reserve: %d slots x %zu bytes: %s", n_slots, bytes, hipGetErrorString(e));
+  // the padding columns (batch rounded up to 64) of a slot are read by the cooperative kernel's idle lanes
+  HIPCHK(c, hipMemsetAsync(c->hist, 0, bytes * n_slots, c->stream));
   c->nhist = n_slots;
   return PB_OK;
 }
 
-static int hist_copy(pb_ctx *c, int slot, bool save)
+extern "C" int pb_set_output_slot(pb_ctx *c, int slot)
+{
+  ENTER(c);
+  if (slot < -1 || slot >= c->nhist) return fail(c, PB_ERR_STATE, "pb_set_output_slot: checkpoint slot %d of %d", slot, c->nhist);
+  c->out_slot = slot;
+  return PB_OK;
+}
+
+extern "C" int pb_state_save(pb_ctx *c, int slot)
 {
   ENTER(c);
   NEED_STATE(c);
   if (slot < 0 || slot >= c->nhist) return fail(c, PB_ERR_STATE, "checkpoint slot %d of %d", slot, c->nhist);
   const size_t n = (size_t) c->nc * c->stride;
   double *h = c->hist + (size_t) slot * n;
-  HIPCHK(c, hipMemcpyAsync(save ? h : c->st, save ? c->st : h, sizeof(double) * n, hipMemcpyDeviceToDevice, c->stream));
+  if (h == c->st) return PB_OK;  // the head was written straight into this slot (pb_set_output_slot)
+  HIPCHK(c, hipMemcpyAsync(h, c->st, sizeof(double) * n, hipMemcpyDeviceToDevice, c->stream));
   return PB_OK;
 }
-extern "C" int pb_state_save(pb_ctx *c, int slot) { return hist_copy(c, slot, true); }
-extern "C" int pb_state_restore(pb_ctx *c, int slot) { return hist_copy(c, slot, false); }
+
+extern "C" int pb_state_restore(pb_ctx *c, int slot)
+{
+  ENTER(c);
+  NEED_STATE(c);
+  if (slot < 0 || slot >= c->nhist) return fail(c, PB_ERR_STATE, "checkpoint slot %d of %d", slot, c->nhist);
+  const size_t n = (size_t) c->nc * c->stride;
+  // always into the context's own array: the slot the head may currently live in stays what it is
+  HIPCHK(c, hipMemcpyAsync(c->st_base, c->hist + (size_t) slot * n, sizeof(double) * n, hipMemcpyDeviceToDevice, c->stream));
+  c->st = c->st_base;
+  c->out_slot = -1;
+  return PB_OK;
+}
 
 extern "C" int pb_smooth_step(pb_ctx *c, int slot_next_pred, int slot_next, int slot_cur, int slot_out, double dt)
 {

@@ -74,7 +74,7 @@ struct IdxVel {
 // RBISIMUProcessStep::updateFilter [+ RBISIndexedMeasurement::updateFilter with idx = {3,4,5}, diagonal R]
 // (rbis_update_interface.cpp:30-52, :54-95).  The BASELINE hot step: 2*(n+4+1+n(n+1)/2)*8 + 56 + 48 bytes/filter.
 template <int NS, bool UPDATE, int MH = MH_DEFAULT>
-__global__ __launch_bounds__(PB_STEP_BLOCK, 1) void k_step(double *__restrict__ st, long stride, int B,
+__global__ __launch_bounds__(PB_STEP_BLOCK, 1) void k_step(const double *st, double *sto, long stride, int B,
                                                 const double *__restrict__ imu, const double *__restrict__ lo,
                                                 const uint8_t *__restrict__ mask, double qg, double qa, double qbg,
                                                 double qba, Consts k)
@@ -86,6 +86,7 @@ __global__ __launch_bounds__(PB_STEP_BLOCK, 1) void k_step(double *__restrict__ 
   const unsigned bo = b * 8u;
   const unsigned s8 = (unsigned) stride * 8u, B8 = (unsigned) B * 8u;  // host guarantees NC*stride*8 < 2^32
   const rsrc_t rs = mkbuf(st, (unsigned) L::NC * s8);
+  const rsrc_t ro = mkbuf(sto, (unsigned) L::NC * s8);  // posterior: the same array (in place) or a checkpoint slot
   const rsrc_t ri = mkbuf(imu, 7u * B8);
   const rsrc_t rl = mkbuf(lo, UPDATE ? 6u * B8 : 0u);
   double x[NS], q[4], ll, P[L::NP];
@@ -130,16 +131,16 @@ __global__ __launch_bounds__(PB_STEP_BLOCK, 1) void k_step(double *__restrict__ 
       for (int j = 0; j <= i; j++)
         S[pk(i, j)] = P[pk(3 + i, 3 + j)] + (i == j ? (upd ? rd[i] : 1.0) : 0.0);  // rbis.cpp:134-135
     measurement_update<NS, 3>(x, q, P, ll, resid, S, IdxVel{}, k,
-                              [rs, s8, bo](int pi, double v) { stg<SA>(rs, (L::OFF_P + pi) * s8, bo, v); }, upd);
+                              [ro, s8, bo](int pi, double v) { stg<SA>(ro, (L::OFF_P + pi) * s8, bo, v); }, upd);
   } else {
 #pragma unroll
-    for (int i = 0; i < L::NP; i++) stg<SA>(rs, (L::OFF_P + i) * s8, bo, P[i]);
+    for (int i = 0; i < L::NP; i++) stg<SA>(ro, (L::OFF_P + i) * s8, bo, P[i]);
   }
 #pragma unroll
-  for (int i = 0; i < NS; i++) stg<SA>(rs, (L::OFF_VEC + i) * s8, bo, x[i]);
+  for (int i = 0; i < NS; i++) stg<SA>(ro, (L::OFF_VEC + i) * s8, bo, x[i]);
 #pragma unroll
-  for (int i = 0; i < 4; i++) stg<SA>(rs, (L::OFF_QUAT + i) * s8, bo, q[i]);
-  stg<SA>(rs, L::OFF_LL * s8, bo, ll);
+  for (int i = 0; i < 4; i++) stg<SA>(ro, (L::OFF_QUAT + i) * s8, bo, q[i]);
+  stg<SA>(ro, L::OFF_LL * s8, bo, ll);
 }
 
 // Time-fused replay: T consecutive predict+update steps per launch with the state and P resident in registers; only the
@@ -229,7 +230,7 @@ struct DiagArg {
 // and a store per entry serialises on the load latency: the compiler may not hoist a load above a possibly aliasing
 // store; that version of k_update ran at 0.33-0.45 of the HBM roofline.)
 template <int NS, int M, int R0, int R1, int MH>
-__device__ __forceinline__ void downdate_rows(rsrc_t rs, unsigned s8, unsigned bo, const double (&W)[NS][M],
+__device__ __forceinline__ void downdate_rows(rsrc_t rs, rsrc_t ro, unsigned s8, unsigned bo, const double (&W)[NS][M],
                                               const double (&id)[M])
 {
   using L = Lay<NS>;
@@ -248,7 +249,7 @@ __device__ __forceinline__ void downdate_rows(rsrc_t rs, unsigned s8, unsigned b
       double acc = buf[pk(i, j) - P0];
 #pragma unroll
       for (int kk = 0; kk < M; kk++) acc = fma(-wd[kk], W[j][kk], acc);
-      stg<MemHint<MH>::SA>(rs, (L::OFF_P + pk(i, j)) * s8, bo, acc);
+      stg<MemHint<MH>::SA>(ro, (L::OFF_P + pk(i, j)) * s8, bo, acc);
     }
   }
 }
@@ -260,7 +261,7 @@ __device__ __forceinline__ void downdate_rows(rsrc_t rs, unsigned s8, unsigned b
 // MH: the gathered columns are read with the default policy (they are read again by the row stream), the row stream's
 // loads and every store carry the hint.
 template <int NS, int M, bool ORIENT, int MH = MH_DEFAULT>
-__global__ __launch_bounds__(64, 1) void k_update(double *__restrict__ st, long stride, int B, IdxArg<M> idx,
+__global__ __launch_bounds__(64, 1) void k_update(const double *st, double *sto, long stride, int B, IdxArg<M> idx,
                                                   const double *__restrict__ z, const double *__restrict__ R,
                                                   int rkind, DiagArg<M> rb, const double *__restrict__ qmeas,
                                                   const uint8_t *__restrict__ mask, Consts k)
@@ -272,6 +273,7 @@ __global__ __launch_bounds__(64, 1) void k_update(double *__restrict__ st, long 
   const unsigned bo = b * 8u;
   const unsigned s8 = (unsigned) stride * 8u, B8 = (unsigned) B * 8u;
   const rsrc_t rs = mkbuf(st, (unsigned) L::NC * s8);
+  const rsrc_t ro = mkbuf(sto, (unsigned) L::NC * s8);
   const rsrc_t rz = mkbuf(z, (unsigned) M * B8);
   const rsrc_t rR = mkbuf(R, rkind == PB_R_DIAG ? (unsigned) M * B8 : (rkind == PB_R_FULL ? (unsigned) (M * M) * B8 : 0u));
   const rsrc_t rq = mkbuf(qmeas, ORIENT ? 4u * B8 : 0u);
@@ -352,28 +354,28 @@ __global__ __launch_bounds__(64, 1) void k_update(double *__restrict__ st, long 
   }
   // chunk sizes keep (chunk + W) inside the register file: W is NS x M doubles
   if constexpr (NS == 15 && M <= 4) {
-    downdate_rows<NS, M, 0, 15, MH>(rs, s8, bo, W, id);
+    downdate_rows<NS, M, 0, 15, MH>(rs, ro, s8, bo, W, id);
   } else if constexpr (NS == 15) {
-    downdate_rows<NS, M, 0, 11, MH>(rs, s8, bo, W, id);
-    downdate_rows<NS, M, 11, 15, MH>(rs, s8, bo, W, id);
+    downdate_rows<NS, M, 0, 11, MH>(rs, ro, s8, bo, W, id);
+    downdate_rows<NS, M, 11, 15, MH>(rs, ro, s8, bo, W, id);
   } else if constexpr (M <= 4) {
-    downdate_rows<NS, M, 0, 12, MH>(rs, s8, bo, W, id);
-    downdate_rows<NS, M, 12, 17, MH>(rs, s8, bo, W, id);
-    downdate_rows<NS, M, 17, 21, MH>(rs, s8, bo, W, id);
+    downdate_rows<NS, M, 0, 12, MH>(rs, ro, s8, bo, W, id);
+    downdate_rows<NS, M, 12, 17, MH>(rs, ro, s8, bo, W, id);
+    downdate_rows<NS, M, 17, 21, MH>(rs, ro, s8, bo, W, id);
   } else {
-    downdate_rows<NS, M, 0, 9, MH>(rs, s8, bo, W, id);
-    downdate_rows<NS, M, 9, 13, MH>(rs, s8, bo, W, id);
-    downdate_rows<NS, M, 13, 16, MH>(rs, s8, bo, W, id);
-    downdate_rows<NS, M, 16, 19, MH>(rs, s8, bo, W, id);
-    downdate_rows<NS, M, 19, 21, MH>(rs, s8, bo, W, id);
+    downdate_rows<NS, M, 0, 9, MH>(rs, ro, s8, bo, W, id);
+    downdate_rows<NS, M, 9, 13, MH>(rs, ro, s8, bo, W, id);
+    downdate_rows<NS, M, 13, 16, MH>(rs, ro, s8, bo, W, id);
+    downdate_rows<NS, M, 16, 19, MH>(rs, ro, s8, bo, W, id);
+    downdate_rows<NS, M, 19, 21, MH>(rs, ro, s8, bo, W, id);
   }
   if (upd) add_delta<NS>(x, q, dx, k.chi_tol);
   constexpr int SA = MemHint<MH>::SA;
 #pragma unroll
-  for (int i = 0; i < NS; i++) stg<SA>(rs, (L::OFF_VEC + i) * s8, bo, x[i]);
+  for (int i = 0; i < NS; i++) stg<SA>(ro, (L::OFF_VEC + i) * s8, bo, x[i]);
 #pragma unroll
-  for (int i = 0; i < 4; i++) stg<SA>(rs, (L::OFF_QUAT + i) * s8, bo, q[i]);
-  stg<SA>(rs, L::OFF_LL * s8, bo, ll);
+  for (int i = 0; i < 4; i++) stg<SA>(ro, (L::OFF_QUAT + i) * s8, bo, q[i]);
+  stg<SA>(ro, L::OFF_LL * s8, bo, ll);
 }
 
 // RBISResetUpdate::updateFilter, per-filter inputs: vec [n][B], quat [4][B], cov [n*n][B] column-major
@@ -486,7 +488,7 @@ __global__ void k_summary(const double *__restrict__ st, long stride, int B, dou
 // No lane returns before the barrier: lanes past the batch end work on the zero-initialised padding columns of the
 // state array (stride is the batch rounded up to 64) and on bounds-checked (zero) inputs.
 template <int NS, bool UPDATE, int MH = MH_DEFAULT>
-__global__ __launch_bounds__(128, 1) void k_step_coop(double *__restrict__ st, long stride, int B,
+__global__ __launch_bounds__(128, 1) void k_step_coop(const double *st, double *sto, long stride, int B,
                                                       const double *__restrict__ imu, const double *__restrict__ lo,
                                                       const uint8_t *__restrict__ mask, double qg, double qa,
                                                       double qbg, double qba, Consts k)
@@ -501,6 +503,7 @@ __global__ __launch_bounds__(128, 1) void k_step_coop(double *__restrict__ st, l
   const unsigned bo = b * 8u;
   const unsigned s8 = (unsigned) stride * 8u, B8 = (unsigned) B * 8u;
   const rsrc_t rs = mkbuf(st, (unsigned) L::NC * s8);
+  const rsrc_t ro = mkbuf(sto, (unsigned) L::NC * s8);
   const rsrc_t ri = mkbuf(imu, 7u * B8);
   const rsrc_t rl = mkbuf(lo, UPDATE ? 6u * B8 : 0u);
   StepInputs in;
@@ -519,7 +522,7 @@ __global__ __launch_bounds__(128, 1) void k_step_coop(double *__restrict__ st, l
     in.qg = ldg(rq, 0u, bo); in.qa = ldg(rq, B8, bo); in.qbg = ldg(rq, 2u * B8, bo); in.qba = ldg(rq, 3u * B8, bo);
   }
   auto ld = [rs, s8, bo](int comp) { return ldg<MemHint<MH>::LA>(rs, (unsigned) comp * s8, bo); };
-  auto stf = [rs, s8, bo](int comp, double v) { stg<MemHint<MH>::SA>(rs, (unsigned) comp * s8, bo, v); };
+  auto stf = [ro, s8, bo](int comp, double v) { stg<MemHint<MH>::SA>(ro, (unsigned) comp * s8, bo, v); };
   auto sync = []() { __syncthreads(); };
   if (role == 0) {
     coop_role_core<NS, UPDATE>(ld, stf, [lane](int s, double v) { xch[s][lane] = v; }, sync, in, k);

@@ -580,3 +580,43 @@ def test_broadcast_inputs_equal_replicated_blocks(pa, oracle, n):
                               (C.c_double * 4)(*q4), PB_HOST_BROADCAST)
     assert rc != 0 and b"BROADCAST" in bc._L.pb_last_error(bc._h)
     rep.close(); bc.close()
+
+
+@pytest.mark.parametrize("n", [15, 21])
+def test_output_slot_checkpoints_equal_copies(pa, oracle, n):
+    """pb_set_output_slot: an update that writes its posterior straight into a checkpoint slot must leave exactly what
+    update + pb_state_save leaves, for every update kind; and a saved posterior is never modified by later updates."""
+    B, T = 300, 12
+    w = Workload(B, n_states=n)
+    vec, quat, P0 = w.initial_state()
+    q4 = w.process_noise()
+    a = pa.BatchEstimator(B, n_states=n)   # update in place, then copy
+    b = pa.BatchEstimator(B, n_states=n)   # update straight into the slot
+    for e in (a, b):
+        e.set_constants(*oracle.constants())
+        e.reset(vec, quat, P0)
+        e.history_reserve(3 * T)
+    for k in range(T):
+        imu = w.imu_block(k)
+        lo, mask = w.legodo_block(k)
+        z, qm, Rd = (w.scanmatch_block(k) if n == 21 else w.vo_block(k))
+        idx = [9, 10, 11, 8] if n == 21 else [9, 10, 11, 6, 7, 8]
+        a.predict(imu, q4); a.state_save(3 * k)
+        b.set_output_slot(3 * k); b.predict(imu, q4); b.state_save(3 * k)          # save = no-op here
+        a.step_legodo(imu, lo, mask, q4); a.state_save(3 * k + 1)
+        b.set_output_slot(3 * k + 1); b.step_legodo(imu, lo, mask, q4)
+        a.update_indexed(idx, pad_z(z, len(idx)), Rd, quat_meas=np.ascontiguousarray(qm))
+        a.state_save(3 * k + 2)
+        if k % 2:   # an update that finds the head in a slot and has no slot of its own goes back to the own array
+            b.update_indexed(idx, pad_z(z, len(idx)), Rd, quat_meas=np.ascontiguousarray(qm))
+            b.state_save(3 * k + 2)
+        else:
+            b.set_output_slot(3 * k + 2)
+            b.update_indexed(idx, pad_z(z, len(idx)), Rd, quat_meas=np.ascontiguousarray(qm))
+    for x, y in zip(a.get_head(), b.get_head()):
+        assert np.array_equal(x, y)
+    for slot in range(3 * T):              # every checkpoint, including the ones later updates read from
+        a.state_restore(slot); b.state_restore(slot)
+        for x, y in zip(a.get_head(), b.get_head()):
+            assert np.array_equal(x, y), slot
+    a.close(); b.close()
