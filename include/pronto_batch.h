@@ -96,6 +96,11 @@ int pb_malloc(pb_ctx *ctx, uint64_t bytes, void **dev_ptr);
 int pb_free(pb_ctx *ctx, void *dev_ptr);
 int pb_memcpy_h2d(pb_ctx *ctx, void *dev_dst, const void *host_src, uint64_t bytes);
 int pb_memcpy_d2h(pb_ctx *ctx, void *host_dst, const void *dev_src, uint64_t bytes);
+/* Page-locked host memory for PB_HOST inputs.  Any host memory works; from pinned buffers the staging copy is a DMA at
+ * link rate, and either way it runs on a second stream into one of two staging buffers, so the copy of message k+1
+ * overlaps the kernels of message k.  A PB_HOST call returns when its buffers have been copied (reusable at once). */
+int pb_host_alloc(pb_ctx *ctx, uint64_t bytes, void **host_ptr);
+int pb_host_free(pb_ctx *ctx, void *host_ptr);
 
 /* ---- update objects (rbis_update_interface.hpp) ----------------------------------------------------- */
 

@@ -62,6 +62,7 @@ class BatchEstimator:
         if rc:
             raise PbError(rc, (self._L.pb_last_error(None) or b"").decode())
         self._h = h
+        self._pinned = []
         self.B, self.n, self.device = batch, n_states, device
         # Launch on torch's current stream of that device (usually the null stream): device tensors handed to this
         # object are produced by torch kernels/copies on that stream, so stream order makes them visible.
@@ -74,6 +75,9 @@ class BatchEstimator:
 
     def close(self):
         if getattr(self, "_h", None):
+            for p in getattr(self, "_pinned", []):
+                self._L.pb_host_free(self._h, p)
+            self._pinned = []
             self._L.pb_destroy(self._h)
             self._h = None
 
@@ -103,6 +107,16 @@ class BatchEstimator:
     # --- posterior checkpoints, RTS smoother ---
     def history_reserve(self, n_slots):
         self._chk(self._L.pb_history_reserve(self._h, n_slots))
+
+    def pinned_empty(self, shape, dtype=np.float64):
+        """A numpy array in page-locked host memory (pb_host_alloc): PB_HOST blocks copied from it move at link rate.
+        Freed when the estimator is closed."""
+        nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = C.c_void_p()
+        self._chk(self._L.pb_host_alloc(self._h, nbytes, C.byref(p)))
+        self._pinned.append(p)
+        buf = (C.c_char * max(nbytes, 1)).from_address(p.value)
+        return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
 
     def set_output_slot(self, slot):
         """The next update writes its posterior straight into checkpoint `slot` (which becomes the head): a checkpoint

@@ -36,6 +36,13 @@ struct pb_ctx {
   bool notch_ready = false;
   void *stage = nullptr;
   size_t stage_bytes = 0;
+  // PB_HOST inputs: two staging buffers filled on a copy stream, so that the copy of message k+1 overlaps the kernels
+  // of message k (with pinned source buffers, pb_host_alloc, the DMA runs at link rate)
+  void *in_stage[2] = { nullptr, nullptr };
+  size_t in_stage_bytes[2] = { 0, 0 };
+  int in_idx = 0;
+  hipStream_t copy_stream = nullptr;
+  hipEvent_t ev_consumed[2] = { nullptr, nullptr }, ev_copied = nullptr;
   Consts k{ 9.80665, 1e-6 };
   int64_t utime = 0;
   bool have_state = false;
@@ -166,6 +173,10 @@ extern "C" int pb_create(pb_ctx **out, int n_states, int batch, int device, int 
   CRCHK(hipMalloc((void **) &c->d_small, sizeof(double) * 1024));
   CRCHK(hipEventCreate(&c->ev0));
   CRCHK(hipEventCreate(&c->ev1));
+  CRCHK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+  CRCHK(hipEventCreateWithFlags(&c->ev_consumed[0], hipEventDisableTiming));
+  CRCHK(hipEventCreateWithFlags(&c->ev_consumed[1], hipEventDisableTiming));
+  CRCHK(hipEventCreateWithFlags(&c->ev_copied, hipEventDisableTiming));
   CRCHK(hipStreamSynchronize(c->stream));
 #undef CRCHK
   *out = c;
@@ -183,6 +194,13 @@ extern "C" int pb_destroy(pb_ctx *c)
   if (c->notch) (void) hipFree(c->notch);
   if (c->d_small) (void) hipFree(c->d_small);
   if (c->stage) (void) hipFree(c->stage);
+  if (c->copy_stream) (void) hipStreamSynchronize(c->copy_stream);
+  for (int i = 0; i < 2; i++) {
+    if (c->in_stage[i]) (void) hipFree(c->in_stage[i]);
+    if (c->ev_consumed[i]) (void) hipEventDestroy(c->ev_consumed[i]);
+  }
+  if (c->ev_copied) (void) hipEventDestroy(c->ev_copied);
+  if (c->copy_stream) (void) hipStreamDestroy(c->copy_stream);
   if (c->ev0) (void) hipEventDestroy(c->ev0);
   if (c->ev1) (void) hipEventDestroy(c->ev1);
   if (c->own_stream) (void) hipStreamDestroy(c->own_stream);
@@ -193,6 +211,7 @@ extern "C" int pb_destroy(pb_ctx *c)
 extern "C" int pb_set_stream(pb_ctx *c, void *s)
 {
   if (!c) return PB_ERR_ARG;
+  if ((hipStream_t) s != c->stream) HIPCHK(c, hipStreamSynchronize(c->stream));  // staging buffers in flight belong to the old stream
   c->stream = (hipStream_t) s;  // literal handle: NULL is the (legacy) null stream, which is torch's default stream
   return PB_OK;
 }
@@ -200,6 +219,7 @@ extern "C" int pb_set_stream(pb_ctx *c, void *s)
 extern "C" int pb_use_own_stream(pb_ctx *c)
 {
   if (!c) return PB_ERR_ARG;
+  if (c->stream != c->own_stream) HIPCHK(c, hipStreamSynchronize(c->stream));
   c->stream = c->own_stream;
   return PB_OK;
 }
@@ -264,6 +284,21 @@ extern "C" int pb_memcpy_d2h(pb_ctx *c, void *h, const void *d, uint64_t bytes)
   return PB_OK;
 }
 
+extern "C" int pb_host_alloc(pb_ctx *c, uint64_t bytes, void **host_ptr)
+{
+  if (!c || !host_ptr) return PB_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->dev));
+  HIPCHK(c, hipHostMalloc(host_ptr, bytes ? (size_t) bytes : 8, hipHostMallocDefault));
+  return PB_OK;
+}
+
+extern "C" int pb_host_free(pb_ctx *c, void *host_ptr)
+{
+  if (!c) return PB_ERR_ARG;
+  if (host_ptr) HIPCHK(c, hipHostFree(host_ptr));
+  return PB_OK;
+}
+
 // staging area for PB_HOST inputs/outputs: a device buffer the host blocks are copied into
 static int stage_reserve(pb_ctx *c, size_t bytes)
 {
@@ -292,8 +327,27 @@ static int stage_in(pb_ctx *c, int mem, Part *parts, int n)
   if (mem != PB_HOST && mem != PB_HOST_BROADCAST) return fail(c, PB_ERR_ARG, "mem must be PB_HOST, PB_DEVICE or PB_HOST_BROADCAST");
   size_t tot = 0;
   for (int i = 0; i < n; i++) tot += (parts[i].bytes + 255) / 256 * 256;
-  int rc = stage_reserve(c, tot);
+  int rc = (mem == PB_HOST_BROADCAST) ? stage_reserve(c, tot) : PB_OK;
   if (rc) return rc;
+  void *in_buf = nullptr;
+  bool copied = false;
+  if (mem == PB_HOST) {
+    // Double-buffered H2D staging on the copy stream.  Everything enqueued on the main stream so far includes the
+    // consumer of the buffer used by the previous call; the buffer used now was consumed two calls ago.
+    const int prev = c->in_idx, cur = prev ^ 1;
+    HIPCHK(c, hipEventRecord(c->ev_consumed[prev], c->stream));
+    c->in_idx = cur;
+    if (tot > c->in_stage_bytes[cur]) {
+      HIPCHK(c, hipEventSynchronize(c->ev_consumed[cur]));
+      if (c->in_stage[cur]) HIPCHK(c, hipFree(c->in_stage[cur]));
+      c->in_stage[cur] = nullptr;
+      c->in_stage_bytes[cur] = 0;
+      HIPCHK(c, hipMalloc(&c->in_stage[cur], tot));
+      c->in_stage_bytes[cur] = tot;
+    }
+    HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->ev_consumed[cur], 0));
+    in_buf = c->in_stage[cur];
+  }
   size_t off = 0;
   for (int i = 0; i < n; i++) {
     if (parts[i].src && mem == PB_HOST_BROADCAST) {
@@ -309,12 +363,19 @@ static int stage_in(pb_ctx *c, int mem, Part *parts, int n)
       HIPCHK(c, hipGetLastError());
       parts[i].dev = (char *) c->stage + off;
     } else if (parts[i].src) {
-      HIPCHK(c, hipMemcpyAsync((char *) c->stage + off, parts[i].src, parts[i].bytes, hipMemcpyHostToDevice, c->stream));
-      parts[i].dev = (char *) c->stage + off;
+      HIPCHK(c, hipMemcpyAsync((char *) in_buf + off, parts[i].src, parts[i].bytes, hipMemcpyHostToDevice, c->copy_stream));
+      parts[i].dev = (char *) in_buf + off;
+      copied = true;
     } else {
       parts[i].dev = nullptr;
     }
     off += (parts[i].bytes + 255) / 256 * 256;
+  }
+  if (copied) {
+    // The caller may reuse its buffers as soon as this returns, so wait for the copy -- NOT for the main stream: the
+    // kernels of the previous message keep running underneath.
+    HIPCHK(c, hipEventRecord(c->ev_copied, c->copy_stream));
+    HIPCHK(c, hipEventSynchronize(c->ev_copied));
   }
   return PB_OK;
 }
