@@ -843,20 +843,32 @@ public:
 class LegOdoHandler {
 public:
   LegOdoCommon *leg_odo_common_;
-  int zero_initial_velocity;  // rbis_legodo_update.cpp:265-269: report zero velocity for the first N ticks
+  int zero_initial_velocity;      // rbis_legodo_update.cpp:58,265-269
+  bool force_torque_init_ = true; // rbis_legodo_update.cpp:98,197,208-211: nothing is integrated before the first
+                                  // force/torque message; a host that replays F/T sets this false and calls
+                                  // forceTorqueHandler() from its F/T callback (the deltas fed here already contain
+                                  // leg_estimate's use of the foot sensing, so the default is "seen")
   explicit LegOdoHandler(BotParam *param) : leg_odo_common_(new LegOdoCommon(param)), zero_initial_velocity(0)
   {
     auto it = param->kv.find("state_estimator.legodo.zero_initial_velocity");
     if (it != param->kv.end()) zero_initial_velocity = atoi(it->second.c_str());
   }
   ~LegOdoHandler() { delete leg_odo_common_; }
+  void forceTorqueHandler() { force_torque_init_ = true; }
   RBISUpdateInterface *processMessage(const msgs::legodo_delta_t *msg, MavStateEstimator *est)
   {
+    if (!force_torque_init_) {
+      fprintf(stdout, "Force/Torque message not received yet, not integrating leg odometry =========================\n");
+      return nullptr;
+    }
+    // "Ignore the calculated velocity at launch" (:264-269): decrement FIRST, then compare -- N zeroes N-1 ticks
+    zero_initial_velocity--;
     if (zero_initial_velocity > 0) {
-      zero_initial_velocity--;
       std::vector<double> zero((size_t) 3 * est->B, 0.0);
       msgs::legodo_delta_t m2 = *msg;
-      m2.delta_trans = zero.data();
+      m2.delta_trans = zero.data();   // odo_delta.setIdentity()
+      m2.delta_quat = nullptr;
+      if (msg->position != nullptr) m2.position = zero.data();  // odo_position.setIdentity(), status passed on as is
       return leg_odo_common_->createMeasurement(&m2, est->B);
     }
     return leg_odo_common_->createMeasurement(msg, est->B);
