@@ -198,6 +198,8 @@ int pb_state_save(pb_ctx *ctx, int slot);      /* slot <- head posterior (state,
  * A saved posterior is never modified afterwards: an update that finds the head in a slot and has no output slot of its
  * own writes back into the context's array; pb_state_restore and pb_reset always land there.  slot = -1 cancels. */
 int pb_set_output_slot(pb_ctx *ctx, int slot);
+/* the checkpoint slot the head currently lives in, or -1 (the context's own array) */
+int pb_head_slot(const pb_ctx *ctx);
 int pb_state_restore(pb_ctx *ctx, int slot);   /* head posterior <- slot */
 
 /* ekfSmoothingStep (rbis.cpp:234-266), one backward step of MavStateEstimator::EKFSmoothBackwardsPass

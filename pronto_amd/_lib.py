@@ -75,6 +75,7 @@ _SIGS = {
     "pb_history_reserve": (C.c_int, [C.c_void_p, C.c_int]),
     "pb_state_save": (C.c_int, [C.c_void_p, C.c_int]),
     "pb_set_output_slot": (C.c_int, [C.c_void_p, C.c_int]),
+    "pb_head_slot": (C.c_int, [C.c_void_p]),
     "pb_host_alloc": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]),
     "pb_host_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "pb_state_restore": (C.c_int, [C.c_void_p, C.c_int]),

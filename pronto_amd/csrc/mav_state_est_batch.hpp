@@ -256,6 +256,25 @@ public:
   }
 };
 
+// Two updates with complementary per-filter masks that together are ONE update of the reference (each filter takes
+// exactly one branch): used where the reference changes the measurement dimension per message (LegOdoCommon's
+// pos_and_lin_rate -> lin_rate fallback, rbis_legodo_common.cpp:118-122).  If the first half wrote its posterior into a
+// checkpoint slot, the second half works in place on that slot.
+class RBISEitherUpdate : public RBISUpdateInterface {
+public:
+  RBISUpdateInterface *first, *second;
+  RBISEitherUpdate(RBISUpdateInterface *a, RBISUpdateInterface *b) : RBISUpdateInterface(a->sensor_id, a->utime), first(a), second(b) {}
+  ~RBISEitherUpdate() override { delete first; delete second; }
+  int updateFilter(pb_ctx *ctx) override
+  {
+    int rc = first->updateFilter(ctx);
+    if (rc != PB_OK) return rc;
+    const int slot = pb_head_slot(ctx);
+    if (slot >= 0) pb_set_output_slot(ctx, slot);
+    return second->updateFilter(ctx);
+  }
+};
+
 // ---------------------------------------------------------------------------------------------------------------
 // updateHistory + MavStateEstimator (update_history.hpp:12-36, mav_state_est.hpp / .cpp:12-96)
 //
@@ -794,10 +813,29 @@ public:
 
   // createMeasurement (rbis_legodo_common.cpp:110-169) for B filters.  Filters whose delta status is < 0 (the
   // handler's "return NULL", rbis_legodo_update.cpp:242-255) get mask 0.  In mode pos_and_lin_rate the reference
-  // falls back to lin_rate per message when the position is invalid (:118-122); a batch cannot change m per filter,
-  // so such filters keep m = 6 with an uninformative (1e12) position variance -- K for those rows is ~0.
+  // falls back to lin_rate per message when the position is invalid (:118-122): those filters take an m = 3 velocity
+  // update, the others the m = 6 one (RBISEitherUpdate), so every filter gets exactly the reference's update and
+  // log-likelihood increment.
   RBISUpdateInterface *createMeasurement(const msgs::legodo_delta_t *msg, int B) const
   {
+    if (mode_ == MODE_POSITION_AND_LIN_RATE && msg->position_status != nullptr) {
+      bool any_bad = false, any_good = false;
+      for (int b = 0; b < B; b++) (msg->position_status[b] ? any_good : any_bad) = true;
+      if (any_bad) {
+        LegOdoCommon lin(*this);
+        lin.mode_ = MODE_LIN_RATE;
+        msgs::legodo_delta_t m3 = *msg;
+        m3.position_status = nullptr;
+        auto *fallback = static_cast<RBISIndexedMeasurement *>(lin.createMeasurement(&m3, B));
+        for (int b = 0; b < B; b++) fallback->owned_mask[(size_t) b] &= (uint8_t) !msg->position_status[b];
+        if (!any_good) return fallback;
+        msgs::legodo_delta_t m6 = *msg;
+        m6.position_status = nullptr;
+        auto *full = static_cast<RBISIndexedMeasurement *>(createMeasurement(&m6, B));
+        for (int b = 0; b < B; b++) full->owned_mask[(size_t) b] &= (uint8_t) (msg->position_status[b] != 0);
+        return new RBISEitherUpdate(full, fallback);
+      }
+    }
     const double elapsed = (double) (msg->utime - msg->prev_utime) * 1E-6;  // pronto_conversions_lcm.hpp:45
     const int m = (mode_ == MODE_LIN_RATE) ? 3 : 6;
     std::vector<double> z((size_t) m * B), R((size_t) m * B);
@@ -824,11 +862,10 @@ public:
           R[(size_t) (3 + i) * B + b] = Rd[3 + i];
         }
       } else {
-        const bool pos_ok = !msg->position_status || msg->position_status[b];
         for (int i = 0; i < 3; i++) {
           z[(size_t) i * B + b] = msg->position ? msg->position[(size_t) i * B + b] : 0.0;
           z[(size_t) (3 + i) * B + b] = vel[i];
-          R[(size_t) i * B + b] = pos_ok ? Rd[i] : 1e12;
+          R[(size_t) i * B + b] = Rd[i];
           R[(size_t) (3 + i) * B + b] = Rd[3 + i];
         }
       }

@@ -915,6 +915,12 @@ extern "C" int pb_set_output_slot(pb_ctx *c, int slot)
   return PB_OK;
 }
 
+extern "C" int pb_head_slot(const pb_ctx *c)
+{
+  if (!c || c->st == c->st_base || !c->hist) return -1;
+  return (int) ((size_t) (c->st - c->hist) / ((size_t) c->nc * c->stride));
+}
+
 extern "C" int pb_state_save(pb_ctx *c, int slot)
 {
   ENTER(c);

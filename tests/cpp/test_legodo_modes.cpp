@@ -1,0 +1,131 @@
+// test_legodo_modes.cpp -- LegOdoCommon::createMeasurement (rbis_legodo_common.cpp:110-169) through the shim for the modes
+// the miniature se-fusion of test_shim.cpp does not use: pos_and_lin_rate with its per-message fall-back to lin_rate when
+// the position is not valid (:118-122; per filter here: RBISEitherUpdate) and lin_rot_rate; delta status -1 / 0 / 1 per
+// filter; with posterior checkpoints on (argv[2] = history slots) the two halves of the either-update must land in the
+// same checkpoint slot.  Checked filter by filter against the oracle.  Exit code 0 + "PASS".  Needs a GPU.
+#include <cinttypes>
+#include <cstdio>
+#include <vector>
+
+#include "../../oracle/pronto_oracle.h"
+#include "../../pronto_amd/csrc/mav_state_est_batch.hpp"
+
+using namespace MavStateEst;
+
+static uint64_t rng_state = 0x4C45474F444FULL;
+static double urand()
+{
+  rng_state = rng_state * 6364136223846793005ULL + 1442695040888963407ULL;
+  return ((rng_state >> 11) + 0.5) / 9007199254740992.0;
+}
+static double nrand() { return sqrt(-2 * log(urand())) * cos(2 * M_PI * urand()); }
+
+int main(int argc, char **argv)
+{
+  const std::string mode = argc > 1 ? argv[1] : "pos_and_lin_rate";
+  const int slots = argc > 2 ? atoi(argv[2]) : 0;
+  const int omode = mode == "lin_rate" ? 0 : (mode == "lin_rot_rate" ? 1 : 2);
+  const int n = 15, B = 150, T = 40;
+  BotParam param;
+  param.set("state_estimator.utime_history_span", "1000000");
+  param.set("state_estimator.history_slots", std::to_string(slots));
+  param.set("state_estimator.ins.channel", "IMU");
+  param.set("state_estimator.ins.q_gyro", 0.5);
+  param.set("state_estimator.ins.q_accel", 0.1);
+  param.set("state_estimator.ins.q_gyro_bias", 0.0);
+  param.set("state_estimator.ins.q_accel_bias", 0.0);
+  param.set("state_estimator.ins.timestep_dt", 0.001);
+  param.set("state_estimator.ins.atlas_filter", "false");
+  param.set("state_estimator.ins.accel_bias_update_online", "false");
+  param.set("state_estimator.ins.gyro_bias_update_online", "false");
+  param.applyOverrides("state_estimator.legodo.mode=" + mode + "|state_estimator.legodo.r_xyz=0.2|state_estimator.legodo.r_vxyz=0.1|"
+                       "state_estimator.legodo.r_vang=0.3|state_estimator.legodo.r_vxyz_uncertain=0.5|"
+                       "state_estimator.legodo.r_vang_uncertain=0.9");
+  for (const char *s : { "ins", "legodo" }) {
+    param.set(std::string("state_estimator.") + s + ".downsample_factor", "1");
+    param.set(std::string("state_estimator.") + s + ".roll_forward_on_receive", "true");
+    param.set(std::string("state_estimator.") + s + ".utime_offset", "0");
+  }
+  RBIS x0(n, B);
+  RBIM P0(n, B);
+  std::vector<po_rbis> ox(B);
+  std::vector<po_rbim> oP(B);
+  std::vector<double> oll(B, 0.0);
+  for (int b = 0; b < B; b++) {
+    double q[4];
+    po_euler_to_quat(0.1 * (urand() - 0.5), 0.1 * (urand() - 0.5), 6.0 * (urand() - 0.5), q);
+    po_rbis_zero(&ox[b]);
+    memset(&oP[b], 0, sizeof(po_rbim));
+    for (int i = 0; i < 4; i++) { x0.q(i, b) = q[i]; ox[b].quat[i] = q[i]; }
+    const double sig[15] = { 0, 0, 0, .15, .15, .15, .05, .05, .05, .5, .5, .5, 0, 0, 0 };
+    for (int i = 0; i < n; i++) { P0(i, i, b) = sig[i] * sig[i]; oP[b].m[i * 21 + i] = sig[i] * sig[i]; }
+  }
+  BotTrans ins_to_body;
+  InsHandler ins_handler(&param, &ins_to_body);
+  LegOdoHandler legodo_handler(&param);
+  FrontEnd front_end(&param);
+  auto on_ins = front_end.addSensor("ins", &InsHandler::processMessage, &ins_handler);
+  auto on_legodo = front_end.addSensor("legodo", &LegOdoHandler::processMessage, &legodo_handler);
+  MavStateEstimator est(new RBISResetUpdate(x0, P0, RBISUpdateInterface::reset, 0), &param, 0);
+  front_end.setStateEstimator(&est);
+  const double q4[4] = { ins_handler.cov_gyro, ins_handler.cov_accel, ins_handler.cov_gyro_bias, ins_handler.cov_accel_bias };
+  const double r5[5] = { 0.2, 0.1, 0.3, 0.5, 0.9 };
+  double g;
+  po_get_constants(&g, nullptr);
+  std::vector<double> pos(3 * B), dtr(3 * B), dq(4 * B);
+  std::vector<int> pstat(B);
+  std::vector<float> status(B);
+  int n_fallback = 0, n_full = 0, n_skip = 0;
+  for (int k = 0; k < T; k++) {
+    const int64_t utime = (int64_t) (k + 1) * 1000;
+    const double v[6] = { 0.2 * sin(0.1 * k), 0.1, -0.15 * cos(0.07 * k), 0.2 * nrand(), 0.2 * nrand(), g + 0.2 * nrand() };
+    msgs::ins_t im{ utime, BatchArray(v, PB_HOST_BROADCAST), BatchArray(v + 3, PB_HOST_BROADCAST) };
+    on_ins(&im);
+    for (int b = 0; b < B; b++) po_imu_process_step(v, v + 3, 0.001, q4[0], q4[1], q4[2], q4[3], &ox[b], &oP[b], oll[b], &ox[b], &oP[b], &oll[b]);
+    for (int b = 0; b < B; b++) {
+      double qq[4];
+      po_euler_to_quat(0.002 * nrand(), 0.002 * nrand(), 0.003 * nrand(), qq);
+      for (int i = 0; i < 3; i++) {
+        pos[i * B + b] = ox[b].vec[9 + i] + 0.2 * nrand();
+        dtr[i * B + b] = (ox[b].vec[3 + i] + 0.1 * nrand()) * 0.001;
+      }
+      for (int i = 0; i < 4; i++) dq[i * B + b] = qq[i];
+      const double u = urand();
+      status[b] = u < 0.15 ? -1.f : (u < 0.45 ? 1.f : 0.f);
+      // every 5th message: the position is bad for everybody, every 7th: good for everybody, else mixed
+      pstat[b] = (k % 5 == 4) ? 0 : ((k % 7 == 6) ? 1 : (urand() < 0.6));
+    }
+    msgs::legodo_delta_t lo{ utime, utime - 1000, pos.data(), dtr.data(), dq.data(), pstat.data(), status.data() };
+    on_legodo(&lo);
+    for (int b = 0; b < B; b++) {
+      if (status[b] < 0) { n_skip++; continue; }
+      int idx[6];
+      double z[6], Rd[6], R[36] = { 0 };
+      const double p3[3] = { pos[b], pos[B + b], pos[2 * B + b] }, t3[3] = { dtr[b], dtr[B + b], dtr[2 * B + b] };
+      const double qi[4] = { dq[b], dq[B + b], dq[2 * B + b], dq[3 * B + b] };
+      const int m = po_legodo_create_measurement(omode, r5, p3, t3, qi, utime, utime - 1000, pstat[b], status[b], idx, z, Rd);
+      (m == 3 && omode == 2 ? n_fallback : n_full)++;
+      for (int i = 0; i < m; i++) R[i * m + i] = Rd[i];
+      po_indexed_update(m, idx, z, R, &ox[b], &oP[b], oll[b], &ox[b], &oP[b], &oll[b]);
+    }
+  }
+  RBIS head;
+  RBIM cov;
+  est.getHeadState(head, cov);
+  std::vector<double> ll = est.getMeasurementsLogLikelihood();
+  double ev = 0, eq = 0, eP = 0, el = 0, sv = 0, sP = 0, sl = 0;
+  for (int b = 0; b < B; b++) {
+    for (int i = 0; i < n; i++) { ev = fmax(ev, fabs(head(i, b) - ox[b].vec[i])); sv = fmax(sv, fabs(ox[b].vec[i])); }
+    for (int i = 0; i < 4; i++) eq = fmax(eq, fabs(head.q(i, b) - ox[b].quat[i]));
+    for (int c = 0; c < n; c++)
+      for (int r = 0; r < n; r++) { eP = fmax(eP, fabs(cov(r, c, b) - oP[b].m[c * 21 + r])); sP = fmax(sP, fabs(oP[b].m[c * 21 + r])); }
+    el = fmax(el, fabs(ll[b] - oll[b]));
+    sl = fmax(sl, fabs(oll[b]));
+  }
+  printf("mode %s, %d history slots: %d full, %d fall-back, %d skipped filter-updates; rel err vec %.2e quat %.2e cov %.2e ll %.2e "
+         "(status %d)\n", mode.c_str(), slots, n_full, n_fallback, n_skip, ev / sv, eq, eP / sP, el / sl, est.last_status);
+  const bool ok = est.last_status == PB_OK && head.utime == (int64_t) T * 1000 && ev / sv < 1e-9 && eq < 1e-9 && eP / sP < 1e-9 &&
+                  el / sl < 1e-9 && n_skip > 0 && (omode != 2 || (n_fallback > 0 && n_full > 0));
+  printf(ok ? "PASS\n" : "FAIL\n");
+  return ok ? 0 : 1;
+}

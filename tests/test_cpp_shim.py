@@ -60,7 +60,19 @@ def test_lcm_log_replay_and_filter_state_publishing_on_gpu(oracle, tmp_path):
     assert r.returncode == 0 and "PASS" in r.stdout, r.stdout + r.stderr
 
 
-@pytest.mark.parametrize("name", ["test_shim", "test_history", "test_atlas_imu", "test_smooth_pass", "test_log_replay"])
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,slots", [("pos_and_lin_rate", 0), ("pos_and_lin_rate", 6), ("lin_rot_rate", 0)])
+def test_legodo_modes_on_gpu(oracle, mode, slots):
+    """LegOdoCommon's other modes, incl. the per-filter pos_and_lin_rate -> lin_rate fall-back (two complementary masked
+    updates), with and without posterior checkpoints, vs the oracle's createMeasurement + indexed update."""
+    exe = build_exe(oracle, "test_legodo_modes")
+    r = subprocess.run([exe, mode, str(slots)], capture_output=True, text=True, timeout=300)
+    print(r.stdout, r.stderr)
+    assert r.returncode == 0 and "PASS" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("name", ["test_shim", "test_history", "test_atlas_imu", "test_smooth_pass", "test_log_replay",
+                                  "test_legodo_modes"])
 def test_shim_compiles_and_links(oracle, name):
     exe = build_exe(oracle, name)
     out = subprocess.run(["ldd", exe], capture_output=True, text=True).stdout
