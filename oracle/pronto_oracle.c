@@ -876,3 +876,53 @@ double po_batch_run_legodo(po_batch *s, int T, const double *imu_stream, const d
   }
   return now_s() - t0;
 }
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * INS initialisation (sensor_handlers.cpp:283-364)
+ * ------------------------------------------------------------------------------------------------------------- */
+void po_quat_from_two_vectors(const double *a, const double *b, double *q)
+{
+  double na = sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]), nb = sqrt(b[0] * b[0] + b[1] * b[1] + b[2] * b[2]);
+  double v0[3], v1[3];
+  int i;
+  for (i = 0; i < 3; i++) {
+    v0[i] = a[i] / na;
+    v1[i] = b[i] / nb;
+  }
+  double c = v0[0] * v1[0] + v0[1] * v1[1] + v0[2] * v1[2];
+  if (c < -1.0 + 1e-12) { /* opposite vectors: half a turn about any axis orthogonal to v0 */
+    double ax[3] = { 0, 0, 0 };
+    int k = (fabs(v0[0]) < fabs(v0[1])) ? (fabs(v0[0]) < fabs(v0[2]) ? 0 : 2) : (fabs(v0[1]) < fabs(v0[2]) ? 1 : 2);
+    double e[3] = { 0, 0, 0 };
+    e[k] = 1.0;
+    ax[0] = v0[1] * e[2] - v0[2] * e[1];
+    ax[1] = v0[2] * e[0] - v0[0] * e[2];
+    ax[2] = v0[0] * e[1] - v0[1] * e[0];
+    double n = sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
+    if (c < -1.0) c = -1.0;
+    double w2 = (1.0 + c) * 0.5;
+    q[0] = sqrt(w2);
+    for (i = 0; i < 3; i++) q[1 + i] = ax[i] / n * sqrt(1.0 - w2);
+    return;
+  }
+  double axis[3] = { v0[1] * v1[2] - v0[2] * v1[1], v0[2] * v1[0] - v0[0] * v1[2], v0[0] * v1[1] - v0[1] * v1[0] };
+  double s = sqrt((1.0 + c) * 2.0), invs = 1.0 / s;
+  q[0] = s * 0.5;
+  for (i = 0; i < 3; i++) q[1 + i] = axis[i] * invs;
+}
+
+void po_ins_init(const double *g_vec_sum, const double *gyro_sum, int count, double max_gyro_bias, const double *quat_in,
+                 double *quat_out, double *gyro_bias_est)
+{
+  double g_est[3], qg[4];
+  const double minus_z[3] = { 0.0, 0.0, -1.0 };
+  int i, too_big = 0;
+  for (i = 0; i < 3; i++) {
+    g_est[i] = g_vec_sum[i] / (double) count;
+    gyro_bias_est[i] = gyro_sum[i] / (double) count;
+    if (fabs(gyro_bias_est[i]) > max_gyro_bias) too_big = 1;
+  }
+  if (too_big) gyro_bias_est[0] = gyro_bias_est[1] = gyro_bias_est[2] = 0.0;
+  po_quat_from_two_vectors(g_est, minus_z, qg);
+  po_quat_mul(quat_in, qg, quat_out);
+}

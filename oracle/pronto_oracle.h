@@ -99,6 +99,18 @@ void po_indexed_orient_update(int m, const int *idx, const double *z, const doub
                               const po_rbis *prior, const po_rbim *prior_cov, double prior_ll, po_rbis *post,
                               po_rbim *post_cov, double *post_ll);                           /* :97-107 */
 
+/* ---- INS initialisation (InsHandler::processMessageInitCommon, sensor_handlers.cpp:283-364, without the GPS/magnetometer
+ * yaw branch) ---- */
+/* Eigen's Quaternion::setFromTwoVectors(a, b) [Eigen NOT IN TREE, restated from its documentation/algorithm]: the
+ * smallest rotation q with q * a parallel to b: v0 = a/|a|, v1 = b/|b|, c = v0.v1, axis = v0 x v1, s = sqrt(2(1+c)),
+ * q = (s/2, axis/s).  For c < -1 + 1e-12 Eigen takes the axis from an SVD; here any unit axis orthogonal to v0. */
+void po_quat_from_two_vectors(const double *a, const double *b, double *q);
+/* g_vec_sum = sum of (-accelerometer), gyro_sum = sum of gyro over `count` body-frame samples (:289-291).
+ * quat_out = quat_in * setFromTwoVectors(g_vec_sum/count, -z) (:305-313); gyro_bias_est = gyro_sum/count, or 0 if any
+ * component exceeds max_gyro_bias in magnitude (:303-311). */
+void po_ins_init(const double *g_vec_sum, const double *gyro_sum, int count, double max_gyro_bias, const double *quat_in,
+                 double *quat_out, double *gyro_bias_est);
+
 /* ---- measurement formers (handlers' arithmetic) ---- */
 void po_euler_to_quat(double roll, double pitch, double yaw, double *q);    /* pronto_math.cpp:25-50 */
 void po_quat_to_euler(const double *q, double *rpy);                        /* pronto_math.cpp:53-61 */

@@ -83,6 +83,22 @@ inline bool bot_param_get_boolean_or_fail(BotParam *p, const char *key)
   return v == "true" || v == "1" || v == "True";
 }
 inline std::string bot_param_get_str_or_fail(BotParam *p, const char *key) { return bot_param_get_raw_or_fail(p, key); }
+// "x, y, z" or "[x, y, z]": libbot's bot_param_get_double_array_or_fail
+inline void bot_param_get_double_array_or_fail(BotParam *p, const char *key, double *out, int len)
+{
+  const std::string &v = bot_param_get_raw_or_fail(p, key);
+  const char *c = v.c_str();
+  for (int i = 0; i < len; i++) {
+    while (*c == ' ' || *c == '[' || *c == ',') c++;
+    char *end = nullptr;
+    out[i] = strtod(c, &end);
+    if (end == c) {
+      fprintf(stderr, "ERROR: BotParam: '%s' does not hold %d numbers\n", key, len);
+      exit(1);
+    }
+    c = end;
+  }
+}
 inline double bot_sq(double a) { return a * a; }
 inline double bot_to_radians(double d) { return d * (M_PI / 180.0); }
 
@@ -645,6 +661,47 @@ private:
 // ---------------------------------------------------------------------------------------------------------------
 // handlers
 // ---------------------------------------------------------------------------------------------------------------
+// RBISInitializer's bookkeeping helpers (rbis_initializer.cpp:96-113)
+struct RBISInitializer {
+  static bool allInitializedExcept(const std::map<std::string, bool> &sensors_initialized, const std::string &sensor_prefix)
+  {
+    for (const auto &kv : sensors_initialized) {
+      if (kv.first == sensor_prefix) continue;
+      if (!kv.second) return false;
+    }
+    return true;
+  }
+  static bool initializingWith(const std::map<std::string, bool> &sensors_initialized, const std::string &sensor_prefix)
+  {
+    return sensors_initialized.count(sensor_prefix) > 0;
+  }
+};
+
+// Eigen's Quaternion::setFromTwoVectors(a, b) (w,x,y,z): the smallest rotation with q * a parallel to b; opposite
+// vectors take any axis orthogonal to a (Eigen takes one from an SVD)
+inline void quat_from_two_vectors(const double a[3], const double b[3], double q[4])
+{
+  const double na = sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]), nb = sqrt(b[0] * b[0] + b[1] * b[1] + b[2] * b[2]);
+  const double v0[3] = { a[0] / na, a[1] / na, a[2] / na }, v1[3] = { b[0] / nb, b[1] / nb, b[2] / nb };
+  double c = v0[0] * v1[0] + v0[1] * v1[1] + v0[2] * v1[2];
+  if (c < -1.0 + 1e-12) {
+    const int k = (fabs(v0[0]) < fabs(v0[1])) ? (fabs(v0[0]) < fabs(v0[2]) ? 0 : 2) : (fabs(v0[1]) < fabs(v0[2]) ? 1 : 2);
+    double e[3] = { 0, 0, 0 };
+    e[k] = 1.0;
+    const double ax[3] = { v0[1] * e[2] - v0[2] * e[1], v0[2] * e[0] - v0[0] * e[2], v0[0] * e[1] - v0[1] * e[0] };
+    const double n = sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
+    if (c < -1.0) c = -1.0;
+    const double w2 = (1.0 + c) * 0.5;
+    q[0] = sqrt(w2);
+    for (int i = 0; i < 3; i++) q[1 + i] = ax[i] / n * sqrt(1.0 - w2);
+    return;
+  }
+  const double axis[3] = { v0[1] * v1[2] - v0[2] * v1[1], v0[2] * v1[0] - v0[0] * v1[2], v0[0] * v1[1] - v0[1] * v1[0] };
+  const double sq = sqrt((1.0 + c) * 2.0), invs = 1.0 / sq;
+  q[0] = sq * 0.5;
+  for (int i = 0; i < 3; i++) q[1 + i] = axis[i] * invs;
+}
+
 class InsHandler {
 public:
   std::string channel;
@@ -655,6 +712,7 @@ public:
 
   InsHandler(BotParam *_param, const BotTrans *ins_to_body_ = nullptr)
   {
+    param_ = _param;
     channel = bot_param_get_str_or_fail(_param, "state_estimator.ins.channel");
     cov_gyro = bot_sq(bot_to_radians(bot_param_get_double_or_fail(_param, "state_estimator.ins.q_gyro")));          // :18-19
     cov_accel = bot_sq(bot_param_get_double_or_fail(_param, "state_estimator.ins.q_accel"));                        // :20-21
@@ -724,7 +782,106 @@ public:
     return build(msg->delta_rotation, msg->linear_acceleration, 1.0 / msg->raw_dt, true, integration_dt, msg->utime, est->B);
   }
 
+  // ---- initialisation from gravity (processMessageInit / processMessageInitCommon, sensor_handlers.cpp:254-364) ----
+  // Averages num_to_init body-frame IMU samples per filter: roll and pitch from the mean specific force
+  // (init quat = init quat * setFromTwoVectors(mean(-accel), -z)), the gyro bias from the mean rate (0 if any axis exceeds
+  // max_initial_gyro_bias), the matching covariance blocks from default_cov.  As in the reference the INS goes last
+  // (allInitializedExcept "ins") and the bias that ends up in init_state is *_bias_initial -- the estimate only if
+  // *_bias_recalc_at_start.  The GPS / magnetometer yaw alignment (:338-351) needs the magnetometer of bot_core::ins_t,
+  // which the batch message does not carry: not built.  Keys are read (or_fail) on first use.
+  int num_to_init = 0, init_counter = 0;
+  double max_initial_gyro_bias = 0;
+  bool accel_bias_recalc_at_start = false, gyro_bias_recalc_at_start = false;
+  std::vector<double> g_vec_sum, gyro_bias_sum;              // [3][B]
+  std::vector<double> gyro_bias_initial, accel_bias_initial;  // [3] (same for every filter) or [3][B] after a recalc
+  bool processMessageInit(const msgs::ins_t *msg, const std::map<std::string, bool> &sensors_initialized,
+                          const RBIS & /*default_state*/, const RBIM &default_cov, RBIS &init_state, RBIM &init_cov)
+  {
+    const int B = init_state.B, n = init_state.n;
+    if (!init_params_read_) {
+      num_to_init = (int) bot_param_get_int_or_fail(param_, "state_estimator.ins.num_to_init");
+      max_initial_gyro_bias = bot_param_get_double_or_fail(param_, "state_estimator.ins.max_initial_gyro_bias");
+      gyro_bias_initial.resize(3);
+      accel_bias_initial.resize(3);
+      bot_param_get_double_array_or_fail(param_, "state_estimator.ins.accel_bias_initial", accel_bias_initial.data(), 3);
+      bot_param_get_double_array_or_fail(param_, "state_estimator.ins.gyro_bias_initial", gyro_bias_initial.data(), 3);
+      accel_bias_recalc_at_start = bot_param_get_boolean_or_fail(param_, "state_estimator.ins.accel_bias_recalc_at_start");
+      gyro_bias_recalc_at_start = bot_param_get_boolean_or_fail(param_, "state_estimator.ins.gyro_bias_recalc_at_start");
+      g_vec_sum.assign((size_t) 3 * B, 0.0);
+      gyro_bias_sum.assign((size_t) 3 * B, 0.0);
+      init_params_read_ = true;
+    }
+    init_state.utime = msg->utime;
+    auto *update = static_cast<RBISIMUProcessStep *>(build(msg->gyro, msg->accel, 1.0, false, dt, msg->utime, B));
+    if (update == nullptr) return false;
+    if (!RBISInitializer::allInitializedExcept(sensors_initialized, "ins")) {  // force the INS to go last (:266-267)
+      delete update;
+      return false;
+    }
+    init_counter++;
+    const bool bcast = update->imu_block.mem == PB_HOST_BROADCAST;
+    const size_t per = bcast ? 1 : (size_t) B;
+    for (int b = 0; b < B; b++) {
+      const size_t sb = bcast ? 0 : (size_t) b;
+      for (int i = 0; i < 3; i++) {
+        gyro_bias_sum[(size_t) i * B + b] += update->owned[(size_t) i * per + sb];            // :291
+        g_vec_sum[(size_t) i * B + b] += -update->owned[(size_t) (3 + i) * per + sb];         // :289
+      }
+    }
+    delete update;
+    if (init_counter < num_to_init) return false;
+    bool warned = false;
+    std::vector<double> gb_est((size_t) 3 * B);
+    for (int b = 0; b < B; b++) {
+      if (!warned && (init_cov(RBIS::chi_ind, RBIS::chi_ind, b) > 0 || init_cov(RBIS::chi_ind + 1, RBIS::chi_ind + 1, b) > 0)) {
+        fprintf(stderr, "Warning: overriding initial roll, pitch with IMU values\n");
+        warned = true;
+      }
+      double g_est[3], gb[3];
+      bool too_big = false;
+      for (int i = 0; i < 3; i++) {
+        g_est[i] = g_vec_sum[(size_t) i * B + b] / (double) init_counter;
+        gb[i] = gyro_bias_sum[(size_t) i * B + b] / (double) init_counter;
+        too_big = too_big || fabs(gb[i]) > max_initial_gyro_bias;
+      }
+      if (too_big) gb[0] = gb[1] = gb[2] = 0.0;                                                 // :303-311
+      const double minus_z[3] = { 0.0, 0.0, -1.0 };
+      double qg[4];
+      quat_from_two_vectors(g_est, minus_z, qg);                                               // :314-315
+      const double q0[4] = { init_state.q(0, b), init_state.q(1, b), init_state.q(2, b), init_state.q(3, b) };
+      const double qn[4] = { q0[0] * qg[0] - q0[1] * qg[1] - q0[2] * qg[2] - q0[3] * qg[3],
+                             q0[0] * qg[1] + q0[1] * qg[0] + q0[2] * qg[3] - q0[3] * qg[2],
+                             q0[0] * qg[2] - q0[1] * qg[3] + q0[2] * qg[0] + q0[3] * qg[1],
+                             q0[0] * qg[3] + q0[1] * qg[2] - q0[2] * qg[1] + q0[3] * qg[0] };
+      for (int i = 0; i < 4; i++) init_state.q(i, b) = qn[i];                                   // :320
+      for (int r = 0; r < 2; r++)
+        for (int c = 0; c < 2; c++)
+          init_cov(RBIS::chi_ind + r, RBIS::chi_ind + c, b) = default_cov(RBIS::chi_ind + r, RBIS::chi_ind + c, b);  // :321-322
+      if (n == RBIS::rbis_num_states)
+        for (int r = 0; r < 3; r++)
+          for (int c = 0; c < 3; c++)
+            init_cov(RBIS::gyro_bias_ind + r, RBIS::gyro_bias_ind + c, b) = default_cov(RBIS::gyro_bias_ind + r, RBIS::gyro_bias_ind + c, b);
+      for (int i = 0; i < 3; i++) gb_est[(size_t) i * B + b] = gb[i];
+    }
+    if (accel_bias_recalc_at_start && n == RBIS::rbis_num_states) {  // :353-356: whatever init_state holds now
+      accel_bias_initial.resize((size_t) 3 * B);
+      for (int b = 0; b < B; b++)
+        for (int i = 0; i < 3; i++) accel_bias_initial[(size_t) i * B + b] = init_state(RBIS::accel_bias_ind + i, b);
+    }
+    if (gyro_bias_recalc_at_start) gyro_bias_initial = gb_est;     // :358-361
+    if (n == RBIS::rbis_num_states) {
+      for (int b = 0; b < B; b++)
+        for (int i = 0; i < 3; i++) {                               // :363-364
+          init_state(RBIS::gyro_bias_ind + i, b) = gyro_bias_initial[gyro_bias_initial.size() == 3 ? (size_t) i : (size_t) i * B + b];
+          init_state(RBIS::accel_bias_ind + i, b) = accel_bias_initial[accel_bias_initial.size() == 3 ? (size_t) i : (size_t) i * B + b];
+        }
+    }
+    return true;
+  }
+
 private:
+  BotParam *param_ = nullptr;
+  bool init_params_read_ = false;
   RBISUpdateInterface *build(BatchArray gyro, BatchArray accel, double gyro_scale, bool accel_translate, double dt_,
                              int64_t utime, int B)
   {

@@ -1,0 +1,110 @@
+// test_ins_init.cpp -- InsHandler::processMessageInit (gravity / gyro-bias initialisation, sensor_handlers.cpp:254-364) of
+// the shim against the oracle's po_ins_init, filter by filter, plus the property the arithmetic exists for: the roll and
+// pitch of a stationary IMU are recovered.  Host-only code path: runs WITHOUT a GPU.  Exit code 0 + "PASS".
+#include <cstdio>
+#include <map>
+#include <vector>
+
+#include "../../oracle/pronto_oracle.h"
+#include "../../pronto_amd/csrc/mav_state_est_batch.hpp"
+
+using namespace MavStateEst;
+
+static uint64_t rng_state = 0x494E4954ULL;
+static double urand()
+{
+  rng_state = rng_state * 6364136223846793005ULL + 1442695040888963407ULL;
+  return ((rng_state >> 11) + 0.5) / 9007199254740992.0;
+}
+static double nrand() { return sqrt(-2 * log(urand())) * cos(2 * M_PI * urand()); }
+
+int main()
+{
+  const int n = 21, B = 40, N = 50;
+  double g;
+  po_get_constants(&g, nullptr);
+  BotParam param;
+  param.set("state_estimator.ins.channel", "IMU");
+  param.set("state_estimator.ins.q_gyro", 0.5);
+  param.set("state_estimator.ins.q_accel", 0.1);
+  param.set("state_estimator.ins.q_gyro_bias", 0.001);
+  param.set("state_estimator.ins.q_accel_bias", 0.0001);
+  param.set("state_estimator.ins.timestep_dt", 0.001);
+  param.set("state_estimator.ins.atlas_filter", "false");
+  param.set("state_estimator.ins.accel_bias_update_online", "true");
+  param.set("state_estimator.ins.gyro_bias_update_online", "true");
+  param.set("state_estimator.ins.num_to_init", std::to_string(N));
+  param.set("state_estimator.ins.max_initial_gyro_bias", "0.02");
+  param.set("state_estimator.ins.accel_bias_initial", "[0.01, -0.02, 0.03]");
+  param.set("state_estimator.ins.gyro_bias_initial", "0, 0, 0");
+  param.set("state_estimator.ins.accel_bias_recalc_at_start", "false");
+  param.set("state_estimator.ins.gyro_bias_recalc_at_start", "true");
+  BotTrans ins_to_body;  // 90 deg about z
+  ins_to_body.rot_quat[0] = sqrt(0.5); ins_to_body.rot_quat[3] = sqrt(0.5);
+  InsHandler ins(&param, &ins_to_body);
+
+  RBIS def_state(n, B), init_state(n, B);
+  RBIM def_cov(n, B), init_cov(n, B);
+  std::vector<double> roll(B), pitch(B), bias(3 * B);
+  for (int b = 0; b < B; b++) {
+    roll[b] = 0.4 * (urand() - 0.5);
+    pitch[b] = 0.4 * (urand() - 0.5);
+    for (int i = 0; i < 3; i++) bias[i * B + b] = (b % 7 == 3 && i == 1) ? 0.05 : 0.004 * nrand();  // filter 3, 10, ..: too large
+    for (int i = 0; i < n; i++) {
+      def_cov(i, i, b) = 0.01 * (1 + i);
+      init_cov(i, i, b) = -1.0;  // "not initialised yet" (rbis_initializer.cpp:124-128)
+    }
+  }
+  std::map<std::string, bool> sensors_initialized = { { "ins", false }, { "vicon", false } };
+  std::vector<double> gs(3 * B, 0.0), ws(3 * B, 0.0), gy(3 * B), ac(3 * B);
+  bool done = false;
+  int calls = 0;
+  for (int k = 0; k < N + 3 && !done; k++) {
+    if (k == 3) sensors_initialized["vicon"] = true;  // the INS waits for everybody else (:266-267)
+    for (int b = 0; b < B; b++) {
+      double q[4], up_w[3] = { 0, 0, g }, up_b[3], qc[4];
+      po_euler_to_quat(roll[b], pitch[b], 0.0, q);
+      qc[0] = q[0]; qc[1] = -q[1]; qc[2] = -q[2]; qc[3] = -q[3];
+      po_quat_rotate(qc, up_w, up_b);                      // specific force of a stationary body, body frame
+      double a_b[3], w_b[3], a_s[3], w_s[3];
+      for (int i = 0; i < 3; i++) { a_b[i] = up_b[i] + 0.05 * nrand(); w_b[i] = bias[i * B + b] + 0.002 * nrand(); }
+      const double sc[4] = { ins_to_body.rot_quat[0], -ins_to_body.rot_quat[1], -ins_to_body.rot_quat[2], -ins_to_body.rot_quat[3] };
+      po_quat_rotate(sc, a_b, a_s);                        // what the sensor reports (sensor frame)
+      po_quat_rotate(sc, w_b, w_s);
+      for (int i = 0; i < 3; i++) { ac[i * B + b] = a_s[i]; gy[i * B + b] = w_s[i]; }
+      if (k >= 3) {                                        // the handler only accumulates once the others are done
+        double a_r[3], w_r[3];
+        po_quat_rotate(ins_to_body.rot_quat, a_s, a_r);
+        po_quat_rotate(ins_to_body.rot_quat, w_s, w_r);
+        for (int i = 0; i < 3; i++) { gs[i * B + b] += -a_r[i]; ws[i * B + b] += w_r[i]; }
+      }
+    }
+    msgs::ins_t m{ (int64_t) (k + 1) * 1000, BatchArray(gy.data(), PB_HOST), BatchArray(ac.data(), PB_HOST) };
+    done = ins.processMessageInit(&m, sensors_initialized, def_state, def_cov, init_state, init_cov);
+    calls++;
+  }
+  bool ok = done && calls == N + 3 && ins.init_counter == N;
+  double eq = 0, eb = 0, erp = 0;
+  int zeroed = 0;
+  for (int b = 0; b < B; b++) {
+    const double g3[3] = { gs[b], gs[B + b], gs[2 * B + b] }, w3[3] = { ws[b], ws[B + b], ws[2 * B + b] };
+    const double qi[4] = { 1, 0, 0, 0 };
+    double qo[4], gb[3], rpy[3];
+    po_ins_init(g3, w3, N, 0.02, qi, qo, gb);
+    for (int i = 0; i < 4; i++) eq = fmax(eq, fabs(init_state.q(i, b) - qo[i]));
+    for (int i = 0; i < 3; i++) eb = fmax(eb, fabs(init_state(RBIS::gyro_bias_ind + i, b) - gb[i]));  // recalc_at_start = true
+    if (gb[0] == 0 && gb[1] == 0 && gb[2] == 0) zeroed++;
+    po_quat_to_euler(qo, rpy);
+    erp = fmax(erp, fmax(fabs(rpy[0] - roll[b]), fabs(rpy[1] - pitch[b])));
+    // covariance blocks: chi roll/pitch and the gyro bias from the defaults, everything else untouched
+    ok = ok && init_cov(6, 6, b) == def_cov(6, 6, b) && init_cov(7, 7, b) == def_cov(7, 7, b) && init_cov(8, 8, b) == -1.0 &&
+         init_cov(15, 15, b) == def_cov(15, 15, b) && init_cov(17, 17, b) == def_cov(17, 17, b) && init_cov(3, 3, b) == -1.0;
+    ok = ok && init_state(RBIS::accel_bias_ind, b) == 0.01 && init_state(RBIS::accel_bias_ind + 1, b) == -0.02 &&
+         init_state(RBIS::accel_bias_ind + 2, b) == 0.03;
+  }
+  printf("init after %d messages (%d accumulated): |quat - oracle| %.2e, |gyro bias - oracle| %.2e, roll/pitch error %.2e rad, "
+         "%d filters with an out-of-range bias estimate zeroed\n", calls, ins.init_counter, eq, eb, erp, zeroed);
+  ok = ok && eq < 1e-14 && eb < 1e-15 && erp < 5e-3 && zeroed == (B + 3) / 7;
+  printf(ok ? "PASS\n" : "FAIL\n");
+  return ok ? 0 : 1;
+}

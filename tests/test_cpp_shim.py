@@ -60,6 +60,15 @@ def test_lcm_log_replay_and_filter_state_publishing_on_gpu(oracle, tmp_path):
     assert r.returncode == 0 and "PASS" in r.stdout, r.stdout + r.stderr
 
 
+def test_ins_gravity_initialisation_host_only(oracle):
+    """InsHandler::processMessageInit (sensor_handlers.cpp:254-364) is host arithmetic: it runs here, without a GPU,
+    against the oracle's po_ins_init."""
+    exe = build_exe(oracle, "test_ins_init")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    print(r.stdout, r.stderr)
+    assert r.returncode == 0 and "PASS" in r.stdout, r.stdout + r.stderr
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode,slots", [("pos_and_lin_rate", 0), ("pos_and_lin_rate", 6), ("lin_rot_rate", 0)])
 def test_legodo_modes_on_gpu(oracle, mode, slots):
