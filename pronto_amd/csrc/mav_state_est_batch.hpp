@@ -1174,6 +1174,39 @@ public:
     u->measurement.mem = u->cov_mem = msg->z_effective.mem;
     return u;
   }
+  // processMessageInit (sensor_handlers.cpp:584-610): the measured entries and their covariance block initialise the
+  // state; chi entries are folded into the quaternion (init_state.chiToQuat()).  Host messages only.
+  double chi_tol = 1e-6;  // eigen_utils' chiToQuat tolerance (the same constant as pb_set_constants' chi_tol)
+  bool processMessageInit(const msgs::indexed_measurement_t *msg, const std::map<std::string, bool> & /*sensors_initialized*/,
+                          const RBIS & /*default_state*/, const RBIM & /*default_cov*/, RBIS &init_state, RBIM &init_cov)
+  {
+    if (msg->z_effective.mem == PB_DEVICE) return false;
+    const int B = init_state.B, m = (int) msg->z_indices.size();
+    const size_t per = (msg->z_effective.mem == PB_HOST_BROADCAST) ? 1 : (size_t) B;
+    for (int b = 0; b < B; b++) {
+      const size_t sb = (per == 1) ? 0 : (size_t) b;
+      for (int ii = 0; ii < m; ii++) {
+        if (msg->z_indices[(size_t) ii] >= init_state.n) continue;  // a 15-state batch has no bias entries to initialise
+        for (int jj = 0; jj < m; jj++)
+          if (msg->z_indices[(size_t) jj] < init_state.n)
+            init_cov(msg->z_indices[(size_t) ii], msg->z_indices[(size_t) jj], b) = msg->R_effective[(size_t) (jj * m + ii) * per + sb];
+        init_state(msg->z_indices[(size_t) ii], b) = msg->z_effective.p[(size_t) ii * per + sb];
+      }
+      // chiToQuat: quat <- quat * Exp(chi), chi <- 0, when |chi| exceeds the tolerance
+      const double c[3] = { init_state(6, b), init_state(7, b), init_state(8, b) };
+      const double ang = sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+      if (ang > chi_tol) {
+        const double sh = sin(0.5 * ang) / ang, dq[4] = { cos(0.5 * ang), c[0] * sh, c[1] * sh, c[2] * sh };
+        const double q0[4] = { init_state.q(0, b), init_state.q(1, b), init_state.q(2, b), init_state.q(3, b) };
+        init_state.q(0, b) = q0[0] * dq[0] - q0[1] * dq[1] - q0[2] * dq[2] - q0[3] * dq[3];
+        init_state.q(1, b) = q0[0] * dq[1] + q0[1] * dq[0] + q0[2] * dq[3] - q0[3] * dq[2];
+        init_state.q(2, b) = q0[0] * dq[2] - q0[1] * dq[3] + q0[2] * dq[0] + q0[3] * dq[1];
+        init_state.q(3, b) = q0[0] * dq[3] + q0[1] * dq[2] - q0[2] * dq[1] + q0[3] * dq[0];
+        init_state(6, b) = init_state(7, b) = init_state(8, b) = 0.0;
+      }
+    }
+    return true;
+  }
 private:
   RBISUpdateInterface::sensor_enum indexed_sensor;
 };

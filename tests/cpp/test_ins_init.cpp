@@ -105,6 +105,27 @@ int main()
   printf("init after %d messages (%d accumulated): |quat - oracle| %.2e, |gyro bias - oracle| %.2e, roll/pitch error %.2e rad, "
          "%d filters with an out-of-range bias estimate zeroed\n", calls, ins.init_counter, eq, eb, erp, zeroed);
   ok = ok && eq < 1e-14 && eb < 1e-15 && erp < 5e-3 && zeroed == (B + 3) / 7;
+  // ---- IndexedMeasurementHandler::processMessageInit (sensor_handlers.cpp:584-610): position + yaw from one message ----
+  {
+    IndexedMeasurementHandler h(RBISUpdateInterface::laser_gpf);
+    RBIS st(15, 3);
+    RBIM cv(15, 3);
+    const double z[4] = { 1.5, -2.0, 0.25, 0.3 }, R[16] = { 4, 0.1, 0, 0, 0.1, 5, 0, 0, 0, 0, 6, 0.2, 0, 0, 0.2, 7 };
+    msgs::indexed_measurement_t m;
+    m.utime = 5;
+    m.z_indices = { 9, 10, 11, 8 };
+    m.z_effective = BatchArray(z, PB_HOST_BROADCAST);
+    m.R_effective = R;
+    const bool r = h.processMessageInit(&m, sensors_initialized, st, cv, st, cv);
+    bool good = r;
+    for (int b = 0; b < 3; b++) {
+      good = good && st(9, b) == 1.5 && st(10, b) == -2.0 && st(11, b) == 0.25 && st(8, b) == 0.0 &&
+             fabs(st.q(0, b) - cos(0.15)) < 1e-16 && fabs(st.q(3, b) - sin(0.15)) < 1e-16 && st.q(1, b) == 0 && st.q(2, b) == 0 &&
+             cv(9, 9, b) == 4 && cv(9, 10, b) == 0.1 && cv(10, 10, b) == 5 && cv(11, 8, b) == 0.2 && cv(8, 8, b) == 7 && cv(3, 3, b) == 0;
+    }
+    if (!good) printf("IndexedMeasurementHandler::processMessageInit: unexpected initial state\n");
+    ok = ok && good;
+  }
   printf(ok ? "PASS\n" : "FAIL\n");
   return ok ? 0 : 1;
 }
