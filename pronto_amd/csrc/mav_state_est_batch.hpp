@@ -590,6 +590,10 @@ struct indexed_measurement_t {  // pronto::indexed_measurement_t
   BatchArray z_effective;      // [m][B]
   const double *R_effective;   // [m*m][B] column-major, same memory space as z_effective
 };
+struct rigid_transform_t {  // bot_core::rigid_transform_t (Vicon)
+  int64_t utime;
+  BatchArray trans, quat;    // [3][B], [4][B] host (or host-broadcast) arrays
+};
 struct gps_data_t {
   int64_t utime;
   const uint8_t *has_lock;     // [B]: gps_lock >= 3
@@ -1224,6 +1228,139 @@ public:
   {
     return makeIndexedMeasurement(RBIS::positionInds(), msg->xyz_pos, est->B, cov_xyz, msg->has_lock, RBISUpdateInterface::gps,
                                   msg->utime);  // sensor_handlers.cpp:374-381
+  }
+  // processMessageInit (sensor_handlers.cpp:383-403): position and its covariance from the fix (filters without lock keep theirs)
+  bool processMessageInit(const msgs::gps_data_t *msg, const std::map<std::string, bool> & /*sensors_initialized*/,
+                          const RBIS & /*default_state*/, const RBIM & /*default_cov*/, RBIS &init_state, RBIM &init_cov)
+  {
+    if (msg->xyz_pos.mem == PB_DEVICE) return false;
+    const int B = init_state.B;
+    const size_t per = (msg->xyz_pos.mem == PB_HOST_BROADCAST) ? 1 : (size_t) B;
+    init_state.utime = msg->utime;
+    bool any = false;
+    for (int b = 0; b < B; b++) {
+      if (msg->has_lock != nullptr && !msg->has_lock[b]) continue;
+      any = true;
+      for (int i = 0; i < 3; i++) {
+        init_state(RBIS::position_ind + i, b) = msg->xyz_pos.p[(size_t) i * per + (per == 1 ? 0 : (size_t) b)];
+        for (int j = 0; j < 3; j++) init_cov(RBIS::position_ind + i, RBIS::position_ind + j, b) = (i == j) ? cov_xyz[(size_t) i] : 0.0;
+      }
+    }
+    return any;
+  }
+};
+
+// ViconHandler (sensor_handlers.cpp:406-574): motion-capture pose as position / orientation / yaw / position+orientation
+// measurement.  local_to_body = local_to_vicon o body_to_vicon when apply_frame (libbot's bot_trans_apply_trans_to
+// [NOT IN TREE]: rotation q1 * q2, translation R(q1) t2 + t1).  Host (or host-broadcast) messages.
+class ViconHandler {
+public:
+  typedef enum { MODE_POSITION, MODE_POSITION_ORIENT, MODE_ORIENTATION, MODE_YAW } ViconMode;
+  ViconMode mode;
+  bool apply_frame;
+  BotTrans body_to_vicon;
+  std::vector<int> z_indices;
+  std::vector<double> cov_vicon;  // diagonal, of the measured entries
+  double r_xyz2, r_chi2;
+  ViconHandler(BotParam *param, const BotTrans *body_to_vicon_ = nullptr)
+  {
+    const std::string mode_str = bot_param_get_str_or_fail(param, "state_estimator.vicon.mode");
+    if (mode_str == "position") mode = MODE_POSITION;
+    else if (mode_str == "position_orient") mode = MODE_POSITION_ORIENT;
+    else if (mode_str == "orientation") mode = MODE_ORIENTATION;
+    else if (mode_str == "yaw") mode = MODE_YAW;
+    else {
+      mode = MODE_POSITION;
+      fprintf(stdout, "Unrecognized Vicon mode. Using position mode by default.\n");
+    }
+    apply_frame = bot_param_get_boolean_or_fail(param, "state_estimator.vicon.apply_frame");
+    if (apply_frame && body_to_vicon_) body_to_vicon = *body_to_vicon_;
+    r_xyz2 = bot_sq(bot_param_get_double_or_fail(param, "state_estimator.vicon.r_xyz"));
+    r_chi2 = bot_sq(bot_to_radians(bot_param_get_double_or_fail(param, "state_estimator.vicon.r_chi")));
+    if (mode == MODE_POSITION) { z_indices = RBIS::positionInds(); cov_vicon = { r_xyz2, r_xyz2, r_xyz2 }; }
+    else if (mode == MODE_YAW) { z_indices = { RBIS::chi_ind + 2 }; cov_vicon = { r_chi2 }; }
+    else if (mode == MODE_ORIENTATION) { z_indices = RBIS::chiInds(); cov_vicon = { r_chi2, r_chi2, r_chi2 }; }
+    else { z_indices = { 9, 10, 11, 6, 7, 8 }; cov_vicon = { r_xyz2, r_xyz2, r_xyz2, r_chi2, r_chi2, r_chi2 }; }
+  }
+  RBISUpdateInterface *processMessage(const msgs::rigid_transform_t *msg, MavStateEstimator *est)
+  {
+    std::vector<double> t, q;
+    std::vector<uint8_t> mask;
+    int mem;
+    if (!to_body(msg, est->B, t, q, mask, mem)) return nullptr;
+    const int m = (int) z_indices.size();
+    const size_t per = t.size() / 3;
+    if (mode == MODE_POSITION) {
+      auto *u = new RBISIndexedMeasurement(z_indices, std::move(t), std::vector<double>(cov_vicon), PB_R_DIAG_BROADCAST, std::move(mask),
+                                           RBISUpdateInterface::vicon, msg->utime);
+      u->measurement.mem = mem;
+      return u;
+    }
+    std::vector<double> z((size_t) m * per, 0.0);  // entries at chi indices are ignored (rbis.cpp:203-205)
+    if (mode == MODE_POSITION_ORIENT) memcpy(z.data(), t.data(), sizeof(double) * 3 * per);
+    auto *u = new RBISIndexedPlusOrientationMeasurement(z_indices, std::move(z), std::vector<double>(cov_vicon), PB_R_DIAG_BROADCAST,
+                                                        std::move(q), std::move(mask), RBISUpdateInterface::vicon, msg->utime);
+    u->measurement.mem = u->orientation.mem = mem;
+    return u;
+  }
+  bool processMessageInit(const msgs::rigid_transform_t *msg, const std::map<std::string, bool> & /*sensors_initialized*/,
+                          const RBIS & /*default_state*/, const RBIM & /*default_cov*/, RBIS &init_state, RBIM &init_cov)
+  {
+    std::vector<double> t, q;
+    std::vector<uint8_t> mask;
+    int mem;
+    const int B = init_state.B;
+    if (!to_body(msg, B, t, q, mask, mem, /*for_init=*/true)) return false;
+    const size_t per = t.size() / 3;
+    init_state.utime = msg->utime;
+    for (int b = 0; b < B; b++) {
+      const size_t sb = per == 1 ? 0 : (size_t) b;
+      for (int i = 0; i < 3; i++) {
+        init_state(RBIS::position_ind + i, b) = t[(size_t) i * per + sb];
+        for (int j = 0; j < 3; j++) {
+          init_cov(RBIS::position_ind + i, RBIS::position_ind + j, b) = (i == j) ? r_xyz2 : 0.0;
+          init_cov(RBIS::chi_ind + i, RBIS::chi_ind + j, b) = (i == j) ? r_chi2 : 0.0;
+        }
+      }
+      for (int i = 0; i < 4; i++) init_state.q(i, b) = q[(size_t) i * per + sb];
+    }
+    return true;
+  }
+private:
+  // msg -> body pose per filter; mask 0 where |translation| < 1e-5 on all axes (":493-494 return NULL")
+  bool to_body(const msgs::rigid_transform_t *msg, int B, std::vector<double> &t, std::vector<double> &q, std::vector<uint8_t> &mask,
+               int &mem, bool for_init = false) const
+  {
+    mem = msg->trans.mem;
+    if (mem == PB_DEVICE || msg->quat.mem != mem) {
+      fprintf(stderr, "ViconHandler: host (or host-broadcast) trans and quat arrays expected\n");
+      return false;
+    }
+    const size_t per = (mem == PB_HOST_BROADCAST) ? 1 : (size_t) B;
+    t.resize(3 * per);
+    q.resize(4 * per);
+    bool any = false;
+    if (per > 1) mask.assign(per, 1);
+    for (size_t b = 0; b < per; b++) {
+      const double tv[3] = { msg->trans.p[b], msg->trans.p[per + b], msg->trans.p[2 * per + b] };
+      const double qv[4] = { msg->quat.p[b], msg->quat.p[per + b], msg->quat.p[2 * per + b], msg->quat.p[3 * per + b] };
+      double tb[3] = { tv[0], tv[1], tv[2] }, qb[4] = { qv[0], qv[1], qv[2], qv[3] };
+      if (apply_frame) {
+        bot_quat_rotate_to(qv, body_to_vicon.trans_vec, tb);
+        for (int i = 0; i < 3; i++) tb[i] += tv[i];
+        const double *a = qv, *c = body_to_vicon.rot_quat;
+        qb[0] = a[0] * c[0] - a[1] * c[1] - a[2] * c[2] - a[3] * c[3];
+        qb[1] = a[0] * c[1] + a[1] * c[0] + a[2] * c[3] - a[3] * c[2];
+        qb[2] = a[0] * c[2] - a[1] * c[3] + a[2] * c[0] + a[3] * c[1];
+        qb[3] = a[0] * c[3] + a[1] * c[2] - a[2] * c[1] + a[3] * c[0];
+      }
+      const bool dropped = !for_init && fabs(tv[0]) < 1e-5 && fabs(tv[1]) < 1e-5 && fabs(tv[2]) < 1e-5;
+      if (per > 1) mask[b] = !dropped;
+      any = any || !dropped;
+      for (int i = 0; i < 3; i++) t[(size_t) i * per + b] = tb[i];
+      for (int i = 0; i < 4; i++) q[(size_t) i * per + b] = qb[i];
+    }
+    return any;
   }
 };
 

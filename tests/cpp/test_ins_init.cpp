@@ -126,6 +126,39 @@ int main()
     if (!good) printf("IndexedMeasurementHandler::processMessageInit: unexpected initial state\n");
     ok = ok && good;
   }
+  // ---- ViconHandler (sensor_handlers.cpp:406-574): frame composition, the near-zero drop, modes, initialisation ----
+  {
+    BotParam vp;
+    vp.applyOverrides("state_estimator.vicon.mode=position_orient|state_estimator.vicon.apply_frame=true|"
+                      "state_estimator.vicon.r_xyz=0.01|state_estimator.vicon.r_chi=2.0");
+    BotTrans body_to_vicon;
+    body_to_vicon.rot_quat[0] = sqrt(0.5); body_to_vicon.rot_quat[3] = sqrt(0.5);
+    body_to_vicon.trans_vec[0] = 0.1;
+    ViconHandler vh(&vp, &body_to_vicon);
+    const double t[3] = { 1.0, 2.0, 3.0 }, q[4] = { 1, 0, 0, 0 };
+    msgs::rigid_transform_t m{ 7, BatchArray(t, PB_HOST_BROADCAST), BatchArray(q, PB_HOST_BROADCAST) };
+    RBIS st(15, 4);
+    RBIM cv(15, 4);
+    bool good = vh.processMessageInit(&m, sensors_initialized, st, cv, st, cv);
+    for (int b = 0; b < 4; b++)
+      good = good && fabs(st(9, b) - 1.1) < 1e-15 && st(10, b) == 2.0 && st(11, b) == 3.0 && fabs(st.q(0, b) - sqrt(0.5)) < 1e-16 &&
+             fabs(st.q(3, b) - sqrt(0.5)) < 1e-16 && cv(9, 9, b) == 1e-4 && fabs(cv(6, 6, b) - bot_sq(bot_to_radians(2.0))) < 1e-18;
+    if (!good) printf("ViconHandler::processMessageInit: unexpected initial state\n");
+    ok = ok && good;
+    // GpsHandler::processMessageInit: filters without lock keep their state
+    BotParam gp;
+    gp.applyOverrides("state_estimator.gps.r_xy=2.0|state_estimator.gps.r_z=3.0");
+    GpsHandler gh(&gp);
+    std::vector<double> xyz = { 10, 11, 12, 13, 20, 21, 22, 23, 30, 31, 32, 33 };
+    const uint8_t lock[4] = { 1, 0, 1, 1 };
+    msgs::gps_data_t gm{ 11, lock, BatchArray(xyz.data(), PB_HOST) };
+    RBIS gs2(15, 4);
+    RBIM gc(15, 4);
+    good = gh.processMessageInit(&gm, sensors_initialized, gs2, gc, gs2, gc) && gs2(9, 0) == 10 && gs2(10, 2) == 22 && gs2(11, 3) == 33 &&
+           gs2(9, 1) == 0 && gc(9, 9, 0) == 4.0 && gc(11, 11, 0) == 9.0 && gc(9, 9, 1) == 0.0;
+    if (!good) printf("GpsHandler::processMessageInit: unexpected initial state\n");
+    ok = ok && good;
+  }
   printf(ok ? "PASS\n" : "FAIL\n");
   return ok ? 0 : 1;
 }

@@ -109,6 +109,37 @@ int main(int argc, char **argv)
       po_indexed_update(m, idx, z, R, &ox[b], &oP[b], oll[b], &ox[b], &oP[b], &oll[b]);
     }
   }
+  // ---- one Vicon pose (position_orient, with a frame) on top: filter 3 reports a near-zero translation -> no update ----
+  {
+    param.applyOverrides("state_estimator.vicon.mode=position_orient|state_estimator.vicon.apply_frame=true|"
+                         "state_estimator.vicon.r_xyz=0.01|state_estimator.vicon.r_chi=2.0|state_estimator.vicon.downsample_factor=1|"
+                         "state_estimator.vicon.roll_forward_on_receive=true|state_estimator.vicon.utime_offset=0");
+    BotTrans body_to_vicon;
+    body_to_vicon.rot_quat[0] = cos(0.2); body_to_vicon.rot_quat[3] = sin(0.2);
+    body_to_vicon.trans_vec[0] = 0.05; body_to_vicon.trans_vec[2] = -0.1;
+    ViconHandler vicon_handler(&param, &body_to_vicon);
+    auto on_vicon = front_end.addSensor("vicon", &ViconHandler::processMessage, &vicon_handler);
+    std::vector<double> vt(3 * B), vq(4 * B);
+    for (int b = 0; b < B; b++) {
+      double qq[4];
+      po_euler_to_quat(0.05 * nrand(), 0.05 * nrand(), 3.0 * (urand() - 0.5), qq);
+      for (int i = 0; i < 3; i++) vt[i * B + b] = (b == 3) ? 1e-7 : ox[b].vec[9 + i] + 0.05 * nrand();
+      for (int i = 0; i < 4; i++) vq[i * B + b] = qq[i];
+    }
+    msgs::rigid_transform_t vm{ (int64_t) (T + 1) * 1000, BatchArray(vt.data(), PB_HOST), BatchArray(vq.data(), PB_HOST) };
+    on_vicon(&vm);
+    for (int b = 0; b < B; b++) {
+      if (b == 3) continue;
+      const double tv[3] = { vt[b], vt[B + b], vt[2 * B + b] }, qv[4] = { vq[b], vq[B + b], vq[2 * B + b], vq[3 * B + b] };
+      double tb[3], qb[4], z[6] = { 0 }, R[36] = { 0 };
+      po_quat_rotate(qv, body_to_vicon.trans_vec, tb);
+      for (int i = 0; i < 3; i++) z[i] = tb[i] + tv[i];
+      po_quat_mul(qv, body_to_vicon.rot_quat, qb);
+      const int idx[6] = { 9, 10, 11, 6, 7, 8 };
+      for (int i = 0; i < 6; i++) R[i * 6 + i] = (i < 3) ? 1e-4 : bot_sq(bot_to_radians(2.0));
+      po_indexed_orient_update(6, idx, z, R, qb, &ox[b], &oP[b], oll[b], &ox[b], &oP[b], &oll[b]);
+    }
+  }
   RBIS head;
   RBIM cov;
   est.getHeadState(head, cov);
@@ -124,7 +155,7 @@ int main(int argc, char **argv)
   }
   printf("mode %s, %d history slots: %d full, %d fall-back, %d skipped filter-updates; rel err vec %.2e quat %.2e cov %.2e ll %.2e "
          "(status %d)\n", mode.c_str(), slots, n_full, n_fallback, n_skip, ev / sv, eq, eP / sP, el / sl, est.last_status);
-  const bool ok = est.last_status == PB_OK && head.utime == (int64_t) T * 1000 && ev / sv < 1e-9 && eq < 1e-9 && eP / sP < 1e-9 &&
+  const bool ok = est.last_status == PB_OK && head.utime == (int64_t) (T + 1) * 1000 && ev / sv < 1e-9 && eq < 1e-9 && eP / sP < 1e-9 &&
                   el / sl < 1e-9 && n_skip > 0 && (omode != 2 || (n_fallback > 0 && n_full > 0));
   printf(ok ? "PASS\n" : "FAIL\n");
   return ok ? 0 : 1;
