@@ -477,6 +477,8 @@ __global__ __launch_bounds__(256, 2) void k_smooth_reg(const double *__restrict_
 
   // ---- 2. pivoted LDL^T of P^-: rows in registers, the pivot row goes round through LDS ----
   int piv[NS];
+  constexpr bool KEEP_L = (NS <= 16);
+  double lreg[KEEP_L ? NS : 1];
   int mypos = 0;                 // pivot position of this lane's row
   double *const mine = row ? Lf + rr * PG : Rf + NS;  // this lane's row of the n x n scratch (padding lanes: dummy slot)
   const int one = row ? 1 : 0;
@@ -515,7 +517,10 @@ __global__ __launch_bounds__(256, 2) void k_smooth_reg(const double *__restrict_
         if (j + 1 < NS) am[j + 1] = fma(-l, pr.y, am[j + 1]);
       }
       dg = fma(-l, c, dg);
-      mine[one * kk] = l;        // L[r][kk]: 0 for the pivot row itself and for rows pivoted earlier
+      // L[r][kk]: 0 for the pivot row itself and for rows pivoted earlier.  15 states: kept in registers (there is
+      // room); 21 states: parked in this lane's row of the LDS scratch (42 more live registers would spill)
+      if constexpr (KEEP_L) lreg[kk] = l;
+      else mine[one * kk] = l;
       done = done || is_p;
       group_sync();
       step_fence();
@@ -554,9 +559,9 @@ __global__ __launch_bounds__(256, 2) void k_smooth_reg(const double *__restrict_
 
   // ---- 4. A y = x.  (Publishing stores are unconditional with a selected address -- padding lanes write a dummy slot --
   //         because whatever only feeds a store inside `if (row)` is sunk into that block, see step 6.) ----
-  double lrow[NS];               // this lane's L row, parked while the scratch carries x
+  double lrow[NS];               // this lane's L row, kept while the scratch carries x
 #pragma unroll
-  for (int kk = 0; kk < NS; kk++) lrow[kk] = mine[one * kk];
+  for (int kk = 0; kk < NS; kk++) lrow[kk] = KEEP_L ? lreg[kk] : mine[one * kk];
   group_sync();
 #pragma unroll
   for (int i = 0; i < NS; i++) mine[one * i] = z[i];
