@@ -57,3 +57,14 @@ for n in (15, 21):
     rows.append(("k_update m=4 orient (scan-match position_yaw)", t, 2 * st + 88))
     for name, t, nb in rows:
         print("n=%d %-48s %7.1f us  %6.0f GB/s  frac %.3f" % (n, name, t * 1e6, nb * B / t / 1e9, nb * B / t / 1e9 / 8000))
+
+# IMU front end: the 3-stage notch cascade (k_notch), 3 packets per message (the KVH batch's typical new-packet count),
+# device-resident packets; bytes = packets in + the 36-double filter state read and written + the filtered sample out
+est = BatchEstimator(B, n_states=15)
+est.imu_notch_init(87.0, 1000.0)
+pk = torch.randn((3, 3, B), dtype=torch.float64, device=dev)
+ao = torch.empty((3, B), dtype=torch.float64, device=dev)
+t = timeit(lambda: est.imu_notch(pk, ao))
+nb = (3 * 3 + 2 * 36 + 3) * 8
+print("k_notch, 3 packets per message                               %7.1f us  %6.0f GB/s  frac %.3f" % (t * 1e6, nb * B / t / 1e9, nb * B / t / 1e9 / 8000))
+est.close()
