@@ -865,7 +865,7 @@ extern "C" int pb_imu_notch(pb_ctx *c, int n_packets, const double *accel_packet
   } else {
     return fail(c, PB_ERR_ARG, "mem must be PB_HOST or PB_DEVICE");
   }
-  k_notch<<<nblk(c->B), 64, 0, c->stream>>>(c->notch, c->stride, c->B, n_packets, (const double *) p[0].dev, d_out, c->notch_coef);
+  k_notch<<<dim3((unsigned) nblk(c->B), 3u), 64, 0, c->stream>>>(c->notch, c->stride, c->B, n_packets, (const double *) p[0].dev, d_out, c->notch_coef);
   LAUNCHCHK(c);
   if (mem == PB_HOST) {
     HIPCHK(c, hipMemcpyAsync(accel_out, d_out, sizeof(double) * 3 * B, hipMemcpyDeviceToHost, c->stream));

@@ -602,44 +602,38 @@ __global__ void k_window_nll(const double *__restrict__ st, long stride, int B, 
 struct NotchCoef {
   double b[3][3], a[3][3];  // [stage][tap]
 };
+// One lane per (filter, axis): blockIdx.y is the axis -- three times the waves of a lane-per-filter mapping, which this
+// short, latency-bound kernel needs (rocprof: 14.6 us -> see DESIGN.md 6 for the lane-per-filter version it replaced).
 __global__ void k_notch(double *__restrict__ nst, long stride, int B, int n_packets, const double *__restrict__ acc_in,
                         double *__restrict__ acc_out, NotchCoef k)
 {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  const int ax = blockIdx.y;
   if (b >= B) return;
-  double s[3][3][4];
+  double s[3][4];
 #pragma unroll
-  for (int ax = 0; ax < 3; ax++)
+  for (int i = 0; i < 3; i++)
 #pragma unroll
-    for (int i = 0; i < 3; i++)
-#pragma unroll
-      for (int t = 0; t < 4; t++) s[ax][i][t] = nst[(long) ((ax * 3 + i) * 4 + t) * stride + b];
-  double v[3] = { 0, 0, 0 };
+    for (int t = 0; t < 4; t++) s[i][t] = nst[(long) ((ax * 3 + i) * 4 + t) * stride + b];
+  double v = 0.0;
   for (int p = 0; p < n_packets; p++) {
+    v = acc_in[((long) p * 3 + ax) * B + b];
 #pragma unroll
-    for (int ax = 0; ax < 3; ax++) v[ax] = acc_in[((long) p * 3 + ax) * B + b];
-#pragma unroll
-    for (int i = 0; i < 3; i++)
-#pragma unroll
-      for (int ax = 0; ax < 3; ax++) {
-        const double in = v[ax];
-        const double xb = in * k.b[i][0] + s[ax][i][0] * k.b[i][1] + s[ax][i][1] * k.b[i][2];
-        const double ya = s[ax][i][2] * k.a[i][1] + s[ax][i][3] * k.a[i][2];
-        const double out = xb - ya;
-        s[ax][i][1] = s[ax][i][0]; s[ax][i][0] = in;
-        s[ax][i][3] = s[ax][i][2]; s[ax][i][2] = out;
-        v[ax] = out;
-      }
+    for (int i = 0; i < 3; i++) {
+      const double in = v;
+      const double xb = in * k.b[i][0] + s[i][0] * k.b[i][1] + s[i][1] * k.b[i][2];
+      const double ya = s[i][2] * k.a[i][1] + s[i][3] * k.a[i][2];
+      const double out = xb - ya;
+      s[i][1] = s[i][0]; s[i][0] = in;
+      s[i][3] = s[i][2]; s[i][2] = out;
+      v = out;
+    }
   }
 #pragma unroll
-  for (int ax = 0; ax < 3; ax++)
+  for (int i = 0; i < 3; i++)
 #pragma unroll
-    for (int i = 0; i < 3; i++)
-#pragma unroll
-      for (int t = 0; t < 4; t++) nst[(long) ((ax * 3 + i) * 4 + t) * stride + b] = s[ax][i][t];
-  if (n_packets > 0)
-#pragma unroll
-    for (int ax = 0; ax < 3; ax++) acc_out[(long) ax * B + b] = v[ax];
+    for (int t = 0; t < 4; t++) nst[(long) ((ax * 3 + i) * 4 + t) * stride + b] = s[i][t];
+  if (n_packets > 0) acc_out[(long) ax * B + b] = v;
 }
 
 // Counter calibration: a plain copy with EXACTLY the access pattern of k_step (buffer_load/store_dwordx2, 8 bytes
