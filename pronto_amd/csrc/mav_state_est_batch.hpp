@@ -330,6 +330,14 @@ public:
   std::vector<int> free_slots;
   RBISUpdateInterface *device_head = nullptr;  // the update whose posterior the device currently holds
   int64_t replayed_updates = 0;                // statistics: updates re-applied because of late arrivals
+  // state_estimator.fuse_ins_legodo = true (this build's addition, off by default): an INS process step is held back
+  // until the next update arrives; if that is a velocity measurement on {3,4,5} with a diagonal R (LegOdoCommon's
+  // lin_rate) both run as ONE fused kernel (pb_step_legodo: one state round trip instead of two -- 21.7 us instead of
+  // 20.2 + 23.6 us at 64k filters).  Only the posterior after the pair exists then, so this is for replays nobody
+  // observes between the two messages; it is ignored when posterior checkpoints are kept (history_slots > 0).
+  // Anything that reads the device (getHeadState, the smoother, FovisHandler) flushes the held step first.
+  bool fuse_ins_legodo = false;
+  int64_t fused_pairs = 0;
 
   MavStateEstimator(RBISResetUpdate *init_state, BotParam *param, int device = 0, int n_snapshots = 2)
   {
@@ -341,6 +349,10 @@ public:
     history_slots = opt("state_estimator.history_slots", 0);
     checkpoint_every = opt("state_estimator.history_checkpoint_every", 1);
     if (checkpoint_every < 1) checkpoint_every = 1;
+    {
+      auto it = param->kv.find("state_estimator.fuse_ins_legodo");
+      fuse_ins_legodo = history_slots == 0 && it != param->kv.end() && (it->second == "true" || it->second == "1");
+    }
     n = init_state->reset_state.n;
     B = init_state->reset_state.B;
     int rc = pb_create(&ctx, n, B, device, n_snapshots);
@@ -398,8 +410,33 @@ public:
       for (auto it = current_it; it != map.end(); ++it) drop_checkpoint(it->second);
       since_checkpoint = 0;
     }
+    bool held = false;
     while (current_it != map.end()) {
       RBISUpdateInterface *u = current_it->second;
+      if (fuse_ins_legodo) {
+        if (auto *imu = dynamic_cast<RBISIMUProcessStep *>(u)) {
+          auto nxt = current_it;
+          ++nxt;
+          if (nxt == map.end() && !flushing_) {  // newest element: hold it back until the next update shows up
+            held = true;
+            break;
+          }
+          if (nxt != map.end()) {
+            int rc = PB_OK;
+            if (run_fused(imu, nxt->second, rc)) {
+              if (rc != PB_OK) {
+                last_status = rc;
+                fprintf(stderr, "MavStateEstimator::addUpdate: fused ins+legodo step failed: %s\n", pb_last_error(ctx));
+              }
+              fused_pairs++;
+              device_head = nxt->second;
+              head_utime = nxt->second->utime;
+              current_it = ++nxt;
+              continue;
+            }
+          }
+        }
+      }
       // a checkpointed update writes its posterior straight into the checkpoint slot (no copy afterwards)
       int slot = -1;
       if (history_slots > 0 && ++since_checkpoint >= checkpoint_every && (slot = reserve_slot(u)) >= 0)
@@ -422,12 +459,32 @@ public:
       ++current_it;
     }
     pb_set_utime(ctx, head_utime);
+    holding_ = held;
     clearHistoryBeforeUtime(head_utime - utime_history_span);                 // :72-77
+    unprocessed_updates_start = held ? current_it : map.end();
+  }
+
+  // apply an INS step that fuse_ins_legodo is holding back (no-op otherwise)
+  void flushPending()
+  {
+    if (!fuse_ins_legodo || unprocessed_updates_start == history.updateMap.end()) return;
+    flushing_ = true;
+    auto &map = history.updateMap;
+    for (auto it = unprocessed_updates_start; it != map.end(); ++it) {
+      int rc = it->second->updateFilter(ctx);
+      if (rc != PB_OK) last_status = rc;
+      device_head = it->second;
+      head_utime = it->second->utime;
+    }
+    flushing_ = false;
+    holding_ = false;
+    pb_set_utime(ctx, head_utime);
     unprocessed_updates_start = map.end();
   }
 
   void getHeadState(RBIS &head_state, RBIM &head_cov)
   {
+    flushPending();
     head_state = RBIS(n, B);
     head_cov = RBIM(n, B);
     last_status = pb_get_head(ctx, 0, B, head_state.vec.data(), head_state.quat.data(), head_cov.m.data(), nullptr, PB_HOST);
@@ -435,6 +492,7 @@ public:
   }
   std::vector<double> getMeasurementsLogLikelihood()
   {
+    flushPending();
     std::vector<double> ll(B);
     last_status = pb_get_head(ctx, 0, B, nullptr, nullptr, nullptr, ll.data(), PB_HOST);
     return ll;
@@ -494,6 +552,34 @@ public:
   }
 
 private:
+  bool flushing_ = false, holding_ = false;
+  // imu followed by a velocity measurement LegOdoCommon's lin_rate mode produces -> one pb_step_legodo; false = not fusible
+  bool run_fused(RBISIMUProcessStep *imu, RBISUpdateInterface *next, int &rc)
+  {
+    if (dynamic_cast<RBISIndexedPlusOrientationMeasurement *>(next) != nullptr) return false;
+    auto *m = dynamic_cast<RBISIndexedMeasurement *>(next);
+    if (m == nullptr || m->index != RBIS::velocityInds()) return false;
+    const double q[4] = { imu->q_gyro, imu->q_accel, imu->q_gyro_bias, imu->q_accel_bias };
+    if (imu->imu_block.mem == PB_HOST_BROADCAST && m->measurement.mem == PB_HOST_BROADCAST && m->r_kind == PB_R_DIAG_BROADCAST &&
+        m->mask == nullptr) {
+      const double lo[6] = { m->measurement.p[0], m->measurement.p[1], m->measurement.p[2],
+                             m->measurement_cov[0], m->measurement_cov[1], m->measurement_cov[2] };
+      rc = pb_step_legodo(ctx, imu->imu_block.p, lo, nullptr, q, PB_HOST_BROADCAST);
+      return true;
+    }
+    if (imu->imu_block.mem == PB_HOST && m->measurement.mem == PB_HOST && m->cov_mem == PB_HOST &&
+        (m->r_kind == PB_R_DIAG || m->r_kind == PB_R_DIAG_BROADCAST)) {
+      fuse_lo_.resize((size_t) 6 * B);
+      memcpy(fuse_lo_.data(), m->measurement.p, sizeof(double) * 3 * B);
+      if (m->r_kind == PB_R_DIAG) memcpy(fuse_lo_.data() + (size_t) 3 * B, m->measurement_cov, sizeof(double) * 3 * B);
+      else
+        for (int i = 0; i < 3; i++) std::fill_n(fuse_lo_.begin() + (size_t) (3 + i) * B, B, m->measurement_cov[i]);
+      rc = pb_step_legodo(ctx, imu->imu_block.p, fuse_lo_.data(), m->mask, q, PB_HOST);
+      return true;
+    }
+    return false;
+  }
+  std::vector<double> fuse_lo_;
   void drop_checkpoint(RBISUpdateInterface *u)
   {
     auto it = checkpoint_of.find(u);
@@ -544,6 +630,7 @@ private:
     if (history_slots == 0) {  // in-order only: keep just the head
       auto last = map.end();
       --last;
+      if (holding_) --last;    // the newest element is an INS step that has not been applied: the head is before it
       erase_before(last);
       return;
     }
@@ -1418,7 +1505,12 @@ public:
 
   // The estimator calls this when the posterior at a future `prev_timestamp` is the head: the device-side
   // replacement of history.updateMap.lower_bound(prev_timestamp) (rbis_fovis_update.cpp:184-207).
-  void markKeyframe(MavStateEstimator *est) { pb_snapshot(est->ctx, slot); prev_t0_body_utime_ = est->head_utime; }
+  void markKeyframe(MavStateEstimator *est)
+  {
+    est->flushPending();
+    pb_snapshot(est->ctx, slot);
+    prev_t0_body_utime_ = est->head_utime;
+  }
 
   RBISUpdateInterface *processMessage(const msgs::update_t *msg, MavStateEstimator *est)
   {
@@ -1447,6 +1539,7 @@ public:
       return u;
     }
     // position / position_orient: T1 = T0(posterior at prev_timestamp) * (t, q)
+    est->flushPending();
     const double diff = (double) (prev_t0_body_utime_ - msg->prev_timestamp) * 1E-6;
     if (diff > 0.025 || diff < -0.025) {
       fprintf(stdout, "FOIVS: time difference for VO delta root pose is too great (%fsec). Will not use\n", diff);  // :186-189

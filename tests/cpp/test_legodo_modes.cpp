@@ -24,11 +24,13 @@ int main(int argc, char **argv)
 {
   const std::string mode = argc > 1 ? argv[1] : "pos_and_lin_rate";
   const int slots = argc > 2 ? atoi(argv[2]) : 0;
+  const bool fuse = argc > 3 && std::string(argv[3]) == "fuse";  // state_estimator.fuse_ins_legodo
   const int omode = mode == "lin_rate" ? 0 : (mode == "lin_rot_rate" ? 1 : 2);
   const int n = 15, B = 150, T = 40;
   BotParam param;
   param.set("state_estimator.utime_history_span", "1000000");
   param.set("state_estimator.history_slots", std::to_string(slots));
+  param.set("state_estimator.fuse_ins_legodo", fuse ? "true" : "false");
   param.set("state_estimator.ins.channel", "IMU");
   param.set("state_estimator.ins.q_gyro", 0.5);
   param.set("state_estimator.ins.q_accel", 0.1);
@@ -79,7 +81,12 @@ int main(int argc, char **argv)
   for (int k = 0; k < T; k++) {
     const int64_t utime = (int64_t) (k + 1) * 1000;
     const double v[6] = { 0.2 * sin(0.1 * k), 0.1, -0.15 * cos(0.07 * k), 0.2 * nrand(), 0.2 * nrand(), g + 0.2 * nrand() };
-    msgs::ins_t im{ utime, BatchArray(v, PB_HOST_BROADCAST), BatchArray(v + 3, PB_HOST_BROADCAST) };
+    std::vector<double> gyb(3 * B), acb(3 * B);
+    for (int i = 0; i < 3; i++)
+      for (int b = 0; b < B; b++) { gyb[i * B + b] = v[i]; acb[i * B + b] = v[3 + i]; }
+    // fused pairs need the IMU and the leg odometry in the same memory space: per-filter host blocks when fusing
+    msgs::ins_t im = fuse ? msgs::ins_t{ utime, BatchArray(gyb.data(), PB_HOST), BatchArray(acb.data(), PB_HOST) }
+                          : msgs::ins_t{ utime, BatchArray(v, PB_HOST_BROADCAST), BatchArray(v + 3, PB_HOST_BROADCAST) };
     on_ins(&im);
     for (int b = 0; b < B; b++) po_imu_process_step(v, v + 3, 0.001, q4[0], q4[1], q4[2], q4[3], &ox[b], &oP[b], oll[b], &ox[b], &oP[b], &oll[b]);
     for (int b = 0; b < B; b++) {
@@ -153,10 +160,14 @@ int main(int argc, char **argv)
     el = fmax(el, fabs(ll[b] - oll[b]));
     sl = fmax(sl, fabs(oll[b]));
   }
+  printf("fused ins+legodo pairs: %lld\n", (long long) est.fused_pairs);
   printf("mode %s, %d history slots: %d full, %d fall-back, %d skipped filter-updates; rel err vec %.2e quat %.2e cov %.2e ll %.2e "
          "(status %d)\n", mode.c_str(), slots, n_full, n_fallback, n_skip, ev / sv, eq, eP / sP, el / sl, est.last_status);
   const bool ok = est.last_status == PB_OK && head.utime == (int64_t) (T + 1) * 1000 && ev / sv < 1e-9 && eq < 1e-9 && eP / sP < 1e-9 &&
-                  el / sl < 1e-9 && n_skip > 0 && (omode != 2 || (n_fallback > 0 && n_full > 0));
+                  el / sl < 1e-9 && n_skip > 0 && (omode != 2 || (n_fallback > 0 && n_full > 0)) &&
+                  // fusible: every lin_rate message, and in pos_and_lin_rate the messages whose position is bad for
+                  // everybody (k % 5 == 4: a pure lin_rate fall-back)
+                  est.fused_pairs == ((fuse && slots == 0) ? (omode == 0 ? T : (omode == 2 ? T / 5 : 0)) : 0);
   printf(ok ? "PASS\n" : "FAIL\n");
   return ok ? 0 : 1;
 }

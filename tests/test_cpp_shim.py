@@ -70,12 +70,15 @@ def test_ins_gravity_initialisation_host_only(oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode,slots", [("pos_and_lin_rate", 0), ("pos_and_lin_rate", 6), ("lin_rot_rate", 0)])
-def test_legodo_modes_on_gpu(oracle, mode, slots):
+@pytest.mark.parametrize("mode,slots,fuse", [("pos_and_lin_rate", 0, ""), ("pos_and_lin_rate", 6, ""), ("lin_rot_rate", 0, ""),
+                                             ("lin_rate", 0, "fuse"), ("lin_rate", 4, "fuse"), ("pos_and_lin_rate", 0, "fuse")])
+def test_legodo_modes_on_gpu(oracle, mode, slots, fuse):
     """LegOdoCommon's other modes, incl. the per-filter pos_and_lin_rate -> lin_rate fall-back (two complementary masked
-    updates), with and without posterior checkpoints, vs the oracle's createMeasurement + indexed update."""
+    updates), with and without posterior checkpoints, vs the oracle's createMeasurement + indexed update.  "fuse": the
+    opt-in state_estimator.fuse_ins_legodo -- every INS step followed by a lin_rate measurement runs as one fused kernel
+    (and is ignored with checkpoints on / for updates that are not fusible)."""
     exe = build_exe(oracle, "test_legodo_modes")
-    r = subprocess.run([exe, mode, str(slots)], capture_output=True, text=True, timeout=300)
+    r = subprocess.run([exe, mode, str(slots), fuse], capture_output=True, text=True, timeout=300)
     print(r.stdout, r.stderr)
     assert r.returncode == 0 and "PASS" in r.stdout, r.stdout + r.stderr
 
