@@ -37,6 +37,14 @@
 #include "../../include/pronto_batch.h"
 #include "pronto_wire.hpp"
 
+// The handlers' per-filter host loops (frame rotation, velocity from deltas ...) are independent per filter: compile the
+// host program with -fopenmp and they run on all cores; without it the pragma disappears.
+#ifdef _OPENMP
+#define PB_SHIM_PARALLEL_FOR _Pragma("omp parallel for schedule(static)")
+#else
+#define PB_SHIM_PARALLEL_FOR
+#endif
+
 namespace MavStateEst {
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -985,6 +993,7 @@ private:
     if (mem == PB_HOST_BROADCAST) B = 1;
     std::vector<double> blk((size_t) 7 * B);
     const bool ident = ins_to_body.isIdentityRotation();
+    PB_SHIM_PARALLEL_FOR
     for (int b = 0; b < B; b++) {
       double g[3] = { gyro.p[b] * gyro_scale, gyro.p[(size_t) B + b] * gyro_scale, gyro.p[(size_t) 2 * B + b] * gyro_scale };
       double a[3] = { accel.p[b], accel.p[(size_t) B + b], accel.p[(size_t) 2 * B + b] };
@@ -1041,21 +1050,22 @@ public:
   }
 
   // getCovariance (rbis_legodo_common.cpp:34-88) for one filter: fills Rdiag[m], z_indices; returns m
-  int getCovariance(LegOdoCommonMode mode_current, bool delta_certain, double *Rdiag, std::vector<int> &z_indices) const
+  // getCovariance (rbis_legodo_common.cpp:34-91): diagonal of R and, if asked for, the index list
+  int getCovariance(LegOdoCommonMode mode_current, bool delta_certain, double *Rdiag, std::vector<int> *z_indices) const
   {
     const double rv = delta_certain ? R_legodo_vxyz_ : R_legodo_vxyz_uncertain_;
     const double ra = delta_certain ? R_legodo_vang_ : R_legodo_vang_uncertain_;
     if (mode_current == MODE_LIN_AND_ROT_RATE) {
       for (int i = 0; i < 3; i++) { Rdiag[i] = bot_sq(rv); Rdiag[3 + i] = bot_sq(ra); }
-      z_indices = { 3, 4, 5, 0, 1, 2 };
+      if (z_indices) *z_indices = { 3, 4, 5, 0, 1, 2 };
       return 6;
     } else if (mode_current == MODE_POSITION_AND_LIN_RATE) {
       for (int i = 0; i < 3; i++) { Rdiag[i] = bot_sq(R_legodo_xyz_); Rdiag[3 + i] = bot_sq(rv); }
-      z_indices = { 9, 10, 11, 3, 4, 5 };
+      if (z_indices) *z_indices = { 9, 10, 11, 3, 4, 5 };
       return 6;
     }
     for (int i = 0; i < 3; i++) Rdiag[i] = bot_sq(rv);
-    z_indices = { 3, 4, 5 };
+    if (z_indices) *z_indices = { 3, 4, 5 };
     return 3;
   }
 
@@ -1089,12 +1099,17 @@ public:
     std::vector<double> z((size_t) m * B), R((size_t) m * B);
     std::vector<uint8_t> mask(B);
     std::vector<int> idx;
+    {
+      double unused[6];
+      getCovariance(mode_, true, unused, &idx);
+    }
+    PB_SHIM_PARALLEL_FOR
     for (int b = 0; b < B; b++) {
       const float st = msg->delta_status ? msg->delta_status[b] : 0.f;
       mask[b] = st >= 0;
       const bool certain = st < 0.5;                                        // :124-129
       double Rd[6];
-      getCovariance(mode_, certain, Rd, idx);
+      getCovariance(mode_, certain, Rd, nullptr);
       double vel[3];
       for (int i = 0; i < 3; i++) vel[i] = msg->delta_trans[(size_t) i * B + b] / elapsed;   // getDeltaAsVelocity :73
       if (mode_ == MODE_LIN_RATE) {
