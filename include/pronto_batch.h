@@ -153,6 +153,9 @@ int pb_replay_legodo_fused(pb_ctx *ctx, int n_steps, int steps_per_launch, const
 /* remember the head posterior's (position, quat) in `slot` (the reference finds it again by
  * history.updateMap.lower_bound(prev_timestamp)) */
 int pb_snapshot(pb_ctx *ctx, int slot);
+/* the same from a saved posterior (pb_history_reserve checkpoint) instead of the head: what FovisHandler does when the
+ * keyframe changes -- history.updateMap.lower_bound(prev_timestamp)->posterior_state (rbis_fovis_update.cpp:184-207) */
+int pb_snapshot_from_slot(pb_ctx *ctx, int slot, int checkpoint_slot);
 /* T1 = T0(slot) * (t, q): z_out [3][B] = T1.translation, quat_out [4][B] = T1.rotation (device buffers) */
 int pb_compose_delta(pb_ctx *ctx, int slot, const double *t, const double *q, double *z_out, double *quat_out,
                      int mem);

@@ -76,6 +76,7 @@ _SIGS = {
     "pb_state_save": (C.c_int, [C.c_void_p, C.c_int]),
     "pb_set_output_slot": (C.c_int, [C.c_void_p, C.c_int]),
     "pb_head_slot": (C.c_int, [C.c_void_p]),
+    "pb_snapshot_from_slot": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "pb_host_alloc": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]),
     "pb_host_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "pb_state_restore": (C.c_int, [C.c_void_p, C.c_int]),

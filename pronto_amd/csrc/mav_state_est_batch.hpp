@@ -1555,8 +1555,34 @@ public:
     }
     // position / position_orient: T1 = T0(posterior at prev_timestamp) * (t, q)
     est->flushPending();
+    if (est->history_slots > 0 && msg->prev_timestamp != prev_t0_body_utime_) {
+      // The reference's own look-up (:177-213): the posterior of the first update at or after prev_timestamp, at most
+      // 25 ms later, becomes the cached T0 -- here: copied from that update's checkpoint into the snapshot slot.
+      auto &map = est->history.updateMap;
+      auto lower_it = map.lower_bound(msg->prev_timestamp);
+      if (lower_it == map.end()) {
+        fprintf(stdout, "%lld at the end\n", (long long) msg->prev_timestamp);  // :192-195
+        return nullptr;
+      }
+      const double diff_utime = (double) (lower_it->first - msg->prev_timestamp) * 1E-6;
+      if (diff_utime > 0.025) {
+        fprintf(stdout, "FOIVS: time difference for VO delta root pose is too great (%fsec). Will not use\n", diff_utime);
+        return nullptr;
+      }
+      auto ck = est->checkpoint_of.find(lower_it->second);
+      if (ck == est->checkpoint_of.end()) {
+        fprintf(stdout, "FovisHandler: no saved posterior for the update at %lld (history_checkpoint_every > 1, or not applied "
+                        "yet). Will not use\n", (long long) lower_it->first);
+        return nullptr;
+      }
+      if (pb_snapshot_from_slot(est->ctx, slot, ck->second) != PB_OK) {
+        fprintf(stderr, "FovisHandler: %s\n", pb_last_error(est->ctx));
+        return nullptr;
+      }
+      prev_t0_body_utime_ = msg->prev_timestamp;  // :213
+    }
     const double diff = (double) (prev_t0_body_utime_ - msg->prev_timestamp) * 1E-6;
-    if (diff > 0.025 || diff < -0.025) {
+    if (diff > 0.025 || diff < -0.025) {  // without a history the keyframe is whatever markKeyframe() last captured
       fprintf(stdout, "FOIVS: time difference for VO delta root pose is too great (%fsec). Will not use\n", diff);  // :186-189
       return nullptr;
     }

@@ -654,6 +654,20 @@ extern "C" int pb_snapshot(pb_ctx *c, int slot)
   return PB_OK;
 }
 
+extern "C" int pb_snapshot_from_slot(pb_ctx *c, int slot, int checkpoint_slot)
+{
+  ENTER(c);
+  if (slot < 0 || slot >= c->nsnap) return fail(c, PB_ERR_STATE, "pb_snapshot_from_slot: slot %d of %d", slot, c->nsnap);
+  if (checkpoint_slot < 0 || checkpoint_slot >= c->nhist)
+    return fail(c, PB_ERR_STATE, "pb_snapshot_from_slot: checkpoint slot %d of %d", checkpoint_slot, c->nhist);
+  double *snap = c->snaps + (size_t) slot * 7 * c->stride;
+  const double *src = c->hist + (size_t) checkpoint_slot * (size_t) c->nc * c->stride;
+  if (c->ns == 15) k_snapshot<15><<<nblk(c->B), 64, 0, c->stream>>>(src, c->stride, c->B, snap);
+  else k_snapshot<21><<<nblk(c->B), 64, 0, c->stream>>>(src, c->stride, c->B, snap);
+  LAUNCHCHK(c);
+  return PB_OK;
+}
+
 extern "C" int pb_compose_delta(pb_ctx *c, int slot, const double *t, const double *q, double *z_out,
                                 double *quat_out, int mem)
 {

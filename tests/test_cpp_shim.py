@@ -60,6 +60,16 @@ def test_lcm_log_replay_and_filter_state_publishing_on_gpu(oracle, tmp_path):
     assert r.returncode == 0 and "PASS" in r.stdout, r.stdout + r.stderr
 
 
+@pytest.mark.gpu
+def test_fovis_keyframe_lookup_in_history_on_gpu(oracle):
+    """FovisHandler with posterior checkpoints on: T0 comes from history.updateMap.lower_bound(prev_timestamp) like in the
+    reference (25 ms rule, cached per keyframe, 'at the end' rejection), no manual keyframe marking."""
+    exe = build_exe(oracle, "test_fovis_history")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    print(r.stdout[-2000:], r.stderr[-2000:])
+    assert r.returncode == 0 and "PASS" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 def test_ins_gravity_initialisation_host_only(oracle):
     """InsHandler::processMessageInit (sensor_handlers.cpp:254-364) is host arithmetic: it runs here, without a GPU,
     against the oracle's po_ins_init."""
@@ -84,7 +94,7 @@ def test_legodo_modes_on_gpu(oracle, mode, slots, fuse):
 
 
 @pytest.mark.parametrize("name", ["test_shim", "test_history", "test_atlas_imu", "test_smooth_pass", "test_log_replay",
-                                  "test_legodo_modes"])
+                                  "test_legodo_modes", "test_fovis_history"])
 def test_shim_compiles_and_links(oracle, name):
     exe = build_exe(oracle, name)
     out = subprocess.run(["ldd", exe], capture_output=True, text=True).stdout
