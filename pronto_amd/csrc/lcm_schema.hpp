@@ -1,0 +1,329 @@
+// lcm_schema.hpp -- run-time LCM types: parse .lcm definitions, compute lcm-gen's fingerprints (nested types included),
+// decode messages into a generic value tree.  Host-only, header-only C++17, no lcm / lcm-gen dependency.
+//
+// Why: the bot_core messages the reference's handlers consume (ins_t, kvh_raw_imu_batch_t, joint_state_t, pose_t,
+// rigid_transform_t, gps_data_t ...) are defined in libbot's bot_core .lcm files, which are NOT in the reference tree, so
+// their layouts and fingerprints cannot be compiled in (pronto_wire.hpp only carries the three pronto types that are).
+// A user replaying a recorded log has those .lcm files: hand their text to Schema::parse and the log's events decode by
+// field NAME -- the names the reference's handlers read (msg->gyro, msg->accel, msg->pos, msg->orientation,
+// msg->raw_imu[i].delta_rotation ...: sensor_handlers.cpp:96-131,165-252,374-381,476-536,689-724, imu_stream.cpp:62-98).
+//
+// Rules restated from LCM's type-specification document and lcm-gen's emitted code:
+//  * grammar: [package P;] struct N { member* };  member: TYPE name[dim]... {, name[dim]...};  |  const TYPE n = v {, ...};
+//    dim = integer constant or the name of an earlier integer member; TYPE = primitive | [package.]struct name
+//  * primitives: int8_t int16_t int32_t int64_t byte float double string boolean; all big-endian; string = int32 length
+//    (with the terminating NUL) + bytes + NUL; boolean and byte one octet; arrays element after element, outer dimension
+//    first, no length prefix; a nested struct is encoded inline WITHOUT a fingerprint; only the message starts with one
+//  * fingerprint(S) = rot1(base(S) + sum over members of non-primitive type of fingerprint(member type | parents + S)),
+//    a type already among its parents contributing 0; base(S) as in pronto_wire.hpp (member names, primitive type names,
+//    dimensions; compound type names are NOT hashed); rot1(h) = (h << 1) + (h >> 63).
+// The all-primitive case is pinned by the LCM tutorial's example_t constant (tests/test_wire.py); the nested rule is
+// restated twice (here and in tests/lcm_ref.py) but has no known answer available in this image.
+#pragma once
+
+#include <cctype>
+#include <cstdint>
+#include <cstring>
+#include <map>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "pronto_wire.hpp"
+
+namespace pronto_wire {
+
+struct SchemaDim {
+  int mode;          // LCM_CONST / LCM_VAR
+  std::string size;  // as written
+};
+struct SchemaField {
+  std::string name, type;  // type as written ("double", "inner_t", "bot_core.kvh_raw_imu_t")
+  std::vector<SchemaDim> dims;
+};
+struct SchemaType {
+  std::string package, name;
+  std::vector<SchemaField> fields;
+  std::string full() const { return package.empty() ? name : package + "." + name; }
+};
+
+// one decoded value: a number, a string, a struct (named fields) or an array (items)
+struct Value {
+  enum Kind { INT, FLOAT, STRING, STRUCT, ARRAY } kind = INT;
+  int64_t i = 0;
+  double f = 0.0;
+  std::string s;
+  std::vector<Value> items;
+  std::vector<std::pair<std::string, Value>> fields;
+
+  const Value *get(const std::string &name) const
+  {
+    for (const auto &kv : fields)
+      if (kv.first == name) return &kv.second;
+    return nullptr;
+  }
+  double number() const { return kind == FLOAT ? f : (double) i; }
+  // numeric array member -> out[0..n); false if the member is missing, not an array or of another length
+  bool numbers(const std::string &name, double *out, size_t n) const
+  {
+    const Value *v = get(name);
+    if (v == nullptr || v->kind != ARRAY || v->items.size() != n) return false;
+    for (size_t k = 0; k < n; k++) out[k] = v->items[k].number();
+    return true;
+  }
+  bool integer(const std::string &name, int64_t &out) const
+  {
+    const Value *v = get(name);
+    if (v == nullptr || v->kind != INT) return false;
+    out = v->i;
+    return true;
+  }
+};
+
+class Schema {
+public:
+  // Adds every struct of `text` (one .lcm file's contents; several files = several calls).  false + *err on a syntax error.
+  bool parse(const std::string &text, std::string *err = nullptr)
+  {
+    Lexer lx(text);
+    std::string package;
+    for (;;) {
+      std::string t = lx.next();
+      if (t.empty()) return true;
+      if (t == "package") {
+        package = lx.next();
+        if (lx.next() != ";") return fail(err, "expected ';' after package");
+      } else if (t == "struct") {
+        SchemaType st;
+        st.package = package;
+        st.name = lx.next();
+        if (st.name.empty() || lx.next() != "{") return fail(err, "expected '{' after struct " + st.name);
+        for (;;) {
+          std::string type = lx.next();
+          if (type.empty()) return fail(err, "unterminated struct " + st.name);
+          if (type == "}") break;
+          const bool is_const = (type == "const");
+          if (is_const) type = lx.next();
+          for (;;) {
+            SchemaField f;
+            f.type = type;
+            f.name = lx.next();
+            if (f.name.empty()) return fail(err, "member name expected in " + st.name);
+            std::string t2 = lx.next();
+            while (t2 == "[") {
+              SchemaDim d;
+              d.size = lx.next();
+              d.mode = (!d.size.empty() && isdigit((unsigned char) d.size[0])) ? LCM_CONST : LCM_VAR;
+              if (lx.next() != "]") return fail(err, "expected ']' in " + st.name + "." + f.name);
+              f.dims.push_back(d);
+              t2 = lx.next();
+            }
+            if (is_const) {  // const TYPE name = value: not on the wire, not in the fingerprint
+              if (t2 != "=") return fail(err, "expected '=' in const " + f.name);
+              lx.next();
+              t2 = lx.next();
+            } else {
+              st.fields.push_back(f);
+            }
+            if (t2 == ",") continue;
+            if (t2 == ";") break;
+            return fail(err, "expected ',' or ';' after " + st.name + "." + f.name);
+          }
+        }
+        types_[st.full()] = st;
+      } else if (t != ";") {
+        return fail(err, "unexpected token '" + t + "'");
+      }
+    }
+  }
+
+  // "package.name", or a bare name if only one package defines it
+  const SchemaType *find(const std::string &name) const
+  {
+    auto it = types_.find(name);
+    if (it != types_.end()) return &it->second;
+    const SchemaType *hit = nullptr;
+    for (const auto &kv : types_)
+      if (kv.second.name == name) {
+        if (hit != nullptr) return nullptr;
+        hit = &kv.second;
+      }
+    return hit;
+  }
+
+  static bool is_primitive(const std::string &t)
+  {
+    static const char *prim[] = { "int8_t", "int16_t", "int32_t", "int64_t", "byte", "float", "double", "string", "boolean" };
+    for (const char *p : prim)
+      if (t == p) return true;
+    return false;
+  }
+
+  // 0 if the type (or one it nests) is unknown
+  uint64_t fingerprint(const std::string &name) const
+  {
+    const SchemaType *t = find(name);
+    if (t == nullptr) return 0;
+    std::vector<const SchemaType *> parents;
+    bool ok = true;
+    const uint64_t h = hash_recursive(*t, parents, ok);
+    return ok ? h : 0;
+  }
+
+  // decodes one message (fingerprint + body) of type `name`; false + *err if it does not fit
+  bool decode(const std::string &name, const void *data, size_t len, Value &out, std::string *err = nullptr) const
+  {
+    const SchemaType *t = find(name);
+    if (t == nullptr) return fail(err, "unknown type " + name);
+    Reader r(data, len);
+    const uint64_t fp = r.u64();
+    if (!r.ok) return fail(err, "short message");
+    if (fp != fingerprint(name)) return fail(err, "fingerprint mismatch for " + name);
+    if (!decode_struct(*t, r, out, err)) return false;
+    if (r.pos != len) return fail(err, "trailing bytes after " + name);
+    return true;
+  }
+
+private:
+  std::map<std::string, SchemaType> types_;
+
+  static bool fail(std::string *err, const std::string &what)
+  {
+    if (err) *err = what;
+    return false;
+  }
+
+  const SchemaType *resolve(const SchemaType &ctx, const std::string &type) const
+  {
+    if (type.find('.') != std::string::npos) {
+      auto it = types_.find(type);
+      return it == types_.end() ? nullptr : &it->second;
+    }
+    auto it = types_.find(ctx.package.empty() ? type : ctx.package + "." + type);
+    return it == types_.end() ? nullptr : &it->second;
+  }
+
+  uint64_t hash_recursive(const SchemaType &t, std::vector<const SchemaType *> &parents, bool &ok) const
+  {
+    for (const SchemaType *p : parents)
+      if (p == &t) return 0;
+    std::vector<Member> members;
+    for (const SchemaField &f : t.fields) {
+      Member m;
+      m.name = f.name.c_str();
+      m.prim = is_primitive(f.type) ? f.type.c_str() : nullptr;
+      for (const SchemaDim &d : f.dims) m.dims.push_back(Dim{ d.mode, d.size.c_str() });
+      members.push_back(m);
+    }
+    uint64_t h = (uint64_t) lcm_base_hash(members);
+    parents.push_back(&t);
+    for (const SchemaField &f : t.fields) {
+      if (is_primitive(f.type)) continue;
+      const SchemaType *nested = resolve(t, f.type);
+      if (nested == nullptr) {
+        ok = false;
+        continue;
+      }
+      h += hash_recursive(*nested, parents, ok);
+    }
+    parents.pop_back();
+    return (h << 1) + ((h >> 63) & 1u);
+  }
+
+  bool decode_primitive(const std::string &type, Reader &r, Value &v, std::string *err) const
+  {
+    if (type == "double") { v.kind = Value::FLOAT; v.f = r.f64(); }
+    else if (type == "float") {
+      const uint32_t u = r.u32();
+      float x;
+      memcpy(&x, &u, 4);
+      v.kind = Value::FLOAT;
+      v.f = x;
+    }
+    else if (type == "int64_t") { v.kind = Value::INT; v.i = r.i64(); }
+    else if (type == "int32_t") { v.kind = Value::INT; v.i = r.i32(); }
+    else if (type == "int16_t") {
+      if (!r.need(2)) return fail(err, "short message");
+      v.kind = Value::INT;
+      v.i = (int16_t) ((r.p[r.pos] << 8) | r.p[r.pos + 1]);
+      r.pos += 2;
+    }
+    else if (type == "int8_t" || type == "boolean") { v.kind = Value::INT; v.i = r.i8(); }
+    else if (type == "byte") { v.kind = Value::INT; v.i = (uint8_t) r.i8(); }
+    else if (type == "string") {
+      const int32_t n = r.i32();
+      if (!r.ok || n < 1 || !r.need((size_t) n)) return fail(err, "bad string length");
+      v.kind = Value::STRING;
+      v.s.assign((const char *) r.p + r.pos, (size_t) n - 1);
+      r.pos += (size_t) n;
+    }
+    else return fail(err, "not a primitive: " + type);
+    return r.ok ? true : fail(err, "short message");
+  }
+
+  bool decode_elements(const SchemaType &ctx, const SchemaField &f, size_t dim, const Value &self, Reader &r, Value &out,
+                       std::string *err) const
+  {
+    if (dim == f.dims.size()) {
+      if (is_primitive(f.type)) return decode_primitive(f.type, r, out, err);
+      const SchemaType *nested = resolve(ctx, f.type);
+      if (nested == nullptr) return fail(err, "unknown type " + f.type);
+      return decode_struct(*nested, r, out, err);
+    }
+    int64_t n = 0;
+    if (f.dims[dim].mode == LCM_CONST) n = atoll(f.dims[dim].size.c_str());
+    else if (!self.integer(f.dims[dim].size, n)) return fail(err, "array length member " + f.dims[dim].size + " not found");
+    if (n < 0 || (size_t) n > r.n - r.pos) return fail(err, "array length of " + f.name + " exceeds the message");
+    out.kind = Value::ARRAY;
+    out.items.resize((size_t) n);
+    for (int64_t k = 0; k < n; k++)
+      if (!decode_elements(ctx, f, dim + 1, self, r, out.items[(size_t) k], err)) return false;
+    return true;
+  }
+
+  bool decode_struct(const SchemaType &t, Reader &r, Value &out, std::string *err) const
+  {
+    out = Value();
+    out.kind = Value::STRUCT;
+    for (const SchemaField &f : t.fields) {
+      Value v;
+      if (!decode_elements(t, f, 0, out, r, v, err)) return false;
+      out.fields.emplace_back(f.name, std::move(v));
+    }
+    return true;
+  }
+
+  class Lexer {
+  public:
+    explicit Lexer(const std::string &s) : s_(s) {}
+    std::string next()
+    {
+      for (;;) {  // white space and comments
+        while (i_ < s_.size() && isspace((unsigned char) s_[i_])) i_++;
+        if (i_ + 1 < s_.size() && s_[i_] == '/' && s_[i_ + 1] == '/') {
+          while (i_ < s_.size() && s_[i_] != '\n') i_++;
+        } else if (i_ + 1 < s_.size() && s_[i_] == '/' && s_[i_ + 1] == '*') {
+          i_ += 2;
+          while (i_ + 1 < s_.size() && !(s_[i_] == '*' && s_[i_ + 1] == '/')) i_++;
+          i_ = (i_ + 2 <= s_.size()) ? i_ + 2 : s_.size();
+        } else {
+          break;
+        }
+      }
+      if (i_ >= s_.size()) return "";
+      const char c = s_[i_];
+      if (isalnum((unsigned char) c) || c == '_' || c == '.' || c == '-' || c == '+') {
+        const size_t b = i_;
+        while (i_ < s_.size() && (isalnum((unsigned char) s_[i_]) || s_[i_] == '_' || s_[i_] == '.' || s_[i_] == '-' || s_[i_] == '+')) i_++;
+        return s_.substr(b, i_ - b);
+      }
+      i_++;
+      return std::string(1, c);
+    }
+  private:
+    const std::string &s_;
+    size_t i_ = 0;
+  };
+};
+
+}  // namespace pronto_wire

@@ -35,7 +35,7 @@
 #include <vector>
 
 #include "../../include/pronto_batch.h"
-#include "pronto_wire.hpp"
+#include "lcm_schema.hpp"  // includes pronto_wire.hpp
 
 // The handlers' per-filter host loops (frame rotation, velocity from deltas ...) are independent per filter: compile the
 // host program with -fopenmp and they run on all cores; without it the pragma disappears.
@@ -1760,6 +1760,65 @@ public:
       msg.R_effective = w.R_effective.data();
       cb(&msg);
     };
+  }
+  // Messages whose .lcm definition the caller supplies at run time (lcm_schema.hpp; libbot's bot_core types are not in
+  // the reference tree): decoded into a value tree and handed over with the raw event.  `schema` must outlive the player.
+  void subscribeSchema(const std::string &channel, const pronto_wire::Schema *schema, const std::string &type,
+                       std::function<void(const pronto_wire::Value &, const pronto_wire::LogEvent &)> cb)
+  {
+    subs_[channel] = [this, schema, type, cb](const pronto_wire::LogEvent &ev) {
+      pronto_wire::Value v;
+      if (!schema->decode(type, ev.data.data(), ev.data.size(), v)) {
+        n_bad_++;
+        return;
+      }
+      cb(v, ev);
+    };
+  }
+  // bot_core::ins_t by field name (utime, gyro[3], accel[3]: what InsHandler::processMessage reads, sensor_handlers.cpp:96-131)
+  void subscribeIns(const std::string &channel, const pronto_wire::Schema *schema, const std::string &type,
+                    std::function<void(const msgs::ins_t *)> cb)
+  {
+    subscribeSchema(channel, schema, type, [this, cb](const pronto_wire::Value &v, const pronto_wire::LogEvent &) {
+      double g[3], a[3];
+      int64_t utime;
+      if (!v.integer("utime", utime) || !v.numbers("gyro", g, 3) || !v.numbers("accel", a, 3)) {
+        n_bad_++;
+        return;
+      }
+      msgs::ins_t m{ utime, BatchArray(g, PB_HOST_BROADCAST), BatchArray(a, PB_HOST_BROADCAST) };
+      cb(&m);
+    });
+  }
+  // bot_core::pose_t (utime, pos[3], vel[3], orientation[4]: ScanMatcherHandler::processMessage, sensor_handlers.cpp:689-724)
+  void subscribePose(const std::string &channel, const pronto_wire::Schema *schema, const std::string &type,
+                     std::function<void(const msgs::pose_t *)> cb)
+  {
+    subscribeSchema(channel, schema, type, [this, cb](const pronto_wire::Value &v, const pronto_wire::LogEvent &) {
+      double p[3], vel[3], q[4];
+      int64_t utime;
+      if (!v.integer("utime", utime) || !v.numbers("pos", p, 3) || !v.numbers("vel", vel, 3) || !v.numbers("orientation", q, 4)) {
+        n_bad_++;
+        return;
+      }
+      msgs::pose_t m{ utime, BatchArray(p, PB_HOST_BROADCAST), BatchArray(vel, PB_HOST_BROADCAST), BatchArray(q, PB_HOST_BROADCAST) };
+      cb(&m);
+    });
+  }
+  // bot_core::rigid_transform_t (utime, trans[3], quat[4]: ViconHandler::processMessage, sensor_handlers.cpp:476-536)
+  void subscribeRigidTransform(const std::string &channel, const pronto_wire::Schema *schema, const std::string &type,
+                               std::function<void(const msgs::rigid_transform_t *)> cb)
+  {
+    subscribeSchema(channel, schema, type, [this, cb](const pronto_wire::Value &v, const pronto_wire::LogEvent &) {
+      double t[3], q[4];
+      int64_t utime;
+      if (!v.integer("utime", utime) || !v.numbers("trans", t, 3) || !v.numbers("quat", q, 4)) {
+        n_bad_++;
+        return;
+      }
+      msgs::rigid_transform_t m{ utime, BatchArray(t, PB_HOST_BROADCAST), BatchArray(q, PB_HOST_BROADCAST) };
+      cb(&m);
+    });
   }
   void subscribeUpdate(const std::string &channel, std::function<void(const msgs::update_t *)> cb)
   {

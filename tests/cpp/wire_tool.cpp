@@ -7,7 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 
-#include "../../pronto_amd/csrc/pronto_wire.hpp"
+#include "../../pronto_amd/csrc/lcm_schema.hpp"
 
 using namespace pronto_wire;
 
@@ -109,6 +109,61 @@ int main(int argc, char **argv)
     }
     return 0;
   }
-  fprintf(stderr, "usage: wire_tool hashes | write <path> | dump <path>\n");
+  if (mode == "schema" && argc > 4) {  // schema <lcm files, comma separated> <type> <message file>
+    Schema sc;
+    std::string files = argv[2], err;
+    size_t a = 0;
+    while (a <= files.size()) {
+      const size_t b = files.find(',', a);
+      const std::string path = files.substr(a, b == std::string::npos ? std::string::npos : b - a);
+      FILE *f = fopen(path.c_str(), "rb");
+      if (!f) return 2;
+      std::string text;
+      char buf[4096];
+      size_t n;
+      while ((n = fread(buf, 1, sizeof buf, f)) > 0) text.append(buf, n);
+      fclose(f);
+      if (!sc.parse(text, &err)) { printf("parse error: %s\n", err.c_str()); return 3; }
+      if (b == std::string::npos) break;
+      a = b + 1;
+    }
+    printf("fingerprint %016" PRIx64 "\n", sc.fingerprint(argv[3]));
+    FILE *f = fopen(argv[4], "rb");
+    if (!f) return 2;
+    std::vector<uint8_t> msg;
+    int c;
+    while ((c = fgetc(f)) != EOF) msg.push_back((uint8_t) c);
+    fclose(f);
+    Value v;
+    if (!sc.decode(argv[3], msg.data(), msg.size(), v, &err)) { printf("decode error: %s\n", err.c_str()); return 0; }
+    struct Printer {
+      static void print(const Value &v)
+      {
+        switch (v.kind) {
+          case Value::INT: printf("%lld", (long long) v.i); break;
+          case Value::FLOAT: printf("%.17g", v.f); break;
+          case Value::STRING: printf("\"%s\"", v.s.c_str()); break;
+          case Value::ARRAY:
+            printf("[");
+            for (size_t k = 0; k < v.items.size(); k++) { if (k) printf(","); print(v.items[k]); }
+            printf("]");
+            break;
+          case Value::STRUCT:
+            printf("{");
+            for (size_t k = 0; k < v.fields.size(); k++) {
+              if (k) printf(",");
+              printf("%s:", v.fields[k].first.c_str());
+              print(v.fields[k].second);
+            }
+            printf("}");
+            break;
+        }
+      }
+    };
+    Printer::print(v);
+    printf("\n");
+    return 0;
+  }
+  fprintf(stderr, "usage: wire_tool hashes | write <path> | dump <path> | schema <lcm files> <type> <message file>\n");
   return 1;
 }

@@ -95,3 +95,55 @@ def read_log(blob):
             return out
         out.append((num, ts, blob[pos + 28:pos + 28 + clen].decode(), blob[pos + 28 + clen:end]))
         pos = end
+
+
+# ---- generic types (tests of pronto_amd/csrc/lcm_schema.hpp) --------------------------------------------------------------
+PRIMS = {"int8_t": ">b", "int16_t": ">h", "int32_t": ">i", "int64_t": ">q", "byte": ">B", "float": ">f", "double": ">d",
+         "boolean": ">b"}
+
+
+def base_hash_nested(fields):
+    """Like base_hash, for fields whose type may be a struct: (name, type or None for a struct member, dims)."""
+    v = 0x12345678
+    for name, typ, dims in fields:
+        v = _upd_str(v, name)
+        if typ in PRIMS or typ == "string":
+            v = _upd_str(v, typ)
+        v = _upd(v, len(dims))
+        for mode, size in dims:
+            v = _upd(v, mode)
+            v = _upd_str(v, size)
+    return v & M64
+
+
+def fingerprint_nested(types, name, parents=()):
+    """lcm-gen's recursive hash: base + the nested members' hashes (0 for a type already among the parents), rotated."""
+    if name in parents:
+        return 0
+    h = base_hash_nested(types[name])
+    for _, typ, _ in types[name]:
+        if typ not in PRIMS and typ != "string":
+            h = (h + fingerprint_nested(types, typ, parents + (name,))) & M64
+    return ((h << 1) + (h >> 63)) & M64
+
+
+def _enc_value(types, typ, dims, value, scope):
+    if dims:
+        mode, size = dims[0]
+        n = int(size) if mode == 0 else scope[size]
+        assert len(value) == n, (typ, size, len(value), n)
+        return b"".join(_enc_value(types, typ, dims[1:], v, scope) for v in value)
+    if typ == "string":
+        b = value.encode()
+        return struct.pack(">i", len(b) + 1) + b + b"\0"
+    if typ in PRIMS:
+        return struct.pack(PRIMS[typ], value)
+    return encode_struct(types, typ, value)
+
+
+def encode_struct(types, name, value):
+    return b"".join(_enc_value(types, typ, dims, value[fname], value) for fname, typ, dims in types[name])
+
+
+def encode_message(types, name, value):
+    return struct.pack(">Q", fingerprint_nested(types, name)) + encode_struct(types, name, value)

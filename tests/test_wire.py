@@ -17,8 +17,9 @@ def tool():
     exe = os.path.join(ROOT, "tests", "build", "wire_tool")
     src = os.path.join(ROOT, "tests", "cpp", "wire_tool.cpp")
     hdr = os.path.join(ROOT, "pronto_amd", "csrc", "pronto_wire.hpp")
+    hdr2 = os.path.join(ROOT, "pronto_amd", "csrc", "lcm_schema.hpp")
     os.makedirs(os.path.dirname(exe), exist_ok=True)
-    if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+    if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(src), os.path.getmtime(hdr), os.path.getmtime(hdr2)):
         subprocess.check_call(["g++", "-O1", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-o", exe, src])
     return exe
 
@@ -124,3 +125,85 @@ def test_decode_rejects_wrong_type_and_short_buffers(tool, tmp_path):
     open(path, "wb").write(blob)
     lines = subprocess.check_output([tool, "dump", path], text=True).splitlines()
     assert len(lines) == 4 and all(l.split()[5] == "unknown" for l in lines)
+
+
+DEMO_LCM = """
+// a made-up package exercising every construct of the LCM type language (not a reference file)
+package demo;
+struct inner_t {
+    int16_t id;      /* block
+                        comment */
+    float w[2];
+    string label;
+}
+struct outer_t
+{
+    int64_t utime;
+    int32_t n, m;
+    const int32_t K = 3, L = 0x10;
+    inner_t items[n];
+    double grid[2][m];
+    boolean ok;
+    byte raw[4];
+    demo.inner_t single;
+    const double PI = 3.14;
+}
+"""
+DEMO_TYPES = {
+    "demo.inner_t": [("id", "int16_t", []), ("w", "float", [(0, "2")]), ("label", "string", [])],
+    "demo.outer_t": [("utime", "int64_t", []), ("n", "int32_t", []), ("m", "int32_t", []),
+                     ("items", "demo.inner_t", [(1, "n")]), ("grid", "double", [(0, "2"), (1, "m")]), ("ok", "boolean", []),
+                     ("raw", "byte", [(0, "4")]), ("single", "demo.inner_t", [])],
+}
+EXAMPLE_LCM = """package exlcm;
+struct example_t
+{
+    int64_t  timestamp;
+    double   position[3];
+    double   orientation[4];
+    int32_t  num_ranges;
+    int16_t  ranges[num_ranges];
+    string   name;
+    boolean  enabled;
+}
+"""
+
+
+def test_runtime_schema_parse_fingerprint_decode(tool, tmp_path):
+    """lcm_schema.hpp: a .lcm text parsed at run time (comments, consts, several declarators, nested and qualified types,
+    variable and multi-dimensional arrays, strings), its recursive fingerprint and a decoded message, against the Python
+    restatement; and the tutorial type's known constant through the same path."""
+    demo = tmp_path / "demo.lcm"
+    demo.write_text(DEMO_LCM)
+    ex = tmp_path / "example_t.lcm"
+    ex.write_text(EXAMPLE_LCM)
+    value = {"utime": 123456789012, "n": 2, "m": 3,
+             "items": [{"id": -7, "w": [0.5, -2.25], "label": "left foot"}, {"id": 300, "w": [1.0, 8.0], "label": ""}],
+             "grid": [[0.1, 0.2, 0.3], [-1.5, 2.5e-7, 3e9]], "ok": 1, "raw": [0, 127, 128, 255],
+             "single": {"id": 1, "w": [3.0, 4.0], "label": "x"}}
+    msg = tmp_path / "outer.bin"
+    msg.write_bytes(L.encode_message(DEMO_TYPES, "demo.outer_t", value))
+    out = subprocess.check_output([tool, "schema", "%s,%s" % (demo, ex), "demo.outer_t", str(msg)], text=True).splitlines()
+    assert int(out[0].split()[1], 16) == L.fingerprint_nested(DEMO_TYPES, "demo.outer_t")
+    assert out[1] == ('{utime:123456789012,n:2,m:3,items:[{id:-7,w:[0.5,-2.25],label:"left foot"},{id:300,w:[1,8],label:""}],'
+                      'grid:[[0.10000000000000001,0.20000000000000001,0.29999999999999999],[-1.5,2.4999999999999999e-07,3000000000]],'
+                      'ok:1,raw:[0,127,128,255],single:{id:1,w:[3,4],label:"x"}}')
+    # the nested types enter the fingerprint: it is not the rotated base hash alone
+    hb = L.base_hash_nested(DEMO_TYPES["demo.outer_t"])
+    assert L.fingerprint_nested(DEMO_TYPES, "demo.outer_t") != ((hb << 1) + (hb >> 63)) & L.M64
+    # tutorial type, bare name: rot1(0x1baa9e29b0fbaa8b)
+    ex_types = {"exlcm.example_t": L.EXAMPLE_T}
+    ex_val = {"timestamp": 5, "position": [1.0, 2.0, 3.0], "orientation": [1.0, 0.0, 0.0, 0.0], "num_ranges": 3,
+              "ranges": [10, -20, 30], "name": "example string", "enabled": 1}
+    emsg = tmp_path / "example.bin"
+    emsg.write_bytes(L.encode_message(ex_types, "exlcm.example_t", ex_val))
+    out = subprocess.check_output([tool, "schema", "%s,%s" % (demo, ex), "example_t", str(emsg)], text=True).splitlines()
+    base = 0x1BAA9E29B0FBAA8B
+    assert int(out[0].split()[1], 16) == ((base << 1) + (base >> 63)) & L.M64
+    assert out[1].startswith("{timestamp:5,position:[1,2,3],orientation:[1,0,0,0],num_ranges:3,ranges:[10,-20,30],name:\"example string\"")
+    # damage: truncated message and a wrong type are refused
+    (tmp_path / "short.bin").write_bytes(msg.read_bytes()[:-3])
+    out = subprocess.check_output([tool, "schema", str(demo), "demo.outer_t", str(tmp_path / "short.bin")], text=True)
+    assert "decode error" in out
+    out = subprocess.check_output([tool, "schema", "%s,%s" % (demo, ex), "demo.inner_t", str(msg)], text=True)
+    assert "fingerprint mismatch" in out
