@@ -179,7 +179,7 @@ public:
     const uint64_t fp = r.u64();
     if (!r.ok) return fail(err, "short message");
     if (fp != fingerprint(name)) return fail(err, "fingerprint mismatch for " + name);
-    if (!decode_struct(*t, r, out, err)) return false;
+    if (!decode_struct(*t, r, out, err, 0)) return false;
     if (r.pos != len) return fail(err, "trailing bytes after " + name);
     return true;
   }
@@ -262,13 +262,13 @@ private:
   }
 
   bool decode_elements(const SchemaType &ctx, const SchemaField &f, size_t dim, const Value &self, Reader &r, Value &out,
-                       std::string *err) const
+                       std::string *err, int depth) const
   {
     if (dim == f.dims.size()) {
       if (is_primitive(f.type)) return decode_primitive(f.type, r, out, err);
       const SchemaType *nested = resolve(ctx, f.type);
       if (nested == nullptr) return fail(err, "unknown type " + f.type);
-      return decode_struct(*nested, r, out, err);
+      return decode_struct(*nested, r, out, err, depth + 1);
     }
     int64_t n = 0;
     if (f.dims[dim].mode == LCM_CONST) n = atoll(f.dims[dim].size.c_str());
@@ -277,17 +277,18 @@ private:
     out.kind = Value::ARRAY;
     out.items.resize((size_t) n);
     for (int64_t k = 0; k < n; k++)
-      if (!decode_elements(ctx, f, dim + 1, self, r, out.items[(size_t) k], err)) return false;
+      if (!decode_elements(ctx, f, dim + 1, self, r, out.items[(size_t) k], err, depth)) return false;
     return true;
   }
 
-  bool decode_struct(const SchemaType &t, Reader &r, Value &out, std::string *err) const
+  bool decode_struct(const SchemaType &t, Reader &r, Value &out, std::string *err, int depth) const
   {
+    if (depth > 32) return fail(err, "types nest deeper than 32 levels (a struct containing itself?)");
     out = Value();
     out.kind = Value::STRUCT;
     for (const SchemaField &f : t.fields) {
       Value v;
-      if (!decode_elements(t, f, 0, out, r, v, err)) return false;
+      if (!decode_elements(t, f, 0, out, r, v, err, depth)) return false;
       out.fields.emplace_back(f.name, std::move(v));
     }
     return true;
