@@ -701,6 +701,7 @@ struct kvh_raw_imu_packet_t {  // bot_core::kvh_raw_imu_t
 struct kvh_raw_imu_batch_t {   // bot_core::kvh_raw_imu_batch_t: raw_imu[0] is the NEWEST packet, as on the wire
   int64_t utime;
   std::vector<kvh_raw_imu_packet_t> raw_imu;
+  int mem = PB_HOST;           // PB_HOST_BROADCAST: the packets' arrays are [3], one robot's IMU for every filter
 };
 }  // namespace msgs
 
@@ -715,6 +716,31 @@ struct IMUBatch {
   std::vector<IMUPacket> packets;      // new packets, [0] oldest ... [end] newest
   std::vector<IMUPacket> packets_old;  // packets already seen in an earlier message
 };
+// estimate_tools/src/estimate_tools/iir_notch.cpp:3-61: 2nd-order IIR notch, host version.  The batch runs the cascade
+// on the device (pb_imu_notch, one state per filter); when ONE robot's IMU feeds every filter (PB_HOST_BROADCAST) every
+// filter would compute the same numbers, so the handler filters once on the host -- the reference's own code path.
+class IIRNotch {
+public:
+  double b[3], a[3], x[2] = { 0, 0 }, y[2] = { 0, 0 };
+  IIRNotch(double notch_freq, double fs)
+  {
+    const double Wo0 = notch_freq / (fs / 2), Ab = fabs(10 * log10(.5));
+    const double BW = Wo0 * M_PI, Wo = Wo0 * M_PI;      // "Inputs are normalized by pi" (:21-23); Bw = Wo (:8)
+    const double Gb = pow(10, -Ab / 20.);
+    const double beta = (sqrt(1.0 - Gb * Gb) / Gb) * tan(BW / 2.0);
+    const double gain = 1 / (1 + beta);
+    b[0] = gain; b[1] = gain * (-2.0 * cos(Wo)); b[2] = gain;
+    a[0] = 1.0; a[1] = -2 * gain * cos(Wo); a[2] = 2 * gain - 1;
+  }
+  double processSample(double input)
+  {
+    const double output = (input * b[0] + x[0] * b[1] + x[1] * b[2]) - (y[0] * a[1] + y[1] * a[2]);  // :52
+    x[1] = x[0]; x[0] = input;
+    y[1] = y[0]; y[0] = output;
+    return output;
+  }
+};
+
 class IMUStream {
 public:
   IMUStream() : last_packet_(-1), last_packet_utime_(0), counter_(0) {}
@@ -832,12 +858,33 @@ public:
   RBISUpdateInterface *processMessageAtlas(const msgs::kvh_raw_imu_batch_t *msg, MavStateEstimator *est)
   {
     const int B = est->B;
+    if (msg->mem != PB_HOST && msg->mem != PB_HOST_BROADCAST) return nullptr;
     if (!atlas_filter) {
       // :199-204: newest packet unfiltered, raw_dt from the two newest packets
       if (msg->raw_imu.size() < 2) return nullptr;
-      msgs::kvh_raw_imu_t m{ msg->utime, BatchArray(msg->raw_imu[0].delta_rotation, PB_HOST),
-                             BatchArray(msg->raw_imu[0].linear_acceleration, PB_HOST),
+      msgs::kvh_raw_imu_t m{ msg->utime, BatchArray(msg->raw_imu[0].delta_rotation, msg->mem),
+                             BatchArray(msg->raw_imu[0].linear_acceleration, msg->mem),
                              (msg->raw_imu[0].utime - msg->raw_imu[1].utime) * 1E-6 };
+      return processMessageAtlasPacket(&m, est);
+    }
+    if (msg->mem == PB_HOST_BROADCAST) {
+      // one robot for every filter: de-duplicate and filter ONCE on the host (IIRNotch above), hand the newest filtered
+      // packet over as a broadcast block.  (Do not mix with per-filter messages in one run: that state lives on the device.)
+      if (host_notch_.empty())
+        for (int ax = 0; ax < 3; ax++)
+          for (int i = 0; i < 3; i++) host_notch_.emplace_back(notch_freq * (double) (1 << i), 1000.0);  // :33-40: f, 2f, 4f
+      IMUBatch batch = imu_data_.convertFromLCMBatch(msg);
+      if (batch.packets.empty()) return nullptr;
+      double filt[3] = { 0, 0, 0 };
+      for (const IMUPacket &pk : batch.packets)
+        for (int ax = 0; ax < 3; ax++) {
+          double v = pk.linear_acceleration[ax];
+          for (int i = 0; i < 3; i++) v = host_notch_[(size_t) ax * 3 + i].processSample(v);
+          filt[ax] = v;
+        }
+      const IMUPacket &p = batch.packets.back();
+      msgs::kvh_raw_imu_t m{ msg->utime, BatchArray(p.delta_rotation, PB_HOST_BROADCAST), BatchArray(filt, PB_HOST_BROADCAST),
+                             p.utime_delta * 1E-6 };
       return processMessageAtlasPacket(&m, est);
     }
     if (!notch_initialised) {
@@ -865,6 +912,7 @@ public:
   double notch_freq = 0.0;
   bool notch_initialised = false;
   IMUStream imu_data_;
+  std::vector<IIRNotch> host_notch_;  // [axis][stage], broadcast messages only
 
   // Microstrain path (sensor_handlers.cpp:96-131): rotate accel and gyro into the body frame, dt = param
   RBISUpdateInterface *processMessage(const msgs::ins_t *msg, MavStateEstimator *est)
@@ -1817,6 +1865,35 @@ public:
         return;
       }
       msgs::rigid_transform_t m{ utime, BatchArray(t, PB_HOST_BROADCAST), BatchArray(q, PB_HOST_BROADCAST) };
+      cb(&m);
+    });
+  }
+  // bot_core::kvh_raw_imu_batch_t (utime, raw_imu[]{utime, packet_count, delta_rotation[3], linear_acceleration[3]}:
+  // IMUStream::convertFromLCMBatch, imu_stream.cpp:62-98; newest packet first, as on the wire)
+  void subscribeKvhBatch(const std::string &channel, const pronto_wire::Schema *schema, const std::string &type,
+                         std::function<void(const msgs::kvh_raw_imu_batch_t *)> cb)
+  {
+    subscribeSchema(channel, schema, type, [this, cb](const pronto_wire::Value &v, const pronto_wire::LogEvent &) {
+      msgs::kvh_raw_imu_batch_t m;
+      m.mem = PB_HOST_BROADCAST;
+      const pronto_wire::Value *raw = v.get("raw_imu");
+      if (!v.integer("utime", m.utime) || raw == nullptr || raw->kind != pronto_wire::Value::ARRAY) {
+        n_bad_++;
+        return;
+      }
+      std::vector<double> store(raw->items.size() * 6);
+      for (size_t k = 0; k < raw->items.size(); k++) {
+        const pronto_wire::Value &pk = raw->items[k];
+        msgs::kvh_raw_imu_packet_t p;
+        if (!pk.integer("utime", p.utime) || !pk.integer("packet_count", p.packet_count) ||
+            !pk.numbers("delta_rotation", &store[k * 6], 3) || !pk.numbers("linear_acceleration", &store[k * 6 + 3], 3)) {
+          n_bad_++;
+          return;
+        }
+        p.delta_rotation = &store[k * 6];
+        p.linear_acceleration = &store[k * 6 + 3];
+        m.raw_imu.push_back(p);
+      }
       cb(&m);
     });
   }

@@ -20,7 +20,7 @@ static double urand()
 }
 static double nrand() { return sqrt(-2 * log(urand())) * cos(2 * M_PI * urand()); }
 
-int main()
+int main(int argc, char **argv)
 {
   const int n = 15, B = 70, NMSG = 60;
   double g;
@@ -125,6 +125,115 @@ int main()
   printf("atlas IMU front end: %d messages, %d process steps, head utime %" PRId64 "; rel err vec %.2e quat %.2e cov %.2e; residual "
          "vibration in a_z %.3f m/s^2\n", NMSG, n_updates, head.utime, ev / sv, eq, eP / sP, vib);
   const bool ok = est.last_status == PB_OK && ev / sv < 1e-9 && eq < 1e-9 && eP / sP < 1e-9 && vib < 0.4 && n_updates == NMSG - NMSG / 7;
-  printf(ok ? "PASS\n" : "FAIL\n");
-  return ok ? 0 : 1;
+  // ---- phase 2: ONE robot's KVH batches for every filter, from a recorded log whose message type is known only through
+  //      its .lcm text: LogPlayer::subscribeKvhBatch -> PB_HOST_BROADCAST packets -> de-dup + notch on the host ->
+  //      broadcast process step.  Every filter must equal the oracle's chain on that one stream. ----
+  bool ok2 = false;
+  {
+    pronto_wire::Schema sc;
+    std::string err;
+    const bool parsed = sc.parse("package test_core;\n"
+                                 "struct kvh_raw_imu_t { int64_t utime; int64_t packet_count; double delta_rotation[3]; double linear_acceleration[3]; }\n"
+                                 "struct kvh_raw_imu_batch_t { int64_t utime; int32_t num_packets; kvh_raw_imu_t raw_imu[num_packets]; }\n", &err);
+    const std::string path = std::string(argc > 1 ? argv[1] : "/tmp") + "/kvh.lcmlog";
+    const int B2 = 70, NM2 = 60;
+    struct P2 { int64_t utime, count; double drot[3], acc[3]; };
+    std::deque<P2> ring2;
+    std::vector<std::vector<P2>> fresh_of;  // the NEW packets of each message, for the oracle
+    std::vector<int64_t> msg_utime;
+    {
+      pronto_wire::LogWriter log(path);
+      int64_t cnt = 0;
+      for (int m = 0; parsed && m < NM2; m++) {
+        const int fresh = (m % 5 == 4) ? 0 : 3;
+        std::vector<P2> fr;
+        for (int j = 0; j < fresh; j++) {
+          P2 p;
+          p.count = ++cnt;
+          p.utime = p.count * 1000;
+          for (int i = 0; i < 3; i++) {
+            p.drot[i] = 0.2 * sin(0.002 * p.count + i) * 0.001;
+            p.acc[i] = (i == 2 ? g : 0.0) + 1.5 * sin(2 * M_PI * 87.0 * p.count * 1e-3) + 0.05 * nrand();
+          }
+          ring2.push_back(p);
+          if (ring2.size() > 5) ring2.pop_front();
+          fr.push_back(p);
+        }
+        pronto_wire::Writer w;
+        w.u64(sc.fingerprint("test_core.kvh_raw_imu_batch_t"));
+        w.i64(cnt * 1000 + 200);
+        w.i32((int32_t) ring2.size());
+        for (int i = (int) ring2.size() - 1; i >= 0; i--) {  // newest first
+          w.i64(ring2[i].utime); w.i64(ring2[i].count);
+          w.f64s(ring2[i].drot, 3); w.f64s(ring2[i].acc, 3);
+        }
+        log.write(cnt * 1000 + 200, "ATLAS_IMU_BATCH", w.buf);
+        fresh_of.push_back(fr);
+        msg_utime.push_back(cnt * 1000 + 200);
+      }
+    }
+    RBIS y0(n, B2);
+    RBIM Q0(n, B2);
+    for (int b = 0; b < B2; b++)
+      for (int i = 3; i < 12; i++) Q0(i, i, b) = 0.01;
+    InsHandler h2(&param);
+    FrontEnd fe2(&param);
+    auto on_ins2 = fe2.addSensor("ins", &InsHandler::processMessageAtlas, &h2);
+    MavStateEstimator est2(new RBISResetUpdate(y0, Q0, RBISUpdateInterface::reset, 0), &param, 0);
+    fe2.setStateEstimator(&est2);
+    LogPlayer player(B2);
+    int seen = 0;
+    player.subscribeKvhBatch("ATLAS_IMU_BATCH", &sc, "test_core.kvh_raw_imu_batch_t", [&](const msgs::kvh_raw_imu_batch_t *m) {
+      if (m->mem != PB_HOST_BROADCAST) exit(1);
+      on_ins2(m);
+      seen++;
+    });
+    const int64_t dispatched = parsed ? player.run(path) : -1;
+    // oracle: one filter on the one stream
+    po_rbis o1;
+    po_rbim oP1;
+    double oll1 = 0.0;
+    po_rbis_zero(&o1);
+    memset(&oP1, 0, sizeof oP1);
+    for (int i = 3; i < 12; i++) oP1.m[i * 21 + i] = 0.01;
+    std::vector<po_notch> nt(9);
+    po_notch_cascade_init(nt.data(), 87.0, 1000);
+    int64_t last_pkt = 0, prev_upd = 0;
+    int steps = 0;
+    for (size_t m = 0; m < fresh_of.size(); m++) {
+      if (fresh_of[m].empty()) continue;
+      double af[3] = { 0, 0, 0 };
+      int64_t prev_pkt = last_pkt;
+      for (size_t i = 0; i < fresh_of[m].size(); i++) {
+        double a3[3] = { fresh_of[m][i].acc[0], fresh_of[m][i].acc[1], fresh_of[m][i].acc[2] };
+        po_notch_cascade(nt.data(), a3);
+        af[0] = a3[0]; af[1] = a3[1]; af[2] = a3[2];
+        if (i + 1 < fresh_of[m].size()) prev_pkt = fresh_of[m][i].utime;
+      }
+      const P2 &nw = fresh_of[m].back();
+      const double raw_dt = (nw.utime - prev_pkt) * 1E-6;
+      const double gy[3] = { nw.drot[0] / raw_dt, nw.drot[1] / raw_dt, nw.drot[2] / raw_dt };
+      const double dt2 = (prev_upd == 0) ? 0.003 : (msg_utime[m] - prev_upd) * 1E-6;
+      po_imu_process_step(gy, af, dt2, q4[0], q4[1], q4[2], q4[3], &o1, &oP1, oll1, &o1, &oP1, &oll1);
+      last_pkt = nw.utime;
+      prev_upd = msg_utime[m];
+      steps++;
+    }
+    RBIS h;
+    RBIM c;
+    est2.getHeadState(h, c);
+    double e2 = 0, s2 = 0, eq2 = 0, eP2 = 0, sP2 = 0;
+    for (int b = 0; b < B2; b++) {
+      for (int i = 0; i < n; i++) { e2 = fmax(e2, fabs(h(i, b) - o1.vec[i])); s2 = fmax(s2, fabs(o1.vec[i])); }
+      for (int i = 0; i < 4; i++) eq2 = fmax(eq2, fabs(h.q(i, b) - o1.quat[i]));
+      for (int cc = 0; cc < n; cc++)
+        for (int r = 0; r < n; r++) { eP2 = fmax(eP2, fabs(c(r, cc, b) - oP1.m[cc * 21 + r])); sP2 = fmax(sP2, fabs(oP1.m[cc * 21 + r])); }
+    }
+    printf("broadcast KVH log: %lld events, %d messages, %d process steps; rel err vec %.2e quat %.2e cov %.2e (status %d, undecodable %lld)\n",
+           (long long) dispatched, seen, steps, e2 / s2, eq2, eP2 / sP2, est2.last_status, (long long) player.undecodable());
+    ok2 = parsed && dispatched == NM2 && seen == NM2 && steps == NM2 - NM2 / 5 && est2.last_status == PB_OK && player.undecodable() == 0 &&
+          e2 / s2 < 1e-9 && eq2 < 1e-9 && eP2 / sP2 < 1e-9;
+  }
+  printf((ok && ok2) ? "PASS\n" : "FAIL\n");
+  return (ok && ok2) ? 0 : 1;
 }

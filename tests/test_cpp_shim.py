@@ -30,10 +30,10 @@ def build_exe(oracle, name="test_shim"):
 
 
 @pytest.mark.gpu
-def test_atlas_imu_front_end_on_gpu(oracle):
+def test_atlas_imu_front_end_on_gpu(oracle, tmp_path):
     """KVH batch de-dup + device notch cascade + process step through InsHandler::processMessageAtlas vs the oracle."""
     exe = build_exe(oracle, "test_atlas_imu")
-    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    r = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=300)
     print(r.stdout, r.stderr)
     assert r.returncode == 0 and "PASS" in r.stdout, r.stdout + r.stderr
 
