@@ -6,7 +6,12 @@ idx 3..5) for every filter of the batch = ONE kernel launch; the posterior is wr
 step (T = 1 accounting).  Inputs (IMU + leg-odometry streams for warmup+steps) are resident
 in HBM before the timed region.  N > 1: one process per GPU (torch.distributed / RCCL), the batch is split by
 filter range with NO data-path collective ("weak" scaling: per-GPU batch fixed); the only collective is the
-end-of-run summary all-reduce.
+end-of-run summary all-reduce.  `python bench.py --gpus N` starts its N ranks itself (child processes, the parent never
+touches the GPU); under torch.distributed.run (WORLD_SIZE set) it is one of the ranks.
+
+The K timed steps are repeated (`repeats`) until the timed region lasts >= --min-timed-ms; `value`, `ms_per_step` and the
+roofline figures are over all `timed_steps` = K x repeats launches.  At N=1 a second leg times the same step on 1 M filters
+(state 1.17 GB, nothing cache-resident) -> roofline.frac_cache_busting.
 
 Prints ONE JSON line on rank 0.
 """
@@ -135,6 +140,70 @@ def cpu_structured(n, dt_us, threads, target_s):
                                  "for the host (tests/host_harness.cpp), %.1f s" % (threads, Bt, T * reps, sec)}
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as CHILD processes (one per GPU) and relay rank 0's
+    JSON line.  This parent never touches the GPU (no torch import, no HIP call), children are fresh interpreters, nothing
+    is re-exec'ed; a failing rank makes the whole run fail."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode]
+    for p in procs[1:]:
+        try:
+            rcs.append(p.wait(timeout=600 if rcs[0] == 0 else 20))
+        except subprocess.TimeoutExpired:
+            p.kill()
+            rcs.append(-9)
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        raise SystemExit("bench.py: rank(s) failed: %s" % bad)
+
+
+def cache_busting(BatchEstimator, dev, local_rank, n, d_imu, d_lo, d_mask, vec, quat, P0, q4, min_ms):
+    """The same step on 1 M filters (state 1.17 GB >> the 256 MB Infinity Cache): the true-HBM figure next to the
+    cache-resident 64k headline.  Inputs: the 64k workload's first blocks tiled 16x along the filter axis (a bandwidth
+    measurement; parity is tested elsewhere), 24 distinct blocks cycled."""
+    import torch
+    reps_f = (1 << 20) // d_imu.shape[2]
+    if reps_f < 1 or (1 << 20) % d_imu.shape[2]:
+        return None
+    Bb, Tb = 1 << 20, min(24, d_imu.shape[0])
+    est = BatchEstimator(Bb, n_states=n, device=local_rank)
+    est.reset(torch.from_numpy(vec).to(dev).repeat(1, reps_f).contiguous(),
+              torch.from_numpy(quat).to(dev).repeat(1, reps_f).contiguous(),
+              torch.from_numpy(P0).to(dev).repeat(1, 1, reps_f).contiguous())
+    imu = d_imu[:Tb].repeat(1, 1, reps_f).contiguous()
+    lo = d_lo[:Tb].repeat(1, 1, reps_f).contiguous()
+    mask = d_mask[:Tb].repeat(1, reps_f).contiguous()
+    est.run_legodo(imu, lo, mask, q4)
+    ms = est.run_legodo(imu, lo, mask, q4, timed=True)
+    R = max(1, int(np.ceil(min_ms / max(ms, 1e-3))))
+    tot = 0.0
+    for _ in range(R):
+        tot += est.run_legodo(imu, lo, mask, q4, timed=True)
+    torch.cuda.synchronize()
+    kern = est.hot_kernel()
+    s = est.summary()
+    est.close()
+    del imu, lo, mask
+    us = tot / (R * Tb) * 1e3
+    bps = bytes_per_step(n)
+    return {"batch": Bb, "kernel": kern, "kernel_avg_us": us, "launches_timed": R * Tb,
+            "algorithmic_bytes_per_launch": bps * Bb, "achieved": bps * Bb / (us * 1e-6) / 1e9,
+            "frac": bps * Bb / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, "value": Bb / (us * 1e-6), "nonfinite": float(s[3])}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -144,10 +213,16 @@ def main():
     ap.add_argument("--n-states", type=int, default=15, choices=[15, 21])
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cache-busting", action="store_true", help="skip the 1 M-filter true-HBM leg (N=1 only)")
+    ap.add_argument("--min-timed-ms", type=float, default=50.0,
+                    help="the K timed steps are repeated until the timed region is at least this long")
     ap.add_argument("--fused", type=int, default=0, metavar="T",
                     help="also time the time-fused replay kernel (T steps per launch, state resident in registers) and "
                          "report it under its own accounting in a 'fused' object; never the headline value")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args.gpus)
 
     import torch
     import torch.distributed as dist
@@ -159,18 +234,38 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    # Rehearsals of the N > 1 code on a box with ONE GPU (or none):
+    #   PRONTO_BENCH_FORCE_DIST=1  the RCCL path with a single rank;
+    #   PRONTO_BENCH_REHEARSE=1    N ranks that all use GPU 0 and rendezvous over gloo (RCCL refuses two ranks on one
+    #                              device): everything but the collective's transport is the real path;
+    #   PRONTO_BENCH_REHEARSE=dry  no GPU at all: rendezvous + one all-reduce over gloo, rank 0 prints a stub line (the
+    #                              CPU test of the self-spawn logic, tests/test_shard_dist.py).
+    rehearse = os.environ.get("PRONTO_BENCH_REHEARSE", "")
+    if rehearse == "dry":
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        dist.all_reduce(t)
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "rank_sum": float(t[0])}), flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py: no GPU visible; the HIP path has no CPU fallback")
+    if rehearse == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    # PRONTO_BENCH_FORCE_DIST=1 takes the torch.distributed / RCCL path with a single rank too (a rehearsal of the N > 1
-    # code on a one-GPU box; launch through torch.distributed.run so that the rendezvous variables exist)
     use_dist = world > 1 or os.environ.get("PRONTO_BENCH_FORCE_DIST") == "1"
+    cdev = torch.device("cpu") if rehearse == "1" else dev   # where collective payloads live
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearse == "1":
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     n, K, W = args.n_states, args.steps, args.warmup
     Bper = args.batch_per_gpu
@@ -200,30 +295,49 @@ def main():
     est.sync()
 
     def barrier():
-        if use_dist:
+        if use_dist and rehearse == "1":
+            dist.barrier()
+        elif use_dist:
             dist.barrier(device_ids=[local_rank])
 
     # ---- warmup (untimed) ----
     if W:
         est.run_legodo(d_imu[:W], d_lo[:W], d_mask[:W], q4)
+    # How often the K-step block is repeated inside the timed region so that it lasts >= --min-timed-ms whatever K is
+    # (20 steps of 22 us would be a 0.4 ms measurement): one untimed calibration pass over the K steps, max over ranks.
+    reps = 1
+    if K > 0 and args.min_timed_ms > 0:
+        cal_ms = est.run_legodo(d_imu[W:], d_lo[W:], d_mask[W:], q4, timed=True)
+        r = torch.tensor([np.ceil(args.min_timed_ms / max(cal_ms, 1e-3))], dtype=torch.float64, device=cdev)
+        if use_dist:
+            dist.all_reduce(r, op=dist.ReduceOp.MAX)
+        reps = int(max(1, min(1e6, float(r[0]))))
+        # every repeat replays the same K input blocks on the state the previous one left; restart from x0 so that the
+        # timed trajectory starts where a plain K-step run would
+        est.reset(vec, quat, P0)
+        if W:
+            est.run_legodo(d_imu[:W], d_lo[:W], d_mask[:W], q4)
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
-    # ---- timed: exactly K steps = K launches of k_step<15,true> ----
+    # ---- timed: reps x K steps = reps x K launches of the hot kernel ----
+    ev_ms = 0.0
     t0 = time.perf_counter()
-    ev_ms = est.run_legodo(d_imu[W:], d_lo[W:], d_mask[W:], q4, timed=True)
+    for _ in range(reps):
+        ev_ms += est.run_legodo(d_imu[W:], d_lo[W:], d_mask[W:], q4, timed=True)
     torch.cuda.synchronize()
     barrier()
     t1 = time.perf_counter()
-    wall = torch.tensor([t1 - t0, ev_ms * 1e-3], dtype=torch.float64, device=dev)
+    wall = torch.tensor([t1 - t0, ev_ms * 1e-3], dtype=torch.float64, device=cdev)
     if use_dist:
         dist.all_reduce(wall, op=dist.ReduceOp.MAX)
     wall_s, ev_s = float(wall[0]), float(wall[1])
+    KR = K * reps
 
-    summary = allreduce_summary(est.summary(), dist if use_dist else None, dev)
+    summary = allreduce_summary(est.summary(), dist if use_dist else None, cdev)
 
     fused = None
-    if args.fused > 0 and n == 15:
+    if args.fused > 0:
         # secondary accounting: bytes_step(T) = 2*(S_x+S_P+8)/T + 56 + 48; the bound is fp64 VALU issue
         Tf = args.fused
         est.reset(vec, quat, P0)
@@ -237,33 +351,55 @@ def main():
                  "frac_of_hbm_roofline_under_this_accounting": bst * B * K / (fms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                  "note": "posterior written once per launch; not the plugin path, not the headline metric"}
 
+    hot = est.hot_kernel()
+    est.close()
+    busting = None
+    if world == 1 and not args.no_cache_busting and Bper <= (1 << 19):
+        try:
+            busting = cache_busting(BatchEstimator, dev, local_rank, n, d_imu, d_lo, d_mask, vec, quat, P0, q4,
+                                    args.min_timed_ms)
+        except Exception as e:  # a reported extra, never a reason to lose the bench line
+            busting = {"error": repr(e)}
+
     if rank == 0:
         bps = bytes_per_step(n)
-        value = total * K / wall_s
-        launch_s = ev_s / K                       # HIP events on the launch stream around the K launches
+        value = total * KR / wall_s
+        launch_s = ev_s / KR                      # HIP events on the launch stream around the launches
         achieved = bps * B / launch_s / 1e9       # algorithmic bytes of ONE launch (this rank's shard) / its duration
+        state_mb = (n + 5 + n * (n + 1) // 2) * 8 * B / 1e6
         out = {
             "metric": METRIC, "value": value, "unit": "steps/s", "n_gpus": world, "steps": K, "warmup": W,
-            "ms_per_step": wall_s / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": wall_s / KR * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
+            "repeats": reps, "timed_steps": KR, "timed_region_ms": wall_s * 1e3,
             "config": {"workload": "64k batched 15-state filters, IMU predict + 3-DoF leg-odom update, 1 MI355X"
                        if (n == 15 and Bper == 65536) else
                        "%d batched %d-state filters per GPU, IMU predict + 3-DoF leg-odom update" % (Bper, n),
-                       "batch_per_gpu": Bper, "n_states": n, "imu_dt_us": dt_us, "kernel": est.hot_kernel(),
+                       "batch_per_gpu": Bper, "n_states": n, "imu_dt_us": dt_us, "kernel": hot,
                        "launches_per_step": 1, "bytes_per_filter_step": bps, "parallelism": "filter-range split x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                         "kernel_avg_us": launch_s * 1e6, "algorithmic_bytes_per_launch": bps * B},
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "traffic_source": None,
+                         "kernel_avg_us": launch_s * 1e6, "algorithmic_bytes_per_launch": bps * B,
+                         "resident": ("infinity_cache: the %.0f MB state stays in the 256 MB memory-side cache between "
+                                      "launches, so `frac` is NOT an HBM-DRAM rate; see frac_cache_busting" % state_mb)
+                         if state_mb < 256 else "hbm"},
             "summary": {"sum_loglik": float(summary[0]), "checksum_abs": float(summary[1]),
                         "max_quat_norm_dev": float(summary[2]), "nonfinite": float(summary[3])},
         }
+        if busting is not None:
+            out["roofline"]["frac_cache_busting"] = busting.get("frac")
+            out["roofline"]["cache_busting"] = busting
         tr = os.path.join(ROOT, "profiles", "traffic.json")  # HBM bytes per launch from a separate --pmc pass
         if os.path.exists(tr):
             try:
                 rec = json.load(open(tr))
-                key = "%s@%d" % (est.hot_kernel(), B)
+                key = "%s@%d" % (hot, B)
                 if key in rec:
                     out["roofline"]["traffic"] = rec[key]["hbm_bytes_per_launch"]
+                    out["roofline"]["traffic_source"] = (
+                        "NOT measured in this run: profiles/traffic.json, round %s, separate rocprofv3 --pmc FETCH_SIZE / "
+                        "WRITE_SIZE passes of this command (scripts/profile.sh), counter scales from profiles/%s_pmc.json"
+                        % (rec[key].get("source"), rec[key].get("source")))
             except Exception:
                 pass
         if fused is not None:
@@ -271,9 +407,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(n, dt_us, args.cpu_seconds, BatchEstimator)
         print(json.dumps(out), flush=True)
-    est.close()
     if use_dist:
-        dist.barrier(device_ids=[local_rank])
+        barrier()
         dist.destroy_process_group()
 
 

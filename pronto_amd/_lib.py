@@ -19,8 +19,8 @@ PB_R_DIAG_BROADCAST, PB_R_DIAG, PB_R_FULL = 0, 1, 2
 
 
 def sources():
-    return [os.path.join(CSRC, f) for f in ("pronto_batch.hip", "rbis_kernels.hpp", "rbis_coop.hpp", "rbis_smooth.hpp",
-                                            "rbis_device.hpp")] + [HEADER]
+    return [os.path.join(CSRC, f) for f in ("pronto_batch.hip", "pb_step.hip", "pb_update.hip", "pb_smooth.hip", "pb_ctx.hpp",
+                                            "rbis_kernels.hpp", "rbis_coop.hpp", "rbis_smooth.hpp", "rbis_device.hpp")] + [HEADER]
 
 
 def is_stale():

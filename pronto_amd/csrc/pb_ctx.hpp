@@ -1,0 +1,101 @@
+// pb_ctx.hpp -- the context behind the C ABI and the launchers shared by the translation units of libpronto_batch.so
+// (the kernels are instantiated in several .hip files so that they compile in parallel: pb_step.hip the step kernels,
+// pb_update15.hip / pb_update21.hip the generic update kernels, pb_smooth.hip the smoother, pronto_batch.hip the rest).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "../../include/pronto_batch.h"
+#include "rbis_kernels.hpp"
+
+using namespace pb;
+
+struct pb_ctx {
+  int ns = 0, B = 0, dev = 0, nsnap = 0, nc = 0;  // nc: canonical components (Lay<NS>::NC)
+  long stride = 0;      // batch rounded up to whole 64-filter tiles
+  size_t state_doubles = 0;  // one state array / checkpoint slot: stride * Slots<NS>::NSLOT (tiled layout)
+  hipStream_t stream = nullptr, own_stream = nullptr;
+  double *st = nullptr;       // the HEAD posterior: st_base, or a checkpoint slot an update wrote its posterior into
+  double *st_base = nullptr;  // the context's own state array
+  int out_slot = -1;          // pb_set_output_slot: where the next update writes (then that slot is the head)
+  double *snaps = nullptr, *d_small = nullptr;
+  double *hist = nullptr;  // posterior checkpoint slots (pb_history_reserve)
+  int nhist = 0;
+  double *notch = nullptr;  // IMU notch cascade state [36][stride] (pb_imu_notch_init)
+  NotchCoef notch_coef;
+  bool notch_ready = false;
+  void *stage = nullptr;
+  size_t stage_bytes = 0;
+  // PB_HOST inputs: two staging buffers filled on a copy stream, so that the copy of message k+1 overlaps the kernels
+  // of message k (with pinned source buffers, pb_host_alloc, the DMA runs at link rate)
+  void *in_stage[2] = { nullptr, nullptr };
+  size_t in_stage_bytes[2] = { 0, 0 };
+  int in_idx = 0;
+  hipStream_t copy_stream = nullptr;
+  hipEvent_t ev_consumed[2] = { nullptr, nullptr }, ev_copied = nullptr;
+  Consts k{ 9.80665, 1e-6 };
+  int64_t utime = 0;
+  bool have_state = false;
+  bool coop15 = false;  // PRONTO_BATCH_COOP15=1: run the 15-state step on the two-wave cooperative kernel (A/B switch)
+  int mem_hint = 0;     // MH_* cache policy of the step kernels' state round trip (PRONTO_BATCH_MEMHINT=0/1/2 forces it)
+  bool smooth_attr = false;  // dynamic-LDS limit of the smoother kernels raised on this device
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  char err[512] = { 0 };
+};
+
+inline thread_local char g_create_err[512] = "";
+
+inline int fail(pb_ctx *c, int code, const char *fmt, ...)
+{
+  char *dst = c ? c->err : g_create_err;
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(dst, 512, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIPCHK(c, call)                                                                               \
+  do {                                                                                                \
+    hipError_t e_ = (call);                                                                           \
+    if (e_ != hipSuccess) return fail((c), PB_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
+  } while (0)
+
+inline int nblk(int n) { return (n + 63) / 64; }
+
+// Where an update writes its posterior.  Normally in place.  With pb_set_output_slot the posterior goes straight into a
+// checkpoint slot (a checkpoint per update without a copy: the step moves the same bytes either way).  If the head IS a
+// checkpoint slot and no output slot was named, the update writes back into the context's own array, so a saved
+// posterior is never modified.
+int detach_head(pb_ctx *c, bool keep_contents);
+
+inline double *update_target(pb_ctx *c)
+{
+  if (c->out_slot >= 0) return c->hist + (size_t) c->out_slot * c->state_doubles;
+  return (c->st != c->st_base) ? c->st_base : c->st;
+}
+inline void update_done(pb_ctx *c, double *target)
+{
+  c->st = target;
+  c->out_slot = -1;
+}
+
+
+#define LAUNCHCHK(c) HIPCHK((c), hipGetLastError())
+
+// ---- launchers defined in the other translation units ----
+// pb_step.hip: predict (update = false) or predict + leg-odometry update on the kernel pb_create picked
+int pbk_step(pb_ctx *c, bool update, const double *imu, const double *lo, const uint8_t *mask, const double q[4]);
+int pbk_replay_fused(pb_ctx *c, int T, const double *imu, const double *lo, const uint8_t *mask, const double q[4]);
+// pb_update15.hip / pb_update21.hip: generic indexed (+ orientation, qm != NULL) update, m = 1..6
+int pbk_update15(pb_ctx *c, int m, const int *idx, const double *z, const double *R, int rkind, const double *rb,
+                 const double *qm, const uint8_t *mask);
+int pbk_update21(pb_ctx *c, int m, const int *idx, const double *z, const double *R, int rkind, const double *rb,
+                 const double *qm, const uint8_t *mask);
+// pb_smooth.hip
+int pbk_smooth_step(pb_ctx *c, const double *next_pred, const double *next_sm, const double *cur, double *out, double dt);

@@ -1,0 +1,25 @@
+// pb_smooth.hip -- launcher of the RTS smoother kernel (rbis_smooth.hpp); see pb_ctx.hpp.
+#include "pb_ctx.hpp"
+#include "rbis_smooth.hpp"
+
+int pbk_smooth_step(pb_ctx *c, const double *np_, const double *ns_, const double *cu, double *out, double dt)
+{
+  if (!c->smooth_attr) {  // more than the default 64 KB of dynamic LDS per workgroup
+    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_smooth_reg<15>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int) (sizeof(double) * SmoothRegCfg<15>::LDS_DOUBLES)));
+    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_smooth_reg<21>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int) (sizeof(double) * SmoothRegCfg<21>::LDS_DOUBLES)));
+    c->smooth_attr = true;
+  }
+  if (c->ns == 15) {
+    using S = SmoothRegCfg<15>;
+    k_smooth_reg<15><<<(c->B + S::F - 1) / S::F, S::THREADS, sizeof(double) * S::LDS_DOUBLES, c->stream>>>(
+        np_, ns_, cu, out, c->B, dt, c->k);
+  } else {
+    using S = SmoothRegCfg<21>;
+    k_smooth_reg<21><<<(c->B + S::F - 1) / S::F, S::THREADS, sizeof(double) * S::LDS_DOUBLES, c->stream>>>(
+        np_, ns_, cu, out, c->B, dt, c->k);
+  }
+  LAUNCHCHK(c);
+  return PB_OK;
+}

@@ -1,97 +1,11 @@
 // pronto_batch.hip -- host side of the C ABI declared in include/pronto_batch.h: context, staging, launches.
 // The kernels live in rbis_kernels.hpp, the per-filter arithmetic in rbis_device.hpp.
 // There is no CPU path here: without a gfx950 device pb_create fails with PB_ERR_NO_DEVICE.
-#include <hip/hip_runtime.h>
-
-#include <cstdarg>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
 #include <new>
 
-#include "../../include/pronto_batch.h"
-#include "rbis_kernels.hpp"
-#include "rbis_smooth.hpp"
+#include "pb_ctx.hpp"
 
-using namespace pb;
-
-#define PB_VERSION_STR "pronto_batch 0.1 gfx950"
-
-// ------------------------------------------------------------------------------------------------------------
-// host side
-// ------------------------------------------------------------------------------------------------------------
-
-struct pb_ctx {
-  int ns = 0, B = 0, dev = 0, nsnap = 0, nc = 0;
-  long stride = 0;
-  hipStream_t stream = nullptr, own_stream = nullptr;
-  double *st = nullptr;       // the HEAD posterior: st_base, or a checkpoint slot an update wrote its posterior into
-  double *st_base = nullptr;  // the context's own state array
-  int out_slot = -1;          // pb_set_output_slot: where the next update writes (then that slot is the head)
-  double *snaps = nullptr, *d_small = nullptr;
-  double *hist = nullptr;  // posterior checkpoint slots (pb_history_reserve)
-  int nhist = 0;
-  double *notch = nullptr;  // IMU notch cascade state [36][stride] (pb_imu_notch_init)
-  NotchCoef notch_coef;
-  bool notch_ready = false;
-  void *stage = nullptr;
-  size_t stage_bytes = 0;
-  // PB_HOST inputs: two staging buffers filled on a copy stream, so that the copy of message k+1 overlaps the kernels
-  // of message k (with pinned source buffers, pb_host_alloc, the DMA runs at link rate)
-  void *in_stage[2] = { nullptr, nullptr };
-  size_t in_stage_bytes[2] = { 0, 0 };
-  int in_idx = 0;
-  hipStream_t copy_stream = nullptr;
-  hipEvent_t ev_consumed[2] = { nullptr, nullptr }, ev_copied = nullptr;
-  Consts k{ 9.80665, 1e-6 };
-  int64_t utime = 0;
-  bool have_state = false;
-  bool coop15 = false;  // PRONTO_BATCH_COOP15=1: run the 15-state step on the two-wave cooperative kernel (A/B switch)
-  int mem_hint = 0;     // MH_* cache policy of the step kernels' state round trip (PRONTO_BATCH_MEMHINT=0/1/2 forces it)
-  bool smooth_attr = false;  // dynamic-LDS limit of the smoother kernels raised on this device
-  bool smooth_lds = false;  // PRONTO_BATCH_SMOOTH_LDS=1: smoother on the first (LDS-resident) kernel, for A/B runs
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  char err[512] = { 0 };
-};
-
-static thread_local char g_create_err[512] = "";
-
-static int fail(pb_ctx *c, int code, const char *fmt, ...)
-{
-  char *dst = c ? c->err : g_create_err;
-  va_list ap;
-  va_start(ap, fmt);
-  vsnprintf(dst, 512, fmt, ap);
-  va_end(ap);
-  return code;
-}
-
-#define HIPCHK(c, call)                                                                               \
-  do {                                                                                                \
-    hipError_t e_ = (call);                                                                           \
-    if (e_ != hipSuccess) return fail((c), PB_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
-  } while (0)
-
-static inline int nblk(int n) { return (n + 63) / 64; }
-
-// Where an update writes its posterior.  Normally in place.  With pb_set_output_slot the posterior goes straight into a
-// checkpoint slot (a checkpoint per update without a copy: the step moves the same bytes either way).  If the head IS a
-// checkpoint slot and no output slot was named, the update writes back into the context's own array, so a saved
-// posterior is never modified.
-static inline double *update_target(pb_ctx *c);
-static inline void update_done(pb_ctx *c, double *target);
-static int detach_head(pb_ctx *c, bool keep_contents);
-
-static inline double *update_target(pb_ctx *c)
-{
-  if (c->out_slot >= 0) return c->hist + (size_t) c->out_slot * (size_t) c->nc * c->stride;
-  return (c->st != c->st_base) ? c->st_base : c->st;
-}
-static inline void update_done(pb_ctx *c, double *target)
-{
-  c->st = target;
-  c->out_slot = -1;
-}
+#define PB_VERSION_STR "pronto_batch 0.2 gfx950"
 
 extern "C" const char *pb_version(void) { return PB_VERSION_STR; }
 
@@ -127,28 +41,29 @@ extern "C" int pb_create(pb_ctx **out, int n_states, int batch, int device, int 
   }
   c->stride = ((long) batch + 63) / 64 * 64;
   c->nc = (n_states == 15) ? Lay<15>::NC : Lay<21>::NC;
+  c->state_doubles = (size_t) c->stride * (size_t) ((n_states == 15) ? Slots<15>::NSLOT : Slots<21>::NSLOT);
   {
     // XCD-contiguous workgroup order for the cooperative kernel: measured 1-5 % faster at every 15-state batch size,
     // and for 21 states only while the state (135 MB at 64k filters) sits well inside the 256 MB memory-side cache
     // (3-15 % slower beyond).  PRONTO_BATCH_XCD=0/1 forces it either way for A/B runs.
     const char *e = getenv("PRONTO_BATCH_XCD");
-    c->k.xcd_remap = e ? (e[0] == '1') : (n_states == 15 || (long) c->nc * c->stride * 8 <= (160L << 20));
+    c->k.xcd_remap = e ? (e[0] == '1') : (n_states == 15 || (long) c->state_doubles * 8 <= (160L << 20));
     // Cache policy of the state round trip (rbis_kernels.hpp MemHint), measured on both step kernels: a state that
     // fits the XCDs' L2s (< ~48 MB) wants the default policy (sc1 stores 7 % slower at 32k x 15 states); up to ~1.3x
     // the 256 MB memory-side cache sc1 stores are 1-4 % faster; beyond, non-temporal loads+stores are 7-15 % faster
     // (1M filters: 469 -> 417 us) and 10-40 % SLOWER if used on a cache-sized state.  PRONTO_BATCH_MEMHINT=0/1/2 forces.
-    const long state_bytes = (long) c->nc * c->stride * 8;
+    const long state_bytes = (long) c->state_doubles * 8;
     const char *h = getenv("PRONTO_BATCH_MEMHINT");
     c->mem_hint = h ? (h[0] - '0')
                     : (state_bytes < (48L << 20) ? MH_DEFAULT : state_bytes < (340L << 20) ? MH_STORE_SC1 : MH_STREAM_NT);
     if (c->mem_hint < 0 || c->mem_hint > 2) c->mem_hint = MH_DEFAULT;
-    const char *s = getenv("PRONTO_BATCH_SMOOTH_LDS");
-    c->smooth_lds = s && s[0] == '1';
   }
-  // the kernels address the state through one 32-bit-ranged buffer descriptor (rbis_kernels.hpp)
-  if ((unsigned long long) c->nc * (unsigned long long) c->stride * 8ull >= (1ull << 32)) {
+  // The kernels address the STATE through one buffer descriptor per 64-filter tile (64-bit tile base), so its size is
+  // bounded by HBM only; the per-message INPUT blocks ([rows][B], at most 36 rows) go through one 32-bit-ranged
+  // descriptor each, which bounds the batch of one context at 2^32 / (36 * 8) filters.
+  if ((unsigned long long) batch * 36ull * 8ull >= (1ull << 32)) {
     delete c;
-    return fail(nullptr, PB_ERR_ARG, "pb_create: batch %d too large for one context (state must stay below 4 GiB; "
+    return fail(nullptr, PB_ERR_ARG, "pb_create: batch %d too large for one context (input blocks must stay below 4 GiB; "
                 "split the batch over several contexts)", batch);
   }
 #define CRCHK(call)                                                                                 \
@@ -163,9 +78,9 @@ extern "C" int pb_create(pb_ctx **out, int n_states, int batch, int device, int 
   CRCHK(hipSetDevice(device));
   CRCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
   c->stream = c->own_stream;
-  CRCHK(hipMalloc((void **) &c->st_base, sizeof(double) * c->nc * c->stride));
+  CRCHK(hipMalloc((void **) &c->st_base, sizeof(double) * c->state_doubles));
   c->st = c->st_base;
-  CRCHK(hipMemsetAsync(c->st, 0, sizeof(double) * c->nc * c->stride, c->stream));
+  CRCHK(hipMemsetAsync(c->st, 0, sizeof(double) * c->state_doubles, c->stream));
   if (n_snapshots > 0) {
     CRCHK(hipMalloc((void **) &c->snaps, sizeof(double) * 7 * c->stride * n_snapshots));
     CRCHK(hipMemsetAsync(c->snaps, 0, sizeof(double) * 7 * c->stride * n_snapshots, c->stream));
@@ -387,7 +302,6 @@ static int stage_in(pb_ctx *c, int mem, Part *parts, int n)
 #define NEED_STATE(c) \
   if (!(c)->have_state) return fail((c), PB_ERR_STATE, "%s before pb_reset", __func__)
 
-#define LAUNCHCHK(c) HIPCHK((c), hipGetLastError())
 
 extern "C" int pb_reset(pb_ctx *c, const double *vec, const double *quat, const double *cov, int broadcast, int mem)
 {
@@ -406,7 +320,8 @@ extern "C" int pb_reset(pb_ctx *c, const double *vec, const double *quat, const 
     for (int i = 0; i < n; i++)
       for (int j = 0; j <= i; j++) comp[off_p + pk(i, j)] = cov[j * n + i];
     HIPCHK(c, hipMemcpyAsync(c->d_small, comp, sizeof(double) * c->nc, hipMemcpyHostToDevice, c->stream));
-    k_reset_bcast<<<nblk(B), 64, 0, c->stream>>>(c->st, c->stride, B, c->nc, c->d_small);
+    if (n == 15) k_reset_bcast<15><<<nblk(B), 64, 0, c->stream>>>(c->st, B, c->d_small);
+    else k_reset_bcast<21><<<nblk(B), 64, 0, c->stream>>>(c->st, B, c->d_small);
     LAUNCHCHK(c);
     HIPCHK(c, hipStreamSynchronize(c->stream));  // comp is a stack buffer
   } else {
@@ -415,41 +330,12 @@ extern "C" int pb_reset(pb_ctx *c, const double *vec, const double *quat, const 
     int rc = stage_in(c, mem, p, 3);
     if (rc) return rc;
     if (n == 15)
-      k_reset<15><<<nblk(B), 64, 0, c->stream>>>(c->st, c->stride, B, (const double *) p[0].dev, (const double *) p[1].dev, (const double *) p[2].dev);
+      k_reset<15><<<nblk(B), 64, 0, c->stream>>>(c->st, B, (const double *) p[0].dev, (const double *) p[1].dev, (const double *) p[2].dev);
     else
-      k_reset<21><<<nblk(B), 64, 0, c->stream>>>(c->st, c->stride, B, (const double *) p[0].dev, (const double *) p[1].dev, (const double *) p[2].dev);
+      k_reset<21><<<nblk(B), 64, 0, c->stream>>>(c->st, B, (const double *) p[0].dev, (const double *) p[1].dev, (const double *) p[2].dev);
     LAUNCHCHK(c);
   }
   c->have_state = true;
-  return PB_OK;
-}
-
-template <bool UPDATE, int MH>
-static void launch_step_mh(pb_ctx *c, double *out, const double *imu, const double *lo, const uint8_t *mask, const double q[4])
-{
-  const int B = c->B;
-  if (c->ns == 15 && c->coop15) {
-    k_step_coop<15, UPDATE, MH><<<nblk(B), 128, 0, c->stream>>>(c->st, out, c->stride, B, imu, lo, mask, q[0], q[1], q[2], q[3], c->k);
-  } else if (c->ns == 15) {
-    k_step<15, UPDATE, MH><<<(B + PB_STEP_BLOCK - 1) / PB_STEP_BLOCK, PB_STEP_BLOCK, 0, c->stream>>>(c->st, out, c->stride, B, imu, lo, mask, q[0], q[1], q[2], q[3], c->k);
-  } else {
-    // n = 21: 231 packed covariance entries do not fit one lane's registers; the step runs on the two-wave
-    // cooperative kernel (rbis_coop.hpp): one launch, one state round trip.
-    k_step_coop<21, UPDATE, MH><<<nblk(B), 128, 0, c->stream>>>(c->st, out, c->stride, B, imu, lo, mask, q[0], q[1], q[2], q[3], c->k);
-  }
-}
-
-template <bool UPDATE>
-static int launch_step(pb_ctx *c, const double *imu, const double *lo, const uint8_t *mask, const double q[4])
-{
-  double *out = update_target(c);
-  switch (c->mem_hint) {  // cache policy of the state round trip, chosen in pb_create from the state size
-  case MH_STORE_SC1: launch_step_mh<UPDATE, MH_STORE_SC1>(c, out, imu, lo, mask, q); break;
-  case MH_STREAM_NT: launch_step_mh<UPDATE, MH_STREAM_NT>(c, out, imu, lo, mask, q); break;
-  default: launch_step_mh<UPDATE, MH_DEFAULT>(c, out, imu, lo, mask, q); break;
-  }
-  LAUNCHCHK(c);
-  update_done(c, out);
   return PB_OK;
 }
 
@@ -461,7 +347,7 @@ extern "C" int pb_predict(pb_ctx *c, const double *imu_block, const double q[4],
   Part p[1] = { { imu_block, sizeof(double) * 7 * c->B, 0 } };
   int rc = stage_in(c, mem, p, 1);
   if (rc) return rc;
-  return launch_step<false>(c, (const double *) p[0].dev, nullptr, nullptr, q);
+  return pbk_step(c, false, (const double *) p[0].dev, nullptr, nullptr, q);
 }
 
 extern "C" int pb_step_legodo(pb_ctx *c, const double *imu_block, const double *lo_block, const uint8_t *mask,
@@ -474,7 +360,7 @@ extern "C" int pb_step_legodo(pb_ctx *c, const double *imu_block, const double *
                 { mask, (size_t) c->B, 0 } };
   int rc = stage_in(c, mem, p, 3);
   if (rc) return rc;
-  return launch_step<true>(c, (const double *) p[0].dev, (const double *) p[1].dev, (const uint8_t *) p[2].dev, q);
+  return pbk_step(c, true, (const double *) p[0].dev, (const double *) p[1].dev, (const uint8_t *) p[2].dev, q);
 }
 
 extern "C" int pb_run_legodo(pb_ctx *c, int n_steps, const double *imu_stream, const double *lo_stream,
@@ -492,8 +378,8 @@ extern "C" int pb_run_legodo(pb_ctx *c, int n_steps, const double *imu_stream, c
     hipGraphExec_t exec = nullptr;
     HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
     for (int s = 0; s < n_steps; s++) {
-      int rc = launch_step<true>(c, imu_stream + (size_t) s * 7 * B, lo_stream + (size_t) s * 6 * B,
-                                 mask_stream ? mask_stream + (size_t) s * B : nullptr, q);
+      int rc = pbk_step(c, true, imu_stream + (size_t) s * 7 * B, lo_stream + (size_t) s * 6 * B,
+                        mask_stream ? mask_stream + (size_t) s * B : nullptr, q);
       if (rc) return rc;
     }
     HIPCHK(c, hipStreamEndCapture(c->stream, &graph));
@@ -509,8 +395,8 @@ extern "C" int pb_run_legodo(pb_ctx *c, int n_steps, const double *imu_stream, c
   }
   if (elapsed_ms) HIPCHK(c, hipEventRecord(c->ev0, c->stream));
   for (int s = 0; s < n_steps; s++) {
-    int rc = launch_step<true>(c, imu_stream + (size_t) s * 7 * B, lo_stream + (size_t) s * 6 * B,
-                               mask_stream ? mask_stream + (size_t) s * B : nullptr, q);
+    int rc = pbk_step(c, true, imu_stream + (size_t) s * 7 * B, lo_stream + (size_t) s * 6 * B,
+                      mask_stream ? mask_stream + (size_t) s * B : nullptr, q);
     if (rc) return rc;
   }
   if (elapsed_ms) {
@@ -538,63 +424,15 @@ extern "C" int pb_replay_legodo_fused(pb_ctx *c, int n_steps, int steps_per_laun
   if (elapsed_ms) HIPCHK(c, hipEventRecord(c->ev0, c->stream));
   for (int s = 0; s < n_steps; s += steps_per_launch) {
     const int T = (n_steps - s < steps_per_launch) ? n_steps - s : steps_per_launch;
-    k_replay_fused<15><<<nblk(c->B), 64, 0, c->stream>>>(c->st, c->stride, c->B, T, imu_stream + (size_t) s * 7 * B,
-                                                         lo_stream + (size_t) s * 6 * B,
-                                                         mask_stream ? mask_stream + (size_t) s * B : nullptr, q[0], q[1],
-                                                         q[2], q[3], c->k);
-    LAUNCHCHK(c);
+    int rc = pbk_replay_fused(c, T, imu_stream + (size_t) s * 7 * B, lo_stream + (size_t) s * 6 * B,
+                              mask_stream ? mask_stream + (size_t) s * B : nullptr, q);
+    if (rc) return rc;
   }
   if (elapsed_ms) {
     HIPCHK(c, hipEventRecord(c->ev1, c->stream));
     HIPCHK(c, hipEventSynchronize(c->ev1));
     HIPCHK(c, hipEventElapsedTime(elapsed_ms, c->ev0, c->ev1));
   }
-  return PB_OK;
-}
-
-template <int NS, int M, int MH>
-static void launch_update_mh(pb_ctx *c, const IdxArg<M> &ia, const DiagArg<M> &da, const double *z, const double *R,
-                             int rkind, const double *qm, const uint8_t *mask)
-{
-  double *out = update_target(c);
-  if (qm)
-    k_update<NS, M, true, MH><<<nblk(c->B), 64, 0, c->stream>>>(c->st, out, c->stride, c->B, ia, z, R, rkind, da, qm, mask, c->k);
-  else
-    k_update<NS, M, false, MH><<<nblk(c->B), 64, 0, c->stream>>>(c->st, out, c->stride, c->B, ia, z, R, rkind, da, qm, mask, c->k);
-  update_done(c, out);
-}
-
-template <int NS, int M>
-static void launch_update_m(pb_ctx *c, const int *idx, const double *z, const double *R, int rkind, const double *rb,
-                            const double *qm, const uint8_t *mask)
-{
-  IdxArg<M> ia;
-  DiagArg<M> da;
-  for (int i = 0; i < M; i++) {
-    ia.v[i] = idx[i];
-    da.v[i] = rb ? rb[i] : 0.0;
-  }
-  switch (c->mem_hint) {
-  case MH_STORE_SC1: launch_update_mh<NS, M, MH_STORE_SC1>(c, ia, da, z, R, rkind, qm, mask); break;
-  case MH_STREAM_NT: launch_update_mh<NS, M, MH_STREAM_NT>(c, ia, da, z, R, rkind, qm, mask); break;
-  default: launch_update_mh<NS, M, MH_DEFAULT>(c, ia, da, z, R, rkind, qm, mask); break;
-  }
-}
-
-template <int NS>
-static int launch_update(pb_ctx *c, int m, const int *idx, const double *z, const double *R, int rkind,
-                         const double *rb, const double *qm, const uint8_t *mask)
-{
-  switch (m) {
-    case 1: launch_update_m<NS, 1>(c, idx, z, R, rkind, rb, qm, mask); break;
-    case 2: launch_update_m<NS, 2>(c, idx, z, R, rkind, rb, qm, mask); break;
-    case 3: launch_update_m<NS, 3>(c, idx, z, R, rkind, rb, qm, mask); break;
-    case 4: launch_update_m<NS, 4>(c, idx, z, R, rkind, rb, qm, mask); break;
-    case 5: launch_update_m<NS, 5>(c, idx, z, R, rkind, rb, qm, mask); break;
-    case 6: launch_update_m<NS, 6>(c, idx, z, R, rkind, rb, qm, mask); break;
-    default: return fail(c, PB_ERR_ARG, "update: m must be 1..6");
-  }
-  LAUNCHCHK(c);
   return PB_OK;
 }
 
@@ -624,10 +462,10 @@ static int update_common(pb_ctx *c, int m, const int *idx, const double *z, cons
   int rc = stage_in(c, mem, p, 4);
   if (rc) return rc;
   if (c->ns == 15)
-    return launch_update<15>(c, m, idx, (const double *) p[0].dev, (const double *) p[1].dev, rkind, rb,
-                             (const double *) p[2].dev, (const uint8_t *) p[3].dev);
-  return launch_update<21>(c, m, idx, (const double *) p[0].dev, (const double *) p[1].dev, rkind, rb,
-                           (const double *) p[2].dev, (const uint8_t *) p[3].dev);
+    return pbk_update15(c, m, idx, (const double *) p[0].dev, (const double *) p[1].dev, rkind, rb,
+                        (const double *) p[2].dev, (const uint8_t *) p[3].dev);
+  return pbk_update21(c, m, idx, (const double *) p[0].dev, (const double *) p[1].dev, rkind, rb,
+                      (const double *) p[2].dev, (const uint8_t *) p[3].dev);
 }
 
 extern "C" int pb_update_indexed(pb_ctx *c, int m, const int *idx, const double *z, const double *R, int r_kind,
@@ -661,7 +499,7 @@ extern "C" int pb_snapshot_from_slot(pb_ctx *c, int slot, int checkpoint_slot)
   if (checkpoint_slot < 0 || checkpoint_slot >= c->nhist)
     return fail(c, PB_ERR_STATE, "pb_snapshot_from_slot: checkpoint slot %d of %d", checkpoint_slot, c->nhist);
   double *snap = c->snaps + (size_t) slot * 7 * c->stride;
-  const double *src = c->hist + (size_t) checkpoint_slot * (size_t) c->nc * c->stride;
+  const double *src = c->hist + (size_t) checkpoint_slot * c->state_doubles;
   if (c->ns == 15) k_snapshot<15><<<nblk(c->B), 64, 0, c->stream>>>(src, c->stride, c->B, snap);
   else k_snapshot<21><<<nblk(c->B), 64, 0, c->stream>>>(src, c->stride, c->B, snap);
   LAUNCHCHK(c);
@@ -709,8 +547,8 @@ extern "C" int pb_get_head(pb_ctx *c, int first, int count, double *vec_out, dou
   } else if (mem != PB_DEVICE) {
     return fail(c, PB_ERR_ARG, "mem must be PB_HOST or PB_DEVICE");
   }
-  if (n == 15) k_get_head<15><<<nblk(count), 64, 0, c->stream>>>(c->st, c->stride, first, count, dv, dq, dc, dl);
-  else k_get_head<21><<<nblk(count), 64, 0, c->stream>>>(c->st, c->stride, first, count, dv, dq, dc, dl);
+  if (n == 15) k_get_head<15><<<nblk(count), 64, 0, c->stream>>>(c->st, first, count, dv, dq, dc, dl);
+  else k_get_head<21><<<nblk(count), 64, 0, c->stream>>>(c->st, first, count, dv, dq, dc, dl);
   LAUNCHCHK(c);
   if (mem == PB_HOST) {
     if (vec_out) HIPCHK(c, hipMemcpyAsync(vec_out, dv, sizeof(double) * n * count, hipMemcpyDeviceToHost, c->stream));
@@ -746,8 +584,8 @@ extern "C" int pb_summary(pb_ctx *c, double out[4])
   int rc = stage_reserve(c, sizeof(double) * 4 * (size_t) nb);
   if (rc) return rc;
   double *part = (double *) c->stage;
-  if (c->ns == 15) k_summary<15><<<nb, 64, 0, c->stream>>>(c->st, c->stride, c->B, part);
-  else k_summary<21><<<nb, 64, 0, c->stream>>>(c->st, c->stride, c->B, part);
+  if (c->ns == 15) k_summary<15><<<nb, 64, 0, c->stream>>>(c->st, c->B, part);
+  else k_summary<21><<<nb, 64, 0, c->stream>>>(c->st, c->B, part);
   LAUNCHCHK(c);
   double *h = (double *) malloc(sizeof(double) * 4 * (size_t) nb);
   if (!h) return fail(c, PB_ERR_ARG, "pb_summary: out of host memory");
@@ -782,7 +620,7 @@ static int launch_nll(pb_ctx *c, int m, const int *idx, const double *tv, const 
   case M: {                                                                                                 \
     IdxArg<M> ia;                                                                                           \
     for (int i = 0; i < M; i++) ia.v[i] = idx[i];                                                           \
-    k_window_nll<NS, M><<<nblk(c->B), 64, 0, c->stream>>>(c->st, c->stride, c->B, ia, tv, tq, out, err);    \
+    k_window_nll<NS, M><<<nblk(c->B), 64, 0, c->stream>>>(c->st, c->B, ia, tv, tq, out, err);    \
   } break;
   switch (m) {
     NLL_CASE(1) NLL_CASE(2) NLL_CASE(3) NLL_CASE(4) NLL_CASE(5) NLL_CASE(6) NLL_CASE(7) NLL_CASE(8) NLL_CASE(9)
@@ -889,11 +727,11 @@ extern "C" int pb_imu_notch(pb_ctx *c, int n_packets, const double *accel_packet
 }
 
 // the head goes back to the context's own array (copying it there if it currently lives in a checkpoint slot)
-static int detach_head(pb_ctx *c, bool keep_contents)
+int detach_head(pb_ctx *c, bool keep_contents)
 {
   if (c->st != c->st_base) {
     if (keep_contents)
-      HIPCHK(c, hipMemcpyAsync(c->st_base, c->st, sizeof(double) * (size_t) c->nc * c->stride, hipMemcpyDeviceToDevice, c->stream));
+      HIPCHK(c, hipMemcpyAsync(c->st_base, c->st, sizeof(double) * c->state_doubles, hipMemcpyDeviceToDevice, c->stream));
     c->st = c->st_base;
   }
   c->out_slot = -1;
@@ -911,7 +749,7 @@ extern "C" int pb_history_reserve(pb_ctx *c, int n_slots)
   c->hist = nullptr;
   c->nhist = 0;
   if (n_slots == 0) return PB_OK;
-  const size_t bytes = sizeof(double) * (size_t) c->nc * c->stride;
+  const size_t bytes = sizeof(double) * c->state_doubles;
   hipError_t e = hipMalloc((void **) &c->hist, bytes * n_slots);
   if (e != hipSuccess)
     return fail(c, PB_ERR_HIP, "pb_history_reserve: %d slots x %zu bytes: %s", n_slots, bytes, hipGetErrorString(e));
@@ -932,7 +770,7 @@ extern "C" int pb_set_output_slot(pb_ctx *c, int slot)
 extern "C" int pb_head_slot(const pb_ctx *c)
 {
   if (!c || c->st == c->st_base || !c->hist) return -1;
-  return (int) ((size_t) (c->st - c->hist) / ((size_t) c->nc * c->stride));
+  return (int) ((size_t) (c->st - c->hist) / c->state_doubles);
 }
 
 extern "C" int pb_state_save(pb_ctx *c, int slot)
@@ -940,7 +778,7 @@ extern "C" int pb_state_save(pb_ctx *c, int slot)
   ENTER(c);
   NEED_STATE(c);
   if (slot < 0 || slot >= c->nhist) return fail(c, PB_ERR_STATE, "checkpoint slot %d of %d", slot, c->nhist);
-  const size_t n = (size_t) c->nc * c->stride;
+  const size_t n = c->state_doubles;
   double *h = c->hist + (size_t) slot * n;
   if (h == c->st) return PB_OK;  // the head was written straight into this slot (pb_set_output_slot)
   HIPCHK(c, hipMemcpyAsync(h, c->st, sizeof(double) * n, hipMemcpyDeviceToDevice, c->stream));
@@ -952,7 +790,7 @@ extern "C" int pb_state_restore(pb_ctx *c, int slot)
   ENTER(c);
   NEED_STATE(c);
   if (slot < 0 || slot >= c->nhist) return fail(c, PB_ERR_STATE, "checkpoint slot %d of %d", slot, c->nhist);
-  const size_t n = (size_t) c->nc * c->stride;
+  const size_t n = c->state_doubles;
   // always into the context's own array: the slot the head may currently live in stays what it is
   HIPCHK(c, hipMemcpyAsync(c->st_base, c->hist + (size_t) slot * n, sizeof(double) * n, hipMemcpyDeviceToDevice, c->stream));
   c->st = c->st_base;
@@ -968,38 +806,11 @@ extern "C" int pb_smooth_step(pb_ctx *c, int slot_next_pred, int slot_next, int 
     if (s[i] < 0 || s[i] >= c->nhist) return fail(c, PB_ERR_STATE, "pb_smooth_step: checkpoint slot %d of %d", s[i], c->nhist);
   if (slot_out == slot_next_pred || slot_out == slot_next)
     return fail(c, PB_ERR_ARG, "pb_smooth_step: slot_out may alias slot_cur only");
-  const size_t n = (size_t) c->nc * c->stride;
+  const size_t n = c->state_doubles;
   const double *np_ = c->hist + (size_t) slot_next_pred * n, *ns_ = c->hist + (size_t) slot_next * n;
   const double *cu = c->hist + (size_t) slot_cur * n;
   double *out = c->hist + (size_t) slot_out * n;
-  if (!c->smooth_lds) {  // factorisation in registers, run-time indices as LDS addresses (rbis_smooth.hpp)
-    if (!c->smooth_attr) {  // more than the default 64 KB of dynamic LDS per workgroup
-      HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_smooth_reg<15>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int) (sizeof(double) * SmoothRegCfg<15>::LDS_DOUBLES)));
-      HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_smooth_reg<21>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int) (sizeof(double) * SmoothRegCfg<21>::LDS_DOUBLES)));
-      c->smooth_attr = true;
-    }
-    if (c->ns == 15) {
-      using S = SmoothRegCfg<15>;
-      k_smooth_reg<15><<<(c->B + S::F - 1) / S::F, S::THREADS, sizeof(double) * S::LDS_DOUBLES, c->stream>>>(
-          np_, ns_, cu, out, c->stride, c->B, dt, c->k);
-    } else {
-      using S = SmoothRegCfg<21>;
-      k_smooth_reg<21><<<(c->B + S::F - 1) / S::F, S::THREADS, sizeof(double) * S::LDS_DOUBLES, c->stream>>>(
-          np_, ns_, cu, out, c->stride, c->B, dt, c->k);
-    }
-  } else if (c->ns == 15) {
-    using S = SmoothCfg<15>;
-    k_smooth_step<15><<<(c->B + S::F - 1) / S::F, S::THREADS, sizeof(double) * S::PER_FILTER * S::F, c->stream>>>(
-        np_, ns_, cu, out, c->stride, c->B, dt, c->k);
-  } else {
-    using S = SmoothCfg<21>;
-    k_smooth_step<21><<<(c->B + S::F - 1) / S::F, S::THREADS, sizeof(double) * S::PER_FILTER * S::F, c->stream>>>(
-        np_, ns_, cu, out, c->stride, c->B, dt, c->k);
-  }
-  LAUNCHCHK(c);
-  return PB_OK;
+  return pbk_smooth_step(c, np_, ns_, cu, out, dt);
 }
 
 extern "C" int pb_calib_copy(pb_ctx *c, int reps, float *elapsed_ms)
@@ -1007,11 +818,11 @@ extern "C" int pb_calib_copy(pb_ctx *c, int reps, float *elapsed_ms)
   ENTER(c);
   if (reps < 1) return fail(c, PB_ERR_ARG, "pb_calib_copy: reps must be >= 1");
   double *dst = nullptr;
-  const size_t bytes = sizeof(double) * (size_t) c->nc * c->stride;
+  const size_t bytes = sizeof(double) * c->state_doubles;
   HIPCHK(c, hipMalloc((void **) &dst, bytes));
   hipError_t e = hipEventRecord(c->ev0, c->stream);
   for (int r = 0; r < reps && e == hipSuccess; r++) {
-    k_calib_copy<<<nblk(c->B), 64, 0, c->stream>>>(c->st, dst, c->stride, c->B, c->nc);
+    k_calib_copy<<<nblk(c->B), 64, 0, c->stream>>>(c->st, dst, c->B, (int) (c->state_doubles / (size_t) c->stride / 2));
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipEventRecord(c->ev1, c->stream);

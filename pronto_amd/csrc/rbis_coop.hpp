@@ -29,11 +29,15 @@ struct Coop {
   static constexpr int NSC = HB ? 15 : 9;           // role C sub-state: v chi Delta [bg ba]
   static constexpr int NPC = NSC * (NSC + 1) / 2;
   static constexpr int NB_ = HB ? 6 : 0;            // bias states
-  static constexpr int NXCH = 9 + 3 * NSC;          // LDS hand-off doubles per filter: L(3) id(3) yd(3) W_c,b
+  // The log-likelihood lives in role C's rows for n = 21 and in role P's rows for n = 15 (Slots<NS>: both roles must
+  // own an even number of components); for n = 15 role C hands its increment over with the factors.
+  static constexpr bool LL_IN_P = !HB;
+  static constexpr int XCH_LLI = 9 + 3 * NSC;       // hand-off slot of the log-likelihood increment (LL_IN_P only)
+  static constexpr int NXCH = 9 + 3 * NSC + (LL_IN_P ? 1 : 0);  // LDS hand-off doubles per filter: L(3) id(3) yd(3) W_c,b [lli]
   // sub index -> full state index
-  PB_HD static constexpr int fullc(int s) { return s < 9 ? 3 + s : 15 + (s - 9); }
+  PB_HD static constexpr int fullc(int s) { return core_full(s); }
   // passive index 0..5 -> full state index (omega 0..2, accel 12..14)
-  PB_HD static constexpr int fullp(int p) { return p < 3 ? p : 12 + (p - 3); }
+  PB_HD static constexpr int fullp(int p) { return passive_full(p); }
 };
 
 // blocks of Ac*dt about the prior state (rbis.cpp:12-35), shared by both roles
@@ -106,12 +110,12 @@ PB_HD void coop_role_core(LD ld, ST st, XW xw, SYNC sync, const StepInputs &in, 
   using L = Lay<NS>;
   using C = Coop<NS>;
   constexpr int NSC = C::NSC;
-  double x[NS], q[4], ll;
+  double x[NS], q[4], ll = 0.0;
 #pragma unroll
   for (int i = 0; i < NS; i++) x[i] = ld(L::OFF_VEC + i);
 #pragma unroll
   for (int i = 0; i < 4; i++) q[i] = ld(L::OFF_QUAT + i);
-  ll = ld(L::OFF_LL);
+  if constexpr (!C::LL_IN_P) ll = ld(L::OFF_LL);
   double Pc[C::NPC];
 #pragma unroll
   for (int i = 0; i < NSC; i++)
@@ -193,7 +197,7 @@ PB_HD void coop_role_core(LD ld, ST st, XW xw, SYNC sync, const StepInputs &in, 
 #pragma unroll
       for (int j = 0; j <= i; j++) S[pk(i, j)] = Pc[pk(i, j)] + (i == j ? (in.upd ? in.rd[i] : 1.0) : 0.0);
     ldlt<3>(S, d);
-    double lli = 0.0;
+    double quad = 0.0, det = 1.0;
 #pragma unroll
     for (int kk = 0; kk < 3; kk++) {
       double s = resid[kk];
@@ -202,9 +206,12 @@ PB_HD void coop_role_core(LD ld, ST st, XW xw, SYNC sync, const StepInputs &in, 
       y[kk] = in.upd ? s : 0.0;
       id[kk] = in.upd ? 1.0 / d[kk] : 0.0;
       yd[kk] = y[kk] * id[kk];
-      lli -= log(d[kk]) + s * s * id[kk];
+      det *= d[kk];
+      quad += s * s * id[kk];
     }
-    if (in.upd) ll += lli;
+    const double lli = -log(det) - quad;  // -log(S.determinant()) - r^T S^-1 r (rbis.cpp:142): ONE log of the product
+    if constexpr (C::LL_IN_P) xw(C::XCH_LLI, lli);
+    else if (in.upd) ll += lli;
     double W[NSC][3];
 #pragma unroll
     for (int i = 0; i < NSC; i++)
@@ -253,10 +260,12 @@ PB_HD void coop_role_core(LD ld, ST st, XW xw, SYNC sync, const StepInputs &in, 
     sync();
   }
 #pragma unroll
-  for (int i = 0; i < NSC; i++) st(L::OFF_VEC + C::fullc(i), x[C::fullc(i)]);
+  for (int i = 0; i < 9; i++) st(L::OFF_VEC + C::fullc(i), x[C::fullc(i)]);
 #pragma unroll
   for (int i = 0; i < 4; i++) st(L::OFF_QUAT + i, q[i]);
-  st(L::OFF_LL, ll);
+  if constexpr (!C::LL_IN_P) st(L::OFF_LL, ll);
+#pragma unroll
+  for (int i = 9; i < NSC; i++) st(L::OFF_VEC + C::fullc(i), x[C::fullc(i)]);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -288,6 +297,8 @@ PB_HD void coop_role_passive(LD ld, ST st, XR xr, SYNC sync, const StepInputs &i
   for (int i = 0; i < 6; i++)
 #pragma unroll
     for (int j = 0; j <= i; j++) Ppp[pk(i, j)] = ld(L::OFF_P + pk(C::fullp(i), C::fullp(j)));
+  double ll = 0.0;
+  if constexpr (C::LL_IN_P) ll = ld(L::OFF_LL);
 
   ProcBlocks f;
   make_proc_blocks<NS>(x, q, in.dt, k, f);
@@ -346,24 +357,29 @@ PB_HD void coop_role_passive(LD ld, ST st, XR xr, SYNC sync, const StepInputs &i
       Wp[pi][2] = c2 - Wp[pi][0] * L20 - Wp[pi][1] * L21;
       xp[pi] += fma(Wp[pi][2], yd[2], fma(Wp[pi][1], yd[1], Wp[pi][0] * yd[0]));
     }
-    // downdate (c,p) and (b,p) panels with role C's rows of W
+    if constexpr (C::LL_IN_P) {
+      const double lli = xr(C::XCH_LLI);
+      if (in.upd) ll += lli;
+    }
+    // downdate (c,p) and (b,p) panels with role C's rows of W; every entry is stored the moment it is final, in the
+    // row order of the storage layout (Slots<NS>: omega panel, accel panel, P_pp)
 #pragma unroll
-    for (int sb = 0; sb < NSB; sb++)
+    for (int J = 0; J < 2; J++)
 #pragma unroll
-      for (int r = 0; r < 3; r++) {
-        double wd[3];
+      for (int sb = 0; sb < NSB; sb++)
 #pragma unroll
-        for (int kk = 0; kk < 3; kk++) wd[kk] = xr(9 + 3 * (3 * sb + r) + kk) * id[kk];
+        for (int r = 0; r < 3; r++) {
+          double wd[3];
 #pragma unroll
-        for (int J = 0; J < 2; J++)
+          for (int kk = 0; kk < 3; kk++) wd[kk] = xr(9 + 3 * (3 * sb + r) + kk) * id[kk];
 #pragma unroll
           for (int c = 0; c < 3; c++) {
             double acc = X[sb][J][3 * r + c];
 #pragma unroll
             for (int kk = 0; kk < 3; kk++) acc = fma(-wd[kk], Wp[3 * J + c][kk], acc);
-            X[sb][J][3 * r + c] = acc;
+            st(L::OFF_P + pk(C::fullc(3 * sb + r), C::fullp(3 * J + c)), acc);
           }
-      }
+        }
 #pragma unroll
     for (int i = 0; i < 6; i++) {
       double wd[3];
@@ -374,22 +390,24 @@ PB_HD void coop_role_passive(LD ld, ST st, XR xr, SYNC sync, const StepInputs &i
         double acc = Ppp[pk(i, j)];
 #pragma unroll
         for (int kk = 0; kk < 3; kk++) acc = fma(-wd[kk], Wp[j][kk], acc);
-        Ppp[pk(i, j)] = acc;
+        st(L::OFF_P + pk(C::fullp(i), C::fullp(j)), acc);
       }
     }
-  }
-#pragma unroll
-  for (int sb = 0; sb < NSB; sb++)
+  } else {
 #pragma unroll
     for (int J = 0; J < 2; J++)
 #pragma unroll
-      for (int r = 0; r < 3; r++)
+      for (int sb = 0; sb < NSB; sb++)
 #pragma unroll
-        for (int c = 0; c < 3; c++) st(L::OFF_P + pk(C::fullc(3 * sb + r), C::fullp(3 * J + c)), X[sb][J][3 * r + c]);
+        for (int r = 0; r < 3; r++)
 #pragma unroll
-  for (int i = 0; i < 6; i++)
+          for (int c = 0; c < 3; c++) st(L::OFF_P + pk(C::fullc(3 * sb + r), C::fullp(3 * J + c)), X[sb][J][3 * r + c]);
 #pragma unroll
-    for (int j = 0; j <= i; j++) st(L::OFF_P + pk(C::fullp(i), C::fullp(j)), Ppp[pk(i, j)]);
+    for (int i = 0; i < 6; i++)
+#pragma unroll
+      for (int j = 0; j <= i; j++) st(L::OFF_P + pk(C::fullp(i), C::fullp(j)), Ppp[pk(i, j)]);
+  }
+  if constexpr (C::LL_IN_P) st(L::OFF_LL, ll);
 #pragma unroll
   for (int i = 0; i < 6; i++) st(L::OFF_VEC + C::fullp(i), xp[i]);
 }

@@ -19,6 +19,8 @@
 #pragma once
 
 #include <cmath>
+#include <type_traits>
+#include <utility>
 
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
@@ -43,6 +45,103 @@ struct Lay {
 
 // packed index of P(i,j): lower triangle, row-major
 PB_HD constexpr int pk(int i, int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
+
+// row / column of a packed index
+PB_HD constexpr int pk_row(int p)
+{
+  int i = 0;
+  while ((i + 1) * (i + 2) / 2 <= p) i++;
+  return i;
+}
+PB_HD constexpr int pk_col(int p) { return p - pk_row(p) * (pk_row(p) + 1) / 2; }
+
+// compile-time loop: fn(std::integral_constant<int, 0>) ... fn(std::integral_constant<int, N-1>)
+template <class Fn, int... I>
+PB_HD void static_for_impl(Fn &&fn, std::integer_sequence<int, I...>)
+{
+  (fn(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class Fn>
+PB_HD void static_for(Fn &&fn)
+{
+  static_for_impl(fn, std::make_integer_sequence<int, N>{});
+}
+
+// The process model cuts the state into a dynamic core c = {v, chi, Delta} [+ b = {gyro bias, accel bias}] and a passive
+// part p = {omega, accel} (identity rows/cols of Ad, never a source; rbis.cpp:12-35, see rbis_coop.hpp).
+//   core sub index 0..NSC-1 -> full state index;  passive index 0..5 -> full state index (omega 0..2, accel 12..14)
+PB_HD constexpr int core_full(int s) { return s < 9 ? 3 + s : 15 + (s - 9); }
+PB_HD constexpr int passive_full(int p) { return p < 3 ? p : 12 + (p - 3); }
+
+// ------------------------------------------------------------------------------------------------------------
+// Storage layout in HBM.  The state array is cut into TILES of 64 filters; one tile holds the whole state
+// of its 64 filters as NROW rows of 64 x 16 bytes: row r = the component PAIR (slot 2r, slot 2r+1) of each filter, so a
+// lane moves 16 bytes per access (buffer_load/store_dwordx4; 1 KiB per wave instruction) and a wave's whole round trip
+// stays inside one contiguous 70 KiB (n=15) / 129 KiB (n=21) block.  "Slot" order is a permutation of the canonical
+// component order of Lay<NS>, chosen so that the two roles of the cooperative step kernel (rbis_coop.hpp) own disjoint
+// row ranges and store their rows in increasing order:
+//   core rows:    x[v chi Delta] | quat | (n=21: loglik) | P_(cb)(cb) packed by core sub index | (n=21: x[bg ba])
+//   passive rows: P_(cb),omega panel | P_(cb),accel panel | P_pp | (n=15: loglik) | x[omega accel] | (n=21: one pad)
+// Element (component c, filter b) lives at double index  (b/64)*NSLOT*64 + (slot(c)/2)*128 + (b%64)*2 + slot(c)%2.
+// ------------------------------------------------------------------------------------------------------------
+template <int NS>
+struct Slots {
+  using L = Lay<NS>;
+  static constexpr bool HB = (NS == 21);
+  static constexpr int NSC = HB ? 15 : 9;   // core sub-state
+  static constexpr int NSB = HB ? 5 : 3;    // its 3x3 block rows
+  static constexpr int NROW = (L::NC + 1) / 2, NSLOT = 2 * NROW;
+  static constexpr int TILE = 64;
+  static constexpr long TILE_DOUBLES = (long) NSLOT * TILE;
+  static constexpr unsigned TILE_BYTES = (unsigned) (NSLOT * TILE * 8);
+  struct Tab {
+    short slot_of[L::NC];
+    short comp_of[NSLOT];
+    int ncore;  // slots of the core rows (even)
+  };
+  static constexpr Tab make()
+  {
+    Tab t{};
+    int s = 0;
+    for (int i = 0; i < 9; i++) { t.slot_of[L::OFF_VEC + 3 + i] = (short) s; t.comp_of[s++] = (short) (L::OFF_VEC + 3 + i); }
+    for (int i = 0; i < 4; i++) { t.slot_of[L::OFF_QUAT + i] = (short) s; t.comp_of[s++] = (short) (L::OFF_QUAT + i); }
+    if (HB) { t.slot_of[L::OFF_LL] = (short) s; t.comp_of[s++] = (short) L::OFF_LL; }
+    for (int i = 0; i < NSC; i++)
+      for (int j = 0; j <= i; j++) {
+        const int c = L::OFF_P + pk(core_full(i), core_full(j));
+        t.slot_of[c] = (short) s; t.comp_of[s++] = (short) c;
+      }
+    if (HB)
+      for (int i = 0; i < 6; i++) { t.slot_of[L::OFF_VEC + 15 + i] = (short) s; t.comp_of[s++] = (short) (L::OFF_VEC + 15 + i); }
+    t.ncore = s;
+    for (int J = 0; J < 2; J++)
+      for (int i = 0; i < NSC; i++)
+        for (int cc = 0; cc < 3; cc++) {
+          const int c = L::OFF_P + pk(core_full(i), passive_full(3 * J + cc));
+          t.slot_of[c] = (short) s; t.comp_of[s++] = (short) c;
+        }
+    for (int i = 0; i < 6; i++)
+      for (int j = 0; j <= i; j++) {
+        const int c = L::OFF_P + pk(passive_full(i), passive_full(j));
+        t.slot_of[c] = (short) s; t.comp_of[s++] = (short) c;
+      }
+    if (!HB) { t.slot_of[L::OFF_LL] = (short) s; t.comp_of[s++] = (short) L::OFF_LL; }
+    for (int i = 0; i < 6; i++) { t.slot_of[L::OFF_VEC + passive_full(i)] = (short) s; t.comp_of[s++] = (short) (L::OFF_VEC + passive_full(i)); }
+    while (s < NSLOT) t.comp_of[s++] = -1;  // padding slot (n=21: 257 components in 129 rows)
+    return t;
+  }
+  static constexpr Tab T = make();
+  static_assert(T.ncore % 2 == 0, "the two roles must own whole rows");
+  static constexpr int ROW_SPLIT = T.ncore / 2;  // rows [0, ROW_SPLIT) = core role, [ROW_SPLIT, NROW) = passive role
+  PB_HD static constexpr int slot(int comp) { return T.slot_of[comp]; }
+  // double index of (component, filter) in a state array
+  PB_HD static long eidx(int comp, long b)
+  {
+    const int sl = T.slot_of[comp];
+    return (b >> 6) * TILE_DOUBLES + (long) (sl >> 1) * (2 * TILE) + (b & 63) * 2 + (sl & 1);
+  }
+  PB_HD static long eidx_slot(int sl, long b) { return (b >> 6) * TILE_DOUBLES + (long) (sl >> 1) * (2 * TILE) + (b & 63) * 2 + (sl & 1); }
+};
 
 // block rows of the RBIS vector (rbis.hpp:22-24 + eigen_utils::RigidBodyState)
 enum { BW = 0, BV = 1, BCHI = 2, BPOS = 3, BACC = 4, BBG = 5, BBA = 6 };
@@ -453,7 +552,7 @@ PB_HD void measurement_update(double (&x)[NS], double (&q)[4], double (&P)[NS * 
   ldlt<M>(S, d);
   // y = L^-1 r ; ll += -log det S - r^T S^-1 r  (rbis.cpp:142)
   double y[M], id[M];
-  double lli = 0.0;
+  double quad = 0.0, det = 1.0;
 #pragma unroll
   for (int kk = 0; kk < M; kk++) {
     double s = resid[kk];
@@ -461,9 +560,12 @@ PB_HD void measurement_update(double (&x)[NS], double (&q)[4], double (&P)[NS * 
     for (int j = 0; j < kk; j++) s -= S[pk(kk, j)] * y[j];
     y[kk] = active ? s : 0.0;
     id[kk] = active ? 1.0 / d[kk] : 0.0;
-    lli -= log(d[kk]) + s * s * id[kk];
+    det *= d[kk];
+    quad += s * s * id[kk];
   }
-  if (active) ll += lli;
+  // the reference takes ONE log of S.determinant() (rbis.cpp:142): log of the product of the pivots, not a sum of logs
+  // (the two differ when S is indefinite with an even number of negative pivots: finite there, NaN here)
+  if (active) ll += -log(det) - quad;
   // W = P[:, idx] L^-T  (row i: W_ik = P(i,idx_k) - sum_{j<k} W_ij L_kj)
   double W[NS][M];
 #pragma unroll

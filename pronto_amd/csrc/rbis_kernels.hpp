@@ -1,13 +1,13 @@
 // rbis_kernels.hpp -- gfx950 kernels of the batched RBIS EKF (included by pronto_batch.hip only).
 //
-// Data layout in HBM: st[NC][stride] doubles per context, component-major with the filter index fastest
-// (stride = batch rounded up to 64); components = vec[n] | quat[4] | loglik | P packed lower [n(n+1)/2].
-// One lane owns one filter, so every global access of a wave is one fully coalesced 512-byte row segment.
+// Data layout in HBM (Slots<NS> in rbis_device.hpp): the state array is cut into tiles of 64 filters; a tile is NROW rows
+// of 64 x 16 bytes, row r holding the component pair (slot 2r, slot 2r+1) of each of its filters.  One lane owns one
+// filter and moves 16 bytes per access, so every global access of a wave is one fully coalesced 1 KiB row and the whole
+// round trip of a wave stays inside one contiguous tile (70 KiB for n=15, 129 KiB for n=21).
 //
-// Addressing: one 128-bit buffer descriptor per array, the component offset in an SGPR (soffset) and ONE per-lane
-// 32-bit byte offset shared by every access: `buffer_load/store_dwordx2 v, v_off, s[rsrc], s_off offen`.  No per-access
-// 64-bit VGPR address is materialised (flat addressing cost ~700 instructions, ~60 VGPRs and 164 spilled registers in the
-// first version of k_step).
+// Addressing: ONE 128-bit buffer descriptor per tile (64-bit tile base in SGPRs, so a context is not limited to 4 GiB),
+// the row offset as an immediate / SGPR and ONE per-lane byte offset (lane * 16) shared by every access:
+// `buffer_load/store_dwordx4 v, v_off, s[rsrc], s_off offen`.  No per-access 64-bit VGPR address is materialised.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -17,14 +17,14 @@
 #include "rbis_coop.hpp"
 #include "rbis_device.hpp"
 
-// workgroup size of the hot kernel (one wave per SIMD either way; 64 = one wave per workgroup)
-#ifndef PB_STEP_BLOCK
+// workgroup size of the one-lane hot kernel = one tile
 #define PB_STEP_BLOCK 64
-#endif
 
 namespace pb {
 
 typedef unsigned v2u __attribute__((ext_vector_type(2)));
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+typedef double d2_t __attribute__((ext_vector_type(2)));
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
 
 // 128-bit buffer descriptor over [p, p+bytes): out-of-range lanes read 0 / drop their stores (hardware check)
@@ -32,7 +32,7 @@ __device__ __forceinline__ rsrc_t mkbuf(const void *p, unsigned bytes)
 {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, bytes, 0x00020000);
 }
-// buffer_load_dwordx2 v, v_off, s[rsrc], s_off offen : voff = per-lane byte offset, soff = uniform component offset
+// buffer_load_dwordx2 v, v_off, s[rsrc], s_off offen : voff = per-lane byte offset, soff = uniform offset
 // AUX = cache-policy bits of the instruction (gfx940+: 1 = sc0, 2 = nt, 16 = sc1)
 template <int AUX = 0>
 __device__ __forceinline__ double ldg(rsrc_t r, unsigned soff, unsigned voff)
@@ -44,19 +44,38 @@ __device__ __forceinline__ void stg(rsrc_t r, unsigned soff, unsigned voff, doub
 {
   __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, v), r, voff, soff, AUX);
 }
+// 16 bytes per lane
+template <int AUX = 0>
+__device__ __forceinline__ d2_t ldg2(rsrc_t r, unsigned soff, unsigned voff)
+{
+  return __builtin_bit_cast(d2_t, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, AUX));
+}
+// HAZARD (found on MI355X, ROCm 7.2): a buffer store of more than 64 bits reads its data VGPRs over several cycles; a VALU
+// instruction that overwrites one of them in the very next slot can reach the register file first, and the LAST four lanes
+// of every 16 then store the new value (observed: `buffer_store_dwordx4 v[130:133] ... s48 offen` directly followed by
+// `v_mul_f64 v[130:131], ...` corrupted lanes 12-15, 28-31, 44-47, 60-63 of that row, once per ~1000 launches).  LLVM's
+// hazard recognizer inserts the wait state only when soffset is NOT an SGPR (GCNHazardRecognizer::createsVALUHazard);
+// here soffset is always an SGPR, so the wait states are placed by hand: the volatile asm keeps its place behind the store
+// (side-effect order) and takes the data registers as INPUTS, so they stay untouched until the nop has issued.
+template <int AUX = 0>
+__device__ __forceinline__ void stg2(rsrc_t r, unsigned soff, unsigned voff, d2_t v)
+{
+  const v4u d = __builtin_bit_cast(v4u, v);
+  __builtin_amdgcn_raw_buffer_store_b128(d, r, voff, soff, AUX);
+  asm volatile("s_nop 1" ::"v"(d));
+}
 
 // Memory hint of the state round trip in the step kernels (template parameter MH), picked by the host from the state
-// size.  Measured with an in-place streaming copy of the same layout: while the state fits the 256 MB
-// memory-side cache, stores with sc1 (write through the XCD's L2) are 3-5 % faster; far beyond it, non-temporal loads
-// AND stores are ~5 % faster; in between neither helps.
+// size: while the state fits the 256 MB memory-side cache, stores with sc1 (write through the XCD's L2) are
+// a few % faster; far beyond it, non-temporal loads AND stores are; in between neither helps.
 enum { MH_DEFAULT = 0, MH_STORE_SC1 = 1, MH_STREAM_NT = 2 };
 template <int MH> struct MemHint {
   static constexpr int LA = (MH == MH_STREAM_NT) ? 2 : 0;
   static constexpr int SA = (MH == MH_STORE_SC1) ? 16 : (MH == MH_STREAM_NT) ? 2 : 0;
 };
 
-// Workgroups are dealt round-robin to the 8 XCDs.  With k.xcd_remap each XCD walks one contiguous filter range
-// (bijective for any grid size) instead of every 8th 512-byte segment of each component row (host picks).
+// Workgroups are dealt round-robin to the 8 XCDs.  With k.xcd_remap each XCD walks one contiguous range of tiles
+// (bijective for any grid size) instead of every 8th tile (host picks).
 __device__ __forceinline__ unsigned xcd_workgroup(const Consts &k)
 {
   unsigned wg = blockIdx.x;
@@ -67,36 +86,108 @@ __device__ __forceinline__ unsigned xcd_workgroup(const Consts &k)
   return wg;
 }
 
+// One lane's window on its tile: component-addressed reads and writes on top of 16-byte row accesses.
+//   ld(comp)      value of a canonical component (Lay<NS> numbering); the row is loaded on first use and cached
+//   need<R0,R1>() issue the loads of rows [R0, R1) now (before any store that could alias them)
+//   st(comp, v)   posterior value of a component; a row is stored the moment both its halves are known
+// Every index is a compile-time constant once the callers' loops are unrolled, so `loaded[]` / `have[]` fold away and
+// the caches are plain registers (cdna_hip_programming.md rule 20); the kernels' resource usage shows 0 bytes of scratch.
+template <int NS, int LA, int SA>
+struct TileIO {
+  using S = Slots<NS>;
+  rsrc_t rs, ro;
+  unsigned vo;  // lane * 16
+  d2_t cache[S::NROW];
+  bool loaded[S::NROW];
+  double outv[S::NSLOT];
+  bool have[S::NSLOT];
+  __device__ __forceinline__ TileIO(const double *st, double *sto, unsigned tile, unsigned lane)
+  {
+    rs = mkbuf(reinterpret_cast<const char *>(st) + (size_t) tile * S::TILE_BYTES, S::TILE_BYTES);
+    ro = mkbuf(reinterpret_cast<char *>(sto) + (size_t) tile * S::TILE_BYTES, S::TILE_BYTES);
+    vo = lane * 16u;
+#pragma unroll
+    for (int r = 0; r < S::NROW; r++) loaded[r] = false;
+#pragma unroll
+    for (int s = 0; s < S::NSLOT; s++) {
+      have[s] = S::T.comp_of[s] < 0;  // a padding slot is always "known" (0)
+      outv[s] = 0.0;
+    }
+  }
+  __device__ __forceinline__ void fetch(int r)
+  {
+    if (!loaded[r]) {
+      cache[r] = ldg2<LA>(rs, (unsigned) r * 1024u, vo);
+      loaded[r] = true;
+    }
+  }
+  template <int R0, int R1>
+  __device__ __forceinline__ void need()
+  {
+#pragma unroll
+    for (int r = R0; r < R1; r++) fetch(r);
+  }
+  __device__ __forceinline__ double ld(int comp)
+  {
+    const int s = S::T.slot_of[comp];
+    fetch(s >> 1);
+    return (s & 1) ? cache[s >> 1].y : cache[s >> 1].x;
+  }
+  __device__ __forceinline__ void st(int comp, double v)
+  {
+    const int s = S::T.slot_of[comp];
+    outv[s] = v;
+    have[s] = true;
+    if (have[s ^ 1]) {
+      const d2_t o = { outv[s & ~1], outv[s | 1] };
+      stg2<SA>(ro, (unsigned) (s >> 1) * 1024u, vo, o);
+    }
+  }
+  // one component at a RUN-TIME slot (wave-uniform): an 8-byte access into the row
+  __device__ __forceinline__ double ld_slot_rt(int slot) const
+  {
+    return ldg(rs, (unsigned) (slot >> 1) * 1024u + (unsigned) (slot & 1) * 8u, vo);
+  }
+};
+
+// slot of a component known only at run time (wave-uniform: a scalar table read)
+template <int NS>
+__device__ __forceinline__ int slot_rt(int comp)
+{
+  return Slots<NS>::T.slot_of[comp];
+}
+__device__ __forceinline__ int pk_rt(int i, int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
+
 struct IdxVel {
   static constexpr Idx<3> value = { { 3, 4, 5 } };
 };
 
 // RBISIMUProcessStep::updateFilter [+ RBISIndexedMeasurement::updateFilter with idx = {3,4,5}, diagonal R]
 // (rbis_update_interface.cpp:30-52, :54-95).  The BASELINE hot step: 2*(n+4+1+n(n+1)/2)*8 + 56 + 48 bytes/filter.
+// One lane per filter, one tile per 64-thread workgroup.
 template <int NS, bool UPDATE, int MH = MH_DEFAULT>
-__global__ __launch_bounds__(PB_STEP_BLOCK, 1) void k_step(const double *st, double *sto, long stride, int B,
+__global__ __launch_bounds__(PB_STEP_BLOCK, 1) void k_step(const double *st, double *sto, int B,
                                                 const double *__restrict__ imu, const double *__restrict__ lo,
                                                 const uint8_t *__restrict__ mask, double qg, double qa, double qbg,
                                                 double qba, Consts k)
 {
   using L = Lay<NS>;
-  constexpr int LA = MemHint<MH>::LA, SA = MemHint<MH>::SA;
-  const unsigned b = xcd_workgroup(k) * blockDim.x + threadIdx.x;
+  const unsigned tile = xcd_workgroup(k);
+  const unsigned b = tile * 64u + threadIdx.x;
   if (b >= (unsigned) B) return;
-  const unsigned bo = b * 8u;
-  const unsigned s8 = (unsigned) stride * 8u, B8 = (unsigned) B * 8u;  // host guarantees NC*stride*8 < 2^32
-  const rsrc_t rs = mkbuf(st, (unsigned) L::NC * s8);
-  const rsrc_t ro = mkbuf(sto, (unsigned) L::NC * s8);  // posterior: the same array (in place) or a checkpoint slot
+  const unsigned bo = b * 8u, B8 = (unsigned) B * 8u;
+  TileIO<NS, MemHint<MH>::LA, MemHint<MH>::SA> io(st, sto, tile, threadIdx.x);  // posterior: in place or a checkpoint slot
   const rsrc_t ri = mkbuf(imu, 7u * B8);
   const rsrc_t rl = mkbuf(lo, UPDATE ? 6u * B8 : 0u);
+  io.template need<0, Slots<NS>::NROW>();
   double x[NS], q[4], ll, P[L::NP];
 #pragma unroll
-  for (int i = 0; i < NS; i++) x[i] = ldg<LA>(rs, (L::OFF_VEC + i) * s8, bo);
+  for (int i = 0; i < NS; i++) x[i] = io.ld(L::OFF_VEC + i);
 #pragma unroll
-  for (int i = 0; i < 4; i++) q[i] = ldg<LA>(rs, (L::OFF_QUAT + i) * s8, bo);
-  ll = ldg<LA>(rs, L::OFF_LL * s8, bo);
+  for (int i = 0; i < 4; i++) q[i] = io.ld(L::OFF_QUAT + i);
+  ll = io.ld(L::OFF_LL);
 #pragma unroll
-  for (int i = 0; i < L::NP; i++) P[i] = ldg<LA>(rs, (L::OFF_P + i) * s8, bo);
+  for (int i = 0; i < L::NP; i++) P[i] = io.ld(L::OFF_P + i);
   double gyro[3], accel[3];
 #pragma unroll
   for (int i = 0; i < 3; i++) {
@@ -130,17 +221,16 @@ __global__ __launch_bounds__(PB_STEP_BLOCK, 1) void k_step(const double *st, dou
 #pragma unroll
       for (int j = 0; j <= i; j++)
         S[pk(i, j)] = P[pk(3 + i, 3 + j)] + (i == j ? (upd ? rd[i] : 1.0) : 0.0);  // rbis.cpp:134-135
-    measurement_update<NS, 3>(x, q, P, ll, resid, S, IdxVel{}, k,
-                              [ro, s8, bo](int pi, double v) { stg<SA>(ro, (L::OFF_P + pi) * s8, bo, v); }, upd);
+    measurement_update<NS, 3>(x, q, P, ll, resid, S, IdxVel{}, k, [&io](int pi, double v) { io.st(L::OFF_P + pi, v); }, upd);
   } else {
 #pragma unroll
-    for (int i = 0; i < L::NP; i++) stg<SA>(ro, (L::OFF_P + i) * s8, bo, P[i]);
+    for (int i = 0; i < L::NP; i++) io.st(L::OFF_P + i, P[i]);
   }
 #pragma unroll
-  for (int i = 0; i < NS; i++) stg<SA>(ro, (L::OFF_VEC + i) * s8, bo, x[i]);
+  for (int i = 0; i < NS; i++) io.st(L::OFF_VEC + i, x[i]);
 #pragma unroll
-  for (int i = 0; i < 4; i++) stg<SA>(ro, (L::OFF_QUAT + i) * s8, bo, q[i]);
-  stg<SA>(ro, L::OFF_LL * s8, bo, ll);
+  for (int i = 0; i < 4; i++) io.st(L::OFF_QUAT + i, q[i]);
+  io.st(L::OFF_LL, ll);
 }
 
 // Time-fused replay: T consecutive predict+update steps per launch with the state and P resident in registers; only the
@@ -150,7 +240,7 @@ __global__ __launch_bounds__(PB_STEP_BLOCK, 1) void k_step(const double *st, dou
 // bound moves from HBM to fp64 VALU issue; bench.py reports it separately (never as the headline value).
 // Inputs of step t+1 are prefetched while step t computes (one wave per SIMD: nothing else hides their latency).
 template <int NS>
-__global__ __launch_bounds__(64, 1) void k_replay_fused(double *__restrict__ st, long stride, int B, int T,
+__global__ __launch_bounds__(64, 1) void k_replay_fused(double *__restrict__ st, int B, int T,
                                                         const double *__restrict__ imu, const double *__restrict__ lo,
                                                         const uint8_t *__restrict__ mask, double qg, double qa, double qbg,
                                                         double qba, Consts k)
@@ -158,17 +248,17 @@ __global__ __launch_bounds__(64, 1) void k_replay_fused(double *__restrict__ st,
   using L = Lay<NS>;
   const unsigned b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= (unsigned) B) return;
-  const unsigned bo = b * 8u;
-  const unsigned s8 = (unsigned) stride * 8u, B8 = (unsigned) B * 8u;
-  const rsrc_t rs = mkbuf(st, (unsigned) L::NC * s8);
+  const unsigned bo = b * 8u, B8 = (unsigned) B * 8u;
+  TileIO<NS, 0, 0> io(st, st, blockIdx.x, threadIdx.x);
+  io.template need<0, Slots<NS>::NROW>();
   double x[NS], q[4], ll, P[L::NP];
 #pragma unroll
-  for (int i = 0; i < NS; i++) x[i] = ldg(rs, (L::OFF_VEC + i) * s8, bo);
+  for (int i = 0; i < NS; i++) x[i] = io.ld(L::OFF_VEC + i);
 #pragma unroll
-  for (int i = 0; i < 4; i++) q[i] = ldg(rs, (L::OFF_QUAT + i) * s8, bo);
-  ll = ldg(rs, L::OFF_LL * s8, bo);
+  for (int i = 0; i < 4; i++) q[i] = io.ld(L::OFF_QUAT + i);
+  ll = io.ld(L::OFF_LL);
 #pragma unroll
-  for (int i = 0; i < L::NP; i++) P[i] = ldg(rs, (L::OFF_P + i) * s8, bo);
+  for (int i = 0; i < L::NP; i++) P[i] = io.ld(L::OFF_P + i);
   if (k.qblk != nullptr) {
     const rsrc_t rq = mkbuf(k.qblk, 4u * B8);
     qg = ldg(rq, 0u, bo); qa = ldg(rq, B8, bo); qbg = ldg(rq, 2u * B8, bo); qba = ldg(rq, 3u * B8, bo);
@@ -209,12 +299,12 @@ __global__ __launch_bounds__(64, 1) void k_replay_fused(double *__restrict__ st,
 #endif
   }
 #pragma unroll
-  for (int i = 0; i < L::NP; i++) stg(rs, (L::OFF_P + i) * s8, bo, P[i]);
+  for (int i = 0; i < L::NP; i++) io.st(L::OFF_P + i, P[i]);
 #pragma unroll
-  for (int i = 0; i < NS; i++) stg(rs, (L::OFF_VEC + i) * s8, bo, x[i]);
+  for (int i = 0; i < NS; i++) io.st(L::OFF_VEC + i, x[i]);
 #pragma unroll
-  for (int i = 0; i < 4; i++) stg(rs, (L::OFF_QUAT + i) * s8, bo, q[i]);
-  stg(rs, L::OFF_LL * s8, bo, ll);
+  for (int i = 0; i < 4; i++) io.st(L::OFF_QUAT + i, q[i]);
+  io.st(L::OFF_LL, ll);
 }
 
 template <int M>
@@ -226,81 +316,107 @@ struct DiagArg {
   double v[M];
 };
 
-// rows [R0, R1) of the packed covariance: issue ALL their loads, then downdate and store them.  (Interleaving a load
-// and a store per entry serialises on the load latency: the compiler may not hoist a load above a possibly aliasing
-// store; that version of k_update ran at 0.33-0.45 of the HBM roofline.)
-template <int NS, int M, int R0, int R1, int MH>
-__device__ __forceinline__ void downdate_rows(rsrc_t rs, rsrc_t ro, unsigned s8, unsigned bo, const double (&W)[NS][M],
-                                              const double (&id)[M])
+// Storage rows [R0, R1): issue ALL their loads, then downdate the covariance entries in them and store the rows.
+// (Interleaving a load and a store per entry serialises on the load latency: the compiler may not hoist a load above a
+// possibly aliasing store; that version of k_update ran at 0.33-0.45 of the HBM roofline.)  Slots that hold x / quat /
+// loglik are skipped here: their rows complete when the kernel stores the updated state at the end.
+// W here is W |D|^-1/2 (scaled once by the caller) and sg[k] the sign bit of pivot k (0x80000000 or 0):
+// P -= sum_k sign(d_k) (W |D|^-1/2)_ik (W |D|^-1/2)_jk needs ONE array and no per-entry scaling (with W D^-1 formed per
+// entry, common-subexpression elimination kept all NS x M products alive across the chunks: 250+ registers of spills).
+// S is SPD in a healthy filter, but the reference's LDLT takes any symmetric S, so the sign is carried, not assumed.
+__device__ __forceinline__ double flip_sign(double x, unsigned sgbit)
+{
+  return __hiloint2double(__double2hiint(x) ^ (int) sgbit, __double2loint(x));
+}
+// For the largest W (n = 21, m >= 5: 210+ registers) even the flipped operands, which the compiler shares between entries,
+// do not fit: there W is W D^-1 and the term is (W D^-1)_ik (W D^-1)_jk d_k -- two multiplies, nothing shareable.
+template <int NS, int M>
+struct UpdateForm {
+  static constexpr bool SCALED_BY_INVERSE = (NS * M > 90);
+};
+template <int NS, int M, int R0, int R1, class IO>
+__device__ __forceinline__ void downdate_rows(IO &io, const double (&W)[NS][M], const unsigned (&sg)[M], const double (&d)[M])
 {
   using L = Lay<NS>;
-  constexpr int CNT = (R1 * (R1 + 1) - R0 * (R0 + 1)) / 2;
-  constexpr int P0 = R0 * (R0 + 1) / 2;
-  double buf[CNT];
+  using S = Slots<NS>;
+  io.template need<R0, R1>();
+  static_for<2 * (R1 - R0)>([&](auto I) {
+    constexpr int c = S::T.comp_of[2 * R0 + decltype(I)::value];
+    if constexpr (c >= L::OFF_P) {
+      constexpr int i = pk_row(c - L::OFF_P), j = pk_col(c - L::OFF_P);
+      double acc = io.ld(c);
 #pragma unroll
-  for (int e = 0; e < CNT; e++) buf[e] = ldg<MemHint<MH>::LA>(rs, (L::OFF_P + P0 + e) * s8, bo);
-#pragma unroll
-  for (int i = R0; i < R1; i++) {
-    double wd[M];
-#pragma unroll
-    for (int kk = 0; kk < M; kk++) wd[kk] = W[i][kk] * id[kk];
-#pragma unroll
-    for (int j = 0; j <= i; j++) {
-      double acc = buf[pk(i, j) - P0];
-#pragma unroll
-      for (int kk = 0; kk < M; kk++) acc = fma(-wd[kk], W[j][kk], acc);
-      stg<MemHint<MH>::SA>(ro, (L::OFF_P + pk(i, j)) * s8, bo, acc);
+      for (int kk = 0; kk < M; kk++) {
+        if constexpr (UpdateForm<NS, M>::SCALED_BY_INVERSE) acc = fma(-(W[i][kk] * W[j][kk]), d[kk], acc);
+        else acc = fma(-W[i][kk], flip_sign(W[j][kk], sg[kk]), acc);
+      }
+      io.st(c, acc);
     }
-  }
+  });
 }
 
+// number of equal row chunks the covariance streams through in k_update (register budget: chunk + W + temporaries)
+#ifndef PB_UPD_CHUNKS
+#define PB_UPD_CHUNKS(NS, M) ((NS) == 15 ? ((M) <= 4 ? 3 : 4) : ((M) == 1 ? 3 : (M) == 2 ? 4 : (M) <= 4 ? 5 : 7))
+#endif
+// waves per SIMD the register allocation of k_update is held to
+#ifndef PB_UPD_WAVES
+#define PB_UPD_WAVES(NS, M) ((((NS) == 15 && (M) <= 3) || ((NS) == 21 && (M) <= 2)) ? 2 : 1)
+#endif
+template <int NS, int M>
+struct UpdateChunks {
+  static constexpr int N = PB_UPD_CHUNKS(NS, M);
+};
+
 // Generic RBISIndexedMeasurement / RBISIndexedPlusOrientationMeasurement::updateFilter with a RUNTIME index list
-// (rbis_update_interface.cpp:54-107).  The m gathered columns P[:, idx] (wave-uniform component addresses) and x
-// live in registers; P itself is streamed through once in row chunks (load a chunk, rank-m downdate, store it).
+// (rbis_update_interface.cpp:54-107).  The m gathered columns P[:, idx] (wave-uniform slot addresses, 8-byte reads) and
+// x live in registers; P itself is streamed through once in chunks of storage rows (load a chunk, rank-m downdate, store).
 // The skip mask is predicated like in k_step: every lane stores whole rows with D^-1 = 0 for skipped filters.
 // MH: the gathered columns are read with the default policy (they are read again by the row stream), the row stream's
 // loads and every store carry the hint.
 template <int NS, int M, bool ORIENT, int MH = MH_DEFAULT>
-__global__ __launch_bounds__(64, (NS == 15 && M <= 3) ? 2 : 1) void k_update(const double *st, double *sto, long stride, int B, IdxArg<M> idx,
+__global__ __launch_bounds__(64, PB_UPD_WAVES(NS, M)) void k_update(const double *st, double *sto, int B, IdxArg<M> idx,
                                                   const double *__restrict__ z, const double *__restrict__ R,
                                                   int rkind, DiagArg<M> rb, const double *__restrict__ qmeas,
                                                   const uint8_t *__restrict__ mask, Consts k)
 {
   using L = Lay<NS>;
-  const unsigned b = xcd_workgroup(k) * blockDim.x + threadIdx.x;
+  using S = Slots<NS>;
+  const unsigned tile = xcd_workgroup(k);
+  const unsigned b = tile * 64u + threadIdx.x;
   if (b >= (unsigned) B) return;
   const bool upd = (mask == nullptr) || (mask[b] != 0);  // 0 = handler returned NULL for this filter
-  const unsigned bo = b * 8u;
-  const unsigned s8 = (unsigned) stride * 8u, B8 = (unsigned) B * 8u;
-  const rsrc_t rs = mkbuf(st, (unsigned) L::NC * s8);
-  const rsrc_t ro = mkbuf(sto, (unsigned) L::NC * s8);
+  const unsigned bo = b * 8u, B8 = (unsigned) B * 8u;
+  TileIO<NS, MemHint<MH>::LA, MemHint<MH>::SA> io(st, sto, tile, threadIdx.x);
   const rsrc_t rz = mkbuf(z, (unsigned) M * B8);
   const rsrc_t rR = mkbuf(R, rkind == PB_R_DIAG ? (unsigned) M * B8 : (rkind == PB_R_FULL ? (unsigned) (M * M) * B8 : 0u));
   const rsrc_t rq = mkbuf(qmeas, ORIENT ? 4u * B8 : 0u);
-  double x[NS], q[4];
-#pragma unroll
-  for (int i = 0; i < NS; i++) x[i] = ldg(rs, (L::OFF_VEC + i) * s8, bo);
-#pragma unroll
-  for (int i = 0; i < 4; i++) q[i] = ldg(rs, (L::OFF_QUAT + i) * s8, bo);
-  double ll = ldg(rs, L::OFF_LL * s8, bo);
   // gather the measured columns first: all these loads are in flight together
   double W[NS][M];
 #pragma unroll
   for (int i = 0; i < NS; i++)
 #pragma unroll
-    for (int kk = 0; kk < M; kk++) W[i][kk] = ldg(rs, (L::OFF_P + pk(i, idx.v[kk])) * s8, bo);
+    for (int kk = 0; kk < M; kk++) W[i][kk] = io.ld_slot_rt(slot_rt<NS>(L::OFF_P + pk_rt(i, idx.v[kk])));
+  // the rows holding x / quat / loglik (cached by the tile window; their covariance halves are used by the stream) are
+  // requested up front unless W leaves no room for them (n = 21, m = 6: W alone is 252 registers)
+  if constexpr (NS * M <= 110) {
+#pragma unroll
+    for (int i = 0; i < NS; i++) (void) io.ld(L::OFF_VEC + i);
+  }
+  double ll = io.ld(L::OFF_LL);
 
   // residual (rbis.cpp:169-172 / :199-208)
   double resid[M];
   double dq[3] = { 0, 0, 0 };
   if constexpr (ORIENT) {
     const double qm[4] = { ldg(rq, 0u, bo), ldg(rq, B8, bo), ldg(rq, 2u * B8, bo), ldg(rq, 3u * B8, bo) };
-    subtract_quats(qm, q, dq);
+    const double qc[4] = { io.ld(L::OFF_QUAT), io.ld(L::OFF_QUAT + 1), io.ld(L::OFF_QUAT + 2), io.ld(L::OFF_QUAT + 3) };
+    subtract_quats(qm, qc, dq);
   }
 #pragma unroll
   for (int kk = 0; kk < M; kk++) {
     const int ii = idx.v[kk];
-    const double xi = ldg(rs, (L::OFF_VEC + ii) * s8, bo);  // runtime index: re-read instead of x[ii]
+    const double xi = io.ld_slot_rt(slot_rt<NS>(L::OFF_VEC + ii));  // runtime index: re-read instead of x[ii]
     double r = ldg(rz, kk * B8, bo) - xi;
     if constexpr (ORIENT) {
       if (ii >= 6 && ii <= 8) r = (ii == 6) ? dq[0] : (ii == 7 ? dq[1] : dq[2]);
@@ -308,7 +424,7 @@ __global__ __launch_bounds__(64, (NS == 15 && M <= 3) ? 2 : 1) void k_update(con
     resid[kk] = upd ? r : 0.0;
   }
   // S = R + P[idx, idx]
-  double S[M * (M + 1) / 2], d[M];
+  double Sm[M * (M + 1) / 2], d[M];
 #pragma unroll
   for (int i = 0; i < M; i++)
 #pragma unroll
@@ -318,21 +434,22 @@ __global__ __launch_bounds__(64, (NS == 15 && M <= 3) ? 2 : 1) void k_update(con
       else if (rkind == PB_R_DIAG) r = (i == j) ? ldg(rR, i * B8, bo) : 0.0;
       else r = ldg(rR, (j * M + i) * B8, bo);
       if (!upd) r = (i == j) ? 1.0 : 0.0;  // benign R for skipped filters (their R block may hold anything)
-      S[pk(i, j)] = r + ldg(rs, (L::OFF_P + pk(idx.v[i], idx.v[j])) * s8, bo);
+      Sm[pk(i, j)] = r + io.ld_slot_rt(slot_rt<NS>(L::OFF_P + pk_rt(idx.v[i], idx.v[j])));
     }
-  ldlt<M>(S, d);
-  double y[M], id[M], yd[M], lli = 0.0;
+  ldlt<M>(Sm, d);
+  double y[M], id[M], yd[M], quad = 0.0, det = 1.0;
 #pragma unroll
   for (int kk = 0; kk < M; kk++) {
     double s = resid[kk];
 #pragma unroll
-    for (int j = 0; j < kk; j++) s -= S[pk(kk, j)] * y[j];
+    for (int j = 0; j < kk; j++) s -= Sm[pk(kk, j)] * y[j];
     y[kk] = s;
     id[kk] = upd ? 1.0 / d[kk] : 0.0;
     yd[kk] = s * id[kk];
-    lli -= log(d[kk]) + s * s * id[kk];
+    det *= d[kk];
+    quad += s * s * id[kk];
   }
-  if (upd) ll += lli;
+  if (upd) ll += -log(det) - quad;  // -log(S.determinant()) - r^T S^-1 r (rbis.cpp:142)
   // W = P[:, idx] L^-T  (in place on the gathered columns)
 #pragma unroll
   for (int i = 0; i < NS; i++) {
@@ -340,90 +457,111 @@ __global__ __launch_bounds__(64, (NS == 15 && M <= 3) ? 2 : 1) void k_update(con
     for (int kk = 0; kk < M; kk++) {
       double s = W[i][kk];
 #pragma unroll
-      for (int j = 0; j < kk; j++) s -= W[i][j] * S[pk(kk, j)];
+      for (int j = 0; j < kk; j++) s -= W[i][j] * Sm[pk(kk, j)];
       W[i][kk] = s;
     }
   }
-  double dx[NS];
-#pragma unroll
-  for (int i = 0; i < NS; i++) {
+  // dx = K r = W D^-1 y, applied as rbisApplyDelta does (RigidBodyState::addState, see add_delta): the chi part of dx is
+  // folded into its own quaternion first, vec += dx, then chi of the sum is folded into quat, then quat *= dq.  Written
+  // out here so that no dx[NS] array is alive next to W (n = 21, m = 6: W alone is 252 registers).
+  // The state rows are final before the covariance streams through: x and quat are dead from then on (a row that pairs
+  // a state entry with a covariance entry is stored when the stream reaches it).
+  auto dxi = [&](int i) {
     double s = 0.0;
 #pragma unroll
     for (int kk = 0; kk < M; kk++) s = (kk == 0) ? W[i][0] * yd[0] : fma(W[i][kk], yd[kk], s);
-    dx[i] = s;
+    return s;
+  };
+  {
+    double dchi[3] = { dxi(6), dxi(7), dxi(8) };
+    double dq4[4] = { 1.0, 0.0, 0.0, 0.0 };
+    fold_chi(dchi, dq4, k.chi_tol);
+    double xn[NS];
+#pragma unroll
+    for (int i = 0; i < NS; i++) xn[i] = io.ld(L::OFF_VEC + i) + ((i >= 6 && i <= 8) ? dchi[i - 6] : dxi(i));
+    double q[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) q[i] = io.ld(L::OFF_QUAT + i);
+    double qn[4] = { q[0], q[1], q[2], q[3] };
+    double chi[3] = { xn[6], xn[7], xn[8] };
+    fold_chi(chi, qn, k.chi_tol);
+    xn[6] = chi[0]; xn[7] = chi[1]; xn[8] = chi[2];
+    double o[4];
+    quat_mul(qn, dq4, o);
+#pragma unroll
+    for (int i = 0; i < NS; i++) io.st(L::OFF_VEC + i, upd ? xn[i] : io.ld(L::OFF_VEC + i));
+#pragma unroll
+    for (int i = 0; i < 4; i++) io.st(L::OFF_QUAT + i, upd ? o[i] : q[i]);
+    io.st(L::OFF_LL, ll);
+  }
+  // W <- W |D|^-1/2 (or W D^-1, see UpdateForm; 0 for skipped filters) + the pivots' sign bits, then the rank-m downdate
+  // streams through the covariance
+  unsigned sg[M];
+  {
+    double sq[M];
+#pragma unroll
+    for (int kk = 0; kk < M; kk++) {
+      sq[kk] = UpdateForm<NS, M>::SCALED_BY_INVERSE ? id[kk] : sqrt(fabs(id[kk]));
+      sg[kk] = (unsigned) __double2hiint(id[kk]) & 0x80000000u;
+    }
+#pragma unroll
+    for (int i = 0; i < NS; i++)
+#pragma unroll
+      for (int kk = 0; kk < M; kk++) W[i][kk] *= sq[kk];
   }
   // chunk sizes keep (chunk + W) inside the register file: W is NS x M doubles
-  if constexpr (NS == 15 && M <= 3) {
-    // small W: three chunks fit 256 registers -> two waves per SIMD (m = 3: 25.7 -> 23.2 us at 64k filters; for m = 4 the
-    // same split measured 7 % slower than one chunk at one wave per SIMD)
-    downdate_rows<NS, M, 0, 8, MH>(rs, ro, s8, bo, W, id);
-    downdate_rows<NS, M, 8, 12, MH>(rs, ro, s8, bo, W, id);
-    downdate_rows<NS, M, 12, 15, MH>(rs, ro, s8, bo, W, id);
-  } else if constexpr (NS == 15 && M == 4) {
-    downdate_rows<NS, M, 0, 15, MH>(rs, ro, s8, bo, W, id);
-  } else if constexpr (NS == 15) {
-    downdate_rows<NS, M, 0, 11, MH>(rs, ro, s8, bo, W, id);
-    downdate_rows<NS, M, 11, 15, MH>(rs, ro, s8, bo, W, id);
-  } else if constexpr (M <= 4) {
-    downdate_rows<NS, M, 0, 12, MH>(rs, ro, s8, bo, W, id);
-    downdate_rows<NS, M, 12, 17, MH>(rs, ro, s8, bo, W, id);
-    downdate_rows<NS, M, 17, 21, MH>(rs, ro, s8, bo, W, id);
-  } else {
-    downdate_rows<NS, M, 0, 9, MH>(rs, ro, s8, bo, W, id);
-    downdate_rows<NS, M, 9, 13, MH>(rs, ro, s8, bo, W, id);
-    downdate_rows<NS, M, 13, 16, MH>(rs, ro, s8, bo, W, id);
-    downdate_rows<NS, M, 16, 19, MH>(rs, ro, s8, bo, W, id);
-    downdate_rows<NS, M, 19, 21, MH>(rs, ro, s8, bo, W, id);
-  }
-  if (upd) add_delta<NS>(x, q, dx, k.chi_tol);
-  constexpr int SA = MemHint<MH>::SA;
-#pragma unroll
-  for (int i = 0; i < NS; i++) stg<SA>(ro, (L::OFF_VEC + i) * s8, bo, x[i]);
-#pragma unroll
-  for (int i = 0; i < 4; i++) stg<SA>(ro, (L::OFF_QUAT + i) * s8, bo, q[i]);
-  stg<SA>(ro, L::OFF_LL * s8, bo, ll);
+  constexpr int NR = S::NROW;
+  using CH = UpdateChunks<NS, M>;
+  static_for<CH::N>([&](auto I) {
+    constexpr int i = decltype(I)::value;
+    downdate_rows<NS, M, (NR * i) / CH::N, (NR * (i + 1)) / CH::N>(io, W, sg, d);
+  });
 }
 
 // RBISResetUpdate::updateFilter, per-filter inputs: vec [n][B], quat [4][B], cov [n*n][B] column-major
 template <int NS>
-__global__ void k_reset(double *__restrict__ st, long stride, int B, const double *__restrict__ vec,
+__global__ void k_reset(double *__restrict__ st, int B, const double *__restrict__ vec,
                         const double *__restrict__ quat, const double *__restrict__ cov)
 {
   using L = Lay<NS>;
+  using S = Slots<NS>;
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
-  for (int i = 0; i < NS; i++) st[(long) (L::OFF_VEC + i) * stride + b] = vec[(long) i * B + b];
-  for (int i = 0; i < 4; i++) st[(long) (L::OFF_QUAT + i) * stride + b] = quat[(long) i * B + b];
-  st[(long) L::OFF_LL * stride + b] = 0.0;
+  for (int i = 0; i < NS; i++) st[S::eidx(L::OFF_VEC + i, b)] = vec[(long) i * B + b];
+  for (int i = 0; i < 4; i++) st[S::eidx(L::OFF_QUAT + i, b)] = quat[(long) i * B + b];
+  st[S::eidx(L::OFF_LL, b)] = 0.0;
   for (int i = 0; i < NS; i++)
-    for (int j = 0; j <= i; j++) st[(long) (L::OFF_P + pk(i, j)) * stride + b] = cov[(long) (j * NS + i) * B + b];
+    for (int j = 0; j <= i; j++) st[S::eidx(L::OFF_P + pk(i, j), b)] = cov[(long) (j * NS + i) * B + b];
 }
 
-// broadcast reset: comp [NC] already packed on the host
-__global__ void k_reset_bcast(double *__restrict__ st, long stride, int B, int NC, const double *__restrict__ comp)
+// broadcast reset: comp [NC] in canonical component order, packed on the host
+template <int NS>
+__global__ void k_reset_bcast(double *__restrict__ st, int B, const double *__restrict__ comp)
 {
+  using S = Slots<NS>;
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
-  for (int c = 0; c < NC; c++) st[(long) c * stride + b] = comp[c];
+  for (int c = 0; c < Lay<NS>::NC; c++) st[S::eidx(c, b)] = comp[c];
 }
 
 template <int NS>
-__global__ void k_get_head(const double *__restrict__ st, long stride, int first, int count, double *vec_out,
+__global__ void k_get_head(const double *__restrict__ st, int first, int count, double *vec_out,
                            double *quat_out, double *cov_out, double *ll_out)
 {
   using L = Lay<NS>;
+  using S = Slots<NS>;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= count) return;
   const int b = first + t;
   if (vec_out)
-    for (int i = 0; i < NS; i++) vec_out[(long) i * count + t] = st[(long) (L::OFF_VEC + i) * stride + b];
+    for (int i = 0; i < NS; i++) vec_out[(long) i * count + t] = st[S::eidx(L::OFF_VEC + i, b)];
   if (quat_out)
-    for (int i = 0; i < 4; i++) quat_out[(long) i * count + t] = st[(long) (L::OFF_QUAT + i) * stride + b];
-  if (ll_out) ll_out[t] = st[(long) L::OFF_LL * stride + b];
+    for (int i = 0; i < 4; i++) quat_out[(long) i * count + t] = st[S::eidx(L::OFF_QUAT + i, b)];
+  if (ll_out) ll_out[t] = st[S::eidx(L::OFF_LL, b)];
   if (cov_out)
     for (int c = 0; c < NS; c++)
       for (int r = 0; r < NS; r++)
-        cov_out[(long) (c * NS + r) * count + t] = st[(long) (L::OFF_P + pk(r, c)) * stride + b];
+        cov_out[(long) (c * NS + r) * count + t] = st[S::eidx(L::OFF_P + pk(r, c), b)];
 }
 
 // (position, quat) of the head posterior -> snapshot slot [7][stride]
@@ -431,14 +569,15 @@ template <int NS>
 __global__ void k_snapshot(const double *__restrict__ st, long stride, int B, double *__restrict__ snap)
 {
   using L = Lay<NS>;
+  using S = Slots<NS>;
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
-  for (int i = 0; i < 3; i++) snap[(long) i * stride + b] = st[(long) (L::OFF_VEC + 9 + i) * stride + b];
-  for (int i = 0; i < 4; i++) snap[(long) (3 + i) * stride + b] = st[(long) (L::OFF_QUAT + i) * stride + b];
+  for (int i = 0; i < 3; i++) snap[(long) i * stride + b] = st[S::eidx(L::OFF_VEC + 9 + i, b)];
+  for (int i = 0; i < 4; i++) snap[(long) (3 + i) * stride + b] = st[S::eidx(L::OFF_QUAT + i, b)];
 }
 
 // T1 = T0 * (t, q)   (rbis_fovis_update.cpp:219-223)
-__global__ void k_compose(const double *__restrict__ snap, long stride, int B, const double *__restrict__ t,
+static __global__ void k_compose(const double *__restrict__ snap, long stride, int B, const double *__restrict__ t,
                           const double *__restrict__ q, double *__restrict__ z_out, double *__restrict__ q_out)
 {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -456,22 +595,23 @@ __global__ void k_compose(const double *__restrict__ snap, long stride, int B, c
 }
 
 template <int NS>
-__global__ void k_summary(const double *__restrict__ st, long stride, int B, double *__restrict__ out)
+__global__ void k_summary(const double *__restrict__ st, int B, double *__restrict__ out)
 {
   using L = Lay<NS>;
+  using S = Slots<NS>;
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   double s_ll = 0, s_abs = 0, qdev = 0, nonfin = 0;
   if (b < B) {
-    s_ll = st[(long) L::OFF_LL * stride + b];
+    s_ll = st[S::eidx(L::OFF_LL, b)];
     double qn = 0;
     for (int i = 0; i < NS + 4; i++) {
-      const double v = st[(long) i * stride + b];
+      const double v = st[S::eidx(i, b)];
       s_abs += fabs(v);
       if (!isfinite(v)) nonfin += 1;
       if (i >= NS) qn += v * v;
     }
     for (int i = 0; i < L::NP; i++)
-      if (!isfinite(st[(long) (L::OFF_P + i) * stride + b])) nonfin += 1;
+      if (!isfinite(st[S::eidx(L::OFF_P + i, b)])) nonfin += 1;
     if (!isfinite(s_ll)) nonfin += 1;
     qdev = fabs(qn - 1.0);
   }
@@ -489,27 +629,25 @@ __global__ void k_summary(const double *__restrict__ st, long stride, int B, dou
 }
 
 // Two-wave cooperative step (rbis_coop.hpp): 128-thread workgroups, wave 0 = role C (dynamic core sub-matrix, state,
-// quaternion), wave 1 = role P (passive omega/accel panels) for the SAME 64 filters; one LDS hand-off + one barrier.
-// This is the 21-state hot kernel (231 packed entries do not fit one lane) and an alternative mapping for n = 15.
-// No lane returns before the barrier: lanes past the batch end work on the zero-initialised padding columns of the
-// state array (stride is the batch rounded up to 64) and on bounds-checked (zero) inputs.
+// quaternion), wave 1 = role P (passive omega/accel panels) for the SAME 64 filters = one tile; each role owns a
+// contiguous range of the tile's rows (Slots<NS>::ROW_SPLIT); one LDS hand-off + one barrier.
+// This is the 21-state hot kernel (231 packed entries do not fit one lane) and the default mapping for n = 15.
+// No lane returns before the barrier: lanes past the batch end work on the zero-initialised padding filters of the
+// last tile and on bounds-checked (zero) inputs.
 template <int NS, bool UPDATE, int MH = MH_DEFAULT>
-__global__ __launch_bounds__(128, 1) void k_step_coop(const double *st, double *sto, long stride, int B,
+__global__ __launch_bounds__(128, 1) void k_step_coop(const double *st, double *sto, int B,
                                                       const double *__restrict__ imu, const double *__restrict__ lo,
                                                       const uint8_t *__restrict__ mask, double qg, double qa,
                                                       double qbg, double qba, Consts k)
 {
-  using L = Lay<NS>;
   using C = Coop<NS>;
   __shared__ double xch[UPDATE ? C::NXCH : 1][64];
   const int role = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
   const unsigned lane = threadIdx.x & 63u;
-  const unsigned wg = xcd_workgroup(k);
-  const unsigned b = wg * 64u + lane;
-  const unsigned bo = b * 8u;
-  const unsigned s8 = (unsigned) stride * 8u, B8 = (unsigned) B * 8u;
-  const rsrc_t rs = mkbuf(st, (unsigned) L::NC * s8);
-  const rsrc_t ro = mkbuf(sto, (unsigned) L::NC * s8);
+  const unsigned tile = xcd_workgroup(k);
+  const unsigned b = tile * 64u + lane;
+  const unsigned bo = b * 8u, B8 = (unsigned) B * 8u;
+  TileIO<NS, MemHint<MH>::LA, MemHint<MH>::SA> io(st, sto, tile, lane);
   const rsrc_t ri = mkbuf(imu, 7u * B8);
   const rsrc_t rl = mkbuf(lo, UPDATE ? 6u * B8 : 0u);
   StepInputs in;
@@ -527,12 +665,14 @@ __global__ __launch_bounds__(128, 1) void k_step_coop(const double *st, double *
     const rsrc_t rq = mkbuf(k.qblk, 4u * B8);
     in.qg = ldg(rq, 0u, bo); in.qa = ldg(rq, B8, bo); in.qbg = ldg(rq, 2u * B8, bo); in.qba = ldg(rq, 3u * B8, bo);
   }
-  auto ld = [rs, s8, bo](int comp) { return ldg<MemHint<MH>::LA>(rs, (unsigned) comp * s8, bo); };
-  auto stf = [ro, s8, bo](int comp, double v) { stg<MemHint<MH>::SA>(ro, (unsigned) comp * s8, bo, v); };
+  auto ld = [&io](int comp) { return io.ld(comp); };
+  auto stf = [&io](int comp, double v) { io.st(comp, v); };
   auto sync = []() { __syncthreads(); };
   if (role == 0) {
+    io.template need<0, Slots<NS>::ROW_SPLIT>();
     coop_role_core<NS, UPDATE>(ld, stf, [lane](int s, double v) { xch[s][lane] = v; }, sync, in, k);
   } else {
+    io.template need<Slots<NS>::ROW_SPLIT, Slots<NS>::NROW>();
     coop_role_passive<NS, UPDATE>(ld, stf, [lane](int s) { return xch[s][lane]; }, sync, in, k);
   }
 }
@@ -542,7 +682,7 @@ struct RowVals {
   static constexpr int MAX = 36;  // the largest block of one call: a full 6 x 6 measurement covariance
   double v[MAX];
 };
-__global__ void k_fill_rows(double *__restrict__ dst, int rows, int B, RowVals vals)
+static __global__ void k_fill_rows(double *__restrict__ dst, int rows, int B, RowVals vals)
 {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
@@ -554,48 +694,50 @@ __global__ void k_fill_rows(double *__restrict__ dst, int rows, int B, RowVals v
 // eigen_utils' loglike_normalized).  out [3][B] = logdet, mahalanobis^2, -0.5*(m log 2pi + logdet + maha).
 // err_out [NS][B] (optional) receives the full error vector.  Runtime index list, gathered like k_update.
 template <int NS, int M>
-__global__ void k_window_nll(const double *__restrict__ st, long stride, int B, IdxArg<M> idx,
+__global__ void k_window_nll(const double *__restrict__ st, int B, IdxArg<M> idx,
                              const double *__restrict__ tvec, const double *__restrict__ tquat, double *__restrict__ out,
                              double *__restrict__ err_out)
 {
   using L = Lay<NS>;
+  using S = Slots<NS>;
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   double q[4], tq[4], dchi[3];
 #pragma unroll
   for (int i = 0; i < 4; i++) {
-    q[i] = st[(long) (L::OFF_QUAT + i) * stride + b];
+    q[i] = st[S::eidx(L::OFF_QUAT + i, b)];
     tq[i] = tquat[(long) i * B + b];
   }
   subtract_quats(q, tq, dchi);
   if (err_out != nullptr) {
     for (int i = 0; i < NS; i++) {
-      double e = st[(long) (L::OFF_VEC + i) * stride + b] - tvec[(long) i * B + b];
+      double e = st[S::eidx(L::OFF_VEC + i, b)] - tvec[(long) i * B + b];
       if (i >= 6 && i <= 8) e = dchi[i - 6];
       err_out[(long) i * B + b] = e;
     }
   }
-  double e[M], S[M * (M + 1) / 2], d[M];
+  double e[M], Sm[M * (M + 1) / 2], d[M];
 #pragma unroll
   for (int kk = 0; kk < M; kk++) {
     const int ii = idx.v[kk];
-    double v = st[(long) (L::OFF_VEC + ii) * stride + b] - tvec[(long) ii * B + b];
+    double v = st[S::eidx(L::OFF_VEC + ii, b)] - tvec[(long) ii * B + b];
     if (ii >= 6 && ii <= 8) v = (ii == 6) ? dchi[0] : (ii == 7 ? dchi[1] : dchi[2]);
     e[kk] = v;
 #pragma unroll
-    for (int j = 0; j <= kk; j++) S[pk(kk, j)] = st[(long) (L::OFF_P + pk(ii, idx.v[j])) * stride + b];
+    for (int j = 0; j <= kk; j++) Sm[pk(kk, j)] = st[S::eidx(L::OFF_P + pk(ii, idx.v[j]), b)];
   }
-  ldlt<M>(S, d);
-  double logdet = 0.0, maha = 0.0, y[M];
+  ldlt<M>(Sm, d);
+  double det = 1.0, maha = 0.0, y[M];
 #pragma unroll
   for (int kk = 0; kk < M; kk++) {
     double s = e[kk];
 #pragma unroll
-    for (int j = 0; j < kk; j++) s -= S[pk(kk, j)] * y[j];
+    for (int j = 0; j < kk; j++) s -= Sm[pk(kk, j)] * y[j];
     y[kk] = s;
-    logdet += log(d[kk]);
+    det *= d[kk];
     maha += s * s / d[kk];
   }
+  const double logdet = log(det);
   out[b] = logdet;
   out[(long) B + b] = maha;
   out[2L * B + b] = -0.5 * (M * 1.8378770664093453 + logdet + maha);  // log(2 pi)
@@ -610,7 +752,7 @@ struct NotchCoef {
 };
 // One lane per (filter, axis): blockIdx.y is the axis -- three times the waves of a lane-per-filter mapping, which this
 // short, latency-bound kernel needs (rocprof: 14.6 us -> see DESIGN.md 6 for the lane-per-filter version it replaced).
-__global__ void k_notch(double *__restrict__ nst, long stride, int B, int n_packets, const double *__restrict__ acc_in,
+static __global__ void k_notch(double *__restrict__ nst, long stride, int B, int n_packets, const double *__restrict__ acc_in,
                         double *__restrict__ acc_out, NotchCoef k)
 {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -642,23 +784,25 @@ __global__ void k_notch(double *__restrict__ nst, long stride, int B, int n_pack
   if (n_packets > 0) acc_out[(long) ax * B + b] = v;
 }
 
-// Counter calibration: a plain copy with EXACTLY the access pattern of k_step (buffer_load/store_dwordx2, 8 bytes
-// per lane, component-major rows of `stride` doubles), so that rocprofv3's FETCH_SIZE / WRITE_SIZE can be scaled
-// on a known byte count (MI355X_MICROARCH.md section HBM: widths other than 16 B/lane are uncalibrated).
-__global__ __launch_bounds__(64, 1) void k_calib_copy(const double *__restrict__ src, double *__restrict__ dst,
-                                                      long stride, int B, int ncomp)
+// Counter calibration: a plain copy with EXACTLY the access pattern of the step kernels (buffer_load/store_dwordx4,
+// 16 bytes per lane, one tile per wave, all loads of a chunk before its stores), so that rocprofv3's FETCH_SIZE /
+// WRITE_SIZE can be scaled on a known byte count, and the copy ceiling of this access pattern measured.
+static __global__ __launch_bounds__(64, 1) void k_calib_copy(const double *__restrict__ src, double *__restrict__ dst, int B,
+                                                      int nrow)
 {
-  const unsigned b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= (unsigned) B) return;
-  const unsigned bo = b * 8u, s8 = (unsigned) stride * 8u;
-  const rsrc_t ri = mkbuf(src, (unsigned) ncomp * s8), ro = mkbuf(dst, (unsigned) ncomp * s8);
-  for (int c0 = 0; c0 < ncomp; c0 += 20) {
-    double v[20];
+  const unsigned tile = blockIdx.x;
+  if (tile * 64u >= (unsigned) B) return;
+  const unsigned tb = (unsigned) nrow * 1024u;
+  const rsrc_t ri = mkbuf(reinterpret_cast<const char *>(src) + (size_t) tile * tb, tb);
+  const rsrc_t ro = mkbuf(reinterpret_cast<char *>(dst) + (size_t) tile * tb, tb);
+  const unsigned vo = threadIdx.x * 16u;
+  for (int r0 = 0; r0 < nrow; r0 += 35) {
+    d2_t v[35];
 #pragma unroll
-    for (int i = 0; i < 20; i++) v[i] = (c0 + i < ncomp) ? ldg(ri, (unsigned) (c0 + i) * s8, bo) : 0.0;
+    for (int i = 0; i < 35; i++) v[i] = (r0 + i < nrow) ? ldg2(ri, (unsigned) (r0 + i) * 1024u, vo) : d2_t{ 0, 0 };
 #pragma unroll
-    for (int i = 0; i < 20; i++)
-      if (c0 + i < ncomp) stg(ro, (unsigned) (c0 + i) * s8, bo, v[i]);
+    for (int i = 0; i < 35; i++)
+      if (r0 + i < nrow) stg2(ro, (unsigned) (r0 + i) * 1024u, vo, v[i]);
   }
 }
 

@@ -28,3 +28,15 @@ def allreduce_summary(summary4, dist=None, device=None):
     out = sums.clone()
     out[2] = mx[2]
     return out.cpu()
+
+
+def reduce_summaries(shard_summaries):
+    """What the all-reduce computes, on a plain list of per-shard summaries (the C++ multi-device driver and the
+    one-GPU rehearsal of config 4 use this order: sums in rank order, max of the quaternion-norm deviation)."""
+    out = [0.0, 0.0, 0.0, 0.0]
+    for s in shard_summaries:
+        out[0] += float(s[0])
+        out[1] += float(s[1])
+        out[2] = max(out[2], float(s[2]))
+        out[3] += float(s[3])
+    return out

@@ -19,6 +19,54 @@ template<int DEPTH, int LA, int SA, bool XCD> __global__ __launch_bounds__(64) v
     for(int i=0;i<DEPTH;i++){ v[i].x+=1u; __builtin_amdgcn_raw_buffer_store_b64(v[i],ro,bo,(unsigned)(c0+i)*s8,SA);}
   }
 }
+
+// 16 B per lane: component PAIRS interleaved, st[NC/2][stride][2] -- lane b reads components (2c, 2c+1) of its filter with one
+// buffer_load_dwordx4 (1 KiB contiguous per wave instruction instead of 512 B)
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+template<int DEPTH, int LA, int SA, bool XCD, int WG> __global__ __launch_bounds__(WG) void copyB(const double* src, double* dst, long stride, int B, int npair){
+  unsigned wg=blockIdx.x;
+  if(XCD){ unsigned nq=gridDim.x>>3,nr=gridDim.x&7u,x=blockIdx.x&7u,r=blockIdx.x>>3; wg=(x<nr? x*(nq+1u): nr*(nq+1u)+(x-nr)*nq)+r; }
+  unsigned b=wg*(unsigned)WG+threadIdx.x; if(b>=(unsigned)B) return; unsigned bo=b*16u, s16=(unsigned)stride*16u;
+  rsrc_t ri=mkbuf(src,(unsigned)npair*s16), ro=mkbuf(dst,(unsigned)npair*s16);
+  for(int c0=0;c0<npair;c0+=DEPTH){ v4u v[DEPTH];
+#pragma unroll
+    for(int i=0;i<DEPTH;i++) v[i]=__builtin_amdgcn_raw_buffer_load_b128(ri,bo,(unsigned)(c0+i)*s16,LA);
+#pragma unroll
+    for(int i=0;i<DEPTH;i++){ v[i].x+=1u; __builtin_amdgcn_raw_buffer_store_b128(v[i],ro,bo,(unsigned)(c0+i)*s16,SA);}
+  }
+}
+
+// TILED layouts: st[B/TF][NC][TF] (8 B/lane) or st[B/TF][NC/2][TF][2] (16 B/lane): the whole state of TF filters is one
+// contiguous block (TF=64: 71 680 B), so a wave's 140 component accesses stay inside one or two pages instead of touching
+// 140 rows that lie `stride*8` bytes (8 MB at 1 M filters) apart
+template<int DEPTH, int LA, int SA, bool XCD, int TF> __global__ __launch_bounds__(64) void copyT8(const double* src, double* dst, int B, int nc){
+  unsigned wg=blockIdx.x;
+  if(XCD){ unsigned nq=gridDim.x>>3,nr=gridDim.x&7u,x=blockIdx.x&7u,r=blockIdx.x>>3; wg=(x<nr? x*(nq+1u): nr*(nq+1u)+(x-nr)*nq)+r; }
+  unsigned b=wg*64u+threadIdx.x; if(b>=(unsigned)B) return;
+  const unsigned tile=b/TF, l=b%TF; const size_t tb=(size_t)tile*nc*TF*8;
+  rsrc_t ri=mkbuf((const char*)src+tb,(unsigned)nc*TF*8), ro=mkbuf((char*)dst+tb,(unsigned)nc*TF*8);
+  const unsigned bo=l*8u;
+  for(int c0=0;c0<nc;c0+=DEPTH){ v2u v[DEPTH];
+#pragma unroll
+    for(int i=0;i<DEPTH;i++) v[i]=__builtin_amdgcn_raw_buffer_load_b64(ri,bo,(unsigned)(c0+i)*TF*8u,LA);
+#pragma unroll
+    for(int i=0;i<DEPTH;i++){ v[i].x+=1u; __builtin_amdgcn_raw_buffer_store_b64(v[i],ro,bo,(unsigned)(c0+i)*TF*8u,SA);}
+  }
+}
+template<int DEPTH, int LA, int SA, bool XCD, int TF> __global__ __launch_bounds__(64) void copyT16(const double* src, double* dst, int B, int npair){
+  unsigned wg=blockIdx.x;
+  if(XCD){ unsigned nq=gridDim.x>>3,nr=gridDim.x&7u,x=blockIdx.x&7u,r=blockIdx.x>>3; wg=(x<nr? x*(nq+1u): nr*(nq+1u)+(x-nr)*nq)+r; }
+  unsigned b=wg*64u+threadIdx.x; if(b>=(unsigned)B) return;
+  const unsigned tile=b/TF, l=b%TF; const size_t tb=(size_t)tile*npair*TF*16;
+  rsrc_t ri=mkbuf((const char*)src+tb,(unsigned)npair*TF*16), ro=mkbuf((char*)dst+tb,(unsigned)npair*TF*16);
+  const unsigned bo=l*16u;
+  for(int c0=0;c0<npair;c0+=DEPTH){ v4u v[DEPTH];
+#pragma unroll
+    for(int i=0;i<DEPTH;i++) v[i]=__builtin_amdgcn_raw_buffer_load_b128(ri,bo,(unsigned)(c0+i)*TF*16u,LA);
+#pragma unroll
+    for(int i=0;i<DEPTH;i++){ v[i].x+=1u; __builtin_amdgcn_raw_buffer_store_b128(v[i],ro,bo,(unsigned)(c0+i)*TF*16u,SA);}
+  }
+}
 #define CK(x) do{hipError_t e=(x); if(e!=hipSuccess){printf("err %s line %d\n",hipGetErrorString(e),__LINE__); return 1;}}while(0)
 template<class F> float timeit(F f,int reps){ hipEvent_t a,b; hipEventCreate(&a);hipEventCreate(&b); f(); f(); hipDeviceSynchronize(); hipEventRecord(a); for(int i=0;i<reps;i++) f(); hipEventRecord(b); hipEventSynchronize(b); float ms; hipEventElapsedTime(&ms,a,b); return ms/reps; }
 int main(){
@@ -39,6 +87,40 @@ int main(){
     RUN("in-place d35 xcd st-sc0sc1",35,0,17,true,s);
     RUN("in-place d70 xcd",70,0,0,true,s);
     RUN("in-place d70 xcd st-nt",70,0,2,true,s);
+#define RUNB(NAME,D,LA,SA,X,WG,DST) rep(NAME, timeit([&]{ copyB<D,LA,SA,X,WG><<<(B+WG-1)/WG,WG>>>(s,DST,stride,B,nc/2);},reps))
+    RUNB("16B out-of-place d35",35,0,0,false,64,d);
+    RUNB("16B in-place d35",35,0,0,false,64,s);
+    RUNB("16B in-place d35 xcd",35,0,0,true,64,s);
+    RUNB("16B in-place d35 xcd st-sc1",35,0,16,true,64,s);
+    RUNB("16B in-place d35 xcd st-nt",35,0,2,true,64,s);
+    RUNB("16B in-place d35 xcd ld-nt st-nt",35,2,2,true,64,s);
+    RUNB("16B in-place d14 xcd",14,0,0,true,64,s);
+    RUNB("16B in-place d14 xcd wg256",14,0,0,true,256,s);
+    RUNB("16B in-place d14 xcd wg256 nt",14,2,2,true,256,s);
+    RUNB("16B in-place d7 wg256",7,0,0,false,256,s);
+    RUNB("16B in-place d7 wg256 ld-nt st-nt",7,2,2,false,256,s);
+    RUNB("16B in-place d70 xcd",70,0,0,true,64,s);
+    RUNB("16B in-place d70 xcd ld-nt st-nt",70,2,2,true,64,s);
+#define RUNT8(NAME,D,LA,SA,X,TF,DST) rep(NAME, timeit([&]{ copyT8<D,LA,SA,X,TF><<<g,64>>>(s,DST,B,nc);},reps))
+#define RUNT16(NAME,D,LA,SA,X,TF,DST) rep(NAME, timeit([&]{ copyT16<D,LA,SA,X,TF><<<g,64>>>(s,DST,B,nc/2);},reps))
+    RUNT8("tile64 8B in-place d35",35,0,0,false,64,s);
+    RUNT8("tile64 8B in-place d35 xcd",35,0,0,true,64,s);
+    RUNT8("tile64 8B in-place d35 xcd st-sc1",35,0,16,true,64,s);
+    RUNT8("tile64 8B in-place d35 xcd nt",35,2,2,true,64,s);
+    RUNT8("tile64 8B in-place d35 nt",35,2,2,false,64,s);
+    RUNT8("tile64 8B out-of-place d35 xcd",35,0,0,true,64,d);
+    RUNT16("tile64 16B in-place d35",35,0,0,false,64,s);
+    RUNT16("tile64 16B in-place d35 xcd",35,0,0,true,64,s);
+    RUNT16("tile64 16B in-place d35 xcd st-sc1",35,0,16,true,64,s);
+    RUNT16("tile64 16B in-place d35 xcd nt",35,2,2,true,64,s);
+    RUNT16("tile64 16B in-place d35 nt",35,2,2,false,64,s);
+    RUNT16("tile64 16B in-place d70 xcd",70,0,0,true,64,s);
+    RUNT16("tile64 16B in-place d70 xcd nt",70,2,2,true,64,s);
+    RUNT16("tile64 16B out-of-place d35 xcd",35,0,0,true,64,d);
+    RUNT16("tile256 16B in-place d35 xcd",35,0,0,true,256,s);
+    RUNT16("tile256 16B in-place d35 xcd nt",35,2,2,true,256,s);
+    RUNT8("tile1024 8B in-place d35 xcd",35,0,0,true,1024,s);
+    RUNT8("tile1024 8B in-place d35 xcd nt",35,2,2,true,1024,s);
     hipFree(s);hipFree(d);
   }
   return 0;

@@ -9,13 +9,14 @@ import os
 import numpy as np
 import pytest
 
-from util import embed21, pad_z, random_spd, rel, run_config
+from util import embed21, pad_z, random_spd, rel, rel_elem, run_config
 
 from pronto_amd.synth import Workload
 
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-9
+ELEM_TOL = 1e-7   # element-wise bound with a floor of 1e-4 * max|block|: an entry 1e4 below the largest still gets 7 digits
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
@@ -48,6 +49,10 @@ def check(est, ob, tol=TOL):
     v, q, P, ll = est.get_head()
     errs = dict(vec=rel(v, ob.vec[:n]), quat=rel(q, ob.quat), cov=rel(P, ob.cov[:n, :n]), ll=rel(ll, ob.ll))
     assert max(errs.values()) < tol, errs
+    # element-wise with an absolute floor (tests/util.py): small entries are held to 1e-4 * tol * max|block| absolute
+    elem = dict(vec=rel_elem(v, ob.vec[:n]), quat=rel_elem(q, ob.quat), cov=rel_elem(P, ob.cov[:n, :n]),
+                ll=rel_elem(ll, ob.ll))
+    assert max(elem.values()) < ELEM_TOL, elem
     return errs
 
 
@@ -366,7 +371,7 @@ def test_error_behaviour_and_wire_layout(pa, oracle):
         est.snapshot(5)
     assert e.value.code == 4
     with pytest.raises(pa.PbError) as e:
-        pa.BatchEstimator(3_000_000, n_states=21)      # 257 components x 3M filters x 8 B > 4 GiB per context
+        pa.BatchEstimator(15_000_000, n_states=15)     # the [36][B] input blocks of one context must stay below 4 GiB
     assert e.value.code == 1 and "too large" in str(e.value)
     for call in (lambda: est.state_save(0), lambda: est.smooth_step(0, 1, 2, 3, 1e-3)):
         with pytest.raises(pa.PbError) as e:
@@ -620,3 +625,57 @@ def test_output_slot_checkpoints_equal_copies(pa, oracle, n):
         for x, y in zip(a.get_head(), b.get_head()):
             assert np.array_equal(x, y), slot
     a.close(); b.close()
+
+
+def test_config4_256k_whole_equals_its_eight_shards(pa, oracle):
+    """BASELINE config 4 (262 144 filters sharded 8 x 32 768) rehearsed on ONE GPU: the whole batch in one context, then
+    each of the eight filter-range shards alone (what rank r of `bench.py --gpus 8` runs: Workload(b0=...) + its own
+    context).  Filters never interact, so (a) every shard's head state is BIT-identical to its slice of the whole batch,
+    (b) the reduction of the eight shard summaries (what the end-of-run all-reduce computes) equals the whole batch's
+    pb_summary, (c) sampled filters of the whole batch match the oracle, (d) nothing non-finite."""
+    import torch
+    from pronto_amd.shard import reduce_summaries, shard_range
+    Btot, world, n, T = 262144, 8, 15, 16
+    dev = torch.device("cuda:0")
+    w = Workload(Btot, n_states=n)
+    vec, quat, P0 = w.initial_state()
+    q4 = w.process_noise()
+    imu, lo, mask = w.streams(0, T)
+    est = pa.BatchEstimator(Btot, n_states=n)
+    est.set_constants(*oracle.constants())
+    est.reset(vec, quat, P0)
+    est.run_legodo(torch.from_numpy(imu).to(dev), torch.from_numpy(lo).to(dev), torch.from_numpy(mask).to(dev), q4)
+    whole = est.summary()
+    v, q, P, ll = est.get_head()
+    est.close()
+    assert whole[3] == 0 and whole[2] < 1e-12                                             # (d)
+    sel = np.concatenate([np.arange(0, 32), np.arange(32768 - 16, 32768 + 16), np.arange(Btot - 32, Btot)])
+    v21, P21 = embed21(vec[:, sel], P0[:, :, sel])
+    ob = oracle.OracleBatch(v21, quat[:, sel], P21)
+    ob.run_legodo(np.ascontiguousarray(imu[:, :, sel]), np.ascontiguousarray(lo[:, :, sel]),
+                  np.ascontiguousarray(mask[:, sel]), q4)
+    assert rel(v[:, sel], ob.vec[:n]) < TOL and rel(q[:, sel], ob.quat) < TOL             # (c)
+    assert rel(P[:, :, sel], ob.cov[:n, :n]) < TOL and rel(ll[sel], ob.ll) < TOL
+    shard_sums = []
+    for r in range(world):
+        b0, b1 = shard_range(Btot, r, world)
+        assert b1 - b0 == 32768
+        if r in (0, 5):   # exactly what a rank does: its own generator instance at offset b0
+            ws = Workload(b1 - b0, b0=b0, n_states=n)
+            sv, sq, sP = ws.initial_state()
+            simu, slo, smask = ws.streams(0, T)
+        else:             # the generator is counter-based (tests/test_shard_dist.py): a slice is the same bits
+            sv, sq, sP = (np.ascontiguousarray(a[..., b0:b1]) for a in (vec, quat, P0))
+            simu, slo, smask = (np.ascontiguousarray(a[..., b0:b1]) for a in (imu, lo, mask))
+        e = pa.BatchEstimator(b1 - b0, n_states=n)
+        e.set_constants(*oracle.constants())
+        e.reset(sv, sq, sP)
+        e.run_legodo(torch.from_numpy(simu).to(dev), torch.from_numpy(slo).to(dev), torch.from_numpy(smask).to(dev), q4)
+        shard_sums.append(e.summary())
+        hv, hq, hP, hl = e.get_head()
+        e.close()
+        assert np.array_equal(hv, v[:, b0:b1]) and np.array_equal(hq, q[:, b0:b1])       # (a)
+        assert np.array_equal(hP, P[:, :, b0:b1]) and np.array_equal(hl, ll[b0:b1])
+    red = reduce_summaries(shard_sums)                                                    # (b)
+    assert np.isclose(red[0], whole[0], rtol=1e-12) and np.isclose(red[1], whole[1], rtol=1e-12)
+    assert red[2] == whole[2] and red[3] == whole[3] == 0

@@ -73,5 +73,35 @@ def test_summary_allreduce_world2_gloo():
         assert tmax == 1.5
 
 
+def test_bench_spawns_its_own_ranks_dry():
+    """`python bench.py --gpus 2` with no launcher starts two child ranks itself (the form the driver uses); the dry
+    rehearsal runs the rendezvous + an all-reduce over gloo without a GPU and rank 0 prints the one JSON line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PRONTO_BENCH_REHEARSE="dry")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["rank_sum"] == 3.0
+    # a failing rank fails the whole run (no GPU here -> every real rank exits non-zero)
+    env.pop("PRONTO_BENCH_REHEARSE")
+    if not torch.cuda.is_available():
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2"],
+                           env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode != 0 and "rank(s) failed" in r.stderr
+
+
+def test_reduce_summaries_matches_allreduce_semantics():
+    from pronto_amd.shard import reduce_summaries
+    assert reduce_summaries([[1.0, 10.0, 1e-15, 0.0], [2.0, 20.0, 3e-15, 1.0]]) == [3.0, 30.0, 3e-15, 1.0]
+
+
 def test_single_process_is_identity():
     assert allreduce_summary([1.0, 2.0, 3.0, 4.0]).tolist() == [1.0, 2.0, 3.0, 4.0]

@@ -7,6 +7,16 @@ def rel(a, b):
     return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
 
 
+def rel_elem(a, b, floor_frac=1e-4):
+    """Element-wise relative error with an absolute floor: max_i |a_i-b_i| / max(|b_i|, floor_frac * max|b|).
+    A wrong SMALL entry (an off-diagonal of P four orders below the largest one) fails this where the block-relative
+    `rel` would let it through; entries below the floor are checked to floor_frac * tol * max|b| absolute."""
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    scale = max(float(np.max(np.abs(b))), 1e-300)
+    den = np.maximum(np.abs(b), floor_frac * scale)
+    return float(np.max(np.abs(a - b) / den))
+
+
 def embed21(vec, P):
     """n-state (vec [n,B], P [n,n,B]) -> the oracle's 21-state layout with zero bias rows (KAT vii)."""
     n, B = vec.shape
