@@ -132,6 +132,20 @@ int pb_update_indexed_orient(pb_ctx *ctx, int m, const int *idx, const double *z
 int pb_step_legodo(pb_ctx *ctx, const double *imu_block, const double *lo_block, const uint8_t *mask,
                    const double q[4], int mem);
 
+/* The same step with ONE MORE measurement behind it, still one launch and one round trip of the state: what the
+ * reference does as a third updateFilter call when a correction message follows the IMU / leg-odometry pair.
+ *   PB_CORR_POS_ORIENT  idx = {9,10,11,6,7,8}  FovisHandler position_orient (rbis_fovis_update.cpp:299-305)
+ *   PB_CORR_POS_YAW     idx = {9,10,11,8}      ScanMatcherHandler position_yaw (sensor_handlers.cpp:709-722)
+ * both RBISIndexedPlusOrientationMeasurement (rbis.cpp:189-217) with a diagonal R: z2 [m][B] (entries at chi indices are
+ * ignored), R2 [m][B] (r_kind2 = PB_R_DIAG) or host double[m] (PB_R_DIAG_BROADCAST), quat_meas2 [4][B], mask2 [B] or NULL.
+ * `mem` says where imu_block / lo_block / mask live, `mem2` where z2 / R2 / quat_meas2 / mask2 live (a FovisHandler
+ * measurement is composed on the device, pb_compose_delta, while the IMU message comes from the host).
+ * Results equal pb_step_legodo followed by pb_update_indexed_orient to rounding (tests/: <= 1e-12 relative). */
+enum pb_corr { PB_CORR_POS_ORIENT = 0, PB_CORR_POS_YAW = 1 };
+int pb_step_legodo_correct(pb_ctx *ctx, const double *imu_block, const double *lo_block, const uint8_t *mask,
+                           const double q[4], int mem, int corr_kind, const double *z2, const double *R2, int r_kind2,
+                           const double *quat_meas2, const uint8_t *mask2, int mem2);
+
 /* n_steps consecutive fused steps from HBM-resident streams: imu_stream [n_steps][7][B],
  * lo_stream [n_steps][6][B], mask_stream [n_steps][B] or NULL (device pointers).  One launch per step (the
  * posterior is materialised in HBM after every message, as MavStateEstimator::addUpdate does,

@@ -16,10 +16,11 @@ HEADER = os.path.join(os.path.dirname(_HERE), "include", "pronto_batch.h")
 PB_OK, PB_ERR_ARG, PB_ERR_HIP, PB_ERR_NO_DEVICE, PB_ERR_STATE = range(5)
 PB_HOST, PB_DEVICE, PB_HOST_BROADCAST = 0, 1, 2
 PB_R_DIAG_BROADCAST, PB_R_DIAG, PB_R_FULL = 0, 1, 2
+PB_CORR_POS_ORIENT, PB_CORR_POS_YAW = 0, 1
 
 
 def sources():
-    return [os.path.join(CSRC, f) for f in ("pronto_batch.hip", "pb_step.hip", "pb_update.hip", "pb_smooth.hip", "pb_ctx.hpp",
+    return [os.path.join(CSRC, f) for f in ("pronto_batch.hip", "pb_step.hip", "pb_update.hip", "pb_update_ct.hip", "pb_smooth.hip", "pb_ctx.hpp",
                                             "rbis_kernels.hpp", "rbis_coop.hpp", "rbis_smooth.hpp", "rbis_device.hpp")] + [HEADER]
 
 
@@ -62,6 +63,8 @@ _SIGS = {
     "pb_update_indexed_orient": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_void_p, C.c_void_p, C.c_int,
                                            C.c_void_p, C.c_void_p, C.c_int]),
     "pb_step_legodo": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, _dp, C.c_int]),
+    "pb_step_legodo_correct": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, _dp, C.c_int, C.c_int, C.c_void_p,
+                                         C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
     "pb_run_legodo": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, _dp, C.POINTER(C.c_float)]),
     "pb_replay_legodo_fused": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, _dp,
                                          C.POINTER(C.c_float)]),

@@ -216,6 +216,23 @@ class BatchEstimator:
         q = (C.c_double * 4)(*q4)
         self._chk(self._L.pb_step_legodo(self._h, pi, pl, pm, q, _same_mem(m1, m2, m3)))
 
+    def step_legodo_correct(self, imu_block, lo_block, mask, q4, corr_kind, z2, R2, quat_meas2, mask2=None):
+        """predict + leg-odometry update + one more orientation update (corr_kind: _lib.PB_CORR_POS_ORIENT m=6 idx
+        9,10,11,6,7,8 / PB_CORR_POS_YAW m=4 idx 9,10,11,8) in one state round trip.  R2: length-m list or [m,B]."""
+        pi, m1 = _ptr_block(imu_block)
+        pl, m2 = _ptr_block(lo_block)
+        pm, m3 = _ptr(mask, np.uint8)
+        pz, m4 = _ptr_block(z2)
+        if corr_kind not in (_lib.PB_CORR_POS_ORIENT, _lib.PB_CORR_POS_YAW):
+            raise ValueError("corr_kind must be PB_CORR_POS_ORIENT or PB_CORR_POS_YAW")
+        m = 6 if corr_kind == _lib.PB_CORR_POS_ORIENT else 4
+        _keep, pr, kind, m5 = self._r(R2, m)
+        pq, m6 = _ptr_block(quat_meas2)
+        pm2, m7 = _ptr(mask2, np.uint8)
+        q = (C.c_double * 4)(*q4)
+        self._chk(self._L.pb_step_legodo_correct(self._h, pi, pl, pm, q, _same_mem(m1, m2, m3), int(corr_kind), pz, pr, kind,
+                                                 pq, pm2, _same_mem(m4, m5, m6, m7)))
+
     def run_legodo(self, imu_stream, lo_stream, mask_stream, q4, timed=False):
         """n_steps fused steps from device-resident streams [T,7,B], [T,6,B], [T,B]; returns device ms if timed."""
         T = imu_stream.shape[0]

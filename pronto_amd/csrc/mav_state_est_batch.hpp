@@ -175,6 +175,43 @@ struct BatchArray {
 
 class MavStateEstimator;
 
+// Device memory that an update object OWNS (the reference's update objects own their measurement; here a measurement that
+// was formed on the device -- FovisHandler's T1 = T0 * delta -- must stay what it was when the history re-applies the
+// update after a late arrival).  Blocks of one size are recycled through a pool shared by the handler and its updates;
+// `alive` is the estimator's lifetime token: device memory is only released while the context still exists.
+struct DevicePool {
+  pb_ctx *ctx;
+  std::shared_ptr<bool> alive;
+  size_t bytes;
+  std::vector<void *> free_;
+  DevicePool(pb_ctx *c, std::shared_ptr<bool> a, size_t b) : ctx(c), alive(std::move(a)), bytes(b) {}
+  ~DevicePool()
+  {
+    if (alive && *alive)
+      for (void *p : free_) pb_free(ctx, p);
+  }
+  void *get(bool &fresh)
+  {
+    fresh = free_.empty();
+    void *p = nullptr;
+    if (!fresh) {
+      p = free_.back();
+      free_.pop_back();
+    } else if (pb_malloc(ctx, bytes, &p) != PB_OK) {
+      p = nullptr;
+    }
+    return p;
+  }
+};
+struct DeviceBlock {
+  std::shared_ptr<DevicePool> pool;
+  void *p;
+  DeviceBlock(std::shared_ptr<DevicePool> pl, void *ptr) : pool(std::move(pl)), p(ptr) {}
+  ~DeviceBlock() { if (p) pool->free_.push_back(p); }  // stream order makes the reuse safe: every consumer was enqueued before
+  DeviceBlock(const DeviceBlock &) = delete;
+  DeviceBlock &operator=(const DeviceBlock &) = delete;
+};
+
 // ---------------------------------------------------------------------------------------------------------------
 // update objects (rbis_update_interface.hpp)
 // ---------------------------------------------------------------------------------------------------------------
@@ -238,6 +275,7 @@ public:
   std::vector<int> index;
   std::vector<double> owned_z, owned_R;
   std::vector<uint8_t> owned_mask;
+  std::shared_ptr<DeviceBlock> owned_dev;  // device-resident z / quat / mask this update owns (FovisHandler)
   BatchArray measurement;           // [m][B]
   const double *measurement_cov;    // per r_kind
   int r_kind, cov_mem;
@@ -327,6 +365,7 @@ class MavStateEstimator {
 public:
   int64_t utime_history_span;
   pb_ctx *ctx = nullptr;
+  std::shared_ptr<bool> ctx_alive = std::make_shared<bool>(false);  // lifetime token for device memory owned elsewhere
   int n = 0, B = 0;
   int64_t head_utime = 0;
   int last_status = PB_OK;
@@ -346,6 +385,12 @@ public:
   // Anything that reads the device (getHeadState, the smoother, FovisHandler) flushes the held step first.
   bool fuse_ins_legodo = false;
   int64_t fused_pairs = 0;
+  // state_estimator.fuse_corrections = true (with fuse_ins_legodo): the fused pair is held back one more message; if
+  // that is a FovisHandler position_orient (idx 9,10,11,6,7,8) or ScanMatcherHandler position_yaw (idx 9,10,11,8)
+  // measurement with a diagonal R, all THREE updates run as one kernel and one state round trip
+  // (pb_step_legodo_correct; reference seam: rbis_fovis_update.cpp:299-305, sensor_handlers.cpp:709-722).
+  bool fuse_corrections = false;
+  int64_t fused_triples = 0;
 
   MavStateEstimator(RBISResetUpdate *init_state, BotParam *param, int device = 0, int n_snapshots = 2)
   {
@@ -360,6 +405,8 @@ public:
     {
       auto it = param->kv.find("state_estimator.fuse_ins_legodo");
       fuse_ins_legodo = history_slots == 0 && it != param->kv.end() && (it->second == "true" || it->second == "1");
+      it = param->kv.find("state_estimator.fuse_corrections");
+      fuse_corrections = fuse_ins_legodo && it != param->kv.end() && (it->second == "true" || it->second == "1");
     }
     n = init_state->reset_state.n;
     B = init_state->reset_state.B;
@@ -369,6 +416,7 @@ public:
       fprintf(stderr, "MavStateEstimator: %s\n", pb_last_error(rc == PB_OK ? nullptr : ctx));
       exit(1);  // the reference's constructor cannot fail softly either (bot_param_get_int_or_fail)
     }
+    *ctx_alive = true;
     for (int i = history_slots - 1; i >= 0; i--) free_slots.push_back(i);
     last_status = init_state->updateFilter(ctx);  // "apply update from zero... should reset the state" (:16)
     head_utime = init_state->utime;
@@ -378,7 +426,14 @@ public:
     if (history_slots > 0) save_checkpoint(init_state);
     unprocessed_updates_start = history.updateMap.end();
   }
-  ~MavStateEstimator() { pb_destroy(ctx); }
+  ~MavStateEstimator()
+  {
+    // updates may own device memory of this context: release them first, then the context
+    for (auto &kv : history.updateMap) delete kv.second;
+    history.updateMap.clear();
+    *ctx_alive = false;
+    pb_destroy(ctx);
+  }
   MavStateEstimator(const MavStateEstimator &) = delete;
   MavStateEstimator &operator=(const MavStateEstimator &) = delete;
 
@@ -418,7 +473,7 @@ public:
       for (auto it = current_it; it != map.end(); ++it) drop_checkpoint(it->second);
       since_checkpoint = 0;
     }
-    bool held = false;
+    int held = 0;
     while (current_it != map.end()) {
       RBISUpdateInterface *u = current_it->second;
       if (fuse_ins_legodo) {
@@ -426,11 +481,30 @@ public:
           auto nxt = current_it;
           ++nxt;
           if (nxt == map.end() && !flushing_) {  // newest element: hold it back until the next update shows up
-            held = true;
+            held = 1;
             break;
           }
           if (nxt != map.end()) {
             int rc = PB_OK;
+            if (fuse_corrections && fusible_pair(imu, nxt->second)) {
+              auto third = nxt;
+              ++third;
+              if (third == map.end() && !flushing_) {  // the pair is complete: wait for what follows it
+                held = 2;
+                break;
+              }
+              if (third != map.end() && run_fused3(imu, nxt->second, third->second, rc)) {
+                if (rc != PB_OK) {
+                  last_status = rc;
+                  fprintf(stderr, "MavStateEstimator::addUpdate: fused ins+legodo+correction step failed: %s\n", pb_last_error(ctx));
+                }
+                fused_triples++;
+                device_head = third->second;
+                head_utime = third->second->utime;
+                current_it = ++third;
+                continue;
+              }
+            }
             if (run_fused(imu, nxt->second, rc)) {
               if (rc != PB_OK) {
                 last_status = rc;
@@ -485,7 +559,7 @@ public:
       head_utime = it->second->utime;
     }
     flushing_ = false;
-    holding_ = false;
+    holding_ = 0;
     pb_set_utime(ctx, head_utime);
     unprocessed_updates_start = map.end();
   }
@@ -560,7 +634,55 @@ public:
   }
 
 private:
-  bool flushing_ = false, holding_ = false;
+  bool flushing_ = false;
+  int holding_ = 0;  // updates at the end of the history that have not been applied yet (0, 1 = an INS step, 2 = INS + legodo)
+  // an INS step followed by the velocity measurement LegOdoCommon's lin_rate mode produces (what run_fused accepts)
+  bool fusible_pair(RBISIMUProcessStep *imu, RBISUpdateInterface *next)
+  {
+    if (dynamic_cast<RBISIndexedPlusOrientationMeasurement *>(next) != nullptr) return false;
+    auto *m = dynamic_cast<RBISIndexedMeasurement *>(next);
+    if (m == nullptr || m->index != RBIS::velocityInds()) return false;
+    if (imu->imu_block.mem == PB_HOST_BROADCAST && m->measurement.mem == PB_HOST_BROADCAST && m->r_kind == PB_R_DIAG_BROADCAST && m->mask == nullptr)
+      return true;
+    return imu->imu_block.mem == PB_HOST && m->measurement.mem == PB_HOST && m->cov_mem == PB_HOST &&
+           (m->r_kind == PB_R_DIAG || m->r_kind == PB_R_DIAG_BROADCAST);
+  }
+  // ... followed by a position_orient / position_yaw correction with a diagonal R -> one pb_step_legodo_correct
+  bool run_fused3(RBISIMUProcessStep *imu, RBISUpdateInterface *second, RBISUpdateInterface *third, int &rc)
+  {
+    auto *m = dynamic_cast<RBISIndexedMeasurement *>(second);
+    auto *o = dynamic_cast<RBISIndexedPlusOrientationMeasurement *>(third);
+    if (m == nullptr || o == nullptr) return false;
+    int kind;
+    if (o->index == std::vector<int>{ 9, 10, 11, 6, 7, 8 }) kind = PB_CORR_POS_ORIENT;
+    else if (o->index == std::vector<int>{ 9, 10, 11, 8 }) kind = PB_CORR_POS_YAW;
+    else return false;
+    if (o->r_kind != PB_R_DIAG && o->r_kind != PB_R_DIAG_BROADCAST) return false;
+    if (o->measurement.mem != o->orientation.mem) return false;
+    if (o->r_kind == PB_R_DIAG && o->cov_mem != o->measurement.mem) return false;
+    const double q[4] = { imu->q_gyro, imu->q_accel, imu->q_gyro_bias, imu->q_accel_bias };
+    const double *lo;
+    const uint8_t *mask1 = nullptr;
+    int mem1;
+    double lo6[6];
+    if (imu->imu_block.mem == PB_HOST_BROADCAST) {
+      for (int i = 0; i < 3; i++) { lo6[i] = m->measurement.p[i]; lo6[3 + i] = m->measurement_cov[i]; }
+      lo = lo6;
+      mem1 = PB_HOST_BROADCAST;
+    } else {
+      fuse_lo_.resize((size_t) 6 * B);
+      memcpy(fuse_lo_.data(), m->measurement.p, sizeof(double) * 3 * B);
+      if (m->r_kind == PB_R_DIAG) memcpy(fuse_lo_.data() + (size_t) 3 * B, m->measurement_cov, sizeof(double) * 3 * B);
+      else
+        for (int i = 0; i < 3; i++) std::fill_n(fuse_lo_.begin() + (size_t) (3 + i) * B, B, m->measurement_cov[i]);
+      lo = fuse_lo_.data();
+      mask1 = m->mask;
+      mem1 = PB_HOST;
+    }
+    rc = pb_step_legodo_correct(ctx, imu->imu_block.p, lo, mask1, q, mem1, kind, o->measurement.p, o->measurement_cov,
+                                o->r_kind, o->orientation.p, o->mask, o->measurement.mem);
+    return true;
+  }
   // imu followed by a velocity measurement LegOdoCommon's lin_rate mode produces -> one pb_step_legodo; false = not fusible
   bool run_fused(RBISIMUProcessStep *imu, RBISUpdateInterface *next, int &rc)
   {
@@ -638,7 +760,7 @@ private:
     if (history_slots == 0) {  // in-order only: keep just the head
       auto last = map.end();
       --last;
-      if (holding_) --last;    // the newest element is an INS step that has not been applied: the head is before it
+      for (int h = 0; h < holding_; h++) --last;  // held-back updates have not been applied: the head is before them
       erase_before(last);
       return;
     }
@@ -1522,9 +1644,9 @@ public:
   std::vector<double> cov_fovis;  // diagonal
   int64_t prev_t0_body_utime_ = 0;
   int slot;                       // device snapshot slot holding the filter posterior at prev_timestamp
-  double *d_q = nullptr, *d_z6 = nullptr;  // device scratch: composed orientation [4][B], z [6][B] (rows 3-5 zero)
-  uint8_t *d_valid = nullptr;              // device copy of msg->estimate_valid [B]
-  pb_ctx *owner = nullptr;
+  // one device block per update, owned by that update and recycled through this pool when the history drops it:
+  // z [6][B] (rows 3-5 stay zero) | composed orientation [4][B] | copy of msg->estimate_valid [B]
+  std::shared_ptr<DevicePool> pool;
 
   explicit FovisHandler(BotParam *param, int snapshot_slot = 0) : slot(snapshot_slot)
   {
@@ -1557,15 +1679,6 @@ public:
       }
     }
   }
-  ~FovisHandler()
-  {
-    if (owner) {
-      pb_free(owner, d_q);
-      pb_free(owner, d_z6);
-      pb_free(owner, d_valid);
-    }
-  }
-
   // The estimator calls this when the posterior at a future `prev_timestamp` is the head: the device-side
   // replacement of history.updateMap.lower_bound(prev_timestamp) (rbis_fovis_update.cpp:184-207).
   void markKeyframe(MavStateEstimator *est)
@@ -1601,8 +1714,9 @@ public:
       if (bcast) u->measurement.mem = PB_HOST_BROADCAST;
       return u;
     }
-    // position / position_orient: T1 = T0(posterior at prev_timestamp) * (t, q)
-    est->flushPending();
+    // position / position_orient: T1 = T0(posterior at prev_timestamp) * (t, q).  T0 comes from a checkpoint (history) or
+    // from the snapshot markKeyframe() took, never from the head: updates the estimator is holding back for fusion
+    // (fuse_ins_legodo / fuse_corrections) stay held, so that this measurement can ride in the same kernel.
     if (est->history_slots > 0 && msg->prev_timestamp != prev_t0_body_utime_) {
       // The reference's own look-up (:177-213): the posterior of the first update at or after prev_timestamp, at most
       // 25 ms later, becomes the cached T0 -- here: copied from that update's checkpoint into the snapshot slot.
@@ -1634,13 +1748,21 @@ public:
       fprintf(stdout, "FOIVS: time difference for VO delta root pose is too great (%fsec). Will not use\n", diff);  // :186-189
       return nullptr;
     }
-    if (!owner) {
-      owner = est->ctx;
-      pb_malloc(owner, sizeof(double) * 4 * B, (void **) &d_q);
-      pb_malloc(owner, sizeof(double) * 6 * B, (void **) &d_z6);
-      pb_malloc(owner, (size_t) B, (void **) &d_valid);
+    // The measurement (T1's translation and rotation) is formed on the device and belongs to THIS update: a later message
+    // must not overwrite it, because the history re-applies the update when an older measurement arrives late.
+    if (!pool) pool = std::make_shared<DevicePool>(est->ctx, est->ctx_alive, sizeof(double) * 10 * (size_t) B + (size_t) B);
+    bool fresh = false;
+    void *blk = pool->get(fresh);
+    if (blk == nullptr) {
+      fprintf(stderr, "FovisHandler: %s\n", pb_last_error(est->ctx));
+      return nullptr;
+    }
+    auto block = std::make_shared<DeviceBlock>(pool, blk);
+    double *d_z6 = (double *) blk, *d_q = d_z6 + (size_t) 6 * B;
+    uint8_t *d_valid = (uint8_t *) (d_q + (size_t) 4 * B);
+    if (fresh) {  // rows 3..5 of z are never written again: z at chi indices is ignored (rbis.cpp:203-205)
       std::vector<double> zero((size_t) 6 * B, 0.0);
-      pb_memcpy_h2d(owner, d_z6, zero.data(), sizeof(double) * 6 * B);
+      pb_memcpy_h2d(est->ctx, d_z6, zero.data(), sizeof(double) * 6 * B);
     }
     if (pb_compose_delta(est->ctx, slot, msg->translation.p, msg->rotation.p, d_z6, d_q, msg->translation.mem) != PB_OK) {
       fprintf(stderr, "FovisHandler: %s\n", pb_last_error(est->ctx));
@@ -1648,16 +1770,21 @@ public:
     }
     const uint8_t *valid = nullptr;  // the composed z / q live on the device, so does the mask that goes with them
     if (msg->estimate_valid != nullptr && msg->translation.mem != PB_HOST_BROADCAST) {  // broadcast: all valid here
-      pb_memcpy_h2d(owner, d_valid, msg->estimate_valid, (size_t) B);
+      pb_memcpy_h2d(est->ctx, d_valid, msg->estimate_valid, (size_t) B);
       valid = d_valid;
     }
+    RBISIndexedMeasurement *u;
     if (mode == MODE_POSITION)
-      return new RBISIndexedMeasurement(RBIS::positionInds(), BatchArray(d_z6, PB_DEVICE), cov_fovis.data(), PB_R_DIAG_BROADCAST,
-                                        valid, RBISUpdateInterface::fovis, msg->timestamp);
-    // rows 3..5 of d_z6 stay zero: z at chi indices is ignored (rbis.cpp:203-205)
-    return new RBISIndexedPlusOrientationMeasurement(z_indices, BatchArray(d_z6, PB_DEVICE), cov_fovis.data(), PB_R_DIAG_BROADCAST,
-                                                     BatchArray(d_q, PB_DEVICE), valid, RBISUpdateInterface::fovis,
-                                                     msg->timestamp);
+      u = new RBISIndexedMeasurement(RBIS::positionInds(), BatchArray(d_z6, PB_DEVICE), cov_fovis.data(), PB_R_DIAG_BROADCAST,
+                                     valid, RBISUpdateInterface::fovis, msg->timestamp);
+    else
+      u = new RBISIndexedPlusOrientationMeasurement(z_indices, BatchArray(d_z6, PB_DEVICE), cov_fovis.data(), PB_R_DIAG_BROADCAST,
+                                                    BatchArray(d_q, PB_DEVICE), valid, RBISUpdateInterface::fovis,
+                                                    msg->timestamp);
+    u->owned_dev = block;
+    u->owned_R = cov_fovis;  // the update owns its R too (the reference copies cov_fovis into the update object)
+    u->measurement_cov = u->owned_R.data();
+    return u;
   }
 };
 

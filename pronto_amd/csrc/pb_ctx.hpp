@@ -43,6 +43,7 @@ struct pb_ctx {
   bool have_state = false;
   bool coop15 = false;  // PRONTO_BATCH_COOP15=1: run the 15-state step on the two-wave cooperative kernel (A/B switch)
   int mem_hint = 0;     // MH_* cache policy of the step kernels' state round trip (PRONTO_BATCH_MEMHINT=0/1/2 forces it)
+  bool generic_update = false;  // PRONTO_BATCH_GENERIC_UPDATE=1: every stand-alone update on the run-time-index kernel (A/B, tests)
   bool smooth_attr = false;  // dynamic-LDS limit of the smoother kernels raised on this device
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   char err[512] = { 0 };
@@ -92,10 +93,17 @@ inline void update_done(pb_ctx *c, double *target)
 // pb_step.hip: predict (update = false) or predict + leg-odometry update on the kernel pb_create picked
 int pbk_step(pb_ctx *c, bool update, const double *imu, const double *lo, const uint8_t *mask, const double q[4]);
 int pbk_replay_fused(pb_ctx *c, int T, const double *imu, const double *lo, const uint8_t *mask, const double q[4]);
+// predict + leg-odometry update + a second (orientation) update in one state round trip; corr_kind = enum pb_corr
+int pbk_step_correct(pb_ctx *c, int corr_kind, const double *imu, const double *lo, const uint8_t *mask, const double q[4],
+                     const double *z2, const double *r2, const double *rb2, const double *qm2, const uint8_t *mask2);
 // pb_update15.hip / pb_update21.hip: generic indexed (+ orientation, qm != NULL) update, m = 1..6
 int pbk_update15(pb_ctx *c, int m, const int *idx, const double *z, const double *R, int rkind, const double *rb,
                  const double *qm, const uint8_t *mask);
 int pbk_update21(pb_ctx *c, int m, const int *idx, const double *z, const double *R, int rkind, const double *rb,
                  const double *qm, const uint8_t *mask);
+// pb_update_ct.hip: the same update on the cooperative mapping when idx is one of the handlers' lists and R is diagonal
+// (r2 = [m][B] device diagonal or NULL with rb2 = m broadcast values); -1 = no such kernel, use pbk_update15/21
+int pbk_update_ct(pb_ctx *c, int m, const int *idx, const double *z, const double *r2, const double *rb2, const double *qm,
+                  const uint8_t *mask);
 // pb_smooth.hip
 int pbk_smooth_step(pb_ctx *c, const double *next_pred, const double *next_sm, const double *cur, double *out, double dt);

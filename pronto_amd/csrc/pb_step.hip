@@ -6,13 +6,13 @@ static void launch_step_mh(pb_ctx *c, double *out, const double *imu, const doub
 {
   const int B = c->B;
   if (c->ns == 15 && c->coop15) {
-    k_step_coop<15, UPDATE, MH><<<nblk(B), 128, 0, c->stream>>>(c->st, out, B, imu, lo, mask, q[0], q[1], q[2], q[3], c->k);
+    k_step_coop<15, UPDATE, MH><<<nblk(B), 128, 0, c->stream>>>(c->st, out, B, imu, lo, mask, q[0], q[1], q[2], q[3], c->k, CorrArgs());
   } else if (c->ns == 15) {
     k_step<15, UPDATE, MH><<<(B + PB_STEP_BLOCK - 1) / PB_STEP_BLOCK, PB_STEP_BLOCK, 0, c->stream>>>(c->st, out, B, imu, lo, mask, q[0], q[1], q[2], q[3], c->k);
   } else {
     // n = 21: 231 packed covariance entries do not fit one lane's registers; the step runs on the two-wave
     // cooperative kernel (rbis_coop.hpp): one launch, one state round trip.
-    k_step_coop<21, UPDATE, MH><<<nblk(B), 128, 0, c->stream>>>(c->st, out, B, imu, lo, mask, q[0], q[1], q[2], q[3], c->k);
+    k_step_coop<21, UPDATE, MH><<<nblk(B), 128, 0, c->stream>>>(c->st, out, B, imu, lo, mask, q[0], q[1], q[2], q[3], c->k, CorrArgs());
   }
 }
 
@@ -40,5 +40,53 @@ int pbk_replay_fused(pb_ctx *c, int T, const double *imu, const double *lo, cons
 {
   k_replay_fused<15><<<nblk(c->B), 64, 0, c->stream>>>(c->st, c->B, T, imu, lo, mask, q[0], q[1], q[2], q[3], c->k);
   LAUNCHCHK(c);
+  return PB_OK;
+}
+
+// predict + leg-odometry update + one more (orientation) update in ONE state round trip on the cooperative kernel
+template <int NS, int MH, class CORR>
+static void launch_corr(pb_ctx *c, double *out, const double *imu, const double *lo, const uint8_t *mask, const double q[4],
+                        const CorrArgs &ca)
+{
+  k_step_coop<NS, true, MH, CORR><<<nblk(c->B), 128, 0, c->stream>>>(c->st, out, c->B, imu, lo, mask, q[0], q[1], q[2], q[3], c->k, ca);
+}
+template <int NS, class CORR>
+static void launch_corr_mh(pb_ctx *c, double *out, const double *imu, const double *lo, const uint8_t *mask, const double q[4],
+                           const CorrArgs &ca)
+{
+  switch (c->mem_hint) {
+  case MH_STORE_SC1: launch_corr<NS, MH_STORE_SC1, CORR>(c, out, imu, lo, mask, q, ca); break;
+  case MH_STREAM_NT: launch_corr<NS, MH_STREAM_NT, CORR>(c, out, imu, lo, mask, q, ca); break;
+  default: launch_corr<NS, MH_DEFAULT, CORR>(c, out, imu, lo, mask, q, ca); break;
+  }
+}
+
+int pbk_step_correct(pb_ctx *c, int corr_kind, const double *imu, const double *lo, const uint8_t *mask, const double q[4],
+                     const double *z2, const double *r2, const double *rb2, const double *qm2, const uint8_t *mask2)
+{
+  if (c->ns == 21) {
+    // 21 states: role C's 15 x 15 sub-matrix already fills the register file (256 VGPR + 242 AGPR for the plain step); a
+    // second update stage in the same kernel spills 550-690 bytes per lane and measured SLOWER than two launches.  Same
+    // arithmetic as two launches: the fused step, then the correction alone on the cooperative update kernel.
+    int rc = pbk_step(c, true, imu, lo, mask, q);
+    if (rc) return rc;
+    static const int idx_po[6] = { 9, 10, 11, 6, 7, 8 }, idx_py[4] = { 9, 10, 11, 8 };
+    const int m2 = (corr_kind == PB_CORR_POS_ORIENT) ? 6 : 4;
+    const int *idx2 = (corr_kind == PB_CORR_POS_ORIENT) ? idx_po : idx_py;
+    const int slot = pb_head_slot(c);  // a checkpointed step: the correction lands in the same slot
+    if (slot >= 0) c->out_slot = slot;
+    rc = pbk_update_ct(c, m2, idx2, z2, r2, rb2, qm2, mask2);
+    if (rc >= 0) return rc;
+    return pbk_update21(c, m2, idx2, z2, r2 ? r2 : rb2, r2 ? PB_R_DIAG : PB_R_DIAG_BROADCAST, r2 ? nullptr : rb2, qm2, mask2);
+  }
+  CorrArgs ca;
+  ca.z2 = z2; ca.r2 = r2; ca.qm2 = qm2; ca.mask2 = mask2;
+  if (rb2)
+    for (int i = 0; i < 6; i++) ca.rb2[i] = rb2[i];
+  double *out = update_target(c);
+  if (corr_kind == PB_CORR_POS_ORIENT) launch_corr_mh<15, CorrPosOrient>(c, out, imu, lo, mask, q, ca);
+  else launch_corr_mh<15, CorrPosYaw>(c, out, imu, lo, mask, q, ca);
+  LAUNCHCHK(c);
+  update_done(c, out);
   return PB_OK;
 }

@@ -1,0 +1,82 @@
+// pb_update_ct.hip -- stand-alone indexed (+ orientation) updates whose index list is one the handlers actually produce
+// (compile-time core indices, diagonal R): they run on the two-role cooperative mapping (k_step_coop with PREDICT = false,
+// rbis_coop.hpp) -- one coalesced round trip of the state, no column gather -- instead of the generic run-time-index kernel
+// k_update.  See pb_ctx.hpp.
+#include "pb_ctx.hpp"
+
+template <int NS, int MH, class CORR>
+static void launch_ct(pb_ctx *c, double *out, const CorrArgs &ca)
+{
+  k_step_coop<NS, false, MH, CORR, false><<<nblk(c->B), 128, 0, c->stream>>>(c->st, out, c->B, nullptr, nullptr, nullptr, 0.0, 0.0,
+                                                                             0.0, 0.0, c->k, ca);
+}
+template <class CORR>
+static void launch_ct_mh(pb_ctx *c, double *out, const CorrArgs &ca)
+{
+  if constexpr (CORR::M > 4) {  // 21-state variants of these are never launched (see pbk_update_ct): do not build them
+    switch (c->mem_hint) {
+    case MH_STORE_SC1: launch_ct<15, MH_STORE_SC1, CORR>(c, out, ca); break;
+    case MH_STREAM_NT: launch_ct<15, MH_STREAM_NT, CORR>(c, out, ca); break;
+    default: launch_ct<15, MH_DEFAULT, CORR>(c, out, ca); break;
+    }
+    return;
+  }
+  if (c->ns == 15) {
+    switch (c->mem_hint) {
+    case MH_STORE_SC1: launch_ct<15, MH_STORE_SC1, CORR>(c, out, ca); break;
+    case MH_STREAM_NT: launch_ct<15, MH_STREAM_NT, CORR>(c, out, ca); break;
+    default: launch_ct<15, MH_DEFAULT, CORR>(c, out, ca); break;
+    }
+  } else {
+    switch (c->mem_hint) {
+    case MH_STORE_SC1: launch_ct<21, MH_STORE_SC1, CORR>(c, out, ca); break;
+    case MH_STREAM_NT: launch_ct<21, MH_STREAM_NT, CORR>(c, out, ca); break;
+    default: launch_ct<21, MH_DEFAULT, CORR>(c, out, ca); break;
+    }
+  }
+}
+
+static bool same(const int *idx, int m, std::initializer_list<int> l)
+{
+  if ((int) l.size() != m) return false;
+  int i = 0;
+  for (int v : l)
+    if (idx[i++] != v) return false;
+  return true;
+}
+
+// returns PB_OK after a launch, -1 when this (idx, R kind, orientation) combination has no compile-time kernel
+int pbk_update_ct(pb_ctx *c, int m, const int *idx, const double *z, const double *r2, const double *rb2, const double *qm,
+                  const uint8_t *mask)
+{
+  CorrArgs ca;
+  ca.z2 = z; ca.r2 = r2; ca.qm2 = qm; ca.mask2 = mask;
+  if (rb2)
+    for (int i = 0; i < m; i++) ca.rb2[i] = rb2[i];
+  const bool orient = qm != nullptr;
+  int which = -1;
+  if (same(idx, m, { 3, 4, 5 })) which = 0;
+  else if (same(idx, m, { 9, 10, 11 })) which = 1;
+  else if (same(idx, m, { 9, 10, 11, 3, 4, 5 })) which = 2;
+  else if (orient && same(idx, m, { 9, 10, 11, 6, 7, 8 })) which = 3;
+  else if (orient && same(idx, m, { 9, 10, 11, 8 })) which = 4;
+  else if (orient && same(idx, m, { 3, 4, 5, 8 })) which = 5;
+  else if (orient && same(idx, m, { 8 })) which = 6;
+  if (which < 0) return -1;
+  // 21 states with six measurement rows: role C's sub-matrix plus the second-stage temporaries spill (268-324 bytes per
+  // lane); the generic kernel streams the covariance instead and has no scratch
+  if (c->ns == 21 && m > 4) return -1;
+  double *out = update_target(c);
+  switch (which) {
+  case 0: launch_ct_mh<CorrVel>(c, out, ca); break;
+  case 1: launch_ct_mh<CorrPos>(c, out, ca); break;
+  case 2: launch_ct_mh<CorrPosVel>(c, out, ca); break;
+  case 3: launch_ct_mh<CorrPosOrient>(c, out, ca); break;
+  case 4: launch_ct_mh<CorrPosYaw>(c, out, ca); break;
+  case 5: launch_ct_mh<CorrVelYaw>(c, out, ca); break;
+  default: launch_ct_mh<CorrYaw>(c, out, ca); break;
+  }
+  LAUNCHCHK(c);
+  update_done(c, out);
+  return PB_OK;
+}

@@ -43,16 +43,18 @@ extern "C" int pb_create(pb_ctx **out, int n_states, int batch, int device, int 
   c->nc = (n_states == 15) ? Lay<15>::NC : Lay<21>::NC;
   c->state_doubles = (size_t) c->stride * (size_t) ((n_states == 15) ? Slots<15>::NSLOT : Slots<21>::NSLOT);
   {
-    // XCD-contiguous workgroup order for the cooperative kernel: measured 1-5 % faster at every 15-state batch size,
-    // and for 21 states only while the state (135 MB at 64k filters) sits well inside the 256 MB memory-side cache
-    // (3-15 % slower beyond).  PRONTO_BATCH_XCD=0/1 forces it either way for A/B runs.
+    // XCD-contiguous tile order: each of the 8 XCDs walks one contiguous range of tiles instead of every 8th tile.  With
+    // the tiled layout it measured equal or faster for both state sizes at every batch size (n = 21 at 192k filters:
+    // 162 -> 146 us).  PRONTO_BATCH_XCD=0/1 forces it either way for A/B runs.
     const char *e = getenv("PRONTO_BATCH_XCD");
-    c->k.xcd_remap = e ? (e[0] == '1') : (n_states == 15 || (long) c->state_doubles * 8 <= (160L << 20));
+    c->k.xcd_remap = e ? (e[0] == '1') : 1;
     // Cache policy of the state round trip (rbis_kernels.hpp MemHint), measured on both step kernels: a state that
     // fits the XCDs' L2s (< ~48 MB) wants the default policy (sc1 stores 7 % slower at 32k x 15 states); up to ~1.3x
     // the 256 MB memory-side cache sc1 stores are 1-4 % faster; beyond, non-temporal loads+stores are 7-15 % faster
     // (1M filters: 469 -> 417 us) and 10-40 % SLOWER if used on a cache-sized state.  PRONTO_BATCH_MEMHINT=0/1/2 forces.
     const long state_bytes = (long) c->state_doubles * 8;
+    const char *gu = getenv("PRONTO_BATCH_GENERIC_UPDATE");
+    c->generic_update = gu && gu[0] == '1';
     const char *h = getenv("PRONTO_BATCH_MEMHINT");
     c->mem_hint = h ? (h[0] - '0')
                     : (state_bytes < (48L << 20) ? MH_DEFAULT : state_bytes < (340L << 20) ? MH_STORE_SC1 : MH_STREAM_NT);
@@ -363,6 +365,36 @@ extern "C" int pb_step_legodo(pb_ctx *c, const double *imu_block, const double *
   return pbk_step(c, true, (const double *) p[0].dev, (const double *) p[1].dev, (const uint8_t *) p[2].dev, q);
 }
 
+extern "C" int pb_step_legodo_correct(pb_ctx *c, const double *imu_block, const double *lo_block, const uint8_t *mask,
+                                      const double q[4], int mem, int corr_kind, const double *z2, const double *R2,
+                                      int r_kind2, const double *quat_meas2, const uint8_t *mask2, int mem2)
+{
+  ENTER(c);
+  NEED_STATE(c);
+  if (!imu_block || !lo_block || !q || !z2 || !R2 || !quat_meas2) return fail(c, PB_ERR_ARG, "pb_step_legodo_correct: NULL input");
+  if (corr_kind != PB_CORR_POS_ORIENT && corr_kind != PB_CORR_POS_YAW) return fail(c, PB_ERR_ARG, "pb_step_legodo_correct: bad corr_kind %d", corr_kind);
+  if (mem2 == PB_HOST_BROADCAST && r_kind2 == PB_R_DIAG) r_kind2 = PB_R_DIAG_BROADCAST;
+  if (r_kind2 != PB_R_DIAG && r_kind2 != PB_R_DIAG_BROADCAST) return fail(c, PB_ERR_ARG, "pb_step_legodo_correct: R2 must be diagonal (PB_R_DIAG or PB_R_DIAG_BROADCAST)");
+  const int m2 = (corr_kind == PB_CORR_POS_ORIENT) ? 6 : 4;
+  const size_t B = (size_t) c->B;
+  const bool rbc = r_kind2 == PB_R_DIAG_BROADCAST;
+  Part p[7] = { { imu_block, sizeof(double) * 7 * B, 0 }, { lo_block, sizeof(double) * 6 * B, 0 }, { mask, B, 0 },
+                { z2, sizeof(double) * m2 * B, 0 }, { rbc ? nullptr : R2, rbc ? 0 : sizeof(double) * m2 * B, 0 },
+                { quat_meas2, sizeof(double) * 4 * B, 0 }, { mask2, B, 0 } };
+  // one staging call when both groups live in the same space (the double-buffered host staging must not be flipped twice
+  // before its consumer is enqueued); otherwise at most one of the two groups is PB_HOST
+  int rc;
+  if (mem == mem2) rc = stage_in(c, mem, p, 7);
+  else {
+    rc = stage_in(c, mem, p, 3);
+    if (!rc) rc = stage_in(c, mem2, p + 3, 4);
+  }
+  if (rc) return rc;
+  return pbk_step_correct(c, corr_kind, (const double *) p[0].dev, (const double *) p[1].dev, (const uint8_t *) p[2].dev, q,
+                          (const double *) p[3].dev, (const double *) p[4].dev, rbc ? R2 : nullptr, (const double *) p[5].dev,
+                          (const uint8_t *) p[6].dev);
+}
+
 extern "C" int pb_run_legodo(pb_ctx *c, int n_steps, const double *imu_stream, const double *lo_stream,
                              const uint8_t *mask_stream, const double q[4], float *elapsed_ms)
 {
@@ -461,6 +493,13 @@ static int update_common(pb_ctx *c, int m, const int *idx, const double *z, cons
                 { orient ? qm : nullptr, sizeof(double) * 4 * B, 0 }, { mask, B, 0 } };
   int rc = stage_in(c, mem, p, 4);
   if (rc) return rc;
+  // the handlers' own index lists with a diagonal R run on the cooperative two-role kernel (no column gather);
+  // PRONTO_BATCH_GENERIC_UPDATE=1 forces the run-time-index kernel for A/B runs and tests
+  if (!c->generic_update && (rkind == PB_R_DIAG || rkind == PB_R_DIAG_BROADCAST)) {
+    rc = pbk_update_ct(c, m, idx, (const double *) p[0].dev, rb ? nullptr : (const double *) p[1].dev, rb,
+                       (const double *) p[2].dev, (const uint8_t *) p[3].dev);
+    if (rc >= 0) return rc;
+  }
   if (c->ns == 15)
     return pbk_update15(c, m, idx, (const double *) p[0].dev, (const double *) p[1].dev, rkind, rb,
                         (const double *) p[2].dev, (const uint8_t *) p[3].dev);

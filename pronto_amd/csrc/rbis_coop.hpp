@@ -100,16 +100,56 @@ struct StepInputs {
   double qg, qa, qbg, qba;
 };
 
+// A SECOND measurement applied in the same state round trip, behind the leg-odometry update: what the reference does as
+// a third updateFilter call when a visual-odometry or scan-match message follows the IMU / leg-odometry pair
+// (rbis_fovis_update.cpp:299-305, sensor_handlers.cpp:689-724).  Its indices are a compile-time list of CORE sub indices
+// (v 0-2, chi 3-5, Delta 6-8, gyro bias 9-11, accel bias 12-14); chi entries take the orientation residual
+// (indexedPlusOrientationMeasurement, rbis.cpp:189-217); R is diagonal.
+template <bool ORIENT_, int... SUB>
+struct Corr {
+  static constexpr int M = (int) sizeof...(SUB);
+  static constexpr bool ORIENT = ORIENT_;
+  static constexpr int MM = M > 0 ? M : 1;
+  static constexpr int sub[MM] = { SUB... };
+};
+using NoCorr = Corr<false>;
+using CorrPosOrient = Corr<true, 6, 7, 8, 3, 4, 5>;  // idx 9,10,11,6,7,8: FovisHandler position_orient, ViconHandler
+using CorrPosYaw = Corr<true, 6, 7, 8, 5>;           // idx 9,10,11,8:     ScanMatcherHandler position_yaw
+using CorrVelYaw = Corr<true, 0, 1, 2, 5>;           // idx 3,4,5,8:       ScanMatcherHandler velocity_yaw
+using CorrYaw = Corr<true, 5>;                       // idx 8:             ScanMatcherHandler yaw
+using CorrVel = Corr<false, 0, 1, 2>;                // idx 3,4,5:         LegOdoCommon lin_rate, Fovis / ScanMatcher velocity
+using CorrPos = Corr<false, 6, 7, 8>;                // idx 9,10,11:       GpsHandler, Fovis / ScanMatcher position
+using CorrPosVel = Corr<false, 6, 7, 8, 0, 1, 2>;    // idx 9,10,11,3,4,5: LegOdoCommon pos_and_lin_rate
+struct CorrInputs {
+  double z[6], rd[6], qm[4];
+  bool upd;
+};
+// LDS hand-off of the second update, behind the first one's: L2 (strict lower, packed by rows), id2, yd2, W2 rows, [lli2]
+template <int NS, class CORR>
+struct CoopX {
+  using C = Coop<NS>;
+  static constexpr int M = CORR::M;
+  static constexpr int X2_L = C::NXCH, X2_ID = X2_L + M * (M - 1) / 2, X2_YD = X2_ID + M, X2_W = X2_YD + M,
+                       X2_LLI = X2_W + C::NSC * M;
+  static constexpr int NXCH = (M == 0) ? C::NXCH : X2_LLI + (C::LL_IN_P ? 1 : 0);
+};
+
 // ------------------------------------------------------------------------------------------------------------
 // role C: (c,b) sub-matrix, state, quaternion, log-likelihood
 //   LD(comp) -> double, ST(comp, v), XW(slot, v) writes the hand-off, SYNC() is the workgroup barrier
 // ------------------------------------------------------------------------------------------------------------
-template <int NS, bool UPDATE, class LD, class ST, class XW, class SYNC>
-PB_HD void coop_role_core(LD ld, ST st, XW xw, SYNC sync, const StepInputs &in, const Consts &k)
+// What one launch does is three compile-time switches: PREDICT (the IMU process step), UPDATE (the leg-odometry velocity
+// update behind it), CORR (one more measurement with compile-time core indices).  PREDICT + UPDATE is the BASELINE hot step;
+// CORR alone is a stand-alone indexed / indexed+orientation update on the same two-role mapping.
+template <int NS, bool UPDATE, class CORR = NoCorr, bool PREDICT = true, class LD, class ST, class XW, class XR, class SYNC>
+PB_HD void coop_role_core(LD ld, ST st, XW xw, XR xr, SYNC sync, const StepInputs &in, const Consts &k,
+                          const CorrInputs &cin = CorrInputs())
 {
   using L = Lay<NS>;
   using C = Coop<NS>;
   constexpr int NSC = C::NSC;
+  static_assert(PREDICT || !UPDATE, "the leg-odometry update rides behind a predict");
+  static_assert(PREDICT || CORR::M > 0, "nothing to do");
   double x[NS], q[4], ll = 0.0;
 #pragma unroll
   for (int i = 0; i < NS; i++) x[i] = ld(L::OFF_VEC + i);
@@ -122,6 +162,7 @@ PB_HD void coop_role_core(LD ld, ST st, XW xw, SYNC sync, const StepInputs &in, 
 #pragma unroll
     for (int j = 0; j <= i; j++) Pc[pk(i, j)] = ld(L::OFF_P + pk(C::fullc(i), C::fullc(j)));
 
+  if constexpr (PREDICT) {
   // ---- covariance propagate on the sub-matrix (blocks: v=0 chi=1 Delta=2 bg=3 ba=4) ----
   ProcBlocks f;
   make_proc_blocks<NS>(x, q, in.dt, k, f);
@@ -186,6 +227,7 @@ PB_HD void coop_role_core(LD ld, ST st, XW xw, SYNC sync, const StepInputs &in, 
   }
   // ---- state propagate (rbis.cpp:37-75); omega/accel entries are role P's to store ----
   ins_update_state<NS>(x, q, in.gyro, in.accel, in.dt, k);
+  }  // PREDICT
 
   if constexpr (UPDATE) {
     // S = R + P[v,v]; unpivoted LDL^T; y = L^-1 r  (rbis.cpp:124-143)
@@ -246,11 +288,94 @@ PB_HD void coop_role_core(LD ld, ST st, XW xw, SYNC sync, const StepInputs &in, 
         double acc = Pc[pk(i, j)];
 #pragma unroll
         for (int kk = 0; kk < 3; kk++) acc = fma(-wd[kk], W[j][kk], acc);
-        st(L::OFF_P + pk(C::fullc(i), C::fullc(j)), acc);
+        if constexpr (CORR::M == 0) st(L::OFF_P + pk(C::fullc(i), C::fullc(j)), acc);
+        else Pc[pk(i, j)] = acc;  // row i of W is not needed for any later row j' > i's column i: W[i] stays as is
       }
     }
     if (in.upd) add_delta<NS>(x, q, dfull, k.chi_tol);
-  } else {
+  }
+  if constexpr (CORR::M > 0) {
+    // ---- the second update on the posterior of the first (indexedPlusOrientationMeasurement, rbis.cpp:189-217) ----
+    constexpr int M = CORR::M;
+    using CX = CoopX<NS, CORR>;
+    double r2[M], S2[M * (M + 1) / 2], d2[M], y2[M], id2[M], yd2[M];
+    double dq3[3] = { 0.0, 0.0, 0.0 };
+    if constexpr (CORR::ORIENT) subtract_quats(cin.qm, q, dq3);
+#pragma unroll
+    for (int kk = 0; kk < M; kk++) {
+      const int ii = C::fullc(CORR::sub[kk]);
+      const double r = (CORR::ORIENT && ii >= 6 && ii <= 8) ? dq3[ii - 6] : cin.z[kk] - x[ii];
+      r2[kk] = cin.upd ? r : 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < M; i++)
+#pragma unroll
+      for (int j = 0; j <= i; j++)
+        S2[pk(i, j)] = Pc[pk(CORR::sub[i], CORR::sub[j])] + (i == j ? (cin.upd ? cin.rd[i] : 1.0) : 0.0);
+    ldlt<M>(S2, d2);
+    double quad2 = 0.0, det2 = 1.0;
+#pragma unroll
+    for (int kk = 0; kk < M; kk++) {
+      double s2 = r2[kk];
+#pragma unroll
+      for (int j = 0; j < kk; j++) s2 -= S2[pk(kk, j)] * y2[j];
+      y2[kk] = cin.upd ? s2 : 0.0;
+      id2[kk] = cin.upd ? 1.0 / d2[kk] : 0.0;
+      yd2[kk] = y2[kk] * id2[kk];
+      det2 *= d2[kk];
+      quad2 += s2 * s2 * id2[kk];
+    }
+    const double lli2 = -log(det2) - quad2;
+    if constexpr (C::LL_IN_P) xw(CX::X2_LLI, lli2);
+    else if (cin.upd) ll += lli2;
+    // W2 = P[:, idx2] L2^-T row by row, published as it is formed.  n = 21: the 15 x 15 sub-matrix (240 registers) and W2
+    // (15 x M) do not fit together, so W2 is NOT kept: the downdate below reads its rows back from the hand-off area
+    // (this wave's own LDS writes are in order); n = 15 keeps it in registers.
+    constexpr bool W2_LDS = C::HB;
+    double W2[W2_LDS ? 1 : NSC][M];
+    double dfull2[NS];
+#pragma unroll
+    for (int i = 0; i < NS; i++) dfull2[i] = 0.0;
+#pragma unroll
+    for (int i = 1; i < M; i++)
+#pragma unroll
+      for (int j = 0; j < i; j++) xw(CX::X2_L + i * (i - 1) / 2 + j, S2[pk(i, j)]);
+#pragma unroll
+    for (int kk = 0; kk < M; kk++) { xw(CX::X2_ID + kk, id2[kk]); xw(CX::X2_YD + kk, yd2[kk]); }
+#pragma unroll
+    for (int i = 0; i < NSC; i++) {
+      double w2[M], dxs = 0.0;
+#pragma unroll
+      for (int kk = 0; kk < M; kk++) {
+        double s2 = Pc[pk(i, CORR::sub[kk])];
+#pragma unroll
+        for (int j = 0; j < kk; j++) s2 -= w2[j] * S2[pk(kk, j)];
+        w2[kk] = s2;
+        xw(CX::X2_W + M * i + kk, s2);
+        dxs = (kk == 0) ? s2 * yd2[0] : fma(s2, yd2[kk], dxs);
+        if constexpr (!W2_LDS) W2[i][kk] = s2;
+      }
+      dfull2[C::fullc(i)] = dxs;
+    }
+    sync();
+#pragma unroll
+    for (int i = 0; i < NSC; i++) {
+      // (without the clobber the compiler shares every LDS read of W2 between the rows: all of W2 back in registers)
+      if constexpr (W2_LDS) reload_fence();
+      double wd2[M];
+#pragma unroll
+      for (int kk = 0; kk < M; kk++) wd2[kk] = (W2_LDS ? xr(CX::X2_W + M * i + kk) : W2[i][kk]) * id2[kk];
+#pragma unroll
+      for (int j = 0; j <= i; j++) {
+        double acc = Pc[pk(i, j)];
+#pragma unroll
+        for (int kk = 0; kk < M; kk++) acc = fma(-wd2[kk], W2_LDS ? xr(CX::X2_W + M * j + kk) : W2[j][kk], acc);
+        st(L::OFF_P + pk(C::fullc(i), C::fullc(j)), acc);
+      }
+    }
+    if (cin.upd) add_delta<NS>(x, q, dfull2, k.chi_tol);
+  }
+  if constexpr (!UPDATE && CORR::M == 0) {
 #pragma unroll
     for (int i = 0; i < NSC; i++)
 #pragma unroll
@@ -271,16 +396,24 @@ PB_HD void coop_role_core(LD ld, ST st, XW xw, SYNC sync, const StepInputs &in, 
 // ------------------------------------------------------------------------------------------------------------
 // role P: passive panels P_cp, P_bp, P_pp and the omega / accel entries of x.   XR(slot) reads the hand-off.
 // ------------------------------------------------------------------------------------------------------------
-template <int NS, bool UPDATE, class LD, class ST, class XR, class SYNC>
-PB_HD void coop_role_passive(LD ld, ST st, XR xr, SYNC sync, const StepInputs &in, const Consts &k)
+template <int NS, bool UPDATE, class CORR = NoCorr, bool PREDICT = true, class LD, class ST, class XR, class SYNC>
+PB_HD void coop_role_passive(LD ld, ST st, XR xr, SYNC sync, const StepInputs &in, const Consts &k,
+                             const CorrInputs &cin = CorrInputs())
 {
   using L = Lay<NS>;
   using C = Coop<NS>;
-  double x[NS], q[4];
+  double x[NS], q[4] = { 1.0, 0.0, 0.0, 0.0 };
 #pragma unroll
-  for (int i = 0; i < NS; i++) x[i] = ld(L::OFF_VEC + i);
+  for (int i = 0; i < NS; i++) x[i] = 0.0;
+  if constexpr (PREDICT) {  // the process blocks need the whole prior state
 #pragma unroll
-  for (int i = 0; i < 4; i++) q[i] = ld(L::OFF_QUAT + i);
+    for (int i = 0; i < NS; i++) x[i] = ld(L::OFF_VEC + i);
+#pragma unroll
+    for (int i = 0; i < 4; i++) q[i] = ld(L::OFF_QUAT + i);
+  } else {                  // a stand-alone update only moves this role's own omega / accel entries
+#pragma unroll
+    for (int i = 0; i < 6; i++) x[C::fullp(i)] = ld(L::OFF_VEC + C::fullp(i));
+  }
   // X[sb][J] = 3x3 block P(state block sb, passive block J), row-major; sb: v chi Delta [bg ba]; J: omega, accel
   constexpr int NSB = C::HB ? 5 : 3;
   double X[NSB][2][9];
@@ -300,6 +433,12 @@ PB_HD void coop_role_passive(LD ld, ST st, XR xr, SYNC sync, const StepInputs &i
   double ll = 0.0;
   if constexpr (C::LL_IN_P) ll = ld(L::OFF_LL);
 
+  double xp[6];
+  if constexpr (!PREDICT) {
+#pragma unroll
+    for (int i = 0; i < 6; i++) xp[i] = x[C::fullp(i)];
+  }
+  if constexpr (PREDICT) {
   ProcBlocks f;
   make_proc_blocks<NS>(x, q, in.dt, k, f);
   // panel propagate: all right-hand sides use the ORIGINAL blocks (Ad = E2 E1 E3)
@@ -333,14 +472,14 @@ PB_HD void coop_role_passive(LD ld, ST st, XR xr, SYNC sync, const StepInputs &i
       Ppp[pk(3 + r, 3 + c)] = (r == c) ? in.qa : 0.0;
     }
   // rbis.cpp:50-51
-  double xp[6];
 #pragma unroll
   for (int i = 0; i < 3; i++) {
     xp[i] = in.gyro[i] - (C::HB ? x[15 + i] : 0.0);
     xp[3 + i] = in.accel[i] - (C::HB ? x[18 + i] : 0.0);
   }
+  }  // PREDICT
 
-  if constexpr (!UPDATE) sync();  // pairs with role C's barrier before it overwrites x / quat
+  if constexpr (!UPDATE && CORR::M == 0) sync();  // pairs with role C's barrier before it overwrites x / quat
   if constexpr (UPDATE) {
     sync();
     const double L10 = xr(0), L20 = xr(1), L21 = xr(2);
@@ -377,7 +516,8 @@ PB_HD void coop_role_passive(LD ld, ST st, XR xr, SYNC sync, const StepInputs &i
             double acc = X[sb][J][3 * r + c];
 #pragma unroll
             for (int kk = 0; kk < 3; kk++) acc = fma(-wd[kk], Wp[3 * J + c][kk], acc);
-            st(L::OFF_P + pk(C::fullc(3 * sb + r), C::fullp(3 * J + c)), acc);
+            if constexpr (CORR::M == 0) st(L::OFF_P + pk(C::fullc(3 * sb + r), C::fullp(3 * J + c)), acc);
+            else X[sb][J][3 * r + c] = acc;
           }
         }
 #pragma unroll
@@ -390,10 +530,72 @@ PB_HD void coop_role_passive(LD ld, ST st, XR xr, SYNC sync, const StepInputs &i
         double acc = Ppp[pk(i, j)];
 #pragma unroll
         for (int kk = 0; kk < 3; kk++) acc = fma(-wd[kk], Wp[j][kk], acc);
+        if constexpr (CORR::M == 0) st(L::OFF_P + pk(C::fullp(i), C::fullp(j)), acc);
+        else Ppp[pk(i, j)] = acc;
+      }
+    }
+  }
+  if constexpr (CORR::M > 0) {
+    // ---- the second update: role C's factors and rows of W2 arrive through the second hand-off ----
+    constexpr int M = CORR::M;
+    using CX = CoopX<NS, CORR>;
+    sync();
+    double id2[M], yd2[M], L2[M * (M - 1) / 2 + 1];
+#pragma unroll
+    for (int i = 0; i < M * (M - 1) / 2; i++) L2[i] = xr(CX::X2_L + i);
+#pragma unroll
+    for (int kk = 0; kk < M; kk++) { id2[kk] = xr(CX::X2_ID + kk); yd2[kk] = xr(CX::X2_YD + kk); }
+    if constexpr (C::LL_IN_P) {
+      const double lli2 = xr(CX::X2_LLI);
+      if (cin.upd) ll += lli2;
+    }
+    // W2_p = P''[p, idx2] L2^-T with P''(p_i, core s) = X[s / 3][i / 3][(s % 3) * 3 + i % 3]
+    double W2p[6][M];
+#pragma unroll
+    for (int pi = 0; pi < 6; pi++) {
+      double dxs = 0.0;
+#pragma unroll
+      for (int kk = 0; kk < M; kk++) {
+        double s2 = X[CORR::sub[kk] / 3][pi / 3][(CORR::sub[kk] % 3) * 3 + pi % 3];
+#pragma unroll
+        for (int j = 0; j < kk; j++) s2 -= W2p[pi][j] * L2[kk * (kk - 1) / 2 + j];
+        W2p[pi][kk] = s2;
+        dxs = (kk == 0) ? s2 * yd2[0] : fma(s2, yd2[kk], dxs);
+      }
+      xp[pi] += dxs;
+    }
+#pragma unroll
+    for (int J = 0; J < 2; J++)
+#pragma unroll
+      for (int sb = 0; sb < NSB; sb++)
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+          double wd2[M];
+#pragma unroll
+          for (int kk = 0; kk < M; kk++) wd2[kk] = xr(CX::X2_W + M * (3 * sb + r) + kk) * id2[kk];
+#pragma unroll
+          for (int c = 0; c < 3; c++) {
+            double acc = X[sb][J][3 * r + c];
+#pragma unroll
+            for (int kk = 0; kk < M; kk++) acc = fma(-wd2[kk], W2p[3 * J + c][kk], acc);
+            st(L::OFF_P + pk(C::fullc(3 * sb + r), C::fullp(3 * J + c)), acc);
+          }
+        }
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+      double wd2[M];
+#pragma unroll
+      for (int kk = 0; kk < M; kk++) wd2[kk] = W2p[i][kk] * id2[kk];
+#pragma unroll
+      for (int j = 0; j <= i; j++) {
+        double acc = Ppp[pk(i, j)];
+#pragma unroll
+        for (int kk = 0; kk < M; kk++) acc = fma(-wd2[kk], W2p[j][kk], acc);
         st(L::OFF_P + pk(C::fullp(i), C::fullp(j)), acc);
       }
     }
-  } else {
+  }
+  if constexpr (!UPDATE && CORR::M == 0) {
 #pragma unroll
     for (int J = 0; J < 2; J++)
 #pragma unroll

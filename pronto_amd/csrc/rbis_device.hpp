@@ -46,6 +46,9 @@ struct Lay {
 // packed index of P(i,j): lower triangle, row-major
 PB_HD constexpr int pk(int i, int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
 
+// compiler-level memory clobber: loads behind it are re-issued instead of being shared with loads in front of it
+PB_HD void reload_fence() { asm volatile("" ::: "memory"); }
+
 // row / column of a packed index
 PB_HD constexpr int pk_row(int p)
 {

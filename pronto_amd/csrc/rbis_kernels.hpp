@@ -634,47 +634,79 @@ __global__ void k_summary(const double *__restrict__ st, int B, double *__restri
 // This is the 21-state hot kernel (231 packed entries do not fit one lane) and the default mapping for n = 15.
 // No lane returns before the barrier: lanes past the batch end work on the zero-initialised padding filters of the
 // last tile and on bounds-checked (zero) inputs.
-template <int NS, bool UPDATE, int MH = MH_DEFAULT>
+// inputs of the fused second update (CORR != NoCorr): z2 [M][B], R2 diagonal ([M][B], or broadcast values in rb2 when
+// r2 == nullptr), quaternion measurement [4][B] (ORIENT), mask2 [B] (0 = the handler returned NULL for this filter)
+struct CorrArgs {
+  const double *z2 = nullptr, *r2 = nullptr, *qm2 = nullptr;
+  const uint8_t *mask2 = nullptr;
+  double rb2[6] = { 0, 0, 0, 0, 0, 0 };
+};
+template <int NS, bool UPDATE, int MH = MH_DEFAULT, class CORR = NoCorr, bool PREDICT = true>
 __global__ __launch_bounds__(128, 1) void k_step_coop(const double *st, double *sto, int B,
                                                       const double *__restrict__ imu, const double *__restrict__ lo,
                                                       const uint8_t *__restrict__ mask, double qg, double qa,
-                                                      double qbg, double qba, Consts k)
+                                                      double qbg, double qba, Consts k, CorrArgs ca)
 {
   using C = Coop<NS>;
-  __shared__ double xch[UPDATE ? C::NXCH : 1][64];
+  __shared__ double xch[(UPDATE || CORR::M > 0) ? CoopX<NS, CORR>::NXCH : 1][64];
   const int role = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
   const unsigned lane = threadIdx.x & 63u;
   const unsigned tile = xcd_workgroup(k);
   const unsigned b = tile * 64u + lane;
   const unsigned bo = b * 8u, B8 = (unsigned) B * 8u;
   TileIO<NS, MemHint<MH>::LA, MemHint<MH>::SA> io(st, sto, tile, lane);
-  const rsrc_t ri = mkbuf(imu, 7u * B8);
+  const rsrc_t ri = mkbuf(imu, PREDICT ? 7u * B8 : 0u);
   const rsrc_t rl = mkbuf(lo, UPDATE ? 6u * B8 : 0u);
   StepInputs in;
 #pragma unroll
   for (int i = 0; i < 3; i++) {
-    in.gyro[i] = ldg(ri, i * B8, bo);
-    in.accel[i] = ldg(ri, (3 + i) * B8, bo);
+    in.gyro[i] = PREDICT ? ldg(ri, i * B8, bo) : 0.0;
+    in.accel[i] = PREDICT ? ldg(ri, (3 + i) * B8, bo) : 0.0;
     in.z[i] = UPDATE ? ldg(rl, i * B8, bo) : 0.0;
     in.rd[i] = UPDATE ? ldg(rl, (3 + i) * B8, bo) : 1.0;
   }
-  in.dt = ldg(ri, 6u * B8, bo);
+  in.dt = PREDICT ? ldg(ri, 6u * B8, bo) : 0.0;
   in.upd = UPDATE && (b < (unsigned) B) && (mask == nullptr || mask[b] != 0);
   in.qg = qg; in.qa = qa; in.qbg = qbg; in.qba = qba;
-  if (k.qblk != nullptr) {  // per-filter process noise (wave-uniform branch)
+  if (PREDICT && k.qblk != nullptr) {  // per-filter process noise (wave-uniform branch)
     const rsrc_t rq = mkbuf(k.qblk, 4u * B8);
     in.qg = ldg(rq, 0u, bo); in.qa = ldg(rq, B8, bo); in.qbg = ldg(rq, 2u * B8, bo); in.qba = ldg(rq, 3u * B8, bo);
+  }
+  CorrInputs cin;
+  if constexpr (CORR::M > 0) {
+    const rsrc_t rz = mkbuf(ca.z2, (unsigned) CORR::M * B8);
+    const rsrc_t rr = mkbuf(ca.r2, ca.r2 ? (unsigned) CORR::M * B8 : 0u);
+    const rsrc_t rq2 = mkbuf(ca.qm2, CORR::ORIENT ? 4u * B8 : 0u);
+#pragma unroll
+    for (int i = 0; i < CORR::M; i++) {
+      cin.z[i] = ldg(rz, i * B8, bo);
+      cin.rd[i] = ca.r2 ? ldg(rr, i * B8, bo) : ca.rb2[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) cin.qm[i] = CORR::ORIENT ? ldg(rq2, i * B8, bo) : 0.0;
+    cin.upd = (b < (unsigned) B) && (ca.mask2 == nullptr || ca.mask2[b] != 0);
   }
   auto ld = [&io](int comp) { return io.ld(comp); };
   auto stf = [&io](int comp, double v) { io.st(comp, v); };
   auto sync = []() { __syncthreads(); };
-  if (role == 0) {
+  auto xrd = [lane](int s) { return xch[s][lane]; };
+#ifdef PB_DBG_ONLY_ROLE  // register-pressure probe (scratch builds only): compile ONE role
+  if (PB_DBG_ONLY_ROLE == 0) {
     io.template need<0, Slots<NS>::ROW_SPLIT>();
-    coop_role_core<NS, UPDATE>(ld, stf, [lane](int s, double v) { xch[s][lane] = v; }, sync, in, k);
+    coop_role_core<NS, UPDATE, CORR, PREDICT>(ld, stf, [lane](int s, double v) { xch[s][lane] = v; }, xrd, sync, in, k, cin);
   } else {
     io.template need<Slots<NS>::ROW_SPLIT, Slots<NS>::NROW>();
-    coop_role_passive<NS, UPDATE>(ld, stf, [lane](int s) { return xch[s][lane]; }, sync, in, k);
+    coop_role_passive<NS, UPDATE, CORR, PREDICT>(ld, stf, xrd, sync, in, k, cin);
   }
+#else
+  if (role == 0) {
+    io.template need<0, Slots<NS>::ROW_SPLIT>();
+    coop_role_core<NS, UPDATE, CORR, PREDICT>(ld, stf, [lane](int s, double v) { xch[s][lane] = v; }, xrd, sync, in, k, cin);
+  } else {
+    io.template need<Slots<NS>::ROW_SPLIT, Slots<NS>::NROW>();
+    coop_role_passive<NS, UPDATE, CORR, PREDICT>(ld, stf, xrd, sync, in, k, cin);
+  }
+#endif
 }
 
 // PB_HOST_BROADCAST inputs: dst [rows][B] <- one value per row (pronto_batch.hip stage_in)

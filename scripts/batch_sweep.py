@@ -1,0 +1,54 @@
+"""Fused-step time per launch over batch sizes and kernel variants (HIP events around back-to-back launches, inputs
+resident in HBM, 16 distinct input blocks cycled; a 4096-filter synthetic workload tiled along the filter axis -- a
+bandwidth measurement, parity is tested elsewhere).
+  python scripts/batch_sweep.py [n_states ...]      env: SWEEP_SIZES="65536,1048576"  SWEEP_VARIANTS="default,coop0,..."
+"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from pronto_amd.batch import BatchEstimator  # noqa: E402
+from pronto_amd.synth import Workload  # noqa: E402
+
+dev = torch.device("cuda:0")
+ns = [int(a) for a in sys.argv[1:]] or [15, 21]
+sizes = [int(a) for a in os.environ.get("SWEEP_SIZES", "32768,65536,131072,196608,262144,524288,1048576").split(",")]
+VARIANTS = {"default": {}, "coop0": {"PRONTO_BATCH_COOP15": "0"}, "coop1": {"PRONTO_BATCH_COOP15": "1"},
+            "xcd0": {"PRONTO_BATCH_XCD": "0"}, "xcd1": {"PRONTO_BATCH_XCD": "1"},
+            "mh0": {"PRONTO_BATCH_MEMHINT": "0"}, "mh1": {"PRONTO_BATCH_MEMHINT": "1"}, "mh2": {"PRONTO_BATCH_MEMHINT": "2"}}
+variants = os.environ.get("SWEEP_VARIANTS", "default").split(",")
+K, B0 = 16, 4096
+for n in ns:
+    w = Workload(B0, n_states=n)
+    vec, quat, P0 = w.initial_state()
+    q4 = w.process_noise()
+    imu, lo, mask = w.streams(0, K)
+    bps = 2 * ((n + 4) * 8 + n * (n + 1) // 2 * 8 + 8) + 104
+    for B in sizes:
+        if n == 21 and B > 524288:
+            continue
+        r = B // B0
+        d_imu = torch.from_numpy(imu).to(dev).repeat(1, 1, r).contiguous()
+        d_lo = torch.from_numpy(lo).to(dev).repeat(1, 1, r).contiguous()
+        d_mask = torch.from_numpy(mask).to(dev).repeat(1, r).contiguous()
+        tv = torch.from_numpy(vec).to(dev).repeat(1, r).contiguous()
+        tq = torch.from_numpy(quat).to(dev).repeat(1, r).contiguous()
+        tP = torch.from_numpy(P0).to(dev).repeat(1, 1, r).contiguous()
+        for v in variants:
+            for k_, x in VARIANTS[v].items():
+                os.environ[k_] = x
+            est = BatchEstimator(B, n_states=n)
+            for k_ in VARIANTS[v]:
+                os.environ.pop(k_)
+            est.reset(tv, tq, tP)
+            est.run_legodo(d_imu, d_lo, d_mask, q4)
+            reps = max(2, int(3e-2 / (K * B * bps / 5e12)))
+            ms = min(sum(est.run_legodo(d_imu, d_lo, d_mask, q4, timed=True) for _ in range(reps)) / reps for _ in range(3))
+            us = ms / K * 1e3
+            print("n=%d B=%8d %-8s %-24s %8.2f us  %6.0f GB/s  frac %.3f" % (n, B, v, est.hot_kernel(), us, bps * B / us / 1e3,
+                                                                         bps * B / us / 1e3 / 8000), flush=True)
+            est.close()
+        del d_imu, d_lo, d_mask, tv, tq, tP

@@ -22,6 +22,8 @@ static double nrand() { return sqrt(-2 * log(urand())) * cos(2 * M_PI * urand())
 int main(int argc, char **argv)
 {
   const int n = (argc > 1) ? atoi(argv[1]) : 15;
+  // "fuse3": state_estimator.fuse_ins_legodo + fuse_corrections -- INS + leg odometry (+ VO / scan-match) as ONE kernel
+  const bool fuse3 = argc > 2 && std::string(argv[2]) == "fuse3";
   const int B = 200, T = 120;
   double g;
   po_get_constants(&g, nullptr);
@@ -30,6 +32,8 @@ int main(int argc, char **argv)
   BotParam param;
   param.set("state_estimator.utime_history_span", "1000000");
   param.set("state_estimator.ins.channel", "ATLAS_IMU_BATCH");
+  param.set("state_estimator.fuse_ins_legodo", fuse3 ? "true" : "false");
+  param.set("state_estimator.fuse_corrections", fuse3 ? "true" : "false");
   param.set("state_estimator.ins.q_gyro", 0.5);       // deg/s
   param.set("state_estimator.ins.q_accel", 0.1);
   param.set("state_estimator.ins.q_gyro_bias", n == 21 ? 0.001 : 0.0);
@@ -193,9 +197,12 @@ int main(int argc, char **argv)
     el = fmax(el, fabs(ll[b] - oll[b]));
     sl = fmax(sl, fabs(oll[b]));
   }
-  printf("n=%d B=%d T=%d head utime %" PRId64 ": rel err vec %.2e quat %.2e cov %.2e ll %.2e (status %d)\n", n, B, T, head.utime,
-         ev / sv, eq, eP / sP, el / sl, est.last_status);
-  const bool ok = est.last_status == PB_OK && head.utime == (int64_t) T * 1000 && ev / sv < 1e-9 && eq < 1e-9 && eP / sP < 1e-9 && el / sl < 1e-9;
+  printf("n=%d B=%d T=%d head utime %" PRId64 ": rel err vec %.2e quat %.2e cov %.2e ll %.2e (status %d), fused pairs %lld, fused triples %lld\n",
+         n, B, T, head.utime, ev / sv, eq, eP / sP, el / sl, est.last_status, (long long) est.fused_pairs, (long long) est.fused_triples);
+  // VO every 20th step (6) and scan-match every 25th (4); at k = 99 both follow the same pair: the VO rides with it, the
+  // scan-match measurement then finds nothing held and runs alone
+  const bool fused_ok = fuse3 ? (est.fused_triples == 9 && est.fused_pairs == T - 9) : (est.fused_triples == 0 && est.fused_pairs == 0);
+  const bool ok = fused_ok && est.last_status == PB_OK && head.utime == (int64_t) T * 1000 && ev / sv < 1e-9 && eq < 1e-9 && eP / sP < 1e-9 && el / sl < 1e-9;
   printf(ok ? "PASS\n" : "FAIL\n");
   return ok ? 0 : 1;
 }

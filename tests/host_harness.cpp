@@ -108,14 +108,19 @@ void hh_update_posyaw(int ns, double *st, long stride, int B, const double *z, c
 // column, with a plain array standing in for the LDS hand-off; stores are applied after both roles have read. ----
 #include "../pronto_amd/csrc/rbis_coop.hpp"
 
-template <int NS>
+template <int NS, class CORR = NoCorr>
 static void step_coop(double *st, long stride, int B, const double *imu, const double *lo, const uint8_t *mask,
-                      const double *q4, double g, double tol, int do_update)
+                      const double *q4, double g, double tol, int do_update, const double *z2 = nullptr,
+                      const double *rd2 = nullptr, const double *qm2 = nullptr, const uint8_t *mask2 = nullptr)
 {
   Consts k{ g, tol };
   constexpr int NC = Lay<NS>::NC;
   for (int b = 0; b < B; b++) {
-    double in_col[NC], out_col[NC], xch[Coop<NS>::NXCH];
+    double in_col[NC], out_col[NC], xch[CoopX<NS, CORR>::NXCH];
+    CorrInputs cin;
+    for (int i = 0; i < CORR::M; i++) { cin.z[i] = z2[i * B + b]; cin.rd[i] = rd2[i * B + b]; }
+    for (int i = 0; i < 4; i++) cin.qm[i] = (CORR::M > 0) ? qm2[i * B + b] : 0.0;
+    cin.upd = CORR::M > 0 && (!mask2 || mask2[b]);
     for (int c = 0; c < NC; c++) in_col[c] = out_col[c] = st[c * stride + b];
     StepInputs in;
     for (int i = 0; i < 3; i++) {
@@ -130,12 +135,22 @@ static void step_coop(double *st, long stride, int B, const double *imu, const d
     auto ld = [&](int c) { return in_col[c]; };
     auto stf = [&](int c, double v) { out_col[c] = v; };
     auto sync = []() {};
-    if (do_update) {
-      coop_role_core<NS, true>(ld, stf, [&](int s, double v) { xch[s] = v; }, sync, in, k);
-      coop_role_passive<NS, true>(ld, stf, [&](int s) { return xch[s]; }, sync, in, k);
+    auto xw = [&](int s, double v) { xch[s] = v; };
+    auto xr = [&](int s) { return xch[s]; };
+    if constexpr (CORR::M > 0) {
+      if (do_update == 2) {  // the correction alone: no predict, no leg-odometry update
+        coop_role_core<NS, false, CORR, false>(ld, stf, xw, xr, sync, in, k, cin);
+        coop_role_passive<NS, false, CORR, false>(ld, stf, xr, sync, in, k, cin);
+      } else {
+        coop_role_core<NS, true, CORR>(ld, stf, xw, xr, sync, in, k, cin);
+        coop_role_passive<NS, true, CORR>(ld, stf, xr, sync, in, k, cin);
+      }
+    } else if (do_update) {
+      coop_role_core<NS, true>(ld, stf, xw, xr, sync, in, k);
+      coop_role_passive<NS, true>(ld, stf, xr, sync, in, k);
     } else {
-      coop_role_core<NS, false>(ld, stf, [&](int s, double v) { xch[s] = v; }, sync, in, k);
-      coop_role_passive<NS, false>(ld, stf, [&](int s) { return xch[s]; }, sync, in, k);
+      coop_role_core<NS, false>(ld, stf, xw, xr, sync, in, k);
+      coop_role_passive<NS, false>(ld, stf, xr, sync, in, k);
     }
     for (int c = 0; c < NC; c++) st[c * stride + b] = out_col[c];
   }
@@ -146,4 +161,16 @@ extern "C" void hh_step_coop(int ns, double *st, long stride, int B, const doubl
 {
   if (ns == 15) step_coop<15>(st, stride, B, imu, lo, mask, q4, g, tol, do_update);
   else step_coop<21>(st, stride, B, imu, lo, mask, q4, g, tol, do_update);
+}
+
+// predict + leg-odometry update + a fused second (orientation) update: kind 0 = position_orient (m = 6), 1 = position_yaw
+// (m = 4); mode 1 = all three, mode 2 = the correction alone (stand-alone update on the two-role mapping)
+extern "C" void hh_step_coop_correct(int ns, int kind, int mode, double *st, long stride, int B, const double *imu, const double *lo,
+                                     const uint8_t *mask, const double *q4, double g, double tol, const double *z2,
+                                     const double *rd2, const double *qm2, const uint8_t *mask2)
+{
+  if (ns == 15 && kind == 0) step_coop<15, CorrPosOrient>(st, stride, B, imu, lo, mask, q4, g, tol, mode, z2, rd2, qm2, mask2);
+  else if (ns == 15) step_coop<15, CorrPosYaw>(st, stride, B, imu, lo, mask, q4, g, tol, mode, z2, rd2, qm2, mask2);
+  else if (kind == 0) step_coop<21, CorrPosOrient>(st, stride, B, imu, lo, mask, q4, g, tol, mode, z2, rd2, qm2, mask2);
+  else step_coop<21, CorrPosYaw>(st, stride, B, imu, lo, mask, q4, g, tol, mode, z2, rd2, qm2, mask2);
 }

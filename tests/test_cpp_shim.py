@@ -70,6 +70,16 @@ def test_fovis_keyframe_lookup_in_history_on_gpu(oracle):
     assert r.returncode == 0 and "PASS" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
 
 
+@pytest.mark.gpu
+def test_fovis_updates_own_their_measurement_across_a_replay(oracle):
+    """Two FovisHandler updates in the window, then a measurement older than both: the replay re-applies each VO update
+    with the z / quaternion it was built with (the handler is even destroyed before the estimator)."""
+    exe = build_exe(oracle, "test_fovis_replay")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    print(r.stdout[-2000:], r.stderr[-2000:])
+    assert r.returncode == 0 and "PASS" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 def test_ins_gravity_initialisation_host_only(oracle):
     """InsHandler::processMessageInit (sensor_handlers.cpp:254-364) is host arithmetic: it runs here, without a GPU,
     against the oracle's po_ins_init."""
@@ -94,7 +104,7 @@ def test_legodo_modes_on_gpu(oracle, mode, slots, fuse):
 
 
 @pytest.mark.parametrize("name", ["test_shim", "test_history", "test_atlas_imu", "test_smooth_pass", "test_log_replay",
-                                  "test_legodo_modes", "test_fovis_history"])
+                                  "test_legodo_modes", "test_fovis_history", "test_fovis_replay"])
 def test_shim_compiles_and_links(oracle, name):
     exe = build_exe(oracle, name)
     out = subprocess.run(["ldd", exe], capture_output=True, text=True).stdout
@@ -103,9 +113,14 @@ def test_shim_compiles_and_links(oracle, name):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("n", [15, 21])
-def test_shim_matches_oracle_on_gpu(oracle, n):
+@pytest.mark.parametrize("fuse", ["", "fuse3"])
+def test_shim_matches_oracle_on_gpu(oracle, n, fuse):
+    """The miniature se-fusion (INS + leg odometry + VO position_orient + scan-match position_yaw through the handlers)
+    against the oracle.  "fuse3": with state_estimator.fuse_ins_legodo / fuse_corrections every INS + leg-odometry pair runs
+    as one kernel and the pairs followed by a VO / scan-match message as ONE kernel with all three updates
+    (pb_step_legodo_correct); the executable checks the launch counts."""
     exe = build_exe(oracle)
-    r = subprocess.run([exe, str(n)], capture_output=True, text=True, timeout=300)
+    r = subprocess.run([exe, str(n)] + ([fuse] if fuse else []), capture_output=True, text=True, timeout=300)
     print(r.stdout, r.stderr)
     assert r.returncode == 0 and "PASS" in r.stdout, r.stdout + r.stderr
     assert "discarding update" in r.stderr  # the late update was rejected like update_history.cpp:28-39

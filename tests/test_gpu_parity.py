@@ -71,9 +71,12 @@ def test_fused_step_host_buffers(pa, oracle, n, B):
     check(est, ob)
 
 
+@pytest.mark.parametrize("generic", ["0", "1"])
 @pytest.mark.parametrize("n", [15, 21])
-def test_separate_calls_equal_fused(pa, oracle, n):
-    """pb_predict + pb_update_indexed (generic kernel, runtime idx) == pb_step_legodo == oracle."""
+def test_separate_calls_equal_fused(pa, oracle, n, generic, monkeypatch):
+    """pb_predict + pb_update_indexed == pb_step_legodo == oracle, with the stand-alone update on the cooperative
+    compile-time-index kernel (the handlers' index lists, default) and on the generic run-time-index kernel."""
+    monkeypatch.setenv("PRONTO_BATCH_GENERIC_UPDATE", generic)
     B = 192
     w = Workload(B, n_states=n)
     est_f, ob = make_pair(pa, oracle, w)
@@ -442,11 +445,13 @@ def test_time_fused_replay_equals_per_step_path(pa, oracle, T_fuse):
         est21.replay_legodo_fused(d[0], d[1], d[2], q4, 4)   # 15-state only (and before reset)
 
 
+@pytest.mark.parametrize("generic", ["0", "1"])
 @pytest.mark.parametrize("n,vo,sm", [(15, 32, 0), (21, 0, 25)])
-def test_full_size_configs_3_and_5_sampled_parity(pa, oracle, n, vo, sm):
+def test_full_size_configs_3_and_5_sampled_parity(pa, oracle, n, vo, sm, generic, monkeypatch):
     """BASELINE configs 3 (n=15, +VO m=6 every 32nd step) and 5 (n=21, +scan-match m=4 every 25th) at the full
     65 536 filters with device-resident inputs; 192 sampled filters against the oracle, everything finite."""
     import torch
+    monkeypatch.setenv("PRONTO_BATCH_GENERIC_UPDATE", generic)   # corrections on the cooperative / the generic update kernel
     B, T = 65536, 64
     w = Workload(B, n_states=n)
     vec, quat, P0 = w.initial_state()
@@ -679,3 +684,113 @@ def test_config4_256k_whole_equals_its_eight_shards(pa, oracle):
     red = reduce_summaries(shard_sums)                                                    # (b)
     assert np.isclose(red[0], whole[0], rtol=1e-12) and np.isclose(red[1], whole[1], rtol=1e-12)
     assert red[2] == whole[2] and red[3] == whole[3] == 0
+
+
+@pytest.mark.parametrize("n,kind", [(15, 0), (15, 1), (21, 0), (21, 1)])
+def test_fused_correction_step_equals_three_updates(pa, oracle, n, kind):
+    """pb_step_legodo_correct (predict + leg-odometry m=3 + VO position_orient m=6 / scan-match position_yaw m=4 in ONE
+    kernel and one state round trip) against the oracle's three updates and against the three-launch path
+    (pb_step_legodo + pb_update_indexed_orient; equal to rounding, <= 1e-12: the generic update kernel scales W by
+    |D|^-1/2, the fused one by D^-1).  Ragged batch, masks on both measurements, host / device / mixed memory spaces,
+    per-filter and broadcast R."""
+    import torch
+    from pronto_amd._lib import PB_CORR_POS_ORIENT, PB_CORR_POS_YAW
+    B, T = 333, 48
+    dev = torch.device("cuda:0")
+    w = Workload(B, n_states=n)
+    est_f, ob = make_pair(pa, oracle, w, dense_p0=4)
+    est_s, _ = make_pair(pa, oracle, w, dense_p0=4)
+    q4 = w.process_noise()
+    idx = [9, 10, 11, 6, 7, 8] if kind == 0 else [9, 10, 11, 8]
+    ck = PB_CORR_POS_ORIENT if kind == 0 else PB_CORR_POS_YAW
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    for k in range(T):
+        imu = w.imu_block(k)
+        lo, mask = w.legodo_block(k)
+        ob.predict(imu, q4)
+        ob.update_indexed([3, 4, 5], lo[0:3], lo[3:6], mask=mask)
+        if k % 3 != 2:
+            est_f.step_legodo(imu, lo, mask, q4)
+            est_s.step_legodo(imu, lo, mask, q4)
+            continue
+        z, qm, Rd = w.vo_block(k) if kind == 0 else w.scanmatch_block(k)
+        zz, qm, Rd = pad_z(z, len(idx)), np.ascontiguousarray(qm), np.ascontiguousarray(Rd)
+        mask2 = ((np.arange(B) + k) % 7 != 0).astype(np.uint8)
+        ob.update_indexed(idx, zz, Rd, quat_meas=qm, mask=mask2)
+        est_s.step_legodo(imu, lo, mask, q4)
+        est_s.update_indexed(idx, zz, Rd, mask=mask2, quat_meas=qm)
+        v = (k // 3) % 3
+        if v == 0:      # everything from the host
+            est_f.step_legodo_correct(imu, lo, mask, q4, ck, zz, Rd, qm, mask2)
+        elif v == 1:    # IMU / leg odometry from the host, the correction resident on the device (FovisHandler's case)
+            est_f.step_legodo_correct(imu, lo, mask, q4, ck, up(zz), up(Rd), up(qm), up(mask2))
+        else:           # everything on the device
+            est_f.step_legodo_correct(up(imu), up(lo), up(mask), q4, ck, up(zz), up(Rd), up(qm), up(mask2))
+    check(est_f, ob)
+    check(est_s, ob)
+    for a, b in zip(est_f.get_head(), est_s.get_head()):
+        assert rel(a, b) < 1e-12
+    # broadcast R2 (a handler's cov_* members) == the same values per filter, bit for bit
+    e1, _ = make_pair(pa, oracle, w)
+    e2, _ = make_pair(pa, oracle, w)
+    imu = w.imu_block(0); lo, mask = w.legodo_block(0)
+    z, qm, Rd = w.vo_block(0) if kind == 0 else w.scanmatch_block(0)
+    zz, qm = pad_z(z, len(idx)), np.ascontiguousarray(qm)
+    rb = [float(Rd[i, 0]) for i in range(len(idx))]
+    e1.step_legodo_correct(imu, lo, mask, q4, ck, zz, np.ascontiguousarray(np.tile(np.array(rb)[:, None], (1, B))), qm)
+    e2.step_legodo_correct(imu, lo, mask, q4, ck, zz, rb, qm)
+    for a, b in zip(e1.get_head(), e2.get_head()):
+        assert np.array_equal(a, b)
+    with pytest.raises(ValueError):
+        e1.step_legodo_correct(imu, lo, mask, q4, 7, zz, rb, qm)     # unknown correction kind: refused by the binding ...
+    import ctypes as C
+    rc = e1._L.pb_step_legodo_correct(e1._h, C.c_void_p(imu.ctypes.data), C.c_void_p(lo.ctypes.data), None,
+                                      (C.c_double * 4)(*q4), 0, 7, C.c_void_p(zz.ctypes.data),
+                                      C.c_void_p(np.array(rb).ctypes.data), 0, C.c_void_p(qm.ctypes.data), None, 0)
+    assert rc == 1 and b"corr_kind" in e1._L.pb_last_error(e1._h)  # ... and by the C ABI
+
+
+@pytest.mark.parametrize("n", [15, 21])
+def test_handler_index_lists_on_the_cooperative_update_kernel(pa, oracle, n, monkeypatch):
+    """Every index list a handler produces (velocity, position, position+velocity, position+orientation, position+yaw,
+    velocity+yaw, yaw) as a stand-alone update: the compile-time-index cooperative kernel against the oracle and against
+    the generic run-time-index kernel (<= 1e-12), per-filter and broadcast diagonal R, masks; a full R or any other index
+    list still takes the generic kernel."""
+    from oracle import numpy_restatement as nr
+    B = 200
+    rng = np.random.default_rng(77 + n)
+    w = Workload(B, n_states=n)
+    lists = [([3, 4, 5], False), ([9, 10, 11], False), ([9, 10, 11, 3, 4, 5], False), ([9, 10, 11, 6, 7, 8], True),
+             ([9, 10, 11, 8], True), ([3, 4, 5, 8], True), ([8], True), ([9, 10, 11], True), ([4, 9], False)]
+    ests = []
+    for gen in ("0", "1"):
+        monkeypatch.setenv("PRONTO_BATCH_GENERIC_UPDATE", gen)
+        est, ob = make_pair(pa, oracle, w, dense_p0=9)
+        ests.append(est)
+    q4 = w.process_noise()
+    for t, (idx, orient) in enumerate(lists * 2):
+        imu = w.imu_block(t)
+        for e in ests:
+            e.predict(imu, q4)
+        ob.predict(imu, q4)
+        m = len(idx)
+        z = np.ascontiguousarray(ob.vec[idx] + 0.05 * rng.normal(size=(m, B)))
+        mask = (rng.random(B) > 0.25).astype(np.uint8)
+        qm = None
+        if orient:
+            d = 0.03 * rng.normal(size=(3, B))
+            qm = np.ascontiguousarray(nr.quat_mul(ob.quat.T, nr.quat_exp(d.T)[0]).T)
+        if t < len(lists):
+            Rd = np.ascontiguousarray(0.01 + 0.05 * rng.random((m, B)))
+            for e in ests:
+                e.update_indexed(idx, z, Rd, mask=mask, quat_meas=qm)
+        else:
+            rb = list(0.01 + 0.05 * rng.random(m))
+            Rd = np.tile(np.array(rb)[:, None], (1, B))
+            for e in ests:
+                e.update_indexed(idx, z, rb, mask=mask, quat_meas=qm)
+        ob.update_indexed(idx, z, Rd, quat_meas=qm, mask=mask)
+    for e in ests:
+        check(e, ob)
+    for a, b in zip(ests[0].get_head(), ests[1].get_head()):
+        assert rel(a, b) < 1e-12

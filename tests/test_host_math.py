@@ -107,6 +107,44 @@ def test_cooperative_roles_match_oracle(oracle, harness, ns, upd):
         assert rel(ll, ob.ll) < 1e-11
 
 
+@pytest.mark.parametrize("alone", [False, True])
+@pytest.mark.parametrize("ns,kind", [(15, 0), (15, 1), (21, 0), (21, 1)])
+def test_cooperative_roles_with_fused_correction_match_oracle(oracle, harness, ns, kind, alone):
+    """predict + leg-odometry + a second orientation update (VO position_orient m=6 / scan-match position_yaw m=4) through
+    the two roles with both LDS hand-offs, against three separate oracle updates; second-update mask exercised."""
+    H = harness
+    g, tol = oracle.constants()
+    B, T = 24, 60
+    w = Workload(B, n_states=ns)
+    vec, quat, P0 = w.initial_state()
+    P0 = P0 + random_spd(ns, B, 0.03, 7)
+    if ns == 21:
+        vec[15:18], vec[18:21] = 0.5 * w.bg, 0.5 * w.ba
+    v21, P21 = embed21(vec, P0)
+    ob = oracle.OracleBatch(v21, quat, P21)
+    st = pack(H, ns, vec, quat, P0, np.zeros(B))
+    q4 = w.process_noise()
+    idx = [9, 10, 11, 6, 7, 8] if kind == 0 else [9, 10, 11, 8]
+    for k in range(T):
+        imu = w.imu_block(k)
+        lo, mask = w.legodo_block(k)
+        z, qm, Rd = w.vo_block(k) if kind == 0 else w.scanmatch_block(k)
+        zz, qm, Rd = pad_z(z, len(idx)), np.ascontiguousarray(qm), np.ascontiguousarray(Rd)
+        mask2 = ((np.arange(B) + k) % 5 != 0).astype(np.uint8)
+        ob.predict(imu, q4)
+        ob.update_indexed([3, 4, 5], lo[0:3], lo[3:6], mask=mask)
+        ob.update_indexed(idx, zz, Rd, quat_meas=qm, mask=mask2)
+        if alone:   # the same three updates as two calls: fused step, then the correction ALONE on the two-role mapping
+            H.hh_step_coop(ns, P(st), C.c_long(B), B, P(imu), P(lo), mask.ctypes.data_as(C.c_void_p), P(q4),
+                           C.c_double(g), C.c_double(tol), 1)
+        H.hh_step_coop_correct(ns, kind, 2 if alone else 1, P(st), C.c_long(B), B, P(imu), P(lo),
+                               mask.ctypes.data_as(C.c_void_p), P(q4), C.c_double(g), C.c_double(tol), P(zz), P(Rd), P(qm),
+                               mask2.ctypes.data_as(C.c_void_p))
+    v, q, cov, ll = unpack(H, ns, st)
+    assert rel(v, ob.vec[:ns]) < 1e-11 and rel(q, ob.quat) < 1e-11 and rel(cov, ob.cov[:ns, :ns]) < 1e-11
+    assert rel(ll, ob.ll) < 1e-11
+
+
 def test_predict_only_and_masked_lanes(oracle, harness):
     H = harness
     g, tol = oracle.constants()
