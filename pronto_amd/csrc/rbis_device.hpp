@@ -229,8 +229,10 @@ PB_HD void subtract_quats(const double (&q1)[4], const double (&q2)[4], double (
   quat_mul(q2i, q1, r);
   const double n = sqrt(r[1] * r[1] + r[2] * r[2] + r[3] * r[3]);
   if (n != 0.0) {
-    // angle = 2 atan2(n, |w|) in [0, pi]; axis = vec / (sign(w) n)
-    const double angle = 2.0 * atan2(n, fabs(r[0]));
+    // angle = 2 atan2(n, |w|) in [0, pi]; axis = vec / (sign(w) n); bot_mod2pi maps an angle of exactly pi (w == 0 to
+    // rounding) to -pi
+    double angle = 2.0 * atan2(n, fabs(r[0]));
+    if (angle >= 3.141592653589793) angle -= 6.283185307179586;
     const double f = (r[0] < 0 ? -angle : angle) / n;
     out[0] = r[1] * f; out[1] = r[2] * f; out[2] = r[3] * f;
   } else {

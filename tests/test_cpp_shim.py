@@ -80,6 +80,20 @@ def test_fovis_updates_own_their_measurement_across_a_replay(oracle):
     assert r.returncode == 0 and "PASS" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["sm_position", "sm_velocity", "sm_yaw", "sm_position_yaw", "sm_velocity_yaw", "fovis_velocity",
+                                  "fovis_position", "legodo_zero3", "legodo_ft"])
+def test_every_handler_mode_on_gpu(oracle, mode):
+    """The handler modes the miniature se-fusion does not reach: all five ScanMatcherHandler modes
+    (sensor_handlers.cpp:612-724), FovisHandler velocity / position (rbis_fovis_update.cpp:93-117), LegOdoHandler's
+    zero_initial_velocity = 3 and its force/torque gate (rbis_legodo_update.cpp:208-211,264-268), each against the oracle's
+    restatement of the same handler arithmetic."""
+    exe = build_exe(oracle, "test_handler_modes")
+    r = subprocess.run([exe, mode], capture_output=True, text=True, timeout=300)
+    print(r.stdout[-2000:], r.stderr[-2000:])
+    assert r.returncode == 0 and "PASS" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 def test_ins_gravity_initialisation_host_only(oracle):
     """InsHandler::processMessageInit (sensor_handlers.cpp:254-364) is host arithmetic: it runs here, without a GPU,
     against the oracle's po_ins_init."""
@@ -104,7 +118,8 @@ def test_legodo_modes_on_gpu(oracle, mode, slots, fuse):
 
 
 @pytest.mark.parametrize("name", ["test_shim", "test_history", "test_atlas_imu", "test_smooth_pass", "test_log_replay",
-                                  "test_legodo_modes", "test_fovis_history", "test_fovis_replay"])
+                                  "test_legodo_modes", "test_fovis_history", "test_fovis_replay",
+                                  "test_handler_modes"])
 def test_shim_compiles_and_links(oracle, name):
     exe = build_exe(oracle, name)
     out = subprocess.run(["ldd", exe], capture_output=True, text=True).stdout
