@@ -23,10 +23,13 @@ def _is_torch(a):
     return type(a).__module__.startswith("torch")
 
 
-def _ptr(a, dtype=np.float64):
-    """(pointer, mem) of a numpy array or a torch tensor; None -> (NULL, None)."""
+def _ptr(a, dtype=np.float64, shape=None):
+    """(pointer, mem) of a numpy array or a torch tensor; None -> (NULL, None).  The C ABI takes no lengths (it reads
+    rows x batch elements), so a mis-shaped array would be an out-of-bounds read: `shape` is checked here."""
     if a is None:
         return None, None
+    if shape is not None and tuple(a.shape) != tuple(shape):
+        raise ValueError("expected an array of shape %s, got %s" % (tuple(shape), tuple(a.shape)))
     if _is_torch(a):
         import torch
         want = {np.float64: torch.float64, np.uint8: torch.uint8}[dtype]
@@ -38,13 +41,13 @@ def _ptr(a, dtype=np.float64):
     return C.c_void_p(a.ctypes.data), PB_HOST
 
 
-def _ptr_block(a):
+def _ptr_block(a, rows=None, B=None):
     """Like _ptr for a [rows, B] data block; a 1-D numpy array of `rows` values means ONE message for every filter of the
     batch (PB_HOST_BROADCAST: expanded on the device, nothing of batch size crosses PCIe)."""
     if isinstance(a, np.ndarray) and a.ndim == 1:
-        p, _ = _ptr(a)
+        p, _ = _ptr(a, shape=None if rows is None else (rows,))
         return p, PB_HOST_BROADCAST
-    return _ptr(a)
+    return _ptr(a, shape=None if rows is None else (rows, B))
 
 
 def _same_mem(*mems):
@@ -138,7 +141,7 @@ class BatchEstimator:
         if q_block is None:
             self._chk(self._L.pb_set_process_noise_block(self._h, None))
             return
-        p, m = _ptr(q_block)
+        p, m = _ptr(q_block, shape=(4, self.B))
         if m != PB_DEVICE:
             raise ValueError("the process-noise block must be device memory")
         self._chk(self._L.pb_set_process_noise_block(self._h, p))
@@ -149,8 +152,8 @@ class BatchEstimator:
         ia = (C.c_int * m)(*[int(i) for i in idx])
         out = np.empty((3, self.B))
         err = np.empty((self.n, self.B)) if want_err else None
-        pv, m1 = _ptr(truth_vec)
-        pq, m2 = _ptr(truth_quat)
+        pv, m1 = _ptr(truth_vec, shape=(self.n, self.B))
+        pq, m2 = _ptr(truth_quat, shape=(4, self.B))
         if _same_mem(m1, m2) != PB_HOST:
             raise ValueError("window_nll takes host truth arrays")
         self._chk(self._L.pb_window_nll(self._h, m, ia, pv, pq, C.c_void_p(out.ctypes.data),
@@ -163,8 +166,10 @@ class BatchEstimator:
 
     def imu_notch(self, accel_packets, accel_out):
         """accel_packets [n_packets,3,B] oldest first -> accel_out [3,B] (newest filtered sample)."""
-        pi, m1 = _ptr(accel_packets)
-        po_, m2 = _ptr(accel_out)
+        if accel_packets.ndim != 3:
+            raise ValueError("accel_packets must be [n_packets, 3, B]")
+        pi, m1 = _ptr(accel_packets, shape=(accel_packets.shape[0], 3, self.B))
+        po_, m2 = _ptr(accel_out, shape=(3, self.B))
         self._chk(self._L.pb_imu_notch(self._h, accel_packets.shape[0], pi, po_, _same_mem(m1, m2)))
 
     # --- update objects ---
@@ -174,13 +179,14 @@ class BatchEstimator:
             cov_cm = cov.transpose(0, 1).contiguous()
         else:
             cov_cm = np.ascontiguousarray(np.swapaxes(cov, 0, 1))  # column-major flat index c*n+r
-        pv, m1 = _ptr(vec)
-        pq, m2 = _ptr(quat)
-        pc, m3 = _ptr(cov_cm)
+        n, B = self.n, self.B
+        pv, m1 = _ptr(vec, shape=(n,) if broadcast else (n, B))
+        pq, m2 = _ptr(quat, shape=(4,) if broadcast else (4, B))
+        pc, m3 = _ptr(cov_cm, shape=(n, n) if broadcast else (n, n, B))
         self._chk(self._L.pb_reset(self._h, pv, pq, pc, int(broadcast), _same_mem(m1, m2, m3)))
 
     def predict(self, imu_block, q4):
-        p, m = _ptr_block(imu_block)
+        p, m = _ptr_block(imu_block, 7, self.B)
         q = (C.c_double * 4)(*q4)
         self._chk(self._L.pb_predict(self._h, p, q, m))
 
@@ -191,8 +197,8 @@ class BatchEstimator:
                 return arr, C.c_void_p(arr.ctypes.data), PB_R_FULL, PB_HOST_BROADCAST
             assert arr.shape == (m,)
             return arr, C.c_void_p(arr.ctypes.data), PB_R_DIAG_BROADCAST, None
-        p, mem = _ptr(R)
         kind = PB_R_DIAG if R.shape[0] == m and len(R.shape) == 2 else PB_R_FULL
+        p, mem = _ptr(R, shape=(m, self.B) if kind == PB_R_DIAG else (m * m, self.B))
         return R, p, kind, mem
 
     def update_indexed(self, idx, z, R, mask=None, quat_meas=None):
@@ -200,35 +206,35 @@ class BatchEstimator:
         R: length-m list (broadcast diag), [m,B] per-filter diag, or [m*m,B] full column-major."""
         m = len(idx)
         ia = (C.c_int * m)(*[int(i) for i in idx])
-        pz, mz = _ptr_block(z)
+        pz, mz = _ptr_block(z, m, self.B)
         _keep, pr, kind, mr = self._r(R, m)
-        pm, mm = _ptr(mask, np.uint8)
+        pm, mm = _ptr(mask, np.uint8, shape=(self.B,))
         if quat_meas is None:
             self._chk(self._L.pb_update_indexed(self._h, m, ia, pz, pr, kind, pm, _same_mem(mz, mr, mm)))
         else:
-            pq, mq = _ptr_block(quat_meas)
+            pq, mq = _ptr_block(quat_meas, 4, self.B)
             self._chk(self._L.pb_update_indexed_orient(self._h, m, ia, pz, pr, kind, pq, pm, _same_mem(mz, mr, mm, mq)))
 
     def step_legodo(self, imu_block, lo_block, mask, q4):
-        pi, m1 = _ptr_block(imu_block)
-        pl, m2 = _ptr_block(lo_block)
-        pm, m3 = _ptr(mask, np.uint8)
+        pi, m1 = _ptr_block(imu_block, 7, self.B)
+        pl, m2 = _ptr_block(lo_block, 6, self.B)
+        pm, m3 = _ptr(mask, np.uint8, shape=(self.B,))
         q = (C.c_double * 4)(*q4)
         self._chk(self._L.pb_step_legodo(self._h, pi, pl, pm, q, _same_mem(m1, m2, m3)))
 
     def step_legodo_correct(self, imu_block, lo_block, mask, q4, corr_kind, z2, R2, quat_meas2, mask2=None):
         """predict + leg-odometry update + one more orientation update (corr_kind: _lib.PB_CORR_POS_ORIENT m=6 idx
         9,10,11,6,7,8 / PB_CORR_POS_YAW m=4 idx 9,10,11,8) in one state round trip.  R2: length-m list or [m,B]."""
-        pi, m1 = _ptr_block(imu_block)
-        pl, m2 = _ptr_block(lo_block)
-        pm, m3 = _ptr(mask, np.uint8)
-        pz, m4 = _ptr_block(z2)
+        pi, m1 = _ptr_block(imu_block, 7, self.B)
+        pl, m2 = _ptr_block(lo_block, 6, self.B)
+        pm, m3 = _ptr(mask, np.uint8, shape=(self.B,))
         if corr_kind not in (_lib.PB_CORR_POS_ORIENT, _lib.PB_CORR_POS_YAW):
             raise ValueError("corr_kind must be PB_CORR_POS_ORIENT or PB_CORR_POS_YAW")
         m = 6 if corr_kind == _lib.PB_CORR_POS_ORIENT else 4
+        pz, m4 = _ptr_block(z2, m, self.B)
         _keep, pr, kind, m5 = self._r(R2, m)
-        pq, m6 = _ptr_block(quat_meas2)
-        pm2, m7 = _ptr(mask2, np.uint8)
+        pq, m6 = _ptr_block(quat_meas2, 4, self.B)
+        pm2, m7 = _ptr(mask2, np.uint8, shape=(self.B,))
         q = (C.c_double * 4)(*q4)
         self._chk(self._L.pb_step_legodo_correct(self._h, pi, pl, pm, q, _same_mem(m1, m2, m3), int(corr_kind), pz, pr, kind,
                                                  pq, pm2, _same_mem(m4, m5, m6, m7)))
@@ -236,9 +242,9 @@ class BatchEstimator:
     def run_legodo(self, imu_stream, lo_stream, mask_stream, q4, timed=False):
         """n_steps fused steps from device-resident streams [T,7,B], [T,6,B], [T,B]; returns device ms if timed."""
         T = imu_stream.shape[0]
-        pi, m1 = _ptr(imu_stream)
-        pl, m2 = _ptr(lo_stream)
-        pm, m3 = _ptr(mask_stream, np.uint8)
+        pi, m1 = _ptr(imu_stream, shape=(T, 7, self.B))
+        pl, m2 = _ptr(lo_stream, shape=(T, 6, self.B))
+        pm, m3 = _ptr(mask_stream, np.uint8, shape=(T, self.B))
         if _same_mem(m1, m2, m3) != PB_DEVICE:
             raise ValueError("run_legodo needs device-resident streams")
         q = (C.c_double * 4)(*q4)
@@ -249,9 +255,9 @@ class BatchEstimator:
     def replay_legodo_fused(self, imu_stream, lo_stream, mask_stream, q4, steps_per_launch, timed=False):
         """Time-fused replay (P resident in registers for steps_per_launch steps); same results as run_legodo."""
         T = imu_stream.shape[0]
-        pi, m1 = _ptr(imu_stream)
-        pl, m2 = _ptr(lo_stream)
-        pm, m3 = _ptr(mask_stream, np.uint8)
+        pi, m1 = _ptr(imu_stream, shape=(T, 7, self.B))
+        pl, m2 = _ptr(lo_stream, shape=(T, 6, self.B))
+        pm, m3 = _ptr(mask_stream, np.uint8, shape=(T, self.B))
         if _same_mem(m1, m2, m3) != PB_DEVICE:
             raise ValueError("replay_legodo_fused needs device-resident streams")
         q = (C.c_double * 4)(*q4)
@@ -264,10 +270,10 @@ class BatchEstimator:
         self._chk(self._L.pb_snapshot(self._h, slot))
 
     def compose_delta(self, slot, t, q, z_out, quat_out):
-        pt, m1 = _ptr_block(t)
-        pq, m2 = _ptr_block(q)
-        pz, m3 = _ptr(z_out)
-        po_, m4 = _ptr(quat_out)
+        pt, m1 = _ptr_block(t, 3, self.B)
+        pq, m2 = _ptr_block(q, 4, self.B)
+        pz, m3 = _ptr(z_out, shape=(3, self.B))
+        po_, m4 = _ptr(quat_out, shape=(4, self.B))
         if m3 != PB_DEVICE or m4 != PB_DEVICE:
             raise ValueError("compose_delta outputs must be device tensors")
         self._chk(self._L.pb_compose_delta(self._h, slot, pt, pq, pz, po_, _same_mem(m1, m2)))

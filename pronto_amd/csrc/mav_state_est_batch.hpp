@@ -377,6 +377,8 @@ public:
   std::vector<int> free_slots;
   RBISUpdateInterface *device_head = nullptr;  // the update whose posterior the device currently holds
   int64_t replayed_updates = 0;                // statistics: updates re-applied because of late arrivals
+  int64_t dropped_updates = 0;                 // updates discarded as too old (update_history.cpp:28-39)
+  bool derived_history_ = false;               // history_slots / checkpoint cadence were derived from utime_history_span
   // state_estimator.fuse_ins_legodo = true (this build's addition, off by default): an INS process step is held back
   // until the next update arrives; if that is a velocity measurement on {3,4,5} with a diagonal R (LegOdoCommon's
   // lin_rate) both run as ONE fused kernel (pb_step_legodo: one state round trip instead of two -- 21.7 us instead of
@@ -399,8 +401,22 @@ public:
       auto it = param->kv.find(k);
       return it == param->kv.end() ? dflt : atoi(it->second.c_str());
     };
-    history_slots = opt("state_estimator.history_slots", 0);
-    checkpoint_every = opt("state_estimator.history_checkpoint_every", 1);
+    // The reference re-orders and re-applies ANY update inside utime_history_span (update_history.cpp:16-42,
+    // mav_state_est.cpp:28-80).  Here that needs posterior checkpoints on the device, so a configuration that only sets
+    // utime_history_span (every reference .cfg) gets a default pool: 32 slots, spaced so that they cover the span at an
+    // assumed two updates per millisecond (1 kHz IMU + leg odometry).  state_estimator.history_slots = 0 asks explicitly
+    // for the in-order-only estimator (no checkpoints; an update older than the head is counted in dropped_updates and
+    // discarded) -- the throughput configuration of the benchmarks.
+    if (param->kv.find("state_estimator.history_slots") == param->kv.end() && utime_history_span > 0) {
+      const int64_t expected = std::min<int64_t>(utime_history_span / 500 + 1, 1 << 20);
+      history_slots = (int) std::min<int64_t>(32, expected + 2);
+      checkpoint_every = (int) std::max<int64_t>(1, (expected + history_slots - 3) / std::max(1, history_slots - 2));
+      derived_history_ = true;
+    } else {
+      history_slots = opt("state_estimator.history_slots", 0);
+      checkpoint_every = 1;
+    }
+    checkpoint_every = opt("state_estimator.history_checkpoint_every", checkpoint_every);
     if (checkpoint_every < 1) checkpoint_every = 1;
     {
       auto it = param->kv.find("state_estimator.fuse_ins_legodo");
@@ -448,6 +464,7 @@ public:
       fprintf(stderr, "error: update type %s had timestamp %jd, which was before the first in history (%jd)\ndiscarding update!\n",
               RBISUpdateInterface::sensor_enum_string(update->sensor_id), (intmax_t) update->utime, (intmax_t) oldest);
       delete update;
+      dropped_updates++;
       return;
     }
     auto added_it = map.insert(map.end(), updateHistory::historyPair(update->utime, update));

@@ -33,6 +33,7 @@ int main(int argc, char **argv)
   po_get_constants(&g, nullptr);
   BotParam param;
   param.set("state_estimator.utime_history_span", "1000000");
+  param.set("state_estimator.history_slots", "0");  // in-order only (no posterior checkpoints)
   param.set("state_estimator.ins.channel", "IMU");
   param.set("state_estimator.ins.q_gyro", 0.5);
   param.set("state_estimator.ins.q_accel", 0.1);

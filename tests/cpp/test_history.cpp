@@ -34,8 +34,10 @@ int main(int argc, char **argv)
   po_get_constants(&g, nullptr);
   BotParam param;
   param.set("state_estimator.utime_history_span", "30000");  // 30 ms window
-  param.set("state_estimator.history_slots", every == 1 ? "40" : "12");
-  param.set("state_estimator.history_checkpoint_every", (double) every);
+  if (every > 0) {
+    param.set("state_estimator.history_slots", every == 1 ? "40" : "12");
+    param.set("state_estimator.history_checkpoint_every", (double) every);
+  }  // every == 0: ONLY utime_history_span, like a reference .cfg -- the estimator derives its checkpoint pool from it
 
   RBIS x0(n, B);
   RBIM P0(n, B);

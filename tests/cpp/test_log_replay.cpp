@@ -98,6 +98,7 @@ int main(int argc, char **argv)
   // ---- the estimator, configured with the reference's keys ----
   BotParam param;
   param.set("state_estimator.utime_history_span", "1000000");
+  param.set("state_estimator.history_slots", "0");  // in-order only (no posterior checkpoints)
   param.set("state_estimator.ins.channel", "IMU_TICK");
   param.set("state_estimator.ins.q_gyro", 0.5);
   param.set("state_estimator.ins.q_accel", 0.1);

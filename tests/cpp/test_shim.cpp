@@ -31,6 +31,7 @@ int main(int argc, char **argv)
   // ---- parameters, with the reference's key names ----
   BotParam param;
   param.set("state_estimator.utime_history_span", "1000000");
+  param.set("state_estimator.history_slots", "0");  // in-order only (no posterior checkpoints)
   param.set("state_estimator.ins.channel", "ATLAS_IMU_BATCH");
   param.set("state_estimator.fuse_ins_legodo", fuse3 ? "true" : "false");
   param.set("state_estimator.fuse_corrections", fuse3 ? "true" : "false");

@@ -59,3 +59,32 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         _lib.load()
+
+
+def test_binding_refuses_misshaped_arrays_before_calling_the_abi():
+    """The C ABI takes no lengths (rows x batch are implied), so the Python binding checks shapes: a wrong batch or row count
+    raises ValueError instead of becoming an out-of-bounds host read.  No GPU needed: the check precedes every ABI call."""
+    import numpy as np
+    import pytest
+    from pronto_amd import batch as pa
+
+    class Shapes(pa.BatchEstimator):
+        def __init__(self):
+            self.B, self.n = 8, 15
+
+        def close(self):
+            pass
+        __del__ = close
+
+    f = Shapes()
+    bad = [(f.predict, (np.zeros((7, 7)), [0, 0, 0, 0])),
+           (f.predict, (np.zeros(6), [0, 0, 0, 0])),
+           (f.update_indexed, ([3, 4, 5], np.zeros((3, 9)), [1, 1, 1])),
+           (f.update_indexed, ([3, 4, 5], np.zeros((3, 8)), np.zeros((3, 7)))),
+           (f.update_indexed, ([3, 4, 5], np.zeros((3, 8)), [1, 1, 1], np.ones(7, dtype=np.uint8))),
+           (f.step_legodo, (np.zeros((7, 8)), np.zeros((5, 8)), None, [0] * 4)),
+           (f.reset, (np.zeros((15, 8)), np.zeros((4, 8)), np.zeros((15, 15, 7)))),
+           (f.reset, (np.zeros((21, 8)), np.zeros((4, 8)), np.zeros((15, 15, 8))))]
+    for fn, args in bad:
+        with pytest.raises(ValueError):
+            fn(*args)

@@ -142,11 +142,12 @@ def test_shim_matches_oracle_on_gpu(oracle, n, fuse):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("checkpoint_every,delay", [(1, 0), (1, 7), (4, 13)])
+@pytest.mark.parametrize("checkpoint_every,delay", [(1, 0), (1, 7), (4, 13), (0, 7)])
 def test_delayed_measurements_replay_equals_in_order(oracle, checkpoint_every, delay):
     """measurements arriving `delay` steps late are inserted at their timestamp and everything
     after them is re-applied from the nearest posterior checkpoint (mav_state_est.cpp:28-80); the head must equal an
-    in-order pass (the oracle).  Dense and sparse checkpointing agree."""
+    in-order pass (the oracle).  Dense and sparse checkpointing agree; checkpoint_every = 0 sets ONLY utime_history_span,
+    like a reference .cfg: the estimator derives its checkpoint pool and cadence from the span."""
     exe = build_exe(oracle, "test_history")
     r = subprocess.run([exe, str(checkpoint_every), str(delay)], capture_output=True, text=True, timeout=300)
     print(r.stdout, r.stderr)
