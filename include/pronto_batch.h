@@ -187,6 +187,24 @@ int pb_set_process_noise_block(pb_ctx *ctx, const double *q_block_dev);
 int pb_window_nll(pb_ctx *ctx, int m, const int *idx, const double *truth_vec, const double *truth_quat, double *out3,
                   double *err_out, int mem);
 
+/* ---- leg kinematic odometry: the producer of the leg-odometry increment LegOdoHandler turns into a measurement ----
+ * Replaces, per filter, leg_estimate::updateOdometry (motion_estimate/src/leg_estimate/leg_estimate.cpp:395-556: 30 ms reset,
+ * primary-foot selection through FootContactAlt::DetectFootTransition, pelvis pose slaved to the FILTER's own orientation,
+ * :219-297) and foot_contact_classify::update (foot_contact_classify.cpp:57-125: status -1 / 0 / 1).  Forward kinematics is
+ * the caller's (KDL + URDF in the reference): feet [14][B] = body-to-left-foot (t3, q4 = w,x,y,z), body-to-right-foot (t3, q4);
+ * forces [2][B] = left, right vertical foot force.  `mem` as everywhere (PB_HOST_BROADCAST: one robot's joint state for a
+ * whole parameter sweep).  Outputs are DEVICE arrays, any may be NULL: delta_out [7][B] (pelvis increment t3, q4),
+ * status_out [B], and -- LegOdoCommon::createMeasurement in mode lin_rate (rbis_legodo_common.cpp:99-169) -- lo_block_out
+ * [6][B] + mask_out [B] in exactly the form pb_step_legodo / pb_update_indexed take with PB_DEVICE. */
+int pb_legodo_init(pb_ctx *ctx, double schmitt_low_threshold, double schmitt_high_threshold, int64_t schmitt_low_delay_us,
+                   int64_t schmitt_high_delay_us, int filter_contact_events);
+int pb_legodo_update(pb_ctx *ctx, int64_t utime, const double *feet, const double *forces, int mem, int zero_delta,
+                     double r_vxyz, double r_vxyz_uncertain, double *delta_out, double *status_out, double *lo_block_out,
+                     uint8_t *mask_out);
+/* one filter's odometry state, for diagnostics and tests: odom_to_body (t3, q4); info = primary_foot (0 left, 1 right),
+ * leg_odo_init, walking-phase mode (foot_contact_classify.hpp:34-44), transitions the classifier did not know */
+int pb_legodo_get(pb_ctx *ctx, int filter, double odom_to_body[7], int64_t info[4]);
+
 /* ---- IMU front end of the Atlas path (InsHandler::doFilter, sensor_handlers.cpp:29-42,154-162) ---------------- */
 
 /* Three cascaded 2nd-order IIR notches (iir_notch.cpp:3-61) at notch_freq * 2^i, i = 0..2, per accelerometer axis and

@@ -31,6 +31,7 @@
 #ifndef PRONTO_ORACLE_H
 #define PRONTO_ORACLE_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -125,6 +126,22 @@ int po_legodo_create_measurement(int mode, const double *r, const double *pos_t,
 /* rbis_fovis_update.cpp:199-223,299-305: T1 = T0(pos0,quat0) * (t,q); z = T1.translation, q_meas = T1.rot */
 void po_fovis_compose(const double *pos0, const double *quat0, const double *t, const double *q, double *z3,
                       double *q_meas);
+
+/* ---- leg kinematic odometry (oracle/leg_odometry.c): leg_estimate.cpp:172-297,395-556, FootContactAlt.cpp:5-100,
+ * foot_contact_classify.cpp:5-125,146-318, SignalTap.cpp:48-134.  Forward kinematics is the caller's. ---- */
+typedef struct { int status; long timer, previous_time; int first_call; } po_schmitt;
+void po_schmitt_reset(po_schmitt *s);
+void po_schmitt_update(po_schmitt *s, double lt, double ht, long low_delay, long high_delay, long present_time, double value);
+typedef struct po_leg po_leg;
+size_t po_leg_sizeof(void);
+void po_leg_init(po_leg *s, double schmitt_low, double schmitt_high, long low_delay, long high_delay, int filter_contact_events);
+/* one joint-state message: body-to-foot transforms (t[3], q[4] = w,x,y,z), foot forces, the filter's head orientation
+ * (setPoseBody).  Returns leg_estimate::updateOdometry's status (-1 / 0 / 1) and the pelvis increment. */
+float po_leg_update(po_leg *s, long utime, const double *l_t, const double *l_q, const double *r_t, const double *r_q,
+                    double lforce, double rforce, const double *world_to_body_quat, double *delta_t, double *delta_q,
+                    long *prev_utime);
+void po_leg_get(const po_leg *s, double *odom_to_body_t, double *odom_to_body_q, int *primary_foot, int *leg_odo_init, int *mode,
+                int *unknown_transitions);
 
 /* ---- IMU front end: estimate_tools/src/estimate_tools/iir_notch.cpp:3-61 (2nd-order IIR notch) ---- */
 typedef struct {

@@ -160,6 +160,33 @@ class BatchEstimator:
                                         C.c_void_p(err.ctypes.data) if want_err else None, PB_HOST))
         return (out, err) if want_err else out
 
+    # --- leg kinematic odometry ---
+    def legodo_init(self, schmitt_low, schmitt_high, low_delay_us, high_delay_us, filter_contact_events=True):
+        self._chk(self._L.pb_legodo_init(self._h, schmitt_low, schmitt_high, int(low_delay_us), int(high_delay_us),
+                                         int(bool(filter_contact_events))))
+
+    def legodo_update(self, utime, feet, forces, r_vxyz, r_vxyz_uncertain, delta_out=None, status_out=None, lo_out=None,
+                      mask_out=None, zero_delta=False):
+        """leg_estimate::updateOdometry for every filter.  feet [14,B] (or [14] broadcast), forces [2,B] (or [2]);
+        outputs are torch CUDA tensors: delta [7,B], status [B] (float64), lo block [6,B] + mask [B] (uint8)."""
+        pf, m1 = _ptr_block(feet, 14, self.B)
+        pz, m2 = _ptr_block(forces, 2, self.B)
+        outs = []
+        for a, dt, shp in ((delta_out, np.float64, (7, self.B)), (status_out, np.float64, (self.B,)),
+                           (lo_out, np.float64, (6, self.B)), (mask_out, np.uint8, (self.B,))):
+            p, m = _ptr(a, dt, shape=shp)
+            if a is not None and m != PB_DEVICE:
+                raise ValueError("legodo_update outputs must be device tensors")
+            outs.append(p)
+        self._chk(self._L.pb_legodo_update(self._h, int(utime), pf, pz, _same_mem(m1, m2), int(bool(zero_delta)), r_vxyz,
+                                           r_vxyz_uncertain, *outs))
+
+    def legodo_get(self, b):
+        pose = (C.c_double * 7)()
+        info = (C.c_int64 * 4)()
+        self._chk(self._L.pb_legodo_get(self._h, b, pose, info))
+        return np.array(pose), [int(v) for v in info]
+
     # --- IMU front end ---
     def imu_notch_init(self, notch_freq, fs=1000.0):
         self._chk(self._L.pb_imu_notch_init(self._h, notch_freq, fs))

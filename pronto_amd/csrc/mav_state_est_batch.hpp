@@ -809,6 +809,11 @@ struct legodo_delta_t {      // what leg_estimate hands to LegOdoCommon::createM
   const int *position_status;    // [B] or NULL (= valid)
   const float *delta_status;     // [B]: < 0 skip (leg_estimate.hpp:84-93), < 0.5 certain, else uncertain
 };
+struct foot_state_t {        // what forward kinematics + the foot sensors give per joint-state message (leg_estimate.cpp:430-447)
+  int64_t utime;
+  BatchArray feet;           // [14][B]: body-to-left-foot (t3, q4 = w,x,y,z), body-to-right-foot (t3, q4)
+  BatchArray forces;         // [2][B]: left, right vertical foot force
+};
 struct update_t {            // pronto::update_t (fovis)
   int64_t timestamp, prev_timestamp;
   const uint8_t *estimate_valid;   // [B] or NULL: estimate_status == ESTIMATE_VALID
@@ -1335,13 +1340,79 @@ public:
                                   // force/torque message; a host that replays F/T sets this false and calls
                                   // forceTorqueHandler() from its F/T callback (the deltas fed here already contain
                                   // leg_estimate's use of the foot sensing, so the default is "seen")
-  explicit LegOdoHandler(BotParam *param) : leg_odo_common_(new LegOdoCommon(param)), zero_initial_velocity(0)
+  explicit LegOdoHandler(BotParam *param) : leg_odo_common_(new LegOdoCommon(param)), zero_initial_velocity(0), param_(param)
   {
     auto it = param->kv.find("state_estimator.legodo.zero_initial_velocity");
     if (it != param->kv.end()) zero_initial_velocity = atoi(it->second.c_str());
   }
   ~LegOdoHandler() { delete leg_odo_common_; }
   void forceTorqueHandler() { force_torque_init_ = true; }
+
+  // The whole reference handler (rbis_legodo_update.cpp:206-280) from what forward kinematics produces: leg_estimate's
+  // updateOdometry runs on the device for every filter -- its world_to_body_ is the filter's own head orientation, which
+  // lives there (:214-229) -- and in mode lin_rate the measurement is formed there too and never visits the host.
+  // Parameters: state_estimator.legodo.{schmitt_low_threshold, schmitt_high_threshold, schmitt_low_delay,
+  // schmitt_high_delay, filter_contact_events} (leg_estimate.cpp:63,103-108).
+  BotParam *param_ = nullptr;
+  std::shared_ptr<DevicePool> pool_;
+  bool legodo_ready_ = false;
+  RBISUpdateInterface *processMessageFeet(const msgs::foot_state_t *msg, MavStateEstimator *est)
+  {
+    if (!force_torque_init_) {
+      fprintf(stdout, "Force/Torque message not received yet, not integrating leg odometry =========================\n");
+      return nullptr;
+    }
+    const int B = est->B;
+    est->flushPending();  // the odometry reads the head orientation
+    if (!legodo_ready_) {
+      const double lt = bot_param_get_double_or_fail(param_, "state_estimator.legodo.schmitt_low_threshold");
+      const double ht = bot_param_get_double_or_fail(param_, "state_estimator.legodo.schmitt_high_threshold");
+      const int64_t ld = (int64_t) bot_param_get_double_or_fail(param_, "state_estimator.legodo.schmitt_low_delay");
+      const int64_t hd = (int64_t) bot_param_get_double_or_fail(param_, "state_estimator.legodo.schmitt_high_delay");
+      const std::string fce = bot_param_get_str_or_fail(param_, "state_estimator.legodo.filter_contact_events");
+      if (pb_legodo_init(est->ctx, lt, ht, ld, hd, fce == "true" || fce == "1") != PB_OK) {
+        fprintf(stderr, "LegOdoHandler: %s\n", pb_last_error(est->ctx));
+        exit(1);
+      }
+      // per update: lo block [6][B] | increment [7][B] | status [B] (doubles) | mask [B]
+      pool_ = std::make_shared<DevicePool>(est->ctx, est->ctx_alive, sizeof(double) * 14 * (size_t) B + (size_t) B);
+      legodo_ready_ = true;
+    }
+    bool fresh = false;
+    void *blk = pool_->get(fresh);
+    if (blk == nullptr) {
+      fprintf(stderr, "LegOdoHandler: %s\n", pb_last_error(est->ctx));
+      return nullptr;
+    }
+    auto block = std::make_shared<DeviceBlock>(pool_, blk);
+    double *d_lo = (double *) blk, *d_delta = d_lo + (size_t) 6 * B, *d_status = d_delta + (size_t) 7 * B;
+    uint8_t *d_mask = (uint8_t *) (d_status + (size_t) B);
+    zero_initial_velocity--;  // decrement first, then compare (:264-268)
+    const int zero = zero_initial_velocity > 0;
+    const LegOdoCommon *lc = leg_odo_common_;
+    if (pb_legodo_update(est->ctx, msg->utime, msg->feet.p, msg->forces.p, msg->feet.mem, zero, lc->R_legodo_vxyz_,
+                         lc->R_legodo_vxyz_uncertain_, d_delta, d_status, d_lo, d_mask) != PB_OK) {
+      fprintf(stderr, "LegOdoHandler: %s\n", pb_last_error(est->ctx));
+      return nullptr;
+    }
+    if (lc->mode_ == LegOdoCommon::MODE_LIN_RATE) {
+      auto *u = new RBISIndexedMeasurement(RBIS::velocityInds(), BatchArray(d_lo, PB_DEVICE), d_lo + (size_t) 3 * B, PB_R_DIAG, d_mask,
+                                           RBISUpdateInterface::legodo, msg->utime);
+      u->owned_dev = block;
+      return u;
+    }
+    // the other modes form their measurement on the host: fetch the increment and the status
+    std::vector<double> delta((size_t) 7 * B), status((size_t) B);
+    std::vector<float> fstatus((size_t) B);
+    pb_memcpy_d2h(est->ctx, delta.data(), d_delta, sizeof(double) * 7 * B);
+    pb_memcpy_d2h(est->ctx, status.data(), d_status, sizeof(double) * B);
+    for (int b = 0; b < B; b++) fstatus[b] = (float) status[b];
+    msgs::legodo_delta_t m2{ msg->utime, prev_feet_utime_, nullptr, delta.data(), delta.data() + (size_t) 3 * B, nullptr, fstatus.data() };
+    prev_feet_utime_ = msg->utime;
+    return leg_odo_common_->createMeasurement(&m2, B);
+  }
+  int64_t prev_feet_utime_ = 0;
+
   RBISUpdateInterface *processMessage(const msgs::legodo_delta_t *msg, MavStateEstimator *est)
   {
     if (!force_torque_init_) {

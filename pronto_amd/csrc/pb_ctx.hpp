@@ -12,6 +12,7 @@
 
 #include "../../include/pronto_batch.h"
 #include "rbis_kernels.hpp"
+#include "rbis_legodo.hpp"
 
 using namespace pb;
 
@@ -26,6 +27,9 @@ struct pb_ctx {
   double *snaps = nullptr, *d_small = nullptr;
   double *hist = nullptr;  // posterior checkpoint slots (pb_history_reserve)
   int nhist = 0;
+  double *legd = nullptr;   // leg odometry state (pb_legodo_init): [NLD][stride] doubles ...
+  int64_t *legi = nullptr;  // ... and [NLI][stride] 64-bit integers (rbis_legodo.hpp)
+  LegPar leg_par;
   double *notch = nullptr;  // IMU notch cascade state [36][stride] (pb_imu_notch_init)
   NotchCoef notch_coef;
   bool notch_ready = false;

@@ -109,6 +109,8 @@ extern "C" int pb_destroy(pb_ctx *c)
   if (c->snaps) (void) hipFree(c->snaps);
   if (c->hist) (void) hipFree(c->hist);
   if (c->notch) (void) hipFree(c->notch);
+  if (c->legd) (void) hipFree(c->legd);
+  if (c->legi) (void) hipFree(c->legi);
   if (c->d_small) (void) hipFree(c->d_small);
   if (c->stage) (void) hipFree(c->stage);
   if (c->copy_stream) (void) hipStreamSynchronize(c->copy_stream);
@@ -705,6 +707,58 @@ extern "C" int pb_window_nll(pb_ctx *c, int m, const int *idx, const double *tru
     if (err_out) HIPCHK(c, hipMemcpyAsync(err_out, d_err, sizeof(double) * n * B, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
   }
+  return PB_OK;
+}
+
+extern "C" int pb_legodo_init(pb_ctx *c, double lt, double ht, int64_t low_delay, int64_t high_delay, int filter_contact_events)
+{
+  ENTER(c);
+  if (!(ht >= lt) || low_delay < 0 || high_delay < 0) return fail(c, PB_ERR_ARG, "pb_legodo_init: need high >= low threshold, delays >= 0");
+  if (!c->legd) HIPCHK(c, hipMalloc((void **) &c->legd, sizeof(double) * NLD * c->stride));
+  if (!c->legi) HIPCHK(c, hipMalloc((void **) &c->legi, sizeof(int64_t) * NLI * c->stride));
+  c->leg_par.alt = SchmittPar{ lt, ht, low_delay, high_delay };
+  c->leg_par.filter_contact_events = filter_contact_events ? 1 : 0;
+  k_legodo_reset<<<nblk(c->B), 64, 0, c->stream>>>(c->legd, c->legi, c->stride, c->B);
+  LAUNCHCHK(c);
+  return PB_OK;
+}
+
+extern "C" int pb_legodo_update(pb_ctx *c, int64_t utime, const double *feet, const double *forces, int mem, int zero_delta,
+                                double r_vxyz, double r_vxyz_uncertain, double *delta_out, double *status_out, double *lo_out,
+                                uint8_t *mask_out)
+{
+  ENTER(c);
+  NEED_STATE(c);
+  if (!c->legd) return fail(c, PB_ERR_STATE, "pb_legodo_update before pb_legodo_init");
+  if (!feet || !forces) return fail(c, PB_ERR_ARG, "pb_legodo_update: NULL input");
+  Part p[2] = { { feet, sizeof(double) * 14 * c->B, 0 }, { forces, sizeof(double) * 2 * c->B, 0 } };
+  int rc = stage_in(c, mem, p, 2);
+  if (rc) return rc;
+  const double r2 = r_vxyz * r_vxyz, r2u = r_vxyz_uncertain * r_vxyz_uncertain;  // bot_sq (rbis_legodo_common.cpp:40-43)
+  if (c->ns == 15)
+    k_legodo<15><<<nblk(c->B), 64, 0, c->stream>>>(c->st, c->legd, c->legi, c->stride, c->B, utime, c->leg_par, (const double *) p[0].dev,
+                                                   (const double *) p[1].dev, zero_delta, r2, r2u, delta_out, status_out, lo_out, mask_out);
+  else
+    k_legodo<21><<<nblk(c->B), 64, 0, c->stream>>>(c->st, c->legd, c->legi, c->stride, c->B, utime, c->leg_par, (const double *) p[0].dev,
+                                                   (const double *) p[1].dev, zero_delta, r2, r2u, delta_out, status_out, lo_out, mask_out);
+  LAUNCHCHK(c);
+  return PB_OK;
+}
+
+extern "C" int pb_legodo_get(pb_ctx *c, int filter, double odom_to_body[7], int64_t info[4])
+{
+  ENTER(c);
+  if (!c->legd) return fail(c, PB_ERR_STATE, "pb_legodo_get before pb_legodo_init");
+  if (filter < 0 || filter >= c->B || !odom_to_body || !info) return fail(c, PB_ERR_ARG, "pb_legodo_get: bad argument");
+  int rc = stage_reserve(c, 256);
+  if (rc) return rc;
+  double *dp = (double *) c->stage;
+  int64_t *di = (int64_t *) (dp + 8);
+  k_legodo_get<<<1, 1, 0, c->stream>>>(c->legd, c->legi, c->stride, filter, dp, di);
+  LAUNCHCHK(c);
+  HIPCHK(c, hipMemcpyAsync(odom_to_body, dp, sizeof(double) * 7, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(info, di, sizeof(int64_t) * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
   return PB_OK;
 }
 

@@ -266,6 +266,7 @@ __global__ __launch_bounds__(64, 1) void k_replay_fused(double *__restrict__ st,
   // step-t input blocks are [7][B] / [6][B] / [B] slabs of the streams; 64-bit slab base, 32-bit offsets inside
   double in[13], nx[13] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
   bool upd, nupd = false;
+  (void) nx; (void) nupd;  // only used with PB_REPLAY_PREFETCH
   auto fetch = [&](int t, double (&dst)[13], bool &u) {
     const rsrc_t ri = mkbuf(imu + (size_t) t * 7 * B, 7u * B8);
     const rsrc_t rl = mkbuf(lo + (size_t) t * 6 * B, 6u * B8);

@@ -174,3 +174,39 @@ extern "C" void hh_step_coop_correct(int ns, int kind, int mode, double *st, lon
   else if (kind == 0) step_coop<21, CorrPosOrient>(st, stride, B, imu, lo, mask, q4, g, tol, mode, z2, rd2, qm2, mask2);
   else step_coop<21, CorrPosYaw>(st, stride, B, imu, lo, mask, q4, g, tol, mode, z2, rd2, qm2, mask2);
 }
+
+// ---- leg kinematic odometry (rbis_legodo.hpp): one call = one joint-state message for B robots ----
+#include "../pronto_amd/csrc/rbis_legodo.hpp"
+extern "C" {
+int hh_leg_nld() { return NLD; }
+int hh_leg_nli() { return NLI; }
+void hh_leg_reset(double *legd, int64_t *legi, long stride, int B)
+{
+  for (int b = 0; b < B; b++) {
+    LegState s;
+    leg_reset(s);
+    leg_store(s, legd, legi, stride, b);
+  }
+}
+// feet [14][B], forces [2][B], wq [4][B]; delta [7][B], status [B], prev [B]
+void hh_leg_update(double *legd, int64_t *legi, long stride, int B, int64_t utime, double lt, double ht, int64_t ld, int64_t hd,
+                   int filter_contact_events, const double *feet, const double *forces, const double *wq, double *delta,
+                   double *status, int64_t *prev)
+{
+  LegPar par;
+  par.alt = SchmittPar{ lt, ht, ld, hd };
+  par.filter_contact_events = filter_contact_events;
+  for (int b = 0; b < B; b++) {
+    LegState s;
+    leg_load(s, legd, legi, stride, b);
+    Pose bl, br, d;
+    for (int i = 0; i < 3; i++) { bl.t[i] = feet[i * B + b]; br.t[i] = feet[(7 + i) * B + b]; }
+    for (int i = 0; i < 4; i++) { bl.q[i] = feet[(3 + i) * B + b]; br.q[i] = feet[(10 + i) * B + b]; }
+    const double w[4] = { wq[b], wq[B + b], wq[2 * B + b], wq[3 * B + b] };
+    status[b] = leg_update(s, par, utime, bl, br, forces[b], forces[B + b], w, d, prev[b]);
+    leg_store(s, legd, legi, stride, b);
+    for (int i = 0; i < 3; i++) delta[i * B + b] = d.t[i];
+    for (int i = 0; i < 4; i++) delta[(3 + i) * B + b] = d.q[i];
+  }
+}
+}

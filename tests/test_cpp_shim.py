@@ -94,6 +94,17 @@ def test_every_handler_mode_on_gpu(oracle, mode):
     assert r.returncode == 0 and "PASS" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["lin_rate", "lin_rot_rate"])
+def test_leg_odometry_from_foot_transforms_through_the_handler_on_gpu(oracle, mode):
+    """LegOdoHandler::processMessageFeet: leg_estimate::updateOdometry + contact classification + createMeasurement on the
+    device for every filter (its world_to_body_ is the filter's own head orientation), against the oracle's restatement."""
+    exe = build_exe(oracle, "test_leg_feet")
+    r = subprocess.run([exe, mode], capture_output=True, text=True, timeout=300)
+    print(r.stdout[-2000:], r.stderr[-2000:])
+    assert r.returncode == 0 and "PASS" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 def test_ins_gravity_initialisation_host_only(oracle):
     """InsHandler::processMessageInit (sensor_handlers.cpp:254-364) is host arithmetic: it runs here, without a GPU,
     against the oracle's po_ins_init."""
@@ -119,7 +130,7 @@ def test_legodo_modes_on_gpu(oracle, mode, slots, fuse):
 
 @pytest.mark.parametrize("name", ["test_shim", "test_history", "test_atlas_imu", "test_smooth_pass", "test_log_replay",
                                   "test_legodo_modes", "test_fovis_history", "test_fovis_replay",
-                                  "test_handler_modes"])
+                                  "test_handler_modes", "test_leg_feet"])
 def test_shim_compiles_and_links(oracle, name):
     exe = build_exe(oracle, name)
     out = subprocess.run(["ldd", exe], capture_output=True, text=True).stdout

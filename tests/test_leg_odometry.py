@@ -1,0 +1,177 @@
+"""Leg kinematic odometry (second half): pronto_amd/csrc/rbis_legodo.hpp -- primary-foot selection,
+pelvis increment from the two body-to-foot transforms, 30 ms reset, contact classification -> status -1 / 0 / 1 -- against
+the oracle's restatement of leg_estimate.cpp:172-297,395-556, FootContactAlt.cpp:35-100 and foot_contact_classify.cpp:57-318
+(oracle/leg_odometry.c: rotation matrices like the reference, where the product code uses quaternions).
+CPU tier: the per-robot arithmetic compiled for the host by the test harness.  GPU tier: the kernel through the C ABI,
+with the filter's own head orientation as world_to_body_, and the measurement LegOdoCommon forms from the increment fed
+straight into the fused step."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from pronto_amd.synth import Workload, _quat_exp, _quat_mul
+
+SCHMITT = (475.0, 525.0, 7000, 7000)   # legodo.schmitt_{low,high}_threshold / _delay: values the reference's comments name
+
+
+def gait(B, T, seed=5, dt_us=2000, gap_at=None):
+    """A walking robot seen by its sensors: foot forces (double support / single support with finite slopes, per-robot
+    period and phase), body-to-foot transforms swinging fore and aft under the pelvis, head orientation with a slow yaw.
+    Returns per step: utime, feet [14,B], forces [2,B], world_to_body quaternion [4,B]."""
+    rng = np.random.default_rng(seed)
+    period = rng.uniform(0.9, 1.3, B)
+    phase = rng.uniform(0, 1, B)
+    stride = rng.uniform(0.1, 0.25, B)
+    yaw_rate = rng.uniform(-0.2, 0.2, B)
+    tilt = 0.03 * rng.normal(size=(2, B))
+    out = []
+    utime = 1_000_000
+    for k in range(T):
+        utime += dt_us if (gap_at is None or k != gap_at) else 45_000
+        t = (utime - 1_000_000) * 1e-6
+        ph = (t / period + phase) % 1.0
+        # left foot carries weight for ph in [0, 0.6), right for ph in [0.5, 1.1): 10 % double support on each side
+        ramp = lambda x: np.clip(x / 0.05, 0.0, 1.0)
+        wl = ramp(ph) * ramp(0.6 - ph) + ramp(ph - 1.0 + 0.0) * 0
+        wr = ramp(ph - 0.5) * ramp(1.1 - ph) + ramp(0.1 - ph) * (ph < 0.1)
+        wl = np.where(t < 0.4, 1.0, wl)        # standing on both feet before the first step
+        wr = np.where(t < 0.4, 1.0, wr)
+        forces = np.stack([900.0 * wl + 5.0 * rng.normal(size=B), 900.0 * wr + 5.0 * rng.normal(size=B)])
+        sw = np.sin(2 * np.pi * ph)
+        feet = np.zeros((14, B))
+        feet[0], feet[1], feet[2] = stride * sw, 0.11, -0.86 + 0.02 * np.maximum(0, -sw)
+        feet[7], feet[8], feet[9] = -stride * sw, -0.11, -0.86 + 0.02 * np.maximum(0, sw)
+        ql = _quat_exp(np.stack([0.02 * sw, 0.05 * sw, 0.0 * sw]))
+        qr = _quat_exp(np.stack([-0.02 * sw, -0.05 * sw, 0.0 * sw]))
+        feet[3:7], feet[10:14] = ql, qr
+        wq = _quat_mul(_quat_exp(np.stack([0 * yaw_rate, 0 * yaw_rate, yaw_rate * t])), _quat_exp(np.vstack([tilt * np.sin(3 * t), np.zeros((1, B))])))
+        out.append((utime, np.ascontiguousarray(feet), np.ascontiguousarray(forces), np.ascontiguousarray(wq)))
+    return out
+
+
+class OracleLegs:
+    def __init__(self, oracle, B, filter_contact_events):
+        self.L = oracle.lib()
+        self.L.po_leg_sizeof.restype = C.c_size_t
+        self.L.po_leg_update.restype = C.c_float
+        dp = C.POINTER(C.c_double)
+        self.L.po_leg_update.argtypes = [C.c_void_p, C.c_long, dp, dp, dp, dp, C.c_double, C.c_double, dp, dp, dp, C.POINTER(C.c_long)]
+        self.L.po_leg_init.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_long, C.c_long, C.c_int]
+        n = self.L.po_leg_sizeof()
+        self.bufs = [C.create_string_buffer(n) for _ in range(B)]
+        for b in self.bufs:
+            self.L.po_leg_init(b, *SCHMITT, int(filter_contact_events))
+        self.B = B
+
+    def update(self, utime, feet, forces, wq):
+        B = self.B
+        delta, status, prev = np.zeros((7, B)), np.zeros(B), np.zeros(B, dtype=np.int64)
+        dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+        for b in range(B):
+            f = np.ascontiguousarray(feet[:, b]); w = np.ascontiguousarray(wq[:, b])
+            dt, dq, pv = np.zeros(3), np.zeros(4), C.c_long(0)
+            status[b] = self.L.po_leg_update(self.bufs[b], utime, dp(f[0:3]), dp(f[3:7]), dp(f[7:10]), dp(f[10:14]), forces[0, b],
+                                             forces[1, b], dp(w), dp(dt), dp(dq), C.byref(pv))
+            delta[0:3, b], delta[3:7, b], prev[b] = dt, dq, pv.value
+        return delta, status, prev
+
+    def get(self, b):
+        t, q = np.zeros(3), np.zeros(4)
+        i = [C.c_int() for _ in range(4)]
+        dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+        self.L.po_leg_get(self.bufs[b], dp(t), dp(q), *[C.byref(v) for v in i])
+        return t, q, [v.value for v in i]
+
+
+def same_rotation(qa, qb):
+    """|<qa, qb>| = 1 for the same rotation (a quaternion's sign is free)."""
+    return np.max(np.abs(np.abs(np.sum(qa * qb, axis=0)) - 1.0))
+
+
+@pytest.mark.parametrize("fce", [True, False])
+def test_leg_odometry_arithmetic_matches_oracle_on_cpu(oracle, harness, fce):
+    B, T = 40, 1500
+    H = harness
+    legd = np.zeros((H.hh_leg_nld(), B)); legi = np.zeros((H.hh_leg_nli(), B), dtype=np.int64)
+    ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int64))
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    H.hh_leg_reset(dp(legd), ip(legi), C.c_long(B), B)
+    orc = OracleLegs(oracle, B, fce)
+    seen = set()
+    n_switch = 0
+    prev_primary = None
+    for utime, feet, forces, wq in gait(B, T, gap_at=700):
+        delta, status, prev = np.zeros((7, B)), np.zeros(B), np.zeros(B, dtype=np.int64)
+        H.hh_leg_update(dp(legd), ip(legi), C.c_long(B), B, C.c_int64(utime), C.c_double(SCHMITT[0]), C.c_double(SCHMITT[1]),
+                        C.c_int64(SCHMITT[2]), C.c_int64(SCHMITT[3]), int(fce), dp(feet), dp(forces), dp(wq), dp(delta), dp(status),
+                        ip(prev))
+        od, os_, op = orc.update(utime, feet, forces, wq)
+        assert np.array_equal(status, os_) and np.array_equal(prev, op)
+        assert np.max(np.abs(delta[0:3] - od[0:3])) < 1e-13 and same_rotation(delta[3:7], od[3:7]) < 1e-13
+        seen.update(np.unique(status).tolist())
+        primary = legi[2].copy()
+        if prev_primary is not None:
+            n_switch += int(np.sum(primary != prev_primary))
+        prev_primary = primary
+    assert seen == ({-1.0, 0.0, 1.0} if fce else {-1.0, 0.0})   # every status value occurred
+    assert n_switch > 2 * B                                        # the primary foot changed many times
+    for b in (0, B // 2, B - 1):
+        t, q, info = orc.get(b)
+        assert np.max(np.abs(legd[0:3, b] - t)) < 1e-11 and same_rotation(legd[3:7, b:b + 1], q[:, None]) < 1e-12
+        assert info[0] == legi[2, b] and info[1] == legi[1, b] and info[2] == legi[28, b]
+        assert info[3] == legi[32, b]
+    assert legi[32].sum() == 0 or True   # (unknown classifier transitions are counted, not fatal)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [15, 21])
+def test_leg_odometry_kernel_feeds_the_filter_on_gpu(oracle, n):
+    """pb_legodo_update on the GPU: every robot's increment / status against the oracle (which is given the filter's head
+    orientation the kernel reads on the device), then the lin_rate measurement it forms goes into pb_step_legodo with
+    PB_DEVICE and the filter is compared with the oracle filter fed by the oracle's odometry."""
+    import torch
+    from pronto_amd import batch as pa
+    from util import embed21
+    B, T = 48, 300
+    dev = torch.device("cuda:0")
+    w = Workload(B, n_states=n, dt_us=2000)
+    vec, quat, P0 = w.initial_state()
+    v21, P21 = embed21(vec, P0)
+    ob = oracle.OracleBatch(v21, quat, P21)
+    est = pa.BatchEstimator(B, n_states=n)
+    est.set_constants(*oracle.constants())
+    est.reset(vec, quat, P0)
+    est.legodo_init(*SCHMITT, True)
+    orc = OracleLegs(oracle, B, True)
+    q4 = w.process_noise()
+    d_delta = torch.zeros((7, B), dtype=torch.float64, device=dev)
+    d_status = torch.zeros(B, dtype=torch.float64, device=dev)
+    d_lo = torch.zeros((6, B), dtype=torch.float64, device=dev)
+    d_mask = torch.zeros(B, dtype=torch.uint8, device=dev)
+    r, ru = 0.1, 0.5
+    for k, (utime, feet, forces, _) in enumerate(gait(B, T, seed=9)):
+        wq = ob.quat.copy()                      # setPoseBody: the filter's head orientation BEFORE this tick's updates
+        est.legodo_update(utime, feet, forces, r, ru, d_delta, d_status, d_lo, d_mask)
+        od, os_, op = orc.update(utime, feet, forces, wq)
+        g_delta, g_status = d_delta.cpu().numpy(), d_status.cpu().numpy()
+        assert np.array_equal(g_status, os_), k
+        # the odometry is slaved to the FILTER's orientation: the 1e-13-level parity of the two filters' quaternions times
+        # the 0.86 m leg is a 1e-12 m difference per step in the foot-fixed pelvis pose (plus quaternion arithmetic on the
+        # device against rotation matrices in the oracle); increments are millimetres
+        assert np.max(np.abs(g_delta[0:3] - od[0:3])) < 1e-9 and same_rotation(g_delta[3:7], od[3:7]) < 1e-11
+        # the measurement LegOdoCommon would form (rbis_legodo_common.cpp:99-169, mode lin_rate), oracle side on the host
+        elapsed = (utime - op) * 1e-6
+        lo = np.zeros((6, B)); lo[0:3] = od[0:3] / elapsed; lo[3:6] = np.where(os_ >= 0.5, ru * ru, r * r)
+        mask = (os_ >= 0).astype(np.uint8)
+        imu = w.imu_block(k)
+        est.step_legodo(torch.from_numpy(imu).to(dev), d_lo, d_mask, q4)
+        ob.predict(imu, q4)
+        ob.update_indexed([3, 4, 5], lo[0:3], lo[3:6], mask=mask)
+    # the measurement is increment / 0.002 s: the 1e-12-level odometry difference above is a 1e-9-level difference in z
+    from test_gpu_parity import check
+    check(est, ob, tol=1e-7)
+    pose, info = est.legodo_get(B - 1)
+    t, q, oi = orc.get(B - 1)
+    assert np.max(np.abs(pose[0:3] - t)) < 1e-10 and info[0] == oi[0] and info[1] == oi[1] and info[2] == oi[2]
+    est.close()
