@@ -911,6 +911,15 @@ void po_quat_from_two_vectors(const double *a, const double *b, double *q)
   for (i = 0; i < 3; i++) q[1 + i] = axis[i] * invs;
 }
 
+/* sensor_handlers.cpp:338-351: yaw from the mean magnetometer vector (body frame), horizontal part turned onto +y (ENU) */
+void po_ins_init_yaw(const double *mag_vec_sum, int count, const double *quat_in, double *quat_out)
+{
+  double m_est[3] = { mag_vec_sum[0] / (double) count, mag_vec_sum[1] / (double) count, 0.0 }, qm[4];
+  const double unit_y[3] = { 0.0, 1.0, 0.0 };
+  po_quat_from_two_vectors(m_est, unit_y, qm);
+  po_quat_mul(qm, quat_in, quat_out);
+}
+
 void po_ins_init(const double *g_vec_sum, const double *gyro_sum, int count, double max_gyro_bias, const double *quat_in,
                  double *quat_out, double *gyro_bias_est)
 {

@@ -112,6 +112,9 @@ void po_quat_from_two_vectors(const double *a, const double *b, double *q);
 void po_ins_init(const double *g_vec_sum, const double *gyro_sum, int count, double max_gyro_bias, const double *quat_in,
                  double *quat_out, double *gyro_bias_est);
 
+/* the GPS / magnetometer yaw branch (:338-351): quat_out = setFromTwoVectors((mag_sum/count with z = 0), +y) * quat_in */
+void po_ins_init_yaw(const double *mag_vec_sum, int count, const double *quat_in, double *quat_out);
+
 /* ---- measurement formers (handlers' arithmetic) ---- */
 void po_euler_to_quat(double roll, double pitch, double yaw, double *q);    /* pronto_math.cpp:25-50 */
 void po_quat_to_euler(const double *q, double *rpy);                        /* pronto_math.cpp:53-61 */

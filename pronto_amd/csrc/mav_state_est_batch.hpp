@@ -795,6 +795,7 @@ namespace msgs {
 struct ins_t {               // bot_core::ins_t
   int64_t utime;
   BatchArray gyro, accel;    // [3][B] each, sensor frame
+  BatchArray mag;            // [3][B] magnetometer, sensor frame; optional (p == NULL: zeros, like the Atlas path :274)
 };
 struct kvh_raw_imu_t {       // the newest packet of bot_core::kvh_raw_imu_batch_t (atlas_filter == false path)
   int64_t utime;
@@ -1078,12 +1079,13 @@ public:
   // (init quat = init quat * setFromTwoVectors(mean(-accel), -z)), the gyro bias from the mean rate (0 if any axis exceeds
   // max_initial_gyro_bias), the matching covariance blocks from default_cov.  As in the reference the INS goes last
   // (allInitializedExcept "ins") and the bias that ends up in init_state is *_bias_initial -- the estimate only if
-  // *_bias_recalc_at_start.  The GPS / magnetometer yaw alignment (:338-351) needs the magnetometer of bot_core::ins_t,
-  // which the batch message does not carry: not built.  Keys are read (or_fail) on first use.
+  // *_bias_recalc_at_start.  When the filter also initialises with "gps", the yaw comes from the mean magnetometer vector
+  // (msgs::ins_t::mag, moved to the body frame with bot_trans_apply_vec like :148): its horizontal part is turned onto +y
+  // (ENU, :338-351).  Keys are read (or_fail) on first use.
   int num_to_init = 0, init_counter = 0;
   double max_initial_gyro_bias = 0;
   bool accel_bias_recalc_at_start = false, gyro_bias_recalc_at_start = false;
-  std::vector<double> g_vec_sum, gyro_bias_sum;              // [3][B]
+  std::vector<double> g_vec_sum, gyro_bias_sum, mag_vec_sum;  // [3][B]
   std::vector<double> gyro_bias_initial, accel_bias_initial;  // [3] (same for every filter) or [3][B] after a recalc
   bool processMessageInit(const msgs::ins_t *msg, const std::map<std::string, bool> &sensors_initialized,
                           const RBIS & /*default_state*/, const RBIM &default_cov, RBIS &init_state, RBIM &init_cov)
@@ -1100,6 +1102,7 @@ public:
       gyro_bias_recalc_at_start = bot_param_get_boolean_or_fail(param_, "state_estimator.ins.gyro_bias_recalc_at_start");
       g_vec_sum.assign((size_t) 3 * B, 0.0);
       gyro_bias_sum.assign((size_t) 3 * B, 0.0);
+      mag_vec_sum.assign((size_t) 3 * B, 0.0);
       init_params_read_ = true;
     }
     init_state.utime = msg->utime;
@@ -1120,6 +1123,16 @@ public:
       }
     }
     delete update;
+    if (msg->mag.p != nullptr && msg->mag.mem != PB_DEVICE) {  // :147-149, :290
+      const size_t mper = (msg->mag.mem == PB_HOST_BROADCAST) ? 1 : (size_t) B;
+      for (int b = 0; b < B; b++) {
+        const size_t sb = (mper == 1) ? 0 : (size_t) b;
+        const double ms[3] = { msg->mag.p[sb], msg->mag.p[mper + sb], msg->mag.p[2 * mper + sb] };
+        double mb[3];
+        bot_trans_apply_vec(&ins_to_body, ms, mb);
+        for (int i = 0; i < 3; i++) mag_vec_sum[(size_t) i * B + b] += mb[i];
+      }
+    }
     if (init_counter < num_to_init) return false;
     bool warned = false;
     std::vector<double> gb_est((size_t) 3 * B);
@@ -1153,6 +1166,19 @@ public:
           for (int c = 0; c < 3; c++)
             init_cov(RBIS::gyro_bias_ind + r, RBIS::gyro_bias_ind + c, b) = default_cov(RBIS::gyro_bias_ind + r, RBIS::gyro_bias_ind + c, b);
       for (int i = 0; i < 3; i++) gb_est[(size_t) i * B + b] = gb[i];
+      if (RBISInitializer::initializingWith(sensors_initialized, "gps")) {                      // :338-351
+        double m_est[3] = { mag_vec_sum[b] / (double) init_counter, mag_vec_sum[(size_t) B + b] / (double) init_counter, 0.0 };
+        const double unit_y[3] = { 0.0, 1.0, 0.0 };  // "in ENU, the magnetic vector should be aligned with Y axis"
+        double qm[4];
+        quat_from_two_vectors(m_est, unit_y, qm);
+        const double q1[4] = { init_state.q(0, b), init_state.q(1, b), init_state.q(2, b), init_state.q(3, b) };
+        const double qy[4] = { qm[0] * q1[0] - qm[1] * q1[1] - qm[2] * q1[2] - qm[3] * q1[3],
+                               qm[0] * q1[1] + qm[1] * q1[0] + qm[2] * q1[3] - qm[3] * q1[2],
+                               qm[0] * q1[2] - qm[1] * q1[3] + qm[2] * q1[0] + qm[3] * q1[1],
+                               qm[0] * q1[3] + qm[1] * q1[2] - qm[2] * q1[1] + qm[3] * q1[0] };
+        for (int i = 0; i < 4; i++) init_state.q(i, b) = qy[i];                                 // quat_mag * orientation
+        init_cov(RBIS::chi_ind + 2, RBIS::chi_ind + 2, b) = default_cov(RBIS::chi_ind + 2, RBIS::chi_ind + 2, b);
+      }
     }
     if (accel_bias_recalc_at_start && n == RBIS::rbis_num_states) {  // :353-356: whatever init_state holds now
       accel_bias_initial.resize((size_t) 3 * B);
