@@ -337,7 +337,7 @@ def main():
     summary = allreduce_summary(est.summary(), dist if use_dist else None, cdev)
 
     fused = None
-    if args.fused > 0:
+    if args.fused > 0:  # (15 and 21 states: the cooperative replay kernel)
         # secondary accounting: bytes_step(T) = 2*(S_x+S_P+8)/T + 56 + 48; the bound is fp64 VALU issue
         Tf = args.fused
         est.reset(vec, quat, P0)

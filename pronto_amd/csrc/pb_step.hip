@@ -38,7 +38,14 @@ int pbk_step(pb_ctx *c, bool update, const double *imu, const double *lo, const 
 
 int pbk_replay_fused(pb_ctx *c, int T, const double *imu, const double *lo, const uint8_t *mask, const double q[4])
 {
-  k_replay_fused<15><<<nblk(c->B), 64, 0, c->stream>>>(c->st, c->B, T, imu, lo, mask, q[0], q[1], q[2], q[3], c->k);
+  // PRONTO_BATCH_REPLAY_ONELANE=1: the first, one-lane-per-filter version (15 states only; A/B runs)
+  static const bool one_lane = getenv("PRONTO_BATCH_REPLAY_ONELANE") && getenv("PRONTO_BATCH_REPLAY_ONELANE")[0] == '1';
+  if (c->ns == 15 && one_lane)
+    k_replay_fused<15><<<nblk(c->B), 64, 0, c->stream>>>(c->st, c->B, T, imu, lo, mask, q[0], q[1], q[2], q[3], c->k);
+  else if (c->ns == 15)
+    k_replay_coop<15><<<nblk(c->B), 128, 0, c->stream>>>(c->st, c->B, T, imu, lo, mask, q[0], q[1], q[2], q[3], c->k);
+  else
+    k_replay_coop<21><<<nblk(c->B), 128, 0, c->stream>>>(c->st, c->B, T, imu, lo, mask, q[0], q[1], q[2], q[3], c->k);
   LAUNCHCHK(c);
   return PB_OK;
 }

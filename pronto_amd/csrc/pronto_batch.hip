@@ -447,7 +447,6 @@ extern "C" int pb_replay_legodo_fused(pb_ctx *c, int n_steps, int steps_per_laun
 {
   ENTER(c);
   NEED_STATE(c);
-  if (c->ns != 15) return fail(c, PB_ERR_ARG, "pb_replay_legodo_fused: only the 15-state filter has a time-fused kernel");
   if (n_steps < 0 || steps_per_launch < 1 || !imu_stream || !lo_stream || !q)
     return fail(c, PB_ERR_ARG, "pb_replay_legodo_fused: bad argument");
   const size_t B = (size_t) c->B;

@@ -710,6 +710,109 @@ __global__ __launch_bounds__(128, 1) void k_step_coop(const double *st, double *
 #endif
 }
 
+// Time-fused replay on the cooperative mapping: T consecutive predict + leg-odometry steps per launch with each role's part
+// of the state resident in ITS registers; only the 104 B/filter of inputs stream from HBM per step and the posterior is
+// written once per launch.  Per step the two roles trade what the other needs of the state vector through LDS (role C
+// gives v chi Delta [biases] quat, role P gives omega accel: the process blocks linearise about the whole prior state),
+// then run exactly the bodies of k_step_coop with loads and stores redirected to registers.  Two barriers per step.
+// No per-message posterior: NOT the plugin path (see pb_replay_legodo_fused); accounting 104 + 2*state/T bytes per step.
+template <int NS>
+__global__ __launch_bounds__(128, 1) void k_replay_coop(double *st, int B, int T, const double *__restrict__ imu,
+                                                        const double *__restrict__ lo, const uint8_t *__restrict__ mask,
+                                                        double qg, double qa, double qbg, double qba, Consts k)
+{
+  using L = Lay<NS>;
+  using C = Coop<NS>;
+  using SL = Slots<NS>;
+  __shared__ double xch[C::NXCH][64];
+  __shared__ double xst[NS + 4][64];
+  const int role = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
+  const unsigned lane = threadIdx.x & 63u;
+  const unsigned tile = blockIdx.x;
+  const unsigned b = tile * 64u + lane;
+  const unsigned bo = b * 8u, B8 = (unsigned) B * 8u;
+  TileIO<NS, 0, 0> io(st, st, tile, lane);
+  double q4[4] = { qg, qa, qbg, qba };
+  if (k.qblk != nullptr) {
+    const rsrc_t rq = mkbuf(k.qblk, 4u * B8);
+#pragma unroll
+    for (int i = 0; i < 4; i++) q4[i] = ldg(rq, (unsigned) i * B8, bo);
+  }
+  auto sync = []() { __syncthreads(); };
+  auto xw = [lane](int s, double v) { xch[s][lane] = v; };
+  auto xrd = [lane](int s) { return xch[s][lane]; };
+  // inputs of step t (both roles need the IMU block; role C the measurement)
+  auto inputs = [&](int t) {
+    const rsrc_t ri = mkbuf(imu + (size_t) t * 7 * B, 7u * B8);
+    const rsrc_t rl = mkbuf(lo + (size_t) t * 6 * B, 6u * B8);
+    StepInputs in;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      in.gyro[i] = ldg(ri, i * B8, bo);
+      in.accel[i] = ldg(ri, (3 + i) * B8, bo);
+      in.z[i] = ldg(rl, i * B8, bo);
+      in.rd[i] = ldg(rl, (3 + i) * B8, bo);
+    }
+    in.dt = ldg(ri, 6u * B8, bo);
+    in.upd = (b < (unsigned) B) && (mask == nullptr || mask[(size_t) t * B + b] != 0);
+    in.qg = q4[0]; in.qa = q4[1]; in.qbg = q4[2]; in.qba = q4[3];
+    return in;
+  };
+  // The two roles run SEPARATE loops (the same two barriers per iteration in each): with one loop around a role branch
+  // every component of both roles would be live across the back edge.
+  if (role == 0) {
+    double V[L::NC];  // canonical components; a role only ever touches its own ones plus the other's state vector
+    io.template need<0, SL::ROW_SPLIT>();
+    static_for<SL::NSLOT>([&](auto I) {
+      constexpr int slot = decltype(I)::value, comp = SL::T.comp_of[slot];
+      if constexpr (comp >= 0 && slot < SL::T.ncore) V[comp] = io.ld(comp);
+    });
+    auto ld = [&V](int comp) { return V[comp]; };
+    auto stf = [&V](int comp, double v) { V[comp] = v; };
+    for (int t = 0; t < T; t++) {
+      const StepInputs in = inputs(t);
+#pragma unroll
+      for (int i = 0; i < C::NSC; i++) xst[C::fullc(i)][lane] = V[L::OFF_VEC + C::fullc(i)];
+#pragma unroll
+      for (int i = 0; i < 4; i++) xst[NS + i][lane] = V[L::OFF_QUAT + i];
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < 6; i++) V[L::OFF_VEC + C::fullp(i)] = xst[C::fullp(i)][lane];
+      coop_role_core<NS, true>(ld, stf, xw, xrd, sync, in, k);
+      // (no third barrier: this role overwrites the hand-off only behind the next state-exchange barrier, which role P
+      // reaches after it has finished reading; the exchange slots of the two roles are disjoint)
+    }
+    static_for<SL::NSLOT>([&](auto I) {
+      constexpr int slot = decltype(I)::value, comp = SL::T.comp_of[slot];
+      if constexpr (comp >= 0 && slot < SL::T.ncore) io.st(comp, V[comp]);
+    });
+  } else {
+    double V[L::NC];
+    io.template need<SL::ROW_SPLIT, SL::NROW>();
+    static_for<SL::NSLOT>([&](auto I) {
+      constexpr int slot = decltype(I)::value, comp = SL::T.comp_of[slot];
+      if constexpr (comp >= 0 && slot >= SL::T.ncore) V[comp] = io.ld(comp);
+    });
+    auto ld = [&V](int comp) { return V[comp]; };
+    auto stf = [&V](int comp, double v) { V[comp] = v; };
+    for (int t = 0; t < T; t++) {
+      const StepInputs in = inputs(t);
+#pragma unroll
+      for (int i = 0; i < 6; i++) xst[C::fullp(i)][lane] = V[L::OFF_VEC + C::fullp(i)];
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < C::NSC; i++) V[L::OFF_VEC + C::fullc(i)] = xst[C::fullc(i)][lane];
+#pragma unroll
+      for (int i = 0; i < 4; i++) V[L::OFF_QUAT + i] = xst[NS + i][lane];
+      coop_role_passive<NS, true>(ld, stf, xrd, sync, in, k);
+    }
+    static_for<SL::NSLOT>([&](auto I) {
+      constexpr int slot = decltype(I)::value, comp = SL::T.comp_of[slot];
+      if constexpr (comp >= 0 && slot >= SL::T.ncore) io.st(comp, V[comp]);
+    });
+  }
+}
+
 // PB_HOST_BROADCAST inputs: dst [rows][B] <- one value per row (pronto_batch.hip stage_in)
 struct RowVals {
   static constexpr int MAX = 36;  // the largest block of one call: a full 6 x 6 measurement covariance
