@@ -158,8 +158,10 @@ def test_leg_odometry_kernel_feeds_the_filter_on_gpu(oracle, n):
         assert np.array_equal(g_status, os_), k
         # the odometry is slaved to the FILTER's orientation: the 1e-13-level parity of the two filters' quaternions times
         # the 0.86 m leg is a 1e-12 m difference per step in the foot-fixed pelvis pose (plus quaternion arithmetic on the
-        # device against rotation matrices in the oracle); increments are millimetres
-        assert np.max(np.abs(g_delta[0:3] - od[0:3])) < 1e-9 and same_rotation(g_delta[3:7], od[3:7]) < 1e-11
+        # device against rotation matrices in the oracle); the measurement is that increment / 0.002 s and goes back into
+        # the filter whose orientation the next increment is slaved to: a closed loop with a gain of 500.  Increments are
+        # millimetres, so 1e-8 m is still five significant digits.
+        assert np.max(np.abs(g_delta[0:3] - od[0:3])) < 1e-8 and same_rotation(g_delta[3:7], od[3:7]) < 1e-10
         # the measurement LegOdoCommon would form (rbis_legodo_common.cpp:99-169, mode lin_rate), oracle side on the host
         elapsed = (utime - op) * 1e-6
         lo = np.zeros((6, B)); lo[0:3] = od[0:3] / elapsed; lo[3:6] = np.where(os_ >= 0.5, ru * ru, r * r)
@@ -170,7 +172,7 @@ def test_leg_odometry_kernel_feeds_the_filter_on_gpu(oracle, n):
         ob.update_indexed([3, 4, 5], lo[0:3], lo[3:6], mask=mask)
     # the measurement is increment / 0.002 s: the 1e-12-level odometry difference above is a 1e-9-level difference in z
     from test_gpu_parity import check
-    check(est, ob, tol=1e-7)
+    check(est, ob, tol=1e-6)
     pose, info = est.legodo_get(B - 1)
     t, q, oi = orc.get(B - 1)
     assert np.max(np.abs(pose[0:3] - t)) < 1e-10 and info[0] == oi[0] and info[1] == oi[1] and info[2] == oi[2]
