@@ -9,9 +9,12 @@ static void launch_step_mh(pb_ctx *c, double *out, const double *imu, const doub
     k_step_coop<15, UPDATE, MH><<<nblk(B), 128, 0, c->stream>>>(c->st, out, B, imu, lo, mask, q[0], q[1], q[2], q[3], c->k, CorrArgs());
   } else if (c->ns == 15) {
     k_step<15, UPDATE, MH><<<(B + PB_STEP_BLOCK - 1) / PB_STEP_BLOCK, PB_STEP_BLOCK, 0, c->stream>>>(c->st, out, B, imu, lo, mask, q[0], q[1], q[2], q[3], c->k);
+  } else if (c->quad21) {
+    // n = 21: 231 packed covariance entries do not fit one lane's registers; four cooperating waves per tile at two waves
+    // per SIMD (rbis_quad.hpp): one launch, one state round trip.
+    k_step_quad<UPDATE, MH><<<nblk(B), 256, 0, c->stream>>>(c->st, out, B, imu, lo, mask, q[0], q[1], q[2], q[3], c->k);
   } else {
-    // n = 21: 231 packed covariance entries do not fit one lane's registers; the step runs on the two-wave
-    // cooperative kernel (rbis_coop.hpp): one launch, one state round trip.
+    // the two-wave cooperative kernel at one wave per SIMD (rbis_coop.hpp); PRONTO_BATCH_QUAD21=0
     k_step_coop<21, UPDATE, MH><<<nblk(B), 128, 0, c->stream>>>(c->st, out, B, imu, lo, mask, q[0], q[1], q[2], q[3], c->k, CorrArgs());
   }
 }

@@ -55,6 +55,8 @@ extern "C" int pb_create(pb_ctx **out, int n_states, int batch, int device, int 
     const long state_bytes = (long) c->state_doubles * 8;
     const char *gu = getenv("PRONTO_BATCH_GENERIC_UPDATE");
     c->generic_update = gu && gu[0] == '1';
+    const char *q21 = getenv("PRONTO_BATCH_QUAD21");
+    c->quad21 = !(q21 && q21[0] == '0');
     const char *h = getenv("PRONTO_BATCH_MEMHINT");
     c->mem_hint = h ? (h[0] - '0')
                     : (state_bytes < (48L << 20) ? MH_DEFAULT : state_bytes < (340L << 20) ? MH_STORE_SC1 : MH_STREAM_NT);
@@ -163,10 +165,11 @@ extern "C" int pb_sync(pb_ctx *c)
 extern "C" const char *pb_hot_kernel(const pb_ctx *c)
 {
   if (!c) return "";
-  static const char *const names[3][3] = { { "k_step_coop<21,true,0>", "k_step_coop<21,true,1>", "k_step_coop<21,true,2>" },
+  static const char *const names[4][3] = { { "k_step_quad<true,0>", "k_step_quad<true,1>", "k_step_quad<true,2>" },
+                                           { "k_step_coop<21,true,0>", "k_step_coop<21,true,1>", "k_step_coop<21,true,2>" },
                                            { "k_step_coop<15,true,0>", "k_step_coop<15,true,1>", "k_step_coop<15,true,2>" },
                                            { "k_step<15,true,0>", "k_step<15,true,1>", "k_step<15,true,2>" } };
-  return names[c->ns == 21 ? 0 : (c->coop15 ? 1 : 2)][c->mem_hint];
+  return names[c->ns == 21 ? (c->quad21 ? 0 : 1) : (c->coop15 ? 2 : 3)][c->mem_hint];
 }
 extern "C" int pb_batch(const pb_ctx *c) { return c ? c->B : -1; }
 extern "C" int pb_n_states(const pb_ctx *c) { return c ? c->ns : -1; }

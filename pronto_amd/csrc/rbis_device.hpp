@@ -83,8 +83,11 @@ PB_HD constexpr int passive_full(int p) { return p < 3 ? p : 12 + (p - 3); }
 // stays inside one contiguous 70 KiB (n=15) / 129 KiB (n=21) block.  "Slot" order is a permutation of the canonical
 // component order of Lay<NS>, chosen so that the two roles of the cooperative step kernel (rbis_coop.hpp) own disjoint
 // row ranges and store their rows in increasing order:
-//   core rows:    x[v chi Delta] | quat | (n=21: loglik) | P_(cb)(cb) packed by core sub index | (n=21: x[bg ba])
-//   passive rows: P_(cb),omega panel | P_(cb),accel panel | P_pp | (n=15: loglik) | x[omega accel] | (n=21: one pad)
+//   n=15 core rows:    x[v chi Delta] | quat | P_cc packed by core sub index
+//        passive rows: P_c,omega panel | P_c,accel panel | P_pp | loglik | x[omega accel]
+//   n=21 core rows:    x[v chi Delta] | quat | P_cc || loglik | P_bc, P_bb by bias row | x[bg ba]
+//        passive rows: P_(cb),omega panel | P_omega,omega | x[omega] || P_(cb),accel panel | P_accel,(omega accel) | x[accel] | pad
+//   (|| = the further split into the four waves of rbis_quad.hpp)
 // Element (component c, filter b) lives at double index  (b/64)*NSLOT*64 + (slot(c)/2)*128 + (b%64)*2 + slot(c)%2.
 // ------------------------------------------------------------------------------------------------------------
 template <int NS>
@@ -101,41 +104,59 @@ struct Slots {
     short slot_of[L::NC];
     short comp_of[NSLOT];
     int ncore;  // slots of the core rows (even)
+    int nq[4];  // end slot of each of the four waves' rows (rbis_quad.hpp)
   };
   static constexpr Tab make()
   {
     Tab t{};
     int s = 0;
-    for (int i = 0; i < 9; i++) { t.slot_of[L::OFF_VEC + 3 + i] = (short) s; t.comp_of[s++] = (short) (L::OFF_VEC + 3 + i); }
-    for (int i = 0; i < 4; i++) { t.slot_of[L::OFF_QUAT + i] = (short) s; t.comp_of[s++] = (short) (L::OFF_QUAT + i); }
-    if (HB) { t.slot_of[L::OFF_LL] = (short) s; t.comp_of[s++] = (short) L::OFF_LL; }
-    for (int i = 0; i < NSC; i++)
-      for (int j = 0; j <= i; j++) {
-        const int c = L::OFF_P + pk(core_full(i), core_full(j));
-        t.slot_of[c] = (short) s; t.comp_of[s++] = (short) c;
-      }
-    if (HB)
-      for (int i = 0; i < 6; i++) { t.slot_of[L::OFF_VEC + 15 + i] = (short) s; t.comp_of[s++] = (short) (L::OFF_VEC + 15 + i); }
+    auto put = [&](int c) { t.slot_of[c] = (short) s; t.comp_of[s++] = (short) c; };
+    // ---- core rows.  n = 21: first what rbis_quad.hpp's wave 0 writes, then wave 1's; rbis_coop.hpp's role C = both ----
+    for (int i = 0; i < 9; i++) put(L::OFF_VEC + 3 + i);
+    for (int i = 0; i < 4; i++) put(L::OFF_QUAT + i);
+    for (int i = 0; i < 9; i++)
+      for (int j = 0; j <= i; j++) put(L::OFF_P + pk(core_full(i), core_full(j)));
+    t.nq[0] = s;
+    if (HB) {
+      put(L::OFF_LL);
+      for (int i = 9; i < NSC; i++)
+        for (int j = 0; j <= i; j++) put(L::OFF_P + pk(core_full(i), core_full(j)));
+      for (int i = 0; i < 6; i++) put(L::OFF_VEC + 15 + i);
+    }
     t.ncore = s;
-    for (int J = 0; J < 2; J++)
-      for (int i = 0; i < NSC; i++)
-        for (int cc = 0; cc < 3; cc++) {
-          const int c = L::OFF_P + pk(core_full(i), passive_full(3 * J + cc));
-          t.slot_of[c] = (short) s; t.comp_of[s++] = (short) c;
-        }
-    for (int i = 0; i < 6; i++)
-      for (int j = 0; j <= i; j++) {
-        const int c = L::OFF_P + pk(passive_full(i), passive_full(j));
-        t.slot_of[c] = (short) s; t.comp_of[s++] = (short) c;
-      }
-    if (!HB) { t.slot_of[L::OFF_LL] = (short) s; t.comp_of[s++] = (short) L::OFF_LL; }
-    for (int i = 0; i < 6; i++) { t.slot_of[L::OFF_VEC + passive_full(i)] = (short) s; t.comp_of[s++] = (short) (L::OFF_VEC + passive_full(i)); }
+    t.nq[1] = s;
+    // ---- passive rows.  n = 21: the omega block column (wave 2), then the accel block column (wave 3) ----
+    for (int i = 0; i < NSC; i++)
+      for (int cc = 0; cc < 3; cc++) put(L::OFF_P + pk(core_full(i), passive_full(cc)));
+    if (HB) {
+      for (int i = 0; i < 3; i++)
+        for (int j = 0; j <= i; j++) put(L::OFF_P + pk(passive_full(i), passive_full(j)));
+      for (int i = 0; i < 3; i++) put(L::OFF_VEC + passive_full(i));
+      t.nq[2] = s;
+    }
+    for (int i = 0; i < NSC; i++)
+      for (int cc = 0; cc < 3; cc++) put(L::OFF_P + pk(core_full(i), passive_full(3 + cc)));
+    if (HB) {
+      for (int i = 3; i < 6; i++)
+        for (int j = 0; j <= i; j++) put(L::OFF_P + pk(passive_full(i), passive_full(j)));
+      for (int i = 3; i < 6; i++) put(L::OFF_VEC + passive_full(i));
+    } else {
+      for (int i = 0; i < 6; i++)
+        for (int j = 0; j <= i; j++) put(L::OFF_P + pk(passive_full(i), passive_full(j)));
+      put(L::OFF_LL);
+      for (int i = 0; i < 6; i++) put(L::OFF_VEC + passive_full(i));
+      t.nq[2] = s;
+    }
     while (s < NSLOT) t.comp_of[s++] = -1;  // padding slot (n=21: 257 components in 129 rows)
+    t.nq[3] = s;
     return t;
   }
   static constexpr Tab T = make();
   static_assert(T.ncore % 2 == 0, "the two roles must own whole rows");
+  static_assert(T.nq[0] % 2 == 0 && T.nq[2] % 2 == 0, "the four roles must own whole rows");
   static constexpr int ROW_SPLIT = T.ncore / 2;  // rows [0, ROW_SPLIT) = core role, [ROW_SPLIT, NROW) = passive role
+  // n = 21, four-wave mapping: rows [QROW[w], QROW[w+1]) belong to wave w
+  static constexpr int QROW[5] = { 0, T.nq[0] / 2, T.nq[1] / 2, T.nq[2] / 2, T.nq[3] / 2 };
   PB_HD static constexpr int slot(int comp) { return T.slot_of[comp]; }
   // double index of (component, filter) in a state array
   PB_HD static long eidx(int comp, long b)

@@ -15,6 +15,7 @@
 
 #include "../../include/pronto_batch.h"
 #include "rbis_coop.hpp"
+#include "rbis_quad.hpp"
 #include "rbis_device.hpp"
 
 // workgroup size of the one-lane hot kernel = one tile
@@ -708,6 +709,61 @@ __global__ __launch_bounds__(128, 1) void k_step_coop(const double *st, double *
     coop_role_passive<NS, UPDATE, CORR, PREDICT>(ld, stf, xrd, sync, in, k, cin);
   }
 #endif
+}
+
+// The 21-state hot step on FOUR cooperating waves per 64 filters (rbis_quad.hpp): <= 256 registers per role, so two
+// workgroups (8 waves) share a CU and one tile's loads overlap another's arithmetic and stores.  Same inputs, same
+// posterior (to rounding: the c-b coupling enters P_cc as one additive term instead of inside the row operations) and the
+// same bytes as k_step_coop<21>.  No lane returns before the barriers (see k_step_coop).
+template <bool UPDATE, int MH = MH_DEFAULT>
+__global__ __launch_bounds__(256, 2) void k_step_quad(const double *st, double *sto, int B,
+                                                      const double *__restrict__ imu, const double *__restrict__ lo,
+                                                      const uint8_t *__restrict__ mask, double qg, double qa,
+                                                      double qbg, double qba, Consts k)
+{
+  using SL = Slots<21>;
+  __shared__ double xch[Quad::NXCH][64];
+  const int role = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
+  const unsigned lane = threadIdx.x & 63u;
+  const unsigned tile = xcd_workgroup(k);
+  const unsigned b = tile * 64u + lane;
+  const unsigned bo = b * 8u, B8 = (unsigned) B * 8u;
+  TileIO<21, MemHint<MH>::LA, MemHint<MH>::SA> io(st, sto, tile, lane);
+  const rsrc_t ri = mkbuf(imu, 7u * B8);
+  const rsrc_t rl = mkbuf(lo, UPDATE ? 6u * B8 : 0u);
+  StepInputs in;
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    in.gyro[i] = ldg(ri, i * B8, bo);
+    in.accel[i] = ldg(ri, (3 + i) * B8, bo);
+    in.z[i] = (UPDATE && role == 0) ? ldg(rl, i * B8, bo) : 0.0;
+    in.rd[i] = (UPDATE && role == 0) ? ldg(rl, (3 + i) * B8, bo) : 1.0;
+  }
+  in.dt = ldg(ri, 6u * B8, bo);
+  in.upd = UPDATE && (b < (unsigned) B) && (mask == nullptr || mask[b] != 0);
+  in.qg = qg; in.qa = qa; in.qbg = qbg; in.qba = qba;
+  if (k.qblk != nullptr) {  // per-filter process noise (wave-uniform branch)
+    const rsrc_t rq = mkbuf(k.qblk, 4u * B8);
+    in.qg = ldg(rq, 0u, bo); in.qa = ldg(rq, B8, bo); in.qbg = ldg(rq, 2u * B8, bo); in.qba = ldg(rq, 3u * B8, bo);
+  }
+  auto ld = [&io](int comp) { return io.ld(comp); };
+  auto stf = [&io](int comp, double v) { io.st(comp, v); };
+  auto sync = []() { __syncthreads(); };
+  auto xrd = [lane](int s) { return xch[s][lane]; };
+  auto xwr = [lane](int s, double v) { xch[s][lane] = v; };
+  if (role == 0) {
+    io.template need<SL::QROW[0], SL::QROW[1]>();
+    quad_role_cc<UPDATE>(ld, stf, xwr, xrd, sync, in, k);
+  } else if (role == 1) {
+    io.template need<SL::QROW[1], SL::QROW[2]>();
+    quad_role_cb<UPDATE>(ld, stf, xwr, xrd, sync, in, k);
+  } else if (role == 2) {
+    io.template need<SL::QROW[2], SL::QROW[3]>();
+    quad_role_passive<UPDATE, 0>(ld, stf, xwr, xrd, sync, in, k);
+  } else {
+    io.template need<SL::QROW[3], SL::QROW[4]>();
+    quad_role_passive<UPDATE, 1>(ld, stf, xwr, xrd, sync, in, k);
+  }
 }
 
 // Time-fused replay on the cooperative mapping: T consecutive predict + leg-odometry steps per launch with each role's part

@@ -1,0 +1,484 @@
+// rbis_quad.hpp -- the 21-state predict(+update) step split over FOUR cooperating waves per 64 filters.
+//
+// Why: the two-role mapping (rbis_coop.hpp) leaves role C with the 15 x 15 (c,b) sub-matrix = 240 registers of state
+// per lane: one wave per SIMD, so loads, arithmetic and stores of a tile never overlap with another tile's.  The
+// process model (rbis.cpp:12-35) splits once more.  With c = {v, chi, Delta}, b = {gyro bias, accel bias},
+// p = {omega, accel} and Ad = I + N (N's only non-zero block rows: v <- v chi bg ba, chi <- chi bg, Delta <- v chi):
+//
+//   P'_cc = F_cc P_cc F_cc^T + H,     H = P'_cb F_cb^T + F_cb T1^T,   T1 = F_cc P_cb,   P'_cb = T1 + F_cb P_bb
+//   P'_bb = P_bb + Q_b dt,            P'_(cb)p = [F_cc F_cb; 0 I] P_(cb)p  column by column of p
+//
+//   wave 0 (role CC):  x[v chi Delta], quat, P_cc (45)         -- exactly the 15-state core role + H from wave 1
+//   wave 1 (role CB):  P_cb (54), P_bb (21), x[bg ba], loglik  -- publishes H (39 non-zero entries) and P'_bv
+//   wave 2 (role PW):  P_(cb),omega (45), P_omega,omega, x[omega]
+//   wave 3 (role PA):  P_(cb),accel (45), P_accel,accel, P_accel,omega, x[accel]
+//
+// 58 / 82 / 54 / 63 components: every role fits 256 registers -> TWO waves per SIMD, two workgroups per CU, and one
+// tile's loads overlap another tile's arithmetic and stores.  Two barriers: A (H is published; nobody has overwritten
+// the prior x / quat that all four roles linearise about) and B (wave 0 has published the LDL^T factors and its rows of
+// W = P[:,idx] L^-T).  W_b and W_omega are recomputed by their consumers from the raw P'_bv / P'_v,omega columns that
+// their owners publish before B, so that no third barrier is needed.
+//
+// The role bodies are PB_HD templates over load/store/exchange functors (tests/host_harness.cpp runs the four roles as
+// four threads with a real barrier on the CPU against the oracle).
+#pragma once
+
+#include "rbis_coop.hpp"
+
+namespace pb {
+
+struct Quad {
+  // LDS hand-off, doubles per filter.  [0, 45): H packed by (i, j <= i) over the 9 c-states before barrier A; wave 0 is
+  // its only reader and re-uses the area for L(3) id(3) yd(3) lli(1) W_c(27) before barrier B.
+  static constexpr int X_H = 0, X_L = 0, X_ID = 3, X_YD = 6, X_LLI = 9, X_WC = 10;
+  static constexpr int X_BV = 45;  // raw P'(v_k, b_j) at X_BV + 3 j + k   (18)
+  static constexpr int X_VW = 63;  // raw P'(v_k, omega_c) at X_VW + 3 c + k (9)
+  static constexpr int NXCH = 72;
+};
+
+// (X hat(m)^T)[r][c] = (m x X_r)[c] for a row-major 3x3 block X
+PB_HD double x_hat_t(const double (&X)[9], const double (&m)[3], int r, int c)
+{
+  if (c == 0) return X[3 * r + 2] * m[1] - X[3 * r + 1] * m[2];
+  if (c == 1) return X[3 * r + 0] * m[2] - X[3 * r + 2] * m[0];
+  return X[3 * r + 1] * m[0] - X[3 * r + 0] * m[1];
+}
+
+// the c-rows of one block column of a panel: (V, C, D) <- F_cc (V, C, D)   (all right-hand sides ORIGINAL blocks)
+PB_HD void fcc_apply(const ProcBlocks &f, double (&V)[9], double (&Cc)[9], double (&D)[9])
+{
+  double nD[9], nV[9], nC[9];
+#pragma unroll
+  for (int i = 0; i < 9; i++) { nD[i] = D[i]; nV[i] = V[i]; nC[i] = Cc[i]; }
+  mat_mul_acc(f.A_R, V, nD);
+  mat_mul_acc(f.A_RV, Cc, nD);
+  hat_mul_acc(f.a_mw, V, nV);
+  hat_mul_acc(f.a_g, Cc, nV);
+  hat_mul_acc(f.a_mw, Cc, nC);
+#pragma unroll
+  for (int i = 0; i < 9; i++) { D[i] = nD[i]; V[i] = nV[i]; Cc[i] = nC[i]; }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// wave 0, role CC: x[v chi Delta], quat, P_cc
+// ------------------------------------------------------------------------------------------------------------
+template <bool UPDATE, class LD, class ST, class XW, class XR, class SYNC>
+PB_HD void quad_role_cc(LD ld, ST st, XW xw, XR xr, SYNC sync, const StepInputs &in, const Consts &k)
+{
+  constexpr int NS = 21;
+  using L = Lay<NS>;
+  double x[NS], q[4];
+#pragma unroll
+  for (int i = 0; i < NS; i++) x[i] = ld(L::OFF_VEC + i);
+#pragma unroll
+  for (int i = 0; i < 4; i++) q[i] = ld(L::OFF_QUAT + i);
+  double Pc[45];
+#pragma unroll
+  for (int i = 0; i < 9; i++)
+#pragma unroll
+    for (int j = 0; j <= i; j++) Pc[pk(i, j)] = ld(L::OFF_P + pk(core_full(i), core_full(j)));
+  ProcBlocks f;
+  make_proc_blocks<NS>(x, q, in.dt, k, f);
+  {  // F_cc P_cc F_cc^T as three elementary block-row congruences (blocks v=0 chi=1 Delta=2)
+    const int src[2] = { 0, 1 };
+    const int kind[2] = { 0, 0 };
+    double A[2][9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) { A[0][i] = f.A_R[i]; A[1][i] = f.A_RV[i]; }
+    RowOp<9, 2, 2>::apply(Pc, src, kind, A);
+    const int kind1[2] = { 1, 1 };
+    double A1[2][9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) { A1[0][i] = f.a_mw[i % 3]; A1[1][i] = f.a_g[i % 3]; }
+    RowOp<9, 0, 2>::apply(Pc, src, kind1, A1);
+    const int src2[1] = { 1 };
+    const int kind2[1] = { 1 };
+    double A2[1][9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) A2[0][i] = f.a_mw[i % 3];
+    RowOp<9, 1, 1>::apply(Pc, src2, kind2, A2);
+  }
+  {  // Qd (closed form of rbis.cpp:91-116), c-part
+    const double qgd = in.qg * in.dt, qad = in.qa * in.dt;
+    const double vv = f.v[0] * f.v[0] + f.v[1] * f.v[1] + f.v[2] * f.v[2];
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+      for (int c = 0; c <= r; c++) Pc[pk(r, c)] += qgd * ((r == c ? vv : 0.0) - f.v[r] * f.v[c]) + (r == c ? qad : 0.0);
+    const double m[9] = { 0, f.v[2], -f.v[1], -f.v[2], 0, f.v[0], f.v[1], -f.v[0], 0 };
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+      for (int c = 0; c < 3; c++)
+        if (r != c) Pc[pk(3 + r, c)] += qgd * m[3 * r + c];
+#pragma unroll
+    for (int r = 0; r < 3; r++) Pc[pk(3 + r, 3 + r)] += qgd;
+  }
+  ins_update_state<NS>(x, q, in.gyro, in.accel, in.dt, k);
+  sync();  // A: H is there; every role has consumed the prior x / quat
+#pragma unroll
+  for (int i = 0; i < 9; i++)
+#pragma unroll
+    for (int j = 0; j <= i; j++)
+      if (i < 6 || j < 6) Pc[pk(i, j)] += xr(Quad::X_H + pk(i, j));
+
+  if constexpr (UPDATE) {
+    // S = R + P[v,v]; unpivoted LDL^T; y = L^-1 r  (rbis.cpp:124-143)
+    double resid[3], S[6], d[3], y[3], id[3], yd[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) resid[i] = in.upd ? in.z[i] - x[3 + i] : 0.0;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+      for (int j = 0; j <= i; j++) S[pk(i, j)] = Pc[pk(i, j)] + (i == j ? (in.upd ? in.rd[i] : 1.0) : 0.0);
+    ldlt<3>(S, d);
+    double quad = 0.0, det = 1.0;
+#pragma unroll
+    for (int kk = 0; kk < 3; kk++) {
+      double s = resid[kk];
+#pragma unroll
+      for (int j = 0; j < kk; j++) s -= S[pk(kk, j)] * y[j];
+      y[kk] = in.upd ? s : 0.0;
+      id[kk] = in.upd ? 1.0 / d[kk] : 0.0;
+      yd[kk] = y[kk] * id[kk];
+      det *= d[kk];
+      quad += s * s * id[kk];
+    }
+    xw(Quad::X_LLI, -log(det) - quad);  // -log(S.determinant()) - r^T S^-1 r (rbis.cpp:142); role CB owns loglik
+    double W[9][3];
+#pragma unroll
+    for (int i = 0; i < 9; i++)
+#pragma unroll
+      for (int kk = 0; kk < 3; kk++) {
+        double s = Pc[pk(i, kk)];
+#pragma unroll
+        for (int j = 0; j < kk; j++) s -= W[i][j] * S[pk(kk, j)];
+        W[i][kk] = s;
+      }
+    xw(Quad::X_L + 0, S[pk(1, 0)]); xw(Quad::X_L + 1, S[pk(2, 0)]); xw(Quad::X_L + 2, S[pk(2, 1)]);
+#pragma unroll
+    for (int kk = 0; kk < 3; kk++) { xw(Quad::X_ID + kk, id[kk]); xw(Quad::X_YD + kk, yd[kk]); }
+#pragma unroll
+    for (int i = 0; i < 9; i++)
+#pragma unroll
+      for (int kk = 0; kk < 3; kk++) xw(Quad::X_WC + 3 * i + kk, W[i][kk]);
+    sync();  // B
+    double dfull[NS];
+#pragma unroll
+    for (int i = 0; i < NS; i++) dfull[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+      double wd[3];
+#pragma unroll
+      for (int kk = 0; kk < 3; kk++) wd[kk] = W[i][kk] * id[kk];
+      dfull[core_full(i)] = fma(W[i][2], yd[2], fma(W[i][1], yd[1], W[i][0] * yd[0]));
+#pragma unroll
+      for (int j = 0; j <= i; j++) {
+        double acc = Pc[pk(i, j)];
+#pragma unroll
+        for (int kk = 0; kk < 3; kk++) acc = fma(-wd[kk], W[j][kk], acc);
+        st(L::OFF_P + pk(core_full(i), core_full(j)), acc);
+      }
+    }
+    if (in.upd) add_delta<NS>(x, q, dfull, k.chi_tol);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 9; i++)
+#pragma unroll
+      for (int j = 0; j <= i; j++) st(L::OFF_P + pk(core_full(i), core_full(j)), Pc[pk(i, j)]);
+  }
+#pragma unroll
+  for (int i = 0; i < 9; i++) st(L::OFF_VEC + core_full(i), x[core_full(i)]);
+#pragma unroll
+  for (int i = 0; i < 4; i++) st(L::OFF_QUAT + i, q[i]);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// wave 1, role CB: P_cb, P_bb, x[bg ba], loglik
+// ------------------------------------------------------------------------------------------------------------
+template <bool UPDATE, class LD, class ST, class XW, class XR, class SYNC>
+PB_HD void quad_role_cb(LD ld, ST st, XW xw, XR xr, SYNC sync, const StepInputs &in, const Consts &k)
+{
+  constexpr int NS = 21;
+  using L = Lay<NS>;
+  double x[NS], q[4];
+#pragma unroll
+  for (int i = 0; i < NS; i++) x[i] = ld(L::OFF_VEC + i);
+#pragma unroll
+  for (int i = 0; i < 4; i++) q[i] = ld(L::OFF_QUAT + i);
+  // Y[sb][J] = 3x3 block P(c block sb, bias block J), row-major; sb: v chi Delta; J: gyro bias, accel bias
+  double Y[3][2][9];
+#pragma unroll
+  for (int sb = 0; sb < 3; sb++)
+#pragma unroll
+    for (int J = 0; J < 2; J++)
+#pragma unroll
+      for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) Y[sb][J][3 * r + c] = ld(L::OFF_P + pk(core_full(3 * sb + r), core_full(9 + 3 * J + c)));
+  double Pbb[21];
+#pragma unroll
+  for (int i = 0; i < 6; i++)
+#pragma unroll
+    for (int j = 0; j <= i; j++) Pbb[pk(i, j)] = ld(L::OFF_P + pk(core_full(9 + i), core_full(9 + j)));
+  double ll = ld(L::OFF_LL);
+  double xb[6];
+#pragma unroll
+  for (int i = 0; i < 6; i++) xb[i] = x[15 + i];
+
+  ProcBlocks f;
+  make_proc_blocks<NS>(x, q, in.dt, k, f);
+  // T1 = F_cc P_cb, block column by block column; P'_cb = T1 + F_cb P_bb; H = P'_cb F_cb^T + F_cb T1^T
+  double T1vg[9], T1va[9], T1cg[9];
+#pragma unroll
+  for (int J = 0; J < 2; J++) {
+    fcc_apply(f, Y[0][J], Y[1][J], Y[2][J]);
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+      if (J == 0) { T1vg[i] = Y[0][0][i]; T1cg[i] = Y[1][0][i]; }
+      else T1va[i] = Y[0][1][i];
+    }
+    // blocks (bg, J) and (ba, J) of the symmetric P_bb
+    double Bg[9], Ba[9];
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        Bg[3 * r + c] = Pbb[pk(r, 3 * J + c)];
+        Ba[3 * r + c] = Pbb[pk(3 + r, 3 * J + c)];
+      }
+    hat_mul_acc(f.a_mv, Bg, Y[0][J]);
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+      Y[0][J][i] -= in.dt * Ba[i];
+      Y[1][J][i] -= in.dt * Bg[i];
+    }
+  }
+  // H, lower block triangle of the 9 x 9 (the Delta,Delta block is zero)
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      if (c <= r)
+        xw(Quad::X_H + pk(r, c), x_hat_t(Y[0][0], f.a_mv, r, c) - in.dt * Y[0][1][3 * r + c] + x_hat_t(T1vg, f.a_mv, c, r) -
+                                   in.dt * T1va[3 * c + r]);
+      xw(Quad::X_H + pk(3 + r, c), x_hat_t(Y[1][0], f.a_mv, r, c) - in.dt * Y[1][1][3 * r + c] - in.dt * T1vg[3 * c + r]);
+      if (c <= r) xw(Quad::X_H + pk(3 + r, 3 + c), -in.dt * (Y[1][0][3 * r + c] + T1cg[3 * c + r]));
+      xw(Quad::X_H + pk(6 + r, c), x_hat_t(Y[2][0], f.a_mv, r, c) - in.dt * Y[2][1][3 * r + c]);
+      xw(Quad::X_H + pk(6 + r, 3 + c), -in.dt * Y[2][0][3 * r + c]);
+    }
+  if constexpr (UPDATE) {
+#pragma unroll
+    for (int j = 0; j < 6; j++)
+#pragma unroll
+      for (int kk = 0; kk < 3; kk++) xw(Quad::X_BV + 3 * j + kk, Y[0][j / 3][3 * kk + j % 3]);
+  }
+#pragma unroll
+  for (int r = 0; r < 3; r++) {
+    Pbb[pk(r, r)] += in.qbg * in.dt;
+    Pbb[pk(3 + r, 3 + r)] += in.qba * in.dt;
+  }
+  sync();  // A
+  if constexpr (UPDATE) {
+    sync();  // B
+    const double L10 = xr(Quad::X_L + 0), L20 = xr(Quad::X_L + 1), L21 = xr(Quad::X_L + 2);
+    double id[3], yd[3];
+#pragma unroll
+    for (int kk = 0; kk < 3; kk++) { id[kk] = xr(Quad::X_ID + kk); yd[kk] = xr(Quad::X_YD + kk); }
+    const double lli = xr(Quad::X_LLI);
+    if (in.upd) ll += lli;
+    double Wb[6][3];
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+      const double c0 = Y[0][j / 3][0 + j % 3], c1 = Y[0][j / 3][3 + j % 3], c2 = Y[0][j / 3][6 + j % 3];
+      Wb[j][0] = c0;
+      Wb[j][1] = c1 - Wb[j][0] * L10;
+      Wb[j][2] = c2 - Wb[j][0] * L20 - Wb[j][1] * L21;
+      xb[j] += fma(Wb[j][2], yd[2], fma(Wb[j][1], yd[1], Wb[j][0] * yd[0]));
+    }
+    // rows of the storage layout: bias j: its 9 c-entries, then its P_bb entries
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+      double wd[3];
+#pragma unroll
+      for (int kk = 0; kk < 3; kk++) wd[kk] = Wb[j][kk] * id[kk];
+#pragma unroll
+      for (int i = 0; i < 9; i++) {
+        double acc = Y[i / 3][j / 3][3 * (i % 3) + j % 3];
+#pragma unroll
+        for (int kk = 0; kk < 3; kk++) acc = fma(-wd[kk], xr(Quad::X_WC + 3 * i + kk), acc);
+        st(L::OFF_P + pk(core_full(9 + j), core_full(i)), acc);
+      }
+#pragma unroll
+      for (int j2 = 0; j2 <= j; j2++) {
+        double acc = Pbb[pk(j, j2)];
+#pragma unroll
+        for (int kk = 0; kk < 3; kk++) acc = fma(-wd[kk], Wb[j2][kk], acc);
+        st(L::OFF_P + pk(core_full(9 + j), core_full(9 + j2)), acc);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+#pragma unroll
+      for (int i = 0; i < 9; i++) st(L::OFF_P + pk(core_full(9 + j), core_full(i)), Y[i / 3][j / 3][3 * (i % 3) + j % 3]);
+#pragma unroll
+      for (int j2 = 0; j2 <= j; j2++) st(L::OFF_P + pk(core_full(9 + j), core_full(9 + j2)), Pbb[pk(j, j2)]);
+    }
+  }
+  st(L::OFF_LL, ll);
+#pragma unroll
+  for (int i = 0; i < 6; i++) st(L::OFF_VEC + 15 + i, xb[i]);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// waves 2 and 3, roles PW (J = 0: omega) and PA (J = 1: accel): one block column of the passive panels
+// ------------------------------------------------------------------------------------------------------------
+template <bool UPDATE, int J, class LD, class ST, class XW, class XR, class SYNC>
+PB_HD void quad_role_passive(LD ld, ST st, XW xw, XR xr, SYNC sync, const StepInputs &in, const Consts &k)
+{
+  constexpr int NS = 21;
+  using L = Lay<NS>;
+  double x[NS], q[4];
+#pragma unroll
+  for (int i = 0; i < NS; i++) x[i] = ld(L::OFF_VEC + i);
+#pragma unroll
+  for (int i = 0; i < 4; i++) q[i] = ld(L::OFF_QUAT + i);
+  // X[sb] = 3x3 block P(core block sb, passive block J), row-major; sb: v chi Delta bg ba
+  double X[5][9];
+#pragma unroll
+  for (int sb = 0; sb < 5; sb++)
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+      for (int c = 0; c < 3; c++) X[sb][3 * r + c] = ld(L::OFF_P + pk(core_full(3 * sb + r), passive_full(3 * J + c)));
+  double Pjj[6];
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+#pragma unroll
+    for (int c = 0; c <= r; c++) Pjj[pk(r, c)] = ld(L::OFF_P + pk(passive_full(3 * J + r), passive_full(3 * J + c)));
+  double Paw[J == 1 ? 9 : 1];  // P(accel_r, omega_c): untouched by the process step (rbis.cpp:120-121)
+  if constexpr (J == 1) {
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+      for (int c = 0; c < 3; c++) Paw[3 * r + c] = ld(L::OFF_P + pk(passive_full(3 + r), passive_full(c)));
+  }
+  ProcBlocks f;
+  make_proc_blocks<NS>(x, q, in.dt, k, f);
+  {
+    double G0[9], A0[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) { G0[i] = X[3][i]; A0[i] = X[4][i]; }
+    fcc_apply(f, X[0], X[1], X[2]);
+    hat_mul_acc(f.a_mv, G0, X[0]);
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+      X[0][i] -= in.dt * A0[i];
+      X[1][i] -= in.dt * G0[i];
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+#pragma unroll
+    for (int c = 0; c <= r; c++) Pjj[pk(r, c)] = (r == c) ? (J == 0 ? in.qg : in.qa) : 0.0;
+  double xp[3];  // rbis.cpp:50-51
+#pragma unroll
+  for (int i = 0; i < 3; i++) xp[i] = (J == 0 ? in.gyro[i] - x[15 + i] : in.accel[i] - x[18 + i]);
+  if constexpr (UPDATE && J == 0) {
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+#pragma unroll
+      for (int kk = 0; kk < 3; kk++) xw(Quad::X_VW + 3 * c + kk, X[0][3 * kk + c]);
+  }
+  sync();  // A
+  if constexpr (UPDATE) {
+    sync();  // B
+    const double L10 = xr(Quad::X_L + 0), L20 = xr(Quad::X_L + 1), L21 = xr(Quad::X_L + 2);
+    double id[3], yd[3];
+#pragma unroll
+    for (int kk = 0; kk < 3; kk++) { id[kk] = xr(Quad::X_ID + kk); yd[kk] = xr(Quad::X_YD + kk); }
+    double Wp[3][3];  // W_p = P'[p, v] L^-T
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      Wp[c][0] = X[0][0 + c];
+      Wp[c][1] = X[0][3 + c] - Wp[c][0] * L10;
+      Wp[c][2] = X[0][6 + c] - Wp[c][0] * L20 - Wp[c][1] * L21;
+      xp[c] += fma(Wp[c][2], yd[2], fma(Wp[c][1], yd[1], Wp[c][0] * yd[0]));
+    }
+#pragma unroll
+    for (int sb = 0; sb < 5; sb++)
+#pragma unroll
+      for (int r = 0; r < 3; r++) {
+        double wd[3];
+        if (sb < 3) {  // role CC's rows of W
+#pragma unroll
+          for (int kk = 0; kk < 3; kk++) wd[kk] = xr(Quad::X_WC + 3 * (3 * sb + r) + kk) * id[kk];
+        } else {       // W_b = P'[b, v] L^-T from role CB's raw column
+          const int j = 3 * (sb - 3) + r;
+          const double w0 = xr(Quad::X_BV + 3 * j + 0);
+          const double w1 = xr(Quad::X_BV + 3 * j + 1) - w0 * L10;
+          const double w2 = xr(Quad::X_BV + 3 * j + 2) - w0 * L20 - w1 * L21;
+          wd[0] = w0 * id[0]; wd[1] = w1 * id[1]; wd[2] = w2 * id[2];
+        }
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+          double acc = X[sb][3 * r + c];
+#pragma unroll
+          for (int kk = 0; kk < 3; kk++) acc = fma(-wd[kk], Wp[c][kk], acc);
+          st(L::OFF_P + pk(core_full(3 * sb + r), passive_full(3 * J + c)), acc);
+        }
+      }
+    double Ww[3][3];  // J == 1: W_omega from role PW's raw column
+    if constexpr (J == 1) {
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        Ww[c][0] = xr(Quad::X_VW + 3 * c + 0);
+        Ww[c][1] = xr(Quad::X_VW + 3 * c + 1) - Ww[c][0] * L10;
+        Ww[c][2] = xr(Quad::X_VW + 3 * c + 2) - Ww[c][0] * L20 - Ww[c][1] * L21;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      double wd[3];
+#pragma unroll
+      for (int kk = 0; kk < 3; kk++) wd[kk] = Wp[r][kk] * id[kk];
+      if constexpr (J == 1) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+          double acc = Paw[3 * r + c];
+#pragma unroll
+          for (int kk = 0; kk < 3; kk++) acc = fma(-wd[kk], Ww[c][kk], acc);
+          st(L::OFF_P + pk(passive_full(3 + r), passive_full(c)), acc);
+        }
+      }
+#pragma unroll
+      for (int c = 0; c <= r; c++) {
+        double acc = Pjj[pk(r, c)];
+#pragma unroll
+        for (int kk = 0; kk < 3; kk++) acc = fma(-wd[kk], Wp[c][kk], acc);
+        st(L::OFF_P + pk(passive_full(3 * J + r), passive_full(3 * J + c)), acc);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int sb = 0; sb < 5; sb++)
+#pragma unroll
+      for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) st(L::OFF_P + pk(core_full(3 * sb + r), passive_full(3 * J + c)), X[sb][3 * r + c]);
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      if constexpr (J == 1) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) st(L::OFF_P + pk(passive_full(3 + r), passive_full(c)), Paw[3 * r + c]);
+      }
+#pragma unroll
+      for (int c = 0; c <= r; c++) st(L::OFF_P + pk(passive_full(3 * J + r), passive_full(3 * J + c)), Pjj[pk(r, c)]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 3; i++) st(L::OFF_VEC + passive_full(3 * J + i), xp[i]);
+}
+
+}  // namespace pb

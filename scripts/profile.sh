@@ -1,26 +1,40 @@
 #!/bin/bash
-# Profiling recipe (run on the GPU box through gpurun):  bash scripts/profile.sh r01
+# Profiling recipe (run on the GPU box through gpurun):  bash scripts/profile.sh r02
 # Outputs under gpurun_out/prof_<tag>/ ; condense them with scripts/profile_summary.py into profiles/.
 #  1. rocprofv3 --kernel-trace --stats of the default bench command (and of the n=21 variant)
 #  2. separate --pmc passes (FETCH_SIZE, then WRITE_SIZE; never combined with trace domains) of the bench command,
 #     the cache-busting 1M-filter run, the n=21 run, and the calibration copy (known bytes, same access pattern)
+#  3. the adjacent kernels, whole configurations and the smoother (trace + SQ/LDS counters); copy ceilings and sweeps
 set -o pipefail
-TAG=${1:-r01}
+TAG=${1:-r02}
 export TMPDIR=/tmp
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd $ROOT
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace64k -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline > $OUT/trace64k.json 2> $OUT/trace64k.err || exit 11
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace64k_n21 -- python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline --n-states 21 > $OUT/trace64k_n21.json 2> $OUT/trace64k_n21.err || exit 11
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace64k -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-cache-busting > $OUT/trace64k.json 2> $OUT/trace64k.err || exit 11
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace64k_n21 -- python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-cache-busting --n-states 21 > $OUT/trace64k_n21.json 2> $OUT/trace64k_n21.err || exit 11
 echo "traces done"
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --output-format csv -d $OUT/pmc64k_$C -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/pmc64k_$C.json 2> $OUT/pmc64k_$C.err || exit 12
-  rocprofv3 --pmc $C --output-format csv -d $OUT/pmc64k_n21_$C -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --n-states 21 > $OUT/pmc64k_n21_$C.json 2> $OUT/pmc64k_n21_$C.err || exit 12
-  rocprofv3 --pmc $C --output-format csv -d $OUT/pmc1m_$C -- python3 bench.py --batch-per-gpu 1048576 --steps 10 --warmup 2 --no-cpu-baseline > $OUT/pmc1m_$C.json 2> $OUT/pmc1m_$C.err || exit 13
+  rocprofv3 --pmc $C --output-format csv -d $OUT/pmc64k_$C -- python3 bench.py --steps 20 --warmup 5 --min-timed-ms 0 --no-cpu-baseline --no-cache-busting > $OUT/pmc64k_$C.json 2> $OUT/pmc64k_$C.err || exit 12
+  rocprofv3 --pmc $C --output-format csv -d $OUT/pmc64k_n21_$C -- python3 bench.py --steps 20 --warmup 5 --min-timed-ms 0 --no-cpu-baseline --no-cache-busting --n-states 21 > $OUT/pmc64k_n21_$C.json 2> $OUT/pmc64k_n21_$C.err || exit 12
+  rocprofv3 --pmc $C --output-format csv -d $OUT/pmc1m_$C -- python3 bench.py --batch-per-gpu 1048576 --steps 10 --warmup 2 --min-timed-ms 0 --no-cpu-baseline > $OUT/pmc1m_$C.json 2> $OUT/pmc1m_$C.err || exit 13
   rocprofv3 --pmc $C --output-format csv -d $OUT/calib_$C -- python3 scripts/calib_copy.py > $OUT/calib_$C.txt 2> $OUT/calib_$C.err || exit 14
   echo "pmc $C done"
 done
-python3 bench.py --batch-per-gpu 1048576 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench1m.json 2> $OUT/bench1m.err
+python3 bench.py --batch-per-gpu 1048576 --steps 20 --warmup 5 --min-timed-ms 0 --no-cpu-baseline --no-cache-busting > $OUT/bench1m.json 2> $OUT/bench1m.err
 python3 scripts/calib_copy.py > $OUT/calib_plain.txt 2>&1
+echo "hot path done"
+# the kernels next to the hot step, the whole configurations, the smoother (kernel trace, then two SQ / LDS counter passes)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/others -- python3 scripts/kernel_rates.py > $OUT/others.txt 2> $OUT/others.err || exit 21
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/configs -- python3 scripts/config_rates.py > $OUT/configs.txt 2> $OUT/configs.err || exit 22
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/smoother -- python3 scripts/smooth_rate.py > $OUT/smoother.txt 2> $OUT/smoother.err || exit 23
+echo "adjacent kernels done"
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU --output-format csv -d $OUT/smooth_pmc_a -- python3 scripts/smooth_rate.py > $OUT/smooth_pmc_a.txt 2>&1 || exit 24
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAVES SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL --output-format csv -d $OUT/smooth_pmc_b -- python3 scripts/smooth_rate.py > $OUT/smooth_pmc_b.txt 2>&1 || exit 25
+echo "smoother counters done"
+# ceilings and sweeps, not under the profiler
+hipcc -O3 --offload-arch=gfx950 -o /tmp/copybench scripts/copybench.hip && /tmp/copybench > $OUT/copybench.txt 2>&1
+python3 scripts/batch_sweep.py 15 21 > $OUT/batch_sweep.txt 2>&1
+python3 bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
 echo "profile done"

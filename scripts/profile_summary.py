@@ -23,20 +23,30 @@ out = os.path.join(root, "profiles")
 os.makedirs(out, exist_ok=True)
 
 
+def kname(raw):
+    """rocprofv3's demangled name -> what pb_hot_kernel() reports: k_step_coop<15,true,1> for the plain fused step
+    (no second measurement, with predict); the other instantiations keep their full argument list."""
+    n = re.sub(r"\s+", "", raw.split("(")[0].replace("void ", "").replace("pb::", ""))
+    return re.sub(r"^(k_step_coop<\d+,true,\d),Corr<false>,true>$", r"\1>", n)
+
+
 def counters(d):
     by = collections.defaultdict(list)
     for f in glob.glob(os.path.join(src, d, "*", "*counter_collection.csv")):
         for r in csv.DictReader(open(f)):
-            name = re.sub(r"\s+", "", r["Kernel_Name"].split("(")[0].replace("void ", "").replace("pb::", ""))
+            name = kname(r["Kernel_Name"])
             by[(name, r["Counter_Name"])].append(float(r["Counter_Value"]))
     return by
 
 
-for d, name in (("trace64k", "_kernel_stats.csv"), ("trace64k_n21", "_kernel_stats_n21.csv")):
+for d, name in (("trace64k", "_kernel_stats.csv"), ("trace64k_n21", "_kernel_stats_n21.csv"),
+                ("others", "_kernel_stats_others.csv"), ("configs", "_kernel_stats_configs.csv"),
+                ("smoother", "_kernel_stats_smoother.csv")):
     ks = glob.glob(os.path.join(src, d, "*", "*kernel_stats.csv"))
     if ks:
         shutil.copy(ks[0], os.path.join(out, tag + name))
-for name in ("trace64k.json", "trace64k_n21.json", "bench1m.json", "calib_plain.txt"):
+for name in ("trace64k.json", "trace64k_n21.json", "bench1m.json", "calib_plain.txt", "copybench.txt", "batch_sweep.txt",
+             "bench_default.json", "others.txt", "configs.txt", "smoother.txt"):
     p = os.path.join(src, name)
     if os.path.exists(p):
         shutil.copy(p, os.path.join(out, tag + "_" + name))
@@ -46,7 +56,7 @@ kf = statistics.median(counters("calib_FETCH_SIZE")[("k_calib_copy", "FETCH_SIZE
 kw = statistics.median(counters("calib_WRITE_SIZE")[("k_calib_copy", "WRITE_SIZE")]) * 1024
 fs, ws = known / kf, known / kw
 res = {"units": "bytes per launch (median over launches)",
-       "calibration": {"kernel": "k_calib_copy (1M filters x 140 components, 8 B/lane buffer loads+stores)",
+       "calibration": {"kernel": "k_calib_copy (1M filters x 70 rows of a tile, 16 B/lane buffer loads+stores)",
                        "known_read_bytes": known, "known_write_bytes": known, "FETCH_SIZE_bytes_raw": kf,
                        "WRITE_SIZE_bytes_raw": kw, "fetch_scale": fs, "write_scale": ws},
        "runs": {}}
@@ -64,6 +74,32 @@ for run, B, bps in (("pmc64k", 65536, 2344), ("pmc1m", 1 << 20, 2344), ("pmc64k_
         traffic["%s@%d" % (k, B)] = {"hbm_bytes_per_launch": rd + wr, "read": rd, "write": wr, "source": tag}
 json.dump(res, open(os.path.join(out, tag + "_pmc.json"), "w"), indent=1)
 json.dump(traffic, open(os.path.join(out, "traffic.json"), "w"), indent=1)
+# the smoother's SQ / LDS counters (two passes), averaged per launch
+sm = {}
+for d in ("smooth_pmc_a", "smooth_pmc_b"):
+    for (k, c), v in counters(d).items():
+        m = re.match(r"k_smooth_reg<(\d+)>", k)
+        if m:
+            sm.setdefault("n" + m.group(1), {})[c] = sum(v) / len(v)
+txt = os.path.join(src, "smoother.txt")
+if sm:
+    for line in open(txt) if os.path.exists(txt) else ():
+        m = re.search(r"n=(\d+): \d+ filters, ([\d.]+) us/step", line)
+        if m and "n" + m.group(1) in sm:
+            sm["n" + m.group(1)]["launch_us"] = float(m.group(2))
+    for r in sm.values():
+        # SQ_LDS_IDX_ACTIVE: cycles the LDS index pipe is busy, summed over the 256 CUs; kernel cycles at 2.4 GHz
+        if "SQ_LDS_IDX_ACTIVE" in r and "launch_us" in r:
+            r["lds_busy_fraction_per_cu"] = r["SQ_LDS_IDX_ACTIVE"] / 256 / (r["launch_us"] * 2400.0)
+        if "SQ_LDS_BANK_CONFLICT" in r and r.get("SQ_LDS_IDX_ACTIVE"):
+            r["lds_bank_conflict_share"] = r["SQ_LDS_BANK_CONFLICT"] / r["SQ_LDS_IDX_ACTIVE"]
+        if r.get("SQ_WAVES"):
+            r["valu_insts_per_wave"] = r.get("SQ_INSTS_VALU", 0) / r["SQ_WAVES"]
+            r["lds_insts_per_wave"] = r.get("SQ_INSTS_LDS", 0) / r["SQ_WAVES"]
+    json.dump({"what": "rocprofv3 --pmc of scripts/smooth_rate.py (64k filters), two passes (scripts/profile.sh); averages per launch",
+               "kernel": "k_smooth_reg<NS> (pb_smooth_step)", "runs": sm},
+              open(os.path.join(out, tag + "_smoother_pmc.json"), "w"), indent=1)
+
 for k, v in res["runs"].items():
     print("%-40s read %.1f MB write %.1f MB = %.3f x algorithmic" % (k, v["hbm_read_bytes"] / 1e6, v["hbm_write_bytes"] / 1e6, v["traffic_over_algorithmic"]))
 for f in sorted(glob.glob(os.path.join(out, tag + "_kernel_stats*.csv"))):
