@@ -81,13 +81,15 @@ PB_HD constexpr int passive_full(int p) { return p < 3 ? p : 12 + (p - 3); }
 // of its 64 filters as NROW rows of 64 x 16 bytes: row r = the component PAIR (slot 2r, slot 2r+1) of each filter, so a
 // lane moves 16 bytes per access (buffer_load/store_dwordx4; 1 KiB per wave instruction) and a wave's whole round trip
 // stays inside one contiguous 70 KiB (n=15) / 129 KiB (n=21) block.  "Slot" order is a permutation of the canonical
-// component order of Lay<NS>, chosen so that the two roles of the cooperative step kernel (rbis_coop.hpp) own disjoint
-// row ranges and store their rows in increasing order:
-//   n=15 core rows:    x[v chi Delta] | quat | P_cc packed by core sub index
-//        passive rows: P_c,omega panel | P_c,accel panel | P_pp | loglik | x[omega accel]
-//   n=21 core rows:    x[v chi Delta] | quat | P_cc || loglik | P_bc, P_bb by bias row | x[bg ba]
-//        passive rows: P_(cb),omega panel | P_omega,omega | x[omega] || P_(cb),accel panel | P_accel,(omega accel) | x[accel] | pad
-//   (|| = the further split into the four waves of rbis_quad.hpp)
+// component order of Lay<NS>, chosen so that the waves that share a tile (the two roles of rbis_coop.hpp for n = 15, the
+// four of rbis_quad.hpp for n = 21) own disjoint row ranges and store their rows in increasing order:
+//   n=15 role C: x[v chi Delta] | quat | P_cc packed by core sub index
+//        role P: P_c,omega panel | P_c,accel panel | P_pp | loglik | x[omega accel]
+//   n=21 wave 0: P_cc | loglik              wave 1: P_bc, P_bb by bias row | x[bg ba] | x[omega]
+//        wave 2: P_(cb),omega panel | P_omega,omega | x[v chi Delta] | quat
+//        wave 3: P_(cb),accel panel | P_accel,(omega accel) | x[accel] | pad
+//   (the two-role kernels that remain for n = 21 -- stand-alone updates, replay -- write the two rows whose slots belong
+//    to different roles, Tab::split2, with 8-byte stores)
 // Element (component c, filter b) lives at double index  (b/64)*NSLOT*64 + (slot(c)/2)*128 + (b%64)*2 + slot(c)%2.
 // ------------------------------------------------------------------------------------------------------------
 template <int NS>
@@ -103,58 +105,75 @@ struct Slots {
   struct Tab {
     short slot_of[L::NC];
     short comp_of[NSLOT];
-    int ncore;  // slots of the core rows (even)
-    int nq[4];  // end slot of each of the four waves' rows (rbis_quad.hpp)
+    signed char role2[NSLOT];  // two-role mapping (rbis_coop.hpp): 0 = role C writes this slot, 1 = role P
+    bool split2[NROW];         // the row's two slots belong to different roles of the two-role mapping (8-byte stores)
+    int ncore;                 // n = 15: slots of role C's rows
+    int nq[4];                 // n = 21: end slot of each of the four waves' rows (rbis_quad.hpp)
   };
   static constexpr Tab make()
   {
     Tab t{};
-    int s = 0;
-    auto put = [&](int c) { t.slot_of[c] = (short) s; t.comp_of[s++] = (short) c; };
-    // ---- core rows.  n = 21: first what rbis_quad.hpp's wave 0 writes, then wave 1's; rbis_coop.hpp's role C = both ----
-    for (int i = 0; i < 9; i++) put(L::OFF_VEC + 3 + i);
-    for (int i = 0; i < 4; i++) put(L::OFF_QUAT + i);
-    for (int i = 0; i < 9; i++)
-      for (int j = 0; j <= i; j++) put(L::OFF_P + pk(core_full(i), core_full(j)));
-    t.nq[0] = s;
-    if (HB) {
-      put(L::OFF_LL);
-      for (int i = 9; i < NSC; i++)
+    int s = 0, role = 0;
+    auto put = [&](int c) { t.slot_of[c] = (short) s; t.role2[s] = (signed char) role; t.comp_of[s++] = (short) c; };
+    if (!HB) {
+      // ---- n = 15: role C's rows, then role P's ----
+      for (int i = 0; i < 9; i++) put(L::OFF_VEC + 3 + i);
+      for (int i = 0; i < 4; i++) put(L::OFF_QUAT + i);
+      for (int i = 0; i < 9; i++)
         for (int j = 0; j <= i; j++) put(L::OFF_P + pk(core_full(i), core_full(j)));
-      for (int i = 0; i < 6; i++) put(L::OFF_VEC + 15 + i);
-    }
-    t.ncore = s;
-    t.nq[1] = s;
-    // ---- passive rows.  n = 21: the omega block column (wave 2), then the accel block column (wave 3) ----
-    for (int i = 0; i < NSC; i++)
-      for (int cc = 0; cc < 3; cc++) put(L::OFF_P + pk(core_full(i), passive_full(cc)));
-    if (HB) {
-      for (int i = 0; i < 3; i++)
-        for (int j = 0; j <= i; j++) put(L::OFF_P + pk(passive_full(i), passive_full(j)));
-      for (int i = 0; i < 3; i++) put(L::OFF_VEC + passive_full(i));
-      t.nq[2] = s;
-    }
-    for (int i = 0; i < NSC; i++)
-      for (int cc = 0; cc < 3; cc++) put(L::OFF_P + pk(core_full(i), passive_full(3 + cc)));
-    if (HB) {
-      for (int i = 3; i < 6; i++)
-        for (int j = 0; j <= i; j++) put(L::OFF_P + pk(passive_full(i), passive_full(j)));
-      for (int i = 3; i < 6; i++) put(L::OFF_VEC + passive_full(i));
-    } else {
+      t.ncore = s;
+      t.nq[0] = t.nq[1] = s;
+      role = 1;
+      for (int J = 0; J < 2; J++)
+        for (int i = 0; i < NSC; i++)
+          for (int cc = 0; cc < 3; cc++) put(L::OFF_P + pk(core_full(i), passive_full(3 * J + cc)));
       for (int i = 0; i < 6; i++)
         for (int j = 0; j <= i; j++) put(L::OFF_P + pk(passive_full(i), passive_full(j)));
       put(L::OFF_LL);
       for (int i = 0; i < 6; i++) put(L::OFF_VEC + passive_full(i));
       t.nq[2] = s;
+    } else {
+      // ---- n = 21: the four waves of rbis_quad.hpp, balanced by ARITHMETIC (the state vector and the quaternion, whose
+      // update is the expensive part, go with the lightest panel).  `role` = the writer in the two-role mapping. ----
+      // wave 0 (CC): P_cc, loglik
+      for (int i = 0; i < 9; i++)
+        for (int j = 0; j <= i; j++) put(L::OFF_P + pk(core_full(i), core_full(j)));
+      put(L::OFF_LL);
+      t.nq[0] = s;
+      // wave 1 (CB): P_bc and P_bb by bias row, x[bg ba], x[omega]
+      for (int i = 9; i < NSC; i++)
+        for (int j = 0; j <= i; j++) put(L::OFF_P + pk(core_full(i), core_full(j)));
+      for (int i = 0; i < 6; i++) put(L::OFF_VEC + 15 + i);
+      role = 1;
+      for (int i = 0; i < 3; i++) put(L::OFF_VEC + passive_full(i));
+      t.nq[1] = s;
+      t.ncore = s;
+      // wave 2 (PW): the omega block column, P_omega,omega, x[v chi Delta], quat
+      for (int i = 0; i < NSC; i++)
+        for (int cc = 0; cc < 3; cc++) put(L::OFF_P + pk(core_full(i), passive_full(cc)));
+      for (int i = 0; i < 3; i++)
+        for (int j = 0; j <= i; j++) put(L::OFF_P + pk(passive_full(i), passive_full(j)));
+      role = 0;
+      for (int i = 0; i < 9; i++) put(L::OFF_VEC + 3 + i);
+      for (int i = 0; i < 4; i++) put(L::OFF_QUAT + i);
+      t.nq[2] = s;
+      // wave 3 (PA): the accel block column, P_accel,(omega accel), x[accel], pad
+      role = 1;
+      for (int i = 0; i < NSC; i++)
+        for (int cc = 0; cc < 3; cc++) put(L::OFF_P + pk(core_full(i), passive_full(3 + cc)));
+      for (int i = 3; i < 6; i++)
+        for (int j = 0; j <= i; j++) put(L::OFF_P + pk(passive_full(i), passive_full(j)));
+      for (int i = 3; i < 6; i++) put(L::OFF_VEC + passive_full(i));
     }
-    while (s < NSLOT) t.comp_of[s++] = -1;  // padding slot (n=21: 257 components in 129 rows)
+    while (s < NSLOT) { t.role2[s] = (signed char) role; t.comp_of[s++] = -1; }  // padding slot (n=21: 257 components in 129 rows)
     t.nq[3] = s;
+    for (int r = 0; r < NROW; r++) t.split2[r] = t.role2[2 * r] != t.role2[2 * r + 1];
     return t;
   }
   static constexpr Tab T = make();
-  static_assert(T.ncore % 2 == 0, "the two roles must own whole rows");
-  static_assert(T.nq[0] % 2 == 0 && T.nq[2] % 2 == 0, "the four roles must own whole rows");
-  static constexpr int ROW_SPLIT = T.ncore / 2;  // rows [0, ROW_SPLIT) = core role, [ROW_SPLIT, NROW) = passive role
+  static_assert(T.nq[0] % 2 == 0 && T.nq[1] % 2 == 0 && T.nq[2] % 2 == 0, "every wave must own whole rows");
+  // prefetch hint of the two-role kernels: rows [0, ROW_SPLIT) are (mostly) role C's, [ROW_SPLIT, NROW) role P's
+  static constexpr int ROW_SPLIT = T.ncore / 2;
   // n = 21, four-wave mapping: rows [QROW[w], QROW[w+1]) belong to wave w
   static constexpr int QROW[5] = { 0, T.nq[0] / 2, T.nq[1] / 2, T.nq[2] / 2, T.nq[3] / 2 };
   PB_HD static constexpr int slot(int comp) { return T.slot_of[comp]; }
@@ -178,6 +197,9 @@ struct Consts {
   const double *qblk = nullptr;
   // k_step_coop: 1 = give each of the 8 XCDs one contiguous filter range (workgroups are dealt round-robin to XCDs)
   int xcd_remap = 0;
+  // k_step_quad experiment (PRONTO_BATCH_STAGGER=n): the second workgroup of every CU starts n x ~0.5 us late so that the
+  // two resident workgroups are in different phases (load / arithmetic / store)
+  int stagger = 0;
 };
 
 // ------------------------------------------------------------------------------------------------------------

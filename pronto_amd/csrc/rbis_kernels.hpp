@@ -93,7 +93,7 @@ __device__ __forceinline__ unsigned xcd_workgroup(const Consts &k)
 //   st(comp, v)   posterior value of a component; a row is stored the moment both its halves are known
 // Every index is a compile-time constant once the callers' loops are unrolled, so `loaded[]` / `have[]` fold away and
 // the caches are plain registers (cdna_hip_programming.md rule 20); the kernels' resource usage shows 0 bytes of scratch.
-template <int NS, int LA, int SA>
+template <int NS, int LA, int SA, bool TWO_ROLE = false>
 struct TileIO {
   using S = Slots<NS>;
   rsrc_t rs, ro;
@@ -137,6 +137,10 @@ struct TileIO {
   __device__ __forceinline__ void st(int comp, double v)
   {
     const int s = S::T.slot_of[comp];
+    if (TWO_ROLE && S::T.split2[s >> 1]) {  // the other half of this row is the other role's: store 8 bytes
+      stg<SA>(ro, (unsigned) (s >> 1) * 1024u + (unsigned) (s & 1) * 8u, vo, v);
+      return;
+    }
     outv[s] = v;
     have[s] = true;
     if (have[s ^ 1]) {
@@ -656,7 +660,7 @@ __global__ __launch_bounds__(128, 1) void k_step_coop(const double *st, double *
   const unsigned tile = xcd_workgroup(k);
   const unsigned b = tile * 64u + lane;
   const unsigned bo = b * 8u, B8 = (unsigned) B * 8u;
-  TileIO<NS, MemHint<MH>::LA, MemHint<MH>::SA> io(st, sto, tile, lane);
+  TileIO<NS, MemHint<MH>::LA, MemHint<MH>::SA, true> io(st, sto, tile, lane);
   const rsrc_t ri = mkbuf(imu, PREDICT ? 7u * B8 : 0u);
   const rsrc_t rl = mkbuf(lo, UPDATE ? 6u * B8 : 0u);
   StepInputs in;
@@ -723,29 +727,36 @@ __global__ __launch_bounds__(256, 2) void k_step_quad(const double *st, double *
 {
   using SL = Slots<21>;
   __shared__ double xch[Quad::NXCH][64];
+  if (k.stagger > 0 && (((blockIdx.x >> 3) >> 5) & 1)) {
+    for (int i = 0; i < k.stagger; i++) __builtin_amdgcn_s_sleep(16);
+  }
   const int role = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
   const unsigned lane = threadIdx.x & 63u;
   const unsigned tile = xcd_workgroup(k);
   const unsigned b = tile * 64u + lane;
   const unsigned bo = b * 8u, B8 = (unsigned) B * 8u;
   TileIO<21, MemHint<MH>::LA, MemHint<MH>::SA> io(st, sto, tile, lane);
-  const rsrc_t ri = mkbuf(imu, 7u * B8);
-  const rsrc_t rl = mkbuf(lo, UPDATE ? 6u * B8 : 0u);
-  StepInputs in;
+  // every role fetches its own copy of the inputs INSIDE its branch: nothing but addresses is live across the dispatch
+  auto inputs = [&](bool meas) {
+    const rsrc_t ri = mkbuf(imu, 7u * B8);
+    const rsrc_t rl = mkbuf(lo, UPDATE ? 6u * B8 : 0u);
+    StepInputs in;
 #pragma unroll
-  for (int i = 0; i < 3; i++) {
-    in.gyro[i] = ldg(ri, i * B8, bo);
-    in.accel[i] = ldg(ri, (3 + i) * B8, bo);
-    in.z[i] = (UPDATE && role == 0) ? ldg(rl, i * B8, bo) : 0.0;
-    in.rd[i] = (UPDATE && role == 0) ? ldg(rl, (3 + i) * B8, bo) : 1.0;
-  }
-  in.dt = ldg(ri, 6u * B8, bo);
-  in.upd = UPDATE && (b < (unsigned) B) && (mask == nullptr || mask[b] != 0);
-  in.qg = qg; in.qa = qa; in.qbg = qbg; in.qba = qba;
-  if (k.qblk != nullptr) {  // per-filter process noise (wave-uniform branch)
-    const rsrc_t rq = mkbuf(k.qblk, 4u * B8);
-    in.qg = ldg(rq, 0u, bo); in.qa = ldg(rq, B8, bo); in.qbg = ldg(rq, 2u * B8, bo); in.qba = ldg(rq, 3u * B8, bo);
-  }
+    for (int i = 0; i < 3; i++) {
+      in.gyro[i] = ldg(ri, i * B8, bo);
+      in.accel[i] = ldg(ri, (3 + i) * B8, bo);
+      in.z[i] = (UPDATE && meas) ? ldg(rl, i * B8, bo) : 0.0;
+      in.rd[i] = (UPDATE && meas) ? ldg(rl, (3 + i) * B8, bo) : 1.0;
+    }
+    in.dt = ldg(ri, 6u * B8, bo);
+    in.upd = UPDATE && (b < (unsigned) B) && (mask == nullptr || mask[b] != 0);
+    in.qg = qg; in.qa = qa; in.qbg = qbg; in.qba = qba;
+    if (k.qblk != nullptr) {  // per-filter process noise (wave-uniform branch)
+      const rsrc_t rq = mkbuf(k.qblk, 4u * B8);
+      in.qg = ldg(rq, 0u, bo); in.qa = ldg(rq, B8, bo); in.qbg = ldg(rq, 2u * B8, bo); in.qba = ldg(rq, 3u * B8, bo);
+    }
+    return in;
+  };
   auto ld = [&io](int comp) { return io.ld(comp); };
   auto stf = [&io](int comp, double v) { io.st(comp, v); };
   auto sync = []() { __syncthreads(); };
@@ -753,16 +764,16 @@ __global__ __launch_bounds__(256, 2) void k_step_quad(const double *st, double *
   auto xwr = [lane](int s, double v) { xch[s][lane] = v; };
   if (role == 0) {
     io.template need<SL::QROW[0], SL::QROW[1]>();
-    quad_role_cc<UPDATE>(ld, stf, xwr, xrd, sync, in, k);
+    quad_role_cc<UPDATE>(ld, stf, xwr, xrd, sync, inputs(true), k);
   } else if (role == 1) {
     io.template need<SL::QROW[1], SL::QROW[2]>();
-    quad_role_cb<UPDATE>(ld, stf, xwr, xrd, sync, in, k);
+    quad_role_cb<UPDATE>(ld, stf, xwr, xrd, sync, inputs(false), k);
   } else if (role == 2) {
     io.template need<SL::QROW[2], SL::QROW[3]>();
-    quad_role_passive<UPDATE, 0>(ld, stf, xwr, xrd, sync, in, k);
+    quad_role_passive<UPDATE, 0>(ld, stf, xwr, xrd, sync, inputs(false), k);
   } else {
     io.template need<SL::QROW[3], SL::QROW[4]>();
-    quad_role_passive<UPDATE, 1>(ld, stf, xwr, xrd, sync, in, k);
+    quad_role_passive<UPDATE, 1>(ld, stf, xwr, xrd, sync, inputs(false), k);
   }
 }
 
@@ -787,7 +798,7 @@ __global__ __launch_bounds__(128, 1) void k_replay_coop(double *st, int B, int T
   const unsigned tile = blockIdx.x;
   const unsigned b = tile * 64u + lane;
   const unsigned bo = b * 8u, B8 = (unsigned) B * 8u;
-  TileIO<NS, 0, 0> io(st, st, tile, lane);
+  TileIO<NS, 0, 0, true> io(st, st, tile, lane);
   double q4[4] = { qg, qa, qbg, qba };
   if (k.qblk != nullptr) {
     const rsrc_t rq = mkbuf(k.qblk, 4u * B8);
@@ -821,7 +832,7 @@ __global__ __launch_bounds__(128, 1) void k_replay_coop(double *st, int B, int T
     io.template need<0, SL::ROW_SPLIT>();
     static_for<SL::NSLOT>([&](auto I) {
       constexpr int slot = decltype(I)::value, comp = SL::T.comp_of[slot];
-      if constexpr (comp >= 0 && slot < SL::T.ncore) V[comp] = io.ld(comp);
+      if constexpr (comp >= 0 && SL::T.role2[slot] == 0) V[comp] = io.ld(comp);
     });
     auto ld = [&V](int comp) { return V[comp]; };
     auto stf = [&V](int comp, double v) { V[comp] = v; };
@@ -840,14 +851,14 @@ __global__ __launch_bounds__(128, 1) void k_replay_coop(double *st, int B, int T
     }
     static_for<SL::NSLOT>([&](auto I) {
       constexpr int slot = decltype(I)::value, comp = SL::T.comp_of[slot];
-      if constexpr (comp >= 0 && slot < SL::T.ncore) io.st(comp, V[comp]);
+      if constexpr (comp >= 0 && SL::T.role2[slot] == 0) io.st(comp, V[comp]);
     });
   } else {
     double V[L::NC];
     io.template need<SL::ROW_SPLIT, SL::NROW>();
     static_for<SL::NSLOT>([&](auto I) {
       constexpr int slot = decltype(I)::value, comp = SL::T.comp_of[slot];
-      if constexpr (comp >= 0 && slot >= SL::T.ncore) V[comp] = io.ld(comp);
+      if constexpr (comp >= 0 && SL::T.role2[slot] == 1) V[comp] = io.ld(comp);
     });
     auto ld = [&V](int comp) { return V[comp]; };
     auto stf = [&V](int comp, double v) { V[comp] = v; };
@@ -864,7 +875,7 @@ __global__ __launch_bounds__(128, 1) void k_replay_coop(double *st, int B, int T
     }
     static_for<SL::NSLOT>([&](auto I) {
       constexpr int slot = decltype(I)::value, comp = SL::T.comp_of[slot];
-      if constexpr (comp >= 0 && slot >= SL::T.ncore) io.st(comp, V[comp]);
+      if constexpr (comp >= 0 && SL::T.role2[slot] == 1) io.st(comp, V[comp]);
     });
   }
 }

@@ -8,13 +8,14 @@
 //   P'_cc = F_cc P_cc F_cc^T + H,     H = P'_cb F_cb^T + F_cb T1^T,   T1 = F_cc P_cb,   P'_cb = T1 + F_cb P_bb
 //   P'_bb = P_bb + Q_b dt,            P'_(cb)p = [F_cc F_cb; 0 I] P_(cb)p  column by column of p
 //
-//   wave 0 (role CC):  x[v chi Delta], quat, P_cc (45)         -- exactly the 15-state core role + H from wave 1
-//   wave 1 (role CB):  P_cb (54), P_bb (21), x[bg ba], loglik  -- publishes H (39 non-zero entries) and P'_bv
-//   wave 2 (role PW):  P_(cb),omega (45), P_omega,omega, x[omega]
+//   wave 0 (role CC):  P_cc (45), loglik                        -- the LDL^T of S and the rows of W for the c-states
+//   wave 1 (role CB):  P_cb (54), P_bb (21), x[bg ba], x[omega]  -- publishes H (39 non-zero entries) and P'_bv
+//   wave 2 (role PW):  P_(cb),omega (45), P_omega,omega, x[v chi Delta], quat -- the state / quaternion propagate and update
 //   wave 3 (role PA):  P_(cb),accel (45), P_accel,accel, P_accel,omega, x[accel]
 //
-// 58 / 82 / 54 / 63 components: every role fits 256 registers -> TWO waves per SIMD, two workgroups per CU, and one
-// tile's loads overlap another tile's arithmetic and stores.  Two barriers: A (H is published; nobody has overwritten
+// 46 / 84 / 64 / 63 components, balanced by ARITHMETIC rather than by bytes: the quaternion work (two exponential maps
+// per step) rides with the lightest panel instead of with the wave every other wave waits for.  Every role fits 256
+// registers -> TWO waves per SIMD, two workgroups per CU, and one tile's loads overlap another tile's arithmetic and stores.  Two barriers: A (H is published; nobody has overwritten
 // the prior x / quat that all four roles linearise about) and B (wave 0 has published the LDL^T factors and its rows of
 // W = P[:,idx] L^-T).  W_b and W_omega are recomputed by their consumers from the raw P'_bv / P'_v,omega columns that
 // their owners publish before B, so that no third barrier is needed.
@@ -29,11 +30,13 @@ namespace pb {
 
 struct Quad {
   // LDS hand-off, doubles per filter.  [0, 45): H packed by (i, j <= i) over the 9 c-states before barrier A; wave 0 is
-  // its only reader and re-uses the area for L(3) id(3) yd(3) lli(1) W_c(27) before barrier B.
-  static constexpr int X_H = 0, X_L = 0, X_ID = 3, X_YD = 6, X_LLI = 9, X_WC = 10;
+  // its only reader and re-uses the area for L(3) id(3) yd(3) W_c(27) dx_c(9) before barrier B.
+  static constexpr int X_H = 0, X_L = 0, X_ID = 3, X_YD = 6, X_WC = 9, X_DX = 36;
   static constexpr int X_BV = 45;  // raw P'(v_k, b_j) at X_BV + 3 j + k   (18)
   static constexpr int X_VW = 63;  // raw P'(v_k, omega_c) at X_VW + 3 c + k (9)
-  static constexpr int NXCH = 72;
+  static constexpr int X_H2 = 72;  // the F_cb T1^T part of H: chi-v block (9, row-major), chi-chi block (6, packed)
+  static constexpr int X_XV = 87;  // the propagated velocity x'[3..5] (role PW -> role CC, for the residual)
+  static constexpr int NXCH = 90;
 };
 
 // (X hat(m)^T)[r][c] = (m x X_r)[c] for a row-major 3x3 block X
@@ -60,7 +63,7 @@ PB_HD void fcc_apply(const ProcBlocks &f, double (&V)[9], double (&Cc)[9], doubl
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// wave 0, role CC: x[v chi Delta], quat, P_cc
+// wave 0, role CC: P_cc, loglik
 // ------------------------------------------------------------------------------------------------------------
 template <bool UPDATE, class LD, class ST, class XW, class XR, class SYNC>
 PB_HD void quad_role_cc(LD ld, ST st, XW xw, XR xr, SYNC sync, const StepInputs &in, const Consts &k)
@@ -72,6 +75,7 @@ PB_HD void quad_role_cc(LD ld, ST st, XW xw, XR xr, SYNC sync, const StepInputs 
   for (int i = 0; i < NS; i++) x[i] = ld(L::OFF_VEC + i);
 #pragma unroll
   for (int i = 0; i < 4; i++) q[i] = ld(L::OFF_QUAT + i);
+  double ll = ld(L::OFF_LL);
   double Pc[45];
 #pragma unroll
   for (int i = 0; i < 9; i++)
@@ -114,19 +118,30 @@ PB_HD void quad_role_cc(LD ld, ST st, XW xw, XR xr, SYNC sync, const StepInputs 
 #pragma unroll
     for (int r = 0; r < 3; r++) Pc[pk(3 + r, 3 + r)] += qgd;
   }
-  ins_update_state<NS>(x, q, in.gyro, in.accel, in.dt, k);
-  sync();  // A: H is there; every role has consumed the prior x / quat
+  sync();  // A: H and the propagated velocity are there; every role has consumed the prior x / quat
+  double xv[3] = { 0.0, 0.0, 0.0 };
+  if constexpr (UPDATE) {
+#pragma unroll
+    for (int i = 0; i < 3; i++) xv[i] = xr(Quad::X_XV + i);
+  }
 #pragma unroll
   for (int i = 0; i < 9; i++)
 #pragma unroll
     for (int j = 0; j <= i; j++)
       if (i < 6 || j < 6) Pc[pk(i, j)] += xr(Quad::X_H + pk(i, j));
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      Pc[pk(3 + r, c)] += xr(Quad::X_H2 + 3 * r + c);
+      if (c <= r) Pc[pk(3 + r, 3 + c)] += xr(Quad::X_H2 + 9 + pk(r, c));
+    }
 
   if constexpr (UPDATE) {
     // S = R + P[v,v]; unpivoted LDL^T; y = L^-1 r  (rbis.cpp:124-143)
     double resid[3], S[6], d[3], y[3], id[3], yd[3];
 #pragma unroll
-    for (int i = 0; i < 3; i++) resid[i] = in.upd ? in.z[i] - x[3 + i] : 0.0;
+    for (int i = 0; i < 3; i++) resid[i] = in.upd ? in.z[i] - xv[i] : 0.0;
 #pragma unroll
     for (int i = 0; i < 3; i++)
 #pragma unroll
@@ -144,7 +159,6 @@ PB_HD void quad_role_cc(LD ld, ST st, XW xw, XR xr, SYNC sync, const StepInputs 
       det *= d[kk];
       quad += s * s * id[kk];
     }
-    xw(Quad::X_LLI, -log(det) - quad);  // -log(S.determinant()) - r^T S^-1 r (rbis.cpp:142); role CB owns loglik
     double W[9][3];
 #pragma unroll
     for (int i = 0; i < 9; i++)
@@ -159,19 +173,17 @@ PB_HD void quad_role_cc(LD ld, ST st, XW xw, XR xr, SYNC sync, const StepInputs 
 #pragma unroll
     for (int kk = 0; kk < 3; kk++) { xw(Quad::X_ID + kk, id[kk]); xw(Quad::X_YD + kk, yd[kk]); }
 #pragma unroll
-    for (int i = 0; i < 9; i++)
+    for (int i = 0; i < 9; i++) {
 #pragma unroll
       for (int kk = 0; kk < 3; kk++) xw(Quad::X_WC + 3 * i + kk, W[i][kk]);
+      xw(Quad::X_DX + i, fma(W[i][2], yd[2], fma(W[i][1], yd[1], W[i][0] * yd[0])));  // role PW applies it to x / quat
+    }
     sync();  // B
-    double dfull[NS];
-#pragma unroll
-    for (int i = 0; i < NS; i++) dfull[i] = 0.0;
 #pragma unroll
     for (int i = 0; i < 9; i++) {
       double wd[3];
 #pragma unroll
       for (int kk = 0; kk < 3; kk++) wd[kk] = W[i][kk] * id[kk];
-      dfull[core_full(i)] = fma(W[i][2], yd[2], fma(W[i][1], yd[1], W[i][0] * yd[0]));
 #pragma unroll
       for (int j = 0; j <= i; j++) {
         double acc = Pc[pk(i, j)];
@@ -180,21 +192,20 @@ PB_HD void quad_role_cc(LD ld, ST st, XW xw, XR xr, SYNC sync, const StepInputs 
         st(L::OFF_P + pk(core_full(i), core_full(j)), acc);
       }
     }
-    if (in.upd) add_delta<NS>(x, q, dfull, k.chi_tol);
+    // -log(S.determinant()) - r^T S^-1 r (rbis.cpp:142): ONE log of the product, behind everything the other waves or
+    // the memory system wait for
+    if (in.upd) ll += -log(det) - quad;
   } else {
 #pragma unroll
     for (int i = 0; i < 9; i++)
 #pragma unroll
       for (int j = 0; j <= i; j++) st(L::OFF_P + pk(core_full(i), core_full(j)), Pc[pk(i, j)]);
   }
-#pragma unroll
-  for (int i = 0; i < 9; i++) st(L::OFF_VEC + core_full(i), x[core_full(i)]);
-#pragma unroll
-  for (int i = 0; i < 4; i++) st(L::OFF_QUAT + i, q[i]);
+  st(L::OFF_LL, ll);
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// wave 1, role CB: P_cb, P_bb, x[bg ba], loglik
+// wave 1, role CB: P_cb, P_bb, x[bg ba], x[omega]
 // ------------------------------------------------------------------------------------------------------------
 template <bool UPDATE, class LD, class ST, class XW, class XR, class SYNC>
 PB_HD void quad_role_cb(LD ld, ST st, XW xw, XR xr, SYNC sync, const StepInputs &in, const Consts &k)
@@ -221,23 +232,33 @@ PB_HD void quad_role_cb(LD ld, ST st, XW xw, XR xr, SYNC sync, const StepInputs 
   for (int i = 0; i < 6; i++)
 #pragma unroll
     for (int j = 0; j <= i; j++) Pbb[pk(i, j)] = ld(L::OFF_P + pk(core_full(9 + i), core_full(9 + j)));
-  double ll = ld(L::OFF_LL);
-  double xb[6];
+  double xb[6], xw_[3];
 #pragma unroll
   for (int i = 0; i < 6; i++) xb[i] = x[15 + i];
+#pragma unroll
+  for (int i = 0; i < 3; i++) xw_[i] = in.gyro[i] - x[15 + i];  // rbis.cpp:50
 
   ProcBlocks f;
   make_proc_blocks<NS>(x, q, in.dt, k, f);
-  // T1 = F_cc P_cb, block column by block column; P'_cb = T1 + F_cb P_bb; H = P'_cb F_cb^T + F_cb T1^T
-  double T1vg[9], T1va[9], T1cg[9];
+  // T1 = F_cc P_cb, block column by block column; P'_cb = T1 + F_cb P_bb; H = P'_cb F_cb^T + F_cb T1^T.  The F_cb T1^T part
+  // (non-zero in the vv, chi-v and chi-chi blocks only) is published the moment a block column of T1 exists, so that T1
+  // need not be kept next to P'_cb (27 doubles per lane).
+  double hvv[6];
 #pragma unroll
   for (int J = 0; J < 2; J++) {
     fcc_apply(f, Y[0][J], Y[1][J], Y[2][J]);
 #pragma unroll
-    for (int i = 0; i < 9; i++) {
-      if (J == 0) { T1vg[i] = Y[0][0][i]; T1cg[i] = Y[1][0][i]; }
-      else T1va[i] = Y[0][1][i];
-    }
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        if (J == 0) {
+          if (c <= r) hvv[pk(r, c)] = x_hat_t(Y[0][0], f.a_mv, c, r);
+          xw(Quad::X_H2 + 3 * r + c, -in.dt * Y[0][0][3 * c + r]);
+          if (c <= r) xw(Quad::X_H2 + 9 + pk(r, c), -in.dt * Y[1][0][3 * c + r]);
+        } else if (c <= r) {
+          hvv[pk(r, c)] -= in.dt * Y[0][1][3 * c + r];
+        }
+      }
     // blocks (bg, J) and (ba, J) of the symmetric P_bb
     double Bg[9], Ba[9];
 #pragma unroll
@@ -254,16 +275,14 @@ PB_HD void quad_role_cb(LD ld, ST st, XW xw, XR xr, SYNC sync, const StepInputs 
       Y[1][J][i] -= in.dt * Bg[i];
     }
   }
-  // H, lower block triangle of the 9 x 9 (the Delta,Delta block is zero)
+  // the P'_cb F_cb^T part, lower block triangle of the 9 x 9 (the Delta,Delta block is zero)
 #pragma unroll
   for (int r = 0; r < 3; r++)
 #pragma unroll
     for (int c = 0; c < 3; c++) {
-      if (c <= r)
-        xw(Quad::X_H + pk(r, c), x_hat_t(Y[0][0], f.a_mv, r, c) - in.dt * Y[0][1][3 * r + c] + x_hat_t(T1vg, f.a_mv, c, r) -
-                                   in.dt * T1va[3 * c + r]);
-      xw(Quad::X_H + pk(3 + r, c), x_hat_t(Y[1][0], f.a_mv, r, c) - in.dt * Y[1][1][3 * r + c] - in.dt * T1vg[3 * c + r]);
-      if (c <= r) xw(Quad::X_H + pk(3 + r, 3 + c), -in.dt * (Y[1][0][3 * r + c] + T1cg[3 * c + r]));
+      if (c <= r) xw(Quad::X_H + pk(r, c), x_hat_t(Y[0][0], f.a_mv, r, c) - in.dt * Y[0][1][3 * r + c] + hvv[pk(r, c)]);
+      xw(Quad::X_H + pk(3 + r, c), x_hat_t(Y[1][0], f.a_mv, r, c) - in.dt * Y[1][1][3 * r + c]);
+      if (c <= r) xw(Quad::X_H + pk(3 + r, 3 + c), -in.dt * Y[1][0][3 * r + c]);
       xw(Quad::X_H + pk(6 + r, c), x_hat_t(Y[2][0], f.a_mv, r, c) - in.dt * Y[2][1][3 * r + c]);
       xw(Quad::X_H + pk(6 + r, 3 + c), -in.dt * Y[2][0][3 * r + c]);
     }
@@ -285,8 +304,6 @@ PB_HD void quad_role_cb(LD ld, ST st, XW xw, XR xr, SYNC sync, const StepInputs 
     double id[3], yd[3];
 #pragma unroll
     for (int kk = 0; kk < 3; kk++) { id[kk] = xr(Quad::X_ID + kk); yd[kk] = xr(Quad::X_YD + kk); }
-    const double lli = xr(Quad::X_LLI);
-    if (in.upd) ll += lli;
     double Wb[6][3];
 #pragma unroll
     for (int j = 0; j < 6; j++) {
@@ -295,6 +312,13 @@ PB_HD void quad_role_cb(LD ld, ST st, XW xw, XR xr, SYNC sync, const StepInputs 
       Wb[j][1] = c1 - Wb[j][0] * L10;
       Wb[j][2] = c2 - Wb[j][0] * L20 - Wb[j][1] * L21;
       xb[j] += fma(Wb[j][2], yd[2], fma(Wb[j][1], yd[1], Wb[j][0] * yd[0]));
+    }
+#pragma unroll
+    for (int c = 0; c < 3; c++) {  // W_omega from role PW's raw column
+      const double w0 = xr(Quad::X_VW + 3 * c + 0);
+      const double w1 = xr(Quad::X_VW + 3 * c + 1) - w0 * L10;
+      const double w2 = xr(Quad::X_VW + 3 * c + 2) - w0 * L20 - w1 * L21;
+      xw_[c] += fma(w2, yd[2], fma(w1, yd[1], w0 * yd[0]));
     }
     // rows of the storage layout: bias j: its 9 c-entries, then its P_bb entries
 #pragma unroll
@@ -326,13 +350,15 @@ PB_HD void quad_role_cb(LD ld, ST st, XW xw, XR xr, SYNC sync, const StepInputs 
       for (int j2 = 0; j2 <= j; j2++) st(L::OFF_P + pk(core_full(9 + j), core_full(9 + j2)), Pbb[pk(j, j2)]);
     }
   }
-  st(L::OFF_LL, ll);
 #pragma unroll
   for (int i = 0; i < 6; i++) st(L::OFF_VEC + 15 + i, xb[i]);
+#pragma unroll
+  for (int i = 0; i < 3; i++) st(L::OFF_VEC + i, xw_[i]);
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// waves 2 and 3, roles PW (J = 0: omega) and PA (J = 1: accel): one block column of the passive panels
+// waves 2 and 3, roles PW (J = 0: omega; + x[v chi Delta], quat) and PA (J = 1: accel; + x[accel]): one block column of
+// the passive panels each
 // ------------------------------------------------------------------------------------------------------------
 template <bool UPDATE, int J, class LD, class ST, class XW, class XR, class SYNC>
 PB_HD void quad_role_passive(LD ld, ST st, XW xw, XR xr, SYNC sync, const StepInputs &in, const Consts &k)
@@ -382,14 +408,20 @@ PB_HD void quad_role_passive(LD ld, ST st, XW xw, XR xr, SYNC sync, const StepIn
   for (int r = 0; r < 3; r++)
 #pragma unroll
     for (int c = 0; c <= r; c++) Pjj[pk(r, c)] = (r == c) ? (J == 0 ? in.qg : in.qa) : 0.0;
-  double xp[3];  // rbis.cpp:50-51
+  double xp[3];  // J == 1: rbis.cpp:51
 #pragma unroll
-  for (int i = 0; i < 3; i++) xp[i] = (J == 0 ? in.gyro[i] - x[15 + i] : in.accel[i] - x[18 + i]);
-  if constexpr (UPDATE && J == 0) {
+  for (int i = 0; i < 3; i++) xp[i] = in.accel[i] - x[18 + i];
+  if constexpr (J == 0) {
+    // state propagate (rbis.cpp:37-75) on this role's copy: x[v chi Delta] and quat are its to store
+    ins_update_state<NS>(x, q, in.gyro, in.accel, in.dt, k);
+    if constexpr (UPDATE) {
 #pragma unroll
-    for (int c = 0; c < 3; c++)
+      for (int i = 0; i < 3; i++) xw(Quad::X_XV + i, x[3 + i]);
 #pragma unroll
-      for (int kk = 0; kk < 3; kk++) xw(Quad::X_VW + 3 * c + kk, X[0][3 * kk + c]);
+      for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int kk = 0; kk < 3; kk++) xw(Quad::X_VW + 3 * c + kk, X[0][3 * kk + c]);
+    }
   }
   sync();  // A
   if constexpr (UPDATE) {
@@ -404,7 +436,15 @@ PB_HD void quad_role_passive(LD ld, ST st, XW xw, XR xr, SYNC sync, const StepIn
       Wp[c][0] = X[0][0 + c];
       Wp[c][1] = X[0][3 + c] - Wp[c][0] * L10;
       Wp[c][2] = X[0][6 + c] - Wp[c][0] * L20 - Wp[c][1] * L21;
-      xp[c] += fma(Wp[c][2], yd[2], fma(Wp[c][1], yd[1], Wp[c][0] * yd[0]));
+      if constexpr (J == 1) xp[c] += fma(Wp[c][2], yd[2], fma(Wp[c][1], yd[1], Wp[c][0] * yd[0]));
+    }
+    if constexpr (J == 0) {  // apply role CC's dx to the state vector and the quaternion (addState, rbis.cpp:219-227)
+      double dfull[NS];
+#pragma unroll
+      for (int i = 0; i < NS; i++) dfull[i] = 0.0;
+#pragma unroll
+      for (int i = 0; i < 9; i++) dfull[core_full(i)] = xr(Quad::X_DX + i);
+      if (in.upd) add_delta<NS>(x, q, dfull, k.chi_tol);
     }
 #pragma unroll
     for (int sb = 0; sb < 5; sb++)
@@ -477,8 +517,15 @@ PB_HD void quad_role_passive(LD ld, ST st, XW xw, XR xr, SYNC sync, const StepIn
       for (int c = 0; c <= r; c++) st(L::OFF_P + pk(passive_full(3 * J + r), passive_full(3 * J + c)), Pjj[pk(r, c)]);
     }
   }
+  if constexpr (J == 0) {
 #pragma unroll
-  for (int i = 0; i < 3; i++) st(L::OFF_VEC + passive_full(3 * J + i), xp[i]);
+    for (int i = 0; i < 9; i++) st(L::OFF_VEC + core_full(i), x[core_full(i)]);
+#pragma unroll
+    for (int i = 0; i < 4; i++) st(L::OFF_QUAT + i, q[i]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 3; i++) st(L::OFF_VEC + passive_full(3 + i), xp[i]);
+  }
 }
 
 }  // namespace pb

@@ -69,6 +69,25 @@ template<int DEPTH, int LA, int SA, bool XCD, int TF> __global__ __launch_bounds
 }
 #define CK(x) do{hipError_t e=(x); if(e!=hipSuccess){printf("err %s line %d\n",hipGetErrorString(e),__LINE__); return 1;}}while(0)
 template<class F> float timeit(F f,int reps){ hipEvent_t a,b; hipEventCreate(&a);hipEventCreate(&b); f(); f(); hipDeviceSynchronize(); hipEventRecord(a); for(int i=0;i<reps;i++) f(); hipEventRecord(b); hipEventSynchronize(b); float ms; hipEventElapsedTime(&ms,a,b); return ms/reps; }
+// 21-state tiles (129 rows of 64 x 16 B) with the step kernels' wave mappings: NW waves per tile, wave w moves rows
+// [R[w], R[w+1]) -- every load of the wave first, then every store (what a role does around its arithmetic); rows beyond
+// 64 per wave go in two halves (register file)
+template<int NW, int LA, int SA, bool XCD> __global__ __launch_bounds__(NW*64) void copyQ(const double* src, double* dst, int B, int r0, int r1, int r2, int r3, int r4){
+  unsigned wg=blockIdx.x;
+  if(XCD){ unsigned nq=gridDim.x>>3,nr=gridDim.x&7u,x=blockIdx.x&7u,r=blockIdx.x>>3; wg=(x<nr? x*(nq+1u): nr*(nq+1u)+(x-nr)*nq)+r; }
+  const unsigned lane=threadIdx.x&63u; const int w=__builtin_amdgcn_readfirstlane((int)(threadIdx.x>>6));
+  const size_t tb=(size_t)wg*129*1024;
+  rsrc_t ri=mkbuf((const char*)src+tb,129*1024), ro=mkbuf((char*)dst+tb,129*1024);
+  const int lo_ = w==0? r0 : w==1? r1 : w==2? r2 : r3, hi_ = w==0? r1 : w==1? r2 : w==2? r3 : r4;
+  const unsigned bo=lane*16u;
+  for(int c0=lo_; c0<hi_; c0+=42){ v4u v[42];
+#pragma unroll
+    for(int i=0;i<42;i++) if(c0+i<hi_) v[i]=__builtin_amdgcn_raw_buffer_load_b128(ri,bo,(unsigned)(c0+i)*1024u,LA);
+#pragma unroll
+    for(int i=0;i<42;i++) if(c0+i<hi_){ v[i].x+=1u; __builtin_amdgcn_raw_buffer_store_b128(v[i],ro,bo,(unsigned)(c0+i)*1024u,SA); asm volatile("s_nop 1"::"v"(v[i])); }
+  }
+}
+
 int main(){
   const int nc=140;
   for(int B : {65536, 196608, 262144, 1<<20}){
@@ -121,6 +140,21 @@ int main(){
     RUNT16("tile256 16B in-place d35 xcd nt",35,2,2,true,256,s);
     RUNT8("tile1024 8B in-place d35 xcd",35,0,0,true,1024,s);
     RUNT8("tile1024 8B in-place d35 xcd nt",35,2,2,true,1024,s);
+    hipFree(s);hipFree(d);
+  }
+  for(int B : {32768, 65536, 131072, 262144}){
+    size_t bytes=(size_t)(B/64)*129*1024; double *s,*d; CK(hipMalloc(&s,bytes)); CK(hipMalloc(&d,bytes)); CK(hipMemset(s,1,bytes)); CK(hipMemset(d,0,bytes));
+    auto rep=[&](const char*name,float ms){ printf("n21 B=%8d %-34s %9.1f us  %7.1f GB/s (r+w)\n",B,name,ms*1e3,2.0*bytes/(ms*1e-3)/1e9); fflush(stdout); };
+    int reps = B>100000? 20: 100; int g=B/64;
+#define RUNQ(NAME,NW,LA,SA,X,DST,R1,R2,R3) rep(NAME, timeit([&]{ copyQ<NW,LA,SA,X><<<g,NW*64>>>(s,DST,B,0,R1,R2,R3,129);},reps))
+    RUNQ("4 waves (29|41|27|32 rows) xcd",4,0,0,true,s,29,70,97);
+    RUNQ("4 waves xcd st-sc1",4,0,16,true,s,29,70,97);
+    RUNQ("4 waves xcd nt",4,2,2,true,s,29,70,97);
+    RUNQ("4 waves st-sc1",4,0,16,false,s,29,70,97);
+    RUNQ("4 waves xcd st-sc1 out-of-place",4,0,16,true,d,29,70,97);
+    RUNQ("2 waves (70|59 rows) xcd st-sc1",2,0,16,true,s,70,129,129);
+    RUNQ("2 waves xcd nt",2,2,2,true,s,70,129,129);
+    RUNQ("1 wave xcd st-sc1",1,0,16,true,s,129,129,129);
     hipFree(s);hipFree(d);
   }
   return 0;

@@ -175,6 +175,66 @@ extern "C" void hh_step_coop_correct(int ns, int kind, int mode, double *st, lon
   else step_coop<21, CorrPosYaw>(st, stride, B, imu, lo, mask, q4, g, tol, mode, z2, rd2, qm2, mask2);
 }
 
+// ---- four-wave 21-state step (rbis_quad.hpp): the four roles run as four threads with a real barrier (role CB needs
+// role CC's factors and role CC needs role CB's H, so no back-to-back order works); a plain array stands in for LDS. ----
+#include <pthread.h>
+
+#include <thread>
+
+#include "../pronto_amd/csrc/rbis_quad.hpp"
+
+template <bool UPDATE>
+static void step_quad(double *st, long stride, int B, const double *imu, const double *lo, const uint8_t *mask, const double *q4,
+                      double g, double tol)
+{
+  Consts k{ g, tol };
+  constexpr int NC = Lay<21>::NC;
+  static double in_col[NC], out_col[NC], xch[Quad::NXCH];
+  static StepInputs in;
+  pthread_barrier_t bar;
+  pthread_barrier_init(&bar, nullptr, 4);
+  auto body = [&](int role) {
+    for (int b = 0; b < B; b++) {
+      if (role == 0) {
+        for (int c = 0; c < NC; c++) in_col[c] = out_col[c] = st[c * stride + b];
+        for (int i = 0; i < 3; i++) {
+          in.gyro[i] = imu[i * B + b];
+          in.accel[i] = imu[(3 + i) * B + b];
+          in.z[i] = UPDATE ? lo[i * B + b] : 0.0;
+          in.rd[i] = UPDATE ? lo[(3 + i) * B + b] : 1.0;
+        }
+        in.dt = imu[6 * B + b];
+        in.upd = UPDATE && (!mask || mask[b]);
+        in.qg = q4[0]; in.qa = q4[1]; in.qbg = q4[2]; in.qba = q4[3];
+      }
+      pthread_barrier_wait(&bar);
+      auto ld = [&](int c) { return in_col[c]; };
+      auto stf = [&](int c, double v) { out_col[c] = v; };
+      auto sync = [&]() { pthread_barrier_wait(&bar); };
+      auto xw = [&](int s, double v) { xch[s] = v; };
+      auto xr = [&](int s) { return xch[s]; };
+      if (role == 0) quad_role_cc<UPDATE>(ld, stf, xw, xr, sync, in, k);
+      else if (role == 1) quad_role_cb<UPDATE>(ld, stf, xw, xr, sync, in, k);
+      else if (role == 2) quad_role_passive<UPDATE, 0>(ld, stf, xw, xr, sync, in, k);
+      else quad_role_passive<UPDATE, 1>(ld, stf, xw, xr, sync, in, k);
+      pthread_barrier_wait(&bar);
+      if (role == 0)
+        for (int c = 0; c < NC; c++) st[c * stride + b] = out_col[c];
+    }
+  };
+  std::thread t1(body, 1), t2(body, 2), t3(body, 3);
+  body(0);
+  t1.join(); t2.join(); t3.join();
+  pthread_barrier_destroy(&bar);
+}
+
+extern "C" void hh_step_quad(double *st, long stride, int B, const double *imu, const double *lo, const uint8_t *mask,
+                             const double *q4, double g, double tol, int do_update)
+{
+  if (do_update) step_quad<true>(st, stride, B, imu, lo, mask, q4, g, tol);
+  else step_quad<false>(st, stride, B, imu, lo, mask, q4, g, tol);
+}
+
 // ---- leg kinematic odometry (rbis_legodo.hpp): one call = one joint-state message for B robots ----
 #include "../pronto_amd/csrc/rbis_legodo.hpp"
 extern "C" {

@@ -493,9 +493,10 @@ def test_full_size_configs_3_and_5_sampled_parity(pa, oracle, n, vo, sm, generic
     assert rel(P[:, :, sel], ob.cov[:n, :n]) < TOL and rel(ll[sel], ob.ll) < TOL
 
 
-@pytest.mark.parametrize("n,B,coop", [(15, 1000, "1"), (15, 715, "1"), (15, 715, "0"), (21, 700, "1")])
-def test_every_kernel_variant_is_bit_identical(pa, oracle, n, B, coop, monkeypatch):
-    """pb_create picks the step kernel (one-lane / two-wave), the workgroup order (XCD-contiguous or not) and the cache
+@pytest.mark.parametrize("n,B,kern", [(15, 1000, "coop"), (15, 715, "coop"), (15, 715, "lane"), (21, 700, "coop"),
+                                      (21, 700, "quad"), (21, 1000, "quad")])
+def test_every_kernel_variant_is_bit_identical(pa, oracle, n, B, kern, monkeypatch):
+    """pb_create picks the step kernel (one-lane / two-wave / four-wave), the workgroup order (XCD-contiguous or not) and the cache
     policy of the state round trip (default / sc1 stores / non-temporal) from the batch size, so the small batches of the
     other tests never reach most variants.  Force every combination on ragged grids (16, 12 and 11 workgroups: remainder
     0, 4 and 3 over the 8 XCDs): each step kernel is checked against the oracle, and workgroup order and cache policy
@@ -503,14 +504,15 @@ def test_every_kernel_variant_is_bit_identical(pa, oracle, n, B, coop, monkeypat
     w = Workload(B, n_states=n)
     q4 = w.process_noise()
     vo, sm = (7, 0) if n == 15 else (0, 7)
-    monkeypatch.setenv("PRONTO_BATCH_COOP15", coop)
+    monkeypatch.setenv("PRONTO_BATCH_COOP15", "1" if kern == "coop" else "0")
+    monkeypatch.setenv("PRONTO_BATCH_QUAD21", "1" if kern == "quad" else "0")
     ref = None
     for xcd in ("0", "1"):
         for hint in ("0", "1", "2"):
             monkeypatch.setenv("PRONTO_BATCH_XCD", xcd)
             monkeypatch.setenv("PRONTO_BATCH_MEMHINT", hint)
             est, ob = make_pair(pa, oracle, w, dense_p0=5)
-            assert ("coop" in est.hot_kernel()) == (coop == "1")
+            assert [t for t in ("coop", "quad") if t in est.hot_kernel()] == ([] if kern == "lane" else [kern])
             for k in range(30):  # fused step kernel
                 lo, mask = w.legodo_block(k)
                 est.step_legodo(w.imu_block(k), lo, mask, q4)

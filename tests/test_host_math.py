@@ -107,6 +107,36 @@ def test_cooperative_roles_match_oracle(oracle, harness, ns, upd):
         assert rel(ll, ob.ll) < 1e-11
 
 
+@pytest.mark.parametrize("upd", [1, 0])
+def test_four_wave_roles_match_oracle(oracle, harness, upd):
+    """rbis_quad.hpp: the 21-state step as four roles (P_cc | P_cb P_bb | omega column | accel column) run as four threads
+    with a real barrier; the c-b coupling enters P_cc as the additive term H."""
+    H = harness
+    g, tol = oracle.constants()
+    ns, B, T = 21, 24, 150
+    w = Workload(B, n_states=ns)
+    vec, quat, P0 = w.initial_state()
+    P0 = P0 + random_spd(ns, B, 0.03, 5)
+    vec[15:18], vec[18:21] = 0.5 * w.bg, 0.5 * w.ba
+    ob = oracle.OracleBatch(vec, quat, P0)
+    st = pack(H, ns, vec, quat, P0, np.zeros(B))
+    q4 = w.process_noise()
+    for k in range(T):
+        imu = w.imu_block(k)
+        lo, mask = w.legodo_block(k)
+        ob.predict(imu, q4)
+        if upd:
+            ob.update_indexed([3, 4, 5], lo[0:3], lo[3:6], mask=mask)
+        H.hh_step_quad(P(st), C.c_long(B), B, P(imu), P(lo), mask.ctypes.data_as(C.c_void_p), P(q4),
+                       C.c_double(g), C.c_double(tol), upd)
+    v, q, cov, ll = unpack(H, ns, st)
+    assert rel(v, ob.vec[:ns]) < 1e-11 and rel(q, ob.quat) < 1e-11 and rel(cov, ob.cov[:ns, :ns]) < 1e-11
+    from util import rel_elem
+    assert rel_elem(cov, ob.cov[:ns, :ns]) < 1e-9
+    if upd:
+        assert rel(ll, ob.ll) < 1e-11
+
+
 @pytest.mark.parametrize("alone", [False, True])
 @pytest.mark.parametrize("ns,kind", [(15, 0), (15, 1), (21, 0), (21, 1)])
 def test_cooperative_roles_with_fused_correction_match_oracle(oracle, harness, ns, kind, alone):
