@@ -164,3 +164,34 @@ def test_delayed_measurements_replay_equals_in_order(oracle, checkpoint_every, d
     print(r.stdout, r.stderr)
     assert r.returncode == 0 and "PASS" in r.stdout, r.stdout + r.stderr
     assert "before the first in history" in r.stderr  # the too-old fix was discarded (update_history.cpp:28-39)
+
+
+def build_multi_gpu_sweep():
+    """examples/multi_gpu_sweep.cpp exactly as its header comment says (plain g++, the C ABI, RCCL called directly)."""
+    _lib.build()
+    exe = os.path.join(ROOT, "tests", "build", "multi_gpu_sweep")
+    os.makedirs(os.path.dirname(exe), exist_ok=True)
+    src = os.path.join(ROOT, "examples", "multi_gpu_sweep.cpp")
+    if os.path.exists(exe) and all(os.path.getmtime(exe) >= os.path.getmtime(d) for d in (src, _lib.LIB_PATH)):
+        return exe
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(ROOT, "include"),
+                           "-I/opt/rocm/include", src, "-L" + os.path.dirname(_lib.LIB_PATH), "-lpronto_batch",
+                           "-L/opt/rocm/lib", "-lrccl", "-lamdhip64", "-lpthread",
+                           "-Wl,-rpath," + os.path.dirname(_lib.LIB_PATH), "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    return exe
+
+
+def test_multi_gpu_sweep_example_compiles_and_links():
+    assert os.path.exists(build_multi_gpu_sweep())
+
+
+@pytest.mark.gpu
+def test_multi_gpu_sweep_example_on_the_visible_devices():
+    """The C++ filter-range split: one context and one host thread per shard (two shards share the one device of the test
+    box), no data-path exchange, one RCCL all-reduce of the summary; its built-in check re-runs the job as ONE context and
+    demands the same summary."""
+    exe = build_multi_gpu_sweep()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([exe, "4096", "40", "2"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "RCCL all-reduce" in r.stdout and "x 2 shard(s)" in r.stdout, r.stdout
