@@ -1,7 +1,7 @@
 // pb_update_ct.hip -- stand-alone indexed (+ orientation) updates whose index list is one the handlers actually produce
-// (compile-time core indices, diagonal R): they run on the two-role cooperative mapping (k_step_coop with PREDICT = false,
-// rbis_coop.hpp) -- one coalesced round trip of the state, no column gather -- instead of the generic run-time-index kernel
-// k_update.  See pb_ctx.hpp.
+// (compile-time core indices, diagonal R): 15 states on the two-role cooperative mapping (k_step_coop with PREDICT = false,
+// rbis_coop.hpp), 21 states on the four-wave mapping (k_update_quad, rbis_quad.hpp) -- one coalesced round trip of the
+// state, no column gather -- instead of the generic run-time-index kernel k_update.  See pb_ctx.hpp.
 #include "pb_ctx.hpp"
 
 template <int NS, int MH, class CORR>
@@ -13,21 +13,19 @@ static void launch_ct(pb_ctx *c, double *out, const CorrArgs &ca)
 template <class CORR>
 static void launch_ct_mh(pb_ctx *c, double *out, const CorrArgs &ca)
 {
-  if constexpr (CORR::M > 4) {  // 21-state variants of these are never launched (see pbk_update_ct): do not build them
-    switch (c->mem_hint) {
-    case MH_STORE_SC1: launch_ct<15, MH_STORE_SC1, CORR>(c, out, ca); break;
-    case MH_STREAM_NT: launch_ct<15, MH_STREAM_NT, CORR>(c, out, ca); break;
-    default: launch_ct<15, MH_DEFAULT, CORR>(c, out, ca); break;
-    }
-    return;
-  }
   if (c->ns == 15) {
     switch (c->mem_hint) {
     case MH_STORE_SC1: launch_ct<15, MH_STORE_SC1, CORR>(c, out, ca); break;
     case MH_STREAM_NT: launch_ct<15, MH_STREAM_NT, CORR>(c, out, ca); break;
     default: launch_ct<15, MH_DEFAULT, CORR>(c, out, ca); break;
     }
-  } else {
+  } else if (c->quad21) {
+    switch (c->mem_hint) {
+    case MH_STORE_SC1: k_update_quad<CORR, MH_STORE_SC1><<<nblk(c->B), 256, 0, c->stream>>>(c->st, out, c->B, c->k, ca); break;
+    case MH_STREAM_NT: k_update_quad<CORR, MH_STREAM_NT><<<nblk(c->B), 256, 0, c->stream>>>(c->st, out, c->B, c->k, ca); break;
+    default: k_update_quad<CORR, MH_DEFAULT><<<nblk(c->B), 256, 0, c->stream>>>(c->st, out, c->B, c->k, ca); break;
+    }
+  } else if constexpr (CORR::M <= 4) {  // PRONTO_BATCH_QUAD21=0: the two-role mapping (its six-row variants spill: not built)
     switch (c->mem_hint) {
     case MH_STORE_SC1: launch_ct<21, MH_STORE_SC1, CORR>(c, out, ca); break;
     case MH_STREAM_NT: launch_ct<21, MH_STREAM_NT, CORR>(c, out, ca); break;
@@ -63,9 +61,8 @@ int pbk_update_ct(pb_ctx *c, int m, const int *idx, const double *z, const doubl
   else if (orient && same(idx, m, { 3, 4, 5, 8 })) which = 5;
   else if (orient && same(idx, m, { 8 })) which = 6;
   if (which < 0) return -1;
-  // 21 states with six measurement rows: role C's sub-matrix plus the second-stage temporaries spill (268-324 bytes per
-  // lane); the generic kernel streams the covariance instead and has no scratch
-  if (c->ns == 21 && m > 4) return -1;
+  // two-role mapping only (A/B switch): 21 states with six measurement rows spill there; the generic kernel takes them
+  if (c->ns == 21 && !c->quad21 && m > 4) return -1;
   double *out = update_target(c);
   switch (which) {
   case 0: launch_ct_mh<CorrVel>(c, out, ca); break;

@@ -719,7 +719,7 @@ __global__ __launch_bounds__(128, 1) void k_step_coop(const double *st, double *
 // workgroups (8 waves) share a CU and one tile's loads overlap another's arithmetic and stores.  Same inputs, same
 // posterior (to rounding: the c-b coupling enters P_cc as one additive term instead of inside the row operations) and the
 // same bytes as k_step_coop<21>.  No lane returns before the barriers (see k_step_coop).
-template <bool UPDATE, int MH = MH_DEFAULT>
+template <bool UPDATE, int MH = MH_DEFAULT, int INA = 0>
 __global__ __launch_bounds__(256, 2) void k_step_quad(const double *st, double *sto, int B,
                                                       const double *__restrict__ imu, const double *__restrict__ lo,
                                                       const uint8_t *__restrict__ mask, double qg, double qa,
@@ -743,12 +743,12 @@ __global__ __launch_bounds__(256, 2) void k_step_quad(const double *st, double *
     StepInputs in;
 #pragma unroll
     for (int i = 0; i < 3; i++) {
-      in.gyro[i] = ldg(ri, i * B8, bo);
-      in.accel[i] = ldg(ri, (3 + i) * B8, bo);
-      in.z[i] = (UPDATE && meas) ? ldg(rl, i * B8, bo) : 0.0;
-      in.rd[i] = (UPDATE && meas) ? ldg(rl, (3 + i) * B8, bo) : 1.0;
+      in.gyro[i] = ldg<INA>(ri, i * B8, bo);
+      in.accel[i] = ldg<INA>(ri, (3 + i) * B8, bo);
+      in.z[i] = (UPDATE && meas) ? ldg<INA>(rl, i * B8, bo) : 0.0;
+      in.rd[i] = (UPDATE && meas) ? ldg<INA>(rl, (3 + i) * B8, bo) : 1.0;
     }
-    in.dt = ldg(ri, 6u * B8, bo);
+    in.dt = ldg<INA>(ri, 6u * B8, bo);
     in.upd = UPDATE && (b < (unsigned) B) && (mask == nullptr || mask[b] != 0);
     in.qg = qg; in.qa = qa; in.qbg = qbg; in.qba = qba;
     if (k.qblk != nullptr) {  // per-filter process noise (wave-uniform branch)
@@ -774,6 +774,54 @@ __global__ __launch_bounds__(256, 2) void k_step_quad(const double *st, double *
   } else {
     io.template need<SL::QROW[3], SL::QROW[4]>();
     quad_role_passive<UPDATE, 1>(ld, stf, xwr, xrd, sync, inputs(false), k);
+  }
+}
+
+// Stand-alone indexed (+ orientation) update of a 21-state batch on the four-wave mapping (rbis_quad.hpp, quad_upd_*): the
+// handlers' index lists as compile-time c-state indices, diagonal R, one barrier, one state round trip at two waves per SIMD.
+template <class CORR, int MH = MH_DEFAULT>
+__global__ __launch_bounds__(256, 2) void k_update_quad(const double *st, double *sto, int B, Consts k, CorrArgs ca)
+{
+  using SL = Slots<21>;
+  __shared__ double xch[QuadU<CORR>::NXCH][64];
+  const int role = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
+  const unsigned lane = threadIdx.x & 63u;
+  const unsigned tile = xcd_workgroup(k);
+  const unsigned b = tile * 64u + lane;
+  const unsigned bo = b * 8u, B8 = (unsigned) B * 8u;
+  TileIO<21, MemHint<MH>::LA, MemHint<MH>::SA> io(st, sto, tile, lane);
+  auto inputs = [&](bool meas) {
+    CorrInputs cin;
+    const rsrc_t rz = mkbuf(ca.z2, (unsigned) CORR::M * B8);
+    const rsrc_t rr = mkbuf(ca.r2, ca.r2 ? (unsigned) CORR::M * B8 : 0u);
+    const rsrc_t rq2 = mkbuf(ca.qm2, CORR::ORIENT ? 4u * B8 : 0u);
+#pragma unroll
+    for (int i = 0; i < CORR::M; i++) {
+      cin.z[i] = meas ? ldg(rz, i * B8, bo) : 0.0;
+      cin.rd[i] = meas ? (ca.r2 ? ldg(rr, i * B8, bo) : ca.rb2[i]) : 1.0;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) cin.qm[i] = (CORR::ORIENT && meas) ? ldg(rq2, i * B8, bo) : 0.0;
+    cin.upd = (b < (unsigned) B) && (ca.mask2 == nullptr || ca.mask2[b] != 0);
+    return cin;
+  };
+  auto ld = [&io](int comp) { return io.ld(comp); };
+  auto stf = [&io](int comp, double v) { io.st(comp, v); };
+  auto sync = []() { __syncthreads(); };
+  auto xrd = [lane](int s) { return xch[s][lane]; };
+  auto xwr = [lane](int s, double v) { xch[s][lane] = v; };
+  if (role == 0) {
+    io.template need<SL::QROW[0], SL::QROW[1]>();
+    quad_upd_cc<CORR>(ld, stf, xwr, xrd, sync, inputs(true), k);
+  } else if (role == 1) {
+    io.template need<SL::QROW[1], SL::QROW[2]>();
+    quad_upd_cb<CORR>(ld, stf, xwr, xrd, sync, inputs(false), k);
+  } else if (role == 2) {
+    io.template need<SL::QROW[2], SL::QROW[3]>();
+    quad_upd_passive<CORR, 0>(ld, stf, xwr, xrd, sync, inputs(false), k);
+  } else {
+    io.template need<SL::QROW[3], SL::QROW[4]>();
+    quad_upd_passive<CORR, 1>(ld, stf, xwr, xrd, sync, inputs(false), k);
   }
 }
 

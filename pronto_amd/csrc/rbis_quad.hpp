@@ -528,4 +528,344 @@ PB_HD void quad_role_passive(LD ld, ST st, XW xw, XR xr, SYNC sync, const StepIn
   }
 }
 
+// =================================================================================================================
+// Stand-alone indexed (+ orientation) update on the four-wave mapping: the measurement indices are a compile-time list of
+// c-states (v chi Delta: every index list the reference's handlers produce), R is diagonal.  S = R + P_cc[idx,idx] lives
+// entirely in role CC, so ONE barrier is enough: before it role CC publishes the LDL^T factors, its rows of
+// W = P[:,idx] L^-T and dx for the c-states, role CB its raw P[idx, b] columns and role PW its raw P[idx, omega] columns;
+// behind it every role forms the rows of W it needs and downdates its own entries.
+// (RBISIndexedMeasurement / RBISIndexedPlusOrientationMeasurement::updateFilter, rbis_update_interface.cpp:54-107.)
+// =================================================================================================================
+template <class CORR>
+struct QuadU {
+  static constexpr int M = CORR::M;
+  static constexpr int X_L = 0, X_ID = X_L + M * (M - 1) / 2, X_YD = X_ID + M, X_WC = X_YD + M, X_DX = X_WC + 9 * M,
+                       X_BV = X_DX + 9,        // raw P(idx_k, b_j) at X_BV + M j + k
+                       X_VW = X_BV + 6 * M,    // raw P(idx_k, omega_c) at X_VW + M c + k
+                       NXCH = X_VW + 3 * M;
+  PB_HD static constexpr bool all_core()
+  {
+    for (int i = 0; i < M; i++)
+      if (CORR::sub[i] >= 9) return false;
+    return true;
+  }
+};
+
+// rows of W for a raw column set: w[kk] = raw[kk] - sum_{j<kk} w[j] L[kk][j]   (L packed strictly-lower by rows)
+template <int M>
+PB_HD void quad_fsub(const double (&raw)[M], const double (&Lp)[M * (M - 1) / 2 + 1], double (&w)[M])
+{
+#pragma unroll
+  for (int kk = 0; kk < M; kk++) {
+    double s2 = raw[kk];
+#pragma unroll
+    for (int j = 0; j < kk; j++) s2 -= w[j] * Lp[kk * (kk - 1) / 2 + j];
+    w[kk] = s2;
+  }
+}
+
+template <class CORR, class LD, class ST, class XW, class XR, class SYNC>
+PB_HD void quad_upd_cc(LD ld, ST st, XW xw, XR xr, SYNC sync, const CorrInputs &cin, const Consts &k)
+{
+  constexpr int NS = 21, M = CORR::M;
+  using L = Lay<NS>;
+  using QU = QuadU<CORR>;
+  static_assert(QU::all_core(), "measurement indices must be c-states");
+  double ll = ld(L::OFF_LL);
+  double Pc[45];
+#pragma unroll
+  for (int i = 0; i < 9; i++)
+#pragma unroll
+    for (int j = 0; j <= i; j++) Pc[pk(i, j)] = ld(L::OFF_P + pk(core_full(i), core_full(j)));
+  double r2[M], S2[M * (M + 1) / 2], d2[M], y2[M], id2[M], yd2[M];
+  double dq3[3] = { 0.0, 0.0, 0.0 };
+  if constexpr (CORR::ORIENT) {
+    double q[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) q[i] = ld(L::OFF_QUAT + i);
+    subtract_quats(cin.qm, q, dq3);
+  }
+#pragma unroll
+  for (int kk = 0; kk < M; kk++) {
+    const int ii = core_full(CORR::sub[kk]);
+    const double r = (CORR::ORIENT && ii >= 6 && ii <= 8) ? dq3[ii - 6] : cin.z[kk] - ld(L::OFF_VEC + ii);
+    r2[kk] = cin.upd ? r : 0.0;
+  }
+#pragma unroll
+  for (int i = 0; i < M; i++)
+#pragma unroll
+    for (int j = 0; j <= i; j++)
+      S2[pk(i, j)] = Pc[pk(CORR::sub[i], CORR::sub[j])] + (i == j ? (cin.upd ? cin.rd[i] : 1.0) : 0.0);
+  ldlt<M>(S2, d2);
+  double quad2 = 0.0, det2 = 1.0;
+#pragma unroll
+  for (int kk = 0; kk < M; kk++) {
+    double s2 = r2[kk];
+#pragma unroll
+    for (int j = 0; j < kk; j++) s2 -= S2[pk(kk, j)] * y2[j];
+    y2[kk] = cin.upd ? s2 : 0.0;
+    id2[kk] = cin.upd ? 1.0 / d2[kk] : 0.0;
+    yd2[kk] = y2[kk] * id2[kk];
+    det2 *= d2[kk];
+    quad2 += s2 * s2 * id2[kk];
+  }
+#pragma unroll
+  for (int i = 1; i < M; i++)
+#pragma unroll
+    for (int j = 0; j < i; j++) xw(QU::X_L + i * (i - 1) / 2 + j, S2[pk(i, j)]);
+#pragma unroll
+  for (int kk = 0; kk < M; kk++) { xw(QU::X_ID + kk, id2[kk]); xw(QU::X_YD + kk, yd2[kk]); }
+  // W = P_cc[:, idx] L^-T row by row, published as it is formed.  Six measurement rows: P_cc (90 registers) and W (108) do
+  // not fit together at two waves per SIMD, so W is NOT kept: the downdate reads its rows back from the hand-off area
+  // (this wave's own LDS writes are in order).
+  constexpr bool W_LDS = (M > 4);
+  double W[W_LDS ? 1 : 9][M];
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    double w2[M], dxs = 0.0;
+#pragma unroll
+    for (int kk = 0; kk < M; kk++) {
+      double s2 = Pc[pk(i, CORR::sub[kk])];
+#pragma unroll
+      for (int j = 0; j < kk; j++) s2 -= w2[j] * S2[pk(kk, j)];
+      w2[kk] = s2;
+      if constexpr (!W_LDS) W[i][kk] = s2;
+      xw(QU::X_WC + M * i + kk, s2);
+      dxs = (kk == 0) ? s2 * yd2[0] : fma(s2, yd2[kk], dxs);
+    }
+    xw(QU::X_DX + i, dxs);
+  }
+  sync();
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    // (without the clobber the compiler shares every LDS read of W between the rows: all of W back in registers)
+    if constexpr (W_LDS) reload_fence();
+    double wd[M];
+#pragma unroll
+    for (int kk = 0; kk < M; kk++) wd[kk] = (W_LDS ? xr(QU::X_WC + M * i + kk) : W[i][kk]) * id2[kk];
+#pragma unroll
+    for (int j = 0; j <= i; j++) {
+      double acc = Pc[pk(i, j)];
+#pragma unroll
+      for (int kk = 0; kk < M; kk++) acc = fma(-wd[kk], W_LDS ? xr(QU::X_WC + M * j + kk) : W[j][kk], acc);
+      st(L::OFF_P + pk(core_full(i), core_full(j)), acc);
+    }
+  }
+  if (cin.upd) ll += -log(det2) - quad2;
+  st(L::OFF_LL, ll);
+}
+
+template <class CORR, class LD, class ST, class XW, class XR, class SYNC>
+PB_HD void quad_upd_cb(LD ld, ST st, XW xw, XR xr, SYNC sync, const CorrInputs &cin, const Consts &k)
+{
+  constexpr int NS = 21, M = CORR::M;
+  using L = Lay<NS>;
+  using QU = QuadU<CORR>;
+  double Y[3][2][9];
+#pragma unroll
+  for (int sb = 0; sb < 3; sb++)
+#pragma unroll
+    for (int J = 0; J < 2; J++)
+#pragma unroll
+      for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) Y[sb][J][3 * r + c] = ld(L::OFF_P + pk(core_full(3 * sb + r), core_full(9 + 3 * J + c)));
+  double Pbb[21];
+#pragma unroll
+  for (int i = 0; i < 6; i++)
+#pragma unroll
+    for (int j = 0; j <= i; j++) Pbb[pk(i, j)] = ld(L::OFF_P + pk(core_full(9 + i), core_full(9 + j)));
+  double xb[6], xw_[3];
+#pragma unroll
+  for (int i = 0; i < 6; i++) xb[i] = ld(L::OFF_VEC + 15 + i);
+#pragma unroll
+  for (int i = 0; i < 3; i++) xw_[i] = ld(L::OFF_VEC + i);
+  auto pcb = [&](int i, int j) { return Y[i / 3][j / 3][3 * (i % 3) + j % 3]; };  // P(c_i, b_j)
+#pragma unroll
+  for (int j = 0; j < 6; j++)
+#pragma unroll
+    for (int kk = 0; kk < M; kk++) xw(QU::X_BV + M * j + kk, pcb(CORR::sub[kk], j));
+  sync();
+  double Lp[M * (M - 1) / 2 + 1], id2[M], yd2[M];
+#pragma unroll
+  for (int i = 0; i < M * (M - 1) / 2; i++) Lp[i] = xr(QU::X_L + i);
+#pragma unroll
+  for (int kk = 0; kk < M; kk++) { id2[kk] = xr(QU::X_ID + kk); yd2[kk] = xr(QU::X_YD + kk); }
+  double Wb[6][M];
+#pragma unroll
+  for (int j = 0; j < 6; j++) {
+    double raw[M];
+#pragma unroll
+    for (int kk = 0; kk < M; kk++) raw[kk] = pcb(CORR::sub[kk], j);
+    quad_fsub<M>(raw, Lp, Wb[j]);
+#pragma unroll
+    for (int kk = 0; kk < M; kk++) xb[j] = fma(Wb[j][kk], yd2[kk], xb[j]);
+  }
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    double raw[M], w[M];
+#pragma unroll
+    for (int kk = 0; kk < M; kk++) raw[kk] = xr(QU::X_VW + M * c + kk);
+    quad_fsub<M>(raw, Lp, w);
+#pragma unroll
+    for (int kk = 0; kk < M; kk++) xw_[c] = fma(w[kk], yd2[kk], xw_[c]);
+  }
+#pragma unroll
+  for (int j = 0; j < 6; j++) {
+    double wd[M];
+#pragma unroll
+    for (int kk = 0; kk < M; kk++) wd[kk] = Wb[j][kk] * id2[kk];
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+      double acc = pcb(i, j);
+#pragma unroll
+      for (int kk = 0; kk < M; kk++) acc = fma(-wd[kk], xr(QU::X_WC + M * i + kk), acc);
+      st(L::OFF_P + pk(core_full(9 + j), core_full(i)), acc);
+    }
+#pragma unroll
+    for (int j2 = 0; j2 <= j; j2++) {
+      double acc = Pbb[pk(j, j2)];
+#pragma unroll
+      for (int kk = 0; kk < M; kk++) acc = fma(-wd[kk], Wb[j2][kk], acc);
+      st(L::OFF_P + pk(core_full(9 + j), core_full(9 + j2)), acc);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 6; i++) st(L::OFF_VEC + 15 + i, xb[i]);
+#pragma unroll
+  for (int i = 0; i < 3; i++) st(L::OFF_VEC + i, xw_[i]);
+}
+
+template <class CORR, int J, class LD, class ST, class XW, class XR, class SYNC>
+PB_HD void quad_upd_passive(LD ld, ST st, XW xw, XR xr, SYNC sync, const CorrInputs &cin, const Consts &k)
+{
+  constexpr int NS = 21, M = CORR::M;
+  using L = Lay<NS>;
+  using QU = QuadU<CORR>;
+  double X[5][9];
+#pragma unroll
+  for (int sb = 0; sb < 5; sb++)
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+      for (int c = 0; c < 3; c++) X[sb][3 * r + c] = ld(L::OFF_P + pk(core_full(3 * sb + r), passive_full(3 * J + c)));
+  double Pjj[6];
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+#pragma unroll
+    for (int c = 0; c <= r; c++) Pjj[pk(r, c)] = ld(L::OFF_P + pk(passive_full(3 * J + r), passive_full(3 * J + c)));
+  double Paw[J == 1 ? 9 : 1];
+  double xa[3] = { 0.0, 0.0, 0.0 };
+  if constexpr (J == 1) {
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+      for (int c = 0; c < 3; c++) Paw[3 * r + c] = ld(L::OFF_P + pk(passive_full(3 + r), passive_full(c)));
+#pragma unroll
+    for (int i = 0; i < 3; i++) xa[i] = ld(L::OFF_VEC + 12 + i);
+  }
+  double x[NS], q[4] = { 1.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+  for (int i = 0; i < NS; i++) x[i] = 0.0;
+  if constexpr (J == 0) {  // role PW owns x[v chi Delta] and the quaternion
+#pragma unroll
+    for (int i = 0; i < 9; i++) x[core_full(i)] = ld(L::OFF_VEC + core_full(i));
+#pragma unroll
+    for (int i = 0; i < 4; i++) q[i] = ld(L::OFF_QUAT + i);
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+#pragma unroll
+      for (int kk = 0; kk < M; kk++) xw(QU::X_VW + M * c + kk, X[CORR::sub[kk] / 3][3 * (CORR::sub[kk] % 3) + c]);
+  }
+  sync();
+  double Lp[M * (M - 1) / 2 + 1], id2[M], yd2[M];
+#pragma unroll
+  for (int i = 0; i < M * (M - 1) / 2; i++) Lp[i] = xr(QU::X_L + i);
+#pragma unroll
+  for (int kk = 0; kk < M; kk++) { id2[kk] = xr(QU::X_ID + kk); yd2[kk] = xr(QU::X_YD + kk); }
+  double Wp[3][M];  // W_p = P[p, idx] L^-T
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    double raw[M];
+#pragma unroll
+    for (int kk = 0; kk < M; kk++) raw[kk] = X[CORR::sub[kk] / 3][3 * (CORR::sub[kk] % 3) + c];
+    quad_fsub<M>(raw, Lp, Wp[c]);
+    if constexpr (J == 1) {
+#pragma unroll
+      for (int kk = 0; kk < M; kk++) xa[c] = fma(Wp[c][kk], yd2[kk], xa[c]);
+    }
+  }
+#pragma unroll
+  for (int sb = 0; sb < 5; sb++)
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      double wd[M];
+      if (sb < 3) {  // role CC's rows of W
+#pragma unroll
+        for (int kk = 0; kk < M; kk++) wd[kk] = xr(QU::X_WC + M * (3 * sb + r) + kk) * id2[kk];
+      } else {       // W_b from role CB's raw column
+        double raw[M], w[M];
+#pragma unroll
+        for (int kk = 0; kk < M; kk++) raw[kk] = xr(QU::X_BV + M * (3 * (sb - 3) + r) + kk);
+        quad_fsub<M>(raw, Lp, w);
+#pragma unroll
+        for (int kk = 0; kk < M; kk++) wd[kk] = w[kk] * id2[kk];
+      }
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        double acc = X[sb][3 * r + c];
+#pragma unroll
+        for (int kk = 0; kk < M; kk++) acc = fma(-wd[kk], Wp[c][kk], acc);
+        st(L::OFF_P + pk(core_full(3 * sb + r), passive_full(3 * J + c)), acc);
+      }
+    }
+  double Ww[J == 1 ? 3 : 1][M];
+  if constexpr (J == 1) {
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      double raw[M];
+#pragma unroll
+      for (int kk = 0; kk < M; kk++) raw[kk] = xr(QU::X_VW + M * c + kk);
+      quad_fsub<M>(raw, Lp, Ww[c]);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 3; r++) {
+    double wd[M];
+#pragma unroll
+    for (int kk = 0; kk < M; kk++) wd[kk] = Wp[r][kk] * id2[kk];
+    if constexpr (J == 1) {
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        double acc = Paw[3 * r + c];
+#pragma unroll
+        for (int kk = 0; kk < M; kk++) acc = fma(-wd[kk], Ww[c][kk], acc);
+        st(L::OFF_P + pk(passive_full(3 + r), passive_full(c)), acc);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c <= r; c++) {
+      double acc = Pjj[pk(r, c)];
+#pragma unroll
+      for (int kk = 0; kk < M; kk++) acc = fma(-wd[kk], Wp[c][kk], acc);
+      st(L::OFF_P + pk(passive_full(3 * J + r), passive_full(3 * J + c)), acc);
+    }
+  }
+  if constexpr (J == 0) {
+    double dfull[NS];
+#pragma unroll
+    for (int i = 0; i < NS; i++) dfull[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) dfull[core_full(i)] = xr(QU::X_DX + i);
+    if (cin.upd) add_delta<NS>(x, q, dfull, k.chi_tol);
+#pragma unroll
+    for (int i = 0; i < 9; i++) st(L::OFF_VEC + core_full(i), x[core_full(i)]);
+#pragma unroll
+    for (int i = 0; i < 4; i++) st(L::OFF_QUAT + i, q[i]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 3; i++) st(L::OFF_VEC + 12 + i, xa[i]);
+  }
+}
+
 }  // namespace pb

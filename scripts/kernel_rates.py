@@ -17,7 +17,8 @@ B = 65536
 
 
 def timeit(fn, reps=50):
-    fn()
+    for _ in range(5):
+        fn()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(reps):

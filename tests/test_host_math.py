@@ -38,6 +38,15 @@ def unpack(H, ns, st):
     return st[:ns], st[ns:ns + 4], cov, st[ns + 4]
 
 
+def quat_mul(a, b):
+    """Hamilton product of [4, B] quaternion arrays (w first)."""
+    w = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3]
+    x = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2]
+    y = a[0] * b[2] + a[2] * b[0] + a[3] * b[1] - a[1] * b[3]
+    z = a[0] * b[3] + a[3] * b[0] + a[1] * b[2] - a[2] * b[1]
+    return np.stack([w, x, y, z])
+
+
 @pytest.mark.parametrize("ns", [15, 21])
 def test_structured_math_matches_dense_oracle(oracle, harness, ns):
     H = harness
@@ -170,6 +179,45 @@ def test_cooperative_roles_with_fused_correction_match_oracle(oracle, harness, n
         H.hh_step_coop_correct(ns, kind, 2 if alone else 1, P(st), C.c_long(B), B, P(imu), P(lo),
                                mask.ctypes.data_as(C.c_void_p), P(q4), C.c_double(g), C.c_double(tol), P(zz), P(Rd), P(qm),
                                mask2.ctypes.data_as(C.c_void_p))
+    v, q, cov, ll = unpack(H, ns, st)
+    assert rel(v, ob.vec[:ns]) < 1e-11 and rel(q, ob.quat) < 1e-11 and rel(cov, ob.cov[:ns, :ns]) < 1e-11
+    assert rel(ll, ob.ll) < 1e-11
+
+
+@pytest.mark.parametrize("kind", range(7))
+def test_four_wave_stand_alone_updates_match_oracle(oracle, harness, kind):
+    """rbis_quad.hpp quad_upd_*: the handlers' seven index lists as stand-alone updates on the four-wave mapping (one
+    barrier), between four-wave steps, against the oracle's indexed (+ orientation) update; masks exercised."""
+    H = harness
+    g, tol = oracle.constants()
+    ns, B, T = 21, 24, 40
+    idx = [[3, 4, 5], [9, 10, 11], [9, 10, 11, 3, 4, 5], [9, 10, 11, 6, 7, 8], [9, 10, 11, 8], [3, 4, 5, 8], [8]][kind]
+    orient = kind >= 3
+    m = len(idx)
+    w = Workload(B, n_states=ns)
+    vec, quat, P0 = w.initial_state()
+    P0 = P0 + random_spd(ns, B, 0.03, 7)
+    vec[15:18], vec[18:21] = 0.5 * w.bg, 0.5 * w.ba
+    ob = oracle.OracleBatch(vec, quat, P0)
+    st = pack(H, ns, vec, quat, P0, np.zeros(B))
+    q4 = w.process_noise()
+    rng = np.random.default_rng(kind)
+    for k in range(T):
+        imu = w.imu_block(k)
+        lo, mask = w.legodo_block(k)
+        ob.predict(imu, q4)
+        ob.update_indexed([3, 4, 5], lo[0:3], lo[3:6], mask=mask)
+        H.hh_step_quad(P(st), C.c_long(B), B, P(imu), P(lo), mask.ctypes.data_as(C.c_void_p), P(q4),
+                       C.c_double(g), C.c_double(tol), 1)
+        # a measurement near the current estimate: z = x[idx] + noise, quaternion = head * small rotation
+        zz = np.ascontiguousarray(ob.vec[idx, :] + 0.02 * rng.standard_normal((m, B)))
+        dq = np.concatenate([np.ones((1, B)), 0.01 * rng.standard_normal((3, B))])
+        qm = np.ascontiguousarray(quat_mul(ob.quat, dq / np.linalg.norm(dq, axis=0)))
+        Rd = np.ascontiguousarray(np.abs(0.01 + 0.01 * rng.standard_normal((m, B))))
+        mask2 = ((np.arange(B) + k) % 5 != 0).astype(np.uint8)
+        ob.update_indexed(idx, zz, Rd, quat_meas=qm if orient else None, mask=mask2)
+        H.hh_update_quad(kind, P(st), C.c_long(B), B, P(zz), P(Rd), P(qm), mask2.ctypes.data_as(C.c_void_p),
+                         C.c_double(g), C.c_double(tol))
     v, q, cov, ll = unpack(H, ns, st)
     assert rel(v, ob.vec[:ns]) < 1e-11 and rel(q, ob.quat) < 1e-11 and rel(cov, ob.cov[:ns, :ns]) < 1e-11
     assert rel(ll, ob.ll) < 1e-11
