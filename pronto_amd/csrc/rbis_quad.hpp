@@ -691,6 +691,19 @@ PB_HD void quad_upd_cb(LD ld, ST st, XW xw, XR xr, SYNC sync, const CorrInputs &
   for (int i = 0; i < M * (M - 1) / 2; i++) Lp[i] = xr(QU::X_L + i);
 #pragma unroll
   for (int kk = 0; kk < M; kk++) { id2[kk] = xr(QU::X_ID + kk); yd2[kk] = xr(QU::X_YD + kk); }
+#pragma unroll
+  for (int c = 0; c < 3; c++) {  // omega's share of dx: W_omega from role PW's raw columns
+    double raw[M], w[M];
+#pragma unroll
+    for (int kk = 0; kk < M; kk++) raw[kk] = xr(QU::X_VW + M * c + kk);
+    quad_fsub<M>(raw, Lp, w);
+#pragma unroll
+    for (int kk = 0; kk < M; kk++) xw_[c] = fma(w[kk], yd2[kk], xw_[c]);
+  }
+  // Six measurement rows: P_cb (108 registers), P_bb (42) and all of W_b (72) do not fit together at two waves per SIMD.
+  // Two passes then: the P_cb columns with ONE row of W_b at a time, and W_b again (its raw columns are still in this
+  // wave's own hand-off slots) for P_bb once the P_cb registers are free.
+  constexpr bool TWO_PASS = (M > 4);
   double Wb[6][M];
 #pragma unroll
   for (int j = 0; j < 6; j++) {
@@ -700,27 +713,42 @@ PB_HD void quad_upd_cb(LD ld, ST st, XW xw, XR xr, SYNC sync, const CorrInputs &
     quad_fsub<M>(raw, Lp, Wb[j]);
 #pragma unroll
     for (int kk = 0; kk < M; kk++) xb[j] = fma(Wb[j][kk], yd2[kk], xb[j]);
+    if constexpr (TWO_PASS) {
+      double wd[M];
+#pragma unroll
+      for (int kk = 0; kk < M; kk++) wd[kk] = Wb[j][kk] * id2[kk];
+#pragma unroll
+      for (int i = 0; i < 9; i++) {
+        double acc = pcb(i, j);
+#pragma unroll
+        for (int kk = 0; kk < M; kk++) acc = fma(-wd[kk], xr(QU::X_WC + M * i + kk), acc);
+        st(L::OFF_P + pk(core_full(9 + j), core_full(i)), acc);
+      }
+      reload_fence();
+    }
   }
+  if constexpr (TWO_PASS) {
 #pragma unroll
-  for (int c = 0; c < 3; c++) {
-    double raw[M], w[M];
+    for (int j = 0; j < 6; j++) {
+      double raw[M];
 #pragma unroll
-    for (int kk = 0; kk < M; kk++) raw[kk] = xr(QU::X_VW + M * c + kk);
-    quad_fsub<M>(raw, Lp, w);
-#pragma unroll
-    for (int kk = 0; kk < M; kk++) xw_[c] = fma(w[kk], yd2[kk], xw_[c]);
+      for (int kk = 0; kk < M; kk++) raw[kk] = xr(QU::X_BV + M * j + kk);
+      quad_fsub<M>(raw, Lp, Wb[j]);
+    }
   }
 #pragma unroll
   for (int j = 0; j < 6; j++) {
     double wd[M];
 #pragma unroll
     for (int kk = 0; kk < M; kk++) wd[kk] = Wb[j][kk] * id2[kk];
+    if constexpr (!TWO_PASS) {
 #pragma unroll
-    for (int i = 0; i < 9; i++) {
-      double acc = pcb(i, j);
+      for (int i = 0; i < 9; i++) {
+        double acc = pcb(i, j);
 #pragma unroll
-      for (int kk = 0; kk < M; kk++) acc = fma(-wd[kk], xr(QU::X_WC + M * i + kk), acc);
-      st(L::OFF_P + pk(core_full(9 + j), core_full(i)), acc);
+        for (int kk = 0; kk < M; kk++) acc = fma(-wd[kk], xr(QU::X_WC + M * i + kk), acc);
+        st(L::OFF_P + pk(core_full(9 + j), core_full(i)), acc);
+      }
     }
 #pragma unroll
     for (int j2 = 0; j2 <= j; j2++) {

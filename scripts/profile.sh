@@ -36,5 +36,6 @@ echo "smoother counters done"
 # ceilings and sweeps, not under the profiler
 hipcc -O3 --offload-arch=gfx950 -o /tmp/copybench scripts/copybench.hip && /tmp/copybench > $OUT/copybench.txt 2>&1
 python3 scripts/batch_sweep.py 15 21 > $OUT/batch_sweep.txt 2>&1
+bash scripts/input_footprint.sh > $OUT/n21_input_footprint.txt 2>&1
 python3 bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
 echo "profile done"

@@ -46,7 +46,7 @@ for d, name in (("trace64k", "_kernel_stats.csv"), ("trace64k_n21", "_kernel_sta
     if ks:
         shutil.copy(ks[0], os.path.join(out, tag + name))
 for name in ("trace64k.json", "trace64k_n21.json", "bench1m.json", "calib_plain.txt", "copybench.txt", "batch_sweep.txt",
-             "bench_default.json", "others.txt", "configs.txt", "smoother.txt"):
+             "bench_default.json", "others.txt", "configs.txt", "smoother.txt", "n21_input_footprint.txt"):
     p = os.path.join(src, name)
     if os.path.exists(p):
         shutil.copy(p, os.path.join(out, tag + "_" + name))
