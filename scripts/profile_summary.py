@@ -27,12 +27,20 @@ def kname(raw):
     """rocprofv3's demangled name -> what pb_hot_kernel() reports: k_step_coop<15,true,1> for the plain fused step
     (no second measurement, with predict); the other instantiations keep their full argument list."""
     n = re.sub(r"\s+", "", raw.split("(")[0].replace("void ", "").replace("pb::", ""))
-    return re.sub(r"^(k_step_coop<\d+,true,\d),Corr<false>,true>$", r"\1>", n)
+    n = re.sub(r"^(k_step_coop<\d+,true,\d),Corr<false>,true>$", r"\1>", n)
+    return re.sub(r"^(k_step_quad<(?:true|false),\d),0>$", r"\1>", n)  # (third argument: cache policy of the input loads)
+
+
+def newest(pattern):
+    """gpurun MERGES a run's output into gpurun_out/: a directory can hold the files of several runs (one pid prefix
+    each); only the newest one counts."""
+    fs = sorted(glob.glob(pattern), key=os.path.getmtime)
+    return fs[-1:] if fs else []
 
 
 def counters(d):
     by = collections.defaultdict(list)
-    for f in glob.glob(os.path.join(src, d, "*", "*counter_collection.csv")):
+    for f in newest(os.path.join(src, d, "*", "*counter_collection.csv")):
         for r in csv.DictReader(open(f)):
             name = kname(r["Kernel_Name"])
             by[(name, r["Counter_Name"])].append(float(r["Counter_Value"]))
@@ -42,7 +50,7 @@ def counters(d):
 for d, name in (("trace64k", "_kernel_stats.csv"), ("trace64k_n21", "_kernel_stats_n21.csv"),
                 ("others", "_kernel_stats_others.csv"), ("configs", "_kernel_stats_configs.csv"),
                 ("smoother", "_kernel_stats_smoother.csv")):
-    ks = glob.glob(os.path.join(src, d, "*", "*kernel_stats.csv"))
+    ks = newest(os.path.join(src, d, "*", "*kernel_stats.csv"))
     if ks:
         shutil.copy(ks[0], os.path.join(out, tag + name))
 for name in ("trace64k.json", "trace64k_n21.json", "bench1m.json", "calib_plain.txt", "copybench.txt", "batch_sweep.txt",
