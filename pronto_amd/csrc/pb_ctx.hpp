@@ -47,7 +47,6 @@ struct pb_ctx {
   bool have_state = false;
   bool coop15 = false;  // PRONTO_BATCH_COOP15=1: run the 15-state step on the two-wave cooperative kernel (A/B switch)
   int mem_hint = 0;     // MH_* cache policy of the step kernels' state round trip (PRONTO_BATCH_MEMHINT=0/1/2 forces it)
-  int input_nt = 0;  // PRONTO_BATCH_INPUT_NT=<aux bits>: cache policy of the sensor-block loads in k_step_quad (experiment)
   bool quad21 = true;   // PRONTO_BATCH_QUAD21=0: run the 21-state step on the two-wave kernel instead of the four-wave one (A/B)
   bool generic_update = false;  // PRONTO_BATCH_GENERIC_UPDATE=1: every stand-alone update on the run-time-index kernel (A/B, tests)
   bool smooth_attr = false;  // dynamic-LDS limit of the smoother kernels raised on this device

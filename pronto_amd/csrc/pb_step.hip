@@ -12,14 +12,7 @@ static void launch_step_mh(pb_ctx *c, double *out, const double *imu, const doub
   } else if (c->quad21) {
     // n = 21: 231 packed covariance entries do not fit one lane's registers; four cooperating waves per tile at two waves
     // per SIMD (rbis_quad.hpp): one launch, one state round trip.
-    // input_nt: the read-once sensor blocks are loaded non-temporal so that a long input stream does not push the state
-    // (135 MB at 64k filters) out of the 256 MB memory-side cache
-    switch (c->input_nt) {
-    case 2: k_step_quad<UPDATE, MH, 2><<<nblk(B), 256, 0, c->stream>>>(c->st, out, B, imu, lo, mask, q[0], q[1], q[2], q[3], c->k); break;
-    case 17: k_step_quad<UPDATE, MH, 17><<<nblk(B), 256, 0, c->stream>>>(c->st, out, B, imu, lo, mask, q[0], q[1], q[2], q[3], c->k); break;
-    case 19: k_step_quad<UPDATE, MH, 19><<<nblk(B), 256, 0, c->stream>>>(c->st, out, B, imu, lo, mask, q[0], q[1], q[2], q[3], c->k); break;
-    default: k_step_quad<UPDATE, MH, 0><<<nblk(B), 256, 0, c->stream>>>(c->st, out, B, imu, lo, mask, q[0], q[1], q[2], q[3], c->k); break;
-    }
+    k_step_quad<UPDATE, MH><<<nblk(B), 256, 0, c->stream>>>(c->st, out, B, imu, lo, mask, q[0], q[1], q[2], q[3], c->k);
   } else {
     // the two-wave cooperative kernel at one wave per SIMD (rbis_coop.hpp); PRONTO_BATCH_QUAD21=0
     k_step_coop<21, UPDATE, MH><<<nblk(B), 128, 0, c->stream>>>(c->st, out, B, imu, lo, mask, q[0], q[1], q[2], q[3], c->k, CorrArgs());

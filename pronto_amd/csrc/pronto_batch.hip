@@ -55,10 +55,6 @@ extern "C" int pb_create(pb_ctx **out, int n_states, int batch, int device, int 
     const long state_bytes = (long) c->state_doubles * 8;
     const char *gu = getenv("PRONTO_BATCH_GENERIC_UPDATE");
     c->generic_update = gu && gu[0] == '1';
-    const char *sg = getenv("PRONTO_BATCH_STAGGER");
-    c->k.stagger = sg ? atoi(sg) : 0;
-    const char *inn = getenv("PRONTO_BATCH_INPUT_NT");
-    c->input_nt = inn ? atoi(inn) : 0;
     const char *q21 = getenv("PRONTO_BATCH_QUAD21");
     c->quad21 = !(q21 && q21[0] == '0');
     const char *h = getenv("PRONTO_BATCH_MEMHINT");

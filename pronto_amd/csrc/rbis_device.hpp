@@ -197,9 +197,6 @@ struct Consts {
   const double *qblk = nullptr;
   // k_step_coop: 1 = give each of the 8 XCDs one contiguous filter range (workgroups are dealt round-robin to XCDs)
   int xcd_remap = 0;
-  // k_step_quad experiment (PRONTO_BATCH_STAGGER=n): the second workgroup of every CU starts n x ~0.5 us late so that the
-  // two resident workgroups are in different phases (load / arithmetic / store)
-  int stagger = 0;
 };
 
 // ------------------------------------------------------------------------------------------------------------

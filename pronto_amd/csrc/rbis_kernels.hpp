@@ -711,7 +711,7 @@ __global__ __launch_bounds__(128, 1) void k_step_coop(const double *st, double *
 // workgroups (8 waves) share a CU and one tile's loads overlap another's arithmetic and stores.  Same inputs, same
 // posterior (to rounding: the c-b coupling enters P_cc as one additive term instead of inside the row operations) and the
 // same bytes as k_step_coop<21>.  No lane returns before the barriers (see k_step_coop).
-template <bool UPDATE, int MH = MH_DEFAULT, int INA = 0>
+template <bool UPDATE, int MH = MH_DEFAULT>
 __global__ __launch_bounds__(256, 2) void k_step_quad(const double *st, double *sto, int B,
                                                       const double *__restrict__ imu, const double *__restrict__ lo,
                                                       const uint8_t *__restrict__ mask, double qg, double qa,
@@ -719,9 +719,6 @@ __global__ __launch_bounds__(256, 2) void k_step_quad(const double *st, double *
 {
   using SL = Slots<21>;
   __shared__ double xch[Quad::NXCH][64];
-  if (k.stagger > 0 && (((blockIdx.x >> 3) >> 5) & 1)) {
-    for (int i = 0; i < k.stagger; i++) __builtin_amdgcn_s_sleep(16);
-  }
   const int role = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
   const unsigned lane = threadIdx.x & 63u;
   const unsigned tile = xcd_workgroup(k);
@@ -735,12 +732,12 @@ __global__ __launch_bounds__(256, 2) void k_step_quad(const double *st, double *
     StepInputs in;
 #pragma unroll
     for (int i = 0; i < 3; i++) {
-      in.gyro[i] = ldg<INA>(ri, i * B8, bo);
-      in.accel[i] = ldg<INA>(ri, (3 + i) * B8, bo);
-      in.z[i] = (UPDATE && meas) ? ldg<INA>(rl, i * B8, bo) : 0.0;
-      in.rd[i] = (UPDATE && meas) ? ldg<INA>(rl, (3 + i) * B8, bo) : 1.0;
+      in.gyro[i] = ldg(ri, i * B8, bo);
+      in.accel[i] = ldg(ri, (3 + i) * B8, bo);
+      in.z[i] = (UPDATE && meas) ? ldg(rl, i * B8, bo) : 0.0;
+      in.rd[i] = (UPDATE && meas) ? ldg(rl, (3 + i) * B8, bo) : 1.0;
     }
-    in.dt = ldg<INA>(ri, 6u * B8, bo);
+    in.dt = ldg(ri, 6u * B8, bo);
     in.upd = UPDATE && (b < (unsigned) B) && (mask == nullptr || mask[b] != 0);
     in.qg = qg; in.qa = qa; in.qbg = qbg; in.qba = qba;
     if (k.qblk != nullptr) {  // per-filter process noise (wave-uniform branch)

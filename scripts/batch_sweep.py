@@ -18,8 +18,7 @@ ns = [int(a) for a in sys.argv[1:]] or [15, 21]
 sizes = [int(a) for a in os.environ.get("SWEEP_SIZES", "32768,65536,131072,196608,262144,524288,1048576").split(",")]
 VARIANTS = {"default": {}, "coop0": {"PRONTO_BATCH_COOP15": "0"}, "coop1": {"PRONTO_BATCH_COOP15": "1"},
             "xcd0": {"PRONTO_BATCH_XCD": "0"}, "xcd1": {"PRONTO_BATCH_XCD": "1"},
-            "quad0": {"PRONTO_BATCH_QUAD21": "0"}, "innt": {"PRONTO_BATCH_INPUT_NT": "2"}, "stag4": {"PRONTO_BATCH_STAGGER": "4"}, "stag8": {"PRONTO_BATCH_STAGGER": "8"},
-            "stag16": {"PRONTO_BATCH_STAGGER": "16"}, "mh0": {"PRONTO_BATCH_MEMHINT": "0"}, "mh1": {"PRONTO_BATCH_MEMHINT": "1"}, "mh2": {"PRONTO_BATCH_MEMHINT": "2"}}
+            "quad0": {"PRONTO_BATCH_QUAD21": "0"}, "mh0": {"PRONTO_BATCH_MEMHINT": "0"}, "mh1": {"PRONTO_BATCH_MEMHINT": "1"}, "mh2": {"PRONTO_BATCH_MEMHINT": "2"}}
 variants = os.environ.get("SWEEP_VARIANTS", "default").split(",")
 K, B0 = 16, 4096
 for n in ns:

@@ -27,8 +27,7 @@ def kname(raw):
     """rocprofv3's demangled name -> what pb_hot_kernel() reports: k_step_coop<15,true,1> for the plain fused step
     (no second measurement, with predict); the other instantiations keep their full argument list."""
     n = re.sub(r"\s+", "", raw.split("(")[0].replace("void ", "").replace("pb::", ""))
-    n = re.sub(r"^(k_step_coop<\d+,true,\d),Corr<false>,true>$", r"\1>", n)
-    return re.sub(r"^(k_step_quad<(?:true|false),\d),0>$", r"\1>", n)  # (third argument: cache policy of the input loads)
+    return re.sub(r"^(k_step_coop<\d+,true,\d),Corr<false>,true>$", r"\1>", n)
 
 
 def newest(pattern):
