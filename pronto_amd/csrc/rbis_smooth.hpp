@@ -144,22 +144,41 @@ __global__ __launch_bounds__(256, 2) void k_smooth_reg(const double *__restrict_
   // filters of a workgroup sit side by side in one tile: F x 16 contiguous bytes per row), and scatters the two
   // components of a row to their canonical places in the staging layout
   const long srow0 = (sb >> 6) * SL::TILE_DOUBLES + (sb & 63) * 2;
-  auto stage = [&](const double *src) {
-#pragma unroll 4
-    for (int r2 = sc; r2 < SL::NROW; r2 += G) {
-      const d2_t v2 = *reinterpret_cast<const d2_t *>(src + srow0 + (long) r2 * 128);
-      const int c0 = SL::T.comp_of[2 * r2], c1 = SL::T.comp_of[2 * r2 + 1];
-      U[sf * PITCH + c0] = v2.x;
-      if (c1 >= 0) U[sf * PITCH + c1] = v2.y;
+  // The three checkpoints are requested from memory up front (`issue`) and scattered into the staging layout one after
+  // the other (`commit`): the kernel is latency-bound, and with load -> scatter -> barrier per checkpoint the
+  // second and third global-load latencies were exposed one after the other.  21 states have no registers to spare
+  // (254 VGPRs): only the first two are in flight together there.
+  constexpr int NST = (SL::NROW + G - 1) / G;  // storage rows per staging thread
+  auto issue = [&](const double *src, d2_t (&v)[NST]) {
+#pragma unroll
+    for (int i = 0; i < NST; i++) {
+      const int r2 = sc + i * G;
+      v[i] = (r2 < SL::NROW) ? *reinterpret_cast<const d2_t *>(src + srow0 + (long) r2 * 128) : d2_t{ 0.0, 0.0 };
     }
   };
+  auto commit = [&](const d2_t (&v)[NST]) {
+#pragma unroll
+    for (int i = 0; i < NST; i++) {
+      const int r2 = sc + i * G;
+      if (r2 < SL::NROW) {
+        const int c0 = SL::T.comp_of[2 * r2], c1 = SL::T.comp_of[2 * r2 + 1];
+        U[sf * PITCH + c0] = v[i].x;
+        if (c1 >= 0) U[sf * PITCH + c1] = v[i].y;
+      }
+    }
+  };
+  constexpr bool PREFETCH_CUR = (NS <= 16);
+  d2_t vp[NST], vs[NST], vc[NST];
+  issue(next_pred, vp);
+  issue(next_sm, vs);
+  if constexpr (PREFETCH_CUR) issue(cur, vc);
   int poff[NS];                          // packed offsets of this lane's row
 #pragma unroll
   for (int j = 0; j < NS; j++) poff[j] = L::OFF_P + pk_rt(rr, j);
 
   // ---- 1. operands through LDS: P^- row, D = P^s - P^- (packed, LDS), residual, P_k row, prior state ----
   double am[NS], prow[NS];
-  stage(next_pred);
+  commit(vp);
   __syncthreads();
   double qp[4];
 #pragma unroll
@@ -190,7 +209,8 @@ __global__ __launch_bounds__(256, 2) void k_smooth_reg(const double *__restrict_
     dg = ((fix_g & (rr >= 15) & (rr < 18)) | (fix_a & (rr >= 18) & (rr < 21))) ? 1.0 : dg;
   }
   __syncthreads();
-  stage(next_sm);
+  commit(vs);
+  if constexpr (!PREFETCH_CUR) issue(cur, vc);
   __syncthreads();
   {
     // D = P^s - P^- with the UNCORRECTED P^- (the bias fix applies to the factorised matrix only): every lane its full
@@ -209,7 +229,7 @@ __global__ __launch_bounds__(256, 2) void k_smooth_reg(const double *__restrict_
     Rf[row ? C::RB_RES + rr : NS] = res;
   }
   __syncthreads();
-  stage(cur);
+  commit(vc);
   __syncthreads();
   double w[3], v[3], q[4];
 #pragma unroll
