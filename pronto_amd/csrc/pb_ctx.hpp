@@ -96,7 +96,8 @@ inline void update_done(pb_ctx *c, double *target)
 
 // ---- launchers defined in the other translation units ----
 // pb_step.hip: predict (update = false) or predict + leg-odometry update on the kernel pb_create picked
-int pbk_step(pb_ctx *c, bool update, const double *imu, const double *lo, const uint8_t *mask, const double q[4]);
+int pbk_step(pb_ctx *c, bool update, const double *imu, const double *lo, const uint8_t *mask, const double q[4],
+             const StepBcast *bcast = nullptr);  // bcast: one message for every filter, as kernel arguments
 int pbk_replay_fused(pb_ctx *c, int T, const double *imu, const double *lo, const uint8_t *mask, const double q[4]);
 // predict + leg-odometry update + a second (orientation) update in one state round trip; corr_kind = enum pb_corr
 int pbk_step_correct(pb_ctx *c, int corr_kind, const double *imu, const double *lo, const uint8_t *mask, const double q[4],

@@ -2,31 +2,32 @@
 #include "pb_ctx.hpp"
 
 template <bool UPDATE, int MH>
-static void launch_step_mh(pb_ctx *c, double *out, const double *imu, const double *lo, const uint8_t *mask, const double q[4])
+static void launch_step_mh(pb_ctx *c, double *out, const double *imu, const double *lo, const uint8_t *mask, const double q[4],
+                           const StepBcast &bc)
 {
   const int B = c->B;
   if (c->ns == 15 && c->coop15) {
-    k_step_coop<15, UPDATE, MH><<<nblk(B), 128, 0, c->stream>>>(c->st, out, B, imu, lo, mask, q[0], q[1], q[2], q[3], c->k, CorrArgs());
+    k_step_coop<15, UPDATE, MH><<<nblk(B), 128, 0, c->stream>>>(c->st, out, B, imu, lo, mask, q[0], q[1], q[2], q[3], c->k, CorrArgs(), bc);
   } else if (c->ns == 15) {
-    k_step<15, UPDATE, MH><<<(B + PB_STEP_BLOCK - 1) / PB_STEP_BLOCK, PB_STEP_BLOCK, 0, c->stream>>>(c->st, out, B, imu, lo, mask, q[0], q[1], q[2], q[3], c->k);
+    k_step<15, UPDATE, MH><<<(B + PB_STEP_BLOCK - 1) / PB_STEP_BLOCK, PB_STEP_BLOCK, 0, c->stream>>>(c->st, out, B, imu, lo, mask, q[0], q[1], q[2], q[3], c->k, bc);
   } else if (c->quad21) {
     // n = 21: 231 packed covariance entries do not fit one lane's registers; four cooperating waves per tile at two waves
     // per SIMD (rbis_quad.hpp): one launch, one state round trip.
-    k_step_quad<UPDATE, MH><<<nblk(B), 256, 0, c->stream>>>(c->st, out, B, imu, lo, mask, q[0], q[1], q[2], q[3], c->k);
+    k_step_quad<UPDATE, MH><<<nblk(B), 256, 0, c->stream>>>(c->st, out, B, imu, lo, mask, q[0], q[1], q[2], q[3], c->k, bc);
   } else {
     // the two-wave cooperative kernel at one wave per SIMD (rbis_coop.hpp); PRONTO_BATCH_QUAD21=0
-    k_step_coop<21, UPDATE, MH><<<nblk(B), 128, 0, c->stream>>>(c->st, out, B, imu, lo, mask, q[0], q[1], q[2], q[3], c->k, CorrArgs());
+    k_step_coop<21, UPDATE, MH><<<nblk(B), 128, 0, c->stream>>>(c->st, out, B, imu, lo, mask, q[0], q[1], q[2], q[3], c->k, CorrArgs(), bc);
   }
 }
 
 template <bool UPDATE>
-static int launch_step(pb_ctx *c, const double *imu, const double *lo, const uint8_t *mask, const double q[4])
+static int launch_step(pb_ctx *c, const double *imu, const double *lo, const uint8_t *mask, const double q[4], const StepBcast &bc)
 {
   double *out = update_target(c);
   switch (c->mem_hint) {  // cache policy of the state round trip, chosen in pb_create from the state size
-  case MH_STORE_SC1: launch_step_mh<UPDATE, MH_STORE_SC1>(c, out, imu, lo, mask, q); break;
-  case MH_STREAM_NT: launch_step_mh<UPDATE, MH_STREAM_NT>(c, out, imu, lo, mask, q); break;
-  default: launch_step_mh<UPDATE, MH_DEFAULT>(c, out, imu, lo, mask, q); break;
+  case MH_STORE_SC1: launch_step_mh<UPDATE, MH_STORE_SC1>(c, out, imu, lo, mask, q, bc); break;
+  case MH_STREAM_NT: launch_step_mh<UPDATE, MH_STREAM_NT>(c, out, imu, lo, mask, q, bc); break;
+  default: launch_step_mh<UPDATE, MH_DEFAULT>(c, out, imu, lo, mask, q, bc); break;
   }
   LAUNCHCHK(c);
   update_done(c, out);
@@ -34,9 +35,11 @@ static int launch_step(pb_ctx *c, const double *imu, const double *lo, const uin
 }
 
 
-int pbk_step(pb_ctx *c, bool update, const double *imu, const double *lo, const uint8_t *mask, const double q[4])
+int pbk_step(pb_ctx *c, bool update, const double *imu, const double *lo, const uint8_t *mask, const double q[4],
+             const StepBcast *bcast)
 {
-  return update ? launch_step<true>(c, imu, lo, mask, q) : launch_step<false>(c, imu, nullptr, nullptr, q);
+  const StepBcast bc = bcast ? *bcast : StepBcast();
+  return update ? launch_step<true>(c, imu, lo, mask, q, bc) : launch_step<false>(c, imu, nullptr, nullptr, q, bc);
 }
 
 int pbk_replay_fused(pb_ctx *c, int T, const double *imu, const double *lo, const uint8_t *mask, const double q[4])

@@ -351,6 +351,12 @@ extern "C" int pb_predict(pb_ctx *c, const double *imu_block, const double q[4],
   ENTER(c);
   NEED_STATE(c);
   if (!imu_block || !q) return fail(c, PB_ERR_ARG, "pb_predict: NULL input");
+  if (mem == PB_HOST_BROADCAST) {  // one message for every filter: the 7 values are kernel arguments
+    StepBcast bc;
+    memcpy(bc.imu, imu_block, sizeof(bc.imu));
+    bc.on = 1;
+    return pbk_step(c, false, nullptr, nullptr, nullptr, q, &bc);
+  }
   Part p[1] = { { imu_block, sizeof(double) * 7 * c->B, 0 } };
   int rc = stage_in(c, mem, p, 1);
   if (rc) return rc;
@@ -363,6 +369,16 @@ extern "C" int pb_step_legodo(pb_ctx *c, const double *imu_block, const double *
   ENTER(c);
   NEED_STATE(c);
   if (!imu_block || !lo_block || !q) return fail(c, PB_ERR_ARG, "pb_step_legodo: NULL input");
+  if (mem == PB_HOST_BROADCAST) {
+    // one message for every filter (a parameter sweep replaying one robot's log): the 13 values are kernel arguments --
+    // no device block, no fill launch, no input traffic.  A mask cannot be broadcast.
+    if (mask) return fail(c, PB_ERR_ARG, "PB_HOST_BROADCAST: a mask cannot be broadcast (pass mask = NULL)");
+    StepBcast bc;
+    memcpy(bc.imu, imu_block, sizeof(bc.imu));
+    memcpy(bc.lo, lo_block, sizeof(bc.lo));
+    bc.on = 1;
+    return pbk_step(c, true, nullptr, nullptr, nullptr, q, &bc);
+  }
   Part p[3] = { { imu_block, sizeof(double) * 7 * c->B, 0 }, { lo_block, sizeof(double) * 6 * c->B, 0 },
                 { mask, (size_t) c->B, 0 } };
   int rc = stage_in(c, mem, p, 3);

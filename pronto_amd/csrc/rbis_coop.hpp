@@ -93,6 +93,14 @@ PB_HD void mat_mul_acc(const double (&A)[9], const double (&X)[9], double (&Y)[9
       Y[3 * r + c] += A[3 * r] * X[c] + A[3 * r + 1] * X[3 + c] + A[3 * r + 2] * X[6 + c];
 }
 
+// One robot's IMU (+ leg-odometry) message for EVERY filter of the batch (a parameter sweep replaying one log,
+// PB_HOST_BROADCAST): the 13 values travel as a kernel argument -- no device block, no fill launch, no input traffic.
+struct StepBcast {
+  double imu[7] = { 0, 0, 0, 0, 0, 0, 0 };
+  double lo[6] = { 0, 0, 0, 1, 1, 1 };
+  int on = 0;
+};
+
 struct StepInputs {
   double gyro[3], accel[3], dt;
   double z[3], rd[3];

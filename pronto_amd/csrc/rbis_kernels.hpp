@@ -174,7 +174,7 @@ template <int NS, bool UPDATE, int MH = MH_DEFAULT>
 __global__ __launch_bounds__(PB_STEP_BLOCK, 1) void k_step(const double *st, double *sto, int B,
                                                 const double *__restrict__ imu, const double *__restrict__ lo,
                                                 const uint8_t *__restrict__ mask, double qg, double qa, double qbg,
-                                                double qba, Consts k)
+                                                double qba, Consts k, StepBcast bc)
 {
   using L = Lay<NS>;
   const unsigned tile = xcd_workgroup(k);
@@ -186,22 +186,22 @@ __global__ __launch_bounds__(PB_STEP_BLOCK, 1) void k_step(const double *st, dou
   const rsrc_t rl = mkbuf(lo, UPDATE ? 6u * B8 : 0u);
   // the sensor blocks are requested FIRST: they are the only loads of the step that are never cache-resident (a new block
   // every message) and returns are in order per wave (k_step_quad: 43.5 -> 39.8 us at 64k x 21 states with long streams)
-  double gyro[3], accel[3];
-#pragma unroll
-  for (int i = 0; i < 3; i++) {
-    gyro[i] = ldg(ri, i * B8, bo);
-    accel[i] = ldg(ri, (3 + i) * B8, bo);
-  }
-  const double dt = ldg(ri, 6u * B8, bo);
-  double z[3], rd[3];
+  double gyro[3], accel[3], dt, z[3], rd[3];
   bool upd = false;
-  if constexpr (UPDATE) {
-    upd = (mask == nullptr) || (mask[b] != 0);
+  if constexpr (UPDATE) upd = (mask == nullptr) || (mask[b] != 0);
+  if (bc.on) {  // one message for every filter: kernel arguments (wave-uniform branch)
+#pragma unroll
+    for (int i = 0; i < 3; i++) { gyro[i] = bc.imu[i]; accel[i] = bc.imu[3 + i]; z[i] = bc.lo[i]; rd[i] = bc.lo[3 + i]; }
+    dt = bc.imu[6];
+  } else {
 #pragma unroll
     for (int i = 0; i < 3; i++) {
-      z[i] = ldg(rl, i * B8, bo);
-      rd[i] = ldg(rl, (3 + i) * B8, bo);
+      gyro[i] = ldg(ri, i * B8, bo);
+      accel[i] = ldg(ri, (3 + i) * B8, bo);
+      z[i] = UPDATE ? ldg(rl, i * B8, bo) : 0.0;
+      rd[i] = UPDATE ? ldg(rl, (3 + i) * B8, bo) : 1.0;
     }
+    dt = ldg(ri, 6u * B8, bo);
   }
   if (k.qblk != nullptr) {  // per-filter process noise (wave-uniform branch)
     const rsrc_t rq = mkbuf(k.qblk, 4u * B8);
@@ -653,7 +653,7 @@ template <int NS, bool UPDATE, int MH = MH_DEFAULT, class CORR = NoCorr, bool PR
 __global__ __launch_bounds__(128, 1) void k_step_coop(const double *st, double *sto, int B,
                                                       const double *__restrict__ imu, const double *__restrict__ lo,
                                                       const uint8_t *__restrict__ mask, double qg, double qa,
-                                                      double qbg, double qba, Consts k, CorrArgs ca)
+                                                      double qbg, double qba, Consts k, CorrArgs ca, StepBcast bc = StepBcast())
 {
   using C = Coop<NS>;
   __shared__ double xch[(UPDATE || CORR::M > 0) ? CoopX<NS, CORR>::NXCH : 1][64];
@@ -666,14 +666,20 @@ __global__ __launch_bounds__(128, 1) void k_step_coop(const double *st, double *
   const rsrc_t ri = mkbuf(imu, PREDICT ? 7u * B8 : 0u);
   const rsrc_t rl = mkbuf(lo, UPDATE ? 6u * B8 : 0u);
   StepInputs in;
+  if (PREDICT && bc.on) {  // one message for every filter: kernel arguments (wave-uniform branch)
 #pragma unroll
-  for (int i = 0; i < 3; i++) {
-    in.gyro[i] = PREDICT ? ldg(ri, i * B8, bo) : 0.0;
-    in.accel[i] = PREDICT ? ldg(ri, (3 + i) * B8, bo) : 0.0;
-    in.z[i] = UPDATE ? ldg(rl, i * B8, bo) : 0.0;
-    in.rd[i] = UPDATE ? ldg(rl, (3 + i) * B8, bo) : 1.0;
+    for (int i = 0; i < 3; i++) { in.gyro[i] = bc.imu[i]; in.accel[i] = bc.imu[3 + i]; in.z[i] = bc.lo[i]; in.rd[i] = bc.lo[3 + i]; }
+    in.dt = bc.imu[6];
+  } else {
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      in.gyro[i] = PREDICT ? ldg(ri, i * B8, bo) : 0.0;
+      in.accel[i] = PREDICT ? ldg(ri, (3 + i) * B8, bo) : 0.0;
+      in.z[i] = UPDATE ? ldg(rl, i * B8, bo) : 0.0;
+      in.rd[i] = UPDATE ? ldg(rl, (3 + i) * B8, bo) : 1.0;
+    }
+    in.dt = PREDICT ? ldg(ri, 6u * B8, bo) : 0.0;
   }
-  in.dt = PREDICT ? ldg(ri, 6u * B8, bo) : 0.0;
   in.upd = UPDATE && (b < (unsigned) B) && (mask == nullptr || mask[b] != 0);
   in.qg = qg; in.qa = qa; in.qbg = qbg; in.qba = qba;
   if (PREDICT && k.qblk != nullptr) {  // per-filter process noise (wave-uniform branch)
@@ -715,7 +721,7 @@ template <bool UPDATE, int MH = MH_DEFAULT>
 __global__ __launch_bounds__(256, 2) void k_step_quad(const double *st, double *sto, int B,
                                                       const double *__restrict__ imu, const double *__restrict__ lo,
                                                       const uint8_t *__restrict__ mask, double qg, double qa,
-                                                      double qbg, double qba, Consts k)
+                                                      double qbg, double qba, Consts k, StepBcast bc)
 {
   using SL = Slots<21>;
   __shared__ double xch[Quad::NXCH][64];
@@ -730,14 +736,20 @@ __global__ __launch_bounds__(256, 2) void k_step_quad(const double *st, double *
     const rsrc_t ri = mkbuf(imu, 7u * B8);
     const rsrc_t rl = mkbuf(lo, UPDATE ? 6u * B8 : 0u);
     StepInputs in;
+    if (bc.on) {  // one message for every filter: kernel arguments (wave-uniform branch)
 #pragma unroll
-    for (int i = 0; i < 3; i++) {
-      in.gyro[i] = ldg(ri, i * B8, bo);
-      in.accel[i] = ldg(ri, (3 + i) * B8, bo);
-      in.z[i] = (UPDATE && meas) ? ldg(rl, i * B8, bo) : 0.0;
-      in.rd[i] = (UPDATE && meas) ? ldg(rl, (3 + i) * B8, bo) : 1.0;
+      for (int i = 0; i < 3; i++) { in.gyro[i] = bc.imu[i]; in.accel[i] = bc.imu[3 + i]; in.z[i] = bc.lo[i]; in.rd[i] = bc.lo[3 + i]; }
+      in.dt = bc.imu[6];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 3; i++) {
+        in.gyro[i] = ldg(ri, i * B8, bo);
+        in.accel[i] = ldg(ri, (3 + i) * B8, bo);
+        in.z[i] = (UPDATE && meas) ? ldg(rl, i * B8, bo) : 0.0;
+        in.rd[i] = (UPDATE && meas) ? ldg(rl, (3 + i) * B8, bo) : 1.0;
+      }
+      in.dt = ldg(ri, 6u * B8, bo);
     }
-    in.dt = ldg(ri, 6u * B8, bo);
     in.upd = UPDATE && (b < (unsigned) B) && (mask == nullptr || mask[b] != 0);
     in.qg = qg; in.qa = qa; in.qbg = qbg; in.qba = qba;
     if (k.qblk != nullptr) {  // per-filter process noise (wave-uniform branch)

@@ -29,7 +29,7 @@ print("PCIe-inclusive: %d filters x %d steps from pageable host blocks: %.3e ste
       % (B, T - 10, B * (T - 10) / dt, dt / (T - 10) * 1e3, 105 * B * (T - 10) / dt / 1e9))
 
 # the same loop when ONE robot's stream feeds every filter (parameter sweep, LogPlayer): PB_HOST_BROADCAST blocks of
-# [7] + [6] values, expanded on the device -- no batch-sized PCIe traffic, one small fill launch per block
+# [7] + [6] values that travel as kernel arguments -- no device block, no fill launch, no input traffic
 est.reset(vec, quat, P0)
 imu1 = np.ascontiguousarray(imu[:, :, 0])
 lo1 = np.ascontiguousarray(lo[:, :, 0])
