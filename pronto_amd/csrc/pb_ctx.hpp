@@ -101,7 +101,8 @@ int pbk_step(pb_ctx *c, bool update, const double *imu, const double *lo, const 
 int pbk_replay_fused(pb_ctx *c, int T, const double *imu, const double *lo, const uint8_t *mask, const double q[4]);
 // predict + leg-odometry update + a second (orientation) update in one state round trip; corr_kind = enum pb_corr
 int pbk_step_correct(pb_ctx *c, int corr_kind, const double *imu, const double *lo, const uint8_t *mask, const double q[4],
-                     const double *z2, const double *r2, const double *rb2, const double *qm2, const uint8_t *mask2);
+                     const double *z2, const double *r2, const double *rb2, const double *qm2, const uint8_t *mask2,
+                     const StepBcast *bcast = nullptr, const double *zb = nullptr, const double *qb = nullptr);
 // pb_update15.hip / pb_update21.hip: generic indexed (+ orientation, qm != NULL) update, m = 1..6
 int pbk_update15(pb_ctx *c, int m, const int *idx, const double *z, const double *R, int rkind, const double *rb,
                  const double *qm, const uint8_t *mask);
@@ -109,7 +110,8 @@ int pbk_update21(pb_ctx *c, int m, const int *idx, const double *z, const double
                  const double *qm, const uint8_t *mask);
 // pb_update_ct.hip: the same update on the cooperative mapping when idx is one of the handlers' lists and R is diagonal
 // (r2 = [m][B] device diagonal or NULL with rb2 = m broadcast values); -1 = no such kernel, use pbk_update15/21
+// zb / qb: HOST values of a measurement that is the same for every filter (kernel arguments instead of device blocks)
 int pbk_update_ct(pb_ctx *c, int m, const int *idx, const double *z, const double *r2, const double *rb2, const double *qm,
-                  const uint8_t *mask);
+                  const uint8_t *mask, const double *zb = nullptr, const double *qb = nullptr);
 // pb_smooth.hip
 int pbk_smooth_step(pb_ctx *c, const double *next_pred, const double *next_sm, const double *cur, double *out, double dt);

@@ -59,46 +59,54 @@ int pbk_replay_fused(pb_ctx *c, int T, const double *imu, const double *lo, cons
 // predict + leg-odometry update + one more (orientation) update in ONE state round trip on the cooperative kernel
 template <int NS, int MH, class CORR>
 static void launch_corr(pb_ctx *c, double *out, const double *imu, const double *lo, const uint8_t *mask, const double q[4],
-                        const CorrArgs &ca)
+                        const CorrArgs &ca, const StepBcast &bc)
 {
-  k_step_coop<NS, true, MH, CORR><<<nblk(c->B), 128, 0, c->stream>>>(c->st, out, c->B, imu, lo, mask, q[0], q[1], q[2], q[3], c->k, ca);
+  k_step_coop<NS, true, MH, CORR><<<nblk(c->B), 128, 0, c->stream>>>(c->st, out, c->B, imu, lo, mask, q[0], q[1], q[2], q[3], c->k, ca, bc);
 }
 template <int NS, class CORR>
 static void launch_corr_mh(pb_ctx *c, double *out, const double *imu, const double *lo, const uint8_t *mask, const double q[4],
-                           const CorrArgs &ca)
+                           const CorrArgs &ca, const StepBcast &bc)
 {
   switch (c->mem_hint) {
-  case MH_STORE_SC1: launch_corr<NS, MH_STORE_SC1, CORR>(c, out, imu, lo, mask, q, ca); break;
-  case MH_STREAM_NT: launch_corr<NS, MH_STREAM_NT, CORR>(c, out, imu, lo, mask, q, ca); break;
-  default: launch_corr<NS, MH_DEFAULT, CORR>(c, out, imu, lo, mask, q, ca); break;
+  case MH_STORE_SC1: launch_corr<NS, MH_STORE_SC1, CORR>(c, out, imu, lo, mask, q, ca, bc); break;
+  case MH_STREAM_NT: launch_corr<NS, MH_STREAM_NT, CORR>(c, out, imu, lo, mask, q, ca, bc); break;
+  default: launch_corr<NS, MH_DEFAULT, CORR>(c, out, imu, lo, mask, q, ca, bc); break;
   }
 }
 
 int pbk_step_correct(pb_ctx *c, int corr_kind, const double *imu, const double *lo, const uint8_t *mask, const double q[4],
-                     const double *z2, const double *r2, const double *rb2, const double *qm2, const uint8_t *mask2)
+                     const double *z2, const double *r2, const double *rb2, const double *qm2, const uint8_t *mask2,
+                     const StepBcast *bcast, const double *zb, const double *qb)
 {
   if (c->ns == 21) {
     // 21 states: role C's 15 x 15 sub-matrix already fills the register file (256 VGPR + 242 AGPR for the plain step); a
     // second update stage in the same kernel spills 550-690 bytes per lane and measured SLOWER than two launches.  Same
     // arithmetic as two launches: the fused step, then the correction alone on the cooperative update kernel.
-    int rc = pbk_step(c, true, imu, lo, mask, q);
+    int rc = pbk_step(c, true, imu, lo, mask, q, bcast);
     if (rc) return rc;
     static const int idx_po[6] = { 9, 10, 11, 6, 7, 8 }, idx_py[4] = { 9, 10, 11, 8 };
     const int m2 = (corr_kind == PB_CORR_POS_ORIENT) ? 6 : 4;
     const int *idx2 = (corr_kind == PB_CORR_POS_ORIENT) ? idx_po : idx_py;
     const int slot = pb_head_slot(c);  // a checkpointed step: the correction lands in the same slot
     if (slot >= 0) c->out_slot = slot;
-    rc = pbk_update_ct(c, m2, idx2, z2, r2, rb2, qm2, mask2);
+    rc = pbk_update_ct(c, m2, idx2, z2, r2, rb2, qm2, mask2, zb, qb);
     if (rc >= 0) return rc;
     return pbk_update21(c, m2, idx2, z2, r2 ? r2 : rb2, r2 ? PB_R_DIAG : PB_R_DIAG_BROADCAST, r2 ? nullptr : rb2, qm2, mask2);
   }
   CorrArgs ca;
   ca.z2 = z2; ca.r2 = r2; ca.qm2 = qm2; ca.mask2 = mask2;
+  const int m2 = (corr_kind == PB_CORR_POS_ORIENT) ? 6 : 4;
   if (rb2)
-    for (int i = 0; i < 6; i++) ca.rb2[i] = rb2[i];
+    for (int i = 0; i < m2; i++) ca.rb2[i] = rb2[i];
+  if (zb) {  // one correction for every filter: kernel arguments
+    ca.zbc = 1;
+    for (int i = 0; i < m2; i++) ca.zb2[i] = zb[i];
+    for (int i = 0; i < 4; i++) ca.qb2[i] = qb[i];
+  }
+  const StepBcast bc = bcast ? *bcast : StepBcast();
   double *out = update_target(c);
-  if (corr_kind == PB_CORR_POS_ORIENT) launch_corr_mh<15, CorrPosOrient>(c, out, imu, lo, mask, q, ca);
-  else launch_corr_mh<15, CorrPosYaw>(c, out, imu, lo, mask, q, ca);
+  if (corr_kind == PB_CORR_POS_ORIENT) launch_corr_mh<15, CorrPosOrient>(c, out, imu, lo, mask, q, ca, bc);
+  else launch_corr_mh<15, CorrPosYaw>(c, out, imu, lo, mask, q, ca, bc);
   LAUNCHCHK(c);
   update_done(c, out);
   return PB_OK;

@@ -45,13 +45,19 @@ static bool same(const int *idx, int m, std::initializer_list<int> l)
 
 // returns PB_OK after a launch, -1 when this (idx, R kind, orientation) combination has no compile-time kernel
 int pbk_update_ct(pb_ctx *c, int m, const int *idx, const double *z, const double *r2, const double *rb2, const double *qm,
-                  const uint8_t *mask)
+                  const uint8_t *mask, const double *zb, const double *qb)
 {
   CorrArgs ca;
   ca.z2 = z; ca.r2 = r2; ca.qm2 = qm; ca.mask2 = mask;
   if (rb2)
     for (int i = 0; i < m; i++) ca.rb2[i] = rb2[i];
-  const bool orient = qm != nullptr;
+  if (zb) {  // one measurement for every filter: host values as kernel arguments
+    ca.zbc = 1;
+    for (int i = 0; i < m; i++) ca.zb2[i] = zb[i];
+    if (qb)
+      for (int i = 0; i < 4; i++) ca.qb2[i] = qb[i];
+  }
+  const bool orient = qm != nullptr || qb != nullptr;
   int which = -1;
   if (same(idx, m, { 3, 4, 5 })) which = 0;
   else if (same(idx, m, { 9, 10, 11 })) which = 1;

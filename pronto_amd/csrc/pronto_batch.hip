@@ -399,6 +399,14 @@ extern "C" int pb_step_legodo_correct(pb_ctx *c, const double *imu_block, const 
   const int m2 = (corr_kind == PB_CORR_POS_ORIENT) ? 6 : 4;
   const size_t B = (size_t) c->B;
   const bool rbc = r_kind2 == PB_R_DIAG_BROADCAST;
+  if (mem == PB_HOST_BROADCAST && mem2 == PB_HOST_BROADCAST && rbc && !mask && !mask2) {
+    // one robot's three messages for every filter: everything travels as kernel arguments
+    StepBcast bc;
+    memcpy(bc.imu, imu_block, sizeof(bc.imu));
+    memcpy(bc.lo, lo_block, sizeof(bc.lo));
+    bc.on = 1;
+    return pbk_step_correct(c, corr_kind, nullptr, nullptr, nullptr, q, nullptr, nullptr, R2, nullptr, nullptr, &bc, z2, quat_meas2);
+  }
   Part p[7] = { { imu_block, sizeof(double) * 7 * B, 0 }, { lo_block, sizeof(double) * 6 * B, 0 }, { mask, B, 0 },
                 { z2, sizeof(double) * m2 * B, 0 }, { rbc ? nullptr : R2, rbc ? 0 : sizeof(double) * m2 * B, 0 },
                 { quat_meas2, sizeof(double) * 4 * B, 0 }, { mask2, B, 0 } };
@@ -509,9 +517,15 @@ static int update_common(pb_ctx *c, int m, const int *idx, const double *z, cons
   else if (rkind == PB_R_DIAG) rbytes = sizeof(double) * m * B;
   else if (rkind == PB_R_FULL) rbytes = sizeof(double) * m * m * B;
   else return fail(c, PB_ERR_ARG, "update: bad r_kind %d", rkind);
+  int rc;
+  if (mem == PB_HOST_BROADCAST && rb && !mask && !c->generic_update) {
+    // one measurement for every filter on a compile-time-index kernel: z, R and the quaternion are kernel arguments
+    rc = pbk_update_ct(c, m, idx, nullptr, nullptr, rb, nullptr, nullptr, z, orient ? qm : nullptr);
+    if (rc >= 0) return rc;
+  }
   Part p[4] = { { z, sizeof(double) * m * B, 0 }, { rb ? nullptr : R, rbytes, 0 },
                 { orient ? qm : nullptr, sizeof(double) * 4 * B, 0 }, { mask, B, 0 } };
-  int rc = stage_in(c, mem, p, 4);
+  rc = stage_in(c, mem, p, 4);
   if (rc) return rc;
   // the handlers' own index lists with a diagonal R run on the cooperative two-role kernel (no column gather);
   // PRONTO_BATCH_GENERIC_UPDATE=1 forces the run-time-index kernel for A/B runs and tests

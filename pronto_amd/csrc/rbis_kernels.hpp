@@ -648,6 +648,9 @@ struct CorrArgs {
   const double *z2 = nullptr, *r2 = nullptr, *qm2 = nullptr;
   const uint8_t *mask2 = nullptr;
   double rb2[6] = { 0, 0, 0, 0, 0, 0 };
+  // zbc: ONE measurement for every filter (PB_HOST_BROADCAST): z and the quaternion travel as kernel arguments too
+  double zb2[6] = { 0, 0, 0, 0, 0, 0 }, qb2[4] = { 1, 0, 0, 0 };
+  int zbc = 0;
 };
 template <int NS, bool UPDATE, int MH = MH_DEFAULT, class CORR = NoCorr, bool PREDICT = true>
 __global__ __launch_bounds__(128, 1) void k_step_coop(const double *st, double *sto, int B,
@@ -693,11 +696,11 @@ __global__ __launch_bounds__(128, 1) void k_step_coop(const double *st, double *
     const rsrc_t rq2 = mkbuf(ca.qm2, CORR::ORIENT ? 4u * B8 : 0u);
 #pragma unroll
     for (int i = 0; i < CORR::M; i++) {
-      cin.z[i] = ldg(rz, i * B8, bo);
+      cin.z[i] = ca.zbc ? ca.zb2[i] : ldg(rz, i * B8, bo);
       cin.rd[i] = ca.r2 ? ldg(rr, i * B8, bo) : ca.rb2[i];
     }
 #pragma unroll
-    for (int i = 0; i < 4; i++) cin.qm[i] = CORR::ORIENT ? ldg(rq2, i * B8, bo) : 0.0;
+    for (int i = 0; i < 4; i++) cin.qm[i] = CORR::ORIENT ? (ca.zbc ? ca.qb2[i] : ldg(rq2, i * B8, bo)) : 0.0;
     cin.upd = (b < (unsigned) B) && (ca.mask2 == nullptr || ca.mask2[b] != 0);
   }
   auto ld = [&io](int comp) { return io.ld(comp); };
@@ -804,11 +807,11 @@ __global__ __launch_bounds__(256, 2) void k_update_quad(const double *st, double
     const rsrc_t rq2 = mkbuf(ca.qm2, CORR::ORIENT ? 4u * B8 : 0u);
 #pragma unroll
     for (int i = 0; i < CORR::M; i++) {
-      cin.z[i] = meas ? ldg(rz, i * B8, bo) : 0.0;
+      cin.z[i] = meas ? (ca.zbc ? ca.zb2[i] : ldg(rz, i * B8, bo)) : 0.0;
       cin.rd[i] = meas ? (ca.r2 ? ldg(rr, i * B8, bo) : ca.rb2[i]) : 1.0;
     }
 #pragma unroll
-    for (int i = 0; i < 4; i++) cin.qm[i] = (CORR::ORIENT && meas) ? ldg(rq2, i * B8, bo) : 0.0;
+    for (int i = 0; i < 4; i++) cin.qm[i] = (CORR::ORIENT && meas) ? (ca.zbc ? ca.qb2[i] : ldg(rq2, i * B8, bo)) : 0.0;
     cin.upd = (b < (unsigned) B) && (ca.mask2 == nullptr || ca.mask2[b] != 0);
     return cin;
   };

@@ -581,6 +581,14 @@ def test_broadcast_inputs_equal_replicated_blocks(pa, oracle, n):
                 e.snapshot(0)
                 outs.append((zo.cpu().numpy(), qo.cpu().numpy()))
             assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+        if k % 6 == 5:   # IMU + leg odometry + scan-match / VO correction in one call, every block broadcast
+            from pronto_amd import _lib
+            kind, m = (_lib.PB_CORR_POS_YAW, 4) if k % 12 == 5 else (_lib.PB_CORR_POS_ORIENT, 6)
+            zc = 0.1 * rng.standard_normal(m)
+            qc = np.array([0.995, 0.01, -0.02, 0.09]); qc /= np.linalg.norm(qc)
+            Rc = [0.0025] * 3 + [3e-4] * (m - 3)
+            rep.step_legodo_correct(tile(imu), tile(lo), None, q4, kind, tile(zc), Rc, tile(qc))
+            bc.step_legodo_correct(imu, lo, None, q4, kind, zc, Rc, qc)
         if k % 10 == 9:  # scan-match style: broadcast z and quat_meas, broadcast diagonal R
             z4 = np.concatenate([0.1 * rng.standard_normal(3), [0.0]])
             qm = np.array([0.99, 0.0, 0.0, 0.14]); qm /= np.linalg.norm(qm)
