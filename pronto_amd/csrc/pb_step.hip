@@ -50,6 +50,10 @@ int pbk_replay_fused(pb_ctx *c, int T, const double *imu, const double *lo, cons
     k_replay_fused<15><<<nblk(c->B), 64, 0, c->stream>>>(c->st, c->B, T, imu, lo, mask, q[0], q[1], q[2], q[3], c->k);
   else if (c->ns == 15)
     k_replay_coop<15><<<nblk(c->B), 128, 0, c->stream>>>(c->st, c->B, T, imu, lo, mask, q[0], q[1], q[2], q[3], c->k);
+  else if (c->quad21)
+    // four waves per tile, register budget of ONE wave per SIMD: 3.3e9 steps/s at 64k filters, T = 32; cut for two waves
+    // per SIMD it carries 452 B of scratch and measured 2.4e9; the two-wave kernel below 1.7e9
+    k_replay_quad<1><<<nblk(c->B), 256, 0, c->stream>>>(c->st, c->B, T, imu, lo, mask, q[0], q[1], q[2], q[3], c->k);
   else
     k_replay_coop<21><<<nblk(c->B), 128, 0, c->stream>>>(c->st, c->B, T, imu, lo, mask, q[0], q[1], q[2], q[3], c->k);
   LAUNCHCHK(c);

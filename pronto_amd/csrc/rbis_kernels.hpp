@@ -942,6 +942,98 @@ __global__ __launch_bounds__(128, 1) void k_replay_coop(double *st, int B, int T
   }
 }
 
+// Time-fused replay of a 21-state batch on the FOUR-wave mapping: each role keeps the components it owns (Slots<21>::QROW
+// row ranges) in ITS registers for T steps and runs the bodies of k_step_quad with loads and stores redirected to them.  Per
+// step the owners of the state vector trade it through LDS (role PW: v chi Delta quat; role CB: biases, omega; role PA:
+// accel -- every role linearises about the whole prior state), three barriers per step; the next step's sensor block is
+// requested before this step's arithmetic.  OCC = waves per SIMD the register budget is cut for (2: 256 registers per role
+// and 452 B of scratch, two workgroups per CU; 1: no scratch, one workgroup per CU: the faster one, see pb_step.hip).
+template <int OCC>
+__global__ __launch_bounds__(256, OCC) void k_replay_quad(double *st, int B, int T, const double *__restrict__ imu,
+                                                        const double *__restrict__ lo, const uint8_t *__restrict__ mask,
+                                                        double qg, double qa, double qbg, double qba, Consts k)
+{
+  constexpr int NS = 21;
+  using L = Lay<NS>;
+  using SL = Slots<NS>;
+  __shared__ double xch[Quad::NXCH][64];
+  __shared__ double xst[NS + 4][64];
+  const int role = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
+  const unsigned lane = threadIdx.x & 63u;
+  const unsigned tile = blockIdx.x;
+  const unsigned b = tile * 64u + lane;
+  const unsigned bo = b * 8u, B8 = (unsigned) B * 8u;
+  TileIO<NS, 0, 0> io(st, st, tile, lane);
+  double q4[4] = { qg, qa, qbg, qba };
+  if (k.qblk != nullptr) {
+    const rsrc_t rq = mkbuf(k.qblk, 4u * B8);
+#pragma unroll
+    for (int i = 0; i < 4; i++) q4[i] = ldg(rq, (unsigned) i * B8, bo);
+  }
+  auto sync = []() { __syncthreads(); };
+  auto xw = [lane](int s, double v) { xch[s][lane] = v; };
+  auto xrd = [lane](int s) { return xch[s][lane]; };
+  auto inputs = [&](int t, bool meas) {
+    const rsrc_t ri = mkbuf(imu + (size_t) t * 7 * B, 7u * B8);
+    const rsrc_t rl = mkbuf(lo + (size_t) t * 6 * B, 6u * B8);
+    StepInputs in;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      in.gyro[i] = ldg(ri, i * B8, bo);
+      in.accel[i] = ldg(ri, (3 + i) * B8, bo);
+      in.z[i] = meas ? ldg(rl, i * B8, bo) : 0.0;
+      in.rd[i] = meas ? ldg(rl, (3 + i) * B8, bo) : 1.0;
+    }
+    in.dt = ldg(ri, 6u * B8, bo);
+    in.upd = (b < (unsigned) B) && (mask == nullptr || mask[(size_t) t * B + b] != 0);
+    in.qg = q4[0]; in.qa = q4[1]; in.qbg = q4[2]; in.qba = q4[3];
+    return in;
+  };
+  // state-vector slots of xst: x[i] at i, quat at NS + i.  Owner of each entry in the four-wave mapping:
+  //   role 1 (CB): x[0..2] omega, x[15..20] biases;  role 2 (PW): x[3..11] v chi Delta, quat;  role 3 (PA): x[12..14] accel
+  // The four roles run SEPARATE loops (the same three barriers per iteration in each), see k_replay_coop.
+#define PB_REPLAY_QUAD_ROLE(ROLE_ID, MEAS, OWN_EXPR, BODY)                                                            \
+  {                                                                                                                   \
+    double V[L::NC];                                                                                                  \
+    io.template need<SL::QROW[ROLE_ID], SL::QROW[ROLE_ID + 1]>();                                                     \
+    static_for<SL::NSLOT>([&](auto I) {                                                                               \
+      constexpr int slot = decltype(I)::value, comp = SL::T.comp_of[slot];                                            \
+      if constexpr (comp >= 0 && slot >= SL::T.nq[ROLE_ID] - (SL::QROW[ROLE_ID + 1] - SL::QROW[ROLE_ID]) * 2 &&       \
+                    slot < SL::T.nq[ROLE_ID])                                                                         \
+        V[comp] = io.ld(comp);                                                                                        \
+    });                                                                                                               \
+    auto ld = [&V](int comp) { return V[comp]; };                                                                     \
+    auto stf = [&V](int comp, double v) { V[comp] = v; };                                                             \
+    auto own = [](int i) { return OWN_EXPR; };                                                                        \
+    StepInputs nxt = inputs(0, MEAS);                                                                                 \
+    for (int t = 0; t < T; t++) {                                                                                     \
+      const StepInputs in = nxt;                                                                                      \
+      if (t + 1 < T) nxt = inputs(t + 1, MEAS);                                                                       \
+      static_for<NS + 4>([&](auto I) {                                                                                \
+        constexpr int i = decltype(I)::value;                                                                         \
+        if (own(i)) xst[i][lane] = V[i < NS ? L::OFF_VEC + i : L::OFF_QUAT + (i - NS)];                               \
+      });                                                                                                             \
+      __syncthreads();                                                                                                \
+      static_for<NS + 4>([&](auto I) {                                                                                \
+        constexpr int i = decltype(I)::value;                                                                         \
+        if (!own(i)) V[i < NS ? L::OFF_VEC + i : L::OFF_QUAT + (i - NS)] = xst[i][lane];                              \
+      });                                                                                                             \
+      BODY;                                                                                                           \
+    }                                                                                                                 \
+    static_for<SL::NSLOT>([&](auto I) {                                                                               \
+      constexpr int slot = decltype(I)::value, comp = SL::T.comp_of[slot];                                            \
+      if constexpr (comp >= 0 && slot >= SL::T.nq[ROLE_ID] - (SL::QROW[ROLE_ID + 1] - SL::QROW[ROLE_ID]) * 2 &&       \
+                    slot < SL::T.nq[ROLE_ID])                                                                         \
+        io.st(comp, V[comp]);                                                                                         \
+    });                                                                                                               \
+  }
+  if (role == 0) PB_REPLAY_QUAD_ROLE(0, true, false, (quad_role_cc<true>(ld, stf, xw, xrd, sync, in, k)))
+  else if (role == 1) PB_REPLAY_QUAD_ROLE(1, false, (i < 3 || (i >= 15 && i < NS)), (quad_role_cb<true>(ld, stf, xw, xrd, sync, in, k)))
+  else if (role == 2) PB_REPLAY_QUAD_ROLE(2, false, ((i >= 3 && i < 12) || i >= NS), (quad_role_passive<true, 0>(ld, stf, xw, xrd, sync, in, k)))
+  else PB_REPLAY_QUAD_ROLE(3, false, (i >= 12 && i < 15), (quad_role_passive<true, 1>(ld, stf, xw, xrd, sync, in, k)))
+#undef PB_REPLAY_QUAD_ROLE
+}
+
 // PB_HOST_BROADCAST inputs: dst [rows][B] <- one value per row (pronto_batch.hip stage_in)
 struct RowVals {
   static constexpr int MAX = 36;  // the largest block of one call: a full 6 x 6 measurement covariance
