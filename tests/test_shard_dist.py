@@ -1,6 +1,9 @@
 """Multi-rank path on CPU: world_size-2 gloo (the N>1 bench path uses the same helpers over RCCL)."""
+import json
 import os
 import socket
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -105,3 +108,40 @@ def test_reduce_summaries_matches_allreduce_semantics():
 
 def test_single_process_is_identity():
     assert allreduce_summary([1.0, 2.0, 3.0, 4.0]).tolist() == [1.0, 2.0, 3.0, 4.0]
+
+
+def _bench_line(extra_env, *flags):
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "PRONTO_BENCH_REHEARSE", "PRONTO_BENCH_FORCE_DIST"):
+        env.pop(k, None)
+    env.update(extra_env)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "6", "--warmup", "2", "--min-timed-ms", "0",
+                        "--batch-per-gpu", "4096", "--no-cpu-baseline", "--no-cache-busting", *flags],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_one_card_equal_one_rank_of_twice_the_batch():
+    """The N > 1 code of bench.py on the one-GPU test box: two self-spawned ranks share GPU 0 and rendezvous over gloo
+    (PRONTO_BENCH_REHEARSE=1); their reduced summary must equal the summary of ONE rank that runs both shards as one
+    batch (the generator is counter-based: shard r is a slice of the global workload)."""
+    two = _bench_line({"PRONTO_BENCH_REHEARSE": "1"}, "--gpus", "2")
+    one = _bench_line({}, "--batch-per-gpu", "8192")
+    assert two["n_gpus"] == 2 and one["n_gpus"] == 1
+    a, b = two["summary"], one["summary"]
+    assert abs(a["sum_loglik"] - b["sum_loglik"]) <= 1e-9 * abs(b["sum_loglik"])
+    assert abs(a["checksum_abs"] - b["checksum_abs"]) <= 1e-12 * abs(b["checksum_abs"])
+    assert a["nonfinite"] == 0 and b["nonfinite"] == 0
+
+
+@pytest.mark.gpu
+def test_bench_rccl_path_with_a_single_rank():
+    """PRONTO_BENCH_FORCE_DIST=1: init_process_group("nccl") = RCCL, barrier and the summary all-reduce on the device,
+    with world size 1 -- the transport the multi-GPU run uses, as far as one card can exercise it."""
+    out = _bench_line({"PRONTO_BENCH_FORCE_DIST": "1", "MASTER_PORT": "29547"})
+    assert out["n_gpus"] == 1 and out["summary"]["nonfinite"] == 0 and out["value"] > 0
