@@ -48,8 +48,11 @@ enum pb_mem {
   PB_DEVICE = 1, /* caller's buffers are device memory, [rows][B] */
   /* host memory holding ONE value per row ([rows] doubles): the same message for every filter of the batch, the batch
    * differing in parameters / initial state only (the reference's own batch use: state-estimator/python/param_sweep.py:39-52
-   * replays one log per parameter set).  The rows are expanded on the device; nothing of batch size crosses PCIe.
-   * Accepted by pb_predict, pb_update_indexed(_orient), pb_step_legodo and pb_compose_delta; mask must be NULL. */
+   * replays one log per parameter set).  Nothing of batch size crosses PCIe: the step kernels (pb_predict,
+   * pb_step_legodo, pb_step_legodo_correct) and the handlers' index lists of pb_update_indexed(_orient) with a diagonal R
+   * take the values as kernel arguments (no device block, no input traffic); any other block is expanded on the device.
+   * Accepted by pb_predict, pb_update_indexed(_orient), pb_step_legodo(_correct), pb_legodo_update and pb_compose_delta;
+   * mask must be NULL. */
   PB_HOST_BROADCAST = 2
 };
 
