@@ -1,0 +1,136 @@
+// shim_sweep_rate.cpp -- throughput of the DROP-IN path itself: the reference's handler API (BotParam keys -> InsHandler,
+// LegOdoHandler -> FrontEnd::addSensor -> MavStateEstimator::addUpdate, pronto_amd/csrc/mav_state_est_batch.hpp) driving
+// the batched filters, not the bare C ABI.  The workload is the reference's own batch use (state-estimator/python/
+// param_sweep.py:39-52): ONE robot's recorded IMU + foot-state stream replayed into B filters that differ in their
+// initial state, every message passed once (PB_HOST_BROADCAST), leg kinematic odometry and its contact classifier run
+// per filter on the device (LegOdoHandler::processMessageFeet -> pb_legodo_update), the IMU step and the leg-odometry
+// update fused into one launch (state_estimator.fuse_ins_legodo).
+//
+//   g++ -std=c++17 -O2 -Iinclude -Ipronto_amd/csrc examples/shim_sweep_rate.cpp -Lpronto_amd/lib -lpronto_batch
+//       -Wl,-rpath,$PWD/pronto_amd/lib -o shim_sweep_rate
+//   ./shim_sweep_rate [filters=65536] [messages=2000] [n_states=15] [history_slots=0] [utime_history_span=1000000]
+//
+// Prints messages/s and filter-steps/s (one step = IMU predict + leg-odometry update of one filter).
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+#include "mav_state_est_batch.hpp"
+
+using namespace MavStateEst;
+
+static uint64_t rng_state = 0x5357454550ULL;
+static double urand()
+{
+  rng_state = rng_state * 6364136223846793005ULL + 1442695040888963407ULL;
+  return ((rng_state >> 11) + 0.5) / 9007199254740992.0;
+}
+static double nrand() { return std::sqrt(-2 * std::log(urand())) * std::cos(2 * M_PI * urand()); }
+static double ramp(double x) { return x < 0 ? 0 : (x > 0.05 ? 1.0 : x / 0.05); }
+static void euler_to_quat(double r, double p, double y, double q[4])
+{
+  const double cr = std::cos(r / 2), sr = std::sin(r / 2), cp = std::cos(p / 2), sp = std::sin(p / 2), cy = std::cos(y / 2), sy = std::sin(y / 2);
+  q[0] = cr * cp * cy + sr * sp * sy; q[1] = sr * cp * cy - cr * sp * sy; q[2] = cr * sp * cy + sr * cp * sy; q[3] = cr * cp * sy - sr * sp * cy;
+}
+
+int main(int argc, char **argv)
+{
+  const int B = argc > 1 ? std::atoi(argv[1]) : 65536;
+  const int T = argc > 2 ? std::atoi(argv[2]) : 2000;
+  const int n = argc > 3 ? std::atoi(argv[3]) : 15;
+  const std::string slots = argc > 4 ? argv[4] : "0";
+  const std::string span = argc > 5 ? argv[5] : "1000000";  // us of update history kept (update_history.cpp:28-39)
+  BotParam param;
+  param.set("state_estimator.utime_history_span", span);
+  param.set("state_estimator.history_slots", slots);
+  param.set("state_estimator.fuse_ins_legodo", "true");
+  param.set("state_estimator.ins.channel", "IMU");
+  param.set("state_estimator.ins.q_gyro", 0.5);
+  param.set("state_estimator.ins.q_accel", 0.1);
+  param.set("state_estimator.ins.q_gyro_bias", n == 21 ? 0.001 : 0.0);
+  param.set("state_estimator.ins.q_accel_bias", n == 21 ? 0.0001 : 0.0);
+  param.set("state_estimator.ins.timestep_dt", 0.002);
+  param.set("state_estimator.ins.atlas_filter", "false");
+  param.set("state_estimator.ins.accel_bias_update_online", n == 21 ? "true" : "false");
+  param.set("state_estimator.ins.gyro_bias_update_online", n == 21 ? "true" : "false");
+  param.applyOverrides("state_estimator.legodo.mode=lin_rate|state_estimator.legodo.r_xyz=0.2|state_estimator.legodo.r_vxyz=0.1|"
+                       "state_estimator.legodo.r_vang=0.3|state_estimator.legodo.r_vxyz_uncertain=0.5|state_estimator.legodo.r_vang_uncertain=0.9|"
+                       "state_estimator.legodo.schmitt_low_threshold=475|state_estimator.legodo.schmitt_high_threshold=525|"
+                       "state_estimator.legodo.schmitt_low_delay=7000|state_estimator.legodo.schmitt_high_delay=7000|"
+                       "state_estimator.legodo.filter_contact_events=true|state_estimator.legodo.zero_initial_velocity=3");
+  for (const char *s : { "ins", "legodo" }) {
+    param.set(std::string("state_estimator.") + s + ".downsample_factor", "1");
+    param.set(std::string("state_estimator.") + s + ".roll_forward_on_receive", "true");
+    param.set(std::string("state_estimator.") + s + ".utime_offset", "0");
+  }
+  // the sweep: every filter its own initial attitude and velocity
+  RBIS x0(n, B);
+  RBIM P0(n, B);
+  for (int b = 0; b < B; b++) {
+    double q[4];
+    euler_to_quat(0.05 * (urand() - 0.5), 0.05 * (urand() - 0.5), 6.0 * (urand() - 0.5), q);
+    for (int i = 0; i < 4; i++) x0.q(i, b) = q[i];
+    for (int i = 0; i < 3; i++) x0(3 + i, b) = 0.1 * nrand();
+    const double sig[21] = { 0, 0, 0, .15, .15, .15, .05, .05, .05, .5, .5, .5, 0, 0, 0, .008, .008, .008, .1, .1, .1 };
+    for (int i = 0; i < n; i++) P0(i, i, b) = sig[i] * sig[i];
+  }
+  BotTrans ins_to_body;
+  InsHandler ins_handler(&param, &ins_to_body);
+  LegOdoHandler legodo_handler(&param);
+  FrontEnd front_end(&param);
+  auto on_ins = front_end.addSensor("ins", &InsHandler::processMessage, &ins_handler);
+  auto on_feet = front_end.addSensor("legodo", &LegOdoHandler::processMessageFeet, &legodo_handler);
+  MavStateEstimator est(new RBISResetUpdate(x0, P0, RBISUpdateInterface::reset, 0), &param, 0);
+  if (est.last_status != PB_OK) { std::fprintf(stderr, "shim_sweep_rate: %s\n", pb_last_error(est.ctx)); return 1; }
+  front_end.setStateEstimator(&est);
+
+  // one robot's log: a walking gait (left / right foot poses in the body frame, vertical foot forces) and its IMU
+  std::vector<double> imu(6 * (size_t) T), feet(14 * (size_t) T), forces(2 * (size_t) T);
+  for (int k = 0; k < T; k++) {
+    const double t = (k + 1) * 0.002;
+    double ph = t / 1.1 + 0.3;
+    ph -= std::floor(ph);
+    double wl = ramp(ph) * ramp(0.6 - ph), wr = ramp(ph - 0.5) * ramp(1.1 - ph) + (ph < 0.1 ? ramp(0.1 - ph) : 0.0);
+    if (t < 0.4) wl = wr = 1.0;
+    const double sw = std::sin(2 * M_PI * ph), v[6] = { 0.2 * std::sin(0.05 * k), 0.05, -0.1 * std::cos(0.03 * k), 0.3 * nrand(), 0.3 * nrand(), 9.80665 + 0.3 * nrand() };
+    for (int i = 0; i < 6; i++) imu[6 * (size_t) k + i] = v[i];
+    double ql[4], qr[4];
+    euler_to_quat(0.02 * sw, 0.05 * sw, 0, ql);
+    euler_to_quat(-0.02 * sw, -0.05 * sw, 0, qr);
+    const double lt[3] = { 0.15 * sw, 0.11, -0.86 + 0.02 * std::fmax(0, -sw) }, rt[3] = { -0.15 * sw, -0.11, -0.86 + 0.02 * std::fmax(0, sw) };
+    double *f = &feet[14 * (size_t) k];
+    for (int i = 0; i < 3; i++) { f[i] = lt[i]; f[7 + i] = rt[i]; }
+    for (int i = 0; i < 4; i++) { f[3 + i] = ql[i]; f[10 + i] = qr[i]; }
+    forces[2 * (size_t) k] = 900 * wl + 5 * nrand();
+    forces[2 * (size_t) k + 1] = 900 * wr + 5 * nrand();
+  }
+  auto feed = [&](int k) {
+    const int64_t utime = 1000000 + (int64_t) (k + 1) * 2000;
+    msgs::ins_t im{ utime, BatchArray(&imu[6 * (size_t) k], PB_HOST_BROADCAST), BatchArray(&imu[6 * (size_t) k + 3], PB_HOST_BROADCAST) };
+    on_ins(&im);
+    msgs::foot_state_t fs{ utime, BatchArray(&feet[14 * (size_t) k], PB_HOST_BROADCAST), BatchArray(&forces[2 * (size_t) k], PB_HOST_BROADCAST) };
+    on_feet(&fs);
+  };
+  const int warm = T / 10;
+  for (int k = 0; k < warm; k++) feed(k);
+  pb_sync(est.ctx);
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int k = warm; k < T; k++) feed(k);
+  pb_sync(est.ctx);
+  const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  if (est.last_status != PB_OK) { std::fprintf(stderr, "shim_sweep_rate: %s\n", pb_last_error(est.ctx)); return 1; }
+  RBIS head;
+  RBIM cov;
+  est.getHeadState(head, cov);
+  double sum = 0;
+  bool finite = true;
+  for (int b = 0; b < B; b++)
+    for (int i = 0; i < n; i++) { sum += std::fabs(head(i, b)); finite = finite && std::isfinite(head(i, b)); }
+  std::printf("shim sweep: %d filters x %d message pairs (n=%d, history_slots=%s): %.1f us per IMU + foot-state pair, "
+              "%.3e filter-steps/s, dropped %lld, checksum %.6g %s\n", B, T - warm, n, slots.c_str(), dt / (T - warm) * 1e6,
+              (double) B * (T - warm) / dt, (long long) est.dropped_updates, sum, finite ? "finite" : "NON-FINITE");
+  return finite ? 0 : 1;
+}

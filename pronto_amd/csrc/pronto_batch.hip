@@ -764,15 +764,22 @@ extern "C" int pb_legodo_update(pb_ctx *c, int64_t utime, const double *feet, co
   if (!c->legd) return fail(c, PB_ERR_STATE, "pb_legodo_update before pb_legodo_init");
   if (!feet || !forces) return fail(c, PB_ERR_ARG, "pb_legodo_update: NULL input");
   Part p[2] = { { feet, sizeof(double) * 14 * c->B, 0 }, { forces, sizeof(double) * 2 * c->B, 0 } };
-  int rc = stage_in(c, mem, p, 2);
-  if (rc) return rc;
+  LegBcast bc;
+  if (mem == PB_HOST_BROADCAST) {  // one robot's joint state for every filter: kernel arguments, no device block
+    memcpy(bc.feet, feet, sizeof(bc.feet));
+    memcpy(bc.forces, forces, sizeof(bc.forces));
+    bc.on = 1;
+  } else {
+    int rc = stage_in(c, mem, p, 2);
+    if (rc) return rc;
+  }
   const double r2 = r_vxyz * r_vxyz, r2u = r_vxyz_uncertain * r_vxyz_uncertain;  // bot_sq (rbis_legodo_common.cpp:40-43)
   if (c->ns == 15)
     k_legodo<15><<<nblk(c->B), 64, 0, c->stream>>>(c->st, c->legd, c->legi, c->stride, c->B, utime, c->leg_par, (const double *) p[0].dev,
-                                                   (const double *) p[1].dev, zero_delta, r2, r2u, delta_out, status_out, lo_out, mask_out);
+                                                   (const double *) p[1].dev, zero_delta, r2, r2u, delta_out, status_out, lo_out, mask_out, bc);
   else
     k_legodo<21><<<nblk(c->B), 64, 0, c->stream>>>(c->st, c->legd, c->legi, c->stride, c->B, utime, c->leg_par, (const double *) p[0].dev,
-                                                   (const double *) p[1].dev, zero_delta, r2, r2u, delta_out, status_out, lo_out, mask_out);
+                                                   (const double *) p[1].dev, zero_delta, r2, r2u, delta_out, status_out, lo_out, mask_out, bc);
   LAUNCHCHK(c);
   return PB_OK;
 }

@@ -343,11 +343,20 @@ PB_HD void leg_store(const LegState &s, double *d, int64_t *iw, long stride, lon
 // rbis_legodo_update.cpp:214-229), then -- optionally -- LegOdoCommon::createMeasurement in mode lin_rate on the result
 // (rbis_legodo_common.cpp:99-107,124-129,153-156): z = delta translation / elapsed time, R = r_vxyz^2 or r_vxyz_uncertain^2
 // when status >= 0.5, no update (mask 0) when status < 0.  feet [14][B] = left (t3, q4), right (t3, q4); forces [2][B].
+// ONE robot's foot poses and forces for every filter of the batch (PB_HOST_BROADCAST: a parameter sweep over one log): the 16
+// values are kernel arguments.
+struct LegBcast {
+  double feet[14] = { 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0 }, forces[2] = { 0, 0 };
+  int on = 0;
+};
+// (launch bounds: without them the compiler budgets for 1024-thread blocks, 128 registers, and spilled 668 bytes per lane)
 template <int NS>
-static __global__ void k_legodo(const double *__restrict__ st, double *__restrict__ legd, int64_t *__restrict__ legi, long stride,
-                                int B, int64_t utime, LegPar par, const double *__restrict__ feet, const double *__restrict__ forces,
-                                int zero_delta, double r2, double r2_uncertain, double *__restrict__ delta_out,
-                                double *__restrict__ status_out, double *__restrict__ lo_out, uint8_t *__restrict__ mask_out)
+static __global__ __launch_bounds__(64, 2) void k_legodo(const double *__restrict__ st, double *__restrict__ legd,
+                                                         int64_t *__restrict__ legi, long stride, int B, int64_t utime, LegPar par,
+                                                         const double *__restrict__ feet, const double *__restrict__ forces,
+                                                         int zero_delta, double r2, double r2_uncertain,
+                                                         double *__restrict__ delta_out, double *__restrict__ status_out,
+                                                         double *__restrict__ lo_out, uint8_t *__restrict__ mask_out, LegBcast bc)
 {
   using L = Lay<NS>;
   using S = Slots<NS>;
@@ -356,12 +365,20 @@ static __global__ void k_legodo(const double *__restrict__ st, double *__restric
   LegState s;
   leg_load(s, legd, legi, stride, b);
   Pose bl, br, delta;
-  for (int i = 0; i < 3; i++) { bl.t[i] = feet[(long) i * B + b]; br.t[i] = feet[(long) (7 + i) * B + b]; }
-  for (int i = 0; i < 4; i++) { bl.q[i] = feet[(long) (3 + i) * B + b]; br.q[i] = feet[(long) (10 + i) * B + b]; }
+  double fl, fr;
+  if (bc.on) {  // wave-uniform
+    for (int i = 0; i < 3; i++) { bl.t[i] = bc.feet[i]; br.t[i] = bc.feet[7 + i]; }
+    for (int i = 0; i < 4; i++) { bl.q[i] = bc.feet[3 + i]; br.q[i] = bc.feet[10 + i]; }
+    fl = bc.forces[0]; fr = bc.forces[1];
+  } else {
+    for (int i = 0; i < 3; i++) { bl.t[i] = feet[(long) i * B + b]; br.t[i] = feet[(long) (7 + i) * B + b]; }
+    for (int i = 0; i < 4; i++) { bl.q[i] = feet[(long) (3 + i) * B + b]; br.q[i] = feet[(long) (10 + i) * B + b]; }
+    fl = forces[b]; fr = forces[(long) B + b];
+  }
   double wq[4];
   for (int i = 0; i < 4; i++) wq[i] = st[S::eidx(L::OFF_QUAT + i, b)];
   int64_t prev = 0;
-  const double status = leg_update(s, par, utime, bl, br, forces[b], forces[(long) B + b], wq, delta, prev);
+  const double status = leg_update(s, par, utime, bl, br, fl, fr, wq, delta, prev);
   leg_store(s, legd, legi, stride, b);
   if (zero_delta) pose_identity(delta);  // "Ignore the calculated velocity at launch" (rbis_legodo_update.cpp:264-268)
   if (delta_out != nullptr) {

@@ -195,3 +195,32 @@ def test_multi_gpu_sweep_example_on_the_visible_devices():
     r = subprocess.run([exe, "4096", "40", "2"], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "RCCL all-reduce" in r.stdout and "x 2 shard(s)" in r.stdout, r.stdout
+
+
+def build_shim_sweep_rate():
+    """examples/shim_sweep_rate.cpp as its header comment says."""
+    _lib.build()
+    exe = os.path.join(ROOT, "tests", "build", "shim_sweep_rate")
+    os.makedirs(os.path.dirname(exe), exist_ok=True)
+    src = os.path.join(ROOT, "examples", "shim_sweep_rate.cpp")
+    deps = (src, _lib.LIB_PATH, os.path.join(ROOT, "pronto_amd", "csrc", "mav_state_est_batch.hpp"))
+    if os.path.exists(exe) and all(os.path.getmtime(exe) >= os.path.getmtime(d) for d in deps):
+        return exe
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-I" + os.path.join(ROOT, "include"),
+                           "-I" + os.path.join(ROOT, "pronto_amd", "csrc"), src, "-L" + os.path.dirname(_lib.LIB_PATH),
+                           "-lpronto_batch", "-Wl,-rpath," + os.path.dirname(_lib.LIB_PATH), "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    return exe
+
+
+def test_shim_sweep_rate_example_compiles_and_links():
+    assert os.path.exists(build_shim_sweep_rate())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,slots", [(15, "0"), (21, "0"), (15, "8")])
+def test_shim_sweep_rate_example_runs(n, slots):
+    """The drop-in path end to end (handler API -> estimator -> kernels) with one robot's log broadcast into a sweep of
+    filters: runs, stays finite, drops nothing."""
+    r = subprocess.run([build_shim_sweep_rate(), "2048", "300", str(n), slots], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "dropped 0" in r.stdout and "finite" in r.stdout and "NON-FINITE" not in r.stdout, r.stdout
