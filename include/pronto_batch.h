@@ -134,6 +134,11 @@ int pb_update_indexed_orient(pb_ctx *ctx, int m, const int *idx, const double *z
  * lo_block [6][B] = z xyz, Rdiag xyz; mask as above. */
 int pb_step_legodo(pb_ctx *ctx, const double *imu_block, const double *lo_block, const uint8_t *mask,
                    const double q[4], int mem);
+/* The same step with the IMU block and the leg-odometry block (+ mask) living in DIFFERENT spaces, e.g. one robot's IMU
+ * message for every filter (PB_HOST_BROADCAST) and a per-filter measurement that pb_legodo_update_after_predict left on
+ * the device (PB_DEVICE).  At most one of the two may be PB_HOST. */
+int pb_step_legodo_split(pb_ctx *ctx, const double *imu_block, int imu_mem, const double *lo_block, const uint8_t *mask,
+                         int lo_mem, const double q[4]);
 
 /* The same step with ONE MORE measurement behind it, still one launch and one round trip of the state: what the
  * reference does as a third updateFilter call when a correction message follows the IMU / leg-odometry pair.
@@ -204,6 +209,14 @@ int pb_legodo_init(pb_ctx *ctx, double schmitt_low_threshold, double schmitt_hig
 int pb_legodo_update(pb_ctx *ctx, int64_t utime, const double *feet, const double *forces, int mem, int zero_delta,
                      double r_vxyz, double r_vxyz_uncertain, double *delta_out, double *status_out, double *lo_block_out,
                      uint8_t *mask_out);
+/* The same odometry, slaved to the orientation the filter WILL have after pb_predict(imu_block) -- computed from the head
+ * state on the device, covariance untouched -- so that the caller can then run that IMU step and the leg-odometry update this
+ * call produced as ONE fused kernel (pb_step_legodo_split with lo_block_out / mask_out as PB_DEVICE blocks) instead of
+ * pb_predict, pb_legodo_update, pb_update_indexed: two state round trips become one.  Results equal that three-call sequence
+ * to rounding.  imu_block: [7][B] (PB_DEVICE / PB_HOST) or [7] (PB_HOST_BROADCAST); not both it and the foot blocks PB_HOST. */
+int pb_legodo_update_after_predict(pb_ctx *ctx, const double *imu_block, int imu_mem, int64_t utime, const double *feet,
+                                   const double *forces, int mem, int zero_delta, double r_vxyz, double r_vxyz_uncertain,
+                                   double *delta_out, double *status_out, double *lo_block_out, uint8_t *mask_out);
 /* one filter's odometry state, for diagnostics and tests: odom_to_body (t3, q4); info = primary_foot (0 left, 1 right),
  * leg_odo_init, walking-phase mode (foot_contact_classify.hpp:34-44), transitions the classifier did not know */
 int pb_legodo_get(pb_ctx *ctx, int filter, double odom_to_body[7], int64_t info[4]);

@@ -63,6 +63,7 @@ _SIGS = {
     "pb_update_indexed_orient": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_void_p, C.c_void_p, C.c_int,
                                            C.c_void_p, C.c_void_p, C.c_int]),
     "pb_step_legodo": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, _dp, C.c_int]),
+    "pb_step_legodo_split": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, _dp]),
     "pb_step_legodo_correct": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, _dp, C.c_int, C.c_int, C.c_void_p,
                                          C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
     "pb_run_legodo": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, _dp, C.POINTER(C.c_float)]),
@@ -76,6 +77,8 @@ _SIGS = {
     "pb_legodo_init": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_int64, C.c_int64, C.c_int]),
     "pb_legodo_update": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pb_legodo_update_after_predict": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                                 C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pb_legodo_get": (C.c_int, [C.c_void_p, C.c_int, _dp, C.POINTER(C.c_int64)]),
     "pb_imu_notch_init": (C.c_int, [C.c_void_p, C.c_double, C.c_double]),
     "pb_imu_notch": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),

@@ -166,9 +166,11 @@ class BatchEstimator:
                                          int(bool(filter_contact_events))))
 
     def legodo_update(self, utime, feet, forces, r_vxyz, r_vxyz_uncertain, delta_out=None, status_out=None, lo_out=None,
-                      mask_out=None, zero_delta=False):
+                      mask_out=None, zero_delta=False, after_predict=None):
         """leg_estimate::updateOdometry for every filter.  feet [14,B] (or [14] broadcast), forces [2,B] (or [2]);
-        outputs are torch CUDA tensors: delta [7,B], status [B] (float64), lo block [6,B] + mask [B] (uint8)."""
+        outputs are torch CUDA tensors: delta [7,B], status [B] (float64), lo block [6,B] + mask [B] (uint8).
+        after_predict = an IMU block ([7,B] or [7]): the odometry is slaved to the orientation the filter WILL have after
+        predict(that block), which is then run fused with the measurement produced here (step_legodo)."""
         pf, m1 = _ptr_block(feet, 14, self.B)
         pz, m2 = _ptr_block(forces, 2, self.B)
         outs = []
@@ -178,6 +180,11 @@ class BatchEstimator:
             if a is not None and m != PB_DEVICE:
                 raise ValueError("legodo_update outputs must be device tensors")
             outs.append(p)
+        if after_predict is not None:
+            pi, mi = _ptr_block(after_predict, 7, self.B)
+            self._chk(self._L.pb_legodo_update_after_predict(self._h, pi, mi, int(utime), pf, pz, _same_mem(m1, m2),
+                                                             int(bool(zero_delta)), r_vxyz, r_vxyz_uncertain, *outs))
+            return
         self._chk(self._L.pb_legodo_update(self._h, int(utime), pf, pz, _same_mem(m1, m2), int(bool(zero_delta)), r_vxyz,
                                            r_vxyz_uncertain, *outs))
 
@@ -243,11 +250,17 @@ class BatchEstimator:
             self._chk(self._L.pb_update_indexed_orient(self._h, m, ia, pz, pr, kind, pq, pm, _same_mem(mz, mr, mm, mq)))
 
     def step_legodo(self, imu_block, lo_block, mask, q4):
+        """IMU block and leg-odometry block (+ mask) may live in different spaces (e.g. a broadcast [7] IMU message and a
+        per-filter device measurement from legodo_update(..., after_predict=imu)): pb_step_legodo_split."""
         pi, m1 = _ptr_block(imu_block, 7, self.B)
         pl, m2 = _ptr_block(lo_block, 6, self.B)
         pm, m3 = _ptr(mask, np.uint8, shape=(self.B,))
         q = (C.c_double * 4)(*q4)
-        self._chk(self._L.pb_step_legodo(self._h, pi, pl, pm, q, _same_mem(m1, m2, m3)))
+        mlo = _same_mem(m2, m3)
+        if m1 == mlo:
+            self._chk(self._L.pb_step_legodo(self._h, pi, pl, pm, q, m1))
+        else:
+            self._chk(self._L.pb_step_legodo_split(self._h, pi, m1, pl, pm, mlo, q))
 
     def step_legodo_correct(self, imu_block, lo_block, mask, q4, corr_kind, z2, R2, quat_meas2, mask2=None):
         """predict + leg-odometry update + one more orientation update (corr_kind: _lib.PB_CORR_POS_ORIENT m=6 idx

@@ -563,6 +563,17 @@ public:
     unprocessed_updates_start = held ? current_it : map.end();
   }
 
+  // the INS step fuse_ins_legodo is holding back, when it is the ONLY pending update (nullptr otherwise): a handler whose
+  // measurement depends on the head state (leg kinematic odometry) can ask the device for the state "after that step"
+  // instead of flushing it, so that the pair still runs as one fused kernel
+  RBISIMUProcessStep *pendingImu()
+  {
+    if (!fuse_ins_legodo || holding_ != 1 || unprocessed_updates_start == history.updateMap.end()) return nullptr;
+    auto it = unprocessed_updates_start;
+    auto *imu = dynamic_cast<RBISIMUProcessStep *>(it->second);
+    if (imu == nullptr || ++it != history.updateMap.end()) return nullptr;
+    return imu;
+  }
   // apply an INS step that fuse_ins_legodo is holding back (no-op otherwise)
   void flushPending()
   {
@@ -661,6 +672,7 @@ private:
     if (m == nullptr || m->index != RBIS::velocityInds()) return false;
     if (imu->imu_block.mem == PB_HOST_BROADCAST && m->measurement.mem == PB_HOST_BROADCAST && m->r_kind == PB_R_DIAG_BROADCAST && m->mask == nullptr)
       return true;
+    if (device_lo_block(m)) return true;
     return imu->imu_block.mem == PB_HOST && m->measurement.mem == PB_HOST && m->cov_mem == PB_HOST &&
            (m->r_kind == PB_R_DIAG || m->r_kind == PB_R_DIAG_BROADCAST);
   }
@@ -670,6 +682,7 @@ private:
     auto *m = dynamic_cast<RBISIndexedMeasurement *>(second);
     auto *o = dynamic_cast<RBISIndexedPlusOrientationMeasurement *>(third);
     if (m == nullptr || o == nullptr) return false;
+    if (m->measurement.mem == PB_DEVICE) return false;  // (a device-resident leg-odometry block pairs, it does not triple)
     int kind;
     if (o->index == std::vector<int>{ 9, 10, 11, 6, 7, 8 }) kind = PB_CORR_POS_ORIENT;
     else if (o->index == std::vector<int>{ 9, 10, 11, 8 }) kind = PB_CORR_POS_YAW;
@@ -700,6 +713,12 @@ private:
                                 o->r_kind, o->orientation.p, o->mask, o->measurement.mem);
     return true;
   }
+  // a velocity measurement that lives on the device as ONE [6][B] block (z, diagonal R) + mask: what
+  // LegOdoHandler::processMessageFeet / pb_legodo_update(_after_predict) leave there
+  bool device_lo_block(const RBISIndexedMeasurement *m) const
+  {
+    return m->measurement.mem == PB_DEVICE && m->r_kind == PB_R_DIAG && m->measurement_cov == m->measurement.p + (size_t) 3 * B;
+  }
   // imu followed by a velocity measurement LegOdoCommon's lin_rate mode produces -> one pb_step_legodo; false = not fusible
   bool run_fused(RBISIMUProcessStep *imu, RBISUpdateInterface *next, int &rc)
   {
@@ -707,6 +726,10 @@ private:
     auto *m = dynamic_cast<RBISIndexedMeasurement *>(next);
     if (m == nullptr || m->index != RBIS::velocityInds()) return false;
     const double q[4] = { imu->q_gyro, imu->q_accel, imu->q_gyro_bias, imu->q_accel_bias };
+    if (device_lo_block(m)) {  // IMU block from the host (broadcast or per filter), measurement on the device
+      rc = pb_step_legodo_split(ctx, imu->imu_block.p, imu->imu_block.mem, m->measurement.p, m->mask, PB_DEVICE, q);
+      return true;
+    }
     if (imu->imu_block.mem == PB_HOST_BROADCAST && m->measurement.mem == PB_HOST_BROADCAST && m->r_kind == PB_R_DIAG_BROADCAST &&
         m->mask == nullptr) {
       const double lo[6] = { m->measurement.p[0], m->measurement.p[1], m->measurement.p[2],
@@ -1389,7 +1412,12 @@ public:
       return nullptr;
     }
     const int B = est->B;
-    est->flushPending();  // the odometry reads the head orientation
+    // The odometry reads the head orientation.  An INS step that fuse_ins_legodo is holding back is either applied first,
+    // or -- when the measurement made here will pair with it (mode lin_rate) -- left pending: the device then slaves the
+    // odometry to the orientation "after that step" (pb_legodo_update_after_predict) and the pair runs as one fused kernel.
+    RBISIMUProcessStep *ahead = (leg_odo_common_->mode_ == LegOdoCommon::MODE_LIN_RATE) ? est->pendingImu() : nullptr;
+    if (ahead != nullptr && ahead->imu_block.mem == PB_HOST && msg->feet.mem == PB_HOST) ahead = nullptr;  // one host staging area
+    if (ahead == nullptr) est->flushPending();
     if (!legodo_ready_) {
       const double lt = bot_param_get_double_or_fail(param_, "state_estimator.legodo.schmitt_low_threshold");
       const double ht = bot_param_get_double_or_fail(param_, "state_estimator.legodo.schmitt_high_threshold");
@@ -1416,8 +1444,12 @@ public:
     zero_initial_velocity--;  // decrement first, then compare (:264-268)
     const int zero = zero_initial_velocity > 0;
     const LegOdoCommon *lc = leg_odo_common_;
-    if (pb_legodo_update(est->ctx, msg->utime, msg->feet.p, msg->forces.p, msg->feet.mem, zero, lc->R_legodo_vxyz_,
-                         lc->R_legodo_vxyz_uncertain_, d_delta, d_status, d_lo, d_mask) != PB_OK) {
+    const int lrc = ahead ? pb_legodo_update_after_predict(est->ctx, ahead->imu_block.p, ahead->imu_block.mem, msg->utime, msg->feet.p,
+                                                           msg->forces.p, msg->feet.mem, zero, lc->R_legodo_vxyz_,
+                                                           lc->R_legodo_vxyz_uncertain_, d_delta, d_status, d_lo, d_mask)
+                          : pb_legodo_update(est->ctx, msg->utime, msg->feet.p, msg->forces.p, msg->feet.mem, zero, lc->R_legodo_vxyz_,
+                                             lc->R_legodo_vxyz_uncertain_, d_delta, d_status, d_lo, d_mask);
+    if (lrc != PB_OK) {
       fprintf(stderr, "LegOdoHandler: %s\n", pb_last_error(est->ctx));
       return nullptr;
     }

@@ -376,7 +376,7 @@ extern "C" int pb_step_legodo(pb_ctx *c, const double *imu_block, const double *
     StepBcast bc;
     memcpy(bc.imu, imu_block, sizeof(bc.imu));
     memcpy(bc.lo, lo_block, sizeof(bc.lo));
-    bc.on = 1;
+    bc.on = 3;
     return pbk_step(c, true, nullptr, nullptr, nullptr, q, &bc);
   }
   Part p[3] = { { imu_block, sizeof(double) * 7 * c->B, 0 }, { lo_block, sizeof(double) * 6 * c->B, 0 },
@@ -384,6 +384,42 @@ extern "C" int pb_step_legodo(pb_ctx *c, const double *imu_block, const double *
   int rc = stage_in(c, mem, p, 3);
   if (rc) return rc;
   return pbk_step(c, true, (const double *) p[0].dev, (const double *) p[1].dev, (const uint8_t *) p[2].dev, q);
+}
+
+extern "C" int pb_step_legodo_split(pb_ctx *c, const double *imu_block, int imu_mem, const double *lo_block,
+                                    const uint8_t *mask, int lo_mem, const double q[4])
+{
+  if (imu_mem == lo_mem) return pb_step_legodo(c, imu_block, lo_block, mask, q, imu_mem);
+  ENTER(c);
+  NEED_STATE(c);
+  if (!imu_block || !lo_block || !q) return fail(c, PB_ERR_ARG, "pb_step_legodo_split: NULL input");
+  if (imu_mem == PB_HOST && lo_mem == PB_HOST) return fail(c, PB_ERR_ARG, "pb_step_legodo_split: unreachable");
+  StepBcast bc;
+  const double *d_imu = nullptr, *d_lo = nullptr;
+  const uint8_t *d_mask = nullptr;
+  // at most one of the two groups goes through the double-buffered host staging (PB_HOST); a broadcast group travels as
+  // kernel arguments, a device group is read in place
+  if (imu_mem == PB_HOST_BROADCAST) {
+    memcpy(bc.imu, imu_block, sizeof(bc.imu));
+    bc.on |= 1;
+  } else {
+    Part p[1] = { { imu_block, sizeof(double) * 7 * c->B, 0 } };
+    int rc = stage_in(c, imu_mem, p, 1);
+    if (rc) return rc;
+    d_imu = (const double *) p[0].dev;
+  }
+  if (lo_mem == PB_HOST_BROADCAST) {
+    if (mask) return fail(c, PB_ERR_ARG, "PB_HOST_BROADCAST: a mask cannot be broadcast (pass mask = NULL)");
+    memcpy(bc.lo, lo_block, sizeof(bc.lo));
+    bc.on |= 2;
+  } else {
+    Part p[2] = { { lo_block, sizeof(double) * 6 * c->B, 0 }, { mask, (size_t) c->B, 0 } };
+    int rc = stage_in(c, lo_mem, p, 2);
+    if (rc) return rc;
+    d_lo = (const double *) p[0].dev;
+    d_mask = (const uint8_t *) p[1].dev;
+  }
+  return pbk_step(c, true, d_imu, d_lo, d_mask, q, &bc);
 }
 
 extern "C" int pb_step_legodo_correct(pb_ctx *c, const double *imu_block, const double *lo_block, const uint8_t *mask,
@@ -404,7 +440,7 @@ extern "C" int pb_step_legodo_correct(pb_ctx *c, const double *imu_block, const 
     StepBcast bc;
     memcpy(bc.imu, imu_block, sizeof(bc.imu));
     memcpy(bc.lo, lo_block, sizeof(bc.lo));
-    bc.on = 1;
+    bc.on = 3;
     return pbk_step_correct(c, corr_kind, nullptr, nullptr, nullptr, q, nullptr, nullptr, R2, nullptr, nullptr, &bc, z2, quat_meas2);
   }
   Part p[7] = { { imu_block, sizeof(double) * 7 * B, 0 }, { lo_block, sizeof(double) * 6 * B, 0 }, { mask, B, 0 },
@@ -755,33 +791,64 @@ extern "C" int pb_legodo_init(pb_ctx *c, double lt, double ht, int64_t low_delay
   return PB_OK;
 }
 
-extern "C" int pb_legodo_update(pb_ctx *c, int64_t utime, const double *feet, const double *forces, int mem, int zero_delta,
-                                double r_vxyz, double r_vxyz_uncertain, double *delta_out, double *status_out, double *lo_out,
-                                uint8_t *mask_out)
+static int legodo_update_impl(pb_ctx *c, const double *imu_block, int imu_mem, bool ahead, int64_t utime, const double *feet,
+                              const double *forces, int mem, int zero_delta, double r_vxyz, double r_vxyz_uncertain,
+                              double *delta_out, double *status_out, double *lo_out, uint8_t *mask_out)
 {
   ENTER(c);
   NEED_STATE(c);
   if (!c->legd) return fail(c, PB_ERR_STATE, "pb_legodo_update before pb_legodo_init");
-  if (!feet || !forces) return fail(c, PB_ERR_ARG, "pb_legodo_update: NULL input");
+  if (!feet || !forces || (ahead && !imu_block)) return fail(c, PB_ERR_ARG, "pb_legodo_update: NULL input");
   Part p[2] = { { feet, sizeof(double) * 14 * c->B, 0 }, { forces, sizeof(double) * 2 * c->B, 0 } };
+  Part pi[1] = { { imu_block, sizeof(double) * 7 * c->B, 0 } };
   LegBcast bc;
+  if (ahead && imu_mem == PB_HOST && mem == PB_HOST)
+    return fail(c, PB_ERR_ARG, "pb_legodo_update_after_predict: the IMU block and the foot blocks cannot both be PB_HOST");
   if (mem == PB_HOST_BROADCAST) {  // one robot's joint state for every filter: kernel arguments, no device block
     memcpy(bc.feet, feet, sizeof(bc.feet));
     memcpy(bc.forces, forces, sizeof(bc.forces));
-    bc.on = 1;
+    bc.on |= 1;
   } else {
     int rc = stage_in(c, mem, p, 2);
     if (rc) return rc;
   }
+  if (ahead) {
+    bc.on |= 2;
+    if (imu_mem == PB_HOST_BROADCAST) {
+      memcpy(bc.imu, imu_block, sizeof(bc.imu));
+      bc.on |= 4;
+    } else {
+      int rc = stage_in(c, imu_mem, pi, 1);
+      if (rc) return rc;
+    }
+  }
   const double r2 = r_vxyz * r_vxyz, r2u = r_vxyz_uncertain * r_vxyz_uncertain;  // bot_sq (rbis_legodo_common.cpp:40-43)
   if (c->ns == 15)
     k_legodo<15><<<nblk(c->B), 64, 0, c->stream>>>(c->st, c->legd, c->legi, c->stride, c->B, utime, c->leg_par, (const double *) p[0].dev,
-                                                   (const double *) p[1].dev, zero_delta, r2, r2u, delta_out, status_out, lo_out, mask_out, bc);
+                                                   (const double *) p[1].dev, zero_delta, r2, r2u, delta_out, status_out, lo_out, mask_out,
+                                                   bc, (const double *) pi[0].dev, c->k);
   else
     k_legodo<21><<<nblk(c->B), 64, 0, c->stream>>>(c->st, c->legd, c->legi, c->stride, c->B, utime, c->leg_par, (const double *) p[0].dev,
-                                                   (const double *) p[1].dev, zero_delta, r2, r2u, delta_out, status_out, lo_out, mask_out, bc);
+                                                   (const double *) p[1].dev, zero_delta, r2, r2u, delta_out, status_out, lo_out, mask_out,
+                                                   bc, (const double *) pi[0].dev, c->k);
   LAUNCHCHK(c);
   return PB_OK;
+}
+
+extern "C" int pb_legodo_update(pb_ctx *c, int64_t utime, const double *feet, const double *forces, int mem, int zero_delta,
+                                double r_vxyz, double r_vxyz_uncertain, double *delta_out, double *status_out, double *lo_out,
+                                uint8_t *mask_out)
+{
+  return legodo_update_impl(c, nullptr, PB_DEVICE, false, utime, feet, forces, mem, zero_delta, r_vxyz, r_vxyz_uncertain, delta_out,
+                            status_out, lo_out, mask_out);
+}
+
+extern "C" int pb_legodo_update_after_predict(pb_ctx *c, const double *imu_block, int imu_mem, int64_t utime, const double *feet,
+                                              const double *forces, int mem, int zero_delta, double r_vxyz, double r_vxyz_uncertain,
+                                              double *delta_out, double *status_out, double *lo_out, uint8_t *mask_out)
+{
+  return legodo_update_impl(c, imu_block, imu_mem, true, utime, feet, forces, mem, zero_delta, r_vxyz, r_vxyz_uncertain, delta_out,
+                            status_out, lo_out, mask_out);
 }
 
 extern "C" int pb_legodo_get(pb_ctx *c, int filter, double odom_to_body[7], int64_t info[4])

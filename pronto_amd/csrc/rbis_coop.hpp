@@ -98,7 +98,7 @@ PB_HD void mat_mul_acc(const double (&A)[9], const double (&X)[9], double (&Y)[9
 struct StepBcast {
   double imu[7] = { 0, 0, 0, 0, 0, 0, 0 };
   double lo[6] = { 0, 0, 0, 1, 1, 1 };
-  int on = 0;
+  int on = 0;  // bit 0: the IMU block is broadcast, bit 1: the leg-odometry block is (the other one is read from memory)
 };
 
 struct StepInputs {

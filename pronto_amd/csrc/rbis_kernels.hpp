@@ -189,19 +189,27 @@ __global__ __launch_bounds__(PB_STEP_BLOCK, 1) void k_step(const double *st, dou
   double gyro[3], accel[3], dt, z[3], rd[3];
   bool upd = false;
   if constexpr (UPDATE) upd = (mask == nullptr) || (mask[b] != 0);
-  if (bc.on) {  // one message for every filter: kernel arguments (wave-uniform branch)
+  if (bc.on & 1) {  // one IMU message for every filter: kernel arguments (wave-uniform branch)
 #pragma unroll
-    for (int i = 0; i < 3; i++) { gyro[i] = bc.imu[i]; accel[i] = bc.imu[3 + i]; z[i] = bc.lo[i]; rd[i] = bc.lo[3 + i]; }
+    for (int i = 0; i < 3; i++) { gyro[i] = bc.imu[i]; accel[i] = bc.imu[3 + i]; }
     dt = bc.imu[6];
   } else {
 #pragma unroll
     for (int i = 0; i < 3; i++) {
       gyro[i] = ldg(ri, i * B8, bo);
       accel[i] = ldg(ri, (3 + i) * B8, bo);
+    }
+    dt = ldg(ri, 6u * B8, bo);
+  }
+  if (bc.on & 2) {
+#pragma unroll
+    for (int i = 0; i < 3; i++) { z[i] = bc.lo[i]; rd[i] = bc.lo[3 + i]; }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
       z[i] = UPDATE ? ldg(rl, i * B8, bo) : 0.0;
       rd[i] = UPDATE ? ldg(rl, (3 + i) * B8, bo) : 1.0;
     }
-    dt = ldg(ri, 6u * B8, bo);
   }
   if (k.qblk != nullptr) {  // per-filter process noise (wave-uniform branch)
     const rsrc_t rq = mkbuf(k.qblk, 4u * B8);
@@ -669,19 +677,27 @@ __global__ __launch_bounds__(128, 1) void k_step_coop(const double *st, double *
   const rsrc_t ri = mkbuf(imu, PREDICT ? 7u * B8 : 0u);
   const rsrc_t rl = mkbuf(lo, UPDATE ? 6u * B8 : 0u);
   StepInputs in;
-  if (PREDICT && bc.on) {  // one message for every filter: kernel arguments (wave-uniform branch)
+  if (PREDICT && (bc.on & 1)) {  // one IMU message for every filter: kernel arguments (wave-uniform branch)
 #pragma unroll
-    for (int i = 0; i < 3; i++) { in.gyro[i] = bc.imu[i]; in.accel[i] = bc.imu[3 + i]; in.z[i] = bc.lo[i]; in.rd[i] = bc.lo[3 + i]; }
+    for (int i = 0; i < 3; i++) { in.gyro[i] = bc.imu[i]; in.accel[i] = bc.imu[3 + i]; }
     in.dt = bc.imu[6];
   } else {
 #pragma unroll
     for (int i = 0; i < 3; i++) {
       in.gyro[i] = PREDICT ? ldg(ri, i * B8, bo) : 0.0;
       in.accel[i] = PREDICT ? ldg(ri, (3 + i) * B8, bo) : 0.0;
+    }
+    in.dt = PREDICT ? ldg(ri, 6u * B8, bo) : 0.0;
+  }
+  if (PREDICT && (bc.on & 2)) {
+#pragma unroll
+    for (int i = 0; i < 3; i++) { in.z[i] = bc.lo[i]; in.rd[i] = bc.lo[3 + i]; }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
       in.z[i] = UPDATE ? ldg(rl, i * B8, bo) : 0.0;
       in.rd[i] = UPDATE ? ldg(rl, (3 + i) * B8, bo) : 1.0;
     }
-    in.dt = PREDICT ? ldg(ri, 6u * B8, bo) : 0.0;
   }
   in.upd = UPDATE && (b < (unsigned) B) && (mask == nullptr || mask[b] != 0);
   in.qg = qg; in.qa = qa; in.qbg = qbg; in.qba = qba;
@@ -739,19 +755,27 @@ __global__ __launch_bounds__(256, 2) void k_step_quad(const double *st, double *
     const rsrc_t ri = mkbuf(imu, 7u * B8);
     const rsrc_t rl = mkbuf(lo, UPDATE ? 6u * B8 : 0u);
     StepInputs in;
-    if (bc.on) {  // one message for every filter: kernel arguments (wave-uniform branch)
+    if (bc.on & 1) {  // one IMU message for every filter: kernel arguments (wave-uniform branch)
 #pragma unroll
-      for (int i = 0; i < 3; i++) { in.gyro[i] = bc.imu[i]; in.accel[i] = bc.imu[3 + i]; in.z[i] = bc.lo[i]; in.rd[i] = bc.lo[3 + i]; }
+      for (int i = 0; i < 3; i++) { in.gyro[i] = bc.imu[i]; in.accel[i] = bc.imu[3 + i]; }
       in.dt = bc.imu[6];
     } else {
 #pragma unroll
       for (int i = 0; i < 3; i++) {
         in.gyro[i] = ldg(ri, i * B8, bo);
         in.accel[i] = ldg(ri, (3 + i) * B8, bo);
+      }
+      in.dt = ldg(ri, 6u * B8, bo);
+    }
+    if (bc.on & 2) {
+#pragma unroll
+      for (int i = 0; i < 3; i++) { in.z[i] = bc.lo[i]; in.rd[i] = bc.lo[3 + i]; }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 3; i++) {
         in.z[i] = (UPDATE && meas) ? ldg(rl, i * B8, bo) : 0.0;
         in.rd[i] = (UPDATE && meas) ? ldg(rl, (3 + i) * B8, bo) : 1.0;
       }
-      in.dt = ldg(ri, 6u * B8, bo);
     }
     in.upd = UPDATE && (b < (unsigned) B) && (mask == nullptr || mask[b] != 0);
     in.qg = qg; in.qa = qa; in.qbg = qbg; in.qba = qba;

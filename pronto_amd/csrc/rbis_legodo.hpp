@@ -347,16 +347,22 @@ PB_HD void leg_store(const LegState &s, double *d, int64_t *iw, long stride, lon
 // values are kernel arguments.
 struct LegBcast {
   double feet[14] = { 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0 }, forces[2] = { 0, 0 };
-  int on = 0;
+  double imu[7] = { 0, 0, 0, 0, 0, 0, 0 };
+  int on = 0;  // bit 0: feet / forces are broadcast; bit 1: AHEAD (see k_legodo); bit 2: the IMU block of AHEAD is broadcast
 };
 // (launch bounds: without them the compiler budgets for 1024-thread blocks, 128 registers, and spilled 668 bytes per lane)
+// AHEAD (bc.on & 2): the odometry is slaved to the orientation the filter WILL have after the IMU step in `imu` / bc.imu
+// (rbis_update_interface.cpp:30-52 applied to the head), computed here from the head state with the step kernels' own
+// ins_update_state -- the covariance is not touched.  That lets the estimator run the IMU step and the leg-odometry update
+// it produces as ONE fused kernel afterwards instead of predict, odometry, update.
 template <int NS>
 static __global__ __launch_bounds__(64, 2) void k_legodo(const double *__restrict__ st, double *__restrict__ legd,
                                                          int64_t *__restrict__ legi, long stride, int B, int64_t utime, LegPar par,
                                                          const double *__restrict__ feet, const double *__restrict__ forces,
                                                          int zero_delta, double r2, double r2_uncertain,
                                                          double *__restrict__ delta_out, double *__restrict__ status_out,
-                                                         double *__restrict__ lo_out, uint8_t *__restrict__ mask_out, LegBcast bc)
+                                                         double *__restrict__ lo_out, uint8_t *__restrict__ mask_out, LegBcast bc,
+                                                         const double *__restrict__ imu, Consts k)
 {
   using L = Lay<NS>;
   using S = Slots<NS>;
@@ -366,7 +372,7 @@ static __global__ __launch_bounds__(64, 2) void k_legodo(const double *__restric
   leg_load(s, legd, legi, stride, b);
   Pose bl, br, delta;
   double fl, fr;
-  if (bc.on) {  // wave-uniform
+  if (bc.on & 1) {  // wave-uniform
     for (int i = 0; i < 3; i++) { bl.t[i] = bc.feet[i]; br.t[i] = bc.feet[7 + i]; }
     for (int i = 0; i < 4; i++) { bl.q[i] = bc.feet[3 + i]; br.q[i] = bc.feet[10 + i]; }
     fl = bc.forces[0]; fr = bc.forces[1];
@@ -377,6 +383,19 @@ static __global__ __launch_bounds__(64, 2) void k_legodo(const double *__restric
   }
   double wq[4];
   for (int i = 0; i < 4; i++) wq[i] = st[S::eidx(L::OFF_QUAT + i, b)];
+  if (bc.on & 2) {
+    double x[NS], gyro[3], accel[3], dt;
+#pragma unroll
+    for (int i = 0; i < NS; i++) x[i] = st[S::eidx(L::OFF_VEC + i, b)];
+    if (bc.on & 4) {
+      for (int i = 0; i < 3; i++) { gyro[i] = bc.imu[i]; accel[i] = bc.imu[3 + i]; }
+      dt = bc.imu[6];
+    } else {
+      for (int i = 0; i < 3; i++) { gyro[i] = imu[(long) i * B + b]; accel[i] = imu[(long) (3 + i) * B + b]; }
+      dt = imu[(long) 6 * B + b];
+    }
+    ins_update_state<NS>(x, wq, gyro, accel, dt, k);
+  }
   int64_t prev = 0;
   const double status = leg_update(s, par, utime, bl, br, fl, fr, wq, delta, prev);
   leg_store(s, legd, legi, stride, b);

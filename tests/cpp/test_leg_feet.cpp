@@ -25,12 +25,16 @@ static double ramp(double x) { return x < 0 ? 0 : (x > 0.05 ? 1.0 : x / 0.05); }
 int main(int argc, char **argv)
 {
   const std::string lomode = argc > 1 ? argv[1] : "lin_rate";
+  // argv[2] = "fuse": state_estimator.fuse_ins_legodo -- the INS step is held back, the odometry is slaved to the orientation
+  // AFTER it (pb_legodo_update_after_predict) and the pair runs as one fused kernel (lin_rate only; same oracle sequence)
+  const bool fuse = argc > 2 && std::string(argv[2]) == "fuse";
   const int n = 15, B = 64, T = 900;
   double g;
   po_get_constants(&g, nullptr);
   BotParam param;
   param.set("state_estimator.utime_history_span", "1000000");
   param.set("state_estimator.history_slots", "0");
+  param.set("state_estimator.fuse_ins_legodo", fuse ? "true" : "false");
   param.set("state_estimator.ins.channel", "IMU");
   param.set("state_estimator.ins.q_gyro", 0.5);
   param.set("state_estimator.ins.q_accel", 0.1);
@@ -136,12 +140,14 @@ int main(int argc, char **argv)
     el = fmax(el, fabs(ll[b] - oll[b]));
     sl = fmax(sl, fabs(oll[b]));
   }
-  printf("mode %s: status skip/certain/uncertain %d/%d/%d: rel err vec %.2e quat %.2e cov %.2e ll %.2e (status %d)\n", lomode.c_str(),
-         n_status[0], n_status[1], n_status[2], ev / sv, eq, eP / sP, el / sl, est.last_status);
+  printf("mode %s%s: status skip/certain/uncertain %d/%d/%d: rel err vec %.2e quat %.2e cov %.2e ll %.2e (status %d, fused pairs %lld)\n",
+         lomode.c_str(), fuse ? " fused" : "", n_status[0], n_status[1], n_status[2], ev / sv, eq, eP / sP, el / sl, est.last_status,
+         (long long) est.fused_pairs);
   // Tolerance 1e-6: the device integrates the odometry with quaternions, the oracle with rotation matrices like the reference;
   // the two pelvis poses differ at the 1e-12 level after hundreds of steps and the measurement is increment / 0.002 s (and,
   // in lin_rot_rate, the Euler angles of a 1e-4 rad rotation divided by the same 0.002 s).
-  const bool ok = est.last_status == PB_OK && n_status[0] > 100 && n_status[1] > 50 && n_status[2] > 100 && ev / sv < 1e-6 && eq < 1e-6 &&
+  const bool fused_ok = !fuse || lomode != "lin_rate" || est.fused_pairs > T / 2;
+  const bool ok = fused_ok && est.last_status == PB_OK && n_status[0] > 100 && n_status[1] > 50 && n_status[2] > 100 && ev / sv < 1e-6 && eq < 1e-6 &&
                   eP / sP < 1e-6 && el / sl < 1e-6;
   printf(ok ? "PASS\n" : "FAIL\n");
   return ok ? 0 : 1;

@@ -95,12 +95,14 @@ def test_every_handler_mode_on_gpu(oracle, mode):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["lin_rate", "lin_rot_rate"])
-def test_leg_odometry_from_foot_transforms_through_the_handler_on_gpu(oracle, mode):
+@pytest.mark.parametrize("mode,fuse", [("lin_rate", ""), ("lin_rot_rate", ""), ("lin_rate", "fuse"), ("lin_rot_rate", "fuse")])
+def test_leg_odometry_from_foot_transforms_through_the_handler_on_gpu(oracle, mode, fuse):
     """LegOdoHandler::processMessageFeet: leg_estimate::updateOdometry + contact classification + createMeasurement on the
-    device for every filter (its world_to_body_ is the filter's own head orientation), against the oracle's restatement."""
+    device for every filter (its world_to_body_ is the filter's own head orientation), against the oracle's restatement.
+    "fuse": with state_estimator.fuse_ins_legodo the INS step stays pending, the odometry is slaved to the orientation after it
+    and the pair runs as one fused kernel -- same oracle sequence (predict, odometry, update)."""
     exe = build_exe(oracle, "test_leg_feet")
-    r = subprocess.run([exe, mode], capture_output=True, text=True, timeout=300)
+    r = subprocess.run([exe, mode] + ([fuse] if fuse else []), capture_output=True, text=True, timeout=300)
     print(r.stdout[-2000:], r.stderr[-2000:])
     assert r.returncode == 0 and "PASS" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
 

@@ -181,3 +181,55 @@ def test_leg_odometry_kernel_feeds_the_filter_on_gpu(oracle, n):
     t, q, oi = orc.get(B - 1)
     assert np.max(np.abs(pose[0:3] - t)) < 1e-10 and info[0] == oi[0] and info[1] == oi[1] and info[2] == oi[2]
     est.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [15, 21])
+@pytest.mark.parametrize("bcast", [True, False])
+def test_odometry_after_predict_and_split_step_equal_the_three_call_sequence(n, bcast):
+    """pb_legodo_update_after_predict + pb_step_legodo_split (ONE state round trip) against pb_predict, pb_legodo_update,
+    pb_update_indexed (two): same odometry increments, statuses and posterior to rounding.  bcast: one robot's IMU and
+    foot state for every filter (kernel arguments) / per-filter device blocks."""
+    import torch
+    from pronto_amd import batch as pa
+    B, T = 200, 400
+    dev = torch.device("cuda:0")
+    w = Workload(B, n_states=n, dt_us=2000)
+    vec, quat, P0 = w.initial_state()
+    q4 = w.process_noise()
+    ests = []
+    for _ in range(2):
+        e = pa.BatchEstimator(B, n_states=n)
+        e.reset(vec, quat, P0)
+        e.legodo_init(*SCHMITT, True)
+        ests.append(e)
+    seq, fus = ests
+    outs = [[torch.zeros((7, B), dtype=torch.float64, device=dev), torch.zeros(B, dtype=torch.float64, device=dev),
+             torch.zeros((6, B), dtype=torch.float64, device=dev), torch.zeros(B, dtype=torch.uint8, device=dev)] for _ in range(2)]
+    r, ru = 0.1, 0.5
+    n_upd = 0
+    for k, (utime, feet, forces, _) in enumerate(gait(B, T, seed=3)):
+        imu = w.imu_block(k)
+        if bcast:
+            imu_in, feet_in, forces_in = np.ascontiguousarray(imu[:, 0]), np.ascontiguousarray(feet[:, 0]), np.ascontiguousarray(forces[:, 0])
+        else:
+            imu_in, feet_in, forces_in = torch.from_numpy(imu).to(dev), torch.from_numpy(feet).to(dev), torch.from_numpy(forces).to(dev)
+        # the reference's order of events: IMU update, then the odometry from the new head, then its measurement
+        seq.predict(imu_in, q4)
+        seq.legodo_update(utime, feet_in, forces_in, r, ru, *outs[0])
+        seq.update_indexed([3, 4, 5], outs[0][2][0:3].contiguous(), outs[0][2][3:6].contiguous(), mask=outs[0][3])
+        # the same as two calls and one round trip of the state
+        fus.legodo_update(utime, feet_in, forces_in, r, ru, *outs[1], after_predict=imu_in)
+        fus.step_legodo(imu_in, outs[1][2], outs[1][3], q4)
+        a, b = [o.cpu().numpy() for o in outs[0]], [o.cpu().numpy() for o in outs[1]]
+        assert np.array_equal(a[1], b[1]) and np.array_equal(a[3], b[3]), k           # status, mask
+        # two runs of one CLOSED loop (the measurement is increment / 2 ms and the next increment is slaved to the orientation it
+        # corrects) whose arithmetic differs in rounding only: 1e-16-level differences grow to the 1e-11 level over 400 ticks
+        assert np.max(np.abs(a[0] - b[0])) < 1e-9 and np.max(np.abs(a[2] - b[2])) < 1e-6, k
+        n_upd += int(a[3].sum())
+    assert n_upd > B * T // 20   # (the classifier accepts a fraction of the ticks of this gait; all of them must be applied)
+    from util import rel
+    for x, y in zip(seq.get_head(), fus.get_head()):
+        assert rel(x, y) < 1e-7
+    for e in ests:
+        e.close()
