@@ -14,7 +14,7 @@
 // rounding (a quaternion's overall sign never matters for a pose).  The joint filters (:411-428), the controller-contact
 // override (use_controller_input, :365-387) and the "standing" control mode's classifier (:453-454) are not built.
 //
-// Per-robot state: NLD doubles + NLI 64-bit integers, struct-of-arrays with the robot index fastest.
+// Per-robot state: NLD doubles + NLI 64-bit integers (flags packed into one of them), struct-of-arrays, robot index fastest.
 #pragma once
 
 #include <stdint.h>
@@ -112,8 +112,11 @@ struct LegState {
   Schmitt weak_l, weak_r, strong_l, strong_r;
   int64_t mode, initialized, last_strike, last_break, unknown_transitions;
 };
-static constexpr int NLD = 21;                 // three poses
-static constexpr int NLI = 3 + 8 + 1 + 16 + 5; // 33
+static constexpr int NLD = 21;  // three poses
+// Stored integers: utime, 6 x (timer, previous_time), last_strike, last_break (true 64-bit times) + ONE word that packs every
+// flag, enum and the transition counter (leg_pack_flags): 16 words instead of the 33 fields of LegState -- the kernel is
+// bound by the bytes of this state (21 doubles + these, read and written per robot and message: 432 -> 296 bytes).
+static constexpr int NLI = 1 + 12 + 2 + 1;
 
 PB_HD void leg_reset(LegState &s)
 {
@@ -304,6 +307,30 @@ PB_HD double leg_update(LegState &s, const LegPar &p, int64_t utime, const Pose 
   return status;
 }
 
+// every flag, enum and counter of LegState in one word: bit 0 leg_odo_init, 1-2 primary_foot + 1, 3-8 the six triggers'
+// status, 9-14 their first_call, 15-16 standing_foot + 1, 17-24 mode + 1, 25 initialized, 32-63 unknown_transitions
+PB_HD int64_t leg_pack_flags(const LegState &s)
+{
+  const Schmitt *ss[6] = { &s.alt_l, &s.alt_r, &s.weak_l, &s.weak_r, &s.strong_l, &s.strong_r };
+  uint64_t w = (uint64_t) (s.leg_odo_init != 0) | ((uint64_t) (s.primary_foot + 1) & 3u) << 1;
+  for (int k = 0; k < 6; k++) w |= (uint64_t) (ss[k]->status != 0) << (3 + k) | (uint64_t) (ss[k]->first_call != 0) << (9 + k);
+  w |= ((uint64_t) (s.standing_foot + 1) & 3u) << 15 | ((uint64_t) (s.mode + 1) & 255u) << 17 | (uint64_t) (s.initialized != 0) << 25;
+  w |= ((uint64_t) s.unknown_transitions & 0xFFFFFFFFu) << 32;
+  return (int64_t) w;
+}
+PB_HD void leg_unpack_flags(LegState &s, int64_t word)
+{
+  const uint64_t w = (uint64_t) word;
+  Schmitt *ss[6] = { &s.alt_l, &s.alt_r, &s.weak_l, &s.weak_r, &s.strong_l, &s.strong_r };
+  s.leg_odo_init = (int64_t) (w & 1u);
+  s.primary_foot = (int64_t) ((w >> 1) & 3u) - 1;
+  for (int k = 0; k < 6; k++) { ss[k]->status = (int64_t) ((w >> (3 + k)) & 1u); ss[k]->first_call = (int64_t) ((w >> (9 + k)) & 1u); }
+  s.standing_foot = (int64_t) ((w >> 15) & 3u) - 1;
+  s.mode = (int64_t) ((w >> 17) & 255u) - 1;
+  s.initialized = (int64_t) ((w >> 25) & 1u);
+  s.unknown_transitions = (int64_t) (w >> 32);
+}
+
 // SoA <-> struct (robot index fastest; d: [NLD][stride] doubles, iw: [NLI][stride] 64-bit integers)
 PB_HD void leg_load(LegState &s, const double *d, const int64_t *iw, long stride, long b)
 {
@@ -314,12 +341,11 @@ PB_HD void leg_load(LegState &s, const double *d, const int64_t *iw, long stride
   }
   int c = 0;
   auto rd = [&]() { return iw[(long) (c++) * stride + b]; };
-  s.utime = rd(); s.leg_odo_init = rd(); s.primary_foot = rd();
+  s.utime = rd();
   Schmitt *ss[6] = { &s.alt_l, &s.alt_r, &s.weak_l, &s.weak_r, &s.strong_l, &s.strong_r };
-  for (int k = 0; k < 2; k++) { ss[k]->status = rd(); ss[k]->timer = rd(); ss[k]->previous_time = rd(); ss[k]->first_call = rd(); }
-  s.standing_foot = rd();
-  for (int k = 2; k < 6; k++) { ss[k]->status = rd(); ss[k]->timer = rd(); ss[k]->previous_time = rd(); ss[k]->first_call = rd(); }
-  s.mode = rd(); s.initialized = rd(); s.last_strike = rd(); s.last_break = rd(); s.unknown_transitions = rd();
+  for (int k = 0; k < 6; k++) { ss[k]->timer = rd(); ss[k]->previous_time = rd(); }
+  s.last_strike = rd(); s.last_break = rd();
+  leg_unpack_flags(s, rd());
 }
 PB_HD void leg_store(const LegState &s, double *d, int64_t *iw, long stride, long b)
 {
@@ -330,12 +356,11 @@ PB_HD void leg_store(const LegState &s, double *d, int64_t *iw, long stride, lon
   }
   int c = 0;
   auto wr = [&](int64_t v) { iw[(long) (c++) * stride + b] = v; };
-  wr(s.utime); wr(s.leg_odo_init); wr(s.primary_foot);
+  wr(s.utime);
   const Schmitt *ss[6] = { &s.alt_l, &s.alt_r, &s.weak_l, &s.weak_r, &s.strong_l, &s.strong_r };
-  for (int k = 0; k < 2; k++) { wr(ss[k]->status); wr(ss[k]->timer); wr(ss[k]->previous_time); wr(ss[k]->first_call); }
-  wr(s.standing_foot);
-  for (int k = 2; k < 6; k++) { wr(ss[k]->status); wr(ss[k]->timer); wr(ss[k]->previous_time); wr(ss[k]->first_call); }
-  wr(s.mode); wr(s.initialized); wr(s.last_strike); wr(s.last_break); wr(s.unknown_transitions);
+  for (int k = 0; k < 6; k++) { wr(ss[k]->timer); wr(ss[k]->previous_time); }
+  wr(s.last_strike); wr(s.last_break);
+  wr(leg_pack_flags(s));
 }
 
 #if defined(__HIPCC__)

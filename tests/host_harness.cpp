@@ -295,6 +295,13 @@ extern "C" void hh_update_quad(int kind, double *st, long stride, int B, const d
 extern "C" {
 int hh_leg_nld() { return NLD; }
 int hh_leg_nli() { return NLI; }
+// info = primary_foot, leg_odo_init, walking-phase mode, unknown transitions of robot b (the integers are stored packed)
+void hh_leg_info(const double *legd, const int64_t *legi, long stride, long b, int64_t *info)
+{
+  LegState s;
+  leg_load(s, legd, legi, stride, b);
+  info[0] = s.primary_foot; info[1] = s.leg_odo_init; info[2] = s.mode; info[3] = s.unknown_transitions;
+}
 void hh_leg_reset(double *legd, int64_t *legi, long stride, int B)
 {
   for (int b = 0; b < B; b++) {

@@ -110,7 +110,7 @@ def test_leg_odometry_arithmetic_matches_oracle_on_cpu(oracle, harness, fce):
         assert np.array_equal(status, os_) and np.array_equal(prev, op)
         assert np.max(np.abs(delta[0:3] - od[0:3])) < 1e-13 and same_rotation(delta[3:7], od[3:7]) < 1e-13
         seen.update(np.unique(status).tolist())
-        primary = legi[2].copy()
+        primary = ((legi[-1] >> 1) & 3) - 1    # (the flags word: bits 1-2 = primary_foot + 1, rbis_legodo.hpp leg_pack_flags)
         if prev_primary is not None:
             n_switch += int(np.sum(primary != prev_primary))
         prev_primary = primary
@@ -119,9 +119,9 @@ def test_leg_odometry_arithmetic_matches_oracle_on_cpu(oracle, harness, fce):
     for b in (0, B // 2, B - 1):
         t, q, info = orc.get(b)
         assert np.max(np.abs(legd[0:3, b] - t)) < 1e-11 and same_rotation(legd[3:7, b:b + 1], q[:, None]) < 1e-12
-        assert info[0] == legi[2, b] and info[1] == legi[1, b] and info[2] == legi[28, b]
-        assert info[3] == legi[32, b]
-    assert legi[32].sum() == 0 or True   # (unknown classifier transitions are counted, not fatal)
+        hi = np.zeros(4, dtype=np.int64)
+        H.hh_leg_info(dp(legd), ip(legi), C.c_long(B), C.c_long(b), ip(hi))
+        assert info[0] == hi[0] and info[1] == hi[1] and info[2] == hi[2] and info[3] == hi[3]
 
 
 @pytest.mark.gpu
