@@ -8,7 +8,7 @@
 //
 //   g++ -std=c++17 -O2 -Iinclude -Ipronto_amd/csrc examples/shim_sweep_rate.cpp -Lpronto_amd/lib -lpronto_batch
 //       -Wl,-rpath,$PWD/pronto_amd/lib -o shim_sweep_rate
-//   ./shim_sweep_rate [filters=65536] [messages=2000] [n_states=15] [history_slots=0] [utime_history_span=1000000]
+//   ./shim_sweep_rate [filters=65536] [messages=2000] [n_states=15] [history_slots=0] [utime_history_span=1000000] [vo_every=0]
 //
 // Prints messages/s and filter-steps/s (one step = IMU predict + leg-odometry update of one filter).
 #include <chrono>
@@ -43,6 +43,7 @@ int main(int argc, char **argv)
   const int n = argc > 3 ? std::atoi(argv[3]) : 15;
   const std::string slots = argc > 4 ? argv[4] : "0";
   const std::string span = argc > 5 ? argv[5] : "1000000";  // us of update history kept (update_history.cpp:28-39)
+  const int vo_every = argc > 6 ? std::atoi(argv[6]) : 0;     // a visual-odometry delta every N-th pair (0 = none): config 3
   BotParam param;
   param.set("state_estimator.utime_history_span", span);
   param.set("state_estimator.history_slots", slots);
@@ -61,7 +62,8 @@ int main(int argc, char **argv)
                        "state_estimator.legodo.schmitt_low_threshold=475|state_estimator.legodo.schmitt_high_threshold=525|"
                        "state_estimator.legodo.schmitt_low_delay=7000|state_estimator.legodo.schmitt_high_delay=7000|"
                        "state_estimator.legodo.filter_contact_events=true|state_estimator.legodo.zero_initial_velocity=3");
-  for (const char *s : { "ins", "legodo" }) {
+  param.applyOverrides("state_estimator.fovis.mode=position_orient|state_estimator.fovis.r_pxyz=0.02|state_estimator.fovis.r_chi=0.01");
+  for (const char *s : { "ins", "legodo", "fovis" }) {
     param.set(std::string("state_estimator.") + s + ".downsample_factor", "1");
     param.set(std::string("state_estimator.") + s + ".roll_forward_on_receive", "true");
     param.set(std::string("state_estimator.") + s + ".utime_offset", "0");
@@ -83,9 +85,12 @@ int main(int argc, char **argv)
   FrontEnd front_end(&param);
   auto on_ins = front_end.addSensor("ins", &InsHandler::processMessage, &ins_handler);
   auto on_feet = front_end.addSensor("legodo", &LegOdoHandler::processMessageFeet, &legodo_handler);
+  FovisHandler fovis_handler(&param, /*snapshot_slot=*/0);
+  auto on_fovis = front_end.addSensor("fovis", &FovisHandler::processMessage, &fovis_handler);
   MavStateEstimator est(new RBISResetUpdate(x0, P0, RBISUpdateInterface::reset, 0), &param, 0);
   if (est.last_status != PB_OK) { std::fprintf(stderr, "shim_sweep_rate: %s\n", pb_last_error(est.ctx)); return 1; }
   front_end.setStateEstimator(&est);
+  if (vo_every > 0) fovis_handler.markKeyframe(&est);
 
   // one robot's log: a walking gait (left / right foot poses in the body frame, vertical foot forces) and its IMU
   std::vector<double> imu(6 * (size_t) T), feet(14 * (size_t) T), forces(2 * (size_t) T);
@@ -113,6 +118,14 @@ int main(int argc, char **argv)
     on_ins(&im);
     msgs::foot_state_t fs{ utime, BatchArray(&feet[14 * (size_t) k], PB_HOST_BROADCAST), BatchArray(&forces[2 * (size_t) k], PB_HOST_BROADCAST) };
     on_feet(&fs);
+    if (vo_every > 0 && k % vo_every == vo_every - 1) {  // one camera's delta since the last keyframe, for every filter
+      const double vt[3] = { 0.004 * std::sin(0.01 * k), 0.002, -0.001 * std::cos(0.02 * k) };
+      double vq[4];
+      euler_to_quat(0.002 * std::sin(0.03 * k), -0.001, 0.004 * std::cos(0.01 * k), vq);
+      msgs::update_t vo{ utime, fovis_handler.prev_t0_body_utime_, nullptr, BatchArray(vt, PB_HOST_BROADCAST), BatchArray(vq, PB_HOST_BROADCAST) };
+      on_fovis(&vo);
+      fovis_handler.markKeyframe(&est);
+    }
   };
   const int warm = T / 10;
   for (int k = 0; k < warm; k++) feed(k);
@@ -129,8 +142,8 @@ int main(int argc, char **argv)
   bool finite = true;
   for (int b = 0; b < B; b++)
     for (int i = 0; i < n; i++) { sum += std::fabs(head(i, b)); finite = finite && std::isfinite(head(i, b)); }
-  std::printf("shim sweep: %d filters x %d message pairs (n=%d, history_slots=%s): %.1f us per IMU + foot-state pair, "
-              "%.3e filter-steps/s, dropped %lld, checksum %.6g %s\n", B, T - warm, n, slots.c_str(), dt / (T - warm) * 1e6,
+  std::printf("shim sweep: %d filters x %d message pairs (n=%d, history_slots=%s%s): %.1f us per IMU + foot-state pair, "
+              "%.3e filter-steps/s, dropped %lld, checksum %.6g %s\n", B, T - warm, n, slots.c_str(), vo_every > 0 ? (", VO every " + std::to_string(vo_every)).c_str() : "", dt / (T - warm) * 1e6,
               (double) B * (T - warm) / dt, (long long) est.dropped_updates, sum, finite ? "finite" : "NON-FINITE");
   return finite ? 0 : 1;
 }

@@ -379,12 +379,13 @@ public:
   int64_t replayed_updates = 0;                // statistics: updates re-applied because of late arrivals
   int64_t dropped_updates = 0;                 // updates discarded as too old (update_history.cpp:28-39)
   bool derived_history_ = false;               // history_slots / checkpoint cadence were derived from utime_history_span
-  // state_estimator.fuse_ins_legodo = true (this build's addition, off by default): an INS process step is held back
+  // state_estimator.fuse_ins_legodo = true (this build's addition, off by default; works with and without checkpoints): an INS process step is held back
   // until the next update arrives; if that is a velocity measurement on {3,4,5} with a diagonal R (LegOdoCommon's
   // lin_rate) both run as ONE fused kernel (pb_step_legodo: one state round trip instead of two -- 21.7 us instead of
   // 20.2 + 23.6 us at 64k filters).  Only the posterior after the pair exists then, so this is for replays nobody
-  // observes between the two messages; it is ignored when posterior checkpoints are kept (history_slots > 0).
-  // Anything that reads the device (getHeadState, the smoother, FovisHandler) flushes the held step first.
+  // observes between the two messages; with posterior checkpoints (history_slots > 0) the pair is checkpointed as one
+  // update behind its second half (the backward smoother needs every INS posterior and refuses to run with it).
+  // Anything that reads the device (getHeadState, FovisHandler) flushes the held step first.
   bool fuse_ins_legodo = false;
   int64_t fused_pairs = 0;
   // state_estimator.fuse_corrections = true (with fuse_ins_legodo): the fused pair is held back one more message; if
@@ -420,9 +421,11 @@ public:
     if (checkpoint_every < 1) checkpoint_every = 1;
     {
       auto it = param->kv.find("state_estimator.fuse_ins_legodo");
-      fuse_ins_legodo = history_slots == 0 && it != param->kv.end() && (it->second == "true" || it->second == "1");
+      fuse_ins_legodo = it != param->kv.end() && (it->second == "true" || it->second == "1");
+      // (with posterior checkpoints a fused PAIR is checkpointed as one update, behind its second half; the three-message
+      // fusion is for the in-order-only estimator)
       it = param->kv.find("state_estimator.fuse_corrections");
-      fuse_corrections = fuse_ins_legodo && it != param->kv.end() && (it->second == "true" || it->second == "1");
+      fuse_corrections = fuse_ins_legodo && history_slots == 0 && it != param->kv.end() && (it->second == "true" || it->second == "1");
     }
     n = init_state->reset_state.n;
     B = init_state->reset_state.B;
@@ -522,6 +525,12 @@ public:
                 continue;
               }
             }
+            // a fused pair counts as two updates towards the checkpoint cadence and writes its posterior straight into
+            // the slot of its SECOND half (a replay that starts there continues behind the pair)
+            int pslot = -1;
+            if (history_slots > 0 && fusible_pair(imu, nxt->second) && (since_checkpoint += 2) >= checkpoint_every &&
+                (pslot = reserve_slot(nxt->second)) >= 0)
+              pb_set_output_slot(ctx, pslot);
             if (run_fused(imu, nxt->second, rc)) {
               if (rc != PB_OK) {
                 last_status = rc;
@@ -530,6 +539,13 @@ public:
               fused_pairs++;
               device_head = nxt->second;
               head_utime = nxt->second->utime;
+              if (pslot >= 0) {
+                pb_set_output_slot(ctx, -1);
+                rc = pb_state_save(ctx, pslot);  // a no-op: the step wrote there
+                if (rc != PB_OK) last_status = rc;
+                checkpoint_of[nxt->second] = pslot;
+                since_checkpoint = 0;
+              }
               current_it = ++nxt;
               continue;
             }
@@ -618,6 +634,10 @@ public:
   int EKFSmoothBackwardsPass(double dt, const std::function<void(int64_t, int)> &on_smoothed)
   {
     auto &map = history.updateMap;
+    if (fuse_ins_legodo) {
+      fprintf(stderr, "EKFSmoothBackwardsPass: needs the posterior of every INS update; run with state_estimator.fuse_ins_legodo = false\n");
+      return -1;
+    }
     if (free_slots.size() < 2) {
       fprintf(stderr, "EKFSmoothBackwardsPass: needs 2 free checkpoint slots (state_estimator.history_slots)\n");
       return -1;

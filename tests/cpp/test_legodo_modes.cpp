@@ -167,7 +167,7 @@ int main(int argc, char **argv)
                   el / sl < 1e-9 && n_skip > 0 && (omode != 2 || (n_fallback > 0 && n_full > 0)) &&
                   // fusible: every lin_rate message, and in pos_and_lin_rate the messages whose position is bad for
                   // everybody (k % 5 == 4: a pure lin_rate fall-back)
-                  est.fused_pairs == ((fuse && slots == 0) ? (omode == 0 ? T : (omode == 2 ? T / 5 : 0)) : 0);
+                  est.fused_pairs == (fuse ? (omode == 0 ? T : (omode == 2 ? T / 5 : 0)) : 0);
   printf(ok ? "PASS\n" : "FAIL\n");
   return ok ? 0 : 1;
 }

@@ -122,8 +122,8 @@ def test_ins_gravity_initialisation_host_only(oracle):
 def test_legodo_modes_on_gpu(oracle, mode, slots, fuse):
     """LegOdoCommon's other modes, incl. the per-filter pos_and_lin_rate -> lin_rate fall-back (two complementary masked
     updates), with and without posterior checkpoints, vs the oracle's createMeasurement + indexed update.  "fuse": the
-    opt-in state_estimator.fuse_ins_legodo -- every INS step followed by a lin_rate measurement runs as one fused kernel
-    (and is ignored with checkpoints on / for updates that are not fusible)."""
+    opt-in state_estimator.fuse_ins_legodo -- every INS step followed by a lin_rate measurement runs as one fused kernel,
+    with checkpoints too (the pair is checkpointed behind its second half); updates that are not fusible run one by one."""
     exe = build_exe(oracle, "test_legodo_modes")
     r = subprocess.run([exe, mode, str(slots), fuse], capture_output=True, text=True, timeout=300)
     print(r.stdout, r.stderr)
@@ -155,14 +155,16 @@ def test_shim_matches_oracle_on_gpu(oracle, n, fuse):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("checkpoint_every,delay", [(1, 0), (1, 7), (4, 13), (0, 7)])
-def test_delayed_measurements_replay_equals_in_order(oracle, checkpoint_every, delay):
+@pytest.mark.parametrize("checkpoint_every,delay,fuse", [(1, 0, ""), (1, 7, ""), (4, 13, ""), (0, 7, ""), (1, 7, "fuse"), (4, 13, "fuse"),
+                                                         (0, 7, "fuse")])
+def test_delayed_measurements_replay_equals_in_order(oracle, checkpoint_every, delay, fuse):
     """measurements arriving `delay` steps late are inserted at their timestamp and everything
     after them is re-applied from the nearest posterior checkpoint (mav_state_est.cpp:28-80); the head must equal an
     in-order pass (the oracle).  Dense and sparse checkpointing agree; checkpoint_every = 0 sets ONLY utime_history_span,
-    like a reference .cfg: the estimator derives its checkpoint pool and cadence from the span."""
+    like a reference .cfg: the estimator derives its checkpoint pool and cadence from the span.  "fuse": the same with
+    state_estimator.fuse_ins_legodo -- INS + leg-odometry pairs run as one kernel and are checkpointed as one update."""
     exe = build_exe(oracle, "test_history")
-    r = subprocess.run([exe, str(checkpoint_every), str(delay)], capture_output=True, text=True, timeout=300)
+    r = subprocess.run([exe, str(checkpoint_every), str(delay)] + ([fuse] if fuse else []), capture_output=True, text=True, timeout=300)
     print(r.stdout, r.stderr)
     assert r.returncode == 0 and "PASS" in r.stdout, r.stdout + r.stderr
     assert "before the first in history" in r.stderr  # the too-old fix was discarded (update_history.cpp:28-39)
