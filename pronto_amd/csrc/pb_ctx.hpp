@@ -112,6 +112,6 @@ int pbk_update21(pb_ctx *c, int m, const int *idx, const double *z, const double
 // (r2 = [m][B] device diagonal or NULL with rb2 = m broadcast values); -1 = no such kernel, use pbk_update15/21
 // zb / qb: HOST values of a measurement that is the same for every filter (kernel arguments instead of device blocks)
 int pbk_update_ct(pb_ctx *c, int m, const int *idx, const double *z, const double *r2, const double *rb2, const double *qm,
-                  const uint8_t *mask, const double *zb = nullptr, const double *qb = nullptr);
+                  const uint8_t *mask, const double *zb = nullptr, const double *qb = nullptr, const double *rfull = nullptr);
 // pb_smooth.hip
 int pbk_smooth_step(pb_ctx *c, const double *next_pred, const double *next_sm, const double *cur, double *out, double dt);

@@ -45,10 +45,10 @@ static bool same(const int *idx, int m, std::initializer_list<int> l)
 
 // returns PB_OK after a launch, -1 when this (idx, R kind, orientation) combination has no compile-time kernel
 int pbk_update_ct(pb_ctx *c, int m, const int *idx, const double *z, const double *r2, const double *rb2, const double *qm,
-                  const uint8_t *mask, const double *zb, const double *qb)
+                  const uint8_t *mask, const double *zb, const double *qb, const double *rfull)
 {
   CorrArgs ca;
-  ca.z2 = z; ca.r2 = r2; ca.qm2 = qm; ca.mask2 = mask;
+  ca.z2 = z; ca.r2 = r2; ca.qm2 = qm; ca.mask2 = mask; ca.rfull = rfull;
   if (rb2)
     for (int i = 0; i < m; i++) ca.rb2[i] = rb2[i];
   if (zb) {  // one measurement for every filter: host values as kernel arguments

@@ -563,11 +563,16 @@ static int update_common(pb_ctx *c, int m, const int *idx, const double *z, cons
                 { orient ? qm : nullptr, sizeof(double) * 4 * B, 0 }, { mask, B, 0 } };
   rc = stage_in(c, mem, p, 4);
   if (rc) return rc;
-  // the handlers' own index lists with a diagonal R run on the cooperative two-role kernel (no column gather);
+  // the handlers' own index lists run on the compile-time-index kernels (two-role for 15 states, four-wave for 21; no column gather);
   // PRONTO_BATCH_GENERIC_UPDATE=1 forces the run-time-index kernel for A/B runs and tests
   if (!c->generic_update && (rkind == PB_R_DIAG || rkind == PB_R_DIAG_BROADCAST)) {
     rc = pbk_update_ct(c, m, idx, (const double *) p[0].dev, rb ? nullptr : (const double *) p[1].dev, rb,
                        (const double *) p[2].dev, (const uint8_t *) p[3].dev);
+    if (rc >= 0) return rc;
+  }
+  if (!c->generic_update && rkind == PB_R_FULL) {  // a full per-filter R on the handlers' index lists: same kernels
+    rc = pbk_update_ct(c, m, idx, (const double *) p[0].dev, nullptr, nullptr, (const double *) p[2].dev, (const uint8_t *) p[3].dev,
+                       nullptr, nullptr, (const double *) p[1].dev);
     if (rc >= 0) return rc;
   }
   if (c->ns == 15)

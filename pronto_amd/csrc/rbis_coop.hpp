@@ -130,6 +130,7 @@ using CorrPos = Corr<false, 6, 7, 8>;                // idx 9,10,11:       GpsHa
 using CorrPosVel = Corr<false, 6, 7, 8, 0, 1, 2>;    // idx 9,10,11,3,4,5: LegOdoCommon pos_and_lin_rate
 struct CorrInputs {
   double z[6], rd[6], qm[4];
+  double ro[15] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };  // strictly-lower part of a FULL R, packed by rows (i > j: i(i-1)/2 + j)
   bool upd;
 };
 // LDS hand-off of the second update, behind the first one's: L2 (strict lower, packed by rows), id2, yd2, W2 rows, [lli2]
@@ -319,7 +320,7 @@ PB_HD void coop_role_core(LD ld, ST st, XW xw, XR xr, SYNC sync, const StepInput
     for (int i = 0; i < M; i++)
 #pragma unroll
       for (int j = 0; j <= i; j++)
-        S2[pk(i, j)] = Pc[pk(CORR::sub[i], CORR::sub[j])] + (i == j ? (cin.upd ? cin.rd[i] : 1.0) : 0.0);
+        S2[pk(i, j)] = Pc[pk(CORR::sub[i], CORR::sub[j])] + (i == j ? (cin.upd ? cin.rd[i] : 1.0) : (cin.upd ? cin.ro[i * (i - 1) / 2 + j] : 0.0));
     ldlt<M>(S2, d2);
     double quad2 = 0.0, det2 = 1.0;
 #pragma unroll

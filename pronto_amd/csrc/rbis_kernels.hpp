@@ -659,6 +659,8 @@ struct CorrArgs {
   // zbc: ONE measurement for every filter (PB_HOST_BROADCAST): z and the quaternion travel as kernel arguments too
   double zb2[6] = { 0, 0, 0, 0, 0, 0 }, qb2[4] = { 1, 0, 0, 0 };
   int zbc = 0;
+  // rfull: a FULL per-filter R, [m*m][B] column-major (pronto::indexed_measurement_t's R_effective); r2 / rb2 are unused then
+  const double *rfull = nullptr;
 };
 template <int NS, bool UPDATE, int MH = MH_DEFAULT, class CORR = NoCorr, bool PREDICT = true>
 __global__ __launch_bounds__(128, 1) void k_step_coop(const double *st, double *sto, int B,
@@ -714,6 +716,15 @@ __global__ __launch_bounds__(128, 1) void k_step_coop(const double *st, double *
     for (int i = 0; i < CORR::M; i++) {
       cin.z[i] = ca.zbc ? ca.zb2[i] : ldg(rz, i * B8, bo);
       cin.rd[i] = ca.r2 ? ldg(rr, i * B8, bo) : ca.rb2[i];
+    }
+    if (ca.rfull != nullptr) {  // full R (wave-uniform branch): diagonal + strictly-lower part
+      const rsrc_t rf = mkbuf(ca.rfull, (unsigned) (CORR::M * CORR::M) * B8);
+#pragma unroll
+      for (int i = 0; i < CORR::M; i++) {
+        cin.rd[i] = ldg(rf, (unsigned) (i * CORR::M + i) * B8, bo);
+#pragma unroll
+        for (int j = 0; j < i; j++) cin.ro[i * (i - 1) / 2 + j] = ldg(rf, (unsigned) (j * CORR::M + i) * B8, bo);
+      }
     }
 #pragma unroll
     for (int i = 0; i < 4; i++) cin.qm[i] = CORR::ORIENT ? (ca.zbc ? ca.qb2[i] : ldg(rq2, i * B8, bo)) : 0.0;
@@ -833,6 +844,15 @@ __global__ __launch_bounds__(256, 2) void k_update_quad(const double *st, double
     for (int i = 0; i < CORR::M; i++) {
       cin.z[i] = meas ? (ca.zbc ? ca.zb2[i] : ldg(rz, i * B8, bo)) : 0.0;
       cin.rd[i] = meas ? (ca.r2 ? ldg(rr, i * B8, bo) : ca.rb2[i]) : 1.0;
+    }
+    if (meas && ca.rfull != nullptr) {  // full R (wave-uniform branch): diagonal + strictly-lower part
+      const rsrc_t rf = mkbuf(ca.rfull, (unsigned) (CORR::M * CORR::M) * B8);
+#pragma unroll
+      for (int i = 0; i < CORR::M; i++) {
+        cin.rd[i] = ldg(rf, (unsigned) (i * CORR::M + i) * B8, bo);
+#pragma unroll
+        for (int j = 0; j < i; j++) cin.ro[i * (i - 1) / 2 + j] = ldg(rf, (unsigned) (j * CORR::M + i) * B8, bo);
+      }
     }
 #pragma unroll
     for (int i = 0; i < 4; i++) cin.qm[i] = (CORR::ORIENT && meas) ? (ca.zbc ? ca.qb2[i] : ldg(rq2, i * B8, bo)) : 0.0;

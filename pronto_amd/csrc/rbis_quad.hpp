@@ -595,7 +595,7 @@ PB_HD void quad_upd_cc(LD ld, ST st, XW xw, XR xr, SYNC sync, const CorrInputs &
   for (int i = 0; i < M; i++)
 #pragma unroll
     for (int j = 0; j <= i; j++)
-      S2[pk(i, j)] = Pc[pk(CORR::sub[i], CORR::sub[j])] + (i == j ? (cin.upd ? cin.rd[i] : 1.0) : 0.0);
+      S2[pk(i, j)] = Pc[pk(CORR::sub[i], CORR::sub[j])] + (i == j ? (cin.upd ? cin.rd[i] : 1.0) : (cin.upd ? cin.ro[i * (i - 1) / 2 + j] : 0.0));
   ldlt<M>(S2, d2);
   double quad2 = 0.0, det2 = 1.0;
 #pragma unroll

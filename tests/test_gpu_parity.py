@@ -175,6 +175,66 @@ def test_full_r_offdiagonal(pa, oracle):
     assert rel(v, exp_v[:n]) < TOL and rel(P, exp_P[:n, :n]) < TOL and rel(ll, exp_ll) < TOL
 
 
+@pytest.mark.parametrize("n", [15, 21])
+@pytest.mark.parametrize("idx,orient", [([3, 4, 5], False), ([9, 10, 11], False), ([9, 10, 11, 3, 4, 5], False),
+                                        ([9, 10, 11, 6, 7, 8], True), ([9, 10, 11, 8], True)])
+def test_full_r_on_the_handler_index_lists(pa, oracle, n, idx, orient):
+    """PB_R_FULL (pronto::indexed_measurement_t carries a full R_effective; the laser GPF's is genuinely non-diagonal) on the
+    handlers' own index lists: runs on the compile-time-index kernels like a diagonal R does, against the oracle's
+    single-filter entry points; a mask skips a third of the filters."""
+    import ctypes as C
+    B, m = 173, len(idx)
+    rng = np.random.default_rng(n + m)
+    w = Workload(B, n_states=n)
+    est, ob = make_pair(pa, oracle, w, dense_p0=6)
+    q4 = w.process_noise()
+    for k in range(5):
+        lo, mk = w.legodo_block(k)
+        est.step_legodo(w.imu_block(k), lo, mk, q4)
+        ob.predict(w.imu_block(k), q4)
+        ob.update_indexed([3, 4, 5], lo[0:3], lo[3:6], mask=mk)
+    z = np.ascontiguousarray(ob.vec[idx] + 0.05 * rng.normal(size=(m, B)))
+    dq = np.concatenate([np.ones((1, B)), 0.02 * rng.normal(size=(3, B))])
+    dq /= np.linalg.norm(dq, axis=0)
+    a, b_ = ob.quat, dq
+    qm = np.ascontiguousarray(np.stack([a[0] * b_[0] - a[1] * b_[1] - a[2] * b_[2] - a[3] * b_[3],
+                                        a[0] * b_[1] + a[1] * b_[0] + a[2] * b_[3] - a[3] * b_[2],
+                                        a[0] * b_[2] + a[2] * b_[0] + a[3] * b_[1] - a[1] * b_[3],
+                                        a[0] * b_[3] + a[3] * b_[0] + a[1] * b_[2] - a[2] * b_[1]]))
+    A = rng.normal(size=(B, m, m)) * 0.1
+    R = np.einsum("bij,bkj->bik", A, A) + 0.01 * np.eye(m)
+    Rf = np.ascontiguousarray(np.transpose(R, (2, 1, 0)).reshape(m * m, B))  # [c*m+r, b]
+    mask = (np.arange(B) % 3 != 1).astype(np.uint8)
+    est.update_indexed(idx, z, Rf, quat_meas=qm if orient else None, mask=mask)
+    L = oracle.lib()
+    dp = lambda arr: arr.ctypes.data_as(C.POINTER(C.c_double))
+    exp_v, exp_q, exp_P, exp_ll = ob.vec.copy(), ob.quat.copy(), ob.cov.copy(), ob.ll.copy()
+    for b in range(B):
+        if not mask[b]:
+            continue
+        x, Pm = oracle.Rbis(), oracle.Rbim()
+        for i in range(21):
+            x.vec[i] = ob.vec[i, b]
+        for i in range(4):
+            x.quat[i] = ob.quat[i, b]
+        Pm.m[:] = list(np.ascontiguousarray(ob.cov[:, :, b].T).ravel())
+        ll = C.c_double(0)
+        zz = np.ascontiguousarray(z[:, b])
+        Rb = np.ascontiguousarray(R[b].T).ravel()
+        ia = (C.c_int * m)(*idx)
+        if orient:
+            qq = np.ascontiguousarray(qm[:, b])
+            L.po_indexed_orient_update(m, ia, dp(zz), dp(Rb), dp(qq), C.byref(x), C.byref(Pm), float(ob.ll[b]), C.byref(x), C.byref(Pm), C.byref(ll))
+        else:
+            L.po_indexed_update(m, ia, dp(zz), dp(Rb), C.byref(x), C.byref(Pm), float(ob.ll[b]), C.byref(x), C.byref(Pm), C.byref(ll))
+        exp_v[:, b] = x.vec[:]
+        exp_q[:, b] = x.quat[:]
+        exp_P[:, :, b] = np.array(Pm.m[:]).reshape(21, 21).T
+        exp_ll[b] = ll.value
+    v, q, P, ll = est.get_head()
+    assert rel(v, exp_v[:n]) < TOL and rel(q, exp_q) < TOL and rel(P, exp_P[:n, :n]) < TOL and rel(ll, exp_ll) < TOL
+
+
 def test_config3_vo_with_history_snapshot(pa, oracle):
     """BASELINE config 3 in miniature: predict + legodo every step, FovisHandler position_orient every 32nd step
     with T0 taken from the filter's own posterior at the previous VO time (pb_snapshot / pb_compose_delta)."""
