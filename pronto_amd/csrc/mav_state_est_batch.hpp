@@ -1464,11 +1464,14 @@ public:
     zero_initial_velocity--;  // decrement first, then compare (:264-268)
     const int zero = zero_initial_velocity > 0;
     const LegOdoCommon *lc = leg_odo_common_;
+    // (mode lin_rate consumes the measurement block and the mask only: the increment and the status are not written out)
+    const bool lin = lc->mode_ == LegOdoCommon::MODE_LIN_RATE;
+    double *o_delta = lin ? nullptr : d_delta, *o_status = lin ? nullptr : d_status;
     const int lrc = ahead ? pb_legodo_update_after_predict(est->ctx, ahead->imu_block.p, ahead->imu_block.mem, msg->utime, msg->feet.p,
                                                            msg->forces.p, msg->feet.mem, zero, lc->R_legodo_vxyz_,
-                                                           lc->R_legodo_vxyz_uncertain_, d_delta, d_status, d_lo, d_mask)
+                                                           lc->R_legodo_vxyz_uncertain_, o_delta, o_status, d_lo, d_mask)
                           : pb_legodo_update(est->ctx, msg->utime, msg->feet.p, msg->forces.p, msg->feet.mem, zero, lc->R_legodo_vxyz_,
-                                             lc->R_legodo_vxyz_uncertain_, d_delta, d_status, d_lo, d_mask);
+                                             lc->R_legodo_vxyz_uncertain_, o_delta, o_status, d_lo, d_mask);
     if (lrc != PB_OK) {
       fprintf(stderr, "LegOdoHandler: %s\n", pb_last_error(est->ctx));
       return nullptr;
