@@ -66,6 +66,9 @@ int pbk_update_ct(pb_ctx *c, int m, const int *idx, const double *z, const doubl
   else if (orient && same(idx, m, { 9, 10, 11, 8 })) which = 4;
   else if (orient && same(idx, m, { 3, 4, 5, 8 })) which = 5;
   else if (orient && same(idx, m, { 8 })) which = 6;
+  else if (!orient && same(idx, m, { 8, 9, 10, 11 })) which = 7;          // GPF pos_yaw
+  else if (!orient && same(idx, m, { 6, 7, 8, 9, 10, 11 })) which = 8;    // GPF pos_chi
+  else if (!orient && same(idx, m, { 11 })) which = 9;                    // GPF z_only
   if (which < 0) return -1;
   // two-role mapping only (A/B switch): 21 states with six measurement rows spill there; the generic kernel takes them
   if (c->ns == 21 && !c->quad21 && m > 4) return -1;
@@ -77,7 +80,10 @@ int pbk_update_ct(pb_ctx *c, int m, const int *idx, const double *z, const doubl
   case 3: launch_ct_mh<CorrPosOrient>(c, out, ca); break;
   case 4: launch_ct_mh<CorrPosYaw>(c, out, ca); break;
   case 5: launch_ct_mh<CorrVelYaw>(c, out, ca); break;
-  default: launch_ct_mh<CorrYaw>(c, out, ca); break;
+  case 6: launch_ct_mh<CorrYaw>(c, out, ca); break;
+  case 7: launch_ct_mh<CorrGpfYawPos>(c, out, ca); break;
+  case 8: launch_ct_mh<CorrGpfChiPos>(c, out, ca); break;
+  default: launch_ct_mh<CorrGpfZ>(c, out, ca); break;
   }
   LAUNCHCHK(c);
   update_done(c, out);

@@ -128,6 +128,10 @@ using CorrYaw = Corr<true, 5>;                       // idx 8:             ScanM
 using CorrVel = Corr<false, 0, 1, 2>;                // idx 3,4,5:         LegOdoCommon lin_rate, Fovis / ScanMatcher velocity
 using CorrPos = Corr<false, 6, 7, 8>;                // idx 9,10,11:       GpsHandler, Fovis / ScanMatcher position
 using CorrPosVel = Corr<false, 6, 7, 8, 0, 1, 2>;    // idx 9,10,11,3,4,5: LegOdoCommon pos_and_lin_rate
+// the laser / RGB-D GPF's substates (rgbd_gpf_lib.cpp:71-96), plain indexed measurements (chi entries are vector states here)
+using CorrGpfYawPos = Corr<false, 5, 6, 7, 8>;       // idx 8,9,10,11:     pos_yaw
+using CorrGpfChiPos = Corr<false, 3, 4, 5, 6, 7, 8>; // idx 6,7,8,9,10,11: pos_chi
+using CorrGpfZ = Corr<false, 8>;                     // idx 11:            z_only
 struct CorrInputs {
   double z[6], rd[6], qm[4];
   double ro[15] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };  // strictly-lower part of a FULL R, packed by rows (i > j: i(i-1)/2 + j)

@@ -275,7 +275,7 @@ static void update_quad(double *st, long stride, int B, const double *z2, const 
   pthread_barrier_destroy(&bar);
 }
 
-// kind: 0 vel, 1 pos, 2 pos+vel, 3 pos+orient, 4 pos+yaw, 5 vel+yaw, 6 yaw (the handlers' index lists, pb_update_ct.hip)
+// kind: 0 vel, 1 pos, 2 pos+vel, 3 pos+orient, 4 pos+yaw, 5 vel+yaw, 6 yaw, 7-9 the GPF's yaw+pos, chi+pos, z (pb_update_ct.hip)
 extern "C" void hh_update_quad(int kind, double *st, long stride, int B, const double *z2, const double *rd2, const double *qm2,
                                const uint8_t *mask2, double g, double tol)
 {
@@ -286,7 +286,10 @@ extern "C" void hh_update_quad(int kind, double *st, long stride, int B, const d
   case 3: update_quad<CorrPosOrient>(st, stride, B, z2, rd2, qm2, mask2, g, tol); break;
   case 4: update_quad<CorrPosYaw>(st, stride, B, z2, rd2, qm2, mask2, g, tol); break;
   case 5: update_quad<CorrVelYaw>(st, stride, B, z2, rd2, qm2, mask2, g, tol); break;
-  default: update_quad<CorrYaw>(st, stride, B, z2, rd2, qm2, mask2, g, tol); break;
+  case 6: update_quad<CorrYaw>(st, stride, B, z2, rd2, qm2, mask2, g, tol); break;
+  case 7: update_quad<CorrGpfYawPos>(st, stride, B, z2, rd2, qm2, mask2, g, tol); break;
+  case 8: update_quad<CorrGpfChiPos>(st, stride, B, z2, rd2, qm2, mask2, g, tol); break;
+  default: update_quad<CorrGpfZ>(st, stride, B, z2, rd2, qm2, mask2, g, tol); break;
   }
 }
 

@@ -177,7 +177,8 @@ def test_full_r_offdiagonal(pa, oracle):
 
 @pytest.mark.parametrize("n", [15, 21])
 @pytest.mark.parametrize("idx,orient", [([3, 4, 5], False), ([9, 10, 11], False), ([9, 10, 11, 3, 4, 5], False),
-                                        ([9, 10, 11, 6, 7, 8], True), ([9, 10, 11, 8], True)])
+                                        ([9, 10, 11, 6, 7, 8], True), ([9, 10, 11, 8], True),
+                                        ([8, 9, 10, 11], False), ([6, 7, 8, 9, 10, 11], False), ([11], False)])  # (the GPF's substates)
 def test_full_r_on_the_handler_index_lists(pa, oracle, n, idx, orient):
     """PB_R_FULL (pronto::indexed_measurement_t carries a full R_effective; the laser GPF's is genuinely non-diagonal) on the
     handlers' own index lists: runs on the compile-time-index kernels like a diagonal R does, against the oracle's

@@ -184,15 +184,16 @@ def test_cooperative_roles_with_fused_correction_match_oracle(oracle, harness, n
     assert rel(ll, ob.ll) < 1e-11
 
 
-@pytest.mark.parametrize("kind", range(7))
+@pytest.mark.parametrize("kind", range(10))
 def test_four_wave_stand_alone_updates_match_oracle(oracle, harness, kind):
     """rbis_quad.hpp quad_upd_*: the handlers' seven index lists as stand-alone updates on the four-wave mapping (one
     barrier), between four-wave steps, against the oracle's indexed (+ orientation) update; masks exercised."""
     H = harness
     g, tol = oracle.constants()
     ns, B, T = 21, 24, 40
-    idx = [[3, 4, 5], [9, 10, 11], [9, 10, 11, 3, 4, 5], [9, 10, 11, 6, 7, 8], [9, 10, 11, 8], [3, 4, 5, 8], [8]][kind]
-    orient = kind >= 3
+    idx = [[3, 4, 5], [9, 10, 11], [9, 10, 11, 3, 4, 5], [9, 10, 11, 6, 7, 8], [9, 10, 11, 8], [3, 4, 5, 8], [8],
+           [8, 9, 10, 11], [6, 7, 8, 9, 10, 11], [11]][kind]
+    orient = 3 <= kind <= 6
     m = len(idx)
     w = Workload(B, n_states=ns)
     vec, quat, P0 = w.initial_state()
