@@ -870,3 +870,44 @@ def test_handler_index_lists_on_the_cooperative_update_kernel(pa, oracle, n, mon
         check(e, ob)
     for a, b in zip(ests[0].get_head(), ests[1].get_head()):
         assert rel(a, b) < 1e-12
+
+
+@pytest.mark.parametrize("n", [15, 21])
+def test_split_space_step_equals_the_plain_step(pa, oracle, n):
+    """pb_step_legodo_split: the IMU block and the leg-odometry block (+ mask) in different memory spaces -- host / device,
+    device / host, broadcast / device, device / broadcast -- must give bit-identical results to the same numbers passed
+    as per-filter device blocks."""
+    import torch
+    B = 300
+    dev = torch.device("cuda:0")
+    w = Workload(B, n_states=n)
+    vec, quat, P0 = w.initial_state()
+    q4 = w.process_noise()
+    ref = pa.BatchEstimator(B, n_states=n)
+    alt = pa.BatchEstimator(B, n_states=n)
+    for e in (ref, alt):
+        e.set_constants(*oracle.constants())
+        e.reset(vec, quat, P0)
+    tile = lambda a: np.ascontiguousarray(np.repeat(np.asarray(a, dtype=np.float64)[:, None], B, axis=1))
+    for k in range(24):
+        imu = w.imu_block(k)
+        lo, mask = w.legodo_block(k)
+        case = k % 4
+        if case == 2:   # one IMU message for everybody
+            imu = tile(imu[:, 0])
+        if case == 3:   # one measurement for everybody, no mask
+            lo, mask = tile(lo[:, 0]), None
+        d_imu, d_lo = torch.from_numpy(imu).to(dev), torch.from_numpy(lo).to(dev)
+        d_mask = None if mask is None else torch.from_numpy(mask).to(dev)
+        ref.step_legodo(d_imu, d_lo, d_mask, q4)
+        if case == 0:
+            alt.step_legodo(imu, d_lo, d_mask, q4)                                   # host / device
+        elif case == 1:
+            alt.step_legodo(d_imu, lo, mask, q4)                                     # device / host
+        elif case == 2:
+            alt.step_legodo(np.ascontiguousarray(imu[:, 0]), d_lo, d_mask, q4)       # broadcast / device
+        else:
+            alt.step_legodo(d_imu, np.ascontiguousarray(lo[:, 0]), None, q4)         # device / broadcast
+    for a, b in zip(ref.get_head(), alt.get_head()):
+        assert np.array_equal(a, b)
+    ref.close(); alt.close()
