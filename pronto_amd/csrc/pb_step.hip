@@ -95,6 +95,7 @@ int pbk_step_correct(pb_ctx *c, int corr_kind, const double *imu, const double *
     if (slot >= 0) c->out_slot = slot;
     rc = pbk_update_ct(c, m2, idx2, z2, r2, rb2, qm2, mask2, zb, qb);
     if (rc >= 0) return rc;
+    if (!z2 || !qm2) return fail(c, PB_ERR_ARG, "pb_step_legodo_correct: no kernel takes this correction as arguments; stage the blocks");
     return pbk_update21(c, m2, idx2, z2, r2 ? r2 : rb2, r2 ? PB_R_DIAG : PB_R_DIAG_BROADCAST, r2 ? nullptr : rb2, qm2, mask2);
   }
   CorrArgs ca;

@@ -435,7 +435,10 @@ extern "C" int pb_step_legodo_correct(pb_ctx *c, const double *imu_block, const 
   const int m2 = (corr_kind == PB_CORR_POS_ORIENT) ? 6 : 4;
   const size_t B = (size_t) c->B;
   const bool rbc = r_kind2 == PB_R_DIAG_BROADCAST;
-  if (mem == PB_HOST_BROADCAST && mem2 == PB_HOST_BROADCAST && rbc && !mask && !mask2) {
+  // (the two-wave 21-state mapping, PRONTO_BATCH_QUAD21=0, has no m = 6 kernel that takes z / quat_meas as arguments:
+  // its correction falls back to the generic update, which needs the replicated blocks staged below)
+  const bool arg_kernel = c->ns == 15 || c->quad21 || m2 <= 4;
+  if (mem == PB_HOST_BROADCAST && mem2 == PB_HOST_BROADCAST && rbc && !mask && !mask2 && arg_kernel) {
     // one robot's three messages for every filter: everything travels as kernel arguments
     StepBcast bc;
     memcpy(bc.imu, imu_block, sizeof(bc.imu));

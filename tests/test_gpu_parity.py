@@ -593,12 +593,16 @@ def test_every_kernel_variant_is_bit_identical(pa, oracle, n, B, kern, monkeypat
             est.close()
 
 
-@pytest.mark.parametrize("n", [15, 21])
-def test_broadcast_inputs_equal_replicated_blocks(pa, oracle, n):
+@pytest.mark.parametrize("n,default_kernels", [(15, True), (21, True), (15, False), (21, False)])
+def test_broadcast_inputs_equal_replicated_blocks(pa, oracle, n, default_kernels, monkeypatch):
     """PB_HOST_BROADCAST: one message for every filter of the batch (a parameter sweep replaying one robot's log) passed
     as [rows] host values must give bit-identical results to the same values replicated into [rows, B] blocks; a mask
-    cannot be broadcast."""
+    cannot be broadcast.  Also on the A/B kernels (one-lane 15-state step, two-wave 21-state step), where the m = 6
+    correction has no kernel taking its measurement as arguments and the broadcast blocks must be staged instead."""
     import torch
+    if not default_kernels:
+        monkeypatch.setenv("PRONTO_BATCH_COOP15", "0")
+        monkeypatch.setenv("PRONTO_BATCH_QUAD21", "0")
     B = 333
     w = Workload(B, n_states=n)
     vec, quat, P0 = w.initial_state()
