@@ -4,20 +4,21 @@
 
 int pbk_smooth_step(pb_ctx *c, const double *np_, const double *ns_, const double *cu, double *out, double dt)
 {
+  static const size_t pad = getenv("PRONTO_SMOOTH_LDS_PAD") ? (size_t) atoi(getenv("PRONTO_SMOOTH_LDS_PAD")) : 0;  // EXPERIMENT
   if (!c->smooth_attr) {  // more than the default 64 KB of dynamic LDS per workgroup
     HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_smooth_reg<15>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int) (sizeof(double) * SmoothRegCfg<15>::LDS_DOUBLES)));
+                                  (int) (pad + sizeof(double) * SmoothRegCfg<15>::LDS_DOUBLES)));
     HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_smooth_reg<21>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int) (sizeof(double) * SmoothRegCfg<21>::LDS_DOUBLES)));
+                                  (int) (pad + sizeof(double) * SmoothRegCfg<21>::LDS_DOUBLES)));
     c->smooth_attr = true;
   }
   if (c->ns == 15) {
     using S = SmoothRegCfg<15>;
-    k_smooth_reg<15><<<(c->B + S::F - 1) / S::F, S::THREADS, sizeof(double) * S::LDS_DOUBLES, c->stream>>>(
+    k_smooth_reg<15><<<(c->B + S::F - 1) / S::F, S::THREADS, pad + sizeof(double) * S::LDS_DOUBLES, c->stream>>>(
         np_, ns_, cu, out, c->B, dt, c->k);
   } else {
     using S = SmoothRegCfg<21>;
-    k_smooth_reg<21><<<(c->B + S::F - 1) / S::F, S::THREADS, sizeof(double) * S::LDS_DOUBLES, c->stream>>>(
+    k_smooth_reg<21><<<(c->B + S::F - 1) / S::F, S::THREADS, pad + sizeof(double) * S::LDS_DOUBLES, c->stream>>>(
         np_, ns_, cu, out, c->B, dt, c->k);
   }
   LAUNCHCHK(c);

@@ -86,6 +86,13 @@ __device__ __forceinline__ void lds_st2(double *p, double a, double b)
   *reinterpret_cast<d2_t *>(__builtin_assume_aligned(p, 16)) = v;
 }
 
+// v_mfma_f64_16x16x4_f64 (one 16 x 16 x 4 product per wave; maps checked by scripts/mfma_f64_probe.hip): lane l supplies
+// A[l & 15][l >> 4] and B[l >> 4][l & 15] and receives D[(l >> 4) + 4 v][l & 15] in result register v = 0..3.
+typedef double d4_t __attribute__((ext_vector_type(4)));
+// Column c of an n <= 16 row sits at position mfma_pos(c): the four k = h, h + 4, h + 8, h + 12 that lane group h = l >> 4
+// supplies to the four MFMAs of a 16-deep product are then 32 contiguous bytes (two ds_read_b128).
+__host__ __device__ constexpr int mfma_pos(int c) { return 4 * (c % 4) + c / 4; }
+
 // End of one unrolled step: the scheduling barrier keeps later steps' LDS reads from being hoisted to the top, the
 // memory clobber makes a re-read in a later phase a real LDS read instead of a value kept in a register since its first use.
 __device__ __forceinline__ void step_fence()
@@ -102,18 +109,35 @@ __device__ __forceinline__ double row_ror_d(double v)
 {
   return __hiloint2double(row_ror_i<S>(__double2hiint(v)), row_ror_i<S>(__double2loint(v)));
 }
-// one butterfly stage of the pivot search: keep the larger |d|, on ties the smaller key (= current position * 32 + lane)
-__device__ __forceinline__ void pivot_take(double &cs, int &key, double os, int okey)
-{
-  // bitwise, not short-circuit: `||` / `&&` became two branches per stage
-  const bool take = (fabs(os) > fabs(cs)) | ((fabs(os) == fabs(cs)) & (okey < key));
-  cs = take ? os : cs;
-  key = take ? okey : key;
-}
+// Pivot search of one factorisation step over the G lanes of a group (Eigen's rule: the largest remaining |A_ii|, ties to
+// the smallest CURRENT position).  Two all-reduces over row rotations instead of one (value, key) butterfly with a compare /
+// select chain per stage: the maximum of |d| (two DPP moves + v_max_f64 per stage), then the minimum key among the lanes
+// that hold exactly that value (v_min_u32 with a DPP operand).  The key carries the sign of the winner's d in its lowest
+// bit, so every lane can rebuild the signed pivot without another exchange.
 template <int S>
-__device__ __forceinline__ void pivot_stage(double &cs, int &key)
+__device__ __forceinline__ double max_stage(double v) { return fmax(v, row_ror_d<S>(v)); }
+template <int S>
+__device__ __forceinline__ unsigned min_stage(unsigned v)
 {
-  pivot_take(cs, key, row_ror_d<S>(cs), row_ror_i<S>(key));
+  const unsigned o = (unsigned) row_ror_i<S>((int) v);
+  return o < v ? o : v;
+}
+
+// 32-lane groups (21 states): the last stage joins the two 16-lane rows of a group.  gfx950's v_permlane16_swap exchanges
+// the odd rows of one register with the even rows of another: applied to two copies of v it leaves the even row's value
+// in both rows of one result and the odd row's value in both rows of the other -- a VALU instruction where __shfl_xor(v, 16)
+// is an LDS-crossbar round trip (ds_bpermute) on the factorisation's critical path.
+__device__ __forceinline__ double rowpair_max(double v)
+{
+  const unsigned hi = (unsigned) __double2hiint(v), lo = (unsigned) __double2loint(v);
+  const auto h = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  const auto l = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  return fmax(__hiloint2double((int) h[0], (int) l[0]), __hiloint2double((int) h[1], (int) l[1]));
+}
+__device__ __forceinline__ unsigned rowpair_min(unsigned v)
+{
+  const auto x = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+  return x[0] < x[1] ? x[0] : x[1];
 }
 
 template <int NS>
@@ -126,6 +150,8 @@ __global__ __launch_bounds__(256, 2) void k_smooth_reg(const double *__restrict_
   using SL = Slots<NS>;
   using C = SmoothRegCfg<NS>;
   constexpr int G = C::G, F = C::F, PITCH = C::PITCH, PG = C::PG, MATP = C::MATP;
+  constexpr bool MFMA = (NS <= 16);  // the two n x n products of step 5 on v_mfma_f64_16x16x4 (one 16 x 16 tile per filter)
+  static_assert(!MFMA || (G == 16 && PG >= 16), "one filter per 16-lane group, rows padded to 16 columns");
   static_assert(NS < 24 && C::U_DOUBLES >= F * PITCH + C::THREADS, "buffer slots");
   extern __shared__ __attribute__((aligned(16))) double lds[];
   double *U = lds + F * C::RB, *DP = U + C::U_DOUBLES;  // [small buffers | staging / x / L / gain | D packed]
@@ -217,13 +243,25 @@ __global__ __launch_bounds__(256, 2) void k_smooth_reg(const double *__restrict_
     // row, bitwise symmetric because both (r,j) and (j,r) subtract the same two packed entries
     double *const drow = row ? Df + rr * PG : Rf;  // padding lanes: the pivot-row buffer is not in use yet
     auto pminus = [&](int j) { return (NS == 21 && j >= 15) ? am_raw[j - 15] : am[j]; };
+    if constexpr (MFMA) {  // columns in mfma_pos order (pairs (j, j + 4) are neighbours there); column 15 = 0
+      auto dval = [&](int j) { return j < NS ? Uf[poff[j < NS ? j : 0]] - pminus(j < NS ? j : 0) : 0.0; };
+      static_for<8>([&](auto JJ) {
+        constexpr int j = (decltype(JJ)::value % 4) + 8 * (decltype(JJ)::value / 4);
+        lds_st2(drow + mfma_pos(j), dval(j), dval(j + 4));
+      });
+    } else {
 #pragma unroll
-    for (int j = 0; j + 1 < NS; j += 2) lds_st2(drow + j, Uf[poff[j]] - pminus(j), Uf[poff[j + 1]] - pminus(j + 1));
-    if (NS & 1) drow[NS - 1] = Uf[poff[NS - 1]] - pminus(NS - 1);
+      for (int j = 0; j + 1 < NS; j += 2) lds_st2(drow + j, Uf[poff[j]] - pminus(j), Uf[poff[j + 1]] - pminus(j + 1));
+      if (NS & 1) drow[NS - 1] = Uf[poff[NS - 1]] - pminus(NS - 1);
+    }
     double qs[4], dchi[3];
 #pragma unroll
     for (int i = 0; i < 4; i++) qs[i] = Uf[L::OFF_QUAT + i];
+#ifdef SM_SKIP_QUAT
+    dchi[0] = qs[1] - qp[1]; dchi[1] = qs[2] - qp[2]; dchi[2] = qs[3] - qp[3];
+#else
     subtract_quats(qs, qp, dchi);  // chi = Log(q^-^-1 q^s)   (rbis.cpp:259-261)
+#endif
     double res = Uf[L::OFF_VEC + rr] - xpr;
     if (rr >= 6 && rr <= 8) res = (rr == 6) ? dchi[0] : (rr == 7 ? dchi[1] : dchi[2]);
     Rf[row ? C::RB_RES + rr : NS] = res;
@@ -231,6 +269,17 @@ __global__ __launch_bounds__(256, 2) void k_smooth_reg(const double *__restrict_
   __syncthreads();
   commit(vc);
   __syncthreads();
+#ifdef SM_COPY_ONLY
+  if (b0 + sf < B) {
+#pragma unroll 4
+    for (int r2 = sc; r2 < SL::NROW; r2 += G) {
+      const int c0 = SL::T.comp_of[2 * r2], c1 = SL::T.comp_of[2 * r2 + 1];
+      const d2_t v2 = { U[sf * PITCH + c0] + am[0], c1 >= 0 ? U[sf * PITCH + c1] : 0.0 };
+      *reinterpret_cast<d2_t *>(out + srow0 + (long) r2 * 128) = v2;
+    }
+  }
+  return;
+#endif
   double w[3], v[3], q[4];
 #pragma unroll
   for (int j = 0; j < NS; j++) prow[j] = Uf[poff[j]];
@@ -242,6 +291,18 @@ __global__ __launch_bounds__(256, 2) void k_smooth_reg(const double *__restrict_
 #pragma unroll
   for (int i = 0; i < 4; i++) q[i] = Uf[L::OFF_QUAT + i];
   const double xcur = Uf[L::OFF_VEC + rr], llcur = Uf[L::OFF_LL];
+  // 15 states: P_k of the four filters of this wave in the MFMA result layout (the accumulator of step 5)
+  const int mh = (t >> 4) & 3, mj = (r < NS) ? r : NS - 1, fw = f & ~3;
+  d4_t acc[MFMA ? 4 : 1];
+  if constexpr (MFMA) {
+#pragma unroll
+    for (int ff = 0; ff < 4; ff++)
+#pragma unroll
+      for (int v = 0; v < 4; v++) {
+        const int i = (mh + 4 * v < NS) ? mh + 4 * v : NS - 1;  // row / column 15 do not exist: never stored
+        acc[ff][v] = U[(fw + ff) * PITCH + L::OFF_P + pk_rt(i, mj)];
+      }
+  }
   double chi_cur[3];
 #pragma unroll
   for (int i = 0; i < 3; i++) chi_cur[i] = Uf[L::OFF_VEC + 6 + i];
@@ -259,19 +320,29 @@ __global__ __launch_bounds__(256, 2) void k_smooth_reg(const double *__restrict_
     int pos = r;                 // current position of this row under Eigen's swaps (tie-break only)
     static_for<NS>([&](auto KK) {
       constexpr int kk = decltype(KK)::value;
-      double cs = done ? 0.0 : dg;
-      int key = done ? ((1 << 20) + r) : (pos * 32 + r);
-      pivot_stage<1>(cs, key);
-      pivot_stage<2>(cs, key);
-      pivot_stage<4>(cs, key);
-      pivot_stage<8>(cs, key);
-      if constexpr (G == 32) pivot_take(cs, key, __shfl_xor(cs, 16), __shfl_xor(key, 16));
-      const int p = key & 31;    // pivot row (= lane of the group), identical in all lanes of the group
+#ifdef SM_SKIP_FACT
+      piv[kk] = kk; if (r == kk) mypos = kk; if constexpr (KEEP_L) lreg[kk] = 0.0; Rf[C::RB_INV + kk] = 1.0; return;
+#endif
+      // candidates: |d| >= 0; rows pivoted earlier and the padding lanes: -1 (never the maximum while a row remains)
+      const double ad = done ? -1.0 : fabs(dg);
+      double mx = max_stage<1>(ad);
+      mx = max_stage<2>(mx);
+      mx = max_stage<4>(mx);
+      mx = max_stage<8>(mx);
+      if constexpr (G == 32) mx = rowpair_max(mx);
+      unsigned key = (!done & (ad == mx)) ? (unsigned) ((pos * 32 + r) * 2 + (dg < 0.0 ? 1 : 0)) : (0x40000000u + 2u * (unsigned) r);
+      key = min_stage<1>(key);
+      key = min_stage<2>(key);
+      key = min_stage<4>(key);
+      key = min_stage<8>(key);
+      if constexpr (G == 32) key = rowpair_min(key);
+      const double cs = (key & 1u) ? -mx : mx;  // the pivot, signed
+      const int p = (int) (key >> 1) & 31;      // pivot row (= lane of the group), identical in all lanes of the group
       const bool is_p = (r == p);
       piv[kk] = p;
       const double inv = (fabs(cs) > 5.562684646268003e-309) ? 1.0 / cs : 0.0;  // Eigen's solve() tolerance: 1/highest
       // Eigen swaps position kk with the pivot's position: the row sitting at kk inherits the pivot's old position
-      if (!done && pos == kk) pos = key >> 5;
+      if (!done && pos == kk) pos = (int) (key >> 6);
       if (is_p) {
 #pragma unroll
         for (int j = 0; j + 1 < NS; j += 2) lds_st2(Rf + j, am[j], am[j + 1]);
@@ -349,6 +420,9 @@ __global__ __launch_bounds__(256, 2) void k_smooth_reg(const double *__restrict_
   group_sync();
   static_for<NS>([&](auto KK) {  // forward: z[kk] -= sum_{m<kk} L[kk][m] z[m], row kk read 16 bytes at a time
     constexpr int kk = decltype(KK)::value;
+#ifdef SM_SKIP_SUBST
+    return;
+#endif
     double s = z[kk];
 #pragma unroll
     for (int m = 0; m < kk; m += 2) {
@@ -372,6 +446,9 @@ __global__ __launch_bounds__(256, 2) void k_smooth_reg(const double *__restrict_
   group_sync();
   static_for<NS>([&](auto KR) {  // backward: z[kk] -= sum_{m>kk} L[m][kk] z[m]
     constexpr int kk = NS - 1 - decltype(KR)::value;
+#ifdef SM_SKIP_SUBST
+    return;
+#endif
     double s = z[kk];
 #pragma unroll
     for (int m = (kk + 1) & ~1; m < NS; m += 2) {
@@ -385,19 +462,59 @@ __global__ __launch_bounds__(256, 2) void k_smooth_reg(const double *__restrict_
   group_sync();  // every lane of the group is done reading L^T
   // z[kk] = ((P^-)^-1 T[:,r])_{piv[kk]} = G[r][piv[kk]]; published TRANSPOSED (Gt[i][r] = G[r][i]) so that step 5
   // reads a row, and read back in row order for this lane's own gain row
-  {
+  double gain[NS];
+  if constexpr (MFMA) {
+    // 15 states: by rows, columns in mfma_pos order, column 15 = 0 (operand of the matrix instructions of step 5)
+    double *const gr = row ? Lf + rr * PG : Rf + NS;
+#pragma unroll
+    for (int kk = 0; kk < NS; kk++) gr[one * (((piv[kk] & 3) << 2) | (piv[kk] >> 2))] = z[kk];
+    gr[one * 15] = 0.0;
+    group_sync();
+#pragma unroll
+    for (int c = 0; c < 16; c += 2) {
+      const d2_t gv = lds_ld2(Lf + rr * PG + c);
+      // position c holds column (c % 4) * 4 + c / 4 ... inverse of mfma_pos: column = 4 * (c % 4) + c / 4 as well
+      if (mfma_pos(c) < NS) gain[mfma_pos(c)] = gv.x;
+      if (mfma_pos(c + 1) < NS) gain[mfma_pos(c + 1)] = gv.y;
+    }
+  } else {
     double *const gt = row ? Lf + rr : Rf + NS;
     const int step = row ? PG : 0;
 #pragma unroll
     for (int kk = 0; kk < NS; kk++) gt[step * piv[kk]] = z[kk];
-  }
-  group_sync();
-  double gain[NS];
+    group_sync();
 #pragma unroll
-  for (int i = 0; i < NS; i++) gain[i] = Lf[i * PG + rr];
+    for (int i = 0; i < NS; i++) gain[i] = Lf[i * PG + rr];
+  }
   step_fence();
 
   // ---- 5. P^s_row = P_row + (g D) G^T: row bcol of D (symmetric) and row bcol of Gt, 16 bytes at a time ----
+  if constexpr (MFMA) {
+    // 15 states on the matrix pipe: F = D G^T, then P^s = P_k + G F, one 16 x 16 x 16 product = four v_mfma_f64_16x16x4 each,
+    // for the four filters of this wave (independent chains).  Lane (h, j) supplies D[j][h + 4 s] and G[j][h + 4 s]
+    // (s = 0..3: contiguous in mfma_pos order), F's result register s IS the B operand of k-slice s of the second product.
+#ifndef SM_SKIP_PROD
+    d4_t gq[4], dq[4];
+#pragma unroll
+    for (int ff = 0; ff < 4; ff++) {
+      const double *const gp = U + (fw + ff) * C::U_PER + mj * PG + 4 * mh, *const dp = DP + (fw + ff) * C::D_PER + mj * PG + 4 * mh;
+      const d2_t g0 = lds_ld2(gp), g1 = lds_ld2(gp + 2), d0 = lds_ld2(dp), d1 = lds_ld2(dp + 2);
+      gq[ff] = d4_t{ g0.x, g0.y, g1.x, g1.y };
+      dq[ff] = d4_t{ d0.x, d0.y, d1.x, d1.y };
+    }
+    d4_t fq[4];
+#pragma unroll
+    for (int ff = 0; ff < 4; ff++) fq[ff] = d4_t{ 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+    for (int s4 = 0; s4 < 4; s4++)
+#pragma unroll
+      for (int ff = 0; ff < 4; ff++) fq[ff] = __builtin_amdgcn_mfma_f64_16x16x4f64(dq[ff][s4], gq[ff][s4], fq[ff], 0, 0, 0);
+#pragma unroll
+    for (int s4 = 0; s4 < 4; s4++)
+#pragma unroll
+      for (int ff = 0; ff < 4; ff++) acc[ff] = __builtin_amdgcn_mfma_f64_16x16x4f64(gq[ff][s4], fq[ff][s4], acc[ff], 0, 0, 0);
+#endif
+  } else {
 #pragma unroll
   for (int bcol = 0; bcol < NS; bcol++) {
     double ub = 0.0;
@@ -415,6 +532,7 @@ __global__ __launch_bounds__(256, 2) void k_smooth_reg(const double *__restrict_
     }
     step_fence();
   }
+  }
   // ---- 6. state: dx = G resid; cur.addState(RBIS(dx))  (rbis.cpp:263-265) ----
   double dx = 0.0;
 #pragma unroll
@@ -425,18 +543,32 @@ __global__ __launch_bounds__(256, 2) void k_smooth_reg(const double *__restrict_
   // staging layout): with the stores inside `if (row && m <= rr)` the compiler sinks all the multiply-adds of step 5
   // into that block, below the barrier, and keeps every LDS operand they need alive (or spilled) until then.
   const int dummy = F * PITCH + t;
+  if constexpr (MFMA) {  // lane (h, j) holds P^s[h + 4 v][j] of the wave's four filters: the lower triangle goes out
 #pragma unroll
-  for (int m = 0; m < NS; m++) U[(row && m <= rr) ? f * PITCH + poff[m] : dummy] = prow[m];
+    for (int ff = 0; ff < 4; ff++)
+#pragma unroll
+      for (int v = 0; v < 4; v++) {
+        const int i = mh + 4 * v;
+        U[(i < NS && r <= i) ? (fw + ff) * PITCH + L::OFF_P + i * (i + 1) / 2 + r : dummy] = acc[ff][v];
+      }
+  } else {
+#pragma unroll
+    for (int m = 0; m < NS; m++) U[(row && m <= rr) ? f * PITCH + poff[m] : dummy] = prow[m];
+  }
   U[(row && !(rr >= 6 && rr <= 8)) ? f * PITCH + L::OFF_VEC + rr : dummy] = xcur + dx;
   if (r == 0) {
     double dchi[3] = { Rf[C::RB_DX + 6], Rf[C::RB_DX + 7], Rf[C::RB_DX + 8] };
     double dq[4] = { 1.0, 0.0, 0.0, 0.0 };
+#ifndef SM_SKIP_QUAT
     fold_chi(dchi, dq, k.chi_tol);  // RBIS(vec) constructor
+#endif
     double chi[3];
 #pragma unroll
     for (int i = 0; i < 3; i++) chi[i] = chi_cur[i] + dchi[i];
     double qq[4] = { q[0], q[1], q[2], q[3] };
+#ifndef SM_SKIP_QUAT
     fold_chi(chi, qq, k.chi_tol);
+#endif
     double o[4];
     quat_mul(qq, dq, o);
 #pragma unroll
