@@ -9,7 +9,10 @@
 // is the wrong shape: a GROUP of G = 16 / 32 lanes owns one filter, lane r owns matrix row r (k_smooth_reg below).
 // The reference calls Eigen's .ldlt(): the kernel keeps Eigen's diagonal pivoting (same pivot order keeps parity at
 // 1e-15 instead of cond(P^-) * eps).
-// fp64 MFMA brings nothing here on MI355X (its f64 matrix rate equals the vector rate), so this is VALU + LDS.
+// The factorisation and the substitutions are VALU + LDS; the two n x n products of the 15-state kernel run on the matrix
+// pipe (v_mfma_f64_16x16x4_f64, one 16 x 16 tile per filter, step 5): its fp64 rate equals the vector rate on MI355X, the
+// gain is the VALU / LDS work and the row registers it takes away, not arithmetic throughput.
+// Build flags SM_SKIP_* / SM_NO_* / SM_COPY_ONLY / SM_EMPTY compile parts out for scripts/smooth_attribution.sh (timing only).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -154,6 +157,9 @@ __global__ __launch_bounds__(256, 2) void k_smooth_reg(const double *__restrict_
   static_assert(!MFMA || (G == 16 && PG >= 16), "one filter per 16-lane group, rows padded to 16 columns");
   static_assert(NS < 24 && C::U_DOUBLES >= F * PITCH + C::THREADS, "buffer slots");
   extern __shared__ __attribute__((aligned(16))) double lds[];
+#ifdef SM_EMPTY  // workgroup dispatch cost alone: same registers, same LDS request, no work
+  if (B > 0) return;
+#endif
   double *U = lds + F * C::RB, *DP = U + C::U_DOUBLES;  // [small buffers | staging / x / L / gain | D packed]
   const int t = threadIdx.x;
   const int f = t / G, r = t % G;        // compute mapping: filter slot f, matrix row r
@@ -179,7 +185,11 @@ __global__ __launch_bounds__(256, 2) void k_smooth_reg(const double *__restrict_
 #pragma unroll
     for (int i = 0; i < NST; i++) {
       const int r2 = sc + i * G;
+#ifdef SM_NO_LOAD
+      v[i] = d2_t{ 1.0 + 0.001 * r2 + 1e-6 * threadIdx.x, 0.5 + 0.002 * r2 };
+#else
       v[i] = (r2 < SL::NROW) ? *reinterpret_cast<const d2_t *>(src + srow0 + (long) r2 * 128) : d2_t{ 0.0, 0.0 };
+#endif
     }
   };
   auto commit = [&](const d2_t (&v)[NST]) {
@@ -515,6 +525,7 @@ __global__ __launch_bounds__(256, 2) void k_smooth_reg(const double *__restrict_
       for (int ff = 0; ff < 4; ff++) acc[ff] = __builtin_amdgcn_mfma_f64_16x16x4f64(gq[ff][s4], fq[ff][s4], acc[ff], 0, 0, 0);
 #endif
   } else {
+#ifndef SM_SKIP_PROD
 #pragma unroll
   for (int bcol = 0; bcol < NS; bcol++) {
     double ub = 0.0;
@@ -532,6 +543,7 @@ __global__ __launch_bounds__(256, 2) void k_smooth_reg(const double *__restrict_
     }
     step_fence();
   }
+#endif
   }
   // ---- 6. state: dx = G resid; cur.addState(RBIS(dx))  (rbis.cpp:263-265) ----
   double dx = 0.0;
@@ -583,7 +595,11 @@ __global__ __launch_bounds__(256, 2) void k_smooth_reg(const double *__restrict_
     for (int r2 = sc; r2 < SL::NROW; r2 += G) {
       const int c0 = SL::T.comp_of[2 * r2], c1 = SL::T.comp_of[2 * r2 + 1];
       const d2_t v2 = { U[sf * PITCH + c0], c1 >= 0 ? U[sf * PITCH + c1] : 0.0 };
+#ifdef SM_NO_STORE
+      if (v2.x == 1.2345e300) *reinterpret_cast<d2_t *>(out + srow0 + (long) r2 * 128) = v2;
+#else
       *reinterpret_cast<d2_t *>(out + srow0 + (long) r2 * 128) = v2;
+#endif
     }
   }
 }

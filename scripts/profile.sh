@@ -10,8 +10,22 @@ TAG=${1:-r02}
 export TMPDIR=/tmp
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/prof_$TAG
-rm -rf $OUT; mkdir -p $OUT
+ONLY=${2:-all}   # "smoother": refresh the smoother's trace and counters only (merged into the same prof_<tag>/)
 cd $ROOT
+smoother_trace() {
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/smoother -- python3 scripts/smooth_rate.py > $OUT/smoother.txt 2> $OUT/smoother.err || exit 23
+}
+smoother_pmc() {
+  rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU --output-format csv -d $OUT/smooth_pmc_a -- python3 scripts/smooth_rate.py > $OUT/smooth_pmc_a.txt 2>&1 || exit 24
+  rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAVES SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL --output-format csv -d $OUT/smooth_pmc_b -- python3 scripts/smooth_rate.py > $OUT/smooth_pmc_b.txt 2>&1 || exit 25
+}
+if [ "$ONLY" = smoother ]; then
+  mkdir -p $OUT; rm -rf $OUT/smoother $OUT/smooth_pmc_a $OUT/smooth_pmc_b
+  smoother_trace; smoother_pmc
+  echo "smoother profile done"
+  exit 0
+fi
+rm -rf $OUT; mkdir -p $OUT
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace64k -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-cache-busting > $OUT/trace64k.json 2> $OUT/trace64k.err || exit 11
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace64k_n21 -- python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-cache-busting --n-states 21 > $OUT/trace64k_n21.json 2> $OUT/trace64k_n21.err || exit 11
 echo "traces done"
@@ -28,10 +42,9 @@ echo "hot path done"
 # the kernels next to the hot step, the whole configurations, the smoother (kernel trace, then two SQ / LDS counter passes)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/others -- python3 scripts/kernel_rates.py > $OUT/others.txt 2> $OUT/others.err || exit 21
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/configs -- python3 scripts/config_rates.py > $OUT/configs.txt 2> $OUT/configs.err || exit 22
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/smoother -- python3 scripts/smooth_rate.py > $OUT/smoother.txt 2> $OUT/smoother.err || exit 23
+smoother_trace
 echo "adjacent kernels done"
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU --output-format csv -d $OUT/smooth_pmc_a -- python3 scripts/smooth_rate.py > $OUT/smooth_pmc_a.txt 2>&1 || exit 24
-rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAVES SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL --output-format csv -d $OUT/smooth_pmc_b -- python3 scripts/smooth_rate.py > $OUT/smooth_pmc_b.txt 2>&1 || exit 25
+smoother_pmc
 echo "smoother counters done"
 # ceilings and sweeps, not under the profiler
 hipcc -O3 --offload-arch=gfx950 -o /tmp/copybench scripts/copybench.hip && /tmp/copybench > $OUT/copybench.txt 2>&1
