@@ -9,8 +9,8 @@
 // is the wrong shape: a GROUP of G = 16 / 32 lanes owns one filter, lane r owns matrix row r (k_smooth_reg below).
 // The reference calls Eigen's .ldlt(): the kernel keeps Eigen's diagonal pivoting (same pivot order keeps parity at
 // 1e-15 instead of cond(P^-) * eps).
-// The factorisation and the substitutions are VALU + LDS; the two n x n products of the 15-state kernel run on the matrix
-// pipe (v_mfma_f64_16x16x4_f64, one 16 x 16 tile per filter, step 5): its fp64 rate equals the vector rate on MI355X, the
+// The factorisation and the substitutions are VALU + LDS; the two n x n products run on the matrix pipe
+// (v_mfma_f64_16x16x4_f64: one 16 x 16 tile per 15-state filter, 2 x 2 tiles with k padded to 24 per 21-state filter, step 5): its fp64 rate equals the vector rate on MI355X, the
 // gain is the VALU / LDS work and the row registers it takes away, not arithmetic throughput.
 // Build flags SM_SKIP_* / SM_NO_* / SM_COPY_ONLY / SM_EMPTY compile parts out for scripts/smooth_attribution.sh (timing only).
 #pragma once
@@ -68,7 +68,8 @@ struct SmoothRegCfg {
   //  * per-filter strides: the 64/G filters of one wave read their rows as 16-byte broadcasts at the same time; with
   //    4 (mod 8) dwords between them their 4-bank groups never coincide.
   static constexpr int bank_stride(int x) { return (x % 4 == 2) ? x : x + ((6 - x % 4) % 4); }
-  static constexpr int PG = bank_stride(NS), MATP = NS * PG;
+  static constexpr int KPAD = (NS <= 16) ? 16 : 24;  // columns of an operand row: the k range of the matrix products, zero-padded
+  static constexpr int PG = bank_stride(KPAD), MATP = NS * PG;
   static constexpr int U_PER = bank_stride((PITCH + 1 > MATP) ? PITCH + 1 : MATP);  // staging, then L, x, L, L^T, gain^T
   static constexpr int U_DOUBLES = F * U_PER;
   static constexpr int D_PER = bank_stride(MATP);  // D = P^s - P^- (full, row pitch PG)
@@ -95,6 +96,9 @@ typedef double d4_t __attribute__((ext_vector_type(4)));
 // Column c of an n <= 16 row sits at position mfma_pos(c): the four k = h, h + 4, h + 8, h + 12 that lane group h = l >> 4
 // supplies to the four MFMAs of a 16-deep product are then 32 contiguous bytes (two ds_read_b128).
 __host__ __device__ constexpr int mfma_pos(int c) { return 4 * (c % 4) + c / 4; }
+// 21 states: k is padded to 24 = 6 slices of 4, lane group h supplies k = h + 4 s, s = 0..5: 48 contiguous bytes
+__host__ __device__ constexpr int mfma_pos6(int c) { return 6 * (c % 4) + c / 4; }
+__host__ __device__ constexpr int mfma_col6(int p) { return 4 * (p % 6) + p / 6; }  // column held at position p
 
 // End of one unrolled step: the scheduling barrier keeps later steps' LDS reads from being hoisted to the top, the
 // memory clobber makes a re-read in a later phase a real LDS read instead of a value kept in a register since its first use.
@@ -154,6 +158,7 @@ __global__ __launch_bounds__(256, 2) void k_smooth_reg(const double *__restrict_
   using C = SmoothRegCfg<NS>;
   constexpr int G = C::G, F = C::F, PITCH = C::PITCH, PG = C::PG, MATP = C::MATP;
   constexpr bool MFMA = (NS <= 16);  // the two n x n products of step 5 on v_mfma_f64_16x16x4 (one 16 x 16 tile per filter)
+  constexpr bool MFMA21 = !MFMA;     // 21 states: the same on 2 x 2 tiles of 16 x 16 with k padded to 24 (two filters per wave)
   static_assert(!MFMA || (G == 16 && PG >= 16), "one filter per 16-lane group, rows padded to 16 columns");
   static_assert(NS < 24 && C::U_DOUBLES >= F * PITCH + C::THREADS, "buffer slots");
   extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -259,10 +264,12 @@ __global__ __launch_bounds__(256, 2) void k_smooth_reg(const double *__restrict_
         constexpr int j = (decltype(JJ)::value % 4) + 8 * (decltype(JJ)::value / 4);
         lds_st2(drow + mfma_pos(j), dval(j), dval(j + 4));
       });
-    } else {
-#pragma unroll
-      for (int j = 0; j + 1 < NS; j += 2) lds_st2(drow + j, Uf[poff[j]] - pminus(j), Uf[poff[j + 1]] - pminus(j + 1));
-      if (NS & 1) drow[NS - 1] = Uf[poff[NS - 1]] - pminus(NS - 1);
+    } else {  // 21 states: mfma_pos6 order, columns 21..23 = 0
+      auto dval = [&](int j) { return j < NS ? Uf[poff[j < NS ? j : 0]] - pminus(j < NS ? j : 0) : 0.0; };
+      static_for<12>([&](auto JJ) {
+        constexpr int j = (decltype(JJ)::value % 4) + 8 * (decltype(JJ)::value / 4);
+        lds_st2(drow + mfma_pos6(j), dval(j), dval(j + 4));
+      });
     }
     double qs[4], dchi[3];
 #pragma unroll
@@ -488,15 +495,34 @@ __global__ __launch_bounds__(256, 2) void k_smooth_reg(const double *__restrict_
       if (mfma_pos(c + 1) < NS) gain[mfma_pos(c + 1)] = gv.y;
     }
   } else {
-    double *const gt = row ? Lf + rr : Rf + NS;
-    const int step = row ? PG : 0;
+    // 21 states: by rows, columns in mfma_pos6 order, columns 21..23 (positions 11, 17, 23) = 0
+    double *const gr = row ? Lf + rr * PG : Rf + NS;
 #pragma unroll
-    for (int kk = 0; kk < NS; kk++) gt[step * piv[kk]] = z[kk];
+    for (int kk = 0; kk < NS; kk++) gr[one * (6 * (piv[kk] & 3) + (piv[kk] >> 2))] = z[kk];
+    gr[one * 11] = 0.0;
+    gr[one * 17] = 0.0;
+    gr[one * 23] = 0.0;
     group_sync();
 #pragma unroll
-    for (int i = 0; i < NS; i++) gain[i] = Lf[i * PG + rr];
+    for (int c = 0; c < 24; c += 2) {
+      const d2_t gv = lds_ld2(Lf + rr * PG + c);
+      if (mfma_col6(c) < NS) gain[mfma_col6(c)] = gv.x;
+      if (mfma_col6(c + 1) < NS) gain[mfma_col6(c + 1)] = gv.y;
+    }
   }
   step_fence();
+  // dx = G resid (rbis.cpp:263).  21 states: ahead of the products, so that the gain row is dead under them and its scratch
+  // row can take the product; 15 states: after them (measured 1 % faster there)
+  double dx = 0.0;
+  auto state_delta = [&]() {
+#pragma unroll
+    for (int a = 0; a < NS; a++) dx = fma(gain[a], Rf[C::RB_RES + a], dx);
+    Rf[row ? C::RB_DX + rr : NS] = dx;
+  };
+  if constexpr (MFMA21) {
+    state_delta();
+    step_fence();
+  }
 
   // ---- 5. P^s_row = P_row + (g D) G^T: row bcol of D (symmetric) and row bcol of Gt, 16 bytes at a time ----
   if constexpr (MFMA) {
@@ -526,30 +552,73 @@ __global__ __launch_bounds__(256, 2) void k_smooth_reg(const double *__restrict_
 #endif
   } else {
 #ifndef SM_SKIP_PROD
+    // 21 states on the matrix pipe: 2 x 2 tiles of 16 x 16, k padded to 24 = 6 slices.  F = D G^T (4 tiles x 6 MFMAs), then the
+    // lower tiles (0,0), (1,0), (1,1) of G F (3 x 6): F's tile (tk, tj) has row 16 tk + h + 4 v in result register v of lane
+    // (h, j) -- the B operand of k-slice (tk, v) -- and the matching A operand G[i][16 tk + h + 4 v] is slice 4 tk + v of the
+    // six this lane group holds.  The product goes back through this filter's scratch (its gain is in registers by now)
+    // into the row layout and is added to the P_k row there.
+    const int ml = t & 63, mh2 = ml >> 4, mi = ml & 15, fw2 = f & ~1;
+    const int r0 = mi, r1 = (16 + mi < NS) ? 16 + mi : NS - 1;  // rows 21..31 do not exist: finite stand-ins, never stored
 #pragma unroll
-  for (int bcol = 0; bcol < NS; bcol++) {
-    double ub = 0.0;
+    for (int ff = 0; ff < 2; ff++) {
+      double *const Gb = U + (fw2 + ff) * C::U_PER;
+      const double *const Db = DP + (fw2 + ff) * C::D_PER;
+      double gq[2][6], dq[2][6];
 #pragma unroll
-    for (int a = 0; a < NS; a += 2) {
-      const d2_t dvv = lds_ld2(Df + bcol * PG + a);
-      ub = fma(gain[a], dvv.x, ub);
-      if (a + 1 < NS) ub = fma(gain[a + 1], dvv.y, ub);
+      for (int ti = 0; ti < 2; ti++) {
+        const int rw = ti ? r1 : r0;
+#pragma unroll
+        for (int c = 0; c < 6; c += 2) {
+          const d2_t gv = lds_ld2(Gb + rw * PG + 6 * mh2 + c), dv = lds_ld2(Db + rw * PG + 6 * mh2 + c);
+          gq[ti][c] = gv.x; gq[ti][c + 1] = gv.y;
+          dq[ti][c] = dv.x; dq[ti][c + 1] = dv.y;
+        }
+      }
+      d4_t fq[2][2], oq[3];
+#pragma unroll
+      for (int tk = 0; tk < 2; tk++)
+#pragma unroll
+        for (int tj = 0; tj < 2; tj++) fq[tk][tj] = d4_t{ 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+      for (int s6 = 0; s6 < 6; s6++)
+#pragma unroll
+        for (int tk = 0; tk < 2; tk++)
+#pragma unroll
+          for (int tj = 0; tj < 2; tj++)
+            fq[tk][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(dq[tk][s6], gq[tj][s6], fq[tk][tj], 0, 0, 0);
+#pragma unroll
+      for (int o = 0; o < 3; o++) oq[o] = d4_t{ 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+      for (int s6 = 0; s6 < 6; s6++)
+#pragma unroll
+        for (int o = 0; o < 3; o++) {
+          const int ti = (o + 1) / 2, tj = o / 2;  // (0,0), (1,0), (1,1)
+          oq[o] = __builtin_amdgcn_mfma_f64_16x16x4f64(gq[ti][s6], fq[s6 / 4][tj][s6 % 4], oq[o], 0, 0, 0);
+        }
+      group_sync();  // this wave's operand reads of the filter's scratch are done
+#pragma unroll
+      for (int o = 0; o < 3; o++) {
+        const int ti = (o + 1) / 2, tj = o / 2;
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+          const int orow = 16 * ti + mh2 + 4 * v, ocol = 16 * tj + mi;
+          double *const dst = (orow < NS && ocol <= orow) ? Gb + orow * PG + ocol : Rf + NS;
+          *dst = oq[o][v];
+        }
+      }
     }
+    group_sync();
 #pragma unroll
-    for (int m = 0; m < NS; m += 2) {
-      const d2_t gv = lds_ld2(Lf + bcol * PG + m);
-      prow[m] = fma(ub, gv.x, prow[m]);
-      if (m + 1 < NS) prow[m + 1] = fma(ub, gv.y, prow[m + 1]);
+    for (int m = 0; m < NS; m += 2) {  // this lane's row of G D G^T (entries m <= row are the ones stored and used)
+      const d2_t pv = lds_ld2(Lf + rr * PG + m);
+      prow[m] += pv.x;
+      if (m + 1 < NS) prow[m + 1] += pv.y;
     }
     step_fence();
-  }
 #endif
   }
-  // ---- 6. state: dx = G resid; cur.addState(RBIS(dx))  (rbis.cpp:263-265) ----
-  double dx = 0.0;
-#pragma unroll
-  for (int a = 0; a < NS; a++) dx = fma(gain[a], Rf[C::RB_RES + a], dx);
-  Rf[row ? C::RB_DX + rr : NS] = dx;
+  // ---- 6. state: cur.addState(RBIS(dx))  (rbis.cpp:263-265) ----
+  if constexpr (!MFMA21) state_delta();
   __syncthreads();  // all waves are done with L / G: the buffer becomes the output staging area
   // Unconditional stores with a selected ADDRESS (entries this lane does not own go to a private dummy slot behind the
   // staging layout): with the stores inside `if (row && m <= rr)` the compiler sinks all the multiply-adds of step 5
@@ -565,7 +634,7 @@ __global__ __launch_bounds__(256, 2) void k_smooth_reg(const double *__restrict_
       }
   } else {
 #pragma unroll
-    for (int m = 0; m < NS; m++) U[(row && m <= rr) ? f * PITCH + poff[m] : dummy] = prow[m];
+    for (int m = 0; m < NS; m++) U[(row && m <= rr) ? f * PITCH + L::OFF_P + rr * (rr + 1) / 2 + m : dummy] = prow[m];  // (m <= rr: pk(rr, m))
   }
   U[(row && !(rr >= 6 && rr <= 8)) ? f * PITCH + L::OFF_VEC + rr : dummy] = xcur + dx;
   if (r == 0) {
