@@ -143,3 +143,61 @@ def test_backward_pass_matches_golden_fixture(oracle, n):
             assert rel(v, gold["vec_" + tag][:n]) < TOL and rel(q, gold["quat_" + tag]) < TOL
             assert rel(P, gold["cov_" + tag][:n, :n]) < TOL
     est.close()
+
+
+@pytest.mark.parametrize("n", [15, 21])
+def test_full_size_smooth_step_equals_its_shard(oracle, n):
+    """BASELINE's batch size (65 536 filters, 4 096 / 8 192 workgroups, the matrix-pipe products with four / two filters per
+    wave): the smoothed posterior of a window of filters must be bit-identical to the same filters smoothed alone in a
+    small batch (another position in the tile, the workgroup and the wave), stay finite everywhere, and never increase
+    the uncertainty.  (Parity with the oracle on small batches: the tests above.)"""
+    from pronto_amd.batch import BatchEstimator
+    dt = 1e-3
+
+    def run(B, b0, first, count):
+        w = Workload(B, b0=b0, n_states=n)
+        est = BatchEstimator(B, n_states=n)
+        est.set_constants(*oracle.constants())
+        vec, quat, P0 = w.initial_state()
+        est.reset(vec, quat, P0)
+        est.history_reserve(4)
+        q4 = w.process_noise()
+        for k in range(4):
+            lo, mask = w.legodo_block(k)
+            est.step_legodo(w.imu_block(k), lo, mask, q4)
+        est.state_save(0)
+        est.predict(w.imu_block(4), q4)
+        est.state_save(1)
+        lo, mask = w.legodo_block(4)
+        est.update_indexed([3, 4, 5], np.ascontiguousarray(lo[0:3]), np.ascontiguousarray(lo[3:6]), mask=mask)
+        est.state_save(2)
+        est.smooth_step(1, 2, 0, 3, dt)
+        est.state_restore(0)
+        filt = est.get_head(first, count)
+        est.state_restore(3)
+        sm = est.get_head(first, count)
+        summ = est.summary()
+        est.close()
+        return filt, sm, summ
+
+    B, b0, Bs = 65536, 40007, 45
+    filt, whole, summ = run(B, 0, b0, Bs)
+    assert summ[3] == 0                      # no non-finite entry anywhere in the 64k smoothed states
+    _, shard, _ = run(Bs, b0, 0, Bs)
+    for a, b in zip(whole[:3], shard[:3]):
+        assert np.array_equal(a, b)
+    for j in range(Bs):
+        d = filt[2][:, :, j] - whole[2][:, :, j]
+        assert np.linalg.eigvalsh(0.5 * (d + d.T)).min() > -1e-9 * np.abs(filt[2][:, :, j]).max()
+
+
+def test_mfma_f64_lane_maps(tmp_path):
+    """The smoother's products rely on the operand / result lane maps of v_mfma_f64_16x16x4_f64 (which differ from the f32
+    forms): scripts/mfma_f64_probe.hip checks them with random data on this box."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "mfma_f64_probe")
+    subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-Wno-unused-value",
+                    os.path.join(root, "scripts", "mfma_f64_probe.hip"), "-o", exe], check=True, timeout=300)
+    out = subprocess.run([exe], check=True, timeout=120, capture_output=True, text=True).stdout
+    assert "lane maps" in out and "(OK)" in out, out
