@@ -1,4 +1,5 @@
-// pb_update.hip -- launchers of the generic update kernel k_update<NS, M, ORIENT, MH>; compiled twice, with
+// pb_update.hip -- launchers of the generic (run-time index list) update kernels: k_update_lane_rt<15, M, ORIENT, MH> (one lane,
+// the filter in registers) and k_update<21, M, ORIENT, MH> (columns gathered, covariance streamed); compiled twice, with
 // -DPB_UPD_NS=15 and -DPB_UPD_NS=21, into pb_update15.o / pb_update21.o (72 kernel instances in all); see pb_ctx.hpp.
 #include "pb_ctx.hpp"
 
@@ -7,10 +8,17 @@ static void launch_update_mh(pb_ctx *c, const IdxArg<M> &ia, const DiagArg<M> &d
                              int rkind, const double *qm, const uint8_t *mask)
 {
   double *out = update_target(c);
-  if (qm)
-    k_update<NS, M, true, MH><<<nblk(c->B), 64, 0, c->stream>>>(c->st, out, c->B, ia, z, R, rkind, da, qm, mask, c->k);
-  else
-    k_update<NS, M, false, MH><<<nblk(c->B), 64, 0, c->stream>>>(c->st, out, c->B, ia, z, R, rkind, da, qm, mask, c->k);
+  if constexpr (NS == 15) {  // the whole 15-state filter fits one lane's registers: no column gather (k_update_lane_rt)
+    if (qm)
+      k_update_lane_rt<NS, M, true, MH><<<nblk(c->B), 64, 0, c->stream>>>(c->st, out, c->B, ia, z, R, rkind, da, qm, mask, c->k);
+    else
+      k_update_lane_rt<NS, M, false, MH><<<nblk(c->B), 64, 0, c->stream>>>(c->st, out, c->B, ia, z, R, rkind, da, qm, mask, c->k);
+  } else {
+    if (qm)
+      k_update<NS, M, true, MH><<<nblk(c->B), 64, 0, c->stream>>>(c->st, out, c->B, ia, z, R, rkind, da, qm, mask, c->k);
+    else
+      k_update<NS, M, false, MH><<<nblk(c->B), 64, 0, c->stream>>>(c->st, out, c->B, ia, z, R, rkind, da, qm, mask, c->k);
+  }
   update_done(c, out);
 }
 

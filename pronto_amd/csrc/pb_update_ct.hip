@@ -1,7 +1,8 @@
 // pb_update_ct.hip -- stand-alone indexed (+ orientation) updates whose index list is one the handlers actually produce
 // (compile-time core indices, diagonal R): 15 states on the two-role cooperative mapping (k_step_coop with PREDICT = false,
 // rbis_coop.hpp), 21 states on the four-wave mapping (k_update_quad, rbis_quad.hpp) -- one coalesced round trip of the
-// state, no column gather -- instead of the generic run-time-index kernel k_update.  See pb_ctx.hpp.
+// state, no column gather -- instead of the generic run-time-index kernel k_update.  LegOdoCommon's lin_rot_rate list reaches
+// the pass-through angular-velocity states: 15 states take it on the one-lane in-register kernel k_update_lane.  See pb_ctx.hpp.
 #include "pb_ctx.hpp"
 
 template <int NS, int MH, class CORR>
@@ -69,6 +70,7 @@ int pbk_update_ct(pb_ctx *c, int m, const int *idx, const double *z, const doubl
   else if (!orient && same(idx, m, { 8, 9, 10, 11 })) which = 7;          // GPF pos_yaw
   else if (!orient && same(idx, m, { 6, 7, 8, 9, 10, 11 })) which = 8;    // GPF pos_chi
   else if (!orient && same(idx, m, { 11 })) which = 9;                    // GPF z_only
+  else if (!orient && c->ns == 15 && same(idx, m, { 3, 4, 5, 0, 1, 2 })) which = 10;  // LegOdoCommon lin_rot_rate
   if (which < 0) return -1;
   // two-role mapping only (A/B switch): 21 states with six measurement rows spill there; the generic kernel takes them
   if (c->ns == 21 && !c->quad21 && m > 4) return -1;
@@ -83,7 +85,14 @@ int pbk_update_ct(pb_ctx *c, int m, const int *idx, const double *z, const doubl
   case 6: launch_ct_mh<CorrYaw>(c, out, ca); break;
   case 7: launch_ct_mh<CorrGpfYawPos>(c, out, ca); break;
   case 8: launch_ct_mh<CorrGpfChiPos>(c, out, ca); break;
-  default: launch_ct_mh<CorrGpfZ>(c, out, ca); break;
+  case 9: launch_ct_mh<CorrGpfZ>(c, out, ca); break;
+  default:  // a list that reaches the pass-through states: the one-lane in-register kernel (15 states only)
+    switch (c->mem_hint) {
+    case MH_STORE_SC1: k_update_lane<15, 6, IdxVelOmega, MH_STORE_SC1><<<nblk(c->B), 64, 0, c->stream>>>(c->st, out, c->B, c->k, ca); break;
+    case MH_STREAM_NT: k_update_lane<15, 6, IdxVelOmega, MH_STREAM_NT><<<nblk(c->B), 64, 0, c->stream>>>(c->st, out, c->B, c->k, ca); break;
+    default: k_update_lane<15, 6, IdxVelOmega, MH_DEFAULT><<<nblk(c->B), 64, 0, c->stream>>>(c->st, out, c->B, c->k, ca); break;
+    }
+    break;
   }
   LAUNCHCHK(c);
   update_done(c, out);

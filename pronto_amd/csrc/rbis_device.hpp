@@ -583,16 +583,17 @@ struct NoSink {
 
 // `sink(packed_index, value)` is called for every entry of the posterior covariance as soon as it is final, so a
 // kernel can store it straight away and free its register.
-template <int NS, int M, typename IDXT, typename SINK = NoSink>
-PB_HD void measurement_update(double (&x)[NS], double (&q)[4], double (&P)[NS * (NS + 1) / 2], double &ll,
-                              const double (&resid)[M], double (&S)[M * (M + 1) / 2], IDXT, const Consts &k,
-                              SINK sink = SINK(), bool active = true)
+// measurement_update_cols: the measured columns W = P[:, idx] arrive already gathered (compile-time indices: below;
+// wave-uniform run-time indices: k_update_lane_rt); they are turned into P[:, idx] L^-T in place.
+template <int NS, int M, typename SINK = NoSink>
+PB_HD void measurement_update_cols(double (&x)[NS], double (&q)[4], double (&P)[NS * (NS + 1) / 2], double &ll,
+                                   const double (&resid)[M], double (&S)[M * (M + 1) / 2], double (&W)[NS][M], const Consts &k,
+                                   SINK sink = SINK(), bool active = true)
 {
   // `active == false` = "the handler returned NULL for this filter": the lane runs the same instruction stream
   // with D^-1 forced to 0, so P, x and ll come out bit-identical to their inputs, and -- the point -- every lane
   // of the wave issues the SAME store instructions (whole 512-byte rows; a divergent skip path splits each row
   // store into two partial-line writes, measured as +28 % HBM write traffic).
-  constexpr Idx<M> idx = IDXT::value;
   double d[M];
   ldlt<M>(S, d);
   // y = L^-1 r ; ll += -log det S - r^T S^-1 r  (rbis.cpp:142)
@@ -612,12 +613,11 @@ PB_HD void measurement_update(double (&x)[NS], double (&q)[4], double (&P)[NS * 
   // (the two differ when S is indefinite with an even number of negative pivots: finite there, NaN here)
   if (active) ll += -log(det) - quad;
   // W = P[:, idx] L^-T  (row i: W_ik = P(i,idx_k) - sum_{j<k} W_ij L_kj)
-  double W[NS][M];
 #pragma unroll
   for (int i = 0; i < NS; i++) {
 #pragma unroll
     for (int kk = 0; kk < M; kk++) {
-      double s = P[pk(i, idx.v[kk])];
+      double s = W[i][kk];
 #pragma unroll
       for (int j = 0; j < kk; j++) s -= W[i][j] * S[pk(kk, j)];
       W[i][kk] = s;
@@ -648,6 +648,21 @@ PB_HD void measurement_update(double (&x)[NS], double (&q)[4], double (&P)[NS * 
     }
   }
   if (active) add_delta<NS>(x, q, dx, k.chi_tol);
+}
+
+// IDX is a constexpr index list so that P[pk(i, idx_k)] is a register, not a scratch access.
+template <int NS, int M, typename IDXT, typename SINK = NoSink>
+PB_HD void measurement_update(double (&x)[NS], double (&q)[4], double (&P)[NS * (NS + 1) / 2], double &ll,
+                              const double (&resid)[M], double (&S)[M * (M + 1) / 2], IDXT, const Consts &k,
+                              SINK sink = SINK(), bool active = true)
+{
+  constexpr Idx<M> idx = IDXT::value;
+  double W[NS][M];
+#pragma unroll
+  for (int i = 0; i < NS; i++)
+#pragma unroll
+    for (int kk = 0; kk < M; kk++) W[i][kk] = P[pk(i, idx.v[kk])];
+  measurement_update_cols<NS, M>(x, q, P, ll, resid, S, W, k, sink, active);
 }
 
 }  // namespace pb

@@ -662,6 +662,155 @@ struct CorrArgs {
   // rfull: a FULL per-filter R, [m*m][B] column-major (pronto::indexed_measurement_t's R_effective); r2 / rb2 are unused then
   const double *rfull = nullptr;
 };
+// LegOdoCommon's lin_rot_rate list (rbis_legodo_common.cpp:66-67): velocity AND angular velocity -- the angular-velocity
+// rows are pass-through states of the other role, so the two-role kernels below do not take it.
+struct IdxVelOmega {
+  static constexpr Idx<6> value = { { 3, 4, 5, 0, 1, 2 } };
+};
+
+// Stand-alone indexed update, one lane per filter, COMPILE-TIME index list anywhere in the state (15 states: the whole
+// filter lives in registers, as in k_step): one coalesced round trip of the state and the in-register update of the fused
+// step (measurement_update) instead of the generic k_update's run-time column gather, which reads the measured columns a
+// second time.  Diagonal (per filter or one for all) or full per-filter R, skip mask, broadcast z: CorrArgs.
+template <int NS, int M, class IDXT, int MH = MH_DEFAULT>
+__global__ __launch_bounds__(64, 1) void k_update_lane(const double *st, double *sto, int B, Consts k, CorrArgs ca)
+{
+  using L = Lay<NS>;
+  constexpr Idx<M> idx = IDXT::value;
+  const unsigned tile = xcd_workgroup(k);
+  const unsigned b = tile * 64u + threadIdx.x;
+  if (b >= (unsigned) B) return;
+  const unsigned bo = b * 8u, B8 = (unsigned) B * 8u;
+  TileIO<NS, MemHint<MH>::LA, MemHint<MH>::SA> io(st, sto, tile, threadIdx.x);
+  const bool upd = (ca.mask2 == nullptr) || (ca.mask2[b] != 0);  // 0 = handler returned NULL for this filter
+  // the measurement first (the only loads that are never cache-resident), then the state rows
+  const rsrc_t rz = mkbuf(ca.z2, ca.zbc ? 0u : (unsigned) M * B8);
+  const rsrc_t rr = mkbuf(ca.rfull ? ca.rfull : ca.r2, ca.rfull ? (unsigned) (M * M) * B8 : (ca.r2 ? (unsigned) M * B8 : 0u));
+  double z[M], R[M * (M + 1) / 2];
+#pragma unroll
+  for (int i = 0; i < M; i++) {
+    z[i] = ca.zbc ? ca.zb2[i] : ldg(rz, i * B8, bo);
+#pragma unroll
+    for (int j = 0; j <= i; j++) {
+      double r;
+      if (ca.rfull) r = ldg(rr, (j * M + i) * B8, bo);
+      else if (i != j) r = 0.0;
+      else r = ca.r2 ? ldg(rr, i * B8, bo) : ca.rb2[i];
+      R[pk(i, j)] = upd ? r : (i == j ? 1.0 : 0.0);  // benign R for skipped filters (their block may hold anything)
+    }
+  }
+  io.template need<0, Slots<NS>::NROW>();
+  double x[NS], q[4], ll, P[L::NP];
+#pragma unroll
+  for (int i = 0; i < NS; i++) x[i] = io.ld(L::OFF_VEC + i);
+#pragma unroll
+  for (int i = 0; i < 4; i++) q[i] = io.ld(L::OFF_QUAT + i);
+  ll = io.ld(L::OFF_LL);
+#pragma unroll
+  for (int i = 0; i < L::NP; i++) P[i] = io.ld(L::OFF_P + i);
+  double resid[M], S[M * (M + 1) / 2];
+#pragma unroll
+  for (int i = 0; i < M; i++) {
+    resid[i] = upd ? z[i] - x[idx.v[i]] : 0.0;                                   // rbis.cpp:170
+#pragma unroll
+    for (int j = 0; j <= i; j++) S[pk(i, j)] = P[pk(idx.v[i], idx.v[j])] + R[pk(i, j)];  // rbis.cpp:134-135
+  }
+  measurement_update<NS, M>(x, q, P, ll, resid, S, IDXT{}, k, [&io](int pi, double v) { io.st(L::OFF_P + pi, v); }, upd);
+#pragma unroll
+  for (int i = 0; i < NS; i++) io.st(L::OFF_VEC + i, x[i]);
+#pragma unroll
+  for (int i = 0; i < 4; i++) io.st(L::OFF_QUAT + i, q[i]);
+  io.st(L::OFF_LL, ll);
+}
+
+// Column c (wave-uniform) of the packed covariance into column KK of W, with the residual and row KK of S = R + P[idx, idx]:
+// a chain of scalar compares over the compile-time candidates CC, CC + 1, ... (one branch taken, NS register moves).
+template <int NS, int M, int KK, int CC, bool ORIENT>
+__device__ __forceinline__ void pick_column(int c, const double (&P)[NS * (NS + 1) / 2], const double (&x)[NS], const double (&zz)[M],
+                                            const double (&dq)[3], bool upd, double (&W)[NS][M], double (&resid)[M],
+                                            double (&S)[M * (M + 1) / 2])
+{
+  if constexpr (CC < NS) {
+    if (c == CC) {
+      // (a distinct marker per branch: otherwise the identical branch bodies are merged into ONE body that loads through a
+      // selected address, which pins the whole covariance in scratch memory)
+      asm volatile("; column %0 -> %1" ::"n"(CC), "n"(KK));
+#pragma unroll
+      for (int i = 0; i < NS; i++) W[i][KK] = P[pk(i, CC)];
+      double r = zz[KK] - x[CC];                                    // rbis.cpp:170
+      if constexpr (ORIENT && CC >= 6 && CC <= 8) r = dq[CC - 6];   // rbis.cpp:206-208
+      resid[KK] = upd ? r : 0.0;
+#pragma unroll
+      for (int j = 0; j < KK; j++) S[pk(KK, j)] += W[CC][j];        // P[idx_KK, idx_j]: row CC of an earlier column
+      S[pk(KK, KK)] += P[pk(CC, CC)];
+      asm volatile("; column %0 -> %1 done" ::"n"(CC), "n"(KK));  // (common-tail sinking stops here)
+    } else {
+      pick_column<NS, M, KK, CC + 1, ORIENT>(c, P, x, zz, dq, upd, W, resid, S);
+    }
+  }
+}
+
+// The generic update for 15 states: RUN-TIME index list (any indices, m = 1..6, diagonal / broadcast / full R, orientation
+// residual, skip mask -- RBISIndexedMeasurement / RBISIndexedPlusOrientationMeasurement::updateFilter,
+// rbis_update_interface.cpp:54-107) on the same one-lane in-register scheme.  The index list is a kernel argument, i.e.
+// wave-uniform: each measured column is picked by a scalar branch over the 15 compile-time candidates (15 register moves
+// taken, nothing gathered from memory), then measurement_update_cols runs as for a compile-time list -- so the result is
+// bit-identical to k_update_lane's for the same list.  21 states do not fit one lane's registers: k_update stays for them.
+template <int NS, int M, bool ORIENT, int MH = MH_DEFAULT>
+__global__ __launch_bounds__(64, 1) void k_update_lane_rt(const double *st, double *sto, int B, IdxArg<M> idx,
+                                                          const double *__restrict__ z, const double *__restrict__ R,
+                                                          int rkind, DiagArg<M> rb, const double *__restrict__ qmeas,
+                                                          const uint8_t *__restrict__ mask, Consts k)
+{
+  using L = Lay<NS>;
+  const unsigned tile = xcd_workgroup(k);
+  const unsigned b = tile * 64u + threadIdx.x;
+  if (b >= (unsigned) B) return;
+  const bool upd = (mask == nullptr) || (mask[b] != 0);  // 0 = handler returned NULL for this filter
+  const unsigned bo = b * 8u, B8 = (unsigned) B * 8u;
+  TileIO<NS, MemHint<MH>::LA, MemHint<MH>::SA> io(st, sto, tile, threadIdx.x);
+  const rsrc_t rz = mkbuf(z, (unsigned) M * B8);
+  const rsrc_t rR = mkbuf(R, rkind == PB_R_DIAG ? (unsigned) M * B8 : (rkind == PB_R_FULL ? (unsigned) (M * M) * B8 : 0u));
+  const rsrc_t rq = mkbuf(qmeas, ORIENT ? 4u * B8 : 0u);
+  double zz[M], S[M * (M + 1) / 2], qm[4] = { 1.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+  for (int i = 0; i < M; i++) {
+    zz[i] = ldg(rz, i * B8, bo);
+#pragma unroll
+    for (int j = 0; j <= i; j++) {
+      double r;
+      if (rkind == PB_R_DIAG_BROADCAST) r = (i == j) ? rb.v[i] : 0.0;
+      else if (rkind == PB_R_DIAG) r = (i == j) ? ldg(rR, i * B8, bo) : 0.0;
+      else r = ldg(rR, (j * M + i) * B8, bo);
+      S[pk(i, j)] = upd ? r : (i == j ? 1.0 : 0.0);  // benign R for skipped filters (their R block may hold anything)
+    }
+  }
+  if constexpr (ORIENT) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) qm[i] = ldg(rq, i * B8, bo);
+  }
+  io.template need<0, Slots<NS>::NROW>();
+  double x[NS], q[4], ll, P[L::NP];
+#pragma unroll
+  for (int i = 0; i < NS; i++) x[i] = io.ld(L::OFF_VEC + i);
+#pragma unroll
+  for (int i = 0; i < 4; i++) q[i] = io.ld(L::OFF_QUAT + i);
+  ll = io.ld(L::OFF_LL);
+#pragma unroll
+  for (int i = 0; i < L::NP; i++) P[i] = io.ld(L::OFF_P + i);
+  double dq[3] = { 0.0, 0.0, 0.0 };
+  if constexpr (ORIENT) subtract_quats(qm, q, dq);  // rbis.cpp:199-205
+  // the measured columns, the measured states and P[idx, idx], by scalar branches on the (uniform) indices
+  double W[NS][M], resid[M];
+  static_for<M>([&](auto KK) { pick_column<NS, M, decltype(KK)::value, 0, ORIENT>(idx.v[decltype(KK)::value], P, x, zz, dq, upd, W, resid, S); });
+  measurement_update_cols<NS, M>(x, q, P, ll, resid, S, W, k, [&io](int pi, double v) { io.st(L::OFF_P + pi, v); }, upd);
+#pragma unroll
+  for (int i = 0; i < NS; i++) io.st(L::OFF_VEC + i, x[i]);
+#pragma unroll
+  for (int i = 0; i < 4; i++) io.st(L::OFF_QUAT + i, q[i]);
+  io.st(L::OFF_LL, ll);
+}
+
 template <int NS, bool UPDATE, int MH = MH_DEFAULT, class CORR = NoCorr, bool PREDICT = true>
 __global__ __launch_bounds__(128, 1) void k_step_coop(const double *st, double *sto, int B,
                                                       const double *__restrict__ imu, const double *__restrict__ lo,

@@ -56,8 +56,11 @@ for n in (15, 21):
     d_qm4, d_Rd4 = up(qm), up(Rd)
     t = timeit(lambda: est.update_indexed([9, 10, 11, 8], z4, d_Rd4, quat_meas=d_qm4))
     rows.append(("k_update m=4 orient (scan-match position_yaw)", t, 2 * st + 88))
+    z6r, r6r = up(np.vstack([lo[0:3], 0.01 * np.ones((3, B))])), up(np.vstack([lo[3:6], 0.09 * np.ones((3, B))]))
+    t = timeit(lambda: est.update_indexed([3, 4, 5, 0, 1, 2], z6r, r6r, mask=d_mask))
+    rows.append(("m=6 legodo lin_rot_rate (15: k_update_lane, 21: generic)", t, 2 * st + 96))
     for name, t, nb in rows:
-        print("n=%d %-48s %7.1f us  %6.0f GB/s  frac %.3f" % (n, name, t * 1e6, nb * B / t / 1e9, nb * B / t / 1e9 / 8000))
+        print("n=%d %-56s %7.1f us  %6.0f GB/s  frac %.3f" % (n, name, t * 1e6, nb * B / t / 1e9, nb * B / t / 1e9 / 8000))
 
 # IMU front end: the 3-stage notch cascade (k_notch), 3 packets per message (the KVH batch's typical new-packet count),
 # device-resident packets; bytes = packets in + the 36-double filter state read and written + the filtered sample out

@@ -178,7 +178,8 @@ def test_full_r_offdiagonal(pa, oracle):
 @pytest.mark.parametrize("n", [15, 21])
 @pytest.mark.parametrize("idx,orient", [([3, 4, 5], False), ([9, 10, 11], False), ([9, 10, 11, 3, 4, 5], False),
                                         ([9, 10, 11, 6, 7, 8], True), ([9, 10, 11, 8], True),
-                                        ([8, 9, 10, 11], False), ([6, 7, 8, 9, 10, 11], False), ([11], False)])  # (the GPF's substates)
+                                        ([8, 9, 10, 11], False), ([6, 7, 8, 9, 10, 11], False), ([11], False),  # (the GPF's substates)
+                                        ([3, 4, 5, 0, 1, 2], False)])  # LegOdoCommon lin_rot_rate
 def test_full_r_on_the_handler_index_lists(pa, oracle, n, idx, orient):
     """PB_R_FULL (pronto::indexed_measurement_t carries a full R_effective; the laser GPF's is genuinely non-diagonal) on the
     handlers' own index lists: runs on the compile-time-index kernels like a diagonal R does, against the oracle's
@@ -841,7 +842,8 @@ def test_handler_index_lists_on_the_cooperative_update_kernel(pa, oracle, n, mon
     rng = np.random.default_rng(77 + n)
     w = Workload(B, n_states=n)
     lists = [([3, 4, 5], False), ([9, 10, 11], False), ([9, 10, 11, 3, 4, 5], False), ([9, 10, 11, 6, 7, 8], True),
-             ([9, 10, 11, 8], True), ([3, 4, 5, 8], True), ([8], True), ([9, 10, 11], True), ([4, 9], False)]
+             ([9, 10, 11, 8], True), ([3, 4, 5, 8], True), ([8], True), ([9, 10, 11], True), ([4, 9], False),
+             ([3, 4, 5, 0, 1, 2], False)]   # LegOdoCommon lin_rot_rate: one-lane in-register kernel for 15 states
     ests = []
     for gen in ("0", "1"):
         monkeypatch.setenv("PRONTO_BATCH_GENERIC_UPDATE", gen)
