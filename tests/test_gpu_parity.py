@@ -917,3 +917,39 @@ def test_split_space_step_equals_the_plain_step(pa, oracle, n):
     for a, b in zip(ref.get_head(), alt.get_head()):
         assert np.array_equal(a, b)
     ref.close(); alt.close()
+
+
+def test_lin_rot_rate_compile_time_and_run_time_lists_agree_bitwise(pa, oracle, monkeypatch):
+    """LegOdoCommon's lin_rot_rate list [3,4,5,0,1,2] (rbis_legodo_common.cpp:66-67) on 15 states: the compile-time-list
+    kernel (k_update_lane) and the run-time-list kernel (k_update_lane_rt, PRONTO_BATCH_GENERIC_UPDATE=1) pick the same
+    registers and run the same in-register update, so they must agree bit for bit; both against the oracle."""
+    B, n, idx = 300, 15, [3, 4, 5, 0, 1, 2]
+    rng = np.random.default_rng(21)
+    w = Workload(B, n_states=n)
+    ests = []
+    for gen in ("0", "1"):
+        monkeypatch.setenv("PRONTO_BATCH_GENERIC_UPDATE", gen)
+        est, ob = make_pair(pa, oracle, w, dense_p0=4)
+        ests.append(est)
+    q4 = w.process_noise()
+    for t in range(6):
+        imu = w.imu_block(t)
+        for e in ests:
+            e.predict(imu, q4)
+        ob.predict(imu, q4)
+        z = np.ascontiguousarray(ob.vec[idx] + 0.05 * rng.normal(size=(6, B)))
+        mask = (rng.random(B) > 0.2).astype(np.uint8)
+        if t % 2:
+            rb = list(0.01 + 0.05 * rng.random(6))
+            Rd = np.tile(np.array(rb)[:, None], (1, B))
+            for e in ests:
+                e.update_indexed(idx, z, rb, mask=mask)
+        else:
+            Rd = np.ascontiguousarray(0.01 + 0.05 * rng.random((6, B)))
+            for e in ests:
+                e.update_indexed(idx, z, Rd, mask=mask)
+        ob.update_indexed(idx, z, Rd, mask=mask)
+    for e in ests:
+        check(e, ob)
+    for a, b in zip(ests[0].get_head(), ests[1].get_head()):
+        assert np.array_equal(a, b)
