@@ -1,0 +1,49 @@
+"""The committed rocprofv3 evidence must agree with the committed bench line (profiles/README.md): the hot kernel's average
+duration from `rocprofv3 --kernel-trace --stats` against `roofline.kernel_avg_us` measured with HIP events by bench.py
+WITHOUT the profiler (both come from one scripts/profile.sh run on one box: 8 % covers the tracer and run-to-run spread), and the roofline figures must be recomputable from the line itself.  CPU-only: reads profiles/."""
+import csv
+import glob
+import json
+import os
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def latest_round():
+    tags = sorted({os.path.basename(p)[:3] for p in glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_bench_default.json"))})
+    if not tags:
+        pytest.skip("no committed bench line")
+    return tags[-1]
+
+
+def bench_line(tag):
+    with open(os.path.join(ROOT, "profiles", tag + "_bench_default.json")) as f:
+        return json.loads([l for l in f.read().splitlines() if l.startswith("{")][-1])
+
+
+def test_rocprof_average_agrees_with_the_bench_line():
+    tag = latest_round()
+    d = bench_line(tag)
+    with open(os.path.join(ROOT, "profiles", tag + "_kernel_stats.csv")) as f:
+        rows = list(csv.DictReader(f))
+    hot = max(rows, key=lambda r: float(r["TotalDurationNs"]))
+    assert "k_step" in hot["Name"]
+    prof_us = float(hot["AverageNs"]) / 1e3
+    assert abs(prof_us - d["roofline"]["kernel_avg_us"]) / prof_us < 0.08, (prof_us, d["roofline"]["kernel_avg_us"])
+
+
+def test_roofline_is_recomputable_from_the_line():
+    d = bench_line(latest_round())
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s"
+    achieved = r["algorithmic_bytes_per_launch"] / (r["kernel_avg_us"] * 1e-6) / 1e9
+    assert abs(achieved - r["achieved"]) / achieved < 1e-6 and abs(r["frac"] - achieved / r["peak"]) < 1e-9
+    assert r["frac"] < 1.0 and r["frac_cache_busting"] < r["frac"]
+    # whole-job throughput cannot beat the kernel's own rate
+    batch = r["algorithmic_bytes_per_launch"] // 2344  # 2 344 B per 15-state step
+    assert d["value"] <= batch / (r["kernel_avg_us"] * 1e-6) * 1.001
+    cb = r["cache_busting"]
+    assert abs(cb["algorithmic_bytes_per_launch"] / (cb["kernel_avg_us"] * 1e-6) / 1e9 - cb["achieved"]) / cb["achieved"] < 1e-6
+    assert d["cpu_baseline"]["kind"] in ("port", "reference") and d["cpu_baseline"]["cores"] >= 1
