@@ -196,14 +196,17 @@ int pb_window_nll(pb_ctx *ctx, int m, const int *idx, const double *truth_vec, c
                   double *err_out, int mem);
 
 /* ---- leg kinematic odometry: the producer of the leg-odometry increment LegOdoHandler turns into a measurement ----
- * Replaces, per filter, leg_estimate::updateOdometry (motion_estimate/src/leg_estimate/leg_estimate.cpp:395-556: 30 ms reset,
- * primary-foot selection through FootContactAlt::DetectFootTransition, pelvis pose slaved to the FILTER's own orientation,
- * :219-297) and foot_contact_classify::update (foot_contact_classify.cpp:57-125: status -1 / 0 / 1).  Forward kinematics is
- * the caller's (KDL + URDF in the reference): feet [14][B] = body-to-left-foot (t3, q4 = w,x,y,z), body-to-right-foot (t3, q4);
- * forces [2][B] = left, right vertical foot force.  `mem` as everywhere (PB_HOST_BROADCAST: one robot's joint state for a
- * whole parameter sweep).  Outputs are DEVICE arrays, any may be NULL: delta_out [7][B] (pelvis increment t3, q4),
+ * Replaces, per filter, leg_estimate::updateOdometry (motion_estimate/src/leg_estimate/leg_estimate.cpp:395-556: forward
+ * kinematics :430-447, 30 ms reset, primary-foot selection through FootContactAlt::DetectFootTransition or -- contact mode
+ * "standing" -- FootContact::DetectFootTransition, pelvis pose slaved to the FILTER's own orientation, :219-297) and
+ * foot_contact_classify::update (foot_contact_classify.cpp:57-125: status -1 / 0 / 1).  Inputs are either the two
+ * body-to-foot transforms (pb_legodo_update*: feet [14][B] = body-to-left-foot (t3, q4 = w,x,y,z), body-to-right-foot
+ * (t3, q4); forces [2][B] = left, right |vertical foot force|, doubles) or the joint state itself (pb_legodo_update_joints,
+ * after pb_legodo_set_chain).  `mem` as everywhere (PB_HOST_BROADCAST: one robot's message for a whole parameter sweep).
+ * Outputs are DEVICE arrays, any may be NULL: delta_out [7][B] (pelvis increment t3, q4),
  * status_out [B], and -- LegOdoCommon::createMeasurement in mode lin_rate (rbis_legodo_common.cpp:99-169) -- lo_block_out
- * [6][B] + mask_out [B] in exactly the form pb_step_legodo / pb_update_indexed take with PB_DEVICE. */
+ * [6][B] + mask_out [B] in exactly the form pb_step_legodo / pb_update_indexed take with PB_DEVICE.
+ * The thresholds are rounded to float like the reference's (leg_estimate.cpp:103-104); delays < 2e9 us. */
 int pb_legodo_init(pb_ctx *ctx, double schmitt_low_threshold, double schmitt_high_threshold, int64_t schmitt_low_delay_us,
                    int64_t schmitt_high_delay_us, int filter_contact_events);
 int pb_legodo_update(pb_ctx *ctx, int64_t utime, const double *feet, const double *forces, int mem, int zero_delta,
@@ -217,6 +220,45 @@ int pb_legodo_update(pb_ctx *ctx, int64_t utime, const double *feet, const doubl
 int pb_legodo_update_after_predict(pb_ctx *ctx, const double *imu_block, int imu_mem, int64_t utime, const double *feet,
                                    const double *forces, int mem, int zero_delta, double r_vxyz, double r_vxyz_uncertain,
                                    double *delta_out, double *status_out, double *lo_block_out, uint8_t *mask_out);
+/* Contact mode (leg_estimate.cpp:113-121): standing != 0 = state_estimator.legodo.init_contact_mode "standing", the
+ * conservative FootContact classifier (foot_contact/FootContact.cpp:29-54; total_force and standing_schmitt_level are floats
+ * there and here); use_controller_input != 0 lets the controller's contact counts overrule FootContactAlt's standing foot
+ * (leg_estimate.cpp:365-387).  Call after pb_legodo_init (which selects the default: FootContactAlt, no controller input). */
+int pb_legodo_set_contact_mode(pb_ctx *ctx, int standing, double total_force, double standing_schmitt_level,
+                               int use_controller_input);
+/* LegOdoHandler's "ignore the calculated velocity at launch" (state_estimator.legodo.zero_initial_velocity,
+ * rbis_legodo_update.cpp:58,264-268), counted PER FILTER on the device: the counter is decremented by every message whose
+ * status is valid for that filter (the reference returns NULL before the decrement otherwise, :243-255) and while it stays
+ * above zero the increment (and the position) handed on is the identity.  Independent of the per-call zero_delta flag. */
+int pb_legodo_set_zero_initial_velocity(pb_ctx *ctx, int ticks);
+/* The last CONTROLLER_FOOT_CONTACT message (LegOdoHandler::controllerInputHandler, rbis_legodo_update.cpp:190-193):
+ * n_contacts = {num_left_foot_contacts, num_right_foot_contacts} for every filter (PB_HOST_BROADCAST) or [2][B]
+ * (PB_HOST / PB_DEVICE); kept until the next call; before the first call both are -1 (rbis_legodo_update.cpp:100-101). */
+int pb_legodo_set_control_contacts(pb_ctx *ctx, const int32_t *n_contacts, int mem);
+/* Forward kinematics table: what kdl_parser + KDL::TreeFkSolverPosFull_recursive make of the URDF for the two standing links
+ * (leg_estimate.cpp:68-73,430-447; state_estimator.legodo.{left,right}_standing_link).  KDL and the URDF are not part of the
+ * reference tree, so the caller supplies, for the joints from the root link down to each standing link (left chain first,
+ * n_left + n_right entries): joint_type (0 fixed, 1 revolute / continuous, 2 prismatic), joint_row (row of the joint-position
+ * block that holds the joint, i.e. its index in joint_state_t.joint_name), origin_xyz_rpy [.][6] (the URDF <origin>),
+ * axis [.][3] (the URDF <axis>, normalised here like KDL::Joint does), adjustment_gain [.] or NULL
+ * (state_estimator.legodo.adjustment_gain of that joint, EstimateTools::TorqueAdjustment: 0, inf or nan = none).
+ * body_to_foot = prod_j [R(rpy_j), xyz_j] * Rot(axis_j, position_j).  At most 8 joints per leg. */
+int pb_legodo_set_chain(pb_ctx *ctx, int n_left, int n_right, const int *joint_type, const int *joint_row,
+                        const double *origin_xyz_rpy, const double *axis, const float *adjustment_gain);
+/* leg_estimate::updateOdometry from a joint state: joint_position [n_rows][B] floats (bot_core::joint_state_t carries
+ * floats), joint_effort [n_rows][B] or NULL (torque adjustment off, rbis_legodo_update.cpp:236-238), forces [2][B] floats
+ * (FootSensing::force_z).  PB_HOST_BROADCAST: [n_rows] / [2] values of ONE robot.  imu_block != NULL: slaved to the
+ * orientation after that IMU step, as pb_legodo_update_after_predict.  position_out [3][B] + position_status_out [B]
+ * (DEVICE, may be NULL): the pelvis position leg_estimate derives from the foot it last put down
+ * (getLegOdometryWorldConstraint, leg_estimate.cpp:299-318,461-492: world_to_body_constraint_ and its _init_ flag), which
+ * LegOdoCommon's mode pos_and_lin_rate measures; it is tracked from the first call that passes position_out.
+ * Everything else as pb_legodo_update. */
+int pb_legodo_update_joints(pb_ctx *ctx, const double *imu_block, int imu_mem, int64_t utime, int n_rows,
+                            const float *joint_position, const float *joint_effort, const float *forces, int mem, int zero_delta,
+                            double r_vxyz, double r_vxyz_uncertain, double *delta_out, double *status_out, double *lo_block_out,
+                            uint8_t *mask_out, double *position_out, uint8_t *position_status_out);
+/* forward kinematics alone (diagnostics, tests): feet_out [14][B] DEVICE array in pb_legodo_update's layout */
+int pb_legodo_fk(pb_ctx *ctx, int n_rows, const float *joint_position, const float *joint_effort, int mem, double *feet_out);
 /* one filter's odometry state, for diagnostics and tests: odom_to_body (t3, q4); info = primary_foot (0 left, 1 right),
  * leg_odo_init, walking-phase mode (foot_contact_classify.hpp:34-44), transitions the classifier did not know */
 int pb_legodo_get(pb_ctx *ctx, int filter, double odom_to_body[7], int64_t info[4]);

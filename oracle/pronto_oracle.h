@@ -143,6 +143,18 @@ void po_leg_init(po_leg *s, double schmitt_low, double schmitt_high, long low_de
 float po_leg_update(po_leg *s, long utime, const double *l_t, const double *l_q, const double *r_t, const double *r_q,
                     double lforce, double rforce, const double *world_to_body_quat, double *delta_t, double *delta_q,
                     long *prev_utime);
+/* contact mode "standing" (FootContact) and the controller-contact override (leg_estimate.cpp:113-121,322-393) */
+void po_leg_set_contact_mode(po_leg *s, int standing, double total_force, double standing_schmitt_level, int use_controller_input);
+float po_leg_update_cc(po_leg *s, long utime, const double *l_t, const double *l_q, const double *r_t, const double *r_q,
+                       double lforce, double rforce, int n_control_contacts_left, int n_control_contacts_right,
+                       const double *world_to_body_quat, double *delta_t, double *delta_q, long *prev_utime);
+float po_leg_update_wc(po_leg *s, long utime, const double *l_t, const double *l_q, const double *r_t, const double *r_q,
+                       double lforce, double rforce, int n_control_contacts_left, int n_control_contacts_right,
+                       const double *world_to_body_pos, const double *world_to_body_quat, double *delta_t, double *delta_q,
+                       long *prev_utime, double *constraint_pos, int *constraint_ok);
+/* forward kinematics of one chain as KDL computes it (leg_estimate.cpp:430-447), torque adjustment (torque_adjustment.cpp) */
+void po_fk(int n, const int *type, const double *origin_xyz_rpy, const double *axis, const double *angle, double *t_out, double *q_out);
+float po_torque_adjust(float position, float effort, float gain);
 void po_leg_get(const po_leg *s, double *odom_to_body_t, double *odom_to_body_q, int *primary_foot, int *leg_odo_init, int *mode,
                 int *unknown_transitions);
 

@@ -21,7 +21,8 @@ PB_CORR_POS_ORIENT, PB_CORR_POS_YAW = 0, 1
 
 def sources():
     return [os.path.join(CSRC, f) for f in ("pronto_batch.hip", "pb_step.hip", "pb_update.hip", "pb_update_ct.hip", "pb_smooth.hip", "pb_ctx.hpp",
-                                            "rbis_kernels.hpp", "rbis_legodo.hpp", "rbis_coop.hpp", "rbis_smooth.hpp", "rbis_device.hpp")] + [HEADER]
+                                            "rbis_kernels.hpp", "rbis_legodo.hpp", "rbis_coop.hpp", "rbis_quad.hpp", "rbis_smooth.hpp",
+                                            "rbis_device.hpp", "Makefile")] + [HEADER]
 
 
 def is_stale():
@@ -79,6 +80,14 @@ _SIGS = {
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pb_legodo_update_after_predict": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                                  C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pb_legodo_set_contact_mode": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_int]),
+    "pb_legodo_set_control_contacts": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    "pb_legodo_set_chain": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), _dp, _dp, C.POINTER(C.c_float)]),
+    "pb_legodo_update_joints": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                          C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_void_p]),
+    "pb_legodo_set_zero_initial_velocity": (C.c_int, [C.c_void_p, C.c_int]),
+    "pb_legodo_fk": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "pb_legodo_get": (C.c_int, [C.c_void_p, C.c_int, _dp, C.POINTER(C.c_int64)]),
     "pb_imu_notch_init": (C.c_int, [C.c_void_p, C.c_double, C.c_double]),
     "pb_imu_notch": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),

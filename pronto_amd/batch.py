@@ -32,7 +32,7 @@ def _ptr(a, dtype=np.float64, shape=None):
         raise ValueError("expected an array of shape %s, got %s" % (tuple(shape), tuple(a.shape)))
     if _is_torch(a):
         import torch
-        want = {np.float64: torch.float64, np.uint8: torch.uint8}[dtype]
+        want = {np.float64: torch.float64, np.uint8: torch.uint8, np.float32: torch.float32, np.int32: torch.int32}[dtype]
         if a.dtype != want or not a.is_contiguous():
             raise TypeError("expected a contiguous %s tensor" % want)
         return C.c_void_p(a.data_ptr()), (PB_DEVICE if a.is_cuda else PB_HOST)
@@ -41,13 +41,13 @@ def _ptr(a, dtype=np.float64, shape=None):
     return C.c_void_p(a.ctypes.data), PB_HOST
 
 
-def _ptr_block(a, rows=None, B=None):
+def _ptr_block(a, rows=None, B=None, dtype=np.float64):
     """Like _ptr for a [rows, B] data block; a 1-D numpy array of `rows` values means ONE message for every filter of the
     batch (PB_HOST_BROADCAST: expanded on the device, nothing of batch size crosses PCIe)."""
     if isinstance(a, np.ndarray) and a.ndim == 1:
-        p, _ = _ptr(a, shape=None if rows is None else (rows,))
+        p, _ = _ptr(a, dtype, shape=None if rows is None else (rows,))
         return p, PB_HOST_BROADCAST
-    return _ptr(a, shape=None if rows is None else (rows, B))
+    return _ptr(a, dtype, shape=None if rows is None else (rows, B))
 
 
 def _same_mem(*mems):
@@ -187,6 +187,59 @@ class BatchEstimator:
             return
         self._chk(self._L.pb_legodo_update(self._h, int(utime), pf, pz, _same_mem(m1, m2), int(bool(zero_delta)), r_vxyz,
                                            r_vxyz_uncertain, *outs))
+
+    def legodo_set_contact_mode(self, standing=False, total_force=0.0, standing_schmitt_level=0.0, use_controller_input=False):
+        self._chk(self._L.pb_legodo_set_contact_mode(self._h, int(bool(standing)), total_force, standing_schmitt_level,
+                                                     int(bool(use_controller_input))))
+
+    def legodo_set_zero_initial_velocity(self, ticks):
+        self._chk(self._L.pb_legodo_set_zero_initial_velocity(self._h, int(ticks)))
+
+    def legodo_set_control_contacts(self, n_contacts):
+        """[2] int32 (every filter) or [2,B] int32 (numpy or torch CUDA)."""
+        p, m = _ptr_block(n_contacts, 2, self.B, dtype=np.int32)
+        self._chk(self._L.pb_legodo_set_control_contacts(self._h, p, m))
+
+    def legodo_set_chain(self, n_left, n_right, joint_type, joint_row, origin_xyz_rpy, axis, adjustment_gain=None):
+        n = n_left + n_right
+        ty = (C.c_int * n)(*[int(v) for v in joint_type])
+        rw = (C.c_int * n)(*[int(v) for v in joint_row])
+        org = np.ascontiguousarray(origin_xyz_rpy, dtype=np.float64).reshape(n, 6)
+        ax = np.ascontiguousarray(axis, dtype=np.float64).reshape(n, 3)
+        gain = None if adjustment_gain is None else np.ascontiguousarray(adjustment_gain, dtype=np.float32).reshape(n)
+        dp = C.POINTER(C.c_double)
+        self._chk(self._L.pb_legodo_set_chain(self._h, n_left, n_right, ty, rw, org.ctypes.data_as(dp), ax.ctypes.data_as(dp),
+                                              None if gain is None else gain.ctypes.data_as(C.POINTER(C.c_float))))
+
+    def legodo_update_joints(self, utime, joint_position, joint_effort, forces, r_vxyz, r_vxyz_uncertain, delta_out=None,
+                             status_out=None, lo_out=None, mask_out=None, zero_delta=False, after_predict=None, position_out=None,
+                             position_status_out=None):
+        """leg_estimate::updateOdometry from a joint state: joint_position [rows,B] float32 (or [rows] broadcast),
+        joint_effort the same or None, forces [2,B] float32 (or [2]).  Outputs as legodo_update."""
+        rows = joint_position.shape[0]
+        pj, m1 = _ptr_block(joint_position, rows, self.B, dtype=np.float32)
+        pe, m2 = (None, None) if joint_effort is None else _ptr_block(joint_effort, rows, self.B, dtype=np.float32)
+        pz, m3 = _ptr_block(forces, 2, self.B, dtype=np.float32)
+        outs = []
+        for a, dt, shp in ((delta_out, np.float64, (7, self.B)), (status_out, np.float64, (self.B,)),
+                           (lo_out, np.float64, (6, self.B)), (mask_out, np.uint8, (self.B,)),
+                           (position_out, np.float64, (3, self.B)), (position_status_out, np.uint8, (self.B,))):
+            p, m = _ptr(a, dt, shape=shp)
+            if a is not None and m != PB_DEVICE:
+                raise ValueError("legodo_update_joints outputs must be device tensors")
+            outs.append(p)
+        pi, mi = (None, PB_DEVICE) if after_predict is None else _ptr_block(after_predict, 7, self.B)
+        self._chk(self._L.pb_legodo_update_joints(self._h, pi, mi, int(utime), rows, pj, pe, pz, _same_mem(m1, m2, m3),
+                                                  int(bool(zero_delta)), r_vxyz, r_vxyz_uncertain, *outs))
+
+    def legodo_fk(self, joint_position, joint_effort, feet_out):
+        rows = joint_position.shape[0]
+        pj, m1 = _ptr_block(joint_position, rows, self.B, dtype=np.float32)
+        pe, m2 = (None, None) if joint_effort is None else _ptr_block(joint_effort, rows, self.B, dtype=np.float32)
+        po, mo = _ptr(feet_out, shape=(14, self.B))
+        if mo != PB_DEVICE:
+            raise ValueError("legodo_fk output must be a device tensor")
+        self._chk(self._L.pb_legodo_fk(self._h, rows, pj, pe, _same_mem(m1, m2), po))
 
     def legodo_get(self, b):
         pose = (C.c_double * 7)()

@@ -858,6 +858,22 @@ struct foot_state_t {        // what forward kinematics + the foot sensors give 
   BatchArray feet;           // [14][B]: body-to-left-foot (t3, q4 = w,x,y,z), body-to-right-foot (t3, q4)
   BatchArray forces;         // [2][B]: left, right vertical foot force
 };
+struct joint_state_t {       // bot_core::joint_state_t: the arrays are float on the wire and here
+  int64_t utime;
+  std::vector<std::string> joint_name;      // num_joints names, the same for every filter
+  const float *joint_position = nullptr;    // [num_joints][B] (PB_HOST / PB_DEVICE) or [num_joints] (PB_HOST_BROADCAST)
+  const float *joint_velocity = nullptr;    // (only the joint Kalman filter reads it, leg_estimate.cpp:418-426: not built)
+  const float *joint_effort = nullptr;      // same shape as joint_position; read when legodo.torque_adjustment is set
+  int mem = PB_HOST;
+};
+struct six_axis_force_torque_array_t {   // bot_core::six_axis_force_torque_array_t: what the leg odometry reads of it
+  int64_t utime;
+  BatchArray force_z;        // [2][B] (PB_HOST) or [2] (PB_HOST_BROADCAST): sensors[0].force[2], sensors[1].force[2] (left, right foot)
+};
+struct controller_foot_contact_t {       // pronto::controller_foot_contact_t
+  int64_t utime;
+  int32_t num_left_foot_contacts, num_right_foot_contacts;
+};
 struct update_t {            // pronto::update_t (fovis)
   int64_t timestamp, prev_timestamp;
   const uint8_t *estimate_valid;   // [B] or NULL: estimate_status == ESTIMATE_VALID
@@ -1399,58 +1415,271 @@ public:
   }
 };
 
-// LegOdoHandler::processMessage (rbis_legodo_update.cpp:206-280) minus the kinematics: leg_estimate (KDL forward
-// kinematics + contact classifier, out of scope) is the producer of msgs::legodo_delta_t.
+// ModelClient (the reference hands its URDF string to kdl_parser, leg_estimate.cpp:68-73): here it carries what the
+// forward kinematics of the two standing links needs of the robot model -- per leg the joints from the root link down to
+// the standing link with their <origin>, <axis> and type -- filled in by hand or by fromURDFString(), a reader for exactly
+// those URDF elements (<joint name type> with <parent link>, <child link>, <origin xyz rpy>, <axis xyz>).
+class ModelClient {
+public:
+  struct Joint {
+    std::string name;
+    int type = 1;  // 0 fixed, 1 revolute / continuous, 2 prismatic (pb_legodo_set_chain)
+    double xyz[3] = { 0, 0, 0 }, rpy[3] = { 0, 0, 0 }, axis[3] = { 1, 0, 0 };  // (URDF defaults)
+  };
+  std::vector<Joint> left_chain, right_chain;
+  std::string urdf;
+  std::string getURDFString() const { return urdf; }
+
+  // the chain of joints from the root link to `link`; false if the link is not the child of any joint or a joint type is
+  // not one the chain table knows (floating, planar)
+  static bool chainTo(const std::string &urdf_xml, const std::string &link, std::vector<Joint> &chain)
+  {
+    struct J { Joint j; std::string parent, child; };
+    std::vector<J> all;
+    auto attr = [](const std::string &tag, const char *name, std::string &out) {
+      const std::string key = std::string(name) + "=";
+      size_t p = 0;
+      while ((p = tag.find(key, p)) != std::string::npos) {
+        if (p > 0 && (isalnum((unsigned char) tag[p - 1]) || tag[p - 1] == '_')) { p += key.size(); continue; }
+        p += key.size();
+        if (p >= tag.size() || (tag[p] != '"' && tag[p] != '\'')) continue;
+        const char qc = tag[p];
+        const size_t e = tag.find(qc, p + 1);
+        if (e == std::string::npos) return false;
+        out = tag.substr(p + 1, e - p - 1);
+        return true;
+      }
+      return false;
+    };
+    auto three = [](const std::string &v, double *o) { return sscanf(v.c_str(), "%lf %lf %lf", o, o + 1, o + 2) == 3; };
+    size_t pos = 0;
+    while ((pos = urdf_xml.find("<joint", pos)) != std::string::npos) {
+      const size_t head_end = urdf_xml.find('>', pos);
+      if (head_end == std::string::npos) break;
+      const std::string head = urdf_xml.substr(pos, head_end - pos + 1);
+      const char nx = urdf_xml[pos + 6];
+      if (!(nx == ' ' || nx == '\t' || nx == '\n' || nx == '\r')) { pos = head_end; continue; }  // e.g. <joint_properties>
+      std::string type;
+      J j;
+      if (!attr(head, "name", j.j.name) || !attr(head, "type", type) || head[head.size() - 2] == '/') { pos = head_end; continue; }  // (a <transmission>'s <joint name=.../>)
+      const size_t end = urdf_xml.find("</joint>", head_end);
+      if (end == std::string::npos) break;
+      const std::string body = urdf_xml.substr(head_end + 1, end - head_end - 1);
+      pos = end;
+      j.j.type = (type == "fixed") ? 0 : (type == "revolute" || type == "continuous") ? 1 : (type == "prismatic") ? 2 : -1;
+      auto child_tag = [&](const char *name, std::string &tag) {
+        const size_t p = body.find(std::string("<") + name);
+        if (p == std::string::npos) return false;
+        const size_t e = body.find('>', p);
+        if (e == std::string::npos) return false;
+        tag = body.substr(p, e - p + 1);
+        return true;
+      };
+      std::string tag, v;
+      if (!child_tag("parent", tag) || !attr(tag, "link", j.parent)) continue;
+      if (!child_tag("child", tag) || !attr(tag, "link", j.child)) continue;
+      if (child_tag("origin", tag)) {
+        if (attr(tag, "xyz", v)) three(v, j.j.xyz);
+        if (attr(tag, "rpy", v)) three(v, j.j.rpy);
+      }
+      if (child_tag("axis", tag) && attr(tag, "xyz", v)) three(v, j.j.axis);
+      all.push_back(j);
+    }
+    chain.clear();
+    std::string cur = link;
+    for (size_t guard = 0; guard <= all.size(); guard++) {
+      const J *up = nullptr;
+      for (const J &j : all)
+        if (j.child == cur) up = &j;
+      if (up == nullptr) break;  // cur is the root link
+      if (up->j.type < 0) return false;
+      chain.insert(chain.begin(), up->j);
+      cur = up->parent;
+    }
+    return !chain.empty();
+  }
+  bool fromURDFString(const std::string &urdf_xml, const std::string &left_standing_link, const std::string &right_standing_link)
+  {
+    urdf = urdf_xml;
+    return chainTo(urdf_xml, left_standing_link, left_chain) && chainTo(urdf_xml, right_standing_link, right_chain);
+  }
+};
+
+// LegOdoHandler (rbis_legodo_update.cpp:10-280).  processMessage(joint_state_t) is the reference's handler: torque
+// adjustment, forward kinematics, leg_estimate::updateOdometry and LegOdoCommon::createMeasurement -- all of it per filter
+// on the device, because its world_to_body_ is the filter's own head pose (:214-229).  processMessageFeet takes the two
+// body-to-foot transforms instead of the joint angles (a caller with its own kinematics), processMessageDelta the finished
+// increment.
 class LegOdoHandler {
 public:
   LegOdoCommon *leg_odo_common_;
   int zero_initial_velocity;      // rbis_legodo_update.cpp:58,265-269
   bool force_torque_init_ = true; // rbis_legodo_update.cpp:98,197,208-211: nothing is integrated before the first
-                                  // force/torque message; a host that replays F/T sets this false and calls
-                                  // forceTorqueHandler() from its F/T callback (the deltas fed here already contain
-                                  // leg_estimate's use of the foot sensing, so the default is "seen")
+                                  // force/torque message; the joint-state path starts with false like the reference (its foot
+                                  // forces come from forceTorqueHandler); the increment / foot-state paths, whose callers
+                                  // already hold the foot sensing, start with true
   explicit LegOdoHandler(BotParam *param) : leg_odo_common_(new LegOdoCommon(param)), zero_initial_velocity(0), param_(param)
   {
     auto it = param->kv.find("state_estimator.legodo.zero_initial_velocity");
     if (it != param->kv.end()) zero_initial_velocity = atoi(it->second.c_str());
   }
+  // the reference's constructor (lcm_recv, lcm_pub, param, model, frames) without the LCM objects and BotFrames
+  LegOdoHandler(BotParam *param, const ModelClient *model) : LegOdoHandler(param)
+  {
+    model_ = model;
+    force_torque_init_ = false;
+    // leg_estimate's constructor (leg_estimate.cpp:29-142)
+    const std::string init_mode = bot_param_get_str_or_fail(param, "state_estimator.legodo.initialization_mode");
+    if (init_mode != "zero") fprintf(stdout, "Leg Odometry Initialize Mode: %s (only \"zero\" moves the pose, leg_estimate.cpp:172-190)\n", init_mode.c_str());
+    const std::string filt = bot_param_get_str_or_fail(param, "state_estimator.legodo.filter_joint_positions");
+    if (filt == "lowpass" || filt == "kalman") {
+      fprintf(stderr, "LegOdoHandler: state_estimator.legodo.filter_joint_positions = %s is not built (use none)\n", filt.c_str());
+      exit(1);
+    }
+    use_torque_adjustment_ = bot_param_get_boolean_or_fail(param, "state_estimator.legodo.torque_adjustment");
+    if (use_torque_adjustment_) {  // rbis_legodo_update.cpp:29-53
+      const std::string &names = bot_param_get_raw_or_fail(param, "state_estimator.legodo.adjustment_joints");
+      size_t p = 0;
+      while (p < names.size()) {
+        while (p < names.size() && (names[p] == ' ' || names[p] == ',' || names[p] == '[' || names[p] == ']' || names[p] == '"')) p++;
+        size_t e = p;
+        while (e < names.size() && names[e] != ' ' && names[e] != ',' && names[e] != ']' && names[e] != '"') e++;
+        if (e > p) adjustment_joints_.push_back(names.substr(p, e - p));
+        p = e;
+      }
+      std::vector<double> g(adjustment_joints_.size());
+      bot_param_get_double_array_or_fail(param, "state_estimator.legodo.adjustment_gain", g.data(), (int) g.size());
+      for (double v : g) adjustment_gain_.push_back((float) v);
+    }
+  }
   ~LegOdoHandler() { delete leg_odo_common_; }
   void forceTorqueHandler() { force_torque_init_ = true; }
-
-  // The whole reference handler (rbis_legodo_update.cpp:206-280) from what forward kinematics produces: leg_estimate's
-  // updateOdometry runs on the device for every filter -- its world_to_body_ is the filter's own head orientation, which
-  // lives there (:214-229) -- and in mode lin_rate the measurement is formed there too and never visits the host.
-  // Parameters: state_estimator.legodo.{schmitt_low_threshold, schmitt_high_threshold, schmitt_low_delay,
-  // schmitt_high_delay, filter_contact_events} (leg_estimate.cpp:63,103-108).
-  BotParam *param_ = nullptr;
-  std::shared_ptr<DevicePool> pool_;
-  bool legodo_ready_ = false;
-  RBISUpdateInterface *processMessageFeet(const msgs::foot_state_t *msg, MavStateEstimator *est)
+  // rbis_legodo_update.cpp:195-204: keep the last force/torque message; processMessage reads |force z| of the two feet
+  void forceTorqueHandler(const msgs::six_axis_force_torque_array_t *msg, int B)
   {
-    if (!force_torque_init_) {
-      fprintf(stdout, "Force/Torque message not received yet, not integrating leg odometry =========================\n");
-      return nullptr;
-    }
+    const size_t n = (msg->force_z.mem == PB_HOST_BROADCAST) ? 2 : (size_t) 2 * B;
+    foot_force_.resize(n);
+    for (size_t i = 0; i < n; i++) foot_force_[i] = (float) fabs(msg->force_z.p[i]);  // FootSensing(fabs(...)) (:234-235), float members
+    foot_force_mem_ = (msg->force_z.mem == PB_HOST_BROADCAST) ? PB_HOST_BROADCAST : PB_HOST;
+    foot_force_dev_ = nullptr;
+    force_torque_init_ = true;
+  }
+  // device-resident replays: |force z| [2][B] floats in HBM, valid until the next call
+  void forceTorqueDevice(const float *abs_force_z)
+  {
+    foot_force_dev_ = abs_force_z;
+    force_torque_init_ = true;
+  }
+  // rbis_legodo_update.cpp:190-193
+  void controllerInputHandler(const msgs::controller_foot_contact_t *msg)
+  {
+    n_control_contacts_[0] = msg->num_left_foot_contacts;
+    n_control_contacts_[1] = msg->num_right_foot_contacts;
+    control_contacts_dirty_ = true;
+  }
+
+  BotParam *param_ = nullptr;
+  const ModelClient *model_ = nullptr;
+  bool use_torque_adjustment_ = false;
+  std::vector<std::string> adjustment_joints_;
+  std::vector<float> adjustment_gain_;
+  std::vector<float> foot_force_;
+  int foot_force_mem_ = PB_HOST;
+  const float *foot_force_dev_ = nullptr;
+  int32_t n_control_contacts_[2] = { -1, -1 };
+  bool control_contacts_dirty_ = false;
+  std::shared_ptr<DevicePool> pool_;
+  bool legodo_ready_ = false, chain_ready_ = false;
+  std::vector<std::string> chain_names_;  // the joint_name list the chain rows were resolved against
+
+  // leg_estimate's constructor parameters (leg_estimate.cpp:63,93-121) -> the device side, once
+  void initLegEstimate(MavStateEstimator *est)
+  {
     const int B = est->B;
-    // The odometry reads the head orientation.  An INS step that fuse_ins_legodo is holding back is either applied first,
-    // or -- when the measurement made here will pair with it (mode lin_rate) -- left pending: the device then slaves the
-    // odometry to the orientation "after that step" (pb_legodo_update_after_predict) and the pair runs as one fused kernel.
-    RBISIMUProcessStep *ahead = (leg_odo_common_->mode_ == LegOdoCommon::MODE_LIN_RATE) ? est->pendingImu() : nullptr;
-    if (ahead != nullptr && ahead->imu_block.mem == PB_HOST && msg->feet.mem == PB_HOST) ahead = nullptr;  // one host staging area
-    if (ahead == nullptr) est->flushPending();
-    if (!legodo_ready_) {
-      const double lt = bot_param_get_double_or_fail(param_, "state_estimator.legodo.schmitt_low_threshold");
-      const double ht = bot_param_get_double_or_fail(param_, "state_estimator.legodo.schmitt_high_threshold");
-      const int64_t ld = (int64_t) bot_param_get_double_or_fail(param_, "state_estimator.legodo.schmitt_low_delay");
-      const int64_t hd = (int64_t) bot_param_get_double_or_fail(param_, "state_estimator.legodo.schmitt_high_delay");
-      const std::string fce = bot_param_get_str_or_fail(param_, "state_estimator.legodo.filter_contact_events");
-      if (pb_legodo_init(est->ctx, lt, ht, ld, hd, fce == "true" || fce == "1") != PB_OK) {
-        fprintf(stderr, "LegOdoHandler: %s\n", pb_last_error(est->ctx));
-        exit(1);
+    const double lt = bot_param_get_double_or_fail(param_, "state_estimator.legodo.schmitt_low_threshold");
+    const double ht = bot_param_get_double_or_fail(param_, "state_estimator.legodo.schmitt_high_threshold");
+    const int64_t ld = (int64_t) bot_param_get_double_or_fail(param_, "state_estimator.legodo.schmitt_low_delay");
+    const int64_t hd = (int64_t) bot_param_get_double_or_fail(param_, "state_estimator.legodo.schmitt_high_delay");
+    const bool fce = bot_param_get_boolean_or_fail(param_, "state_estimator.legodo.filter_contact_events");
+    bool bad = pb_legodo_init(est->ctx, lt, ht, ld, hd, fce) != PB_OK;
+    // the contact mode keys are read by leg_estimate's constructor, i.e. only when the handler was given a robot model
+    if (!bad && model_ != nullptr) {
+      const bool standing = bot_param_get_str_or_fail(param_, "state_estimator.legodo.init_contact_mode") == "standing";
+      const double total_force = bot_param_get_double_or_fail(param_, "state_estimator.legodo.total_force");
+      const double level = bot_param_get_double_or_fail(param_, "state_estimator.legodo.standing_schmitt_level");
+      const bool ctrl = bot_param_get_boolean_or_fail(param_, "state_estimator.legodo.use_controller_input");
+      bad = pb_legodo_set_contact_mode(est->ctx, standing, total_force, level, ctrl) != PB_OK;
+    }
+    // "ignore the calculated velocity at launch" is counted per filter on the device (valid ticks only, like :243-268)
+    if (!bad) bad = pb_legodo_set_zero_initial_velocity(est->ctx, zero_initial_velocity) != PB_OK;
+    if (bad) {
+      fprintf(stderr, "LegOdoHandler: %s\n", pb_last_error(est->ctx));
+      exit(1);
+    }
+    // per update: lo block [6][B] | increment [7][B] | status [B] | position [3][B] (doubles) | mask [B] | position status [B]
+    pool_ = std::make_shared<DevicePool>(est->ctx, est->ctx_alive, sizeof(double) * 17 * (size_t) B + 2 * (size_t) B);
+    legodo_ready_ = true;
+  }
+  // fksolver_->JntToCart looks joints up by name (leg_estimate.cpp:432-436): resolve the chain's names against the message's
+  void initChain(const msgs::joint_state_t *msg, MavStateEstimator *est)
+  {
+    std::vector<int> type, row;
+    std::vector<double> org, axis;
+    std::vector<float> gain;
+    for (const std::vector<ModelClient::Joint> *chain : { &model_->left_chain, &model_->right_chain })
+      for (const ModelClient::Joint &j : *chain) {
+        int r = 0;
+        if (j.type != 0) {
+          const auto it = std::find(msg->joint_name.begin(), msg->joint_name.end(), j.name);
+          if (it == msg->joint_name.end()) {  // KDL treats a missing joint as an error; the reference then exit(-1)s (:438-441)
+            fprintf(stderr, "Error: could not calculate forward kinematics! (joint %s is not in the joint state)\n", j.name.c_str());
+            exit(-1);
+          }
+          r = (int) (it - msg->joint_name.begin());
+        }
+        type.push_back(j.type);
+        row.push_back(r);
+        for (int i = 0; i < 3; i++) org.push_back(j.xyz[i]);
+        for (int i = 0; i < 3; i++) org.push_back(j.rpy[i]);
+        for (int i = 0; i < 3; i++) axis.push_back(j.axis[i]);
+        float g = 0.0f;
+        if (use_torque_adjustment_) {
+          const auto it = std::find(adjustment_joints_.begin(), adjustment_joints_.end(), j.name);
+          if (it != adjustment_joints_.end()) g = adjustment_gain_[(size_t) (it - adjustment_joints_.begin())];
+        }
+        gain.push_back(g);
       }
-      // per update: lo block [6][B] | increment [7][B] | status [B] (doubles) | mask [B]
-      pool_ = std::make_shared<DevicePool>(est->ctx, est->ctx_alive, sizeof(double) * 14 * (size_t) B + (size_t) B);
-      legodo_ready_ = true;
+    if (use_torque_adjustment_)
+      for (const std::string &n : adjustment_joints_)
+        if (std::find(msg->joint_name.begin(), msg->joint_name.end(), n) == msg->joint_name.end()) {
+          fprintf(stdout, "TorqueAdjustment: %s joint not found\n", n.c_str());  // torque_adjustment.cpp:44-46
+          exit(-1);
+        }
+    if (pb_legodo_set_chain(est->ctx, (int) model_->left_chain.size(), (int) model_->right_chain.size(), type.data(), row.data(), org.data(),
+                            axis.data(), use_torque_adjustment_ ? gain.data() : nullptr) != PB_OK) {
+      fprintf(stderr, "LegOdoHandler: %s\n", pb_last_error(est->ctx));
+      exit(1);
+    }
+    chain_names_ = msg->joint_name;
+    chain_ready_ = true;
+  }
+
+  // what both device-side entry points share: the pending-IMU decision, the odometry launch (`launch` gets the IMU block to
+  // run ahead of, or NULL, and the output pointers) and the measurement LegOdoCommon forms from its result
+  template <class LAUNCH>
+  RBISUpdateInterface *odometryUpdate(MavStateEstimator *est, int64_t utime, int input_mem, LAUNCH &&launch)
+  {
+    const int B = est->B;
+    // The odometry reads the head pose.  An INS step that fuse_ins_legodo is holding back is either applied first, or -- when
+    // the measurement made here will pair with it (mode lin_rate) -- left pending: the device then slaves the odometry to the
+    // pose "after that step" and the pair runs as one fused kernel.
+    RBISIMUProcessStep *ahead = (leg_odo_common_->mode_ == LegOdoCommon::MODE_LIN_RATE) ? est->pendingImu() : nullptr;
+    if (ahead != nullptr && ahead->imu_block.mem == PB_HOST && input_mem == PB_HOST) ahead = nullptr;  // one host staging area
+    if (ahead == nullptr) est->flushPending();
+    if (!legodo_ready_) initLegEstimate(est);
+    if (control_contacts_dirty_) {
+      if (pb_legodo_set_control_contacts(est->ctx, n_control_contacts_, PB_HOST_BROADCAST) != PB_OK) fprintf(stderr, "LegOdoHandler: %s\n", pb_last_error(est->ctx));
+      control_contacts_dirty_ = false;
     }
     bool fresh = false;
     void *blk = pool_->get(fresh);
@@ -1459,46 +1688,107 @@ public:
       return nullptr;
     }
     auto block = std::make_shared<DeviceBlock>(pool_, blk);
-    double *d_lo = (double *) blk, *d_delta = d_lo + (size_t) 6 * B, *d_status = d_delta + (size_t) 7 * B;
-    uint8_t *d_mask = (uint8_t *) (d_status + (size_t) B);
-    zero_initial_velocity--;  // decrement first, then compare (:264-268)
-    const int zero = zero_initial_velocity > 0;
+    double *d_lo = (double *) blk, *d_delta = d_lo + (size_t) 6 * B, *d_status = d_delta + (size_t) 7 * B, *d_pos = d_status + (size_t) B;
+    uint8_t *d_mask = (uint8_t *) (d_pos + (size_t) 3 * B), *d_pos_ok = d_mask + (size_t) B;
     const LegOdoCommon *lc = leg_odo_common_;
     // (mode lin_rate consumes the measurement block and the mask only: the increment and the status are not written out)
-    const bool lin = lc->mode_ == LegOdoCommon::MODE_LIN_RATE;
-    double *o_delta = lin ? nullptr : d_delta, *o_status = lin ? nullptr : d_status;
-    const int lrc = ahead ? pb_legodo_update_after_predict(est->ctx, ahead->imu_block.p, ahead->imu_block.mem, msg->utime, msg->feet.p,
-                                                           msg->forces.p, msg->feet.mem, zero, lc->R_legodo_vxyz_,
-                                                           lc->R_legodo_vxyz_uncertain_, o_delta, o_status, d_lo, d_mask)
-                          : pb_legodo_update(est->ctx, msg->utime, msg->feet.p, msg->forces.p, msg->feet.mem, zero, lc->R_legodo_vxyz_,
-                                             lc->R_legodo_vxyz_uncertain_, o_delta, o_status, d_lo, d_mask);
+    const bool lin = lc->mode_ == LegOdoCommon::MODE_LIN_RATE, want_pos = lc->mode_ == LegOdoCommon::MODE_POSITION_AND_LIN_RATE;
+    const int lrc = launch(ahead, lin ? nullptr : d_delta, lin ? nullptr : d_status, d_lo, d_mask, want_pos ? d_pos : nullptr,
+                           want_pos ? d_pos_ok : nullptr);
     if (lrc != PB_OK) {
       fprintf(stderr, "LegOdoHandler: %s\n", pb_last_error(est->ctx));
       return nullptr;
     }
-    if (lc->mode_ == LegOdoCommon::MODE_LIN_RATE) {
+    if (lin) {
       auto *u = new RBISIndexedMeasurement(RBIS::velocityInds(), BatchArray(d_lo, PB_DEVICE), d_lo + (size_t) 3 * B, PB_R_DIAG, d_mask,
-                                           RBISUpdateInterface::legodo, msg->utime);
+                                           RBISUpdateInterface::legodo, utime);
       u->owned_dev = block;
       return u;
     }
-    // the other modes form their measurement on the host: fetch the increment and the status
-    std::vector<double> delta((size_t) 7 * B), status((size_t) B);
+    // the other modes form their measurement on the host: fetch the increment, the status (and the position)
+    std::vector<double> delta((size_t) 7 * B), status((size_t) B), pos;
     std::vector<float> fstatus((size_t) B);
+    std::vector<int> pos_status;
     pb_memcpy_d2h(est->ctx, delta.data(), d_delta, sizeof(double) * 7 * B);
     pb_memcpy_d2h(est->ctx, status.data(), d_status, sizeof(double) * B);
+    if (want_pos) {
+      std::vector<uint8_t> ok((size_t) B);
+      pos.resize((size_t) 3 * B);
+      pb_memcpy_d2h(est->ctx, pos.data(), d_pos, sizeof(double) * 3 * B);
+      pb_memcpy_d2h(est->ctx, ok.data(), d_pos_ok, (size_t) B);
+      pos_status.assign(ok.begin(), ok.end());
+    } else if (lc->mode_ == LegOdoCommon::MODE_POSITION_AND_LIN_RATE) {
+      pos_status.assign((size_t) B, 0);
+    }
     for (int b = 0; b < B; b++) fstatus[b] = (float) status[b];
-    msgs::legodo_delta_t m2{ msg->utime, prev_feet_utime_, nullptr, delta.data(), delta.data() + (size_t) 3 * B, nullptr, fstatus.data() };
-    prev_feet_utime_ = msg->utime;
+    msgs::legodo_delta_t m2{ utime, prev_legodo_utime_, want_pos ? pos.data() : nullptr, delta.data(), delta.data() + (size_t) 3 * B,
+                             pos_status.empty() ? nullptr : pos_status.data(), fstatus.data() };
+    prev_legodo_utime_ = utime;
     return leg_odo_common_->createMeasurement(&m2, B);
   }
-  int64_t prev_feet_utime_ = 0;
+  int64_t prev_legodo_utime_ = 0;
 
-  RBISUpdateInterface *processMessage(const msgs::legodo_delta_t *msg, MavStateEstimator *est)
+  // the reference's handler (rbis_legodo_update.cpp:206-280)
+  RBISUpdateInterface *processMessage(const msgs::joint_state_t *msg, MavStateEstimator *est)
   {
     if (!force_torque_init_) {
       fprintf(stdout, "Force/Torque message not received yet, not integrating leg odometry =========================\n");
       return nullptr;
+    }
+    if (model_ == nullptr) {
+      fprintf(stderr, "LegOdoHandler: a joint_state_t needs the robot model (construct the handler with a ModelClient)\n");
+      exit(1);
+    }
+    if (!legodo_ready_) initLegEstimate(est);
+    if (!chain_ready_ || msg->joint_name != chain_names_) initChain(msg, est);
+    const float *forces = foot_force_dev_ ? foot_force_dev_ : foot_force_.data();
+    const int fmem = foot_force_dev_ ? PB_DEVICE : foot_force_mem_;
+    if (fmem != msg->mem) {
+      fprintf(stderr, "LegOdoHandler: the joint state and the force/torque message must live in the same memory space\n");
+      return nullptr;
+    }
+    const int rows = (int) msg->joint_name.size();
+    const LegOdoCommon *lc = leg_odo_common_;
+    return odometryUpdate(est, msg->utime, msg->mem,
+                          [&](RBISIMUProcessStep *ahead, double *o_delta, double *o_status, double *d_lo, uint8_t *d_mask, double *o_pos, uint8_t *o_pos_ok) {
+                            return pb_legodo_update_joints(est->ctx, ahead ? ahead->imu_block.p : nullptr, ahead ? ahead->imu_block.mem : PB_DEVICE,
+                                                           msg->utime, rows, msg->joint_position, use_torque_adjustment_ ? msg->joint_effort : nullptr,
+                                                           forces, msg->mem, 0, lc->R_legodo_vxyz_, lc->R_legodo_vxyz_uncertain_, o_delta, o_status,
+                                                           d_lo, d_mask, o_pos, o_pos_ok);
+                          });
+  }
+
+  // the same from what forward kinematics produces (msgs::foot_state_t); no pelvis position: mode pos_and_lin_rate falls back
+  // to lin_rate like the reference does while its world constraint is not initialised (rbis_legodo_common.cpp:118-122)
+  RBISUpdateInterface *processMessageFeet(const msgs::foot_state_t *msg, MavStateEstimator *est)
+  {
+    if (!force_torque_init_) {
+      fprintf(stdout, "Force/Torque message not received yet, not integrating leg odometry =========================\n");
+      return nullptr;
+    }
+    const LegOdoCommon *lc = leg_odo_common_;
+    return odometryUpdate(est, msg->utime, msg->feet.mem,
+                          [&](RBISIMUProcessStep *ahead, double *o_delta, double *o_status, double *d_lo, uint8_t *d_mask, double *, uint8_t *) {
+                            return ahead ? pb_legodo_update_after_predict(est->ctx, ahead->imu_block.p, ahead->imu_block.mem, msg->utime, msg->feet.p,
+                                                                          msg->forces.p, msg->feet.mem, 0, lc->R_legodo_vxyz_,
+                                                                          lc->R_legodo_vxyz_uncertain_, o_delta, o_status, d_lo, d_mask)
+                                         : pb_legodo_update(est->ctx, msg->utime, msg->feet.p, msg->forces.p, msg->feet.mem, 0, lc->R_legodo_vxyz_,
+                                                            lc->R_legodo_vxyz_uncertain_, o_delta, o_status, d_lo, d_mask);
+                          });
+  }
+
+  // from a finished increment (a caller that runs its own leg_estimate): createMeasurement and the handler's gates
+  RBISUpdateInterface *processMessageDelta(const msgs::legodo_delta_t *msg, MavStateEstimator *est)
+  {
+    if (!force_torque_init_) {
+      fprintf(stdout, "Force/Torque message not received yet, not integrating leg odometry =========================\n");
+      return nullptr;
+    }
+    // (:243-255) "Leg Odometry is not valid not integrating": no update and no decrement when no filter has a valid increment
+    if (msg->delta_status != nullptr) {
+      bool any = false;
+      for (int b = 0; b < est->B && !any; b++) any = msg->delta_status[b] >= 0;
+      if (!any) return nullptr;
     }
     // "Ignore the calculated velocity at launch" (:264-269): decrement FIRST, then compare -- N zeroes N-1 ticks
     zero_initial_velocity--;

@@ -30,6 +30,12 @@ struct pb_ctx {
   double *legd = nullptr;   // leg odometry state (pb_legodo_init): [NLD][stride] doubles ...
   int64_t *legi = nullptr;  // ... and [NLI][stride] 64-bit integers (rbis_legodo.hpp)
   LegPar leg_par;
+  LegChain *leg_chain = nullptr;  // forward-kinematics chain table (pb_legodo_set_chain), device copy ...
+  LegChain leg_chain_h;           // ... and the host copy (PB_HOST_BROADCAST joint states are reduced to chain angles on the host)
+  int leg_chain_rows = 0;         // rows a joint-position block must have (highest row the chain reads + 1)
+  int32_t *leg_nc = nullptr;      // controller contact counts [2][B] (pb_legodo_set_control_contacts), used when leg_nc_dev
+  int leg_nc_h[2] = { -1, -1 };   // ... or ONE pair for every filter (-1: none received yet)
+  bool leg_nc_dev = false;
   double *notch = nullptr;  // IMU notch cascade state [36][stride] (pb_imu_notch_init)
   NotchCoef notch_coef;
   bool notch_ready = false;

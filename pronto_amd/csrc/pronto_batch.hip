@@ -113,6 +113,8 @@ extern "C" int pb_destroy(pb_ctx *c)
   if (c->notch) (void) hipFree(c->notch);
   if (c->legd) (void) hipFree(c->legd);
   if (c->legi) (void) hipFree(c->legi);
+  if (c->leg_chain) (void) hipFree(c->leg_chain);
+  if (c->leg_nc) (void) hipFree(c->leg_nc);
   if (c->d_small) (void) hipFree(c->d_small);
   if (c->stage) (void) hipFree(c->stage);
   if (c->copy_stream) (void) hipStreamSynchronize(c->copy_stream);
@@ -790,11 +792,166 @@ extern "C" int pb_legodo_init(pb_ctx *c, double lt, double ht, int64_t low_delay
 {
   ENTER(c);
   if (!(ht >= lt) || low_delay < 0 || high_delay < 0) return fail(c, PB_ERR_ARG, "pb_legodo_init: need high >= low threshold, delays >= 0");
-  if (!c->legd) HIPCHK(c, hipMalloc((void **) &c->legd, sizeof(double) * NLD * c->stride));
+  if (low_delay > 2000000000LL || high_delay > 2000000000LL) return fail(c, PB_ERR_ARG, "pb_legodo_init: delays must be below 2e9 us");
+  if (!c->legd) HIPCHK(c, hipMalloc((void **) &c->legd, sizeof(double) * (NLD + NLD_WC) * c->stride));
   if (!c->legi) HIPCHK(c, hipMalloc((void **) &c->legi, sizeof(int64_t) * NLI * c->stride));
-  c->leg_par.alt = SchmittPar{ lt, ht, low_delay, high_delay };
+  // the thresholds pass through `float` variables in the reference (leg_estimate.cpp:103-104, FootContactAlt.cpp:5)
+  c->leg_par.alt = SchmittPar{ (double) (float) lt, (double) (float) ht, low_delay, high_delay };
   c->leg_par.filter_contact_events = filter_contact_events ? 1 : 0;
-  k_legodo_reset<<<nblk(c->B), 64, 0, c->stream>>>(c->legd, c->legi, c->stride, c->B);
+  k_legodo_reset<<<nblk(c->B), 64, 0, c->stream>>>(c->legd, c->legi, c->stride, c->B, -1);
+  LAUNCHCHK(c);
+  return PB_OK;
+}
+
+extern "C" int pb_legodo_set_contact_mode(pb_ctx *c, int standing, double total_force, double standing_schmitt_level,
+                                          int use_controller_input)
+{
+  ENTER(c);
+  if (!c->legd) return fail(c, PB_ERR_STATE, "pb_legodo_set_contact_mode before pb_legodo_init");
+  c->leg_par.standing = standing ? 1 : 0;
+  c->leg_par.total_force = (float) total_force;                        // float members (FootContact.h:24-28)
+  c->leg_par.standing_schmitt_level = (float) standing_schmitt_level;
+  c->leg_par.use_controller_input = use_controller_input ? 1 : 0;
+  return PB_OK;
+}
+
+extern "C" int pb_legodo_set_zero_initial_velocity(pb_ctx *c, int ticks)
+{
+  ENTER(c);
+  if (!c->legd) return fail(c, PB_ERR_STATE, "pb_legodo_set_zero_initial_velocity before pb_legodo_init");
+  k_legodo_reset<<<nblk(c->B), 64, 0, c->stream>>>(c->legd, c->legi, c->stride, c->B, ticks < 0 ? 0 : ticks);
+  LAUNCHCHK(c);
+  return PB_OK;
+}
+
+extern "C" int pb_legodo_set_control_contacts(pb_ctx *c, const int32_t *n_contacts, int mem)
+{
+  ENTER(c);
+  if (!c->legd) return fail(c, PB_ERR_STATE, "pb_legodo_set_control_contacts before pb_legodo_init");
+  if (!n_contacts) return fail(c, PB_ERR_ARG, "pb_legodo_set_control_contacts: NULL input");
+  if (mem == PB_HOST_BROADCAST) {
+    c->leg_nc_h[0] = n_contacts[0];
+    c->leg_nc_h[1] = n_contacts[1];
+    c->leg_nc_dev = false;
+    return PB_OK;
+  }
+  if (mem != PB_HOST && mem != PB_DEVICE) return fail(c, PB_ERR_ARG, "mem must be PB_HOST, PB_DEVICE or PB_HOST_BROADCAST");
+  if (!c->leg_nc) HIPCHK(c, hipMalloc((void **) &c->leg_nc, sizeof(int32_t) * 2 * (size_t) c->B));
+  // kept by the context until the next call, like the handler keeps the last CONTROLLER_FOOT_CONTACT message
+  HIPCHK(c, hipMemcpyAsync(c->leg_nc, n_contacts, sizeof(int32_t) * 2 * (size_t) c->B,
+                           mem == PB_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, c->stream));
+  if (mem == PB_HOST) HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->leg_nc_dev = true;
+  return PB_OK;
+}
+
+extern "C" int pb_legodo_set_chain(pb_ctx *c, int n_left, int n_right, const int *joint_type, const int *joint_row,
+                                   const double *origin_xyz_rpy, const double *axis, const float *adjustment_gain)
+{
+  ENTER(c);
+  if (n_left < 1 || n_right < 1 || n_left > LEG_MAXJ || n_right > LEG_MAXJ)
+    return fail(c, PB_ERR_ARG, "pb_legodo_set_chain: 1..%d joints per leg", LEG_MAXJ);
+  if (!joint_type || !joint_row || !origin_xyz_rpy || !axis) return fail(c, PB_ERR_ARG, "pb_legodo_set_chain: NULL input");
+  LegChain ch;
+  memset(&ch, 0, sizeof ch);
+  ch.n[0] = n_left;
+  ch.n[1] = n_right;
+  int max_row = -1;
+  for (int side = 0, k = 0; side < 2; side++) {
+    for (int j = 0; j < ch.n[side]; j++, k++) {
+      const int ty = joint_type[k];
+      if (ty != LJ_FIXED && ty != LJ_REVOLUTE && ty != LJ_PRISMATIC) return fail(c, PB_ERR_ARG, "pb_legodo_set_chain: joint %d: bad type %d", k, ty);
+      ch.type[side][j] = ty;
+      ch.row[side][j] = (ty == LJ_FIXED) ? 0 : joint_row[k];
+      if (ty != LJ_FIXED && joint_row[k] < 0) return fail(c, PB_ERR_ARG, "pb_legodo_set_chain: joint %d: negative row", k);
+      if (ty != LJ_FIXED && joint_row[k] > max_row) max_row = joint_row[k];
+      const double *o = origin_xyz_rpy + 6 * k;
+      for (int i = 0; i < 3; i++) ch.org_t[side][j][i] = o[i];
+      // urdf::Rotation::setFromRPY (urdfdom_headers pose.h; NOT in the tree): the quaternion every consumer of the URDF sees
+      const double phi = o[3] / 2.0, the = o[4] / 2.0, psi = o[5] / 2.0;
+      double q[4] = { cos(phi) * cos(the) * cos(psi) + sin(phi) * sin(the) * sin(psi),
+                      sin(phi) * cos(the) * cos(psi) - cos(phi) * sin(the) * sin(psi),
+                      cos(phi) * sin(the) * cos(psi) + sin(phi) * cos(the) * sin(psi),
+                      cos(phi) * cos(the) * sin(psi) - sin(phi) * sin(the) * cos(psi) };
+      const double qn = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+      for (int i = 0; i < 4; i++) ch.org_q[side][j][i] = q[i] / qn;
+      ch.org_rot[side][j] = (o[3] != 0.0 || o[4] != 0.0 || o[5] != 0.0) ? 1 : 0;
+      const double *a = axis + 3 * k;
+      const double an = sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
+      if (ty != LJ_FIXED && !(an > 0.0)) return fail(c, PB_ERR_ARG, "pb_legodo_set_chain: joint %d: zero axis", k);
+      for (int i = 0; i < 3; i++) ch.axis[side][j][i] = (ty == LJ_FIXED) ? 0.0 : a[i] / an;  // KDL::Joint normalises the axis
+      const float g = adjustment_gain ? adjustment_gain[k] : 0.0f;
+      ch.gain[side][j] = (ty != LJ_FIXED && std::isnormal(g)) ? g : 0.0f;  // torque_adjustment.cpp:52
+    }
+  }
+  if (!c->leg_chain) HIPCHK(c, hipMalloc((void **) &c->leg_chain, sizeof(LegChain)));
+  HIPCHK(c, hipStreamSynchronize(c->stream));  // kernels in flight may still read the old table
+  HIPCHK(c, hipMemcpy(c->leg_chain, &ch, sizeof ch, hipMemcpyHostToDevice));
+  c->leg_chain_h = ch;
+  c->leg_chain_rows = max_row + 1;
+  return PB_OK;
+}
+
+// the joint-state inputs of one message as the kernels take them (LegIn kind 1); forces may be NULL (forward kinematics only)
+static int leg_in_joints(pb_ctx *c, const char *who, int n_rows, const float *jpos, const float *jeff, const float *forces, int mem,
+                         LegIn &in)
+{
+  if (!c->leg_chain) return fail(c, PB_ERR_STATE, "%s before pb_legodo_set_chain", who);
+  if (!jpos) return fail(c, PB_ERR_ARG, "%s: NULL input", who);
+  if (n_rows < c->leg_chain_rows) return fail(c, PB_ERR_ARG, "%s: the chain reads joint row %d, the block has %d rows", who, c->leg_chain_rows - 1, n_rows);
+  in.kind = 1;
+  in.chain = c->leg_chain;
+  if (mem == PB_HOST_BROADCAST) {  // one robot's joint state for every filter: the chain's angles travel as kernel arguments
+    const LegChain &ch = c->leg_chain_h;
+    for (int side = 0; side < 2; side++)
+      for (int j = 0; j < ch.n[side]; j++) {
+        if (ch.type[side][j] == LJ_FIXED) continue;
+        const int r = ch.row[side][j];
+        in.v[side * LEG_MAXJ + j] = (double) (jeff ? torque_adjust(jpos[r], jeff[r], ch.gain[side][j]) : jpos[r]);
+      }
+    if (forces) { in.v[2 * LEG_MAXJ] = forces[0]; in.v[2 * LEG_MAXJ + 1] = forces[1]; }
+    in.bcast = 1;
+    return PB_OK;
+  }
+  const size_t blk = sizeof(float) * (size_t) n_rows * c->B;
+  Part p[3] = { { jpos, blk, 0 }, { jeff, jeff ? blk : 0, 0 }, { forces, forces ? sizeof(float) * 2 * (size_t) c->B : 0, 0 } };
+  int rc = stage_in(c, mem, p, 3);
+  if (rc) return rc;
+  in.jpos = (const float *) p[0].dev;
+  in.jeff = (const float *) p[1].dev;
+  in.jforces = (const float *) p[2].dev;
+  return PB_OK;
+}
+
+static int legodo_launch(pb_ctx *c, LegIn &in, const double *imu_block, int imu_mem, int64_t utime, int zero_delta, double r_vxyz,
+                         double r_vxyz_uncertain, double *delta_out, double *status_out, double *lo_out, uint8_t *mask_out,
+                         double *pos_out = nullptr, uint8_t *pos_ok_out = nullptr)
+{
+  LegAhead ah;
+  if (imu_block) {
+    ah.on = 1;
+    if (imu_mem == PB_HOST_BROADCAST) {
+      memcpy(ah.v, imu_block, sizeof(ah.v));
+      ah.bcast = 1;
+    } else {
+      Part pi[1] = { { imu_block, sizeof(double) * 7 * c->B, 0 } };
+      int rc = stage_in(c, imu_mem, pi, 1);
+      if (rc) return rc;
+      ah.imu = (const double *) pi[0].dev;
+    }
+  }
+  if (c->leg_nc_dev) in.ncontacts = c->leg_nc;
+  in.nc[0] = c->leg_nc_h[0];
+  in.nc[1] = c->leg_nc_h[1];
+  const double r2 = r_vxyz * r_vxyz, r2u = r_vxyz_uncertain * r_vxyz_uncertain;  // bot_sq (rbis_legodo_common.cpp:40-43)
+  // the world constraint (the transition foot's world position) is tracked from the first call that asks for the position
+  if (pos_out != nullptr) c->leg_par.world_constraint = 1;
+  if (c->ns == 15)
+    k_legodo<15><<<nblk(c->B), 64, 0, c->stream>>>(c->st, c->legd, c->legi, c->stride, c->B, utime, c->leg_par, in, ah, zero_delta, r2, r2u,
+                                                   delta_out, status_out, lo_out, mask_out, pos_out, pos_ok_out, c->k);
+  else
+    k_legodo<21><<<nblk(c->B), 64, 0, c->stream>>>(c->st, c->legd, c->legi, c->stride, c->B, utime, c->leg_par, in, ah, zero_delta, r2, r2u,
+                                                   delta_out, status_out, lo_out, mask_out, pos_out, pos_ok_out, c->k);
   LAUNCHCHK(c);
   return PB_OK;
 }
@@ -807,40 +964,23 @@ static int legodo_update_impl(pb_ctx *c, const double *imu_block, int imu_mem, b
   NEED_STATE(c);
   if (!c->legd) return fail(c, PB_ERR_STATE, "pb_legodo_update before pb_legodo_init");
   if (!feet || !forces || (ahead && !imu_block)) return fail(c, PB_ERR_ARG, "pb_legodo_update: NULL input");
-  Part p[2] = { { feet, sizeof(double) * 14 * c->B, 0 }, { forces, sizeof(double) * 2 * c->B, 0 } };
-  Part pi[1] = { { imu_block, sizeof(double) * 7 * c->B, 0 } };
-  LegBcast bc;
   if (ahead && imu_mem == PB_HOST && mem == PB_HOST)
     return fail(c, PB_ERR_ARG, "pb_legodo_update_after_predict: the IMU block and the foot blocks cannot both be PB_HOST");
-  if (mem == PB_HOST_BROADCAST) {  // one robot's joint state for every filter: kernel arguments, no device block
-    memcpy(bc.feet, feet, sizeof(bc.feet));
-    memcpy(bc.forces, forces, sizeof(bc.forces));
-    bc.on |= 1;
+  LegIn in;
+  if (mem == PB_HOST_BROADCAST) {  // one robot's foot poses for every filter: kernel arguments, no device block
+    memcpy(in.v, feet, sizeof(double) * 14);
+    in.v[14] = forces[0];
+    in.v[15] = forces[1];
+    in.bcast = 1;
   } else {
+    Part p[2] = { { feet, sizeof(double) * 14 * c->B, 0 }, { forces, sizeof(double) * 2 * c->B, 0 } };
     int rc = stage_in(c, mem, p, 2);
     if (rc) return rc;
+    in.feet = (const double *) p[0].dev;
+    in.forces = (const double *) p[1].dev;
   }
-  if (ahead) {
-    bc.on |= 2;
-    if (imu_mem == PB_HOST_BROADCAST) {
-      memcpy(bc.imu, imu_block, sizeof(bc.imu));
-      bc.on |= 4;
-    } else {
-      int rc = stage_in(c, imu_mem, pi, 1);
-      if (rc) return rc;
-    }
-  }
-  const double r2 = r_vxyz * r_vxyz, r2u = r_vxyz_uncertain * r_vxyz_uncertain;  // bot_sq (rbis_legodo_common.cpp:40-43)
-  if (c->ns == 15)
-    k_legodo<15><<<nblk(c->B), 64, 0, c->stream>>>(c->st, c->legd, c->legi, c->stride, c->B, utime, c->leg_par, (const double *) p[0].dev,
-                                                   (const double *) p[1].dev, zero_delta, r2, r2u, delta_out, status_out, lo_out, mask_out,
-                                                   bc, (const double *) pi[0].dev, c->k);
-  else
-    k_legodo<21><<<nblk(c->B), 64, 0, c->stream>>>(c->st, c->legd, c->legi, c->stride, c->B, utime, c->leg_par, (const double *) p[0].dev,
-                                                   (const double *) p[1].dev, zero_delta, r2, r2u, delta_out, status_out, lo_out, mask_out,
-                                                   bc, (const double *) pi[0].dev, c->k);
-  LAUNCHCHK(c);
-  return PB_OK;
+  return legodo_launch(c, in, ahead ? imu_block : nullptr, imu_mem, utime, zero_delta, r_vxyz, r_vxyz_uncertain, delta_out, status_out,
+                       lo_out, mask_out);
 }
 
 extern "C" int pb_legodo_update(pb_ctx *c, int64_t utime, const double *feet, const double *forces, int mem, int zero_delta,
@@ -857,6 +997,36 @@ extern "C" int pb_legodo_update_after_predict(pb_ctx *c, const double *imu_block
 {
   return legodo_update_impl(c, imu_block, imu_mem, true, utime, feet, forces, mem, zero_delta, r_vxyz, r_vxyz_uncertain, delta_out,
                             status_out, lo_out, mask_out);
+}
+
+extern "C" int pb_legodo_update_joints(pb_ctx *c, const double *imu_block, int imu_mem, int64_t utime, int n_rows,
+                                       const float *joint_position, const float *joint_effort, const float *forces, int mem,
+                                       int zero_delta, double r_vxyz, double r_vxyz_uncertain, double *delta_out, double *status_out,
+                                       double *lo_out, uint8_t *mask_out, double *position_out, uint8_t *position_status_out)
+{
+  ENTER(c);
+  NEED_STATE(c);
+  if (!c->legd) return fail(c, PB_ERR_STATE, "pb_legodo_update_joints before pb_legodo_init");
+  if (!forces) return fail(c, PB_ERR_ARG, "pb_legodo_update_joints: NULL input");
+  if (imu_block && imu_mem == PB_HOST && mem == PB_HOST)
+    return fail(c, PB_ERR_ARG, "pb_legodo_update_joints: the IMU block and the joint blocks cannot both be PB_HOST");
+  LegIn in;
+  int rc = leg_in_joints(c, "pb_legodo_update_joints", n_rows, joint_position, joint_effort, forces, mem, in);
+  if (rc) return rc;
+  return legodo_launch(c, in, imu_block, imu_mem, utime, zero_delta, r_vxyz, r_vxyz_uncertain, delta_out, status_out, lo_out, mask_out,
+                       position_out, position_status_out);
+}
+
+extern "C" int pb_legodo_fk(pb_ctx *c, int n_rows, const float *joint_position, const float *joint_effort, int mem, double *feet_out)
+{
+  ENTER(c);
+  if (!feet_out) return fail(c, PB_ERR_ARG, "pb_legodo_fk: NULL output");
+  LegIn in;
+  int rc = leg_in_joints(c, "pb_legodo_fk", n_rows, joint_position, joint_effort, nullptr, mem, in);
+  if (rc) return rc;
+  k_leg_fk<<<nblk(c->B), 64, 0, c->stream>>>(in, c->B, feet_out);
+  LAUNCHCHK(c);
+  return PB_OK;
 }
 
 extern "C" int pb_legodo_get(pb_ctx *c, int filter, double odom_to_body[7], int64_t info[4])

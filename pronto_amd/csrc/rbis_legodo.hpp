@@ -1,20 +1,32 @@
-// rbis_legodo.hpp -- leg kinematic odometry for one robot per lane: which foot is the fixed one, the pelvis pose that
-// follows from it, its increment since the previous message and how far that increment can be trusted.
+// rbis_legodo.hpp -- leg kinematic odometry for one robot per lane: forward kinematics of the two legs from the joint
+// angles, which foot is the fixed one, the pelvis pose that follows from it, its increment since the previous message and
+// how far that increment can be trusted.
 //
 // Restatement of (paths relative to the reference tree)
+//   motion_estimate/src/leg_estimate/leg_estimate.cpp:430-447   forward kinematics (KDL TreeFkSolverPosFull_recursive over the
+//                                                               URDF tree; KDL / kdl_parser / urdfdom are NOT in the tree: the
+//                                                               published algorithm is restated, see leg_fk)
 //   motion_estimate/src/leg_estimate/leg_estimate.cpp:172-297   initializePose / prepInitialization /
 //                                                               leg_odometry_gravity_slaved_always
+//   motion_estimate/src/leg_estimate/leg_estimate.cpp:322-393   footTransition ("standing" mode), footTransitionAlt incl. the
+//                                                               controller-contact override (use_controller_input)
 //   motion_estimate/src/leg_estimate/leg_estimate.cpp:395-556   updateOdometry (30 ms reset :402-408, delta :485, status :545-551)
-//   motion_estimate/src/foot_contact_alt/FootContactAlt.cpp:35-100   DetectFootTransition (primary-foot selection)
+//   motion_estimate/src/foot_contact/FootContact.cpp:29-83      DetectFootTransition of the "standing" mode (float arithmetic)
+//   motion_estimate/src/foot_contact_alt/FootContactAlt.cpp:35-130   DetectFootTransition, forceLeft/RightStandingFoot
 //   motion_estimate/src/leg_estimate/foot_contact_classify.cpp:57-125,146-318   update / updateWalkingPhase (status -1 / 0 / 1)
-//   estimate_tools/src/filter_tools/SignalTap.cpp:83-130        SchmittTrigger::UpdateState
-// Forward kinematics stays with the caller (KDL + URDF in the reference, leg_estimate.cpp:430-444): the inputs are the two
-// body-to-foot transforms it produces.  Poses are (translation, unit quaternion) pairs here, where the reference holds
-// Eigen::Isometry3d and converts rotation matrices to quaternions and back at every step (:231-240); the two agree to
-// rounding (a quaternion's overall sign never matters for a pose).  The joint filters (:411-428), the controller-contact
-// override (use_controller_input, :365-387) and the "standing" control mode's classifier (:453-454) are not built.
+//   estimate_tools/src/filter_tools/SignalTap.cpp:64-130        SchmittTrigger
+//   estimate_tools/src/backlash_filter_tools/torque_adjustment.cpp:27-62   TorqueAdjustment::processSample (float arithmetic)
+// Poses are (translation, unit quaternion) pairs here, where the reference holds Eigen::Isometry3d and converts rotation
+// matrices to quaternions and back at every step (:231-240); the two agree to rounding (a quaternion's overall sign never
+// matters for a pose; Isometry3d::inverse() transposes, which is the quaternion CONJUGATE, no division).  The joint
+// low-pass / Kalman filters (:411-428, filter_joint_positions = none) are not built.
 //
-// Per-robot state: NLD doubles + NLI 64-bit integers (flags packed into one of them), struct-of-arrays, robot index fastest.
+// Per-robot state (round 3: 136 bytes, was 296): NLD doubles + NLI 64-bit words, struct-of-arrays, robot index fastest.
+//   * odom_to_secondary_foot_ is not kept: the reference only draws it (pc_vis_, determineContactPoints);
+//   * odom_to_primary_foot_fixed_'s rotation is not kept: every branch that reads the pose overwrites it first (:233-240);
+//   * the six triggers' previous_time is the previous message's utime for all of them (they are all updated with the same
+//     clock in every call), so it is not stored six times; their timers are only ever compared with a delay and are kept as
+//     SATURATING 32-bit values (identical decisions for |utime steps| < 2^31 us = 35 minutes and delays < 2^31 us).
 #pragma once
 
 #include <stdint.h>
@@ -31,13 +43,15 @@ PB_HD void pose_identity(Pose &p)
   p.t[0] = p.t[1] = p.t[2] = 0.0;
   p.q[0] = 1.0; p.q[1] = p.q[2] = p.q[3] = 0.0;
 }
+// toRotationMatrix() * v without forming the matrix: v + 2 w (u x v) + 2 u x (u x v) -- the same polynomial in q as Eigen's
 PB_HD void quat_rot(const double (&q)[4], const double (&v)[3], double (&o)[3])
 {
-  double R[9];
-  quat_to_rot(q, R);
-#pragma unroll
-  for (int i = 0; i < 3; i++) o[i] = R[3 * i] * v[0] + R[3 * i + 1] * v[1] + R[3 * i + 2] * v[2];
+  const double tx = 2.0 * (q[2] * v[2] - q[3] * v[1]), ty = 2.0 * (q[3] * v[0] - q[1] * v[2]), tz = 2.0 * (q[1] * v[1] - q[2] * v[0]);
+  o[0] = v[0] + q[0] * tx + (q[2] * tz - q[3] * ty);
+  o[1] = v[1] + q[0] * ty + (q[3] * tx - q[1] * tz);
+  o[2] = v[2] + q[0] * tz + (q[1] * ty - q[2] * tx);
 }
+PB_HD void quat_conj(const double (&q)[4], double (&o)[4]) { o[0] = q[0]; o[1] = -q[1]; o[2] = -q[2]; o[3] = -q[3]; }
 // a * b
 PB_HD void pose_mul(const Pose &a, const Pose &b, Pose &o)
 {
@@ -49,11 +63,11 @@ PB_HD void pose_mul(const Pose &a, const Pose &b, Pose &o)
 #pragma unroll
   for (int i = 0; i < 4; i++) o.q[i] = q[i];
 }
+// Isometry3d::inverse(): (R^T, -R^T t)
 PB_HD void pose_inv(const Pose &a, Pose &o)
 {
-  const double n2 = a.q[0] * a.q[0] + a.q[1] * a.q[1] + a.q[2] * a.q[2] + a.q[3] * a.q[3];
-  const double qi[4] = { a.q[0] / n2, -a.q[1] / n2, -a.q[2] / n2, -a.q[3] / n2 };
-  double rt[3];
+  double qi[4], rt[3];
+  quat_conj(a.q, qi);
   quat_rot(qi, a.t, rt);
 #pragma unroll
   for (int i = 0; i < 3; i++) o.t[i] = -rt[i];
@@ -61,90 +75,195 @@ PB_HD void pose_inv(const Pose &a, Pose &o)
   for (int i = 0; i < 4; i++) o.q[i] = qi[i];
 }
 
-// SchmittTrigger (SignalTap.cpp:48-134)
-struct Schmitt {
-  int64_t status, timer, previous_time, first_call;
+// sin and cos of a joint angle (|x| < 2^20): Cody-Waite reduction by pi/2 in two pieces, then the classic minimax
+// polynomials on [-pi/4, pi/4] (coefficients: fdlibm's __kernel_sin / __kernel_cos, < 1 ulp).  No large-argument path, so
+// ~35 instructions for the pair where the library call costs ~3x that plus the registers of its Payne-Hanek branch.
+PB_HD void sincos_joint(double x, double &s, double &c)
+{
+  const double kf = rint(x * 6.36619772367581382433e-01);
+  double r = fma(-kf, 1.57079632673412561417e+00, x);
+  r = fma(-kf, 6.07710050650619224932e-11, r);
+  const double z = r * r;
+  double ps = 1.58969099521155010221e-10;
+  ps = fma(ps, z, -2.50507602534068634195e-08);
+  ps = fma(ps, z, 2.75573137070700676789e-06);
+  ps = fma(ps, z, -1.98412698298579493134e-04);
+  ps = fma(ps, z, 8.33333333332248946124e-03);
+  ps = fma(ps, z, -1.66666666666666324348e-01);
+  const double sn = fma(r * z, ps, r);
+  double pc = -1.13596475577881948265e-11;
+  pc = fma(pc, z, 2.08757232129817482790e-09);
+  pc = fma(pc, z, -2.75573143513906633035e-07);
+  pc = fma(pc, z, 2.48015872894767294178e-05);
+  pc = fma(pc, z, -1.38888888888741095749e-03);
+  pc = fma(pc, z, 4.16666666666666019037e-02);
+  const double cs = fma(z * z, pc, fma(-0.5, z, 1.0));
+  const int k = (int) kf & 3;
+  const double a = (k & 1) ? cs : sn, b = (k & 1) ? sn : cs;
+  s = (k & 2) ? -a : a;
+  c = ((k + 1) & 2) ? -b : b;
+}
+
+// ---- forward kinematics of the two legs -------------------------------------------------------------------------------
+// What KDL computes for leg_estimate.cpp:430-444 (JntToCart with flatten_tree = true, then the frames of the two standing
+// links): kdl_parser turns every URDF joint into a KDL segment whose pose is
+//     pose(theta) = (Rot(M a, theta) M, p)      M, p = the joint's <origin rpy xyz>, a = its <axis>
+// and the solver multiplies the segment poses from the root link down, so body_to_foot = prod_j [M_j, p_j] * Rot(a_j, theta_j)
+// (Rot(M a, theta) M = M Rot(a, theta)).  The chain table is supplied by the caller (the URDF is not in the tree):
+// per leg the joints from the root link to the standing link, each with its origin, axis, type and the row of the
+// joint-position block that holds its angle.  Here the product is formed with quaternions and half angles; the oracle
+// forms KDL's 3x3 matrices with Rot2's Rodrigues formula (oracle/leg_odometry.c).
+static constexpr int LEG_MAXJ = 8;  // joints per leg chain (Atlas: 6)
+enum { LJ_FIXED = 0, LJ_REVOLUTE = 1, LJ_PRISMATIC = 2 };
+struct LegChain {
+  int n[2];                        // joints of the left / right chain
+  int type[2][LEG_MAXJ];           // LJ_*
+  int row[2][LEG_MAXJ];            // row of the joint-position block ([rows][B]); unused for LJ_FIXED
+  int org_rot[2][LEG_MAXJ];        // 0: the origin's rpy is zero (its quaternion multiplication is skipped)
+  float gain[2][LEG_MAXJ];         // TorqueAdjustment spring constant of the joint, 0 = none (torque_adjustment.cpp:52)
+  double org_t[2][LEG_MAXJ][3];    // <origin xyz>
+  double org_q[2][LEG_MAXJ][4];    // <origin rpy> as the quaternion urdfdom makes of it (setFromRPY)
+  double axis[2][LEG_MAXJ][3];     // <axis>, normalised (KDL::Joint normalises it)
 };
+
+// TorqueAdjustment::processSample for one joint, in float like the reference: position -= clamp(effort / gain, +-0.1)
+PB_HD float torque_adjust(float position, float effort, float gain)
+{
+  if (gain == 0.0f) return position;  // (the host stores 0 for a gain that is not std::isnormal, torque_adjustment.cpp:52)
+  float a = effort / gain;
+  a = a > 0.1f ? 0.1f : (a < -0.1f ? -0.1f : a);
+  return position - a;
+}
+
+// body_to_foot of leg `side`; angle(j) returns joint j's (torque-adjusted) position as a double
+template <class ANGLE>
+PB_HD void leg_fk(const LegChain &ch, int side, ANGLE &&angle, Pose &T)
+{
+  pose_identity(T);
+  const int n = ch.n[side];
+  for (int j = 0; j < n; j++) {  // trip count and every branch below are uniform over the batch
+    double rt[3];
+    const double ot[3] = { ch.org_t[side][j][0], ch.org_t[side][j][1], ch.org_t[side][j][2] };
+    quat_rot(T.q, ot, rt);
+#pragma unroll
+    for (int i = 0; i < 3; i++) T.t[i] += rt[i];
+    if (ch.org_rot[side][j]) {
+      const double oq[4] = { ch.org_q[side][j][0], ch.org_q[side][j][1], ch.org_q[side][j][2], ch.org_q[side][j][3] };
+      double q[4];
+      quat_mul(T.q, oq, q);
+#pragma unroll
+      for (int i = 0; i < 4; i++) T.q[i] = q[i];
+    }
+    const int ty = ch.type[side][j];
+    if (ty == LJ_REVOLUTE) {
+      double s, c;
+      sincos_joint(0.5 * angle(j), s, c);
+      const double jq[4] = { c, s * ch.axis[side][j][0], s * ch.axis[side][j][1], s * ch.axis[side][j][2] };
+      double q[4];
+      quat_mul(T.q, jq, q);
+#pragma unroll
+      for (int i = 0; i < 4; i++) T.q[i] = q[i];
+    } else if (ty == LJ_PRISMATIC) {
+      const double d = angle(j);
+      const double av[3] = { d * ch.axis[side][j][0], d * ch.axis[side][j][1], d * ch.axis[side][j][2] };
+      quat_rot(T.q, av, rt);
+#pragma unroll
+      for (int i = 0; i < 3; i++) T.t[i] += rt[i];
+    }
+  }
+}
+
+// ---- contact logic ------------------------------------------------------------------------------------------------------
 struct SchmittPar {
   double low, high;
   int64_t low_delay, high_delay;
 };
-PB_HD void schmitt_reset(Schmitt &s) { s.status = 0; s.timer = 0; s.previous_time = 0; s.first_call = 1; }
-PB_HD void schmitt_update(Schmitt &s, const SchmittPar &p, int64_t now, double value)
+// SchmittTrigger::UpdateState (SignalTap.cpp:83-130); dt = present_time - previous_time (0 in the first call, :84-87)
+PB_HD int32_t sat_add(int32_t timer, int64_t dt)
 {
-  if (s.first_call) {
-    s.first_call = 0;
-    s.previous_time = now;
-  }
-  if (s.status) {
+  const int64_t v = (int64_t) timer + dt;
+  return (int32_t) (v > 2147483647LL ? 2147483647LL : (v < -2147483647LL ? -2147483647LL : v));
+}
+PB_HD void schmitt_update(bool &status, int32_t &timer, const SchmittPar &p, int64_t dt, double value)
+{
+  if (status) {
     if (value <= p.low) {
-      if (s.timer > p.low_delay) s.status = 0;
-      else s.timer += now - s.previous_time;
+      if (timer > p.low_delay) status = false;
+      else timer = sat_add(timer, dt);
     } else {
-      s.timer = 0;
+      timer = 0;
     }
   } else {
     if (value >= p.high) {
-      if (s.timer > p.high_delay) s.status = 1;
-      else s.timer += now - s.previous_time;
+      if (timer > p.high_delay) status = true;
+      else timer = sat_add(timer, dt);
     } else {
-      s.timer = 0;
+      timer = 0;
     }
   }
-  s.previous_time = now;
 }
 
-enum { LF_UNKNOWN = -1, LF_LEFT = 0, LF_RIGHT = 1 };                                         // footid_alt
+enum { LF_UNKNOWN = -1, LF_LEFT = 0, LF_RIGHT = 1 };                                         // footid / footid_alt
 enum { LC_UNKNOWN = -1, LC_LEFT_NEW = 0, LC_RIGHT_NEW = 1, LC_LEFT_FIXED = 2, LC_RIGHT_FIXED = 3 };  // contact_status_id
+enum { T_ALT_L = 0, T_ALT_R, T_WEAK_L, T_WEAK_R, T_STRONG_L, T_STRONG_R };                  // the six triggers
 
 struct LegPar {
   SchmittPar alt;                    // state_estimator.legodo.schmitt_{low,high}_threshold / _delay (leg_estimate.cpp:103-108)
   int filter_contact_events;         // state_estimator.legodo.filter_contact_events (:63)
+  int standing = 0;                  // init_contact_mode == "standing": FootContact instead of FootContactAlt (:113-118,453-457)
+  float total_force = 0.f, standing_schmitt_level = 0.f;  // state_estimator.legodo.{total_force, standing_schmitt_level} (:93-97)
+  int use_controller_input = 0;      // state_estimator.legodo.use_controller_input (:121)
+  int world_constraint = 0;          // keep world_to_primary_foot_transition_ and form world_to_body_constraint_ (:299-318, 461-492):
+                                     // the pelvis position LegOdoCommon's mode pos_and_lin_rate measures
 };
 
 struct LegState {
-  Pose odom_to_body, odom_to_primary, odom_to_secondary;
-  int64_t utime, leg_odo_init, primary_foot;
-  // FootContactAlt
-  Schmitt alt_l, alt_r;
-  int64_t standing_foot;
-  // foot_contact_classify
-  Schmitt weak_l, weak_r, strong_l, strong_r;
-  int64_t mode, initialized, last_strike, last_break, unknown_transitions;
+  double body_t[3], body_q[4];       // odom_to_body_
+  double prim_t[3];                  // translation of odom_to_primary_foot_fixed_
+  double trans_t[3];                 // translation of world_to_primary_foot_transition_ (only with LegPar::world_constraint)
+  int64_t utime, last_strike, last_break;
+  int32_t timer[6];                  // T_*; in "standing" mode timer[0] is FootContact's transition_timespan
+  bool status[6];
+  bool started;                      // the triggers have seen a first call
+  bool leg_odo_init, initialized, fc_flag;   // fc_flag: FootContact's foottransitionintermediateflag
+  bool trans_init;                   // world_to_primary_foot_transition_init_
+  int primary_foot, standing_foot, mode;
+  int zero_ticks;                    // LegOdoHandler::zero_initial_velocity, counted per robot (rbis_legodo_update.cpp:264-268)
+  int unknown_transitions;
 };
-static constexpr int NLD = 21;  // three poses
-// Stored integers: utime, 6 x (timer, previous_time), last_strike, last_break (true 64-bit times) + ONE word that packs every
-// flag, enum and the transition counter (leg_pack_flags): 16 words instead of the 33 fields of LegState -- the kernel is
-// bound by the bytes of this state (21 doubles + these, read and written per robot and message: 432 -> 296 bytes).
-static constexpr int NLI = 1 + 12 + 2 + 1;
+static constexpr int NLD = 10, NLD_WC = 3;  // + trans_t rows, read and written only with LegPar::world_constraint
+static constexpr int NLI = 3 + 3 + 1;  // utime, last_strike, last_break | three timer pairs | the flag word
 
 PB_HD void leg_reset(LegState &s)
 {
-  pose_identity(s.odom_to_body);
-  pose_identity(s.odom_to_primary);
-  pose_identity(s.odom_to_secondary);
-  s.utime = 0;               // current_utime_ = 0 (leg_estimate.cpp: the first message always triggers the 30 ms reset, harmlessly)
-  s.leg_odo_init = 0;        // :128
-  s.primary_foot = LF_LEFT;  // :126 primary_foot_ = F_LEFT
-  schmitt_reset(s.alt_l); schmitt_reset(s.alt_r);
-  s.alt_l.status = 1; s.alt_l.timer = 0;  // forceHigh (FootContactAlt.cpp:28-29)
-  s.alt_r.status = 1; s.alt_r.timer = 0;
-  s.standing_foot = LF_UNKNOWN;
-  schmitt_reset(s.weak_l); schmitt_reset(s.weak_r); schmitt_reset(s.strong_l); schmitt_reset(s.strong_r);
-  s.mode = -1;  // UNKNOWN
-  s.initialized = 0;
+#pragma unroll
+  for (int i = 0; i < 3; i++) s.body_t[i] = s.prim_t[i] = s.trans_t[i] = 0.0;
+  s.body_q[0] = 1.0; s.body_q[1] = s.body_q[2] = s.body_q[3] = 0.0;
+  s.utime = 0;               // current_utime_ = 0 (the first message always triggers the 30 ms reset, harmlessly)
   s.last_strike = 0; s.last_break = 0;
+#pragma unroll
+  for (int k = 0; k < 6; k++) { s.timer[k] = 0; s.status[k] = false; }
+  s.status[T_ALT_L] = s.status[T_ALT_R] = true;  // forceHigh (FootContactAlt.cpp:28-29)
+  s.started = false;
+  s.leg_odo_init = false;    // leg_estimate.cpp:128
+  s.initialized = false;
+  s.fc_flag = true;          // FootContact.cpp:21
+  s.trans_init = false;      // leg_estimate.cpp:140
+  s.zero_ticks = 0;
+  s.primary_foot = LF_LEFT;  // :126 primary_foot_ = F_LEFT
+  s.standing_foot = LF_LEFT; // setStandingFoot(FOOT_LEFT) / setStandingFoot(F_LEFT) (:98, :110)
+  s.mode = -1;               // UNKNOWN
   s.unknown_transitions = 0;
 }
 
-// FootContactAlt::DetectFootTransition (FootContactAlt.cpp:35-100).  The reference exit(-1)s when neither foot has ever been
-// the standing one and nothing changes; here that returns LC_UNKNOWN (no odometry this tick).
-PB_HD int alt_detect(LegState &s, const LegPar &p, int64_t utime, double lz, double rz)
+// FootContactAlt::DetectFootTransition (FootContactAlt.cpp:35-100).  The reference exit(-1)s when neither foot is the standing
+// one and nothing changes; here that returns LC_UNKNOWN (no odometry this tick).
+PB_HD int alt_detect(LegState &s, const LegPar &p, int64_t dt, double lz, double rz)
 {
-  const bool l_last = s.alt_l.status != 0, r_last = s.alt_r.status != 0;
-  schmitt_update(s.alt_l, p.alt, utime, lz);
-  schmitt_update(s.alt_r, p.alt, utime, rz);
-  const bool l = s.alt_l.status != 0, r = s.alt_r.status != 0;
+  const bool l_last = s.status[T_ALT_L], r_last = s.status[T_ALT_R];
+  schmitt_update(s.status[T_ALT_L], s.timer[T_ALT_L], p.alt, dt, lz);
+  schmitt_update(s.status[T_ALT_R], s.timer[T_ALT_R], p.alt, dt, rz);
+  const bool l = s.status[T_ALT_L], r = s.status[T_ALT_R];
   if (!l_last && l) { s.standing_foot = LF_LEFT; return LC_LEFT_NEW; }
   if (!r_last && r) { s.standing_foot = LF_RIGHT; return LC_RIGHT_NEW; }
   if (l_last && !l) {
@@ -160,6 +279,64 @@ PB_HD int alt_detect(LegState &s, const LegPar &p, int64_t utime, double lz, dou
   return LC_UNKNOWN;
 }
 
+// leg_estimate::footTransitionAlt (leg_estimate.cpp:359-393): the detector above, overruled by the controller's contact
+// counts (CONTROLLER_FOOT_CONTACT, rbis_legodo_update.cpp:190-193) when use_controller_input is set.  (standing_foot_ is a
+// footid_alt compared with contact_status_id constants there: F_LEFT_NEW = 0 = F_LEFT and F_RIGHT_NEW = 1 = F_RIGHT are
+// the only values that can match.)
+PB_HD int foot_transition_alt(LegState &s, const LegPar &p, int64_t dt, double lz, double rz, int ncl, int ncr)
+{
+  int cs = alt_detect(s, p, dt, lz, rz);
+  if (p.use_controller_input) {
+    if (s.standing_foot == LF_LEFT) {
+      if (ncl > -1 && ncl < 3 && ncr >= 3) {
+        cs = LC_RIGHT_NEW;
+        s.status[T_ALT_L] = false; s.timer[T_ALT_L] = 0;  // forceRightStandingFoot (FootContactAlt.cpp:125-129)
+        s.status[T_ALT_R] = true; s.timer[T_ALT_R] = 0;
+        s.standing_foot = LF_RIGHT;
+      }
+    } else if (s.standing_foot == LF_RIGHT) {
+      if (ncr > -1 && ncr < 3 && ncl >= 3) {
+        cs = LC_LEFT_NEW;
+        s.status[T_ALT_L] = true; s.timer[T_ALT_L] = 0;   // forceLeftStandingFoot (:119-123)
+        s.status[T_ALT_R] = false; s.timer[T_ALT_R] = 0;
+        s.standing_foot = LF_LEFT;
+      }
+    }
+  }
+  return cs;
+}
+
+// secondary - level * total_force > primary, evaluated in float with a rounding after the product like the reference's
+// compiled code (FootContact.cpp:38; no fused multiply-add on its x86-64 baseline target)
+PB_HD bool fc_exceeds(float secondary, float level, float total, float primary)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __fsub_rn(secondary, __fmul_rn(level, total)) > primary;
+#else
+  volatile float prod = level * total;
+  volatile float diff = secondary - prod;
+  return diff > primary;
+#endif
+}
+// leg_estimate::footTransition (leg_estimate.cpp:322-356) around FootContact::DetectFootTransition (FootContact.cpp:29-54):
+// the "standing" contact mode.  dt = utime - lcmutime, and lcmutime is the previous message's utime (0 before the first).
+PB_HD int foot_transition_standing(LegState &s, const LegPar &p, int64_t dt_since_prev, float lz, float rz)
+{
+  const float prim = (s.standing_foot == LF_LEFT) ? lz : rz, sec = (s.standing_foot == LF_LEFT) ? rz : lz;  // :72-82
+  if (fc_exceeds(sec, p.standing_schmitt_level, p.total_force, prim)) {
+    s.timer[0] = sat_add(s.timer[0], dt_since_prev);
+  } else {
+    s.timer[0] = 0;
+    s.fc_flag = true;
+  }
+  if (s.timer[0] > 4000 && s.fc_flag) {  // transition_timeout_ (:13)
+    s.fc_flag = false;
+    s.standing_foot = (s.standing_foot == LF_LEFT) ? LF_RIGHT : LF_LEFT;  // getSecondaryFoot + setStandingFoot (:326-329)
+    return s.standing_foot == LF_LEFT ? LC_LEFT_NEW : LC_RIGHT_NEW;
+  }
+  return s.standing_foot == LF_LEFT ? LC_LEFT_FIXED : LC_RIGHT_FIXED;
+}
+
 // foot_contact_classify::updateWalkingPhase (foot_contact_classify.cpp:146-318).  Where the reference blocks on
 // `cin >> blah` for a transition it does not know, the mode is kept and the event counted.
 PB_HD void walking_phase(LegState &s, int64_t utime, bool lc, bool rc, bool ls, bool rs)
@@ -167,7 +344,7 @@ PB_HD void walking_phase(LegState &s, int64_t utime, bool lc, bool rc, bool ls, 
   enum { L_PRIME_R_STAND = 0, L_PRIME_R_BREAK, L_PRIME_R_SWING, L_PRIME_R_STRIKE, L_STAND_R_PRIME, L_BREAK_R_PRIME, L_SWING_R_PRIME,
          L_STRIKE_R_PRIME };
   if (!s.initialized) {
-    if (lc && rc) { s.mode = L_PRIME_R_STAND; s.initialized = 1; }
+    if (lc && rc) { s.mode = L_PRIME_R_STAND; s.initialized = true; }
     return;
   }
   switch (s.mode) {
@@ -224,14 +401,14 @@ PB_HD void walking_phase(LegState &s, int64_t utime, bool lc, bool rc, bool ls, 
 
 // foot_contact_classify::update (foot_contact_classify.cpp:57-125): 0 accurate, -1 unusable (95 ms after a foot strike),
 // 1 very inaccurate (800 ms after a foot break)
-PB_HD double classify_update(LegState &s, int64_t utime, double lz, double rz)
+PB_HD double classify_update(LegState &s, int64_t utime, int64_t dt, double lz, double rz)
 {
   const SchmittPar weak = { 20.0, 30.0, 5000, 5000 }, strong = { 275.0, 375.0, 7000, 7000 };  // :34-37
-  schmitt_update(s.weak_l, weak, utime, lz);
-  schmitt_update(s.weak_r, weak, utime, rz);
-  schmitt_update(s.strong_l, strong, utime, lz);
-  schmitt_update(s.strong_r, strong, utime, rz);
-  walking_phase(s, utime, s.weak_l.status != 0, s.weak_r.status != 0, s.strong_l.status != 0, s.strong_r.status != 0);
+  schmitt_update(s.status[T_WEAK_L], s.timer[T_WEAK_L], weak, dt, lz);
+  schmitt_update(s.status[T_WEAK_R], s.timer[T_WEAK_R], weak, dt, rz);
+  schmitt_update(s.status[T_STRONG_L], s.timer[T_STRONG_L], strong, dt, lz);
+  schmitt_update(s.status[T_STRONG_R], s.timer[T_STRONG_R], strong, dt, rz);
+  walking_phase(s, utime, s.status[T_WEAK_L], s.status[T_WEAK_R], s.status[T_STRONG_L], s.status[T_STRONG_R]);
   const bool recent_strike = utime - s.last_strike < 95000;   // strike_blackout_duration_ (:41)
   const bool recent_break = utime - s.last_break < 800000;    // break_blackout_duration_ (:42)
   if (recent_strike) return -1.0;
@@ -239,220 +416,393 @@ PB_HD double classify_update(LegState &s, int64_t utime, double lz, double rz)
   return 0.0;
 }
 
-// odom_to_foot: translation kept, orientation = world_to_body's rotation * body_to_foot's (leg_estimate.cpp:230-240)
-PB_HD void slave_foot_orientation(Pose &foot, const double (&wq)[4], const Pose &body_to_foot)
-{
-  double q[4];
-  quat_mul(wq, body_to_foot.q, q);
-#pragma unroll
-  for (int i = 0; i < 4; i++) foot.q[i] = q[i];
-}
-
-// leg_estimate::updateOdometry (leg_estimate.cpp:395-556) without the joint filters and forward kinematics.
-//   wq            rotation of world_to_body_ (setPoseBody: the filter's own head orientation, rbis_legodo_update.cpp:214-229)
-//   returns the status (-1 no usable increment, 0 accurate, 1 inaccurate); delta = previous_odom_to_body^-1 * odom_to_body
-PB_HD double leg_update(LegState &s, const LegPar &p, int64_t utime, const Pose &bl, const Pose &br, double lz, double rz,
-                        const double (&wq)[4], Pose &delta, int64_t &prev_utime)
+// The part of leg_estimate::updateOdometry that does not need the pelvis orientation: clock, 30 ms reset, contact
+// classification, contact status (leg_estimate.cpp:398-408,447-457).  lz / rz are FootSensing::force_z, i.e. floats
+// (foot_contact_classify.hpp:24-31).  Returns the contact status; classification = foot_contact_classify's verdict.
+PB_HD int leg_contacts(LegState &s, const LegPar &p, int64_t utime, float lz, float rz, int ncl, int ncr, double &classification,
+                       int64_t &prev_utime)
 {
   prev_utime = s.utime;
-  const Pose previous = s.odom_to_body;
   s.utime = utime;
-  if ((double) (s.utime - prev_utime) * 1E-6 > 30E-3) s.leg_odo_init = 0;  // :402-408
-  const double classification = classify_update(s, utime, lz, rz);        // :449-450
-  const int cs = alt_detect(s, p, utime, lz, rz);                          // footTransitionAlt (:456)
-  bool init_this_iteration = false;
-  Pose inv;
-  if (!s.leg_odo_init) {  // prepInitialization + initializePose, initialization_mode "zero" (:172-216)
-    if (cs == LC_LEFT_FIXED || cs == LC_RIGHT_FIXED) {
-      const Pose &prim = (cs == LC_LEFT_FIXED) ? bl : br, &sec = (cs == LC_LEFT_FIXED) ? br : bl;
-      pose_identity(s.odom_to_primary);
-      slave_foot_orientation(s.odom_to_primary, wq, prim);
-      pose_inv(prim, inv);
-      pose_mul(s.odom_to_primary, inv, s.odom_to_body);
-      pose_mul(s.odom_to_body, sec, s.odom_to_secondary);
-      s.primary_foot = (cs == LC_LEFT_FIXED) ? LF_LEFT : LF_RIGHT;
-      s.leg_odo_init = 1;
-      init_this_iteration = true;
-    }
-  } else if ((cs == LC_LEFT_FIXED && s.primary_foot == LF_LEFT) || (cs == LC_RIGHT_FIXED && s.primary_foot == LF_RIGHT)) {
-    // the fixed foot keeps its position and is turned to agree with the pelvis orientation (:227-243, :259-275)
-    const Pose &prim = (s.primary_foot == LF_LEFT) ? bl : br, &sec = (s.primary_foot == LF_LEFT) ? br : bl;
-    slave_foot_orientation(s.odom_to_primary, wq, prim);
-    pose_inv(prim, inv);
-    pose_mul(s.odom_to_primary, inv, s.odom_to_body);
-    pose_mul(s.odom_to_body, sec, s.odom_to_secondary);
-  } else if ((cs == LC_RIGHT_NEW && s.primary_foot == LF_LEFT) || (cs == LC_LEFT_NEW && s.primary_foot == LF_RIGHT)) {
-    // transition: the pelvis keeps its position, takes the filter's orientation, and the other foot becomes fixed where
-    // forward kinematics puts it (:244-258, :276-291)
-    const Pose &prim = (cs == LC_RIGHT_NEW) ? br : bl, &sec = (cs == LC_RIGHT_NEW) ? bl : br;
-    Pose sw;
-#pragma unroll
-    for (int i = 0; i < 3; i++) sw.t[i] = s.odom_to_body.t[i];
-#pragma unroll
-    for (int i = 0; i < 4; i++) sw.q[i] = wq[i];
-    pose_mul(sw, prim, s.odom_to_primary);
-    pose_inv(prim, inv);
-    pose_mul(s.odom_to_primary, inv, s.odom_to_body);
-    pose_mul(s.odom_to_body, sec, s.odom_to_secondary);
-    s.primary_foot = (cs == LC_RIGHT_NEW) ? LF_RIGHT : LF_LEFT;
+  if ((double) (s.utime - prev_utime) * 1E-6 > 30E-3) s.leg_odo_init = false;  // :402-408
+  const int64_t dt = s.started ? utime - prev_utime : 0;                       // SignalTap.cpp:84-87
+  s.started = true;
+  classification = classify_update(s, utime, dt, (double) lz, (double) rz);    // :449-450
+  return p.standing ? foot_transition_standing(s, p, utime - prev_utime, lz, rz)  // :453-454
+                    : foot_transition_alt(s, p, dt, (double) lz, (double) rz, ncl, ncr);  // :456
+}
+
+// leg_odometry_gravity_slaved_always + the increment (leg_estimate.cpp:219-297,480-551).
+//   wq   rotation of world_to_body_ (setPoseBody: the filter's own head orientation, rbis_legodo_update.cpp:214-229)
+//   returns the status (-1 no usable increment, 0 accurate, 1 inaccurate); delta = previous_odom_to_body^-1 * odom_to_body
+// All three moving branches of the reference (initialise :172-216, fixed foot :227-243/:259-275, transition :244-258/:276-291)
+// end in  odom_to_body = odom_to_primary * body_to_primary^-1  with  rotation(odom_to_primary) = wq * rotation(body_to_primary);
+// they differ in the primary foot and in where odom_to_primary's translation comes from, so the pose arithmetic runs once.
+//   wpos / position / position_ok: with LegPar::world_constraint, world_to_body_'s translation (the head position) in,
+//   world_to_body_constraint_'s translation and world_to_body_constraint_init_ out (determine_position_constraint_slaved_always)
+PB_HD double leg_integrate(LegState &s, const LegPar &p, int cs, double classification, const Pose &bl, const Pose &br,
+                           const double (&wq)[4], Pose &delta, const double (&wpos)[3], double (&position)[3], bool &position_ok)
+{
+  const double prev_t[3] = { s.body_t[0], s.body_t[1], s.body_t[2] };
+  const double prev_q[4] = { s.body_q[0], s.body_q[1], s.body_q[2], s.body_q[3] };
+  enum { NONE, INIT, FIXED, SWITCH };
+  int act = NONE, pf = s.primary_foot;
+  if (!s.leg_odo_init) {
+    if (cs == LC_LEFT_FIXED || cs == LC_RIGHT_FIXED) { act = INIT; pf = (cs == LC_LEFT_FIXED) ? LF_LEFT : LF_RIGHT; }
+  } else if ((cs == LC_LEFT_FIXED && pf == LF_LEFT) || (cs == LC_RIGHT_FIXED && pf == LF_RIGHT)) {
+    act = FIXED;
+  } else if ((cs == LC_RIGHT_NEW && pf == LF_LEFT) || (cs == LC_LEFT_NEW && pf == LF_RIGHT)) {
+    act = SWITCH;
+    pf = (cs == LC_RIGHT_NEW) ? LF_RIGHT : LF_LEFT;
   }  // else: "initialized but unknown update" (:292-294): nothing moves
+  if (act != NONE) {
+    Pose prim;
+#pragma unroll
+    for (int i = 0; i < 3; i++) prim.t[i] = (pf == LF_LEFT) ? bl.t[i] : br.t[i];
+#pragma unroll
+    for (int i = 0; i < 4; i++) prim.q[i] = (pf == LF_LEFT) ? bl.q[i] : br.q[i];
+    double rt[3], fq[4], cq[4];
+    quat_rot(wq, prim.t, rt);
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      // INIT: the foot at the origin (:184); FIXED: where it was; SWITCH: where forward kinematics puts it from the pelvis'
+      // position and the filter's orientation (:250-253)
+      s.prim_t[i] = (act == INIT) ? 0.0 : ((act == SWITCH) ? s.body_t[i] + rt[i] : s.prim_t[i]);
+    }
+    quat_mul(wq, prim.q, fq);          // the foot turned to agree with the pelvis orientation (:230-240)
+    quat_conj(prim.q, cq);
+    quat_mul(fq, cq, s.body_q);        // odom_to_body = odom_to_primary * body_to_primary^-1 (:242)
+    quat_rot(s.body_q, prim.t, rt);
+#pragma unroll
+    for (int i = 0; i < 3; i++) s.body_t[i] = s.prim_t[i] - rt[i];
+    s.primary_foot = pf;
+  }
+  position[0] = position[1] = position[2] = 0.0;
+  position_ok = false;
+  Pose pfk;  // getPrimaryFootFK(primary_foot_, ...) with the primary foot as it is AFTER the update above
+  if (p.world_constraint) {
+#pragma unroll
+    for (int i = 0; i < 3; i++) pfk.t[i] = (s.primary_foot == LF_LEFT) ? bl.t[i] : br.t[i];
+#pragma unroll
+    for (int i = 0; i < 4; i++) pfk.q[i] = (s.primary_foot == LF_LEFT) ? bl.q[i] : br.q[i];
+    if (cs == LC_LEFT_NEW || cs == LC_RIGHT_NEW) {  // :461-466 world_to_primary_foot_transition_ = world_to_body_ * primary FK
+      double rt[3];
+      quat_rot(wq, pfk.t, rt);
+#pragma unroll
+      for (int i = 0; i < 3; i++) s.trans_t[i] = wpos[i] + rt[i];
+      s.trans_init = true;
+    }
+  }
   double status = -1.0;
   pose_identity(delta);
-  if (s.leg_odo_init && !init_this_iteration) {
-    pose_inv(previous, inv);
-    pose_mul(inv, s.odom_to_body, delta);  // :485
+  if (act == INIT) {
+    s.leg_odo_init = true;
+  } else if (s.leg_odo_init) {  // :482-486
+    if (p.world_constraint && s.trans_init) {  // :488-492 -> :299-318: the foot where it was at the transition, turned to
+      double fq[4], cq[4], bq[4], rt[3];       // agree with the pelvis orientation; the pelvis follows from it
+      quat_mul(wq, pfk.q, fq);
+      quat_conj(pfk.q, cq);
+      quat_mul(fq, cq, bq);
+      quat_rot(bq, pfk.t, rt);
+#pragma unroll
+      for (int i = 0; i < 3; i++) position[i] = s.trans_t[i] - rt[i];
+      position_ok = true;
+    }
+    double cq[4];
+    quat_conj(prev_q, cq);
+    const double d[3] = { s.body_t[0] - prev_t[0], s.body_t[1] - prev_t[1], s.body_t[2] - prev_t[2] };
+    quat_rot(cq, d, delta.t);
+    quat_mul(cq, s.body_q, delta.q);
     status = 0.0;
   }
   if (p.filter_contact_events && status > -1.0) status = classification;  // :545-551
   return status;
 }
 
+// leg_estimate::updateOdometry (leg_estimate.cpp:395-556) from the two body-to-foot transforms
+PB_HD double leg_update(LegState &s, const LegPar &p, int64_t utime, const Pose &bl, const Pose &br, float lz, float rz, int ncl, int ncr,
+                        const double (&wq)[4], Pose &delta, int64_t &prev_utime, const double (&wpos)[3], double (&position)[3],
+                        bool &position_ok)
+{
+  double classification;
+  const int cs = leg_contacts(s, p, utime, lz, rz, ncl, ncr, classification, prev_utime);
+  return leg_integrate(s, p, cs, classification, bl, br, wq, delta, wpos, position, position_ok);
+}
+PB_HD double leg_update(LegState &s, const LegPar &p, int64_t utime, const Pose &bl, const Pose &br, float lz, float rz, int ncl, int ncr,
+                        const double (&wq)[4], Pose &delta, int64_t &prev_utime)
+{
+  const double wpos[3] = { 0.0, 0.0, 0.0 };
+  double position[3];
+  bool ok;
+  return leg_update(s, p, utime, bl, br, lz, rz, ncl, ncr, wq, delta, prev_utime, wpos, position, ok);
+}
+// "Ignore the calculated velocity at launch" (rbis_legodo_update.cpp:264-268: `zero_initial_velocity--; if (... > 0)`), which
+// the reference only reaches for a valid status (:243-255 return NULL first); counted per robot because validity is per robot
+PB_HD bool leg_zero_velocity(LegState &s, double status)
+{
+  if (status >= 0.0 && s.zero_ticks > 0) {
+    s.zero_ticks--;
+    return s.zero_ticks > 0;
+  }
+  return false;
+}
+
 // every flag, enum and counter of LegState in one word: bit 0 leg_odo_init, 1-2 primary_foot + 1, 3-8 the six triggers'
-// status, 9-14 their first_call, 15-16 standing_foot + 1, 17-24 mode + 1, 25 initialized, 32-63 unknown_transitions
+// status, 9 started, 10 fc_flag, 11 trans_init, 15-16 standing_foot + 1, 17-24 mode + 1, 25 initialized, 32-47 unknown_transitions
+// (saturating), 48-63 zero_ticks
 PB_HD int64_t leg_pack_flags(const LegState &s)
 {
-  const Schmitt *ss[6] = { &s.alt_l, &s.alt_r, &s.weak_l, &s.weak_r, &s.strong_l, &s.strong_r };
-  uint64_t w = (uint64_t) (s.leg_odo_init != 0) | ((uint64_t) (s.primary_foot + 1) & 3u) << 1;
-  for (int k = 0; k < 6; k++) w |= (uint64_t) (ss[k]->status != 0) << (3 + k) | (uint64_t) (ss[k]->first_call != 0) << (9 + k);
-  w |= ((uint64_t) (s.standing_foot + 1) & 3u) << 15 | ((uint64_t) (s.mode + 1) & 255u) << 17 | (uint64_t) (s.initialized != 0) << 25;
-  w |= ((uint64_t) s.unknown_transitions & 0xFFFFFFFFu) << 32;
+  uint64_t w = (uint64_t) s.leg_odo_init | ((uint64_t) (s.primary_foot + 1) & 3u) << 1;
+#pragma unroll
+  for (int k = 0; k < 6; k++) w |= (uint64_t) s.status[k] << (3 + k);
+  w |= (uint64_t) s.started << 9 | (uint64_t) s.fc_flag << 10 | (uint64_t) s.trans_init << 11;
+  w |= ((uint64_t) (s.standing_foot + 1) & 3u) << 15 | ((uint64_t) (s.mode + 1) & 255u) << 17 | (uint64_t) s.initialized << 25;
+  w |= (uint64_t) (s.unknown_transitions > 65535 ? 65535 : s.unknown_transitions) << 32 | ((uint64_t) s.zero_ticks & 0xFFFFu) << 48;
   return (int64_t) w;
 }
 PB_HD void leg_unpack_flags(LegState &s, int64_t word)
 {
   const uint64_t w = (uint64_t) word;
-  Schmitt *ss[6] = { &s.alt_l, &s.alt_r, &s.weak_l, &s.weak_r, &s.strong_l, &s.strong_r };
-  s.leg_odo_init = (int64_t) (w & 1u);
-  s.primary_foot = (int64_t) ((w >> 1) & 3u) - 1;
-  for (int k = 0; k < 6; k++) { ss[k]->status = (int64_t) ((w >> (3 + k)) & 1u); ss[k]->first_call = (int64_t) ((w >> (9 + k)) & 1u); }
-  s.standing_foot = (int64_t) ((w >> 15) & 3u) - 1;
-  s.mode = (int64_t) ((w >> 17) & 255u) - 1;
-  s.initialized = (int64_t) ((w >> 25) & 1u);
-  s.unknown_transitions = (int64_t) (w >> 32);
+  s.leg_odo_init = (w & 1u) != 0;
+  s.primary_foot = (int) ((w >> 1) & 3u) - 1;
+#pragma unroll
+  for (int k = 0; k < 6; k++) s.status[k] = ((w >> (3 + k)) & 1u) != 0;
+  s.started = ((w >> 9) & 1u) != 0;
+  s.fc_flag = ((w >> 10) & 1u) != 0;
+  s.trans_init = ((w >> 11) & 1u) != 0;
+  s.standing_foot = (int) ((w >> 15) & 3u) - 1;
+  s.mode = (int) ((w >> 17) & 255u) - 1;
+  s.initialized = ((w >> 25) & 1u) != 0;
+  s.unknown_transitions = (int) ((w >> 32) & 0xFFFFu);
+  s.zero_ticks = (int) (w >> 48);
 }
 
-// SoA <-> struct (robot index fastest; d: [NLD][stride] doubles, iw: [NLI][stride] 64-bit integers)
-PB_HD void leg_load(LegState &s, const double *d, const int64_t *iw, long stride, long b)
+// SoA <-> struct (robot index fastest; d: [NLD][stride] doubles, iw: [NLI][stride] 64-bit words)
+PB_HD void leg_load(LegState &s, const double *d, const int64_t *iw, long stride, long b, bool world_constraint = false)
 {
-  Pose *ps[3] = { &s.odom_to_body, &s.odom_to_primary, &s.odom_to_secondary };
-  for (int k = 0; k < 3; k++) {
-    for (int i = 0; i < 3; i++) ps[k]->t[i] = d[(long) (7 * k + i) * stride + b];
-    for (int i = 0; i < 4; i++) ps[k]->q[i] = d[(long) (7 * k + 3 + i) * stride + b];
+  if (world_constraint) {
+#pragma unroll
+    for (int i = 0; i < 3; i++) s.trans_t[i] = d[(long) (NLD + i) * stride + b];
+  } else {
+    s.trans_t[0] = s.trans_t[1] = s.trans_t[2] = 0.0;
   }
-  int c = 0;
-  auto rd = [&]() { return iw[(long) (c++) * stride + b]; };
-  s.utime = rd();
-  Schmitt *ss[6] = { &s.alt_l, &s.alt_r, &s.weak_l, &s.weak_r, &s.strong_l, &s.strong_r };
-  for (int k = 0; k < 6; k++) { ss[k]->timer = rd(); ss[k]->previous_time = rd(); }
-  s.last_strike = rd(); s.last_break = rd();
-  leg_unpack_flags(s, rd());
+#pragma unroll
+  for (int i = 0; i < 3; i++) s.body_t[i] = d[(long) i * stride + b];
+#pragma unroll
+  for (int i = 0; i < 4; i++) s.body_q[i] = d[(long) (3 + i) * stride + b];
+#pragma unroll
+  for (int i = 0; i < 3; i++) s.prim_t[i] = d[(long) (7 + i) * stride + b];
+  s.utime = iw[b];
+  s.last_strike = iw[stride + b];
+  s.last_break = iw[2 * stride + b];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const uint64_t w = (uint64_t) iw[(long) (3 + k) * stride + b];
+    s.timer[2 * k] = (int32_t) (uint32_t) (w & 0xFFFFFFFFu);
+    s.timer[2 * k + 1] = (int32_t) (uint32_t) (w >> 32);
+  }
+  leg_unpack_flags(s, iw[6 * stride + b]);
 }
-PB_HD void leg_store(const LegState &s, double *d, int64_t *iw, long stride, long b)
+PB_HD void leg_store(const LegState &s, double *d, int64_t *iw, long stride, long b, bool world_constraint = false)
 {
-  const Pose *ps[3] = { &s.odom_to_body, &s.odom_to_primary, &s.odom_to_secondary };
-  for (int k = 0; k < 3; k++) {
-    for (int i = 0; i < 3; i++) d[(long) (7 * k + i) * stride + b] = ps[k]->t[i];
-    for (int i = 0; i < 4; i++) d[(long) (7 * k + 3 + i) * stride + b] = ps[k]->q[i];
+  if (world_constraint) {
+#pragma unroll
+    for (int i = 0; i < 3; i++) d[(long) (NLD + i) * stride + b] = s.trans_t[i];
   }
-  int c = 0;
-  auto wr = [&](int64_t v) { iw[(long) (c++) * stride + b] = v; };
-  wr(s.utime);
-  const Schmitt *ss[6] = { &s.alt_l, &s.alt_r, &s.weak_l, &s.weak_r, &s.strong_l, &s.strong_r };
-  for (int k = 0; k < 6; k++) { wr(ss[k]->timer); wr(ss[k]->previous_time); }
-  wr(s.last_strike); wr(s.last_break);
-  wr(leg_pack_flags(s));
+#pragma unroll
+  for (int i = 0; i < 3; i++) d[(long) i * stride + b] = s.body_t[i];
+#pragma unroll
+  for (int i = 0; i < 4; i++) d[(long) (3 + i) * stride + b] = s.body_q[i];
+#pragma unroll
+  for (int i = 0; i < 3; i++) d[(long) (7 + i) * stride + b] = s.prim_t[i];
+  iw[b] = s.utime;
+  iw[stride + b] = s.last_strike;
+  iw[2 * stride + b] = s.last_break;
+#pragma unroll
+  for (int k = 0; k < 3; k++)
+    iw[(long) (3 + k) * stride + b] = (int64_t) ((uint64_t) (uint32_t) s.timer[2 * k] | (uint64_t) (uint32_t) s.timer[2 * k + 1] << 32);
+  iw[6 * stride + b] = leg_pack_flags(s);
+}
+
+// ---- one message's inputs ----------------------------------------------------------------------------------------------
+// Either the two body-to-foot transforms (kind 0: feet [14][B] = left (t3, q4), right (t3, q4), forces [2][B], doubles) or the
+// joint state itself (kind 1: joint positions [rows][B], optionally efforts [rows][B] for the torque adjustment, forces
+// [2][B], floats like bot_core::joint_state_t / six_axis_force_torque_t carry them), per filter in device memory -- or ONE
+// robot's message for every filter (bcast: a parameter sweep over one log), whose values travel as kernel arguments
+// (feet kind: v = feet[14] + forces[2]; joint kind: v = torque-adjusted chain angles [2][LEG_MAXJ] + forces[2]).
+struct LegIn {
+  int kind = 0, bcast = 0;
+  const double *feet = nullptr, *forces = nullptr;
+  const float *jpos = nullptr, *jeff = nullptr, *jforces = nullptr;
+  const LegChain *chain = nullptr;
+  const int32_t *ncontacts = nullptr;  // controller contact counts [2][B] (device) or NULL: nc[] for every filter
+  int nc[2] = { -1, -1 };              // (-1: no CONTROLLER_FOOT_CONTACT message yet, rbis_legodo_update.cpp:100-101)
+  double v[2 * LEG_MAXJ + 2] = { 0 };
+};
+
+PB_HD void leg_inputs(const LegIn &in, long b, long B, Pose &bl, Pose &br, float &fl, float &fr, int &ncl, int &ncr)
+{
+  if (in.kind == 0) {
+    if (in.bcast) {
+#pragma unroll
+      for (int i = 0; i < 3; i++) { bl.t[i] = in.v[i]; br.t[i] = in.v[7 + i]; }
+#pragma unroll
+      for (int i = 0; i < 4; i++) { bl.q[i] = in.v[3 + i]; br.q[i] = in.v[10 + i]; }
+      fl = (float) in.v[14]; fr = (float) in.v[15];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 3; i++) { bl.t[i] = in.feet[(long) i * B + b]; br.t[i] = in.feet[(long) (7 + i) * B + b]; }
+#pragma unroll
+      for (int i = 0; i < 4; i++) { bl.q[i] = in.feet[(long) (3 + i) * B + b]; br.q[i] = in.feet[(long) (10 + i) * B + b]; }
+      fl = (float) in.forces[b]; fr = (float) in.forces[B + b];
+    }
+  } else {
+    const LegChain &ch = *in.chain;
+    if (in.bcast) {
+      leg_fk(ch, 0, [&](int j) { return in.v[j]; }, bl);
+      leg_fk(ch, 1, [&](int j) { return in.v[LEG_MAXJ + j]; }, br);
+      fl = (float) in.v[2 * LEG_MAXJ]; fr = (float) in.v[2 * LEG_MAXJ + 1];
+    } else {
+      auto angle = [&](int side, int j) {
+        const long at = (long) ch.row[side][j] * B + b;
+        float pos = in.jpos[at];
+        if (in.jeff != nullptr) pos = torque_adjust(pos, in.jeff[at], ch.gain[side][j]);
+        return (double) pos;
+      };
+      leg_fk(ch, 0, [&](int j) { return angle(0, j); }, bl);
+      leg_fk(ch, 1, [&](int j) { return angle(1, j); }, br);
+      fl = in.jforces[b]; fr = in.jforces[B + b];
+    }
+  }
+  if (in.ncontacts != nullptr) { ncl = in.ncontacts[b]; ncr = in.ncontacts[B + b]; }
+  else { ncl = in.nc[0]; ncr = in.nc[1]; }
+}
+
+// LegOdoCommon::createMeasurement in mode lin_rate on the odometry's result (rbis_legodo_common.cpp:99-107,124-129,153-156,
+// pronto_conversions_lcm.hpp:38-87): z = delta translation / elapsed time, R = r_vxyz^2 or r_vxyz_uncertain^2 when
+// status >= 0.5, no update (mask 0) when status < 0
+struct LegMeas {
+  double z[3], r;
+  bool valid;
+};
+PB_HD void leg_measurement(const Pose &delta, double status, int64_t utime, int64_t prev_utime, double r2, double r2_uncertain, LegMeas &m)
+{
+  const double elapsed = (double) (utime - prev_utime) * 1E-6;
+#pragma unroll
+  for (int i = 0; i < 3; i++) m.z[i] = delta.t[i] / elapsed;
+  m.r = (status >= 0.5) ? r2_uncertain : r2;
+  m.valid = !(status < 0);
 }
 
 #if defined(__HIPCC__)
-// One robot per lane: leg_update on its state, with the filter's own head orientation as world_to_body_ (setPoseBody,
-// rbis_legodo_update.cpp:214-229), then -- optionally -- LegOdoCommon::createMeasurement in mode lin_rate on the result
-// (rbis_legodo_common.cpp:99-107,124-129,153-156): z = delta translation / elapsed time, R = r_vxyz^2 or r_vxyz_uncertain^2
-// when status >= 0.5, no update (mask 0) when status < 0.  feet [14][B] = left (t3, q4), right (t3, q4); forces [2][B].
-// ONE robot's foot poses and forces for every filter of the batch (PB_HOST_BROADCAST: a parameter sweep over one log): the 16
-// values are kernel arguments.
-struct LegBcast {
-  double feet[14] = { 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0 }, forces[2] = { 0, 0 };
-  double imu[7] = { 0, 0, 0, 0, 0, 0, 0 };
-  int on = 0;  // bit 0: feet / forces are broadcast; bit 1: AHEAD (see k_legodo); bit 2: the IMU block of AHEAD is broadcast
-};
-// (launch bounds: without them the compiler budgets for 1024-thread blocks, 128 registers, and spilled 668 bytes per lane)
-// AHEAD (bc.on & 2): the odometry is slaved to the orientation the filter WILL have after the IMU step in `imu` / bc.imu
+// One robot per lane: the odometry on its state, with the filter's own head orientation as world_to_body_ (setPoseBody,
+// rbis_legodo_update.cpp:214-229), then -- optionally -- the lin_rate measurement of it.
+// AHEAD: the odometry is slaved to the orientation the filter WILL have after the IMU step in `imu` / imu_bc
 // (rbis_update_interface.cpp:30-52 applied to the head), computed here from the head state with the step kernels' own
 // ins_update_state -- the covariance is not touched.  That lets the estimator run the IMU step and the leg-odometry update
 // it produces as ONE fused kernel afterwards instead of predict, odometry, update.
+// (launch bounds: without them the compiler budgets for 1024-thread blocks, 128 registers, and spills)
+struct LegAhead {
+  int on = 0, bcast = 0;
+  const double *imu = nullptr;  // [7][B]
+  double v[7] = { 0, 0, 0, 0, 0, 0, 0 };
+};
 template <int NS>
 static __global__ __launch_bounds__(64, 2) void k_legodo(const double *__restrict__ st, double *__restrict__ legd,
                                                          int64_t *__restrict__ legi, long stride, int B, int64_t utime, LegPar par,
-                                                         const double *__restrict__ feet, const double *__restrict__ forces,
-                                                         int zero_delta, double r2, double r2_uncertain,
+                                                         LegIn in, LegAhead ah, int zero_delta, double r2, double r2_uncertain,
                                                          double *__restrict__ delta_out, double *__restrict__ status_out,
-                                                         double *__restrict__ lo_out, uint8_t *__restrict__ mask_out, LegBcast bc,
-                                                         const double *__restrict__ imu, Consts k)
+                                                         double *__restrict__ lo_out, uint8_t *__restrict__ mask_out,
+                                                         double *__restrict__ pos_out, uint8_t *__restrict__ pos_ok_out, Consts k)
 {
   using L = Lay<NS>;
   using S = Slots<NS>;
   const long b = (long) blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   LegState s;
-  leg_load(s, legd, legi, stride, b);
+  leg_load(s, legd, legi, stride, b, par.world_constraint != 0);
   Pose bl, br, delta;
-  double fl, fr;
-  if (bc.on & 1) {  // wave-uniform
-    for (int i = 0; i < 3; i++) { bl.t[i] = bc.feet[i]; br.t[i] = bc.feet[7 + i]; }
-    for (int i = 0; i < 4; i++) { bl.q[i] = bc.feet[3 + i]; br.q[i] = bc.feet[10 + i]; }
-    fl = bc.forces[0]; fr = bc.forces[1];
-  } else {
-    for (int i = 0; i < 3; i++) { bl.t[i] = feet[(long) i * B + b]; br.t[i] = feet[(long) (7 + i) * B + b]; }
-    for (int i = 0; i < 4; i++) { bl.q[i] = feet[(long) (3 + i) * B + b]; br.q[i] = feet[(long) (10 + i) * B + b]; }
-    fl = forces[b]; fr = forces[(long) B + b];
-  }
-  double wq[4];
+  float fl, fr;
+  int ncl, ncr;
+  double wq[4], wpos[3] = { 0.0, 0.0, 0.0 };
   for (int i = 0; i < 4; i++) wq[i] = st[S::eidx(L::OFF_QUAT + i, b)];
-  if (bc.on & 2) {
+  if (par.world_constraint && !ah.on)
+    for (int i = 0; i < 3; i++) wpos[i] = st[S::eidx(L::OFF_VEC + 9 + i, b)];
+  if (ah.on) {
     double x[NS], gyro[3], accel[3], dt;
 #pragma unroll
     for (int i = 0; i < NS; i++) x[i] = st[S::eidx(L::OFF_VEC + i, b)];
-    if (bc.on & 4) {
-      for (int i = 0; i < 3; i++) { gyro[i] = bc.imu[i]; accel[i] = bc.imu[3 + i]; }
-      dt = bc.imu[6];
+    if (ah.bcast) {
+      for (int i = 0; i < 3; i++) { gyro[i] = ah.v[i]; accel[i] = ah.v[3 + i]; }
+      dt = ah.v[6];
     } else {
-      for (int i = 0; i < 3; i++) { gyro[i] = imu[(long) i * B + b]; accel[i] = imu[(long) (3 + i) * B + b]; }
-      dt = imu[(long) 6 * B + b];
+      for (int i = 0; i < 3; i++) { gyro[i] = ah.imu[(long) i * B + b]; accel[i] = ah.imu[(long) (3 + i) * B + b]; }
+      dt = ah.imu[(long) 6 * B + b];
     }
     ins_update_state<NS>(x, wq, gyro, accel, dt, k);
+    for (int i = 0; i < 3; i++) wpos[i] = x[9 + i];
   }
+  leg_inputs(in, b, B, bl, br, fl, fr, ncl, ncr);
   int64_t prev = 0;
-  const double status = leg_update(s, par, utime, bl, br, fl, fr, wq, delta, prev);
-  leg_store(s, legd, legi, stride, b);
-  if (zero_delta) pose_identity(delta);  // "Ignore the calculated velocity at launch" (rbis_legodo_update.cpp:264-268)
+  double position[3];
+  bool position_ok;
+  const double status = leg_update(s, par, utime, bl, br, fl, fr, ncl, ncr, wq, delta, prev, wpos, position, position_ok);
+  const bool zero = leg_zero_velocity(s, status) || zero_delta != 0;
+  leg_store(s, legd, legi, stride, b, par.world_constraint != 0);
+  if (zero) {  // odo_delta.setIdentity(); odo_position.setIdentity() (rbis_legodo_update.cpp:266-267)
+    pose_identity(delta);
+    position[0] = position[1] = position[2] = 0.0;
+  }
+  if (pos_out != nullptr) {
+    for (int i = 0; i < 3; i++) pos_out[(long) i * B + b] = position[i];
+    if (pos_ok_out != nullptr) pos_ok_out[b] = position_ok ? 1 : 0;
+  }
   if (delta_out != nullptr) {
     for (int i = 0; i < 3; i++) delta_out[(long) i * B + b] = delta.t[i];
     for (int i = 0; i < 4; i++) delta_out[(long) (3 + i) * B + b] = delta.q[i];
   }
   if (status_out != nullptr) status_out[b] = status;
   if (lo_out != nullptr) {
-    const double elapsed = (double) (utime - prev) * 1E-6;  // pronto_conversions_lcm.hpp:38-87
+    LegMeas m;
+    leg_measurement(delta, status, utime, prev, r2, r2_uncertain, m);
     for (int i = 0; i < 3; i++) {
-      lo_out[(long) i * B + b] = delta.t[i] / elapsed;
-      lo_out[(long) (3 + i) * B + b] = (status >= 0.5) ? r2_uncertain : r2;
+      lo_out[(long) i * B + b] = m.z[i];
+      lo_out[(long) (3 + i) * B + b] = m.r;
     }
-    if (mask_out != nullptr) mask_out[b] = status < 0 ? 0 : 1;
+    if (mask_out != nullptr) mask_out[b] = m.valid ? 1 : 0;
   }
 }
-static __global__ void k_legodo_reset(double *legd, int64_t *legi, long stride, int B)
+// forward kinematics alone: feet_out [14][B] (diagnostics, tests)
+static __global__ __launch_bounds__(64) void k_leg_fk(LegIn in, int B, double *__restrict__ feet_out)
+{
+  const long b = (long) blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  Pose bl, br;
+  float fl, fr;
+  int ncl, ncr;
+  leg_inputs(in, b, B, bl, br, fl, fr, ncl, ncr);
+  for (int i = 0; i < 3; i++) { feet_out[(long) i * B + b] = bl.t[i]; feet_out[(long) (7 + i) * B + b] = br.t[i]; }
+  for (int i = 0; i < 4; i++) { feet_out[(long) (3 + i) * B + b] = bl.q[i]; feet_out[(long) (10 + i) * B + b] = br.q[i]; }
+}
+// zero_ticks < 0: reset everything; otherwise only set the per-robot zero_initial_velocity counter
+static __global__ void k_legodo_reset(double *legd, int64_t *legi, long stride, int B, int zero_ticks)
 {
   const long b = (long) blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   LegState s;
-  leg_reset(s);
-  leg_store(s, legd, legi, stride, b);
+  if (zero_ticks < 0) leg_reset(s);
+  else {
+    leg_load(s, legd, legi, stride, b, true);
+    s.zero_ticks = zero_ticks > 65535 ? 65535 : zero_ticks;
+  }
+  leg_store(s, legd, legi, stride, b, true);
 }
 static __global__ void k_legodo_get(const double *legd, const int64_t *legi, long stride, long b, double *pose7, int64_t *info)
 {
   LegState s;
   leg_load(s, legd, legi, stride, b);
-  for (int i = 0; i < 3; i++) pose7[i] = s.odom_to_body.t[i];
-  for (int i = 0; i < 4; i++) pose7[3 + i] = s.odom_to_body.q[i];
+  for (int i = 0; i < 3; i++) pose7[i] = s.body_t[i];
+  for (int i = 0; i < 4; i++) pose7[3 + i] = s.body_q[i];
   info[0] = s.primary_foot; info[1] = s.leg_odo_init; info[2] = s.mode; info[3] = s.unknown_transitions;
 }
 #endif

@@ -82,7 +82,7 @@ int main(int argc, char **argv)
   auto on_ins = front_end.addSensor("ins", &InsHandler::processMessage, &ins_handler);
   auto on_sm = front_end.addSensor("scan_matcher", &ScanMatcherHandler::processMessage, &sm_handler);
   auto on_fovis = front_end.addSensor("fovis", &FovisHandler::processMessage, &fovis_handler);
-  auto on_legodo = front_end.addSensor("legodo", &LegOdoHandler::processMessage, &legodo_handler);
+  auto on_legodo = front_end.addSensor("legodo", &LegOdoHandler::processMessageDelta, &legodo_handler);
   MavStateEstimator est(new RBISResetUpdate(x0, P0, RBISUpdateInterface::reset, 0), &param, 0);
   front_end.setStateEstimator(&est);
   fovis_handler.markKeyframe(&est);

@@ -44,8 +44,8 @@ int main(int argc, char **argv)
   param.set("state_estimator.ins.atlas_filter", "false");
   param.set("state_estimator.ins.accel_bias_update_online", "false");
   param.set("state_estimator.ins.gyro_bias_update_online", "false");
-  param.applyOverrides("state_estimator.legodo.mode=" + lomode + "|state_estimator.legodo.r_xyz=0.2|state_estimator.legodo.r_vxyz=0.1|"
-                       "state_estimator.legodo.r_vang=0.3|state_estimator.legodo.r_vxyz_uncertain=0.5|state_estimator.legodo.r_vang_uncertain=0.9|"
+  param.applyOverrides("state_estimator.legodo.mode=" + lomode + "|state_estimator.legodo.r_xyz=0.2|state_estimator.legodo.r_vxyz=5|"
+                       "state_estimator.legodo.r_vang=3|state_estimator.legodo.r_vxyz_uncertain=10|state_estimator.legodo.r_vang_uncertain=9|"
                        "state_estimator.legodo.schmitt_low_threshold=475|state_estimator.legodo.schmitt_high_threshold=525|"
                        "state_estimator.legodo.schmitt_low_delay=7000|state_estimator.legodo.schmitt_high_delay=7000|"
                        "state_estimator.legodo.filter_contact_events=true|state_estimator.legodo.zero_initial_velocity=3");
@@ -78,11 +78,12 @@ int main(int argc, char **argv)
   MavStateEstimator est(new RBISResetUpdate(x0, P0, RBISUpdateInterface::reset, 0), &param, 0);
   front_end.setStateEstimator(&est);
   int n_status[3] = { 0, 0, 0 }, lo_ticks = 0;
+  std::vector<int> zero_count(B, 3);
   {
     LegOdoHandler legodo_handler(&param);
     auto on_feet = front_end.addSensor("legodo", &LegOdoHandler::processMessageFeet, &legodo_handler);
     const double q4[4] = { ins_handler.cov_gyro, ins_handler.cov_accel, ins_handler.cov_gyro_bias, ins_handler.cov_accel_bias };
-    const double r5[5] = { 0.2, 0.1, 0.3, 0.5, 0.9 };
+    const double r5[5] = { 0.2, 5.0, 3.0, 10.0, 9.0 };  // (r_vxyz = 5 / 10 m/s: see tests/test_leg_odometry.py R_VXYZ)
     const int omode = lomode == "lin_rate" ? 0 : 1;
     std::vector<double> feet(14 * B), forces(2 * B);
     for (int k = 0; k < T; k++) {
@@ -116,9 +117,10 @@ int main(int argc, char **argv)
         double dt3[3], dq[4];
         long prev = 0;
         float status = po_leg_update((po_leg *) legs[b].data(), utime, lt, ql, rt, qr, forces[b], forces[B + b], ox[b].quat, dt3, dq, &prev);
-        if (lo_ticks < 3) { dt3[0] = dt3[1] = dt3[2] = 0; dq[0] = 1; dq[1] = dq[2] = dq[3] = 0; }  // zero_initial_velocity = 3
         n_status[status < 0 ? 0 : (status < 0.5 ? 1 : 2)]++;
-        if (status < 0) continue;
+        if (status < 0) continue;   // "return NULL" (rbis_legodo_update.cpp:243-255), before the counter is touched
+        zero_count[b]--;            // zero_initial_velocity = 3 (:264-268), per filter: validity is per filter
+        if (zero_count[b] > 0) { dt3[0] = dt3[1] = dt3[2] = 0; dq[0] = 1; dq[1] = dq[2] = dq[3] = 0; }
         int idx[6];
         double z[6], Rd[6], R[36] = { 0 }, p3[3] = { 0, 0, 0 };
         const int m = po_legodo_create_measurement(omode, r5, p3, dt3, dq, utime, prev, 1, status, idx, z, Rd);

@@ -67,7 +67,7 @@ int main(int argc, char **argv)
   LegOdoHandler legodo_handler(&param);
   FrontEnd front_end(&param);
   auto on_ins = front_end.addSensor("ins", &InsHandler::processMessage, &ins_handler);
-  auto on_legodo = front_end.addSensor("legodo", &LegOdoHandler::processMessage, &legodo_handler);
+  auto on_legodo = front_end.addSensor("legodo", &LegOdoHandler::processMessageDelta, &legodo_handler);
   MavStateEstimator est(new RBISResetUpdate(x0, P0, RBISUpdateInterface::reset, 0), &param, 0);
   front_end.setStateEstimator(&est);
   const double q4[4] = { ins_handler.cov_gyro, ins_handler.cov_accel, ins_handler.cov_gyro_bias, ins_handler.cov_accel_bias };

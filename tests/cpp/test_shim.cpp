@@ -82,7 +82,7 @@ int main(int argc, char **argv)
   ScanMatcherHandler sm_handler(&param);
   FrontEnd front_end(&param);
   auto on_ins = front_end.addSensor("ins", &InsHandler::processMessageAtlas, &ins_handler);
-  auto on_legodo = front_end.addSensor("legodo", &LegOdoHandler::processMessage, &legodo_handler);
+  auto on_legodo = front_end.addSensor("legodo", &LegOdoHandler::processMessageDelta, &legodo_handler);
   auto on_fovis = front_end.addSensor("fovis", &FovisHandler::processMessage, &fovis_handler);
   auto on_sm = front_end.addSensor("scan_matcher", &ScanMatcherHandler::processMessage, &sm_handler);
 

@@ -296,7 +296,7 @@ extern "C" void hh_update_quad(int kind, double *st, long stride, int B, const d
 // ---- leg kinematic odometry (rbis_legodo.hpp): one call = one joint-state message for B robots ----
 #include "../pronto_amd/csrc/rbis_legodo.hpp"
 extern "C" {
-int hh_leg_nld() { return NLD; }
+int hh_leg_nld() { return NLD + NLD_WC; }
 int hh_leg_nli() { return NLI; }
 // info = primary_foot, leg_odo_init, walking-phase mode, unknown transitions of robot b (the integers are stored packed)
 void hh_leg_info(const double *legd, const int64_t *legi, long stride, long b, int64_t *info)
@@ -310,17 +310,32 @@ void hh_leg_reset(double *legd, int64_t *legi, long stride, int B)
   for (int b = 0; b < B; b++) {
     LegState s;
     leg_reset(s);
-    leg_store(s, legd, legi, stride, b);
+    leg_store(s, legd, legi, stride, b, true);
+  }
+}
+void hh_leg_set_zero_ticks(double *legd, int64_t *legi, long stride, int B, int ticks)
+{
+  for (int b = 0; b < B; b++) {
+    LegState s;
+    leg_load(s, legd, legi, stride, b, true);
+    s.zero_ticks = ticks;
+    leg_store(s, legd, legi, stride, b, true);
   }
 }
 // feet [14][B], forces [2][B], wq [4][B]; delta [7][B], status [B], prev [B]
-void hh_leg_update(double *legd, int64_t *legi, long stride, int B, int64_t utime, double lt, double ht, int64_t ld, int64_t hd,
-                   int filter_contact_events, const double *feet, const double *forces, const double *wq, double *delta,
-                   double *status, int64_t *prev)
+// par9 = schmitt low, high, low delay, high delay, filter_contact_events, standing, total_force, standing_schmitt_level,
+// use_controller_input (thresholds rounded to float like pb_legodo_init / pb_legodo_set_contact_mode do); nc = controller
+// contact counts {left, right} for every robot
+void hh_leg_update(double *legd, int64_t *legi, long stride, int B, int64_t utime, const double *par9, const int *nc,
+                   const double *feet, const double *forces, const double *wq, double *delta, double *status, int64_t *prev)
 {
   LegPar par;
-  par.alt = SchmittPar{ lt, ht, ld, hd };
-  par.filter_contact_events = filter_contact_events;
+  par.alt = SchmittPar{ (double) (float) par9[0], (double) (float) par9[1], (int64_t) par9[2], (int64_t) par9[3] };
+  par.filter_contact_events = (int) par9[4];
+  par.standing = (int) par9[5];
+  par.total_force = (float) par9[6];
+  par.standing_schmitt_level = (float) par9[7];
+  par.use_controller_input = (int) par9[8];
   for (int b = 0; b < B; b++) {
     LegState s;
     leg_load(s, legd, legi, stride, b);
@@ -328,10 +343,75 @@ void hh_leg_update(double *legd, int64_t *legi, long stride, int B, int64_t utim
     for (int i = 0; i < 3; i++) { bl.t[i] = feet[i * B + b]; br.t[i] = feet[(7 + i) * B + b]; }
     for (int i = 0; i < 4; i++) { bl.q[i] = feet[(3 + i) * B + b]; br.q[i] = feet[(10 + i) * B + b]; }
     const double w[4] = { wq[b], wq[B + b], wq[2 * B + b], wq[3 * B + b] };
-    status[b] = leg_update(s, par, utime, bl, br, forces[b], forces[B + b], w, d, prev[b]);
+    status[b] = leg_update(s, par, utime, bl, br, (float) forces[b], (float) forces[B + b], nc[0], nc[1], w, d, prev[b]);
     leg_store(s, legd, legi, stride, b);
     for (int i = 0; i < 3; i++) delta[i * B + b] = d.t[i];
     for (int i = 0; i < 4; i++) delta[(3 + i) * B + b] = d.q[i];
   }
 }
+// the same with the world constraint (LegPar::world_constraint) and the per-robot zero_initial_velocity counter, as k_legodo
+// runs them: wpos [3][B] head position; pos [3][B], pos_ok [B] out
+void hh_leg_update_wc(double *legd, int64_t *legi, long stride, int B, int64_t utime, const double *par9, const int *nc,
+                      const double *feet, const double *forces, const double *wpos, const double *wq, double *delta, double *status,
+                      int64_t *prev, double *pos, int *pos_ok)
+{
+  LegPar par;
+  par.alt = SchmittPar{ (double) (float) par9[0], (double) (float) par9[1], (int64_t) par9[2], (int64_t) par9[3] };
+  par.filter_contact_events = (int) par9[4];
+  par.standing = (int) par9[5];
+  par.total_force = (float) par9[6];
+  par.standing_schmitt_level = (float) par9[7];
+  par.use_controller_input = (int) par9[8];
+  par.world_constraint = 1;
+  for (int b = 0; b < B; b++) {
+    LegState s;
+    leg_load(s, legd, legi, stride, b, true);
+    Pose bl, br, d;
+    for (int i = 0; i < 3; i++) { bl.t[i] = feet[i * B + b]; br.t[i] = feet[(7 + i) * B + b]; }
+    for (int i = 0; i < 4; i++) { bl.q[i] = feet[(3 + i) * B + b]; br.q[i] = feet[(10 + i) * B + b]; }
+    const double w[4] = { wq[b], wq[B + b], wq[2 * B + b], wq[3 * B + b] }, wp[3] = { wpos[b], wpos[B + b], wpos[2 * B + b] };
+    double position[3];
+    bool ok;
+    status[b] = leg_update(s, par, utime, bl, br, (float) forces[b], (float) forces[B + b], nc[0], nc[1], w, d, prev[b], wp, position, ok);
+    if (leg_zero_velocity(s, status[b])) {
+      pose_identity(d);
+      position[0] = position[1] = position[2] = 0.0;
+    }
+    leg_store(s, legd, legi, stride, b, true);
+    for (int i = 0; i < 3; i++) { delta[i * B + b] = d.t[i]; pos[i * B + b] = position[i]; }
+    for (int i = 0; i < 4; i++) delta[(3 + i) * B + b] = d.q[i];
+    pos_ok[b] = ok;
+  }
+}
+// forward kinematics of one chain with the device code's quaternion arithmetic: type / origin_xyz_rpy [n][6] / axis [n][3] as
+// pb_legodo_set_chain takes them, angle [n] -> t[3], q[4]
+void hh_fk(int n, const int *type, const double *origin_xyz_rpy, const double *axis, const double *angle, double *t, double *q)
+{
+  LegChain ch;
+  memset(&ch, 0, sizeof ch);
+  ch.n[0] = n;
+  for (int j = 0; j < n; j++) {
+    ch.type[0][j] = type[j];
+    const double *o = origin_xyz_rpy + 6 * j;
+    for (int i = 0; i < 3; i++) ch.org_t[0][j][i] = o[i];
+    const double phi = o[3] / 2.0, the = o[4] / 2.0, psi = o[5] / 2.0;
+    double oq[4] = { cos(phi) * cos(the) * cos(psi) + sin(phi) * sin(the) * sin(psi), sin(phi) * cos(the) * cos(psi) - cos(phi) * sin(the) * sin(psi),
+                     cos(phi) * sin(the) * cos(psi) + sin(phi) * cos(the) * sin(psi), cos(phi) * cos(the) * sin(psi) - sin(phi) * sin(the) * cos(psi) };
+    const double qn = sqrt(oq[0] * oq[0] + oq[1] * oq[1] + oq[2] * oq[2] + oq[3] * oq[3]);
+    for (int i = 0; i < 4; i++) ch.org_q[0][j][i] = oq[i] / qn;
+    ch.org_rot[0][j] = (o[3] != 0.0 || o[4] != 0.0 || o[5] != 0.0);
+    const double *a = axis + 3 * j;
+    const double an = sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
+    for (int i = 0; i < 3; i++) ch.axis[0][j][i] = type[j] ? a[i] / an : 0.0;
+  }
+  Pose T;
+  leg_fk(ch, 0, [&](int j) { return angle[j]; }, T);
+  for (int i = 0; i < 3; i++) t[i] = T.t[i];
+  for (int i = 0; i < 4; i++) q[i] = T.q[i];
+}
+void hh_sincos_joint(int n, const double *x, double *s, double *c)
+{
+  for (int i = 0; i < n; i++) sincos_joint(x[i], s[i], c[i]);
+}
+float hh_torque_adjust(float position, float effort, float gain) { return torque_adjust(position, effort, gain); }
 }

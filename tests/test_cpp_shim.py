@@ -228,3 +228,16 @@ def test_shim_sweep_rate_example_runs(n, slots):
     r = subprocess.run([build_shim_sweep_rate(), "2048", "300", str(n), slots], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "dropped 0" in r.stdout and "finite" in r.stdout and "NON-FINITE" not in r.stdout, r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("args", [("lin_rate", "alt"), ("lin_rate", "alt", "fuse"), ("lin_rate", "standing", "fuse", "bcast"),
+                                  ("lin_rot_rate", "ctrl"), ("pos_and_lin_rate", "alt"), ("lin_rate", "ctrl", "nofuse", "bcast")])
+def test_joint_state_handler_on_gpu(oracle, args):
+    """LegOdoHandler::processMessage(joint_state_t) -- the reference's handler signature -- from a synthetic 6-DoF-per-leg gait:
+    URDF text -> chains, force/torque + controller messages, torque adjustment, forward kinematics, contact logic, odometry and
+    LegOdoCommon's measurement on the device, against the oracle chain (tests/cpp/test_leg_joints.cpp)."""
+    exe = build_exe(oracle, "test_leg_joints")
+    r = subprocess.run([exe, *args], capture_output=True, text=True, timeout=300)
+    print(r.stdout[-2000:], r.stderr[-2000:])
+    assert r.returncode == 0 and "PASS" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]

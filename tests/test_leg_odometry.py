@@ -51,29 +51,40 @@ def gait(B, T, seed=5, dt_us=2000, gap_at=None):
 
 
 class OracleLegs:
-    def __init__(self, oracle, B, filter_contact_events):
+    def __init__(self, oracle, B, filter_contact_events, standing=None, use_controller_input=False):
+        """standing = (total_force, standing_schmitt_level): contact mode "standing" (FootContact), else FootContactAlt."""
         self.L = oracle.lib()
         self.L.po_leg_sizeof.restype = C.c_size_t
-        self.L.po_leg_update.restype = C.c_float
+        self.L.po_leg_update_wc.restype = C.c_float
         dp = C.POINTER(C.c_double)
-        self.L.po_leg_update.argtypes = [C.c_void_p, C.c_long, dp, dp, dp, dp, C.c_double, C.c_double, dp, dp, dp, C.POINTER(C.c_long)]
+        self.L.po_leg_update_wc.argtypes = [C.c_void_p, C.c_long, dp, dp, dp, dp, C.c_double, C.c_double, C.c_int, C.c_int, dp, dp, dp, dp,
+                                            C.POINTER(C.c_long), dp, C.POINTER(C.c_int)]
         self.L.po_leg_init.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_long, C.c_long, C.c_int]
+        self.L.po_leg_set_contact_mode.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_int]
         n = self.L.po_leg_sizeof()
         self.bufs = [C.create_string_buffer(n) for _ in range(B)]
         for b in self.bufs:
             self.L.po_leg_init(b, *SCHMITT, int(filter_contact_events))
+            if standing is not None or use_controller_input:
+                tf, lvl = standing if standing is not None else (0.0, 0.0)
+                self.L.po_leg_set_contact_mode(b, int(standing is not None), tf, lvl, int(use_controller_input))
         self.B = B
 
-    def update(self, utime, feet, forces, wq):
+    def update(self, utime, feet, forces, wq, nc=(-1, -1), wpos=None):
+        """-> increment [7,B], status [B], previous utime [B]; self.pos [3,B] / self.pos_ok [B] = the world constraint."""
         B = self.B
+        self.pos, self.pos_ok = np.zeros((3, B)), np.zeros(B, dtype=bool)
         delta, status, prev = np.zeros((7, B)), np.zeros(B), np.zeros(B, dtype=np.int64)
         dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
         for b in range(B):
             f = np.ascontiguousarray(feet[:, b]); w = np.ascontiguousarray(wq[:, b])
-            dt, dq, pv = np.zeros(3), np.zeros(4), C.c_long(0)
-            status[b] = self.L.po_leg_update(self.bufs[b], utime, dp(f[0:3]), dp(f[3:7]), dp(f[7:10]), dp(f[10:14]), forces[0, b],
-                                             forces[1, b], dp(w), dp(dt), dp(dq), C.byref(pv))
+            dt, dq, pv, cp, cok = np.zeros(3), np.zeros(4), C.c_long(0), np.zeros(3), C.c_int(0)
+            wp = np.zeros(3) if wpos is None else np.ascontiguousarray(wpos[:, b])
+            status[b] = self.L.po_leg_update_wc(self.bufs[b], utime, dp(f[0:3]), dp(f[3:7]), dp(f[7:10]), dp(f[10:14]), forces[0, b],
+                                                forces[1, b], int(nc[0]), int(nc[1]), dp(wp), dp(w), dp(dt), dp(dq), C.byref(pv), dp(cp),
+                                                C.byref(cok))
             delta[0:3, b], delta[3:7, b], prev[b] = dt, dq, pv.value
+            self.pos[:, b], self.pos_ok[b] = cp, bool(cok.value)
         return delta, status, prev
 
     def get(self, b):
@@ -89,25 +100,55 @@ def same_rotation(qa, qb):
     return np.max(np.abs(np.abs(np.sum(qa * qb, axis=0)) - 1.0))
 
 
-@pytest.mark.parametrize("fce", [True, False])
-def test_leg_odometry_arithmetic_matches_oracle_on_cpu(oracle, harness, fce):
+# legodo.r_vxyz / r_vxyz_uncertain for the closed-loop tests.  The synthetic gait is not the motion the synthetic IMU measures, and
+# the measurement is (increment slaved to the filter's orientation) / 2 ms with a 0.86 m lever arm, i.e. 430 m/s per radian of
+# orientation error fed back through the Kalman gain: with the reference's 0.1 m/s the loop gain exceeds one and the filter
+# flips by radians per tick within seven ticks (seen on the GPU and in the oracle alike) -- a chaotic system that amplifies the
+# last bit of either side.  5 / 10 m/s keeps the loop gain below one; the update still moves the state at the 1e-3 level.
+R_VXYZ = (5.0, 10.0)
+STANDING = (900.0, 0.65)   # legodo.total_force / standing_schmitt_level of the "standing" contact mode (test values)
+
+
+def harness_par(fce, standing=None, use_ctrl=False):
+    tf, lvl = standing if standing is not None else (0.0, 0.0)
+    return np.array([SCHMITT[0], SCHMITT[1], SCHMITT[2], SCHMITT[3], float(fce), float(standing is not None), tf, lvl, float(use_ctrl)])
+
+
+def controller_contacts(k):
+    """CONTROLLER_FOOT_CONTACT as the test's controller sends it: none before tick 50, then 4 + 4 contact points with
+    stretches where it reports toe-off on one foot."""
+    if k < 50:
+        return (-1, -1)
+    if 300 <= k % 500 < 360:
+        return (2, 4)
+    if 100 <= k % 500 < 150:
+        return (4, 1)
+    return (4, 4)
+
+
+@pytest.mark.parametrize("fce,standing,use_ctrl", [(True, None, False), (False, None, False), (True, STANDING, False), (True, None, True)])
+def test_leg_odometry_arithmetic_matches_oracle_on_cpu(oracle, harness, fce, standing, use_ctrl):
+    """The per-robot arithmetic of rbis_legodo.hpp (quaternions, shared trigger clock, saturating 32-bit timers) against the
+    oracle (rotation matrices, one clock per trigger, 64-bit timers) in FootContactAlt mode, in the "standing" mode
+    (FootContact.cpp) and with the controller's contact counts overruling the standing foot (leg_estimate.cpp:365-387)."""
     B, T = 40, 1500
     H = harness
     legd = np.zeros((H.hh_leg_nld(), B)); legi = np.zeros((H.hh_leg_nli(), B), dtype=np.int64)
     ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int64))
     dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
     H.hh_leg_reset(dp(legd), ip(legi), C.c_long(B), B)
-    orc = OracleLegs(oracle, B, fce)
+    orc = OracleLegs(oracle, B, fce, standing, use_ctrl)
+    par = harness_par(fce, standing, use_ctrl)
     seen = set()
     n_switch = 0
     prev_primary = None
-    for utime, feet, forces, wq in gait(B, T, gap_at=700):
+    for k, (utime, feet, forces, wq) in enumerate(gait(B, T, gap_at=700)):
+        nc = controller_contacts(k) if use_ctrl else (-1, -1)
         delta, status, prev = np.zeros((7, B)), np.zeros(B), np.zeros(B, dtype=np.int64)
-        H.hh_leg_update(dp(legd), ip(legi), C.c_long(B), B, C.c_int64(utime), C.c_double(SCHMITT[0]), C.c_double(SCHMITT[1]),
-                        C.c_int64(SCHMITT[2]), C.c_int64(SCHMITT[3]), int(fce), dp(feet), dp(forces), dp(wq), dp(delta), dp(status),
-                        ip(prev))
-        od, os_, op = orc.update(utime, feet, forces, wq)
-        assert np.array_equal(status, os_) and np.array_equal(prev, op)
+        H.hh_leg_update(dp(legd), ip(legi), C.c_long(B), B, C.c_int64(utime), dp(par), (C.c_int * 2)(*nc), dp(feet), dp(forces), dp(wq),
+                        dp(delta), dp(status), ip(prev))
+        od, os_, op = orc.update(utime, feet, forces, wq, nc)
+        assert np.array_equal(status, os_) and np.array_equal(prev, op), k
         assert np.max(np.abs(delta[0:3] - od[0:3])) < 1e-13 and same_rotation(delta[3:7], od[3:7]) < 1e-13
         seen.update(np.unique(status).tolist())
         primary = ((legi[-1] >> 1) & 3) - 1    # (the flags word: bits 1-2 = primary_foot + 1, rbis_legodo.hpp leg_pack_flags)
@@ -122,6 +163,144 @@ def test_leg_odometry_arithmetic_matches_oracle_on_cpu(oracle, harness, fce):
         hi = np.zeros(4, dtype=np.int64)
         H.hh_leg_info(dp(legd), ip(legi), C.c_long(B), C.c_long(b), ip(hi))
         assert info[0] == hi[0] and info[1] == hi[1] and info[2] == hi[2] and info[3] == hi[3]
+
+
+def test_world_constraint_and_zero_initial_velocity_on_cpu(oracle, harness):
+    """getLegOdometryWorldConstraint (leg_estimate.cpp:299-318,461-492: the pelvis position that follows from the foot last put
+    down, which mode pos_and_lin_rate measures) and LegOdoHandler's zero_initial_velocity (rbis_legodo_update.cpp:264-268)
+    counted per robot over VALID ticks only (:243-255 return NULL before the decrement)."""
+    B, T, ZERO = 30, 900, 7
+    H, L = harness, oracle.lib()
+    dpt = C.POINTER(C.c_double)
+    L.po_leg_update_wc.restype = C.c_float
+    L.po_leg_update_wc.argtypes = [C.c_void_p, C.c_long, dpt, dpt, dpt, dpt, C.c_double, C.c_double, C.c_int, C.c_int, dpt, dpt, dpt, dpt,
+                                   C.POINTER(C.c_long), dpt, C.POINTER(C.c_int)]
+    legd = np.zeros((H.hh_leg_nld(), B)); legi = np.zeros((H.hh_leg_nli(), B), dtype=np.int64)
+    ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int64))
+    dp = lambda a: a.ctypes.data_as(dpt)
+    H.hh_leg_reset(dp(legd), ip(legi), C.c_long(B), B)
+    H.hh_leg_set_zero_ticks(dp(legd), ip(legi), C.c_long(B), B, ZERO)
+    orc = OracleLegs(oracle, B, True)
+    par = harness_par(True)
+    rng = np.random.default_rng(8)
+    n_valid = np.zeros(B, dtype=int)
+    n_pos = 0
+    for k, (utime, feet, forces, wq) in enumerate(gait(B, T, seed=12)):
+        wpos = np.ascontiguousarray(np.cumsum(0.002 * rng.normal(size=(3, B)), axis=1) + np.array([[0.001 * k], [0.0], [0.9]]))
+        delta, status, prev = np.zeros((7, B)), np.zeros(B), np.zeros(B, dtype=np.int64)
+        pos, ok = np.zeros((3, B)), np.zeros(B, dtype=np.int32)
+        H.hh_leg_update_wc(dp(legd), ip(legi), C.c_long(B), B, C.c_int64(utime), dp(par), (C.c_int * 2)(-1, -1), dp(feet), dp(forces), dp(wpos), dp(wq),
+                           dp(delta), dp(status), ip(prev), dp(pos), ok.ctypes.data_as(C.POINTER(C.c_int)))
+        for b in range(B):
+            f = np.ascontiguousarray(feet[:, b]); w = np.ascontiguousarray(wq[:, b]); wp = np.ascontiguousarray(wpos[:, b])
+            dt, dq, pv, cp, cok = np.zeros(3), np.zeros(4), C.c_long(0), np.zeros(3), C.c_int(0)
+            st = L.po_leg_update_wc(orc.bufs[b], utime, dp(f[0:3]), dp(f[3:7]), dp(f[7:10]), dp(f[10:14]), forces[0, b], forces[1, b], -1, -1,
+                                    dp(wp), dp(w), dp(dt), dp(dq), C.byref(pv), dp(cp), C.byref(cok))
+            assert st == status[b]
+            if st < 0:
+                continue
+            n_valid[b] += 1                    # the reference handler's `zero_initial_velocity--` happens here
+            if ZERO - n_valid[b] > 0:          # ... `if (zero_initial_velocity > 0)`: identity increment and position
+                assert np.all(delta[0:3, b] == 0) and np.all(delta[3:7, b] == [1, 0, 0, 0]) and np.all(pos[:, b] == 0)
+                continue
+            assert np.max(np.abs(delta[0:3, b] - dt)) < 1e-13
+            assert bool(ok[b]) == bool(cok.value)
+            if cok.value:
+                assert np.max(np.abs(pos[:, b] - cp)) < 1e-12
+                n_pos += 1
+    assert n_pos > B * T // 8 and np.all(n_valid > ZERO)
+
+
+def test_sincos_of_a_joint_angle(harness):
+    """sincos_joint (two-piece Cody-Waite reduction + minimax polynomials) against libm over the range of joint angles and
+    far beyond it."""
+    rng = np.random.default_rng(2)
+    x = np.concatenate([rng.uniform(-7, 7, 20000), rng.uniform(-2000, 2000, 5000), np.array([0.0, -0.0, np.pi / 4, -np.pi / 4, np.pi / 2, 1e-300, 3e-9])])
+    s, c = np.zeros_like(x), np.zeros_like(x)
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    harness.hh_sincos_joint(len(x), dp(x), dp(s), dp(c))
+    assert np.max(np.abs(s - np.sin(x))) < 2.3e-16 and np.max(np.abs(c - np.cos(x))) < 2.3e-16
+
+
+@pytest.mark.parametrize("which", ["atlas", "odd"])
+def test_forward_kinematics_matches_the_kdl_restatement_on_cpu(oracle, harness, which):
+    """leg_fk (quaternion product with half angles, un-rotated axes) against the oracle's restatement of what KDL computes for
+    leg_estimate.cpp:430-447 (kdl_parser's segments, Rot2's Rodrigues matrices about the rotated axis, GetQuaternion)."""
+    import legs
+    L = oracle.lib()
+    chain = legs.chain_arrays(*((legs.ATLAS_LEFT, legs.ATLAS_RIGHT, legs.ATLAS_ROWS) if which == "atlas" else (legs.ODD_LEFT, legs.ODD_RIGHT, legs.ODD_ROWS)))
+    nl, nr, ty, rows, org, ax = chain
+    rng = np.random.default_rng(7)
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    worst_t = worst_q = 0.0
+    for trial in range(300):
+        for side, (lo, n) in enumerate(((0, nl), (nl, nr))):
+            ang = rng.uniform(-3.2, 3.2, n).astype(np.float32).astype(np.float64)
+            ot, oq = legs.oracle_fk(L, chain, side, ang)
+            t, q = np.zeros(3), np.zeros(4)
+            harness.hh_fk(n, (C.c_int * n)(*ty[lo:lo + n]), dp(np.ascontiguousarray(org[lo:lo + n])), dp(np.ascontiguousarray(ax[lo:lo + n])), dp(ang),
+                          dp(t), dp(q))
+            worst_t = max(worst_t, np.max(np.abs(t - ot)))
+            worst_q = max(worst_q, same_rotation(q[:, None], oq[:, None]))
+            assert abs(np.dot(q, q) - 1.0) < 1e-14
+    # (the odd chain has a prismatic joint driven over +-3.2 m and eight rounding steps more per joint)
+    assert worst_t < (2e-15 if which == "atlas" else 2e-14) and worst_q < 2e-15, (worst_t, worst_q)
+    if which == "atlas":   # the zero pose: feet below the hips, 0.862 m down
+        t, q = legs.oracle_fk(L, chain, 0, np.zeros(6))
+        assert np.allclose(t, [0.0, 0.1115, -0.862]) and np.allclose(np.abs(q), [1, 0, 0, 0])
+
+
+def test_torque_adjustment_is_the_reference_float_arithmetic(oracle, harness):
+    L = oracle.lib()
+    L.po_torque_adjust.restype = C.c_float
+    L.po_torque_adjust.argtypes = [C.c_float, C.c_float, C.c_float]
+    harness.hh_torque_adjust.restype = C.c_float
+    harness.hh_torque_adjust.argtypes = [C.c_float, C.c_float, C.c_float]
+    rng = np.random.default_rng(11)
+    for _ in range(3000):
+        p, e, g = np.float32(rng.normal()), np.float32(200 * rng.normal()), np.float32(rng.choice([700.0, 1000.0, 7000.0, 10000.0, -500.0]))
+        assert harness.hh_torque_adjust(p, e, g) == L.po_torque_adjust(p, e, g)
+    for g in (0.0, np.inf, np.nan):   # "don't do the correction if filterGains_[i] is zero, NaN, or infinite" -> the ABI stores 0
+        assert L.po_torque_adjust(np.float32(0.3), np.float32(50.0), np.float32(g)) == np.float32(0.3)
+    assert harness.hh_torque_adjust(np.float32(0.3), np.float32(50.0), np.float32(0.0)) == np.float32(0.3)
+
+
+def test_joint_state_odometry_arithmetic_matches_oracle_on_cpu(oracle, harness):
+    """joint angles -> forward kinematics -> odometry, harness (device arithmetic) against the oracle chain
+    po_torque_adjust -> po_fk -> po_leg_update: the statuses must be identical, the increments agree to 1e-13."""
+    import legs
+    B, T = 12, 700
+    H, L = harness, oracle.lib()
+    chain = legs.chain_arrays(legs.ATLAS_LEFT, legs.ATLAS_RIGHT, legs.ATLAS_ROWS)
+    nl, nr, ty, rows, org, ax = chain
+    gain = np.array([7000, 10000, 10000, 10000, 10000, 10000] * 2, dtype=np.float32)
+    legd = np.zeros((H.hh_leg_nld(), B)); legi = np.zeros((H.hh_leg_nli(), B), dtype=np.int64)
+    ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int64))
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    H.hh_leg_reset(dp(legd), ip(legi), C.c_long(B), B)
+    H.hh_torque_adjust.restype = C.c_float
+    H.hh_torque_adjust.argtypes = [C.c_float, C.c_float, C.c_float]
+    orc = OracleLegs(oracle, B, True)
+    par = harness_par(True)
+    seen = set()
+    for utime, jp, je, forces, wq in legs.joint_gait(B, T, seed=4):
+        ofeet = legs.oracle_feet(L, chain, jp, je, gain)
+        feet = np.zeros((14, B))
+        for b in range(B):
+            for side, (lo, n) in enumerate(((0, nl), (nl, nr))):
+                ang = np.array([float(np.float32(H.hh_torque_adjust(jp[rows[lo + j], b], je[rows[lo + j], b], gain[lo + j]))) for j in range(n)])
+                t, q = np.zeros(3), np.zeros(4)
+                H.hh_fk(n, (C.c_int * n)(*ty[lo:lo + n]), dp(np.ascontiguousarray(org[lo:lo + n])), dp(np.ascontiguousarray(ax[lo:lo + n])), dp(ang), dp(t), dp(q))
+                feet[7 * side:7 * side + 3, b], feet[7 * side + 3:7 * side + 7, b] = t, q
+        f64 = forces.astype(np.float64)
+        delta, status, prev = np.zeros((7, B)), np.zeros(B), np.zeros(B, dtype=np.int64)
+        H.hh_leg_update(dp(legd), ip(legi), C.c_long(B), B, C.c_int64(utime), dp(par), (C.c_int * 2)(-1, -1), dp(feet), dp(f64), dp(wq),
+                        dp(delta), dp(status), ip(prev))
+        od, os_, op = orc.update(utime, ofeet, f64, wq)
+        assert np.array_equal(status, os_) and np.array_equal(prev, op)
+        assert np.max(np.abs(delta[0:3] - od[0:3])) < 1e-13 and same_rotation(delta[3:7], od[3:7]) < 1e-13
+        seen.update(np.unique(status).tolist())
+    assert seen == {-1.0, 0.0, 1.0}
 
 
 @pytest.mark.gpu
@@ -151,7 +330,7 @@ def test_leg_odometry_kernel_feeds_the_filter_on_gpu(oracle, n):
     d_status = torch.zeros(B, dtype=torch.float64, device=dev)
     d_lo = torch.zeros((6, B), dtype=torch.float64, device=dev)
     d_mask = torch.zeros(B, dtype=torch.uint8, device=dev)
-    r, ru = 0.1, 0.5
+    r, ru = R_VXYZ
     n_upd = 0
     for k, (utime, feet, forces, _) in enumerate(gait(B, T, seed=9)):
         wq = np.ascontiguousarray(est.get_head()[1])  # setPoseBody: the head orientation BEFORE this tick's updates
@@ -206,7 +385,7 @@ def test_odometry_after_predict_and_split_step_equal_the_three_call_sequence(n, 
     seq, fus = ests
     outs = [[torch.zeros((7, B), dtype=torch.float64, device=dev), torch.zeros(B, dtype=torch.float64, device=dev),
              torch.zeros((6, B), dtype=torch.float64, device=dev), torch.zeros(B, dtype=torch.uint8, device=dev)] for _ in range(2)]
-    r, ru = 0.1, 0.5
+    r, ru = R_VXYZ
     n_upd = 0
     for k, (utime, feet, forces, _) in enumerate(gait(B, T, seed=3)):
         imu = w.imu_block(k)
@@ -231,5 +410,177 @@ def test_odometry_after_predict_and_split_step_equal_the_three_call_sequence(n, 
     from util import rel
     for x, y in zip(seq.get_head(), fus.get_head()):
         assert rel(x, y) < 1e-7
+    for e in ests:
+        e.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["atlas", "odd"])
+def test_forward_kinematics_kernel_on_gpu(oracle, which):
+    """pb_legodo_set_chain + pb_legodo_fk against the oracle's KDL restatement: per-filter device blocks, host blocks and one
+    robot's joint state for every filter (PB_HOST_BROADCAST), with and without the torque adjustment."""
+    import torch
+    import legs
+    from pronto_amd import batch as pa
+    B = 200
+    dev = torch.device("cuda:0")
+    L = oracle.lib()
+    left, right, rows = (legs.ATLAS_LEFT, legs.ATLAS_RIGHT, legs.ATLAS_ROWS) if which == "atlas" else (legs.ODD_LEFT, legs.ODD_RIGHT, legs.ODD_ROWS)
+    chain = legs.chain_arrays(left, right, rows)
+    nl, nr, ty, rows, org, ax = chain
+    gain = np.array([7000.0, np.inf, 10000.0, 0.0, 900.0, np.nan, 10000.0, 10000.0, 500.0, 10000.0, 10000.0, 10000.0][:nl + nr], dtype=np.float32)
+    est = pa.BatchEstimator(B, n_states=15)
+    rng = np.random.default_rng(3)
+    jp = rng.uniform(-1.5, 1.5, (legs.N_ROWS, B)).astype(np.float32)
+    je = (150 * rng.normal(size=(legs.N_ROWS, B))).astype(np.float32)
+    out = torch.zeros((14, B), dtype=torch.float64, device=dev)
+    for with_gain in (False, True):
+        est.legodo_set_chain(nl, nr, ty, rows, org, ax, gain if with_gain else None)
+        want = legs.oracle_feet(L, chain, jp, je if with_gain else None, gain if with_gain else None)
+        for kind in ("device", "host", "bcast"):
+            out.zero_()
+            if kind == "device":
+                est.legodo_fk(torch.from_numpy(jp).to(dev), torch.from_numpy(je).to(dev) if with_gain else None, out)
+            elif kind == "host":
+                est.legodo_fk(jp, je if with_gain else None, out)
+            else:
+                est.legodo_fk(np.ascontiguousarray(jp[:, 5]), np.ascontiguousarray(je[:, 5]) if with_gain else None, out)
+            got = out.cpu().numpy()
+            ref = want if kind != "bcast" else np.repeat(want[:, 5:6], B, axis=1)
+            for side in (0, 1):
+                assert np.max(np.abs(got[7 * side:7 * side + 3] - ref[7 * side:7 * side + 3])) < 2e-14, (kind, with_gain)
+                assert same_rotation(got[7 * side + 3:7 * side + 7], ref[7 * side + 3:7 * side + 7]) < 2e-15, (kind, with_gain)
+    with pytest.raises(pa.PbError):   # a block with fewer rows than the chain reads
+        est.legodo_fk(np.zeros((max(rows), B), dtype=np.float32), None, out)
+    est.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,mode", [(15, "alt"), (21, "alt"), (15, "standing"), (21, "ctrl")])
+def test_joint_state_odometry_feeds_the_filter_on_gpu(oracle, n, mode):
+    """The whole of leg_estimate::updateOdometry on the GPU from a joint state (pb_legodo_update_joints: torque adjustment,
+    forward kinematics, contact logic, pelvis integration), stage by stage on identical inputs against the oracle chain
+    po_torque_adjust -> po_fk -> po_leg_update (given the head orientation the kernel read on the device): statuses and masks
+    bit-identical, increments <= 1e-11, the lin_rate measurement, then pb_step_legodo fed that device block against the oracle
+    filter.  Modes: FootContactAlt, the "standing" FootContact classifier, controller contact counts overruling the foot."""
+    import torch
+    import legs
+    from pronto_amd import batch as pa
+    from util import embed21
+    B, T = 48, 300
+    dev = torch.device("cuda:0")
+    L = oracle.lib()
+    chain = legs.chain_arrays(legs.ATLAS_LEFT, legs.ATLAS_RIGHT, legs.ATLAS_ROWS)
+    nl, nr, ty, rows, org, ax = chain
+    gain = np.array([7000, 10000, 10000, 10000, 10000, 10000] * 2, dtype=np.float32)
+    w = Workload(B, n_states=n, dt_us=2000)
+    vec, quat, P0 = w.initial_state()
+    v21, P21 = embed21(vec, P0)
+    ob = oracle.OracleBatch(v21, quat, P21)
+    est = pa.BatchEstimator(B, n_states=n)
+    est.set_constants(*oracle.constants())
+    est.reset(vec, quat, P0)
+    est.legodo_init(*SCHMITT, True)
+    est.legodo_set_chain(nl, nr, ty, rows, org, ax, gain)
+    standing = STANDING if mode == "standing" else None
+    if mode != "alt":
+        est.legodo_set_contact_mode(standing is not None, *(standing or (0.0, 0.0)), use_controller_input=(mode == "ctrl"))
+    orc = OracleLegs(oracle, B, True, standing, mode == "ctrl")
+    q4 = w.process_noise()
+    d_delta = torch.zeros((7, B), dtype=torch.float64, device=dev)
+    d_status = torch.zeros(B, dtype=torch.float64, device=dev)
+    d_lo = torch.zeros((6, B), dtype=torch.float64, device=dev)
+    d_mask = torch.zeros(B, dtype=torch.uint8, device=dev)
+    d_pos = torch.zeros((3, B), dtype=torch.float64, device=dev)
+    d_pok = torch.zeros(B, dtype=torch.uint8, device=dev)
+    r, ru = R_VXYZ
+    n_upd = n_pos = 0
+    seen = set()
+    for k, (utime, jp, je, forces, _) in enumerate(legs.joint_gait(B, T, seed=9)):
+        nc = controller_contacts(k) if mode == "ctrl" else (-1, -1)
+        if mode == "ctrl" and k >= 50:
+            est.legodo_set_control_contacts(np.array(nc, dtype=np.int32))
+        head = est.get_head()
+        wq = np.ascontiguousarray(head[1])  # setPoseBody: the head pose BEFORE this tick's updates
+        wpos = np.ascontiguousarray(head[0][9:12])
+        if k % 2:
+            est.legodo_update_joints(utime, torch.from_numpy(jp).to(dev), torch.from_numpy(je).to(dev), torch.from_numpy(forces).to(dev), r, ru,
+                                     d_delta, d_status, d_lo, d_mask, position_out=d_pos, position_status_out=d_pok)
+        else:
+            est.legodo_update_joints(utime, jp, je, forces, r, ru, d_delta, d_status, d_lo, d_mask, position_out=d_pos, position_status_out=d_pok)
+        ofeet = legs.oracle_feet(L, chain, jp, je, gain)
+        od, os_, op = orc.update(utime, ofeet, forces.astype(np.float64), wq, nc, wpos)
+        valid = os_ >= 0
+        g_pok = d_pok.cpu().numpy().astype(bool)
+        assert np.array_equal(g_pok[valid], orc.pos_ok[valid]), k     # world_to_body_constraint_init_ (read only for a valid status)
+        both = valid & g_pok
+        assert np.max(np.abs(d_pos.cpu().numpy()[:, both] - orc.pos[:, both]), initial=0.0) < 1e-11, k
+        n_pos += int(both.sum())
+        g_delta, g_status = d_delta.cpu().numpy(), d_status.cpu().numpy()
+        assert np.array_equal(g_status, os_), k
+        assert np.max(np.abs(g_delta[0:3] - od[0:3])) < 1e-11 and same_rotation(g_delta[3:7], od[3:7]) < 1e-12, k
+        seen.update(np.unique(os_).tolist())
+        elapsed = (utime - op) * 1e-6
+        lo = np.zeros((6, B)); lo[0:3] = od[0:3] / elapsed; lo[3:6] = np.where(os_ >= 0.5, ru * ru, r * r)
+        mask = (os_ >= 0).astype(np.uint8)
+        g_lo, g_mask = d_lo.cpu().numpy(), d_mask.cpu().numpy()
+        assert np.array_equal(g_mask, mask), k
+        on = mask.astype(bool)
+        assert np.max(np.abs(g_lo[0:3, on] - lo[0:3, on]), initial=0.0) < 1e-8 and np.allclose(g_lo[3:6, on], lo[3:6, on], rtol=1e-14, atol=0), k
+        n_upd += int(on.sum())
+        imu = w.imu_block(k)
+        est.step_legodo(torch.from_numpy(imu).to(dev), d_lo, d_mask, q4)
+        ob.predict(imu, q4)
+        ob.update_indexed([3, 4, 5], np.ascontiguousarray(g_lo[0:3]), np.ascontiguousarray(g_lo[3:6]), mask=mask)
+    assert n_upd > B * T // 10 and seen == {-1.0, 0.0, 1.0} and n_pos > B * T // 20
+    from test_gpu_parity import check
+    check(est, ob)
+    pose, info = est.legodo_get(B - 1)
+    t, q, oi = orc.get(B - 1)
+    assert np.max(np.abs(pose[0:3] - t)) < 1e-10 and info[0] == oi[0] and info[1] == oi[1] and info[2] == oi[2]
+    est.close()
+
+
+@pytest.mark.gpu
+def test_broadcast_joint_state_equals_per_filter_blocks_on_gpu():
+    """One robot's joint state for every filter (kernel arguments, torque adjustment on the host) against the same message
+    replicated into per-filter device blocks: identical statuses, increments to rounding; also slaved to the orientation
+    after a pending IMU step (imu_block != NULL)."""
+    import torch
+    import legs
+    from pronto_amd import batch as pa
+    B, T = 130, 200
+    dev = torch.device("cuda:0")
+    chain = legs.chain_arrays(legs.ATLAS_LEFT, legs.ATLAS_RIGHT, legs.ATLAS_ROWS)
+    gain = np.array([7000, 10000, 10000, 10000, 10000, 10000] * 2, dtype=np.float32)
+    w = Workload(B, n_states=15, dt_us=2000)
+    vec, quat, P0 = w.initial_state()
+    q4 = w.process_noise()
+    ests = []
+    for _ in range(2):
+        e = pa.BatchEstimator(B, n_states=15)
+        e.reset(vec, quat, P0)
+        e.legodo_init(*SCHMITT, True)
+        e.legodo_set_chain(*chain, gain)
+        ests.append(e)
+    outs = [[torch.zeros((7, B), dtype=torch.float64, device=dev), torch.zeros(B, dtype=torch.float64, device=dev),
+             torch.zeros((6, B), dtype=torch.float64, device=dev), torch.zeros(B, dtype=torch.uint8, device=dev)] for _ in range(2)]
+    n_upd = 0
+    for k, (utime, jp, je, forces, _) in enumerate(legs.joint_gait(1, T, seed=6)):
+        imu = np.ascontiguousarray(w.imu_block(k)[:, 0])
+        rep = lambda a: torch.from_numpy(np.ascontiguousarray(np.repeat(a, B, axis=1))).to(dev)
+        ests[0].legodo_update_joints(utime, np.ascontiguousarray(jp[:, 0]), np.ascontiguousarray(je[:, 0]), np.ascontiguousarray(forces[:, 0]), *R_VXYZ,
+                                     *outs[0], after_predict=imu)
+        ests[1].legodo_update_joints(utime, rep(jp), rep(je), rep(forces), *R_VXYZ, *outs[1], after_predict=rep(imu[:, None]))
+        a, b = [o.cpu().numpy() for o in outs[0]], [o.cpu().numpy() for o in outs[1]]
+        assert np.array_equal(a[1], b[1]) and np.array_equal(a[3], b[3]), k
+        assert np.max(np.abs(a[0] - b[0])) < 1e-13 and np.max(np.abs(a[2] - b[2])) < 1e-10, k
+        n_upd += int(a[3].sum())
+        for e, o in zip(ests, outs):
+            e.step_legodo(imu, o[2], o[3], q4)
+    assert n_upd > B * T // 10
+    from util import rel
+    for x, y in zip(ests[0].get_head(), ests[1].get_head()):
+        assert rel(x, y) < 1e-9
     for e in ests:
         e.close()
