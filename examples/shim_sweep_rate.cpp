@@ -9,6 +9,10 @@
 //   g++ -std=c++17 -O2 -Iinclude -Ipronto_amd/csrc examples/shim_sweep_rate.cpp -Lpronto_amd/lib -lpronto_batch
 //       -Wl,-rpath,$PWD/pronto_amd/lib -o shim_sweep_rate
 //   ./shim_sweep_rate [filters=65536] [messages=2000] [n_states=15] [history_slots=0] [utime_history_span=1000000] [vo_every=0]
+//                     [input=feet|joints] [pairs=one|two]
+// input = joints: the log is a bot_core::joint_state_t stream and LegOdoHandler::processMessage(joint_state_t) runs the
+// forward kinematics per filter on the device too (the reference's own handler signature); pairs = two: the leg odometry as
+// its own launch in front of the fused step (round 2's path) instead of inside the step kernel.
 //
 // Prints messages/s and filter-steps/s (one step = IMU predict + leg-odometry update of one filter).
 #include <chrono>
@@ -44,6 +48,8 @@ int main(int argc, char **argv)
   const std::string slots = argc > 4 ? argv[4] : "0";
   const std::string span = argc > 5 ? argv[5] : "1000000";  // us of update history kept (update_history.cpp:28-39)
   const int vo_every = argc > 6 ? std::atoi(argv[6]) : 0;     // a visual-odometry delta every N-th pair (0 = none): config 3
+  const bool joints = argc > 7 && std::string(argv[7]) == "joints";
+  const bool two_launches = argc > 8 && std::string(argv[8]) == "two";
   BotParam param;
   param.set("state_estimator.utime_history_span", span);
   param.set("state_estimator.history_slots", slots);
@@ -61,7 +67,12 @@ int main(int argc, char **argv)
                        "state_estimator.legodo.r_vang=0.3|state_estimator.legodo.r_vxyz_uncertain=0.5|state_estimator.legodo.r_vang_uncertain=0.9|"
                        "state_estimator.legodo.schmitt_low_threshold=475|state_estimator.legodo.schmitt_high_threshold=525|"
                        "state_estimator.legodo.schmitt_low_delay=7000|state_estimator.legodo.schmitt_high_delay=7000|"
-                       "state_estimator.legodo.filter_contact_events=true|state_estimator.legodo.zero_initial_velocity=3");
+                       "state_estimator.legodo.filter_contact_events=true|state_estimator.legodo.zero_initial_velocity=3|"
+                       "state_estimator.legodo.initialization_mode=zero|state_estimator.legodo.filter_joint_positions=none|"
+                       "state_estimator.legodo.init_contact_mode=walking|state_estimator.legodo.total_force=1500|"
+                       "state_estimator.legodo.standing_schmitt_level=0.65|state_estimator.legodo.use_controller_input=false|"
+                       "state_estimator.legodo.torque_adjustment=true|state_estimator.legodo.adjustment_joints=l_leg_hpz,l_leg_kny,r_leg_hpz,r_leg_kny|"
+                       "state_estimator.legodo.adjustment_gain=7000,10000,7000,10000");
   param.applyOverrides("state_estimator.fovis.mode=position_orient|state_estimator.fovis.r_pxyz=0.02|state_estimator.fovis.r_chi=0.01");
   for (const char *s : { "ins", "legodo", "fovis" }) {
     param.set(std::string("state_estimator.") + s + ".downsample_factor", "1");
@@ -81,10 +92,29 @@ int main(int argc, char **argv)
   }
   BotTrans ins_to_body;
   InsHandler ins_handler(&param, &ins_to_body);
-  LegOdoHandler legodo_handler(&param);
+  // the robot model: two 6-DoF legs (hip yaw / roll / pitch, knee, ankle pitch / roll), what ModelClient::fromURDFString
+  // extracts from a URDF for the two standing links
+  ModelClient model;
+  const char *jn[6] = { "leg_hpz", "leg_hpx", "leg_hpy", "leg_kny", "leg_aky", "leg_akx" };
+  const double jo[6][3] = { { 0, 0.089, 0 }, { 0, 0, 0 }, { 0.05, 0.0225, -0.066 }, { -0.05, 0, -0.374 }, { 0, 0, -0.422 }, { 0, 0, 0 } };
+  const double ja[6][3] = { { 0, 0, 1 }, { 1, 0, 0 }, { 0, 1, 0 }, { 0, 1, 0 }, { 0, 1, 0 }, { 1, 0, 0 } };
+  std::vector<std::string> joint_names;
+  for (int side = 0; side < 2; side++)
+    for (int j = 0; j < 6; j++) {
+      ModelClient::Joint J;
+      J.name = std::string(side ? "r_" : "l_") + jn[j];
+      for (int i = 0; i < 3; i++) { J.xyz[i] = jo[j][i]; J.axis[i] = ja[j][i]; }
+      if (side) J.xyz[1] = -J.xyz[1];
+      (side ? model.right_chain : model.left_chain).push_back(J);
+      joint_names.push_back(J.name);
+    }
+  LegOdoHandler legodo_handler(&param, &model);
+  legodo_handler.one_kernel_pairs = !two_launches;
   FrontEnd front_end(&param);
   auto on_ins = front_end.addSensor("ins", &InsHandler::processMessage, &ins_handler);
   auto on_feet = front_end.addSensor("legodo", &LegOdoHandler::processMessageFeet, &legodo_handler);
+  RBISUpdateInterface *(LegOdoHandler::*joint_fn)(const msgs::joint_state_t *, MavStateEstimator *) = &LegOdoHandler::processMessage;
+  auto on_joints = front_end.addSensor("legodo", joint_fn, &legodo_handler);
   FovisHandler fovis_handler(&param, /*snapshot_slot=*/0);
   auto on_fovis = front_end.addSensor("fovis", &FovisHandler::processMessage, &fovis_handler);
   MavStateEstimator est(new RBISResetUpdate(x0, P0, RBISUpdateInterface::reset, 0), &param, 0);
@@ -94,6 +124,7 @@ int main(int argc, char **argv)
 
   // one robot's log: a walking gait (left / right foot poses in the body frame, vertical foot forces) and its IMU
   std::vector<double> imu(6 * (size_t) T), feet(14 * (size_t) T), forces(2 * (size_t) T);
+  std::vector<float> jpos(12 * (size_t) T), jeff(12 * (size_t) T);
   for (int k = 0; k < T; k++) {
     const double t = (k + 1) * 0.002;
     double ph = t / 1.1 + 0.3;
@@ -111,13 +142,33 @@ int main(int argc, char **argv)
     for (int i = 0; i < 4; i++) { f[3 + i] = ql[i]; f[10 + i] = qr[i]; }
     forces[2 * (size_t) k] = 900 * wl + 5 * nrand();
     forces[2 * (size_t) k + 1] = 900 * wr + 5 * nrand();
+    for (int side = 0; side < 2; side++) {
+      const double sgn = side ? -1.0 : 1.0, lift = std::fmax(0.0, -sgn * sw);
+      float *p = &jpos[12 * (size_t) k + 6 * side];
+      p[0] = (float) (0.05 * sgn * sw); p[1] = (float) (0.03 * sgn + 0.02 * sw); p[2] = (float) (-0.35 - sgn * 0.25 * sw - 0.2 * lift);
+      p[3] = (float) (0.7 + 0.5 * lift); p[4] = (float) (-0.35 + sgn * 0.125 * sw - 0.3 * lift); p[5] = (float) (-0.03 * sgn - 0.02 * sw);
+      for (int j = 0; j < 6; j++) jeff[12 * (size_t) k + 6 * side + j] = (float) (40 * nrand());
+    }
   }
+  msgs::joint_state_t js;
+  js.joint_name = joint_names;
+  js.mem = PB_HOST_BROADCAST;
   auto feed = [&](int k) {
     const int64_t utime = 1000000 + (int64_t) (k + 1) * 2000;
     msgs::ins_t im{ utime, BatchArray(&imu[6 * (size_t) k], PB_HOST_BROADCAST), BatchArray(&imu[6 * (size_t) k + 3], PB_HOST_BROADCAST) };
     on_ins(&im);
-    msgs::foot_state_t fs{ utime, BatchArray(&feet[14 * (size_t) k], PB_HOST_BROADCAST), BatchArray(&forces[2 * (size_t) k], PB_HOST_BROADCAST) };
-    on_feet(&fs);
+    if (joints) {
+      msgs::six_axis_force_torque_array_t ft{ utime, BatchArray(&forces[2 * (size_t) k], PB_HOST_BROADCAST) };
+      legodo_handler.forceTorqueHandler(&ft, B);
+      js.utime = utime;
+      js.joint_position = &jpos[12 * (size_t) k];
+      js.joint_effort = &jeff[12 * (size_t) k];
+      on_joints(&js);
+    } else {
+      msgs::foot_state_t fs{ utime, BatchArray(&feet[14 * (size_t) k], PB_HOST_BROADCAST), BatchArray(&forces[2 * (size_t) k], PB_HOST_BROADCAST) };
+      legodo_handler.forceTorqueHandler();
+      on_feet(&fs);
+    }
     if (vo_every > 0 && k % vo_every == vo_every - 1) {  // one camera's delta since the last keyframe, for every filter
       const double vt[3] = { 0.004 * std::sin(0.01 * k), 0.002, -0.001 * std::cos(0.02 * k) };
       double vq[4];
@@ -142,8 +193,11 @@ int main(int argc, char **argv)
   bool finite = true;
   for (int b = 0; b < B; b++)
     for (int i = 0; i < n; i++) { sum += std::fabs(head(i, b)); finite = finite && std::isfinite(head(i, b)); }
-  std::printf("shim sweep: %d filters x %d message pairs (n=%d, history_slots=%s%s): %.1f us per IMU + foot-state pair, "
-              "%.3e filter-steps/s, dropped %lld, checksum %.6g %s\n", B, T - warm, n, slots.c_str(), vo_every > 0 ? (", VO every " + std::to_string(vo_every)).c_str() : "", dt / (T - warm) * 1e6,
-              (double) B * (T - warm) / dt, (long long) est.dropped_updates, sum, finite ? "finite" : "NON-FINITE");
+  std::printf("shim sweep: %d filters x %d message pairs (n=%d, history_slots=%s%s, %s, %s): %.1f us per IMU + %s pair, "
+              "%.3e filter-steps/s, one-kernel pairs %lld of %lld fused, dropped %lld, checksum %.6g %s\n", B, T - warm, n, slots.c_str(),
+              vo_every > 0 ? (", VO every " + std::to_string(vo_every)).c_str() : "", joints ? "joint-state log" : "foot-state log",
+              two_launches ? "odometry as its own launch" : "odometry inside the step kernel", dt / (T - warm) * 1e6, joints ? "joint-state" : "foot-state",
+              (double) B * (T - warm) / dt, (long long) est.leg_kernel_pairs, (long long) est.fused_pairs, (long long) est.dropped_updates, sum,
+              finite ? "finite" : "NON-FINITE");
   return finite ? 0 : 1;
 }

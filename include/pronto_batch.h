@@ -88,8 +88,10 @@ int pb_use_own_stream(pb_ctx *ctx);
 int pb_set_constants(pb_ctx *ctx, double g, double chi_tol);
 int pb_sync(pb_ctx *ctx);
 /* name (as rocprofv3 prints it, without the pb:: prefix) of the kernel pb_step_legodo / pb_run_legodo launch for
- * this context: "k_step<15,true,H>", "k_step_coop<15,true,H>" or "k_step_coop<21,true,H>"; H = 0/1/2 is the cache
- * policy of the state round trip the library picked from the state size (default / sc1 stores / non-temporal) */
+ * this context: "k_step_coop<15,true,H>" (15 states, two waves per tile, up to 393 216 filters), "k_step<15,true,H>"
+ * (15 states, one lane per filter, beyond that), "k_step_quad<true,H>" (21 states, four waves per tile) or
+ * "k_step_coop<21,true,H>" (21 states with PRONTO_BATCH_QUAD21=0); H = 0/1/2 is the cache policy of the state round trip
+ * the library picked from the state size (default / sc1 stores / non-temporal) */
 const char *pb_hot_kernel(const pb_ctx *ctx);
 int pb_batch(const pb_ctx *ctx);
 int pb_n_states(const pb_ctx *ctx);
@@ -257,6 +259,20 @@ int pb_legodo_update_joints(pb_ctx *ctx, const double *imu_block, int imu_mem, i
                             const float *joint_position, const float *joint_effort, const float *forces, int mem, int zero_delta,
                             double r_vxyz, double r_vxyz_uncertain, double *delta_out, double *status_out, double *lo_block_out,
                             uint8_t *mask_out, double *position_out, uint8_t *position_status_out);
+/* ONE call per IMU + joint-state (or foot-state) message pair -- RBISIMUProcessStep::updateFilter, leg_estimate::updateOdometry
+ * slaved to the head AFTER that step, LegOdoCommon::createMeasurement (lin_rate) and RBISIndexedMeasurement::updateFilter
+ * (rbis_update_interface.cpp:30-95, rbis_legodo_update.cpp:206-280) -- and, for 15 states up to 393 216 filters, ONE kernel
+ * and one round trip of the filter state (k_step_leg); other contexts run pb_legodo_update_joints(imu_block, ...) followed by
+ * pb_step_legodo_split internally.  Results equal that two-call sequence (tests: bit-identical statuses, posterior to
+ * rounding).  imu_block / imu_mem and q as pb_step_legodo; the leg inputs as pb_legodo_update_joints / pb_legodo_update; not
+ * both groups PB_HOST.  lo_block_out [6][B] + mask_out [B] (DEVICE, or both NULL): the measurement that was applied, for a
+ * caller that may have to re-apply this update later (history replay) -- the odometry itself must not run twice. */
+int pb_step_legodo_joints(pb_ctx *ctx, const double *imu_block, int imu_mem, const double q[4], int64_t utime, int n_rows,
+                          const float *joint_position, const float *joint_effort, const float *forces, int mem, double r_vxyz,
+                          double r_vxyz_uncertain, double *lo_block_out, uint8_t *mask_out);
+int pb_step_legodo_feet(pb_ctx *ctx, const double *imu_block, int imu_mem, const double q[4], int64_t utime, const double *feet,
+                        const double *forces, int mem, double r_vxyz, double r_vxyz_uncertain, double *lo_block_out,
+                        uint8_t *mask_out);
 /* forward kinematics alone (diagnostics, tests): feet_out [14][B] DEVICE array in pb_legodo_update's layout */
 int pb_legodo_fk(pb_ctx *ctx, int n_rows, const float *joint_position, const float *joint_effort, int mem, double *feet_out);
 /* one filter's odometry state, for diagnostics and tests: odom_to_body (t3, q4); info = primary_foot (0 left, 1 right),
@@ -315,10 +331,18 @@ int pb_get_filter_state(pb_ctx *ctx, int filter, double quat[4], double state[21
  * out[0] = sum loglik, out[1] = sum |vec| + |quat| (checksum), out[2] = max | |quat|^2 - 1 |,
  * out[3] = number of non-finite state entries. */
 int pb_summary(pb_ctx *ctx, double out[4]);
-/* Measurement aid (not on the reference path): `reps` plain copies of the whole state array with k_step's exact
- * access pattern (8 bytes/lane buffer loads and stores), to calibrate rocprofv3's FETCH_SIZE / WRITE_SIZE on a
- * known byte count and to measure this box's achievable copy rate.  elapsed_ms = HIP-event time of the reps. */
+/* Bit-level checksum of the whole device state (every component of every filter, padding lanes of the last tile included):
+ * out[0] a weighted wrapping sum, out[1] a xor of rotated words; slot < 0 = the head, else a checkpoint slot.  Two runs of
+ * the same context over the same inputs must give the same pair (tests: replay identity over thousands of launches);
+ * one pass over the state, ~15 us at 64k filters. */
+int pb_state_checksum(pb_ctx *ctx, int slot, uint64_t out[2]);
+/* Measurement aid (not on the reference path): `reps` plain copies of the whole state array with the step kernels' exact
+ * access pattern (one tile row = 64 lanes x 16 bytes per buffer_load / buffer_store_dwordx4), to calibrate rocprofv3's
+ * FETCH_SIZE / WRITE_SIZE on a known byte count and to measure this box's achievable copy rate.  elapsed_ms = HIP-event
+ * time of the reps.  pb_calib_copy_checksum: the same copies, then pb_state_checksum's pair OF THE COPY (must equal the
+ * head's: the regression test of the 16-byte store path, tests/test_gpu_edge_cases.py). */
 int pb_calib_copy(pb_ctx *ctx, int reps, float *elapsed_ms);
+int pb_calib_copy_checksum(pb_ctx *ctx, int reps, uint64_t out[2]);
 /* head utime bookkeeping (posterior_state.utime = update->utime, mav_state_est.cpp:60) */
 int pb_set_utime(pb_ctx *ctx, int64_t utime);
 int64_t pb_get_utime(const pb_ctx *ctx);

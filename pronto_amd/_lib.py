@@ -21,7 +21,7 @@ PB_CORR_POS_ORIENT, PB_CORR_POS_YAW = 0, 1
 
 def sources():
     return [os.path.join(CSRC, f) for f in ("pronto_batch.hip", "pb_step.hip", "pb_update.hip", "pb_update_ct.hip", "pb_smooth.hip", "pb_ctx.hpp",
-                                            "rbis_kernels.hpp", "rbis_legodo.hpp", "rbis_coop.hpp", "rbis_quad.hpp", "rbis_smooth.hpp",
+                                            "rbis_kernels.hpp", "rbis_legodo.hpp", "rbis_legstep.hpp", "rbis_coop.hpp", "rbis_quad.hpp", "rbis_smooth.hpp",
                                             "rbis_device.hpp", "Makefile")] + [HEADER]
 
 
@@ -87,6 +87,11 @@ _SIGS = {
                                           C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_void_p]),
     "pb_legodo_set_zero_initial_velocity": (C.c_int, [C.c_void_p, C.c_int]),
+    "pb_step_legodo_joints": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, _dp, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                        C.c_double, C.c_double, C.c_void_p, C.c_void_p]),
+    "pb_step_legodo_feet": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, _dp, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_double,
+                                      C.c_double, C.c_void_p, C.c_void_p]),
+    "pb_calib_copy_checksum": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_uint64)]),
     "pb_legodo_fk": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "pb_legodo_get": (C.c_int, [C.c_void_p, C.c_int, _dp, C.POINTER(C.c_int64)]),
     "pb_imu_notch_init": (C.c_int, [C.c_void_p, C.c_double, C.c_double]),
@@ -103,6 +108,7 @@ _SIGS = {
     "pb_get_head": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "pb_get_filter_state": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _dp]),
     "pb_summary": (C.c_int, [C.c_void_p, _dp]),
+    "pb_state_checksum": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_uint64)]),
     "pb_calib_copy": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float)]),
     "pb_set_utime": (C.c_int, [C.c_void_p, C.c_int64]),
     "pb_get_utime": (C.c_int64, [C.c_void_p]),

@@ -232,6 +232,34 @@ class BatchEstimator:
         self._chk(self._L.pb_legodo_update_joints(self._h, pi, mi, int(utime), rows, pj, pe, pz, _same_mem(m1, m2, m3),
                                                   int(bool(zero_delta)), r_vxyz, r_vxyz_uncertain, *outs))
 
+    def step_legodo_joints(self, imu_block, q4, utime, joint_position, joint_effort, forces, r_vxyz, r_vxyz_uncertain, lo_out=None,
+                           mask_out=None):
+        """One call (one kernel where the context has it) per IMU + joint-state pair: pb_step_legodo_joints."""
+        pi, mi = _ptr_block(imu_block, 7, self.B)
+        rows = joint_position.shape[0]
+        pj, m1 = _ptr_block(joint_position, rows, self.B, dtype=np.float32)
+        pe, m2 = (None, None) if joint_effort is None else _ptr_block(joint_effort, rows, self.B, dtype=np.float32)
+        pz, m3 = _ptr_block(forces, 2, self.B, dtype=np.float32)
+        pl, _ = _ptr(lo_out, shape=(6, self.B))
+        pm, _ = _ptr(mask_out, np.uint8, shape=(self.B,))
+        q = (C.c_double * 4)(*q4)
+        self._chk(self._L.pb_step_legodo_joints(self._h, pi, mi, q, int(utime), rows, pj, pe, pz, _same_mem(m1, m2, m3), r_vxyz,
+                                                r_vxyz_uncertain, pl, pm))
+
+    def step_legodo_feet(self, imu_block, q4, utime, feet, forces, r_vxyz, r_vxyz_uncertain, lo_out=None, mask_out=None):
+        pi, mi = _ptr_block(imu_block, 7, self.B)
+        pf, m1 = _ptr_block(feet, 14, self.B)
+        pz, m2 = _ptr_block(forces, 2, self.B)
+        pl, _ = _ptr(lo_out, shape=(6, self.B))
+        pm, _ = _ptr(mask_out, np.uint8, shape=(self.B,))
+        q = (C.c_double * 4)(*q4)
+        self._chk(self._L.pb_step_legodo_feet(self._h, pi, mi, q, int(utime), pf, pz, _same_mem(m1, m2), r_vxyz, r_vxyz_uncertain, pl, pm))
+
+    def calib_copy_checksum(self, reps=1):
+        out = (C.c_uint64 * 2)()
+        self._chk(self._L.pb_calib_copy_checksum(self._h, int(reps), out))
+        return int(out[0]), int(out[1])
+
     def legodo_fk(self, joint_position, joint_effort, feet_out):
         rows = joint_position.shape[0]
         pj, m1 = _ptr_block(joint_position, rows, self.B, dtype=np.float32)
@@ -399,6 +427,12 @@ class BatchEstimator:
         ms = C.c_float(0)
         self._chk(self._L.pb_calib_copy(self._h, reps, C.byref(ms)))
         return ms.value
+
+    def state_checksum(self, slot=-1):
+        """(sum, xor) over every 64-bit word of the device state (slot < 0: the head)."""
+        out = (C.c_uint64 * 2)()
+        self._chk(self._L.pb_state_checksum(self._h, int(slot), out))
+        return int(out[0]), int(out[1])
 
     def summary(self):
         out = (C.c_double * 4)()

@@ -280,6 +280,13 @@ public:
   const double *measurement_cov;    // per r_kind
   int r_kind, cov_mem;
   const uint8_t *mask = nullptr;    // [B]; 0 = this filter's handler returned NULL (lcm_front_end.hpp:156)
+  // A measurement that is still to be MADE on the device from the head state (leg kinematic odometry, LegOdoHandler): either
+  // together with the INS step in front of it -- pair_kernel: that step, the odometry slaved to the state after it and this
+  // update in ONE kernel (pb_step_legodo_joints / _feet; keep = write the measurement block out for later re-applications) --
+  // or on its own right before this update is applied (make_measurement).  Whichever runs first clears both: the odometry
+  // advances once, a history replay re-applies the measurement it left in `measurement` / `mask`.
+  std::function<int(pb_ctx *, const RBISIMUProcessStep *, bool keep)> pair_kernel;
+  std::function<int(pb_ctx *)> make_measurement;
   RBISIndexedMeasurement(const std::vector<int> &index_, BatchArray measurement_, const double *measurement_cov_,
                          int r_kind_, const uint8_t *mask_, sensor_enum sensor_id_, int64_t utime)
       : RBISUpdateInterface(sensor_id_, utime), index(index_), measurement(measurement_),
@@ -292,6 +299,12 @@ public:
         r_kind(r_kind_), cov_mem(PB_HOST), mask(owned_mask.empty() ? nullptr : owned_mask.data()) {}
   int updateFilter(pb_ctx *ctx) override
   {
+    if (make_measurement) {
+      const int rc = make_measurement(ctx);
+      make_measurement = nullptr;
+      pair_kernel = nullptr;
+      if (rc != PB_OK) return rc;
+    }
     return pb_update_indexed(ctx, (int) index.size(), index.data(), measurement.p, measurement_cov, r_kind, mask,
                              measurement.mem);
   }
@@ -394,6 +407,7 @@ public:
   // (pb_step_legodo_correct; reference seam: rbis_fovis_update.cpp:299-305, sensor_handlers.cpp:709-722).
   bool fuse_corrections = false;
   int64_t fused_triples = 0;
+  int64_t leg_kernel_pairs = 0;  // fused pairs whose leg odometry ran inside the step kernel (pb_step_legodo_joints / _feet)
 
   MavStateEstimator(RBISResetUpdate *init_state, BotParam *param, int device = 0, int n_snapshots = 2)
   {
@@ -746,6 +760,13 @@ private:
     auto *m = dynamic_cast<RBISIndexedMeasurement *>(next);
     if (m == nullptr || m->index != RBIS::velocityInds()) return false;
     const double q[4] = { imu->q_gyro, imu->q_accel, imu->q_gyro_bias, imu->q_accel_bias };
+    if (m->pair_kernel) {  // the measurement is made inside the step kernel (leg odometry): one launch for the message pair
+      rc = m->pair_kernel(ctx, imu, history_slots > 0);
+      m->pair_kernel = nullptr;
+      m->make_measurement = nullptr;
+      leg_kernel_pairs++;
+      return true;
+    }
     if (device_lo_block(m)) {  // IMU block from the host (broadcast or per filter), measurement on the device
       rc = pb_step_legodo_split(ctx, imu->imu_block.p, imu->imu_block.mem, m->measurement.p, m->mask, PB_DEVICE, q);
       return true;
@@ -1664,17 +1685,51 @@ public:
     chain_ready_ = true;
   }
 
-  // what both device-side entry points share: the pending-IMU decision, the odometry launch (`launch` gets the IMU block to
-  // run ahead of, or NULL, and the output pointers) and the measurement LegOdoCommon forms from its result
-  template <class LAUNCH>
-  RBISUpdateInterface *odometryUpdate(MavStateEstimator *est, int64_t utime, int input_mem, LAUNCH &&launch)
+  // one message's leg inputs, kept alive by the update made from them: broadcast values are copied (they are a few dozen
+  // numbers), device arrays are referenced (the caller keeps them, as everywhere), host blocks are used before the handler
+  // returns
+  struct LegMsg {
+    int kind = 0, mem = PB_HOST, rows = 0;       // kind 0: foot poses, 1: joint state
+    int64_t utime = 0;
+    const float *jp = nullptr, *je = nullptr, *ff = nullptr;
+    const double *feet = nullptr, *forces = nullptr;
+    std::vector<float> own_f;
+    std::vector<double> own_d;
+    double r = 0, ru = 0;
+    // odometry alone (imu == NULL) or slaved to the state after `imu`; outputs as pb_legodo_update_joints
+    int odometry(pb_ctx *ctx, const BatchArray *imu, double *o_delta, double *o_status, double *d_lo, uint8_t *d_mask, double *o_pos,
+                 uint8_t *o_pos_ok) const
+    {
+      if (kind == 1)
+        return pb_legodo_update_joints(ctx, imu ? imu->p : nullptr, imu ? imu->mem : PB_DEVICE, utime, rows, jp, je, ff, mem, 0, r, ru, o_delta,
+                                       o_status, d_lo, d_mask, o_pos, o_pos_ok);
+      return imu ? pb_legodo_update_after_predict(ctx, imu->p, imu->mem, utime, feet, forces, mem, 0, r, ru, o_delta, o_status, d_lo, d_mask)
+                 : pb_legodo_update(ctx, utime, feet, forces, mem, 0, r, ru, o_delta, o_status, d_lo, d_mask);
+    }
+    // INS step + odometry + update in one call (one kernel where the library has it)
+    int pair(pb_ctx *ctx, const RBISIMUProcessStep *imu, double *d_lo, uint8_t *d_mask) const
+    {
+      const double q[4] = { imu->q_gyro, imu->q_accel, imu->q_gyro_bias, imu->q_accel_bias };
+      if (kind == 1)
+        return pb_step_legodo_joints(ctx, imu->imu_block.p, imu->imu_block.mem, q, utime, rows, jp, je, ff, mem, r, ru, d_lo, d_mask);
+      return pb_step_legodo_feet(ctx, imu->imu_block.p, imu->imu_block.mem, q, utime, feet, forces, mem, r, ru, d_lo, d_mask);
+    }
+  };
+
+  // what the device-side entry points share: the pending-IMU decision, the odometry and the measurement LegOdoCommon forms
+  // from its result
+  RBISUpdateInterface *odometryUpdate(MavStateEstimator *est, std::shared_ptr<LegMsg> lm)
   {
     const int B = est->B;
+    const int64_t utime = lm->utime;
+    const LegOdoCommon *lc = leg_odo_common_;
+    lm->r = lc->R_legodo_vxyz_;
+    lm->ru = lc->R_legodo_vxyz_uncertain_;
     // The odometry reads the head pose.  An INS step that fuse_ins_legodo is holding back is either applied first, or -- when
-    // the measurement made here will pair with it (mode lin_rate) -- left pending: the device then slaves the odometry to the
-    // pose "after that step" and the pair runs as one fused kernel.
-    RBISIMUProcessStep *ahead = (leg_odo_common_->mode_ == LegOdoCommon::MODE_LIN_RATE) ? est->pendingImu() : nullptr;
-    if (ahead != nullptr && ahead->imu_block.mem == PB_HOST && input_mem == PB_HOST) ahead = nullptr;  // one host staging area
+    // the measurement made here will pair with it (mode lin_rate) -- left pending: the pair then runs as ONE kernel that does
+    // the INS step, the odometry slaved to the pose after it and the update (pb_step_legodo_joints / _feet).
+    RBISIMUProcessStep *ahead = (lc->mode_ == LegOdoCommon::MODE_LIN_RATE) ? est->pendingImu() : nullptr;
+    if (ahead != nullptr && ahead->imu_block.mem == PB_HOST && lm->mem == PB_HOST) ahead = nullptr;  // one host staging area
     if (ahead == nullptr) est->flushPending();
     if (!legodo_ready_) initLegEstimate(est);
     if (control_contacts_dirty_) {
@@ -1690,19 +1745,28 @@ public:
     auto block = std::make_shared<DeviceBlock>(pool_, blk);
     double *d_lo = (double *) blk, *d_delta = d_lo + (size_t) 6 * B, *d_status = d_delta + (size_t) 7 * B, *d_pos = d_status + (size_t) B;
     uint8_t *d_mask = (uint8_t *) (d_pos + (size_t) 3 * B), *d_pos_ok = d_mask + (size_t) B;
-    const LegOdoCommon *lc = leg_odo_common_;
     // (mode lin_rate consumes the measurement block and the mask only: the increment and the status are not written out)
     const bool lin = lc->mode_ == LegOdoCommon::MODE_LIN_RATE, want_pos = lc->mode_ == LegOdoCommon::MODE_POSITION_AND_LIN_RATE;
-    const int lrc = launch(ahead, lin ? nullptr : d_delta, lin ? nullptr : d_status, d_lo, d_mask, want_pos ? d_pos : nullptr,
-                           want_pos ? d_pos_ok : nullptr);
-    if (lrc != PB_OK) {
-      fprintf(stderr, "LegOdoHandler: %s\n", pb_last_error(est->ctx));
-      return nullptr;
+    // the measurement can be made later, inside the step kernel, when its inputs outlive this call
+    const bool defer = ahead != nullptr && one_kernel_pairs && lm->mem != PB_HOST;
+    if (!defer) {
+      const int lrc = lm->odometry(est->ctx, ahead ? &ahead->imu_block : nullptr, lin ? nullptr : d_delta, lin ? nullptr : d_status, d_lo, d_mask,
+                                   want_pos ? d_pos : nullptr, want_pos ? d_pos_ok : nullptr);
+      if (lrc != PB_OK) {
+        fprintf(stderr, "LegOdoHandler: %s\n", pb_last_error(est->ctx));
+        return nullptr;
+      }
     }
     if (lin) {
       auto *u = new RBISIndexedMeasurement(RBIS::velocityInds(), BatchArray(d_lo, PB_DEVICE), d_lo + (size_t) 3 * B, PB_R_DIAG, d_mask,
                                            RBISUpdateInterface::legodo, utime);
       u->owned_dev = block;
+      if (defer) {
+        u->pair_kernel = [lm, d_lo, d_mask](pb_ctx *ctx, const RBISIMUProcessStep *imu, bool keep) {
+          return lm->pair(ctx, imu, keep ? d_lo : nullptr, keep ? d_mask : nullptr);
+        };
+        u->make_measurement = [lm, d_lo, d_mask](pb_ctx *ctx) { return lm->odometry(ctx, nullptr, nullptr, nullptr, d_lo, d_mask, nullptr, nullptr); };
+      }
       return u;
     }
     // the other modes form their measurement on the host: fetch the increment, the status (and the position)
@@ -1727,6 +1791,8 @@ public:
     return leg_odo_common_->createMeasurement(&m2, B);
   }
   int64_t prev_legodo_utime_ = 0;
+  // false: always make the measurement in the handler (k_legodo), then the fused step reads it -- round 2's two launches
+  bool one_kernel_pairs = true;
 
   // the reference's handler (rbis_legodo_update.cpp:206-280)
   RBISUpdateInterface *processMessage(const msgs::joint_state_t *msg, MavStateEstimator *est)
@@ -1747,15 +1813,25 @@ public:
       fprintf(stderr, "LegOdoHandler: the joint state and the force/torque message must live in the same memory space\n");
       return nullptr;
     }
-    const int rows = (int) msg->joint_name.size();
-    const LegOdoCommon *lc = leg_odo_common_;
-    return odometryUpdate(est, msg->utime, msg->mem,
-                          [&](RBISIMUProcessStep *ahead, double *o_delta, double *o_status, double *d_lo, uint8_t *d_mask, double *o_pos, uint8_t *o_pos_ok) {
-                            return pb_legodo_update_joints(est->ctx, ahead ? ahead->imu_block.p : nullptr, ahead ? ahead->imu_block.mem : PB_DEVICE,
-                                                           msg->utime, rows, msg->joint_position, use_torque_adjustment_ ? msg->joint_effort : nullptr,
-                                                           forces, msg->mem, 0, lc->R_legodo_vxyz_, lc->R_legodo_vxyz_uncertain_, o_delta, o_status,
-                                                           d_lo, d_mask, o_pos, o_pos_ok);
-                          });
+    auto lm = std::make_shared<LegMsg>();
+    lm->kind = 1;
+    lm->mem = msg->mem;
+    lm->rows = (int) msg->joint_name.size();
+    lm->utime = msg->utime;
+    const float *eff = use_torque_adjustment_ ? msg->joint_effort : nullptr;
+    if (msg->mem == PB_HOST_BROADCAST) {  // one robot's message: own the few numbers
+      lm->own_f.assign(msg->joint_position, msg->joint_position + lm->rows);
+      if (eff) lm->own_f.insert(lm->own_f.end(), eff, eff + lm->rows);
+      lm->own_f.insert(lm->own_f.end(), forces, forces + 2);
+      lm->jp = lm->own_f.data();
+      lm->je = eff ? lm->own_f.data() + lm->rows : nullptr;
+      lm->ff = lm->own_f.data() + (eff ? 2 : 1) * (size_t) lm->rows;
+    } else {
+      lm->jp = msg->joint_position;
+      lm->je = eff;
+      lm->ff = forces;
+    }
+    return odometryUpdate(est, lm);
   }
 
   // the same from what forward kinematics produces (msgs::foot_state_t); no pelvis position: mode pos_and_lin_rate falls back
@@ -1766,15 +1842,20 @@ public:
       fprintf(stdout, "Force/Torque message not received yet, not integrating leg odometry =========================\n");
       return nullptr;
     }
-    const LegOdoCommon *lc = leg_odo_common_;
-    return odometryUpdate(est, msg->utime, msg->feet.mem,
-                          [&](RBISIMUProcessStep *ahead, double *o_delta, double *o_status, double *d_lo, uint8_t *d_mask, double *, uint8_t *) {
-                            return ahead ? pb_legodo_update_after_predict(est->ctx, ahead->imu_block.p, ahead->imu_block.mem, msg->utime, msg->feet.p,
-                                                                          msg->forces.p, msg->feet.mem, 0, lc->R_legodo_vxyz_,
-                                                                          lc->R_legodo_vxyz_uncertain_, o_delta, o_status, d_lo, d_mask)
-                                         : pb_legodo_update(est->ctx, msg->utime, msg->feet.p, msg->forces.p, msg->feet.mem, 0, lc->R_legodo_vxyz_,
-                                                            lc->R_legodo_vxyz_uncertain_, o_delta, o_status, d_lo, d_mask);
-                          });
+    auto lm = std::make_shared<LegMsg>();
+    lm->kind = 0;
+    lm->mem = msg->feet.mem;
+    lm->utime = msg->utime;
+    if (msg->feet.mem == PB_HOST_BROADCAST) {
+      lm->own_d.assign(msg->feet.p, msg->feet.p + 14);
+      lm->own_d.insert(lm->own_d.end(), msg->forces.p, msg->forces.p + 2);
+      lm->feet = lm->own_d.data();
+      lm->forces = lm->own_d.data() + 14;
+    } else {
+      lm->feet = msg->feet.p;
+      lm->forces = msg->forces.p;
+    }
+    return odometryUpdate(est, lm);
   }
 
   // from a finished increment (a caller that runs its own leg_estimate): createMeasurement and the handler's gates

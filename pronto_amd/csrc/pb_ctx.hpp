@@ -13,6 +13,7 @@
 #include "../../include/pronto_batch.h"
 #include "rbis_kernels.hpp"
 #include "rbis_legodo.hpp"
+#include "rbis_legstep.hpp"
 
 using namespace pb;
 
@@ -36,6 +37,7 @@ struct pb_ctx {
   int32_t *leg_nc = nullptr;      // controller contact counts [2][B] (pb_legodo_set_control_contacts), used when leg_nc_dev
   int leg_nc_h[2] = { -1, -1 };   // ... or ONE pair for every filter (-1: none received yet)
   bool leg_nc_dev = false;
+  double *leg_lo = nullptr;       // measurement block + mask between the two kernels of pb_step_legodo_joints' fallback path
   double *notch = nullptr;  // IMU notch cascade state [36][stride] (pb_imu_notch_init)
   NotchCoef notch_coef;
   bool notch_ready = false;
@@ -104,6 +106,10 @@ inline void update_done(pb_ctx *c, double *target)
 // pb_step.hip: predict (update = false) or predict + leg-odometry update on the kernel pb_create picked
 int pbk_step(pb_ctx *c, bool update, const double *imu, const double *lo, const uint8_t *mask, const double q[4],
              const StepBcast *bcast = nullptr);  // bcast: one message for every filter, as kernel arguments
+// IMU step + leg odometry (from `lin`) + its lin_rate update in ONE kernel; -1 = this context has no such kernel (run
+// pb_legodo_update* ahead of pbk_step instead)
+int pbk_step_leg(pb_ctx *c, const double *imu, const StepBcast *bcast, const double q[4], const LegIn &lin, int64_t utime, double r2,
+                 double r2_uncertain, double *lo_out, uint8_t *mask_out);
 int pbk_replay_fused(pb_ctx *c, int T, const double *imu, const double *lo, const uint8_t *mask, const double q[4]);
 // predict + leg-odometry update + a second (orientation) update in one state round trip; corr_kind = enum pb_corr
 int pbk_step_correct(pb_ctx *c, int corr_kind, const double *imu, const double *lo, const uint8_t *mask, const double q[4],

@@ -42,6 +42,38 @@ int pbk_step(pb_ctx *c, bool update, const double *imu, const double *lo, const 
   return update ? launch_step<true>(c, imu, lo, mask, q, bc) : launch_step<false>(c, imu, nullptr, nullptr, q, bc);
 }
 
+template <int MH>
+static void launch_step_leg(pb_ctx *c, double *out, const double *imu, const double q[4], const StepBcast &bc, const LegIn &lin,
+                            const LegStepArgs &la)
+{
+  if (c->ns == 15)
+    k_step_leg<15, MH><<<nblk(c->B), 128, 0, c->stream>>>(c->st, out, c->B, imu, q[0], q[1], q[2], q[3], c->k, bc, c->leg_par, lin, la);
+  else
+    k_step_quad_leg<MH><<<nblk(c->B), 256, 0, c->stream>>>(c->st, out, c->B, imu, q[0], q[1], q[2], q[3], c->k, bc, c->leg_par, lin, la);
+}
+
+int pbk_step_leg(pb_ctx *c, const double *imu, const StepBcast *bcast, const double q[4], const LegIn &lin, int64_t utime, double r2,
+                 double r2_uncertain, double *lo_out, uint8_t *mask_out)
+{
+  // the two-wave 15-state mapping (the default up to 393 216 filters) and the four-wave 21-state mapping; the world
+  // constraint needs the stand-alone kernel
+  if ((c->ns == 15 && !c->coop15) || (c->ns == 21 && !c->quad21) || c->leg_par.world_constraint) return -1;
+  // 21 states with PER-FILTER joint blocks: the forward kinematics in front of barrier A makes role PW the wave the other three
+  // wait for (60.8 us at 64k filters against 52.2 us for the odometry kernel followed by the fused step): two launches
+  if (c->ns == 21 && lin.kind == 1) return -1;
+  const StepBcast bc = bcast ? *bcast : StepBcast();
+  LegStepArgs la{ c->legd, c->legi, c->stride, utime, r2, r2_uncertain, lo_out, mask_out };
+  double *out = update_target(c);
+  switch (c->mem_hint) {
+  case MH_STORE_SC1: launch_step_leg<MH_STORE_SC1>(c, out, imu, q, bc, lin, la); break;
+  case MH_STREAM_NT: launch_step_leg<MH_STREAM_NT>(c, out, imu, q, bc, lin, la); break;
+  default: launch_step_leg<MH_DEFAULT>(c, out, imu, q, bc, lin, la); break;
+  }
+  LAUNCHCHK(c);
+  update_done(c, out);
+  return PB_OK;
+}
+
 int pbk_replay_fused(pb_ctx *c, int T, const double *imu, const double *lo, const uint8_t *mask, const double q[4])
 {
   // PRONTO_BATCH_REPLAY_ONELANE=1: the first, one-lane-per-filter version (15 states only; A/B runs)

@@ -115,6 +115,7 @@ extern "C" int pb_destroy(pb_ctx *c)
   if (c->legi) (void) hipFree(c->legi);
   if (c->leg_chain) (void) hipFree(c->leg_chain);
   if (c->leg_nc) (void) hipFree(c->leg_nc);
+  if (c->leg_lo) (void) hipFree(c->leg_lo);
   if (c->d_small) (void) hipFree(c->d_small);
   if (c->stage) (void) hipFree(c->stage);
   if (c->copy_stream) (void) hipStreamSynchronize(c->copy_stream);
@@ -694,6 +695,44 @@ extern "C" int pb_get_filter_state(pb_ctx *c, int filter, double quat[4], double
   return PB_OK;
 }
 
+// bit-level checksum of a whole state array: wrapping sum and xor of every 64-bit word after a position-dependent rotation,
+// combined with integer atomics, hence independent of the order in which waves finish
+static __global__ __launch_bounds__(256) void k_state_checksum(const uint64_t *__restrict__ w, size_t n, unsigned long long *__restrict__ out)
+{
+  unsigned long long sum = 0, x = 0;
+  for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t) gridDim.x * blockDim.x) {
+    const uint64_t v = w[i];
+    const unsigned r = (unsigned) (i % 63) + 1;
+    sum += v * (2 * (uint64_t) (i % 1021) + 1);
+    x ^= (v << r) | (v >> (64 - r));
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    sum += __shfl_xor(sum, o);
+    x ^= __shfl_xor(x, o);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(out, sum);
+    atomicXor(out + 1, x);
+  }
+}
+
+extern "C" int pb_state_checksum(pb_ctx *c, int slot, uint64_t out[2])
+{
+  ENTER(c);
+  NEED_STATE(c);
+  if (!out) return PB_ERR_ARG;
+  if (slot >= c->nhist) return fail(c, PB_ERR_ARG, "pb_state_checksum: slot %d of %d", slot, c->nhist);
+  const double *src = slot < 0 ? c->st : c->hist + (size_t) slot * c->state_doubles;
+  int rc = stage_reserve(c, 2 * sizeof(uint64_t));
+  if (rc) return rc;
+  HIPCHK(c, hipMemsetAsync(c->stage, 0, 2 * sizeof(uint64_t), c->stream));
+  k_state_checksum<<<2048, 256, 0, c->stream>>>((const uint64_t *) src, c->state_doubles, (unsigned long long *) c->stage);
+  LAUNCHCHK(c);
+  HIPCHK(c, hipMemcpyAsync(out, c->stage, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return PB_OK;
+}
+
 extern "C" int pb_summary(pb_ctx *c, double out[4])
 {
   ENTER(c);
@@ -861,27 +900,10 @@ extern "C" int pb_legodo_set_chain(pb_ctx *c, int n_left, int n_right, const int
     for (int j = 0; j < ch.n[side]; j++, k++) {
       const int ty = joint_type[k];
       if (ty != LJ_FIXED && ty != LJ_REVOLUTE && ty != LJ_PRISMATIC) return fail(c, PB_ERR_ARG, "pb_legodo_set_chain: joint %d: bad type %d", k, ty);
-      ch.type[side][j] = ty;
-      ch.row[side][j] = (ty == LJ_FIXED) ? 0 : joint_row[k];
       if (ty != LJ_FIXED && joint_row[k] < 0) return fail(c, PB_ERR_ARG, "pb_legodo_set_chain: joint %d: negative row", k);
       if (ty != LJ_FIXED && joint_row[k] > max_row) max_row = joint_row[k];
-      const double *o = origin_xyz_rpy + 6 * k;
-      for (int i = 0; i < 3; i++) ch.org_t[side][j][i] = o[i];
-      // urdf::Rotation::setFromRPY (urdfdom_headers pose.h; NOT in the tree): the quaternion every consumer of the URDF sees
-      const double phi = o[3] / 2.0, the = o[4] / 2.0, psi = o[5] / 2.0;
-      double q[4] = { cos(phi) * cos(the) * cos(psi) + sin(phi) * sin(the) * sin(psi),
-                      sin(phi) * cos(the) * cos(psi) - cos(phi) * sin(the) * sin(psi),
-                      cos(phi) * sin(the) * cos(psi) + sin(phi) * cos(the) * sin(psi),
-                      cos(phi) * cos(the) * sin(psi) - sin(phi) * sin(the) * cos(psi) };
-      const double qn = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
-      for (int i = 0; i < 4; i++) ch.org_q[side][j][i] = q[i] / qn;
-      ch.org_rot[side][j] = (o[3] != 0.0 || o[4] != 0.0 || o[5] != 0.0) ? 1 : 0;
-      const double *a = axis + 3 * k;
-      const double an = sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
-      if (ty != LJ_FIXED && !(an > 0.0)) return fail(c, PB_ERR_ARG, "pb_legodo_set_chain: joint %d: zero axis", k);
-      for (int i = 0; i < 3; i++) ch.axis[side][j][i] = (ty == LJ_FIXED) ? 0.0 : a[i] / an;  // KDL::Joint normalises the axis
-      const float g = adjustment_gain ? adjustment_gain[k] : 0.0f;
-      ch.gain[side][j] = (ty != LJ_FIXED && std::isnormal(g)) ? g : 0.0f;  // torque_adjustment.cpp:52
+      if (!leg_chain_entry(ch, side, j, ty, joint_row[k], origin_xyz_rpy + 6 * k, axis + 3 * k, adjustment_gain ? adjustment_gain[k] : 0.0f))
+        return fail(c, PB_ERR_ARG, "pb_legodo_set_chain: joint %d: zero axis", k);
     }
   }
   if (!c->leg_chain) HIPCHK(c, hipMalloc((void **) &c->leg_chain, sizeof(LegChain)));
@@ -901,15 +923,27 @@ static int leg_in_joints(pb_ctx *c, const char *who, int n_rows, const float *jp
   if (n_rows < c->leg_chain_rows) return fail(c, PB_ERR_ARG, "%s: the chain reads joint row %d, the block has %d rows", who, c->leg_chain_rows - 1, n_rows);
   in.kind = 1;
   in.chain = c->leg_chain;
-  if (mem == PB_HOST_BROADCAST) {  // one robot's joint state for every filter: the chain's angles travel as kernel arguments
+  in.chain_rec = &c->leg_chain->rec[0][0][0];
+  if (mem == PB_HOST_BROADCAST) {
+    // ONE robot's joint state for every filter of the batch: its two body-to-foot transforms are a per-MESSAGE quantity, the
+    // same for all filters, so they are formed once, here, with the very leg_fk the kernels run per filter for per-filter
+    // joint blocks (rbis_legodo.hpp), and travel as 14 kernel arguments -- not recomputed 65 536 times on the device.
     const LegChain &ch = c->leg_chain_h;
-    for (int side = 0; side < 2; side++)
-      for (int j = 0; j < ch.n[side]; j++) {
-        if (ch.type[side][j] == LJ_FIXED) continue;
-        const int r = ch.row[side][j];
-        in.v[side * LEG_MAXJ + j] = (double) (jeff ? torque_adjust(jpos[r], jeff[r], ch.gain[side][j]) : jpos[r]);
-      }
-    if (forces) { in.v[2 * LEG_MAXJ] = forces[0]; in.v[2 * LEG_MAXJ + 1] = forces[1]; }
+    Pose feet[2];
+    for (int side = 0; side < 2; side++) {
+      double ang[LEG_MAXJ];
+      leg_angles(ch, side, [&](int j) {
+        const int r = ch.row[side][j];  // (0 for the slots the chain does not use: leg_fk skips them)
+        return (double) (jeff ? torque_adjust(jpos[r], jeff[r], ch.gain[side][j]) : jpos[r]);
+      }, ang);
+      leg_fk(ch, side, ang, [&](int j, int f) { return ch.rec[side][j][f]; }, feet[side]);
+    }
+    for (int side = 0; side < 2; side++) {
+      for (int i = 0; i < 3; i++) in.v[7 * side + i] = feet[side].t[i];
+      for (int i = 0; i < 4; i++) in.v[7 * side + 3 + i] = feet[side].q[i];
+    }
+    if (forces) { in.v[14] = forces[0]; in.v[15] = forces[1]; }
+    in.kind = 0;
     in.bcast = 1;
     return PB_OK;
   }
@@ -1015,6 +1049,91 @@ extern "C" int pb_legodo_update_joints(pb_ctx *c, const double *imu_block, int i
   if (rc) return rc;
   return legodo_launch(c, in, imu_block, imu_mem, utime, zero_delta, r_vxyz, r_vxyz_uncertain, delta_out, status_out, lo_out, mask_out,
                        position_out, position_status_out);
+}
+
+// IMU step + leg odometry + its lin_rate update for one message pair: one kernel where the context has it (pbk_step_leg),
+// else the odometry kernel slaved to the state after the IMU step followed by the fused step (two launches, same results)
+static int step_leg_impl(pb_ctx *c, LegIn &in, const double *imu_block, int imu_mem, const double q[4], int64_t utime, double r_vxyz,
+                         double r_vxyz_uncertain, double *lo_out, uint8_t *mask_out)
+{
+  StepBcast bc;
+  const double *d_imu = nullptr;
+  if (imu_mem == PB_HOST_BROADCAST) {
+    memcpy(bc.imu, imu_block, sizeof(bc.imu));
+    bc.on = 1;
+  } else {
+    Part pi[1] = { { imu_block, sizeof(double) * 7 * c->B, 0 } };
+    int rc = stage_in(c, imu_mem, pi, 1);
+    if (rc) return rc;
+    d_imu = (const double *) pi[0].dev;
+  }
+  if (c->leg_nc_dev) in.ncontacts = c->leg_nc;
+  in.nc[0] = c->leg_nc_h[0];
+  in.nc[1] = c->leg_nc_h[1];
+  const double r2 = r_vxyz * r_vxyz, r2u = r_vxyz_uncertain * r_vxyz_uncertain;
+  int rc = pbk_step_leg(c, d_imu, &bc, q, in, utime, r2, r2u, lo_out, mask_out);
+  if (rc >= 0) return rc;
+  if (lo_out == nullptr) {  // the measurement has to pass through memory between the two kernels
+    const size_t bytes = sizeof(double) * 6 * (size_t) c->B + (size_t) c->B;
+    if (!c->leg_lo) HIPCHK(c, hipMalloc((void **) &c->leg_lo, bytes));
+    lo_out = c->leg_lo;
+    mask_out = (uint8_t *) (c->leg_lo + (size_t) 6 * c->B);
+  }
+  LegAhead ah;
+  ah.on = 1;
+  ah.bcast = bc.on & 1;
+  memcpy(ah.v, bc.imu, sizeof(ah.v));
+  ah.imu = d_imu;
+  if (c->ns == 15)
+    k_legodo<15><<<nblk(c->B), 64, 0, c->stream>>>(c->st, c->legd, c->legi, c->stride, c->B, utime, c->leg_par, in, ah, 0, r2, r2u, nullptr,
+                                                   nullptr, lo_out, mask_out, nullptr, nullptr, c->k);
+  else
+    k_legodo<21><<<nblk(c->B), 64, 0, c->stream>>>(c->st, c->legd, c->legi, c->stride, c->B, utime, c->leg_par, in, ah, 0, r2, r2u, nullptr,
+                                                   nullptr, lo_out, mask_out, nullptr, nullptr, c->k);
+  LAUNCHCHK(c);
+  return pbk_step(c, true, d_imu, lo_out, mask_out, q, &bc);
+}
+
+extern "C" int pb_step_legodo_joints(pb_ctx *c, const double *imu_block, int imu_mem, const double q[4], int64_t utime, int n_rows,
+                                     const float *joint_position, const float *joint_effort, const float *forces, int mem,
+                                     double r_vxyz, double r_vxyz_uncertain, double *lo_block_out, uint8_t *mask_out)
+{
+  ENTER(c);
+  NEED_STATE(c);
+  if (!c->legd) return fail(c, PB_ERR_STATE, "pb_step_legodo_joints before pb_legodo_init");
+  if (!imu_block || !q || !forces || (lo_block_out && !mask_out)) return fail(c, PB_ERR_ARG, "pb_step_legodo_joints: NULL input");
+  if (imu_mem == PB_HOST && mem == PB_HOST)
+    return fail(c, PB_ERR_ARG, "pb_step_legodo_joints: the IMU block and the joint blocks cannot both be PB_HOST");
+  LegIn in;
+  int rc = leg_in_joints(c, "pb_step_legodo_joints", n_rows, joint_position, joint_effort, forces, mem, in);
+  if (rc) return rc;
+  return step_leg_impl(c, in, imu_block, imu_mem, q, utime, r_vxyz, r_vxyz_uncertain, lo_block_out, mask_out);
+}
+
+extern "C" int pb_step_legodo_feet(pb_ctx *c, const double *imu_block, int imu_mem, const double q[4], int64_t utime, const double *feet,
+                                   const double *forces, int mem, double r_vxyz, double r_vxyz_uncertain, double *lo_block_out,
+                                   uint8_t *mask_out)
+{
+  ENTER(c);
+  NEED_STATE(c);
+  if (!c->legd) return fail(c, PB_ERR_STATE, "pb_step_legodo_feet before pb_legodo_init");
+  if (!imu_block || !q || !feet || !forces || (lo_block_out && !mask_out)) return fail(c, PB_ERR_ARG, "pb_step_legodo_feet: NULL input");
+  if (imu_mem == PB_HOST && mem == PB_HOST)
+    return fail(c, PB_ERR_ARG, "pb_step_legodo_feet: the IMU block and the foot blocks cannot both be PB_HOST");
+  LegIn in;
+  if (mem == PB_HOST_BROADCAST) {
+    memcpy(in.v, feet, sizeof(double) * 14);
+    in.v[14] = forces[0];
+    in.v[15] = forces[1];
+    in.bcast = 1;
+  } else {
+    Part p[2] = { { feet, sizeof(double) * 14 * c->B, 0 }, { forces, sizeof(double) * 2 * c->B, 0 } };
+    int rc = stage_in(c, mem, p, 2);
+    if (rc) return rc;
+    in.feet = (const double *) p[0].dev;
+    in.forces = (const double *) p[1].dev;
+  }
+  return step_leg_impl(c, in, imu_block, imu_mem, q, utime, r_vxyz, r_vxyz_uncertain, lo_block_out, mask_out);
 }
 
 extern "C" int pb_legodo_fk(pb_ctx *c, int n_rows, const float *joint_position, const float *joint_effort, int mem, double *feet_out)
@@ -1190,12 +1309,15 @@ extern "C" int pb_smooth_step(pb_ctx *c, int slot_next_pred, int slot_next, int 
   return pbk_smooth_step(c, np_, ns_, cu, out, dt);
 }
 
-extern "C" int pb_calib_copy(pb_ctx *c, int reps, float *elapsed_ms)
+static int calib_copy_impl(pb_ctx *c, int reps, float *elapsed_ms, uint64_t *checksum)
 {
-  ENTER(c);
   if (reps < 1) return fail(c, PB_ERR_ARG, "pb_calib_copy: reps must be >= 1");
   double *dst = nullptr;
   const size_t bytes = sizeof(double) * c->state_doubles;
+  if (checksum) {
+    int rc = stage_reserve(c, 2 * sizeof(uint64_t));
+    if (rc) return rc;
+  }
   HIPCHK(c, hipMalloc((void **) &dst, bytes));
   hipError_t e = hipEventRecord(c->ev0, c->stream);
   for (int r = 0; r < reps && e == hipSuccess; r++) {
@@ -1203,6 +1325,15 @@ extern "C" int pb_calib_copy(pb_ctx *c, int reps, float *elapsed_ms)
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipEventRecord(c->ev1, c->stream);
+  if (e == hipSuccess && checksum) {
+    e = hipMemsetAsync(c->stage, 0, 2 * sizeof(uint64_t), c->stream);
+    if (e == hipSuccess) {
+      k_state_checksum<<<2048, 256, 0, c->stream>>>((const uint64_t *) dst, c->state_doubles, (unsigned long long *) c->stage);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(checksum, c->stage, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  }
   if (e == hipSuccess) e = hipEventSynchronize(c->ev1);
   float ms = 0;
   if (e == hipSuccess) e = hipEventElapsedTime(&ms, c->ev0, c->ev1);
@@ -1210,6 +1341,20 @@ extern "C" int pb_calib_copy(pb_ctx *c, int reps, float *elapsed_ms)
   if (e != hipSuccess) return fail(c, PB_ERR_HIP, "pb_calib_copy failed: %s", hipGetErrorString(e));
   if (elapsed_ms) *elapsed_ms = ms;
   return PB_OK;
+}
+
+extern "C" int pb_calib_copy(pb_ctx *c, int reps, float *elapsed_ms)
+{
+  ENTER(c);
+  return calib_copy_impl(c, reps, elapsed_ms, nullptr);
+}
+
+extern "C" int pb_calib_copy_checksum(pb_ctx *c, int reps, uint64_t out[2])
+{
+  ENTER(c);
+  NEED_STATE(c);
+  if (!out) return PB_ERR_ARG;
+  return calib_copy_impl(c, reps, nullptr, out);
 }
 
 extern "C" int pb_set_utime(pb_ctx *c, int64_t utime)

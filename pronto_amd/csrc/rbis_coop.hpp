@@ -145,6 +145,7 @@ struct CoopX {
   static constexpr int X2_L = C::NXCH, X2_ID = X2_L + M * (M - 1) / 2, X2_YD = X2_ID + M, X2_W = X2_YD + M,
                        X2_LLI = X2_W + C::NSC * M;
   static constexpr int NXCH = (M == 0) ? C::NXCH : X2_LLI + (C::LL_IN_P ? 1 : 0);
+  static constexpr int XCH_LEG = NXCH, NXCH_LEG = NXCH + 5;  // k_step_leg: z[3], R, valid from the odometry wave
 };
 
 // ------------------------------------------------------------------------------------------------------------
@@ -154,10 +155,13 @@ struct CoopX {
 // What one launch does is three compile-time switches: PREDICT (the IMU process step), UPDATE (the leg-odometry velocity
 // update behind it), CORR (one more measurement with compile-time core indices).  PREDICT + UPDATE is the BASELINE hot step;
 // CORR alone is a stand-alone indexed / indexed+orientation update on the same two-role mapping.
-template <int NS, bool UPDATE, class CORR = NoCorr, bool PREDICT = true, class LD, class ST, class XW, class XR, class SYNC>
+// LEG: the leg-odometry measurement (z, R, valid) is not an input but made by the OTHER wave of the tile while this one
+// propagates (k_step_leg, rbis_legstep.hpp): it arrives in the hand-off slots XCH_LEG.. behind one more barrier.
+template <int NS, bool UPDATE, class CORR = NoCorr, bool PREDICT = true, bool LEG = false, class LD, class ST, class XW, class XR, class SYNC>
 PB_HD void coop_role_core(LD ld, ST st, XW xw, XR xr, SYNC sync, const StepInputs &in, const Consts &k,
                           const CorrInputs &cin = CorrInputs())
 {
+  static_assert(!LEG || (UPDATE && PREDICT), "the odometry wave feeds a predict + update step");
   using L = Lay<NS>;
   using C = Coop<NS>;
   constexpr int NSC = C::NSC;
@@ -245,12 +249,24 @@ PB_HD void coop_role_core(LD ld, ST st, XW xw, XR xr, SYNC sync, const StepInput
   if constexpr (UPDATE) {
     // S = R + P[v,v]; unpivoted LDL^T; y = L^-1 r  (rbis.cpp:124-143)
     double resid[3], S[6], d[3], y[3], id[3], yd[3];
+    double mz[3], mr[3];
+    bool mupd = in.upd;
+    if constexpr (LEG) {
+      sync();
+      const double r = xr(CoopX<NS, CORR>::XCH_LEG + 3);
+      mupd = in.upd && xr(CoopX<NS, CORR>::XCH_LEG + 4) != 0.0;
 #pragma unroll
-    for (int i = 0; i < 3; i++) resid[i] = in.upd ? in.z[i] - x[3 + i] : 0.0;
+      for (int i = 0; i < 3; i++) { mz[i] = xr(CoopX<NS, CORR>::XCH_LEG + i); mr[i] = r; }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 3; i++) { mz[i] = in.z[i]; mr[i] = in.rd[i]; }
+    }
+#pragma unroll
+    for (int i = 0; i < 3; i++) resid[i] = mupd ? mz[i] - x[3 + i] : 0.0;
 #pragma unroll
     for (int i = 0; i < 3; i++)
 #pragma unroll
-      for (int j = 0; j <= i; j++) S[pk(i, j)] = Pc[pk(i, j)] + (i == j ? (in.upd ? in.rd[i] : 1.0) : 0.0);
+      for (int j = 0; j <= i; j++) S[pk(i, j)] = Pc[pk(i, j)] + (i == j ? (mupd ? mr[i] : 1.0) : 0.0);
     ldlt<3>(S, d);
     double quad = 0.0, det = 1.0;
 #pragma unroll
@@ -258,15 +274,15 @@ PB_HD void coop_role_core(LD ld, ST st, XW xw, XR xr, SYNC sync, const StepInput
       double s = resid[kk];
 #pragma unroll
       for (int j = 0; j < kk; j++) s -= S[pk(kk, j)] * y[j];
-      y[kk] = in.upd ? s : 0.0;
-      id[kk] = in.upd ? 1.0 / d[kk] : 0.0;
+      y[kk] = mupd ? s : 0.0;
+      id[kk] = mupd ? 1.0 / d[kk] : 0.0;
       yd[kk] = y[kk] * id[kk];
       det *= d[kk];
       quad += s * s * id[kk];
     }
     const double lli = -log(det) - quad;  // -log(S.determinant()) - r^T S^-1 r (rbis.cpp:142): ONE log of the product
     if constexpr (C::LL_IN_P) xw(C::XCH_LLI, lli);
-    else if (in.upd) ll += lli;
+    else if (mupd) ll += lli;
     double W[NSC][3];
 #pragma unroll
     for (int i = 0; i < NSC; i++)
@@ -305,7 +321,7 @@ PB_HD void coop_role_core(LD ld, ST st, XW xw, XR xr, SYNC sync, const StepInput
         else Pc[pk(i, j)] = acc;  // row i of W is not needed for any later row j' > i's column i: W[i] stays as is
       }
     }
-    if (in.upd) add_delta<NS>(x, q, dfull, k.chi_tol);
+    if (mupd) add_delta<NS>(x, q, dfull, k.chi_tol);
   }
   if constexpr (CORR::M > 0) {
     // ---- the second update on the posterior of the first (indexedPlusOrientationMeasurement, rbis.cpp:189-217) ----

@@ -314,6 +314,29 @@ PB_HD void ins_update_state(double (&x)[NS], double (&q)[4], const double (&gyro
   add_delta<NS>(x, q, d, k.chi_tol);  // :63,:69
 }
 
+// The quaternion part of ins_update_state alone -- bit-identical to what it leaves in q -- from the three things it depends
+// on: the prior chi (x[6..8]), the gyro bias (x[15..17], 21 states) and the prior quaternion.  For callers that only need the
+// orientation after an IMU step (the leg odometry slaved to it): no velocity / position arithmetic, 10 components instead of
+// the whole state vector.
+template <int NS>
+PB_HD void ins_update_quat(const double (&chi_prior)[3], const double (&gyro_bias)[3], double (&q)[4], const double (&gyro)[3], double dt,
+                           const Consts &k)
+{
+  double dchi[3], chi[3];
+#pragma unroll
+  for (int i = 0; i < 3; i++) dchi[i] = (gyro[i] - (NS == 21 ? gyro_bias[i] : 0.0)) * dt;  // rbis.cpp:50,58
+  // add_delta: the increment's own chi is folded first (RigidBodyState(vec)), the vector added, the state's chi folded, then
+  // the two rotations composed
+  double dq[4] = { 1.0, 0.0, 0.0, 0.0 };
+  fold_chi(dchi, dq, k.chi_tol);
+#pragma unroll
+  for (int i = 0; i < 3; i++) chi[i] = chi_prior[i] + dchi[i];
+  fold_chi(chi, q, k.chi_tol);
+  double o[4];
+  quat_mul(q, dq, o);
+  q[0] = o[0]; q[1] = o[1]; q[2] = o[2]; q[3] = o[3];
+}
+
 // One elementary block-row congruence P <- E P E^T, E = I + (block row I <- sum_s A[s] * block row SRC[s]).
 // KIND[s]: 0 dense 3x3 (A[s][0..8] row-major), 1 hat(a) = [[0,-a2,a1],[a2,0,-a0],[-a1,a0,0]] (A[s][0..2] = a),
 //          2 scalar*identity (A[s][0] holds the scalar).

@@ -115,62 +115,114 @@ PB_HD void sincos_joint(double x, double &s, double &c)
 // forms KDL's 3x3 matrices with Rot2's Rodrigues formula (oracle/leg_odometry.c).
 static constexpr int LEG_MAXJ = 8;  // joints per leg chain (Atlas: 6)
 enum { LJ_FIXED = 0, LJ_REVOLUTE = 1, LJ_PRISMATIC = 2 };
+// per-joint code word: bits 0-1 type, bit 2 the origin has a rotation (rpy != 0), bit 3 the origin has a translation,
+// bits 4-5 revolute axis kind (0 general, 1 / 2 / 3 = x / y / z: half the multiplications), bit 6 that axis is negative
+enum { LC_TYPE = 3, LC_ORG_ROT = 4, LC_ORG_T = 8, LC_AXIS_SHIFT = 4, LC_AXIS_NEG = 64 };
+static constexpr int LEG_REC = 10;  // doubles per joint record: <origin xyz> (3), <origin rpy> as urdfdom's quaternion (4), <axis> normalised (3)
 struct LegChain {
   int n[2];                        // joints of the left / right chain
-  int type[2][LEG_MAXJ];           // LJ_*
+  int code[2][LEG_MAXJ];           // LC_*
   int row[2][LEG_MAXJ];            // row of the joint-position block ([rows][B]); unused for LJ_FIXED
-  int org_rot[2][LEG_MAXJ];        // 0: the origin's rpy is zero (its quaternion multiplication is skipped)
   float gain[2][LEG_MAXJ];         // TorqueAdjustment spring constant of the joint, 0 = none (torque_adjustment.cpp:52)
-  double org_t[2][LEG_MAXJ][3];    // <origin xyz>
-  double org_q[2][LEG_MAXJ][4];    // <origin rpy> as the quaternion urdfdom makes of it (setFromRPY)
-  double axis[2][LEG_MAXJ][3];     // <axis>, normalised (KDL::Joint normalises it)
+  double rec[2][LEG_MAXJ][LEG_REC];
 };
 
 // TorqueAdjustment::processSample for one joint, in float like the reference: position -= clamp(effort / gain, +-0.1)
+// (branch-free: a select on gain == 0, which the host stores for a gain that is not std::isnormal, torque_adjustment.cpp:52)
 PB_HD float torque_adjust(float position, float effort, float gain)
 {
-  if (gain == 0.0f) return position;  // (the host stores 0 for a gain that is not std::isnormal, torque_adjustment.cpp:52)
   float a = effort / gain;
   a = a > 0.1f ? 0.1f : (a < -0.1f ? -0.1f : a);
-  return position - a;
+  return gain == 0.0f ? position : position - a;
 }
 
-// body_to_foot of leg `side`; angle(j) returns joint j's (torque-adjusted) position as a double
-template <class ANGLE>
-PB_HD void leg_fk(const LegChain &ch, int side, ANGLE &&angle, Pose &T)
+// body_to_foot of leg `side`; ang[j] = joint j's (torque-adjusted) position; rec(j, f) = field f of joint j's record (the
+// kernels read a copy of the table their wave has put into LDS: as scalar loads from memory the 200 table reads, each
+// waited for on its own, cost more than the arithmetic -- measured 6.5 us of a 17 us kernel).  The loop is unrolled over
+// the table's capacity with uniform guards, so the angles are a register array.
+template <class REC>
+PB_HD void leg_fk(const LegChain &ch, int side, const double (&ang)[LEG_MAXJ], REC &&rec, Pose &T)
 {
   pose_identity(T);
   const int n = ch.n[side];
-  for (int j = 0; j < n; j++) {  // trip count and every branch below are uniform over the batch
-    double rt[3];
-    const double ot[3] = { ch.org_t[side][j][0], ch.org_t[side][j][1], ch.org_t[side][j][2] };
-    quat_rot(T.q, ot, rt);
 #pragma unroll
-    for (int i = 0; i < 3; i++) T.t[i] += rt[i];
-    if (ch.org_rot[side][j]) {
-      const double oq[4] = { ch.org_q[side][j][0], ch.org_q[side][j][1], ch.org_q[side][j][2], ch.org_q[side][j][3] };
-      double q[4];
-      quat_mul(T.q, oq, q);
+  for (int j = 0; j < LEG_MAXJ; j++) {
+    if (j < n) {  // uniform over the batch, like every branch below
+      const int code = ch.code[side][j];
+      double rt[3];
+      if (code & LC_ORG_T) {
+        const double ot[3] = { rec(j, 0), rec(j, 1), rec(j, 2) };
+        quat_rot(T.q, ot, rt);
 #pragma unroll
-      for (int i = 0; i < 4; i++) T.q[i] = q[i];
-    }
-    const int ty = ch.type[side][j];
-    if (ty == LJ_REVOLUTE) {
-      double s, c;
-      sincos_joint(0.5 * angle(j), s, c);
-      const double jq[4] = { c, s * ch.axis[side][j][0], s * ch.axis[side][j][1], s * ch.axis[side][j][2] };
-      double q[4];
-      quat_mul(T.q, jq, q);
+        for (int i = 0; i < 3; i++) T.t[i] += rt[i];
+      }
+      if (code & LC_ORG_ROT) {
+        const double oq[4] = { rec(j, 3), rec(j, 4), rec(j, 5), rec(j, 6) };
+        double q[4];
+        quat_mul(T.q, oq, q);
 #pragma unroll
-      for (int i = 0; i < 4; i++) T.q[i] = q[i];
-    } else if (ty == LJ_PRISMATIC) {
-      const double d = angle(j);
-      const double av[3] = { d * ch.axis[side][j][0], d * ch.axis[side][j][1], d * ch.axis[side][j][2] };
-      quat_rot(T.q, av, rt);
+        for (int i = 0; i < 4; i++) T.q[i] = q[i];
+      }
+      const int ty = code & LC_TYPE;
+      if (ty == LJ_REVOLUTE) {
+        double s, c;
+        sincos_joint(0.5 * ang[j], s, c);
+        if (code & LC_AXIS_NEG) s = -s;
+        const int kx = (code >> LC_AXIS_SHIFT) & 3;
+        const double w = T.q[0], x = T.q[1], y = T.q[2], z = T.q[3];
+        // q * (c, s e_k) = c q + s (q * e_k): the product with a unit axis only permutes q's components
+        if (kx == 1) { T.q[0] = fma(-s, x, c * w); T.q[1] = fma(s, w, c * x); T.q[2] = fma(s, z, c * y); T.q[3] = fma(-s, y, c * z); }
+        else if (kx == 2) { T.q[0] = fma(-s, y, c * w); T.q[1] = fma(-s, z, c * x); T.q[2] = fma(s, w, c * y); T.q[3] = fma(s, x, c * z); }
+        else if (kx == 3) { T.q[0] = fma(-s, z, c * w); T.q[1] = fma(s, y, c * x); T.q[2] = fma(-s, x, c * y); T.q[3] = fma(s, w, c * z); }
+        else {
+          const double jq[4] = { c, s * rec(j, 7), s * rec(j, 8), s * rec(j, 9) };
+          double q[4];
+          quat_mul(T.q, jq, q);
 #pragma unroll
-      for (int i = 0; i < 3; i++) T.t[i] += rt[i];
+          for (int i = 0; i < 4; i++) T.q[i] = q[i];
+        }
+      } else if (ty == LJ_PRISMATIC) {
+        const double d = ang[j];
+        const double av[3] = { d * rec(j, 7), d * rec(j, 8), d * rec(j, 9) };
+        quat_rot(T.q, av, rt);
+#pragma unroll
+        for (int i = 0; i < 3; i++) T.t[i] += rt[i];
+      }
     }
   }
+}
+// The angles of one chain through angle(j) (a load, a torque adjustment ...) for ALL table slots, without a branch: the
+// rows of unused and fixed slots are 0 (a valid row), so every load can be requested before the first is used -- behind
+// a uniform guard per joint each load was waited for on its own, twelve memory latencies in a row.
+template <class ANGLE>
+PB_HD void leg_angles(const LegChain &, int, ANGLE &&angle, double (&ang)[LEG_MAXJ])
+{
+#pragma unroll
+  for (int j = 0; j < LEG_MAXJ; j++) ang[j] = angle(j);
+}
+// one joint's table entry from what pb_legodo_set_chain is given (shared with the test harness): the quaternion
+// urdf::Rotation::setFromRPY makes of <origin rpy> (urdfdom_headers pose.h; NOT in the tree), the axis normalised as
+// KDL::Joint does; returns false for a moving joint with a zero axis
+inline bool leg_chain_entry(LegChain &ch, int side, int j, int type, int row, const double *o /* xyz rpy */, const double *a, float gain)
+{
+  double *r = ch.rec[side][j];
+  for (int i = 0; i < 3; i++) r[i] = o[i];
+  const double phi = o[3] / 2.0, the = o[4] / 2.0, psi = o[5] / 2.0;
+  const double q[4] = { cos(phi) * cos(the) * cos(psi) + sin(phi) * sin(the) * sin(psi), sin(phi) * cos(the) * cos(psi) - cos(phi) * sin(the) * sin(psi),
+                        cos(phi) * sin(the) * cos(psi) + sin(phi) * cos(the) * sin(psi), cos(phi) * cos(the) * sin(psi) - sin(phi) * sin(the) * cos(psi) };
+  const double qn = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  for (int i = 0; i < 4; i++) r[3 + i] = q[i] / qn;
+  const double an = sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
+  if (type != LJ_FIXED && !(an > 0.0)) return false;
+  for (int i = 0; i < 3; i++) r[7 + i] = (type == LJ_FIXED) ? 0.0 : a[i] / an;
+  int code = type | ((o[3] != 0.0 || o[4] != 0.0 || o[5] != 0.0) ? LC_ORG_ROT : 0) | ((o[0] != 0.0 || o[1] != 0.0 || o[2] != 0.0) ? LC_ORG_T : 0);
+  if (type == LJ_REVOLUTE)
+    for (int i = 0; i < 3; i++)
+      if (a[(i + 1) % 3] == 0.0 && a[(i + 2) % 3] == 0.0) code |= ((i + 1) << LC_AXIS_SHIFT) | (a[i] < 0 ? LC_AXIS_NEG : 0);
+  ch.code[side][j] = code;
+  ch.row[side][j] = (type == LJ_FIXED) ? 0 : row;
+  ch.gain[side][j] = (type != LJ_FIXED && std::isnormal(gain)) ? gain : 0.0f;  // torque_adjustment.cpp:52
+  return true;
 }
 
 // ---- contact logic ------------------------------------------------------------------------------------------------------
@@ -628,16 +680,18 @@ PB_HD void leg_store(const LegState &s, double *d, int64_t *iw, long stride, lon
 // Either the two body-to-foot transforms (kind 0: feet [14][B] = left (t3, q4), right (t3, q4), forces [2][B], doubles) or the
 // joint state itself (kind 1: joint positions [rows][B], optionally efforts [rows][B] for the torque adjustment, forces
 // [2][B], floats like bot_core::joint_state_t / six_axis_force_torque_t carry them), per filter in device memory -- or ONE
-// robot's message for every filter (bcast: a parameter sweep over one log), whose values travel as kernel arguments
-// (feet kind: v = feet[14] + forces[2]; joint kind: v = torque-adjusted chain angles [2][LEG_MAXJ] + forces[2]).
+// robot's message for every filter (bcast: a parameter sweep over one log): v = feet[14] + forces[2] as kernel arguments (a
+// broadcast JOINT state is reduced to the two foot transforms by the host side of the ABI: they are the same for every
+// filter).
 struct LegIn {
   int kind = 0, bcast = 0;
   const double *feet = nullptr, *forces = nullptr;
   const float *jpos = nullptr, *jeff = nullptr, *jforces = nullptr;
   const LegChain *chain = nullptr;
+  const double *chain_rec = nullptr;   // the records leg_fk reads: chain->rec, or the wave's LDS copy of it (leg_stage_chain)
   const int32_t *ncontacts = nullptr;  // controller contact counts [2][B] (device) or NULL: nc[] for every filter
   int nc[2] = { -1, -1 };              // (-1: no CONTROLLER_FOOT_CONTACT message yet, rbis_legodo_update.cpp:100-101)
-  double v[2 * LEG_MAXJ + 2] = { 0 };
+  double v[16] = { 0 };
 };
 
 PB_HD void leg_inputs(const LegIn &in, long b, long B, Pose &bl, Pose &br, float &fl, float &fr, int &ncl, int &ncr)
@@ -658,21 +712,24 @@ PB_HD void leg_inputs(const LegIn &in, long b, long B, Pose &bl, Pose &br, float
     }
   } else {
     const LegChain &ch = *in.chain;
-    if (in.bcast) {
-      leg_fk(ch, 0, [&](int j) { return in.v[j]; }, bl);
-      leg_fk(ch, 1, [&](int j) { return in.v[LEG_MAXJ + j]; }, br);
-      fl = (float) in.v[2 * LEG_MAXJ]; fr = (float) in.v[2 * LEG_MAXJ + 1];
+    double al[LEG_MAXJ], ar[LEG_MAXJ];
+    if (in.jeff != nullptr) {  // (uniform) with the torque adjustment: positions and efforts of both chains requested together
+      float pl[LEG_MAXJ], pr[LEG_MAXJ], el[LEG_MAXJ], er[LEG_MAXJ];
+#pragma unroll
+      for (int j = 0; j < LEG_MAXJ; j++) {
+        const long atl = (long) ch.row[0][j] * B + b, atr = (long) ch.row[1][j] * B + b;
+        pl[j] = in.jpos[atl]; pr[j] = in.jpos[atr]; el[j] = in.jeff[atl]; er[j] = in.jeff[atr];
+      }
+      leg_angles(ch, 0, [&](int j) { return (double) torque_adjust(pl[j], el[j], ch.gain[0][j]); }, al);
+      leg_angles(ch, 1, [&](int j) { return (double) torque_adjust(pr[j], er[j], ch.gain[1][j]); }, ar);
     } else {
-      auto angle = [&](int side, int j) {
-        const long at = (long) ch.row[side][j] * B + b;
-        float pos = in.jpos[at];
-        if (in.jeff != nullptr) pos = torque_adjust(pos, in.jeff[at], ch.gain[side][j]);
-        return (double) pos;
-      };
-      leg_fk(ch, 0, [&](int j) { return angle(0, j); }, bl);
-      leg_fk(ch, 1, [&](int j) { return angle(1, j); }, br);
-      fl = in.jforces[b]; fr = in.jforces[B + b];
+      leg_angles(ch, 0, [&](int j) { return (double) in.jpos[(long) ch.row[0][j] * B + b]; }, al);
+      leg_angles(ch, 1, [&](int j) { return (double) in.jpos[(long) ch.row[1][j] * B + b]; }, ar);
     }
+    fl = in.jforces[b]; fr = in.jforces[B + b];
+    const double *rec = in.chain_rec;
+    leg_fk(ch, 0, al, [rec](int j, int f) { return rec[j * LEG_REC + f]; }, bl);
+    leg_fk(ch, 1, ar, [rec](int j, int f) { return rec[(LEG_MAXJ + j) * LEG_REC + f]; }, br);
   }
   if (in.ncontacts != nullptr) { ncl = in.ncontacts[b]; ncr = in.ncontacts[B + b]; }
   else { ncl = in.nc[0]; ncr = in.nc[1]; }
@@ -695,6 +752,17 @@ PB_HD void leg_measurement(const Pose &delta, double status, int64_t utime, int6
 }
 
 #if defined(__HIPCC__)
+// The joint records of the chain table into this WAVE's LDS area (2 * LEG_MAXJ * LEG_REC doubles), for leg_fk; only the
+// calling wave reads them, so a wave-level barrier orders the copy (LDS operations of one wave execute in order).
+__device__ __forceinline__ void leg_stage_chain(LegIn &in, double *lds, unsigned lane)
+{
+  if (in.kind == 1) {  // uniform
+    const double *src = &in.chain->rec[0][0][0];
+    for (unsigned i = lane; i < 2u * LEG_MAXJ * LEG_REC; i += 64u) lds[i] = src[i];
+    __builtin_amdgcn_wave_barrier();
+    in.chain_rec = lds;
+  }
+}
 // One robot per lane: the odometry on its state, with the filter's own head orientation as world_to_body_ (setPoseBody,
 // rbis_legodo_update.cpp:214-229), then -- optionally -- the lin_rate measurement of it.
 // AHEAD: the odometry is slaved to the orientation the filter WILL have after the IMU step in `imu` / imu_bc
@@ -717,6 +785,8 @@ static __global__ __launch_bounds__(64, 2) void k_legodo(const double *__restric
 {
   using L = Lay<NS>;
   using S = Slots<NS>;
+  __shared__ double chain_lds[2 * LEG_MAXJ * LEG_REC];
+  leg_stage_chain(in, chain_lds, threadIdx.x);
   const long b = (long) blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   LegState s;
@@ -729,9 +799,7 @@ static __global__ __launch_bounds__(64, 2) void k_legodo(const double *__restric
   if (par.world_constraint && !ah.on)
     for (int i = 0; i < 3; i++) wpos[i] = st[S::eidx(L::OFF_VEC + 9 + i, b)];
   if (ah.on) {
-    double x[NS], gyro[3], accel[3], dt;
-#pragma unroll
-    for (int i = 0; i < NS; i++) x[i] = st[S::eidx(L::OFF_VEC + i, b)];
+    double gyro[3], accel[3], dt;
     if (ah.bcast) {
       for (int i = 0; i < 3; i++) { gyro[i] = ah.v[i]; accel[i] = ah.v[3 + i]; }
       dt = ah.v[6];
@@ -739,8 +807,19 @@ static __global__ __launch_bounds__(64, 2) void k_legodo(const double *__restric
       for (int i = 0; i < 3; i++) { gyro[i] = ah.imu[(long) i * B + b]; accel[i] = ah.imu[(long) (3 + i) * B + b]; }
       dt = ah.imu[(long) 6 * B + b];
     }
-    ins_update_state<NS>(x, wq, gyro, accel, dt, k);
-    for (int i = 0; i < 3; i++) wpos[i] = x[9 + i];
+    if (par.world_constraint) {  // the pose after the IMU step: the whole state propagate
+      double x[NS];
+#pragma unroll
+      for (int i = 0; i < NS; i++) x[i] = st[S::eidx(L::OFF_VEC + i, b)];
+      ins_update_state<NS>(x, wq, gyro, accel, dt, k);
+      for (int i = 0; i < 3; i++) wpos[i] = x[9 + i];
+    } else {                     // only the orientation after it (bit-identical to the above)
+      double chi[3], bg[3] = { 0.0, 0.0, 0.0 };
+      for (int i = 0; i < 3; i++) chi[i] = st[S::eidx(L::OFF_VEC + 6 + i, b)];
+      if (NS == 21)
+        for (int i = 0; i < 3; i++) bg[i] = st[S::eidx(L::OFF_VEC + 15 + i, b)];
+      ins_update_quat<NS>(chi, bg, wq, gyro, dt, k);
+    }
   }
   leg_inputs(in, b, B, bl, br, fl, fr, ncl, ncr);
   int64_t prev = 0;
@@ -775,6 +854,8 @@ static __global__ __launch_bounds__(64, 2) void k_legodo(const double *__restric
 // forward kinematics alone: feet_out [14][B] (diagnostics, tests)
 static __global__ __launch_bounds__(64) void k_leg_fk(LegIn in, int B, double *__restrict__ feet_out)
 {
+  __shared__ double chain_lds[2 * LEG_MAXJ * LEG_REC];
+  leg_stage_chain(in, chain_lds, threadIdx.x);
   const long b = (long) blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   Pose bl, br;

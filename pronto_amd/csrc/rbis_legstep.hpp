@@ -1,0 +1,226 @@
+// rbis_legstep.hpp -- ONE kernel per IMU + joint-state (or foot-state) message pair: what the reference does per pair of
+// messages in LegOdoHandler::processMessage and the two updateFilter calls around it
+//   rbis_legodo_update.cpp:206-280   head pose -> leg_estimate::updateOdometry -> LegOdoCommon::createMeasurement (lin_rate)
+//   rbis_update_interface.cpp:30-95  RBISIMUProcessStep::updateFilter, RBISIndexedMeasurement::updateFilter
+// in one round trip of the filter state.  Round 2 needed two launches for it (k_legodo, then the fused step reading the
+// measurement block k_legodo had written).
+//
+// 15 states, two waves per tile (rbis_coop.hpp).  Role P, the wave that owns the passive panels, has the shorter chain
+// before the hand-off barrier and already reads the whole prior state for its process blocks, so IT runs the odometry
+// FIRST, before it requests its panel rows (the odometry's registers are dead by then):
+//   role P: prior x, quat | leg state | joint / foot inputs -> orientation after the IMU step (ins_update_state on a copy)
+//           -> forward kinematics, contact logic, pelvis increment -> leg state stored, (z, R, valid) to LDS -> barrier L
+//           -> panel rows requested -> the unchanged passive role (its barrier: the Kalman factors from role C)
+//   role C: rows requested -> predict (state, P_cc) -> barrier L -> S = R + P_vv ... the unchanged core role
+// The kernel is HBM-bound like the plain step; the odometry adds its state (136 B read + 136 B written per filter) and its
+// inputs (a float joint block, or nothing for a broadcast message) and removes the 49-byte measurement block.
+#pragma once
+
+#include "rbis_kernels.hpp"
+#include "rbis_legodo.hpp"
+#include "rbis_quad.hpp"
+
+namespace pb {
+
+#if defined(__HIPCC__)
+struct LegStepArgs {
+  double *legd;
+  int64_t *legi;
+  long stride;
+  int64_t utime;
+  double r2, r2_uncertain;
+  double *lo_out;     // [6][B] or NULL: the measurement, kept for a later re-application of this update (history replay)
+  uint8_t *mask_out;  // [B] (with lo_out)
+};
+
+template <int NS, int MH>
+__global__ __launch_bounds__(128, 1) void k_step_leg(const double *st, double *sto, int B, const double *__restrict__ imu, double qg,
+                                                     double qa, double qbg, double qba, Consts k, StepBcast bc, LegPar par, LegIn lin,
+                                                     LegStepArgs la)
+{
+  using L = Lay<NS>;
+  using CX = CoopX<NS, NoCorr>;
+  __shared__ double xch[CX::NXCH_LEG][64];
+  __shared__ double chain_lds[2 * LEG_MAXJ * LEG_REC];
+  const int role = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
+  const unsigned lane = threadIdx.x & 63u;
+  const unsigned tile = xcd_workgroup(k);
+  const unsigned b = tile * 64u + lane;
+  const unsigned bo = b * 8u, B8 = (unsigned) B * 8u;
+  TileIO<NS, MemHint<MH>::LA, MemHint<MH>::SA, true> io(st, sto, tile, lane);
+  const rsrc_t ri = mkbuf(imu, 7u * B8);
+  StepInputs in;
+  if (bc.on & 1) {  // one IMU message for every filter: kernel arguments (wave-uniform branch)
+#pragma unroll
+    for (int i = 0; i < 3; i++) { in.gyro[i] = bc.imu[i]; in.accel[i] = bc.imu[3 + i]; }
+    in.dt = bc.imu[6];
+  } else {
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      in.gyro[i] = ldg(ri, i * B8, bo);
+      in.accel[i] = ldg(ri, (3 + i) * B8, bo);
+    }
+    in.dt = ldg(ri, 6u * B8, bo);
+  }
+#pragma unroll
+  for (int i = 0; i < 3; i++) { in.z[i] = 0.0; in.rd[i] = 1.0; }
+  in.upd = b < (unsigned) B;
+  in.qg = qg; in.qa = qa; in.qbg = qbg; in.qba = qba;
+  if (k.qblk != nullptr) {  // per-filter process noise (wave-uniform branch)
+    const rsrc_t rq = mkbuf(k.qblk, 4u * B8);
+    in.qg = ldg(rq, 0u, bo); in.qa = ldg(rq, B8, bo); in.qbg = ldg(rq, 2u * B8, bo); in.qba = ldg(rq, 3u * B8, bo);
+  }
+  auto ld = [&io](int comp) { return io.ld(comp); };
+  auto stf = [&io](int comp, double v) { io.st(comp, v); };
+  auto sync = []() { __syncthreads(); };
+  auto xrd = [lane](int s) { return xch[s][lane]; };
+  if (role == 0) {
+    io.template need<0, Slots<NS>::ROW_SPLIT>();
+    coop_role_core<NS, true, NoCorr, true, true>(ld, stf, [lane](int s, double v) { xch[s][lane] = v; }, xrd, sync, in, k);
+  } else {
+    // ---- the odometry, on the prior state this role reads anyway ----
+    const long bl_ = b < (unsigned) B ? (long) b : (long) B - 1;  // lanes past the batch read the last robot's inputs, store nothing
+    leg_stage_chain(lin, chain_lds, lane);
+    LegState s;
+    leg_load(s, la.legd, la.legi, la.stride, (long) b, false);     // (the state arrays are padded to whole tiles)
+    double chi[3], bg[3] = { 0.0, 0.0, 0.0 }, wq[4];
+#pragma unroll
+    for (int i = 0; i < 3; i++) chi[i] = io.ld(L::OFF_VEC + 6 + i);
+#pragma unroll
+    for (int i = 0; i < 4; i++) wq[i] = io.ld(L::OFF_QUAT + i);
+    Pose fl_, fr_, delta;
+    float zl, zr;
+    int ncl, ncr;
+    leg_inputs(lin, bl_, (long) B, fl_, fr_, zl, zr, ncl, ncr);
+    ins_update_quat<NS>(chi, bg, wq, in.gyro, in.dt, k);           // world_to_body_ = the head AFTER this pair's IMU step
+    int64_t prev = 0;
+    const double status = leg_update(s, par, la.utime, fl_, fr_, zl, zr, ncl, ncr, wq, delta, prev);
+    if (leg_zero_velocity(s, status)) pose_identity(delta);
+    if (b < (unsigned) B) leg_store(s, la.legd, la.legi, la.stride, (long) b, false);
+    LegMeas m;
+    leg_measurement(delta, status, la.utime, prev, la.r2, la.r2_uncertain, m);
+#pragma unroll
+    for (int i = 0; i < 3; i++) xch[CX::XCH_LEG + i][lane] = m.z[i];
+    xch[CX::XCH_LEG + 3][lane] = m.r;
+    xch[CX::XCH_LEG + 4][lane] = m.valid ? 1.0 : 0.0;
+    if (la.lo_out != nullptr && b < (unsigned) B) {
+#pragma unroll
+      for (int i = 0; i < 3; i++) {
+        la.lo_out[(long) i * B + b] = m.z[i];
+        la.lo_out[(long) (3 + i) * B + b] = m.r;
+      }
+      la.mask_out[b] = m.valid ? 1 : 0;
+    }
+    __syncthreads();  // barrier L
+    in.upd = in.upd && m.valid;
+    io.template need<Slots<NS>::ROW_SPLIT, Slots<NS>::NROW>();
+    coop_role_passive<NS, true, NoCorr, true>(ld, stf, xrd, sync, in, k);
+  }
+}
+
+// The same for 21 states on the four-wave mapping (rbis_quad.hpp).  Role PW owns the state vector and the quaternion and
+// propagates them before barrier A anyway; it runs the odometry first, on the prior state it reads for its process blocks,
+// and publishes (z, R, valid) before that barrier -- role CC reads them behind it: no extra barrier.
+template <int MH>
+__global__ __launch_bounds__(256, 2) void k_step_quad_leg(const double *st, double *sto, int B, const double *__restrict__ imu, double qg,
+                                                          double qa, double qbg, double qba, Consts k, StepBcast bc, LegPar par, LegIn lin,
+                                                          LegStepArgs la)
+{
+  constexpr int NS = 21;
+  using L = Lay<NS>;
+  using SL = Slots<21>;
+  __shared__ double xch[Quad::NXCH_LEG][64];
+  __shared__ double chain_lds[2 * LEG_MAXJ * LEG_REC];
+  const int role = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
+  const unsigned lane = threadIdx.x & 63u;
+  const unsigned tile = xcd_workgroup(k);
+  const unsigned b = tile * 64u + lane;
+  const unsigned bo = b * 8u, B8 = (unsigned) B * 8u;
+  TileIO<21, MemHint<MH>::LA, MemHint<MH>::SA> io(st, sto, tile, lane);
+  // (each role requests its inputs inside its own branch: hoisted above the role switch they cost the four-wave kernel its
+  // registers -- 428 bytes of scratch here, as rbis_kernels.hpp k_step_quad found before)
+  auto inputs = [&]() {
+    const rsrc_t ri = mkbuf(imu, 7u * B8);
+    StepInputs in;
+    if (bc.on & 1) {
+#pragma unroll
+      for (int i = 0; i < 3; i++) { in.gyro[i] = bc.imu[i]; in.accel[i] = bc.imu[3 + i]; }
+      in.dt = bc.imu[6];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 3; i++) {
+        in.gyro[i] = ldg(ri, i * B8, bo);
+        in.accel[i] = ldg(ri, (3 + i) * B8, bo);
+      }
+      in.dt = ldg(ri, 6u * B8, bo);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; i++) { in.z[i] = 0.0; in.rd[i] = 1.0; }
+    in.upd = b < (unsigned) B;
+    in.qg = qg; in.qa = qa; in.qbg = qbg; in.qba = qba;
+    if (k.qblk != nullptr) {
+      const rsrc_t rq = mkbuf(k.qblk, 4u * B8);
+      in.qg = ldg(rq, 0u, bo); in.qa = ldg(rq, B8, bo); in.qbg = ldg(rq, 2u * B8, bo); in.qba = ldg(rq, 3u * B8, bo);
+    }
+    return in;
+  };
+  auto ld = [&io](int comp) { return io.ld(comp); };
+  auto stf = [&io](int comp, double v) { io.st(comp, v); };
+  auto sync = []() { __syncthreads(); };
+  auto xrd = [lane](int s) { return xch[s][lane]; };
+  auto xwr = [lane](int s, double v) { xch[s][lane] = v; };
+  if (role == 0) {
+    const StepInputs in = inputs();
+    io.template need<SL::QROW[0], SL::QROW[1]>();
+    quad_role_cc<true, true>(ld, stf, xwr, xrd, sync, in, k);
+  } else if (role == 1) {
+    const StepInputs in = inputs();
+    io.template need<SL::QROW[1], SL::QROW[2]>();
+    quad_role_cb<true>(ld, stf, xwr, xrd, sync, in, k);
+  } else if (role == 2) {
+    StepInputs in = inputs();
+    const long bl_ = b < (unsigned) B ? (long) b : (long) B - 1;
+    leg_stage_chain(lin, chain_lds, lane);
+    LegState s;
+    leg_load(s, la.legd, la.legi, la.stride, (long) b, false);
+    double chi[3], bg[3], wq[4];
+#pragma unroll
+    for (int i = 0; i < 3; i++) { chi[i] = io.ld(L::OFF_VEC + 6 + i); bg[i] = io.ld(L::OFF_VEC + 15 + i); }
+#pragma unroll
+    for (int i = 0; i < 4; i++) wq[i] = io.ld(L::OFF_QUAT + i);
+    Pose fl_, fr_, delta;
+    float zl, zr;
+    int ncl, ncr;
+    leg_inputs(lin, bl_, (long) B, fl_, fr_, zl, zr, ncl, ncr);
+    ins_update_quat<NS>(chi, bg, wq, in.gyro, in.dt, k);
+    int64_t prev = 0;
+    const double status = leg_update(s, par, la.utime, fl_, fr_, zl, zr, ncl, ncr, wq, delta, prev);
+    if (leg_zero_velocity(s, status)) pose_identity(delta);
+    if (b < (unsigned) B) leg_store(s, la.legd, la.legi, la.stride, (long) b, false);
+    LegMeas m;
+    leg_measurement(delta, status, la.utime, prev, la.r2, la.r2_uncertain, m);
+#pragma unroll
+    for (int i = 0; i < 3; i++) xch[Quad::X_LEG + i][lane] = m.z[i];
+    xch[Quad::X_LEG + 3][lane] = m.r;
+    xch[Quad::X_LEG + 4][lane] = m.valid ? 1.0 : 0.0;
+    if (la.lo_out != nullptr && b < (unsigned) B) {
+#pragma unroll
+      for (int i = 0; i < 3; i++) {
+        la.lo_out[(long) i * B + b] = m.z[i];
+        la.lo_out[(long) (3 + i) * B + b] = m.r;
+      }
+      la.mask_out[b] = m.valid ? 1 : 0;
+    }
+    in.upd = in.upd && m.valid;
+    reload_fence();  // the panel rows are requested HERE, not above the odometry (the two do not fit the registers together)
+    io.template need<SL::QROW[2], SL::QROW[3]>();
+    quad_role_passive<true, 0>(ld, stf, xwr, xrd, sync, in, k);
+  } else {
+    const StepInputs in = inputs();
+    io.template need<SL::QROW[3], SL::QROW[4]>();
+    quad_role_passive<true, 1>(ld, stf, xwr, xrd, sync, in, k);
+  }
+}
+#endif
+
+}  // namespace pb

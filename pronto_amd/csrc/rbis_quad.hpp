@@ -37,6 +37,7 @@ struct Quad {
   static constexpr int X_H2 = 72;  // the F_cb T1^T part of H: chi-v block (9, row-major), chi-chi block (6, packed)
   static constexpr int X_XV = 87;  // the propagated velocity x'[3..5] (role PW -> role CC, for the residual)
   static constexpr int NXCH = 90;
+  static constexpr int X_LEG = 90, NXCH_LEG = 95;  // k_step_quad_leg: z[3], R, valid from the odometry (role PW) before barrier A
 };
 
 // (X hat(m)^T)[r][c] = (m x X_r)[c] for a row-major 3x3 block X
@@ -65,7 +66,8 @@ PB_HD void fcc_apply(const ProcBlocks &f, double (&V)[9], double (&Cc)[9], doubl
 // ------------------------------------------------------------------------------------------------------------
 // wave 0, role CC: P_cc, loglik
 // ------------------------------------------------------------------------------------------------------------
-template <bool UPDATE, class LD, class ST, class XW, class XR, class SYNC>
+// LEG: the leg-odometry measurement is made by role PW of the same tile before barrier A (k_step_quad_leg, rbis_legstep.hpp)
+template <bool UPDATE, bool LEG = false, class LD, class ST, class XW, class XR, class SYNC>
 PB_HD void quad_role_cc(LD ld, ST st, XW xw, XR xr, SYNC sync, const StepInputs &in, const Consts &k)
 {
   constexpr int NS = 21;
@@ -119,6 +121,13 @@ PB_HD void quad_role_cc(LD ld, ST st, XW xw, XR xr, SYNC sync, const StepInputs 
     for (int r = 0; r < 3; r++) Pc[pk(3 + r, 3 + r)] += qgd;
   }
   sync();  // A: H and the propagated velocity are there; every role has consumed the prior x / quat
+  double leg_z[3] = { 0.0, 0.0, 0.0 }, leg_r = 1.0, leg_valid = 0.0;
+  if constexpr (LEG) {  // (read first: this role sits exactly at 256 registers and the allocation is fragile)
+#pragma unroll
+    for (int i = 0; i < 3; i++) leg_z[i] = xr(Quad::X_LEG + i);
+    leg_r = xr(Quad::X_LEG + 3);
+    leg_valid = xr(Quad::X_LEG + 4);
+  }
   double xv[3] = { 0.0, 0.0, 0.0 };
   if constexpr (UPDATE) {
 #pragma unroll
@@ -140,12 +149,22 @@ PB_HD void quad_role_cc(LD ld, ST st, XW xw, XR xr, SYNC sync, const StepInputs 
   if constexpr (UPDATE) {
     // S = R + P[v,v]; unpivoted LDL^T; y = L^-1 r  (rbis.cpp:124-143)
     double resid[3], S[6], d[3], y[3], id[3], yd[3];
+    double mz[3], mr[3];
+    bool mupd = in.upd;
+    if constexpr (LEG) {
+      mupd = in.upd && leg_valid != 0.0;
 #pragma unroll
-    for (int i = 0; i < 3; i++) resid[i] = in.upd ? in.z[i] - xv[i] : 0.0;
+      for (int i = 0; i < 3; i++) { mz[i] = leg_z[i]; mr[i] = leg_r; }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 3; i++) { mz[i] = in.z[i]; mr[i] = in.rd[i]; }
+    }
+#pragma unroll
+    for (int i = 0; i < 3; i++) resid[i] = mupd ? mz[i] - xv[i] : 0.0;
 #pragma unroll
     for (int i = 0; i < 3; i++)
 #pragma unroll
-      for (int j = 0; j <= i; j++) S[pk(i, j)] = Pc[pk(i, j)] + (i == j ? (in.upd ? in.rd[i] : 1.0) : 0.0);
+      for (int j = 0; j <= i; j++) S[pk(i, j)] = Pc[pk(i, j)] + (i == j ? (mupd ? mr[i] : 1.0) : 0.0);
     ldlt<3>(S, d);
     double quad = 0.0, det = 1.0;
 #pragma unroll
@@ -153,8 +172,8 @@ PB_HD void quad_role_cc(LD ld, ST st, XW xw, XR xr, SYNC sync, const StepInputs 
       double s = resid[kk];
 #pragma unroll
       for (int j = 0; j < kk; j++) s -= S[pk(kk, j)] * y[j];
-      y[kk] = in.upd ? s : 0.0;
-      id[kk] = in.upd ? 1.0 / d[kk] : 0.0;
+      y[kk] = mupd ? s : 0.0;
+      id[kk] = mupd ? 1.0 / d[kk] : 0.0;
       yd[kk] = y[kk] * id[kk];
       det *= d[kk];
       quad += s * s * id[kk];
@@ -194,7 +213,7 @@ PB_HD void quad_role_cc(LD ld, ST st, XW xw, XR xr, SYNC sync, const StepInputs 
     }
     // -log(S.determinant()) - r^T S^-1 r (rbis.cpp:142): ONE log of the product, behind everything the other waves or
     // the memory system wait for
-    if (in.upd) ll += -log(det) - quad;
+    if (mupd) ll += -log(det) - quad;
   } else {
 #pragma unroll
     for (int i = 0; i < 9; i++)

@@ -13,10 +13,16 @@ python3 -c "import sys; sys.path.insert(0, 'tests'); import test_cpp_shim as t; 
 EXE=tests/build/shim_sweep_rate
 {
   $EXE 65536 2000 15 0
+  $EXE 65536 2000 15 0 1000000 0 feet two
+  $EXE 65536 2000 15 0 1000000 0 joints
+  $EXE 65536 2000 15 0 1000000 0 joints two
   $EXE 65536 2000 15 32
+  $EXE 65536 2000 15 32 1000000 0 joints
   $EXE 65536 2000 15 0 1000000 32
   $EXE 65536 2000 21 0
+  $EXE 65536 2000 21 0 1000000 0 joints
   $EXE 65536 2000 21 32
 } > $OUT/shim_sweep.txt 2>&1 || exit 12
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $EXE 65536 2000 15 0 > $OUT/trace.txt 2> $OUT/trace.err || exit 13
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $EXE 65536 2000 15 0 1000000 0 joints > $OUT/trace.txt 2> $OUT/trace.err || exit 13
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace21 -- $EXE 65536 2000 21 0 1000000 0 joints > $OUT/trace21.txt 2> $OUT/trace21.err || exit 14
 echo "shim rate done"

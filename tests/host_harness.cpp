@@ -390,22 +390,11 @@ void hh_fk(int n, const int *type, const double *origin_xyz_rpy, const double *a
   LegChain ch;
   memset(&ch, 0, sizeof ch);
   ch.n[0] = n;
-  for (int j = 0; j < n; j++) {
-    ch.type[0][j] = type[j];
-    const double *o = origin_xyz_rpy + 6 * j;
-    for (int i = 0; i < 3; i++) ch.org_t[0][j][i] = o[i];
-    const double phi = o[3] / 2.0, the = o[4] / 2.0, psi = o[5] / 2.0;
-    double oq[4] = { cos(phi) * cos(the) * cos(psi) + sin(phi) * sin(the) * sin(psi), sin(phi) * cos(the) * cos(psi) - cos(phi) * sin(the) * sin(psi),
-                     cos(phi) * sin(the) * cos(psi) + sin(phi) * cos(the) * sin(psi), cos(phi) * cos(the) * sin(psi) - sin(phi) * sin(the) * cos(psi) };
-    const double qn = sqrt(oq[0] * oq[0] + oq[1] * oq[1] + oq[2] * oq[2] + oq[3] * oq[3]);
-    for (int i = 0; i < 4; i++) ch.org_q[0][j][i] = oq[i] / qn;
-    ch.org_rot[0][j] = (o[3] != 0.0 || o[4] != 0.0 || o[5] != 0.0);
-    const double *a = axis + 3 * j;
-    const double an = sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
-    for (int i = 0; i < 3; i++) ch.axis[0][j][i] = type[j] ? a[i] / an : 0.0;
-  }
+  for (int j = 0; j < n; j++) leg_chain_entry(ch, 0, j, type[j], j, origin_xyz_rpy + 6 * j, axis + 3 * j, 0.0f);
   Pose T;
-  leg_fk(ch, 0, [&](int j) { return angle[j]; }, T);
+  double ang[LEG_MAXJ];
+  leg_angles(ch, 0, [&](int j) { return j < n ? angle[j] : 0.0; }, ang);
+  leg_fk(ch, 0, ang, [&](int j, int f) { return ch.rec[0][j][f]; }, T);
   for (int i = 0; i < 3; i++) t[i] = T.t[i];
   for (int i = 0; i < 4; i++) q[i] = T.q[i];
 }

@@ -206,3 +206,38 @@ def test_measurement_covariances_from_1e_minus_12_to_1e_plus_6(pa, oracle, n, fu
         if k == 0:
             check(est, ob)                 # the extreme updates themselves: full tolerance
     check(est, ob, tol=1e-7)               # ten steps on: the pinned blocks have lost digits on BOTH sides
+
+
+@pytest.mark.parametrize("n", [15, 21])
+def test_store_hazard_regression_thousands_of_launches(pa, n):
+    """a buffer_store_dwordx4 with an SGPR soffset directly followed by a VALU write of one of its data registers
+    stored the NEW value in 16 lanes of the row about once per 1000 launches, until every 16-byte store got an `s_nop 1` tied
+    to its data registers (rbis_kernels.hpp stg2).  The guard: 5 000 launches of the hot step kernel (k_step_coop<15> /
+    k_step_quad for 21 states) plus 1 000 of the tile copy (k_calib_copy) on 64k filters; the same 50-step replay must give
+    the same bits -- every 64-bit word of the 73 / 135 MB state -- 100 times over (pb_state_checksum).
+    (scripts/chk_store_hazard.py checks the same property statically on the ISA; tests/test_isa_hazard.py runs it.)"""
+    import torch
+    B, K, REPS = 65536, 50, 100
+    dev = torch.device("cuda:0")
+    w = Workload(B, n_states=n)
+    vec, quat, P0 = w.initial_state()
+    q4 = w.process_noise()
+    est = pa.BatchEstimator(B, n_states=n)
+    est.history_reserve(1)
+    est.reset(vec, quat, P0)
+    est.state_save(0)
+    blocks = [(torch.from_numpy(w.imu_block(k)).to(dev), *[torch.from_numpy(a).to(dev) for a in w.legodo_block(k)]) for k in range(K)]
+    kernel = est.hot_kernel() if hasattr(est, "hot_kernel") else ""
+    first = None
+    for rep in range(REPS):
+        est.state_restore(0)
+        for imu, lo, mask in blocks:
+            est.step_legodo(imu, lo, mask, q4)
+        cs = est.state_checksum()
+        assert est.calib_copy_checksum(10) == cs, rep   # k_calib_copy: a tile copy with the step kernels' 16-byte accesses
+        if first is None:
+            first = cs
+        assert cs == first, (rep, kernel)
+    s = est.summary()
+    assert s[3] == 0 and np.isfinite(s[0])
+    est.close()

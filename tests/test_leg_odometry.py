@@ -584,3 +584,76 @@ def test_broadcast_joint_state_equals_per_filter_blocks_on_gpu():
         assert rel(x, y) < 1e-9
     for e in ests:
         e.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [15, 21])
+@pytest.mark.parametrize("kind", ["joints_bcast", "joints_dev", "feet_bcast", "feet_host"])
+def test_one_call_pair_equals_the_two_call_sequence_on_gpu(n, kind):
+    """pb_step_legodo_joints / pb_step_legodo_feet -- IMU step, odometry slaved to the state after it, lin_rate update: ONE
+    kernel for 15 states (k_step_leg: the odometry runs in the passive-panel wave of each tile), two launches inside the call
+    for 21 -- against pb_legodo_update_joints(after_predict) + pb_step_legodo_split: masks identical, measurement blocks
+    and posteriors to rounding; ragged batch (last tile half full)."""
+    import torch
+    import legs
+    from pronto_amd import batch as pa
+    B, T = 1000, 300
+    dev = torch.device("cuda:0")
+    chain = legs.chain_arrays(legs.ATLAS_LEFT, legs.ATLAS_RIGHT, legs.ATLAS_ROWS)
+    gain = np.array([7000, 10000, 10000, 10000, 10000, 10000] * 2, dtype=np.float32)
+    w = Workload(B, n_states=n, dt_us=2000)
+    vec, quat, P0 = w.initial_state()
+    q4 = w.process_noise()
+    ests = []
+    for _ in range(2):
+        e = pa.BatchEstimator(B, n_states=n)
+        e.reset(vec, quat, P0)
+        e.legodo_init(*SCHMITT, True)
+        e.legodo_set_chain(*chain, gain)
+        e.legodo_set_zero_initial_velocity(4)
+        ests.append(e)
+    two, one = ests
+    assert ("k_step_coop<15" in one.hot_kernel()) == (n == 15)
+    lo = [torch.zeros((6, B), dtype=torch.float64, device=dev) for _ in range(2)]
+    mk = [torch.zeros(B, dtype=torch.uint8, device=dev) for _ in range(2)]
+    bcast = kind.endswith("bcast")
+    n_upd = 0
+    src = legs.joint_gait(1 if bcast else B, T, seed=21) if kind.startswith("joints") else gait(1 if bcast else B, T, seed=21)
+    for k, msg in enumerate(src):
+        imu = w.imu_block(k)
+        imu_in = np.ascontiguousarray(imu[:, 0]) if bcast else torch.from_numpy(imu).to(dev)
+        if kind.startswith("joints"):
+            utime, jp, je, forces, _ = msg
+            if bcast:
+                a = (np.ascontiguousarray(jp[:, 0]), np.ascontiguousarray(je[:, 0]), np.ascontiguousarray(forces[:, 0]))
+            else:
+                a = tuple(torch.from_numpy(x).to(dev) for x in (jp, je, forces))
+            two.legodo_update_joints(utime, *a, *R_VXYZ, None, None, lo[0], mk[0], after_predict=imu_in)
+            two.step_legodo(imu_in, lo[0], mk[0], q4)
+            one.step_legodo_joints(imu_in, q4, utime, *a, *R_VXYZ, lo[1], mk[1])
+        else:
+            utime, feet, forces, _ = msg
+            if bcast:
+                a = (np.ascontiguousarray(feet[:, 0]), np.ascontiguousarray(forces[:, 0]))
+            else:
+                a = (feet, forces)          # host blocks, staged over PCIe
+            two.legodo_update(utime, *a, *R_VXYZ, None, None, lo[0], mk[0], after_predict=imu_in)
+            two.step_legodo(imu_in, lo[0], mk[0], q4)
+            one.step_legodo_feet(imu_in, q4, utime, *a, *R_VXYZ, lo[1], mk[1])
+        ma, mb = mk[0].cpu().numpy(), mk[1].cpu().numpy()
+        assert np.array_equal(ma, mb), k
+        on = ma.astype(bool)
+        la, lb = lo[0].cpu().numpy(), lo[1].cpu().numpy()
+        assert np.max(np.abs(la[:, on] - lb[:, on]), initial=0.0) < 1e-9, k
+        n_upd += int(on.sum())
+    assert n_upd > B * T // 10
+    from util import rel
+    for x, y in zip(two.get_head(), one.get_head()):
+        assert rel(x, y) < 1e-10
+    for b in (0, B - 1):
+        pa_, ia = two.legodo_get(b)
+        pb_, ib = one.legodo_get(b)
+        assert ia == ib and np.max(np.abs(pa_ - pb_)) < 1e-10
+    # without the measurement outputs (no history to replay): same posterior
+    for e in ests:
+        e.close()
