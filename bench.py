@@ -155,15 +155,34 @@ def spawn_ranks(n):
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr))
-    out0, _ = procs[0].communicate()
-    rcs = [procs[0].returncode]
-    for p in procs[1:]:
-        try:
-            rcs.append(p.wait(timeout=600 if rcs[0] == 0 else 20))
-        except subprocess.TimeoutExpired:
-            p.kill()
-            rcs.append(-9)
-    sys.stdout.write(out0.decode())
+    # rank 0's stdout is drained on a thread; ALL children are polled, and the first one that fails takes the others down at
+    # once (a rank that dies before the rendezvous would otherwise leave the rest in init_process_group until its timeout)
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    rcs = [None] * n
+    deadline = time.time() + float(os.environ.get("PRONTO_BENCH_TIMEOUT_S", "1500"))
+    while any(rc is None for rc in rcs):
+        for r, p in enumerate(procs):
+            if rcs[r] is None:
+                rcs[r] = p.poll()
+        failed = [r for r, rc in enumerate(rcs) if rc not in (None, 0)]
+        if failed or time.time() > deadline:
+            for r, p in enumerate(procs):
+                if rcs[r] is None:
+                    p.terminate()
+            for r, p in enumerate(procs):
+                if rcs[r] is None:
+                    try:
+                        rcs[r] = p.wait(timeout=10)
+                    except subprocess.TimeoutExpired:
+                        p.kill()
+                        rcs[r] = -9
+            break
+        time.sleep(0.05)
+    reader.join(timeout=5)
+    sys.stdout.write(b"".join(c for c in chunks if c).decode())
     sys.stdout.flush()
     bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
     if bad:
@@ -214,8 +233,12 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cache-busting", action="store_true", help="skip the 1 M-filter true-HBM leg (N=1 only)")
-    ap.add_argument("--min-timed-ms", type=float, default=50.0,
-                    help="the K timed steps are repeated until the timed region is at least this long")
+    ap.add_argument("--min-timed-ms", type=float, default=1000.0,
+                    help="the K timed steps are repeated until the timed region is at least this long (1 s by default, for "
+                         "the 64k leg and the 1 M-filter leg alike: long enough for an external GPU-busy sampler to see it)")
+    ap.add_argument("--host-streams", action="store_true",
+                    help="generate the input streams with the numpy generator on the host (pronto_amd/synth.py) instead of "
+                         "on the device (pronto_amd/synth_device.py: the same counter-based samples)")
     ap.add_argument("--fused", type=int, default=0, metavar="T",
                     help="also time the time-fused replay kernel (T steps per launch, state resident in registers) and "
                          "report it under its own accounting in a 'fused' object; never the headline value")
@@ -242,8 +265,10 @@ def main():
     #   PRONTO_BENCH_REHEARSE=dry  no GPU at all: rendezvous + one all-reduce over gloo, rank 0 prints a stub line (the
     #                              CPU test of the self-spawn logic, tests/test_shard_dist.py).
     rehearse = os.environ.get("PRONTO_BENCH_REHEARSE", "")
+    import datetime
+    RDV_TIMEOUT = datetime.timedelta(seconds=float(os.environ.get("PRONTO_BENCH_RDV_TIMEOUT_S", "300")))
     if rehearse == "dry":
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=RDV_TIMEOUT)
         t = torch.tensor([float(rank + 1)], dtype=torch.float64)
         dist.all_reduce(t)
         if rank == 0:
@@ -263,9 +288,9 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         if rehearse == "1":
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=RDV_TIMEOUT)
         else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=RDV_TIMEOUT)
 
     n, K, W = args.n_states, args.steps, args.warmup
     Bper = args.batch_per_gpu
@@ -275,6 +300,7 @@ def main():
     dt_us = 1000
 
     # ---- synthetic streams for this shard, resident in HBM before the timed region ----
+    t_gen = time.perf_counter()
     w = Workload(B, b0=b0, n_states=n, dt_us=dt_us)
     vec, quat, P0 = w.initial_state()
     q4 = w.process_noise()
@@ -283,12 +309,23 @@ def main():
     d_lo = torch.empty((T, 6, B), dtype=torch.float64, device=dev)
     d_mask = torch.empty((T, B), dtype=torch.uint8, device=dev)
     CH = 16
-    for s in range(0, T, CH):
-        e = min(T, s + CH)
-        imu, lo, mask = w.streams(s, e - s)
-        d_imu[s:e].copy_(torch.from_numpy(imu))
-        d_lo[s:e].copy_(torch.from_numpy(lo))
-        d_mask[s:e].copy_(torch.from_numpy(mask))
+    if args.host_streams:
+        for s in range(0, T, CH):
+            e = min(T, s + CH)
+            imu, lo, mask = w.streams(s, e - s)
+            d_imu[s:e].copy_(torch.from_numpy(imu))
+            d_lo[s:e].copy_(torch.from_numpy(lo))
+            d_mask[s:e].copy_(torch.from_numpy(mask))
+    else:
+        # the same counter-based samples made on this rank's GPU: N ranks on one host do not queue up behind numpy
+        from pronto_amd.synth_device import DeviceWorkload
+        dw = DeviceWorkload(B, b0=b0, n_states=n, dt_us=dt_us, device=dev)
+        for s in range(0, T, CH):
+            e = min(T, s + CH)
+            d_imu[s:e], d_lo[s:e], d_mask[s:e] = dw.streams(s, e - s)
+        del dw
+    torch.cuda.synchronize()
+    t_gen = time.perf_counter() - t_gen
 
     est = BatchEstimator(B, n_states=n, device=local_rank)
     est.reset(vec, quat, P0)
@@ -329,8 +366,11 @@ def main():
     barrier()
     t1 = time.perf_counter()
     wall = torch.tensor([t1 - t0, ev_ms * 1e-3], dtype=torch.float64, device=cdev)
+    # per-rank spread of the HIP-event time of the timed launches and of the stream generation: (max, -min) through one MAX
+    spread = torch.tensor([ev_ms, -ev_ms, t_gen, -t_gen], dtype=torch.float64, device=cdev)
     if use_dist:
         dist.all_reduce(wall, op=dist.ReduceOp.MAX)
+        dist.all_reduce(spread, op=dist.ReduceOp.MAX)
     wall_s, ev_s = float(wall[0]), float(wall[1])
     KR = K * reps
 
@@ -372,6 +412,9 @@ def main():
             "ms_per_step": wall_s / KR * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "repeats": reps, "timed_steps": KR, "timed_region_ms": wall_s * 1e3,
+            "per_rank_ms": {"kernel_time_max": float(spread[0]), "kernel_time_min": -float(spread[1]),
+                            "stream_generation_max": float(spread[2]) * 1e3, "stream_generation_min": -float(spread[3]) * 1e3,
+                            "streams": "host numpy" if args.host_streams else "device (pronto_amd/synth_device.py)"},
             "config": {"workload": "64k batched 15-state filters, IMU predict + 3-DoF leg-odom update, 1 MI355X"
                        if (n == 15 and Bper == 65536) else
                        "%d batched %d-state filters per GPU, IMU predict + 3-DoF leg-odom update" % (Bper, n),

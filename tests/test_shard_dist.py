@@ -145,3 +145,27 @@ def test_bench_rccl_path_with_a_single_rank():
     with world size 1 -- the transport the multi-GPU run uses, as far as one card can exercise it."""
     out = _bench_line({"PRONTO_BENCH_FORCE_DIST": "1", "MASTER_PORT": "29547"})
     assert out["n_gpus"] == 1 and out["summary"]["nonfinite"] == 0 and out["value"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_four_ranks_on_one_card_rehearsal_is_quick_and_equals_one_rank():
+    """More ranks than the two-rank rehearsal: four self-spawned ranks x 8192 filters on GPU 0 (the GPU box allows at most six
+    processes on its card at once, this test runner included, so eight cannot be rehearsed here) against one rank with all
+    32 768 filters; every rank makes its streams on the device (per_rank_ms reports the spread), and start-to-JSON stays far
+    below the two minutes eight ranks are allowed."""
+    import time
+    t0 = time.time()
+    four = _bench_line({"PRONTO_BENCH_REHEARSE": "1"}, "--gpus", "4", "--batch-per-gpu", "8192")
+    took = time.time() - t0
+    one = _bench_line({}, "--batch-per-gpu", "32768")
+    assert four["n_gpus"] == 4 and took < 120, took
+    pr = four["per_rank_ms"]
+    assert pr["streams"].startswith("device") and 0 < pr["kernel_time_min"] <= pr["kernel_time_max"]
+    assert pr["stream_generation_max"] < 30e3
+    a, b = four["summary"], one["summary"]
+    assert abs(a["sum_loglik"] - b["sum_loglik"]) <= 1e-9 * abs(b["sum_loglik"])
+    assert abs(a["checksum_abs"] - b["checksum_abs"]) <= 1e-12 * abs(b["checksum_abs"])
+    assert a["nonfinite"] == 0
+    # the host generator gives the same workload (to rounding of the device's sin / log)
+    host = _bench_line({}, "--batch-per-gpu", "32768", "--host-streams")
+    assert abs(host["summary"]["checksum_abs"] - b["checksum_abs"]) <= 1e-9 * abs(b["checksum_abs"])
