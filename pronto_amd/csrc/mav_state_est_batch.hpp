@@ -28,6 +28,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <iterator>
 #include <map>
 #include <memory>
 #include <string>
@@ -636,6 +637,51 @@ public:
     std::vector<double> ll(B);
     last_status = pb_get_head(ctx, 0, B, nullptr, nullptr, nullptr, ll.data(), PB_HOST);
     return ll;
+  }
+
+  // (position, quaternion) of the posterior of the update at `it` into device snapshot slot `snap_slot`: what the reference
+  // reads as lower_it->second->posterior_state (rbis_fovis_update.cpp:196-206) -- every update keeps its posterior there.
+  // Here only every checkpoint_every-th update (and never the INS half of a fused pair) has a saved posterior; for the others
+  // it is re-derived: the nearest earlier checkpoint into the context's own array, the updates up to `it` re-applied, the
+  // snapshot taken, and the head put back.  Costs at most checkpoint_every re-applied updates per call; FovisHandler calls it
+  // once per keyframe change.  false: `it` has not been applied yet, or no slot is free to park the head in.
+  int64_t rederived_posteriors = 0;
+  bool snapshotPosteriorOf(updateHistory::historyMapIterator it, int snap_slot)
+  {
+    auto &map = history.updateMap;
+    flushPending();
+    for (auto u = unprocessed_updates_start; u != map.end(); ++u)
+      if (u == it) return false;  // (added without roll_forward: no posterior exists yet)
+    auto ck = checkpoint_of.find(it->second);
+    if (ck != checkpoint_of.end()) return (last_status = pb_snapshot_from_slot(ctx, snap_slot, ck->second)) == PB_OK;
+    if (it->second == device_head) return (last_status = pb_snapshot(ctx, snap_slot)) == PB_OK;
+    // where the head goes meanwhile: its own checkpoint if it has one, else a spare slot
+    int park = -1;
+    bool park_is_spare = false;
+    auto hk = device_head ? checkpoint_of.find(device_head) : checkpoint_of.end();
+    if (hk != checkpoint_of.end()) park = hk->second;
+    else if (!free_slots.empty()) {
+      park = free_slots.back();
+      free_slots.pop_back();
+      park_is_spare = true;
+      if ((last_status = pb_state_save(ctx, park)) != PB_OK) return false;
+    } else {
+      return false;
+    }
+    auto origin = it;
+    while (checkpoint_of.find(origin->second) == checkpoint_of.end()) --origin;  // begin() always has one
+    int rc = pb_state_restore(ctx, checkpoint_of[origin->second]);
+    for (auto u = std::next(origin); rc == PB_OK; ++u) {
+      rc = u->second->updateFilter(ctx);
+      if (u == it) break;
+    }
+    if (rc == PB_OK) rc = pb_snapshot(ctx, snap_slot);
+    const int rc2 = pb_state_restore(ctx, park);   // the head again (a copy in the context's own array)
+    if (park_is_spare) free_slots.push_back(park);
+    pb_set_utime(ctx, head_utime);
+    rederived_posteriors++;
+    if (rc != PB_OK || rc2 != PB_OK) last_status = rc != PB_OK ? rc : rc2;
+    return rc == PB_OK && rc2 == PB_OK;
   }
 
   // EKFSmoothBackwardsPass (mav_state_est.cpp:98-189): walk the history backwards; at every INS update k apply
@@ -2271,14 +2317,12 @@ public:
         fprintf(stdout, "FOIVS: time difference for VO delta root pose is too great (%fsec). Will not use\n", diff_utime);
         return nullptr;
       }
-      auto ck = est->checkpoint_of.find(lower_it->second);
-      if (ck == est->checkpoint_of.end()) {
-        fprintf(stdout, "FovisHandler: no saved posterior for the update at %lld (history_checkpoint_every > 1, or not applied "
-                        "yet). Will not use\n", (long long) lower_it->first);
-        return nullptr;
-      }
-      if (pb_snapshot_from_slot(est->ctx, slot, ck->second) != PB_OK) {
-        fprintf(stderr, "FovisHandler: %s\n", pb_last_error(est->ctx));
+      // lower_it->second->posterior_state (:196-206): from that update's checkpoint, or re-derived from the nearest earlier
+      // one when the checkpoints are sparser than the updates (history_checkpoint_every > 1, the default for a configuration
+      // that only sets utime_history_span) or the update is the INS half of a fused pair
+      if (!est->snapshotPosteriorOf(lower_it, slot)) {
+        fprintf(stdout, "FovisHandler: the posterior of the update at %lld cannot be had (not applied yet, or no free checkpoint "
+                        "slot): %s. Will not use\n", (long long) lower_it->first, pb_last_error(est->ctx));
         return nullptr;
       }
       prev_t0_body_utime_ = msg->prev_timestamp;  // :213

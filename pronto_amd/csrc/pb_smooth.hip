@@ -4,7 +4,15 @@
 
 int pbk_smooth_step(pb_ctx *c, const double *np_, const double *ns_, const double *cu, double *out, double dt)
 {
-  static const size_t pad = getenv("PRONTO_SMOOTH_LDS_PAD") ? (size_t) atoi(getenv("PRONTO_SMOOTH_LDS_PAD")) : 0;  // EXPERIMENT
+#ifdef PB_EXPERIMENTS  // attribution builds only (scripts/smooth_attribution.sh): extra dynamic LDS to force fewer workgroups per CU
+  static const size_t pad = [] {
+    const char *e = getenv("PRONTO_SMOOTH_LDS_PAD");
+    const long v = e ? atol(e) : 0;
+    return (size_t) (v < 0 ? 0 : (v > 65536 ? 65536 : v));
+  }();
+#else
+  constexpr size_t pad = 0;
+#endif
   if (!c->smooth_attr) {  // more than the default 64 KB of dynamic LDS per workgroup
     HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_smooth_reg<15>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int) (pad + sizeof(double) * SmoothRegCfg<15>::LDS_DOUBLES)));

@@ -15,6 +15,11 @@
 // Build flags SM_SKIP_* / SM_NO_* / SM_COPY_ONLY / SM_EMPTY compile parts out for scripts/smooth_attribution.sh (timing only).
 #pragma once
 
+#if !defined(PB_EXPERIMENTS) && (defined(SM_EMPTY) || defined(SM_NO_LOAD) || defined(SM_NO_STORE) || defined(SM_COPY_ONLY) || \
+                                 defined(SM_SKIP_QUAT) || defined(SM_SKIP_FACT) || defined(SM_SKIP_SUBST) || defined(SM_SKIP_PROD))
+#error "the SM_* attribution flags compile parts of the smoother OUT (garbage results): they need -DPB_EXPERIMENTS as well"
+#endif
+
 #include <hip/hip_runtime.h>
 
 #include <type_traits>

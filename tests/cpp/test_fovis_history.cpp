@@ -2,6 +2,11 @@
 // (rbis_fovis_update.cpp:177-213: T0 = posterior of history.updateMap.lower_bound(prev_timestamp), at most 25 ms later,
 // cached while prev_timestamp does not change), with posterior checkpoints on and NO manual markKeyframe.  The oracle keeps
 // the posterior after every update and takes T0 from the same place.  Exit code 0 + "PASS".  Needs a GPU.
+//   argv[1] = "derived": only utime_history_span is set (every reference .cfg): 32 checkpoint slots with a derived
+//             history_checkpoint_every > 1, so most look-ups land on an update WITHOUT a saved posterior, which the
+//             estimator re-derives from the nearest earlier checkpoint (MavStateEstimator::snapshotPosteriorOf);
+//   argv[1] = "fuse": fuse_ins_legodo with a leg-odometry update behind every INS step (same utime): the look-up lands on
+//             the INS half of a fused pair, which never has a checkpoint of its own.
 #include <cinttypes>
 #include <cstdio>
 #include <vector>
@@ -19,14 +24,20 @@ static double urand()
 }
 static double nrand() { return sqrt(-2 * log(urand())) * cos(2 * M_PI * urand()); }
 
-int main()
+int main(int argc, char **argv)
 {
+  const std::string variant = argc > 1 ? argv[1] : "";
+  const bool derived = variant == "derived", fuse = variant == "fuse";
   const int n = 15, B = 70, T = 60;
   double g;
   po_get_constants(&g, nullptr);
   BotParam param;
   param.set("state_estimator.utime_history_span", "40000");  // 40 ms window
-  param.set("state_estimator.history_slots", "64");
+  if (!derived) param.set("state_estimator.history_slots", "64");
+  param.set("state_estimator.fuse_ins_legodo", fuse ? "true" : "false");
+  param.applyOverrides("state_estimator.legodo.mode=lin_rate|state_estimator.legodo.r_xyz=0.2|state_estimator.legodo.r_vxyz=0.3|"
+                       "state_estimator.legodo.r_vang=0.3|state_estimator.legodo.r_vxyz_uncertain=0.5|state_estimator.legodo.r_vang_uncertain=0.9|"
+                       "state_estimator.legodo.zero_initial_velocity=0");
   param.set("state_estimator.ins.channel", "IMU");
   param.set("state_estimator.ins.q_gyro", 0.5);
   param.set("state_estimator.ins.q_accel", 0.1);
@@ -37,7 +48,7 @@ int main()
   param.set("state_estimator.ins.accel_bias_update_online", "false");
   param.set("state_estimator.ins.gyro_bias_update_online", "false");
   param.applyOverrides("state_estimator.fovis.mode=position_orient|state_estimator.fovis.r_pxyz=0.02|state_estimator.fovis.r_chi=0.01");
-  for (const char *s : { "ins", "fovis" }) {
+  for (const char *s : { "ins", "fovis", "legodo" }) {
     param.set(std::string("state_estimator.") + s + ".downsample_factor", "1");
     param.set(std::string("state_estimator.") + s + ".roll_forward_on_receive", "true");
     param.set(std::string("state_estimator.") + s + ".utime_offset", "0");
@@ -63,6 +74,8 @@ int main()
   FrontEnd front_end(&param);
   auto on_ins = front_end.addSensor("ins", &InsHandler::processMessage, &ins_handler);
   auto on_fovis = front_end.addSensor("fovis", &FovisHandler::processMessage, &fovis_handler);
+  LegOdoHandler legodo_handler(&param);
+  auto on_legodo = front_end.addSensor("legodo", &LegOdoHandler::processMessageDelta, &legodo_handler);
   MavStateEstimator est(new RBISResetUpdate(x0, P0, RBISUpdateInterface::reset, 0), &param, 0);
   front_end.setStateEstimator(&est);
   const double q4[4] = { ins_handler.cov_gyro, ins_handler.cov_accel, ins_handler.cov_gyro_bias, ins_handler.cov_accel_bias };
@@ -83,6 +96,24 @@ int main()
     on_ins(&im);
     for (int b = 0; b < B; b++) po_imu_process_step(v, v + 3, 0.001, q4[0], q4[1], q4[2], q4[3], &ox[b], &oP[b], oll[b], &ox[b], &oP[b], &oll[b]);
     record(utime);
+    if (fuse) {  // a leg-odometry increment with the INS message's utime: the pair runs as one fused kernel
+      std::vector<double> dtr(3 * B);
+      std::vector<float> st(B, 0.f);
+      for (int b = 0; b < B; b++)
+        for (int i = 0; i < 3; i++) dtr[i * B + b] = 0.001 * (ox[b].vec[3 + i] + 0.1 * nrand());
+      msgs::legodo_delta_t lm{ utime, utime - 1000, nullptr, dtr.data(), nullptr, nullptr, st.data() };
+      on_legodo(&lm);
+      const double r5[5] = { 0.2, 0.3, 0.3, 0.5, 0.9 }, dq[4] = { 1, 0, 0, 0 }, p3[3] = { 0, 0, 0 };
+      for (int b = 0; b < B; b++) {
+        const double d3[3] = { dtr[b], dtr[B + b], dtr[2 * B + b] };
+        int idx[6];
+        double z[6], Rd[6], R[36] = { 0 };
+        const int m = po_legodo_create_measurement(0, r5, p3, d3, dq, utime, utime - 1000, 1, 0.f, idx, z, Rd);
+        for (int i = 0; i < m; i++) R[i * m + i] = Rd[i];
+        po_indexed_update(m, idx, z, R, &ox[b], &oP[b], oll[b], &ox[b], &oP[b], &oll[b]);
+      }
+      record(utime);
+    }
     if (k % 6 == 5) {
       // the keyframe changes every second VO message: it is an instant 300 us after an IMU message 4-5 ms ago, so the
       // look-up lands on the NEXT update (700 us later); at k == 41 it points 30 ms back -> outside the 40 ms window's
@@ -132,9 +163,13 @@ int main()
     el = fmax(el, fabs(ll[b] - oll[b]));
     sl = fmax(sl, fabs(oll[b]));
   }
-  printf("%d VO messages, %d keyframe changes looked up in the history, %d rejected: rel err vec %.2e quat %.2e cov %.2e ll %.2e "
-         "(status %d)\n", n_vo, n_key_changes, n_rejected, ev / sv, eq, eP / sP, el / sl, est.last_status);
-  const bool ok = est.last_status == PB_OK && n_vo == T / 6 && n_key_changes >= 4 && n_rejected == 1 && ev / sv < 1e-9 && eq < 1e-9 &&
+  printf("%s: %d VO messages, %d keyframe changes looked up in the history (%lld posteriors re-derived, checkpoint every %d, %lld fused pairs), "
+         "%d rejected: rel err vec %.2e quat %.2e cov %.2e ll %.2e (status %d)\n", variant.c_str(), n_vo, n_key_changes,
+         (long long) est.rederived_posteriors, est.checkpoint_every, (long long) est.fused_pairs, n_rejected, ev / sv, eq, eP / sP, el / sl,
+         est.last_status);
+  const bool variant_ok = (!derived || (est.checkpoint_every > 1 && est.rederived_posteriors >= 2)) &&
+                          (!fuse || (est.fused_pairs > T / 2 && est.rederived_posteriors >= 2));
+  const bool ok = variant_ok && est.last_status == PB_OK && n_vo == T / 6 && n_key_changes >= 4 && n_rejected == 1 && ev / sv < 1e-9 && eq < 1e-9 &&
                   eP / sP < 1e-9 && el / sl < 1e-9;
   printf(ok ? "PASS\n" : "FAIL\n");
   return ok ? 0 : 1;

@@ -61,11 +61,14 @@ def test_lcm_log_replay_and_filter_state_publishing_on_gpu(oracle, tmp_path):
 
 
 @pytest.mark.gpu
-def test_fovis_keyframe_lookup_in_history_on_gpu(oracle):
+@pytest.mark.parametrize("variant", ["", "derived", "fuse"])
+def test_fovis_keyframe_lookup_in_history_on_gpu(oracle, variant):
     """FovisHandler with posterior checkpoints on: T0 comes from history.updateMap.lower_bound(prev_timestamp) like in the
-    reference (25 ms rule, cached per keyframe, 'at the end' rejection), no manual keyframe marking."""
+    reference (25 ms rule, cached per keyframe, 'at the end' rejection), no manual keyframe marking.  "derived": only
+    utime_history_span is configured (sparse default checkpoints), "fuse": the look-up lands on the INS half of a fused
+    pair -- in both the posterior has no checkpoint and is re-derived from the nearest earlier one."""
     exe = build_exe(oracle, "test_fovis_history")
-    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    r = subprocess.run([exe] + ([variant] if variant else []), capture_output=True, text=True, timeout=300)
     print(r.stdout[-2000:], r.stderr[-2000:])
     assert r.returncode == 0 and "PASS" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
 
