@@ -16,7 +16,8 @@
 #pragma once
 
 #if !defined(PB_EXPERIMENTS) && (defined(SM_EMPTY) || defined(SM_NO_LOAD) || defined(SM_NO_STORE) || defined(SM_COPY_ONLY) || \
-                                 defined(SM_SKIP_QUAT) || defined(SM_SKIP_FACT) || defined(SM_SKIP_SUBST) || defined(SM_SKIP_PROD))
+                                 defined(SM_SKIP_QUAT) || defined(SM_SKIP_FACT) || defined(SM_SKIP_SUBST) || defined(SM_SKIP_PROD) || \
+                                 defined(SM_OCC3))
 #error "the SM_* attribution flags compile parts of the smoother OUT (garbage results): they need -DPB_EXPERIMENTS as well"
 #endif
 
@@ -81,7 +82,11 @@ struct SmoothRegCfg {
   // small per-filter buffer of four RBW-wide slots: pivot row of the current step (entry NS = dummy for the padding
   // lanes), reciprocal pivots, residual, dx
   static constexpr int RBW = (NS + 2) & ~1, RB_INV = RBW, RB_RES = 2 * RBW, RB_DX = 3 * RBW, RB = bank_stride(4 * RBW);
+#ifdef SM_OCC3
+  static constexpr int LDS_DOUBLES = F * RB + U_DOUBLES;
+#else
   static constexpr int LDS_DOUBLES = F * RB + U_DOUBLES + F * D_PER;
+#endif
 };
 
 // 16-byte LDS access: p must be an even number of doubles from the (16-byte aligned) start of LDS
@@ -152,8 +157,16 @@ __device__ __forceinline__ unsigned rowpair_min(unsigned v)
   return x[0] < x[1] ? x[0] : x[1];
 }
 
+// SM_OCC3 (attribution build, garbage results): what a THIRD workgroup per CU would buy with this instruction stream -- the D
+// buffer aliases the gain buffer (LDS per workgroup 77.6 -> 43 KB for 15 states) and the register budget is the 168 of three
+// waves per SIMD (whatever does not fit goes to scratch): an upper bound for the restructuring DESIGN.md 4 describes.
+#ifdef SM_OCC3
+#define PB_SMOOTH_WG_PER_CU 3
+#else
+#define PB_SMOOTH_WG_PER_CU 2
+#endif
 template <int NS>
-__global__ __launch_bounds__(256, 2) void k_smooth_reg(const double *__restrict__ next_pred,
+__global__ __launch_bounds__(256, PB_SMOOTH_WG_PER_CU) void k_smooth_reg(const double *__restrict__ next_pred,
                                                     const double *__restrict__ next_sm,
                                                     const double *__restrict__ cur, double *__restrict__ out,
                                                     int B, double dt, Consts k)
@@ -170,7 +183,11 @@ __global__ __launch_bounds__(256, 2) void k_smooth_reg(const double *__restrict_
 #ifdef SM_EMPTY  // workgroup dispatch cost alone: same registers, same LDS request, no work
   if (B > 0) return;
 #endif
+#ifdef SM_OCC3
+  double *U = lds + F * C::RB, *DP = U;
+#else
   double *U = lds + F * C::RB, *DP = U + C::U_DOUBLES;  // [small buffers | staging / x / L / gain | D packed]
+#endif
   const int t = threadIdx.x;
   const int f = t / G, r = t % G;        // compute mapping: filter slot f, matrix row r
   const int sf = t % F, sc = t / F;      // staging mapping: filter fastest

@@ -8,7 +8,7 @@
 set -u
 cd "$(dirname "$0")/.."
 V="full:  fact:-DSM_SKIP_FACT subst:-DSM_SKIP_SUBST prod:-DSM_SKIP_PROD quat:-DSM_SKIP_QUAT \
-   compute:-DSM_SKIP_FACT,-DSM_SKIP_SUBST,-DSM_SKIP_PROD,-DSM_SKIP_QUAT staging_only:-DSM_COPY_ONLY noload:-DSM_NO_LOAD nomem:-DSM_NO_LOAD,-DSM_NO_STORE empty:-DSM_EMPTY"
+   compute:-DSM_SKIP_FACT,-DSM_SKIP_SUBST,-DSM_SKIP_PROD,-DSM_SKIP_QUAT staging_only:-DSM_COPY_ONLY noload:-DSM_NO_LOAD nomem:-DSM_NO_LOAD,-DSM_NO_STORE empty:-DSM_EMPTY occ3:-DSM_OCC3"
 D=gpurun_scratch/smooth_attr
 if [ "${1:-}" = build ]; then
   mkdir -p $D

@@ -92,8 +92,16 @@ int main(int argc, char **argv)
   for (int k = 0; k < T; k++) {
     const int64_t utime = (int64_t) (k + 1) * 1000;
     const double v[6] = { 0.3 * sin(0.05 * k), 0.1, -0.2 * cos(0.03 * k), 0.3 * nrand(), 0.3 * nrand(), g + 0.3 * nrand() };
-    msgs::ins_t im{ utime, BatchArray(v, PB_HOST_BROADCAST), BatchArray(v + 3, PB_HOST_BROADCAST) };
-    on_ins(&im);
+    if (fuse) {  // per-filter host blocks on both sides: the pair the estimator fuses (pb_step_legodo with PB_HOST inputs)
+      std::vector<double> gy(3 * B), ac(3 * B);
+      for (int b = 0; b < B; b++)
+        for (int i = 0; i < 3; i++) { gy[i * B + b] = v[i]; ac[i * B + b] = v[3 + i]; }
+      msgs::ins_t im{ utime, BatchArray(gy.data(), PB_HOST), BatchArray(ac.data(), PB_HOST) };
+      on_ins(&im);
+    } else {
+      msgs::ins_t im{ utime, BatchArray(v, PB_HOST_BROADCAST), BatchArray(v + 3, PB_HOST_BROADCAST) };
+      on_ins(&im);
+    }
     for (int b = 0; b < B; b++) po_imu_process_step(v, v + 3, 0.001, q4[0], q4[1], q4[2], q4[3], &ox[b], &oP[b], oll[b], &ox[b], &oP[b], &oll[b]);
     record(utime);
     if (fuse) {  // a leg-odometry increment with the INS message's utime: the pair runs as one fused kernel
