@@ -20,8 +20,8 @@ PB_CORR_POS_ORIENT, PB_CORR_POS_YAW = 0, 1
 
 
 def sources():
-    return [os.path.join(CSRC, f) for f in ("pronto_batch.hip", "pb_step.hip", "pb_update.hip", "pb_update_ct.hip", "pb_smooth.hip", "pb_ctx.hpp",
-                                            "rbis_kernels.hpp", "rbis_legodo.hpp", "rbis_legstep.hpp", "rbis_coop.hpp", "rbis_quad.hpp", "rbis_smooth.hpp",
+    return [os.path.join(CSRC, f) for f in ("pronto_batch.hip", "pb_step.hip", "pb_update.hip", "pb_update_rt21.hip", "pb_update_ct.hip", "pb_smooth.hip", "pb_ctx.hpp",
+                                            "rbis_kernels.hpp", "rbis_legodo.hpp", "rbis_legstep.hpp", "rbis_coop.hpp", "rbis_quad.hpp", "rbis_quad_rt.hpp", "rbis_smooth.hpp",
                                             "rbis_device.hpp", "Makefile")] + [HEADER]
 
 

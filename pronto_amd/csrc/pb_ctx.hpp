@@ -120,6 +120,13 @@ int pbk_update15(pb_ctx *c, int m, const int *idx, const double *z, const double
                  const double *qm, const uint8_t *mask);
 int pbk_update21(pb_ctx *c, int m, const int *idx, const double *z, const double *R, int rkind, const double *rb,
                  const double *qm, const uint8_t *mask);
+// (pb_update_rt21.hip is built as three objects, by m)
+int pbk_update21_m123(pb_ctx *c, int m, const int *idx, const double *z, const double *R, int rkind, const double *rb, const double *qm,
+                      const uint8_t *mask);
+int pbk_update21_m45(pb_ctx *c, int m, const int *idx, const double *z, const double *R, int rkind, const double *rb, const double *qm,
+                     const uint8_t *mask);
+int pbk_update21_m6(pb_ctx *c, int m, const int *idx, const double *z, const double *R, int rkind, const double *rb, const double *qm,
+                    const uint8_t *mask);
 // pb_update_ct.hip: the same update on the cooperative mapping when idx is one of the handlers' lists and R is diagonal
 // (r2 = [m][B] device diagonal or NULL with rb2 = m broadcast values); -1 = no such kernel, use pbk_update15/21
 // zb / qb: HOST values of a measurement that is the same for every filter (kernel arguments instead of device blocks)

@@ -1,6 +1,5 @@
-// pb_update.hip -- launchers of the generic (run-time index list) update kernels: k_update_lane_rt<15, M, ORIENT, MH> (one lane,
-// the filter in registers) and k_update<21, M, ORIENT, MH> (columns gathered, covariance streamed); compiled twice, with
-// -DPB_UPD_NS=15 and -DPB_UPD_NS=21, into pb_update15.o / pb_update21.o (72 kernel instances in all); see pb_ctx.hpp.
+// pb_update.hip -- launcher of the generic (run-time index list) update of a 15-state batch: k_update_lane_rt<15, M, ORIENT, MH>
+// (one lane, the filter in registers); 21 states: pb_update_rt21.hip.  See pb_ctx.hpp.
 #include "pb_ctx.hpp"
 
 template <int NS, int M, int MH>
@@ -13,11 +12,6 @@ static void launch_update_mh(pb_ctx *c, const IdxArg<M> &ia, const DiagArg<M> &d
       k_update_lane_rt<NS, M, true, MH><<<nblk(c->B), 64, 0, c->stream>>>(c->st, out, c->B, ia, z, R, rkind, da, qm, mask, c->k);
     else
       k_update_lane_rt<NS, M, false, MH><<<nblk(c->B), 64, 0, c->stream>>>(c->st, out, c->B, ia, z, R, rkind, da, qm, mask, c->k);
-  } else {
-    if (qm)
-      k_update<NS, M, true, MH><<<nblk(c->B), 64, 0, c->stream>>>(c->st, out, c->B, ia, z, R, rkind, da, qm, mask, c->k);
-    else
-      k_update<NS, M, false, MH><<<nblk(c->B), 64, 0, c->stream>>>(c->st, out, c->B, ia, z, R, rkind, da, qm, mask, c->k);
   }
   update_done(c, out);
 }
@@ -57,16 +51,8 @@ static int launch_update(pb_ctx *c, int m, const int *idx, const double *z, cons
 }
 
 
-#if PB_UPD_NS == 15
 int pbk_update15(pb_ctx *c, int m, const int *idx, const double *z, const double *R, int rkind, const double *rb,
                  const double *qm, const uint8_t *mask)
 {
   return launch_update<15>(c, m, idx, z, R, rkind, rb, qm, mask);
 }
-#else
-int pbk_update21(pb_ctx *c, int m, const int *idx, const double *z, const double *R, int rkind, const double *rb,
-                 const double *qm, const uint8_t *mask)
-{
-  return launch_update<21>(c, m, idx, z, R, rkind, rb, qm, mask);
-}
-#endif

@@ -332,207 +332,9 @@ struct DiagArg {
   double v[M];
 };
 
-// Storage rows [R0, R1): issue ALL their loads, then downdate the covariance entries in them and store the rows.
-// (Interleaving a load and a store per entry serialises on the load latency: the compiler may not hoist a load above a
-// possibly aliasing store; that version of k_update ran at 0.33-0.45 of the HBM roofline.)  Slots that hold x / quat /
-// loglik are skipped here: their rows complete when the kernel stores the updated state at the end.
-// W here is W |D|^-1/2 (scaled once by the caller) and sg[k] the sign bit of pivot k (0x80000000 or 0):
-// P -= sum_k sign(d_k) (W |D|^-1/2)_ik (W |D|^-1/2)_jk needs ONE array and no per-entry scaling (with W D^-1 formed per
-// entry, common-subexpression elimination kept all NS x M products alive across the chunks: 250+ registers of spills).
-// S is SPD in a healthy filter, but the reference's LDLT takes any symmetric S, so the sign is carried, not assumed.
-__device__ __forceinline__ double flip_sign(double x, unsigned sgbit)
-{
-  return __hiloint2double(__double2hiint(x) ^ (int) sgbit, __double2loint(x));
-}
-// For the largest W (n = 21, m >= 5: 210+ registers) even the flipped operands, which the compiler shares between entries,
-// do not fit: there W is W D^-1 and the term is (W D^-1)_ik (W D^-1)_jk d_k -- two multiplies, nothing shareable.
-template <int NS, int M>
-struct UpdateForm {
-  static constexpr bool SCALED_BY_INVERSE = (NS * M > 90);
-};
-template <int NS, int M, int R0, int R1, class IO>
-__device__ __forceinline__ void downdate_rows(IO &io, const double (&W)[NS][M], const unsigned (&sg)[M], const double (&d)[M])
-{
-  using L = Lay<NS>;
-  using S = Slots<NS>;
-  io.template need<R0, R1>();
-  static_for<2 * (R1 - R0)>([&](auto I) {
-    constexpr int c = S::T.comp_of[2 * R0 + decltype(I)::value];
-    if constexpr (c >= L::OFF_P) {
-      constexpr int i = pk_row(c - L::OFF_P), j = pk_col(c - L::OFF_P);
-      double acc = io.ld(c);
-#pragma unroll
-      for (int kk = 0; kk < M; kk++) {
-        if constexpr (UpdateForm<NS, M>::SCALED_BY_INVERSE) acc = fma(-(W[i][kk] * W[j][kk]), d[kk], acc);
-        else acc = fma(-W[i][kk], flip_sign(W[j][kk], sg[kk]), acc);
-      }
-      io.st(c, acc);
-    }
-  });
-}
-
-// number of equal row chunks the covariance streams through in k_update (register budget: chunk + W + temporaries)
-#ifndef PB_UPD_CHUNKS
-#define PB_UPD_CHUNKS(NS, M) ((NS) == 15 ? ((M) <= 4 ? 3 : 4) : ((M) == 1 ? 3 : (M) == 2 ? 4 : (M) <= 4 ? 5 : 7))
-#endif
-// waves per SIMD the register allocation of k_update is held to
-#ifndef PB_UPD_WAVES
-#define PB_UPD_WAVES(NS, M) ((((NS) == 15 && (M) <= 3) || ((NS) == 21 && (M) <= 2)) ? 2 : 1)
-#endif
-template <int NS, int M>
-struct UpdateChunks {
-  static constexpr int N = PB_UPD_CHUNKS(NS, M);
-};
-
-// Generic RBISIndexedMeasurement / RBISIndexedPlusOrientationMeasurement::updateFilter with a RUNTIME index list
-// (rbis_update_interface.cpp:54-107).  The m gathered columns P[:, idx] (wave-uniform slot addresses, 8-byte reads) and
-// x live in registers; P itself is streamed through once in chunks of storage rows (load a chunk, rank-m downdate, store).
-// The skip mask is predicated like in k_step: every lane stores whole rows with D^-1 = 0 for skipped filters.
-// MH: the gathered columns are read with the default policy (they are read again by the row stream), the row stream's
-// loads and every store carry the hint.
-template <int NS, int M, bool ORIENT, int MH = MH_DEFAULT>
-__global__ __launch_bounds__(64, PB_UPD_WAVES(NS, M)) void k_update(const double *st, double *sto, int B, IdxArg<M> idx,
-                                                  const double *__restrict__ z, const double *__restrict__ R,
-                                                  int rkind, DiagArg<M> rb, const double *__restrict__ qmeas,
-                                                  const uint8_t *__restrict__ mask, Consts k)
-{
-  using L = Lay<NS>;
-  using S = Slots<NS>;
-  const unsigned tile = xcd_workgroup(k);
-  const unsigned b = tile * 64u + threadIdx.x;
-  if (b >= (unsigned) B) return;
-  const bool upd = (mask == nullptr) || (mask[b] != 0);  // 0 = handler returned NULL for this filter
-  const unsigned bo = b * 8u, B8 = (unsigned) B * 8u;
-  TileIO<NS, MemHint<MH>::LA, MemHint<MH>::SA> io(st, sto, tile, threadIdx.x);
-  const rsrc_t rz = mkbuf(z, (unsigned) M * B8);
-  const rsrc_t rR = mkbuf(R, rkind == PB_R_DIAG ? (unsigned) M * B8 : (rkind == PB_R_FULL ? (unsigned) (M * M) * B8 : 0u));
-  const rsrc_t rq = mkbuf(qmeas, ORIENT ? 4u * B8 : 0u);
-  // gather the measured columns first: all these loads are in flight together
-  double W[NS][M];
-#pragma unroll
-  for (int i = 0; i < NS; i++)
-#pragma unroll
-    for (int kk = 0; kk < M; kk++) W[i][kk] = io.ld_slot_rt(slot_rt<NS>(L::OFF_P + pk_rt(i, idx.v[kk])));
-  // the rows holding x / quat / loglik (cached by the tile window; their covariance halves are used by the stream) are
-  // requested up front unless W leaves no room for them (n = 21, m = 6: W alone is 252 registers)
-  if constexpr (NS * M <= 110) {
-#pragma unroll
-    for (int i = 0; i < NS; i++) (void) io.ld(L::OFF_VEC + i);
-  }
-  double ll = io.ld(L::OFF_LL);
-
-  // residual (rbis.cpp:169-172 / :199-208)
-  double resid[M];
-  double dq[3] = { 0, 0, 0 };
-  if constexpr (ORIENT) {
-    const double qm[4] = { ldg(rq, 0u, bo), ldg(rq, B8, bo), ldg(rq, 2u * B8, bo), ldg(rq, 3u * B8, bo) };
-    const double qc[4] = { io.ld(L::OFF_QUAT), io.ld(L::OFF_QUAT + 1), io.ld(L::OFF_QUAT + 2), io.ld(L::OFF_QUAT + 3) };
-    subtract_quats(qm, qc, dq);
-  }
-#pragma unroll
-  for (int kk = 0; kk < M; kk++) {
-    const int ii = idx.v[kk];
-    const double xi = io.ld_slot_rt(slot_rt<NS>(L::OFF_VEC + ii));  // runtime index: re-read instead of x[ii]
-    double r = ldg(rz, kk * B8, bo) - xi;
-    if constexpr (ORIENT) {
-      if (ii >= 6 && ii <= 8) r = (ii == 6) ? dq[0] : (ii == 7 ? dq[1] : dq[2]);
-    }
-    resid[kk] = upd ? r : 0.0;
-  }
-  // S = R + P[idx, idx]
-  double Sm[M * (M + 1) / 2], d[M];
-#pragma unroll
-  for (int i = 0; i < M; i++)
-#pragma unroll
-    for (int j = 0; j <= i; j++) {
-      double r;
-      if (rkind == PB_R_DIAG_BROADCAST) r = (i == j) ? rb.v[i] : 0.0;
-      else if (rkind == PB_R_DIAG) r = (i == j) ? ldg(rR, i * B8, bo) : 0.0;
-      else r = ldg(rR, (j * M + i) * B8, bo);
-      if (!upd) r = (i == j) ? 1.0 : 0.0;  // benign R for skipped filters (their R block may hold anything)
-      Sm[pk(i, j)] = r + io.ld_slot_rt(slot_rt<NS>(L::OFF_P + pk_rt(idx.v[i], idx.v[j])));
-    }
-  ldlt<M>(Sm, d);
-  double y[M], id[M], yd[M], quad = 0.0, det = 1.0;
-#pragma unroll
-  for (int kk = 0; kk < M; kk++) {
-    double s = resid[kk];
-#pragma unroll
-    for (int j = 0; j < kk; j++) s -= Sm[pk(kk, j)] * y[j];
-    y[kk] = s;
-    id[kk] = upd ? 1.0 / d[kk] : 0.0;
-    yd[kk] = s * id[kk];
-    det *= d[kk];
-    quad += s * s * id[kk];
-  }
-  if (upd) ll += -log(det) - quad;  // -log(S.determinant()) - r^T S^-1 r (rbis.cpp:142)
-  // W = P[:, idx] L^-T  (in place on the gathered columns)
-#pragma unroll
-  for (int i = 0; i < NS; i++) {
-#pragma unroll
-    for (int kk = 0; kk < M; kk++) {
-      double s = W[i][kk];
-#pragma unroll
-      for (int j = 0; j < kk; j++) s -= W[i][j] * Sm[pk(kk, j)];
-      W[i][kk] = s;
-    }
-  }
-  // dx = K r = W D^-1 y, applied as rbisApplyDelta does (RigidBodyState::addState, see add_delta): the chi part of dx is
-  // folded into its own quaternion first, vec += dx, then chi of the sum is folded into quat, then quat *= dq.  Written
-  // out here so that no dx[NS] array is alive next to W (n = 21, m = 6: W alone is 252 registers).
-  // The state rows are final before the covariance streams through: x and quat are dead from then on (a row that pairs
-  // a state entry with a covariance entry is stored when the stream reaches it).
-  auto dxi = [&](int i) {
-    double s = 0.0;
-#pragma unroll
-    for (int kk = 0; kk < M; kk++) s = (kk == 0) ? W[i][0] * yd[0] : fma(W[i][kk], yd[kk], s);
-    return s;
-  };
-  {
-    double dchi[3] = { dxi(6), dxi(7), dxi(8) };
-    double dq4[4] = { 1.0, 0.0, 0.0, 0.0 };
-    fold_chi(dchi, dq4, k.chi_tol);
-    double xn[NS];
-#pragma unroll
-    for (int i = 0; i < NS; i++) xn[i] = io.ld(L::OFF_VEC + i) + ((i >= 6 && i <= 8) ? dchi[i - 6] : dxi(i));
-    double q[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) q[i] = io.ld(L::OFF_QUAT + i);
-    double qn[4] = { q[0], q[1], q[2], q[3] };
-    double chi[3] = { xn[6], xn[7], xn[8] };
-    fold_chi(chi, qn, k.chi_tol);
-    xn[6] = chi[0]; xn[7] = chi[1]; xn[8] = chi[2];
-    double o[4];
-    quat_mul(qn, dq4, o);
-#pragma unroll
-    for (int i = 0; i < NS; i++) io.st(L::OFF_VEC + i, upd ? xn[i] : io.ld(L::OFF_VEC + i));
-#pragma unroll
-    for (int i = 0; i < 4; i++) io.st(L::OFF_QUAT + i, upd ? o[i] : q[i]);
-    io.st(L::OFF_LL, ll);
-  }
-  // W <- W |D|^-1/2 (or W D^-1, see UpdateForm; 0 for skipped filters) + the pivots' sign bits, then the rank-m downdate
-  // streams through the covariance
-  unsigned sg[M];
-  {
-    double sq[M];
-#pragma unroll
-    for (int kk = 0; kk < M; kk++) {
-      sq[kk] = UpdateForm<NS, M>::SCALED_BY_INVERSE ? id[kk] : sqrt(fabs(id[kk]));
-      sg[kk] = (unsigned) __double2hiint(id[kk]) & 0x80000000u;
-    }
-#pragma unroll
-    for (int i = 0; i < NS; i++)
-#pragma unroll
-      for (int kk = 0; kk < M; kk++) W[i][kk] *= sq[kk];
-  }
-  // chunk sizes keep (chunk + W) inside the register file: W is NS x M doubles
-  constexpr int NR = S::NROW;
-  using CH = UpdateChunks<NS, M>;
-  static_for<CH::N>([&](auto I) {
-    constexpr int i = decltype(I)::value;
-    downdate_rows<NS, M, (NR * i) / CH::N, (NR * (i + 1)) / CH::N>(io, W, sg, d);
-  });
-}
+// (The generic run-time-index update of a 21-state batch is k_update_quad_rt, rbis_quad_rt.hpp; the 15-state one
+//  k_update_lane_rt below.  Round 1 / 2 gathered the measured columns with 8-byte run-time-slot loads and streamed the
+//  covariance through one wave, k_update<NS, M, ORIENT>: 54-80 us for 21 states at 64k filters, retired in round 3.)
 
 // RBISResetUpdate::updateFilter, per-filter inputs: vec [n][B], quat [4][B], cov [n*n][B] column-major
 template <int NS>
