@@ -167,8 +167,9 @@ int pb_run_legodo(pb_ctx *ctx, int n_steps, const double *imu_stream, const doub
 /* Time-fused replay of the same streams: steps_per_launch consecutive steps per kernel launch with the state and
  * covariance resident in registers; the posterior is written to HBM once per launch instead of once per message.  Same
  * arithmetic as pb_run_legodo, NOT the plugin semantics (no per-message posterior): meant for parameter sweeps and
- * likelihood evaluation over log segments (state-estimator/python/param_sweep.py:39-52).  15-state filters only.
- * Accounting differs from the T = 1 path (104 + 2240/T bytes per filter-step): see DESIGN.md section 6. */
+ * likelihood evaluation over log segments (state-estimator/python/param_sweep.py:39-52).  15 states: k_replay_coop (two
+ * waves per tile), 21 states: k_replay_quad (four).  Accounting differs from the T = 1 path (104 + 2240/T bytes per
+ * 15-state filter-step, 104 + 4112/T for 21 states): see DESIGN.md section 6. */
 int pb_replay_legodo_fused(pb_ctx *ctx, int n_steps, int steps_per_launch, const double *imu_stream,
                            const double *lo_stream, const uint8_t *mask_stream, const double q[4], float *elapsed_ms);
 

@@ -46,17 +46,34 @@ def counters(d):
     return by
 
 
-for d, name in (("trace64k", "_kernel_stats.csv"), ("trace64k_n21", "_kernel_stats_n21.csv"),
+for d, name in (("trace64k", "_kernel_stats.csv"), ("trace64k_n21", "_kernel_stats_n21.csv"), ("trace1m", "_kernel_stats_1m.csv"),
+                ("shim/trace", "_kernel_stats_shim.csv"), ("shim/trace21", "_kernel_stats_shim_n21.csv"),
                 ("others", "_kernel_stats_others.csv"), ("configs", "_kernel_stats_configs.csv"),
                 ("smoother", "_kernel_stats_smoother.csv")):
     ks = newest(os.path.join(src, d, "*", "*kernel_stats.csv"))
     if ks:
         shutil.copy(ks[0], os.path.join(out, tag + name))
-for name in ("trace64k.json", "trace64k_n21.json", "bench1m.json", "calib_plain.txt", "copybench.txt", "batch_sweep.txt",
+for name in ("trace64k.json", "trace64k_n21.json", "trace1m.json", "leg_rates.txt", "bench1m.json", "calib_plain.txt", "copybench.txt", "batch_sweep.txt",
              "bench_default.json", "others.txt", "configs.txt", "smoother.txt", "n21_input_footprint.txt"):
     p = os.path.join(src, name)
     if os.path.exists(p):
         shutil.copy(p, os.path.join(out, tag + "_" + name))
+
+p = os.path.join(src, "shim", "shim_sweep.txt")
+if os.path.exists(p):
+    shutil.copy(p, os.path.join(out, tag + "_shim_sweep.txt"))
+# per-kernel MEDIAN durations of the handler-path traces: the stats file's average includes the first launch (module load,
+# tens of milliseconds), the median does not
+for d in ("shim/trace", "shim/trace21"):
+    for f in newest(os.path.join(src, d, "*", "*kernel_trace.csv")):
+        by = collections.defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            by[kname(r["Kernel_Name"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+        with open(os.path.join(out, tag + "_kernel_medians_" + d.split("/")[1].replace("trace", "shim") + ".txt"), "w") as o:
+            o.write("# median / mean-without-the-first-launch duration per kernel (us), from rocprofv3 --kernel-trace of scripts/shim_rate.sh\n")
+            for k, v in sorted(by.items(), key=lambda kv: -sum(kv[1])):
+                rest = v[1:] if len(v) > 1 else v
+                o.write("%-60s calls %6d  median %9.2f  mean w/o first %9.2f  first %12.2f\n" % (k[:60], len(v), statistics.median(v), sum(rest) / len(rest), v[0]))
 
 known = 140 * (1 << 20) * 8
 kf = statistics.median(counters("calib_FETCH_SIZE")[("k_calib_copy", "FETCH_SIZE")]) * 1024

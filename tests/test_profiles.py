@@ -47,3 +47,20 @@ def test_roofline_is_recomputable_from_the_line():
     cb = r["cache_busting"]
     assert abs(cb["algorithmic_bytes_per_launch"] / (cb["kernel_avg_us"] * 1e-6) / 1e9 - cb["achieved"]) / cb["achieved"] < 1e-6
     assert d["cpu_baseline"]["kind"] in ("port", "reference") and d["cpu_baseline"]["cores"] >= 1
+
+
+def test_one_million_filter_trace_agrees_with_the_cache_busting_leg():
+    """the true-HBM figure (roofline.frac_cache_busting, 1 M filters) has a rocprofv3 kernel trace of its own,
+    and its average agrees with the HIP-event average of the bench line's cache-busting leg (same box, same profile run)."""
+    tag = latest_round()
+    path = os.path.join(ROOT, "profiles", tag + "_kernel_stats_1m.csv")
+    if not os.path.exists(path):
+        pytest.skip("no 1 M-filter trace for " + tag)
+    with open(path) as f:
+        rows = list(csv.DictReader(f))
+    hot = max(rows, key=lambda r: float(r["TotalDurationNs"]))
+    assert "k_step" in hot["Name"]
+    prof_us = float(hot["AverageNs"]) / 1e3
+    cb = bench_line(tag)["roofline"]["cache_busting"]
+    assert cb["batch"] == 1 << 20
+    assert abs(prof_us - cb["kernel_avg_us"]) / prof_us < 0.08, (prof_us, cb["kernel_avg_us"])
