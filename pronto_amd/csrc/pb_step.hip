@@ -60,7 +60,8 @@ int pbk_step_leg(pb_ctx *c, const double *imu, const StepBcast *bcast, const dou
   if ((c->ns == 15 && !c->coop15) || (c->ns == 21 && !c->quad21) || c->leg_par.world_constraint) return -1;
   // 21 states with PER-FILTER joint blocks: the forward kinematics in front of barrier A makes role PW the wave the other three
   // wait for (60.8 us at 64k filters against 52.2 us for the odometry kernel followed by the fused step): two launches
-  if (c->ns == 21 && lin.kind == 1) return -1;
+  static const bool leg21 = getenv("PRONTO_BATCH_LEG21_JOINTS") && getenv("PRONTO_BATCH_LEG21_JOINTS")[0] == '1';  // A/B
+  if (c->ns == 21 && lin.kind == 1 && !leg21) return -1;
   const StepBcast bc = bcast ? *bcast : StepBcast();
   LegStepArgs la{ c->legd, c->legi, c->stride, utime, r2, r2_uncertain, lo_out, mask_out };
   double *out = update_target(c);

@@ -735,6 +735,33 @@ PB_HD void leg_inputs(const LegIn &in, long b, long B, Pose &bl, Pose &br, float
   else { ncl = in.nc[0]; ncr = in.nc[1]; }
 }
 
+// One leg's forward kinematics from per-filter joint blocks (kind 1), and the rest of the message (forces, controller
+// contacts) -- the pieces of leg_inputs for the kernels that give the two legs to two different waves of a tile
+PB_HD void leg_fk_side(const LegIn &in, int side, long b, long B, Pose &T)
+{
+  const LegChain &ch = *in.chain;
+  double ang[LEG_MAXJ];
+  if (in.jeff != nullptr) {
+    float p[LEG_MAXJ], e[LEG_MAXJ];
+#pragma unroll
+    for (int j = 0; j < LEG_MAXJ; j++) {
+      const long at = (long) ch.row[side][j] * B + b;
+      p[j] = in.jpos[at]; e[j] = in.jeff[at];
+    }
+    leg_angles(ch, side, [&](int j) { return (double) torque_adjust(p[j], e[j], ch.gain[side][j]); }, ang);
+  } else {
+    leg_angles(ch, side, [&](int j) { return (double) in.jpos[(long) ch.row[side][j] * B + b]; }, ang);
+  }
+  const double *rec = in.chain_rec;
+  leg_fk(ch, side, ang, [rec, side](int j, int f) { return rec[(side * LEG_MAXJ + j) * LEG_REC + f]; }, T);
+}
+PB_HD void leg_inputs_rest(const LegIn &in, long b, long B, float &fl, float &fr, int &ncl, int &ncr)
+{
+  fl = in.jforces[b]; fr = in.jforces[B + b];
+  if (in.ncontacts != nullptr) { ncl = in.ncontacts[b]; ncr = in.ncontacts[B + b]; }
+  else { ncl = in.nc[0]; ncr = in.nc[1]; }
+}
+
 // LegOdoCommon::createMeasurement in mode lin_rate on the odometry's result (rbis_legodo_common.cpp:99-107,124-129,153-156,
 // pronto_conversions_lcm.hpp:38-87): z = delta translation / elapsed time, R = r_vxyz^2 or r_vxyz_uncertain^2 when
 // status >= 0.5, no update (mask 0) when status < 0

@@ -41,7 +41,7 @@ __global__ __launch_bounds__(128, 1) void k_step_leg(const double *st, double *s
   using L = Lay<NS>;
   using CX = CoopX<NS, NoCorr>;
   __shared__ double xch[CX::NXCH_LEG][64];
-  __shared__ double chain_lds[2 * LEG_MAXJ * LEG_REC];
+  __shared__ double chain_lds[2][2 * LEG_MAXJ * LEG_REC];  // one copy of the chain records per wave (no cross-wave ordering needed)
   const int role = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
   const unsigned lane = threadIdx.x & 63u;
   const unsigned tile = xcd_workgroup(k);
@@ -74,13 +74,26 @@ __global__ __launch_bounds__(128, 1) void k_step_leg(const double *st, double *s
   auto stf = [&io](int comp, double v) { io.st(comp, v); };
   auto sync = []() { __syncthreads(); };
   auto xrd = [lane](int s) { return xch[s][lane]; };
+  // Per-filter joint blocks: the forward kinematics of the LEFT leg is role C's -- it has nothing to do until its rows arrive --
+  // the right leg's is role P's; one more barrier (F) hands the left foot over.  (A broadcast joint state arrives as foot poses.)
+  const bool split_fk = lin.kind == 1;  // wave-uniform
+  const long bl_ = b < (unsigned) B ? (long) b : (long) B - 1;  // lanes past the batch read the last robot's inputs, store nothing
   if (role == 0) {
     io.template need<0, Slots<NS>::ROW_SPLIT>();
+    if (split_fk) {
+      leg_stage_chain(lin, chain_lds[0], lane);
+      Pose T;
+      leg_fk_side(lin, 0, bl_, (long) B, T);
+#pragma unroll
+      for (int i = 0; i < 3; i++) xch[CX::XCH_FOOT + i][lane] = T.t[i];
+#pragma unroll
+      for (int i = 0; i < 4; i++) xch[CX::XCH_FOOT + 3 + i][lane] = T.q[i];
+      __syncthreads();  // barrier F
+    }
     coop_role_core<NS, true, NoCorr, true, true>(ld, stf, [lane](int s, double v) { xch[s][lane] = v; }, xrd, sync, in, k);
   } else {
     // ---- the odometry, on the prior state this role reads anyway ----
-    const long bl_ = b < (unsigned) B ? (long) b : (long) B - 1;  // lanes past the batch read the last robot's inputs, store nothing
-    leg_stage_chain(lin, chain_lds, lane);
+    leg_stage_chain(lin, chain_lds[1], lane);
     LegState s;
     leg_load(s, la.legd, la.legi, la.stride, (long) b, false);     // (the state arrays are padded to whole tiles)
     double chi[3], bg[3] = { 0.0, 0.0, 0.0 }, wq[4];
@@ -91,7 +104,17 @@ __global__ __launch_bounds__(128, 1) void k_step_leg(const double *st, double *s
     Pose fl_, fr_, delta;
     float zl, zr;
     int ncl, ncr;
-    leg_inputs(lin, bl_, (long) B, fl_, fr_, zl, zr, ncl, ncr);
+    if (split_fk) {
+      leg_fk_side(lin, 1, bl_, (long) B, fr_);
+      leg_inputs_rest(lin, bl_, (long) B, zl, zr, ncl, ncr);
+      __syncthreads();  // barrier F
+#pragma unroll
+      for (int i = 0; i < 3; i++) fl_.t[i] = xch[CX::XCH_FOOT + i][lane];
+#pragma unroll
+      for (int i = 0; i < 4; i++) fl_.q[i] = xch[CX::XCH_FOOT + 3 + i][lane];
+    } else {
+      leg_inputs(lin, bl_, (long) B, fl_, fr_, zl, zr, ncl, ncr);
+    }
     ins_update_quat<NS>(chi, bg, wq, in.gyro, in.dt, k);           // world_to_body_ = the head AFTER this pair's IMU step
     int64_t prev = 0;
     const double status = leg_update(s, par, la.utime, fl_, fr_, zl, zr, ncl, ncr, wq, delta, prev);
@@ -130,7 +153,7 @@ __global__ __launch_bounds__(256, 2) void k_step_quad_leg(const double *st, doub
   using L = Lay<NS>;
   using SL = Slots<21>;
   __shared__ double xch[Quad::NXCH_LEG][64];
-  __shared__ double chain_lds[2 * LEG_MAXJ * LEG_REC];
+  __shared__ double chain_lds[3][2 * LEG_MAXJ * LEG_REC];  // one copy of the chain records per wave that reads them
   const int role = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
   const unsigned lane = threadIdx.x & 63u;
   const unsigned tile = xcd_workgroup(k);
@@ -169,18 +192,32 @@ __global__ __launch_bounds__(256, 2) void k_step_quad_leg(const double *st, doub
   auto sync = []() { __syncthreads(); };
   auto xrd = [lane](int s) { return xch[s][lane]; };
   auto xwr = [lane](int s, double v) { xch[s][lane] = v; };
+  // per-filter joint blocks: role CC runs the left leg's forward kinematics and role CB the right leg's while their rows are
+  // on the way; barrier F hands both feet to role PW (all four waves take part in it)
+  const bool split_fk = lin.kind == 1;  // wave-uniform
+  const long bl_ = b < (unsigned) B ? (long) b : (long) B - 1;
+  auto fk_to_lds = [&](int side, double *lds) {
+    leg_stage_chain(lin, lds, lane);
+    Pose T;
+    leg_fk_side(lin, side, bl_, (long) B, T);
+#pragma unroll
+    for (int i = 0; i < 3; i++) xch[Quad::X_FOOT + 7 * side + i][lane] = T.t[i];
+#pragma unroll
+    for (int i = 0; i < 4; i++) xch[Quad::X_FOOT + 7 * side + 3 + i][lane] = T.q[i];
+  };
   if (role == 0) {
     const StepInputs in = inputs();
     io.template need<SL::QROW[0], SL::QROW[1]>();
+    if (split_fk) { fk_to_lds(0, chain_lds[0]); __syncthreads(); }
     quad_role_cc<true, true>(ld, stf, xwr, xrd, sync, in, k);
   } else if (role == 1) {
     const StepInputs in = inputs();
     io.template need<SL::QROW[1], SL::QROW[2]>();
+    if (split_fk) { fk_to_lds(1, chain_lds[1]); __syncthreads(); }
     quad_role_cb<true>(ld, stf, xwr, xrd, sync, in, k);
   } else if (role == 2) {
     StepInputs in = inputs();
-    const long bl_ = b < (unsigned) B ? (long) b : (long) B - 1;
-    leg_stage_chain(lin, chain_lds, lane);
+    leg_stage_chain(lin, chain_lds[2], lane);
     LegState s;
     leg_load(s, la.legd, la.legi, la.stride, (long) b, false);
     double chi[3], bg[3], wq[4];
@@ -191,7 +228,16 @@ __global__ __launch_bounds__(256, 2) void k_step_quad_leg(const double *st, doub
     Pose fl_, fr_, delta;
     float zl, zr;
     int ncl, ncr;
-    leg_inputs(lin, bl_, (long) B, fl_, fr_, zl, zr, ncl, ncr);
+    if (split_fk) {
+      leg_inputs_rest(lin, bl_, (long) B, zl, zr, ncl, ncr);
+      __syncthreads();  // barrier F
+#pragma unroll
+      for (int i = 0; i < 3; i++) { fl_.t[i] = xch[Quad::X_FOOT + i][lane]; fr_.t[i] = xch[Quad::X_FOOT + 7 + i][lane]; }
+#pragma unroll
+      for (int i = 0; i < 4; i++) { fl_.q[i] = xch[Quad::X_FOOT + 3 + i][lane]; fr_.q[i] = xch[Quad::X_FOOT + 10 + i][lane]; }
+    } else {
+      leg_inputs(lin, bl_, (long) B, fl_, fr_, zl, zr, ncl, ncr);
+    }
     ins_update_quat<NS>(chi, bg, wq, in.gyro, in.dt, k);
     int64_t prev = 0;
     const double status = leg_update(s, par, la.utime, fl_, fr_, zl, zr, ncl, ncr, wq, delta, prev);
@@ -218,6 +264,7 @@ __global__ __launch_bounds__(256, 2) void k_step_quad_leg(const double *st, doub
   } else {
     const StepInputs in = inputs();
     io.template need<SL::QROW[3], SL::QROW[4]>();
+    if (split_fk) __syncthreads();  // barrier F
     quad_role_passive<true, 1>(ld, stf, xwr, xrd, sync, in, k);
   }
 }

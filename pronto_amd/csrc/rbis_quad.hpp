@@ -37,7 +37,7 @@ struct Quad {
   static constexpr int X_H2 = 72;  // the F_cb T1^T part of H: chi-v block (9, row-major), chi-chi block (6, packed)
   static constexpr int X_XV = 87;  // the propagated velocity x'[3..5] (role PW -> role CC, for the residual)
   static constexpr int NXCH = 90;
-  static constexpr int X_LEG = 90, NXCH_LEG = 95;  // k_step_quad_leg: z[3], R, valid from the odometry (role PW) before barrier A
+  static constexpr int X_LEG = 90, X_FOOT = 95, NXCH_LEG = 109;  // k_step_quad_leg: z[3], R, valid from the odometry (role PW) before barrier A; the two foot poses (2 x 7) from roles CC / CB
 };
 
 // (X hat(m)^T)[r][c] = (m x X_r)[c] for a row-major 3x3 block X
