@@ -58,10 +58,11 @@ int pbk_step_leg(pb_ctx *c, const double *imu, const StepBcast *bcast, const dou
   // the two-wave 15-state mapping (the default up to 393 216 filters) and the four-wave 21-state mapping; the world
   // constraint needs the stand-alone kernel
   if ((c->ns == 15 && !c->coop15) || (c->ns == 21 && !c->quad21) || c->leg_par.world_constraint) return -1;
-  // 21 states with PER-FILTER joint blocks: the forward kinematics in front of barrier A makes role PW the wave the other three
-  // wait for (60.8 us at 64k filters against 52.2 us for the odometry kernel followed by the fused step): two launches
-  static const bool leg21 = getenv("PRONTO_BATCH_LEG21_JOINTS") && getenv("PRONTO_BATCH_LEG21_JOINTS")[0] == '1';  // A/B
-  if (c->ns == 21 && lin.kind == 1 && !leg21) return -1;
+  // 21 states with PER-FILTER joint blocks: even with the two legs' forward kinematics given to roles CC and CB, what is left in
+  // front of barrier A makes role PW the wave the other three wait for (59.3 us at 64k filters against 56.3 us for the
+  // odometry kernel followed by the fused step on the same box): two launches.  k_step_quad_leg keeps the code path (it is
+  // what a foot-state or broadcast joint-state message runs on).
+  if (c->ns == 21 && lin.kind == 1) return -1;
   const StepBcast bc = bcast ? *bcast : StepBcast();
   LegStepArgs la{ c->legd, c->legi, c->stride, utime, r2, r2_uncertain, lo_out, mask_out };
   double *out = update_target(c);
