@@ -1499,10 +1499,19 @@ public:
 
   // the chain of joints from the root link to `link`; false if the link is not the child of any joint or a joint type is
   // not one the chain table knows (floating, planar)
-  static bool chainTo(const std::string &urdf_xml, const std::string &link, std::vector<Joint> &chain)
+  static bool chainTo(const std::string &urdf_with_comments, const std::string &link, std::vector<Joint> &chain)
   {
     struct J { Joint j; std::string parent, child; };
     std::vector<J> all;
+    std::string urdf_xml;  // without <!-- comments -->: a commented-out joint must not be read
+    for (size_t p = 0; p < urdf_with_comments.size();) {
+      const size_t c0 = urdf_with_comments.find("<!--", p);
+      urdf_xml.append(urdf_with_comments, p, (c0 == std::string::npos ? urdf_with_comments.size() : c0) - p);
+      if (c0 == std::string::npos) break;
+      const size_t c1 = urdf_with_comments.find("-->", c0 + 4);
+      if (c1 == std::string::npos) break;
+      p = c1 + 3;
+    }
     auto attr = [](const std::string &tag, const char *name, std::string &out) {
       const std::string key = std::string(name) + "=";
       size_t p = 0;

@@ -119,6 +119,15 @@ def test_ins_gravity_initialisation_host_only(oracle):
     assert r.returncode == 0 and "PASS" in r.stdout, r.stdout + r.stderr
 
 
+def test_urdf_chains_and_leg_handler_configuration_host_only(oracle):
+    """ModelClient::fromURDFString (URDF text -> the two chains the forward kinematics evaluates) and LegOdoHandler's
+    constructor keys / message handlers: host logic, runs here without a GPU."""
+    exe = build_exe(oracle, "test_urdf_chain")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    print(r.stdout, r.stderr)
+    assert r.returncode == 0 and "PASS" in r.stdout, r.stdout + r.stderr
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode,slots,fuse", [("pos_and_lin_rate", 0, ""), ("pos_and_lin_rate", 6, ""), ("lin_rot_rate", 0, ""),
                                              ("lin_rate", 0, "fuse"), ("lin_rate", 4, "fuse"), ("pos_and_lin_rate", 0, "fuse")])

@@ -587,17 +587,18 @@ def test_broadcast_joint_state_equals_per_filter_blocks_on_gpu():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n", [15, 21])
-@pytest.mark.parametrize("kind", ["joints_bcast", "joints_dev", "feet_bcast", "feet_host"])
-def test_one_call_pair_equals_the_two_call_sequence_on_gpu(n, kind):
+@pytest.mark.parametrize("n,kind,B", [(n, k, 1000) for n in (15, 21) for k in ("joints_bcast", "joints_dev", "feet_bcast", "feet_host")] +
+                         [(15, "joints_dev", 1), (21, "feet_host", 1), (15, "feet_host", 65), (21, "joints_dev", 65)])
+def test_one_call_pair_equals_the_two_call_sequence_on_gpu(n, kind, B):
     """pb_step_legodo_joints / pb_step_legodo_feet -- IMU step, odometry slaved to the state after it, lin_rate update: ONE
     kernel for 15 states (k_step_leg: the odometry runs in the passive-panel wave of each tile), two launches inside the call
     for 21 -- against pb_legodo_update_joints(after_predict) + pb_step_legodo_split: masks identical, measurement blocks
-    and posteriors to rounding; ragged batch (last tile half full)."""
+    and posteriors to rounding; ragged batches (last tile partly full: 1000 filters; a single filter; 65 = one lane of a
+    second tile)."""
     import torch
     import legs
     from pronto_amd import batch as pa
-    B, T = 1000, 300
+    T = 300
     dev = torch.device("cuda:0")
     chain = legs.chain_arrays(legs.ATLAS_LEFT, legs.ATLAS_RIGHT, legs.ATLAS_ROWS)
     gain = np.array([7000, 10000, 10000, 10000, 10000, 10000] * 2, dtype=np.float32)
@@ -646,7 +647,7 @@ def test_one_call_pair_equals_the_two_call_sequence_on_gpu(n, kind):
         la, lb = lo[0].cpu().numpy(), lo[1].cpu().numpy()
         assert np.max(np.abs(la[:, on] - lb[:, on]), initial=0.0) < 1e-9, k
         n_upd += int(on.sum())
-    assert n_upd > B * T // 10
+    assert n_upd > B * T // 10 or B == 1
     from util import rel
     for x, y in zip(two.get_head(), one.get_head()):
         assert rel(x, y) < 1e-10
