@@ -658,3 +658,51 @@ def test_one_call_pair_equals_the_two_call_sequence_on_gpu(n, kind, B):
     # without the measurement outputs (no history to replay): same posterior
     for e in ests:
         e.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [15, 21])
+def test_pair_kernel_at_full_batch_size_on_gpu(n):
+    """BASELINE batch size (64k filters, one robot's joint-state log for every filter -- the sweep the handler path runs): the
+    one-kernel pair against the two-call sequence over 40 ticks -- every mask identical, the summaries (sum of log-likelihoods,
+    checksum of the state) equal to rounding, nothing non-finite; and the pair kernel replayed from the same start gives
+    the same bits (pb_state_checksum)."""
+    import torch
+    import legs
+    from pronto_amd import batch as pa
+    B, T = 65536, 40
+    dev = torch.device("cuda:0")
+    chain = legs.chain_arrays(legs.ATLAS_LEFT, legs.ATLAS_RIGHT, legs.ATLAS_ROWS)
+    w = Workload(B, n_states=n, dt_us=2000)
+    vec, quat, P0 = w.initial_state()
+    q4 = w.process_noise()
+    msgs = legs.joint_gait(1, T, seed=33)
+    imus = [np.ascontiguousarray(w.imu_block(k)[:, 0]) for k in range(T)]
+
+    def run(one_call):
+        e = pa.BatchEstimator(B, n_states=n)
+        e.reset(vec, quat, P0)
+        e.legodo_init(*SCHMITT, True)
+        e.legodo_set_chain(*chain)
+        lo = torch.zeros((6, B), dtype=torch.float64, device=dev)
+        mk = torch.zeros(B, dtype=torch.uint8, device=dev)
+        masks = []
+        for k, (utime, jp, je, forces, _) in enumerate(msgs):
+            a = (np.ascontiguousarray(jp[:, 0]), None, np.ascontiguousarray(forces[:, 0]))
+            if one_call:
+                e.step_legodo_joints(imus[k], q4, utime, *a, *R_VXYZ, lo, mk)
+            else:
+                e.legodo_update_joints(utime, *a, *R_VXYZ, None, None, lo, mk, after_predict=imus[k])
+                e.step_legodo(imus[k], lo, mk, q4)
+            masks.append(int(mk.sum().item()))
+        out = (masks, e.summary(), e.state_checksum())
+        e.close()
+        return out
+
+    m1, s1, c1 = run(True)
+    m2, s2, _ = run(False)
+    m3, s3, c3 = run(True)
+    assert m1 == m2 and sum(m1) > B * T // 10
+    assert s1[3] == 0 and s2[3] == 0
+    assert abs(s1[0] - s2[0]) <= 1e-11 * abs(s2[0]) and abs(s1[1] - s2[1]) <= 1e-11 * abs(s2[1])
+    assert c1 == c3 and np.array_equal(s1, s3)
