@@ -1,13 +1,21 @@
 // pb_update.hip -- launcher of the generic (run-time index list) update of a 15-state batch: k_update_lane_rt<15, M, ORIENT, MH>
-// (one lane, the filter in registers); 21 states: pb_update_rt21.hip.  See pb_ctx.hpp.
+// (one lane, the filter in registers) for m <= 4, k_update_coop_rt<M, MH> (two waves per tile, rbis_quad_rt.hpp) for m = 5, 6
+// where the one-lane kernel spills; 21 states: pb_update_rt21.hip.  See pb_ctx.hpp.
 #include "pb_ctx.hpp"
+#include "rbis_quad_rt.hpp"
 
 template <int NS, int M, int MH>
 static void launch_update_mh(pb_ctx *c, const IdxArg<M> &ia, const DiagArg<M> &da, const double *z, const double *R,
                              int rkind, const double *qm, const uint8_t *mask)
 {
   double *out = update_target(c);
-  if constexpr (NS == 15) {  // the whole 15-state filter fits one lane's registers: no column gather (k_update_lane_rt)
+  if constexpr (M >= 5) {  // five / six gathered columns beside the covariance do not fit one lane: two waves per tile
+    // (two cache policies are built: non-temporal streaming falls back to the default one)
+    if (MH == MH_STORE_SC1)
+      k_update_coop_rt<M, MH_STORE_SC1><<<nblk(c->B), 128, 0, c->stream>>>(c->st, out, c->B, ia, z, R, rkind, da, qm, mask, c->k);
+    else
+      k_update_coop_rt<M, MH_DEFAULT><<<nblk(c->B), 128, 0, c->stream>>>(c->st, out, c->B, ia, z, R, rkind, da, qm, mask, c->k);
+  } else {  // the whole 15-state filter fits one lane's registers: no column gather (k_update_lane_rt)
     if (qm)
       k_update_lane_rt<NS, M, true, MH><<<nblk(c->B), 64, 0, c->stream>>>(c->st, out, c->B, ia, z, R, rkind, da, qm, mask, c->k);
     else

@@ -333,7 +333,7 @@ struct DiagArg {
 };
 
 // (The generic run-time-index update of a 21-state batch is k_update_quad_rt, rbis_quad_rt.hpp; the 15-state one
-//  k_update_lane_rt below.  Round 1 / 2 gathered the measured columns with 8-byte run-time-slot loads and streamed the
+//  k_update_lane_rt below (m <= 4) and k_update_coop_rt (m = 5, 6; rbis_quad_rt.hpp).  Round 1 / 2 gathered the measured columns with 8-byte run-time-slot loads and streamed the
 //  covariance through one wave, k_update<NS, M, ORIENT>: 54-80 us for 21 states at 64k filters, retired in round 3.)
 
 // RBISResetUpdate::updateFilter, per-filter inputs: vec [n][B], quat [4][B], cov [n*n][B] column-major

@@ -1,4 +1,4 @@
-// rbis_quad_rt.hpp -- the generic indexed (+ orientation) update of a 21-state batch with a RUN-TIME index list on the
+// rbis_quad_rt.hpp -- the generic indexed (+ orientation) update of a 21-state batch (and, for m = 5, 6, a 15-state one) with a RUN-TIME index list on the
 // four-wave mapping (RBISIndexedMeasurement / RBISIndexedPlusOrientationMeasurement::updateFilter,
 // rbis_update_interface.cpp:54-107; rbis.cpp:124-227): any indices 0..20 (LegOdoCommon's lin_rot_rate list [3,4,5,0,1,2],
 // rbis_legodo_common.cpp:66-67, reaches the angular-velocity states; a free-form pronto_indexed_measurement_t.lcm:3-15 list
@@ -25,64 +25,73 @@
 namespace pb {
 
 #if defined(__HIPCC__)
-template <int M>
+// NS = 21: four waves per tile (rbis_quad.hpp's ownership); NS = 15: the two roles of rbis_coop.hpp.  The 15-state variant is
+// used where the one-lane kernel k_update_lane_rt spills (m = 5, 6: the covariance AND 75-90 gathered doubles in one lane).
+template <int NS>
+struct RtMap {
+  static constexpr int NW = (NS == 21) ? 4 : 2;                 // waves per tile
+  static constexpr int ROWS_PER_WAVE = (NS + NW - 1) / NW;       // rows of W a wave forms in step 3
+  __host__ __device__ static constexpr int row0(int w) { return NS == 21 ? Slots<NS>::QROW[w] : (w == 0 ? 0 : Slots<NS>::ROW_SPLIT); }
+  __host__ __device__ static constexpr int row1(int w) { return NS == 21 ? Slots<NS>::QROW[w + 1] : (w == 0 ? Slots<NS>::ROW_SPLIT : Slots<NS>::NROW); }
+};
+template <int NS, int M>
 struct QuadRt {
-  static constexpr int X_COL = 0, X_XS = 21 * M, X_Q = X_XS + M, NXCH = X_Q + 4;
+  static constexpr int X_COL = 0, X_XS = NS * M, X_Q = X_XS + M, NXCH = X_Q + 4;
 };
 
-template <int W>
+template <int NS, int W>
 __host__ __device__ constexpr bool quad_owns(int comp)
 {
-  const int r = Slots<21>::T.slot_of[comp] >> 1;
-  return r >= Slots<21>::QROW[W] && r < Slots<21>::QROW[W + 1];
+  const int r = Slots<NS>::T.slot_of[comp] >> 1;
+  return r >= RtMap<NS>::row0(W) && r < RtMap<NS>::row1(W);
 }
 
 // does wave W hold any entry P(i, j <= i) of row i?
-template <int W>
+template <int NS, int W>
 __host__ __device__ constexpr bool quad_owns_row(int i)
 {
   for (int j = 0; j <= i; j++)
-    if (quad_owns<W>(Lay<21>::OFF_P + pk(i, j))) return true;
+    if (quad_owns<NS, W>(Lay<NS>::OFF_P + pk(i, j))) return true;
   return false;
 }
 
 // the entries of column I of P (and x[I]) that wave W holds, into COL[.][KK] -- one body per candidate I
-template <int W, int M, int KK, int I, class IO, class XW>
+template <int NS, int W, int M, int KK, int I, class IO, class XW>
 __device__ __forceinline__ void quad_rt_pick(int idxk, IO &io, XW &&xw)
 {
-  using L = Lay<21>;
-  if constexpr (I < 21) {
+  using L = Lay<NS>;
+  if constexpr (I < NS) {
     if (idxk == I) {
       // (a distinct marker per branch keeps the compiler from merging the bodies into one that reads through a selected
       // address, which would pin the wave's rows in scratch memory: rbis_kernels.hpp pick_column)
       asm volatile("; wave %0 column %1 -> %2" ::"n"(W), "n"(I), "n"(KK));
-      static_for<21>([&](auto JJ) {
+      static_for<NS>([&](auto JJ) {
         constexpr int j = decltype(JJ)::value;
-        if constexpr (quad_owns<W>(L::OFF_P + pk(I, j))) xw(QuadRt<M>::X_COL + j * M + KK, io.ld(L::OFF_P + pk(I, j)));
+        if constexpr (quad_owns<NS, W>(L::OFF_P + pk(I, j))) xw(QuadRt<NS, M>::X_COL + j * M + KK, io.ld(L::OFF_P + pk(I, j)));
       });
-      if constexpr (quad_owns<W>(L::OFF_VEC + I)) xw(QuadRt<M>::X_XS + KK, io.ld(L::OFF_VEC + I));
+      if constexpr (quad_owns<NS, W>(L::OFF_VEC + I)) xw(QuadRt<NS, M>::X_XS + KK, io.ld(L::OFF_VEC + I));
       asm volatile("; wave %0 column %1 -> %2 done" ::"n"(W), "n"(I), "n"(KK));
     } else {
-      quad_rt_pick<W, M, KK, I + 1>(idxk, io, xw);
+      quad_rt_pick<NS, W, M, KK, I + 1>(idxk, io, xw);
     }
   }
 }
 
-template <int W, int M, int MH>
+template <int NS, int W, int M, int MH>
 __device__ __forceinline__ void quad_rt_role(const double *st, double *sto, int B, const IdxArg<M> &idx, const double *__restrict__ z,
                                              const double *__restrict__ R, int rkind, const DiagArg<M> &rb,
                                              const double *__restrict__ qmeas, const uint8_t *__restrict__ mask, const Consts &k,
                                              double (*xch)[64])
 {
-  using L = Lay<21>;
-  using SL = Slots<21>;
-  using Q = QuadRt<M>;
+  using L = Lay<NS>;
+  using Q = QuadRt<NS, M>;
+  using RM = RtMap<NS>;
   const unsigned lane = threadIdx.x & 63u;
   const unsigned tile = xcd_workgroup(k);
   const unsigned b = tile * 64u + lane;
   const unsigned bo = b * 8u, B8 = (unsigned) B * 8u;
   const bool upd = (b < (unsigned) B) && (mask == nullptr || mask[b < (unsigned) B ? b : 0] != 0);  // 0 = handler returned NULL for this filter
-  TileIO<21, MemHint<MH>::LA, MemHint<MH>::SA> io(st, sto, tile, lane);
+  TileIO<NS, MemHint<MH>::LA, MemHint<MH>::SA> io(st, sto, tile, lane);
   auto xw = [&](int s, double v) { xch[s][lane] = v; };
   auto xr = [&](int s) { return xch[s][lane]; };
   // the measurement first (never cache-resident), then this wave's rows
@@ -107,11 +116,11 @@ __device__ __forceinline__ void quad_rt_role(const double *st, double *sto, int 
 #pragma unroll
     for (int i = 0; i < 4; i++) qm[i] = ldg(rq, i * B8, bo);
   }
-  io.template need<SL::QROW[W], SL::QROW[W + 1]>();
+  io.template need<RM::row0(W), RM::row1(W)>();
 
   // ---- 1. the measured columns, out of this wave's registers ----
-  static_for<M>([&](auto KK) { quad_rt_pick<W, M, decltype(KK)::value, 0>(idx.v[decltype(KK)::value], io, xw); });
-  if constexpr (quad_owns<W>(L::OFF_QUAT)) {
+  static_for<M>([&](auto KK) { quad_rt_pick<NS, W, M, decltype(KK)::value, 0>(idx.v[decltype(KK)::value], io, xw); });
+  if constexpr (quad_owns<NS, W>(L::OFF_QUAT)) {
 #pragma unroll
     for (int i = 0; i < 4; i++) xw(Q::X_Q + i, io.ld(L::OFF_QUAT + i));
   }
@@ -148,9 +157,9 @@ __device__ __forceinline__ void quad_rt_role(const double *st, double *sto, int 
   }
 
   // ---- 3. W = P[:, idx] L^-T in place, rows 6 W .. 6 W + 5 ----
-  static_for<6>([&](auto RR) {
-    constexpr int j = 6 * W + decltype(RR)::value;
-    if constexpr (j < 21) {
+  static_for<RM::ROWS_PER_WAVE>([&](auto RR) {
+    constexpr int j = RM::ROWS_PER_WAVE * W + decltype(RR)::value;
+    if constexpr (j < NS) {
       double w[M];
 #pragma unroll
       for (int kk = 0; kk < M; kk++) {
@@ -168,16 +177,16 @@ __device__ __forceinline__ void quad_rt_role(const double *st, double *sto, int 
   // ---- 4. downdate and store this wave's entries; dx for its states ----
   // (W is read back row by row; the clobber keeps the compiler from sharing every read between the rows, i.e. from pulling
   //  all of W into registers)
-  static_for<21>([&](auto II) {
+  static_for<NS>([&](auto II) {
     constexpr int i = decltype(II)::value;
-    if constexpr (quad_owns_row<W>(i)) {
+    if constexpr (quad_owns_row<NS, W>(i)) {
       reload_fence();
       double wd[M];
 #pragma unroll
       for (int kk = 0; kk < M; kk++) wd[kk] = xr(Q::X_COL + i * M + kk) * id[kk];
       static_for<i + 1>([&](auto JJ) {
         constexpr int j = decltype(JJ)::value;
-        if constexpr (quad_owns<W>(L::OFF_P + pk(i, j))) {
+        if constexpr (quad_owns<NS, W>(L::OFF_P + pk(i, j))) {
           double acc = io.ld(L::OFF_P + pk(i, j));
 #pragma unroll
           for (int kk = 0; kk < M; kk++) acc = fma(-wd[kk], xr(Q::X_COL + j * M + kk), acc);
@@ -193,38 +202,38 @@ __device__ __forceinline__ void quad_rt_role(const double *st, double *sto, int 
     for (int kk = 0; kk < M; kk++) s = (kk == 0) ? xr(Q::X_COL + i * M) * yd[0] : fma(xr(Q::X_COL + i * M + kk), yd[kk], s);
     return s;
   };
-  if constexpr (quad_owns<W>(L::OFF_QUAT)) {
+  if constexpr (quad_owns<NS, W>(L::OFF_QUAT)) {
     // the wave with x[v chi Delta] and the quaternion: rbisApplyDelta (RigidBodyState::addState, see add_delta) on its part
-    double x[21], dfull[21], q[4];
+    double x[NS], dfull[NS], q[4];
 #pragma unroll
-    for (int i = 0; i < 21; i++) {
+    for (int i = 0; i < NS; i++) {
       x[i] = 0.0;
       dfull[i] = 0.0;
     }
-    static_for<21>([&](auto II) {
+    static_for<NS>([&](auto II) {
       constexpr int i = decltype(II)::value;
-      if constexpr (quad_owns<W>(L::OFF_VEC + i)) { x[i] = io.ld(L::OFF_VEC + i); dfull[i] = dxi(i); }
+      if constexpr (quad_owns<NS, W>(L::OFF_VEC + i)) { x[i] = io.ld(L::OFF_VEC + i); dfull[i] = dxi(i); }
     });
 #pragma unroll
     for (int i = 0; i < 4; i++) q[i] = io.ld(L::OFF_QUAT + i);
-    if (upd) add_delta<21>(x, q, dfull, k.chi_tol);
-    static_for<21>([&](auto II) {
+    if (upd) add_delta<NS>(x, q, dfull, k.chi_tol);
+    static_for<NS>([&](auto II) {
       constexpr int i = decltype(II)::value;
-      if constexpr (quad_owns<W>(L::OFF_VEC + i)) io.st(L::OFF_VEC + i, x[i]);
+      if constexpr (quad_owns<NS, W>(L::OFF_VEC + i)) io.st(L::OFF_VEC + i, x[i]);
     });
 #pragma unroll
     for (int i = 0; i < 4; i++) io.st(L::OFF_QUAT + i, q[i]);
   } else {
-    static_for<21>([&](auto II) {
+    static_for<NS>([&](auto II) {
       constexpr int i = decltype(II)::value;
-      if constexpr (quad_owns<W>(L::OFF_VEC + i)) {
+      if constexpr (quad_owns<NS, W>(L::OFF_VEC + i)) {
         static_assert(i < 6 || i > 8, "chi lives with the quaternion");
         const double xi = io.ld(L::OFF_VEC + i);
         io.st(L::OFF_VEC + i, upd ? xi + dxi(i) : xi);
       }
     });
   }
-  if constexpr (quad_owns<W>(L::OFF_LL)) {
+  if constexpr (quad_owns<NS, W>(L::OFF_LL)) {
     double ll = io.ld(L::OFF_LL);
     if (upd) ll += -log(det) - quad;  // -log(S.determinant()) - r^T S^-1 r (rbis.cpp:142)
     io.st(L::OFF_LL, ll);
@@ -237,12 +246,26 @@ __global__ __launch_bounds__(256, 2) void k_update_quad_rt(const double *st, dou
                                                            DiagArg<M> rb, const double *__restrict__ qmeas,
                                                            const uint8_t *__restrict__ mask, Consts k)
 {
-  __shared__ double xch[QuadRt<M>::NXCH][64];
+  __shared__ double xch[QuadRt<21, M>::NXCH][64];
   const int role = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
-  if (role == 0) quad_rt_role<0, M, MH>(st, sto, B, idx, z, R, rkind, rb, qmeas, mask, k, xch);
-  else if (role == 1) quad_rt_role<1, M, MH>(st, sto, B, idx, z, R, rkind, rb, qmeas, mask, k, xch);
-  else if (role == 2) quad_rt_role<2, M, MH>(st, sto, B, idx, z, R, rkind, rb, qmeas, mask, k, xch);
-  else quad_rt_role<3, M, MH>(st, sto, B, idx, z, R, rkind, rb, qmeas, mask, k, xch);
+  if (role == 0) quad_rt_role<21, 0, M, MH>(st, sto, B, idx, z, R, rkind, rb, qmeas, mask, k, xch);
+  else if (role == 1) quad_rt_role<21, 1, M, MH>(st, sto, B, idx, z, R, rkind, rb, qmeas, mask, k, xch);
+  else if (role == 2) quad_rt_role<21, 2, M, MH>(st, sto, B, idx, z, R, rkind, rb, qmeas, mask, k, xch);
+  else quad_rt_role<21, 3, M, MH>(st, sto, B, idx, z, R, rkind, rb, qmeas, mask, k, xch);
+}
+
+// the same for 15 states on the two roles of rbis_coop.hpp (role C: x[v chi Delta], quat, P_cc; role P: the panels, P_pp,
+// loglik, x[omega accel]): run-time lists of five and six indices, where the one-lane kernel spills
+template <int M, int MH = MH_DEFAULT>
+__global__ __launch_bounds__(128, 2) void k_update_coop_rt(const double *st, double *sto, int B, IdxArg<M> idx,
+                                                           const double *__restrict__ z, const double *__restrict__ R, int rkind,
+                                                           DiagArg<M> rb, const double *__restrict__ qmeas,
+                                                           const uint8_t *__restrict__ mask, Consts k)
+{
+  __shared__ double xch[QuadRt<15, M>::NXCH][64];
+  const int role = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
+  if (role == 0) quad_rt_role<15, 0, M, MH>(st, sto, B, idx, z, R, rkind, rb, qmeas, mask, k, xch);
+  else quad_rt_role<15, 1, M, MH>(st, sto, B, idx, z, R, rkind, rb, qmeas, mask, k, xch);
 }
 #endif
 
