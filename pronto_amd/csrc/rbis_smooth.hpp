@@ -183,6 +183,11 @@ __global__ __launch_bounds__(256, PB_SMOOTH_WG_PER_CU) void k_smooth_reg(const d
 #ifdef SM_EMPTY  // workgroup dispatch cost alone: same registers, same LDS request, no work
   if (B > 0) return;
 #endif
+#ifdef SM_SKEW  // attribution: the second workgroup of every CU in the first dispatch round starts SM_SKEW x 3.4 us late, so that
+                // the two workgroups of a CU are out of phase (one stages while the other computes) instead of in lock-step
+  if (blockIdx.x >= 256 && blockIdx.x < 512)
+    for (int i = 0; i < SM_SKEW; i++) __builtin_amdgcn_s_sleep(127);
+#endif
 #ifdef SM_OCC3
   double *U = lds + F * C::RB, *DP = U;
 #else

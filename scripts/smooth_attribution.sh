@@ -8,7 +8,9 @@
 set -u
 cd "$(dirname "$0")/.."
 V="full:  fact:-DSM_SKIP_FACT subst:-DSM_SKIP_SUBST prod:-DSM_SKIP_PROD quat:-DSM_SKIP_QUAT \
-   compute:-DSM_SKIP_FACT,-DSM_SKIP_SUBST,-DSM_SKIP_PROD,-DSM_SKIP_QUAT staging_only:-DSM_COPY_ONLY noload:-DSM_NO_LOAD nomem:-DSM_NO_LOAD,-DSM_NO_STORE empty:-DSM_EMPTY occ3:-DSM_OCC3"
+   compute:-DSM_SKIP_FACT,-DSM_SKIP_SUBST,-DSM_SKIP_PROD,-DSM_SKIP_QUAT staging_only:-DSM_COPY_ONLY noload:-DSM_NO_LOAD nomem:-DSM_NO_LOAD,-DSM_NO_STORE empty:-DSM_EMPTY occ3:-DSM_OCC3 \
+   skew2:-DSM_SKEW=2 skew4:-DSM_SKEW=4 skew6:-DSM_SKEW=6"
+V=${SM_VARIANTS:-$V}   # e.g. SM_VARIANTS="full: skew4:-DSM_SKEW=4"
 D=gpurun_scratch/smooth_attr
 if [ "${1:-}" = build ]; then
   mkdir -p $D
@@ -17,7 +19,7 @@ if [ "${1:-}" = build ]; then
     n=${v%%:*}; fl=$(echo ${v#*:} | tr ',' ' ')
     /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -DPB_EXPERIMENTS -Ipronto_amd/csrc $fl -c -o $D/pb_smooth_$n.o pronto_amd/csrc/pb_smooth.hip || exit 1
     /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -shared -o $D/lib_$n.so $O/pronto_batch.o $O/pb_step.o $O/pb_update15.o \
-      $O/pb_update21.o $O/pb_update_ct.o $D/pb_smooth_$n.o || exit 1
+      $O/pb_update21_0.o $O/pb_update21_1.o $O/pb_update21_2.o $O/pb_update_ct.o $D/pb_smooth_$n.o || exit 1
     rm -f $D/pb_smooth_$n.o
   done
   ls $D
