@@ -919,10 +919,11 @@ def test_split_space_step_equals_the_plain_step(pa, oracle, n):
     ref.close(); alt.close()
 
 
-def test_lin_rot_rate_compile_time_and_run_time_lists_agree_bitwise(pa, oracle, monkeypatch):
+def test_lin_rot_rate_compile_time_and_run_time_lists_agree(pa, oracle, monkeypatch):
     """LegOdoCommon's lin_rot_rate list [3,4,5,0,1,2] (rbis_legodo_common.cpp:66-67) on 15 states: the compile-time-list
-    kernel (k_update_lane) and the run-time-list kernel (k_update_lane_rt, PRONTO_BATCH_GENERIC_UPDATE=1) pick the same
-    registers and run the same in-register update, so they must agree bit for bit; both against the oracle."""
+    kernel (k_update_lane, one lane per filter) and the run-time-list kernel (PRONTO_BATCH_GENERIC_UPDATE=1: six indices run
+    on two waves per tile, k_update_coop_rt) agree to rounding (the two-wave kernel scales W by 1/d once, like the
+    four-wave ones); both against the oracle."""
     B, n, idx = 300, 15, [3, 4, 5, 0, 1, 2]
     rng = np.random.default_rng(21)
     w = Workload(B, n_states=n)
@@ -952,4 +953,4 @@ def test_lin_rot_rate_compile_time_and_run_time_lists_agree_bitwise(pa, oracle, 
     for e in ests:
         check(e, ob)
     for a, b in zip(ests[0].get_head(), ests[1].get_head()):
-        assert np.array_equal(a, b)
+        assert rel(a, b) < 1e-12
