@@ -274,6 +274,23 @@ int pb_step_legodo_joints(pb_ctx *ctx, const double *imu_block, int imu_mem, con
 int pb_step_legodo_feet(pb_ctx *ctx, const double *imu_block, int imu_mem, const double q[4], int64_t utime, const double *feet,
                         const double *forces, int mem, double r_vxyz, double r_vxyz_uncertain, double *lo_block_out,
                         uint8_t *mask_out);
+/* The joint-position filters in front of the kinematics -- step 0 of leg_estimate::updateOdometry (leg_estimate.cpp:411-428,
+ * state_estimator.legodo.filter_joint_positions): mode 1 = LowPassFilter (estimate_tools filter_tools/Filter.cpp:4-65: 14-tap
+ * FIR, the first sample fills the window), mode 2 = SimpleKalmanFilter (kalman_filter_tools/simple_kalman_filter.cpp:11-50;
+ * the three noise values are its constructor arguments -- leg_estimate.cpp:56 passes (joint_process_noise,
+ * joint_observation_noise) and leaves the third at 5e-4 -- kept as floats like its members).  One filter per robot and joint
+ * ROW THE KINEMATIC CHAINS READ (pb_legodo_set_chain first; setting another chain invalidates the filters) with row < 28
+ * (NUM_FILT_JOINTS, leg_estimate.hpp:59); pb_joint_filter_init starts every filter over.
+ * pb_joint_filter: one joint_state_t message per robot, [n_rows][B] floats (PB_HOST / PB_DEVICE; joint_position_out is a
+ * DEVICE array [n_rows][B] to be handed to pb_legodo_update_joints / pb_step_legodo_joints as PB_DEVICE) or ONE robot's
+ * [n_rows] values (PB_HOST_BROADCAST; joint_position_out is a HOST array [n_rows] to be passed on as PB_HOST_BROADCAST).
+ * joint_velocity: read by the Kalman filter's first sample only (may be NULL for the low-pass).  joint_effort != NULL: the
+ * handler's torque adjustment (rbis_legodo_update.cpp:231-241, gains of pb_legodo_set_chain) is applied BEFORE the filters
+ * as in the reference -- pass joint_effort = NULL to the kinematics afterwards.  Filtered positions are rounded to float
+ * like the reference's std::vector<float> (leg_estimate.hpp:91-93); rows no filter owns are copied. */
+int pb_joint_filter_init(pb_ctx *ctx, int mode, double process_noise_pos, double process_noise_vel, double observation_noise);
+int pb_joint_filter(pb_ctx *ctx, int64_t utime, int n_rows, const float *joint_position, const float *joint_velocity,
+                    const float *joint_effort, int mem, float *joint_position_out);
 /* forward kinematics alone (diagnostics, tests): feet_out [14][B] DEVICE array in pb_legodo_update's layout */
 int pb_legodo_fk(pb_ctx *ctx, int n_rows, const float *joint_position, const float *joint_effort, int mem, double *feet_out);
 /* one filter's odometry state, for diagnostics and tests: odom_to_body (t3, q4); info = primary_foot (0 left, 1 right),

@@ -17,7 +17,7 @@ VEL, CHI, POS = 3, 6, 9
 
 
 def build(force=False):
-    src = [os.path.join(_HERE, f) for f in ("pronto_oracle.c", "pronto_oracle.h")]
+    src = [os.path.join(_HERE, f) for f in ("pronto_oracle.c", "leg_odometry.c", "joint_filter.c", "pronto_oracle.h")]
     if (not force and os.path.exists(_LIB)
             and all(os.path.getmtime(_LIB) >= os.path.getmtime(s) for s in src if os.path.exists(s))):
         return _LIB

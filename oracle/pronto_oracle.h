@@ -158,6 +158,26 @@ float po_torque_adjust(float position, float effort, float gain);
 void po_leg_get(const po_leg *s, double *odom_to_body_t, double *odom_to_body_q, int *primary_foot, int *leg_odo_init, int *mode,
                 int *unknown_transitions);
 
+/* ---- joint-position filters in front of the kinematics (joint_filter.c): leg_estimate.cpp:43-61,411-428,
+ * estimate_tools filter_tools/Filter.cpp:4-65, kalman_filter_tools/simple_kalman_filter.cpp:11-50 ---- */
+#define PO_LP_TAPS 14
+#define PO_NUM_FILT_JOINTS 28
+typedef struct {
+  double coeffs[PO_LP_TAPS], buf[PO_LP_TAPS];
+  int begin, firstsample;
+} po_lowpass;
+typedef struct {
+  double P[2][2], x_est[2], tlast;
+  float R, process_noise_pos, process_noise_vel, observation_noise;
+  int init;
+} po_skf;
+void po_lowpass_init(po_lowpass *f);
+double po_lowpass_sample(po_lowpass *f, double sample);
+void po_skf_init(po_skf *k, double process_noise_pos, double process_noise_vel, double observation_noise);
+void po_skf_sample(po_skf *k, double t, double x, double x_dot, double *x_filtered, double *x_dot_filtered);
+/* mode 1 lowpass (lp[min(n,28)]), 2 kalman (kf[min(n,28)]): one robot's joint vector, filtered in place */
+void po_joint_filter(int mode, po_lowpass *lp, po_skf *kf, long utime, int n, float *joint_position, const float *joint_velocity);
+
 /* ---- IMU front end: estimate_tools/src/estimate_tools/iir_notch.cpp:3-61 (2nd-order IIR notch) ---- */
 typedef struct {
   double b[3], a[3]; /* num, den */

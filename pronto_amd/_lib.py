@@ -21,7 +21,7 @@ PB_CORR_POS_ORIENT, PB_CORR_POS_YAW = 0, 1
 
 def sources():
     return [os.path.join(CSRC, f) for f in ("pronto_batch.hip", "pb_step.hip", "pb_update.hip", "pb_update_rt21.hip", "pb_update_ct.hip", "pb_smooth.hip", "pb_ctx.hpp",
-                                            "rbis_kernels.hpp", "rbis_legodo.hpp", "rbis_legstep.hpp", "rbis_coop.hpp", "rbis_quad.hpp", "rbis_quad_rt.hpp", "rbis_smooth.hpp",
+                                            "rbis_kernels.hpp", "rbis_legodo.hpp", "rbis_legstep.hpp", "rbis_jointfilt.hpp", "rbis_coop.hpp", "rbis_quad.hpp", "rbis_quad_rt.hpp", "rbis_smooth.hpp",
                                             "rbis_device.hpp", "Makefile")] + [HEADER]
 
 
@@ -93,6 +93,8 @@ _SIGS = {
                                       C.c_double, C.c_void_p, C.c_void_p]),
     "pb_calib_copy_checksum": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_uint64)]),
     "pb_legodo_fk": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "pb_joint_filter_init": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double]),
+    "pb_joint_filter": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "pb_legodo_get": (C.c_int, [C.c_void_p, C.c_int, _dp, C.POINTER(C.c_int64)]),
     "pb_imu_notch_init": (C.c_int, [C.c_void_p, C.c_double, C.c_double]),
     "pb_imu_notch": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),

@@ -269,6 +269,30 @@ class BatchEstimator:
             raise ValueError("legodo_fk output must be a device tensor")
         self._chk(self._L.pb_legodo_fk(self._h, rows, pj, pe, _same_mem(m1, m2), po))
 
+    def joint_filter_init(self, mode, process_noise_pos=0.01, process_noise_vel=0.01, observation_noise=5e-4):
+        """mode: "lowpass" | "kalman" (state_estimator.legodo.filter_joint_positions, leg_estimate.cpp:43-61); the noise
+        defaults are SimpleKalmanFilter's constructor defaults."""
+        self._chk(self._L.pb_joint_filter_init(self._h, {"lowpass": 1, "kalman": 2}[mode], process_noise_pos, process_noise_vel,
+                                               observation_noise))
+
+    def joint_filter(self, utime, joint_position, joint_velocity, joint_effort, joint_position_out):
+        """One joint-state message through the joint filters.  Per-robot [rows, B] blocks (numpy or device tensors) ->
+        joint_position_out must be a device tensor [rows, B]; one robot's 1-D [rows] numpy arrays -> a 1-D numpy output."""
+        rows = joint_position.shape[0]
+        pj, m1 = _ptr_block(joint_position, rows, self.B, dtype=np.float32)
+        pv, m2 = (None, None) if joint_velocity is None else _ptr_block(joint_velocity, rows, self.B, dtype=np.float32)
+        pe, m3 = (None, None) if joint_effort is None else _ptr_block(joint_effort, rows, self.B, dtype=np.float32)
+        mem = _same_mem(m1, m2, m3)
+        if mem == PB_HOST_BROADCAST:
+            po, mo = _ptr(joint_position_out, np.float32, shape=(rows,))
+            if mo != PB_HOST:
+                raise ValueError("one robot's message: the output is a numpy array [rows]")
+        else:
+            po, mo = _ptr(joint_position_out, np.float32, shape=(rows, self.B))
+            if mo != PB_DEVICE:
+                raise ValueError("per-robot blocks: the output must be a device tensor [rows, B]")
+        self._chk(self._L.pb_joint_filter(self._h, int(utime), rows, pj, pv, pe, mem, po))
+
     def legodo_get(self, b):
         pose = (C.c_double * 7)()
         info = (C.c_int64 * 4)()

@@ -14,6 +14,7 @@
 #include "rbis_kernels.hpp"
 #include "rbis_legodo.hpp"
 #include "rbis_legstep.hpp"
+#include "rbis_jointfilt.hpp"
 
 using namespace pb;
 
@@ -37,6 +38,16 @@ struct pb_ctx {
   int32_t *leg_nc = nullptr;      // controller contact counts [2][B] (pb_legodo_set_control_contacts), used when leg_nc_dev
   int leg_nc_h[2] = { -1, -1 };   // ... or ONE pair for every filter (-1: none received yet)
   bool leg_nc_dev = false;
+  // joint-position filters in front of the kinematics (pb_joint_filter_init / pb_joint_filter, rbis_jointfilt.hpp)
+  JfPar jf_par;
+  bool jf_ready = false, jf_first = true;
+  int jf_input = -1;              // -1 no message yet, 0 per-robot blocks (state in HBM), 1 one robot (state on the host)
+  int jf_head = 0;                // low-pass window slot of the oldest sample
+  double jf_tlast = 0;            // SimpleKalmanFilter::tlast_
+  float *jf_ring = nullptr;       // [JF_TAPS][nf][B] floats
+  double *jf_kst = nullptr;       // [JF_KSTATE][nf][B]
+  std::vector<float> jf_ring_h;   // [JF_TAPS][nf]   (one robot)
+  std::vector<double> jf_kst_h;   // [JF_KSTATE][nf]
   double *leg_lo = nullptr;       // measurement block + mask between the two kernels of pb_step_legodo_joints' fallback path
   double *notch = nullptr;  // IMU notch cascade state [36][stride] (pb_imu_notch_init)
   NotchCoef notch_coef;

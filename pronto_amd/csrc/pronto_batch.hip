@@ -116,6 +116,8 @@ extern "C" int pb_destroy(pb_ctx *c)
   if (c->leg_chain) (void) hipFree(c->leg_chain);
   if (c->leg_nc) (void) hipFree(c->leg_nc);
   if (c->leg_lo) (void) hipFree(c->leg_lo);
+  if (c->jf_ring) (void) hipFree(c->jf_ring);
+  if (c->jf_kst) (void) hipFree(c->jf_kst);
   if (c->d_small) (void) hipFree(c->d_small);
   if (c->stage) (void) hipFree(c->stage);
   if (c->copy_stream) (void) hipStreamSynchronize(c->copy_stream);
@@ -911,6 +913,121 @@ extern "C" int pb_legodo_set_chain(pb_ctx *c, int n_left, int n_right, const int
   HIPCHK(c, hipMemcpy(c->leg_chain, &ch, sizeof ch, hipMemcpyHostToDevice));
   c->leg_chain_h = ch;
   c->leg_chain_rows = max_row + 1;
+  c->jf_ready = false;  // the filters' row list came from the old chain
+  return PB_OK;
+}
+
+// ---- joint-position filters in front of the kinematics (leg_estimate.cpp:411-428) ----------------------------------
+extern "C" int pb_joint_filter_init(pb_ctx *c, int mode, double process_noise_pos, double process_noise_vel, double observation_noise)
+{
+  ENTER(c);
+  if (mode != JF_LOWPASS && mode != JF_KALMAN) return fail(c, PB_ERR_ARG, "pb_joint_filter_init: mode must be 1 (lowpass) or 2 (kalman)");
+  if (!c->leg_chain) return fail(c, PB_ERR_STATE, "pb_joint_filter_init before pb_legodo_set_chain");
+  JfPar par;
+  memset(&par, 0, sizeof par);
+  par.mode = mode;
+  const LegChain &ch = c->leg_chain_h;
+  for (int side = 0; side < 2; side++) {
+    for (int j = 0; j < ch.n[side]; j++) {
+      if ((ch.code[side][j] & LC_TYPE) == LJ_FIXED) continue;
+      const int row = ch.row[side][j];
+      bool seen = false;
+      for (int f = 0; f < par.nf; f++) seen = seen || par.row[f] == row;
+      if (!seen && row < JF_NUM_FILT_JOINTS) par.row[par.nf++] = row;  // leg_estimate.cpp:415,419: i < NUM_FILT_JOINTS
+      if (ch.gain[side][j] != 0.0f) {
+        bool have = false;
+        for (int a = 0; a < par.nadj; a++) have = have || par.adj_row[a] == row;
+        if (!have) { par.adj_row[par.nadj] = row; par.adj_gain[par.nadj++] = ch.gain[side][j]; }
+      }
+    }
+  }
+  jf_lowpass_coeffs(par.coef);
+  par.pn_pos = (float) process_noise_pos;   // float members (simple_kalman_filter.hpp:39-40)
+  par.pn_vel = (float) process_noise_vel;
+  par.r = (float) observation_noise;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (c->jf_ring) { (void) hipFree(c->jf_ring); c->jf_ring = nullptr; }
+  if (c->jf_kst) { (void) hipFree(c->jf_kst); c->jf_kst = nullptr; }
+  c->jf_ring_h.clear();
+  c->jf_kst_h.clear();
+  c->jf_par = par;
+  c->jf_first = true;
+  c->jf_input = -1;
+  c->jf_head = 0;
+  c->jf_tlast = 0;
+  c->jf_ready = true;
+  return PB_OK;
+}
+
+extern "C" int pb_joint_filter(pb_ctx *c, int64_t utime, int n_rows, const float *joint_position, const float *joint_velocity,
+                               const float *joint_effort, int mem, float *joint_position_out)
+{
+  ENTER(c);
+  if (!c->jf_ready) return fail(c, PB_ERR_STATE, "pb_joint_filter before pb_joint_filter_init (or the chain changed since)");
+  if (!joint_position || !joint_position_out) return fail(c, PB_ERR_ARG, "pb_joint_filter: NULL input");
+  if (n_rows < c->leg_chain_rows) return fail(c, PB_ERR_ARG, "pb_joint_filter: the chain reads joint row %d, the block has %d rows", c->leg_chain_rows - 1, n_rows);
+  JfPar &par = c->jf_par;
+  if (par.mode == JF_KALMAN && !joint_velocity) return fail(c, PB_ERR_ARG, "pb_joint_filter: the Kalman filter starts from joint_velocity");
+  const int input = (mem == PB_HOST_BROADCAST) ? 1 : 0;
+  if (c->jf_input >= 0 && c->jf_input != input)
+    return fail(c, PB_ERR_STATE, "pb_joint_filter: per-robot and one-robot messages cannot be mixed (pb_joint_filter_init starts over)");
+  const double t = (double) utime * 1E-6;  // leg_estimate.cpp:422
+  const double dt = t - c->jf_tlast;
+  const int first = c->jf_first ? 1 : 0;
+  const size_t B = (size_t) c->B, nf = (size_t) par.nf;
+  auto adjusted = [&](const float *pos, const float *eff, int row, size_t at) {
+    float g = 0.0f;
+    for (int a = 0; a < par.nadj; a++) g = (par.adj_row[a] == row) ? par.adj_gain[a] : g;
+    return eff ? torque_adjust(pos[at], eff[at], g) : pos[at];
+  };
+  if (input == 1) {
+    // one robot's joints for every filter of the batch: a per-MESSAGE computation, done once on the host with the functions
+    // the kernel runs per robot; the output is a host array the caller passes on as PB_HOST_BROADCAST
+    if (c->jf_input < 0) {
+      c->jf_ring_h.assign(JF_TAPS * nf, 0.0f);
+      c->jf_kst_h.assign(JF_KSTATE * nf, 0.0);
+    }
+    for (int row = 0; row < n_rows; row++) joint_position_out[row] = adjusted(joint_position, joint_effort, row, (size_t) row);
+    for (size_t f = 0; f < nf; f++) {
+      const int row = par.row[f];
+      const float x = joint_position_out[row];
+      if (par.mode == JF_LOWPASS) {
+        float *ring = c->jf_ring_h.data();
+        if (first) for (int s = 0; s < JF_TAPS; s++) ring[s * nf + f] = x;
+        else ring[c->jf_head * nf + f] = x;
+        const int head = c->jf_head;
+        joint_position_out[row] = jf_lowpass(par.coef, [&](int i) { return first ? x : ring[((head + 1 + i) % JF_TAPS) * nf + f]; });
+      } else {
+        double s[JF_KSTATE];
+        if (first) {
+          s[0] = (double) x; s[1] = (double) joint_velocity[row];
+          s[2] = 1.0; s[3] = 0.0; s[4] = 0.0; s[5] = 1.0;
+        } else {
+          for (int i = 0; i < JF_KSTATE; i++) s[i] = c->jf_kst_h[i * nf + f];
+          joint_position_out[row] = jf_kalman(s, dt, x, par.pn_pos, par.pn_vel, par.r);
+        }
+        for (int i = 0; i < JF_KSTATE; i++) c->jf_kst_h[i * nf + f] = s[i];
+      }
+    }
+  } else {
+    if (par.mode == JF_LOWPASS && !c->jf_ring) HIPCHK(c, hipMalloc((void **) &c->jf_ring, sizeof(float) * JF_TAPS * (nf ? nf : 1) * B));
+    if (par.mode == JF_KALMAN && !c->jf_kst) HIPCHK(c, hipMalloc((void **) &c->jf_kst, sizeof(double) * JF_KSTATE * (nf ? nf : 1) * B));
+    const size_t blk = sizeof(float) * (size_t) n_rows * B;
+    Part p[3] = { { joint_position, blk, 0 }, { joint_velocity, joint_velocity ? blk : 0, 0 }, { joint_effort, joint_effort ? blk : 0, 0 } };
+    int rc = stage_in(c, mem, p, 3);
+    if (rc) return rc;
+    if (par.nf > 0)
+      k_joint_filter<<<dim3((unsigned) nblk(c->B), (unsigned) par.nf), 64, 0, c->stream>>>(
+          par, c->B, (const float *) p[0].dev, (const float *) p[1].dev, (const float *) p[2].dev, joint_position_out, c->jf_ring,
+          c->jf_kst, c->jf_head, first, dt);
+    k_joint_passthrough<<<dim3((unsigned) nblk(c->B), (unsigned) n_rows), 64, 0, c->stream>>>(par, c->B, n_rows, (const float *) p[0].dev,
+                                                                                            (const float *) p[2].dev, joint_position_out);
+    LAUNCHCHK(c);
+  }
+  c->jf_input = input;
+  if (!first && par.mode == JF_LOWPASS) c->jf_head = (c->jf_head + 1) % JF_TAPS;
+  c->jf_first = false;
+  c->jf_tlast = t;
   return PB_OK;
 }
 

@@ -29,7 +29,7 @@ def harness():
     out = os.path.join(ROOT, "tests", "build", "libhost_harness.so")
     src = os.path.join(ROOT, "tests", "host_harness.cpp")
     deps = [src] + [os.path.join(ROOT, "pronto_amd", "csrc", h)
-                    for h in ("rbis_device.hpp", "rbis_coop.hpp", "rbis_quad.hpp", "rbis_legodo.hpp")]
+                    for h in ("rbis_device.hpp", "rbis_coop.hpp", "rbis_quad.hpp", "rbis_legodo.hpp", "rbis_jointfilt.hpp")]
     if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(d) for d in deps):
         os.makedirs(os.path.dirname(out), exist_ok=True)
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-pthread", "-o", out, src])
