@@ -929,7 +929,7 @@ struct joint_state_t {       // bot_core::joint_state_t: the arrays are float on
   int64_t utime;
   std::vector<std::string> joint_name;      // num_joints names, the same for every filter
   const float *joint_position = nullptr;    // [num_joints][B] (PB_HOST / PB_DEVICE) or [num_joints] (PB_HOST_BROADCAST)
-  const float *joint_velocity = nullptr;    // (only the joint Kalman filter reads it, leg_estimate.cpp:418-426: not built)
+  const float *joint_velocity = nullptr;    // (only the joint Kalman filter reads it, leg_estimate.cpp:418-426)
   const float *joint_effort = nullptr;      // same shape as joint_position; read when legodo.torque_adjustment is set
   int mem = PB_HOST;
 };
@@ -1607,10 +1607,14 @@ public:
     // leg_estimate's constructor (leg_estimate.cpp:29-142)
     const std::string init_mode = bot_param_get_str_or_fail(param, "state_estimator.legodo.initialization_mode");
     if (init_mode != "zero") fprintf(stdout, "Leg Odometry Initialize Mode: %s (only \"zero\" moves the pose, leg_estimate.cpp:172-190)\n", init_mode.c_str());
+    // leg_estimate.cpp:43-61: "lowpass" | "kalman" | anything else = no filtering
     const std::string filt = bot_param_get_str_or_fail(param, "state_estimator.legodo.filter_joint_positions");
-    if (filt == "lowpass" || filt == "kalman") {
-      fprintf(stderr, "LegOdoHandler: state_estimator.legodo.filter_joint_positions = %s is not built (use none)\n", filt.c_str());
-      exit(1);
+    if (filt == "lowpass") {
+      filter_joint_positions_ = 1;
+    } else if (filt == "kalman") {
+      filter_joint_positions_ = 2;
+      joint_process_noise_ = bot_param_get_double_or_fail(param, "state_estimator.legodo.joint_process_noise");
+      joint_observation_noise_ = bot_param_get_double_or_fail(param, "state_estimator.legodo.joint_observation_noise");
     }
     use_torque_adjustment_ = bot_param_get_boolean_or_fail(param, "state_estimator.legodo.torque_adjustment");
     if (use_torque_adjustment_) {  // rbis_legodo_update.cpp:29-53
@@ -1656,6 +1660,9 @@ public:
 
   BotParam *param_ = nullptr;
   const ModelClient *model_ = nullptr;
+  int filter_joint_positions_ = 0;   // 0 none, 1 lowpass, 2 kalman (leg_estimate.cpp:43-61)
+  double joint_process_noise_ = 0, joint_observation_noise_ = 0;
+  std::shared_ptr<DevicePool> jf_pool_;   // filtered joint blocks [rows][B] floats (per-filter joint states)
   bool use_torque_adjustment_ = false;
   std::vector<std::string> adjustment_joints_;
   std::vector<float> adjustment_gain_;
@@ -1736,6 +1743,17 @@ public:
       fprintf(stderr, "LegOdoHandler: %s\n", pb_last_error(est->ctx));
       exit(1);
     }
+    if (filter_joint_positions_ != 0) {
+      // SimpleKalmanFilter(joint_process_noise, joint_observation_noise) (leg_estimate.cpp:56): the two values land in
+      // process_noise_pos_ and process_noise_vel_, observation_noise_ keeps its default 5E-4 (simple_kalman_filter.hpp:15).
+      // A new joint order (a new chain) starts the filters over.
+      if (pb_joint_filter_init(est->ctx, filter_joint_positions_, joint_process_noise_, joint_observation_noise_, 5E-4) != PB_OK) {
+        fprintf(stderr, "LegOdoHandler: %s\n", pb_last_error(est->ctx));
+        exit(1);
+      }
+      // per-filter joint states: the filtered block [rows][B] and, for host messages, the two foot forces [2][B] behind it
+      jf_pool_ = std::make_shared<DevicePool>(est->ctx, est->ctx_alive, sizeof(float) * (msg->joint_name.size() + 2) * (size_t) est->B);
+    }
     chain_names_ = msg->joint_name;
     chain_ready_ = true;
   }
@@ -1750,6 +1768,7 @@ public:
     const double *feet = nullptr, *forces = nullptr;
     std::vector<float> own_f;
     std::vector<double> own_d;
+    std::shared_ptr<DeviceBlock> filtered;   // the joint filters' output block, when they run on the device
     double r = 0, ru = 0;
     // odometry alone (imu == NULL) or slaved to the state after `imu`; outputs as pb_legodo_update_joints
     int odometry(pb_ctx *ctx, const BatchArray *imu, double *o_delta, double *o_status, double *d_lo, uint8_t *d_mask, double *o_pos,
@@ -1874,7 +1893,50 @@ public:
     lm->rows = (int) msg->joint_name.size();
     lm->utime = msg->utime;
     const float *eff = use_torque_adjustment_ ? msg->joint_effort : nullptr;
-    if (msg->mem == PB_HOST_BROADCAST) {  // one robot's message: own the few numbers
+    if (filter_joint_positions_ != 0) {
+      // leg_estimate.cpp:411-428, after the torque adjustment (rbis_legodo_update.cpp:231-241): pb_joint_filter does both, the
+      // kinematics then read the filtered block without an effort
+      if (filter_joint_positions_ == 2 && msg->joint_velocity == nullptr) {
+        fprintf(stderr, "LegOdoHandler: filter_joint_positions = kalman reads joint_velocity\n");
+        return nullptr;
+      }
+      float *out = nullptr;
+      if (msg->mem == PB_HOST_BROADCAST) {
+        lm->own_f.assign((size_t) lm->rows + 2, 0.0f);
+        out = lm->own_f.data();
+      } else {
+        bool fresh = false;
+        void *blk = jf_pool_->get(fresh);
+        if (blk == nullptr) {
+          fprintf(stderr, "LegOdoHandler: %s\n", pb_last_error(est->ctx));
+          return nullptr;
+        }
+        lm->filtered = std::make_shared<DeviceBlock>(jf_pool_, blk);
+        out = (float *) blk;
+      }
+      if (pb_joint_filter(est->ctx, msg->utime, lm->rows, msg->joint_position, msg->joint_velocity, eff, msg->mem, out) != PB_OK) {
+        fprintf(stderr, "LegOdoHandler: %s\n", pb_last_error(est->ctx));
+        return nullptr;
+      }
+      lm->jp = out;
+      lm->je = nullptr;
+      if (msg->mem == PB_HOST_BROADCAST) {
+        lm->own_f[(size_t) lm->rows] = forces[0];
+        lm->own_f[(size_t) lm->rows + 1] = forces[1];
+        lm->ff = lm->own_f.data() + lm->rows;
+      } else {
+        lm->ff = forces;
+        if (msg->mem == PB_HOST) {  // the filtered joints are in HBM: the foot forces of a host message follow them there
+          float *dff = out + (size_t) lm->rows * est->B;
+          if (pb_memcpy_h2d(est->ctx, dff, forces, sizeof(float) * 2 * (size_t) est->B) != PB_OK) {
+            fprintf(stderr, "LegOdoHandler: %s\n", pb_last_error(est->ctx));
+            return nullptr;
+          }
+          lm->ff = dff;
+          lm->mem = PB_DEVICE;
+        }
+      }
+    } else if (msg->mem == PB_HOST_BROADCAST) {  // one robot's message: own the few numbers
       lm->own_f.assign(msg->joint_position, msg->joint_position + lm->rows);
       if (eff) lm->own_f.insert(lm->own_f.end(), eff, eff + lm->rows);
       lm->own_f.insert(lm->own_f.end(), forces, forces + 2);

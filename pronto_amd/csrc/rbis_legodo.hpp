@@ -19,7 +19,7 @@
 // Poses are (translation, unit quaternion) pairs here, where the reference holds Eigen::Isometry3d and converts rotation
 // matrices to quaternions and back at every step (:231-240); the two agree to rounding (a quaternion's overall sign never
 // matters for a pose; Isometry3d::inverse() transposes, which is the quaternion CONJUGATE, no division).  The joint
-// low-pass / Kalman filters (:411-428, filter_joint_positions = none) are not built.
+// low-pass / Kalman filters in front of the kinematics (:411-428) are rbis_jointfilt.hpp.
 //
 // Per-robot state (round 3: 136 bytes, was 296): NLD doubles + NLI 64-bit words, struct-of-arrays, robot index fastest.
 //   * odom_to_secondary_foot_ is not kept: the reference only draws it (pc_vis_, determineContactPoints);

@@ -72,6 +72,21 @@ for n in (15, 21):
     rows.append(("pair in one call: IMU + joint state", t, 2 * st + 56 + leg + 56))
     t = timeit(lambda: (lambda m: est.step_legodo_joints(imu, q4, m[0], m[1], m[2], m[3], 0.1, 0.5))(nxt(jm)))
     rows.append(("pair in one call: IMU + joint state + efforts", t, 2 * st + 56 + leg + 104))
+    if n == 15:
+        # the joint filters in front of the kinematics (pb_joint_filter): 12 chain rows; low-pass = 13 window floats in + 1 out,
+        # Kalman = 6 doubles in + 6 out, + the float in / out of each row
+        d_f = torch.zeros((12, B), dtype=torch.float32, device=dev)
+        jv = up(np.zeros((12, B), dtype=np.float32))
+        for mode, nb in (("lowpass", 12 * (13 * 4 + 4 + 8)), ("kalman", 12 * (96 + 8))):
+            est.joint_filter_init(mode, 0.01, 5e-4, 5e-4)
+            ut = [1_000_000]
+
+            def one():
+                ut[0] += 2000
+                m = nxt(jm)
+                est.joint_filter(ut[0], m[1], jv, m[2], d_f)
+            t = timeit(one)
+            rows.append(("k_joint_filter %s: 12 joints (+ torque adjustment)" % mode, t, nb))
     for name, t, nb in rows:
         print("n=%d B=%d %-52s %7.1f us  %6.0f GB/s  frac %.3f" % (n, B, name, t * 1e6, nb * B / t / 1e9, nb * B / t / 1e9 / 8000))
     est.close()

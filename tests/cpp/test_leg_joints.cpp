@@ -5,6 +5,8 @@
 // po_leg_update_wc (given the oracle filter's own head pose) -> po_legodo_create_measurement -> po_indexed_update.
 //   argv[1]: legodo mode (lin_rate | lin_rot_rate | pos_and_lin_rate)      argv[2]: contact mode (alt | standing | ctrl)
 //   argv[3]: "fuse" = state_estimator.fuse_ins_legodo                      argv[4]: "bcast" = one robot's log for every filter
+//   argv[5]: state_estimator.legodo.filter_joint_positions (none | lowpass | kalman; leg_estimate.cpp:411-428), the oracle chain
+//            then has po_joint_filter between the torque adjustment and the kinematics
 // Exit code 0 + "PASS".  Needs a GPU.
 #include <cinttypes>
 #include <cstdio>
@@ -59,6 +61,8 @@ int main(int argc, char **argv)
   const std::string cmode = argc > 2 ? argv[2] : "alt";
   const bool fuse = argc > 3 && std::string(argv[3]) == "fuse";
   const bool bcast = argc > 4 && std::string(argv[4]) == "bcast";
+  const std::string jfilt = argc > 5 ? argv[5] : "none";
+  const int jmode = jfilt == "lowpass" ? 1 : (jfilt == "kalman" ? 2 : 0);
   const int n = 15, B = 64, T = 900, NJ = 16, ZERO = 3;
   double g;
   po_get_constants(&g, nullptr);
@@ -84,7 +88,8 @@ int main(int argc, char **argv)
                        "state_estimator.legodo.schmitt_low_delay=7000|state_estimator.legodo.schmitt_high_delay=7000|"
                        "state_estimator.legodo.filter_contact_events=true|state_estimator.legodo.zero_initial_velocity=3|"
                        "state_estimator.legodo.initialization_mode=zero|state_estimator.legodo.left_standing_link=l_foot|"
-                       "state_estimator.legodo.right_standing_link=r_foot|state_estimator.legodo.filter_joint_positions=none|"
+                       "state_estimator.legodo.right_standing_link=r_foot|state_estimator.legodo.filter_joint_positions=" + jfilt + "|"
+                       "state_estimator.legodo.joint_process_noise=0.01|state_estimator.legodo.joint_observation_noise=0.0005|"
                        "state_estimator.legodo.total_force=900|state_estimator.legodo.standing_schmitt_level=0.65|"
                        "state_estimator.legodo.torque_adjustment=true|state_estimator.legodo.adjustment_joints=l_leg_hpz,l_leg_kny,r_leg_kny,r_leg_akx,back_bkz|"
                        "state_estimator.legodo.adjustment_gain=7000,10000,10000,0,5000");
@@ -130,6 +135,12 @@ int main(int argc, char **argv)
   std::vector<double> oll(B, 0.0), period(B), phase(B), swing(B);
   std::vector<std::vector<char>> legs(B, std::vector<char>(po_leg_sizeof()));
   std::vector<int> zc(B, ZERO);
+  // leg_estimate's lpfilter_ / joint_kf_ (one per joint, leg_estimate.cpp:45-58: SimpleKalmanFilter(process, observation) -- the
+  // second value lands in process_noise_vel_, the observation noise keeps its default)
+  std::vector<std::vector<po_lowpass>> olp(B, std::vector<po_lowpass>(PO_NUM_FILT_JOINTS));
+  std::vector<std::vector<po_skf>> okf(B, std::vector<po_skf>(PO_NUM_FILT_JOINTS));
+  for (int b = 0; b < B; b++)
+    for (int i = 0; i < PO_NUM_FILT_JOINTS; i++) { po_lowpass_init(&olp[b][i]); po_skf_init(&okf[b][i], 0.01, 0.0005, 5E-4); }
   for (int b = 0; b < B; b++) {
     double q[4];
     po_euler_to_quat(0.05 * (urand() - 0.5), 0.05 * (urand() - 0.5), 6.0 * (urand() - 0.5), q);
@@ -160,7 +171,7 @@ int main(int argc, char **argv)
     const double r5[5] = { 2.0, 5.0, 3.0, 10.0, 9.0 };
     const int omode = lomode == "lin_rate" ? 0 : (lomode == "lin_rot_rate" ? 1 : 2);
     const int W = bcast ? 1 : B;
-    std::vector<float> jp((size_t) NJ * W), je((size_t) NJ * W);
+    std::vector<float> jp((size_t) NJ * W), je((size_t) NJ * W), jv((size_t) NJ * W);
     std::vector<double> fz(2 * (size_t) W);
     int ncl = -1, ncr = -1;
     for (int k = 0; k < T; k++) {
@@ -178,7 +189,11 @@ int main(int argc, char **argv)
         fz[b] = -(900 * wl + 5 * nrand());      // the sensor's sign is not the handler's business: it takes fabs (:234-235)
         fz[W + b] = 900 * wr + 5 * nrand();
         const double sw = sin(2 * M_PI * ph);
-        for (int j = 0; j < NJ; j++) { jp[(size_t) j * W + b] = (float) (0.3 * nrand()); je[(size_t) j * W + b] = (float) (40 * nrand()); }
+        for (int j = 0; j < NJ; j++) {
+          jp[(size_t) j * W + b] = (float) (0.3 * nrand());
+          je[(size_t) j * W + b] = (float) (40 * nrand());
+          jv[(size_t) j * W + b] = (float) (0.5 * nrand());
+        }
         for (int side = 0; side < 2; side++) {
           const double sgn = side ? -1.0 : 1.0, lift = fmax(0.0, -sgn * sw);
           const int r0 = side ? 9 : 1, r1 = side ? 13 : 5;
@@ -195,6 +210,7 @@ int main(int argc, char **argv)
       js.joint_name = names;
       js.joint_position = jp.data();
       js.joint_effort = je.data();
+      js.joint_velocity = jv.data();
       js.mem = bcast ? PB_HOST_BROADCAST : PB_HOST;
       if (k == 0) {  // before the first force/torque message nothing is integrated (:208-211)
         const int before = (int) est.history.updateMap.size();
@@ -214,12 +230,18 @@ int main(int argc, char **argv)
       for (int b = 0; b < B; b++) {
         const int s = bcast ? 0 : b;
         double ft_[2][3], fq_[2][4];
-        for (int side = 0; side < 2; side++) {
-          double ang[8];
+        // one robot's joint vector: torque adjustment (rbis_legodo_update.cpp:231-241), then the joint filters (leg_estimate.cpp:411-428)
+        float pos[NJ], vel[NJ];
+        for (int j = 0; j < NJ; j++) { pos[j] = jp[(size_t) j * W + s]; vel[j] = jv[(size_t) j * W + s]; }
+        for (int side = 0; side < 2; side++)
           for (int j = 0; j < och[side].n; j++) {
             const size_t at = (size_t) och[side].row[j] * W + s;
-            ang[j] = (double) po_torque_adjust(jp[at], je[at], och[side].gain[j]);
+            pos[och[side].row[j]] = po_torque_adjust(jp[at], je[at], och[side].gain[j]);
           }
+        po_joint_filter(jmode, olp[b].data(), okf[b].data(), utime, NJ, pos, vel);
+        for (int side = 0; side < 2; side++) {
+          double ang[8];
+          for (int j = 0; j < och[side].n; j++) ang[j] = (double) pos[och[side].row[j]];
           po_fk(och[side].n, och[side].type, och[side].org, och[side].axis, ang, ft_[side], fq_[side]);
         }
         double dt3[3], dq[4], cpos[3];
@@ -253,8 +275,8 @@ int main(int argc, char **argv)
     el = fmax(el, fabs(ll[b] - oll[b]));
     sl = fmax(sl, fabs(oll[b]));
   }
-  printf("mode %s / %s%s%s: status skip/certain/uncertain %d/%d/%d, position updates %d: rel err vec %.2e quat %.2e cov %.2e ll %.2e (status %d, fused pairs %lld)\n",
-         lomode.c_str(), cmode.c_str(), fuse ? " fused" : "", bcast ? " bcast" : "", n_status[0], n_status[1], n_status[2], n_pos, ev / sv, eq, eP / sP,
+  printf("mode %s / %s%s%s, joint filter %s: status skip/certain/uncertain %d/%d/%d, position updates %d: rel err vec %.2e quat %.2e cov %.2e ll %.2e (status %d, fused pairs %lld)\n",
+         lomode.c_str(), cmode.c_str(), fuse ? " fused" : "", bcast ? " bcast" : "", jfilt.c_str(), n_status[0], n_status[1], n_status[2], n_pos, ev / sv, eq, eP / sP,
          el / sl, est.last_status, (long long) est.fused_pairs);
   const bool fused_ok = !fuse || lomode != "lin_rate" || est.fused_pairs > T / 2;
   const bool pos_ok = lomode != "pos_and_lin_rate" || n_pos > B * T / 20;
