@@ -1016,12 +1016,9 @@ extern "C" int pb_joint_filter(pb_ctx *c, int64_t utime, int n_rows, const float
     Part p[3] = { { joint_position, blk, 0 }, { joint_velocity, joint_velocity ? blk : 0, 0 }, { joint_effort, joint_effort ? blk : 0, 0 } };
     int rc = stage_in(c, mem, p, 3);
     if (rc) return rc;
-    if (par.nf > 0)
-      k_joint_filter<<<dim3((unsigned) nblk(c->B), (unsigned) par.nf), 64, 0, c->stream>>>(
-          par, c->B, (const float *) p[0].dev, (const float *) p[1].dev, (const float *) p[2].dev, joint_position_out, c->jf_ring,
-          c->jf_kst, c->jf_head, first, dt);
-    k_joint_passthrough<<<dim3((unsigned) nblk(c->B), (unsigned) n_rows), 64, 0, c->stream>>>(par, c->B, n_rows, (const float *) p[0].dev,
-                                                                                            (const float *) p[2].dev, joint_position_out);
+    k_joint_filter<<<dim3((unsigned) ((c->B + 255) / 256), (unsigned) n_rows), 256, 0, c->stream>>>(
+        par, c->B, (const float *) p[0].dev, (const float *) p[1].dev, (const float *) p[2].dev, joint_position_out, c->jf_ring, c->jf_kst,
+        c->jf_head, first, dt);
     LAUNCHCHK(c);
   }
   c->jf_input = input;

@@ -89,26 +89,29 @@ PB_HD float jf_kalman(double (&s)[JF_KSTATE], double dt, float x_in, float pn_po
 }
 
 #if defined(__HIPCC__)
-// One lane per (robot, filtered row); blockIdx.y = index into par.row.  in/out: [rows][B] floats; ring: [JF_TAPS][nf][B] floats;
-// kst: [JF_KSTATE][nf][B] doubles.  head = window slot of the OLDEST sample (the one this call overwrites); first = this is the
-// first message since pb_joint_filter_init.
-static __global__ void k_joint_filter(JfPar par, int B, const float *__restrict__ pos, const float *__restrict__ vel,
-                                      const float *__restrict__ eff, float *__restrict__ out, float *__restrict__ ring,
-                                      double *__restrict__ kst, int head, int first, double dt)
+// One lane per (robot, row of the message); blockIdx.y = row.  A row no filter owns is copied (torque-adjusted where it has a
+// gain: chain rows >= 28).  in/out: [rows][B] floats; ring: [JF_TAPS][nf][B] floats; kst: [JF_KSTATE][nf][B] doubles.
+// head = window slot of the OLDEST sample (the one this call overwrites); first = this is the first message since
+// pb_joint_filter_init.
+static __global__ __launch_bounds__(256) void k_joint_filter(JfPar par, int B, const float *__restrict__ pos, const float *__restrict__ vel,
+                                                             const float *__restrict__ eff, float *__restrict__ out,
+                                                             float *__restrict__ ring, double *__restrict__ kst, int head, int first,
+                                                             double dt)
 {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  const int f = blockIdx.y;
+  const int row = blockIdx.y;
   if (b >= B) return;
-  const int row = par.row[f];
+  int f = -1;  // (uniform)
+  for (int i = 0; i < par.nf; i++) f = (par.row[i] == row) ? i : f;
   float x = pos[(long) row * B + b];
   if (eff) {
     float g = 0.0f;
     for (int a = 0; a < par.nadj; a++) g = (par.adj_row[a] == row) ? par.adj_gain[a] : g;  // (uniform)
     x = torque_adjust(x, eff[(long) row * B + b], g);
   }
+  float y = x;
   const long nfB = (long) par.nf * B, fb = (long) f * B + b;
-  float y;
-  if (par.mode == JF_LOWPASS) {
+  if (f >= 0 && par.mode == JF_LOWPASS) {
     float w[JF_TAPS];
 #pragma unroll
     for (int i = 0; i < JF_TAPS - 1; i++) {  // the 13 samples that stay, oldest first: slots head + 1 ... head + 13 (mod 14)
@@ -124,13 +127,12 @@ static __global__ void k_joint_filter(JfPar par, int B, const float *__restrict_
     } else {
       ring[(long) head * nfB + fb] = x;
     }
-  } else {
+  } else if (f >= 0) {
     double s[JF_KSTATE];
     if (first) {  // simple_kalman_filter.cpp:27-34: x_est = (x, x_dot), P stays the identity of the constructor, output = input
       s[0] = (double) x;
       s[1] = (double) vel[(long) row * B + b];
       s[2] = 1.0; s[3] = 0.0; s[4] = 0.0; s[5] = 1.0;
-      y = x;
     } else {
 #pragma unroll
       for (int i = 0; i < JF_KSTATE; i++) s[i] = kst[(long) i * nfB + fb];
@@ -140,24 +142,6 @@ static __global__ void k_joint_filter(JfPar par, int B, const float *__restrict_
     for (int i = 0; i < JF_KSTATE; i++) kst[(long) i * nfB + fb] = s[i];
   }
   out[(long) row * B + b] = y;
-}
-
-// the rows no filter touches: copied, torque-adjusted where the row has a gain (chain rows >= 28)
-static __global__ void k_joint_passthrough(JfPar par, int B, int rows, const float *__restrict__ pos, const float *__restrict__ eff,
-                                           float *__restrict__ out)
-{
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  const int row = blockIdx.y;
-  if (b >= B) return;
-  for (int f = 0; f < par.nf; f++)
-    if (par.row[f] == row) return;  // (uniform) k_joint_filter writes this row
-  float x = pos[(long) row * B + b];
-  if (eff) {
-    float g = 0.0f;
-    for (int a = 0; a < par.nadj; a++) g = (par.adj_row[a] == row) ? par.adj_gain[a] : g;
-    x = torque_adjust(x, eff[(long) row * B + b], g);
-  }
-  out[(long) row * B + b] = x;
 }
 #endif
 
