@@ -294,3 +294,33 @@ def test_filtered_joints_through_kinematics_and_contact_logic_on_gpu(oracle, mod
         seen.update(np.unique(os_).tolist())
     assert seen >= {-1.0, 0.0}
     est.close()
+
+
+@pytest.mark.gpu
+def test_joint_filter_argument_errors_on_gpu():
+    """Error behaviour of the two entry points: order of calls, bad mode, short blocks, the Kalman filter without velocities."""
+    import torch
+    import legs
+    from pronto_amd import batch as pa
+    B = 70
+    dev = torch.device("cuda:0")
+    est = pa.BatchEstimator(B, n_states=15)
+    z = np.zeros((legs.N_ROWS, B), dtype=np.float32)
+    out = torch.zeros((legs.N_ROWS, B), dtype=torch.float32, device=dev)
+    with pytest.raises(pa.PbError):
+        est.joint_filter_init("lowpass")                       # no chain yet
+    setup_chain(est, legs)
+    with pytest.raises(pa.PbError):
+        est.joint_filter(1000, z, z, None, out)                # not initialised
+    with pytest.raises(pa.PbError):
+        est._chk(est._L.pb_joint_filter_init(est._h, 3, 0.01, 0.01, 5e-4))   # bad mode
+    est.joint_filter_init("kalman")
+    with pytest.raises(pa.PbError):
+        est.joint_filter(1000, z, None, None, out)             # the Kalman filter starts from the velocity
+    short = np.zeros((10, B), dtype=np.float32)                # the chain reads row 15
+    with pytest.raises(pa.PbError):
+        est.joint_filter(1000, short, short, None, torch.zeros((10, B), dtype=torch.float32, device=dev))
+    est.joint_filter(1000, z, z, None, out)                    # and a good call still works afterwards
+    est.joint_filter(3000, z, z, None, out)
+    assert np.array_equal(out.cpu().numpy(), z)
+    est.close()
