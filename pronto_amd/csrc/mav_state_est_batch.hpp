@@ -2293,6 +2293,91 @@ private:
   }
 };
 
+// PoseMeasHandler (motion_estimate/src/pose_meas/pose_meas.cpp:7-131): a bot_core::pose_t as a position or position +
+// orientation measurement, `no_corrections` messages long, then silent.  Same update kernels as the VO / Vicon lists.
+class PoseMeasHandler {
+public:
+  typedef enum { MODE_POSITION, MODE_POSITION_ORIENT } PoseMeasMode;
+  PoseMeasMode mode;
+  int no_corrections;  // no of corrections to make before going silent
+  std::vector<int> z_indices;
+  std::vector<double> cov_pose_meas;  // diagonal, of the measured entries
+  double r_xyz2, r_chi2;
+  explicit PoseMeasHandler(BotParam *param)
+  {
+    const std::string mode_str = bot_param_get_str_or_fail(param, "state_estimator.pose_meas.mode");
+    if (mode_str == "position") mode = MODE_POSITION;
+    else if (mode_str == "position_orient") mode = MODE_POSITION_ORIENT;
+    else {
+      mode = MODE_POSITION;
+      fprintf(stdout, "Unrecognized PoseMeas mode. Using position mode by default.\n");
+    }
+    no_corrections = (int) bot_param_get_double_or_fail(param, "state_estimator.pose_meas.no_corrections");
+    r_xyz2 = bot_sq(bot_param_get_double_or_fail(param, "state_estimator.pose_meas.r_xyz"));
+    r_chi2 = bot_sq(bot_to_radians(bot_param_get_double_or_fail(param, "state_estimator.pose_meas.r_chi")));
+    if (mode == MODE_POSITION) { z_indices = RBIS::positionInds(); cov_pose_meas = { r_xyz2, r_xyz2, r_xyz2 }; }
+    else { z_indices = { 9, 10, 11, 6, 7, 8 }; cov_pose_meas = { r_xyz2, r_xyz2, r_xyz2, r_chi2, r_chi2, r_chi2 }; }
+  }
+  RBISUpdateInterface *processMessage(const msgs::pose_t *msg, MavStateEstimator *est)
+  {
+    // "If we have created no_corrections, go silent afterwards" (:56-64): decrement first, then compare
+    no_corrections--;
+    if (no_corrections == 1) fprintf(stdout, "Finished making PoseMeas corrections\n");
+    if (no_corrections <= 0) return nullptr;
+    const int mem = msg->pos.mem;
+    if (mem == PB_DEVICE || msg->orientation.mem != mem) {
+      fprintf(stderr, "PoseMeasHandler: host (or host-broadcast) pos and orientation arrays expected\n");
+      return nullptr;
+    }
+    const size_t per = (mem == PB_HOST_BROADCAST) ? 1 : (size_t) est->B;
+    // a pose at the origin is "no pose" (:74-75), per filter: mask
+    std::vector<uint8_t> mask;
+    if (per > 1) mask.assign(per, 1);
+    bool any = false;
+    for (size_t b = 0; b < per; b++) {
+      const bool dropped = fabs(msg->pos.p[b]) < 1e-5 && fabs(msg->pos.p[per + b]) < 1e-5 && fabs(msg->pos.p[2 * per + b]) < 1e-5;
+      if (per > 1) mask[b] = !dropped;
+      any = any || !dropped;
+    }
+    if (!any) return nullptr;
+    std::vector<double> t(msg->pos.p, msg->pos.p + 3 * per);
+    if (mode == MODE_POSITION) {
+      auto *u = new RBISIndexedMeasurement(z_indices, std::move(t), std::vector<double>(cov_pose_meas), PB_R_DIAG_BROADCAST, std::move(mask),
+                                           RBISUpdateInterface::pose_meas, msg->utime);
+      u->measurement.mem = mem;
+      return u;
+    }
+    std::vector<double> z(6 * per, 0.0);  // entries at chi indices are ignored (rbis.cpp:203-205)
+    memcpy(z.data(), t.data(), sizeof(double) * 3 * per);
+    std::vector<double> q(msg->orientation.p, msg->orientation.p + 4 * per);
+    auto *u = new RBISIndexedPlusOrientationMeasurement(z_indices, std::move(z), std::vector<double>(cov_pose_meas), PB_R_DIAG_BROADCAST,
+                                                        std::move(q), std::move(mask), RBISUpdateInterface::pose_meas, msg->utime);
+    u->measurement.mem = u->orientation.mem = mem;
+    return u;
+  }
+  // :98-129
+  bool processMessageInit(const msgs::pose_t *msg, const std::map<std::string, bool> & /*sensors_initialized*/,
+                          const RBIS & /*default_state*/, const RBIM & /*default_cov*/, RBIS &init_state, RBIM &init_cov)
+  {
+    const int mem = msg->pos.mem, B = init_state.B;
+    if (mem == PB_DEVICE || msg->orientation.mem != mem) return false;
+    const size_t per = (mem == PB_HOST_BROADCAST) ? 1 : (size_t) B;
+    init_state.utime = msg->utime;
+    for (int b = 0; b < B; b++) {
+      const size_t sb = per == 1 ? 0 : (size_t) b;
+      for (int i = 0; i < 3; i++) {
+        init_state(RBIS::position_ind + i, b) = msg->pos.p[(size_t) i * per + sb];
+        for (int j = 0; j < 3; j++) {
+          init_cov(RBIS::position_ind + i, RBIS::position_ind + j, b) = (i == j) ? r_xyz2 : 0.0;
+          init_cov(RBIS::chi_ind + i, RBIS::chi_ind + j, b) = (i == j) ? r_chi2 : 0.0;
+        }
+      }
+      for (int i = 0; i < 4; i++) init_state.q(i, b) = msg->orientation.p[(size_t) i * per + sb];
+    }
+    return true;
+  }
+};
+
 class FovisHandler {
 public:
   typedef enum { MODE_VELOCITY, MODE_VELOCITY_ROTATION_RATE, MODE_POSITION, MODE_POSITION_ORIENT } FovisMode;

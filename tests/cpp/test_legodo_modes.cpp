@@ -147,6 +147,35 @@ int main(int argc, char **argv)
       po_indexed_orient_update(6, idx, z, R, qb, &ox[b], &oP[b], oll[b], &ox[b], &oP[b], &oll[b]);
     }
   }
+  // ---- PoseMeasHandler (pose_meas.cpp:53-96): no_corrections = 3 lets two messages through (decrement, then compare), filter 5
+  // reports a pose at the origin -> no update for it; the third and fourth message change nothing ----
+  {
+    param.applyOverrides("state_estimator.pose_meas.mode=position_orient|state_estimator.pose_meas.no_corrections=3|"
+                         "state_estimator.pose_meas.r_xyz=0.02|state_estimator.pose_meas.r_chi=3.0|state_estimator.pose_meas.downsample_factor=1|"
+                         "state_estimator.pose_meas.roll_forward_on_receive=true|state_estimator.pose_meas.utime_offset=0");
+    PoseMeasHandler pose_handler(&param);
+    auto on_pose = front_end.addSensor("pose_meas", &PoseMeasHandler::processMessage, &pose_handler);
+    for (int k = 0; k < 4; k++) {
+      std::vector<double> pp(3 * B), pv(3 * B, 0.0), pq(4 * B);
+      for (int b = 0; b < B; b++) {
+        double qq[4];
+        po_euler_to_quat(0.05 * nrand(), 0.05 * nrand(), 3.0 * (urand() - 0.5), qq);
+        for (int i = 0; i < 3; i++) pp[i * B + b] = (b == 5) ? 1e-7 : ox[b].vec[9 + i] + 0.05 * nrand();
+        for (int i = 0; i < 4; i++) pq[i * B + b] = qq[i];
+      }
+      msgs::pose_t pm{ (int64_t) (T + 1) * 1000, BatchArray(pp.data(), PB_HOST), BatchArray(pv.data(), PB_HOST), BatchArray(pq.data(), PB_HOST) };
+      on_pose(&pm);
+      if (k >= 2) continue;  // silent
+      for (int b = 0; b < B; b++) {
+        if (b == 5) continue;
+        double z[6] = { pp[b], pp[B + b], pp[2 * B + b], 0, 0, 0 }, R[36] = { 0 };
+        const double qb[4] = { pq[b], pq[B + b], pq[2 * B + b], pq[3 * B + b] };
+        const int idx[6] = { 9, 10, 11, 6, 7, 8 };
+        for (int i = 0; i < 6; i++) R[i * 6 + i] = (i < 3) ? 4e-4 : bot_sq(bot_to_radians(3.0));
+        po_indexed_orient_update(6, idx, z, R, qb, &ox[b], &oP[b], oll[b], &ox[b], &oP[b], &oll[b]);
+      }
+    }
+  }
   RBIS head;
   RBIM cov;
   est.getHeadState(head, cov);
