@@ -208,6 +208,35 @@ int main()
     if (!good) printf("GpsHandler::processMessageInit: unexpected initial state\n");
     ok = ok && good;
   }
+  // ---- PoseMeasHandler (pose_meas.cpp:7-131): initialisation from a pose_t; the "N corrections, then silent" counter and the
+  // origin drop need no device (they return before an update object is made) ----
+  {
+    BotParam pp;
+    pp.applyOverrides("state_estimator.pose_meas.mode=nonsense|state_estimator.pose_meas.no_corrections=2|"
+                      "state_estimator.pose_meas.r_xyz=0.03|state_estimator.pose_meas.r_chi=4.0");
+    PoseMeasHandler ph(&pp);
+    const double pos[3] = { 0.5, -1.5, 0.9 }, vel[3] = { 0, 0, 0 }, q[4] = { 0.8, 0, 0.6, 0 }, origin[3] = { 1e-6, -1e-6, 0 };
+    msgs::pose_t m{ 9, BatchArray(pos, PB_HOST_BROADCAST), BatchArray(vel, PB_HOST_BROADCAST), BatchArray(q, PB_HOST_BROADCAST) };
+    RBIS st(15, 3);
+    RBIM cv(15, 3);
+    bool good = ph.mode == PoseMeasHandler::MODE_POSITION /* unrecognised -> position (:19-22) */ && ph.z_indices == std::vector<int>({ 9, 10, 11 }) &&
+                ph.processMessageInit(&m, sensors_initialized, st, cv, st, cv) && st.utime == 9;
+    for (int b = 0; b < 3; b++)
+      good = good && st(9, b) == 0.5 && st(10, b) == -1.5 && st(11, b) == 0.9 && st.q(0, b) == 0.8 && st.q(2, b) == 0.6 &&
+             fabs(cv(9, 9, b) - 9e-4) < 1e-18 && fabs(cv(6, 6, b) - bot_sq(bot_to_radians(4.0))) < 1e-18 && cv(9, 10, b) == 0.0;
+    // a pose at the origin is dropped (:74-75) but still counts as a message (:56-64: the counter is decremented first)
+    msgs::pose_t m0{ 10, BatchArray(origin, PB_HOST_BROADCAST), BatchArray(vel, PB_HOST_BROADCAST), BatchArray(q, PB_HOST_BROADCAST) };
+    ph.no_corrections = 4;
+    good = good && ph.processMessage(&m0, nullptr) == nullptr && ph.no_corrections == 3;
+    // no_corrections = 3 now: two more messages produce updates (3 -> 2, 2 -> 1), the next one (-> 0) and all later ones are silent
+    for (int k = 0; k < 4; k++) {
+      RBISUpdateInterface *u = ph.processMessage(&m, nullptr);
+      good = good && ((k < 2) == (u != nullptr)) && (u == nullptr || (u->sensor_id == RBISUpdateInterface::pose_meas && u->utime == 9));
+      delete u;
+    }
+    if (!good) printf("PoseMeasHandler: unexpected initial state\n");
+    ok = ok && good;
+  }
   printf(ok ? "PASS\n" : "FAIL\n");
   return ok ? 0 : 1;
 }
