@@ -45,6 +45,19 @@ int pbk_update21_m45(pb_ctx *c, int m, const int *idx, const double *z, const do
 int pbk_update21_m6(pb_ctx *c, int m, const int *idx, const double *z, const double *R, int rkind, const double *rb, const double *qm,
                     const uint8_t *mask)
 {
+  static const int lin_rot_rate[6] = { 3, 4, 5, 0, 1, 2 };  // rbis_legodo_common.cpp:66-67
+  if (!c->generic_update && memcmp(idx, lin_rot_rate, sizeof lin_rot_rate) == 0) {
+    DiagArg<6> da;
+    for (int i = 0; i < 6; i++) da.v[i] = rb ? rb[i] : 0.0;
+    double *out = update_target(c);
+    if (c->mem_hint == MH_STORE_SC1)
+      k_update_quad_list<MH_STORE_SC1, 3, 4, 5, 0, 1, 2><<<nblk(c->B), 256, 0, c->stream>>>(c->st, out, c->B, z, R, rkind, da, qm, mask, c->k);
+    else
+      k_update_quad_list<MH_DEFAULT, 3, 4, 5, 0, 1, 2><<<nblk(c->B), 256, 0, c->stream>>>(c->st, out, c->B, z, R, rkind, da, qm, mask, c->k);
+    LAUNCHCHK(c);
+    update_done(c, out);
+    return PB_OK;
+  }
   return launch_rt21<6>(c, idx, z, R, rkind, rb, qm, mask);
 }
 int pbk_update21(pb_ctx *c, int m, const int *idx, const double *z, const double *R, int rkind, const double *rb, const double *qm,

@@ -254,6 +254,24 @@ __global__ __launch_bounds__(256, 2) void k_update_quad_rt(const double *st, dou
   else quad_rt_role<21, 3, M, MH>(st, sto, B, idx, z, R, rkind, rb, qmeas, mask, k, xch);
 }
 
+// The same kernel with the index list fixed at compile time (LegOdoCommon's lin_rot_rate list [3,4,5,0,1,2],
+// rbis_legodo_common.cpp:66-67: the only handler list that reaches the angular-velocity states): the column pick and every
+// LDS address formed from an index fold to constants.
+template <int MH, int... I>
+__global__ __launch_bounds__(256, 2) void k_update_quad_list(const double *st, double *sto, int B, const double *__restrict__ z,
+                                                             const double *__restrict__ R, int rkind, DiagArg<sizeof...(I)> rb,
+                                                             const double *__restrict__ qmeas, const uint8_t *__restrict__ mask, Consts k)
+{
+  constexpr int M = (int) sizeof...(I);
+  __shared__ double xch[QuadRt<21, M>::NXCH][64];
+  const IdxArg<M> idx = { { I... } };
+  const int role = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
+  if (role == 0) quad_rt_role<21, 0, M, MH>(st, sto, B, idx, z, R, rkind, rb, qmeas, mask, k, xch);
+  else if (role == 1) quad_rt_role<21, 1, M, MH>(st, sto, B, idx, z, R, rkind, rb, qmeas, mask, k, xch);
+  else if (role == 2) quad_rt_role<21, 2, M, MH>(st, sto, B, idx, z, R, rkind, rb, qmeas, mask, k, xch);
+  else quad_rt_role<21, 3, M, MH>(st, sto, B, idx, z, R, rkind, rb, qmeas, mask, k, xch);
+}
+
 // the same for 15 states on the two roles of rbis_coop.hpp (role C: x[v chi Delta], quat, P_cc; role P: the panels, P_pp,
 // loglik, x[omega accel]): run-time lists of five and six indices, where the one-lane kernel spills
 template <int M, int MH = MH_DEFAULT>

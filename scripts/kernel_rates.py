@@ -58,7 +58,7 @@ for n in (15, 21):
     rows.append(("k_update m=4 orient (scan-match position_yaw)", t, 2 * st + 88))
     z6r, r6r = up(np.vstack([lo[0:3], 0.01 * np.ones((3, B))])), up(np.vstack([lo[3:6], 0.09 * np.ones((3, B))]))
     t = timeit(lambda: est.update_indexed([3, 4, 5, 0, 1, 2], z6r, r6r, mask=d_mask))
-    rows.append(("m=6 legodo lin_rot_rate (15: k_update_lane, 21: generic)", t, 2 * st + 96))
+    rows.append(("m=6 legodo lin_rot_rate (15: k_update_lane, 21: k_update_quad_list)", t, 2 * st + 96))
     # free-form run-time index lists (pronto_indexed_measurement_t: any states): 15 states k_update_lane_rt (m <= 4) / k_update_coop_rt (m = 5, 6), 21 states k_update_quad_rt
     zf3, rf3 = up(0.1 * np.ones((3, B))), up(0.04 * np.ones((3, B)))
     t = timeit(lambda: est.update_indexed([2, 9, n - 1], zf3, rf3, mask=d_mask))

@@ -876,6 +876,7 @@ def test_handler_index_lists_on_the_cooperative_update_kernel(pa, oracle, n, mon
         check(e, ob)
     for a, b in zip(ests[0].get_head(), ests[1].get_head()):
         assert rel(a, b) < 1e-12
+        assert n == 15 or np.array_equal(a, b)
 
 
 @pytest.mark.parametrize("n", [15, 21])
@@ -919,12 +920,14 @@ def test_split_space_step_equals_the_plain_step(pa, oracle, n):
     ref.close(); alt.close()
 
 
-def test_lin_rot_rate_compile_time_and_run_time_lists_agree(pa, oracle, monkeypatch):
-    """LegOdoCommon's lin_rot_rate list [3,4,5,0,1,2] (rbis_legodo_common.cpp:66-67) on 15 states: the compile-time-list
+@pytest.mark.parametrize("n", [15, 21])
+def test_lin_rot_rate_compile_time_and_run_time_lists_agree(pa, oracle, monkeypatch, n):
+    """LegOdoCommon's lin_rot_rate list [3,4,5,0,1,2] (rbis_legodo_common.cpp:66-67).  15 states: the compile-time-list
     kernel (k_update_lane, one lane per filter) and the run-time-list kernel (PRONTO_BATCH_GENERIC_UPDATE=1: six indices run
     on two waves per tile, k_update_coop_rt) agree to rounding (the two-wave kernel scales W by 1/d once, like the
-    four-wave ones); both against the oracle."""
-    B, n, idx = 300, 15, [3, 4, 5, 0, 1, 2]
+    four-wave ones).  21 states: k_update_quad_list (the four-wave body with the list folded in at compile time) and
+    k_update_quad_rt are the same arithmetic: bit-identical.  Both against the oracle."""
+    B, idx = 300, [3, 4, 5, 0, 1, 2]
     rng = np.random.default_rng(21)
     w = Workload(B, n_states=n)
     ests = []
@@ -954,3 +957,4 @@ def test_lin_rot_rate_compile_time_and_run_time_lists_agree(pa, oracle, monkeypa
         check(e, ob)
     for a, b in zip(ests[0].get_head(), ests[1].get_head()):
         assert rel(a, b) < 1e-12
+        assert n == 15 or np.array_equal(a, b)
