@@ -35,7 +35,8 @@ def is_stale():
 def build(force=False):
     """hipcc --offload-arch=gfx950 -shared (cross-compiles without a GPU)."""
     if force or is_stale():
-        subprocess.check_call(["make", "-C", CSRC, "-s"] + (["-B"] if force else []))
+        # (the translation units are independent: a serial from-scratch build takes ~10 minutes, -j8 ~2.5)
+        subprocess.check_call(["make", "-C", CSRC, "-s", "-j%d" % max(1, min(8, os.cpu_count() or 1))] + (["-B"] if force else []))
     return LIB_PATH
 
 
