@@ -61,10 +61,14 @@ __device__ __forceinline__ void group_sync()
 // values that only feed a store inside `if (row)` are sunk into that block below everything (their LDS operands stay
 // live); LDS reads of later steps are hoisted / kept alive for a later re-read (step_fence).
 // =================================================================================================================
+// workgroup size (attribution builds: -DSM_THREADS=128 / 64 -- fewer filters per workgroup, the same waves per CU)
+#ifndef SM_THREADS
+#define SM_THREADS 256
+#endif
 template <int NS>
 struct SmoothRegCfg {
   static constexpr int G = (NS <= 16) ? 16 : 32;  // lanes per filter
-  static constexpr int THREADS = 256, F = THREADS / G;
+  static constexpr int THREADS = SM_THREADS, F = THREADS / G;
   static constexpr int NC = Lay<NS>::NC, PITCH = NC | 1;  // odd pitch: conflict-free filter-fastest staging
   // Strides = 2 (mod 4) doubles, i.e. 4 (mod 8) dwords, everywhere a stride separates things that are accessed together:
   //  * row pitch PG of the n x n scratch matrices: even, so rows are 16-byte aligned and are read with ds_read_b128
@@ -166,7 +170,7 @@ __device__ __forceinline__ unsigned rowpair_min(unsigned v)
 #define PB_SMOOTH_WG_PER_CU 2
 #endif
 template <int NS>
-__global__ __launch_bounds__(256, PB_SMOOTH_WG_PER_CU) void k_smooth_reg(const double *__restrict__ next_pred,
+__global__ __launch_bounds__(SM_THREADS, PB_SMOOTH_WG_PER_CU) void k_smooth_reg(const double *__restrict__ next_pred,
                                                     const double *__restrict__ next_sm,
                                                     const double *__restrict__ cur, double *__restrict__ out,
                                                     int B, double dt, Consts k)
