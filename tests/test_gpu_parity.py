@@ -876,7 +876,6 @@ def test_handler_index_lists_on_the_cooperative_update_kernel(pa, oracle, n, mon
         check(e, ob)
     for a, b in zip(ests[0].get_head(), ests[1].get_head()):
         assert rel(a, b) < 1e-12
-        assert n == 15 or np.array_equal(a, b)
 
 
 @pytest.mark.parametrize("n", [15, 21])
