@@ -61,7 +61,8 @@ int pbk_step_leg(pb_ctx *c, const double *imu, const StepBcast *bcast, const dou
   // 21 states with PER-FILTER joint blocks: even with the two legs' forward kinematics given to roles CC and CB, what is left in
   // front of barrier A makes role PW the wave the other three wait for (59.3 us at 64k filters against 56.3 us for the
   // odometry kernel followed by the fused step on the same box): two launches.  k_step_quad_leg keeps the code path (it is
-  // what a foot-state or broadcast joint-state message runs on).
+  // what a foot-state or broadcast joint-state message runs on).  (Also tried: k_leg_fk as a pre-pass and the pair kernel on its
+  // foot poses -- 59.8 us, the small kernel costs more than the 3.4 us the kinematics add inside k_legodo.)
   if (c->ns == 21 && lin.kind == 1) return -1;
   const StepBcast bc = bcast ? *bcast : StepBcast();
   LegStepArgs la{ c->legd, c->legi, c->stride, utime, r2, r2_uncertain, lo_out, mask_out };
