@@ -790,17 +790,23 @@ static void scatter(po_batch *s, int b, const po_rbis *x, const po_rbim *P, doub
   s->ll[b] = ll;
 }
 
-static int pick_threads(int nthreads)
+/* nthreads <= 0: automatic -- at most 16 (the CPU share of a one-GPU box; omp_get_max_threads() reports the HOST's cores, and a
+ * team of hundreds of spinning threads on 16 CPUs turns every call into tens of milliseconds), one thread per 32 filters */
+static int pick_threads(int nthreads, int B)
 {
   int mx = po_max_threads();
-  if (nthreads <= 0 || nthreads > mx) nthreads = mx;
+  if (nthreads <= 0) {
+    nthreads = mx < 16 ? mx : 16;
+    if (nthreads > B / 32 + 1) nthreads = B / 32 + 1;
+  }
+  if (nthreads > mx) nthreads = mx;
   return nthreads;
 }
 
 void po_batch_predict(po_batch *s, const double *imu, const double *q4, int nthreads)
 {
   int B = s->B;
-  nthreads = pick_threads(nthreads);
+  nthreads = pick_threads(nthreads, B);
 #pragma omp parallel for num_threads(nthreads) schedule(static)
   for (int b = 0; b < B; b++) {
     po_rbis x; po_rbim P; double ll;
@@ -816,7 +822,7 @@ void po_batch_update_indexed(po_batch *s, int m, const int *idx, const double *z
                              const double *quat_meas, const uint8_t *mask, int nthreads)
 {
   int B = s->B;
-  nthreads = pick_threads(nthreads);
+  nthreads = pick_threads(nthreads, B);
 #pragma omp parallel for num_threads(nthreads) schedule(static)
   for (int b = 0; b < B; b++) {
     if (mask && !mask[b]) continue;
@@ -850,7 +856,7 @@ double po_batch_run_legodo(po_batch *s, int T, const double *imu_stream, const d
    * split statically over threads (BASELINE.md section 4 "cpu-dense-Nt"). */
   static const int idx[3] = { PO_VEL, PO_VEL + 1, PO_VEL + 2 };
   int B = s->B;
-  nthreads = pick_threads(nthreads);
+  nthreads = pick_threads(nthreads, B);
   double t0 = now_s();
 #pragma omp parallel for num_threads(nthreads) schedule(static)
   for (int b = 0; b < B; b++) {

@@ -180,7 +180,7 @@ def test_joint_filter_on_gpu_equals_oracle_bitwise(oracle, mode, effort):
     import torch
     import legs
     from pronto_amd import batch as pa
-    B, T, rows_n = 130, 45, 33
+    B, T, rows_n = 70, 40, 33
     dev = torch.device("cuda:0")
     L = bind(oracle.lib())
     L.po_torque_adjust.restype = C.c_float
@@ -251,7 +251,7 @@ def test_filtered_joints_through_kinematics_and_contact_logic_on_gpu(oracle, mod
     from pronto_amd import batch as pa
     from pronto_amd.synth import Workload
     from test_leg_odometry import OracleLegs, SCHMITT, R_VXYZ, same_rotation
-    B, T = 24, 260
+    B, T = 12, 260
     dev = torch.device("cuda:0")
     L = bind(oracle.lib())
     gain = np.array([7000, 10000, 10000, 10000, 10000, 10000] * 2, dtype=np.float32)
