@@ -5,7 +5,7 @@
 
 #include "pb_ctx.hpp"
 
-#define PB_VERSION_STR "pronto_batch 0.2 gfx950"
+#define PB_VERSION_STR "pronto_batch 0.3 gfx950"
 
 extern "C" const char *pb_version(void) { return PB_VERSION_STR; }
 
