@@ -38,7 +38,7 @@ def test_code_object_is_gfx950_only():
 
 
 def test_version_and_error_paths_without_device(lib):
-    assert lib.pb_version().decode() == "pronto_batch 0.2 gfx950"
+    assert lib.pb_version().decode() == "pronto_batch 0.3 gfx950"
     h = C.c_void_p()
     assert lib.pb_create(C.byref(h), 17, 64, 0, 0) == _lib.PB_ERR_ARG          # bad n_states
     assert b"n_states" in lib.pb_last_error(None)
