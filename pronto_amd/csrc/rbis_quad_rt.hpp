@@ -22,6 +22,10 @@
 
 #include "rbis_kernels.hpp"
 
+#if defined(UQ_SKEW) && !defined(PB_EXPERIMENTS)
+#error "UQ_SKEW is an experiment knob: it needs -DPB_EXPERIMENTS as well"
+#endif
+
 namespace pb {
 
 #if defined(__HIPCC__)
@@ -264,6 +268,10 @@ __global__ __launch_bounds__(256, 2) void k_update_quad_list(const double *st, d
 {
   constexpr int M = (int) sizeof...(I);
   __shared__ double xch[QuadRt<21, M>::NXCH][64];
+#ifdef UQ_SKEW  // experiment (needs -DPB_EXPERIMENTS): the second workgroup of every CU in the first dispatch round starts UQ_SKEW x 0.85 us late
+  if (blockIdx.x >= 256 && blockIdx.x < 512)
+    for (int i = 0; i < UQ_SKEW; i++) __builtin_amdgcn_s_sleep(32);
+#endif
   const IdxArg<M> idx = { { I... } };
   const int role = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
   if (role == 0) quad_rt_role<21, 0, M, MH>(st, sto, B, idx, z, R, rkind, rb, qmeas, mask, k, xch);

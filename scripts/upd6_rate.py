@@ -1,5 +1,5 @@
 """The two six-row updates of a 21-state batch at 64k filters, for counter runs: k_update_quad<CorrPosOrient> (compile-time list,
-VO position_orient) and k_update_quad_rt<6> (run-time list: LegOdoCommon's lin_rot_rate); plus the m = 3 / 4 ones for scale."""
+VO position_orient) and k_update_quad_list (LegOdoCommon's lin_rot_rate; PRONTO_BATCH_GENERIC_UPDATE=1: the run-time-list kernel k_update_quad_rt<6>); plus the m = 3 / 4 ones for scale."""
 import os
 import sys
 import time
@@ -26,7 +26,7 @@ z6r, r6r = up(np.vstack([lo[0:3], 0.01 * np.ones((3, B))])), up(np.vstack([lo[3:
 z3, r3 = up(lo[0:3]), up(lo[3:6])
 z3f = up(0.1 * np.ones((3, B)))
 cases = [("k_update_quad m=6 orient (compile-time list 9,10,11,6,7,8)", lambda: est.update_indexed([9, 10, 11, 6, 7, 8], z6, d_Rd, quat_meas=d_qm)),
-         ("k_update_quad_rt m=6 (lin_rot_rate 3,4,5,0,1,2)", lambda: est.update_indexed([3, 4, 5, 0, 1, 2], z6r, r6r, mask=d_mask)),
+         ("k_update_quad_list m=6 (lin_rot_rate 3,4,5,0,1,2)", lambda: est.update_indexed([3, 4, 5, 0, 1, 2], z6r, r6r, mask=d_mask)),
          ("k_update_quad m=3 (3,4,5)", lambda: est.update_indexed([3, 4, 5], z3, r3, mask=d_mask)),
          ("k_update_quad_rt m=3 (2,9,20)", lambda: est.update_indexed([2, 9, 20], z3f, r3, mask=d_mask))]
 for name, fn in cases:
