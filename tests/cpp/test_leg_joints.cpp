@@ -4,7 +4,8 @@
 // LegOdoCommon's measurement, on the GPU for every filter -- against the oracle chain po_torque_adjust -> po_fk ->
 // po_leg_update_wc (given the oracle filter's own head pose) -> po_legodo_create_measurement -> po_indexed_update.
 //   argv[1]: legodo mode (lin_rate | lin_rot_rate | pos_and_lin_rate)      argv[2]: contact mode (alt | standing | ctrl)
-//   argv[3]: "fuse" = state_estimator.fuse_ins_legodo                      argv[4]: "bcast" = one robot's log for every filter
+//   argv[3]: "fuse" = state_estimator.fuse_ins_legodo                      argv[4]: "bcast" = one robot's log for every filter,
+//                                                                                   "device" = per-filter blocks already in HBM
 //   argv[5]: state_estimator.legodo.filter_joint_positions (none | lowpass | kalman; leg_estimate.cpp:411-428), the oracle chain
 //            then has po_joint_filter between the torque adjustment and the kinematics
 // Exit code 0 + "PASS".  Needs a GPU.
@@ -61,6 +62,7 @@ int main(int argc, char **argv)
   const std::string cmode = argc > 2 ? argv[2] : "alt";
   const bool fuse = argc > 3 && std::string(argv[3]) == "fuse";
   const bool bcast = argc > 4 && std::string(argv[4]) == "bcast";
+  const bool device = argc > 4 && std::string(argv[4]) == "device";
   const std::string jfilt = argc > 5 ? argv[5] : "none";
   const int jmode = jfilt == "lowpass" ? 1 : (jfilt == "kalman" ? 2 : 0);
   const int n = 15, B = 64, T = 900, NJ = 16, ZERO = 3;
@@ -173,6 +175,15 @@ int main(int argc, char **argv)
     const int W = bcast ? 1 : B;
     std::vector<float> jp((size_t) NJ * W), je((size_t) NJ * W), jv((size_t) NJ * W);
     std::vector<double> fz(2 * (size_t) W);
+    // "device": the log segment's blocks are uploaded by the caller and the handler is given device pointers (a device-resident replay)
+    float *d_jp = nullptr, *d_je = nullptr, *d_jv = nullptr, *d_fz = nullptr;
+    std::vector<float> fabs_fz(2 * (size_t) W);
+    if (device) {
+      void *p = nullptr;
+      const size_t blk = sizeof(float) * (size_t) NJ * W;
+      if (pb_malloc(est.ctx, 3 * blk + sizeof(float) * 2 * W, &p) != PB_OK) { printf("FAIL: pb_malloc\n"); return 1; }
+      d_jp = (float *) p; d_je = d_jp + (size_t) NJ * W; d_jv = d_je + (size_t) NJ * W; d_fz = d_jv + (size_t) NJ * W;
+    }
     int ncl = -1, ncr = -1;
     for (int k = 0; k < T; k++) {
       const int64_t utime = 1000000 + (int64_t) (k + 1) * 2000;
@@ -212,13 +223,25 @@ int main(int argc, char **argv)
       js.joint_effort = je.data();
       js.joint_velocity = jv.data();
       js.mem = bcast ? PB_HOST_BROADCAST : PB_HOST;
+      if (device) {
+        const size_t blk = sizeof(float) * (size_t) NJ * W;
+        for (size_t i = 0; i < fabs_fz.size(); i++) fabs_fz[i] = (float) fabs(fz[i]);
+        if (pb_memcpy_h2d(est.ctx, d_jp, jp.data(), blk) != PB_OK || pb_memcpy_h2d(est.ctx, d_je, je.data(), blk) != PB_OK ||
+            pb_memcpy_h2d(est.ctx, d_jv, jv.data(), blk) != PB_OK || pb_memcpy_h2d(est.ctx, d_fz, fabs_fz.data(), sizeof(float) * 2 * W) != PB_OK) {
+          printf("FAIL: upload\n");
+          return 1;
+        }
+        js.joint_position = d_jp; js.joint_effort = d_je; js.joint_velocity = d_jv;
+        js.mem = PB_DEVICE;
+      }
       if (k == 0) {  // before the first force/torque message nothing is integrated (:208-211)
         const int before = (int) est.history.updateMap.size();
         on_joints(&js);
         n_before_ft = (int) est.history.updateMap.size() - before;
       }
       msgs::six_axis_force_torque_array_t ft{ utime, BatchArray(fz.data(), bcast ? PB_HOST_BROADCAST : PB_HOST) };
-      legodo_handler.forceTorqueHandler(&ft, B);
+      if (device) legodo_handler.forceTorqueDevice(d_fz);
+      else legodo_handler.forceTorqueHandler(&ft, B);
       if (cmode == "ctrl" && k >= 50) {
         ncl = 4; ncr = 4;
         if (k % 500 >= 300 && k % 500 < 360) ncl = 2;
@@ -261,6 +284,11 @@ int main(int argc, char **argv)
         po_indexed_update(m, idx, z, R, &ox[b], &oP[b], oll[b], &ox[b], &oP[b], &oll[b]);
       }
     }
+    if (device) {
+      est.flushPending();  // (a pending pair still reads the blocks)
+      pb_sync(est.ctx);
+      pb_free(est.ctx, d_jp);
+    }
   }
   RBIS head;
   RBIM cov;
@@ -276,7 +304,7 @@ int main(int argc, char **argv)
     sl = fmax(sl, fabs(oll[b]));
   }
   printf("mode %s / %s%s%s, joint filter %s: status skip/certain/uncertain %d/%d/%d, position updates %d: rel err vec %.2e quat %.2e cov %.2e ll %.2e (status %d, fused pairs %lld)\n",
-         lomode.c_str(), cmode.c_str(), fuse ? " fused" : "", bcast ? " bcast" : "", jfilt.c_str(), n_status[0], n_status[1], n_status[2], n_pos, ev / sv, eq, eP / sP,
+         lomode.c_str(), cmode.c_str(), fuse ? " fused" : "", bcast ? " bcast" : (device ? " device blocks" : ""), jfilt.c_str(), n_status[0], n_status[1], n_status[2], n_pos, ev / sv, eq, eP / sP,
          el / sl, est.last_status, (long long) est.fused_pairs);
   const bool fused_ok = !fuse || lomode != "lin_rate" || est.fused_pairs > T / 2;
   const bool pos_ok = lomode != "pos_and_lin_rate" || n_pos > B * T / 20;

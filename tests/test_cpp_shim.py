@@ -246,7 +246,8 @@ def test_shim_sweep_rate_example_runs(n, slots):
 @pytest.mark.parametrize("args", [("lin_rate", "alt"), ("lin_rate", "alt", "fuse"), ("lin_rate", "standing", "fuse", "bcast"),
                                   ("lin_rot_rate", "ctrl"), ("pos_and_lin_rate", "alt"), ("lin_rate", "ctrl", "nofuse", "bcast"),
                                   ("lin_rate", "alt", "fuse", "blocks", "lowpass"), ("lin_rate", "alt", "fuse", "bcast", "kalman"),
-                                  ("lin_rot_rate", "standing", "nofuse", "blocks", "kalman"), ("lin_rate", "alt", "nofuse", "bcast", "lowpass")])
+                                  ("lin_rot_rate", "standing", "nofuse", "blocks", "kalman"), ("lin_rate", "alt", "nofuse", "bcast", "lowpass"),
+                                  ("lin_rate", "alt", "fuse", "device", "none"), ("lin_rate", "ctrl", "fuse", "device", "lowpass")])
 def test_joint_state_handler_on_gpu(oracle, args):
     """LegOdoHandler::processMessage(joint_state_t) -- the reference's handler signature -- from a synthetic 6-DoF-per-leg gait:
     URDF text -> chains, force/torque + controller messages, torque adjustment, forward kinematics, contact logic, odometry and
