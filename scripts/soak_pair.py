@@ -1,7 +1,7 @@
 """Soak of the one-kernel IMU + joint-state pair (pb_step_legodo_joints) at 64k filters over thousands of ticks: masks against
 the two-call sequence every tick, summaries to rounding at the end, and the pair kernel replayed from the same start must give
 the same bits (pb_state_checksum).  tests/test_leg_odometry.py::test_pair_kernel_at_full_batch_size_on_gpu is the 40-tick
-version of this that runs in the suite.   usage: python scripts/soak_pair.py [ticks=2000] [n_states=15]"""
+version of this that runs in the suite.   usage: python scripts/soak_pair.py [ticks=2000] [n_states=15] [filters=65536]"""
 import os
 import sys
 
@@ -16,7 +16,7 @@ from pronto_amd.synth import Workload  # noqa: E402
 
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 15
-B = 65536
+B = int(sys.argv[3]) if len(sys.argv) > 3 else 65536
 SCHMITT = (475.0, 525.0, 7000, 7000)
 R_VXYZ = (5.0, 10.0)
 dev = torch.device("cuda:0")
