@@ -226,13 +226,15 @@ int pb_legodo_update_after_predict(pb_ctx *ctx, const double *imu_block, int imu
 /* Contact mode (leg_estimate.cpp:113-121): standing != 0 = state_estimator.legodo.init_contact_mode "standing", the
  * conservative FootContact classifier (foot_contact/FootContact.cpp:29-54; total_force and standing_schmitt_level are floats
  * there and here); use_controller_input != 0 lets the controller's contact counts overrule FootContactAlt's standing foot
- * (leg_estimate.cpp:365-387).  Call after pb_legodo_init (which selects the default: FootContactAlt, no controller input). */
+ * (leg_estimate.cpp:365-387).  Call after pb_legodo_init, which puts EVERYTHING back to the constructor's defaults: FootContactAlt,
+ * no controller input, controller contact counts -1, no world constraint, all per-robot state reset. */
 int pb_legodo_set_contact_mode(pb_ctx *ctx, int standing, double total_force, double standing_schmitt_level,
                                int use_controller_input);
 /* LegOdoHandler's "ignore the calculated velocity at launch" (state_estimator.legodo.zero_initial_velocity,
  * rbis_legodo_update.cpp:58,264-268), counted PER FILTER on the device: the counter is decremented by every message whose
  * status is valid for that filter (the reference returns NULL before the decrement otherwise, :243-255) and while it stays
- * above zero the increment (and the position) handed on is the identity.  Independent of the per-call zero_delta flag. */
+ * above zero the increment (and the position) handed on is the identity.  Independent of the per-call zero_delta flag.
+ * ticks <= 65535 (the counter is a 16-bit field of the per-robot flag word), else PB_ERR_ARG. */
 int pb_legodo_set_zero_initial_velocity(pb_ctx *ctx, int ticks);
 /* The last CONTROLLER_FOOT_CONTACT message (LegOdoHandler::controllerInputHandler, rbis_legodo_update.cpp:190-193):
  * n_contacts = {num_left_foot_contacts, num_right_foot_contacts} for every filter (PB_HOST_BROADCAST) or [2][B]
@@ -349,6 +351,12 @@ int pb_get_filter_state(pb_ctx *ctx, int filter, double quat[4], double state[21
  * out[0] = sum loglik, out[1] = sum |vec| + |quat| (checksum), out[2] = max | |quat|^2 - 1 |,
  * out[3] = number of non-finite state entries. */
 int pb_summary(pb_ctx *ctx, double out[4]);
+/* How many filters a DEVICE-resident update mask [B] lets through (synchronises).  The reference's handlers return NULL when a
+ * message yields no update (rbis_legodo_update.cpp:242-255, rbis_fovis_update.cpp:160-164), so such a message never enters the
+ * history; a batched handler whose per-filter validity is decided on the device cannot know that when it returns.  The shim asks
+ * lazily -- only where the difference is observable: FovisHandler's history.updateMap.lower_bound look-up
+ * (rbis_fovis_update.cpp:184-207) skips updates that applied to no filter. */
+int pb_mask_count(pb_ctx *ctx, const uint8_t *mask_dev, int *count_out);
 /* Bit-level checksum of the whole device state (every component of every filter, padding lanes of the last tile included):
  * out[0] a weighted wrapping sum, out[1] a xor of rotated words; slot < 0 = the head, else a checkpoint slot.  Two runs of
  * the same context over the same inputs must give the same pair (tests: replay identity over thousands of launches);

@@ -111,6 +111,7 @@ _SIGS = {
     "pb_get_head": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "pb_get_filter_state": (C.c_int, [C.c_void_p, C.c_int, _dp, _dp, _dp]),
     "pb_summary": (C.c_int, [C.c_void_p, _dp]),
+    "pb_mask_count": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
     "pb_state_checksum": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_uint64)]),
     "pb_calib_copy": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float)]),
     "pb_set_utime": (C.c_int, [C.c_void_p, C.c_int64]),

@@ -229,6 +229,11 @@ public:
   // Applies this update to the estimator's device-resident posterior (prior = previous posterior,
   // mav_state_est.cpp:55-57).  Returns a pb_status; the posterior/loglikelihood stay on the device.
   virtual int updateFilter(pb_ctx *ctx) = 0;
+  // true: this update changes NO filter of the batch -- the message for which the reference's handler returns NULL, so that
+  // nothing enters the history (rbis_legodo_update.cpp:242-255).  A batched handler whose per-filter validity is decided on the
+  // device cannot know that when it returns; the question is asked lazily (pb_mask_count synchronises), only where the difference
+  // is observable: FovisHandler's history.updateMap.lower_bound look-up skips such updates.
+  virtual bool appliesToNoFilter(pb_ctx * /*ctx*/, int /*B*/) { return false; }
   static const char *sensor_enum_string(sensor_enum s)
   {
     static const char *names[] = { "ins", "gps", "vicon", "laser", "laser_gpf", "scan_matcher", "optic_flow", "reset",
@@ -286,8 +291,21 @@ public:
   // update in ONE kernel (pb_step_legodo_joints / _feet; keep = write the measurement block out for later re-applications) --
   // or on its own right before this update is applied (make_measurement).  Whichever runs first clears both: the odometry
   // advances once, a history replay re-applies the measurement it left in `measurement` / `mask`.
+  // make_measurement(ctx, ahead): ahead != NULL = slaved to the state AFTER that (still pending) INS step -- what the estimator
+  // calls when it has to hold the pair back or was told not to roll forward, so that the handler's inputs are consumed before
+  // control returns to the caller (they are only valid until the next message).
   std::function<int(pb_ctx *, const RBISIMUProcessStep *, bool keep)> pair_kernel;
-  std::function<int(pb_ctx *)> make_measurement;
+  std::function<int(pb_ctx *, const RBISIMUProcessStep *ahead)> make_measurement;
+  bool deferred() const { return (bool) make_measurement; }
+  // run the deferred odometry now (no-op when there is none); afterwards `measurement` / `mask` hold its result
+  int resolve(pb_ctx *ctx, const RBISIMUProcessStep *ahead)
+  {
+    if (!make_measurement) return PB_OK;
+    const int rc = make_measurement(ctx, ahead);
+    make_measurement = nullptr;
+    pair_kernel = nullptr;
+    return rc;
+  }
   RBISIndexedMeasurement(const std::vector<int> &index_, BatchArray measurement_, const double *measurement_cov_,
                          int r_kind_, const uint8_t *mask_, sensor_enum sensor_id_, int64_t utime)
       : RBISUpdateInterface(sensor_id_, utime), index(index_), measurement(measurement_),
@@ -300,15 +318,27 @@ public:
         r_kind(r_kind_), cov_mem(PB_HOST), mask(owned_mask.empty() ? nullptr : owned_mask.data()) {}
   int updateFilter(pb_ctx *ctx) override
   {
-    if (make_measurement) {
-      const int rc = make_measurement(ctx);
-      make_measurement = nullptr;
-      pair_kernel = nullptr;
-      if (rc != PB_OK) return rc;
-    }
+    const int rc = resolve(ctx, nullptr);
+    if (rc != PB_OK) return rc;
     return pb_update_indexed(ctx, (int) index.size(), index.data(), measurement.p, measurement_cov, r_kind, mask,
                              measurement.mem);
   }
+  bool appliesToNoFilter(pb_ctx *ctx, int B) override
+  {
+    if (mask == nullptr || deferred()) return false;  // (a deferred measurement has no mask yet: not applied, not empty)
+    if (empty_known_) return empty_;
+    int n = 1;
+    if (measurement.mem == PB_DEVICE) {
+      if (pb_mask_count(ctx, mask, &n) != PB_OK) return false;
+    } else {
+      n = 0;
+      for (int b = 0; b < B; b++) n += mask[b] != 0;
+    }
+    empty_known_ = true;
+    return empty_ = (n == 0);
+  }
+private:
+  bool empty_known_ = false, empty_ = false;
 };
 
 class RBISIndexedPlusOrientationMeasurement : public RBISIndexedMeasurement {
@@ -349,6 +379,7 @@ public:
     if (slot >= 0) pb_set_output_slot(ctx, slot);
     return second->updateFilter(ctx);
   }
+  bool appliesToNoFilter(pb_ctx *ctx, int B) override { return first->appliesToNoFilter(ctx, B) && second->appliesToNoFilter(ctx, B); }
 };
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -488,7 +519,22 @@ public:
     auto added_it = map.insert(map.end(), updateHistory::historyPair(update->utime, update));
     if (unprocessed_updates_start == map.end() || added_it->first < unprocessed_updates_start->first)
       unprocessed_updates_start = added_it;                                   // mav_state_est.cpp:33-40
-    if (!roll_forward) return;
+    if (!roll_forward) {
+      // a measurement that is still to be made from the handler's inputs is made NOW (those inputs are the caller's and only
+      // valid until its next message): slaved to the state after the INS step in front of it when that is the one held back
+      if (auto *m = dynamic_cast<RBISIndexedMeasurement *>(update))
+        if (m->deferred()) {
+          RBISIMUProcessStep *ahead = nullptr;
+          if (holding_ == 1 && added_it != map.begin()) {
+            auto prev = std::prev(added_it);
+            if (prev == unprocessed_updates_start) ahead = dynamic_cast<RBISIMUProcessStep *>(prev->second);
+          }
+          if (ahead == nullptr) flushPending();
+          const int rc = m->resolve(ctx, ahead);
+          if (rc != PB_OK) last_status = rc;
+        }
+      return;
+    }
 
     // The prior of the first unprocessed update is the posterior of the update before it (:45-57).  If the device
     // does not hold that posterior (late arrival), restore the newest checkpoint at or before it and replay.
@@ -525,6 +571,12 @@ public:
               auto third = nxt;
               ++third;
               if (third == map.end() && !flushing_) {  // the pair is complete: wait for what follows it
+                // (its measurement is made now, slaved to the state after the held INS step: the handler's inputs do not
+                // outlive this call)
+                if (auto *m2 = dynamic_cast<RBISIndexedMeasurement *>(nxt->second)) {
+                  const int rrc = m2->resolve(ctx, imu);
+                  if (rrc != PB_OK) last_status = rrc;
+                }
                 held = 2;
                 break;
               }
@@ -931,7 +983,7 @@ struct joint_state_t {       // bot_core::joint_state_t: the arrays are float on
   const float *joint_position = nullptr;    // [num_joints][B] (PB_HOST / PB_DEVICE) or [num_joints] (PB_HOST_BROADCAST)
   const float *joint_velocity = nullptr;    // (only the joint Kalman filter reads it, leg_estimate.cpp:418-426)
   const float *joint_effort = nullptr;      // same shape as joint_position; read when legodo.torque_adjustment is set
-  int mem = PB_HOST;
+  int mem = PB_HOST;                        // PB_DEVICE arrays must stay valid until the next message (see LegOdoHandler::forceTorqueDevice)
 };
 struct six_axis_force_torque_array_t {   // bot_core::six_axis_force_torque_array_t: what the leg odometry reads of it
   int64_t utime;
@@ -1497,8 +1549,8 @@ public:
   std::string urdf;
   std::string getURDFString() const { return urdf; }
 
-  // the chain of joints from the root link to `link`; false if the link is not the child of any joint or a joint type is
-  // not one the chain table knows (floating, planar)
+  // the chain of joints from the root link to `link`; false if the link is not the child of any joint, a joint type is
+  // not one the chain table knows (floating, planar), or an <origin> / <axis> attribute does not parse
   static bool chainTo(const std::string &urdf_with_comments, const std::string &link, std::vector<Joint> &chain)
   {
     struct J { Joint j; std::string parent, child; };
@@ -1512,22 +1564,34 @@ public:
       if (c1 == std::string::npos) break;
       p = c1 + 3;
     }
+    // name = "value" (XML allows white space around '='; either quote)
     auto attr = [](const std::string &tag, const char *name, std::string &out) {
-      const std::string key = std::string(name) + "=";
+      const std::string key(name);
+      auto space = [](char ch) { return ch == ' ' || ch == '\t' || ch == '\n' || ch == '\r'; };
       size_t p = 0;
       while ((p = tag.find(key, p)) != std::string::npos) {
-        if (p > 0 && (isalnum((unsigned char) tag[p - 1]) || tag[p - 1] == '_')) { p += key.size(); continue; }
+        const bool starts_word = p == 0 || !(isalnum((unsigned char) tag[p - 1]) || tag[p - 1] == '_' || tag[p - 1] == ':');
         p += key.size();
-        if (p >= tag.size() || (tag[p] != '"' && tag[p] != '\'')) continue;
-        const char qc = tag[p];
-        const size_t e = tag.find(qc, p + 1);
+        if (!starts_word) continue;
+        size_t v = p;
+        while (v < tag.size() && space(tag[v])) v++;
+        if (v >= tag.size() || tag[v] != '=') continue;
+        v++;
+        while (v < tag.size() && space(tag[v])) v++;
+        if (v >= tag.size() || (tag[v] != '"' && tag[v] != '\'')) continue;
+        const char qc = tag[v];
+        const size_t e = tag.find(qc, v + 1);
         if (e == std::string::npos) return false;
-        out = tag.substr(p + 1, e - p - 1);
+        out = tag.substr(v + 1, e - v - 1);
         return true;
       }
       return false;
     };
-    auto three = [](const std::string &v, double *o) { return sscanf(v.c_str(), "%lf %lf %lf", o, o + 1, o + 2) == 3; };
+    // exactly three numbers (urdfdom's Vector3::init throws on anything else; the reference exits when kdl_parser fails)
+    auto three = [](const std::string &v, double *o) {
+      char extra;
+      return sscanf(v.c_str(), " %lf %lf %lf %c", o, o + 1, o + 2, &extra) == 3;
+    };
     size_t pos = 0;
     while ((pos = urdf_xml.find("<joint", pos)) != std::string::npos) {
       const size_t head_end = urdf_xml.find('>', pos);
@@ -1554,11 +1618,12 @@ public:
       std::string tag, v;
       if (!child_tag("parent", tag) || !attr(tag, "link", j.parent)) continue;
       if (!child_tag("child", tag) || !attr(tag, "link", j.child)) continue;
+      // an <origin> / <axis> attribute that is present but does not hold three numbers is an error, not a default
       if (child_tag("origin", tag)) {
-        if (attr(tag, "xyz", v)) three(v, j.j.xyz);
-        if (attr(tag, "rpy", v)) three(v, j.j.rpy);
+        if (attr(tag, "xyz", v) && !three(v, j.j.xyz)) return false;
+        if (attr(tag, "rpy", v) && !three(v, j.j.rpy)) return false;
       }
-      if (child_tag("axis", tag) && attr(tag, "xyz", v)) three(v, j.j.axis);
+      if (child_tag("axis", tag) && attr(tag, "xyz", v) && !three(v, j.j.axis)) return false;
       all.push_back(j);
     }
     chain.clear();
@@ -1644,7 +1709,10 @@ public:
     foot_force_dev_ = nullptr;
     force_torque_init_ = true;
   }
-  // device-resident replays: |force z| [2][B] floats in HBM, valid until the next call
+  // device-resident replays: |force z| [2][B] floats in HBM.  Like the device arrays of a PB_DEVICE joint_state_t it must stay
+  // valid until the update made from it has been APPLIED: with fuse_ins_legodo the odometry of a message runs inside the pair
+  // kernel of the addUpdate call that follows processMessage (same dispatch, FrontEnd::addSensor), so "until the next message"
+  // is enough -- the estimator makes a deferred measurement at once whenever it holds the pair back or does not roll forward
   void forceTorqueDevice(const float *abs_force_z)
   {
     foot_force_dev_ = abs_force_z;
@@ -1839,7 +1907,9 @@ public:
         u->pair_kernel = [lm, d_lo, d_mask](pb_ctx *ctx, const RBISIMUProcessStep *imu, bool keep) {
           return lm->pair(ctx, imu, keep ? d_lo : nullptr, keep ? d_mask : nullptr);
         };
-        u->make_measurement = [lm, d_lo, d_mask](pb_ctx *ctx) { return lm->odometry(ctx, nullptr, nullptr, nullptr, d_lo, d_mask, nullptr, nullptr); };
+        u->make_measurement = [lm, d_lo, d_mask](pb_ctx *ctx, const RBISIMUProcessStep *ahead_of) {
+          return lm->odometry(ctx, ahead_of ? &ahead_of->imu_block : nullptr, nullptr, nullptr, d_lo, d_mask, nullptr, nullptr);
+        };
       }
       return u;
     }
@@ -1858,7 +1928,15 @@ public:
     } else if (lc->mode_ == LegOdoCommon::MODE_POSITION_AND_LIN_RATE) {
       pos_status.assign((size_t) B, 0);
     }
-    for (int b = 0; b < B; b++) fstatus[b] = (float) status[b];
+    bool any_valid = false;
+    for (int b = 0; b < B; b++) {
+      fstatus[b] = (float) status[b];
+      any_valid = any_valid || fstatus[b] >= 0;
+    }
+    if (!any_valid) {  // "Leg Odometry is not valid not integrating" for every filter: return NULL (rbis_legodo_update.cpp:242-255)
+      prev_legodo_utime_ = utime;
+      return nullptr;
+    }
     msgs::legodo_delta_t m2{ utime, prev_legodo_utime_, want_pos ? pos.data() : nullptr, delta.data(), delta.data() + (size_t) 3 * B,
                              pos_status.empty() ? nullptr : pos_status.data(), fstatus.data() };
     prev_legodo_utime_ = utime;
@@ -2464,6 +2542,9 @@ public:
       // 25 ms later, becomes the cached T0 -- here: copied from that update's checkpoint into the snapshot slot.
       auto &map = est->history.updateMap;
       auto lower_it = map.lower_bound(msg->prev_timestamp);
+      // an update that applied to NO filter is a message for which the reference's handler returned NULL: it is not in the
+      // reference's history, the look-up lands on the update after it
+      while (lower_it != map.end() && lower_it->second->appliesToNoFilter(est->ctx, B)) ++lower_it;
       if (lower_it == map.end()) {
         fprintf(stdout, "%lld at the end\n", (long long) msg->prev_timestamp);  // :192-195
         return nullptr;

@@ -766,6 +766,31 @@ extern "C" int pb_summary(pb_ctx *c, double out[4])
   return PB_OK;
 }
 
+// number of filters a device-resident update mask [B] lets through (one wave-level popcount + atomic per 256 filters)
+static __global__ __launch_bounds__(256) void k_mask_count(const uint8_t *__restrict__ mask, int B, unsigned *__restrict__ out)
+{
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  const bool on = b < B && mask[b] != 0;
+  const unsigned n = (unsigned) __popcll(__ballot(on));
+  if ((threadIdx.x & 63) == 0 && n) atomicAdd(out, n);
+}
+
+extern "C" int pb_mask_count(pb_ctx *c, const uint8_t *mask_dev, int *count_out)
+{
+  ENTER(c);
+  if (!mask_dev || !count_out) return fail(c, PB_ERR_ARG, "pb_mask_count: NULL argument");
+  int rc = stage_reserve(c, sizeof(unsigned));
+  if (rc) return rc;
+  HIPCHK(c, hipMemsetAsync(c->stage, 0, sizeof(unsigned), c->stream));
+  k_mask_count<<<(c->B + 255) / 256, 256, 0, c->stream>>>(mask_dev, c->B, (unsigned *) c->stage);
+  LAUNCHCHK(c);
+  unsigned n = 0;
+  HIPCHK(c, hipMemcpyAsync(&n, c->stage, sizeof n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  *count_out = (int) n;
+  return PB_OK;
+}
+
 extern "C" int pb_set_process_noise_block(pb_ctx *c, const double *q_block_dev)
 {
   if (!c) return PB_ERR_ARG;
@@ -837,6 +862,11 @@ extern "C" int pb_legodo_init(pb_ctx *c, double lt, double ht, int64_t low_delay
   if (!c->legd) HIPCHK(c, hipMalloc((void **) &c->legd, sizeof(double) * (NLD + NLD_WC) * c->stride));
   if (!c->legi) HIPCHK(c, hipMalloc((void **) &c->legi, sizeof(int64_t) * NLI * c->stride));
   // the thresholds pass through `float` variables in the reference (leg_estimate.cpp:103-104, FootContactAlt.cpp:5)
+  // a (re-)initialised context starts like leg_estimate's constructor: FootContactAlt, no controller input, no world
+  // constraint, controller contact counts -1 (leg_estimate.cpp:93-142, rbis_legodo_update.cpp:100-101)
+  c->leg_par = LegPar{};
+  c->leg_nc_h[0] = c->leg_nc_h[1] = -1;
+  c->leg_nc_dev = false;
   c->leg_par.alt = SchmittPar{ (double) (float) lt, (double) (float) ht, low_delay, high_delay };
   c->leg_par.filter_contact_events = filter_contact_events ? 1 : 0;
   k_legodo_reset<<<nblk(c->B), 64, 0, c->stream>>>(c->legd, c->legi, c->stride, c->B, -1);
@@ -860,6 +890,7 @@ extern "C" int pb_legodo_set_zero_initial_velocity(pb_ctx *c, int ticks)
 {
   ENTER(c);
   if (!c->legd) return fail(c, PB_ERR_STATE, "pb_legodo_set_zero_initial_velocity before pb_legodo_init");
+  if (ticks > 65535) return fail(c, PB_ERR_ARG, "pb_legodo_set_zero_initial_velocity: at most 65535 ticks (16-bit per-robot counter)");
   k_legodo_reset<<<nblk(c->B), 64, 0, c->stream>>>(c->legd, c->legi, c->stride, c->B, ticks < 0 ? 0 : ticks);
   LAUNCHCHK(c);
   return PB_OK;

@@ -12,7 +12,7 @@ for i,l in enumerate(L):
     lo,hi=int(m.group(1)),int(m.group(2))
     j=i+1
     while j<len(L) and 's_nop' not in L[j] and 's_endpgm' not in L[j] and j-i<60:
-        w=re.match(r'\s+(v_\w+|ds_read\w*|buffer_load\w*)\s+v\[?(\d+)(?::(\d+))?\]?',L[j])
+        w=re.match(r'\s+(v_\w+|ds_read\w*|buffer_load\w*|global_load\w*|flat_load\w*|scratch_load\w*)\s+v\[?(\d+)(?::(\d+))?\]?',L[j])
         if w:
             a=int(w.group(2)); b=int(w.group(3) or a)
             if not (b<lo or a>hi): bad+=1; print("OVERLAP", l.strip(), "->", L[j].strip())

@@ -7,8 +7,7 @@
 #include <deque>
 #include <vector>
 
-#include "../../oracle/pronto_oracle.h"
-#include "../../pronto_amd/csrc/mav_state_est_batch.hpp"
+#include "test_n.hpp"
 
 using namespace MavStateEst;
 
@@ -22,7 +21,8 @@ static double nrand() { return sqrt(-2 * log(urand())) * cos(2 * M_PI * urand())
 
 int main(int argc, char **argv)
 {
-  const int n = 15, B = 70, NMSG = 60;
+  const int n = take_n_states(argc, argv);  // "n21" anywhere on the command line: the 21-state filter
+  const int B = 70, NMSG = 60;
   double g;
   po_get_constants(&g, nullptr);
   BotParam param;
@@ -31,13 +31,10 @@ int main(int argc, char **argv)
   param.set("state_estimator.ins.channel", "ATLAS_IMU_BATCH");
   param.set("state_estimator.ins.q_gyro", 0.5);
   param.set("state_estimator.ins.q_accel", 0.1);
-  param.set("state_estimator.ins.q_gyro_bias", 0.0);
-  param.set("state_estimator.ins.q_accel_bias", 0.0);
   param.set("state_estimator.ins.timestep_dt", 0.003);
   param.set("state_estimator.ins.atlas_filter", "true");
   param.set("state_estimator.ins.atlas_filter_freq", 87.0);
-  param.set("state_estimator.ins.accel_bias_update_online", "false");
-  param.set("state_estimator.ins.gyro_bias_update_online", "false");
+  set_ins_bias_keys(param, n);
   param.set("state_estimator.ins.downsample_factor", "1");
   param.set("state_estimator.ins.roll_forward_on_receive", "true");
   param.set("state_estimator.ins.utime_offset", "0");
@@ -52,6 +49,7 @@ int main(int argc, char **argv)
     po_rbis_zero(&ox[b]);
     memset(&oP[b], 0, sizeof(po_rbim));
     for (int i = 3; i < 12; i++) { P0(i, i, b) = 0.01; oP[b].m[i * 21 + i] = 0.01; }
+    init_bias_states(n, b, x0, P0, &ox[b], &oP[b], urand);
     po_notch_cascade_init(&onotch[9 * b], 87.0, 1000);
   }
   InsHandler ins_handler(&param);

@@ -7,12 +7,14 @@
 //             estimator re-derives from the nearest earlier checkpoint (MavStateEstimator::snapshotPosteriorOf);
 //   argv[1] = "fuse": fuse_ins_legodo with a leg-odometry update behind every INS step (same utime): the look-up lands on
 //             the INS half of a fused pair, which never has a checkpoint of its own.
+//   argv[1] = "empty": 500 us after every INS message comes a leg-odometry update whose device-resident mask lets NO filter through
+//             -- the message for which the reference's handler returns NULL (rbis_legodo_update.cpp:242-255), so the reference's
+//             history never holds it: the look-up must step over it (the oracle does not record it).
 #include <cinttypes>
 #include <cstdio>
 #include <vector>
 
-#include "../../oracle/pronto_oracle.h"
-#include "../../pronto_amd/csrc/mav_state_est_batch.hpp"
+#include "test_n.hpp"
 
 using namespace MavStateEst;
 
@@ -26,9 +28,10 @@ static double nrand() { return sqrt(-2 * log(urand())) * cos(2 * M_PI * urand())
 
 int main(int argc, char **argv)
 {
+  const int n = take_n_states(argc, argv);  // "n21" anywhere on the command line: the 21-state filter
   const std::string variant = argc > 1 ? argv[1] : "";
-  const bool derived = variant == "derived", fuse = variant == "fuse";
-  const int n = 15, B = 70, T = 60;
+  const bool derived = variant == "derived", fuse = variant == "fuse", empty = variant == "empty";
+  const int B = 70, T = 60;
   double g;
   po_get_constants(&g, nullptr);
   BotParam param;
@@ -41,12 +44,9 @@ int main(int argc, char **argv)
   param.set("state_estimator.ins.channel", "IMU");
   param.set("state_estimator.ins.q_gyro", 0.5);
   param.set("state_estimator.ins.q_accel", 0.1);
-  param.set("state_estimator.ins.q_gyro_bias", 0.0);
-  param.set("state_estimator.ins.q_accel_bias", 0.0);
   param.set("state_estimator.ins.timestep_dt", 0.001);
   param.set("state_estimator.ins.atlas_filter", "false");
-  param.set("state_estimator.ins.accel_bias_update_online", "false");
-  param.set("state_estimator.ins.gyro_bias_update_online", "false");
+  set_ins_bias_keys(param, n);
   param.applyOverrides("state_estimator.fovis.mode=position_orient|state_estimator.fovis.r_pxyz=0.02|state_estimator.fovis.r_chi=0.01");
   for (const char *s : { "ins", "fovis", "legodo" }) {
     param.set(std::string("state_estimator.") + s + ".downsample_factor", "1");
@@ -66,7 +66,8 @@ int main(int argc, char **argv)
     for (int i = 0; i < 4; i++) { x0.q(i, b) = q[i]; ox[b].quat[i] = q[i]; }
     for (int i = 0; i < 3; i++) { x0(3 + i, b) = 0.3 * nrand(); ox[b].vec[3 + i] = x0(3 + i, b); }
     const double sig[15] = { 0, 0, 0, .15, .15, .15, .05, .05, .05, .5, .5, .5, 0, 0, 0 };
-    for (int i = 0; i < n; i++) { P0(i, i, b) = sig[i] * sig[i]; oP[b].m[i * 21 + i] = sig[i] * sig[i]; }
+    for (int i = 0; i < 15; i++) { P0(i, i, b) = sig[i] * sig[i]; oP[b].m[i * 21 + i] = sig[i] * sig[i]; }
+    init_bias_states(n, b, x0, P0, &ox[b], &oP[b], urand);
   }
   BotTrans ins_to_body;
   InsHandler ins_handler(&param, &ins_to_body);
@@ -89,6 +90,7 @@ int main(int argc, char **argv)
   std::vector<po_rbis> key;    // oracle's cached T0
   int n_vo = 0, n_rejected = 0, n_key_changes = 0;
   std::vector<double> vt(3 * B), vq(4 * B);
+  double *d_empty = nullptr;
   for (int k = 0; k < T; k++) {
     const int64_t utime = (int64_t) (k + 1) * 1000;
     const double v[6] = { 0.3 * sin(0.05 * k), 0.1, -0.2 * cos(0.03 * k), 0.3 * nrand(), 0.3 * nrand(), g + 0.3 * nrand() };
@@ -104,6 +106,17 @@ int main(int argc, char **argv)
     }
     for (int b = 0; b < B; b++) po_imu_process_step(v, v + 3, 0.001, q4[0], q4[1], q4[2], q4[3], &ox[b], &oP[b], oll[b], &ox[b], &oP[b], &oll[b]);
     record(utime);
+    if (empty) {
+      if (d_empty == nullptr) {
+        std::vector<double> blk((size_t) 7 * B, 1.0);  // z [3][B] | R diagonal [3][B] | mask [B] bytes (zero) in the 7th row
+        memset(&blk[(size_t) 6 * B], 0, sizeof(double) * B);
+        void *p = nullptr;
+        if (pb_malloc(est.ctx, sizeof(double) * 7 * B, &p) != PB_OK || pb_memcpy_h2d(est.ctx, p, blk.data(), sizeof(double) * 7 * B) != PB_OK) { printf("FAIL: pb_malloc\n"); return 1; }
+        d_empty = (double *) p;
+      }
+      est.addUpdate(new RBISIndexedMeasurement(RBIS::velocityInds(), BatchArray(d_empty, PB_DEVICE), d_empty + (size_t) 3 * B, PB_R_DIAG,
+                                               (const uint8_t *) (d_empty + (size_t) 6 * B), RBISUpdateInterface::legodo, utime + 500), true);
+    }
     if (fuse) {  // a leg-odometry increment with the INS message's utime: the pair runs as one fused kernel
       std::vector<double> dtr(3 * B);
       std::vector<float> st(B, 0.f);

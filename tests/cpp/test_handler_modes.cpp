@@ -12,8 +12,7 @@
 #include <string>
 #include <vector>
 
-#include "../../oracle/pronto_oracle.h"
-#include "../../pronto_amd/csrc/mav_state_est_batch.hpp"
+#include "test_n.hpp"
 
 using namespace MavStateEst;
 
@@ -27,8 +26,9 @@ static double nrand() { return sqrt(-2 * log(urand())) * cos(2 * M_PI * urand())
 
 int main(int argc, char **argv)
 {
+  const int n = take_n_states(argc, argv);  // "n21" anywhere on the command line: the 21-state filter
   const std::string mode = argc > 1 ? argv[1] : "sm_position";
-  const int n = 15, B = 90, T = 40;
+  const int B = 90, T = 40;
   double g;
   po_get_constants(&g, nullptr);
   BotParam param;
@@ -37,12 +37,9 @@ int main(int argc, char **argv)
   param.set("state_estimator.ins.channel", "IMU");
   param.set("state_estimator.ins.q_gyro", 0.5);
   param.set("state_estimator.ins.q_accel", 0.1);
-  param.set("state_estimator.ins.q_gyro_bias", 0.0);
-  param.set("state_estimator.ins.q_accel_bias", 0.0);
   param.set("state_estimator.ins.timestep_dt", 0.001);
   param.set("state_estimator.ins.atlas_filter", "false");
-  param.set("state_estimator.ins.accel_bias_update_online", "false");
-  param.set("state_estimator.ins.gyro_bias_update_online", "false");
+  set_ins_bias_keys(param, n);
   const bool is_sm = mode.rfind("sm_", 0) == 0, is_fovis = mode.rfind("fovis_", 0) == 0, is_lo = mode.rfind("legodo_", 0) == 0;
   param.applyOverrides("state_estimator.scan_matcher.mode=" + (is_sm ? mode.substr(3) : std::string("position")) +
                        "|state_estimator.scan_matcher.r_pxy=0.05|state_estimator.scan_matcher.r_pz=0.07|"
@@ -70,7 +67,8 @@ int main(int argc, char **argv)
     for (int i = 0; i < 4; i++) { x0.q(i, b) = q[i]; ox[b].quat[i] = q[i]; }
     for (int i = 0; i < 3; i++) { x0(3 + i, b) = 0.3 * nrand(); ox[b].vec[3 + i] = x0(3 + i, b); }
     const double sig[15] = { 0, 0, 0, .15, .15, .15, .05, .05, .05, .5, .5, .5, 0, 0, 0 };
-    for (int i = 0; i < n; i++) { P0(i, i, b) = sig[i] * sig[i]; oP[b].m[i * 21 + i] = sig[i] * sig[i]; }
+    for (int i = 0; i < 15; i++) { P0(i, i, b) = sig[i] * sig[i]; oP[b].m[i * 21 + i] = sig[i] * sig[i]; }
+    init_bias_states(n, b, x0, P0, &ox[b], &oP[b], urand);
   }
   BotTrans ins_to_body;
   InsHandler ins_handler(&param, &ins_to_body);

@@ -8,8 +8,7 @@
 #include <string>
 #include <vector>
 
-#include "../../oracle/pronto_oracle.h"
-#include "../../pronto_amd/csrc/mav_state_est_batch.hpp"
+#include "test_n.hpp"
 
 using namespace MavStateEst;
 
@@ -29,7 +28,8 @@ struct Late {
 
 int main(int argc, char **argv)
 {
-  const int n = 15, B = 96, T = 80; const int DELAY = (argc > 2) ? atoi(argv[2]) : 7;
+  const int n = take_n_states(argc, argv);  // "n21" anywhere on the command line: the 21-state filter
+  const int B = 96, T = 80; const int DELAY = (argc > 2) ? atoi(argv[2]) : 7;
   const int every = (argc > 1) ? atoi(argv[1]) : 1;
   // argv[3] = "fuse": state_estimator.fuse_ins_legodo with checkpoints -- pairs run as one kernel and are checkpointed behind
   // their second half; a late fix restores a checkpoint and the replay fuses again where the pairs are still adjacent
@@ -53,11 +53,12 @@ int main(int argc, char **argv)
     po_rbis_zero(&ox[b]);
     memset(&oP[b], 0, sizeof(po_rbim));
     const double sig[15] = { 0, 0, 0, .15, .15, .15, .05, .05, .05, .5, .5, .5, 0, 0, 0 };
-    for (int i = 0; i < n; i++) { P0(i, i, b) = sig[i] * sig[i]; oP[b].m[i * 21 + i] = sig[i] * sig[i]; }
+    for (int i = 0; i < 15; i++) { P0(i, i, b) = sig[i] * sig[i]; oP[b].m[i * 21 + i] = sig[i] * sig[i]; }
+    init_bias_states(n, b, x0, P0, &ox[b], &oP[b], urand);
   }
   MavStateEstimator est(new RBISResetUpdate(x0, P0, RBISUpdateInterface::reset, 0), &param, 0);
 
-  const double q4[4] = { 7.6e-5, 0.01, 0, 0 }, r_lo[3] = { 0.01, 0.01, 0.01 }, r_pos[3] = { 4e-4, 4e-4, 4e-4 };
+  const double q4[4] = { 7.6e-5, 0.01, n == 21 ? 3e-10 : 0.0, n == 21 ? 1e-8 : 0.0 }, r_lo[3] = { 0.01, 0.01, 0.01 }, r_pos[3] = { 4e-4, 4e-4, 4e-4 };
   // the whole timeline is generated up front so the oracle can run it in timestamp order afterwards
   std::vector<std::vector<double>> imu(T), lo(T);
   std::vector<Late> fixes;

@@ -8,8 +8,7 @@
 #include <string>
 #include <vector>
 
-#include "../../oracle/pronto_oracle.h"
-#include "../../pronto_amd/csrc/mav_state_est_batch.hpp"
+#include "test_n.hpp"
 
 using namespace MavStateEst;
 
@@ -24,11 +23,12 @@ static double ramp(double x) { return x < 0 ? 0 : (x > 0.05 ? 1.0 : x / 0.05); }
 
 int main(int argc, char **argv)
 {
+  const int n = take_n_states(argc, argv);  // "n21" anywhere on the command line: the 21-state filter
   const std::string lomode = argc > 1 ? argv[1] : "lin_rate";
   // argv[2] = "fuse": state_estimator.fuse_ins_legodo -- the INS step is held back, the odometry is slaved to the orientation
   // AFTER it (pb_legodo_update_after_predict) and the pair runs as one fused kernel (lin_rate only; same oracle sequence)
   const bool fuse = argc > 2 && std::string(argv[2]) == "fuse";
-  const int n = 15, B = 64, T = 900;
+  const int B = 64, T = 900;
   double g;
   po_get_constants(&g, nullptr);
   BotParam param;
@@ -38,12 +38,9 @@ int main(int argc, char **argv)
   param.set("state_estimator.ins.channel", "IMU");
   param.set("state_estimator.ins.q_gyro", 0.5);
   param.set("state_estimator.ins.q_accel", 0.1);
-  param.set("state_estimator.ins.q_gyro_bias", 0.0);
-  param.set("state_estimator.ins.q_accel_bias", 0.0);
   param.set("state_estimator.ins.timestep_dt", 0.002);
   param.set("state_estimator.ins.atlas_filter", "false");
-  param.set("state_estimator.ins.accel_bias_update_online", "false");
-  param.set("state_estimator.ins.gyro_bias_update_online", "false");
+  set_ins_bias_keys(param, n);
   param.applyOverrides("state_estimator.legodo.mode=" + lomode + "|state_estimator.legodo.r_xyz=0.2|state_estimator.legodo.r_vxyz=5|"
                        "state_estimator.legodo.r_vang=3|state_estimator.legodo.r_vxyz_uncertain=10|state_estimator.legodo.r_vang_uncertain=9|"
                        "state_estimator.legodo.schmitt_low_threshold=475|state_estimator.legodo.schmitt_high_threshold=525|"
@@ -67,7 +64,8 @@ int main(int argc, char **argv)
     memset(&oP[b], 0, sizeof(po_rbim));
     for (int i = 0; i < 4; i++) { x0.q(i, b) = q[i]; ox[b].quat[i] = q[i]; }
     const double sig[15] = { 0, 0, 0, .15, .15, .15, .05, .05, .05, .5, .5, .5, 0, 0, 0 };
-    for (int i = 0; i < n; i++) { P0(i, i, b) = sig[i] * sig[i]; oP[b].m[i * 21 + i] = sig[i] * sig[i]; }
+    for (int i = 0; i < 15; i++) { P0(i, i, b) = sig[i] * sig[i]; oP[b].m[i * 21 + i] = sig[i] * sig[i]; }
+    init_bias_states(n, b, x0, P0, &ox[b], &oP[b], urand);
     period[b] = 0.9 + 0.4 * urand(); phase[b] = urand(); stride[b] = 0.1 + 0.15 * urand();
     po_leg_init((po_leg *) legs[b].data(), 475, 525, 7000, 7000, 1);
   }

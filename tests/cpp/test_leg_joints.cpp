@@ -4,18 +4,18 @@
 // LegOdoCommon's measurement, on the GPU for every filter -- against the oracle chain po_torque_adjust -> po_fk ->
 // po_leg_update_wc (given the oracle filter's own head pose) -> po_legodo_create_measurement -> po_indexed_update.
 //   argv[1]: legodo mode (lin_rate | lin_rot_rate | pos_and_lin_rate)      argv[2]: contact mode (alt | standing | ctrl)
-//   argv[3]: "fuse" = state_estimator.fuse_ins_legodo                      argv[4]: "bcast" = one robot's log for every filter,
+//   argv[3]: "fuse" = state_estimator.fuse_ins_legodo ("fuse3": + fuse_corrections)                     argv[4]: "bcast" = one robot's log for every filter,
 //                                                                                   "device" = per-filter blocks already in HBM
 //   argv[5]: state_estimator.legodo.filter_joint_positions (none | lowpass | kalman; leg_estimate.cpp:411-428), the oracle chain
 //            then has po_joint_filter between the torque adjustment and the kinematics
+//   "n21" anywhere: the 21-state filter (biases estimated online) instead of the 15-state one
 // Exit code 0 + "PASS".  Needs a GPU.
 #include <cinttypes>
 #include <cstdio>
 #include <string>
 #include <vector>
 
-#include "../../oracle/pronto_oracle.h"
-#include "../../pronto_amd/csrc/mav_state_est_batch.hpp"
+#include "test_n.hpp"
 
 using namespace MavStateEst;
 
@@ -58,29 +58,32 @@ static const char *URDF = R"(<?xml version="1.0"?>
 
 int main(int argc, char **argv)
 {
+  const int n = take_n_states(argc, argv);
   const std::string lomode = argc > 1 ? argv[1] : "lin_rate";
   const std::string cmode = argc > 2 ? argv[2] : "alt";
-  const bool fuse = argc > 3 && std::string(argv[3]) == "fuse";
+  // "fuse3": fuse_ins_legodo + fuse_corrections -- the estimator holds the finished [INS, leg odometry] pair back until the next
+  // message; with "device" blocks the test then OVERWRITES the blocks as soon as the handler has returned (they are the
+  // caller's, valid until the next message): the odometry must have consumed them by then
+  const bool fuse3 = argc > 3 && std::string(argv[3]) == "fuse3";
+  const bool fuse = fuse3 || (argc > 3 && std::string(argv[3]) == "fuse");
   const bool bcast = argc > 4 && std::string(argv[4]) == "bcast";
   const bool device = argc > 4 && std::string(argv[4]) == "device";
   const std::string jfilt = argc > 5 ? argv[5] : "none";
   const int jmode = jfilt == "lowpass" ? 1 : (jfilt == "kalman" ? 2 : 0);
-  const int n = 15, B = 64, T = 900, NJ = 16, ZERO = 3;
+  const int B = 64, T = 900, NJ = 16, ZERO = 3;
   double g;
   po_get_constants(&g, nullptr);
   BotParam param;
   param.set("state_estimator.utime_history_span", "1000000");
   param.set("state_estimator.history_slots", "0");
   param.set("state_estimator.fuse_ins_legodo", fuse ? "true" : "false");
+  param.set("state_estimator.fuse_corrections", fuse3 ? "true" : "false");
   param.set("state_estimator.ins.channel", "IMU");
   param.set("state_estimator.ins.q_gyro", 0.5);
   param.set("state_estimator.ins.q_accel", 0.1);
-  param.set("state_estimator.ins.q_gyro_bias", 0.0);
-  param.set("state_estimator.ins.q_accel_bias", 0.0);
   param.set("state_estimator.ins.timestep_dt", 0.002);
   param.set("state_estimator.ins.atlas_filter", "false");
-  param.set("state_estimator.ins.accel_bias_update_online", "false");
-  param.set("state_estimator.ins.gyro_bias_update_online", "false");
+  set_ins_bias_keys(param, n);
   // r_vxyz = 5 / 10 m/s: the synthetic gait is not the motion the synthetic IMU measures; with the reference's 0.1 m/s the
   // orientation feedback through the 0.86 m lever arm (430 m/s per radian at 2 ms) makes the closed loop chaotic
   // (tests/test_leg_odometry.py R_VXYZ)
@@ -150,7 +153,8 @@ int main(int argc, char **argv)
     memset(&oP[b], 0, sizeof(po_rbim));
     for (int i = 0; i < 4; i++) { x0.q(i, b) = q[i]; ox[b].quat[i] = q[i]; }
     const double sig[15] = { 0, 0, 0, .15, .15, .15, .05, .05, .05, .5, .5, .5, 0, 0, 0 };
-    for (int i = 0; i < n; i++) { P0(i, i, b) = sig[i] * sig[i]; oP[b].m[i * 21 + i] = sig[i] * sig[i]; }
+    for (int i = 0; i < 15; i++) { P0(i, i, b) = sig[i] * sig[i]; oP[b].m[i * 21 + i] = sig[i] * sig[i]; }
+    init_bias_states(n, b, x0, P0, &ox[b], &oP[b], urand);
     const int src = bcast ? 0 : b;
     period[b] = bcast && b ? period[0] : 0.9 + 0.4 * urand();
     phase[b] = bcast && b ? phase[0] : urand();
@@ -250,6 +254,12 @@ int main(int argc, char **argv)
         legodo_handler.controllerInputHandler(&cc);
       }
       on_joints(&js);
+      if (device && fuse3) {  // the caller refills its blocks for the next message right away
+        std::vector<float> junk((size_t) NJ * W, 1e9f);
+        const size_t blk = sizeof(float) * (size_t) NJ * W;
+        if (pb_memcpy_h2d(est.ctx, d_jp, junk.data(), blk) != PB_OK || pb_memcpy_h2d(est.ctx, d_je, junk.data(), blk) != PB_OK ||
+            pb_memcpy_h2d(est.ctx, d_fz, junk.data(), sizeof(float) * 2 * W) != PB_OK) { printf("FAIL: upload\n"); return 1; }
+      }
       for (int b = 0; b < B; b++) {
         const int s = bcast ? 0 : b;
         double ft_[2][3], fq_[2][4];
@@ -303,8 +313,8 @@ int main(int argc, char **argv)
     el = fmax(el, fabs(ll[b] - oll[b]));
     sl = fmax(sl, fabs(oll[b]));
   }
-  printf("mode %s / %s%s%s, joint filter %s: status skip/certain/uncertain %d/%d/%d, position updates %d: rel err vec %.2e quat %.2e cov %.2e ll %.2e (status %d, fused pairs %lld)\n",
-         lomode.c_str(), cmode.c_str(), fuse ? " fused" : "", bcast ? " bcast" : (device ? " device blocks" : ""), jfilt.c_str(), n_status[0], n_status[1], n_status[2], n_pos, ev / sv, eq, eP / sP,
+  printf("n=%d mode %s / %s%s%s, joint filter %s: status skip/certain/uncertain %d/%d/%d, position updates %d: rel err vec %.2e quat %.2e cov %.2e ll %.2e (status %d, fused pairs %lld)\n",
+         n, lomode.c_str(), cmode.c_str(), fuse ? " fused" : "", bcast ? " bcast" : (device ? " device blocks" : ""), jfilt.c_str(), n_status[0], n_status[1], n_status[2], n_pos, ev / sv, eq, eP / sP,
          el / sl, est.last_status, (long long) est.fused_pairs);
   const bool fused_ok = !fuse || lomode != "lin_rate" || est.fused_pairs > T / 2;
   const bool pos_ok = lomode != "pos_and_lin_rate" || n_pos > B * T / 20;

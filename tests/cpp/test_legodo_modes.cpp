@@ -7,8 +7,7 @@
 #include <cstdio>
 #include <vector>
 
-#include "../../oracle/pronto_oracle.h"
-#include "../../pronto_amd/csrc/mav_state_est_batch.hpp"
+#include "test_n.hpp"
 
 using namespace MavStateEst;
 
@@ -22,11 +21,12 @@ static double nrand() { return sqrt(-2 * log(urand())) * cos(2 * M_PI * urand())
 
 int main(int argc, char **argv)
 {
+  const int n = take_n_states(argc, argv);  // "n21" anywhere on the command line: the 21-state filter
   const std::string mode = argc > 1 ? argv[1] : "pos_and_lin_rate";
   const int slots = argc > 2 ? atoi(argv[2]) : 0;
   const bool fuse = argc > 3 && std::string(argv[3]) == "fuse";  // state_estimator.fuse_ins_legodo
   const int omode = mode == "lin_rate" ? 0 : (mode == "lin_rot_rate" ? 1 : 2);
-  const int n = 15, B = 150, T = 40;
+  const int B = 150, T = 40;
   BotParam param;
   param.set("state_estimator.utime_history_span", "1000000");
   param.set("state_estimator.history_slots", std::to_string(slots));
@@ -34,12 +34,9 @@ int main(int argc, char **argv)
   param.set("state_estimator.ins.channel", "IMU");
   param.set("state_estimator.ins.q_gyro", 0.5);
   param.set("state_estimator.ins.q_accel", 0.1);
-  param.set("state_estimator.ins.q_gyro_bias", 0.0);
-  param.set("state_estimator.ins.q_accel_bias", 0.0);
   param.set("state_estimator.ins.timestep_dt", 0.001);
   param.set("state_estimator.ins.atlas_filter", "false");
-  param.set("state_estimator.ins.accel_bias_update_online", "false");
-  param.set("state_estimator.ins.gyro_bias_update_online", "false");
+  set_ins_bias_keys(param, n);
   param.applyOverrides("state_estimator.legodo.mode=" + mode + "|state_estimator.legodo.r_xyz=0.2|state_estimator.legodo.r_vxyz=0.1|"
                        "state_estimator.legodo.r_vang=0.3|state_estimator.legodo.r_vxyz_uncertain=0.5|"
                        "state_estimator.legodo.r_vang_uncertain=0.9");
@@ -60,7 +57,8 @@ int main(int argc, char **argv)
     memset(&oP[b], 0, sizeof(po_rbim));
     for (int i = 0; i < 4; i++) { x0.q(i, b) = q[i]; ox[b].quat[i] = q[i]; }
     const double sig[15] = { 0, 0, 0, .15, .15, .15, .05, .05, .05, .5, .5, .5, 0, 0, 0 };
-    for (int i = 0; i < n; i++) { P0(i, i, b) = sig[i] * sig[i]; oP[b].m[i * 21 + i] = sig[i] * sig[i]; }
+    for (int i = 0; i < 15; i++) { P0(i, i, b) = sig[i] * sig[i]; oP[b].m[i * 21 + i] = sig[i] * sig[i]; }
+    init_bias_states(n, b, x0, P0, &ox[b], &oP[b], urand);
   }
   BotTrans ins_to_body;
   InsHandler ins_handler(&param, &ins_to_body);

@@ -9,8 +9,7 @@
 #include <cstdio>
 #include <vector>
 
-#include "../../oracle/pronto_oracle.h"
-#include "../../pronto_amd/csrc/mav_state_est_batch.hpp"
+#include "test_n.hpp"
 
 using namespace MavStateEst;
 
@@ -24,9 +23,10 @@ static double nrand() { return sqrt(-2 * log(urand())) * cos(2 * M_PI * urand())
 
 int main(int argc, char **argv)
 {
+  const int n = take_n_states(argc, argv);  // "n21" anywhere on the command line: the 21-state filter
   const std::string dir = argc > 1 ? argv[1] : "/tmp";
   const std::string in_log = dir + "/segment.lcmlog", out_log = dir + "/published.lcmlog";
-  const int n = 15, B = 96, T = 100;
+  const int B = 96, T = 100;
   double g;
   po_get_constants(&g, nullptr);
 
@@ -102,12 +102,9 @@ int main(int argc, char **argv)
   param.set("state_estimator.ins.channel", "IMU_TICK");
   param.set("state_estimator.ins.q_gyro", 0.5);
   param.set("state_estimator.ins.q_accel", 0.1);
-  param.set("state_estimator.ins.q_gyro_bias", 0.0);
-  param.set("state_estimator.ins.q_accel_bias", 0.0);
   param.set("state_estimator.ins.timestep_dt", 0.001);
   param.set("state_estimator.ins.atlas_filter", "false");
-  param.set("state_estimator.ins.accel_bias_update_online", "false");
-  param.set("state_estimator.ins.gyro_bias_update_online", "false");
+  set_ins_bias_keys(param, n);
   param.applyOverrides("state_estimator.fovis.mode=position_orient|state_estimator.fovis.r_pxyz=0.02|state_estimator.fovis.r_chi=0.01");
   param.set("state_estimator.filter_state_channel", "STATE_ESTIMATOR_STATE");
   param.set("state_estimator.publish_filter_state", "true");
@@ -129,7 +126,8 @@ int main(int argc, char **argv)
     for (int i = 0; i < 4; i++) { x0.q(i, b) = q[i]; ox[b].quat[i] = q[i]; }
     for (int i = 0; i < 3; i++) { x0(3 + i, b) = 0.2 * nrand(); ox[b].vec[3 + i] = x0(3 + i, b); }
     const double sig[15] = { 0, 0, 0, .15, .15, .15, .05, .05, .05, .5, .5, .5, 0, 0, 0 };
-    for (int i = 0; i < n; i++) { P0(i, i, b) = sig[i] * sig[i] * (1.0 + 0.01 * b); oP[b].m[i * 21 + i] = P0(i, i, b); }
+    for (int i = 0; i < 15; i++) { P0(i, i, b) = sig[i] * sig[i] * (1.0 + 0.01 * b); oP[b].m[i * 21 + i] = P0(i, i, b); }
+    init_bias_states(n, b, x0, P0, &ox[b], &oP[b], urand);
   }
   BotTrans ins_to_body;
   InsHandler ins_handler(&param, &ins_to_body);

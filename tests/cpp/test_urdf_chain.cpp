@@ -46,6 +46,20 @@ int main()
   expect(!ModelClient::chainTo(URDF, "base", ch), "the root link has no chain");
   expect(!ModelClient::chainTo(URDF, "nowhere", ch), "unknown link");
   expect(!ModelClient::chainTo(URDF, "r_weird", ch), "a floating joint on the way is refused");
+  {  // XML allows white space around '='; an attribute that is there but does not hold three numbers is an error
+    const char *spaced = "<robot><joint name = \"j\" type\t=\n'revolute'><parent link = \"a\"/><child link= \"b\"/>"
+                         "<origin xyz = \"1 2 3\" rpy =' 0.1  0.2 0.3 '/><axis xyz\n=\"0 0 1\"/></joint></robot>";
+    expect(ModelClient::chainTo(spaced, "b", ch) && ch.size() == 1 && ch[0].xyz[1] == 2.0 && ch[0].rpy[2] == 0.3 && ch[0].axis[2] == 1.0 && ch[0].axis[0] == 0.0,
+           "white space around '=' in attributes");
+    const char *bad_xyz = "<robot><joint name=\"j\" type=\"revolute\"><parent link=\"a\"/><child link=\"b\"/><origin xyz=\"1 2\"/></joint></robot>";
+    expect(!ModelClient::chainTo(bad_xyz, "b", ch), "an <origin xyz> with two numbers is refused");
+    const char *bad_axis = "<robot><joint name=\"j\" type=\"revolute\"><parent link=\"a\"/><child link=\"b\"/><axis xyz=\"0 0 one\"/></joint></robot>";
+    expect(!ModelClient::chainTo(bad_axis, "b", ch), "an <axis xyz> that is not numeric is refused");
+    const char *four = "<robot><joint name=\"j\" type=\"revolute\"><parent link=\"a\"/><child link=\"b\"/><origin rpy=\"0 0 0 0\"/></joint></robot>";
+    expect(!ModelClient::chainTo(four, "b", ch), "an <origin rpy> with four numbers is refused");
+    ModelClient mb;
+    expect(!mb.fromURDFString(bad_xyz, "b", "b"), "fromURDFString fails on an unreadable URDF");
+  }
   ModelClient m;
   expect(m.fromURDFString(URDF, "l_sole", "r_thigh") && m.left_chain.size() == 4 && m.right_chain.size() == 1 && m.getURDFString() == URDF, "fromURDFString");
   expect(!m.fromURDFString(URDF, "l_sole", "r_weird"), "fromURDFString with an unsupported chain");

@@ -1,6 +1,8 @@
 """The C++ mirror of the reference API (pronto_amd/csrc/mav_state_est_batch.hpp): it compiles and links against the
 C ABI everywhere; on a GPU the miniature se-fusion in tests/cpp/test_shim.cpp and the delayed-measurement replay in
-tests/cpp/test_history.cpp must agree with the oracle."""
+tests/cpp/test_history.cpp must agree with the oracle.  Every handler test runs for the 15-state filter and for the
+21-state one (biases estimated online: BASELINE config 5's filter) -- "n21" on the executable's command line
+(tests/cpp/test_n.hpp)."""
 import os
 import subprocess
 
@@ -9,6 +11,7 @@ import pytest
 from pronto_amd import _lib
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NARG = {15: [], 21: ["n21"]}  # tests/cpp/test_n.hpp
 
 
 def build_exe(oracle, name="test_shim"):
@@ -16,7 +19,7 @@ def build_exe(oracle, name="test_shim"):
     exe = os.path.join(ROOT, "tests", "build", name)
     os.makedirs(os.path.dirname(exe), exist_ok=True)
     src = os.path.join(ROOT, "tests", "cpp", name + ".cpp")
-    deps = [src, os.path.join(ROOT, "pronto_amd", "csrc", "mav_state_est_batch.hpp"),
+    deps = [src, os.path.join(ROOT, "tests", "cpp", "test_n.hpp"), os.path.join(ROOT, "pronto_amd", "csrc", "mav_state_est_batch.hpp"),
             os.path.join(ROOT, "pronto_amd", "csrc", "pronto_wire.hpp"),
             os.path.join(ROOT, "include", "pronto_batch.h"), _lib.LIB_PATH]
     if os.path.exists(exe) and all(os.path.getmtime(exe) >= os.path.getmtime(d) for d in deps):
@@ -30,10 +33,11 @@ def build_exe(oracle, name="test_shim"):
 
 
 @pytest.mark.gpu
-def test_atlas_imu_front_end_on_gpu(oracle, tmp_path):
+@pytest.mark.parametrize("n", [15, 21])
+def test_atlas_imu_front_end_on_gpu(oracle, tmp_path, n):
     """KVH batch de-dup + device notch cascade + process step through InsHandler::processMessageAtlas vs the oracle."""
     exe = build_exe(oracle, "test_atlas_imu")
-    r = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=300)
+    r = subprocess.run([exe, str(tmp_path)] + NARG[n], capture_output=True, text=True, timeout=300)
     print(r.stdout, r.stderr)
     assert r.returncode == 0 and "PASS" in r.stdout, r.stdout + r.stderr
 
@@ -50,35 +54,40 @@ def test_smooth_backwards_pass_on_gpu(oracle, n):
 
 
 @pytest.mark.gpu
-def test_lcm_log_replay_and_filter_state_publishing_on_gpu(oracle, tmp_path):
+@pytest.mark.parametrize("n", [15, 21])
+def test_lcm_log_replay_and_filter_state_publishing_on_gpu(oracle, tmp_path, n):
     """A recorded LCM event log (pronto::indexed_measurement_t, pronto::update_t, raw IMU ticks, foreign channels)
     replayed into the batch through LogPlayer + the reference's handlers vs the oracle; the head published as
     pronto::filter_state_t and read back bit-exactly (pronto_wire.hpp)."""
     exe = build_exe(oracle, "test_log_replay")
-    r = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=300)
+    r = subprocess.run([exe, str(tmp_path)] + NARG[n], capture_output=True, text=True, timeout=300)
     print(r.stdout, r.stderr)
     assert r.returncode == 0 and "PASS" in r.stdout, r.stdout + r.stderr
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("variant", ["", "derived", "fuse"])
-def test_fovis_keyframe_lookup_in_history_on_gpu(oracle, variant):
+@pytest.mark.parametrize("n", [15, 21])
+@pytest.mark.parametrize("variant", ["", "derived", "fuse", "empty"])
+def test_fovis_keyframe_lookup_in_history_on_gpu(oracle, variant, n):
     """FovisHandler with posterior checkpoints on: T0 comes from history.updateMap.lower_bound(prev_timestamp) like in the
     reference (25 ms rule, cached per keyframe, 'at the end' rejection), no manual keyframe marking.  "derived": only
     utime_history_span is configured (sparse default checkpoints), "fuse": the look-up lands on the INS half of a fused
-    pair -- in both the posterior has no checkpoint and is re-derived from the nearest earlier one."""
+    pair -- in both the posterior has no checkpoint and is re-derived from the nearest earlier one.  "empty": updates whose
+    device-resident mask lets no filter through (the reference's handler returns NULL for such a message, so its history never
+    holds them) sit right behind the keyframe instants: the look-up steps over them (pb_mask_count, asked lazily)."""
     exe = build_exe(oracle, "test_fovis_history")
-    r = subprocess.run([exe] + ([variant] if variant else []), capture_output=True, text=True, timeout=300)
+    r = subprocess.run([exe] + ([variant] if variant else []) + NARG[n], capture_output=True, text=True, timeout=300)
     print(r.stdout[-2000:], r.stderr[-2000:])
     assert r.returncode == 0 and "PASS" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
 
 
 @pytest.mark.gpu
-def test_fovis_updates_own_their_measurement_across_a_replay(oracle):
+@pytest.mark.parametrize("n", [15, 21])
+def test_fovis_updates_own_their_measurement_across_a_replay(oracle, n):
     """Two FovisHandler updates in the window, then a measurement older than both: the replay re-applies each VO update
     with the z / quaternion it was built with (the handler is even destroyed before the estimator)."""
     exe = build_exe(oracle, "test_fovis_replay")
-    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    r = subprocess.run([exe] + NARG[n], capture_output=True, text=True, timeout=300)
     print(r.stdout[-2000:], r.stderr[-2000:])
     assert r.returncode == 0 and "PASS" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
 
@@ -86,26 +95,28 @@ def test_fovis_updates_own_their_measurement_across_a_replay(oracle):
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["sm_position", "sm_velocity", "sm_yaw", "sm_position_yaw", "sm_velocity_yaw", "fovis_velocity",
                                   "fovis_position", "legodo_zero3", "legodo_ft"])
-def test_every_handler_mode_on_gpu(oracle, mode):
+@pytest.mark.parametrize("n", [15, 21])
+def test_every_handler_mode_on_gpu(oracle, mode, n):
     """The handler modes the miniature se-fusion does not reach: all five ScanMatcherHandler modes
     (sensor_handlers.cpp:612-724), FovisHandler velocity / position (rbis_fovis_update.cpp:93-117), LegOdoHandler's
     zero_initial_velocity = 3 and its force/torque gate (rbis_legodo_update.cpp:208-211,264-268), each against the oracle's
     restatement of the same handler arithmetic."""
     exe = build_exe(oracle, "test_handler_modes")
-    r = subprocess.run([exe, mode], capture_output=True, text=True, timeout=300)
+    r = subprocess.run([exe, mode] + NARG[n], capture_output=True, text=True, timeout=300)
     print(r.stdout[-2000:], r.stderr[-2000:])
     assert r.returncode == 0 and "PASS" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode,fuse", [("lin_rate", ""), ("lin_rot_rate", ""), ("lin_rate", "fuse"), ("lin_rot_rate", "fuse")])
-def test_leg_odometry_from_foot_transforms_through_the_handler_on_gpu(oracle, mode, fuse):
+@pytest.mark.parametrize("n", [15, 21])
+def test_leg_odometry_from_foot_transforms_through_the_handler_on_gpu(oracle, mode, fuse, n):
     """LegOdoHandler::processMessageFeet: leg_estimate::updateOdometry + contact classification + createMeasurement on the
     device for every filter (its world_to_body_ is the filter's own head orientation), against the oracle's restatement.
     "fuse": with state_estimator.fuse_ins_legodo the INS step stays pending, the odometry is slaved to the orientation after it
     and the pair runs as one fused kernel -- same oracle sequence (predict, odometry, update)."""
     exe = build_exe(oracle, "test_leg_feet")
-    r = subprocess.run([exe, mode] + ([fuse] if fuse else []), capture_output=True, text=True, timeout=300)
+    r = subprocess.run([exe, mode] + ([fuse] if fuse else []) + NARG[n], capture_output=True, text=True, timeout=300)
     print(r.stdout[-2000:], r.stderr[-2000:])
     assert r.returncode == 0 and "PASS" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
 
@@ -131,13 +142,14 @@ def test_urdf_chains_and_leg_handler_configuration_host_only(oracle):
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode,slots,fuse", [("pos_and_lin_rate", 0, ""), ("pos_and_lin_rate", 6, ""), ("lin_rot_rate", 0, ""),
                                              ("lin_rate", 0, "fuse"), ("lin_rate", 4, "fuse"), ("pos_and_lin_rate", 0, "fuse")])
-def test_legodo_modes_on_gpu(oracle, mode, slots, fuse):
+@pytest.mark.parametrize("n", [15, 21])
+def test_legodo_modes_on_gpu(oracle, mode, slots, fuse, n):
     """LegOdoCommon's other modes, incl. the per-filter pos_and_lin_rate -> lin_rate fall-back (two complementary masked
     updates), with and without posterior checkpoints, vs the oracle's createMeasurement + indexed update.  "fuse": the
     opt-in state_estimator.fuse_ins_legodo -- every INS step followed by a lin_rate measurement runs as one fused kernel,
     with checkpoints too (the pair is checkpointed behind its second half); updates that are not fusible run one by one."""
     exe = build_exe(oracle, "test_legodo_modes")
-    r = subprocess.run([exe, mode, str(slots), fuse], capture_output=True, text=True, timeout=300)
+    r = subprocess.run([exe, mode, str(slots), fuse] + NARG[n], capture_output=True, text=True, timeout=300)
     print(r.stdout, r.stderr)
     assert r.returncode == 0 and "PASS" in r.stdout, r.stdout + r.stderr
 
@@ -169,14 +181,15 @@ def test_shim_matches_oracle_on_gpu(oracle, n, fuse):
 @pytest.mark.gpu
 @pytest.mark.parametrize("checkpoint_every,delay,fuse", [(1, 0, ""), (1, 7, ""), (4, 13, ""), (0, 7, ""), (1, 7, "fuse"), (4, 13, "fuse"),
                                                          (0, 7, "fuse")])
-def test_delayed_measurements_replay_equals_in_order(oracle, checkpoint_every, delay, fuse):
+@pytest.mark.parametrize("n", [15, 21])
+def test_delayed_measurements_replay_equals_in_order(oracle, checkpoint_every, delay, fuse, n):
     """measurements arriving `delay` steps late are inserted at their timestamp and everything
     after them is re-applied from the nearest posterior checkpoint (mav_state_est.cpp:28-80); the head must equal an
     in-order pass (the oracle).  Dense and sparse checkpointing agree; checkpoint_every = 0 sets ONLY utime_history_span,
     like a reference .cfg: the estimator derives its checkpoint pool and cadence from the span.  "fuse": the same with
     state_estimator.fuse_ins_legodo -- INS + leg-odometry pairs run as one kernel and are checkpointed as one update."""
     exe = build_exe(oracle, "test_history")
-    r = subprocess.run([exe, str(checkpoint_every), str(delay)] + ([fuse] if fuse else []), capture_output=True, text=True, timeout=300)
+    r = subprocess.run([exe, str(checkpoint_every), str(delay)] + ([fuse] if fuse else []) + NARG[n], capture_output=True, text=True, timeout=300)
     print(r.stdout, r.stderr)
     assert r.returncode == 0 and "PASS" in r.stdout, r.stdout + r.stderr
     assert "before the first in history" in r.stderr  # the too-old fix was discarded (update_history.cpp:28-39)
@@ -247,12 +260,14 @@ def test_shim_sweep_rate_example_runs(n, slots):
                                   ("lin_rot_rate", "ctrl"), ("pos_and_lin_rate", "alt"), ("lin_rate", "ctrl", "nofuse", "bcast"),
                                   ("lin_rate", "alt", "fuse", "blocks", "lowpass"), ("lin_rate", "alt", "fuse", "bcast", "kalman"),
                                   ("lin_rot_rate", "standing", "nofuse", "blocks", "kalman"), ("lin_rate", "alt", "nofuse", "bcast", "lowpass"),
-                                  ("lin_rate", "alt", "fuse", "device", "none"), ("lin_rate", "ctrl", "fuse", "device", "lowpass")])
-def test_joint_state_handler_on_gpu(oracle, args):
+                                  ("lin_rate", "alt", "fuse", "device", "none"), ("lin_rate", "ctrl", "fuse", "device", "lowpass"),
+                                  ("lin_rate", "alt", "fuse3", "device", "none")])
+@pytest.mark.parametrize("n", [15, 21])
+def test_joint_state_handler_on_gpu(oracle, args, n):
     """LegOdoHandler::processMessage(joint_state_t) -- the reference's handler signature -- from a synthetic 6-DoF-per-leg gait:
     URDF text -> chains, force/torque + controller messages, torque adjustment, forward kinematics, contact logic, odometry and
     LegOdoCommon's measurement on the device, against the oracle chain (tests/cpp/test_leg_joints.cpp)."""
     exe = build_exe(oracle, "test_leg_joints")
-    r = subprocess.run([exe, *args], capture_output=True, text=True, timeout=300)
+    r = subprocess.run([exe, *args] + NARG[n], capture_output=True, text=True, timeout=300)
     print(r.stdout[-2000:], r.stderr[-2000:])
     assert r.returncode == 0 and "PASS" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]

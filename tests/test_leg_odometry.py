@@ -706,3 +706,86 @@ def test_pair_kernel_at_full_batch_size_on_gpu(n):
     assert s1[3] == 0 and s2[3] == 0
     assert abs(s1[0] - s2[0]) <= 1e-11 * abs(s2[0]) and abs(s1[1] - s2[1]) <= 1e-11 * abs(s2[1])
     assert c1 == c3 and np.array_equal(s1, s3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [15, 21])
+@pytest.mark.parametrize("kind", ["joints_dev", "joints_bcast", "feet_dev"])
+def test_pair_call_against_the_oracle_chain_on_gpu(oracle, n, kind):
+    """pb_step_legodo_joints / pb_step_legodo_feet DIRECTLY against the oracle -- not against the library's own two-call
+    sequence: per tick po_imu_process_step, then (with the ORACLE filter's own pose after that step as world_to_body_)
+    po_torque_adjust -> po_fk -> po_leg_update_wc -> LegOdoCommon's lin_rate measurement -> po_indexed_update, the
+    zero_initial_velocity counter per filter.  Masks (= statuses >= 0) bit-identical every tick, the measurement block the
+    kernel applied <= 1e-8, the posterior at the end <= 1e-9 (check).  n = 21 is k_step_quad_leg (per-filter joint blocks:
+    one kernel too since round 4), n = 15 k_step_leg."""
+    import torch
+    import legs
+    from pronto_amd import batch as pa
+    from util import embed21
+    B, T, ZERO = 12, 260, 4
+    dev = torch.device("cuda:0")
+    L = oracle.lib()
+    chain = legs.chain_arrays(legs.ATLAS_LEFT, legs.ATLAS_RIGHT, legs.ATLAS_ROWS)
+    gain = np.array([7000, 10000, 10000, 10000, 10000, 10000] * 2, dtype=np.float32)
+    w = Workload(B, n_states=n, dt_us=2000)
+    vec, quat, P0 = w.initial_state()
+    v21, P21 = embed21(vec, P0)
+    ob = oracle.OracleBatch(v21, quat, P21)
+    est = pa.BatchEstimator(B, n_states=n)
+    est.set_constants(*oracle.constants())
+    est.reset(vec, quat, P0)
+    est.legodo_init(*SCHMITT, True)
+    est.legodo_set_chain(*chain, gain)
+    est.legodo_set_zero_initial_velocity(ZERO)
+    orc = OracleLegs(oracle, B, True)
+    zc = np.full(B, ZERO)
+    q4 = w.process_noise()
+    lo = torch.zeros((6, B), dtype=torch.float64, device=dev)
+    mk = torch.zeros(B, dtype=torch.uint8, device=dev)
+    r, ru = R_VXYZ
+    bcast = kind.endswith("bcast")
+    W = 1 if bcast else B
+    src = legs.joint_gait(W, T, seed=27) if kind.startswith("joints") else gait(W, T, seed=27)
+    n_upd, seen = 0, set()
+    for k, msg in enumerate(src):
+        imu = w.imu_block(k)
+        if bcast:
+            imu = np.ascontiguousarray(np.repeat(imu[:, :1], B, axis=1))
+        imu_in = np.ascontiguousarray(imu[:, 0]) if bcast else torch.from_numpy(imu).to(dev)
+        if kind.startswith("joints"):
+            utime, jp, je, forces, _ = msg
+            a = (np.ascontiguousarray(jp[:, 0]), np.ascontiguousarray(je[:, 0]), np.ascontiguousarray(forces[:, 0])) if bcast else \
+                tuple(torch.from_numpy(x).to(dev) for x in (jp, je, forces))
+            est.step_legodo_joints(imu_in, q4, utime, *a, r, ru, lo, mk)
+            ofeet = legs.oracle_feet(L, chain, jp, je, gain)
+        else:
+            utime, feet, forces, _ = msg
+            est.step_legodo_feet(imu_in, q4, utime, torch.from_numpy(feet).to(dev), torch.from_numpy(forces).to(dev), r, ru, lo, mk)
+            ofeet = feet
+        if bcast:
+            ofeet, forces = np.repeat(ofeet, B, axis=1), np.repeat(forces, B, axis=1)
+        # the oracle chain on the oracle filter's OWN state
+        ob.predict(imu, q4)
+        od, os_, op = orc.update(utime, np.ascontiguousarray(ofeet), forces.astype(np.float64), np.ascontiguousarray(ob.quat))
+        valid = os_ >= 0
+        zc[valid] -= 1                                    # rbis_legodo_update.cpp:264-268, reached for a valid status only
+        zero = valid & (zc > 0)
+        od[0:3, zero] = 0.0
+        elapsed = (utime - op) * 1e-6
+        z = od[0:3] / elapsed
+        Rd = np.tile(np.where(os_ >= 0.5, ru * ru, r * r), (3, 1))
+        mask = valid.astype(np.uint8)
+        g_mask, g_lo = mk.cpu().numpy(), lo.cpu().numpy()
+        assert np.array_equal(g_mask, mask), (k, g_mask, mask)
+        assert np.max(np.abs(g_lo[0:3, valid] - z[:, valid]), initial=0.0) < 1e-8, k
+        assert np.allclose(g_lo[3:6, valid], Rd[:, valid], rtol=1e-14, atol=0), k
+        ob.update_indexed([3, 4, 5], np.ascontiguousarray(z), np.ascontiguousarray(Rd), mask=mask)
+        n_upd += int(valid.sum())
+        seen.update(np.unique(os_).tolist())
+    assert n_upd > B * T // 10 and seen == {-1.0, 0.0, 1.0}
+    from test_gpu_parity import check
+    check(est, ob)
+    pose, info = est.legodo_get(B - 1)
+    t, q, oi = orc.get(B - 1)
+    assert np.max(np.abs(pose[0:3] - t)) < 1e-9 and info[0] == oi[0] and info[1] == oi[1] and info[2] == oi[2]
+    est.close()
