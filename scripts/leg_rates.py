@@ -19,8 +19,8 @@ dev = torch.device("cuda:0")
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 
 
-def timeit(fn, reps=60):
-    for _ in range(6):
+def timeit(fn, reps=400):
+    for _ in range(100):  # (long enough for the clocks to settle: with 6 + 60 launches the first rows of a run read 20-30 % high)
         fn()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
