@@ -5,8 +5,9 @@ One step = one IMU predict (RBISIMUProcessStep) + one 3-DoF leg-odometry update 
 idx 3..5) for every filter of the batch = ONE kernel launch; the posterior is written back to HBM after every
 step (T = 1 accounting).  Inputs (IMU + leg-odometry streams for warmup+steps) are resident
 in HBM before the timed region.  N > 1: one process per GPU (torch.distributed / RCCL), the batch is split by
-filter range with NO data-path collective ("weak" scaling: per-GPU batch fixed); the only collective is the
-end-of-run summary all-reduce.  `python bench.py --gpus N` starts its N ranks itself (child processes, the parent never
+filter range with NO data-path collective; the only collective is the end-of-run summary all-reduce.  --scaling weak (default:
+--batch-per-gpu filters on every GPU) or strong (--total-batch filters, default BASELINE config 4's 262 144, split over the
+GPUs); the line's "scaling" and config.workload say which one ran.  `python bench.py --gpus N` starts its N ranks itself (child processes, the parent never
 touches the GPU); under torch.distributed.run (WORLD_SIZE set) it is one of the ranks.
 
 The K timed steps are repeated (`repeats`) until the timed region lasts >= --min-timed-ms; `value`, `ms_per_step` and the
@@ -223,6 +224,20 @@ def cache_busting(BatchEstimator, dev, local_rank, n, d_imu, d_lo, d_mask, vec, 
             "frac": bps * Bb / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, "value": Bb / (us * 1e-6), "nonfinite": float(s[3])}
 
 
+def workload_name(n, Bper, total, world, scaling):
+    """config.workload: BASELINE.json's own wording where the run IS one of its configs, a plain description otherwise."""
+    k = lambda v: "%dk" % (v // 1024) if v % 1024 == 0 else str(v)
+    what = "IMU predict + 3-DoF leg-odom update"
+    if world == 1:
+        if n == 15 and total == 65536:
+            return "64k batched 15-state filters, %s, 1 MI355X" % what          # BASELINE.json configs[1]
+        return "%s batched %d-state filters, %s, 1 MI355X" % (k(total), n, what)
+    if scaling == "strong":
+        tag = " (BASELINE.json configs[3])" if (n == 15 and total == 262144 and world == 8) else ""
+        return "%s batched %d-state filters sharded %dxMI355X, %s per GPU, %s, strong scaling%s" % (k(total), n, world, k(Bper), what, tag)
+    return "%s batched %d-state filters per GPU x %d MI355X = %s filters, %s, weak scaling (per-GPU batch fixed)" % (k(Bper), n, world, k(total), what)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -230,12 +245,17 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch-per-gpu", type=int, default=65536)
     ap.add_argument("--n-states", type=int, default=15, choices=[15, 21])
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline sample")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="N > 1: weak = --batch-per-gpu filters on EVERY GPU (the default; the line says so); strong = --total-batch "
+                         "filters split over the N GPUs -- with the default 262 144 that is BASELINE config 4 (32 768 per GPU at N = 8)")
+    ap.add_argument("--total-batch", type=int, default=262144, help="--scaling strong: filters of the whole job")
+    ap.add_argument("--cpu-seconds", type=float, default=6.0,
+                    help="target wall time of the dense CPU baseline sample (the structured one adds <= 3 s: <= 10 s of CPU work in all)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cache-busting", action="store_true", help="skip the 1 M-filter true-HBM leg (N=1 only)")
-    ap.add_argument("--min-timed-ms", type=float, default=1000.0,
-                    help="the K timed steps are repeated until the timed region is at least this long (1 s by default, for "
-                         "the 64k leg and the 1 M-filter leg alike: long enough for an external GPU-busy sampler to see it)")
+    ap.add_argument("--min-timed-ms", type=float, default=6000.0,
+                    help="the K timed steps are repeated until the timed region is at least this long (6 s by default, for "
+                         "the 64k leg and the 1 M-filter leg alike: an external GPU-busy sampler with a 5 s period must see both)")
     ap.add_argument("--host-streams", action="store_true",
                     help="generate the input streams with the numpy generator on the host (pronto_amd/synth.py) instead of "
                          "on the device (pronto_amd/synth_device.py: the same counter-based samples)")
@@ -293,8 +313,12 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=RDV_TIMEOUT)
 
     n, K, W = args.n_states, args.steps, args.warmup
-    Bper = args.batch_per_gpu
-    total = Bper * world
+    if args.scaling == "strong":
+        total = args.total_batch
+        Bper = (total + world - 1) // world   # (shard_range hands the remainder to the first ranks)
+    else:
+        Bper = args.batch_per_gpu
+        total = Bper * world
     b0, b1 = shard_range(total, rank, world)
     B = b1 - b0
     dt_us = 1000
@@ -409,16 +433,14 @@ def main():
         state_mb = (n + 5 + n * (n + 1) // 2) * 8 * B / 1e6
         out = {
             "metric": METRIC, "value": value, "unit": "steps/s", "n_gpus": world, "steps": K, "warmup": W,
-            "ms_per_step": wall_s / KR * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": wall_s / KR * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "repeats": reps, "timed_steps": KR, "timed_region_ms": wall_s * 1e3,
             "per_rank_ms": {"kernel_time_max": float(spread[0]), "kernel_time_min": -float(spread[1]),
                             "stream_generation_max": float(spread[2]) * 1e3, "stream_generation_min": -float(spread[3]) * 1e3,
                             "streams": "host numpy" if args.host_streams else "device (pronto_amd/synth_device.py)"},
-            "config": {"workload": "64k batched 15-state filters, IMU predict + 3-DoF leg-odom update, 1 MI355X"
-                       if (n == 15 and Bper == 65536) else
-                       "%d batched %d-state filters per GPU, IMU predict + 3-DoF leg-odom update" % (Bper, n),
-                       "batch_per_gpu": Bper, "n_states": n, "imu_dt_us": dt_us, "kernel": hot,
+            "config": {"workload": workload_name(n, Bper, total, world, args.scaling),
+                       "batch_per_gpu": Bper, "total_batch": total, "n_states": n, "imu_dt_us": dt_us, "kernel": hot,
                        "launches_per_step": 1, "bytes_per_filter_step": bps, "parallelism": "filter-range split x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "traffic_source": None,

@@ -1,12 +1,12 @@
 #!/bin/bash
-# Profiling recipe (run on the GPU box through gpurun):  bash scripts/profile.sh r03
+# Profiling recipe (run on the GPU box through gpurun):  bash scripts/profile.sh r04
 # Outputs under gpurun_out/prof_<tag>/ ; condense them with scripts/profile_summary.py into profiles/.
 #  1. rocprofv3 --kernel-trace --stats of the default bench command (and of the n=21 variant)
 #  2. separate --pmc passes (FETCH_SIZE, then WRITE_SIZE; never combined with trace domains) of the bench command,
 #     the cache-busting 1M-filter run, the n=21 run, and the calibration copy (known bytes, same access pattern)
 #  3. the adjacent kernels, whole configurations and the smoother (trace + SQ/LDS counters); copy ceilings and sweeps
 set -o pipefail
-TAG=${1:-r03}
+TAG=${1:-r04}
 export TMPDIR=/tmp
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/prof_$TAG
@@ -26,8 +26,8 @@ if [ "$ONLY" = smoother ]; then
   exit 0
 fi
 rm -rf $OUT; mkdir -p $OUT
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace64k -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-cache-busting > $OUT/trace64k.json 2> $OUT/trace64k.err || exit 11
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace64k_n21 -- python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-cache-busting --n-states 21 > $OUT/trace64k_n21.json 2> $OUT/trace64k_n21.err || exit 11
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace64k -- python3 bench.py --steps 200 --warmup 20 --min-timed-ms 1000 --no-cpu-baseline --no-cache-busting > $OUT/trace64k.json 2> $OUT/trace64k.err || exit 11
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace64k_n21 -- python3 bench.py --steps 100 --warmup 10 --min-timed-ms 1000 --no-cpu-baseline --no-cache-busting --n-states 21 > $OUT/trace64k_n21.json 2> $OUT/trace64k_n21.err || exit 11
 # the true-HBM leg: the same step on 1 M filters (state 1.17 GB), kernel trace of its own
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace1m -- python3 bench.py --batch-per-gpu 1048576 --steps 20 --warmup 5 --min-timed-ms 300 --no-cpu-baseline --no-cache-busting > $OUT/trace1m.json 2> $OUT/trace1m.err || exit 11
 echo "traces done"

@@ -169,3 +169,29 @@ def test_bench_four_ranks_on_one_card_rehearsal_is_quick_and_equals_one_rank():
     # the host generator gives the same workload (to rounding of the device's sin / log)
     host = _bench_line({}, "--batch-per-gpu", "32768", "--host-streams")
     assert abs(host["summary"]["checksum_abs"] - b["checksum_abs"]) <= 1e-9 * abs(b["checksum_abs"])
+
+
+def test_bench_names_its_workload_truthfully_at_every_gpu_count():
+    """config.workload: BASELINE.json's wording only where the run IS that config; N > 1 lines say how many
+    filters each GPU holds, how many there are in all and which scaling mode ran."""
+    import bench
+    assert bench.workload_name(15, 65536, 65536, 1, "weak") == "64k batched 15-state filters, IMU predict + 3-DoF leg-odom update, 1 MI355X"
+    w8 = bench.workload_name(15, 65536, 8 * 65536, 8, "weak")
+    assert "1 MI355X" not in w8 and "x 8 MI355X" in w8 and "512k filters" in w8 and "weak" in w8
+    s8 = bench.workload_name(15, 32768, 262144, 8, "strong")
+    assert "256k" in s8 and "32k per GPU" in s8 and "strong" in s8 and "configs[3]" in s8
+    assert "configs[3]" not in bench.workload_name(15, 131072, 262144, 2, "strong")
+    assert "21-state" in bench.workload_name(21, 65536, 65536, 1, "weak")
+
+
+@pytest.mark.gpu
+def test_bench_strong_scaling_mode_splits_one_job():
+    """--scaling strong: --total-batch filters split over the ranks (BASELINE config 4's shape), two ranks rehearsed on one card
+    against one rank with the whole job; the line says which mode ran."""
+    two = _bench_line({"PRONTO_BENCH_REHEARSE": "1"}, "--gpus", "2", "--scaling", "strong", "--total-batch", "8192")
+    one = _bench_line({}, "--scaling", "strong", "--total-batch", "8192")
+    assert two["scaling"] == "strong" and two["config"]["batch_per_gpu"] == 4096 and two["config"]["total_batch"] == 8192
+    assert "strong" in two["config"]["workload"] and one["config"]["batch_per_gpu"] == 8192
+    a, b = two["summary"], one["summary"]
+    assert abs(a["sum_loglik"] - b["sum_loglik"]) <= 1e-9 * abs(b["sum_loglik"])
+    assert abs(a["checksum_abs"] - b["checksum_abs"]) <= 1e-12 * abs(b["checksum_abs"])
