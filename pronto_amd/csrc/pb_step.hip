@@ -46,10 +46,19 @@ template <int MH>
 static void launch_step_leg(pb_ctx *c, double *out, const double *imu, const double q[4], const StepBcast &bc, const LegIn &lin,
                             const LegStepArgs &la)
 {
-  if (c->ns == 15)
-    k_step_leg<15, MH><<<nblk(c->B), 128, 0, c->stream>>>(c->st, out, c->B, imu, q[0], q[1], q[2], q[3], c->k, bc, c->leg_par, lin, la);
-  else
-    k_step_quad_leg<MH><<<nblk(c->B), 256, 0, c->stream>>>(c->st, out, c->B, imu, q[0], q[1], q[2], q[3], c->k, bc, c->leg_par, lin, la);
+  // PRONTO_BATCH_LEGPLAN=0: round 3's division of the leg work between the waves of a tile (A/B runs; per-filter joint blocks only)
+  static const int plan = getenv("PRONTO_BATCH_LEGPLAN") ? atoi(getenv("PRONTO_BATCH_LEGPLAN")) : -1;
+  if (c->ns == 15) {
+    if (plan == 0 && MH == MH_STORE_SC1)
+      k_step_leg<15, MH, 0><<<nblk(c->B), 128, 0, c->stream>>>(c->st, out, c->B, imu, q[0], q[1], q[2], q[3], c->k, bc, c->leg_par, lin, la);
+    else
+      k_step_leg<15, MH><<<nblk(c->B), 128, 0, c->stream>>>(c->st, out, c->B, imu, q[0], q[1], q[2], q[3], c->k, bc, c->leg_par, lin, la);
+  } else {
+    if (plan == 0 && MH == MH_STORE_SC1)
+      k_step_quad_leg<MH, 0><<<nblk(c->B), 256, 0, c->stream>>>(c->st, out, c->B, imu, q[0], q[1], q[2], q[3], c->k, bc, c->leg_par, lin, la);
+    else
+      k_step_quad_leg<MH><<<nblk(c->B), 256, 0, c->stream>>>(c->st, out, c->B, imu, q[0], q[1], q[2], q[3], c->k, bc, c->leg_par, lin, la);
+  }
 }
 
 int pbk_step_leg(pb_ctx *c, const double *imu, const StepBcast *bcast, const double q[4], const LegIn &lin, int64_t utime, double r2,
@@ -63,7 +72,8 @@ int pbk_step_leg(pb_ctx *c, const double *imu, const StepBcast *bcast, const dou
   // odometry kernel followed by the fused step on the same box): two launches.  k_step_quad_leg keeps the code path (it is
   // what a foot-state or broadcast joint-state message runs on).  (Also tried: k_leg_fk as a pre-pass and the pair kernel on its
   // foot poses -- 59.8 us, the small kernel costs more than the 3.4 us the kinematics add inside k_legodo.)
-  if (c->ns == 21 && lin.kind == 1) return -1;
+  static const bool two_launches21 = getenv("PRONTO_BATCH_LEG21_TWO") && getenv("PRONTO_BATCH_LEG21_TWO")[0] == '1';
+  if (c->ns == 21 && lin.kind == 1 && two_launches21) return -1;
   const StepBcast bc = bcast ? *bcast : StepBcast();
   LegStepArgs la{ c->legd, c->legi, c->stride, utime, r2, r2_uncertain, lo_out, mask_out };
   double *out = update_target(c);

@@ -145,7 +145,7 @@ struct CoopX {
   static constexpr int X2_L = C::NXCH, X2_ID = X2_L + M * (M - 1) / 2, X2_YD = X2_ID + M, X2_W = X2_YD + M,
                        X2_LLI = X2_W + C::NSC * M;
   static constexpr int NXCH = (M == 0) ? C::NXCH : X2_LLI + (C::LL_IN_P ? 1 : 0);
-  static constexpr int XCH_LEG = NXCH, XCH_FOOT = NXCH + 5, NXCH_LEG = NXCH + 12;  // k_step_leg: z[3], R, valid from the odometry wave; one foot pose (7) from the other wave
+  static constexpr int XCH_LEG = NXCH, XCH_FOOT = NXCH + 5, NXCH_LEG = NXCH + 19;  // k_step_leg: z[3], R, valid from the odometry wave; the two foot poses (2 x 7) from the other wave
 };
 
 // ------------------------------------------------------------------------------------------------------------

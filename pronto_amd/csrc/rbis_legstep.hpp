@@ -33,7 +33,11 @@ struct LegStepArgs {
   uint8_t *mask_out;  // [B] (with lo_out)
 };
 
-template <int NS, int MH>
+// PLAN (per-filter joint blocks only; who does what in front of barrier L):
+//   0  role C: forward kinematics of the left leg | role P: right leg, then (barrier F) contact logic + pelvis integration
+//   1  role C: forward kinematics of BOTH legs (it waits for its 29 rows anyway) | role P: contact logic -- Schmitt triggers and the
+//      walking-phase classifier read the foot forces only -- in parallel, then (barrier F) the pelvis integration alone
+template <int NS, int MH, int PLAN = 1>
 __global__ __launch_bounds__(128, 1) void k_step_leg(const double *st, double *sto, int B, const double *__restrict__ imu, double qg,
                                                      double qa, double qbg, double qba, Consts k, StepBcast bc, LegPar par, LegIn lin,
                                                      LegStepArgs la)
@@ -82,18 +86,21 @@ __global__ __launch_bounds__(128, 1) void k_step_leg(const double *st, double *s
     io.template need<0, Slots<NS>::ROW_SPLIT>();
     if (split_fk) {
       leg_stage_chain(lin, chain_lds[0], lane);
-      Pose T;
-      leg_fk_side(lin, 0, bl_, (long) B, T);
 #pragma unroll
-      for (int i = 0; i < 3; i++) xch[CX::XCH_FOOT + i][lane] = T.t[i];
+      for (int side = 0; side < (PLAN == 0 ? 1 : 2); side++) {
+        Pose T;
+        leg_fk_side(lin, side, bl_, (long) B, T);
 #pragma unroll
-      for (int i = 0; i < 4; i++) xch[CX::XCH_FOOT + 3 + i][lane] = T.q[i];
+        for (int i = 0; i < 3; i++) xch[CX::XCH_FOOT + 7 * side + i][lane] = T.t[i];
+#pragma unroll
+        for (int i = 0; i < 4; i++) xch[CX::XCH_FOOT + 7 * side + 3 + i][lane] = T.q[i];
+      }
       __syncthreads();  // barrier F
     }
     coop_role_core<NS, true, NoCorr, true, true>(ld, stf, [lane](int s, double v) { xch[s][lane] = v; }, xrd, sync, in, k);
   } else {
     // ---- the odometry, on the prior state this role reads anyway ----
-    leg_stage_chain(lin, chain_lds[1], lane);
+    if (!split_fk || PLAN == 0) leg_stage_chain(lin, chain_lds[1], lane);
     LegState s;
     leg_load(s, la.legd, la.legi, la.stride, (long) b, false);     // (the state arrays are padded to whole tiles)
     double chi[3], bg[3] = { 0.0, 0.0, 0.0 }, wq[4];
@@ -103,21 +110,35 @@ __global__ __launch_bounds__(128, 1) void k_step_leg(const double *st, double *s
     for (int i = 0; i < 4; i++) wq[i] = io.ld(L::OFF_QUAT + i);
     Pose fl_, fr_, delta;
     float zl, zr;
-    int ncl, ncr;
+    int ncl, ncr, cs;
+    int64_t prev = 0;
+    double classification;
     if (split_fk) {
-      leg_fk_side(lin, 1, bl_, (long) B, fr_);
+      if (PLAN == 0) leg_fk_side(lin, 1, bl_, (long) B, fr_);
       leg_inputs_rest(lin, bl_, (long) B, zl, zr, ncl, ncr);
+      if (PLAN != 0) cs = leg_contacts(s, par, la.utime, zl, zr, ncl, ncr, classification, prev);  // (needs no foot pose)
       __syncthreads();  // barrier F
 #pragma unroll
       for (int i = 0; i < 3; i++) fl_.t[i] = xch[CX::XCH_FOOT + i][lane];
 #pragma unroll
       for (int i = 0; i < 4; i++) fl_.q[i] = xch[CX::XCH_FOOT + 3 + i][lane];
+      if (PLAN != 0) {
+#pragma unroll
+        for (int i = 0; i < 3; i++) fr_.t[i] = xch[CX::XCH_FOOT + 7 + i][lane];
+#pragma unroll
+        for (int i = 0; i < 4; i++) fr_.q[i] = xch[CX::XCH_FOOT + 10 + i][lane];
+      } else {
+        cs = leg_contacts(s, par, la.utime, zl, zr, ncl, ncr, classification, prev);
+      }
     } else {
       leg_inputs(lin, bl_, (long) B, fl_, fr_, zl, zr, ncl, ncr);
+      cs = leg_contacts(s, par, la.utime, zl, zr, ncl, ncr, classification, prev);
     }
     ins_update_quat<NS>(chi, bg, wq, in.gyro, in.dt, k);           // world_to_body_ = the head AFTER this pair's IMU step
-    int64_t prev = 0;
-    const double status = leg_update(s, par, la.utime, fl_, fr_, zl, zr, ncl, ncr, wq, delta, prev);
+    const double wpos0[3] = { 0.0, 0.0, 0.0 };
+    double position[3];
+    bool position_ok;
+    const double status = leg_integrate(s, par, cs, classification, fl_, fr_, wq, delta, wpos0, position, position_ok);
     if (leg_zero_velocity(s, status)) pose_identity(delta);
     if (b < (unsigned) B) leg_store(s, la.legd, la.legi, la.stride, (long) b, false);
     LegMeas m;
@@ -144,7 +165,11 @@ __global__ __launch_bounds__(128, 1) void k_step_leg(const double *st, double *s
 // The same for 21 states on the four-wave mapping (rbis_quad.hpp).  Role PW owns the state vector and the quaternion and
 // propagates them before barrier A anyway; it runs the odometry first, on the prior state it reads for its process blocks,
 // and publishes (z, R, valid) before that barrier -- role CC reads them behind it: no extra barrier.
-template <int MH>
+// PLAN (per-filter joint blocks only):
+//   0  forward kinematics: left leg in role CC, right leg in role CB; role PW contact logic + integration behind barrier F
+//   2  forward kinematics: left leg in role CB, right leg in role PA (the lightest role; CC, the heaviest, does none); role PW
+//      runs the contact logic in parallel and only the pelvis integration behind barrier F
+template <int MH, int PLAN = 2>
 __global__ __launch_bounds__(256, 2) void k_step_quad_leg(const double *st, double *sto, int B, const double *__restrict__ imu, double qg,
                                                           double qa, double qbg, double qba, Consts k, StepBcast bc, LegPar par, LegIn lin,
                                                           LegStepArgs la)
@@ -208,12 +233,15 @@ __global__ __launch_bounds__(256, 2) void k_step_quad_leg(const double *st, doub
   if (role == 0) {
     const StepInputs in = inputs();
     io.template need<SL::QROW[0], SL::QROW[1]>();
-    if (split_fk) { fk_to_lds(0, chain_lds[0]); __syncthreads(); }
+    if (split_fk) {
+      if (PLAN == 0) fk_to_lds(0, chain_lds[0]);
+      __syncthreads();  // barrier F
+    }
     quad_role_cc<true, true>(ld, stf, xwr, xrd, sync, in, k);
   } else if (role == 1) {
     const StepInputs in = inputs();
     io.template need<SL::QROW[1], SL::QROW[2]>();
-    if (split_fk) { fk_to_lds(1, chain_lds[1]); __syncthreads(); }
+    if (split_fk) { fk_to_lds(PLAN == 0 ? 1 : 0, chain_lds[1]); __syncthreads(); }
     quad_role_cb<true>(ld, stf, xwr, xrd, sync, in, k);
   } else if (role == 2) {
     StepInputs in = inputs();
@@ -227,20 +255,27 @@ __global__ __launch_bounds__(256, 2) void k_step_quad_leg(const double *st, doub
     for (int i = 0; i < 4; i++) wq[i] = io.ld(L::OFF_QUAT + i);
     Pose fl_, fr_, delta;
     float zl, zr;
-    int ncl, ncr;
+    int ncl, ncr, cs;
+    int64_t prev = 0;
+    double classification;
     if (split_fk) {
       leg_inputs_rest(lin, bl_, (long) B, zl, zr, ncl, ncr);
+      if (PLAN != 0) cs = leg_contacts(s, par, la.utime, zl, zr, ncl, ncr, classification, prev);  // (needs no foot pose)
       __syncthreads();  // barrier F
 #pragma unroll
       for (int i = 0; i < 3; i++) { fl_.t[i] = xch[Quad::X_FOOT + i][lane]; fr_.t[i] = xch[Quad::X_FOOT + 7 + i][lane]; }
 #pragma unroll
       for (int i = 0; i < 4; i++) { fl_.q[i] = xch[Quad::X_FOOT + 3 + i][lane]; fr_.q[i] = xch[Quad::X_FOOT + 10 + i][lane]; }
+      if (PLAN == 0) cs = leg_contacts(s, par, la.utime, zl, zr, ncl, ncr, classification, prev);
     } else {
       leg_inputs(lin, bl_, (long) B, fl_, fr_, zl, zr, ncl, ncr);
+      cs = leg_contacts(s, par, la.utime, zl, zr, ncl, ncr, classification, prev);
     }
     ins_update_quat<NS>(chi, bg, wq, in.gyro, in.dt, k);
-    int64_t prev = 0;
-    const double status = leg_update(s, par, la.utime, fl_, fr_, zl, zr, ncl, ncr, wq, delta, prev);
+    const double wpos0[3] = { 0.0, 0.0, 0.0 };
+    double position[3];
+    bool position_ok;
+    const double status = leg_integrate(s, par, cs, classification, fl_, fr_, wq, delta, wpos0, position, position_ok);
     if (leg_zero_velocity(s, status)) pose_identity(delta);
     if (b < (unsigned) B) leg_store(s, la.legd, la.legi, la.stride, (long) b, false);
     LegMeas m;
@@ -264,7 +299,10 @@ __global__ __launch_bounds__(256, 2) void k_step_quad_leg(const double *st, doub
   } else {
     const StepInputs in = inputs();
     io.template need<SL::QROW[3], SL::QROW[4]>();
-    if (split_fk) __syncthreads();  // barrier F
+    if (split_fk) {
+      if (PLAN != 0) fk_to_lds(1, chain_lds[0]);
+      __syncthreads();  // barrier F
+    }
     quad_role_passive<true, 1>(ld, stf, xwr, xrd, sync, in, k);
   }
 }

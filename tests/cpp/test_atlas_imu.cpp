@@ -64,7 +64,7 @@ int main(int argc, char **argv)
   std::deque<Pkt> ring;
   int64_t count = 0, prev_upd_utime = 0, last_seen_utime = 0;
   int n_updates = 0;
-  const double q4[4] = { ins_handler.cov_gyro, ins_handler.cov_accel, 0, 0 };
+  const double q4[4] = { ins_handler.cov_gyro, ins_handler.cov_accel, ins_handler.cov_gyro_bias, ins_handler.cov_accel_bias };
   for (int m = 0; m < NMSG; m++) {
     const int fresh = (m % 7 == 6) ? 0 : 3;
     std::vector<const Pkt *> fresh_ptrs;
