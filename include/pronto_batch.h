@@ -230,6 +230,20 @@ int pb_legodo_update_after_predict(pb_ctx *ctx, const double *imu_block, int imu
  * no controller input, controller contact counts -1, no world constraint, all per-robot state reset. */
 int pb_legodo_set_contact_mode(pb_ctx *ctx, int standing, double total_force, double standing_schmitt_level,
                                int use_controller_input);
+/* Which of LegOdoCommon's measurements (state_estimator.legodo.mode, rbis_legodo_common.cpp:5-23,110-169) the odometry calls
+ * pb_legodo_update / _after_predict / _joints write into lo_block_out / mask_out -- formed on the device, where the increment
+ * is, so that no batch-sized array crosses PCIe to form it (the reference forms it on the host right behind updateOdometry):
+ *   0  lin_rate (default)  lo_block_out [6][B]  = z (v), Rdiag;                  mask_out [B]     idx {3,4,5}
+ *   1  lin_rot_rate        lo_block_out [12][B] = z (v, rpy rate) [6], Rdiag [6]; mask_out [B]     idx {3,4,5,0,1,2}
+ *   2  pos_and_lin_rate    lo_block_out [12][B] = z (position, v) [6], Rdiag [6]; mask_out [2][B]  idx {9,10,11,3,4,5}
+ *      mask_out[0][b] = status valid AND position valid: the six-row update; mask_out[1][b] = status valid AND position NOT valid:
+ *      the reference's per-message fall-back to lin_rate (:118-122), a three-row update on rows 3..5 (z) and 9..11 (Rdiag) of
+ *      the same block with idx {3,4,5}.  Joint-state entry points only (the position is leg_estimate's world constraint,
+ *      which this mode switches on).
+ * r_xyz, r_vang, r_vang_uncertain: state_estimator.legodo.r_xyz / r_vang / r_vang_uncertain (r_vxyz and r_vxyz_uncertain stay
+ * arguments of the odometry calls).  The pair calls pb_step_legodo_joints / _feet always form and apply lin_rate.
+ * pb_legodo_init puts the mode back to 0. */
+int pb_legodo_set_measurement_mode(pb_ctx *ctx, int mode, double r_xyz, double r_vang, double r_vang_uncertain);
 /* LegOdoHandler's "ignore the calculated velocity at launch" (state_estimator.legodo.zero_initial_velocity,
  * rbis_legodo_update.cpp:58,264-268), counted PER FILTER on the device: the counter is decremented by every message whose
  * status is valid for that filter (the reference returns NULL before the decrement otherwise, :243-255) and while it stays

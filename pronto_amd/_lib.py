@@ -88,6 +88,7 @@ _SIGS = {
                                           C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_void_p]),
     "pb_legodo_set_zero_initial_velocity": (C.c_int, [C.c_void_p, C.c_int]),
+    "pb_legodo_set_measurement_mode": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double]),
     "pb_step_legodo_joints": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, _dp, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                         C.c_double, C.c_double, C.c_void_p, C.c_void_p]),
     "pb_step_legodo_feet": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, _dp, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_double,
@@ -139,6 +140,8 @@ def load():
         pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in _SIGS.items():
+        if not hasattr(lib, name) and os.environ.get("PRONTO_BATCH_LIB"):
+            continue  # an older A/B build named by PRONTO_BATCH_LIB may lack the newest entry points (timing runs only)
         fn = getattr(lib, name)  # AttributeError if the .so does not export it
         fn.restype = res
         fn.argtypes = args

@@ -1767,8 +1767,8 @@ public:
       fprintf(stderr, "LegOdoHandler: %s\n", pb_last_error(est->ctx));
       exit(1);
     }
-    // per update: lo block [6][B] | increment [7][B] | status [B] | position [3][B] (doubles) | mask [B] | position status [B]
-    pool_ = std::make_shared<DevicePool>(est->ctx, est->ctx_alive, sizeof(double) * 17 * (size_t) B + 2 * (size_t) B);
+    // per update: the measurement block -- z and the diagonal of R, [6][B] (lin_rate) or [12][B] doubles -- and its mask(s) [2][B]
+    pool_ = std::make_shared<DevicePool>(est->ctx, est->ctx_alive, sizeof(double) * 12 * (size_t) B + 2 * (size_t) B);
     legodo_ready_ = true;
   }
   // fksolver_->JntToCart looks joints up by name (leg_estimate.cpp:432-436): resolve the chain's names against the message's
@@ -1885,20 +1885,31 @@ public:
       return nullptr;
     }
     auto block = std::make_shared<DeviceBlock>(pool_, blk);
-    double *d_lo = (double *) blk, *d_delta = d_lo + (size_t) 6 * B, *d_status = d_delta + (size_t) 7 * B, *d_pos = d_status + (size_t) B;
-    uint8_t *d_mask = (uint8_t *) (d_pos + (size_t) 3 * B), *d_pos_ok = d_mask + (size_t) B;
-    // (mode lin_rate consumes the measurement block and the mask only: the increment and the status are not written out)
-    const bool lin = lc->mode_ == LegOdoCommon::MODE_LIN_RATE, want_pos = lc->mode_ == LegOdoCommon::MODE_POSITION_AND_LIN_RATE;
+    double *d_lo = (double *) blk;
+    uint8_t *d_mask = (uint8_t *) (d_lo + (size_t) 6 * B);   // lin_rate: z [3][B] | R diagonal [3][B] | mask [B]
+    // LegOdoCommon::createMeasurement runs on the DEVICE for every mode (pb_legodo_set_measurement_mode): the increment, the status
+    // and the position never cross PCIe.  A foot-state message has no pelvis position: mode pos_and_lin_rate then is the
+    // reference's own fall-back to lin_rate (rbis_legodo_common.cpp:118-122) for every filter.
+    const int dmode = (lc->mode_ == LegOdoCommon::MODE_LIN_AND_ROT_RATE) ? 1 : ((lc->mode_ == LegOdoCommon::MODE_POSITION_AND_LIN_RATE && lm->kind == 1) ? 2 : 0);
+    if (dmode != device_meas_mode_) {
+      if (pb_legodo_set_measurement_mode(est->ctx, dmode, lc->R_legodo_xyz_, lc->R_legodo_vang_, lc->R_legodo_vang_uncertain_) != PB_OK) {
+        fprintf(stderr, "LegOdoHandler: %s\n", pb_last_error(est->ctx));
+        return nullptr;
+      }
+      device_meas_mode_ = dmode;
+    }
+    const bool lin = dmode == 0;
+    if (!lin) d_mask = (uint8_t *) (d_lo + (size_t) 12 * B);   // z [6][B] | R diagonal [6][B] | masks [2][B]
     // the measurement can be made later, inside the step kernel, when its inputs outlive this call
-    const bool defer = ahead != nullptr && one_kernel_pairs && lm->mem != PB_HOST;
+    const bool defer = lin && ahead != nullptr && one_kernel_pairs && lm->mem != PB_HOST;
     if (!defer) {
-      const int lrc = lm->odometry(est->ctx, ahead ? &ahead->imu_block : nullptr, lin ? nullptr : d_delta, lin ? nullptr : d_status, d_lo, d_mask,
-                                   want_pos ? d_pos : nullptr, want_pos ? d_pos_ok : nullptr);
+      const int lrc = lm->odometry(est->ctx, ahead ? &ahead->imu_block : nullptr, nullptr, nullptr, d_lo, d_mask, nullptr, nullptr);
       if (lrc != PB_OK) {
         fprintf(stderr, "LegOdoHandler: %s\n", pb_last_error(est->ctx));
         return nullptr;
       }
     }
+    prev_legodo_utime_ = utime;
     if (lin) {
       auto *u = new RBISIndexedMeasurement(RBIS::velocityInds(), BatchArray(d_lo, PB_DEVICE), d_lo + (size_t) 3 * B, PB_R_DIAG, d_mask,
                                            RBISUpdateInterface::legodo, utime);
@@ -1913,35 +1924,21 @@ public:
       }
       return u;
     }
-    // the other modes form their measurement on the host: fetch the increment, the status (and the position)
-    std::vector<double> delta((size_t) 7 * B), status((size_t) B), pos;
-    std::vector<float> fstatus((size_t) B);
-    std::vector<int> pos_status;
-    pb_memcpy_d2h(est->ctx, delta.data(), d_delta, sizeof(double) * 7 * B);
-    pb_memcpy_d2h(est->ctx, status.data(), d_status, sizeof(double) * B);
-    if (want_pos) {
-      std::vector<uint8_t> ok((size_t) B);
-      pos.resize((size_t) 3 * B);
-      pb_memcpy_d2h(est->ctx, pos.data(), d_pos, sizeof(double) * 3 * B);
-      pb_memcpy_d2h(est->ctx, ok.data(), d_pos_ok, (size_t) B);
-      pos_status.assign(ok.begin(), ok.end());
-    } else if (lc->mode_ == LegOdoCommon::MODE_POSITION_AND_LIN_RATE) {
-      pos_status.assign((size_t) B, 0);
+    std::vector<int> idx;
+    {
+      double unused[6];
+      lc->getCovariance(lc->mode_, true, unused, &idx);
     }
-    bool any_valid = false;
-    for (int b = 0; b < B; b++) {
-      fstatus[b] = (float) status[b];
-      any_valid = any_valid || fstatus[b] >= 0;
-    }
-    if (!any_valid) {  // "Leg Odometry is not valid not integrating" for every filter: return NULL (rbis_legodo_update.cpp:242-255)
-      prev_legodo_utime_ = utime;
-      return nullptr;
-    }
-    msgs::legodo_delta_t m2{ utime, prev_legodo_utime_, want_pos ? pos.data() : nullptr, delta.data(), delta.data() + (size_t) 3 * B,
-                             pos_status.empty() ? nullptr : pos_status.data(), fstatus.data() };
-    prev_legodo_utime_ = utime;
-    return leg_odo_common_->createMeasurement(&m2, B);
+    auto *full = new RBISIndexedMeasurement(idx, BatchArray(d_lo, PB_DEVICE), d_lo + (size_t) 6 * B, PB_R_DIAG, d_mask, RBISUpdateInterface::legodo, utime);
+    full->owned_dev = block;
+    if (dmode == 1) return full;
+    // pos_and_lin_rate: the filters whose position is not valid take the lin_rate update on the velocity rows of the same block
+    auto *fallback = new RBISIndexedMeasurement(RBIS::velocityInds(), BatchArray(d_lo + (size_t) 3 * B, PB_DEVICE), d_lo + (size_t) 9 * B, PB_R_DIAG,
+                                                d_mask + (size_t) B, RBISUpdateInterface::legodo, utime);
+    fallback->owned_dev = block;
+    return new RBISEitherUpdate(full, fallback);
   }
+  int device_meas_mode_ = 0;
   int64_t prev_legodo_utime_ = 0;
   // false: always make the measurement in the handler (k_legodo), then the fused step reads it -- round 2's two launches
   bool one_kernel_pairs = true;

@@ -32,6 +32,7 @@ struct pb_ctx {
   double *legd = nullptr;   // leg odometry state (pb_legodo_init): [NLD][stride] doubles ...
   int64_t *legi = nullptr;  // ... and [NLI][stride] 64-bit integers (rbis_legodo.hpp)
   LegPar leg_par;
+  LegMeasPar leg_meas;            // pb_legodo_set_measurement_mode: which of LegOdoCommon's measurements the odometry calls write
   LegChain *leg_chain = nullptr;  // forward-kinematics chain table (pb_legodo_set_chain), device copy ...
   LegChain leg_chain_h;           // ... and the host copy (PB_HOST_BROADCAST joint states are reduced to chain angles on the host)
   int leg_chain_rows = 0;         // rows a joint-position block must have (highest row the chain reads + 1)

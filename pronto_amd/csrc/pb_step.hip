@@ -46,19 +46,20 @@ template <int MH>
 static void launch_step_leg(pb_ctx *c, double *out, const double *imu, const double q[4], const StepBcast &bc, const LegIn &lin,
                             const LegStepArgs &la)
 {
-  // PRONTO_BATCH_LEGPLAN=0: round 3's division of the leg work between the waves of a tile (A/B runs; per-filter joint blocks only)
+  // (the division of the leg work between the waves and the number of panel rows requested ahead of the odometry are template
+  // parameters with measured defaults, rbis_legstep.hpp; -DPB_EXPERIMENTS builds the alternatives: PRONTO_BATCH_LEGPLAN / _LEGEARLY)
+#define LEG_ARGS c->st, out, c->B, imu, q[0], q[1], q[2], q[3], c->k, bc, c->leg_par, lin, c->leg_chain, la
+#ifdef PB_EXPERIMENTS
   static const int plan = getenv("PRONTO_BATCH_LEGPLAN") ? atoi(getenv("PRONTO_BATCH_LEGPLAN")) : -1;
-  if (c->ns == 15) {
-    if (plan == 0 && MH == MH_STORE_SC1)
-      k_step_leg<15, MH, 0><<<nblk(c->B), 128, 0, c->stream>>>(c->st, out, c->B, imu, q[0], q[1], q[2], q[3], c->k, bc, c->leg_par, lin, la);
-    else
-      k_step_leg<15, MH><<<nblk(c->B), 128, 0, c->stream>>>(c->st, out, c->B, imu, q[0], q[1], q[2], q[3], c->k, bc, c->leg_par, lin, la);
-  } else {
-    if (plan == 0 && MH == MH_STORE_SC1)
-      k_step_quad_leg<MH, 0><<<nblk(c->B), 256, 0, c->stream>>>(c->st, out, c->B, imu, q[0], q[1], q[2], q[3], c->k, bc, c->leg_par, lin, la);
-    else
-      k_step_quad_leg<MH><<<nblk(c->B), 256, 0, c->stream>>>(c->st, out, c->B, imu, q[0], q[1], q[2], q[3], c->k, bc, c->leg_par, lin, la);
-  }
+  static const int early = getenv("PRONTO_BATCH_LEGEARLY") ? atoi(getenv("PRONTO_BATCH_LEGEARLY")) : -1;
+  if (MH == MH_STORE_SC1 && c->ns == 15 && plan == 1) { k_step_leg<15, MH, 1, 0><<<nblk(c->B), 128, 0, c->stream>>>(LEG_ARGS); return; }
+  if (MH == MH_STORE_SC1 && c->ns == 15 && early == 0) { k_step_leg<15, MH, 0, 0><<<nblk(c->B), 128, 0, c->stream>>>(LEG_ARGS); return; }
+  if (MH == MH_STORE_SC1 && c->ns == 21 && plan == 0) { k_step_quad_leg<MH, 0><<<nblk(c->B), 256, 0, c->stream>>>(LEG_ARGS); return; }
+  if (MH == MH_STORE_SC1 && c->ns == 21 && early == 8) { k_step_quad_leg<MH, 2, 8><<<nblk(c->B), 256, 0, c->stream>>>(LEG_ARGS); return; }
+#endif
+  if (c->ns == 15) k_step_leg<15, MH><<<nblk(c->B), 128, 0, c->stream>>>(LEG_ARGS);
+  else k_step_quad_leg<MH><<<nblk(c->B), 256, 0, c->stream>>>(LEG_ARGS);
+#undef LEG_ARGS
 }
 
 int pbk_step_leg(pb_ctx *c, const double *imu, const StepBcast *bcast, const double q[4], const LegIn &lin, int64_t utime, double r2,

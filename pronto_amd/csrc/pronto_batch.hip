@@ -865,6 +865,7 @@ extern "C" int pb_legodo_init(pb_ctx *c, double lt, double ht, int64_t low_delay
   // a (re-)initialised context starts like leg_estimate's constructor: FootContactAlt, no controller input, no world
   // constraint, controller contact counts -1 (leg_estimate.cpp:93-142, rbis_legodo_update.cpp:100-101)
   c->leg_par = LegPar{};
+  c->leg_meas = LegMeasPar{};
   c->leg_nc_h[0] = c->leg_nc_h[1] = -1;
   c->leg_nc_dev = false;
   c->leg_par.alt = SchmittPar{ (double) (float) lt, (double) (float) ht, low_delay, high_delay };
@@ -883,6 +884,20 @@ extern "C" int pb_legodo_set_contact_mode(pb_ctx *c, int standing, double total_
   c->leg_par.total_force = (float) total_force;                        // float members (FootContact.h:24-28)
   c->leg_par.standing_schmitt_level = (float) standing_schmitt_level;
   c->leg_par.use_controller_input = use_controller_input ? 1 : 0;
+  return PB_OK;
+}
+
+extern "C" int pb_legodo_set_measurement_mode(pb_ctx *c, int mode, double r_xyz, double r_vang, double r_vang_uncertain)
+{
+  ENTER(c);
+  if (!c->legd) return fail(c, PB_ERR_STATE, "pb_legodo_set_measurement_mode before pb_legodo_init");
+  if (mode < 0 || mode > 2) return fail(c, PB_ERR_ARG, "pb_legodo_set_measurement_mode: mode 0 (lin_rate), 1 (lin_rot_rate) or 2 (pos_and_lin_rate)");
+  c->leg_meas = LegMeasPar{};
+  c->leg_meas.mode = mode;
+  c->leg_meas.r_xyz2 = r_xyz * r_xyz;                    // bot_sq (rbis_legodo_common.cpp:38-44)
+  c->leg_meas.r_a2 = r_vang * r_vang;
+  c->leg_meas.r_a2_uncertain = r_vang_uncertain * r_vang_uncertain;
+  if (mode == 2) c->leg_par.world_constraint = 1;        // the position it measures is leg_estimate's world constraint
   return PB_OK;
 }
 
@@ -1067,8 +1082,6 @@ static int leg_in_joints(pb_ctx *c, const char *who, int n_rows, const float *jp
   if (!jpos) return fail(c, PB_ERR_ARG, "%s: NULL input", who);
   if (n_rows < c->leg_chain_rows) return fail(c, PB_ERR_ARG, "%s: the chain reads joint row %d, the block has %d rows", who, c->leg_chain_rows - 1, n_rows);
   in.kind = 1;
-  in.chain = c->leg_chain;
-  in.chain_rec = &c->leg_chain->rec[0][0][0];
   if (mem == PB_HOST_BROADCAST) {
     // ONE robot's joint state for every filter of the batch: its two body-to-foot transforms are a per-MESSAGE quantity, the
     // same for all filters, so they are formed once, here, with the very leg_fk the kernels run per filter for per-filter
@@ -1122,14 +1135,18 @@ static int legodo_launch(pb_ctx *c, LegIn &in, const double *imu_block, int imu_
   if (c->leg_nc_dev) in.ncontacts = c->leg_nc;
   in.nc[0] = c->leg_nc_h[0];
   in.nc[1] = c->leg_nc_h[1];
-  const double r2 = r_vxyz * r_vxyz, r2u = r_vxyz_uncertain * r_vxyz_uncertain;  // bot_sq (rbis_legodo_common.cpp:40-43)
+  LegMeasPar mp = c->leg_meas;
+  mp.r_v2 = r_vxyz * r_vxyz;                            // bot_sq (rbis_legodo_common.cpp:40-43)
+  mp.r_v2_uncertain = r_vxyz_uncertain * r_vxyz_uncertain;
+  if (mp.mode == 2 && in.kind != 1)
+    return fail(c, PB_ERR_STATE, "measurement mode pos_and_lin_rate needs the joint-state entry points (the pelvis position comes from the world constraint)");
   // the world constraint (the transition foot's world position) is tracked from the first call that asks for the position
   if (pos_out != nullptr) c->leg_par.world_constraint = 1;
   if (c->ns == 15)
-    k_legodo<15><<<nblk(c->B), 64, 0, c->stream>>>(c->st, c->legd, c->legi, c->stride, c->B, utime, c->leg_par, in, ah, zero_delta, r2, r2u,
+    k_legodo<15><<<nblk(c->B), 64, 0, c->stream>>>(c->st, c->legd, c->legi, c->stride, c->B, utime, c->leg_par, in, c->leg_chain, ah, zero_delta, mp,
                                                    delta_out, status_out, lo_out, mask_out, pos_out, pos_ok_out, c->k);
   else
-    k_legodo<21><<<nblk(c->B), 64, 0, c->stream>>>(c->st, c->legd, c->legi, c->stride, c->B, utime, c->leg_par, in, ah, zero_delta, r2, r2u,
+    k_legodo<21><<<nblk(c->B), 64, 0, c->stream>>>(c->st, c->legd, c->legi, c->stride, c->B, utime, c->leg_par, in, c->leg_chain, ah, zero_delta, mp,
                                                    delta_out, status_out, lo_out, mask_out, pos_out, pos_ok_out, c->k);
   LAUNCHCHK(c);
   return PB_OK;
@@ -1229,11 +1246,14 @@ static int step_leg_impl(pb_ctx *c, LegIn &in, const double *imu_block, int imu_
   ah.bcast = bc.on & 1;
   memcpy(ah.v, bc.imu, sizeof(ah.v));
   ah.imu = d_imu;
+  LegMeasPar mp;  // (lin_rate: what the fused step consumes)
+  mp.r_v2 = r2;
+  mp.r_v2_uncertain = r2u;
   if (c->ns == 15)
-    k_legodo<15><<<nblk(c->B), 64, 0, c->stream>>>(c->st, c->legd, c->legi, c->stride, c->B, utime, c->leg_par, in, ah, 0, r2, r2u, nullptr,
+    k_legodo<15><<<nblk(c->B), 64, 0, c->stream>>>(c->st, c->legd, c->legi, c->stride, c->B, utime, c->leg_par, in, c->leg_chain, ah, 0, mp, nullptr,
                                                    nullptr, lo_out, mask_out, nullptr, nullptr, c->k);
   else
-    k_legodo<21><<<nblk(c->B), 64, 0, c->stream>>>(c->st, c->legd, c->legi, c->stride, c->B, utime, c->leg_par, in, ah, 0, r2, r2u, nullptr,
+    k_legodo<21><<<nblk(c->B), 64, 0, c->stream>>>(c->st, c->legd, c->legi, c->stride, c->B, utime, c->leg_par, in, c->leg_chain, ah, 0, mp, nullptr,
                                                    nullptr, lo_out, mask_out, nullptr, nullptr, c->k);
   LAUNCHCHK(c);
   return pbk_step(c, true, d_imu, lo_out, mask_out, q, &bc);
@@ -1288,7 +1308,7 @@ extern "C" int pb_legodo_fk(pb_ctx *c, int n_rows, const float *joint_position, 
   LegIn in;
   int rc = leg_in_joints(c, "pb_legodo_fk", n_rows, joint_position, joint_effort, nullptr, mem, in);
   if (rc) return rc;
-  k_leg_fk<<<nblk(c->B), 64, 0, c->stream>>>(in, c->B, feet_out);
+  k_leg_fk<<<nblk(c->B), 64, 0, c->stream>>>(in, c->leg_chain, c->B, feet_out);
   LAUNCHCHK(c);
   return PB_OK;
 }

@@ -680,6 +680,13 @@ __global__ __launch_bounds__(128, 1) void k_step_coop(const double *st, double *
 #pragma unroll
     for (int i = 0; i < 4; i++) cin.qm[i] = CORR::ORIENT ? (ca.zbc ? ca.qb2[i] : ldg(rq2, i * B8, bo)) : 0.0;
     cin.upd = (b < (unsigned) B) && (ca.mask2 == nullptr || ca.mask2[b] != 0);
+    // A stand-alone update that NO filter of this tile takes, working in place: nothing to load, nothing to store.  (Both waves
+    // of the tile read the same 64 mask bytes, so they leave together -- no barrier is left waiting.)  This is what makes the
+    // per-filter choice between two updates (RBISEitherUpdate: LegOdoCommon's pos_and_lin_rate / lin_rate fall-back) cost one
+    // state round trip, not two: the half no filter takes returns at once.
+    if constexpr (!PREDICT && !UPDATE) {
+      if (st == sto && ca.mask2 != nullptr && __ballot(cin.upd) == 0ull) return;
+    }
   }
   auto ld = [&io](int comp) { return io.ld(comp); };
   auto stf = [&io](int comp, double v) { io.st(comp, v); };
@@ -786,6 +793,8 @@ __global__ __launch_bounds__(256, 2) void k_update_quad(const double *st, double
   const unsigned b = tile * 64u + lane;
   const unsigned bo = b * 8u, B8 = (unsigned) B * 8u;
   TileIO<21, MemHint<MH>::LA, MemHint<MH>::SA> io(st, sto, tile, lane);
+  // an update that no filter of this tile takes, in place: all four waves see the same mask bytes and leave together (k_step_coop)
+  if (st == sto && ca.mask2 != nullptr && __ballot(b < (unsigned) B && ca.mask2[b < (unsigned) B ? b : 0u] != 0) == 0ull) return;
   auto inputs = [&](bool meas) {
     CorrInputs cin;
     const rsrc_t rz = mkbuf(ca.z2, (unsigned) CORR::M * B8);

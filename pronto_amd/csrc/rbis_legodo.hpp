@@ -687,14 +687,17 @@ struct LegIn {
   int kind = 0, bcast = 0;
   const double *feet = nullptr, *forces = nullptr;
   const float *jpos = nullptr, *jeff = nullptr, *jforces = nullptr;
-  const LegChain *chain = nullptr;
-  const double *chain_rec = nullptr;   // the records leg_fk reads: chain->rec, or the wave's LDS copy of it (leg_stage_chain)
   const int32_t *ncontacts = nullptr;  // controller contact counts [2][B] (device) or NULL: nc[] for every filter
   int nc[2] = { -1, -1 };              // (-1: no CONTROLLER_FOOT_CONTACT message yet, rbis_legodo_update.cpp:100-101)
   double v[16] = { 0 };
 };
 
-PB_HD void leg_inputs(const LegIn &in, long b, long B, Pose &bl, Pose &br, float &fl, float &fr, int &ncl, int &ncr)
+// chain: the table of pb_legodo_set_chain.  The kernels take it as a `const LegChain *__restrict__` KERNEL PARAMETER of its own
+// and read it with compile-time offsets: a read-only, no-alias, wave-uniform address, i.e. scalar loads whose results are SGPR
+// operands.  (Through a pointer inside a struct the same reads were per-lane vector loads; staged into LDS, flat loads with a
+// wait each; passed BY VALUE inside LegIn -- 1.5 KB of kernel arguments -- every launch of every kernel that takes a LegIn got
+// 6 us slower, measured on one box against the same code with the pointer: 24.4 -> 30.6 us for the 15-state foot-pose pair.)
+PB_HD void leg_inputs(const LegIn &in, const LegChain *chain, long b, long B, Pose &bl, Pose &br, float &fl, float &fr, int &ncl, int &ncr)
 {
   if (in.kind == 0) {
     if (in.bcast) {
@@ -711,7 +714,7 @@ PB_HD void leg_inputs(const LegIn &in, long b, long B, Pose &bl, Pose &br, float
       fl = (float) in.forces[b]; fr = (float) in.forces[B + b];
     }
   } else {
-    const LegChain &ch = *in.chain;
+    const LegChain &ch = *chain;
     double al[LEG_MAXJ], ar[LEG_MAXJ];
     if (in.jeff != nullptr) {  // (uniform) with the torque adjustment: positions and efforts of both chains requested together
       float pl[LEG_MAXJ], pr[LEG_MAXJ], el[LEG_MAXJ], er[LEG_MAXJ];
@@ -727,9 +730,8 @@ PB_HD void leg_inputs(const LegIn &in, long b, long B, Pose &bl, Pose &br, float
       leg_angles(ch, 1, [&](int j) { return (double) in.jpos[(long) ch.row[1][j] * B + b]; }, ar);
     }
     fl = in.jforces[b]; fr = in.jforces[B + b];
-    const double *rec = in.chain_rec;
-    leg_fk(ch, 0, al, [rec](int j, int f) { return rec[j * LEG_REC + f]; }, bl);
-    leg_fk(ch, 1, ar, [rec](int j, int f) { return rec[(LEG_MAXJ + j) * LEG_REC + f]; }, br);
+    leg_fk(ch, 0, al, [&ch](int j, int f) { return ch.rec[0][j][f]; }, bl);
+    leg_fk(ch, 1, ar, [&ch](int j, int f) { return ch.rec[1][j][f]; }, br);
   }
   if (in.ncontacts != nullptr) { ncl = in.ncontacts[b]; ncr = in.ncontacts[B + b]; }
   else { ncl = in.nc[0]; ncr = in.nc[1]; }
@@ -737,9 +739,9 @@ PB_HD void leg_inputs(const LegIn &in, long b, long B, Pose &bl, Pose &br, float
 
 // One leg's forward kinematics from per-filter joint blocks (kind 1), and the rest of the message (forces, controller
 // contacts) -- the pieces of leg_inputs for the kernels that give the two legs to two different waves of a tile
-PB_HD void leg_fk_side(const LegIn &in, int side, long b, long B, Pose &T)
+PB_HD void leg_fk_side(const LegIn &in, const LegChain *chain, int side, long b, long B, Pose &T)
 {
-  const LegChain &ch = *in.chain;
+  const LegChain &ch = *chain;
   double ang[LEG_MAXJ];
   if (in.jeff != nullptr) {
     float p[LEG_MAXJ], e[LEG_MAXJ];
@@ -752,8 +754,7 @@ PB_HD void leg_fk_side(const LegIn &in, int side, long b, long B, Pose &T)
   } else {
     leg_angles(ch, side, [&](int j) { return (double) in.jpos[(long) ch.row[side][j] * B + b]; }, ang);
   }
-  const double *rec = in.chain_rec;
-  leg_fk(ch, side, ang, [rec, side](int j, int f) { return rec[(side * LEG_MAXJ + j) * LEG_REC + f]; }, T);
+  leg_fk(ch, side, ang, [&ch, side](int j, int f) { return ch.rec[side][j][f]; }, T);
 }
 PB_HD void leg_inputs_rest(const LegIn &in, long b, long B, float &fl, float &fr, int &ncl, int &ncr)
 {
@@ -778,18 +779,56 @@ PB_HD void leg_measurement(const Pose &delta, double status, int64_t utime, int6
   m.valid = !(status < 0);
 }
 
-#if defined(__HIPCC__)
-// The joint records of the chain table into this WAVE's LDS area (2 * LEG_MAXJ * LEG_REC doubles), for leg_fk; only the
-// calling wave reads them, so a wave-level barrier orders the copy (LDS operations of one wave execute in order).
-__device__ __forceinline__ void leg_stage_chain(LegIn &in, double *lds, unsigned lane)
+// The same for LegOdoCommon's two six-row modes (rbis_legodo_common.cpp:131-165), formed where the increment is: in the
+// reference createMeasurement runs on the host right behind updateOdometry; a batch would have to copy the increment, the status
+// and the position of every filter over PCIe to do that.
+//   mode 1  lin_rot_rate      idx {3,4,5,0,1,2}    z = (v, rpy(delta rotation) / elapsed)   R = (r_vxyz^2 x3, r_vang^2 x3), both
+//                                                  "uncertain" values when status >= 0.5
+//   mode 2  pos_and_lin_rate  idx {9,10,11,3,4,5}  z = (pelvis position, v)                 R = (r_xyz^2 x3, r_vxyz^2 x3)
+//           per filter: position valid -> this update (valid6); else the reference falls back to lin_rate for this message
+//           (:118-122) -> the three-row update on rows 3..5 of the same block (valid3).  Exactly one of the two per valid filter.
+struct LegMeasPar {
+  int mode = 0;
+  double r_v2 = 0, r_v2_uncertain = 0, r_xyz2 = 0, r_a2 = 0, r_a2_uncertain = 0;
+};
+struct LegMeas6 {
+  double z[6], r[6];
+  bool valid6, valid3;
+};
+// bot_quat_to_roll_pitch_yaw (libbot, NOT IN TREE; the same formula as pronto_math.cpp:53-61 quat_to_euler)
+PB_HD void quat_to_rpy(const double (&q)[4], double (&rpy)[3])
 {
-  if (in.kind == 1) {  // uniform
-    const double *src = &in.chain->rec[0][0][0];
-    for (unsigned i = lane; i < 2u * LEG_MAXJ * LEG_REC; i += 64u) lds[i] = src[i];
-    __builtin_amdgcn_wave_barrier();
-    in.chain_rec = lds;
+  rpy[0] = atan2(2.0 * (q[0] * q[1] + q[2] * q[3]), 1.0 - 2.0 * (q[1] * q[1] + q[2] * q[2]));
+  rpy[1] = asin(2.0 * (q[0] * q[2] - q[3] * q[1]));
+  rpy[2] = atan2(2.0 * (q[0] * q[3] + q[1] * q[2]), 1.0 - 2.0 * (q[2] * q[2] + q[3] * q[3]));
+}
+PB_HD void leg_measurement6(const Pose &delta, double status, const double (&position)[3], bool position_ok, int64_t utime, int64_t prev_utime,
+                            const LegMeasPar &mp, LegMeas6 &m)
+{
+  const double elapsed = (double) (utime - prev_utime) * 1E-6;   // getDeltaAsVelocity (pronto_conversions_lcm.hpp:45)
+  const bool valid = !(status < 0), uncertain = status >= 0.5;
+  const double rv = uncertain ? mp.r_v2_uncertain : mp.r_v2;
+  double vel[3];
+#pragma unroll
+  for (int i = 0; i < 3; i++) vel[i] = delta.t[i] / elapsed;
+  if (mp.mode == 1) {  // (wave-uniform)
+    double rpy[3];
+    quat_to_rpy(delta.q, rpy);
+    const double el2 = ((double) utime - (double) prev_utime) / 1000000;   // (:143: its own elapsed_time)
+    const double ra = uncertain ? mp.r_a2_uncertain : mp.r_a2;
+#pragma unroll
+    for (int i = 0; i < 3; i++) { m.z[i] = vel[i]; m.z[3 + i] = rpy[i] / el2; m.r[i] = rv; m.r[3 + i] = ra; }
+    m.valid6 = valid;
+    m.valid3 = false;
+  } else {
+#pragma unroll
+    for (int i = 0; i < 3; i++) { m.z[i] = position[i]; m.z[3 + i] = vel[i]; m.r[i] = mp.r_xyz2; m.r[3 + i] = rv; }
+    m.valid6 = valid && position_ok;
+    m.valid3 = valid && !position_ok;
   }
 }
+
+#if defined(__HIPCC__)
 // One robot per lane: the odometry on its state, with the filter's own head orientation as world_to_body_ (setPoseBody,
 // rbis_legodo_update.cpp:214-229), then -- optionally -- the lin_rate measurement of it.
 // AHEAD: the odometry is slaved to the orientation the filter WILL have after the IMU step in `imu` / imu_bc
@@ -805,15 +844,13 @@ struct LegAhead {
 template <int NS>
 static __global__ __launch_bounds__(64, 2) void k_legodo(const double *__restrict__ st, double *__restrict__ legd,
                                                          int64_t *__restrict__ legi, long stride, int B, int64_t utime, LegPar par,
-                                                         LegIn in, LegAhead ah, int zero_delta, double r2, double r2_uncertain,
+                                                         LegIn in, const LegChain *__restrict__ chain, LegAhead ah, int zero_delta, LegMeasPar mp,
                                                          double *__restrict__ delta_out, double *__restrict__ status_out,
                                                          double *__restrict__ lo_out, uint8_t *__restrict__ mask_out,
                                                          double *__restrict__ pos_out, uint8_t *__restrict__ pos_ok_out, Consts k)
 {
   using L = Lay<NS>;
   using S = Slots<NS>;
-  __shared__ double chain_lds[2 * LEG_MAXJ * LEG_REC];
-  leg_stage_chain(in, chain_lds, threadIdx.x);
   const long b = (long) blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   LegState s;
@@ -848,7 +885,7 @@ static __global__ __launch_bounds__(64, 2) void k_legodo(const double *__restric
       ins_update_quat<NS>(chi, bg, wq, gyro, dt, k);
     }
   }
-  leg_inputs(in, b, B, bl, br, fl, fr, ncl, ncr);
+  leg_inputs(in, chain, b, B, bl, br, fl, fr, ncl, ncr);
   int64_t prev = 0;
   double position[3];
   bool position_ok;
@@ -868,27 +905,36 @@ static __global__ __launch_bounds__(64, 2) void k_legodo(const double *__restric
     for (int i = 0; i < 4; i++) delta_out[(long) (3 + i) * B + b] = delta.q[i];
   }
   if (status_out != nullptr) status_out[b] = status;
-  if (lo_out != nullptr) {
+  if (lo_out != nullptr && mp.mode == 0) {
     LegMeas m;
-    leg_measurement(delta, status, utime, prev, r2, r2_uncertain, m);
+    leg_measurement(delta, status, utime, prev, mp.r_v2, mp.r_v2_uncertain, m);
     for (int i = 0; i < 3; i++) {
       lo_out[(long) i * B + b] = m.z[i];
       lo_out[(long) (3 + i) * B + b] = m.r;
     }
     if (mask_out != nullptr) mask_out[b] = m.valid ? 1 : 0;
+  } else if (lo_out != nullptr) {  // the six-row modes: z [6][B] | R diagonal [6][B]; masks [B] (six rows) | [B] (mode 2's lin_rate fall-back)
+    LegMeas6 m;
+    leg_measurement6(delta, status, position, position_ok, utime, prev, mp, m);
+    for (int i = 0; i < 6; i++) {
+      lo_out[(long) i * B + b] = m.z[i];
+      lo_out[(long) (6 + i) * B + b] = m.r[i];
+    }
+    if (mask_out != nullptr) {
+      mask_out[b] = m.valid6 ? 1 : 0;
+      if (mp.mode == 2) mask_out[(long) B + b] = m.valid3 ? 1 : 0;
+    }
   }
 }
 // forward kinematics alone: feet_out [14][B] (diagnostics, tests)
-static __global__ __launch_bounds__(64) void k_leg_fk(LegIn in, int B, double *__restrict__ feet_out)
+static __global__ __launch_bounds__(64) void k_leg_fk(LegIn in, const LegChain *__restrict__ chain, int B, double *__restrict__ feet_out)
 {
-  __shared__ double chain_lds[2 * LEG_MAXJ * LEG_REC];
-  leg_stage_chain(in, chain_lds, threadIdx.x);
   const long b = (long) blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   Pose bl, br;
   float fl, fr;
   int ncl, ncr;
-  leg_inputs(in, b, B, bl, br, fl, fr, ncl, ncr);
+  leg_inputs(in, chain, b, B, bl, br, fl, fr, ncl, ncr);
   for (int i = 0; i < 3; i++) { feet_out[(long) i * B + b] = bl.t[i]; feet_out[(long) (7 + i) * B + b] = br.t[i]; }
   for (int i = 0; i < 4; i++) { feet_out[(long) (3 + i) * B + b] = bl.q[i]; feet_out[(long) (10 + i) * B + b] = br.q[i]; }
 }

@@ -37,15 +37,18 @@ struct LegStepArgs {
 //   0  role C: forward kinematics of the left leg | role P: right leg, then (barrier F) contact logic + pelvis integration
 //   1  role C: forward kinematics of BOTH legs (it waits for its 29 rows anyway) | role P: contact logic -- Schmitt triggers and the
 //      walking-phase classifier read the foot forces only -- in parallel, then (barrier F) the pelvis integration alone
-template <int NS, int MH, int PLAN = 1>
+// EARLY: panel rows role P requests BEFORE the odometry (the rest behind it): as many as the odometry's registers leave room for.
+// Measured at 64k filters with per-filter joint blocks (one box, min of 3 runs, `scripts/leg_ab.sh`): PLAN 0 / EARLY 0 27.3 us,
+// PLAN 0 / EARLY 12 26.6 us (foot poses 24.2 -> 23.9), EARLY 20 spills (37 us); PLAN 1 31.2 us -- role C is the wave whose rows
+// the memory system is busy with first, a second leg's kinematics in it delays everything behind barrier F.
+template <int NS, int MH, int PLAN = 0, int EARLY = 12>
 __global__ __launch_bounds__(128, 1) void k_step_leg(const double *st, double *sto, int B, const double *__restrict__ imu, double qg,
                                                      double qa, double qbg, double qba, Consts k, StepBcast bc, LegPar par, LegIn lin,
-                                                     LegStepArgs la)
+                                                     const LegChain *__restrict__ chain, LegStepArgs la)
 {
   using L = Lay<NS>;
   using CX = CoopX<NS, NoCorr>;
   __shared__ double xch[CX::NXCH_LEG][64];
-  __shared__ double chain_lds[2][2 * LEG_MAXJ * LEG_REC];  // one copy of the chain records per wave (no cross-wave ordering needed)
   const int role = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
   const unsigned lane = threadIdx.x & 63u;
   const unsigned tile = xcd_workgroup(k);
@@ -85,11 +88,10 @@ __global__ __launch_bounds__(128, 1) void k_step_leg(const double *st, double *s
   if (role == 0) {
     io.template need<0, Slots<NS>::ROW_SPLIT>();
     if (split_fk) {
-      leg_stage_chain(lin, chain_lds[0], lane);
 #pragma unroll
       for (int side = 0; side < (PLAN == 0 ? 1 : 2); side++) {
         Pose T;
-        leg_fk_side(lin, side, bl_, (long) B, T);
+        leg_fk_side(lin, chain, side, bl_, (long) B, T);
 #pragma unroll
         for (int i = 0; i < 3; i++) xch[CX::XCH_FOOT + 7 * side + i][lane] = T.t[i];
 #pragma unroll
@@ -100,7 +102,10 @@ __global__ __launch_bounds__(128, 1) void k_step_leg(const double *st, double *s
     coop_role_core<NS, true, NoCorr, true, true>(ld, stf, [lane](int s, double v) { xch[s][lane] = v; }, xrd, sync, in, k);
   } else {
     // ---- the odometry, on the prior state this role reads anyway ----
-    if (!split_fk || PLAN == 0) leg_stage_chain(lin, chain_lds[1], lane);
+    if constexpr (EARLY > 0) {
+      io.template need<Slots<NS>::ROW_SPLIT, Slots<NS>::ROW_SPLIT + EARLY>();
+      reload_fence();
+    }
     LegState s;
     leg_load(s, la.legd, la.legi, la.stride, (long) b, false);     // (the state arrays are padded to whole tiles)
     double chi[3], bg[3] = { 0.0, 0.0, 0.0 }, wq[4];
@@ -114,7 +119,7 @@ __global__ __launch_bounds__(128, 1) void k_step_leg(const double *st, double *s
     int64_t prev = 0;
     double classification;
     if (split_fk) {
-      if (PLAN == 0) leg_fk_side(lin, 1, bl_, (long) B, fr_);
+      if (PLAN == 0) leg_fk_side(lin, chain, 1, bl_, (long) B, fr_);
       leg_inputs_rest(lin, bl_, (long) B, zl, zr, ncl, ncr);
       if (PLAN != 0) cs = leg_contacts(s, par, la.utime, zl, zr, ncl, ncr, classification, prev);  // (needs no foot pose)
       __syncthreads();  // barrier F
@@ -131,7 +136,7 @@ __global__ __launch_bounds__(128, 1) void k_step_leg(const double *st, double *s
         cs = leg_contacts(s, par, la.utime, zl, zr, ncl, ncr, classification, prev);
       }
     } else {
-      leg_inputs(lin, bl_, (long) B, fl_, fr_, zl, zr, ncl, ncr);
+      leg_inputs(lin, chain, bl_, (long) B, fl_, fr_, zl, zr, ncl, ncr);
       cs = leg_contacts(s, par, la.utime, zl, zr, ncl, ncr, classification, prev);
     }
     ins_update_quat<NS>(chi, bg, wq, in.gyro, in.dt, k);           // world_to_body_ = the head AFTER this pair's IMU step
@@ -169,16 +174,17 @@ __global__ __launch_bounds__(128, 1) void k_step_leg(const double *st, double *s
 //   0  forward kinematics: left leg in role CC, right leg in role CB; role PW contact logic + integration behind barrier F
 //   2  forward kinematics: left leg in role CB, right leg in role PA (the lightest role; CC, the heaviest, does none); role PW
 //      runs the contact logic in parallel and only the pelvis integration behind barrier F
-template <int MH, int PLAN = 2>
+// Measured (same runs): PLAN 2 51.2-51.4 us in ONE kernel, PLAN 0 54.6 us, round 3's two launches 54.2-55.7 us; panel rows of role PW
+// requested ahead of the odometry (EARLY 8 / 16) change nothing (53.1 / 51.8 us).
+template <int MH, int PLAN = 2, int EARLY = 0>
 __global__ __launch_bounds__(256, 2) void k_step_quad_leg(const double *st, double *sto, int B, const double *__restrict__ imu, double qg,
                                                           double qa, double qbg, double qba, Consts k, StepBcast bc, LegPar par, LegIn lin,
-                                                          LegStepArgs la)
+                                                          const LegChain *__restrict__ chain, LegStepArgs la)
 {
   constexpr int NS = 21;
   using L = Lay<NS>;
   using SL = Slots<21>;
   __shared__ double xch[Quad::NXCH_LEG][64];
-  __shared__ double chain_lds[3][2 * LEG_MAXJ * LEG_REC];  // one copy of the chain records per wave that reads them
   const int role = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
   const unsigned lane = threadIdx.x & 63u;
   const unsigned tile = xcd_workgroup(k);
@@ -221,10 +227,9 @@ __global__ __launch_bounds__(256, 2) void k_step_quad_leg(const double *st, doub
   // on the way; barrier F hands both feet to role PW (all four waves take part in it)
   const bool split_fk = lin.kind == 1;  // wave-uniform
   const long bl_ = b < (unsigned) B ? (long) b : (long) B - 1;
-  auto fk_to_lds = [&](int side, double *lds) {
-    leg_stage_chain(lin, lds, lane);
+  auto fk_to_lds = [&](int side) {
     Pose T;
-    leg_fk_side(lin, side, bl_, (long) B, T);
+    leg_fk_side(lin, chain, side, bl_, (long) B, T);
 #pragma unroll
     for (int i = 0; i < 3; i++) xch[Quad::X_FOOT + 7 * side + i][lane] = T.t[i];
 #pragma unroll
@@ -234,18 +239,21 @@ __global__ __launch_bounds__(256, 2) void k_step_quad_leg(const double *st, doub
     const StepInputs in = inputs();
     io.template need<SL::QROW[0], SL::QROW[1]>();
     if (split_fk) {
-      if (PLAN == 0) fk_to_lds(0, chain_lds[0]);
+      if (PLAN == 0) fk_to_lds(0);
       __syncthreads();  // barrier F
     }
     quad_role_cc<true, true>(ld, stf, xwr, xrd, sync, in, k);
   } else if (role == 1) {
     const StepInputs in = inputs();
     io.template need<SL::QROW[1], SL::QROW[2]>();
-    if (split_fk) { fk_to_lds(PLAN == 0 ? 1 : 0, chain_lds[1]); __syncthreads(); }
+    if (split_fk) { fk_to_lds(PLAN == 0 ? 1 : 0); __syncthreads(); }
     quad_role_cb<true>(ld, stf, xwr, xrd, sync, in, k);
   } else if (role == 2) {
     StepInputs in = inputs();
-    leg_stage_chain(lin, chain_lds[2], lane);
+    if constexpr (EARLY > 0) {
+      io.template need<SL::QROW[2], SL::QROW[2] + EARLY>();
+      reload_fence();
+    }
     LegState s;
     leg_load(s, la.legd, la.legi, la.stride, (long) b, false);
     double chi[3], bg[3], wq[4];
@@ -268,7 +276,7 @@ __global__ __launch_bounds__(256, 2) void k_step_quad_leg(const double *st, doub
       for (int i = 0; i < 4; i++) { fl_.q[i] = xch[Quad::X_FOOT + 3 + i][lane]; fr_.q[i] = xch[Quad::X_FOOT + 10 + i][lane]; }
       if (PLAN == 0) cs = leg_contacts(s, par, la.utime, zl, zr, ncl, ncr, classification, prev);
     } else {
-      leg_inputs(lin, bl_, (long) B, fl_, fr_, zl, zr, ncl, ncr);
+      leg_inputs(lin, chain, bl_, (long) B, fl_, fr_, zl, zr, ncl, ncr);
       cs = leg_contacts(s, par, la.utime, zl, zr, ncl, ncr, classification, prev);
     }
     ins_update_quat<NS>(chi, bg, wq, in.gyro, in.dt, k);
@@ -300,7 +308,7 @@ __global__ __launch_bounds__(256, 2) void k_step_quad_leg(const double *st, doub
     const StepInputs in = inputs();
     io.template need<SL::QROW[3], SL::QROW[4]>();
     if (split_fk) {
-      if (PLAN != 0) fk_to_lds(1, chain_lds[0]);
+      if (PLAN != 0) fk_to_lds(1);
       __syncthreads();  // barrier F
     }
     quad_role_passive<true, 1>(ld, stf, xwr, xrd, sync, in, k);

@@ -17,6 +17,7 @@ from pronto_amd.synth import Workload  # noqa: E402
 
 dev = torch.device("cuda:0")
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+PAIRS_ONLY = len(sys.argv) > 2 and sys.argv[2] == "pairs"   # A/B runs of the pair kernels: skip the other rows
 
 
 def timeit(fn, reps=400):
@@ -58,21 +59,22 @@ for n in (15, 21):
         return lst[k[0] % len(lst)]
 
     rows = []
-    t = timeit(lambda: est.legodo_update(*nxt(fm), 0.1, 0.5, None, None, d_lo, d_mask, after_predict=imu))
-    rows.append(("k_legodo: foot poses -> measurement (after_predict)", t, leg + (n + 4) * 8 + 128 + 56 + 49))
-    t = timeit(lambda: (lambda m: est.legodo_update_joints(m[0], m[1], None, m[3], 0.1, 0.5, None, None, d_lo, d_mask, after_predict=imu))(nxt(jm)))
-    rows.append(("k_legodo: joint state -> FK -> measurement", t, leg + (n + 4) * 8 + 56 + 56 + 49))
-    t = timeit(lambda: (lambda m: est.legodo_update_joints(m[0], m[1], m[2], m[3], 0.1, 0.5, None, None, d_lo, d_mask, after_predict=imu))(nxt(jm)))
-    rows.append(("k_legodo: joint state + efforts (torque adjustment)", t, leg + (n + 4) * 8 + 104 + 56 + 49))
-    t = timeit(lambda: est.step_legodo(imu, d_lo, d_mask, q4))
-    rows.append(("fused step reading that measurement", t, 2 * st + 104))
+    if not PAIRS_ONLY:
+        t = timeit(lambda: est.legodo_update(*nxt(fm), 0.1, 0.5, None, None, d_lo, d_mask, after_predict=imu))
+        rows.append(("k_legodo: foot poses -> measurement (after_predict)", t, leg + (n + 4) * 8 + 128 + 56 + 49))
+        t = timeit(lambda: (lambda m: est.legodo_update_joints(m[0], m[1], None, m[3], 0.1, 0.5, None, None, d_lo, d_mask, after_predict=imu))(nxt(jm)))
+        rows.append(("k_legodo: joint state -> FK -> measurement", t, leg + (n + 4) * 8 + 56 + 56 + 49))
+        t = timeit(lambda: (lambda m: est.legodo_update_joints(m[0], m[1], m[2], m[3], 0.1, 0.5, None, None, d_lo, d_mask, after_predict=imu))(nxt(jm)))
+        rows.append(("k_legodo: joint state + efforts (torque adjustment)", t, leg + (n + 4) * 8 + 104 + 56 + 49))
+        t = timeit(lambda: est.step_legodo(imu, d_lo, d_mask, q4))
+        rows.append(("fused step reading that measurement", t, 2 * st + 104))
     t = timeit(lambda: (lambda m: est.step_legodo_feet(imu, q4, m[0], m[1], m[2], 0.1, 0.5))(nxt(fm)))
     rows.append(("pair in one call: IMU + foot poses", t, 2 * st + 56 + leg + 128))
     t = timeit(lambda: (lambda m: est.step_legodo_joints(imu, q4, m[0], m[1], None, m[3], 0.1, 0.5))(nxt(jm)))
     rows.append(("pair in one call: IMU + joint state", t, 2 * st + 56 + leg + 56))
     t = timeit(lambda: (lambda m: est.step_legodo_joints(imu, q4, m[0], m[1], m[2], m[3], 0.1, 0.5))(nxt(jm)))
     rows.append(("pair in one call: IMU + joint state + efforts", t, 2 * st + 56 + leg + 104))
-    if n == 15:
+    if n == 15 and not PAIRS_ONLY:
         # the joint filters in front of the kinematics (pb_joint_filter): 12 chain rows; low-pass = 13 window floats in + 1 out,
         # Kalman = 6 doubles in + 6 out, + the float in / out of each row
         d_f = torch.zeros((12, B), dtype=torch.float32, device=dev)
