@@ -230,6 +230,14 @@ int pb_legodo_update_after_predict(pb_ctx *ctx, const double *imu_block, int imu
  * no controller input, controller contact counts -1, no world constraint, all per-robot state reset. */
 int pb_legodo_set_contact_mode(pb_ctx *ctx, int standing, double total_force, double standing_schmitt_level,
                                int use_controller_input);
+/* Independent log segments (one recorded robot per filter; the reference's se-batch-process.sh runs such logs one after the
+ * other): every filter's message carries its OWN time stamp, and a filter whose segment has ended has none.  For the NEXT
+ * odometry / pair call only: utimes [B] (int64, may be NULL = the call's scalar utime for every filter) is what
+ * leg_estimate::updateOdometry takes as `utime` per filter (elapsed time of the increment, the 30 ms reset, the Schmitt-trigger
+ * clocks, foot_contact_classify's black-out windows); valid [B] (uint8, may be NULL = all) marks the filters that HAVE a message --
+ * the others keep their odometry state and get no measurement (mask 0).  mem: PB_HOST or PB_DEVICE.  (The joint Kalman filter of
+ * pb_joint_filter keeps one clock per context: with per-filter times use the low-pass filter or none.) */
+int pb_legodo_set_message_times(pb_ctx *ctx, const int64_t *utimes, const uint8_t *valid, int mem);
 /* Which of LegOdoCommon's measurements (state_estimator.legodo.mode, rbis_legodo_common.cpp:5-23,110-169) the odometry calls
  * pb_legodo_update / _after_predict / _joints write into lo_block_out / mask_out -- formed on the device, where the increment
  * is, so that no batch-sized array crosses PCIe to form it (the reference forms it on the host right behind updateOdometry):

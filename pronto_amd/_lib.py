@@ -88,6 +88,7 @@ _SIGS = {
                                           C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_void_p]),
     "pb_legodo_set_zero_initial_velocity": (C.c_int, [C.c_void_p, C.c_int]),
+    "pb_legodo_set_message_times": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "pb_legodo_set_measurement_mode": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double]),
     "pb_step_legodo_joints": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, _dp, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                         C.c_double, C.c_double, C.c_void_p, C.c_void_p]),

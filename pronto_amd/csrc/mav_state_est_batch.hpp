@@ -958,6 +958,8 @@ struct ins_t {               // bot_core::ins_t
   int64_t utime;
   BatchArray gyro, accel;    // [3][B] each, sensor frame
   BatchArray mag;            // [3][B] magnetometer, sensor frame; optional (p == NULL: zeros, like the Atlas path :274)
+  const uint8_t *valid = nullptr;  // [B] HOST, PB_HOST messages only (independent log segments, SegmentBatcher): 0 = this filter has
+                                   // no message -- its segment has ended -- and idles: its step is taken with dt = 0
 };
 struct kvh_raw_imu_t {       // the newest packet of bot_core::kvh_raw_imu_batch_t (atlas_filter == false path)
   int64_t utime;
@@ -984,6 +986,11 @@ struct joint_state_t {       // bot_core::joint_state_t: the arrays are float on
   const float *joint_velocity = nullptr;    // (only the joint Kalman filter reads it, leg_estimate.cpp:418-426)
   const float *joint_effort = nullptr;      // same shape as joint_position; read when legodo.torque_adjustment is set
   int mem = PB_HOST;                        // PB_DEVICE arrays must stay valid until the next message (see LegOdoHandler::forceTorqueDevice)
+  // independent log segments (one recorded robot per filter, SegmentBatcher): every filter's message has its OWN time stamp
+  // -- utimes [B], HOST; `utime` above then is the batch-level time that orders the update in the history -- and a filter whose
+  // segment has ended has no message at all: valid [B], HOST, 0 = none.  NULL = one time for all / all valid.
+  const int64_t *utimes = nullptr;
+  const uint8_t *valid = nullptr;
 };
 struct six_axis_force_torque_array_t {   // bot_core::six_axis_force_torque_array_t: what the leg odometry reads of it
   int64_t utime;
@@ -1001,6 +1008,7 @@ struct update_t {            // pronto::update_t (fovis)
 struct pose_t {              // bot_core::pose_t
   int64_t utime;
   BatchArray pos, vel, orientation;  // [3][B], [3][B], [4][B]
+  const uint8_t *valid = nullptr;    // [B] HOST, PB_HOST messages only: 0 = this filter has no message (independent log segments)
 };
 struct indexed_measurement_t {  // pronto::indexed_measurement_t
   int64_t utime;
@@ -1240,7 +1248,7 @@ public:
   // Microstrain path (sensor_handlers.cpp:96-131): rotate accel and gyro into the body frame, dt = param
   RBISUpdateInterface *processMessage(const msgs::ins_t *msg, MavStateEstimator *est)
   {
-    return build(msg->gyro, msg->accel, 1.0, false, dt, msg->utime, est->B);
+    return build(msg->gyro, msg->accel, 1.0, false, dt, msg->utime, est->B, msg->valid);
   }
   // Atlas KVH path without the notch (sensor_handlers.cpp:199-252): gyro = delta_rotation/raw_dt, accel through the
   // full ins_to_body transform (rotation + translation, :227), dt from message timestamps (:239-249)
@@ -1377,8 +1385,10 @@ public:
 private:
   BotParam *param_ = nullptr;
   bool init_params_read_ = false;
+  // valid [B] (per-filter host messages only): a filter without a message takes its step with dt = 0 -- with the sample it was
+  // handed (its own last one) that leaves its state and covariance where they are
   RBISUpdateInterface *build(BatchArray gyro, BatchArray accel, double gyro_scale, bool accel_translate, double dt_,
-                             int64_t utime, int B)
+                             int64_t utime, int B, const uint8_t *valid = nullptr)
   {
     if (gyro.mem == PB_DEVICE || accel.mem == PB_DEVICE || gyro.mem != accel.mem) {
       fprintf(stderr, "InsHandler: sensor-frame inputs must be host arrays (frame rotation is a host pass)\n");
@@ -1407,7 +1417,7 @@ private:
         blk[(size_t) i * B + b] = gb[i];
         blk[(size_t) (3 + i) * B + b] = ab[i];
       }
-      blk[(size_t) 6 * B + b] = dt_;
+      blk[(size_t) 6 * B + b] = (valid != nullptr && mem == PB_HOST && !valid[b]) ? 0.0 : dt_;
     }
     return new RBISIMUProcessStep(std::move(blk), cov_gyro, cov_accel, cov_gyro_bias, cov_accel_bias, utime, mem);
   }
@@ -1731,6 +1741,7 @@ public:
   int filter_joint_positions_ = 0;   // 0 none, 1 lowpass, 2 kalman (leg_estimate.cpp:43-61)
   double joint_process_noise_ = 0, joint_observation_noise_ = 0;
   std::shared_ptr<DevicePool> jf_pool_;   // filtered joint blocks [rows][B] floats (per-filter joint states)
+  std::shared_ptr<DevicePool> ff_pool_;   // foot forces [2][B] floats uploaded for device-resident joint blocks
   bool use_torque_adjustment_ = false;
   std::vector<std::string> adjustment_joints_;
   std::vector<float> adjustment_gain_;
@@ -1837,11 +1848,21 @@ public:
     std::vector<float> own_f;
     std::vector<double> own_d;
     std::shared_ptr<DeviceBlock> filtered;   // the joint filters' output block, when they run on the device
+    std::shared_ptr<DeviceBlock> forces_dev; // the foot forces of a host force/torque message uploaded next to a device joint block
+    std::vector<int64_t> own_ut;             // per-filter message times / validity (independent log segments), copied: the odometry
+    std::vector<uint8_t> own_valid;          // may run after the handler has returned
     double r = 0, ru = 0;
+    int times(pb_ctx *ctx) const
+    {
+      if (own_ut.empty() && own_valid.empty()) return PB_OK;
+      return pb_legodo_set_message_times(ctx, own_ut.empty() ? nullptr : own_ut.data(), own_valid.empty() ? nullptr : own_valid.data(), PB_HOST);
+    }
     // odometry alone (imu == NULL) or slaved to the state after `imu`; outputs as pb_legodo_update_joints
     int odometry(pb_ctx *ctx, const BatchArray *imu, double *o_delta, double *o_status, double *d_lo, uint8_t *d_mask, double *o_pos,
                  uint8_t *o_pos_ok) const
     {
+      const int trc = times(ctx);
+      if (trc != PB_OK) return trc;
       if (kind == 1)
         return pb_legodo_update_joints(ctx, imu ? imu->p : nullptr, imu ? imu->mem : PB_DEVICE, utime, rows, jp, je, ff, mem, 0, r, ru, o_delta,
                                        o_status, d_lo, d_mask, o_pos, o_pos_ok);
@@ -1852,6 +1873,8 @@ public:
     int pair(pb_ctx *ctx, const RBISIMUProcessStep *imu, double *d_lo, uint8_t *d_mask) const
     {
       const double q[4] = { imu->q_gyro, imu->q_accel, imu->q_gyro_bias, imu->q_accel_bias };
+      const int trc = times(ctx);
+      if (trc != PB_OK) return trc;
       if (kind == 1)
         return pb_step_legodo_joints(ctx, imu->imu_block.p, imu->imu_block.mem, q, utime, rows, jp, je, ff, mem, r, ru, d_lo, d_mask);
       return pb_step_legodo_feet(ctx, imu->imu_block.p, imu->imu_block.mem, q, utime, feet, forces, mem, r, ru, d_lo, d_mask);
@@ -1957,16 +1980,36 @@ public:
     if (!legodo_ready_) initLegEstimate(est);
     if (!chain_ready_ || msg->joint_name != chain_names_) initChain(msg, est);
     const float *forces = foot_force_dev_ ? foot_force_dev_ : foot_force_.data();
-    const int fmem = foot_force_dev_ ? PB_DEVICE : foot_force_mem_;
+    int fmem = foot_force_dev_ ? PB_DEVICE : foot_force_mem_;
+    auto lm = std::make_shared<LegMsg>();
+    if (fmem == PB_HOST && msg->mem == PB_DEVICE) {
+      // a device-resident joint block with the force/torque message still on the host (SegmentBatcher uploads the big blocks
+      // itself): the 2 x B floats follow the joints into HBM, in a block this message owns
+      if (!ff_pool_) ff_pool_ = std::make_shared<DevicePool>(est->ctx, est->ctx_alive, sizeof(float) * 2 * (size_t) est->B);
+      bool fresh = false;
+      void *blk = ff_pool_->get(fresh);
+      if (blk == nullptr || pb_memcpy_h2d(est->ctx, blk, forces, sizeof(float) * 2 * (size_t) est->B) != PB_OK) {
+        fprintf(stderr, "LegOdoHandler: %s\n", pb_last_error(est->ctx));
+        return nullptr;
+      }
+      lm->forces_dev = std::make_shared<DeviceBlock>(ff_pool_, blk);
+      forces = (const float *) blk;
+      fmem = PB_DEVICE;
+    }
     if (fmem != msg->mem) {
       fprintf(stderr, "LegOdoHandler: the joint state and the force/torque message must live in the same memory space\n");
       return nullptr;
     }
-    auto lm = std::make_shared<LegMsg>();
     lm->kind = 1;
     lm->mem = msg->mem;
     lm->rows = (int) msg->joint_name.size();
     lm->utime = msg->utime;
+    if (msg->utimes != nullptr) lm->own_ut.assign(msg->utimes, msg->utimes + est->B);
+    if (msg->valid != nullptr) lm->own_valid.assign(msg->valid, msg->valid + est->B);
+    if (msg->utimes != nullptr && filter_joint_positions_ == 2) {
+      fprintf(stderr, "LegOdoHandler: per-filter message times with filter_joint_positions = kalman are not supported (the joint Kalman filters keep one clock per batch)\n");
+      return nullptr;
+    }
     const float *eff = use_torque_adjustment_ ? msg->joint_effort : nullptr;
     if (filter_joint_positions_ != 0) {
       // leg_estimate.cpp:411-428, after the torque adjustment (rbis_legodo_update.cpp:231-241): pb_joint_filter does both, the
@@ -2139,10 +2182,10 @@ public:
   {
     const int B = est->B;
     if (mode == MODE_POSITION)
-      return makeIndexedMeasurement(RBIS::positionInds(), msg->pos, B, cov_scan_match, nullptr, RBISUpdateInterface::scan_matcher,
+      return makeIndexedMeasurement(RBIS::positionInds(), msg->pos, B, cov_scan_match, msg->valid, RBISUpdateInterface::scan_matcher,
                                     msg->utime);
     if (mode == MODE_VELOCITY)
-      return makeIndexedMeasurement(RBIS::velocityInds(), msg->vel, B, cov_scan_match, nullptr, RBISUpdateInterface::scan_matcher,
+      return makeIndexedMeasurement(RBIS::velocityInds(), msg->vel, B, cov_scan_match, msg->valid, RBISUpdateInterface::scan_matcher,
                                     msg->utime);
     const BatchArray src = (mode == MODE_POSITION_YAW) ? msg->pos : msg->vel;
     const int m = (int) z_indices.size();
@@ -2156,8 +2199,10 @@ public:
     if (mode != MODE_YAW) memcpy(z.data(), src.p, sizeof(double) * 3 * per);
     std::vector<double> q(msg->orientation.p, msg->orientation.p + 4 * per);
     std::vector<double> R(cov_scan_match);
+    std::vector<uint8_t> vmask;
+    if (msg->valid != nullptr && omem == PB_HOST) vmask.assign(msg->valid, msg->valid + B);
     auto *u = new RBISIndexedPlusOrientationMeasurement(z_indices, std::move(z), std::move(R), PB_R_DIAG_BROADCAST, std::move(q),
-                                                        std::vector<uint8_t>(), RBISUpdateInterface::scan_matcher, msg->utime);
+                                                        std::move(vmask), RBISUpdateInterface::scan_matcher, msg->utime);
     u->measurement.mem = u->orientation.mem = omem;
     return u;
   }

@@ -32,6 +32,9 @@ struct pb_ctx {
   double *legd = nullptr;   // leg odometry state (pb_legodo_init): [NLD][stride] doubles ...
   int64_t *legi = nullptr;  // ... and [NLI][stride] 64-bit integers (rbis_legodo.hpp)
   LegPar leg_par;
+  int64_t *leg_ut = nullptr;      // per-filter message times / validity of the NEXT odometry call (pb_legodo_set_message_times),
+  uint8_t *leg_valid = nullptr;   // device [B] each; consumed by that call
+  bool leg_ut_on = false, leg_valid_on = false;
   LegMeasPar leg_meas;            // pb_legodo_set_measurement_mode: which of LegOdoCommon's measurements the odometry calls write
   LegChain *leg_chain = nullptr;  // forward-kinematics chain table (pb_legodo_set_chain), device copy ...
   LegChain leg_chain_h;           // ... and the host copy (PB_HOST_BROADCAST joint states are reduced to chain angles on the host)

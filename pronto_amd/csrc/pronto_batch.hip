@@ -114,6 +114,8 @@ extern "C" int pb_destroy(pb_ctx *c)
   if (c->legd) (void) hipFree(c->legd);
   if (c->legi) (void) hipFree(c->legi);
   if (c->leg_chain) (void) hipFree(c->leg_chain);
+  if (c->leg_ut) (void) hipFree(c->leg_ut);
+  if (c->leg_valid) (void) hipFree(c->leg_valid);
   if (c->leg_nc) (void) hipFree(c->leg_nc);
   if (c->leg_lo) (void) hipFree(c->leg_lo);
   if (c->jf_ring) (void) hipFree(c->jf_ring);
@@ -887,6 +889,34 @@ extern "C" int pb_legodo_set_contact_mode(pb_ctx *c, int standing, double total_
   return PB_OK;
 }
 
+extern "C" int pb_legodo_set_message_times(pb_ctx *c, const int64_t *utimes, const uint8_t *valid, int mem)
+{
+  ENTER(c);
+  if (!c->legd) return fail(c, PB_ERR_STATE, "pb_legodo_set_message_times before pb_legodo_init");
+  if (mem != PB_HOST && mem != PB_DEVICE) return fail(c, PB_ERR_ARG, "pb_legodo_set_message_times: mem must be PB_HOST or PB_DEVICE");
+  const hipMemcpyKind kind = mem == PB_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+  c->leg_ut_on = c->leg_valid_on = false;
+  if (utimes) {
+    if (!c->leg_ut) HIPCHK(c, hipMalloc((void **) &c->leg_ut, sizeof(int64_t) * (size_t) c->stride));
+    HIPCHK(c, hipMemcpyAsync(c->leg_ut, utimes, sizeof(int64_t) * (size_t) c->B, kind, c->stream));
+    c->leg_ut_on = true;
+  }
+  if (valid) {
+    if (!c->leg_valid) HIPCHK(c, hipMalloc((void **) &c->leg_valid, (size_t) c->stride));
+    HIPCHK(c, hipMemcpyAsync(c->leg_valid, valid, (size_t) c->B, kind, c->stream));
+    c->leg_valid_on = true;
+  }
+  if (mem == PB_HOST && (utimes || valid)) HIPCHK(c, hipStreamSynchronize(c->stream));  // the caller's arrays are free again
+  return PB_OK;
+}
+// hands the one-shot per-filter times / validity to the launch that consumes them
+static void leg_take_message_times(pb_ctx *c, LegIn &in)
+{
+  if (c->leg_ut_on) in.utimes = c->leg_ut;
+  if (c->leg_valid_on) in.valid = c->leg_valid;
+  c->leg_ut_on = c->leg_valid_on = false;
+}
+
 extern "C" int pb_legodo_set_measurement_mode(pb_ctx *c, int mode, double r_xyz, double r_vang, double r_vang_uncertain)
 {
   ENTER(c);
@@ -1135,6 +1165,7 @@ static int legodo_launch(pb_ctx *c, LegIn &in, const double *imu_block, int imu_
   if (c->leg_nc_dev) in.ncontacts = c->leg_nc;
   in.nc[0] = c->leg_nc_h[0];
   in.nc[1] = c->leg_nc_h[1];
+  leg_take_message_times(c, in);
   LegMeasPar mp = c->leg_meas;
   mp.r_v2 = r_vxyz * r_vxyz;                            // bot_sq (rbis_legodo_common.cpp:40-43)
   mp.r_v2_uncertain = r_vxyz_uncertain * r_vxyz_uncertain;
@@ -1232,6 +1263,7 @@ static int step_leg_impl(pb_ctx *c, LegIn &in, const double *imu_block, int imu_
   if (c->leg_nc_dev) in.ncontacts = c->leg_nc;
   in.nc[0] = c->leg_nc_h[0];
   in.nc[1] = c->leg_nc_h[1];
+  leg_take_message_times(c, in);
   const double r2 = r_vxyz * r_vxyz, r2u = r_vxyz_uncertain * r_vxyz_uncertain;
   int rc = pbk_step_leg(c, d_imu, &bc, q, in, utime, r2, r2u, lo_out, mask_out);
   if (rc >= 0) return rc;

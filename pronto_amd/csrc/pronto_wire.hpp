@@ -41,6 +41,9 @@ public:
   void i32(int32_t v) { u32((uint32_t) v); }
   void u64(uint64_t v) { for (int s = 56; s >= 0; s -= 8) buf.push_back((uint8_t) (v >> s)); }
   void i64(int64_t v) { u64((uint64_t) v); }
+  void i16(int16_t v) { buf.push_back((uint8_t) ((uint16_t) v >> 8)); buf.push_back((uint8_t) ((uint16_t) v & 0xFF)); }
+  void f32(float v) { uint32_t u; memcpy(&u, &v, 4); u32(u); }
+  void str(const std::string &s) { i32((int32_t) s.size() + 1); bytes(s.data(), s.size()); u8(0); }  // LCM string: length incl. NUL
   void f64(double v) { uint64_t u; memcpy(&u, &v, 8); u64(u); }
   void f64s(const double *v, size_t n) { for (size_t i = 0; i < n; i++) f64(v[i]); }
   void bytes(const void *p, size_t n) { const uint8_t *b = (const uint8_t *) p; buf.insert(buf.end(), b, b + n); }

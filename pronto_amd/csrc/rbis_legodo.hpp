@@ -687,6 +687,11 @@ struct LegIn {
   int kind = 0, bcast = 0;
   const double *feet = nullptr, *forces = nullptr;
   const float *jpos = nullptr, *jeff = nullptr, *jforces = nullptr;
+  // independent log segments: every filter has its OWN message, with its own time stamp -- utimes [B] (device) replaces the
+  // call's scalar utime per filter -- and some filters may have none (their segment has ended): valid [B] (device), 0 = leave
+  // this robot's state alone and mask its measurement.  NULL = one time for all / all valid.
+  const int64_t *utimes = nullptr;
+  const uint8_t *valid = nullptr;
   const int32_t *ncontacts = nullptr;  // controller contact counts [2][B] (device) or NULL: nc[] for every filter
   int nc[2] = { -1, -1 };              // (-1: no CONTROLLER_FOOT_CONTACT message yet, rbis_legodo_update.cpp:100-101)
   double v[16] = { 0 };
@@ -886,12 +891,15 @@ static __global__ __launch_bounds__(64, 2) void k_legodo(const double *__restric
     }
   }
   leg_inputs(in, chain, b, B, bl, br, fl, fr, ncl, ncr);
+  if (in.utimes != nullptr) utime = in.utimes[b];                 // this filter's own message time (independent segments)
+  const bool msg_ok = in.valid == nullptr || in.valid[b] != 0;    // ... or no message at all for it
   int64_t prev = 0;
   double position[3];
   bool position_ok;
-  const double status = leg_update(s, par, utime, bl, br, fl, fr, ncl, ncr, wq, delta, prev, wpos, position, position_ok);
+  double status = leg_update(s, par, utime, bl, br, fl, fr, ncl, ncr, wq, delta, prev, wpos, position, position_ok);
   const bool zero = leg_zero_velocity(s, status) || zero_delta != 0;
-  leg_store(s, legd, legi, stride, b, par.world_constraint != 0);
+  if (msg_ok) leg_store(s, legd, legi, stride, b, par.world_constraint != 0);
+  else status = -1.0;
   if (zero) {  // odo_delta.setIdentity(); odo_position.setIdentity() (rbis_legodo_update.cpp:266-267)
     pose_identity(delta);
     position[0] = position[1] = position[2] = 0.0;

@@ -118,10 +118,12 @@ __global__ __launch_bounds__(128, 1) void k_step_leg(const double *st, double *s
     int ncl, ncr, cs;
     int64_t prev = 0;
     double classification;
+    const int64_t ut = lin.utimes != nullptr ? lin.utimes[bl_] : la.utime;     // independent segments: this filter's own message time
+    const bool msg_ok = lin.valid == nullptr || lin.valid[bl_] != 0;           // ... or no message for it at all
     if (split_fk) {
       if (PLAN == 0) leg_fk_side(lin, chain, 1, bl_, (long) B, fr_);
       leg_inputs_rest(lin, bl_, (long) B, zl, zr, ncl, ncr);
-      if (PLAN != 0) cs = leg_contacts(s, par, la.utime, zl, zr, ncl, ncr, classification, prev);  // (needs no foot pose)
+      if (PLAN != 0) cs = leg_contacts(s, par, ut, zl, zr, ncl, ncr, classification, prev);  // (needs no foot pose)
       __syncthreads();  // barrier F
 #pragma unroll
       for (int i = 0; i < 3; i++) fl_.t[i] = xch[CX::XCH_FOOT + i][lane];
@@ -133,21 +135,22 @@ __global__ __launch_bounds__(128, 1) void k_step_leg(const double *st, double *s
 #pragma unroll
         for (int i = 0; i < 4; i++) fr_.q[i] = xch[CX::XCH_FOOT + 10 + i][lane];
       } else {
-        cs = leg_contacts(s, par, la.utime, zl, zr, ncl, ncr, classification, prev);
+        cs = leg_contacts(s, par, ut, zl, zr, ncl, ncr, classification, prev);
       }
     } else {
       leg_inputs(lin, chain, bl_, (long) B, fl_, fr_, zl, zr, ncl, ncr);
-      cs = leg_contacts(s, par, la.utime, zl, zr, ncl, ncr, classification, prev);
+      cs = leg_contacts(s, par, ut, zl, zr, ncl, ncr, classification, prev);
     }
     ins_update_quat<NS>(chi, bg, wq, in.gyro, in.dt, k);           // world_to_body_ = the head AFTER this pair's IMU step
     const double wpos0[3] = { 0.0, 0.0, 0.0 };
     double position[3];
     bool position_ok;
-    const double status = leg_integrate(s, par, cs, classification, fl_, fr_, wq, delta, wpos0, position, position_ok);
+    double status = leg_integrate(s, par, cs, classification, fl_, fr_, wq, delta, wpos0, position, position_ok);
     if (leg_zero_velocity(s, status)) pose_identity(delta);
-    if (b < (unsigned) B) leg_store(s, la.legd, la.legi, la.stride, (long) b, false);
+    if (b < (unsigned) B && msg_ok) leg_store(s, la.legd, la.legi, la.stride, (long) b, false);
+    if (!msg_ok) status = -1.0;
     LegMeas m;
-    leg_measurement(delta, status, la.utime, prev, la.r2, la.r2_uncertain, m);
+    leg_measurement(delta, status, ut, prev, la.r2, la.r2_uncertain, m);
 #pragma unroll
     for (int i = 0; i < 3; i++) xch[CX::XCH_LEG + i][lane] = m.z[i];
     xch[CX::XCH_LEG + 3][lane] = m.r;
@@ -266,28 +269,31 @@ __global__ __launch_bounds__(256, 2) void k_step_quad_leg(const double *st, doub
     int ncl, ncr, cs;
     int64_t prev = 0;
     double classification;
+    const int64_t ut = lin.utimes != nullptr ? lin.utimes[bl_] : la.utime;     // independent segments: this filter's own message time
+    const bool msg_ok = lin.valid == nullptr || lin.valid[bl_] != 0;           // ... or no message for it at all
     if (split_fk) {
       leg_inputs_rest(lin, bl_, (long) B, zl, zr, ncl, ncr);
-      if (PLAN != 0) cs = leg_contacts(s, par, la.utime, zl, zr, ncl, ncr, classification, prev);  // (needs no foot pose)
+      if (PLAN != 0) cs = leg_contacts(s, par, ut, zl, zr, ncl, ncr, classification, prev);  // (needs no foot pose)
       __syncthreads();  // barrier F
 #pragma unroll
       for (int i = 0; i < 3; i++) { fl_.t[i] = xch[Quad::X_FOOT + i][lane]; fr_.t[i] = xch[Quad::X_FOOT + 7 + i][lane]; }
 #pragma unroll
       for (int i = 0; i < 4; i++) { fl_.q[i] = xch[Quad::X_FOOT + 3 + i][lane]; fr_.q[i] = xch[Quad::X_FOOT + 10 + i][lane]; }
-      if (PLAN == 0) cs = leg_contacts(s, par, la.utime, zl, zr, ncl, ncr, classification, prev);
+      if (PLAN == 0) cs = leg_contacts(s, par, ut, zl, zr, ncl, ncr, classification, prev);
     } else {
       leg_inputs(lin, chain, bl_, (long) B, fl_, fr_, zl, zr, ncl, ncr);
-      cs = leg_contacts(s, par, la.utime, zl, zr, ncl, ncr, classification, prev);
+      cs = leg_contacts(s, par, ut, zl, zr, ncl, ncr, classification, prev);
     }
     ins_update_quat<NS>(chi, bg, wq, in.gyro, in.dt, k);
     const double wpos0[3] = { 0.0, 0.0, 0.0 };
     double position[3];
     bool position_ok;
-    const double status = leg_integrate(s, par, cs, classification, fl_, fr_, wq, delta, wpos0, position, position_ok);
+    double status = leg_integrate(s, par, cs, classification, fl_, fr_, wq, delta, wpos0, position, position_ok);
     if (leg_zero_velocity(s, status)) pose_identity(delta);
-    if (b < (unsigned) B) leg_store(s, la.legd, la.legi, la.stride, (long) b, false);
+    if (b < (unsigned) B && msg_ok) leg_store(s, la.legd, la.legi, la.stride, (long) b, false);
+    if (!msg_ok) status = -1.0;
     LegMeas m;
-    leg_measurement(delta, status, la.utime, prev, la.r2, la.r2_uncertain, m);
+    leg_measurement(delta, status, ut, prev, la.r2, la.r2_uncertain, m);
 #pragma unroll
     for (int i = 0; i < 3; i++) xch[Quad::X_LEG + i][lane] = m.z[i];
     xch[Quad::X_LEG + 3][lane] = m.r;

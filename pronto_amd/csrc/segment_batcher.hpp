@@ -1,0 +1,448 @@
+// segment_batcher.hpp -- N independent log segments replayed as ONE batch: segment s feeds filter s.
+//
+// The reference's many-runs workload is a loop over recorded logs, one se-fusion process after the other
+// (motion_estimate/scripts/se-batch-process.sh:17-26,58-59,70-74), each opened as "file://<log>?speed=..&start_timestamp=<t>"
+// (state-estimator/src/mav_state_est/lcm_front_end.cpp:21-33: the log provider skips to the first event at or after t).  Here
+// the N runs share every kernel launch: the k-th message of a channel in each segment becomes column s of ONE batched message
+// ([rows][B] host blocks, filter index fastest) that is handed to the callback LCMFrontEnd::addSensor returns -- the same
+// handlers, the same estimator, B = N filters.  LogPlayer (mav_state_est_batch.hpp) is the other case: one log for every filter.
+//
+// Alignment.  Messages are aligned BY INDEX per channel, and the channels are dispatched in the file order of the LEAD segment
+// (the lowest-numbered segment that still has events).  That is exact for segments recorded by the same robot software -- the
+// same channels at the same rates in the same interleaving -- which is what a set of runs of one robot, or N start offsets into
+// one long log, are.  What is checked instead of assumed:
+//   * order_violations   a segment's own file order differs from the lead's (its k-th message of channel C was not the next
+//                        subscribed event in its log): the filter then sees its updates in the lead's order, not its own;
+//   * max_skew_us        largest difference between a segment's message time (relative to its first dispatched message) and the
+//                        lead's for the same batched message.
+// Time.  A batched message carries the LEAD's time, relative to the lead's first message, on the time base of the first segment (it
+// orders the update in the estimator's history and stays continuous when the lead changes).  Every filter's own time
+// stamp travels beside it where the arithmetic reads one: the leg odometry (msgs::joint_state_t::utimes -> per-filter elapsed
+// time, 30 ms reset, contact-classifier clocks: pb_legodo_set_message_times).  InsHandler::processMessage integrates with the
+// configured timestep_dt like the reference (sensor_handlers.cpp:96-131), so it needs none.
+// Ragged ends.  A segment that runs out of messages on a channel gets valid = 0 in that channel's batched messages from then on:
+// its measurements are masked and its IMU step is taken with dt = 0 on its own last sample.  The RESULT of a run is its head at the
+// end of ITS log: the moment a segment has no event left, its filter's head is read into finalState() / finalLogLikelihood()
+// (one pb_get_head per run of segments that end together: with equal-length segments one call for the whole batch).  The
+// filter idles in the batch afterwards; an idle step keeps pose, velocity, biases and covariance but re-derives the
+// angular-velocity / acceleration entries from its last sample, so the estimator's own head is NOT the result of a finished run.
+//
+// Host side only; every batched array lives in page-locked memory (pb_host_alloc) so that the library's double-buffered staging
+// copies run as DMA.  Decoding goes through the run-time .lcm schema (lcm_schema.hpp): the bot_core definitions are the caller's.
+#pragma once
+
+#include <deque>
+
+#include "mav_state_est_batch.hpp"
+
+namespace MavStateEst {
+
+class SegmentBatcher {
+public:
+  struct Stats {
+    int64_t batches = 0;            // batched messages dispatched
+    int64_t segment_messages = 0;   // per-segment messages they carried
+    int64_t ragged = 0;             // columns without a message (segment ended)
+    int64_t order_violations = 0, undecodable = 0, max_skew_us = 0;
+    std::map<std::string, int64_t> per_channel;
+  };
+  Stats stats;
+
+  explicit SegmentBatcher(MavStateEstimator *est)
+      : est_(est), B_(est->B), final_vec_((size_t) est->n * est->B, 0.0), final_quat_((size_t) 4 * est->B, 0.0),
+        final_cov_((size_t) est->n * est->n * est->B, 0.0), final_ll_((size_t) est->B, 0.0), final_utime_((size_t) est->B, 0),
+        finished_((size_t) est->B, 0) {}
+  ~SegmentBatcher()
+  {
+    est_->flushPending();   // (an update the estimator is holding back may still read the device blocks)
+    pb_sync(est_->ctx);
+    for (void *p : pinned_) pb_host_free(est_->ctx, p);
+    for (void *p : device_) pb_free(est_->ctx, p);
+  }
+  SegmentBatcher(const SegmentBatcher &) = delete;
+  SegmentBatcher &operator=(const SegmentBatcher &) = delete;
+
+  // segment s = filter s, in the order added; false: the file cannot be opened or the batch is full
+  bool addSegment(const std::string &path, int64_t start_timestamp = 0)
+  {
+    if ((int) segs_.size() >= B_) return false;
+    auto sg = std::unique_ptr<Seg>(new Seg(path, start_timestamp));
+    if (!sg->rd.good()) return false;
+    segs_.push_back(std::move(sg));
+    return true;
+  }
+  int segments() const { return (int) segs_.size(); }
+
+  // ---- typed subscriptions: channel -> the callback FrontEnd::addSensor returned ----
+  // bot_core::ins_t by field name (utime, gyro[3], accel[3]): InsHandler::processMessage
+  void subscribeIns(const std::string &channel, const pronto_wire::Schema *schema, const std::string &type,
+                    std::function<void(const msgs::ins_t *)> cb)
+  {
+    Chan c;
+    c.decode = [schema, type](const pronto_wire::LogEvent &ev, Rec &r) {
+      pronto_wire::Value v;
+      if (!schema->decode(type, ev.data.data(), ev.data.size(), v)) return false;
+      r.d.resize(6);
+      return v.integer("utime", r.utime) && v.numbers("gyro", r.d.data(), 3) && v.numbers("accel", r.d.data() + 3, 3);
+    };
+    double *blk = pinned<double>((size_t) 6 * B_);
+    uint8_t *valid = pinned<uint8_t>((size_t) B_);
+    auto last = std::make_shared<std::vector<double>>((size_t) 6 * B_, 0.0);
+    c.dispatch = [this, cb, blk, valid, last](const std::vector<const Rec *> &col, int64_t utime) {
+      for (int s = 0; s < B_; s++) {
+        valid[s] = col[(size_t) s] != nullptr;
+        for (int i = 0; i < 6; i++) {
+          if (col[(size_t) s]) (*last)[(size_t) i * B_ + s] = col[(size_t) s]->d[(size_t) i];
+          blk[(size_t) i * B_ + s] = (*last)[(size_t) i * B_ + s];   // (a filter without a message idles on its own last sample)
+        }
+      }
+      msgs::ins_t m{ utime, BatchArray(blk, PB_HOST), BatchArray(blk + (size_t) 3 * B_, PB_HOST) };
+      m.valid = valid;
+      cb(&m);
+    };
+    chans_[channel] = std::move(c);
+  }
+  // bot_core::joint_state_t (utime, joint_name[], joint_position[], joint_velocity[], joint_effort[]): LegOdoHandler::processMessage
+  void subscribeJointState(const std::string &channel, const pronto_wire::Schema *schema, const std::string &type,
+                           std::function<void(const msgs::joint_state_t *)> cb)
+  {
+    Chan c;
+    c.decode = [schema, type](const pronto_wire::LogEvent &ev, Rec &r) {
+      pronto_wire::Value v;
+      if (!schema->decode(type, ev.data.data(), ev.data.size(), v) || !v.integer("utime", r.utime)) return false;
+      const pronto_wire::Value *nm = v.get("joint_name"), *jp = v.get("joint_position"), *jv = v.get("joint_velocity"), *je = v.get("joint_effort");
+      if (!nm || !jp || !jv || !je || nm->kind != pronto_wire::Value::ARRAY) return false;
+      const size_t n = nm->items.size();
+      if (jp->items.size() != n || jv->items.size() != n || je->items.size() != n) return false;
+      r.names.resize(n);
+      r.f.resize(3 * n);
+      for (size_t j = 0; j < n; j++) {
+        r.names[j] = nm->items[j].s;
+        r.f[j] = (float) jp->items[j].number();
+        r.f[n + j] = (float) jv->items[j].number();
+        r.f[2 * n + j] = (float) je->items[j].number();
+      }
+      return true;
+    };
+    auto st = std::make_shared<JointBlocks>();
+    c.dispatch = [this, cb, st](const std::vector<const Rec *> &col, int64_t utime) {
+      const Rec *lead = nullptr;
+      for (const Rec *r : col)
+        if (r) { lead = r; break; }
+      if (lead == nullptr) return;
+      const size_t n = lead->names.size();
+      if (st->rows != n) {   // first message (or a new joint list): size the page-locked blocks
+        st->rows = n;
+        st->jp = pinned<float>(3 * n * (size_t) B_);
+        st->ut = pinned<int64_t>((size_t) B_);
+        st->valid = pinned<uint8_t>((size_t) B_);
+        std::fill_n(st->jp, 3 * n * (size_t) B_, 0.0f);
+        void *d = nullptr;
+        if (pb_malloc(est_->ctx, sizeof(float) * 3 * n * (size_t) B_, &d) != PB_OK) {
+          fprintf(stderr, "SegmentBatcher: %s\n", pb_last_error(est_->ctx));
+          exit(1);
+        }
+        st->d_jp = (float *) d;
+        device_.push_back(d);
+      }
+      float *jp = st->jp, *jv = jp + n * (size_t) B_, *je = jv + n * (size_t) B_;
+      for (int s = 0; s < B_; s++) {
+        const Rec *r = col[(size_t) s];
+        const bool ok = r != nullptr && r->names == lead->names;   // one robot model for the batch: the same joints in the same order
+        if (r != nullptr && !ok) stats.undecodable++;
+        st->valid[s] = ok;
+        st->ut[s] = ok ? r->utime : 0;
+        if (!ok) continue;                                         // (the block keeps this filter's last message; it is masked)
+        for (size_t j = 0; j < n; j++) {
+          jp[j * B_ + s] = r->f[j];
+          jv[j * B_ + s] = r->f[n + j];
+          je[j * B_ + s] = r->f[2 * n + j];
+        }
+      }
+      // The joint block goes to HBM here (one DMA from page-locked memory) and the handler gets a DEVICE message: with the IMU
+      // block coming from the host, the IMU + joint-state pair then runs as ONE kernel (pb_step_legodo_joints takes at most one
+      // of its two input groups from the host).  The previous message's pair kernel has been enqueued by now and the copy is
+      // stream-ordered behind it, so one device block is enough.
+      if (pb_memcpy_h2d(est_->ctx, st->d_jp, jp, sizeof(float) * 3 * n * (size_t) B_) != PB_OK) {
+        fprintf(stderr, "SegmentBatcher: %s\n", pb_last_error(est_->ctx));
+        return;
+      }
+      msgs::joint_state_t m;
+      m.utime = utime;
+      m.joint_name = lead->names;
+      m.joint_position = st->d_jp;
+      m.joint_velocity = st->d_jp + n * (size_t) B_;
+      m.joint_effort = st->d_jp + 2 * n * (size_t) B_;
+      m.mem = PB_DEVICE;
+      m.utimes = st->ut;
+      m.valid = st->valid;
+      cb(&m);
+    };
+    chans_[channel] = std::move(c);
+  }
+  // bot_core::six_axis_force_torque_array_t (sensors[].force[3]; sensors 0 / 1 = left / right foot): LegOdoHandler::forceTorqueHandler
+  void subscribeForceTorque(const std::string &channel, const pronto_wire::Schema *schema, const std::string &type,
+                            std::function<void(const msgs::six_axis_force_torque_array_t *)> cb)
+  {
+    Chan c;
+    c.decode = [schema, type](const pronto_wire::LogEvent &ev, Rec &r) {
+      pronto_wire::Value v;
+      if (!schema->decode(type, ev.data.data(), ev.data.size(), v) || !v.integer("utime", r.utime)) return false;
+      const pronto_wire::Value *sn = v.get("sensors");
+      if (!sn || sn->kind != pronto_wire::Value::ARRAY || sn->items.size() < 2) return false;
+      r.d.resize(2);
+      for (int k = 0; k < 2; k++) {
+        double f3[3];
+        if (!sn->items[(size_t) k].numbers("force", f3, 3)) return false;
+        r.d[(size_t) k] = f3[2];
+      }
+      return true;
+    };
+    double *fz = pinned<double>((size_t) 2 * B_);
+    std::fill_n(fz, (size_t) 2 * B_, 0.0);
+    c.dispatch = [this, cb, fz](const std::vector<const Rec *> &col, int64_t utime) {
+      for (int s = 0; s < B_; s++)
+        if (col[(size_t) s]) {   // (the handler keeps the LAST force/torque message, per filter: a missing one changes nothing)
+          fz[s] = col[(size_t) s]->d[0];
+          fz[(size_t) B_ + s] = col[(size_t) s]->d[1];
+        }
+      msgs::six_axis_force_torque_array_t m{ utime, BatchArray(fz, PB_HOST) };
+      cb(&m);
+    };
+    chans_[channel] = std::move(c);
+  }
+  // pronto::update_t (pronto_wire.hpp): FovisHandler::processMessage.  timestamp / prev_timestamp are the lead's.
+  void subscribeUpdate(const std::string &channel, std::function<void(const msgs::update_t *)> cb)
+  {
+    Chan c;
+    c.decode = [](const pronto_wire::LogEvent &ev, Rec &r) {
+      pronto_wire::update_t w;
+      if (w.decode(ev.data.data(), ev.data.size()) < 0) return false;
+      r.utime = w.timestamp;
+      r.aux = w.prev_timestamp;
+      r.flag = w.estimate_status == pronto_wire::update_t::ESTIMATE_VALID;
+      r.d.assign(w.translation, w.translation + 3);
+      r.d.insert(r.d.end(), w.rotation, w.rotation + 4);
+      return true;
+    };
+    double *blk = pinned<double>((size_t) 7 * B_);
+    uint8_t *valid = pinned<uint8_t>((size_t) B_);
+    c.dispatch = [this, cb, blk, valid](const std::vector<const Rec *> &col, int64_t utime) {
+      const Rec *lead = nullptr;
+      for (int s = 0; s < B_; s++) {
+        const Rec *r = col[(size_t) s];
+        if (r && !lead) lead = r;
+        valid[s] = r != nullptr && r->flag;
+        for (int i = 0; i < 7; i++) blk[(size_t) i * B_ + s] = r ? r->d[(size_t) i] : (i == 3 ? 1.0 : 0.0);
+      }
+      if (lead == nullptr) return;
+      // (prev_timestamp on the batch's time base, like timestamp)
+      msgs::update_t m{ utime, lead->aux + (utime - lead->utime), valid, BatchArray(blk, PB_HOST), BatchArray(blk + (size_t) 3 * B_, PB_HOST) };
+      cb(&m);
+    };
+    chans_[channel] = std::move(c);
+  }
+  // bot_core::pose_t (utime, pos[3], vel[3], orientation[4]): ScanMatcherHandler::processMessage
+  void subscribePose(const std::string &channel, const pronto_wire::Schema *schema, const std::string &type,
+                     std::function<void(const msgs::pose_t *)> cb)
+  {
+    Chan c;
+    c.decode = [schema, type](const pronto_wire::LogEvent &ev, Rec &r) {
+      pronto_wire::Value v;
+      if (!schema->decode(type, ev.data.data(), ev.data.size(), v)) return false;
+      r.d.resize(10);
+      return v.integer("utime", r.utime) && v.numbers("pos", r.d.data(), 3) && v.numbers("vel", r.d.data() + 3, 3) &&
+             v.numbers("orientation", r.d.data() + 6, 4);
+    };
+    double *blk = pinned<double>((size_t) 10 * B_);
+    uint8_t *valid = pinned<uint8_t>((size_t) B_);
+    c.dispatch = [this, cb, blk, valid](const std::vector<const Rec *> &col, int64_t utime) {
+      for (int s = 0; s < B_; s++) {
+        const Rec *r = col[(size_t) s];
+        valid[s] = r != nullptr;
+        for (int i = 0; i < 10; i++) blk[(size_t) i * B_ + s] = r ? r->d[(size_t) i] : (i == 6 ? 1.0 : 0.0);
+      }
+      msgs::pose_t m{ utime, BatchArray(blk, PB_HOST), BatchArray(blk + (size_t) 3 * B_, PB_HOST), BatchArray(blk + (size_t) 6 * B_, PB_HOST) };
+      m.valid = valid;
+      cb(&m);
+    };
+    chans_[channel] = std::move(c);
+  }
+
+  // Replays every segment to its end.  Returns the number of batched messages dispatched, or -1 when no segment was added.
+  int64_t run()
+  {
+    if (segs_.empty()) return -1;
+    std::vector<const Rec *> col((size_t) B_, nullptr);
+    std::vector<Rec> held((size_t) B_);
+    for (;;) {
+      // the lead: the first segment that still has a subscribed event; its next one names the channel of this batched message
+      int lead = -1;
+      std::string channel;
+      for (int s = 0; s < (int) segs_.size() && lead < 0; s++)
+        if (fill(*segs_[(size_t) s]) && !segs_[(size_t) s]->order.empty()) {
+          lead = s;
+          channel = segs_[(size_t) s]->order.front();
+        }
+      if (lead < 0) break;
+      Chan &ch = chans_[channel];
+      int64_t lead_rel = 0;
+      std::fill(col.begin(), col.end(), nullptr);
+      for (int s = lead; s < (int) segs_.size(); s++) {
+        Seg &sg = *segs_[(size_t) s];
+        if (!pull(sg, channel, held[(size_t) s])) {
+          stats.ragged++;
+          continue;
+        }
+        col[(size_t) s] = &held[(size_t) s];
+        if (sg.t0 == INT64_MIN) sg.t0 = held[(size_t) s].utime;
+        const int64_t rel = held[(size_t) s].utime - sg.t0;
+        if (s == lead) {
+          lead_rel = rel;
+          if (base_ == INT64_MIN) base_ = sg.t0;   // the batch's time base: the first lead's first message
+        } else {
+          stats.max_skew_us = std::max<int64_t>(stats.max_skew_us, std::llabs(rel - lead_rel));
+        }
+        stats.segment_messages++;
+      }
+      stats.ragged += lead;   // (the segments in front of the lead have ended)
+      // batch-level time of this message: the lead's, relative to ITS first message, on the batch's base -- it stays continuous when
+      // the lead changes (segments come from different recordings: their absolute times have nothing to do with each other)
+      ch.dispatch(col, base_ + lead_rel);
+      stats.batches++;
+      stats.per_channel[channel]++;
+      // segments whose log has no subscribed event left: their run is complete, keep its result
+      int first = -1;
+      for (int s = 0; s <= (int) segs_.size(); s++) {
+        const bool ended = s < (int) segs_.size() && !finished_[(size_t) s] && !fill(*segs_[(size_t) s]);
+        if (ended && first < 0) first = s;
+        if (!ended && first >= 0) {
+          finalize(first, s - first);
+          first = -1;
+        }
+      }
+    }
+    return stats.batches;
+  }
+
+  // the head of every segment's filter at the end of ITS log (valid after run(); columns of segments never added are zero)
+  void finalState(RBIS &state, RBIM &cov) const
+  {
+    state = RBIS(est_->n, B_);
+    cov = RBIM(est_->n, B_);
+    state.vec = final_vec_;
+    state.quat = final_quat_;
+    cov.m = final_cov_;
+  }
+  const std::vector<double> &finalLogLikelihood() const { return final_ll_; }
+  int64_t finalUtime(int s) const { return final_utime_[(size_t) s]; }   // batch-level time at which segment s ended
+
+private:
+  // one decoded message, in the compact form its channel's assembler reads
+  struct Rec {
+    int64_t utime = 0, aux = 0;
+    bool flag = false;
+    std::vector<double> d;
+    std::vector<float> f;
+    std::vector<std::string> names;
+  };
+  struct Chan {
+    std::function<bool(const pronto_wire::LogEvent &, Rec &)> decode;
+    std::function<void(const std::vector<const Rec *> &, int64_t)> dispatch;
+  };
+  struct JointBlocks {
+    size_t rows = 0;
+    float *jp = nullptr, *d_jp = nullptr;   // page-locked assembly block and its copy in HBM
+    int64_t *ut = nullptr;
+    uint8_t *valid = nullptr;
+  };
+  struct Seg {
+    pronto_wire::LogReader rd;
+    int64_t start_timestamp, t0 = INT64_MIN;
+    bool eof = false;
+    std::deque<std::string> order;                      // channels of the decoded, not yet consumed events, in file order
+    std::map<std::string, std::deque<Rec>> queue;       // ... and the events themselves, per channel
+    Seg(const std::string &path, int64_t start) : rd(path), start_timestamp(start) {}
+  };
+
+  // reads ahead in the segment's log until one subscribed event is waiting (false: the log has ended and nothing is waiting)
+  bool fill(Seg &sg)
+  {
+    while (sg.order.empty() && !sg.eof) read_one(sg);
+    return !sg.order.empty();
+  }
+  void read_one(Seg &sg)
+  {
+    pronto_wire::LogEvent ev;
+    if (!sg.rd.next(ev)) {
+      sg.eof = true;
+      return;
+    }
+    if (ev.timestamp < sg.start_timestamp) return;      // "?start_timestamp=": lcm_front_end.cpp:21-33
+    auto it = chans_.find(ev.channel);
+    if (it == chans_.end()) return;
+    Rec r;
+    if (!it->second.decode(ev, r)) {
+      stats.undecodable++;
+      return;
+    }
+    sg.order.push_back(ev.channel);
+    sg.queue[ev.channel].push_back(std::move(r));
+  }
+  // the segment's next message on `channel` (reading ahead past other channels' events if need be); false: none left
+  bool pull(Seg &sg, const std::string &channel, Rec &out)
+  {
+    std::deque<Rec> &q = sg.queue[channel];
+    while (q.empty() && !sg.eof) read_one(sg);
+    if (q.empty()) return false;
+    out = std::move(q.front());
+    q.pop_front();
+    auto it = std::find(sg.order.begin(), sg.order.end(), channel);
+    if (it != sg.order.begin()) stats.order_violations++;   // this segment's own log had something else first
+    sg.order.erase(it);
+    return true;
+  }
+  // the runs of segments [first, first + count) are complete: read their heads (applies whatever the estimator holds back first)
+  void finalize(int first, int count)
+  {
+    const int n = est_->n;
+    est_->flushPending();
+    std::vector<double> v((size_t) n * count), q((size_t) 4 * count), c((size_t) n * n * count), l((size_t) count);
+    if (pb_get_head(est_->ctx, first, count, v.data(), q.data(), c.data(), l.data(), PB_HOST) != PB_OK) {
+      fprintf(stderr, "SegmentBatcher: %s\n", pb_last_error(est_->ctx));
+      return;
+    }
+    for (int k = 0; k < count; k++) {
+      const size_t s = (size_t) (first + k);
+      for (int i = 0; i < n; i++) final_vec_[(size_t) i * B_ + s] = v[(size_t) i * count + k];
+      for (int i = 0; i < 4; i++) final_quat_[(size_t) i * B_ + s] = q[(size_t) i * count + k];
+      for (int i = 0; i < n * n; i++) final_cov_[(size_t) i * B_ + s] = c[(size_t) i * count + k];
+      final_ll_[s] = l[(size_t) k];
+      final_utime_[s] = est_->head_utime;
+      finished_[s] = 1;
+    }
+  }
+  template <class T>
+  T *pinned(size_t n)
+  {
+    void *p = nullptr;
+    if (pb_host_alloc(est_->ctx, sizeof(T) * (n ? n : 1), &p) != PB_OK) {
+      fprintf(stderr, "SegmentBatcher: %s\n", pb_last_error(est_->ctx));
+      exit(1);
+    }
+    pinned_.push_back(p);
+    return (T *) p;
+  }
+
+  MavStateEstimator *est_;
+  int B_;
+  int64_t base_ = INT64_MIN;
+  std::vector<double> final_vec_, final_quat_, final_cov_, final_ll_;
+  std::vector<int64_t> final_utime_;
+  std::vector<uint8_t> finished_;
+  std::vector<std::unique_ptr<Seg>> segs_;
+  std::map<std::string, Chan> chans_;
+  std::vector<void *> pinned_, device_;
+};
+
+}  // namespace MavStateEst

@@ -20,6 +20,7 @@ def build_exe(oracle, name="test_shim"):
     os.makedirs(os.path.dirname(exe), exist_ok=True)
     src = os.path.join(ROOT, "tests", "cpp", name + ".cpp")
     deps = [src, os.path.join(ROOT, "tests", "cpp", "test_n.hpp"), os.path.join(ROOT, "pronto_amd", "csrc", "mav_state_est_batch.hpp"),
+            os.path.join(ROOT, "pronto_amd", "csrc", "segment_batcher.hpp"),
             os.path.join(ROOT, "pronto_amd", "csrc", "pronto_wire.hpp"),
             os.path.join(ROOT, "include", "pronto_batch.h"), _lib.LIB_PATH]
     if os.path.exists(exe) and all(os.path.getmtime(exe) >= os.path.getmtime(d) for d in deps):
@@ -156,7 +157,7 @@ def test_legodo_modes_on_gpu(oracle, mode, slots, fuse, n):
 
 @pytest.mark.parametrize("name", ["test_shim", "test_history", "test_atlas_imu", "test_smooth_pass", "test_log_replay",
                                   "test_legodo_modes", "test_fovis_history", "test_fovis_replay",
-                                  "test_handler_modes", "test_leg_feet"])
+                                  "test_handler_modes", "test_leg_feet", "test_leg_joints", "test_segments"])
 def test_shim_compiles_and_links(oracle, name):
     exe = build_exe(oracle, name)
     out = subprocess.run(["ldd", exe], capture_output=True, text=True).stdout
@@ -270,4 +271,17 @@ def test_joint_state_handler_on_gpu(oracle, args, n):
     exe = build_exe(oracle, "test_leg_joints")
     r = subprocess.run([exe, *args] + NARG[n], capture_output=True, text=True, timeout=300)
     print(r.stdout[-2000:], r.stderr[-2000:])
+    assert r.returncode == 0 and "PASS" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,fuse", [(15, "fuse"), (21, "fuse"), (15, "nofuse")])
+def test_independent_log_segments_as_one_batch_on_gpu(oracle, tmp_path, n, fuse):
+    """SegmentBatcher: 64 DIFFERENT recorded segments (another gait, IMU stream, absolute time base, time-stamp jitter, length; some
+    opened at a start_timestamp) written with LogWriter and replayed as ONE batch through InsHandler / LegOdoHandler::processMessage
+    (joint states -> forward kinematics -> odometry, per-filter message times) / ScanMatcherHandler, against 64 single-segment
+    oracle runs -- the reference's se-batch-process.sh workload (one se-fusion run per log) as one batch."""
+    exe = build_exe(oracle, "test_segments")
+    r = subprocess.run([exe, str(tmp_path)] + ([fuse] if fuse == "nofuse" else []) + NARG[n], capture_output=True, text=True, timeout=600)
+    print(r.stdout[-3000:], r.stderr[-2000:])
     assert r.returncode == 0 and "PASS" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
