@@ -21,6 +21,7 @@
 // restated twice (here and in tests/lcm_ref.py) but has no known answer available in this image.
 #pragma once
 
+#include <algorithm>
 #include <cctype>
 #include <cstdint>
 #include <cstring>
@@ -184,8 +185,178 @@ public:
     return true;
   }
 
+  // ---- fast path for replays: a few named members out of a message, without the value tree ----
+  // A plan is compiled once per (type, wanted members) and run per message: it walks the encoding in member order, copies the
+  // wanted members into flat arrays and steps over everything else (fixed-size runs in one jump).  wanted[k]: a top-level member
+  // ("utime", "gyro", "joint_name"), or "array.member" for one member of every element of an array of structs
+  // ("sensors.force").  Numbers of any primitive type come out as doubles, strings as strings.
+  struct Extracted {
+    std::vector<double> num;
+    std::vector<std::string> str;
+  };
+  class Plan {
+  public:
+    bool ok() const { return root_ >= 0; }
+    // false: fingerprint mismatch, short or over-long message
+    bool run(const void *data, size_t len, std::vector<Extracted> &out) const
+    {
+      if (root_ < 0) return false;
+      out.resize(n_slots_);
+      for (Extracted &e : out) { e.num.clear(); e.str.clear(); }
+      Reader r(data, len);
+      if (r.u64() != fp_ || !r.ok) return false;
+      return walk(root_, r, out) && r.pos == len;
+    }
+  private:
+    friend class Schema;
+    enum Kind { I8, I16, I32, I64, F32, F64, STR, STRUCT };
+    struct Dim { int64_t n; int from; };              // constant length, or the value of integer member `from` of the same struct
+    struct Field { Kind kind; int slot, node; std::vector<Dim> dims; bool is_len; };
+    struct Node { std::vector<Field> f; int fixed_bytes; };   // fixed_bytes >= 0: no strings, no variable arrays, nothing wanted inside
+    std::vector<Node> nodes_;
+    int root_ = -1;
+    size_t n_slots_ = 0;
+    uint64_t fp_ = 0;
+    static int prim_size(Kind k) { return k == I8 ? 1 : k == I16 ? 2 : (k == I32 || k == F32) ? 4 : 8; }
+    bool walk(int ni, Reader &r, std::vector<Extracted> &out) const
+    {
+      const Node &nd = nodes_[(size_t) ni];
+      int64_t ints[16];
+      int n_ints = 0;
+      for (const Field &f : nd.f) {
+        int64_t count = 1;
+        for (const Dim &d : f.dims) count *= d.from >= 0 ? ints[d.from] : d.n;
+        if (count < 0 || (size_t) count > r.n - r.pos + 1) return false;
+        if (f.kind == STRUCT) {
+          const Node &sub = nodes_[(size_t) f.node];
+          if (sub.fixed_bytes >= 0) {
+            if (!r.need((size_t) count * (size_t) sub.fixed_bytes)) return false;
+            r.pos += (size_t) count * (size_t) sub.fixed_bytes;
+          } else {
+            for (int64_t k = 0; k < count; k++)
+              if (!walk(f.node, r, out)) return false;
+          }
+          continue;
+        }
+        if (f.kind == STR) {
+          for (int64_t k = 0; k < count; k++) {
+            const int32_t n = r.i32();
+            if (!r.ok || n < 1 || !r.need((size_t) n)) return false;
+            if (f.slot >= 0) out[(size_t) f.slot].str.emplace_back((const char *) r.p + r.pos, (size_t) n - 1);
+            r.pos += (size_t) n;
+          }
+          continue;
+        }
+        const int sz = prim_size(f.kind);
+        if (!r.need((size_t) count * (size_t) sz)) return false;
+        if (f.slot < 0 && !f.is_len) {
+          r.pos += (size_t) count * (size_t) sz;
+          continue;
+        }
+        for (int64_t k = 0; k < count; k++) {
+          double v = 0.0;
+          int64_t iv = 0;
+          switch (f.kind) {
+          case I8: iv = r.i8(); v = (double) iv; break;
+          case I16: iv = (int16_t) ((r.p[r.pos] << 8) | r.p[r.pos + 1]); r.pos += 2; v = (double) iv; break;
+          case I32: iv = r.i32(); v = (double) iv; break;
+          case I64: iv = r.i64(); v = (double) iv; break;
+          case F32: { const uint32_t u = r.u32(); float x; memcpy(&x, &u, 4); v = x; break; }
+          default: v = r.f64(); break;
+          }
+          if (f.slot >= 0) out[(size_t) f.slot].num.push_back(f.kind == I64 ? (double) iv : v);
+          if (f.is_len && n_ints < 16) ints[n_ints] = iv;
+        }
+        if (f.is_len) n_ints++;
+      }
+      return r.ok;
+    }
+  };
+  // (an int64 member comes out as a double: exact below 2^53 -- microsecond time stamps are)
+  Plan compile(const std::string &type, const std::vector<std::string> &wanted) const
+  {
+    Plan p;
+    const SchemaType *t = find(type);
+    if (t == nullptr) return p;
+    p.fp_ = fingerprint(type);
+    p.n_slots_ = wanted.size();
+    std::vector<bool> used(wanted.size(), false);
+    const int root = compile_node(*t, "", wanted, used, p, 0);
+    for (bool u : used)
+      if (!u) return p;                      // a wanted member does not exist
+    p.root_ = root;
+    return p;
+  }
+
 private:
   std::map<std::string, SchemaType> types_;
+
+  int compile_node(const SchemaType &t, const std::string &prefix, const std::vector<std::string> &wanted, std::vector<bool> &used, Plan &p,
+                   int depth) const
+  {
+    if (depth > 32) return -1;
+    const int me = (int) p.nodes_.size();
+    p.nodes_.emplace_back();
+    Plan::Node nd;
+    nd.fixed_bytes = 0;
+    std::vector<std::string> int_names;   // integer members other members take their lengths from, in order
+    for (const SchemaField &f : t.fields)
+      for (const SchemaDim &d : f.dims)
+        if (d.mode == LCM_VAR && std::find(int_names.begin(), int_names.end(), d.size) == int_names.end()) int_names.push_back(d.size);
+    // ints[] is filled in member order: index = position among the length members AS THEY APPEAR in the struct
+    std::vector<std::string> seen_len;
+    for (const SchemaField &f : t.fields) {
+      Plan::Field pf;
+      pf.slot = -1;
+      pf.node = -1;
+      pf.is_len = std::find(int_names.begin(), int_names.end(), f.name) != int_names.end();
+      const std::string path = prefix + f.name;
+      for (size_t k = 0; k < wanted.size(); k++)
+        if (wanted[k] == path) { pf.slot = (int) k; used[k] = true; }
+      bool variable = false;
+      for (const SchemaDim &d : f.dims) {
+        Plan::Dim pd{ 0, -1 };
+        if (d.mode == LCM_CONST) pd.n = atoll(d.size.c_str());
+        else {
+          const auto it = std::find(seen_len.begin(), seen_len.end(), d.size);
+          if (it == seen_len.end()) return -1;          // a length member must precede its array
+          pd.from = (int) (it - seen_len.begin());
+          variable = true;
+        }
+        pf.dims.push_back(pd);
+      }
+      if (is_primitive(f.type)) {
+        pf.kind = f.type == "double" ? Plan::F64 : f.type == "float" ? Plan::F32 : f.type == "int64_t" ? Plan::I64 : f.type == "int32_t" ? Plan::I32
+                  : f.type == "int16_t" ? Plan::I16 : f.type == "string" ? Plan::STR : Plan::I8;
+        if (pf.kind == Plan::STR || variable || pf.slot >= 0 || pf.is_len) nd.fixed_bytes = -1;
+        else if (nd.fixed_bytes >= 0) {
+          int64_t c = 1;
+          for (const Plan::Dim &d : pf.dims) c *= d.n;
+          nd.fixed_bytes += (int) c * Plan::prim_size(pf.kind);
+        }
+      } else {
+        const SchemaType *nested = resolve(t, f.type);
+        if (nested == nullptr) return -1;
+        pf.kind = Plan::STRUCT;
+        pf.node = compile_node(*nested, path + ".", wanted, used, p, depth + 1);
+        if (pf.node < 0) return -1;
+        const int sub = p.nodes_[(size_t) pf.node].fixed_bytes;
+        if (sub < 0 || variable) nd.fixed_bytes = -1;
+        else if (nd.fixed_bytes >= 0) {
+          int64_t c = 1;
+          for (const Plan::Dim &d : pf.dims) c *= d.n;
+          nd.fixed_bytes += (int) c * sub;
+        }
+      }
+      if (pf.is_len) {
+        if (seen_len.size() >= 16) return -1;
+        seen_len.push_back(f.name);
+      }
+      nd.f.push_back(pf);
+    }
+    p.nodes_[(size_t) me] = std::move(nd);
+    return me;
+  }
 
   static bool fail(std::string *err, const std::string &what)
   {

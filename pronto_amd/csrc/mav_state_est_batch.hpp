@@ -41,7 +41,19 @@
 // The handlers' per-filter host loops (frame rotation, velocity from deltas ...) are independent per filter: compile the
 // host program with -fopenmp and they run on all cores; without it the pragma disappears.
 #ifdef _OPENMP
-#define PB_SHIM_PARALLEL_FOR _Pragma("omp parallel for schedule(static)")
+#include <omp.h>
+// At most PRONTO_SHIM_THREADS host threads (default 16: the CPU share a one-GPU job gets on a shared box, whatever the machine's
+// core count says -- a team of 128 spinning threads on a 16-CPU quota is slower than one thread by orders of magnitude).
+static inline int pb_shim_threads()
+{
+  static const int n = [] {
+    const char *e = getenv("PRONTO_SHIM_THREADS");
+    const int want = e ? atoi(e) : 16;
+    return std::max(1, std::min(want, omp_get_max_threads()));
+  }();
+  return n;
+}
+#define PB_SHIM_PARALLEL_FOR _Pragma("omp parallel for schedule(static) num_threads(pb_shim_threads())")
 #else
 #define PB_SHIM_PARALLEL_FOR
 #endif

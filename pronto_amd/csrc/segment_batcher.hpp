@@ -79,11 +79,15 @@ public:
                     std::function<void(const msgs::ins_t *)> cb)
   {
     Chan c;
-    c.decode = [schema, type](const pronto_wire::LogEvent &ev, Rec &r) {
-      pronto_wire::Value v;
-      if (!schema->decode(type, ev.data.data(), ev.data.size(), v)) return false;
-      r.d.resize(6);
-      return v.integer("utime", r.utime) && v.numbers("gyro", r.d.data(), 3) && v.numbers("accel", r.d.data() + 3, 3);
+    auto plan = std::make_shared<pronto_wire::Schema::Plan>(schema->compile(type, { "utime", "gyro", "accel" }));
+    if (!plan->ok()) fprintf(stderr, "SegmentBatcher: %s has no utime / gyro / accel members\n", type.c_str());
+    c.decode = [plan](const pronto_wire::LogEvent &ev, Rec &r) {
+      static thread_local std::vector<pronto_wire::Schema::Extracted> x;
+      if (!plan->run(ev.data.data(), ev.data.size(), x) || x[0].num.size() != 1 || x[1].num.size() != 3 || x[2].num.size() != 3) return false;
+      r.utime = (int64_t) x[0].num[0];
+      r.d.assign(x[1].num.begin(), x[1].num.end());
+      r.d.insert(r.d.end(), x[2].num.begin(), x[2].num.end());
+      return true;
     };
     double *blk = pinned<double>((size_t) 6 * B_);
     uint8_t *valid = pinned<uint8_t>((size_t) B_);
@@ -107,20 +111,21 @@ public:
                            std::function<void(const msgs::joint_state_t *)> cb)
   {
     Chan c;
-    c.decode = [schema, type](const pronto_wire::LogEvent &ev, Rec &r) {
-      pronto_wire::Value v;
-      if (!schema->decode(type, ev.data.data(), ev.data.size(), v) || !v.integer("utime", r.utime)) return false;
-      const pronto_wire::Value *nm = v.get("joint_name"), *jp = v.get("joint_position"), *jv = v.get("joint_velocity"), *je = v.get("joint_effort");
-      if (!nm || !jp || !jv || !je || nm->kind != pronto_wire::Value::ARRAY) return false;
-      const size_t n = nm->items.size();
-      if (jp->items.size() != n || jv->items.size() != n || je->items.size() != n) return false;
-      r.names.resize(n);
+    auto plan = std::make_shared<pronto_wire::Schema::Plan>(
+        schema->compile(type, { "utime", "joint_name", "joint_position", "joint_velocity", "joint_effort" }));
+    if (!plan->ok()) fprintf(stderr, "SegmentBatcher: %s is not a joint_state_t\n", type.c_str());
+    c.decode = [plan](const pronto_wire::LogEvent &ev, Rec &r) {
+      static thread_local std::vector<pronto_wire::Schema::Extracted> x;
+      if (!plan->run(ev.data.data(), ev.data.size(), x) || x[0].num.size() != 1) return false;
+      const size_t n = x[1].str.size();
+      if (x[2].num.size() != n || x[3].num.size() != n || x[4].num.size() != n) return false;
+      r.utime = (int64_t) x[0].num[0];
+      r.names = x[1].str;
       r.f.resize(3 * n);
       for (size_t j = 0; j < n; j++) {
-        r.names[j] = nm->items[j].s;
-        r.f[j] = (float) jp->items[j].number();
-        r.f[n + j] = (float) jv->items[j].number();
-        r.f[2 * n + j] = (float) je->items[j].number();
+        r.f[j] = (float) x[2].num[j];
+        r.f[n + j] = (float) x[3].num[j];
+        r.f[2 * n + j] = (float) x[4].num[j];
       }
       return true;
     };
@@ -185,17 +190,13 @@ public:
                             std::function<void(const msgs::six_axis_force_torque_array_t *)> cb)
   {
     Chan c;
-    c.decode = [schema, type](const pronto_wire::LogEvent &ev, Rec &r) {
-      pronto_wire::Value v;
-      if (!schema->decode(type, ev.data.data(), ev.data.size(), v) || !v.integer("utime", r.utime)) return false;
-      const pronto_wire::Value *sn = v.get("sensors");
-      if (!sn || sn->kind != pronto_wire::Value::ARRAY || sn->items.size() < 2) return false;
-      r.d.resize(2);
-      for (int k = 0; k < 2; k++) {
-        double f3[3];
-        if (!sn->items[(size_t) k].numbers("force", f3, 3)) return false;
-        r.d[(size_t) k] = f3[2];
-      }
+    auto plan = std::make_shared<pronto_wire::Schema::Plan>(schema->compile(type, { "utime", "sensors.force" }));
+    if (!plan->ok()) fprintf(stderr, "SegmentBatcher: %s is not a six_axis_force_torque_array_t\n", type.c_str());
+    c.decode = [plan](const pronto_wire::LogEvent &ev, Rec &r) {
+      static thread_local std::vector<pronto_wire::Schema::Extracted> x;
+      if (!plan->run(ev.data.data(), ev.data.size(), x) || x[0].num.size() != 1 || x[1].num.size() < 6) return false;
+      r.utime = (int64_t) x[0].num[0];
+      r.d = { x[1].num[2], x[1].num[5] };   // sensors[0].force[2], sensors[1].force[2]
       return true;
     };
     double *fz = pinned<double>((size_t) 2 * B_);
@@ -247,12 +248,17 @@ public:
                      std::function<void(const msgs::pose_t *)> cb)
   {
     Chan c;
-    c.decode = [schema, type](const pronto_wire::LogEvent &ev, Rec &r) {
-      pronto_wire::Value v;
-      if (!schema->decode(type, ev.data.data(), ev.data.size(), v)) return false;
-      r.d.resize(10);
-      return v.integer("utime", r.utime) && v.numbers("pos", r.d.data(), 3) && v.numbers("vel", r.d.data() + 3, 3) &&
-             v.numbers("orientation", r.d.data() + 6, 4);
+    auto plan = std::make_shared<pronto_wire::Schema::Plan>(schema->compile(type, { "utime", "pos", "vel", "orientation" }));
+    if (!plan->ok()) fprintf(stderr, "SegmentBatcher: %s is not a pose_t\n", type.c_str());
+    c.decode = [plan](const pronto_wire::LogEvent &ev, Rec &r) {
+      static thread_local std::vector<pronto_wire::Schema::Extracted> x;
+      if (!plan->run(ev.data.data(), ev.data.size(), x) || x[0].num.size() != 1 || x[1].num.size() != 3 || x[2].num.size() != 3 || x[3].num.size() != 4)
+        return false;
+      r.utime = (int64_t) x[0].num[0];
+      r.d.assign(x[1].num.begin(), x[1].num.end());
+      r.d.insert(r.d.end(), x[2].num.begin(), x[2].num.end());
+      r.d.insert(r.d.end(), x[3].num.begin(), x[3].num.end());
+      return true;
     };
     double *blk = pinned<double>((size_t) 10 * B_);
     uint8_t *valid = pinned<uint8_t>((size_t) B_);
@@ -288,9 +294,13 @@ public:
       Chan &ch = chans_[channel];
       int64_t lead_rel = 0;
       std::fill(col.begin(), col.end(), nullptr);
-      for (int s = lead; s < (int) segs_.size(); s++) {
+      const int nseg = (int) segs_.size();
+      // every segment reads and decodes its own log: independent work, one host thread per range of segments (-fopenmp)
+      PB_SHIM_PARALLEL_FOR
+      for (int s = lead; s < nseg; s++) got_[(size_t) s] = pull(*segs_[(size_t) s], channel, held[(size_t) s]);
+      for (int s = lead; s < nseg; s++) {
         Seg &sg = *segs_[(size_t) s];
-        if (!pull(sg, channel, held[(size_t) s])) {
+        if (!got_[(size_t) s]) {
           stats.ragged++;
           continue;
         }
@@ -311,16 +321,24 @@ public:
       ch.dispatch(col, base_ + lead_rel);
       stats.batches++;
       stats.per_channel[channel]++;
-      // segments whose log has no subscribed event left: their run is complete, keep its result
+      // segments whose log has no subscribed event left: their run is complete, keep its result.  (fill() is also the read-ahead
+      // of the next message: in parallel over the segments)
+      PB_SHIM_PARALLEL_FOR
+      for (int s = 0; s < nseg; s++) got_[(size_t) s] = finished_[(size_t) s] || fill(*segs_[(size_t) s]);
       int first = -1;
-      for (int s = 0; s <= (int) segs_.size(); s++) {
-        const bool ended = s < (int) segs_.size() && !finished_[(size_t) s] && !fill(*segs_[(size_t) s]);
+      for (int s = 0; s <= nseg; s++) {
+        const bool ended = s < nseg && !finished_[(size_t) s] && !got_[(size_t) s];
         if (ended && first < 0) first = s;
         if (!ended && first >= 0) {
           finalize(first, s - first);
           first = -1;
         }
       }
+    }
+    for (const auto &sg : segs_) {
+      stats.undecodable += sg->undecodable;
+      stats.order_violations += sg->order_violations;
+      sg->undecodable = sg->order_violations = 0;
     }
     return stats.batches;
   }
@@ -362,6 +380,7 @@ private:
     bool eof = false;
     std::deque<std::string> order;                      // channels of the decoded, not yet consumed events, in file order
     std::map<std::string, std::deque<Rec>> queue;       // ... and the events themselves, per channel
+    int64_t undecodable = 0, order_violations = 0;      // (per segment: the segments are read by different host threads)
     Seg(const std::string &path, int64_t start) : rd(path), start_timestamp(start) {}
   };
 
@@ -383,7 +402,7 @@ private:
     if (it == chans_.end()) return;
     Rec r;
     if (!it->second.decode(ev, r)) {
-      stats.undecodable++;
+      sg.undecodable++;
       return;
     }
     sg.order.push_back(ev.channel);
@@ -398,7 +417,7 @@ private:
     out = std::move(q.front());
     q.pop_front();
     auto it = std::find(sg.order.begin(), sg.order.end(), channel);
-    if (it != sg.order.begin()) stats.order_violations++;   // this segment's own log had something else first
+    if (it != sg.order.begin()) sg.order_violations++;      // this segment's own log had something else first
     sg.order.erase(it);
     return true;
   }
@@ -440,6 +459,7 @@ private:
   std::vector<double> final_vec_, final_quat_, final_cov_, final_ll_;
   std::vector<int64_t> final_utime_;
   std::vector<uint8_t> finished_;
+  std::vector<uint8_t> got_ = std::vector<uint8_t>((size_t) B_, 0);
   std::vector<std::unique_ptr<Seg>> segs_;
   std::map<std::string, Chan> chans_;
   std::vector<void *> pinned_, device_;

@@ -11,6 +11,7 @@
 //   * every filter must equal the ORACLE run of ITS OWN log alone (po_imu_process_step, po_torque_adjust -> po_fk ->
 //     po_leg_update_wc on the oracle filter's own pose with the log's own time stamps -> po_indexed_update), <= 1e-9.
 // argv: "n21" = 21 states, "nofuse" = without fuse_ins_legodo, a directory for the logs.  Exit code 0 + "PASS".  Needs a GPU.
+#include <chrono>
 #include <cinttypes>
 #include <cstdio>
 #include <string>
@@ -70,9 +71,17 @@ int main(int argc, char **argv)
   std::string dir = "/tmp";
   for (int i = 1; i < argc; i++) {
     if (std::string(argv[i]) == "nofuse") fuse = false;
-    else dir = argv[i];
+    else if (argv[i][0] == '/') dir = argv[i];
   }
-  const int B = 64, T = 420, NJ = 16;
+  // "rate <segments> <ticks>": no oracle, time the replay (segments x messages per second, PCIe and log decoding included)
+  int rate_B = 0, rate_T = 0;
+  for (int i = 1; i + 2 < argc; i++)
+    if (std::string(argv[i]) == "rate") {
+      rate_B = atoi(argv[i + 1]);
+      rate_T = atoi(argv[i + 2]);
+    }
+  const bool rate = rate_B > 0;
+  const int B = rate ? rate_B : 64, T = rate ? rate_T : 420, NJ = 16;
   double g;
   po_get_constants(&g, nullptr);
   pronto_wire::Schema schema;
@@ -86,7 +95,7 @@ int main(int argc, char **argv)
   std::vector<int64_t> start_ts((size_t) B, 0);
   std::vector<std::string> paths((size_t) B);
   for (int s = 0; s < B; s++) {
-    const int Ts = T - (s % 5) * 17;                       // ragged ends
+    const int Ts = rate ? T : T - (s % 5) * 17;            // ragged ends
     const int64_t base = 1000000000LL * (s + 1) + 12345 * s;   // another absolute time base per recording
     const double period = 0.9 + 0.4 * urand(), phase = urand(), swing = 0.15 + 0.2 * urand();
     paths[(size_t) s] = dir + "/segment_" + std::to_string(s) + ".lcmlog";
@@ -255,8 +264,20 @@ int main(int argc, char **argv)
                                [&](const msgs::six_axis_force_torque_array_t *m) { legodo_handler.forceTorqueHandler(m, B); });
     batch.subscribeJointState("JOINT_STATE", &schema, "bot_core.joint_state_t", front_end.addSensor("legodo", &LegOdoHandler::processMessage, &legodo_handler));
     batch.subscribePose("POSE_SCAN", &schema, "bot_core.pose_t", front_end.addSensor("scan_matcher", &ScanMatcherHandler::processMessage, &sm_handler));
+    const auto t0 = std::chrono::steady_clock::now();
     const int64_t nb = batch.run();
+    pb_sync(est.ctx);
+    const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     st = batch.stats;
+    if (rate) {
+      printf("segment batch rate: %d segments x %d ticks (IMU + force/torque + joint state per tick, pose every 20th), n=%d, %s: %.2f s -> "
+             "%.3g segment-messages/s, %.3g filter-steps/s (log decoding through the run-time schema, page-locked assembly, PCIe and "
+             "kernels all inside), %lld batched messages, fused pairs %lld, status %d\n",
+             B, T, n, fuse ? "fused pairs" : "unfused", sec, st.segment_messages / sec, (double) B * T / sec, (long long) st.batches,
+             (long long) est.fused_pairs, est.last_status);
+      for (int s2 = 0; s2 < B; s2++) remove(paths[(size_t) s2].c_str());
+      return est.last_status == PB_OK ? 0 : 1;
+    }
     if (nb != st.batches) { printf("FAIL: run() returned %lld\n", (long long) nb); return 1; }
     batch.finalState(head, cov);           // every run's result: its filter's head at the end of ITS log
     ll = batch.finalLogLikelihood();

@@ -25,7 +25,7 @@ def build_exe(oracle, name="test_shim"):
             os.path.join(ROOT, "include", "pronto_batch.h"), _lib.LIB_PATH]
     if os.path.exists(exe) and all(os.path.getmtime(exe) >= os.path.getmtime(d) for d in deps):
         return exe
-    cmd = ["g++", "-O1", "-std=c++17", "-Wall", "-Werror=return-type", "-o", exe, src,
+    cmd = ["g++", "-O1", "-std=c++17", "-fopenmp", "-Wall", "-Werror=return-type", "-o", exe, src,
            "-L" + os.path.dirname(_lib.LIB_PATH), "-lpronto_batch", "-L" + os.path.join(ROOT, "oracle", "build"),
            "-lpronto_oracle", "-L/opt/rocm/lib", "-Wl,-rpath," + os.path.dirname(_lib.LIB_PATH),
            "-Wl,-rpath," + os.path.join(ROOT, "oracle", "build"), "-Wl,-rpath,/opt/rocm/lib"]
