@@ -173,6 +173,17 @@ int pb_run_legodo(pb_ctx *ctx, int n_steps, const double *imu_stream, const doub
 int pb_replay_legodo_fused(pb_ctx *ctx, int n_steps, int steps_per_launch, const double *imu_stream,
                            const double *lo_stream, const uint8_t *mask_stream, const double q[4], float *elapsed_ms);
 
+/* The same replay as a forward pass that KEEPS EVERY POSTERIOR -- what the reference's history does by value
+ * (mav_state_est.cpp:50-70) and what EKFSmoothBackwardsPass reads (:98-189): the posterior of step t is also written into
+ * checkpoint slot first_slot + t (pb_history_reserve; first_slot + n_steps <= slots), while the state stays in registers.
+ * Per step one slot is written and nothing is read back (the per-message path with pb_set_output_slot reads the previous
+ * slot and writes the next one).  Slots are bit-identical to what pb_set_output_slot + pb_step_legodo leave.  The head
+ * afterwards is the context's own array (= the last slot's content).  Accounting: (S_x + S_P + 8) + 104 + 2 (S_x + S_P + 8) / T
+ * bytes per filter-step -- its own, never the headline metric. */
+int pb_replay_legodo_checkpointed(pb_ctx *ctx, int n_steps, int steps_per_launch, const double *imu_stream,
+                                  const double *lo_stream, const uint8_t *mask_stream, const double q[4], int first_slot,
+                                  float *elapsed_ms);
+
 /* ---- history look-up used by FovisHandler (rbis_fovis_update.cpp:184-223) ------------------------------ */
 
 /* remember the head posterior's (position, quat) in `slot` (the reference finds it again by

@@ -71,6 +71,8 @@ _SIGS = {
     "pb_run_legodo": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, _dp, C.POINTER(C.c_float)]),
     "pb_replay_legodo_fused": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, _dp,
                                          C.POINTER(C.c_float)]),
+    "pb_replay_legodo_checkpointed": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, _dp, C.c_int,
+                                                C.POINTER(C.c_float)]),
     "pb_snapshot": (C.c_int, [C.c_void_p, C.c_int]),
     "pb_compose_delta": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "pb_set_process_noise_block": (C.c_int, [C.c_void_p, C.c_void_p]),

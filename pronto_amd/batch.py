@@ -410,6 +410,20 @@ class BatchEstimator:
         self._chk(self._L.pb_replay_legodo_fused(self._h, T, steps_per_launch, pi, pl, pm, q, C.byref(ms) if timed else None))
         return ms.value if timed else None
 
+    def replay_legodo_checkpointed(self, imu_stream, lo_stream, mask_stream, q4, steps_per_launch, first_slot=0, timed=False):
+        """The time-fused replay as a forward pass that keeps every posterior: step t also lands in checkpoint slot first_slot + t
+        (history_reserve first), the state stays in registers -- pb_replay_legodo_checkpointed."""
+        T = imu_stream.shape[0]
+        pi, m1 = _ptr(imu_stream, shape=(T, 7, self.B))
+        pl, m2 = _ptr(lo_stream, shape=(T, 6, self.B))
+        pm, m3 = _ptr(mask_stream, np.uint8, shape=(T, self.B))
+        if _same_mem(m1, m2, m3) != PB_DEVICE:
+            raise ValueError("replay_legodo_checkpointed needs device-resident streams")
+        q = (C.c_double * 4)(*q4)
+        ms = C.c_float(0)
+        self._chk(self._L.pb_replay_legodo_checkpointed(self._h, T, steps_per_launch, pi, pl, pm, q, int(first_slot), C.byref(ms) if timed else None))
+        return ms.value if timed else None
+
     # --- fovis history ---
     def snapshot(self, slot=0):
         self._chk(self._L.pb_snapshot(self._h, slot))

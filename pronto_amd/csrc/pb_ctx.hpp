@@ -125,7 +125,8 @@ int pbk_step(pb_ctx *c, bool update, const double *imu, const double *lo, const 
 // pb_legodo_update* ahead of pbk_step instead)
 int pbk_step_leg(pb_ctx *c, const double *imu, const StepBcast *bcast, const double q[4], const LegIn &lin, int64_t utime, double r2,
                  double r2_uncertain, double *lo_out, uint8_t *mask_out);
-int pbk_replay_fused(pb_ctx *c, int T, const double *imu, const double *lo, const uint8_t *mask, const double q[4]);
+// slot0 >= 0: write-through -- the posterior of step t also goes to checkpoint slot slot0 + t (pb_replay_legodo_checkpointed)
+int pbk_replay_fused(pb_ctx *c, int T, const double *imu, const double *lo, const uint8_t *mask, const double q[4], int slot0 = -1);
 // predict + leg-odometry update + a second (orientation) update in one state round trip; corr_kind = enum pb_corr
 int pbk_step_correct(pb_ctx *c, int corr_kind, const double *imu, const double *lo, const uint8_t *mask, const double q[4],
                      const double *z2, const double *r2, const double *rb2, const double *qm2, const uint8_t *mask2,

@@ -88,20 +88,25 @@ int pbk_step_leg(pb_ctx *c, const double *imu, const StepBcast *bcast, const dou
   return PB_OK;
 }
 
-int pbk_replay_fused(pb_ctx *c, int T, const double *imu, const double *lo, const uint8_t *mask, const double q[4])
+int pbk_replay_fused(pb_ctx *c, int T, const double *imu, const double *lo, const uint8_t *mask, const double q[4], int slot0)
 {
+  SlotOut so;
+  if (slot0 >= 0) {
+    so.base = c->hist + (size_t) slot0 * c->state_doubles;
+    so.stride = c->state_doubles;
+  }
   // PRONTO_BATCH_REPLAY_ONELANE=1: the first, one-lane-per-filter version (15 states only; A/B runs)
   static const bool one_lane = getenv("PRONTO_BATCH_REPLAY_ONELANE") && getenv("PRONTO_BATCH_REPLAY_ONELANE")[0] == '1';
-  if (c->ns == 15 && one_lane)
+  if (c->ns == 15 && one_lane && slot0 < 0)
     k_replay_fused<15><<<nblk(c->B), 64, 0, c->stream>>>(c->st, c->B, T, imu, lo, mask, q[0], q[1], q[2], q[3], c->k);
   else if (c->ns == 15)
-    k_replay_coop<15><<<nblk(c->B), 128, 0, c->stream>>>(c->st, c->B, T, imu, lo, mask, q[0], q[1], q[2], q[3], c->k);
+    k_replay_coop<15><<<nblk(c->B), 128, 0, c->stream>>>(c->st, c->B, T, imu, lo, mask, q[0], q[1], q[2], q[3], c->k, so);
   else if (c->quad21)
     // four waves per tile, register budget of ONE wave per SIMD: 3.3e9 steps/s at 64k filters, T = 32; cut for two waves
     // per SIMD it carries 452 B of scratch and measured 2.4e9; the two-wave kernel below 1.7e9
-    k_replay_quad<1><<<nblk(c->B), 256, 0, c->stream>>>(c->st, c->B, T, imu, lo, mask, q[0], q[1], q[2], q[3], c->k);
+    k_replay_quad<1><<<nblk(c->B), 256, 0, c->stream>>>(c->st, c->B, T, imu, lo, mask, q[0], q[1], q[2], q[3], c->k, so);
   else
-    k_replay_coop<21><<<nblk(c->B), 128, 0, c->stream>>>(c->st, c->B, T, imu, lo, mask, q[0], q[1], q[2], q[3], c->k);
+    k_replay_coop<21><<<nblk(c->B), 128, 0, c->stream>>>(c->st, c->B, T, imu, lo, mask, q[0], q[1], q[2], q[3], c->k, so);
   LAUNCHCHK(c);
   return PB_OK;
 }

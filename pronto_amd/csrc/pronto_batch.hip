@@ -542,6 +542,36 @@ extern "C" int pb_replay_legodo_fused(pb_ctx *c, int n_steps, int steps_per_laun
   return PB_OK;
 }
 
+extern "C" int pb_replay_legodo_checkpointed(pb_ctx *c, int n_steps, int steps_per_launch, const double *imu_stream,
+                                             const double *lo_stream, const uint8_t *mask_stream, const double q[4], int first_slot,
+                                             float *elapsed_ms)
+{
+  ENTER(c);
+  NEED_STATE(c);
+  if (n_steps < 0 || steps_per_launch < 1 || !imu_stream || !lo_stream || !q)
+    return fail(c, PB_ERR_ARG, "pb_replay_legodo_checkpointed: bad argument");
+  if (first_slot < 0 || first_slot + n_steps > c->nhist)
+    return fail(c, PB_ERR_ARG, "pb_replay_legodo_checkpointed: slots %d..%d of %d (pb_history_reserve)", first_slot, first_slot + n_steps - 1, c->nhist);
+  const size_t B = (size_t) c->B;
+  {
+    int rc = detach_head(c, true);  // the state rides in registers from the context's own array; the slots only receive copies
+    if (rc) return rc;
+  }
+  if (elapsed_ms) HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+  for (int s = 0; s < n_steps; s += steps_per_launch) {
+    const int T = (n_steps - s < steps_per_launch) ? n_steps - s : steps_per_launch;
+    int rc = pbk_replay_fused(c, T, imu_stream + (size_t) s * 7 * B, lo_stream + (size_t) s * 6 * B,
+                              mask_stream ? mask_stream + (size_t) s * B : nullptr, q, first_slot + s);
+    if (rc) return rc;
+  }
+  if (elapsed_ms) {
+    HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+    HIPCHK(c, hipEventSynchronize(c->ev1));
+    HIPCHK(c, hipEventElapsedTime(elapsed_ms, c->ev0, c->ev1));
+  }
+  return PB_OK;
+}
+
 static int update_common(pb_ctx *c, int m, const int *idx, const double *z, const double *R, int rkind,
                          const double *qm, bool orient, const uint8_t *mask, int mem)
 {

@@ -849,10 +849,18 @@ __global__ __launch_bounds__(256, 2) void k_update_quad(const double *st, double
 // gives v chi Delta [biases] quat, role P gives omega accel: the process blocks linearise about the whole prior state),
 // then run exactly the bodies of k_step_coop with loads and stores redirected to registers.  Two barriers per step.
 // No per-message posterior: NOT the plugin path (see pb_replay_legodo_fused); accounting 104 + 2*state/T bytes per step.
+// WRITE-THROUGH (pb_replay_legodo_checkpointed): every step's posterior is ALSO stored into its checkpoint slot -- the forward
+// pass of the delayed-measurement history and of the smoother keeps every posterior (mav_state_est.cpp:50-70,98-189) -- while the
+// state stays in the roles' registers: per step one slot is written and nothing is read, where the per-step path reads the
+// previous slot and writes the next (268 MB per step through a 256 MB cache for 64k 21-state filters).
+struct SlotOut {
+  double *base = nullptr;       // first checkpoint slot to write (NULL: no write-through)
+  size_t stride = 0;            // doubles per slot
+};
 template <int NS>
 __global__ __launch_bounds__(128, 1) void k_replay_coop(double *st, int B, int T, const double *__restrict__ imu,
                                                         const double *__restrict__ lo, const uint8_t *__restrict__ mask,
-                                                        double qg, double qa, double qbg, double qba, Consts k)
+                                                        double qg, double qa, double qbg, double qba, Consts k, SlotOut so)
 {
   using L = Lay<NS>;
   using C = Coop<NS>;
@@ -914,6 +922,13 @@ __global__ __launch_bounds__(128, 1) void k_replay_coop(double *st, int B, int T
       coop_role_core<NS, true>(ld, stf, xw, xrd, sync, in, k);
       // (no third barrier: this role overwrites the hand-off only behind the next state-exchange barrier, which role P
       // reaches after it has finished reading; the exchange slots of the two roles are disjoint)
+      if (so.base != nullptr) {  // write-through: this role's components of the posterior of step t
+        TileIO<NS, 0, MemHint<MH_STREAM_NT>::SA, true> ios(st, so.base + (size_t) t * so.stride, tile, lane);
+        static_for<SL::NSLOT>([&](auto I) {
+          constexpr int slot = decltype(I)::value, comp = SL::T.comp_of[slot];
+          if constexpr (comp >= 0 && SL::T.role2[slot] == 0) ios.st(comp, V[comp]);
+        });
+      }
     }
     static_for<SL::NSLOT>([&](auto I) {
       constexpr int slot = decltype(I)::value, comp = SL::T.comp_of[slot];
@@ -938,6 +953,13 @@ __global__ __launch_bounds__(128, 1) void k_replay_coop(double *st, int B, int T
 #pragma unroll
       for (int i = 0; i < 4; i++) V[L::OFF_QUAT + i] = xst[NS + i][lane];
       coop_role_passive<NS, true>(ld, stf, xrd, sync, in, k);
+      if (so.base != nullptr) {
+        TileIO<NS, 0, MemHint<MH_STREAM_NT>::SA, true> ios(st, so.base + (size_t) t * so.stride, tile, lane);
+        static_for<SL::NSLOT>([&](auto I) {
+          constexpr int slot = decltype(I)::value, comp = SL::T.comp_of[slot];
+          if constexpr (comp >= 0 && SL::T.role2[slot] == 1) ios.st(comp, V[comp]);
+        });
+      }
     }
     static_for<SL::NSLOT>([&](auto I) {
       constexpr int slot = decltype(I)::value, comp = SL::T.comp_of[slot];
@@ -955,7 +977,7 @@ __global__ __launch_bounds__(128, 1) void k_replay_coop(double *st, int B, int T
 template <int OCC>
 __global__ __launch_bounds__(256, OCC) void k_replay_quad(double *st, int B, int T, const double *__restrict__ imu,
                                                         const double *__restrict__ lo, const uint8_t *__restrict__ mask,
-                                                        double qg, double qa, double qbg, double qba, Consts k)
+                                                        double qg, double qa, double qbg, double qba, Consts k, SlotOut so)
 {
   constexpr int NS = 21;
   using L = Lay<NS>;
@@ -1023,6 +1045,15 @@ __global__ __launch_bounds__(256, OCC) void k_replay_quad(double *st, int B, int
         if (!own(i)) V[i < NS ? L::OFF_VEC + i : L::OFF_QUAT + (i - NS)] = xst[i][lane];                              \
       });                                                                                                             \
       BODY;                                                                                                           \
+      if (so.base != nullptr) { /* write-through: this role's rows of the posterior of step t */                      \
+        TileIO<NS, 0, MemHint<MH_STREAM_NT>::SA> ios(st, so.base + (size_t) t * so.stride, tile, lane);               \
+        static_for<SL::NSLOT>([&](auto I) {                                                                           \
+          constexpr int slot = decltype(I)::value, comp = SL::T.comp_of[slot];                                        \
+          if constexpr (comp >= 0 && slot >= SL::T.nq[ROLE_ID] - (SL::QROW[ROLE_ID + 1] - SL::QROW[ROLE_ID]) * 2 &&   \
+                        slot < SL::T.nq[ROLE_ID])                                                                     \
+            ios.st(comp, V[comp]);                                                                                    \
+        });                                                                                                           \
+      }                                                                                                               \
     }                                                                                                                 \
     static_for<SL::NSLOT>([&](auto I) {                                                                               \
       constexpr int slot = decltype(I)::value, comp = SL::T.comp_of[slot];                                            \

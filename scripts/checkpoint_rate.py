@@ -37,6 +37,17 @@ for n in (15, 21):
                     est.state_save(k)
             est.sync()
             res[mode] = (time.perf_counter() - t0) / T
-    print("n=%d, 64k filters, per step: no checkpoints %.1f us | step + copy %.1f us | step into the slot %.1f us"
-          % (n, res["none"] * 1e6, res["copy"] * 1e6, res["slot"] * 1e6))
+    # the write-through replay: T steps per launch, every posterior into its slot, nothing read back
+    imus, los, masks = (a.unsqueeze(0).repeat(T, *([1] * a.dim())).contiguous() for a in (imu, lo, mask))
+    wt = {}
+    for Tf in (8, 32):
+        for rep in range(2):
+            est.reset(vec, quat, P0)
+            est.sync()
+            wt[Tf] = est.replay_legodo_checkpointed(imus, los, masks, q4, Tf, first_slot=0, timed=True) / T * 1e-3
+    st = (n + 5 + n * (n + 1) // 2) * 8
+    print("n=%d, 64k filters, per step: no checkpoints %.1f us | step + copy %.1f us | step into the slot %.1f us | write-through replay "
+          "T=8 %.1f us, T=32 %.1f us (%.0f B per filter-step under its own accounting: %.2f of the HBM roofline)"
+          % (n, res["none"] * 1e6, res["copy"] * 1e6, res["slot"] * 1e6, wt[8] * 1e6, wt[32] * 1e6, st + 104 + 2 * st / 32,
+             (st + 104 + 2 * st / 32) * B / wt[32] / 8e12))
     est.close()

@@ -512,6 +512,52 @@ def test_time_fused_replay_equals_per_step_path(pa, oracle, T_fuse, n, onelane, 
         est_new.replay_legodo_fused(d[0][:, :, :8].contiguous(), d[1][:, :, :8].contiguous(), d[2][:, :8].contiguous(), q4, 4)   # before reset
 
 
+@pytest.mark.parametrize("n", [15, 21])
+def test_checkpointed_replay_keeps_every_posterior(pa, oracle, n):
+    """pb_replay_legodo_checkpointed: the time-fused replay as a forward pass that keeps every posterior (history, smoother forward
+    pass; mav_state_est.cpp:50-70,98-189).  Slot t must hold, BIT FOR BIT, what the same replay kernel leaves after t + 1 steps
+    when it is launched one step at a time (the state's trip through memory is exact); it equals the per-message path with
+    pb_set_output_slot to rounding (another kernel: other multiply-add contractions) and the oracle's trajectory; ragged batch,
+    ragged last launch, a second call appending behind the first."""
+    import torch
+    B, T = 333, 23
+    w = Workload(B, n_states=n)
+    imu, lo, mask = w.streams(0, T)
+    dev = torch.device("cuda:0")
+    d = [torch.from_numpy(a).to(dev) for a in (imu, lo, mask)]
+    q4 = w.process_noise()
+    est_c, ob = make_pair(pa, oracle, w)      # checkpointed replay
+    est_1, _ = make_pair(pa, oracle, w)       # the same kernel, one step per launch
+    est_s, _ = make_pair(pa, oracle, w)       # per-message path into slots
+    for e in (est_c, est_s):
+        e.history_reserve(T + 2)
+    with pytest.raises(pa.PbError):
+        est_c.replay_legodo_checkpointed(d[0], d[1], d[2], q4, 7, first_slot=3)        # would run past the last slot
+    est_c.replay_legodo_checkpointed(d[0][:16].contiguous(), d[1][:16].contiguous(), d[2][:16].contiguous(), q4, 7, first_slot=1)
+    est_c.replay_legodo_checkpointed(d[0][16:].contiguous(), d[1][16:].contiguous(), d[2][16:].contiguous(), q4, 5, first_slot=17)
+    head_c = est_c.get_head()
+    for t in range(T):
+        est_1.replay_legodo_fused(d[0][t:t + 1].contiguous(), d[1][t:t + 1].contiguous(), d[2][t:t + 1].contiguous(), q4, 1)
+        est_s.set_output_slot(1 + t)
+        est_s.step_legodo(d[0][t], d[1][t], d[2][t], q4)
+        ob.predict(imu[t], q4)
+        ob.update_indexed([3, 4, 5], np.ascontiguousarray(lo[t][0:3]), np.ascontiguousarray(lo[t][3:6]), mask=mask[t])
+        want = est_1.get_head()
+        est_c.state_restore(1 + t)
+        got = est_c.get_head()
+        for x, y in zip(got, want):
+            assert np.array_equal(x, y), t                      # bit for bit
+        est_s.state_restore(1 + t)
+        for x, y in zip(got, est_s.get_head()):
+            assert rel(x, y) < 1e-12, t
+        if t in (0, T // 2, T - 1):
+            check(est_c, ob)
+    for x, y in zip(head_c, est_1.get_head()):                  # the head after the call = the last slot's content
+        assert np.array_equal(x, y)
+    for e in (est_c, est_1, est_s):
+        e.close()
+
+
 @pytest.mark.parametrize("generic", ["0", "1"])
 @pytest.mark.parametrize("n,vo,sm", [(15, 32, 0), (21, 0, 25)])
 def test_full_size_configs_3_and_5_sampled_parity(pa, oracle, n, vo, sm, generic, monkeypatch):
