@@ -9,7 +9,7 @@
 //   g++ -std=c++17 -O2 -Iinclude -Ipronto_amd/csrc examples/shim_sweep_rate.cpp -Lpronto_amd/lib -lpronto_batch
 //       -Wl,-rpath,$PWD/pronto_amd/lib -o shim_sweep_rate
 //   ./shim_sweep_rate [filters=65536] [messages=2000] [n_states=15] [history_slots=0] [utime_history_span=1000000] [vo_every=0]
-//                     [input=feet|joints] [pairs=one|two]
+//                     [input=feet|joints] [pairs=one|two] [legodo mode=lin_rate|lin_rot_rate|pos_and_lin_rate]
 // input = joints: the log is a bot_core::joint_state_t stream and LegOdoHandler::processMessage(joint_state_t) runs the
 // forward kinematics per filter on the device too (the reference's own handler signature); pairs = two: the leg odometry as
 // its own launch in front of the fused step (round 2's path) instead of inside the step kernel.
@@ -50,6 +50,7 @@ int main(int argc, char **argv)
   const int vo_every = argc > 6 ? std::atoi(argv[6]) : 0;     // a visual-odometry delta every N-th pair (0 = none): config 3
   const bool joints = argc > 7 && std::string(argv[7]) == "joints";
   const bool two_launches = argc > 8 && std::string(argv[8]) == "two";
+  const std::string lomode = argc > 9 ? argv[9] : "lin_rate";   // state_estimator.legodo.mode: lin_rate | lin_rot_rate | pos_and_lin_rate
   BotParam param;
   param.set("state_estimator.utime_history_span", span);
   param.set("state_estimator.history_slots", slots);
@@ -63,7 +64,7 @@ int main(int argc, char **argv)
   param.set("state_estimator.ins.atlas_filter", "false");
   param.set("state_estimator.ins.accel_bias_update_online", n == 21 ? "true" : "false");
   param.set("state_estimator.ins.gyro_bias_update_online", n == 21 ? "true" : "false");
-  param.applyOverrides("state_estimator.legodo.mode=lin_rate|state_estimator.legodo.r_xyz=0.2|state_estimator.legodo.r_vxyz=0.1|"
+  param.applyOverrides("state_estimator.legodo.mode=" + lomode + "|state_estimator.legodo.r_xyz=0.2|state_estimator.legodo.r_vxyz=0.1|"
                        "state_estimator.legodo.r_vang=0.3|state_estimator.legodo.r_vxyz_uncertain=0.5|state_estimator.legodo.r_vang_uncertain=0.9|"
                        "state_estimator.legodo.schmitt_low_threshold=475|state_estimator.legodo.schmitt_high_threshold=525|"
                        "state_estimator.legodo.schmitt_low_delay=7000|state_estimator.legodo.schmitt_high_delay=7000|"
@@ -193,10 +194,10 @@ int main(int argc, char **argv)
   bool finite = true;
   for (int b = 0; b < B; b++)
     for (int i = 0; i < n; i++) { sum += std::fabs(head(i, b)); finite = finite && std::isfinite(head(i, b)); }
-  std::printf("shim sweep: %d filters x %d message pairs (n=%d, history_slots=%s%s, %s, %s): %.1f us per IMU + %s pair, "
+  std::printf("shim sweep: %d filters x %d message pairs (n=%d, history_slots=%s%s, %s, %s, legodo mode %s): %.1f us per IMU + %s pair, "
               "%.3e filter-steps/s, one-kernel pairs %lld of %lld fused, dropped %lld, checksum %.6g %s\n", B, T - warm, n, slots.c_str(),
               vo_every > 0 ? (", VO every " + std::to_string(vo_every)).c_str() : "", joints ? "joint-state log" : "foot-state log",
-              two_launches ? "odometry as its own launch" : "odometry inside the step kernel", dt / (T - warm) * 1e6, joints ? "joint-state" : "foot-state",
+              two_launches ? "odometry as its own launch" : "odometry inside the step kernel", lomode.c_str(), dt / (T - warm) * 1e6, joints ? "joint-state" : "foot-state",
               (double) B * (T - warm) / dt, (long long) est.leg_kernel_pairs, (long long) est.fused_pairs, (long long) est.dropped_updates, sum,
               finite ? "finite" : "NON-FINITE");
   return finite ? 0 : 1;

@@ -22,6 +22,11 @@ EXE=tests/build/shim_sweep_rate
   $EXE 65536 2000 21 0
   $EXE 65536 2000 21 0 1000000 0 joints
   $EXE 65536 2000 21 32
+  # LegOdoCommon's six-row modes: the measurement is formed on the device (round 4), three launches per pair
+  $EXE 65536 2000 15 0 1000000 0 joints one lin_rot_rate
+  $EXE 65536 2000 15 0 1000000 0 joints one pos_and_lin_rate
+  $EXE 65536 2000 21 0 1000000 0 joints one lin_rot_rate
+  $EXE 65536 2000 21 0 1000000 0 joints one pos_and_lin_rate
 } > $OUT/shim_sweep.txt 2>&1 || exit 12
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $EXE 65536 2000 15 0 1000000 0 joints > $OUT/trace.txt 2> $OUT/trace.err || exit 13
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace21 -- $EXE 65536 2000 21 0 1000000 0 joints > $OUT/trace21.txt 2> $OUT/trace21.err || exit 14
