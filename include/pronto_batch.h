@@ -257,8 +257,7 @@ int pb_legodo_set_message_times(pb_ctx *ctx, const int64_t *utimes, const uint8_
  *   2  pos_and_lin_rate    lo_block_out [12][B] = z (position, v) [6], Rdiag [6]; mask_out [2][B]  idx {9,10,11,3,4,5}
  *      mask_out[0][b] = status valid AND position valid: the six-row update; mask_out[1][b] = status valid AND position NOT valid:
  *      the reference's per-message fall-back to lin_rate (:118-122), a three-row update on rows 3..5 (z) and 9..11 (Rdiag) of
- *      the same block with idx {3,4,5}.  Joint-state entry points only (the position is leg_estimate's world constraint,
- *      which this mode switches on).
+ *      the same block with idx {3,4,5}.  (The position is leg_estimate's world constraint, which this mode switches on.)
  * r_xyz, r_vang, r_vang_uncertain: state_estimator.legodo.r_xyz / r_vang / r_vang_uncertain (r_vxyz and r_vxyz_uncertain stay
  * arguments of the odometry calls).  The pair calls pb_step_legodo_joints / _feet always form and apply lin_rate.
  * pb_legodo_init puts the mode back to 0. */

@@ -13,21 +13,29 @@ int pbk_smooth_step(pb_ctx *c, const double *np_, const double *ns_, const doubl
 #else
   constexpr size_t pad = 0;
 #endif
+  // PRONTO_SMOOTH_PIVOT=1: Eigen's diagonal pivoting in the factorisation of P^- (the reference's .ldlt(); parity with the oracle at
+  // 1e-15); default: no pivot search (P^- is SPD; rbis_smooth.hpp)
+  static const bool pivot = getenv("PRONTO_SMOOTH_PIVOT") && getenv("PRONTO_SMOOTH_PIVOT")[0] == '1';
   if (!c->smooth_attr) {  // more than the default 64 KB of dynamic LDS per workgroup
-    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_smooth_reg<15>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int) (pad + sizeof(double) * SmoothRegCfg<15>::LDS_DOUBLES)));
-    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_smooth_reg<21>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int) (pad + sizeof(double) * SmoothRegCfg<21>::LDS_DOUBLES)));
+    const int l15 = (int) (pad + sizeof(double) * SmoothRegCfg<15>::LDS_DOUBLES), l21 = (int) (pad + sizeof(double) * SmoothRegCfg<21>::LDS_DOUBLES);
+    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_smooth_reg<15, true>), hipFuncAttributeMaxDynamicSharedMemorySize, l15));
+    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_smooth_reg<21, true>), hipFuncAttributeMaxDynamicSharedMemorySize, l21));
+    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_smooth_reg<15, false>), hipFuncAttributeMaxDynamicSharedMemorySize, l15));
+    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_smooth_reg<21, false>), hipFuncAttributeMaxDynamicSharedMemorySize, l21));
     c->smooth_attr = true;
   }
   if (c->ns == 15) {
     using S = SmoothRegCfg<15>;
-    k_smooth_reg<15><<<(c->B + S::F - 1) / S::F, S::THREADS, pad + sizeof(double) * S::LDS_DOUBLES, c->stream>>>(
-        np_, ns_, cu, out, c->B, dt, c->k);
+    const dim3 grid((unsigned) ((c->B + S::F - 1) / S::F));
+    const size_t ldsb = pad + sizeof(double) * S::LDS_DOUBLES;
+    if (pivot) k_smooth_reg<15, true><<<grid, S::THREADS, ldsb, c->stream>>>(np_, ns_, cu, out, c->B, dt, c->k);
+    else k_smooth_reg<15, false><<<grid, S::THREADS, ldsb, c->stream>>>(np_, ns_, cu, out, c->B, dt, c->k);
   } else {
     using S = SmoothRegCfg<21>;
-    k_smooth_reg<21><<<(c->B + S::F - 1) / S::F, S::THREADS, pad + sizeof(double) * S::LDS_DOUBLES, c->stream>>>(
-        np_, ns_, cu, out, c->B, dt, c->k);
+    const dim3 grid((unsigned) ((c->B + S::F - 1) / S::F));
+    const size_t ldsb = pad + sizeof(double) * S::LDS_DOUBLES;
+    if (pivot) k_smooth_reg<21, true><<<grid, S::THREADS, ldsb, c->stream>>>(np_, ns_, cu, out, c->B, dt, c->k);
+    else k_smooth_reg<21, false><<<grid, S::THREADS, ldsb, c->stream>>>(np_, ns_, cu, out, c->B, dt, c->k);
   }
   LAUNCHCHK(c);
   return PB_OK;

@@ -1199,8 +1199,6 @@ static int legodo_launch(pb_ctx *c, LegIn &in, const double *imu_block, int imu_
   LegMeasPar mp = c->leg_meas;
   mp.r_v2 = r_vxyz * r_vxyz;                            // bot_sq (rbis_legodo_common.cpp:40-43)
   mp.r_v2_uncertain = r_vxyz_uncertain * r_vxyz_uncertain;
-  if (mp.mode == 2 && in.kind != 1)
-    return fail(c, PB_ERR_STATE, "measurement mode pos_and_lin_rate needs the joint-state entry points (the pelvis position comes from the world constraint)");
   // the world constraint (the transition foot's world position) is tracked from the first call that asks for the position
   if (pos_out != nullptr) c->leg_par.world_constraint = 1;
   if (c->ns == 15)

@@ -169,7 +169,14 @@ __device__ __forceinline__ unsigned rowpair_min(unsigned v)
 #else
 #define PB_SMOOTH_WG_PER_CU 2
 #endif
-template <int NS>
+// PIVOT = true: Eigen's diagonal pivoting (the reference calls .ldlt(): same pivot sequence, parity with the oracle at 1e-15).
+// PIVOT = false: NO pivot search -- P^- (with the bias-block fix) is symmetric positive definite, for which the unpivoted
+// factorisation is backward stable and its accuracy, like Cholesky's, is governed by the condition of the diagonally SCALED
+// matrix (the correlations), not by the spread of the variances (1e-10 for a bias, 0.25 for a position): step kk's pivot is row
+// kk, known at compile time, so the two cross-lane reductions per step (8-10 DPP stages on the critical path), the position
+// bookkeeping and the permutation of the right-hand side disappear.  Results differ from the pivoted path by rounding
+// (tests: <= 1e-9 against the oracle; observed 1e-13).
+template <int NS, bool PIVOT = true>
 __global__ __launch_bounds__(SM_THREADS, PB_SMOOTH_WG_PER_CU) void k_smooth_reg(const double *__restrict__ next_pred,
                                                     const double *__restrict__ next_sm,
                                                     const double *__restrict__ cur, double *__restrict__ out,
@@ -371,6 +378,33 @@ __global__ __launch_bounds__(SM_THREADS, PB_SMOOTH_WG_PER_CU) void k_smooth_reg(
 #ifdef SM_SKIP_FACT
       piv[kk] = kk; if (r == kk) mypos = kk; if constexpr (KEEP_L) lreg[kk] = 0.0; Rf[C::RB_INV + kk] = 1.0; return;
 #endif
+      if constexpr (!PIVOT) {
+        const bool is_k = row && (r == kk);
+        piv[kk] = kk;
+        if (is_k) {
+#pragma unroll
+          for (int j = 0; j + 1 < NS; j += 2) lds_st2(Rf + j, am[j], am[j + 1]);
+          if (NS & 1) Rf[NS - 1] = am[NS - 1];
+          Rf[C::RB_INV + kk] = (fabs(dg) > 5.562684646268003e-309) ? 1.0 / dg : 0.0;
+          mypos = kk;
+        }
+        group_sync();
+        const double inv_k = Rf[C::RB_INV + kk];
+        const double c_k = Rf[rr];                                 // A[kk][r]
+        const double l_k = (row && r > kk) ? c_k * inv_k : 0.0;    // rows above the pivot are done, the pivot row keeps itself
+#pragma unroll
+        for (int j = 0; j < NS; j += 2) {
+          const d2_t pr = lds_ld2(Rf + j);
+          am[j] = fma(-l_k, pr.x, am[j]);
+          if (j + 1 < NS) am[j + 1] = fma(-l_k, pr.y, am[j + 1]);
+        }
+        dg = fma(-l_k, c_k, dg);
+        if constexpr (KEEP_L) lreg[kk] = l_k;
+        else mine[one * kk] = l_k;
+        group_sync();
+        step_fence();
+        return;
+      }
       // candidates: |d| >= 0; rows pivoted earlier and the padding lanes: -1 (never the maximum while a row remains)
       const double ad = done ? -1.0 : fabs(dg);
       double mx = max_stage<1>(ad);

@@ -23,10 +23,11 @@ for n in (15, 21):
     lo, mask = w.legodo_block(0)
     est.update_indexed([3, 4, 5], np.ascontiguousarray(lo[0:3]), np.ascontiguousarray(lo[3:6]), mask=mask)
     est.state_save(2)
-    est.smooth_step(1, 2, 0, 3, 1e-3)
+    for _ in range(50):
+        est.smooth_step(1, 2, 0, 3, 1e-3)
     est.sync()
     import time
-    reps = 20
+    reps = 200  # (20 launches were 4 ms of work: too short for the clocks to settle)
     t0 = time.perf_counter()
     for _ in range(reps):
         est.smooth_step(1, 2, 0, 3, 1e-3)

@@ -262,7 +262,8 @@ def test_shim_sweep_rate_example_runs(n, slots):
                                   ("lin_rate", "alt", "fuse", "blocks", "lowpass"), ("lin_rate", "alt", "fuse", "bcast", "kalman"),
                                   ("lin_rot_rate", "standing", "nofuse", "blocks", "kalman"), ("lin_rate", "alt", "nofuse", "bcast", "lowpass"),
                                   ("lin_rate", "alt", "fuse", "device", "none"), ("lin_rate", "ctrl", "fuse", "device", "lowpass"),
-                                  ("lin_rate", "alt", "fuse3", "device", "none")])
+                                  ("lin_rate", "alt", "fuse3", "device", "none"), ("pos_and_lin_rate", "alt", "nofuse", "bcast"),
+                                  ("lin_rot_rate", "alt", "nofuse", "bcast")])
 @pytest.mark.parametrize("n", [15, 21])
 def test_joint_state_handler_on_gpu(oracle, args, n):
     """LegOdoHandler::processMessage(joint_state_t) -- the reference's handler signature -- from a synthetic 6-DoF-per-leg gait:
