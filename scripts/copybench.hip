@@ -90,7 +90,7 @@ template<int NW, int LA, int SA, bool XCD> __global__ __launch_bounds__(NW*64) v
 
 int main(){
   const int nc=140;
-  for(int B : {65536, 196608, 262144, 1<<20}){
+  for(int B : {32768, 65536, 196608, 262144, 1<<20}){
     long stride=B; size_t bytes=(size_t)nc*stride*8; double *s,*d; CK(hipMalloc(&s,bytes)); CK(hipMalloc(&d,bytes)); CK(hipMemset(s,1,bytes)); CK(hipMemset(d,0,bytes));
     auto rep=[&](const char*name,float ms){ printf("B=%8d %-34s %9.1f us  %7.1f GB/s (r+w)\n",B,name,ms*1e3,2.0*bytes/(ms*1e-3)/1e9); fflush(stdout); };
     int reps = B>100000? 20: 100; int g=(B+63)/64;

@@ -54,14 +54,16 @@ for d, name in (("trace64k", "_kernel_stats.csv"), ("trace64k_n21", "_kernel_sta
     if ks:
         shutil.copy(ks[0], os.path.join(out, tag + name))
 for name in ("trace64k.json", "trace64k_n21.json", "trace1m.json", "leg_rates.txt", "bench1m.json", "calib_plain.txt", "copybench.txt", "batch_sweep.txt",
-             "bench_default.json", "others.txt", "configs.txt", "smoother.txt", "n21_input_footprint.txt"):
+             "bench_default.json", "others.txt", "configs.txt", "smoother.txt", "n21_input_footprint.txt", "checkpoint_rate.txt",
+             "smoother_pivoted.txt", "leg_ab.txt", "segment_rate.txt"):
     p = os.path.join(src, name)
     if os.path.exists(p):
         shutil.copy(p, os.path.join(out, tag + "_" + name))
 
 p = os.path.join(src, "shim", "shim_sweep.txt")
 if os.path.exists(p):
-    shutil.copy(p, os.path.join(out, tag + "_shim_sweep.txt"))
+    with open(p, errors="replace") as f, open(os.path.join(out, tag + "_shim_sweep.txt"), "w") as o:
+        o.writelines(l for l in f if l.startswith("shim sweep"))   # (the file also holds the handlers' chatter on stdout / stderr)
 # per-kernel MEDIAN durations of the handler-path traces: the stats file's average includes the first launch (module load,
 # tens of milliseconds), the median does not
 for d in ("shim/trace", "shim/trace21"):
@@ -102,7 +104,7 @@ json.dump(traffic, open(os.path.join(out, "traffic.json"), "w"), indent=1)
 sm = {}
 for d in ("smooth_pmc_a", "smooth_pmc_b"):
     for (k, c), v in counters(d).items():
-        m = re.match(r"k_smooth_reg<(\d+)>", k)
+        m = re.match(r"k_smooth_reg<(\d+)", k)   # k_smooth_reg<NS,PIVOT> since round 4
         if m:
             sm.setdefault("n" + m.group(1), {})[c] = sum(v) / len(v)
 txt = os.path.join(src, "smoother.txt")
@@ -121,7 +123,7 @@ if sm:
             r["valu_insts_per_wave"] = r.get("SQ_INSTS_VALU", 0) / r["SQ_WAVES"]
             r["lds_insts_per_wave"] = r.get("SQ_INSTS_LDS", 0) / r["SQ_WAVES"]
     json.dump({"what": "rocprofv3 --pmc of scripts/smooth_rate.py (64k filters), two passes (scripts/profile.sh); averages per launch",
-               "kernel": "k_smooth_reg<NS> (pb_smooth_step)", "runs": sm},
+               "kernel": "k_smooth_reg<NS,false> (pb_smooth_step; no pivot search since round 4)", "runs": sm},
               open(os.path.join(out, tag + "_smoother_pmc.json"), "w"), indent=1)
 
 for k, v in res["runs"].items():
