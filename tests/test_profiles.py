@@ -64,3 +64,26 @@ def test_one_million_filter_trace_agrees_with_the_cache_busting_leg():
     cb = bench_line(tag)["roofline"]["cache_busting"]
     assert cb["batch"] == 1 << 20
     assert abs(prof_us - cb["kernel_avg_us"]) / prof_us < 0.08, (prof_us, cb["kernel_avg_us"])
+
+
+def test_numbers_quoted_in_design_are_in_the_committed_profiles():
+    """every microsecond figure DESIGN.md quotes from a profile must be reproducible from the committed file --
+    the table between the quoted-numbers markers of DESIGN.md section 6 names the file, a string that selects one of its lines and the
+    value; the first number followed by "us" behind that string must agree within 5 %."""
+    import re
+    text = open(os.path.join(ROOT, "DESIGN.md")).read()
+    assert "<!-- quoted-numbers-begin -->" in text and "<!-- quoted-numbers-end -->" in text
+    table = text.split("<!-- quoted-numbers-begin -->")[1].split("<!-- quoted-numbers-end -->")[0]
+    rows = [r for r in table.splitlines() if r.startswith("| `profiles/")]
+    assert len(rows) >= 20
+    for r in rows:
+        cells = [c.strip() for c in r.strip().strip("|").split("|")]
+        # (a cell may itself contain '|' inside its back-ticks: the file is the first cell, the value the last)
+        path, want = cells[0].strip("`"), float(cells[-1])
+        key = "|".join(cells[1:-1]).strip().strip("`")
+        lines = open(os.path.join(ROOT, path), errors="replace").read().splitlines()
+        hits = [re.search(re.escape(key) + r"\s*([0-9.]+) us", ln) for ln in lines]
+        hits = [h for h in hits if h]
+        assert hits, (path, key)
+        got = float(hits[0].group(1))
+        assert abs(got - want) <= 0.05 * want, (path, key, got, want)
