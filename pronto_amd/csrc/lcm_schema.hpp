@@ -209,7 +209,7 @@ public:
     }
   private:
     friend class Schema;
-    enum Kind { I8, I16, I32, I64, F32, F64, STR, STRUCT };
+    enum Kind { I8, U8, I16, I32, I64, F32, F64, STR, STRUCT };
     struct Dim { int64_t n; int from; };              // constant length, or the value of integer member `from` of the same struct
     struct Field { Kind kind; int slot, node; std::vector<Dim> dims; bool is_len; };
     struct Node { std::vector<Field> f; int fixed_bytes; };   // fixed_bytes >= 0: no strings, no variable arrays, nothing wanted inside
@@ -217,7 +217,7 @@ public:
     int root_ = -1;
     size_t n_slots_ = 0;
     uint64_t fp_ = 0;
-    static int prim_size(Kind k) { return k == I8 ? 1 : k == I16 ? 2 : (k == I32 || k == F32) ? 4 : 8; }
+    static int prim_size(Kind k) { return (k == I8 || k == U8) ? 1 : k == I16 ? 2 : (k == I32 || k == F32) ? 4 : 8; }
     bool walk(int ni, Reader &r, std::vector<Extracted> &out) const
     {
       const Node &nd = nodes_[(size_t) ni];
@@ -258,6 +258,7 @@ public:
           int64_t iv = 0;
           switch (f.kind) {
           case I8: iv = r.i8(); v = (double) iv; break;
+          case U8: iv = (uint8_t) r.i8(); v = (double) iv; break;   // `byte` is unsigned
           case I16: iv = (int16_t) ((r.p[r.pos] << 8) | r.p[r.pos + 1]); r.pos += 2; v = (double) iv; break;
           case I32: iv = r.i32(); v = (double) iv; break;
           case I64: iv = r.i64(); v = (double) iv; break;
@@ -327,7 +328,7 @@ private:
       }
       if (is_primitive(f.type)) {
         pf.kind = f.type == "double" ? Plan::F64 : f.type == "float" ? Plan::F32 : f.type == "int64_t" ? Plan::I64 : f.type == "int32_t" ? Plan::I32
-                  : f.type == "int16_t" ? Plan::I16 : f.type == "string" ? Plan::STR : Plan::I8;
+                  : f.type == "int16_t" ? Plan::I16 : f.type == "string" ? Plan::STR : f.type == "byte" ? Plan::U8 : Plan::I8;
         if (pf.kind == Plan::STR || variable || pf.slot >= 0 || pf.is_len) nd.fixed_bytes = -1;
         else if (nd.fixed_bytes >= 0) {
           int64_t c = 1;

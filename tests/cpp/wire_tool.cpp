@@ -164,6 +164,47 @@ int main(int argc, char **argv)
     printf("\n");
     return 0;
   }
-  fprintf(stderr, "usage: wire_tool hashes | write <path> | dump <path> | schema <lcm files> <type> <message file>\n");
+  if (mode == "plan" && argc > 5) {  // plan <lcm file> <type> <message file> <wanted,members,...>: Schema::compile + Plan::run
+    Schema sc;
+    std::string err, text;
+    {
+      FILE *f = fopen(argv[2], "rb");
+      if (!f) return 2;
+      char buf[4096];
+      size_t n;
+      while ((n = fread(buf, 1, sizeof buf, f)) > 0) text.append(buf, n);
+      fclose(f);
+    }
+    if (!sc.parse(text, &err)) { printf("parse error: %s\n", err.c_str()); return 3; }
+    std::vector<std::string> wanted;
+    {
+      std::string w = argv[5];
+      size_t a = 0;
+      while (a <= w.size()) {
+        const size_t b = w.find(',', a);
+        wanted.push_back(w.substr(a, b == std::string::npos ? std::string::npos : b - a));
+        if (b == std::string::npos) break;
+        a = b + 1;
+      }
+    }
+    const Schema::Plan plan = sc.compile(argv[3], wanted);
+    if (!plan.ok()) { printf("no plan\n"); return 0; }
+    FILE *f = fopen(argv[4], "rb");
+    if (!f) return 2;
+    std::vector<uint8_t> msg;
+    int c;
+    while ((c = fgetc(f)) != EOF) msg.push_back((uint8_t) c);
+    fclose(f);
+    std::vector<Schema::Extracted> out;
+    if (!plan.run(msg.data(), msg.size(), out)) { printf("run refused\n"); return 0; }
+    for (size_t k = 0; k < out.size(); k++) {
+      printf("%s:", wanted[k].c_str());
+      for (double v : out[k].num) printf(" %.17g", v);
+      for (const std::string &t : out[k].str) printf(" \"%s\"", t.c_str());
+      printf("\n");
+    }
+    return 0;
+  }
+  fprintf(stderr, "usage: wire_tool hashes | write <path> | dump <path> | schema <lcm files> <type> <message file> | plan <lcm file> <type> <message file> <members>\n");
   return 1;
 }

@@ -207,3 +207,46 @@ def test_runtime_schema_parse_fingerprint_decode(tool, tmp_path):
     assert "decode error" in out
     out = subprocess.check_output([tool, "schema", "%s,%s" % (demo, ex), "demo.inner_t", str(msg)], text=True)
     assert "fingerprint mismatch" in out
+
+
+def test_compiled_extraction_plans_agree_with_the_value_tree(tool, tmp_path):
+    """lcm_schema.hpp Schema::compile / Plan::run -- the replay fast path (SegmentBatcher): a few named members out of a message
+    without building the value tree.  Top-level scalars, fixed and variable arrays, strings, a member of every element of an
+    array of structs, a member behind variable-length members; fixed-size runs that are stepped over in one jump; refusals."""
+    demo = tmp_path / "demo.lcm"
+    demo.write_text(DEMO_LCM)
+    value = {"utime": 123456789012, "n": 2, "m": 3,
+             "items": [{"id": -7, "w": [0.5, -2.25], "label": "left foot"}, {"id": 300, "w": [1.0, 8.0], "label": ""}],
+             "grid": [[0.1, 0.2, 0.3], [-1.5, 2.5e-7, 3e9]], "ok": 1, "raw": [0, 127, 128, 255],
+             "single": {"id": 1, "w": [3.0, 4.0], "label": "x"}}
+    msg = tmp_path / "outer.bin"
+    msg.write_bytes(L.encode_message(DEMO_TYPES, "demo.outer_t", value))
+    run = lambda members, path=msg, typ="demo.outer_t": subprocess.check_output([tool, "plan", str(demo), typ, str(path), members], text=True).splitlines()
+    out = run("utime,grid,items.w,items.label,single.id,raw,ok,items.id")
+    assert out[0] == "utime: 123456789012"
+    assert [float(v) for v in out[1].split()[1:]] == [0.1, 0.2, 0.3, -1.5, 2.5e-7, 3e9]
+    assert [float(v) for v in out[2].split()[1:]] == [0.5, -2.25, 1.0, 8.0]          # w of items[0], then of items[1]
+    assert out[3] == 'items.label: "left foot" ""'
+    assert out[4] == "single.id: 1" and out[5] == "raw: 0 127 128 255" and out[6] == "ok: 1" and out[7] == "items.id: -7 300"
+    # only members behind the variable-length ones: everything in front is stepped over
+    assert run("single.label,ok") == ['single.label: "x"', "ok: 1"]
+    # a member that does not exist: no plan; a truncated message, a message of another type: refused
+    assert run("utime,nonsense") == ["no plan"]
+    (tmp_path / "short.bin").write_bytes(msg.read_bytes()[:-3])
+    assert run("utime", tmp_path / "short.bin") == ["run refused"]
+    assert run("id", msg, "demo.inner_t") == ["run refused"]
+    # the bot_core shapes the SegmentBatcher reads (definitions as its test writes them)
+    bot = tmp_path / "bot.lcm"
+    bot.write_text("package bot_core;\n"
+                   "struct six_axis_force_torque_t { int64_t utime; double force[3]; double moment[3]; }\n"
+                   "struct six_axis_force_torque_array_t { int64_t utime; int32_t num_sensors; string names[num_sensors]; "
+                   "six_axis_force_torque_t sensors[num_sensors]; }\n")
+    types = {"bot_core.six_axis_force_torque_t": [("utime", "int64_t", []), ("force", "double", [(0, "3")]), ("moment", "double", [(0, "3")])],
+             "bot_core.six_axis_force_torque_array_t": [("utime", "int64_t", []), ("num_sensors", "int32_t", []), ("names", "string", [(1, "num_sensors")]),
+                                                        ("sensors", "bot_core.six_axis_force_torque_t", [(1, "num_sensors")])]}
+    ft = {"utime": 77, "num_sensors": 2, "names": ["l_foot", "r_foot"],
+          "sensors": [{"utime": 77, "force": [1.0, -2.0, 812.5], "moment": [0.1, 0.2, 0.3]}, {"utime": 77, "force": [3.0, 4.0, -90.25], "moment": [0.0, 0.0, 0.0]}]}
+    fmsg = tmp_path / "ft.bin"
+    fmsg.write_bytes(L.encode_message(types, "bot_core.six_axis_force_torque_array_t", ft))
+    out = subprocess.check_output([tool, "plan", str(bot), "bot_core.six_axis_force_torque_array_t", str(fmsg), "utime,sensors.force"], text=True).splitlines()
+    assert out == ["utime: 77", "sensors.force: 1 -2 812.5 3 4 -90.25"]
