@@ -145,7 +145,22 @@ struct CoopX {
   static constexpr int X2_L = C::NXCH, X2_ID = X2_L + M * (M - 1) / 2, X2_YD = X2_ID + M, X2_W = X2_YD + M,
                        X2_LLI = X2_W + C::NSC * M;
   static constexpr int NXCH = (M == 0) ? C::NXCH : X2_LLI + (C::LL_IN_P ? 1 : 0);
-  static constexpr int XCH_LEG = NXCH, XCH_FOOT = NXCH + 5, NXCH_LEG = NXCH + 19;  // k_step_leg: z[3], R, valid from the odometry wave; the two foot poses (2 x 7) from the other wave
+  // k_step_leg: the measurement from the odometry wave -- z[3], R, valid, and a six-row mode's second block z[3], R, on -- and the
+  // two foot poses (2 x 7) from the other wave.  All of them are consumed before role C writes its SECOND hand-off (behind the
+  // first one's barrier), so they share its slots: four workgroups of the pair kernel must fit a CU's 160 KB.
+  static constexpr int XCH_LEG = C::NXCH, XCH_FOOT = XCH_LEG + 10, NXCH_LEG = (NXCH > XCH_FOOT + 14) ? NXCH : XCH_FOOT + 14;
+  // SIX == 1 (see coop_role_core): role P's omega stage -- 1/d, y/d, its log-likelihood term and the propagated P(c, omega) rows --
+  // lies in the FIRST hand-off's slots: role C reads it behind barrier L and only then writes its own factors there.
+  static constexpr int X6_ID = 0, X6_YD = 3, X6_LLI = 6, X6_A = 9;
+};
+
+// The second 3-row block of LegOdoCommon's six-row measurements (rbis_legodo_common.cpp:46-79), when it is NOT a set of role C's
+// states: lin_rot_rate's angular-velocity rows (idx 0..2).  R is diagonal, so the six-row update equals the two blocks applied one
+// after the other with ONE addState of the summed correction (the residual of the later block taken at x + dx of the earlier one;
+// log-likelihood = sum of the two conditional terms) -- to rounding, not bit for bit: the oracle factors the 6 x 6 S at once.
+struct SixIn {
+  double z[3] = { 0.0, 0.0, 0.0 }, r = 1.0;
+  bool on = false;
 };
 
 // ------------------------------------------------------------------------------------------------------------
@@ -157,11 +172,20 @@ struct CoopX {
 // CORR alone is a stand-alone indexed / indexed+orientation update on the same two-role mapping.
 // LEG: the leg-odometry measurement (z, R, valid) is not an input but made by the OTHER wave of the tile while this one
 // propagates (k_step_leg, rbis_legstep.hpp): it arrives in the hand-off slots XCH_LEG.. behind one more barrier.
-template <int NS, bool UPDATE, class CORR = NoCorr, bool PREDICT = true, bool LEG = false, class LD, class ST, class XW, class XR, class SYNC>
+// SIX: LegOdoCommon's six-row measurements in the SAME state round trip, as two 3-row blocks with one summed correction (SixIn):
+//   1  lin_rot_rate: the angular-velocity block FIRST, by role P -- behind a predict P(omega, omega) = q_gyro I (rbis.cpp:121), so
+//      S = (q_gyro + r) I needs no factorisation; role P publishes 1/d, y/d and its P(c, omega) rows BEFORE barrier L, role C
+//      downdates its sub-matrix with them and runs the velocity block on the result: no extra barrier.
+//   2  pos_and_lin_rate: the velocity block, then CORR = CorrPos on its posterior with the correction summed (the CORR stage
+//      otherwise is a second, separate update: two addState calls, like the reference's two updateFilter calls).
+template <int NS, bool UPDATE, class CORR = NoCorr, bool PREDICT = true, bool LEG = false, int SIX = 0, class LD, class ST, class XW, class XR, class SYNC>
 PB_HD void coop_role_core(LD ld, ST st, XW xw, XR xr, SYNC sync, const StepInputs &in, const Consts &k,
-                          const CorrInputs &cin = CorrInputs())
+                          const CorrInputs &cin_ = CorrInputs())
 {
   static_assert(!LEG || (UPDATE && PREDICT), "the odometry wave feeds a predict + update step");
+  static_assert(SIX == 0 || (UPDATE && PREDICT), "the six-row leg-odometry modes ride on a predict + velocity update");
+  static_assert(SIX != 2 || (CORR::M == 3 && !CORR::ORIENT), "SIX == 2: the second block is a 3-row vector block of role C's states");
+  static_assert(SIX != 1 || CORR::M == 0, "SIX == 1 has no CORR stage");
   using L = Lay<NS>;
   using C = Coop<NS>;
   constexpr int NSC = C::NSC;
@@ -246,15 +270,45 @@ PB_HD void coop_role_core(LD ld, ST st, XW xw, XR xr, SYNC sync, const StepInput
   ins_update_state<NS>(x, q, in.gyro, in.accel, in.dt, k);
   }  // PREDICT
 
+  double dfull[NS];   // the velocity block's correction (SIX == 2: applied together with the second block's)
+#pragma unroll
+  for (int i = 0; i < NS; i++) dfull[i] = 0.0;
+  bool upd1 = false;
+  double leg2[5] = { 0.0, 0.0, 0.0, 1.0, 0.0 };
   if constexpr (UPDATE) {
     // S = R + P[v,v]; unpivoted LDL^T; y = L^-1 r  (rbis.cpp:124-143)
     double resid[3], S[6], d[3], y[3], id[3], yd[3];
     double mz[3], mr[3];
+    double dx1[SIX == 1 ? NSC : 1], idw = 0.0;   // SIX == 1: the omega block's share of the correction; 1/d (0: no such block)
+    dx1[0] = 0.0;
     bool mupd = in.upd;
+    if constexpr (LEG || SIX == 1) sync();  // barrier L
+    if constexpr (SIX == 1) {
+      // the angular-velocity block, applied by role P to its panels; here: P_cc -= A A^T / d, dx_c = A (y / d) with A = P'(c, omega)
+      using CX = CoopX<NS, CORR>;
+      idw = xr(CX::X6_ID);
+      const double ydw[3] = { xr(CX::X6_YD), xr(CX::X6_YD + 1), xr(CX::X6_YD + 2) };
+      if constexpr (!C::LL_IN_P) ll += xr(CX::X6_LLI);
+      double A[NSC][3];
+#pragma unroll
+      for (int i = 0; i < NSC; i++)
+#pragma unroll
+        for (int kk = 0; kk < 3; kk++) A[i][kk] = xr(CX::X6_A + 3 * i + kk);
+#pragma unroll
+      for (int i = 0; i < NSC; i++) {
+        const double ad[3] = { A[i][0] * idw, A[i][1] * idw, A[i][2] * idw };
+        dx1[i] = fma(A[i][2], ydw[2], fma(A[i][1], ydw[1], A[i][0] * ydw[0]));
+#pragma unroll
+        for (int j = 0; j <= i; j++) Pc[pk(i, j)] = fma(-ad[2], A[j][2], fma(-ad[1], A[j][1], fma(-ad[0], A[j][0], Pc[pk(i, j)])));
+      }
+    }
     if constexpr (LEG) {
-      sync();
       const double r = xr(CoopX<NS, CORR>::XCH_LEG + 3);
       mupd = in.upd && xr(CoopX<NS, CORR>::XCH_LEG + 4) != 0.0;
+      if constexpr (SIX == 2) {
+#pragma unroll
+        for (int i = 0; i < 5; i++) leg2[i] = xr(CoopX<NS, CORR>::XCH_LEG + 5 + i);
+      }
 #pragma unroll
       for (int i = 0; i < 3; i++) { mz[i] = xr(CoopX<NS, CORR>::XCH_LEG + i); mr[i] = r; }
     } else {
@@ -262,7 +316,7 @@ PB_HD void coop_role_core(LD ld, ST st, XW xw, XR xr, SYNC sync, const StepInput
       for (int i = 0; i < 3; i++) { mz[i] = in.z[i]; mr[i] = in.rd[i]; }
     }
 #pragma unroll
-    for (int i = 0; i < 3; i++) resid[i] = mupd ? mz[i] - x[3 + i] : 0.0;
+    for (int i = 0; i < 3; i++) resid[i] = mupd ? mz[i] - (SIX == 1 ? x[3 + i] + dx1[i] : x[3 + i]) : 0.0;
 #pragma unroll
     for (int i = 0; i < 3; i++)
 #pragma unroll
@@ -303,15 +357,12 @@ PB_HD void coop_role_core(LD ld, ST st, XW xw, XR xr, SYNC sync, const StepInput
       for (int kk = 0; kk < 3; kk++) xw(9 + 3 * i + kk, W[i][kk]);
     sync();
     // downdate + store own entries, dx for own states
-    double dfull[NS];
-#pragma unroll
-    for (int i = 0; i < NS; i++) dfull[i] = 0.0;
 #pragma unroll
     for (int i = 0; i < NSC; i++) {
       double wd[3];
 #pragma unroll
       for (int kk = 0; kk < 3; kk++) wd[kk] = W[i][kk] * id[kk];
-      dfull[C::fullc(i)] = fma(W[i][2], yd[2], fma(W[i][1], yd[1], W[i][0] * yd[0]));
+      dfull[C::fullc(i)] = fma(W[i][2], yd[2], fma(W[i][1], yd[1], W[i][0] * yd[0])) + (SIX == 1 ? dx1[i] : 0.0);
 #pragma unroll
       for (int j = 0; j <= i; j++) {
         double acc = Pc[pk(i, j)];
@@ -321,19 +372,29 @@ PB_HD void coop_role_core(LD ld, ST st, XW xw, XR xr, SYNC sync, const StepInput
         else Pc[pk(i, j)] = acc;  // row i of W is not needed for any later row j' > i's column i: W[i] stays as is
       }
     }
-    if (mupd) add_delta<NS>(x, q, dfull, k.chi_tol);
+    upd1 = mupd || idw != 0.0;
+    if constexpr (SIX != 2) {
+      if (upd1) add_delta<NS>(x, q, dfull, k.chi_tol);
+    }
   }
   if constexpr (CORR::M > 0) {
     // ---- the second update on the posterior of the first (indexedPlusOrientationMeasurement, rbis.cpp:189-217) ----
     constexpr int M = CORR::M;
     using CX = CoopX<NS, CORR>;
+    CorrInputs cin = cin_;
+    if constexpr (LEG && SIX == 2) {  // the position block of the odometry wave's measurement (read behind barrier L, before
+      // this role's first hand-off: the slots are the second hand-off's)
+#pragma unroll
+      for (int i = 0; i < 3; i++) { cin.z[i] = leg2[i]; cin.rd[i] = leg2[3]; }
+      cin.upd = in.upd && leg2[4] != 0.0;
+    }
     double r2[M], S2[M * (M + 1) / 2], d2[M], y2[M], id2[M], yd2[M];
     double dq3[3] = { 0.0, 0.0, 0.0 };
     if constexpr (CORR::ORIENT) subtract_quats(cin.qm, q, dq3);
 #pragma unroll
     for (int kk = 0; kk < M; kk++) {
       const int ii = C::fullc(CORR::sub[kk]);
-      const double r = (CORR::ORIENT && ii >= 6 && ii <= 8) ? dq3[ii - 6] : cin.z[kk] - x[ii];
+      const double r = (CORR::ORIENT && ii >= 6 && ii <= 8) ? dq3[ii - 6] : cin.z[kk] - (SIX == 2 ? x[ii] + dfull[ii] : x[ii]);
       r2[kk] = cin.upd ? r : 0.0;
     }
 #pragma unroll
@@ -402,7 +463,13 @@ PB_HD void coop_role_core(LD ld, ST st, XW xw, XR xr, SYNC sync, const StepInput
         st(L::OFF_P + pk(C::fullc(i), C::fullc(j)), acc);
       }
     }
-    if (cin.upd) add_delta<NS>(x, q, dfull2, k.chi_tol);
+    if constexpr (SIX == 2) {  // ONE addState of the summed correction (both terms are zero where their block is masked)
+#pragma unroll
+      for (int i = 0; i < NS; i++) dfull2[i] += dfull[i];
+      if (upd1 || cin.upd) add_delta<NS>(x, q, dfull2, k.chi_tol);
+    } else {
+      if (cin.upd) add_delta<NS>(x, q, dfull2, k.chi_tol);
+    }
   }
   if constexpr (!UPDATE && CORR::M == 0) {
 #pragma unroll
@@ -425,10 +492,12 @@ PB_HD void coop_role_core(LD ld, ST st, XW xw, XR xr, SYNC sync, const StepInput
 // ------------------------------------------------------------------------------------------------------------
 // role P: passive panels P_cp, P_bp, P_pp and the omega / accel entries of x.   XR(slot) reads the hand-off.
 // ------------------------------------------------------------------------------------------------------------
-template <int NS, bool UPDATE, class CORR = NoCorr, bool PREDICT = true, class LD, class ST, class XR, class SYNC>
-PB_HD void coop_role_passive(LD ld, ST st, XR xr, SYNC sync, const StepInputs &in, const Consts &k,
-                             const CorrInputs &cin = CorrInputs())
+// SIX == 1: this role applies the angular-velocity block of lin_rot_rate (see coop_role_core) -- XW publishes its factors.
+template <int NS, bool UPDATE, class CORR = NoCorr, bool PREDICT = true, int SIX = 0, class LD, class ST, class XW, class XR, class SYNC>
+PB_HD void coop_role_passive_x(LD ld, ST st, XW xw, XR xr, SYNC sync, const StepInputs &in, const Consts &k,
+                               const CorrInputs &cin = CorrInputs(), const SixIn &six = SixIn())
 {
+  static_assert(SIX != 1 || (UPDATE && PREDICT && CORR::M == 0), "SIX == 1 rides on a predict + velocity update");
   using L = Lay<NS>;
   using C = Coop<NS>;
   double x[NS], q[4] = { 1.0, 0.0, 0.0, 0.0 };
@@ -508,6 +577,60 @@ PB_HD void coop_role_passive(LD ld, ST st, XR xr, SYNC sync, const StepInputs &i
   }
   }  // PREDICT
 
+  if constexpr (SIX == 1) {
+    // ---- the angular-velocity block: S = (q_gyro + r) I, W = P'[:, omega], no factorisation ----
+    using CX = CoopX<NS, CORR>;
+    const double idw = six.on ? 1.0 / (in.qg + six.r) : 0.0;
+    double ydw[3], quad = 0.0;
+#pragma unroll
+    for (int kk = 0; kk < 3; kk++) {
+      const double res = six.on ? six.z[kk] - xp[kk] : 0.0;
+      ydw[kk] = res * idw;
+      quad = fma(res, ydw[kk], quad);
+    }
+    const double dw = in.qg + six.r;
+    const double lliw = six.on ? -log(dw * dw * dw) - quad : 0.0;   // -log det S - r^T S^-1 r of this block
+    xw(CX::X6_ID, idw);
+#pragma unroll
+    for (int kk = 0; kk < 3; kk++) xw(CX::X6_YD + kk, ydw[kk]);
+    if constexpr (!C::LL_IN_P) xw(CX::X6_LLI, lliw);
+    else ll += lliw;
+#pragma unroll
+    for (int sb = 0; sb < NSB; sb++)
+#pragma unroll
+      for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int kk = 0; kk < 3; kk++) xw(CX::X6_A + 3 * (3 * sb + r) + kk, X[sb][0][3 * r + kk]);
+    sync();  // barrier L
+    // own entries: the accel panel with P'(a, omega) (untouched by the predict), the omega panel and P_pp in closed form
+    const double keep = fma(-in.qg, idw, 1.0);   // 1 - q_gyro / d
+#pragma unroll
+    for (int sb = 0; sb < NSB; sb++)
+#pragma unroll
+      for (int r = 0; r < 3; r++) {
+        const double ad[3] = { X[sb][0][3 * r] * idw, X[sb][0][3 * r + 1] * idw, X[sb][0][3 * r + 2] * idw };
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+          X[sb][1][3 * r + c] = fma(-ad[2], Ppp[pk(3 + c, 2)], fma(-ad[1], Ppp[pk(3 + c, 1)], fma(-ad[0], Ppp[pk(3 + c, 0)], X[sb][1][3 * r + c])));
+          X[sb][0][3 * r + c] *= keep;
+        }
+      }
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      const double ad[3] = { Ppp[pk(3 + r, 0)] * idw, Ppp[pk(3 + r, 1)] * idw, Ppp[pk(3 + r, 2)] * idw };
+      xp[3 + r] += fma(Ppp[pk(3 + r, 2)], ydw[2], fma(Ppp[pk(3 + r, 1)], ydw[1], Ppp[pk(3 + r, 0)] * ydw[0]));
+#pragma unroll
+      for (int c = 0; c <= r; c++)
+        Ppp[pk(3 + r, 3 + c)] = fma(-ad[2], Ppp[pk(3 + c, 2)], fma(-ad[1], Ppp[pk(3 + c, 1)], fma(-ad[0], Ppp[pk(3 + c, 0)], Ppp[pk(3 + r, 3 + c)])));
+    }
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+#pragma unroll
+      for (int c = 0; c < 3; c++) Ppp[pk(3 + r, c)] *= keep;
+      Ppp[pk(r, r)] = in.qg * keep;
+      xp[r] = fma(in.qg, ydw[r], xp[r]);
+    }
+  }
   if constexpr (!UPDATE && CORR::M == 0) sync();  // pairs with role C's barrier before it overwrites x / quat
   if constexpr (UPDATE) {
     sync();
@@ -641,6 +764,12 @@ PB_HD void coop_role_passive(LD ld, ST st, XR xr, SYNC sync, const StepInputs &i
   if constexpr (C::LL_IN_P) st(L::OFF_LL, ll);
 #pragma unroll
   for (int i = 0; i < 6; i++) st(L::OFF_VEC + C::fullp(i), xp[i]);
+}
+template <int NS, bool UPDATE, class CORR = NoCorr, bool PREDICT = true, class LD, class ST, class XR, class SYNC>
+PB_HD void coop_role_passive(LD ld, ST st, XR xr, SYNC sync, const StepInputs &in, const Consts &k,
+                             const CorrInputs &cin = CorrInputs())
+{
+  coop_role_passive_x<NS, UPDATE, CORR, PREDICT, 0>(ld, st, [](int, double) {}, xr, sync, in, k, cin);
 }
 
 }  // namespace pb

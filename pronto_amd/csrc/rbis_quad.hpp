@@ -37,7 +37,14 @@ struct Quad {
   static constexpr int X_H2 = 72;  // the F_cb T1^T part of H: chi-v block (9, row-major), chi-chi block (6, packed)
   static constexpr int X_XV = 87;  // the propagated velocity x'[3..5] (role PW -> role CC, for the residual)
   static constexpr int NXCH = 90;
-  static constexpr int X_LEG = 90, X_FOOT = 95, NXCH_LEG = 109;  // k_step_quad_leg: z[3], R, valid from the odometry (role PW) before barrier A; the two foot poses (2 x 7) from roles CC / CB
+  // k_step_quad_leg: z[3], R, valid -- and a six-row mode's second block z[3], R, on -- from the odometry (role PW) before barrier
+  // A; SIX == 2: the propagated position x'[9..11] (role PW -> role CC); the two foot poses (2 x 7) from two other roles
+  static constexpr int X_LEG = 90, X_XD = 100, X_FOOT = 103;
+  // SIX == 1 (rbis_coop.hpp, coop_role_core): role PW's omega stage -- 1/d, y/d (3), its log-likelihood term, P'(c b, omega) (45) --
+  // written before barrier A over the foot poses (role PW has consumed them by then)
+  static constexpr int X6_ID = 103, X6_YD = 104, X6_LLI = 107, X6_A = 108;
+  PB_HD static constexpr int nxch_leg(int six) { return six == 1 ? X6_A + 45 : X_FOOT + 14; }   // 153 | 117: two workgroups per CU fit 160 KB
+  static constexpr int NXCH_SIX = X6_A + 45;
 };
 
 // (X hat(m)^T)[r][c] = (m x X_r)[c] for a row-major 3x3 block X
@@ -67,9 +74,15 @@ PB_HD void fcc_apply(const ProcBlocks &f, double (&V)[9], double (&Cc)[9], doubl
 // wave 0, role CC: P_cc, loglik
 // ------------------------------------------------------------------------------------------------------------
 // LEG: the leg-odometry measurement is made by role PW of the same tile before barrier A (k_step_quad_leg, rbis_legstep.hpp)
-template <bool UPDATE, bool LEG = false, class LD, class ST, class XW, class XR, class SYNC>
-PB_HD void quad_role_cc(LD ld, ST st, XW xw, XR xr, SYNC sync, const StepInputs &in, const Consts &k)
+// SIX: LegOdoCommon's six-row measurements as two 3-row blocks with ONE summed correction (rbis_coop.hpp, coop_role_core):
+//   1  the angular-velocity block first, by role PW before barrier A (S = (q_gyro + r) I): every role downdates its entries with
+//      P'(:, omega) behind barrier A, then the velocity block runs on the result -- no extra barrier
+//   2  the velocity block, then the position block on its posterior: barrier B2 (every role has consumed the first hand-off, whose
+//      slots the second one re-uses) and barrier C (role CC has published the second factors)
+template <bool UPDATE, bool LEG = false, int SIX = 0, class LD, class ST, class XW, class XR, class SYNC>
+PB_HD void quad_role_cc(LD ld, ST st, XW xw, XR xr, SYNC sync, const StepInputs &in, const Consts &k, const SixIn &six = SixIn())
 {
+  static_assert(SIX == 0 || UPDATE, "the six-row leg-odometry modes ride on the velocity update");
   constexpr int NS = 21;
   using L = Lay<NS>;
   double x[NS], q[4];
@@ -128,10 +141,22 @@ PB_HD void quad_role_cc(LD ld, ST st, XW xw, XR xr, SYNC sync, const StepInputs 
     leg_r = xr(Quad::X_LEG + 3);
     leg_valid = xr(Quad::X_LEG + 4);
   }
+  double z2[3] = { six.z[0], six.z[1], six.z[2] }, r2 = six.r, xd[3] = { 0.0, 0.0, 0.0 };
+  bool upd2 = six.on;
+  if constexpr (SIX == 2) {
+    if constexpr (LEG) {
+#pragma unroll
+      for (int i = 0; i < 3; i++) z2[i] = xr(Quad::X_LEG + 5 + i);
+      r2 = xr(Quad::X_LEG + 8);
+      upd2 = in.upd && xr(Quad::X_LEG + 9) != 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < 3; i++) xd[i] = xr(Quad::X_XD + i);
+  }
   double xv[3] = { 0.0, 0.0, 0.0 };
   if constexpr (UPDATE) {
 #pragma unroll
-    for (int i = 0; i < 3; i++) xv[i] = xr(Quad::X_XV + i);
+    for (int i = 0; i < 3; i++) xv[i] = xr(Quad::X_XV + i);   // (SIX == 1: role PW has added the omega block's correction)
   }
 #pragma unroll
   for (int i = 0; i < 9; i++)
@@ -145,6 +170,21 @@ PB_HD void quad_role_cc(LD ld, ST st, XW xw, XR xr, SYNC sync, const StepInputs 
       Pc[pk(3 + r, c)] += xr(Quad::X_H2 + 3 * r + c);
       if (c <= r) Pc[pk(3 + r, 3 + c)] += xr(Quad::X_H2 + 9 + pk(r, c));
     }
+  if constexpr (SIX == 1) {  // the angular-velocity block: P_cc -= A A^T / d with A = P'(c, omega) from role PW
+    const double idw = xr(Quad::X6_ID);
+    ll += xr(Quad::X6_LLI);
+    double A[9][3];
+#pragma unroll
+    for (int i = 0; i < 9; i++)
+#pragma unroll
+      for (int kk = 0; kk < 3; kk++) A[i][kk] = xr(Quad::X6_A + 3 * i + kk);
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+      const double ad[3] = { A[i][0] * idw, A[i][1] * idw, A[i][2] * idw };
+#pragma unroll
+      for (int j = 0; j <= i; j++) Pc[pk(i, j)] = fma(-ad[2], A[j][2], fma(-ad[1], A[j][1], fma(-ad[0], A[j][0], Pc[pk(i, j)])));
+    }
+  }
 
   if constexpr (UPDATE) {
     // S = R + P[v,v]; unpivoted LDL^T; y = L^-1 r  (rbis.cpp:124-143)
@@ -208,12 +248,73 @@ PB_HD void quad_role_cc(LD ld, ST st, XW xw, XR xr, SYNC sync, const StepInputs 
         double acc = Pc[pk(i, j)];
 #pragma unroll
         for (int kk = 0; kk < 3; kk++) acc = fma(-wd[kk], W[j][kk], acc);
-        st(L::OFF_P + pk(core_full(i), core_full(j)), acc);
+        if constexpr (SIX == 2) Pc[pk(i, j)] = acc;
+        else st(L::OFF_P + pk(core_full(i), core_full(j)), acc);
       }
     }
     // -log(S.determinant()) - r^T S^-1 r (rbis.cpp:142): ONE log of the product, behind everything the other waves or
     // the memory system wait for
     if (mupd) ll += -log(det) - quad;
+    if constexpr (SIX == 2) {
+      // ---- the position block on the posterior of the velocity block; residual at x + dx of the first ----
+      double rs2[3], S2[6], d2[3], y2[3], id2[3], yd2[3];
+#pragma unroll
+      for (int i = 0; i < 3; i++) {
+        const double dxd = fma(W[6 + i][2], yd[2], fma(W[6 + i][1], yd[1], W[6 + i][0] * yd[0]));
+        rs2[i] = upd2 ? z2[i] - (xd[i] + dxd) : 0.0;
+      }
+#pragma unroll
+      for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j <= i; j++) S2[pk(i, j)] = Pc[pk(6 + i, 6 + j)] + (i == j ? (upd2 ? r2 : 1.0) : 0.0);
+      ldlt<3>(S2, d2);
+      double quad2 = 0.0, det2 = 1.0;
+#pragma unroll
+      for (int kk = 0; kk < 3; kk++) {
+        double s2 = rs2[kk];
+#pragma unroll
+        for (int j = 0; j < kk; j++) s2 -= S2[pk(kk, j)] * y2[j];
+        y2[kk] = upd2 ? s2 : 0.0;
+        id2[kk] = upd2 ? 1.0 / d2[kk] : 0.0;
+        yd2[kk] = y2[kk] * id2[kk];
+        det2 *= d2[kk];
+        quad2 += s2 * s2 * id2[kk];
+      }
+#pragma unroll
+      for (int i = 0; i < 9; i++)
+#pragma unroll
+        for (int kk = 0; kk < 3; kk++) {
+          double s2 = Pc[pk(i, 6 + kk)];
+#pragma unroll
+          for (int j = 0; j < kk; j++) s2 -= W[i][j] * S2[pk(kk, j)];
+          W[i][kk] = s2;
+        }
+      sync();  // B2: every role has consumed the first hand-off
+      xw(Quad::X_L + 0, S2[pk(1, 0)]); xw(Quad::X_L + 1, S2[pk(2, 0)]); xw(Quad::X_L + 2, S2[pk(2, 1)]);
+#pragma unroll
+      for (int kk = 0; kk < 3; kk++) { xw(Quad::X_ID + kk, id2[kk]); xw(Quad::X_YD + kk, yd2[kk]); }
+#pragma unroll
+      for (int i = 0; i < 9; i++) {
+#pragma unroll
+        for (int kk = 0; kk < 3; kk++) xw(Quad::X_WC + 3 * i + kk, W[i][kk]);
+        xw(Quad::X_DX + i, fma(W[i][2], yd2[2], fma(W[i][1], yd2[1], W[i][0] * yd2[0])));
+      }
+      sync();  // C
+#pragma unroll
+      for (int i = 0; i < 9; i++) {
+        double wd[3];
+#pragma unroll
+        for (int kk = 0; kk < 3; kk++) wd[kk] = W[i][kk] * id2[kk];
+#pragma unroll
+        for (int j = 0; j <= i; j++) {
+          double acc = Pc[pk(i, j)];
+#pragma unroll
+          for (int kk = 0; kk < 3; kk++) acc = fma(-wd[kk], W[j][kk], acc);
+          st(L::OFF_P + pk(core_full(i), core_full(j)), acc);
+        }
+      }
+      if (upd2) ll += -log(det2) - quad2;
+    }
   } else {
 #pragma unroll
     for (int i = 0; i < 9; i++)
@@ -226,7 +327,7 @@ PB_HD void quad_role_cc(LD ld, ST st, XW xw, XR xr, SYNC sync, const StepInputs 
 // ------------------------------------------------------------------------------------------------------------
 // wave 1, role CB: P_cb, P_bb, x[bg ba], x[omega]
 // ------------------------------------------------------------------------------------------------------------
-template <bool UPDATE, class LD, class ST, class XW, class XR, class SYNC>
+template <bool UPDATE, int SIX = 0, class LD, class ST, class XW, class XR, class SYNC>
 PB_HD void quad_role_cb(LD ld, ST st, XW xw, XR xr, SYNC sync, const StepInputs &in, const Consts &k)
 {
   constexpr int NS = 21;
@@ -305,7 +406,7 @@ PB_HD void quad_role_cb(LD ld, ST st, XW xw, XR xr, SYNC sync, const StepInputs 
       xw(Quad::X_H + pk(6 + r, c), x_hat_t(Y[2][0], f.a_mv, r, c) - in.dt * Y[2][1][3 * r + c]);
       xw(Quad::X_H + pk(6 + r, 3 + c), -in.dt * Y[2][0][3 * r + c]);
     }
-  if constexpr (UPDATE) {
+  if constexpr (UPDATE && SIX != 1) {
 #pragma unroll
     for (int j = 0; j < 6; j++)
 #pragma unroll
@@ -317,6 +418,39 @@ PB_HD void quad_role_cb(LD ld, ST st, XW xw, XR xr, SYNC sync, const StepInputs 
     Pbb[pk(3 + r, 3 + r)] += in.qba * in.dt;
   }
   sync();  // A
+  if constexpr (SIX == 1) {
+    // the angular-velocity block (role PW's factors): P_cb -= A_c A_b^T / d, P_bb -= A_b A_b^T / d, x_b += A_b (y / d),
+    // x_omega += q_gyro (y / d); only then the raw P'(v, b) columns of the velocity block (needed behind barrier B)
+    const double idw = xr(Quad::X6_ID);
+    const double ydw[3] = { xr(Quad::X6_YD), xr(Quad::X6_YD + 1), xr(Quad::X6_YD + 2) };
+    double Ab[6][3];
+#pragma unroll
+    for (int j = 0; j < 6; j++)
+#pragma unroll
+      for (int kk = 0; kk < 3; kk++) Ab[j][kk] = xr(Quad::X6_A + 3 * (9 + j) + kk);
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+      const double ad[3] = { xr(Quad::X6_A + 3 * i) * idw, xr(Quad::X6_A + 3 * i + 1) * idw, xr(Quad::X6_A + 3 * i + 2) * idw };
+#pragma unroll
+      for (int j = 0; j < 6; j++) {
+        double &e = Y[i / 3][j / 3][3 * (i % 3) + j % 3];
+        e = fma(-ad[2], Ab[j][2], fma(-ad[1], Ab[j][1], fma(-ad[0], Ab[j][0], e)));
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+      const double ad[3] = { Ab[j][0] * idw, Ab[j][1] * idw, Ab[j][2] * idw };
+      xb[j] += fma(Ab[j][2], ydw[2], fma(Ab[j][1], ydw[1], Ab[j][0] * ydw[0]));
+#pragma unroll
+      for (int j2 = 0; j2 <= j; j2++) Pbb[pk(j, j2)] = fma(-ad[2], Ab[j2][2], fma(-ad[1], Ab[j2][1], fma(-ad[0], Ab[j2][0], Pbb[pk(j, j2)])));
+    }
+#pragma unroll
+    for (int c = 0; c < 3; c++) xw_[c] = fma(in.qg, ydw[c], xw_[c]);
+#pragma unroll
+    for (int j = 0; j < 6; j++)
+#pragma unroll
+      for (int kk = 0; kk < 3; kk++) xw(Quad::X_BV + 3 * j + kk, Y[0][j / 3][3 * kk + j % 3]);
+  }
   if constexpr (UPDATE) {
     sync();  // B
     const double L10 = xr(Quad::X_L + 0), L20 = xr(Quad::X_L + 1), L21 = xr(Quad::X_L + 2);
@@ -350,14 +484,63 @@ PB_HD void quad_role_cb(LD ld, ST st, XW xw, XR xr, SYNC sync, const StepInputs 
         double acc = Y[i / 3][j / 3][3 * (i % 3) + j % 3];
 #pragma unroll
         for (int kk = 0; kk < 3; kk++) acc = fma(-wd[kk], xr(Quad::X_WC + 3 * i + kk), acc);
-        st(L::OFF_P + pk(core_full(9 + j), core_full(i)), acc);
+        if constexpr (SIX == 2) Y[i / 3][j / 3][3 * (i % 3) + j % 3] = acc;
+        else st(L::OFF_P + pk(core_full(9 + j), core_full(i)), acc);
       }
 #pragma unroll
       for (int j2 = 0; j2 <= j; j2++) {
         double acc = Pbb[pk(j, j2)];
 #pragma unroll
         for (int kk = 0; kk < 3; kk++) acc = fma(-wd[kk], Wb[j2][kk], acc);
-        st(L::OFF_P + pk(core_full(9 + j), core_full(9 + j2)), acc);
+        if constexpr (SIX == 2) Pbb[pk(j, j2)] = acc;
+        else st(L::OFF_P + pk(core_full(9 + j), core_full(9 + j2)), acc);
+      }
+    }
+    if constexpr (SIX == 2) {
+      // ---- the position block: this role's raw P''(Delta, b) columns go where the first block's P'(v, b) were ----
+      sync();  // B2
+#pragma unroll
+      for (int j = 0; j < 6; j++)
+#pragma unroll
+        for (int kk = 0; kk < 3; kk++) xw(Quad::X_BV + 3 * j + kk, Y[2][j / 3][3 * kk + j % 3]);
+      sync();  // C
+      const double M10 = xr(Quad::X_L + 0), M20 = xr(Quad::X_L + 1), M21 = xr(Quad::X_L + 2);
+#pragma unroll
+      for (int kk = 0; kk < 3; kk++) { id[kk] = xr(Quad::X_ID + kk); yd[kk] = xr(Quad::X_YD + kk); }
+#pragma unroll
+      for (int j = 0; j < 6; j++) {
+        const double c0 = Y[2][j / 3][0 + j % 3], c1 = Y[2][j / 3][3 + j % 3], c2 = Y[2][j / 3][6 + j % 3];
+        Wb[j][0] = c0;
+        Wb[j][1] = c1 - Wb[j][0] * M10;
+        Wb[j][2] = c2 - Wb[j][0] * M20 - Wb[j][1] * M21;
+        xb[j] += fma(Wb[j][2], yd[2], fma(Wb[j][1], yd[1], Wb[j][0] * yd[0]));
+      }
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        const double w0 = xr(Quad::X_VW + 3 * c + 0);
+        const double w1 = xr(Quad::X_VW + 3 * c + 1) - w0 * M10;
+        const double w2 = xr(Quad::X_VW + 3 * c + 2) - w0 * M20 - w1 * M21;
+        xw_[c] += fma(w2, yd[2], fma(w1, yd[1], w0 * yd[0]));
+      }
+#pragma unroll
+      for (int j = 0; j < 6; j++) {
+        double wd[3];
+#pragma unroll
+        for (int kk = 0; kk < 3; kk++) wd[kk] = Wb[j][kk] * id[kk];
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+          double acc = Y[i / 3][j / 3][3 * (i % 3) + j % 3];
+#pragma unroll
+          for (int kk = 0; kk < 3; kk++) acc = fma(-wd[kk], xr(Quad::X_WC + 3 * i + kk), acc);
+          st(L::OFF_P + pk(core_full(9 + j), core_full(i)), acc);
+        }
+#pragma unroll
+        for (int j2 = 0; j2 <= j; j2++) {
+          double acc = Pbb[pk(j, j2)];
+#pragma unroll
+          for (int kk = 0; kk < 3; kk++) acc = fma(-wd[kk], Wb[j2][kk], acc);
+          st(L::OFF_P + pk(core_full(9 + j), core_full(9 + j2)), acc);
+        }
       }
     }
   } else {
@@ -379,8 +562,8 @@ PB_HD void quad_role_cb(LD ld, ST st, XW xw, XR xr, SYNC sync, const StepInputs 
 // waves 2 and 3, roles PW (J = 0: omega; + x[v chi Delta], quat) and PA (J = 1: accel; + x[accel]): one block column of
 // the passive panels each
 // ------------------------------------------------------------------------------------------------------------
-template <bool UPDATE, int J, class LD, class ST, class XW, class XR, class SYNC>
-PB_HD void quad_role_passive(LD ld, ST st, XW xw, XR xr, SYNC sync, const StepInputs &in, const Consts &k)
+template <bool UPDATE, int J, int SIX = 0, class LD, class ST, class XW, class XR, class SYNC>
+PB_HD void quad_role_passive(LD ld, ST st, XW xw, XR xr, SYNC sync, const StepInputs &in, const Consts &k, const SixIn &six = SixIn())
 {
   constexpr int NS = 21;
   using L = Lay<NS>;
@@ -430,12 +613,49 @@ PB_HD void quad_role_passive(LD ld, ST st, XW xw, XR xr, SYNC sync, const StepIn
   double xp[3];  // J == 1: rbis.cpp:51
 #pragma unroll
   for (int i = 0; i < 3; i++) xp[i] = in.accel[i] - x[18 + i];
+  double dx1[9];    // SIX == 1, role PW: the omega block's correction of x[v chi Delta]
+  double dsum[9];   // SIX == 2, role PW: the velocity block's correction, applied together with the position block's
+#pragma unroll
+  for (int i = 0; i < 9; i++) dx1[i] = dsum[i] = 0.0;
   if constexpr (J == 0) {
     // state propagate (rbis.cpp:37-75) on this role's copy: x[v chi Delta] and quat are its to store
     ins_update_state<NS>(x, q, in.gyro, in.accel, in.dt, k);
+    if constexpr (SIX == 1) {
+      // ---- the angular-velocity block: S = (q_gyro + r) I, W = P'[:, omega] = this role's panel; no factorisation ----
+      const double dw = in.qg + six.r;
+      const double idw = six.on ? 1.0 / dw : 0.0;
+      double ydw[3], quad = 0.0;
+#pragma unroll
+      for (int kk = 0; kk < 3; kk++) {
+        const double res = six.on ? six.z[kk] - x[kk] : 0.0;   // x[0..2] = gyro - bias (rbis.cpp:50)
+        ydw[kk] = res * idw;
+        quad = fma(res, ydw[kk], quad);
+      }
+      xw(Quad::X6_ID, idw);
+#pragma unroll
+      for (int kk = 0; kk < 3; kk++) xw(Quad::X6_YD + kk, ydw[kk]);
+      xw(Quad::X6_LLI, six.on ? -log(dw * dw * dw) - quad : 0.0);
+      const double keep = fma(-in.qg, idw, 1.0);   // 1 - q_gyro / d
+#pragma unroll
+      for (int sb = 0; sb < 5; sb++)
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+#pragma unroll
+          for (int kk = 0; kk < 3; kk++) xw(Quad::X6_A + 3 * (3 * sb + r) + kk, X[sb][3 * r + kk]);
+          if (sb < 3) dx1[3 * sb + r] = fma(X[sb][3 * r + 2], ydw[2], fma(X[sb][3 * r + 1], ydw[1], X[sb][3 * r] * ydw[0]));
+#pragma unroll
+          for (int kk = 0; kk < 3; kk++) X[sb][3 * r + kk] *= keep;
+        }
+#pragma unroll
+      for (int r = 0; r < 3; r++) Pjj[pk(r, r)] = in.qg * keep;
+    }
     if constexpr (UPDATE) {
 #pragma unroll
-      for (int i = 0; i < 3; i++) xw(Quad::X_XV + i, x[3 + i]);
+      for (int i = 0; i < 3; i++) xw(Quad::X_XV + i, SIX == 1 ? x[3 + i] + dx1[i] : x[3 + i]);
+      if constexpr (SIX == 2) {
+#pragma unroll
+        for (int i = 0; i < 3; i++) xw(Quad::X_XD + i, x[9 + i]);
+      }
 #pragma unroll
       for (int c = 0; c < 3; c++)
 #pragma unroll
@@ -443,6 +663,31 @@ PB_HD void quad_role_passive(LD ld, ST st, XW xw, XR xr, SYNC sync, const StepIn
     }
   }
   sync();  // A
+  if constexpr (SIX == 1 && J == 1) {
+    // the angular-velocity block on the accel panel: P'(a, omega) is this role's (untouched by the predict)
+    const double idw = xr(Quad::X6_ID);
+    const double ydw[3] = { xr(Quad::X6_YD), xr(Quad::X6_YD + 1), xr(Quad::X6_YD + 2) };
+#pragma unroll
+    for (int sb = 0; sb < 5; sb++)
+#pragma unroll
+      for (int r = 0; r < 3; r++) {
+        const int i = 3 * sb + r;
+        const double ad[3] = { xr(Quad::X6_A + 3 * i) * idw, xr(Quad::X6_A + 3 * i + 1) * idw, xr(Quad::X6_A + 3 * i + 2) * idw };
+#pragma unroll
+        for (int c = 0; c < 3; c++)
+          X[sb][3 * r + c] = fma(-ad[2], Paw[3 * c + 2], fma(-ad[1], Paw[3 * c + 1], fma(-ad[0], Paw[3 * c], X[sb][3 * r + c])));
+      }
+    const double keep = fma(-in.qg, idw, 1.0);
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      const double ad[3] = { Paw[3 * r] * idw, Paw[3 * r + 1] * idw, Paw[3 * r + 2] * idw };
+      xp[r] += fma(Paw[3 * r + 2], ydw[2], fma(Paw[3 * r + 1], ydw[1], Paw[3 * r] * ydw[0]));
+#pragma unroll
+      for (int c = 0; c <= r; c++) Pjj[pk(r, c)] = fma(-ad[2], Paw[3 * c + 2], fma(-ad[1], Paw[3 * c + 1], fma(-ad[0], Paw[3 * c], Pjj[pk(r, c)])));
+    }
+#pragma unroll
+    for (int i = 0; i < 9; i++) Paw[i] *= keep;
+  }
   if constexpr (UPDATE) {
     sync();  // B
     const double L10 = xr(Quad::X_L + 0), L20 = xr(Quad::X_L + 1), L21 = xr(Quad::X_L + 2);
@@ -462,8 +707,13 @@ PB_HD void quad_role_passive(LD ld, ST st, XW xw, XR xr, SYNC sync, const StepIn
 #pragma unroll
       for (int i = 0; i < NS; i++) dfull[i] = 0.0;
 #pragma unroll
-      for (int i = 0; i < 9; i++) dfull[core_full(i)] = xr(Quad::X_DX + i);
-      if (in.upd) add_delta<NS>(x, q, dfull, k.chi_tol);
+      for (int i = 0; i < 9; i++) dfull[core_full(i)] = (SIX == 1) ? xr(Quad::X_DX + i) + dx1[i] : xr(Quad::X_DX + i);
+      if constexpr (SIX == 2) {
+#pragma unroll
+        for (int i = 0; i < 9; i++) dsum[i] = dfull[core_full(i)];   // applied together with the second block's
+      } else {
+        if (in.upd || (SIX == 1 && six.on)) add_delta<NS>(x, q, dfull, k.chi_tol);
+      }
     }
 #pragma unroll
     for (int sb = 0; sb < 5; sb++)
@@ -485,7 +735,8 @@ PB_HD void quad_role_passive(LD ld, ST st, XW xw, XR xr, SYNC sync, const StepIn
           double acc = X[sb][3 * r + c];
 #pragma unroll
           for (int kk = 0; kk < 3; kk++) acc = fma(-wd[kk], Wp[c][kk], acc);
-          st(L::OFF_P + pk(core_full(3 * sb + r), passive_full(3 * J + c)), acc);
+          if constexpr (SIX == 2) X[sb][3 * r + c] = acc;
+          else st(L::OFF_P + pk(core_full(3 * sb + r), passive_full(3 * J + c)), acc);
         }
       }
     double Ww[3][3];  // J == 1: W_omega from role PW's raw column
@@ -508,7 +759,8 @@ PB_HD void quad_role_passive(LD ld, ST st, XW xw, XR xr, SYNC sync, const StepIn
           double acc = Paw[3 * r + c];
 #pragma unroll
           for (int kk = 0; kk < 3; kk++) acc = fma(-wd[kk], Ww[c][kk], acc);
-          st(L::OFF_P + pk(passive_full(3 + r), passive_full(c)), acc);
+          if constexpr (SIX == 2) Paw[3 * r + c] = acc;
+          else st(L::OFF_P + pk(passive_full(3 + r), passive_full(c)), acc);
         }
       }
 #pragma unroll
@@ -516,7 +768,90 @@ PB_HD void quad_role_passive(LD ld, ST st, XW xw, XR xr, SYNC sync, const StepIn
         double acc = Pjj[pk(r, c)];
 #pragma unroll
         for (int kk = 0; kk < 3; kk++) acc = fma(-wd[kk], Wp[c][kk], acc);
-        st(L::OFF_P + pk(passive_full(3 * J + r), passive_full(3 * J + c)), acc);
+        if constexpr (SIX == 2) Pjj[pk(r, c)] = acc;
+        else st(L::OFF_P + pk(passive_full(3 * J + r), passive_full(3 * J + c)), acc);
+      }
+    }
+    if constexpr (SIX == 2) {
+      // ---- the position block: raw P''(Delta, omega) columns where the first block's P'(v, omega) were ----
+      sync();  // B2
+      if constexpr (J == 0) {
+#pragma unroll
+        for (int c = 0; c < 3; c++)
+#pragma unroll
+          for (int kk = 0; kk < 3; kk++) xw(Quad::X_VW + 3 * c + kk, X[2][3 * kk + c]);
+      }
+      sync();  // C
+      const double M10 = xr(Quad::X_L + 0), M20 = xr(Quad::X_L + 1), M21 = xr(Quad::X_L + 2);
+#pragma unroll
+      for (int kk = 0; kk < 3; kk++) { id[kk] = xr(Quad::X_ID + kk); yd[kk] = xr(Quad::X_YD + kk); }
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        Wp[c][0] = X[2][0 + c];
+        Wp[c][1] = X[2][3 + c] - Wp[c][0] * M10;
+        Wp[c][2] = X[2][6 + c] - Wp[c][0] * M20 - Wp[c][1] * M21;
+        if constexpr (J == 1) xp[c] += fma(Wp[c][2], yd[2], fma(Wp[c][1], yd[1], Wp[c][0] * yd[0]));
+      }
+      if constexpr (J == 0) {  // ONE addState of the two blocks' summed correction
+        double dfull[NS];
+#pragma unroll
+        for (int i = 0; i < NS; i++) dfull[i] = 0.0;
+#pragma unroll
+        for (int i = 0; i < 9; i++) dfull[core_full(i)] = dsum[i] + xr(Quad::X_DX + i);
+        if (in.upd || six.on) add_delta<NS>(x, q, dfull, k.chi_tol);
+      }
+#pragma unroll
+      for (int sb = 0; sb < 5; sb++)
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+          double wd[3];
+          if (sb < 3) {
+#pragma unroll
+            for (int kk = 0; kk < 3; kk++) wd[kk] = xr(Quad::X_WC + 3 * (3 * sb + r) + kk) * id[kk];
+          } else {
+            const int j = 3 * (sb - 3) + r;
+            const double w0 = xr(Quad::X_BV + 3 * j + 0);
+            const double w1 = xr(Quad::X_BV + 3 * j + 1) - w0 * M10;
+            const double w2 = xr(Quad::X_BV + 3 * j + 2) - w0 * M20 - w1 * M21;
+            wd[0] = w0 * id[0]; wd[1] = w1 * id[1]; wd[2] = w2 * id[2];
+          }
+#pragma unroll
+          for (int c = 0; c < 3; c++) {
+            double acc = X[sb][3 * r + c];
+#pragma unroll
+            for (int kk = 0; kk < 3; kk++) acc = fma(-wd[kk], Wp[c][kk], acc);
+            st(L::OFF_P + pk(core_full(3 * sb + r), passive_full(3 * J + c)), acc);
+          }
+        }
+      if constexpr (J == 1) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+          Ww[c][0] = xr(Quad::X_VW + 3 * c + 0);
+          Ww[c][1] = xr(Quad::X_VW + 3 * c + 1) - Ww[c][0] * M10;
+          Ww[c][2] = xr(Quad::X_VW + 3 * c + 2) - Ww[c][0] * M20 - Ww[c][1] * M21;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 3; r++) {
+        double wd[3];
+#pragma unroll
+        for (int kk = 0; kk < 3; kk++) wd[kk] = Wp[r][kk] * id[kk];
+        if constexpr (J == 1) {
+#pragma unroll
+          for (int c = 0; c < 3; c++) {
+            double acc = Paw[3 * r + c];
+#pragma unroll
+            for (int kk = 0; kk < 3; kk++) acc = fma(-wd[kk], Ww[c][kk], acc);
+            st(L::OFF_P + pk(passive_full(3 + r), passive_full(c)), acc);
+          }
+        }
+#pragma unroll
+        for (int c = 0; c <= r; c++) {
+          double acc = Pjj[pk(r, c)];
+#pragma unroll
+          for (int kk = 0; kk < 3; kk++) acc = fma(-wd[kk], Wp[c][kk], acc);
+          st(L::OFF_P + pk(passive_full(3 * J + r), passive_full(3 * J + c)), acc);
+        }
       }
     }
   } else {

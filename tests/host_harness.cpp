@@ -175,12 +175,78 @@ extern "C" void hh_step_coop_correct(int ns, int kind, int mode, double *st, lon
   else step_coop<21, CorrPosYaw>(st, stride, B, imu, lo, mask, q4, g, tol, mode, z2, rd2, qm2, mask2);
 }
 
-// ---- four-wave 21-state step (rbis_quad.hpp): the four roles run as four threads with a real barrier (role CB needs
-// role CC's factors and role CC needs role CB's H, so no back-to-back order works); a plain array stands in for LDS. ----
+// ---- LegOdoCommon's six-row measurements inside the step (SIX, rbis_coop.hpp): the two roles as two threads with a real
+// barrier (SIX == 1: role C needs role P's omega stage, role P needs role C's factors).  lo12 = z [6][B] | R diagonal [6][B] in
+// the order of pb_legodo_set_measurement_mode; masks [2][B]: the six-row update | the three-row (velocity) fall-back of mode 2. ----
 #include <pthread.h>
 
 #include <thread>
 
+template <int NS, int SIX>
+static void step_coop_six(double *st, long stride, int B, const double *imu, const double *lo12, const uint8_t *masks, const double *q4,
+                          double g, double tol)
+{
+  using CORR = typename std::conditional<SIX == 2, CorrPos, NoCorr>::type;
+  Consts k{ g, tol };
+  constexpr int NC = Lay<NS>::NC;
+  static double in_col[NC], out_col[NC], xch[CoopX<NS, CORR>::NXCH_LEG];
+  static StepInputs in;
+  static CorrInputs cin;
+  static SixIn six;
+  pthread_barrier_t bar;
+  pthread_barrier_init(&bar, nullptr, 2);
+  auto body = [&](int role) {
+    for (int b = 0; b < B; b++) {
+      if (role == 0) {
+        for (int c = 0; c < NC; c++) in_col[c] = out_col[c] = st[c * stride + b];
+        const int vrow = SIX == 1 ? 0 : 3;   // rows of the velocity block
+        for (int i = 0; i < 3; i++) {
+          in.gyro[i] = imu[i * B + b];
+          in.accel[i] = imu[(3 + i) * B + b];
+          in.z[i] = lo12[(vrow + i) * B + b];
+          in.rd[i] = lo12[(6 + vrow + i) * B + b];
+        }
+        in.dt = imu[6 * B + b];
+        in.upd = masks[b] != 0 || (SIX == 2 && masks[B + b] != 0);
+        in.qg = q4[0]; in.qa = q4[1]; in.qbg = q4[2]; in.qba = q4[3];
+        const int orow = SIX == 1 ? 3 : 0;   // rows of the other block
+        for (int i = 0; i < 3; i++) {
+          cin.z[i] = six.z[i] = lo12[(orow + i) * B + b];
+          cin.rd[i] = lo12[(6 + orow + i) * B + b];
+        }
+        six.r = lo12[(6 + orow) * B + b];
+        cin.upd = six.on = masks[b] != 0;
+      }
+      pthread_barrier_wait(&bar);
+      auto ld = [&](int c) { return in_col[c]; };
+      auto stf = [&](int c, double v) { out_col[c] = v; };
+      auto sync = [&]() { pthread_barrier_wait(&bar); };
+      auto xw = [&](int s, double v) { xch[s] = v; };
+      auto xr = [&](int s) { return xch[s]; };
+      if (role == 0) coop_role_core<NS, true, CORR, true, false, SIX>(ld, stf, xw, xr, sync, in, k, cin);
+      else coop_role_passive_x<NS, true, CORR, true, SIX>(ld, stf, xw, xr, sync, in, k, cin, six);
+      pthread_barrier_wait(&bar);
+      if (role == 0)
+        for (int c = 0; c < NC; c++) st[c * stride + b] = out_col[c];
+    }
+  };
+  std::thread t1(body, 1);
+  body(0);
+  t1.join();
+  pthread_barrier_destroy(&bar);
+}
+
+extern "C" void hh_step_coop_six(int ns, int six, double *st, long stride, int B, const double *imu, const double *lo12,
+                                 const uint8_t *masks, const double *q4, double g, double tol)
+{
+  if (ns == 15 && six == 1) step_coop_six<15, 1>(st, stride, B, imu, lo12, masks, q4, g, tol);
+  else if (ns == 15) step_coop_six<15, 2>(st, stride, B, imu, lo12, masks, q4, g, tol);
+  else if (six == 1) step_coop_six<21, 1>(st, stride, B, imu, lo12, masks, q4, g, tol);
+  else step_coop_six<21, 2>(st, stride, B, imu, lo12, masks, q4, g, tol);
+}
+
+// ---- four-wave 21-state step (rbis_quad.hpp): the four roles run as four threads with a real barrier (role CB needs
+// role CC's factors and role CC needs role CB's H, so no back-to-back order works); a plain array stands in for LDS. ----
 #include "../pronto_amd/csrc/rbis_quad.hpp"
 
 template <bool UPDATE>
@@ -233,6 +299,64 @@ extern "C" void hh_step_quad(double *st, long stride, int B, const double *imu, 
 {
   if (do_update) step_quad<true>(st, stride, B, imu, lo, mask, q4, g, tol);
   else step_quad<false>(st, stride, B, imu, lo, mask, q4, g, tol);
+}
+
+// the six-row leg-odometry modes on the four-wave mapping (SIX, rbis_quad.hpp); arguments as hh_step_coop_six
+template <int SIX>
+static void step_quad_six(double *st, long stride, int B, const double *imu, const double *lo12, const uint8_t *masks, const double *q4,
+                          double g, double tol)
+{
+  Consts k{ g, tol };
+  constexpr int NC = Lay<21>::NC;
+  static double in_col[NC], out_col[NC], xch[Quad::NXCH_SIX];
+  static StepInputs in;
+  static SixIn six;
+  pthread_barrier_t bar;
+  pthread_barrier_init(&bar, nullptr, 4);
+  auto body = [&](int role) {
+    for (int b = 0; b < B; b++) {
+      if (role == 0) {
+        for (int c = 0; c < NC; c++) in_col[c] = out_col[c] = st[c * stride + b];
+        const int vrow = SIX == 1 ? 0 : 3, orow = SIX == 1 ? 3 : 0;
+        for (int i = 0; i < 3; i++) {
+          in.gyro[i] = imu[i * B + b];
+          in.accel[i] = imu[(3 + i) * B + b];
+          in.z[i] = lo12[(vrow + i) * B + b];
+          in.rd[i] = lo12[(6 + vrow + i) * B + b];
+          six.z[i] = lo12[(orow + i) * B + b];
+        }
+        six.r = lo12[(6 + orow) * B + b];
+        six.on = masks[b] != 0;
+        in.dt = imu[6 * B + b];
+        in.upd = masks[b] != 0 || (SIX == 2 && masks[B + b] != 0);
+        in.qg = q4[0]; in.qa = q4[1]; in.qbg = q4[2]; in.qba = q4[3];
+      }
+      pthread_barrier_wait(&bar);
+      auto ld = [&](int c) { return in_col[c]; };
+      auto stf = [&](int c, double v) { out_col[c] = v; };
+      auto sync = [&]() { pthread_barrier_wait(&bar); };
+      auto xw = [&](int s, double v) { xch[s] = v; };
+      auto xr = [&](int s) { return xch[s]; };
+      if (role == 0) quad_role_cc<true, false, SIX>(ld, stf, xw, xr, sync, in, k, six);
+      else if (role == 1) quad_role_cb<true, SIX>(ld, stf, xw, xr, sync, in, k);
+      else if (role == 2) quad_role_passive<true, 0, SIX>(ld, stf, xw, xr, sync, in, k, six);
+      else quad_role_passive<true, 1, SIX>(ld, stf, xw, xr, sync, in, k, six);
+      pthread_barrier_wait(&bar);
+      if (role == 0)
+        for (int c = 0; c < NC; c++) st[c * stride + b] = out_col[c];
+    }
+  };
+  std::thread t1(body, 1), t2(body, 2), t3(body, 3);
+  body(0);
+  t1.join(); t2.join(); t3.join();
+  pthread_barrier_destroy(&bar);
+}
+
+extern "C" void hh_step_quad_six(int six, double *st, long stride, int B, const double *imu, const double *lo12, const uint8_t *masks,
+                                 const double *q4, double g, double tol)
+{
+  if (six == 1) step_quad_six<1>(st, stride, B, imu, lo12, masks, q4, g, tol);
+  else step_quad_six<2>(st, stride, B, imu, lo12, masks, q4, g, tol);
 }
 
 // ---- stand-alone update on the four-wave mapping (rbis_quad.hpp, quad_upd_*): four threads, one barrier ----

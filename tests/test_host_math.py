@@ -244,3 +244,92 @@ def test_predict_only_and_masked_lanes(oracle, harness):
     v, q, cov, ll = unpack(H, ns, st)
     assert rel(v, ob.vec[:ns]) < 1e-12 and rel(cov, ob.cov[:ns, :ns]) < 1e-12
     assert np.all(ll[mask == 0] == 0.0) and np.all(ll[mask == 1] != 0.0)
+
+
+def six_row_block(ob, w, k, six, rng, B):
+    """A six-row leg-odometry measurement near the current estimate, in pb_legodo_set_measurement_mode's layout:
+    mode 1 (lin_rot_rate) z = (v, omega), idx 3,4,5,0,1,2; mode 2 (pos_and_lin_rate) z = (position, v), idx 9,10,11,3,4,5 with
+    the per-filter three-row fall-back.  Returns lo12 [12][B], masks [2][B], idx."""
+    idx = [3, 4, 5, 0, 1, 2] if six == 1 else [9, 10, 11, 3, 4, 5]
+    z = ob.vec[idx, :] + 0.02 * rng.standard_normal((6, B))
+    ra, rb = 0.01 + 0.02 * rng.random(B), 0.02 + 0.05 * rng.random(B)
+    R = np.concatenate([np.tile(ra, (3, 1)), np.tile(rb, (3, 1))])
+    masks = np.zeros((2, B), np.uint8)
+    valid = (np.arange(B) + k) % 5 != 0
+    full = valid & (((np.arange(B) + k) % 3 != 0) | (six == 1))
+    masks[0] = full
+    masks[1] = valid & ~full
+    return np.ascontiguousarray(np.concatenate([z, R])), masks, idx
+
+
+def apply_six_row_oracle(ob, six, lo12, masks, idx):
+    ob.update_indexed(idx, lo12[0:6], lo12[6:12], mask=masks[0])
+    if six == 2:
+        ob.update_indexed([3, 4, 5], np.ascontiguousarray(lo12[3:6]), np.ascontiguousarray(lo12[9:12]), mask=masks[1])
+
+
+@pytest.mark.parametrize("six", [1, 2])
+@pytest.mark.parametrize("ns", [15, 21])
+def test_cooperative_roles_with_six_row_leg_modes_match_oracle(oracle, harness, ns, six):
+    """LegOdoCommon's lin_rot_rate / pos_and_lin_rate inside the step (SIX, rbis_coop.hpp): two 3-row blocks with ONE summed
+    correction against the oracle's six-row update (and mode 2's three-row fall-back where the position is not valid)."""
+    H = harness
+    g, tol = oracle.constants()
+    B, T = 24, 80
+    w = Workload(B, n_states=ns)
+    vec, quat, P0 = w.initial_state()
+    P0 = P0 + random_spd(ns, B, 0.03, 9)
+    if six == 1:
+        # Every predict resets P(omega, omega) to q_gyro I and keeps the cross terms (rbis.cpp:121): with cross terms that large
+        # next to q_gyro = 7.6e-5 the matrix is far from positive definite and S of a measurement that includes omega amplifies
+        # rounding by many orders (the two statements of the same update then agree to 1e-6 only).  A filter only ever has the
+        # cross terms an omega update left behind, which shrink by r / (q_gyro + r) per message.
+        P0[0:3] *= 0.01
+        P0[:, 0:3] *= 0.01
+    if ns == 21:
+        vec[15:18], vec[18:21] = 0.5 * w.bg, 0.5 * w.ba
+    v21, P21 = embed21(vec, P0)
+    ob = oracle.OracleBatch(v21, quat, P21)
+    st = pack(H, ns, vec, quat, P0, np.zeros(B))
+    q4 = w.process_noise()
+    rng = np.random.default_rng(six)
+    for k in range(T):
+        imu = w.imu_block(k)
+        ob.predict(imu, q4)
+        lo12, masks, idx = six_row_block(ob, w, k, six, rng, B)
+        apply_six_row_oracle(ob, six, lo12, masks, idx)
+        H.hh_step_coop_six(ns, six, P(st), C.c_long(B), B, P(imu), P(lo12), masks.ctypes.data_as(C.c_void_p), P(q4),
+                           C.c_double(g), C.c_double(tol))
+    v, q, cov, ll = unpack(H, ns, st)
+    assert rel(v, ob.vec[:ns]) < 1e-10 and rel(q, ob.quat) < 1e-10 and rel(cov, ob.cov[:ns, :ns]) < 1e-10
+    assert rel(ll, ob.ll) < 1e-10
+
+
+@pytest.mark.parametrize("six", [1, 2])
+def test_four_wave_roles_with_six_row_leg_modes_match_oracle(oracle, harness, six):
+    """The same on the four-wave mapping (SIX, rbis_quad.hpp): mode 1's angular-velocity block ahead of barrier A, mode 2's
+    position block behind two more barriers."""
+    H = harness
+    g, tol = oracle.constants()
+    ns, B, T = 21, 24, 80
+    w = Workload(B, n_states=ns)
+    vec, quat, P0 = w.initial_state()
+    P0 = P0 + random_spd(ns, B, 0.03, 9)
+    if six == 1:   # (see the two-wave test)
+        P0[0:3] *= 0.01
+        P0[:, 0:3] *= 0.01
+    vec[15:18], vec[18:21] = 0.5 * w.bg, 0.5 * w.ba
+    ob = oracle.OracleBatch(vec, quat, P0)
+    st = pack(H, ns, vec, quat, P0, np.zeros(B))
+    q4 = w.process_noise()
+    rng = np.random.default_rng(six)
+    for k in range(T):
+        imu = w.imu_block(k)
+        ob.predict(imu, q4)
+        lo12, masks, idx = six_row_block(ob, w, k, six, rng, B)
+        apply_six_row_oracle(ob, six, lo12, masks, idx)
+        H.hh_step_quad_six(six, P(st), C.c_long(B), B, P(imu), P(lo12), masks.ctypes.data_as(C.c_void_p), P(q4),
+                           C.c_double(g), C.c_double(tol))
+    v, q, cov, ll = unpack(H, ns, st)
+    assert rel(v, ob.vec[:ns]) < 1e-10 and rel(q, ob.quat) < 1e-10 and rel(cov, ob.cov[:ns, :ns]) < 1e-10
+    assert rel(ll, ob.ll) < 1e-10
