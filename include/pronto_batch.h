@@ -259,8 +259,8 @@ int pb_legodo_set_message_times(pb_ctx *ctx, const int64_t *utimes, const uint8_
  *      the reference's per-message fall-back to lin_rate (:118-122), a three-row update on rows 3..5 (z) and 9..11 (Rdiag) of
  *      the same block with idx {3,4,5}.  (The position is leg_estimate's world constraint, which this mode switches on.)
  * r_xyz, r_vang, r_vang_uncertain: state_estimator.legodo.r_xyz / r_vang / r_vang_uncertain (r_vxyz and r_vxyz_uncertain stay
- * arguments of the odometry calls).  The pair calls pb_step_legodo_joints / _feet always form and apply lin_rate.
- * pb_legodo_init puts the mode back to 0. */
+ * arguments of the odometry calls).  The pair calls pb_step_legodo_joints / _feet form AND APPLY the same measurement (their
+ * lo_block_out / mask_out have the shapes above).  pb_legodo_init puts the mode back to 0. */
 int pb_legodo_set_measurement_mode(pb_ctx *ctx, int mode, double r_xyz, double r_vang, double r_vang_uncertain);
 /* LegOdoHandler's "ignore the calculated velocity at launch" (state_estimator.legodo.zero_initial_velocity,
  * rbis_legodo_update.cpp:58,264-268), counted PER FILTER on the device: the counter is decremented by every message whose
@@ -295,13 +295,17 @@ int pb_legodo_update_joints(pb_ctx *ctx, const double *imu_block, int imu_mem, i
                             double r_vxyz, double r_vxyz_uncertain, double *delta_out, double *status_out, double *lo_block_out,
                             uint8_t *mask_out, double *position_out, uint8_t *position_status_out);
 /* ONE call per IMU + joint-state (or foot-state) message pair -- RBISIMUProcessStep::updateFilter, leg_estimate::updateOdometry
- * slaved to the head AFTER that step, LegOdoCommon::createMeasurement (lin_rate) and RBISIndexedMeasurement::updateFilter
- * (rbis_update_interface.cpp:30-95, rbis_legodo_update.cpp:206-280) -- and, for 15 states up to 393 216 filters, ONE kernel
- * and one round trip of the filter state (k_step_leg); other contexts run pb_legodo_update_joints(imu_block, ...) followed by
- * pb_step_legodo_split internally.  Results equal that two-call sequence (tests: bit-identical statuses, posterior to
- * rounding).  imu_block / imu_mem and q as pb_step_legodo; the leg inputs as pb_legodo_update_joints / pb_legodo_update; not
- * both groups PB_HOST.  lo_block_out [6][B] + mask_out [B] (DEVICE, or both NULL): the measurement that was applied, for a
- * caller that may have to re-apply this update later (history replay) -- the odometry itself must not run twice. */
+ * slaved to the head AFTER that step, LegOdoCommon::createMeasurement (the mode of pb_legodo_set_measurement_mode; default
+ * lin_rate) and RBISIndexedMeasurement::updateFilter (rbis_update_interface.cpp:30-95, rbis_legodo_update.cpp:206-280) -- and ONE
+ * kernel and one round trip of the filter state: k_step_leg for 15 states up to 393 216 filters, k_step_quad_leg for 21; other
+ * contexts run pb_legodo_update_joints(imu_block, ...) followed by pb_step_legodo_split (lin_rate) or pb_predict and
+ * pb_update_indexed (the six-row modes) internally.  Results equal that sequence (tests: bit-identical statuses, posterior to
+ * rounding).  The six-row modes are applied as their two 3-row blocks with ONE summed correction -- R is diagonal, so that IS the
+ * six-row update (equal to rounding, not bit for bit: the 6 x 6 S is never factored); mode 2's per-filter fall-back to lin_rate
+ * is the velocity block alone.  imu_block / imu_mem and q as pb_step_legodo; the leg inputs as pb_legodo_update_joints /
+ * pb_legodo_update; not both groups PB_HOST.  lo_block_out + mask_out (DEVICE, or both NULL; [6][B] + [B], six-row modes [12][B] +
+ * [B] / [2][B]): the measurement that was applied, for a caller that may have to re-apply this update later (history replay) --
+ * the odometry itself must not run twice. */
 int pb_step_legodo_joints(pb_ctx *ctx, const double *imu_block, int imu_mem, const double q[4], int64_t utime, int n_rows,
                           const float *joint_position, const float *joint_effort, const float *forces, int mem, double r_vxyz,
                           double r_vxyz_uncertain, double *lo_block_out, uint8_t *mask_out);

@@ -164,6 +164,7 @@ class BatchEstimator:
     def legodo_init(self, schmitt_low, schmitt_high, low_delay_us, high_delay_us, filter_contact_events=True):
         self._chk(self._L.pb_legodo_init(self._h, schmitt_low, schmitt_high, int(low_delay_us), int(high_delay_us),
                                          int(bool(filter_contact_events))))
+        self._leg_mode = 0
 
     def legodo_update(self, utime, feet, forces, r_vxyz, r_vxyz_uncertain, delta_out=None, status_out=None, lo_out=None,
                       mask_out=None, zero_delta=False, after_predict=None):
@@ -175,7 +176,7 @@ class BatchEstimator:
         pz, m2 = _ptr_block(forces, 2, self.B)
         outs = []
         for a, dt, shp in ((delta_out, np.float64, (7, self.B)), (status_out, np.float64, (self.B,)),
-                           (lo_out, np.float64, (6, self.B)), (mask_out, np.uint8, (self.B,))):
+                           (lo_out, np.float64, self._leg_shapes()[0]), (mask_out, np.uint8, self._leg_shapes()[1])):
             p, m = _ptr(a, dt, shape=shp)
             if a is not None and m != PB_DEVICE:
                 raise ValueError("legodo_update outputs must be device tensors")
@@ -211,6 +212,16 @@ class BatchEstimator:
         self._chk(self._L.pb_legodo_set_chain(self._h, n_left, n_right, ty, rw, org.ctypes.data_as(dp), ax.ctypes.data_as(dp),
                                               None if gain is None else gain.ctypes.data_as(C.POINTER(C.c_float))))
 
+    def legodo_set_measurement_mode(self, mode, r_xyz=0.0, r_vang=0.0, r_vang_uncertain=0.0):
+        """LegOdoCommon's mode for the odometry and pair calls: 0 lin_rate (lo [6,B], mask [B]), 1 lin_rot_rate (lo [12,B], mask [B]),
+        2 pos_and_lin_rate (lo [12,B], masks [2,B])."""
+        self._chk(self._L.pb_legodo_set_measurement_mode(self._h, int(mode), float(r_xyz), float(r_vang), float(r_vang_uncertain)))
+        self._leg_mode = int(mode)
+
+    def _leg_shapes(self):
+        mode = getattr(self, "_leg_mode", 0)
+        return ((6, self.B), (self.B,)) if mode == 0 else ((12, self.B), (self.B,) if mode == 1 else (2, self.B))
+
     def legodo_update_joints(self, utime, joint_position, joint_effort, forces, r_vxyz, r_vxyz_uncertain, delta_out=None,
                              status_out=None, lo_out=None, mask_out=None, zero_delta=False, after_predict=None, position_out=None,
                              position_status_out=None):
@@ -222,7 +233,7 @@ class BatchEstimator:
         pz, m3 = _ptr_block(forces, 2, self.B, dtype=np.float32)
         outs = []
         for a, dt, shp in ((delta_out, np.float64, (7, self.B)), (status_out, np.float64, (self.B,)),
-                           (lo_out, np.float64, (6, self.B)), (mask_out, np.uint8, (self.B,)),
+                           (lo_out, np.float64, self._leg_shapes()[0]), (mask_out, np.uint8, self._leg_shapes()[1]),
                            (position_out, np.float64, (3, self.B)), (position_status_out, np.uint8, (self.B,))):
             p, m = _ptr(a, dt, shape=shp)
             if a is not None and m != PB_DEVICE:
@@ -240,8 +251,8 @@ class BatchEstimator:
         pj, m1 = _ptr_block(joint_position, rows, self.B, dtype=np.float32)
         pe, m2 = (None, None) if joint_effort is None else _ptr_block(joint_effort, rows, self.B, dtype=np.float32)
         pz, m3 = _ptr_block(forces, 2, self.B, dtype=np.float32)
-        pl, _ = _ptr(lo_out, shape=(6, self.B))
-        pm, _ = _ptr(mask_out, np.uint8, shape=(self.B,))
+        pl, _ = _ptr(lo_out, shape=self._leg_shapes()[0])
+        pm, _ = _ptr(mask_out, np.uint8, shape=self._leg_shapes()[1])
         q = (C.c_double * 4)(*q4)
         self._chk(self._L.pb_step_legodo_joints(self._h, pi, mi, q, int(utime), rows, pj, pe, pz, _same_mem(m1, m2, m3), r_vxyz,
                                                 r_vxyz_uncertain, pl, pm))
@@ -250,8 +261,8 @@ class BatchEstimator:
         pi, mi = _ptr_block(imu_block, 7, self.B)
         pf, m1 = _ptr_block(feet, 14, self.B)
         pz, m2 = _ptr_block(forces, 2, self.B)
-        pl, _ = _ptr(lo_out, shape=(6, self.B))
-        pm, _ = _ptr(mask_out, np.uint8, shape=(self.B,))
+        pl, _ = _ptr(lo_out, shape=self._leg_shapes()[0])
+        pm, _ = _ptr(mask_out, np.uint8, shape=self._leg_shapes()[1])
         q = (C.c_double * 4)(*q4)
         self._chk(self._L.pb_step_legodo_feet(self._h, pi, mi, q, int(utime), pf, pz, _same_mem(m1, m2), r_vxyz, r_vxyz_uncertain, pl, pm))
 

@@ -534,7 +534,7 @@ public:
     if (!roll_forward) {
       // a measurement that is still to be made from the handler's inputs is made NOW (those inputs are the caller's and only
       // valid until its next message): slaved to the state after the INS step in front of it when that is the one held back
-      if (auto *m = dynamic_cast<RBISIndexedMeasurement *>(update))
+      if (auto *m = deferredMeasurement(update))
         if (m->deferred()) {
           RBISIMUProcessStep *ahead = nullptr;
           if (holding_ == 1 && added_it != map.begin()) {
@@ -585,7 +585,7 @@ public:
               if (third == map.end() && !flushing_) {  // the pair is complete: wait for what follows it
                 // (its measurement is made now, slaved to the state after the held INS step: the handler's inputs do not
                 // outlive this call)
-                if (auto *m2 = dynamic_cast<RBISIndexedMeasurement *>(nxt->second)) {
+                if (auto *m2 = deferredMeasurement(nxt->second)) {
                   const int rrc = m2->resolve(ctx, imu);
                   if (rrc != PB_OK) last_status = rrc;
                 }
@@ -809,8 +809,17 @@ private:
   bool flushing_ = false;
   int holding_ = 0;  // updates at the end of the history that have not been applied yet (0, 1 = an INS step, 2 = INS + legodo)
   // an INS step followed by the velocity measurement LegOdoCommon's lin_rate mode produces (what run_fused accepts)
+  // the measurement object that carries a deferred leg odometry (pair_kernel / make_measurement): the update itself, or the
+  // six-row half of LegOdoCommon's pos_and_lin_rate either-update (its block holds both halves' rows and masks)
+  static RBISIndexedMeasurement *deferredMeasurement(RBISUpdateInterface *u)
+  {
+    if (auto *e = dynamic_cast<RBISEitherUpdate *>(u)) u = e->first;
+    return dynamic_cast<RBISIndexedMeasurement *>(u);
+  }
   bool fusible_pair(RBISIMUProcessStep *imu, RBISUpdateInterface *next)
   {
+    if (auto *d = deferredMeasurement(next))
+      if (d->pair_kernel) return true;   // any of LegOdoCommon's modes: the pair kernel forms and applies it
     if (dynamic_cast<RBISIndexedPlusOrientationMeasurement *>(next) != nullptr) return false;
     auto *m = dynamic_cast<RBISIndexedMeasurement *>(next);
     if (m == nullptr || m->index != RBIS::velocityInds()) return false;
@@ -866,17 +875,18 @@ private:
   // imu followed by a velocity measurement LegOdoCommon's lin_rate mode produces -> one pb_step_legodo; false = not fusible
   bool run_fused(RBISIMUProcessStep *imu, RBISUpdateInterface *next, int &rc)
   {
+    if (auto *d = deferredMeasurement(next))
+      if (d->pair_kernel) {  // the measurement is made inside the step kernel (leg odometry, any of LegOdoCommon's modes): one launch for the message pair
+        rc = d->pair_kernel(ctx, imu, history_slots > 0);
+        d->pair_kernel = nullptr;
+        d->make_measurement = nullptr;
+        leg_kernel_pairs++;
+        return true;
+      }
     if (dynamic_cast<RBISIndexedPlusOrientationMeasurement *>(next) != nullptr) return false;
     auto *m = dynamic_cast<RBISIndexedMeasurement *>(next);
     if (m == nullptr || m->index != RBIS::velocityInds()) return false;
     const double q[4] = { imu->q_gyro, imu->q_accel, imu->q_gyro_bias, imu->q_accel_bias };
-    if (m->pair_kernel) {  // the measurement is made inside the step kernel (leg odometry): one launch for the message pair
-      rc = m->pair_kernel(ctx, imu, history_slots > 0);
-      m->pair_kernel = nullptr;
-      m->make_measurement = nullptr;
-      leg_kernel_pairs++;
-      return true;
-    }
     if (device_lo_block(m)) {  // IMU block from the host (broadcast or per filter), measurement on the device
       rc = pb_step_legodo_split(ctx, imu->imu_block.p, imu->imu_block.mem, m->measurement.p, m->mask, PB_DEVICE, q);
       return true;
@@ -1903,9 +1913,9 @@ public:
     lm->r = lc->R_legodo_vxyz_;
     lm->ru = lc->R_legodo_vxyz_uncertain_;
     // The odometry reads the head pose.  An INS step that fuse_ins_legodo is holding back is either applied first, or -- when
-    // the measurement made here will pair with it (mode lin_rate) -- left pending: the pair then runs as ONE kernel that does
-    // the INS step, the odometry slaved to the pose after it and the update (pb_step_legodo_joints / _feet).
-    RBISIMUProcessStep *ahead = (lc->mode_ == LegOdoCommon::MODE_LIN_RATE) ? est->pendingImu() : nullptr;
+    // the measurement made here will pair with it -- left pending: the pair then runs as ONE kernel that does the INS step, the
+    // odometry slaved to the pose after it and the update in LegOdoCommon's mode (pb_step_legodo_joints / _feet).
+    RBISIMUProcessStep *ahead = est->pendingImu();
     if (ahead != nullptr && ahead->imu_block.mem == PB_HOST && lm->mem == PB_HOST) ahead = nullptr;  // one host staging area
     if (ahead == nullptr) est->flushPending();
     if (!legodo_ready_) initLegEstimate(est);
@@ -1936,7 +1946,7 @@ public:
     const bool lin = dmode == 0;
     if (!lin) d_mask = (uint8_t *) (d_lo + (size_t) 12 * B);   // z [6][B] | R diagonal [6][B] | masks [2][B]
     // the measurement can be made later, inside the step kernel, when its inputs outlive this call
-    const bool defer = lin && ahead != nullptr && one_kernel_pairs && lm->mem != PB_HOST;
+    const bool defer = ahead != nullptr && one_kernel_pairs && lm->mem != PB_HOST;
     if (!defer) {
       const int lrc = lm->odometry(est->ctx, ahead ? &ahead->imu_block : nullptr, nullptr, nullptr, d_lo, d_mask, nullptr, nullptr);
       if (lrc != PB_OK) {
@@ -1966,6 +1976,14 @@ public:
     }
     auto *full = new RBISIndexedMeasurement(idx, BatchArray(d_lo, PB_DEVICE), d_lo + (size_t) 6 * B, PB_R_DIAG, d_mask, RBISUpdateInterface::legodo, utime);
     full->owned_dev = block;
+    if (defer) {  // (the block holds the rows and masks of BOTH halves of mode 2's either-update)
+      full->pair_kernel = [lm, d_lo, d_mask](pb_ctx *ctx, const RBISIMUProcessStep *imu, bool keep) {
+        return lm->pair(ctx, imu, keep ? d_lo : nullptr, keep ? d_mask : nullptr);
+      };
+      full->make_measurement = [lm, d_lo, d_mask](pb_ctx *ctx, const RBISIMUProcessStep *ahead_of) {
+        return lm->odometry(ctx, ahead_of ? &ahead_of->imu_block : nullptr, nullptr, nullptr, d_lo, d_mask, nullptr, nullptr);
+      };
+    }
     if (dmode == 1) return full;
     // pos_and_lin_rate: the filters whose position is not valid take the lin_rate update on the velocity rows of the same block
     auto *fallback = new RBISIndexedMeasurement(RBIS::velocityInds(), BatchArray(d_lo + (size_t) 3 * B, PB_DEVICE), d_lo + (size_t) 9 * B, PB_R_DIAG,

@@ -123,8 +123,12 @@ int pbk_step(pb_ctx *c, bool update, const double *imu, const double *lo, const 
              const StepBcast *bcast = nullptr);  // bcast: one message for every filter, as kernel arguments
 // IMU step + leg odometry (from `lin`) + its lin_rate update in ONE kernel; -1 = this context has no such kernel (run
 // pb_legodo_update* ahead of pbk_step instead)
-int pbk_step_leg(pb_ctx *c, const double *imu, const StepBcast *bcast, const double q[4], const LegIn &lin, int64_t utime, double r2,
-                 double r2_uncertain, double *lo_out, uint8_t *mask_out);
+// mp.mode 1 / 2: LegOdoCommon's six-row measurements instead (lo_out [12][B], mask_out [2][B] as pb_legodo_set_measurement_mode)
+int pbk_step_leg(pb_ctx *c, const double *imu, const StepBcast *bcast, const double q[4], const LegIn &lin, int64_t utime, const LegMeasPar &mp,
+                 double *lo_out, uint8_t *mask_out);
+// pb_step_leg.hip, one object per state size: the pair kernels' launchers
+int pbk_step_leg15(pb_ctx *c, double *out, const double *imu, const double q[4], const StepBcast &bc, const LegIn &lin, const LegStepArgs &la);
+int pbk_step_leg21(pb_ctx *c, double *out, const double *imu, const double q[4], const StepBcast &bc, const LegIn &lin, const LegStepArgs &la);
 // slot0 >= 0: write-through -- the posterior of step t also goes to checkpoint slot slot0 + t (pb_replay_legodo_checkpointed)
 int pbk_replay_fused(pb_ctx *c, int T, const double *imu, const double *lo, const uint8_t *mask, const double q[4], int slot0 = -1);
 // predict + leg-odometry update + a second (orientation) update in one state round trip; corr_kind = enum pb_corr

@@ -42,47 +42,20 @@ int pbk_step(pb_ctx *c, bool update, const double *imu, const double *lo, const 
   return update ? launch_step<true>(c, imu, lo, mask, q, bc) : launch_step<false>(c, imu, nullptr, nullptr, q, bc);
 }
 
-template <int MH>
-static void launch_step_leg(pb_ctx *c, double *out, const double *imu, const double q[4], const StepBcast &bc, const LegIn &lin,
-                            const LegStepArgs &la)
+int pbk_step_leg(pb_ctx *c, const double *imu, const StepBcast *bcast, const double q[4], const LegIn &lin, int64_t utime, const LegMeasPar &mp,
+                 double *lo_out, uint8_t *mask_out)
 {
-  // (the division of the leg work between the waves and the number of panel rows requested ahead of the odometry are template
-  // parameters with measured defaults, rbis_legstep.hpp; -DPB_EXPERIMENTS builds the alternatives: PRONTO_BATCH_LEGPLAN / _LEGEARLY)
-#define LEG_ARGS c->st, out, c->B, imu, q[0], q[1], q[2], q[3], c->k, bc, c->leg_par, lin, c->leg_chain, la
-#ifdef PB_EXPERIMENTS
-  static const int plan = getenv("PRONTO_BATCH_LEGPLAN") ? atoi(getenv("PRONTO_BATCH_LEGPLAN")) : -1;
-  static const int early = getenv("PRONTO_BATCH_LEGEARLY") ? atoi(getenv("PRONTO_BATCH_LEGEARLY")) : -1;
-  if (MH == MH_STORE_SC1 && c->ns == 15 && plan == 1) { k_step_leg<15, MH, 1, 0><<<nblk(c->B), 128, 0, c->stream>>>(LEG_ARGS); return; }
-  if (MH == MH_STORE_SC1 && c->ns == 15 && early == 0) { k_step_leg<15, MH, 0, 0><<<nblk(c->B), 128, 0, c->stream>>>(LEG_ARGS); return; }
-  if (MH == MH_STORE_SC1 && c->ns == 21 && plan == 0) { k_step_quad_leg<MH, 0><<<nblk(c->B), 256, 0, c->stream>>>(LEG_ARGS); return; }
-  if (MH == MH_STORE_SC1 && c->ns == 21 && early == 8) { k_step_quad_leg<MH, 2, 8><<<nblk(c->B), 256, 0, c->stream>>>(LEG_ARGS); return; }
-#endif
-  if (c->ns == 15) k_step_leg<15, MH><<<nblk(c->B), 128, 0, c->stream>>>(LEG_ARGS);
-  else k_step_quad_leg<MH><<<nblk(c->B), 256, 0, c->stream>>>(LEG_ARGS);
-#undef LEG_ARGS
-}
-
-int pbk_step_leg(pb_ctx *c, const double *imu, const StepBcast *bcast, const double q[4], const LegIn &lin, int64_t utime, double r2,
-                 double r2_uncertain, double *lo_out, uint8_t *mask_out)
-{
-  // the two-wave 15-state mapping (the default up to 393 216 filters) and the four-wave 21-state mapping; the world
-  // constraint needs the stand-alone kernel
-  if ((c->ns == 15 && !c->coop15) || (c->ns == 21 && !c->quad21) || c->leg_par.world_constraint) return -1;
-  // 21 states with PER-FILTER joint blocks: even with the two legs' forward kinematics given to roles CC and CB, what is left in
-  // front of barrier A makes role PW the wave the other three wait for (59.3 us at 64k filters against 56.3 us for the
-  // odometry kernel followed by the fused step on the same box): two launches.  k_step_quad_leg keeps the code path (it is
-  // what a foot-state or broadcast joint-state message runs on).  (Also tried: k_leg_fk as a pre-pass and the pair kernel on its
-  // foot poses -- 59.8 us, the small kernel costs more than the 3.4 us the kinematics add inside k_legodo.)
+  // the two-wave 15-state mapping (the default up to 393 216 filters) and the four-wave 21-state mapping.  Mode lin_rate with
+  // leg_estimate's world constraint switched on needs the stand-alone kernel (mode pos_and_lin_rate tracks it inside the pair kernel).
+  if ((c->ns == 15 && !c->coop15) || (c->ns == 21 && !c->quad21) || (c->leg_par.world_constraint && mp.mode != 2)) return -1;
+  // PRONTO_BATCH_LEG21_TWO=1: round 3's two launches for 21 states with per-filter joint blocks (A/B runs)
   static const bool two_launches21 = getenv("PRONTO_BATCH_LEG21_TWO") && getenv("PRONTO_BATCH_LEG21_TWO")[0] == '1';
-  if (c->ns == 21 && lin.kind == 1 && two_launches21) return -1;
+  if (c->ns == 21 && lin.kind == 1 && two_launches21 && mp.mode == 0) return -1;
   const StepBcast bc = bcast ? *bcast : StepBcast();
-  LegStepArgs la{ c->legd, c->legi, c->stride, utime, r2, r2_uncertain, lo_out, mask_out };
+  LegStepArgs la{ c->legd, c->legi, c->stride, utime, mp.r_v2, mp.r_v2_uncertain, lo_out, mask_out, mp };
   double *out = update_target(c);
-  switch (c->mem_hint) {
-  case MH_STORE_SC1: launch_step_leg<MH_STORE_SC1>(c, out, imu, q, bc, lin, la); break;
-  case MH_STREAM_NT: launch_step_leg<MH_STREAM_NT>(c, out, imu, q, bc, lin, la); break;
-  default: launch_step_leg<MH_DEFAULT>(c, out, imu, q, bc, lin, la); break;
-  }
+  if (c->ns == 15) pbk_step_leg15(c, out, imu, q, bc, lin, la);
+  else pbk_step_leg21(c, out, imu, q, bc, lin, la);
   LAUNCHCHK(c);
   update_done(c, out);
   return PB_OK;

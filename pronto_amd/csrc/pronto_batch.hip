@@ -1272,8 +1272,9 @@ extern "C" int pb_legodo_update_joints(pb_ctx *c, const double *imu_block, int i
                        position_out, position_status_out);
 }
 
-// IMU step + leg odometry + its lin_rate update for one message pair: one kernel where the context has it (pbk_step_leg),
-// else the odometry kernel slaved to the state after the IMU step followed by the fused step (two launches, same results)
+// IMU step + leg odometry + its update (LegOdoCommon's mode, pb_legodo_set_measurement_mode) for one message pair: one kernel where
+// the context has it (pbk_step_leg), else the odometry kernel slaved to the state after the IMU step followed by the fused step
+// (lin_rate: two launches) or by the process step and the indexed update(s) (the six-row modes); same results to rounding
 static int step_leg_impl(pb_ctx *c, LegIn &in, const double *imu_block, int imu_mem, const double q[4], int64_t utime, double r_vxyz,
                          double r_vxyz_uncertain, double *lo_out, uint8_t *mask_out)
 {
@@ -1292,23 +1293,24 @@ static int step_leg_impl(pb_ctx *c, LegIn &in, const double *imu_block, int imu_
   in.nc[0] = c->leg_nc_h[0];
   in.nc[1] = c->leg_nc_h[1];
   leg_take_message_times(c, in);
-  const double r2 = r_vxyz * r_vxyz, r2u = r_vxyz_uncertain * r_vxyz_uncertain;
-  int rc = pbk_step_leg(c, d_imu, &bc, q, in, utime, r2, r2u, lo_out, mask_out);
+  LegMeasPar mp = c->leg_meas;
+  mp.r_v2 = r_vxyz * r_vxyz;                            // bot_sq (rbis_legodo_common.cpp:40-43)
+  mp.r_v2_uncertain = r_vxyz_uncertain * r_vxyz_uncertain;
+  if (mp.mode == 2) c->leg_par.world_constraint = 1;    // the measured position IS leg_estimate's world constraint, tracked from here on
+  int rc = pbk_step_leg(c, d_imu, &bc, q, in, utime, mp, lo_out, mask_out);
   if (rc >= 0) return rc;
-  if (lo_out == nullptr) {  // the measurement has to pass through memory between the two kernels
-    const size_t bytes = sizeof(double) * 6 * (size_t) c->B + (size_t) c->B;
+  const int rows = mp.mode == 0 ? 6 : 12;
+  if (lo_out == nullptr) {  // the measurement has to pass through memory between the kernels
+    const size_t bytes = sizeof(double) * 12 * (size_t) c->B + 2 * (size_t) c->B;
     if (!c->leg_lo) HIPCHK(c, hipMalloc((void **) &c->leg_lo, bytes));
     lo_out = c->leg_lo;
-    mask_out = (uint8_t *) (c->leg_lo + (size_t) 6 * c->B);
+    mask_out = (uint8_t *) (c->leg_lo + (size_t) rows * c->B);
   }
   LegAhead ah;
   ah.on = 1;
   ah.bcast = bc.on & 1;
   memcpy(ah.v, bc.imu, sizeof(ah.v));
   ah.imu = d_imu;
-  LegMeasPar mp;  // (lin_rate: what the fused step consumes)
-  mp.r_v2 = r2;
-  mp.r_v2_uncertain = r2u;
   if (c->ns == 15)
     k_legodo<15><<<nblk(c->B), 64, 0, c->stream>>>(c->st, c->legd, c->legi, c->stride, c->B, utime, c->leg_par, in, c->leg_chain, ah, 0, mp, nullptr,
                                                    nullptr, lo_out, mask_out, nullptr, nullptr, c->k);
@@ -1316,7 +1318,18 @@ static int step_leg_impl(pb_ctx *c, LegIn &in, const double *imu_block, int imu_
     k_legodo<21><<<nblk(c->B), 64, 0, c->stream>>>(c->st, c->legd, c->legi, c->stride, c->B, utime, c->leg_par, in, c->leg_chain, ah, 0, mp, nullptr,
                                                    nullptr, lo_out, mask_out, nullptr, nullptr, c->k);
   LAUNCHCHK(c);
-  return pbk_step(c, true, d_imu, lo_out, mask_out, q, &bc);
+  if (mp.mode == 0) return pbk_step(c, true, d_imu, lo_out, mask_out, q, &bc);
+  rc = pbk_step(c, false, d_imu, nullptr, nullptr, q, &bc);
+  if (rc) return rc;
+  static const int idx_lr[6] = { 3, 4, 5, 0, 1, 2 }, idx_pv[6] = { 9, 10, 11, 3, 4, 5 }, idx_v[3] = { 3, 4, 5 };
+  const size_t B = (size_t) c->B;
+  const int slot = pb_head_slot(c);  // a checkpointed step: the update(s) land in the same slot
+  if (slot >= 0) c->out_slot = slot;
+  rc = update_common(c, 6, mp.mode == 1 ? idx_lr : idx_pv, lo_out, lo_out + 6 * B, PB_R_DIAG, nullptr, false, mask_out, PB_DEVICE);
+  if (rc || mp.mode == 1) return rc;
+  const int slot2 = pb_head_slot(c);
+  if (slot2 >= 0) c->out_slot = slot2;
+  return update_common(c, 3, idx_v, lo_out + 3 * B, lo_out + 9 * B, PB_R_DIAG, nullptr, false, mask_out + B, PB_DEVICE);
 }
 
 extern "C" int pb_step_legodo_joints(pb_ctx *c, const double *imu_block, int imu_mem, const double q[4], int64_t utime, int n_rows,

@@ -289,17 +289,22 @@ PB_HD void coop_role_core(LD ld, ST st, XW xw, XR xr, SYNC sync, const StepInput
       idw = xr(CX::X6_ID);
       const double ydw[3] = { xr(CX::X6_YD), xr(CX::X6_YD + 1), xr(CX::X6_YD + 2) };
       if constexpr (!C::LL_IN_P) ll += xr(CX::X6_LLI);
-      double A[NSC][3];
+      // one column of A at a time: NSC values live next to the sub-matrix instead of 3 NSC
 #pragma unroll
-      for (int i = 0; i < NSC; i++)
+      for (int i = 0; i < NSC; i++) dx1[i] = 0.0;
 #pragma unroll
-        for (int kk = 0; kk < 3; kk++) A[i][kk] = xr(CX::X6_A + 3 * i + kk);
+      for (int kk = 0; kk < 3; kk++) {
+        double a[NSC];
 #pragma unroll
-      for (int i = 0; i < NSC; i++) {
-        const double ad[3] = { A[i][0] * idw, A[i][1] * idw, A[i][2] * idw };
-        dx1[i] = fma(A[i][2], ydw[2], fma(A[i][1], ydw[1], A[i][0] * ydw[0]));
+        for (int i = 0; i < NSC; i++) a[i] = xr(CX::X6_A + 3 * i + kk);
 #pragma unroll
-        for (int j = 0; j <= i; j++) Pc[pk(i, j)] = fma(-ad[2], A[j][2], fma(-ad[1], A[j][1], fma(-ad[0], A[j][0], Pc[pk(i, j)])));
+        for (int i = 0; i < NSC; i++) {
+          const double ad = a[i] * idw;
+          dx1[i] = fma(a[i], ydw[kk], dx1[i]);
+#pragma unroll
+          for (int j = 0; j <= i; j++) Pc[pk(i, j)] = fma(-ad, a[j], Pc[pk(i, j)]);
+        }
+        reload_fence();
       }
     }
     if constexpr (LEG) {

@@ -31,7 +31,58 @@ struct LegStepArgs {
   double r2, r2_uncertain;
   double *lo_out;     // [6][B] or NULL: the measurement, kept for a later re-application of this update (history replay)
   uint8_t *mask_out;  // [B] (with lo_out)
+  LegMeasPar mp;      // SIX != 0: the six-row modes' variances; lo_out [12][B], mask_out [2][B] as pb_legodo_set_measurement_mode
 };
+
+// The odometry wave's measurement for the step roles, shared by the two pair kernels.  SIX == 0: lin_rate.  SIX == 1 / 2:
+// LegOdoCommon's lin_rot_rate / pos_and_lin_rate (leg_measurement6) split into the velocity block (zv, rv, valid_v) and the
+// other block (z2, r2, on2): mode 2's per-filter fall-back to lin_rate is the velocity block alone.
+template <int SIX>
+struct LegBlocks {
+  double zv[3], rv, z2[3], r2;
+  bool valid_v, on2;
+};
+template <int SIX>
+__device__ __forceinline__ void leg_blocks(const Pose &delta, double status, const double (&position)[3], bool position_ok, int64_t ut,
+                                           int64_t prev, const LegStepArgs &la, unsigned b, int B, LegBlocks<SIX> &o)
+{
+  if constexpr (SIX == 0) {
+    LegMeas m;
+    leg_measurement(delta, status, ut, prev, la.r2, la.r2_uncertain, m);
+#pragma unroll
+    for (int i = 0; i < 3; i++) { o.zv[i] = m.z[i]; o.z2[i] = 0.0; }
+    o.rv = m.r; o.r2 = 1.0;
+    o.valid_v = m.valid; o.on2 = false;
+    if (la.lo_out != nullptr && b < (unsigned) B) {
+#pragma unroll
+      for (int i = 0; i < 3; i++) {
+        la.lo_out[(long) i * B + b] = m.z[i];
+        la.lo_out[(long) (3 + i) * B + b] = m.r;
+      }
+      la.mask_out[b] = m.valid ? 1 : 0;
+    }
+  } else {
+    LegMeasPar mp = la.mp;
+    mp.mode = SIX;
+    LegMeas6 m;
+    leg_measurement6(delta, status, position, position_ok, ut, prev, mp, m);
+    constexpr int V = (SIX == 1) ? 0 : 3, O = (SIX == 1) ? 3 : 0;   // rows of the velocity block / of the other block
+#pragma unroll
+    for (int i = 0; i < 3; i++) { o.zv[i] = m.z[V + i]; o.z2[i] = m.z[O + i]; }
+    o.rv = m.r[V]; o.r2 = m.r[O];
+    o.valid_v = m.valid6 || m.valid3;
+    o.on2 = m.valid6;
+    if (la.lo_out != nullptr && b < (unsigned) B) {
+#pragma unroll
+      for (int i = 0; i < 6; i++) {
+        la.lo_out[(long) i * B + b] = m.z[i];
+        la.lo_out[(long) (6 + i) * B + b] = m.r[i];
+      }
+      la.mask_out[b] = m.valid6 ? 1 : 0;
+      if (SIX == 2) la.mask_out[(long) B + b] = m.valid3 ? 1 : 0;
+    }
+  }
+}
 
 // PLAN (per-filter joint blocks only; who does what in front of barrier L):
 //   0  role C: forward kinematics of the left leg | role P: right leg, then (barrier F) contact logic + pelvis integration
@@ -41,13 +92,18 @@ struct LegStepArgs {
 // Measured at 64k filters with per-filter joint blocks (one box, min of 3 runs, `scripts/leg_ab.sh`): PLAN 0 / EARLY 0 27.3 us,
 // PLAN 0 / EARLY 12 26.6 us (foot poses 24.2 -> 23.9), EARLY 20 spills (37 us); PLAN 1 31.2 us -- role C is the wave whose rows
 // the memory system is busy with first, a second leg's kinematics in it delays everything behind barrier F.
-template <int NS, int MH, int PLAN = 0, int EARLY = 12>
-__global__ __launch_bounds__(128, 1) void k_step_leg(const double *st, double *sto, int B, const double *__restrict__ imu, double qg,
+// SIX: LegOdoCommon's six-row modes in the same kernel (rbis_coop.hpp, coop_role_core): 1 lin_rot_rate, 2 pos_and_lin_rate (with
+// leg_estimate's world constraint: the pelvis position is measured, so the odometry wave needs the head POSITION after the IMU
+// step too -- the whole state propagate instead of the quaternion's).
+template <int NS, int MH, int PLAN = 0, int EARLY = 12, int SIX = 0>
+__global__ __launch_bounds__(128, 2) void k_step_leg(const double *st, double *sto, int B, const double *__restrict__ imu, double qg,
                                                      double qa, double qbg, double qba, Consts k, StepBcast bc, LegPar par, LegIn lin,
                                                      const LegChain *__restrict__ chain, LegStepArgs la)
 {
+  static_assert(NS == 15, "21 states: k_step_quad_leg");
   using L = Lay<NS>;
-  using CX = CoopX<NS, NoCorr>;
+  using CORR = typename std::conditional<SIX == 2, CorrPos, NoCorr>::type;
+  using CX = CoopX<NS, CORR>;
   __shared__ double xch[CX::NXCH_LEG][64];
   const int role = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
   const unsigned lane = threadIdx.x & 63u;
@@ -99,18 +155,20 @@ __global__ __launch_bounds__(128, 1) void k_step_leg(const double *st, double *s
       }
       __syncthreads();  // barrier F
     }
-    coop_role_core<NS, true, NoCorr, true, true>(ld, stf, [lane](int s, double v) { xch[s][lane] = v; }, xrd, sync, in, k);
+    coop_role_core<NS, true, CORR, true, true, SIX>(ld, stf, [lane](int s, double v) { xch[s][lane] = v; }, xrd, sync, in, k);
   } else {
     // ---- the odometry, on the prior state this role reads anyway ----
     if constexpr (EARLY > 0) {
       io.template need<Slots<NS>::ROW_SPLIT, Slots<NS>::ROW_SPLIT + EARLY>();
       reload_fence();
     }
+    constexpr bool WC = (SIX == 2);
     LegState s;
-    leg_load(s, la.legd, la.legi, la.stride, (long) b, false);     // (the state arrays are padded to whole tiles)
-    double chi[3], bg[3] = { 0.0, 0.0, 0.0 }, wq[4];
+    leg_load(s, la.legd, la.legi, la.stride, (long) b, WC);     // (the state arrays are padded to whole tiles)
+    // what the head orientation after this pair's IMU step depends on: chi and the quaternion -- WC: the whole state vector
+    double xs[WC ? NS : 9], wq[4];
 #pragma unroll
-    for (int i = 0; i < 3; i++) chi[i] = io.ld(L::OFF_VEC + 6 + i);
+    for (int i = WC ? 0 : 6; i < (WC ? NS : 9); i++) xs[i] = io.ld(L::OFF_VEC + i);
 #pragma unroll
     for (int i = 0; i < 4; i++) wq[i] = io.ld(L::OFF_QUAT + i);
     Pose fl_, fr_, delta;
@@ -141,32 +199,51 @@ __global__ __launch_bounds__(128, 1) void k_step_leg(const double *st, double *s
       leg_inputs(lin, chain, bl_, (long) B, fl_, fr_, zl, zr, ncl, ncr);
       cs = leg_contacts(s, par, ut, zl, zr, ncl, ncr, classification, prev);
     }
-    ins_update_quat<NS>(chi, bg, wq, in.gyro, in.dt, k);           // world_to_body_ = the head AFTER this pair's IMU step
-    const double wpos0[3] = { 0.0, 0.0, 0.0 };
+    // world_to_body_ = the head AFTER this pair's IMU step
+    double wpos[3] = { 0.0, 0.0, 0.0 };
+    if constexpr (WC) {
+      ins_update_state<NS>(xs, wq, in.gyro, in.accel, in.dt, k);
+#pragma unroll
+      for (int i = 0; i < 3; i++) wpos[i] = xs[9 + i];
+    } else {
+      const double chi[3] = { xs[6], xs[7], xs[8] }, bg[3] = { 0.0, 0.0, 0.0 };
+      ins_update_quat<NS>(chi, bg, wq, in.gyro, in.dt, k);
+    }
+    LegPar lp = par;
+    lp.world_constraint = WC ? 1 : 0;
     double position[3];
     bool position_ok;
-    double status = leg_integrate(s, par, cs, classification, fl_, fr_, wq, delta, wpos0, position, position_ok);
-    if (leg_zero_velocity(s, status)) pose_identity(delta);
-    if (b < (unsigned) B && msg_ok) leg_store(s, la.legd, la.legi, la.stride, (long) b, false);
-    if (!msg_ok) status = -1.0;
-    LegMeas m;
-    leg_measurement(delta, status, ut, prev, la.r2, la.r2_uncertain, m);
-#pragma unroll
-    for (int i = 0; i < 3; i++) xch[CX::XCH_LEG + i][lane] = m.z[i];
-    xch[CX::XCH_LEG + 3][lane] = m.r;
-    xch[CX::XCH_LEG + 4][lane] = m.valid ? 1.0 : 0.0;
-    if (la.lo_out != nullptr && b < (unsigned) B) {
-#pragma unroll
-      for (int i = 0; i < 3; i++) {
-        la.lo_out[(long) i * B + b] = m.z[i];
-        la.lo_out[(long) (3 + i) * B + b] = m.r;
-      }
-      la.mask_out[b] = m.valid ? 1 : 0;
+    double status = leg_integrate(s, lp, cs, classification, fl_, fr_, wq, delta, wpos, position, position_ok);
+    if (leg_zero_velocity(s, status)) {  // odo_delta.setIdentity(); odo_position.setIdentity() (rbis_legodo_update.cpp:266-267)
+      pose_identity(delta);
+      position[0] = position[1] = position[2] = 0.0;
     }
-    __syncthreads();  // barrier L
-    in.upd = in.upd && m.valid;
+    if (b < (unsigned) B && msg_ok) leg_store(s, la.legd, la.legi, la.stride, (long) b, WC);
+    if (!msg_ok) status = -1.0;
+    LegBlocks<SIX> m;
+    leg_blocks<SIX>(delta, status, position, position_ok, ut, prev, la, b, B, m);
+#pragma unroll
+    for (int i = 0; i < 3; i++) xch[CX::XCH_LEG + i][lane] = m.zv[i];
+    xch[CX::XCH_LEG + 3][lane] = m.rv;
+    xch[CX::XCH_LEG + 4][lane] = m.valid_v ? 1.0 : 0.0;
+    if constexpr (SIX == 2) {
+#pragma unroll
+      for (int i = 0; i < 3; i++) xch[CX::XCH_LEG + 5 + i][lane] = m.z2[i];
+      xch[CX::XCH_LEG + 8][lane] = m.r2;
+      xch[CX::XCH_LEG + 9][lane] = m.on2 ? 1.0 : 0.0;
+    }
+    if constexpr (SIX != 1) __syncthreads();  // barrier L (SIX == 1: inside the passive role, behind its omega stage)
+    else reload_fence();                       // (keeps the panel loads below the odometry, as the barrier does)
+    CorrInputs cin2;
+    SixIn six;
+#pragma unroll
+    for (int i = 0; i < 3; i++) six.z[i] = m.z2[i];
+    six.r = m.r2;
+    six.on = cin2.upd = in.upd && m.on2;
+    in.upd = in.upd && m.valid_v;
     io.template need<Slots<NS>::ROW_SPLIT, Slots<NS>::NROW>();
-    coop_role_passive<NS, true, NoCorr, true>(ld, stf, xrd, sync, in, k);
+    if constexpr (SIX == 0) coop_role_passive<NS, true, NoCorr, true>(ld, stf, xrd, sync, in, k);
+    else coop_role_passive_x<NS, true, CORR, true, SIX>(ld, stf, [lane](int s_, double v) { xch[s_][lane] = v; }, xrd, sync, in, k, cin2, six);
   }
 }
 
@@ -179,7 +256,7 @@ __global__ __launch_bounds__(128, 1) void k_step_leg(const double *st, double *s
 //      runs the contact logic in parallel and only the pelvis integration behind barrier F
 // Measured (same runs): PLAN 2 51.2-51.4 us in ONE kernel, PLAN 0 54.6 us, round 3's two launches 54.2-55.7 us; panel rows of role PW
 // requested ahead of the odometry (EARLY 8 / 16) change nothing (53.1 / 51.8 us).
-template <int MH, int PLAN = 2, int EARLY = 0>
+template <int MH, int PLAN = 2, int EARLY = 0, int SIX = 0>
 __global__ __launch_bounds__(256, 2) void k_step_quad_leg(const double *st, double *sto, int B, const double *__restrict__ imu, double qg,
                                                           double qa, double qbg, double qba, Consts k, StepBcast bc, LegPar par, LegIn lin,
                                                           const LegChain *__restrict__ chain, LegStepArgs la)
@@ -187,7 +264,7 @@ __global__ __launch_bounds__(256, 2) void k_step_quad_leg(const double *st, doub
   constexpr int NS = 21;
   using L = Lay<NS>;
   using SL = Slots<21>;
-  __shared__ double xch[Quad::NXCH_LEG][64];
+  __shared__ double xch[Quad::nxch_leg(SIX)][64];
   const int role = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
   const unsigned lane = threadIdx.x & 63u;
   const unsigned tile = xcd_workgroup(k);
@@ -245,23 +322,25 @@ __global__ __launch_bounds__(256, 2) void k_step_quad_leg(const double *st, doub
       if (PLAN == 0) fk_to_lds(0);
       __syncthreads();  // barrier F
     }
-    quad_role_cc<true, true>(ld, stf, xwr, xrd, sync, in, k);
+    quad_role_cc<true, true, SIX>(ld, stf, xwr, xrd, sync, in, k);
   } else if (role == 1) {
     const StepInputs in = inputs();
     io.template need<SL::QROW[1], SL::QROW[2]>();
     if (split_fk) { fk_to_lds(PLAN == 0 ? 1 : 0); __syncthreads(); }
-    quad_role_cb<true>(ld, stf, xwr, xrd, sync, in, k);
+    quad_role_cb<true, SIX>(ld, stf, xwr, xrd, sync, in, k);
   } else if (role == 2) {
     StepInputs in = inputs();
     if constexpr (EARLY > 0) {
       io.template need<SL::QROW[2], SL::QROW[2] + EARLY>();
       reload_fence();
     }
+    constexpr bool WC = (SIX == 2);
     LegState s;
-    leg_load(s, la.legd, la.legi, la.stride, (long) b, false);
-    double chi[3], bg[3], wq[4];
+    leg_load(s, la.legd, la.legi, la.stride, (long) b, WC);
+    double xs[NS], wq[4];   // (WC: the whole state vector, for the head position after the IMU step; else chi and the gyro bias)
 #pragma unroll
-    for (int i = 0; i < 3; i++) { chi[i] = io.ld(L::OFF_VEC + 6 + i); bg[i] = io.ld(L::OFF_VEC + 15 + i); }
+    for (int i = 0; i < NS; i++)
+      if (WC || (i >= 6 && i < 9) || (i >= 15 && i < 18)) xs[i] = io.ld(L::OFF_VEC + i);
 #pragma unroll
     for (int i = 0; i < 4; i++) wq[i] = io.ld(L::OFF_QUAT + i);
     Pose fl_, fr_, delta;
@@ -284,32 +363,47 @@ __global__ __launch_bounds__(256, 2) void k_step_quad_leg(const double *st, doub
       leg_inputs(lin, chain, bl_, (long) B, fl_, fr_, zl, zr, ncl, ncr);
       cs = leg_contacts(s, par, ut, zl, zr, ncl, ncr, classification, prev);
     }
-    ins_update_quat<NS>(chi, bg, wq, in.gyro, in.dt, k);
-    const double wpos0[3] = { 0.0, 0.0, 0.0 };
+    double wpos[3] = { 0.0, 0.0, 0.0 };
+    if constexpr (WC) {
+      ins_update_state<NS>(xs, wq, in.gyro, in.accel, in.dt, k);
+#pragma unroll
+      for (int i = 0; i < 3; i++) wpos[i] = xs[9 + i];
+    } else {
+      const double chi[3] = { xs[6], xs[7], xs[8] }, bg[3] = { xs[15], xs[16], xs[17] };
+      ins_update_quat<NS>(chi, bg, wq, in.gyro, in.dt, k);
+    }
+    LegPar lp = par;
+    lp.world_constraint = WC ? 1 : 0;
     double position[3];
     bool position_ok;
-    double status = leg_integrate(s, par, cs, classification, fl_, fr_, wq, delta, wpos0, position, position_ok);
-    if (leg_zero_velocity(s, status)) pose_identity(delta);
-    if (b < (unsigned) B && msg_ok) leg_store(s, la.legd, la.legi, la.stride, (long) b, false);
-    if (!msg_ok) status = -1.0;
-    LegMeas m;
-    leg_measurement(delta, status, ut, prev, la.r2, la.r2_uncertain, m);
-#pragma unroll
-    for (int i = 0; i < 3; i++) xch[Quad::X_LEG + i][lane] = m.z[i];
-    xch[Quad::X_LEG + 3][lane] = m.r;
-    xch[Quad::X_LEG + 4][lane] = m.valid ? 1.0 : 0.0;
-    if (la.lo_out != nullptr && b < (unsigned) B) {
-#pragma unroll
-      for (int i = 0; i < 3; i++) {
-        la.lo_out[(long) i * B + b] = m.z[i];
-        la.lo_out[(long) (3 + i) * B + b] = m.r;
-      }
-      la.mask_out[b] = m.valid ? 1 : 0;
+    double status = leg_integrate(s, lp, cs, classification, fl_, fr_, wq, delta, wpos, position, position_ok);
+    if (leg_zero_velocity(s, status)) {
+      pose_identity(delta);
+      position[0] = position[1] = position[2] = 0.0;
     }
-    in.upd = in.upd && m.valid;
+    if (b < (unsigned) B && msg_ok) leg_store(s, la.legd, la.legi, la.stride, (long) b, WC);
+    if (!msg_ok) status = -1.0;
+    LegBlocks<SIX> m;
+    leg_blocks<SIX>(delta, status, position, position_ok, ut, prev, la, b, B, m);
+#pragma unroll
+    for (int i = 0; i < 3; i++) xch[Quad::X_LEG + i][lane] = m.zv[i];
+    xch[Quad::X_LEG + 3][lane] = m.rv;
+    xch[Quad::X_LEG + 4][lane] = m.valid_v ? 1.0 : 0.0;
+    if constexpr (SIX == 2) {
+#pragma unroll
+      for (int i = 0; i < 3; i++) xch[Quad::X_LEG + 5 + i][lane] = m.z2[i];
+      xch[Quad::X_LEG + 8][lane] = m.r2;
+      xch[Quad::X_LEG + 9][lane] = m.on2 ? 1.0 : 0.0;
+    }
+    SixIn six;
+#pragma unroll
+    for (int i = 0; i < 3; i++) six.z[i] = m.z2[i];
+    six.r = m.r2;
+    six.on = in.upd && m.on2;
+    in.upd = in.upd && m.valid_v;
     reload_fence();  // the panel rows are requested HERE, not above the odometry (the two do not fit the registers together)
     io.template need<SL::QROW[2], SL::QROW[3]>();
-    quad_role_passive<true, 0>(ld, stf, xwr, xrd, sync, in, k);
+    quad_role_passive<true, 0, SIX>(ld, stf, xwr, xrd, sync, in, k, six);
   } else {
     const StepInputs in = inputs();
     io.template need<SL::QROW[3], SL::QROW[4]>();
@@ -317,7 +411,7 @@ __global__ __launch_bounds__(256, 2) void k_step_quad_leg(const double *st, doub
       if (PLAN != 0) fk_to_lds(1);
       __syncthreads();  // barrier F
     }
-    quad_role_passive<true, 1>(ld, stf, xwr, xrd, sync, in, k);
+    quad_role_passive<true, 1, SIX>(ld, stf, xwr, xrd, sync, in, k);
   }
 }
 #endif

@@ -74,6 +74,14 @@ for n in (15, 21):
     rows.append(("pair in one call: IMU + joint state", t, 2 * st + 56 + leg + 56))
     t = timeit(lambda: (lambda m: est.step_legodo_joints(imu, q4, m[0], m[1], m[2], m[3], 0.1, 0.5))(nxt(jm)))
     rows.append(("pair in one call: IMU + joint state + efforts", t, 2 * st + 56 + leg + 104))
+    # LegOdoCommon's six-row modes in the same kernel (SIX, rbis_legstep.hpp); the lin_rate rows above are the yardstick
+    for mode, name in ((1, "lin_rot_rate"), (2, "pos_and_lin_rate")):
+        est.legodo_set_measurement_mode(mode, 0.05, 0.4, 0.9)
+        t = timeit(lambda: (lambda m: est.step_legodo_feet(imu, q4, m[0], m[1], m[2], 0.1, 0.5))(nxt(fm)))
+        rows.append(("pair, mode %s: IMU + foot poses" % name, t, 2 * st + 56 + leg + 128 + (48 if mode == 2 else 0)))
+        t = timeit(lambda: (lambda m: est.step_legodo_joints(imu, q4, m[0], m[1], m[2], m[3], 0.1, 0.5))(nxt(jm)))
+        rows.append(("pair, mode %s: IMU + joint state + efforts" % name, t, 2 * st + 56 + leg + 104 + (48 if mode == 2 else 0)))
+    est.legodo_set_measurement_mode(0)
     if n == 15 and not PAIRS_ONLY:
         # the joint filters in front of the kinematics (pb_joint_filter): 12 chain rows; low-pass = 13 window floats in + 1 out,
         # Kalman = 6 doubles in + 6 out, + the float in / out of each row

@@ -263,7 +263,11 @@ def test_shim_sweep_rate_example_runs(n, slots):
                                   ("lin_rot_rate", "standing", "nofuse", "blocks", "kalman"), ("lin_rate", "alt", "nofuse", "bcast", "lowpass"),
                                   ("lin_rate", "alt", "fuse", "device", "none"), ("lin_rate", "ctrl", "fuse", "device", "lowpass"),
                                   ("lin_rate", "alt", "fuse3", "device", "none"), ("pos_and_lin_rate", "alt", "nofuse", "bcast"),
-                                  ("lin_rot_rate", "alt", "nofuse", "bcast")])
+                                  ("lin_rot_rate", "alt", "nofuse", "bcast"),
+                                  # the six-row modes inside the pair kernel (fuse_ins_legodo: SIX, rbis_legstep.hpp)
+                                  ("lin_rot_rate", "alt", "fuse", "device", "none"), ("pos_and_lin_rate", "alt", "fuse", "device", "none"),
+                                  ("lin_rot_rate", "ctrl", "fuse", "bcast"), ("pos_and_lin_rate", "alt", "fuse", "bcast"),
+                                  ("pos_and_lin_rate", "standing", "fuse", "blocks", "lowpass"), ("pos_and_lin_rate", "alt", "fuse3", "device", "none")])
 @pytest.mark.parametrize("n", [15, 21])
 def test_joint_state_handler_on_gpu(oracle, args, n):
     """LegOdoHandler::processMessage(joint_state_t) -- the reference's handler signature -- from a synthetic 6-DoF-per-leg gait:

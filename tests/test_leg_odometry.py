@@ -789,3 +789,77 @@ def test_pair_call_against_the_oracle_chain_on_gpu(oracle, n, kind):
     t, q, oi = orc.get(B - 1)
     assert np.max(np.abs(pose[0:3] - t)) < 1e-9 and info[0] == oi[0] and info[1] == oi[1] and info[2] == oi[2]
     est.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [15, 21])
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("kind,B", [("joints_dev", 1000), ("joints_bcast", 1000), ("feet_dev", 130), ("joints_dev", 65)])
+def test_one_call_pair_in_the_six_row_modes_on_gpu(n, mode, kind, B):
+    """LegOdoCommon's lin_rot_rate / pos_and_lin_rate (pb_legodo_set_measurement_mode 1 / 2) through the pair calls: the IMU step,
+    the odometry slaved to the state after it -- mode 2: with leg_estimate's world constraint, i.e. the head POSITION after the step
+    too -- and the six-row update as two 3-row blocks with one summed correction inside ONE kernel (k_step_leg / k_step_quad_leg,
+    SIX), against the sequence pb_legodo_update_joints(after_predict) -> pb_predict -> pb_update_indexed (six rows; mode 2: then the
+    three-row fall-back under its own mask): masks identical every tick, measurement blocks and the posterior to rounding."""
+    import torch
+    import legs
+    from pronto_amd import batch as pa
+    T = 300
+    dev = torch.device("cuda:0")
+    chain = legs.chain_arrays(legs.ATLAS_LEFT, legs.ATLAS_RIGHT, legs.ATLAS_ROWS)
+    gain = np.array([7000, 10000, 10000, 10000, 10000, 10000] * 2, dtype=np.float32)
+    w = Workload(B, n_states=n, dt_us=2000)
+    vec, quat, P0 = w.initial_state()
+    q4 = w.process_noise()
+    ests = []
+    for _ in range(2):
+        e = pa.BatchEstimator(B, n_states=n)
+        e.reset(vec, quat, P0)
+        e.legodo_init(*SCHMITT, True)
+        e.legodo_set_chain(*chain, gain)
+        e.legodo_set_zero_initial_velocity(4)
+        e.legodo_set_measurement_mode(mode, 0.05, 0.4, 0.9)
+        ests.append(e)
+    seq, one = ests
+    idx = [3, 4, 5, 0, 1, 2] if mode == 1 else [9, 10, 11, 3, 4, 5]
+    lo = [torch.zeros((12, B), dtype=torch.float64, device=dev) for _ in range(2)]
+    mk = [torch.zeros((B,) if mode == 1 else (2, B), dtype=torch.uint8, device=dev) for _ in range(2)]
+    bcast = kind.endswith("bcast")
+    src = legs.joint_gait(1 if bcast else B, T, seed=23) if kind.startswith("joints") else gait(1 if bcast else B, T, seed=23)
+    n_six = n_three = 0
+    for k, msg in enumerate(src):
+        imu = w.imu_block(k)
+        imu_in = np.ascontiguousarray(imu[:, 0]) if bcast else torch.from_numpy(imu).to(dev)
+        if kind.startswith("joints"):
+            utime, jp, je, forces, _ = msg
+            a = (np.ascontiguousarray(jp[:, 0]), np.ascontiguousarray(je[:, 0]), np.ascontiguousarray(forces[:, 0])) if bcast else \
+                tuple(torch.from_numpy(x).to(dev) for x in (jp, je, forces))
+            seq.legodo_update_joints(utime, *a, *R_VXYZ, None, None, lo[0], mk[0], after_predict=imu_in)
+            one.step_legodo_joints(imu_in, q4, utime, *a, *R_VXYZ, lo[1], mk[1])
+        else:
+            utime, feet, forces, _ = msg
+            a = (torch.from_numpy(feet).to(dev), torch.from_numpy(forces).to(dev))
+            seq.legodo_update(utime, *a, *R_VXYZ, None, None, lo[0], mk[0], after_predict=imu_in)
+            one.step_legodo_feet(imu_in, q4, utime, *a, *R_VXYZ, lo[1], mk[1])
+        seq.predict(imu_in, q4)
+        m6 = mk[0] if mode == 1 else mk[0][0]
+        seq.update_indexed(idx, lo[0][0:6], lo[0][6:12], mask=m6)
+        if mode == 2:
+            seq.update_indexed([3, 4, 5], lo[0][3:6].contiguous(), lo[0][9:12].contiguous(), mask=mk[0][1])
+        ma, mb = mk[0].cpu().numpy().reshape(-1, B), mk[1].cpu().numpy().reshape(-1, B)
+        assert np.array_equal(ma, mb), k
+        on = ma.any(axis=0)
+        la, lb = lo[0].cpu().numpy(), lo[1].cpu().numpy()
+        assert np.max(np.abs(la[:, on] - lb[:, on]), initial=0.0) < 1e-9, k
+        n_six += int(ma[0].sum())
+        n_three += int(ma[1].sum()) if mode == 2 else 0
+    assert n_six > B * T // 10 and (mode == 1 or n_three > 0)
+    from util import rel
+    for x, y in zip(seq.get_head(), one.get_head()):
+        assert rel(x, y) < 1e-9
+    for b in (0, B - 1):
+        pa_, ia = seq.legodo_get(b)
+        pb_, ib = one.legodo_get(b)
+        assert ia == ib and np.max(np.abs(pa_ - pb_)) < 1e-10
+    for e in ests:
+        e.close()
