@@ -158,6 +158,13 @@ struct CoopX {
 // states: lin_rot_rate's angular-velocity rows (idx 0..2).  R is diagonal, so the six-row update equals the two blocks applied one
 // after the other with ONE addState of the summed correction (the residual of the later block taken at x + dx of the earlier one;
 // log-likelihood = sum of the two conditional terms) -- to rounding, not bit for bit: the oracle factors the 6 x 6 S at once.
+// "this value exists HERE": an empty asm that reads and writes v.  Arithmetic has no position of its own in the compiler's schedule
+// (it sinks to its first use, across barriers too); a side-effecting user in front of a barrier keeps it there.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ void pb_pin(double &v) { asm volatile("" : "+v"(v)); }
+#else
+inline void pb_pin(double &) {}
+#endif
 struct SixIn {
   double z[3] = { 0.0, 0.0, 0.0 }, r = 1.0;
   bool on = false;
@@ -282,7 +289,19 @@ PB_HD void coop_role_core(LD ld, ST st, XW xw, XR xr, SYNC sync, const StepInput
     double dx1[SIX == 1 ? NSC : 1], idw = 0.0;   // SIX == 1: the omega block's share of the correction; 1/d (0: no such block)
     dx1[0] = 0.0;
     bool mupd = in.upd;
-    if constexpr (LEG || SIX == 1) sync();  // barrier L
+    if constexpr (LEG || SIX == 1) {
+      // The predict ENDS here, in front of barrier L -- while the other wave is still busy with the odometry.  Without the pins the
+      // compiler sinks the covariance propagation behind the barrier (arithmetic has no position of its own): this wave then waits
+      // for the odometry first and propagates afterwards, and with the omega stage behind the barrier as well the two overlap into
+      // 280 live registers (456-528 bytes of scratch, 33-35 us at 64k filters instead of 26).
+#pragma unroll
+      for (int i = 0; i < C::NPC; i++) pb_pin(Pc[i]);
+#pragma unroll
+      for (int i = 0; i < 9; i++) pb_pin(x[C::fullc(i)]);
+#pragma unroll
+      for (int i = 0; i < 4; i++) pb_pin(q[i]);
+      sync();  // barrier L
+    }
     if constexpr (SIX == 1) {
       // the angular-velocity block, applied by role P to its panels; here: P_cc -= A A^T / d, dx_c = A (y / d) with A = P'(c, omega)
       using CX = CoopX<NS, CORR>;

@@ -772,11 +772,11 @@ __global__ __launch_bounds__(256, 2) void k_step_quad(const double *st, double *
   } else if (role == 2) {
     const StepInputs in = inputs(false);
     io.template need<SL::QROW[2], SL::QROW[3]>();
-    quad_role_passive<UPDATE, 0>(ld, stf, xwr, xrd, sync, in, k);
+    quad_role_passive<UPDATE, 0, 0, true>(ld, stf, xwr, xrd, sync, in, k);
   } else {
     const StepInputs in = inputs(false);
     io.template need<SL::QROW[3], SL::QROW[4]>();
-    quad_role_passive<UPDATE, 1>(ld, stf, xwr, xrd, sync, in, k);
+    quad_role_passive<UPDATE, 1, 0, true>(ld, stf, xwr, xrd, sync, in, k);
   }
 }
 

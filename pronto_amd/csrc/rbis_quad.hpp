@@ -133,6 +133,11 @@ PB_HD void quad_role_cc(LD ld, ST st, XW xw, XR xr, SYNC sync, const StepInputs 
 #pragma unroll
     for (int r = 0; r < 3; r++) Pc[pk(3 + r, 3 + r)] += qgd;
   }
+  // F_cc P_cc F_cc^T + Q is done HERE, in front of the barrier, while role CB is still busy with H (pb_pin, rbis_coop.hpp): the
+  // compiler otherwise sinks it behind the barrier, into the stretch every other wave waits for (fused step at 64k filters
+  // 40.6 -> 38.6 us on one box, both libraries in one run; pair kernels 1-4 us)
+#pragma unroll
+  for (int i = 0; i < 45; i++) pb_pin(Pc[i]);
   sync();  // A: H and the propagated velocity are there; every role has consumed the prior x / quat
   double leg_z[3] = { 0.0, 0.0, 0.0 }, leg_r = 1.0, leg_valid = 0.0;
   if constexpr (LEG) {  // (read first: this role sits exactly at 256 registers and the allocation is fragile)
@@ -562,7 +567,9 @@ PB_HD void quad_role_cb(LD ld, ST st, XW xw, XR xr, SYNC sync, const StepInputs 
 // waves 2 and 3, roles PW (J = 0: omega; + x[v chi Delta], quat) and PA (J = 1: accel; + x[accel]): one block column of
 // the passive panels each
 // ------------------------------------------------------------------------------------------------------------
-template <bool UPDATE, int J, int SIX = 0, class LD, class ST, class XW, class XR, class SYNC>
+// PIN: the panel propagation is finished in FRONT of barrier A (pb_pin, rbis_coop.hpp) -- the plain step gains 0.8 us of 40 at 64k
+// filters; the pair kernels, whose role PW runs the odometry first, lose 1-2 us with it and leave the order to the compiler.
+template <bool UPDATE, int J, int SIX = 0, bool PIN = false, class LD, class ST, class XW, class XR, class SYNC>
 PB_HD void quad_role_passive(LD ld, ST st, XW xw, XR xr, SYNC sync, const StepInputs &in, const Consts &k, const SixIn &six = SixIn())
 {
   constexpr int NS = 21;
@@ -661,6 +668,12 @@ PB_HD void quad_role_passive(LD ld, ST st, XW xw, XR xr, SYNC sync, const StepIn
 #pragma unroll
         for (int kk = 0; kk < 3; kk++) xw(Quad::X_VW + 3 * c + kk, X[0][3 * kk + c]);
     }
+  }
+  if constexpr (PIN) {
+#pragma unroll
+    for (int sb = 0; sb < 5; sb++)
+#pragma unroll
+      for (int i = 0; i < 9; i++) pb_pin(X[sb][i]);
   }
   sync();  // A
   if constexpr (SIX == 1 && J == 1) {
