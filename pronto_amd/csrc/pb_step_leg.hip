@@ -22,6 +22,7 @@ static void launch_step_leg(pb_ctx *c, double *out, const double *imu, const dou
   static const int plan = getenv("PRONTO_BATCH_LEGPLAN") ? atoi(getenv("PRONTO_BATCH_LEGPLAN")) : -1;
   static const int early = getenv("PRONTO_BATCH_LEGEARLY") ? atoi(getenv("PRONTO_BATCH_LEGEARLY")) : -1;
   if (MH == MH_STORE_SC1 && SIX == 0 && plan == 1) { k_step_leg<15, MH, 1, 0><<<nblk(c->B), 128, 0, c->stream>>>(LEG_ARGS); return; }
+  if (MH == MH_STORE_SC1 && SIX == 0 && plan == 4) { k_step_leg<15, MH, 4, 12><<<nblk(c->B), 128, 0, c->stream>>>(LEG_ARGS); return; }
   if (MH == MH_STORE_SC1 && SIX == 0 && early == 0) { k_step_leg<15, MH, 0, 0><<<nblk(c->B), 128, 0, c->stream>>>(LEG_ARGS); return; }
 #endif
   k_step_leg<15, MH, 0, (SIX == 2 ? PB_LEG_EARLY_SIX2 : 12), SIX><<<nblk(c->B), 128, 0, c->stream>>>(LEG_ARGS);
@@ -30,9 +31,10 @@ static void launch_step_leg(pb_ctx *c, double *out, const double *imu, const dou
   static const int plan = getenv("PRONTO_BATCH_LEGPLAN") ? atoi(getenv("PRONTO_BATCH_LEGPLAN")) : -1;
   static const int early = getenv("PRONTO_BATCH_LEGEARLY") ? atoi(getenv("PRONTO_BATCH_LEGEARLY")) : -1;
   if (MH == MH_STORE_SC1 && SIX == 0 && plan == 0) { k_step_quad_leg<MH, 0><<<nblk(c->B), 256, 0, c->stream>>>(LEG_ARGS); return; }
-  if (MH == MH_STORE_SC1 && SIX == 0 && early == 8) { k_step_quad_leg<MH, 2, 8><<<nblk(c->B), 256, 0, c->stream>>>(LEG_ARGS); return; }
+  if (MH == MH_STORE_SC1 && SIX == 0 && plan == 2) { k_step_quad_leg<MH, 2><<<nblk(c->B), 256, 0, c->stream>>>(LEG_ARGS); return; }
+  if (MH == MH_STORE_SC1 && SIX == 0 && early == 8) { k_step_quad_leg<MH, 3, 8><<<nblk(c->B), 256, 0, c->stream>>>(LEG_ARGS); return; }
 #endif
-  k_step_quad_leg<MH, 2, 0, SIX><<<nblk(c->B), 256, 0, c->stream>>>(LEG_ARGS);
+  k_step_quad_leg<MH, 3, 0, SIX><<<nblk(c->B), 256, 0, c->stream>>>(LEG_ARGS);
 #endif
 #undef LEG_ARGS
 }

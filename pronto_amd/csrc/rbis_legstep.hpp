@@ -88,6 +88,7 @@ __device__ __forceinline__ void leg_blocks(const Pose &delta, double status, con
 //   0  role C: forward kinematics of the left leg | role P: right leg, then (barrier F) contact logic + pelvis integration
 //   1  role C: forward kinematics of BOTH legs (it waits for its 29 rows anyway) | role P: contact logic -- Schmitt triggers and the
 //      walking-phase classifier read the foot forces only -- in parallel, then (barrier F) the pelvis integration alone
+//   4  as 0 with the contact logic in FRONT of barrier F (behind the right leg's kinematics)
 // EARLY: panel rows role P requests BEFORE the odometry (the rest behind it): as many as the odometry's registers leave room for.
 // Measured at 64k filters with per-filter joint blocks (one box, min of 3 runs, `scripts/leg_ab.sh`): PLAN 0 / EARLY 0 27.3 us,
 // PLAN 0 / EARLY 12 26.6 us (foot poses 24.2 -> 23.9), EARLY 20 spills (37 us); PLAN 1 31.2 us -- role C is the wave whose rows
@@ -145,7 +146,7 @@ __global__ __launch_bounds__(128, 2) void k_step_leg(const double *st, double *s
     io.template need<0, Slots<NS>::ROW_SPLIT>();
     if (split_fk) {
 #pragma unroll
-      for (int side = 0; side < (PLAN == 0 ? 1 : 2); side++) {
+      for (int side = 0; side < (PLAN == 1 ? 2 : 1); side++) {
         Pose T;
         leg_fk_side(lin, chain, side, bl_, (long) B, T);
 #pragma unroll
@@ -179,7 +180,7 @@ __global__ __launch_bounds__(128, 2) void k_step_leg(const double *st, double *s
     const int64_t ut = lin.utimes != nullptr ? lin.utimes[bl_] : la.utime;     // independent segments: this filter's own message time
     const bool msg_ok = lin.valid == nullptr || lin.valid[bl_] != 0;           // ... or no message for it at all
     if (split_fk) {
-      if (PLAN == 0) leg_fk_side(lin, chain, 1, bl_, (long) B, fr_);
+      if (PLAN != 1) leg_fk_side(lin, chain, 1, bl_, (long) B, fr_);
       leg_inputs_rest(lin, bl_, (long) B, zl, zr, ncl, ncr);
       if (PLAN != 0) cs = leg_contacts(s, par, ut, zl, zr, ncl, ncr, classification, prev);  // (needs no foot pose)
       __syncthreads();  // barrier F
@@ -187,12 +188,12 @@ __global__ __launch_bounds__(128, 2) void k_step_leg(const double *st, double *s
       for (int i = 0; i < 3; i++) fl_.t[i] = xch[CX::XCH_FOOT + i][lane];
 #pragma unroll
       for (int i = 0; i < 4; i++) fl_.q[i] = xch[CX::XCH_FOOT + 3 + i][lane];
-      if (PLAN != 0) {
+      if (PLAN == 1) {
 #pragma unroll
         for (int i = 0; i < 3; i++) fr_.t[i] = xch[CX::XCH_FOOT + 7 + i][lane];
 #pragma unroll
         for (int i = 0; i < 4; i++) fr_.q[i] = xch[CX::XCH_FOOT + 10 + i][lane];
-      } else {
+      } else if (PLAN == 0) {
         cs = leg_contacts(s, par, ut, zl, zr, ncl, ncr, classification, prev);
       }
     } else {
@@ -254,9 +255,12 @@ __global__ __launch_bounds__(128, 2) void k_step_leg(const double *st, double *s
 //   0  forward kinematics: left leg in role CC, right leg in role CB; role PW contact logic + integration behind barrier F
 //   2  forward kinematics: left leg in role CB, right leg in role PA (the lightest role; CC, the heaviest, does none); role PW
 //      runs the contact logic in parallel and only the pelvis integration behind barrier F
+//   3  as 2 with the left leg in role CC instead of CB (CB has the most arithmetic in front of barrier A).  The default since role
+//      CC's own propagation is pinned in front of barrier A (pb_pin): 46.6 / 48.1 us against PLAN 2's 48.6 / 49.5 us (joint state /
+//      + efforts, 64k filters, one box, min of 2 interleaved runs), PLAN 0 53.1 / 54.4 us.  (The figures below are older: before the pin.)
 // Measured (same runs): PLAN 2 51.2-51.4 us in ONE kernel, PLAN 0 54.6 us, round 3's two launches 54.2-55.7 us; panel rows of role PW
 // requested ahead of the odometry (EARLY 8 / 16) change nothing (53.1 / 51.8 us).
-template <int MH, int PLAN = 2, int EARLY = 0, int SIX = 0>
+template <int MH, int PLAN = 3, int EARLY = 0, int SIX = 0>
 __global__ __launch_bounds__(256, 2) void k_step_quad_leg(const double *st, double *sto, int B, const double *__restrict__ imu, double qg,
                                                           double qa, double qbg, double qba, Consts k, StepBcast bc, LegPar par, LegIn lin,
                                                           const LegChain *__restrict__ chain, LegStepArgs la)
@@ -319,14 +323,17 @@ __global__ __launch_bounds__(256, 2) void k_step_quad_leg(const double *st, doub
     const StepInputs in = inputs();
     io.template need<SL::QROW[0], SL::QROW[1]>();
     if (split_fk) {
-      if (PLAN == 0) fk_to_lds(0);
+      if (PLAN == 0 || PLAN == 3) fk_to_lds(0);
       __syncthreads();  // barrier F
     }
     quad_role_cc<true, true, SIX>(ld, stf, xwr, xrd, sync, in, k);
   } else if (role == 1) {
     const StepInputs in = inputs();
     io.template need<SL::QROW[1], SL::QROW[2]>();
-    if (split_fk) { fk_to_lds(PLAN == 0 ? 1 : 0); __syncthreads(); }
+    if (split_fk) {
+      if (PLAN != 3) fk_to_lds(PLAN == 0 ? 1 : 0);
+      __syncthreads();
+    }
     quad_role_cb<true, SIX>(ld, stf, xwr, xrd, sync, in, k);
   } else if (role == 2) {
     StepInputs in = inputs();
