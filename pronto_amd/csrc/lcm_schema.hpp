@@ -205,7 +205,82 @@ public:
       for (Extracted &e : out) { e.num.clear(); e.str.clear(); }
       Reader r(data, len);
       if (r.u64() != fp_ || !r.ok) return false;
-      return walk(root_, r, out) && r.pos == len;
+      return walk(root_, r, out, nullptr) && r.pos == len;
+    }
+    // The byte layout of ONE message, kept by the caller per message stream (one log's channel): a recorded stream repeats its
+    // shape -- the same array lengths, the same strings (joint names) -- message after message, and then every wanted number sits
+    // at the offset it had last time.  run() with a Shape checks exactly that (the message length, the length members, the string
+    // length fields and the wanted strings' bytes against its copy: a handful of memcmp) and copies the numbers out by offset,
+    // without walking the structure or building a string; anything different is decoded the long way and becomes the new shape.
+    struct Shape {
+      bool valid = false;
+      size_t len = 0;
+      struct Cmp { uint32_t off, n, at; };                       // bytes [off, off + n) must equal expect[at, at + n)
+      struct Op { uint32_t off, count; uint8_t kind; int16_t slot; };
+      std::vector<Cmp> cmps;
+      std::vector<Op> ops;
+      std::vector<uint8_t> expect;
+      void clear() { valid = false; cmps.clear(); ops.clear(); expect.clear(); }
+    };
+    // as run(); *same_strings (may be NULL) = the message had the cached shape: out[k].str is then left EMPTY -- the strings are
+    // the ones the call that made the shape returned
+    bool run(const void *data, size_t len, std::vector<Extracted> &out, Shape &sh, bool *same_strings) const
+    {
+      if (same_strings) *same_strings = false;
+      if (root_ < 0) return false;
+      const uint8_t *p = (const uint8_t *) data;
+      if (sh.valid && len == sh.len) {
+        bool same = true;
+        for (const Shape::Cmp &c : sh.cmps)
+          if (memcmp(p + c.off, sh.expect.data() + c.at, c.n) != 0) { same = false; break; }
+        if (same) {
+          out.resize(n_slots_);
+          for (Extracted &e : out) { e.num.clear(); e.str.clear(); }
+          for (const Shape::Op &o : sh.ops) {
+            std::vector<double> &v = out[(size_t) o.slot].num;
+            const uint8_t *q = p + o.off;
+            const size_t base = v.size();
+            v.resize(base + o.count);
+            double *dst = v.data() + base;
+            switch ((Kind) o.kind) {
+            case I8: for (uint32_t k = 0; k < o.count; k++) dst[k] = (double) (int8_t) q[k]; break;
+            case U8: for (uint32_t k = 0; k < o.count; k++) dst[k] = (double) q[k]; break;
+            case I16: for (uint32_t k = 0; k < o.count; k++) dst[k] = (double) (int16_t) ((q[2 * k] << 8) | q[2 * k + 1]); break;
+            case I32: for (uint32_t k = 0; k < o.count; k++) { uint32_t u; memcpy(&u, q + 4 * k, 4); dst[k] = (double) (int32_t) __builtin_bswap32(u); } break;
+            case I64: for (uint32_t k = 0; k < o.count; k++) { uint64_t u; memcpy(&u, q + 8 * k, 8); dst[k] = (double) (int64_t) __builtin_bswap64(u); } break;
+            case F32: for (uint32_t k = 0; k < o.count; k++) { uint32_t u; memcpy(&u, q + 4 * k, 4); u = __builtin_bswap32(u); float x; memcpy(&x, &u, 4); dst[k] = x; } break;
+            default: for (uint32_t k = 0; k < o.count; k++) { uint64_t u; memcpy(&u, q + 8 * k, 8); u = __builtin_bswap64(u); memcpy(&dst[k], &u, 8); } break;
+            }
+          }
+          if (same_strings) *same_strings = true;
+          return true;
+        }
+      }
+      sh.clear();
+      out.resize(n_slots_);
+      for (Extracted &e : out) { e.num.clear(); e.str.clear(); }
+      Reader r(data, len);
+      if (r.u64() != fp_ || !r.ok) return false;
+      sh.cmps.push_back(Shape::Cmp{ 0u, 8u, 0u });     // the fingerprint
+      if (!walk(root_, r, out, &sh) || r.pos != len || len > 0xffffffffull) {
+        sh.clear();
+        return false;
+      }
+      // the expected bytes, adjacent ranges merged
+      std::vector<Shape::Cmp> merged;
+      for (const Shape::Cmp &c : sh.cmps) {
+        if (!merged.empty() && merged.back().off + merged.back().n == c.off) merged.back().n += c.n;
+        else merged.push_back(c);
+      }
+      sh.expect.clear();
+      for (Shape::Cmp &c : merged) {
+        c.at = (uint32_t) sh.expect.size();
+        sh.expect.insert(sh.expect.end(), p + c.off, p + c.off + c.n);
+      }
+      sh.cmps = std::move(merged);
+      sh.len = len;
+      sh.valid = true;
+      return true;
     }
   private:
     friend class Schema;
@@ -218,7 +293,8 @@ public:
     size_t n_slots_ = 0;
     uint64_t fp_ = 0;
     static int prim_size(Kind k) { return (k == I8 || k == U8) ? 1 : k == I16 ? 2 : (k == I32 || k == F32) ? 4 : 8; }
-    bool walk(int ni, Reader &r, std::vector<Extracted> &out) const
+    // sh != NULL: record where the wanted numbers were, and what fixes the layout (length members, string lengths, wanted strings)
+    bool walk(int ni, Reader &r, std::vector<Extracted> &out, Shape *sh) const
     {
       const Node &nd = nodes_[(size_t) ni];
       int64_t ints[16];
@@ -234,15 +310,17 @@ public:
             r.pos += (size_t) count * (size_t) sub.fixed_bytes;
           } else {
             for (int64_t k = 0; k < count; k++)
-              if (!walk(f.node, r, out)) return false;
+              if (!walk(f.node, r, out, sh)) return false;
           }
           continue;
         }
         if (f.kind == STR) {
           for (int64_t k = 0; k < count; k++) {
+            const size_t at = r.pos;
             const int32_t n = r.i32();
             if (!r.ok || n < 1 || !r.need((size_t) n)) return false;
             if (f.slot >= 0) out[(size_t) f.slot].str.emplace_back((const char *) r.p + r.pos, (size_t) n - 1);
+            if (sh) sh->cmps.push_back(Shape::Cmp{ (uint32_t) at, (uint32_t) (f.slot >= 0 ? 4 + n : 4), 0u });
             r.pos += (size_t) n;
           }
           continue;
@@ -252,6 +330,16 @@ public:
         if (f.slot < 0 && !f.is_len) {
           r.pos += (size_t) count * (size_t) sz;
           continue;
+        }
+        if (sh) {
+          if (f.is_len) sh->cmps.push_back(Shape::Cmp{ (uint32_t) r.pos, (uint32_t) (count * sz), 0u });
+          if (f.slot >= 0 && count > 0) {
+            // (consecutive elements of one wanted member: one run; a member inside an array of structs adds a run per element)
+            if (!sh->ops.empty() && sh->ops.back().slot == f.slot && sh->ops.back().kind == (uint8_t) f.kind &&
+                sh->ops.back().off + sh->ops.back().count * (uint32_t) sz == (uint32_t) r.pos)
+              sh->ops.back().count += (uint32_t) count;
+            else sh->ops.push_back(Shape::Op{ (uint32_t) r.pos, (uint32_t) count, (uint8_t) f.kind, (int16_t) f.slot });
+          }
         }
         for (int64_t k = 0; k < count; k++) {
           double v = 0.0;

@@ -54,8 +54,11 @@ static inline int pb_shim_threads()
   return n;
 }
 #define PB_SHIM_PARALLEL_FOR _Pragma("omp parallel for schedule(static) num_threads(pb_shim_threads())")
+#define PB_SHIM_PRAGMA(x) _Pragma(#x)
+#define PB_SHIM_PARALLEL_FOR_SUM(v) PB_SHIM_PRAGMA(omp parallel for schedule(static) num_threads(pb_shim_threads()) reduction(+ : v))
 #else
 #define PB_SHIM_PARALLEL_FOR
+#define PB_SHIM_PARALLEL_FOR_SUM(v)
 #endif
 
 namespace MavStateEst {

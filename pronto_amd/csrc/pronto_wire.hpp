@@ -319,6 +319,7 @@ public:
       size_ = ftell(f_);
       fseek(f_, 0, SEEK_SET);
     }
+    if (f_) setvbuf(f_, nullptr, _IOFBF, 32768);   // (a replay of thousands of segments reads a few messages per refill)
   }
   ~LogReader() { if (f_) fclose(f_); }
   LogReader(const LogReader &) = delete;
@@ -333,28 +334,32 @@ public:
     int c;
     int have = 0;
     while ((c = fgetc(f_)) != EOF) {
+      pos_++;
       magic = (magic << 8) | (uint32_t) c;
       if (++have >= 4 && magic == LOG_SYNC) break;
     }
     if (c == EOF) return false;
     uint8_t hdr[24];
     if (fread(hdr, 1, 24, f_) != 24) return false;
+    pos_ += 24;
     Reader r(hdr, 24);
     ev.eventnum = r.i64();
     ev.timestamp = r.i64();
     const int32_t clen = r.i32(), dlen = r.i32();
     if (clen < 0 || clen > 1000 || dlen < 0) return false;  // eventlog.c rejects channel names > 1000
     // a damaged length field must not turn into a multi-gigabyte allocation: the payload cannot outrun the file
-    if (size_ >= 0 && (long) clen + (long) dlen > size_ - ftell(f_)) return false;
+    // (the position is counted here: ftell() is a system call per event)
+    if (size_ >= 0 && (long) clen + (long) dlen > size_ - pos_) return false;
     ev.channel.resize((size_t) clen);
     if (clen && fread(&ev.channel[0], 1, (size_t) clen, f_) != (size_t) clen) return false;
     ev.data.resize((size_t) dlen);
     if (dlen && fread(ev.data.data(), 1, (size_t) dlen, f_) != (size_t) dlen) return false;
+    pos_ += (long) clen + (long) dlen;
     return true;
   }
 private:
   FILE *f_;
-  long size_ = -1;
+  long size_ = -1, pos_ = 0;
 };
 
 }  // namespace pronto_wire

@@ -31,6 +31,7 @@
 // copies run as DMA.  Decoding goes through the run-time .lcm schema (lcm_schema.hpp): the bot_core definitions are the caller's.
 #pragma once
 
+#include <chrono>
 #include <deque>
 
 #include "mav_state_est_batch.hpp"
@@ -45,6 +46,10 @@ public:
     int64_t ragged = 0;             // columns without a message (segment ended)
     int64_t order_violations = 0, undecodable = 0, max_skew_us = 0;
     std::map<std::string, int64_t> per_channel;
+    // where run() spent its wall-clock time, seconds: finding the lead (serial; includes its read-ahead), the segments' reads +
+    // decodes (parallel), book-keeping (serial), assembling the batched arrays + the handler call (parallel loop + one enqueue),
+    // the read-ahead of the next messages (parallel), reading finished runs' heads
+    double t_lead = 0, t_pull = 0, t_book = 0, t_dispatch = 0, t_fill = 0, t_final = 0;
   };
   Stats stats;
 
@@ -81,9 +86,9 @@ public:
     Chan c;
     auto plan = std::make_shared<pronto_wire::Schema::Plan>(schema->compile(type, { "utime", "gyro", "accel" }));
     if (!plan->ok()) fprintf(stderr, "SegmentBatcher: %s has no utime / gyro / accel members\n", type.c_str());
-    c.decode = [plan](const pronto_wire::LogEvent &ev, Rec &r) {
+    c.decode = [plan](const pronto_wire::LogEvent &ev, Rec &r, Stream &st) {
       static thread_local std::vector<pronto_wire::Schema::Extracted> x;
-      if (!plan->run(ev.data.data(), ev.data.size(), x) || x[0].num.size() != 1 || x[1].num.size() != 3 || x[2].num.size() != 3) return false;
+      if (!plan->run(ev.data.data(), ev.data.size(), x, st.shape, nullptr) || x[0].num.size() != 1 || x[1].num.size() != 3 || x[2].num.size() != 3) return false;
       r.utime = (int64_t) x[0].num[0];
       r.d.assign(x[1].num.begin(), x[1].num.end());
       r.d.insert(r.d.end(), x[2].num.begin(), x[2].num.end());
@@ -93,6 +98,7 @@ public:
     uint8_t *valid = pinned<uint8_t>((size_t) B_);
     auto last = std::make_shared<std::vector<double>>((size_t) 6 * B_, 0.0);
     c.dispatch = [this, cb, blk, valid, last](const std::vector<const Rec *> &col, int64_t utime) {
+      PB_SHIM_PARALLEL_FOR
       for (int s = 0; s < B_; s++) {
         valid[s] = col[(size_t) s] != nullptr;
         for (int i = 0; i < 6; i++) {
@@ -114,13 +120,24 @@ public:
     auto plan = std::make_shared<pronto_wire::Schema::Plan>(
         schema->compile(type, { "utime", "joint_name", "joint_position", "joint_velocity", "joint_effort" }));
     if (!plan->ok()) fprintf(stderr, "SegmentBatcher: %s is not a joint_state_t\n", type.c_str());
-    c.decode = [plan](const pronto_wire::LogEvent &ev, Rec &r) {
+    c.decode = [plan](const pronto_wire::LogEvent &ev, Rec &r, Stream &st) {
       static thread_local std::vector<pronto_wire::Schema::Extracted> x;
-      if (!plan->run(ev.data.data(), ev.data.size(), x) || x[0].num.size() != 1) return false;
-      const size_t n = x[1].str.size();
+      bool same = false;
+      if (!plan->run(ev.data.data(), ev.data.size(), x, st.shape, &same) || x[0].num.size() != 1) return false;
+      if (!same || !st.names) {   // a new joint list (normally: the first message of the segment)
+        st.names = std::make_shared<const std::vector<std::string>>(x[1].str);
+        uint64_t h = 1469598103934665603ull;   // FNV-1a over the names and their boundaries
+        for (const std::string &nm : *st.names) {
+          for (unsigned char ch : nm) h = (h ^ ch) * 1099511628211ull;
+          h = (h ^ 0xffu) * 1099511628211ull;
+        }
+        st.names_hash = h;
+      }
+      const size_t n = st.names->size();
       if (x[2].num.size() != n || x[3].num.size() != n || x[4].num.size() != n) return false;
       r.utime = (int64_t) x[0].num[0];
-      r.names = x[1].str;
+      r.names = st.names;
+      r.names_hash = st.names_hash;
       r.f.resize(3 * n);
       for (size_t j = 0; j < n; j++) {
         r.f[j] = (float) x[2].num[j];
@@ -135,7 +152,7 @@ public:
       for (const Rec *r : col)
         if (r) { lead = r; break; }
       if (lead == nullptr) return;
-      const size_t n = lead->names.size();
+      const size_t n = lead->names->size();
       if (st->rows != n) {   // first message (or a new joint list): size the page-locked blocks
         st->rows = n;
         st->jp = pinned<float>(3 * n * (size_t) B_);
@@ -151,10 +168,14 @@ public:
         device_.push_back(d);
       }
       float *jp = st->jp, *jv = jp + n * (size_t) B_, *je = jv + n * (size_t) B_;
+      int64_t mismatched = 0;
+      PB_SHIM_PARALLEL_FOR_SUM(mismatched)
       for (int s = 0; s < B_; s++) {
         const Rec *r = col[(size_t) s];
-        const bool ok = r != nullptr && r->names == lead->names;   // one robot model for the batch: the same joints in the same order
-        if (r != nullptr && !ok) stats.undecodable++;
+        // one robot model for the batch: the same joints in the same order (compared by the hash of the name list, made where the
+        // list was decoded: 30 string compares per segment and message were a third of this loop)
+        const bool ok = r != nullptr && r->names_hash == lead->names_hash && r->names->size() == n;
+        if (r != nullptr && !ok) mismatched++;
         st->valid[s] = ok;
         st->ut[s] = ok ? r->utime : 0;
         if (!ok) continue;                                         // (the block keeps this filter's last message; it is masked)
@@ -164,6 +185,7 @@ public:
           je[j * B_ + s] = r->f[2 * n + j];
         }
       }
+      stats.undecodable += mismatched;
       // The joint block goes to HBM here (one DMA from page-locked memory) and the handler gets a DEVICE message: with the IMU
       // block coming from the host, the IMU + joint-state pair then runs as ONE kernel (pb_step_legodo_joints takes at most one
       // of its two input groups from the host).  The previous message's pair kernel has been enqueued by now and the copy is
@@ -174,7 +196,7 @@ public:
       }
       msgs::joint_state_t m;
       m.utime = utime;
-      m.joint_name = lead->names;
+      m.joint_name = *lead->names;
       m.joint_position = st->d_jp;
       m.joint_velocity = st->d_jp + n * (size_t) B_;
       m.joint_effort = st->d_jp + 2 * n * (size_t) B_;
@@ -192,9 +214,9 @@ public:
     Chan c;
     auto plan = std::make_shared<pronto_wire::Schema::Plan>(schema->compile(type, { "utime", "sensors.force" }));
     if (!plan->ok()) fprintf(stderr, "SegmentBatcher: %s is not a six_axis_force_torque_array_t\n", type.c_str());
-    c.decode = [plan](const pronto_wire::LogEvent &ev, Rec &r) {
+    c.decode = [plan](const pronto_wire::LogEvent &ev, Rec &r, Stream &st) {
       static thread_local std::vector<pronto_wire::Schema::Extracted> x;
-      if (!plan->run(ev.data.data(), ev.data.size(), x) || x[0].num.size() != 1 || x[1].num.size() < 6) return false;
+      if (!plan->run(ev.data.data(), ev.data.size(), x, st.shape, nullptr) || x[0].num.size() != 1 || x[1].num.size() < 6) return false;
       r.utime = (int64_t) x[0].num[0];
       r.d = { x[1].num[2], x[1].num[5] };   // sensors[0].force[2], sensors[1].force[2]
       return true;
@@ -202,6 +224,7 @@ public:
     double *fz = pinned<double>((size_t) 2 * B_);
     std::fill_n(fz, (size_t) 2 * B_, 0.0);
     c.dispatch = [this, cb, fz](const std::vector<const Rec *> &col, int64_t utime) {
+      PB_SHIM_PARALLEL_FOR
       for (int s = 0; s < B_; s++)
         if (col[(size_t) s]) {   // (the handler keeps the LAST force/torque message, per filter: a missing one changes nothing)
           fz[s] = col[(size_t) s]->d[0];
@@ -216,7 +239,7 @@ public:
   void subscribeUpdate(const std::string &channel, std::function<void(const msgs::update_t *)> cb)
   {
     Chan c;
-    c.decode = [](const pronto_wire::LogEvent &ev, Rec &r) {
+    c.decode = [](const pronto_wire::LogEvent &ev, Rec &r, Stream &) {
       pronto_wire::update_t w;
       if (w.decode(ev.data.data(), ev.data.size()) < 0) return false;
       r.utime = w.timestamp;
@@ -250,9 +273,10 @@ public:
     Chan c;
     auto plan = std::make_shared<pronto_wire::Schema::Plan>(schema->compile(type, { "utime", "pos", "vel", "orientation" }));
     if (!plan->ok()) fprintf(stderr, "SegmentBatcher: %s is not a pose_t\n", type.c_str());
-    c.decode = [plan](const pronto_wire::LogEvent &ev, Rec &r) {
+    c.decode = [plan](const pronto_wire::LogEvent &ev, Rec &r, Stream &st) {
       static thread_local std::vector<pronto_wire::Schema::Extracted> x;
-      if (!plan->run(ev.data.data(), ev.data.size(), x) || x[0].num.size() != 1 || x[1].num.size() != 3 || x[2].num.size() != 3 || x[3].num.size() != 4)
+      if (!plan->run(ev.data.data(), ev.data.size(), x, st.shape, nullptr) || x[0].num.size() != 1 || x[1].num.size() != 3 || x[2].num.size() != 3 ||
+          x[3].num.size() != 4)
         return false;
       r.utime = (int64_t) x[0].num[0];
       r.d.assign(x[1].num.begin(), x[1].num.end());
@@ -263,6 +287,7 @@ public:
     double *blk = pinned<double>((size_t) 10 * B_);
     uint8_t *valid = pinned<uint8_t>((size_t) B_);
     c.dispatch = [this, cb, blk, valid](const std::vector<const Rec *> &col, int64_t utime) {
+      PB_SHIM_PARALLEL_FOR
       for (int s = 0; s < B_; s++) {
         const Rec *r = col[(size_t) s];
         valid[s] = r != nullptr;
@@ -279,25 +304,49 @@ public:
   int64_t run()
   {
     if (segs_.empty()) return -1;
+    // channels by index from here on: the per-event work is one name look-up, then deques of ints
+    chan_list_.clear();
+    chan_names_.clear();
+    for (auto &kv : chans_) {
+      kv.second.id = (int) chan_list_.size();
+      chan_list_.push_back(&kv.second);
+      chan_names_.push_back(kv.first);
+    }
+    for (auto &sg : segs_)
+      if (sg->queue.size() != chan_list_.size()) {
+        sg->queue.resize(chan_list_.size());
+        sg->stream.resize(chan_list_.size());
+      }
     std::vector<const Rec *> col((size_t) B_, nullptr);
     std::vector<Rec> held((size_t) B_);
+    auto now = []() { return std::chrono::steady_clock::now(); };
+    auto lap = [&now](std::chrono::steady_clock::time_point &t, double &acc) {
+      const auto t1 = now();
+      acc += std::chrono::duration<double>(t1 - t).count();
+      t = t1;
+    };
     for (;;) {
+      auto tick = now();
       // the lead: the first segment that still has a subscribed event; its next one names the channel of this batched message
-      int lead = -1;
-      std::string channel;
-      for (int s = 0; s < (int) segs_.size() && lead < 0; s++)
+      int lead = -1, channel = -1;
+      for (int s = first_alive_; s < (int) segs_.size() && lead < 0; s++) {
         if (fill(*segs_[(size_t) s]) && !segs_[(size_t) s]->order.empty()) {
           lead = s;
           channel = segs_[(size_t) s]->order.front();
+        } else if (s == first_alive_) {
+          first_alive_++;   // (ended for good: not asked again)
         }
+      }
       if (lead < 0) break;
-      Chan &ch = chans_[channel];
+      Chan &ch = *chan_list_[(size_t) channel];
       int64_t lead_rel = 0;
       std::fill(col.begin(), col.end(), nullptr);
       const int nseg = (int) segs_.size();
+      lap(tick, stats.t_lead);
       // every segment reads and decodes its own log: independent work, one host thread per range of segments (-fopenmp)
       PB_SHIM_PARALLEL_FOR
       for (int s = lead; s < nseg; s++) got_[(size_t) s] = pull(*segs_[(size_t) s], channel, held[(size_t) s]);
+      lap(tick, stats.t_pull);
       for (int s = lead; s < nseg; s++) {
         Seg &sg = *segs_[(size_t) s];
         if (!got_[(size_t) s]) {
@@ -316,15 +365,18 @@ public:
         stats.segment_messages++;
       }
       stats.ragged += lead;   // (the segments in front of the lead have ended)
+      lap(tick, stats.t_book);
       // batch-level time of this message: the lead's, relative to ITS first message, on the batch's base -- it stays continuous when
       // the lead changes (segments come from different recordings: their absolute times have nothing to do with each other)
       ch.dispatch(col, base_ + lead_rel);
       stats.batches++;
-      stats.per_channel[channel]++;
+      stats.per_channel[chan_names_[(size_t) channel]]++;
+      lap(tick, stats.t_dispatch);
       // segments whose log has no subscribed event left: their run is complete, keep its result.  (fill() is also the read-ahead
       // of the next message: in parallel over the segments)
       PB_SHIM_PARALLEL_FOR
       for (int s = 0; s < nseg; s++) got_[(size_t) s] = finished_[(size_t) s] || fill(*segs_[(size_t) s]);
+      lap(tick, stats.t_fill);
       int first = -1;
       for (int s = 0; s <= nseg; s++) {
         const bool ended = s < nseg && !finished_[(size_t) s] && !got_[(size_t) s];
@@ -334,6 +386,7 @@ public:
           first = -1;
         }
       }
+      lap(tick, stats.t_final);
     }
     for (const auto &sg : segs_) {
       stats.undecodable += sg->undecodable;
@@ -362,11 +415,20 @@ private:
     bool flag = false;
     std::vector<double> d;
     std::vector<float> f;
-    std::vector<std::string> names;
+    std::shared_ptr<const std::vector<std::string>> names;   // (shared by the messages of one stream: a joint list is decoded once)
+    uint64_t names_hash = 0;
+  };
+  // what one segment remembers about one channel between messages: the byte layout of its last message (Schema::Plan::Shape: a
+  // recorded stream repeats it, and the wanted numbers are then read by offset) and the strings that came with it
+  struct Stream {
+    pronto_wire::Schema::Plan::Shape shape;
+    std::shared_ptr<const std::vector<std::string>> names;
+    uint64_t names_hash = 0;
   };
   struct Chan {
-    std::function<bool(const pronto_wire::LogEvent &, Rec &)> decode;
+    std::function<bool(const pronto_wire::LogEvent &, Rec &, Stream &)> decode;
     std::function<void(const std::vector<const Rec *> &, int64_t)> dispatch;
+    int id = -1;
   };
   struct JointBlocks {
     size_t rows = 0;
@@ -378,8 +440,9 @@ private:
     pronto_wire::LogReader rd;
     int64_t start_timestamp, t0 = INT64_MIN;
     bool eof = false;
-    std::deque<std::string> order;                      // channels of the decoded, not yet consumed events, in file order
-    std::map<std::string, std::deque<Rec>> queue;       // ... and the events themselves, per channel
+    std::deque<int> order;                              // channels (index) of the decoded, not yet consumed events, in file order
+    std::vector<std::deque<Rec>> queue;                 // ... and the events themselves, per channel
+    std::vector<Stream> stream;
     int64_t undecodable = 0, order_violations = 0;      // (per segment: the segments are read by different host threads)
     Seg(const std::string &path, int64_t start) : rd(path), start_timestamp(start) {}
   };
@@ -392,7 +455,7 @@ private:
   }
   void read_one(Seg &sg)
   {
-    pronto_wire::LogEvent ev;
+    static thread_local pronto_wire::LogEvent ev;       // (its buffers are re-used from event to event)
     if (!sg.rd.next(ev)) {
       sg.eof = true;
       return;
@@ -400,18 +463,19 @@ private:
     if (ev.timestamp < sg.start_timestamp) return;      // "?start_timestamp=": lcm_front_end.cpp:21-33
     auto it = chans_.find(ev.channel);
     if (it == chans_.end()) return;
+    const int id = it->second.id;
     Rec r;
-    if (!it->second.decode(ev, r)) {
+    if (!it->second.decode(ev, r, sg.stream[(size_t) id])) {
       sg.undecodable++;
       return;
     }
-    sg.order.push_back(ev.channel);
-    sg.queue[ev.channel].push_back(std::move(r));
+    sg.order.push_back(id);
+    sg.queue[(size_t) id].push_back(std::move(r));
   }
   // the segment's next message on `channel` (reading ahead past other channels' events if need be); false: none left
-  bool pull(Seg &sg, const std::string &channel, Rec &out)
+  bool pull(Seg &sg, int channel, Rec &out)
   {
-    std::deque<Rec> &q = sg.queue[channel];
+    std::deque<Rec> &q = sg.queue[(size_t) channel];
     while (q.empty() && !sg.eof) read_one(sg);
     if (q.empty()) return false;
     out = std::move(q.front());
@@ -462,6 +526,9 @@ private:
   std::vector<uint8_t> got_ = std::vector<uint8_t>((size_t) B_, 0);
   std::vector<std::unique_ptr<Seg>> segs_;
   std::map<std::string, Chan> chans_;
+  std::vector<Chan *> chan_list_;
+  std::vector<std::string> chan_names_;
+  int first_alive_ = 0;
   std::vector<void *> pinned_, device_;
 };
 

@@ -275,6 +275,8 @@ int main(int argc, char **argv)
              "kernels all inside), %lld batched messages, fused pairs %lld, status %d\n",
              B, T, n, fuse ? "fused pairs" : "unfused", sec, st.segment_messages / sec, (double) B * T / sec, (long long) st.batches,
              (long long) est.fused_pairs, est.last_status);
+      printf("  where the time went [s]: lead %.3f | read + decode %.3f | book-keeping %.3f | assembly + handlers %.3f | read-ahead %.3f | heads %.3f\n",
+             st.t_lead, st.t_pull, st.t_book, st.t_dispatch, st.t_fill, st.t_final);
       for (int s2 = 0; s2 < B; s2++) remove(paths[(size_t) s2].c_str());
       return est.last_status == PB_OK ? 0 : 1;
     }

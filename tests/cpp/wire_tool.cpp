@@ -196,13 +196,32 @@ int main(int argc, char **argv)
     while ((c = fgetc(f)) != EOF) msg.push_back((uint8_t) c);
     fclose(f);
     std::vector<Schema::Extracted> out;
-    if (!plan.run(msg.data(), msg.size(), out)) { printf("run refused\n"); return 0; }
-    for (size_t k = 0; k < out.size(); k++) {
-      printf("%s:", wanted[k].c_str());
-      for (double v : out[k].num) printf(" %.17g", v);
-      for (const std::string &t : out[k].str) printf(" \"%s\"", t.c_str());
-      printf("\n");
+    auto print = [&]() {
+      for (size_t k = 0; k < out.size(); k++) {
+        printf("%s:", wanted[k].c_str());
+        for (double v : out[k].num) printf(" %.17g", v);
+        for (const std::string &t : out[k].str) printf(" \"%s\"", t.c_str());
+        printf("\n");
+      }
+    };
+    if (argc > 6) {  // ... <more message files>: one stream through ONE Plan::Shape -- which messages had the cached layout
+      Schema::Plan::Shape shape;
+      for (int a = 4; a < argc; a++) {
+        if (a == 5) continue;
+        FILE *g = fopen(argv[a], "rb");
+        if (!g) return 2;
+        std::vector<uint8_t> m2;
+        while ((c = fgetc(g)) != EOF) m2.push_back((uint8_t) c);
+        fclose(g);
+        bool same = false;
+        if (!plan.run(m2.data(), m2.size(), out, shape, &same)) { printf("run refused\n"); continue; }
+        printf("shape: %s\n", same ? "same" : "new");
+        print();
+      }
+      return 0;
     }
+    if (!plan.run(msg.data(), msg.size(), out)) { printf("run refused\n"); return 0; }
+    print();
     return 0;
   }
   fprintf(stderr, "usage: wire_tool hashes | write <path> | dump <path> | schema <lcm files> <type> <message file> | plan <lcm file> <type> <message file> <members>\n");

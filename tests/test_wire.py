@@ -230,6 +230,33 @@ def test_compiled_extraction_plans_agree_with_the_value_tree(tool, tmp_path):
     assert out[4] == "single.id: 1" and out[5] == "raw: 0 127 128 255" and out[6] == "ok: 1" and out[7] == "items.id: -7 300"
     # only members behind the variable-length ones: everything in front is stepped over
     assert run("single.label,ok") == ['single.label: "x"', "ok: 1"]
+    # a STREAM of messages through one Plan::Shape: the same layout (lengths, strings) -> the numbers by offset, no strings
+    # rebuilt; another string, another array length, a broken message -> decoded the long way, the stream carries on
+    v2 = dict(value, utime=5, grid=[[9.0, 8.0, 7.0], [6.0, 5.0, 4.0]], raw=[1, 2, 3, 4],
+              items=[{"id": 1, "w": [10.0, 20.0], "label": "left foot"}, {"id": 2, "w": [30.0, 40.0], "label": ""}])
+    v3 = dict(v2, items=[{"id": 1, "w": [10.0, 20.0], "label": "left feet"}, {"id": 2, "w": [30.0, 40.0], "label": ""}])   # same length, other bytes
+    v4 = dict(v2, n=1, m=2, items=[{"id": 1, "w": [10.0, 20.0], "label": "left foot"}], grid=[[9.0, 8.0], [7.0, 6.0]])
+    files = []
+    for k, v in enumerate((v2, v3, v4, v4)):
+        f = tmp_path / ("stream%d.bin" % k)
+        f.write_bytes(L.encode_message(DEMO_TYPES, "demo.outer_t", v))
+        files.append(str(f))
+    (tmp_path / "cut.bin").write_bytes(msg.read_bytes()[:-5])
+    out = subprocess.check_output([tool, "plan", str(demo), "demo.outer_t", str(msg), "utime,items.w,items.label,raw,grid", files[0],
+                                   str(tmp_path / "cut.bin"), files[0], files[1], files[2], files[3]], text=True).splitlines()
+    blocks, cur = [], None
+    for ln in out:
+        if ln.startswith("shape:") or ln == "run refused":
+            cur = [ln]
+            blocks.append(cur)
+        else:
+            cur.append(ln)
+    assert [b[0] for b in blocks] == ["shape: new", "shape: same", "run refused", "shape: new", "shape: new", "shape: new", "shape: same"]
+    assert blocks[1][1:] == ["utime: 5", "items.w: 10 20 30 40", "items.label:", "raw: 1 2 3 4", "grid: 9 8 7 6 5 4"]
+    assert blocks[3][1:] == ["utime: 5", "items.w: 10 20 30 40", 'items.label: "left foot" ""', "raw: 1 2 3 4", "grid: 9 8 7 6 5 4"]
+    assert blocks[4][3] == 'items.label: "left feet" ""'
+    assert blocks[5][1:] == ["utime: 5", "items.w: 10 20", 'items.label: "left foot"', "raw: 1 2 3 4", "grid: 9 8 7 6"]
+    assert blocks[6][1:] == ["utime: 5", "items.w: 10 20", "items.label:", "raw: 1 2 3 4", "grid: 9 8 7 6"]
     # a member that does not exist: no plan; a truncated message, a message of another type: refused
     assert run("utime,nonsense") == ["no plan"]
     (tmp_path / "short.bin").write_bytes(msg.read_bytes()[:-3])
