@@ -63,7 +63,7 @@ PRONTO_SMOOTH_PIVOT=1 python3 scripts/smooth_rate.py 2>/dev/null | grep smoother
 bash scripts/leg_ab.sh 3 - PRONTO_BATCH_LEG21_TWO=1 > $OUT/leg_ab.txt 2>&1
 if [ -x tests/build/test_segments ]; then
   export OMP_WAIT_POLICY=passive
-  for a in "rate 1024 200" "rate 4096 100" "rate 16384 40" "rate 4096 100 n21"; do tests/build/test_segments $a /tmp 2>&1 | grep "segment batch rate"; done > $OUT/segment_rate.txt
-  PRONTO_SHIM_THREADS=1 tests/build/test_segments rate 4096 100 /tmp 2>&1 | grep "segment batch rate" | sed "s/^/PRONTO_SHIM_THREADS=1 /" >> $OUT/segment_rate.txt
+  for a in "rate 1024 200" "rate 4096 100" "rate 16384 40" "rate 4096 100 n21"; do tests/build/test_segments $a /tmp 2>&1 | grep -A1 "segment batch rate"; done > $OUT/segment_rate.txt
+  PRONTO_SHIM_THREADS=1 tests/build/test_segments rate 4096 100 /tmp 2>&1 | grep -A1 "segment batch rate" | sed "s/^/PRONTO_SHIM_THREADS=1 /" >> $OUT/segment_rate.txt
 fi
 echo "profile done"

@@ -22,7 +22,7 @@ EXE=tests/build/shim_sweep_rate
   $EXE 65536 2000 21 0
   $EXE 65536 2000 21 0 1000000 0 joints
   $EXE 65536 2000 21 32
-  # LegOdoCommon's six-row modes: the measurement is formed on the device (round 4), three launches per pair
+  # LegOdoCommon's six-row modes: formed and applied inside the pair kernel (round 4; rbis_legstep.hpp, SIX)
   $EXE 65536 2000 15 0 1000000 0 joints one lin_rot_rate
   $EXE 65536 2000 15 0 1000000 0 joints one pos_and_lin_rate
   $EXE 65536 2000 21 0 1000000 0 joints one lin_rot_rate
