@@ -1062,7 +1062,7 @@ __global__ __launch_bounds__(256, OCC) void k_replay_quad(double *st, int B, int
         io.st(comp, V[comp]);                                                                                         \
     });                                                                                                               \
   }
-  if (role == 0) PB_REPLAY_QUAD_ROLE(0, true, false, (quad_role_cc<true>(ld, stf, xw, xrd, sync, in, k)))
+  if (role == 0) PB_REPLAY_QUAD_ROLE(0, true, false, (quad_role_cc<true, false, 0, false>(ld, stf, xw, xrd, sync, in, k)))
   else if (role == 1) PB_REPLAY_QUAD_ROLE(1, false, (i < 3 || (i >= 15 && i < NS)), (quad_role_cb<true>(ld, stf, xw, xrd, sync, in, k)))
   else if (role == 2) PB_REPLAY_QUAD_ROLE(2, false, ((i >= 3 && i < 12) || i >= NS), (quad_role_passive<true, 0>(ld, stf, xw, xrd, sync, in, k)))
   else PB_REPLAY_QUAD_ROLE(3, false, (i >= 12 && i < 15), (quad_role_passive<true, 1>(ld, stf, xw, xrd, sync, in, k)))

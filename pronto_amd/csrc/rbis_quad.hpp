@@ -79,7 +79,7 @@ PB_HD void fcc_apply(const ProcBlocks &f, double (&V)[9], double (&Cc)[9], doubl
 //      P'(:, omega) behind barrier A, then the velocity block runs on the result -- no extra barrier
 //   2  the velocity block, then the position block on its posterior: barrier B2 (every role has consumed the first hand-off, whose
 //      slots the second one re-uses) and barrier C (role CC has published the second factors)
-template <bool UPDATE, bool LEG = false, int SIX = 0, class LD, class ST, class XW, class XR, class SYNC>
+template <bool UPDATE, bool LEG = false, int SIX = 0, bool PIN = true, class LD, class ST, class XW, class XR, class SYNC>
 PB_HD void quad_role_cc(LD ld, ST st, XW xw, XR xr, SYNC sync, const StepInputs &in, const Consts &k, const SixIn &six = SixIn())
 {
   static_assert(SIX == 0 || UPDATE, "the six-row leg-odometry modes ride on the velocity update");
@@ -136,8 +136,14 @@ PB_HD void quad_role_cc(LD ld, ST st, XW xw, XR xr, SYNC sync, const StepInputs 
   // F_cc P_cc F_cc^T + Q is done HERE, in front of the barrier, while role CB is still busy with H (pb_pin, rbis_coop.hpp): the
   // compiler otherwise sinks it behind the barrier, into the stretch every other wave waits for (fused step at 64k filters
   // 40.6 -> 38.6 us on one box, both libraries in one run; pair kernels 1-4 us)
+  // (PIN = false: the time-fused replay kernels, whose state lives in registers incl. AGPRs from step to step -- the pin wants
+  // VGPRs: write-through replay 34.4 -> 39.0 us per step with it)
+#ifndef PB_NO_PIN_CC   // (A/B builds)
+  if constexpr (PIN) {
 #pragma unroll
-  for (int i = 0; i < 45; i++) pb_pin(Pc[i]);
+    for (int i = 0; i < 45; i++) pb_pin(Pc[i]);
+  }
+#endif
   sync();  // A: H and the propagated velocity are there; every role has consumed the prior x / quat
   double leg_z[3] = { 0.0, 0.0, 0.0 }, leg_r = 1.0, leg_valid = 0.0;
   if constexpr (LEG) {  // (read first: this role sits exactly at 256 registers and the allocation is fragile)
