@@ -50,6 +50,8 @@ public:
     // decodes (parallel), book-keeping (serial), assembling the batched arrays + the handler call (parallel loop + one enqueue),
     // the read-ahead of the next messages (parallel), reading finished runs' heads
     double t_lead = 0, t_pull = 0, t_book = 0, t_dispatch = 0, t_fill = 0, t_final = 0;
+    double t_handler = 0, t_upload = 0;   // of t_dispatch: inside the handlers' callbacks (host passes, enqueues), the joint blocks' DMA
+
   };
   Stats stats;
 
@@ -67,6 +69,13 @@ public:
   SegmentBatcher(const SegmentBatcher &) = delete;
   SegmentBatcher &operator=(const SegmentBatcher &) = delete;
 
+  template <class F>
+  void timed(double &acc, F &&f)
+  {
+    const auto t0 = std::chrono::steady_clock::now();
+    f();
+    acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  }
   // segment s = filter s, in the order added; false: the file cannot be opened or the batch is full
   bool addSegment(const std::string &path, int64_t start_timestamp = 0)
   {
@@ -108,7 +117,7 @@ public:
       }
       msgs::ins_t m{ utime, BatchArray(blk, PB_HOST), BatchArray(blk + (size_t) 3 * B_, PB_HOST) };
       m.valid = valid;
-      cb(&m);
+      timed(stats.t_handler, [&]() { cb(&m); });
     };
     chans_[channel] = std::move(c);
   }
@@ -189,8 +198,12 @@ public:
       // The joint block goes to HBM here (one DMA from page-locked memory) and the handler gets a DEVICE message: with the IMU
       // block coming from the host, the IMU + joint-state pair then runs as ONE kernel (pb_step_legodo_joints takes at most one
       // of its two input groups from the host).  The previous message's pair kernel has been enqueued by now and the copy is
-      // stream-ordered behind it, so one device block is enough.
-      if (pb_memcpy_h2d(est_->ctx, st->d_jp, jp, sizeof(float) * 3 * n * (size_t) B_) != PB_OK) {
+      // stream-ordered behind it, so one device block is enough.  (The call takes ~300 us at 4096 segments where the DMA of a busy
+      // device takes 25: a copy on a second stream into alternating blocks, waiting for nothing but itself, took the same -- the
+      // device idles between ticks in this host-bound replay and every burst pays its wake-up.)
+      int urc = PB_OK;
+      timed(stats.t_upload, [&]() { urc = pb_memcpy_h2d(est_->ctx, st->d_jp, jp, sizeof(float) * 3 * n * (size_t) B_); });
+      if (urc != PB_OK) {
         fprintf(stderr, "SegmentBatcher: %s\n", pb_last_error(est_->ctx));
         return;
       }
@@ -203,7 +216,7 @@ public:
       m.mem = PB_DEVICE;
       m.utimes = st->ut;
       m.valid = st->valid;
-      cb(&m);
+      timed(stats.t_handler, [&]() { cb(&m); });
     };
     chans_[channel] = std::move(c);
   }
@@ -231,7 +244,7 @@ public:
           fz[(size_t) B_ + s] = col[(size_t) s]->d[1];
         }
       msgs::six_axis_force_torque_array_t m{ utime, BatchArray(fz, PB_HOST) };
-      cb(&m);
+      timed(stats.t_handler, [&]() { cb(&m); });
     };
     chans_[channel] = std::move(c);
   }

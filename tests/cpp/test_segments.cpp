@@ -277,6 +277,7 @@ int main(int argc, char **argv)
              (long long) est.fused_pairs, est.last_status);
       printf("  where the time went [s]: lead %.3f | read + decode %.3f | book-keeping %.3f | assembly + handlers %.3f | read-ahead %.3f | heads %.3f\n",
              st.t_lead, st.t_pull, st.t_book, st.t_dispatch, st.t_fill, st.t_final);
+      printf("  of assembly + handlers: inside the handlers' callbacks %.3f, joint blocks to HBM %.3f\n", st.t_handler, st.t_upload);
       for (int s2 = 0; s2 < B; s2++) remove(paths[(size_t) s2].c_str());
       return est.last_status == PB_OK ? 0 : 1;
     }
