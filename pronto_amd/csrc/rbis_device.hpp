@@ -224,13 +224,44 @@ PB_HD void quat_to_rot(const double (&q)[4], double (&R)[9])
   R[6] = txz - twy;       R[7] = tyz + twx;       R[8] = 1 - (txx + tyy);
 }
 
+// sin and cos of an angle with |x| < 2^20 (joint angles, half rotation angles): Cody-Waite reduction by pi/2 in two pieces, then the classic minimax
+// polynomials on [-pi/4, pi/4] (coefficients: fdlibm's __kernel_sin / __kernel_cos, < 1 ulp).  No large-argument path, so
+// ~35 instructions for the pair where the library call costs ~3x that plus the registers of its Payne-Hanek branch.
+PB_HD void sincos_joint(double x, double &s, double &c)
+{
+  const double kf = rint(x * 6.36619772367581382433e-01);
+  double r = fma(-kf, 1.57079632673412561417e+00, x);
+  r = fma(-kf, 6.07710050650619224932e-11, r);
+  const double z = r * r;
+  double ps = 1.58969099521155010221e-10;
+  ps = fma(ps, z, -2.50507602534068634195e-08);
+  ps = fma(ps, z, 2.75573137070700676789e-06);
+  ps = fma(ps, z, -1.98412698298579493134e-04);
+  ps = fma(ps, z, 8.33333333332248946124e-03);
+  ps = fma(ps, z, -1.66666666666666324348e-01);
+  const double sn = fma(r * z, ps, r);
+  double pc = -1.13596475577881948265e-11;
+  pc = fma(pc, z, 2.08757232129817482790e-09);
+  pc = fma(pc, z, -2.75573143513906633035e-07);
+  pc = fma(pc, z, 2.48015872894767294178e-05);
+  pc = fma(pc, z, -1.38888888888741095749e-03);
+  pc = fma(pc, z, 4.16666666666666019037e-02);
+  const double cs = fma(z * z, pc, fma(-0.5, z, 1.0));
+  const int k = (int) kf & 3;
+  const double a = (k & 1) ? cs : sn, b = (k & 1) ? sn : cs;
+  s = (k & 2) ? -a : a;
+  c = ((k + 1) & 2) ? -b : b;
+}
+
 // eigen_utils chiToQuat: if |chi| > tol { q <- q * AngleAxis(|chi|, chi/|chi|); chi <- 0 }
+// (sin / cos through sincos_joint: the library call carries a large-argument branch and ~2x the instructions, four times per step
+// on the critical wave of every step kernel)
 PB_HD void fold_chi(double (&chi)[3], double (&q)[4], double tol)
 {
   const double n = sqrt(chi[0] * chi[0] + chi[1] * chi[1] + chi[2] * chi[2]);
   if (n > tol) {
     double s, c;
-    ::sincos(0.5 * n, &s, &c);
+    sincos_joint(0.5 * n, s, c);
     const double f = s / n;
     const double dq[4] = { c, f * chi[0], f * chi[1], f * chi[2] };
     double o[4];
