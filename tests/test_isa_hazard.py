@@ -75,3 +75,20 @@ def test_pair_kernels_keep_their_registers_and_the_store_guard():
             # for the world constraint, 68 bytes today)
             six2 = name.endswith("ELi2EEEvPKdPdiS2_ddddNS_6ConstsENS_9StepBcastENS_6LegParENS_5LegInEPKNS_8LegChainENS_11LegStepArgsE") and "ILi15E" in name
             assert scratch <= (64 if ns == 21 else 80 if six2 else 0), (name, scratch)
+
+
+def test_step_kernels_fit_two_waves_per_simd():
+    """The hot kernels sit a few registers under the 256 that two waves per SIMD allow (k_step_coop<15>: 250; its launch bounds
+    permit 512): an innocent-looking reordering in a role body -- e.g. the state update in front of the covariance downdate -- made
+    the compiler take 256 + 58 AGPRs, one wave per SIMD, and the 64k-filter step went from 21.3 to 24.9 us with every test green.
+    This holds the register files of the fused steps."""
+    path = _asm("pb_step.s", "pb_step.hip")
+    meta = _kernel_metadata(path)
+    hot = {k: v for k, v in meta.items() if k.startswith("_ZN2pb11k_step_coopILi15ELb1E") and "NS_4CorrILb0EJEEELb1E" in k}
+    assert len(hot) == 3, sorted(meta)     # the plain 15-state fused step, three cache policies
+    for name, (vgpr, agpr, scratch) in hot.items():
+        assert vgpr <= 256 and agpr == 0 and scratch == 0, (name, vgpr, agpr, scratch)
+    quad = {k: v for k, v in meta.items() if k.startswith("_ZN2pb11k_step_quadILb1E")}
+    assert len(quad) == 3, sorted(meta)
+    for name, (vgpr, agpr, scratch) in quad.items():
+        assert vgpr <= 256 and agpr == 0 and scratch <= 16, (name, vgpr, agpr, scratch)
