@@ -1125,9 +1125,22 @@ extern "C" int pb_joint_filter(pb_ctx *c, int64_t utime, int n_rows, const float
     Part p[3] = { { joint_position, blk, 0 }, { joint_velocity, joint_velocity ? blk : 0, 0 }, { joint_effort, joint_effort ? blk : 0, 0 } };
     int rc = stage_in(c, mem, p, 3);
     if (rc) return rc;
-    k_joint_filter<<<dim3((unsigned) ((c->B + 255) / 256), (unsigned) n_rows), 256, 0, c->stream>>>(
-        par, c->B, (const float *) p[0].dev, (const float *) p[1].dev, (const float *) p[2].dev, joint_position_out, c->jf_ring, c->jf_kst,
-        c->jf_head, first, dt);
+    // four robots per lane (16-byte accesses) where the batch and every block's address allow it
+    const bool v4 = c->B % 4 == 0 && ((uintptr_t) p[0].dev | (uintptr_t) p[1].dev | (uintptr_t) p[2].dev | (uintptr_t) joint_position_out) % 16 == 0;
+    // (64k robots, 12 chain rows, one box: low-pass 11.7 / 12.8 / 9.9 us for 1 / 2 / 4 robots per lane, Kalman 15.4 / 14.6 / 16.0 us)
+    const int V = !v4 ? 1 : par.mode == JF_KALMAN ? 2 : 4, jfb = 256;
+    if (V == 4)
+      k_joint_filter<4><<<dim3((unsigned) ((c->B / 4 + jfb - 1) / jfb), (unsigned) n_rows), jfb, 0, c->stream>>>(
+          par, c->B, (const float *) p[0].dev, (const float *) p[1].dev, (const float *) p[2].dev, joint_position_out, c->jf_ring, c->jf_kst,
+          c->jf_head, first, dt);
+    else if (V == 2)
+      k_joint_filter<2><<<dim3((unsigned) ((c->B / 2 + jfb - 1) / jfb), (unsigned) n_rows), jfb, 0, c->stream>>>(
+          par, c->B, (const float *) p[0].dev, (const float *) p[1].dev, (const float *) p[2].dev, joint_position_out, c->jf_ring, c->jf_kst,
+          c->jf_head, first, dt);
+    else
+      k_joint_filter<1><<<dim3((unsigned) ((c->B + 255) / 256), (unsigned) n_rows), 256, 0, c->stream>>>(
+          par, c->B, (const float *) p[0].dev, (const float *) p[1].dev, (const float *) p[2].dev, joint_position_out, c->jf_ring, c->jf_kst,
+          c->jf_head, first, dt);
     LAUNCHCHK(c);
   }
   c->jf_input = input;

@@ -89,59 +89,141 @@ PB_HD float jf_kalman(double (&s)[JF_KSTATE], double dt, float x_in, float pn_po
 }
 
 #if defined(__HIPCC__)
-// One lane per (robot, row of the message); blockIdx.y = row.  A row no filter owns is copied (torque-adjusted where it has a
-// gain: chain rows >= 28).  in/out: [rows][B] floats; ring: [JF_TAPS][nf][B] floats; kst: [JF_KSTATE][nf][B] doubles.
+// V consecutive robots per lane (V = 4: every access is 16 bytes -- the scalar version's 4-byte accesses moved 256 B per wave
+// instruction and reached 0.54 of the HBM roofline at 64k robots; V = 1 for batches that are not a multiple of four) and row of the
+// message; blockIdx.y = row.  A row no filter owns is copied (torque-adjusted where it has a gain: chain rows >= 28).
+// in/out: [rows][B] floats; ring: [JF_TAPS][nf][B] floats; kst: [JF_KSTATE][nf][B] doubles.
 // head = window slot of the OLDEST sample (the one this call overwrites); first = this is the first message since
 // pb_joint_filter_init.
+template <int V>
+struct JfVec {
+  typedef float f_t __attribute__((ext_vector_type(V)));
+  typedef double d_t __attribute__((ext_vector_type(V)));
+};
+template <>
+struct JfVec<1> {
+  typedef float f_t;
+  typedef double d_t;
+};
+template <int V>
+__device__ __forceinline__ void jf_ldf(const float *p, float (&o)[V])
+{
+  const typename JfVec<V>::f_t v = *reinterpret_cast<const typename JfVec<V>::f_t *>(p);
+  if constexpr (V == 1) o[0] = v;
+  else {
+#pragma unroll
+    for (int i = 0; i < V; i++) o[i] = v[i];
+  }
+}
+template <int V>
+__device__ __forceinline__ void jf_stf(float *p, const float (&o)[V])
+{
+  typename JfVec<V>::f_t v;
+  if constexpr (V == 1) v = o[0];
+  else {
+#pragma unroll
+    for (int i = 0; i < V; i++) v[i] = o[i];
+  }
+  *reinterpret_cast<typename JfVec<V>::f_t *>(p) = v;
+}
+template <int V>
+__device__ __forceinline__ void jf_ldd(const double *p, double (&o)[V])
+{
+  const typename JfVec<V>::d_t v = *reinterpret_cast<const typename JfVec<V>::d_t *>(p);
+  if constexpr (V == 1) o[0] = v;
+  else {
+#pragma unroll
+    for (int i = 0; i < V; i++) o[i] = v[i];
+  }
+}
+template <int V>
+__device__ __forceinline__ void jf_std(double *p, const double (&o)[V])
+{
+  typename JfVec<V>::d_t v;
+  if constexpr (V == 1) v = o[0];
+  else {
+#pragma unroll
+    for (int i = 0; i < V; i++) v[i] = o[i];
+  }
+  *reinterpret_cast<typename JfVec<V>::d_t *>(p) = v;
+}
+template <int V>
 static __global__ __launch_bounds__(256) void k_joint_filter(JfPar par, int B, const float *__restrict__ pos, const float *__restrict__ vel,
                                                              const float *__restrict__ eff, float *__restrict__ out,
                                                              float *__restrict__ ring, double *__restrict__ kst, int head, int first,
                                                              double dt)
 {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = (blockIdx.x * blockDim.x + threadIdx.x) * V;   // (B is a multiple of V: the launcher's choice of V)
   const int row = blockIdx.y;
   if (b >= B) return;
   int f = -1;  // (uniform)
   for (int i = 0; i < par.nf; i++) f = (par.row[i] == row) ? i : f;
-  float x = pos[(long) row * B + b];
+  float x[V];
+  jf_ldf<V>(pos + (long) row * B + b, x);
   if (eff) {
     float g = 0.0f;
     for (int a = 0; a < par.nadj; a++) g = (par.adj_row[a] == row) ? par.adj_gain[a] : g;  // (uniform)
-    x = torque_adjust(x, eff[(long) row * B + b], g);
+    float e[V];
+    jf_ldf<V>(eff + (long) row * B + b, e);
+#pragma unroll
+    for (int v = 0; v < V; v++) x[v] = torque_adjust(x[v], e[v], g);
   }
-  float y = x;
+  float y[V];
+#pragma unroll
+  for (int v = 0; v < V; v++) y[v] = x[v];
   const long nfB = (long) par.nf * B, fb = (long) f * B + b;
   if (f >= 0 && par.mode == JF_LOWPASS) {
-    float w[JF_TAPS];
+    float w[JF_TAPS][V];
 #pragma unroll
     for (int i = 0; i < JF_TAPS - 1; i++) {  // the 13 samples that stay, oldest first: slots head + 1 ... head + 13 (mod 14)
       int s = head + 1 + i;
       s = s >= JF_TAPS ? s - JF_TAPS : s;
-      w[i] = first ? x : ring[(long) s * nfB + fb];
+      if (first) {
+#pragma unroll
+        for (int v = 0; v < V; v++) w[i][v] = x[v];
+      } else {
+        jf_ldf<V>(ring + (long) s * nfB + fb, w[i]);
+      }
     }
-    w[JF_TAPS - 1] = x;
-    y = jf_lowpass(par.coef, [&](int i) { return w[i]; });
+#pragma unroll
+    for (int v = 0; v < V; v++) {
+      w[JF_TAPS - 1][v] = x[v];
+      y[v] = jf_lowpass(par.coef, [&](int i) { return w[i][v]; });
+    }
     if (first) {
 #pragma unroll
-      for (int s = 0; s < JF_TAPS; s++) ring[(long) s * nfB + fb] = x;
+      for (int s = 0; s < JF_TAPS; s++) jf_stf<V>(ring + (long) s * nfB + fb, x);
     } else {
-      ring[(long) head * nfB + fb] = x;
+      jf_stf<V>(ring + (long) head * nfB + fb, x);
     }
   } else if (f >= 0) {
-    double s[JF_KSTATE];
+    double s[JF_KSTATE][V];
     if (first) {  // simple_kalman_filter.cpp:27-34: x_est = (x, x_dot), P stays the identity of the constructor, output = input
-      s[0] = (double) x;
-      s[1] = (double) vel[(long) row * B + b];
-      s[2] = 1.0; s[3] = 0.0; s[4] = 0.0; s[5] = 1.0;
+      float xd[V];
+      jf_ldf<V>(vel + (long) row * B + b, xd);
+#pragma unroll
+      for (int v = 0; v < V; v++) {
+        s[0][v] = (double) x[v];
+        s[1][v] = (double) xd[v];
+        s[2][v] = 1.0; s[3][v] = 0.0; s[4][v] = 0.0; s[5][v] = 1.0;
+      }
     } else {
 #pragma unroll
-      for (int i = 0; i < JF_KSTATE; i++) s[i] = kst[(long) i * nfB + fb];
-      y = jf_kalman(s, dt, x, par.pn_pos, par.pn_vel, par.r);
+      for (int i = 0; i < JF_KSTATE; i++) jf_ldd<V>(kst + (long) i * nfB + fb, s[i]);
+#pragma unroll
+      for (int v = 0; v < V; v++) {
+        double sv[JF_KSTATE];
+#pragma unroll
+        for (int i = 0; i < JF_KSTATE; i++) sv[i] = s[i][v];
+        y[v] = jf_kalman(sv, dt, x[v], par.pn_pos, par.pn_vel, par.r);
+#pragma unroll
+        for (int i = 0; i < JF_KSTATE; i++) s[i][v] = sv[i];
+      }
     }
 #pragma unroll
-    for (int i = 0; i < JF_KSTATE; i++) kst[(long) i * nfB + fb] = s[i];
+    for (int i = 0; i < JF_KSTATE; i++) jf_std<V>(kst + (long) i * nfB + fb, s[i]);
   }
-  out[(long) row * B + b] = y;
+  jf_stf<V>(out + (long) row * B + b, y);
 }
 #endif
 
