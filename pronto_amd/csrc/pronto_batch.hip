@@ -1217,12 +1217,16 @@ static int legodo_launch(pb_ctx *c, LegIn &in, const double *imu_block, int imu_
   mp.r_v2_uncertain = r_vxyz_uncertain * r_vxyz_uncertain;
   // the world constraint (the transition foot's world position) is tracked from the first call that asks for the position
   if (pos_out != nullptr) c->leg_par.world_constraint = 1;
-  if (c->ns == 15)
-    k_legodo<15><<<nblk(c->B), 64, 0, c->stream>>>(c->st, c->legd, c->legi, c->stride, c->B, utime, c->leg_par, in, c->leg_chain, ah, zero_delta, mp,
-                                                   delta_out, status_out, lo_out, mask_out, pos_out, pos_ok_out, c->k);
-  else
-    k_legodo<21><<<nblk(c->B), 64, 0, c->stream>>>(c->st, c->legd, c->legi, c->stride, c->B, utime, c->leg_par, in, c->leg_chain, ah, zero_delta, mp,
-                                                   delta_out, status_out, lo_out, mask_out, pos_out, pos_ok_out, c->k);
+  // per-filter joint blocks: two waves per 64 robots, one leg's forward kinematics each
+#define LEGODO_ARGS c->st, c->legd, c->legi, c->stride, c->B, utime, c->leg_par, in, c->leg_chain, ah, zero_delta, mp, delta_out, status_out, lo_out, mask_out, pos_out, pos_ok_out, c->k
+  if (in.kind == 1) {
+    if (c->ns == 15) k_legodo<15, true><<<nblk(c->B), 128, 0, c->stream>>>(LEGODO_ARGS);
+    else k_legodo<21, true><<<nblk(c->B), 128, 0, c->stream>>>(LEGODO_ARGS);
+  } else {
+    if (c->ns == 15) k_legodo<15><<<nblk(c->B), 64, 0, c->stream>>>(LEGODO_ARGS);
+    else k_legodo<21><<<nblk(c->B), 64, 0, c->stream>>>(LEGODO_ARGS);
+  }
+#undef LEGODO_ARGS
   LAUNCHCHK(c);
   return PB_OK;
 }

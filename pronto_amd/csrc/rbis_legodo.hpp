@@ -819,8 +819,10 @@ struct LegAhead {
   const double *imu = nullptr;  // [7][B]
   double v[7] = { 0, 0, 0, 0, 0, 0, 0 };
 };
-template <int NS>
-static __global__ __launch_bounds__(64, 2) void k_legodo(const double *__restrict__ st, double *__restrict__ legd,
+// SPLIT (per-filter joint blocks, 128-thread workgroups): a second wave runs the RIGHT leg's forward kinematics for the same 64
+// robots and hands the foot pose over through LDS -- half of the kinematics leaves the one wave's dependent chain.
+template <int NS, bool SPLIT = false>
+static __global__ __launch_bounds__(SPLIT ? 128 : 64, 2) void k_legodo(const double *__restrict__ st, double *__restrict__ legd,
                                                          int64_t *__restrict__ legi, long stride, int B, int64_t utime, LegPar par,
                                                          LegIn in, const LegChain *__restrict__ chain, LegAhead ah, int zero_delta, LegMeasPar mp,
                                                          double *__restrict__ delta_out, double *__restrict__ status_out,
@@ -829,8 +831,23 @@ static __global__ __launch_bounds__(64, 2) void k_legodo(const double *__restric
 {
   using L = Lay<NS>;
   using S = Slots<NS>;
-  const long b = (long) blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
+  __shared__ double foot_r[SPLIT ? 7 : 1][64];
+  const long b_raw = (long) blockIdx.x * 64 + (threadIdx.x & 63u);
+  const bool live = b_raw < B;
+  if (!SPLIT && !live) return;
+  const long b = live ? b_raw : (long) B - 1;   // (SPLIT: no lane returns before the barrier; lanes past the batch read the last robot)
+  if constexpr (SPLIT) {
+    if (threadIdx.x >= 64) {   // the helper wave
+      Pose T;
+      leg_fk_side(in, chain, 1, b, (long) B, T);
+#pragma unroll
+      for (int i = 0; i < 3; i++) foot_r[i][threadIdx.x & 63u] = T.t[i];
+#pragma unroll
+      for (int i = 0; i < 4; i++) foot_r[3 + i][threadIdx.x & 63u] = T.q[i];
+      __syncthreads();
+      return;
+    }
+  }
   LegState s;
   leg_load(s, legd, legi, stride, b, par.world_constraint != 0);
   Pose bl, br, delta;
@@ -863,7 +880,18 @@ static __global__ __launch_bounds__(64, 2) void k_legodo(const double *__restric
       ins_update_quat<NS>(chi, bg, wq, gyro, dt, k);
     }
   }
-  leg_inputs(in, chain, b, B, bl, br, fl, fr, ncl, ncr);
+  if constexpr (SPLIT) {
+    leg_fk_side(in, chain, 0, b, (long) B, bl);
+    leg_inputs_rest(in, b, (long) B, fl, fr, ncl, ncr);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 3; i++) br.t[i] = foot_r[i][threadIdx.x & 63u];
+#pragma unroll
+    for (int i = 0; i < 4; i++) br.q[i] = foot_r[3 + i][threadIdx.x & 63u];
+    if (!live) return;
+  } else {
+    leg_inputs(in, chain, b, B, bl, br, fl, fr, ncl, ncr);
+  }
   if (in.utimes != nullptr) utime = in.utimes[b];                 // this filter's own message time (independent segments)
   const bool msg_ok = in.valid == nullptr || in.valid[b] != 0;    // ... or no message at all for it
   int64_t prev = 0;
