@@ -8,7 +8,7 @@
 //
 //   g++ -std=c++17 -O2 -Iinclude -Ipronto_amd/csrc examples/shim_sweep_rate.cpp -Lpronto_amd/lib -lpronto_batch
 //       -Wl,-rpath,$PWD/pronto_amd/lib -o shim_sweep_rate
-//   ./shim_sweep_rate [filters=65536] [messages=2000] [n_states=15] [history_slots=0] [utime_history_span=1000000] [vo_every=0]
+//   ./shim_sweep_rate [filters=65536] [messages=2000] [n_states=15] [history_slots=0|derived] [utime_history_span=1000000] [vo_every=0]
 //                     [input=feet|joints] [pairs=one|two] [legodo mode=lin_rate|lin_rot_rate|pos_and_lin_rate]
 // input = joints: the log is a bot_core::joint_state_t stream and LegOdoHandler::processMessage(joint_state_t) runs the
 // forward kinematics per filter on the device too (the reference's own handler signature); pairs = two: the leg odometry as
@@ -52,8 +52,11 @@ int main(int argc, char **argv)
   const bool two_launches = argc > 8 && std::string(argv[8]) == "two";
   const std::string lomode = argc > 9 ? argv[9] : "lin_rate";   // state_estimator.legodo.mode: lin_rate | lin_rot_rate | pos_and_lin_rate
   BotParam param;
+  if (const char *ov = getenv("SHIM_SWEEP_OVERRIDES")) param.applyOverrides(ov);   // "key=value|key=value": extra BotParam keys (experiments)
   param.set("state_estimator.utime_history_span", span);
-  param.set("state_estimator.history_slots", slots);
+  // "derived": only utime_history_span is set, like every reference .cfg -- the estimator then derives its checkpoint pool
+  // (32 slots spaced over the span, mav_state_est_batch.hpp)
+  if (slots != "derived") param.set("state_estimator.history_slots", slots);
   param.set("state_estimator.fuse_ins_legodo", "true");
   param.set("state_estimator.ins.channel", "IMU");
   param.set("state_estimator.ins.q_gyro", 0.5);
@@ -179,11 +182,27 @@ int main(int argc, char **argv)
       fovis_handler.markKeyframe(&est);
     }
   };
-  const int warm = T / 10;
+  // The rate quoted is the steady state: with a history window the warm-up runs until the window has filled and slid once (messages are
+  // 2 ms apart).  While it fills, every message takes new device blocks from the driver (hipMalloc: ~10 us mostly, sporadically 10-20 ms
+  // once a few GB are held); SHIM_SWEEP_TRACE=1 prints the rate of every 100 messages and shows that transient.
+  int warm = T / 10;
+  if (slots != "0") warm = std::max(warm, (int) std::min<long long>(T / 2, atoll(span.c_str()) / 2000 + 100));
   for (int k = 0; k < warm; k++) feed(k);
   pb_sync(est.ctx);
   const auto t0 = std::chrono::steady_clock::now();
-  for (int k = warm; k < T; k++) feed(k);
+  if (getenv("SHIM_SWEEP_TRACE")) {
+    auto tp = t0;
+    for (int k = warm; k < T; k++) {
+      feed(k);
+      if ((k + 1) % 100 == 0) {
+        pb_sync(est.ctx);
+        const auto tn = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "  messages ..%d: %.1f us each\n", k + 1, std::chrono::duration<double>(tn - tp).count() / 100 * 1e6);
+        tp = tn;
+      }
+    }
+  } else
+    for (int k = warm; k < T; k++) feed(k);
   pb_sync(est.ctx);
   const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   if (est.last_status != PB_OK) { std::fprintf(stderr, "shim_sweep_rate: %s\n", pb_last_error(est.ctx)); return 1; }

@@ -206,6 +206,9 @@ struct DevicePool {
     if (alive && *alive)
       for (void *p : free_) pb_free(ctx, p);
   }
+  // One hipMalloc per NEW block, on purpose: while the history window is still filling (the first utime_history_span of a run, ~500
+  // blocks for the reference's 1 s) a few-MB hipMalloc measures ~10 us and hides behind the step it feeds, whereas slabs of many
+  // blocks stall the message that asks for them (a 1 GiB hipMalloc: up to 30 ms, profiles/r04_shim_sweep.txt).
   void *get(bool &fresh)
   {
     fresh = free_.empty();
@@ -503,7 +506,16 @@ public:
     pb_set_utime(ctx, head_utime);
     history.updateMap.insert(updateHistory::historyPair(init_state->utime, init_state));  // update_history.cpp:5-8
     device_head = init_state;
-    if (history_slots > 0) save_checkpoint(init_state);
+    if (history_slots > 0) {
+      save_checkpoint(init_state);
+      // A replay never re-applies the first element of the history (it starts from that element's checkpoint), so the [n][B] and
+      // [n][n][B] host arrays of the initial reset are given back here: freeing them when the window first slides past the
+      // initial state (126 MB at 64k x 15 states, 243 MB at 21) stalls that one message for 16-41 ms.
+      if (checkpoint_of.count(init_state)) {
+        init_state->reset_state = RBIS();
+        init_state->reset_cov = RBIM();
+      }
+    }
     unprocessed_updates_start = history.updateMap.end();
   }
   ~MavStateEstimator()

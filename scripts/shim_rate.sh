@@ -19,6 +19,9 @@ EXE=tests/build/shim_sweep_rate
   $EXE 65536 2000 15 32
   $EXE 65536 2000 15 32 1000000 0 joints
   $EXE 65536 2000 15 0 1000000 32
+  # the history as every reference .cfg gets it (only utime_history_span set: 32 slots spaced over the span)
+  $EXE 65536 2000 15 derived 1000000 0 joints
+  $EXE 65536 2000 21 derived 1000000 0 joints
   $EXE 65536 2000 21 0
   $EXE 65536 2000 21 0 1000000 0 joints
   $EXE 65536 2000 21 32
