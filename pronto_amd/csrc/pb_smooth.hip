@@ -1,6 +1,7 @@
 // pb_smooth.hip -- launcher of the RTS smoother kernel (rbis_smooth.hpp); see pb_ctx.hpp.
 #include "pb_ctx.hpp"
 #include "rbis_smooth.hpp"
+#include "rbis_smooth_lane.hpp"
 
 int pbk_smooth_step(pb_ctx *c, const double *np_, const double *ns_, const double *cu, double *out, double dt)
 {
@@ -16,7 +17,12 @@ int pbk_smooth_step(pb_ctx *c, const double *np_, const double *ns_, const doubl
   // PRONTO_SMOOTH_PIVOT=1: Eigen's diagonal pivoting in the factorisation of P^- (the reference's .ldlt(); parity with the oracle at
   // 1e-15); default: no pivot search (P^- is SPD; rbis_smooth.hpp)
   static const bool pivot = getenv("PRONTO_SMOOTH_PIVOT") && getenv("PRONTO_SMOOTH_PIVOT")[0] == '1';
+  // PRONTO_SMOOTH_KERNEL=reg: the 16 / 32-lanes-per-filter kernel of rounds 2-4 (rbis_smooth.hpp); default: one lane per filter,
+  // the dense work split over role waves (rbis_smooth_lane.hpp)
+  static const bool reg_kernel = pivot || (getenv("PRONTO_SMOOTH_KERNEL") && !strcmp(getenv("PRONTO_SMOOTH_KERNEL"), "reg"));
   if (!c->smooth_attr) {  // more than the default 64 KB of dynamic LDS per workgroup
+    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_smooth_lane<15>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) SmoothLaneCfg<15>::LDS_BYTES));
+    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_smooth_lane<21>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) SmoothLaneCfg<21>::LDS_BYTES));
     const int l15 = (int) (pad + sizeof(double) * SmoothRegCfg<15>::LDS_DOUBLES), l21 = (int) (pad + sizeof(double) * SmoothRegCfg<21>::LDS_DOUBLES);
     HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_smooth_reg<15, true>), hipFuncAttributeMaxDynamicSharedMemorySize, l15));
     HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_smooth_reg<21, true>), hipFuncAttributeMaxDynamicSharedMemorySize, l21));
@@ -24,7 +30,11 @@ int pbk_smooth_step(pb_ctx *c, const double *np_, const double *ns_, const doubl
     HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_smooth_reg<21, false>), hipFuncAttributeMaxDynamicSharedMemorySize, l21));
     c->smooth_attr = true;
   }
-  if (c->ns == 15) {
+  if (!reg_kernel) {
+    const dim3 grid((unsigned) ((c->B + 63) / 64));
+    if (c->ns == 15) k_smooth_lane<15><<<grid, SmoothLaneCfg<15>::THREADS, SmoothLaneCfg<15>::LDS_BYTES, c->stream>>>(np_, ns_, cu, out, c->B, dt, c->k);
+    else k_smooth_lane<21><<<grid, SmoothLaneCfg<21>::THREADS, SmoothLaneCfg<21>::LDS_BYTES, c->stream>>>(np_, ns_, cu, out, c->B, dt, c->k);
+  } else if (c->ns == 15) {
     using S = SmoothRegCfg<15>;
     const dim3 grid((unsigned) ((c->B + S::F - 1) / S::F));
     const size_t ldsb = pad + sizeof(double) * S::LDS_DOUBLES;

@@ -1,0 +1,365 @@
+// rbis_smooth_lane.hpp -- the RTS smoother step (ekfSmoothingStep, state-estimator/src/mav_state_est/rbis.cpp:234-266) with ONE LANE
+// PER FILTER and the dense n x n work split over NR role waves of a 64-filter tile (round 4; replaces k_smooth_reg as the default).
+//
+//   G      = P_k Ad^T (P^-_{k+1})^-1      P^s_k = P_k + G (P^s_{k+1} - P^-_{k+1}) G^T      x^s_k = x_k (+) G (x^s_{k+1} (-) x^-_{k+1})
+//
+// k_smooth_reg (rbis_smooth.hpp) gives a filter to 16 / 32 lanes: every step of the factorisation is a cross-lane round trip (publish
+// the pivot row, read it back), 2 500-3 800 VALU instructions per wave of 4 / 2 filters, 0.19 / 0.11 of the HBM roofline for three
+// rounds.  Here a lane owns a filter as in the forward step, so every index is a compile-time constant and nothing crosses lanes; what
+// one lane cannot hold (P^-, Ad P_k, D and G are n x n each) is split over the waves of the workgroup and LDS:
+//   * role w owns the columns c = w, w + NR, ... of the factorisation, the same columns of the right-hand side Ad P_k and therefore
+//     the same ROWS of the gain G -- in registers;
+//   * P^- = L diag(d) L^T, right-looking, NOT pivoted (P^- is SPD; the reference's .ldlt() pivots on the diagonal, the results
+//     differ by rounding: tests <= 1e-9 against the oracle): the owner of column k publishes l_ik into LDS (where the factor has
+//     to end up anyway), one barrier, every role downdates its own columns.  The factor lives in LDS [packed entry][64 lanes]:
+//     a lane reads ITS filter's entry, 512 contiguous bytes per wave, no bank conflict, and every entry read feeds NCOL FMAs;
+//   * the substitutions run out of that LDS factor on the role's NCOL right-hand sides: G rows come out in registers;
+//   * D = P^s - P^- takes the factor's place in LDS; the rows of M = G D are made by their owners, CH at a time, and handed round
+//     through a small exchange region: P^s[r][c] = P_k[r][c] + G[r] . M[c] is complete as soon as M[c] is there, and is stored at once.
+// One instruction stream for all roles (the role enters as scalar offsets and wave-uniform branches), so the instruction cache
+// holds one copy.  Columns past n (n is not a multiple of NR) are stand-ins that mirror column n-1 and never store.
+// LDS per 64-filter tile: (n (n + 1) / 2 + CH n) doubles per lane = 77 KB (n = 15, two workgroups per CU), 150 KB (n = 21).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "rbis_device.hpp"
+
+namespace pb {
+
+#ifndef SM_LANE_CH15
+#define SM_LANE_CH15 2
+#endif
+
+template <int NS>
+struct SmoothLaneCfg {
+  using L = Lay<NS>;
+  using SL = Slots<NS>;
+  static constexpr int NR = (NS <= 16) ? 4 : 8;          // role waves per tile
+  static constexpr int NCOL = (NS + NR - 1) / NR;        // columns / gain rows per role
+  static constexpr int CH = (NS <= 16) ? SM_LANE_CH15 : 3;  // rows of M per exchange (<= NR: at most one per role)
+  static constexpr int NP = L::NP;
+  static constexpr int O_X = NP;                         // exchange region: residual + dx first, then CH rows of M
+  static constexpr int PER = NP + CH * NS;               // doubles per lane
+  static constexpr int THREADS = 64 * NR;
+  static constexpr int WAVES_PER_SIMD = 2;               // 8 waves per CU either way: 256 registers per lane
+  static constexpr size_t LDS_BYTES = sizeof(double) * PER * 64;
+  static_assert(CH >= 2 && CH <= NR, "the exchange region holds the residual and dx; one M row per role and chunk");
+  // component -> offset (doubles) of lane 0's copy inside a tile (rbis_device.hpp: slot s sits in row s / 2, half s % 2)
+  static constexpr int off_of(int comp) { return (SL::T.slot_of[comp] / 2) * 128 + (SL::T.slot_of[comp] % 2); }
+  // What depends on the role is read from constant memory with wide scalar loads, ONE table row per use: col[w][t][i] = offset of
+  // P(i, column w + NR t) -- by symmetry also of P(row w + NR t, i) --, dsrc[w][u] = offset of packed entry w + NR u.
+  static constexpr int DU = (NP + NR - 1) / NR, NSP = (NS + 3) & ~3;
+  struct Tab {
+    int col[NR][NCOL][NSP];
+    int dsrc[NR][(DU + 3) & ~3];
+  };
+  static constexpr Tab make()
+  {
+    Tab t{};
+    for (int w = 0; w < NR; w++) {
+      for (int c = 0; c < NCOL; c++) {
+        const int j = (w + NR * c < NS) ? w + NR * c : NS - 1;
+        for (int i = 0; i < NSP; i++) t.col[w][c][i] = off_of(L::OFF_P + pk(i < NS ? i : NS - 1, j));
+      }
+      for (int u = 0; u < ((DU + 3) & ~3); u++) t.dsrc[w][u] = off_of(L::OFF_P + ((w + NR * u < NP) ? w + NR * u : NP - 1));
+    }
+    return t;
+  }
+};
+template <int NS>
+__constant__ const typename SmoothLaneCfg<NS>::Tab smooth_lane_tab = SmoothLaneCfg<NS>::make();
+
+__device__ __forceinline__ int pk_s(int i, int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
+
+template <int NS>
+__global__ __launch_bounds__(SmoothLaneCfg<NS>::THREADS, SmoothLaneCfg<NS>::WAVES_PER_SIMD) void k_smooth_lane(
+    const double *__restrict__ next_pred, const double *__restrict__ next_sm, const double *cur, double *out, int B, double dt, Consts k)
+{
+  using L = Lay<NS>;
+  using SL = Slots<NS>;
+  using C = SmoothLaneCfg<NS>;
+  constexpr int NR = C::NR, NCOL = C::NCOL, CH = C::CH, NP = C::NP, O_X = C::O_X;
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
+  const long tb = (long) blockIdx.x * SL::TILE_DOUBLES + lane * 2;
+  const bool active = (long) blockIdx.x * 64 + lane < B;
+  const auto &tab = smooth_lane_tab<NS>;
+  double *const S = lds + lane;  // entry e of this lane's filter: S[e * 64]
+  auto ldc = [&](const double *src, int comp) { return src[tb + C::off_of(comp)]; };  // compile-time component only
+  // column t of this role from one of the checkpoints: the offsets come in with wide scalar loads, the n loads go out back to back
+  auto ld_col = [&](const double *src, int t, double (&v)[NS]) {
+    int o[NS];
+#pragma unroll
+    for (int i = 0; i < NS; i++) o[i] = tab.col[w][t][i];
+#pragma unroll
+    for (int i = 0; i < NS; i++) v[i] = src[tb + o[i]];
+  };
+
+  int cidx[NCOL], cc[NCOL];  // this role's columns (gain rows); stand-ins mirror column n - 1
+#pragma unroll
+  for (int t = 0; t < NCOL; t++) {
+    cidx[t] = w + NR * t;
+    cc[t] = cidx[t] < NS ? cidx[t] : NS - 1;
+  }
+
+  // ---- 0. residual x^s (-) x^- (rbis.cpp:258-261), by role 0, into the exchange region ----
+  if (w == 0) {
+    double qs[4], qp[4], dchi[3];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      qs[i] = ldc(next_sm, L::OFF_QUAT + i);
+      qp[i] = ldc(next_pred, L::OFF_QUAT + i);
+    }
+    subtract_quats(qs, qp, dchi);
+#pragma unroll
+    for (int i = 0; i < NS; i++) {
+      const double r = ldc(next_sm, L::OFF_VEC + i) - ldc(next_pred, L::OFF_VEC + i);
+      S[(O_X + i) * 64] = (i >= 6 && i <= 8) ? dchi[i - 6] : r;
+    }
+  }
+
+  // ---- 1. P^- = L diag(d) L^T ----
+  {
+    double a[NCOL][NS];
+#pragma unroll
+    for (int t = 0; t < NCOL; t++) ld_col(next_pred, t, a[t]);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (NS == 21) {  // rbis.cpp:244-251: a bias block whose variance is < 1e-11 is replaced by I in the factorised matrix
+      bool fix_g = false, fix_a = false;
+#pragma unroll
+      for (int i = 0; i < 3; i++) {
+        fix_g = fix_g | (ldc(next_pred, L::OFF_P + pk(15 + i, 15 + i)) < .00000000001);
+        fix_a = fix_a | (ldc(next_pred, L::OFF_P + pk(18 + i, 18 + i)) < .00000000001);
+      }
+#pragma unroll
+      for (int t = 0; t < NCOL; t++)
+#pragma unroll
+        for (int i = 15; i < 21; i++) {
+          const bool gblk = i < 18, in_blk = gblk ? (cc[t] >= 15 && cc[t] < 18) : (cc[t] >= 18);
+          a[t][i] = ((gblk ? fix_g : fix_a) && in_blk) ? (i == cc[t] ? 1.0 : 0.0) : a[t][i];
+        }
+    }
+    double inv_prev = 0.0;
+    static_for<NS>([&](auto KK) {
+      constexpr int kk = decltype(KK)::value;
+      if (w == kk % NR) {  // owner of column kk
+        constexpr int t = kk / NR;
+        const double d = a[t][kk];
+        const double inv = (fabs(d) > 5.562684646268003e-309) ? 1.0 / d : 0.0;
+        S[pk(kk, kk) * 64] = (kk == NS - 1) ? inv : d;
+#pragma unroll
+        for (int i = kk + 1; i < NS; i++) S[pk(i, kk) * 64] = a[t][i] * inv;
+        inv_prev = inv;
+      }
+      __syncthreads();
+      // the diagonal slot of column kk-1 held d for the downdates of step kk-1; every role is past them now: it becomes 1/d
+      if constexpr (kk > 0)
+        if (w == (kk - 1) % NR) S[pk(kk - 1, kk - 1) * 64] = inv_prev;
+      if constexpr (kk + 1 < NS) {
+        const double dk = S[pk(kk, kk) * 64];
+        double tc[NCOL];
+#pragma unroll
+        for (int t = 0; t < NCOL; t++) tc[t] = S[pk_s(cc[t], kk) * 64] * dk;
+#pragma unroll
+        for (int i = kk + 1; i < NS; i++) {
+          const double lik = S[pk(i, kk) * 64];
+#pragma unroll
+          for (int t = 0; t < NCOL; t++) a[t][i] = fma(-lik, tc[t], a[t][i]);
+        }
+      }
+    });
+  }
+
+  // ---- 2. right-hand sides: columns cc[t] of Ad P_k, Ad = I + dt Ac about the filtered state (rbis.cpp:12-35, 236-239) ----
+  double z[NCOL][NS];
+  {
+    double wv[3], v[3], q[4], R[9];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      wv[i] = ldc(cur, L::OFF_VEC + i);
+      v[i] = ldc(cur, L::OFF_VEC + 3 + i);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) q[i] = ldc(cur, L::OFF_QUAT + i);
+    quat_to_rot(q, R);
+    const double gb[3] = { -k.g * R[6], -k.g * R[7], -k.g * R[8] };
+#pragma unroll
+    for (int t = 0; t < NCOL; t++) {
+      double p[NS];
+      ld_col(cur, t, p);
+#pragma unroll
+      for (int i = 0; i < NS; i++) z[t][i] = p[i];
+      const double pv[3] = { p[3], p[4], p[5] }, pc[3] = { p[6], p[7], p[8] };
+      // v rows: -w x p_v + g_b x p_chi [- v x p_bg - p_ba];  chi rows: -w x p_chi [- p_bg];  Delta rows: R p_v - R (v x p_chi)
+      const double wxpv[3] = { wv[1] * pv[2] - wv[2] * pv[1], wv[2] * pv[0] - wv[0] * pv[2], wv[0] * pv[1] - wv[1] * pv[0] };
+      const double gxpc[3] = { gb[1] * pc[2] - gb[2] * pc[1], gb[2] * pc[0] - gb[0] * pc[2], gb[0] * pc[1] - gb[1] * pc[0] };
+      const double wxpc[3] = { wv[1] * pc[2] - wv[2] * pc[1], wv[2] * pc[0] - wv[0] * pc[2], wv[0] * pc[1] - wv[1] * pc[0] };
+      const double vxpc[3] = { v[1] * pc[2] - v[2] * pc[1], v[2] * pc[0] - v[0] * pc[2], v[0] * pc[1] - v[1] * pc[0] };
+#pragma unroll
+      for (int i = 0; i < 3; i++) {
+        double av = -wxpv[i] + gxpc[i], ac = -wxpc[i];
+        if constexpr (NS == 21) {
+          const double pbg[3] = { p[15], p[16], p[17] };
+          const double vxpbg = (i == 0) ? v[1] * pbg[2] - v[2] * pbg[1] : (i == 1 ? v[2] * pbg[0] - v[0] * pbg[2] : v[0] * pbg[1] - v[1] * pbg[0]);
+          av += -vxpbg - p[18 + i];
+          ac += -pbg[i];
+        }
+        const double ad = R[3 * i] * (pv[0] - vxpc[0]) + R[3 * i + 1] * (pv[1] - vxpc[1]) + R[3 * i + 2] * (pv[2] - vxpc[2]);
+        z[t][3 + i] = fma(dt, av, z[t][3 + i]);
+        z[t][6 + i] = fma(dt, ac, z[t][6 + i]);
+        z[t][9 + i] = fma(dt, ad, z[t][9 + i]);
+      }
+    }
+  }
+  __syncthreads();  // the factor is complete (the last reciprocal pivots were written behind the last barrier of step 1)
+
+  // ---- 3. (P^-) X = Ad P_k out of the LDS factor: z[t][:] becomes row cidx[t] of G ----
+#pragma unroll
+  for (int i = 1; i < NS; i++)
+#pragma unroll
+    for (int m = 0; m < i; m++) {
+      const double l = S[pk(i, m) * 64];
+#pragma unroll
+      for (int t = 0; t < NCOL; t++) z[t][i] = fma(-l, z[t][m], z[t][i]);
+      if (m == i - 1 && (i & 1)) __builtin_amdgcn_sched_barrier(0);  // (the factor is read as it is used, not hoisted: registers)
+    }
+#pragma unroll
+  for (int i = 0; i < NS; i++) {
+    const double inv = S[pk(i, i) * 64];
+#pragma unroll
+    for (int t = 0; t < NCOL; t++) z[t][i] *= inv;
+  }
+#pragma unroll
+  for (int i = NS - 2; i >= 0; i--)
+#pragma unroll
+    for (int m = i + 1; m < NS; m++) {
+      const double l = S[pk(m, i) * 64];
+#pragma unroll
+      for (int t = 0; t < NCOL; t++) z[t][i] = fma(-l, z[t][m], z[t][i]);
+      if (m == NS - 1 && (i & 1)) __builtin_amdgcn_sched_barrier(0);
+    }
+  // dx = G resid (rbis.cpp:263): this role's entries
+  double dxv[NCOL];
+#pragma unroll
+  for (int t = 0; t < NCOL; t++) dxv[t] = 0.0;
+#pragma unroll
+  for (int i = 0; i < NS; i++) {
+    const double r = S[(O_X + i) * 64];
+#pragma unroll
+    for (int t = 0; t < NCOL; t++) dxv[t] = fma(z[t][i], r, dxv[t]);
+  }
+  __syncthreads();  // factor and residual are dead
+
+  // ---- 4. D = P^s - P^- (the uncorrected P^-, rbis.cpp:256) takes the factor's place; dx goes behind the residual ----
+#pragma unroll
+  for (int t = 0; t < NCOL; t++)
+    if (cidx[t] < NS) S[(O_X + NS + cidx[t]) * 64] = dxv[t];
+  {
+    double ds[C::DU], dp[C::DU];
+    int o[C::DU];
+#pragma unroll
+    for (int u = 0; u < C::DU; u++) o[u] = tab.dsrc[w][u];
+#pragma unroll
+    for (int u = 0; u < C::DU; u++) {
+      ds[u] = next_sm[tb + o[u]];
+      dp[u] = next_pred[tb + o[u]];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < C::DU; u++) {
+      const int e = w + NR * u;
+      if (e < NP) S[e * 64] = ds[u] - dp[u];
+    }
+  }
+  __syncthreads();
+
+  // ---- 5. state: cur.addState(RBIS(dx)) (rbis.cpp:263-265), by role 0 ----
+  if (w == 0) {
+    double dchi[3] = { S[(O_X + NS + 6) * 64], S[(O_X + NS + 7) * 64], S[(O_X + NS + 8) * 64] };
+    double dq[4] = { 1.0, 0.0, 0.0, 0.0 };
+    fold_chi(dchi, dq, k.chi_tol);  // RBIS(vec) constructor
+    double chi[3], qq[4], o[4];
+#pragma unroll
+    for (int i = 0; i < 3; i++) chi[i] = ldc(cur, L::OFF_VEC + 6 + i) + dchi[i];
+#pragma unroll
+    for (int i = 0; i < 4; i++) qq[i] = ldc(cur, L::OFF_QUAT + i);
+    fold_chi(chi, qq, k.chi_tol);
+    quat_mul(qq, dq, o);
+    const double ll = ldc(cur, L::OFF_LL);
+    double xo[NS];
+#pragma unroll
+    for (int i = 0; i < NS; i++) xo[i] = (i >= 6 && i <= 8) ? chi[i - 6] : ldc(cur, L::OFF_VEC + i) + S[(O_X + NS + i) * 64];
+    if (active) {
+#pragma unroll
+      for (int i = 0; i < NS; i++) out[tb + C::off_of(L::OFF_VEC + i)] = xo[i];
+#pragma unroll
+      for (int i = 0; i < 4; i++) out[tb + C::off_of(L::OFF_QUAT + i)] = o[i];
+      out[tb + C::off_of(L::OFF_LL)] = ll;
+    }
+  }
+
+  // ---- 6. P^s = P_k + G D G^T, CH rows of M = G D at a time ----
+#pragma unroll 1
+  for (int c0 = 0; c0 < NS; c0 += CH) {
+    // the owner of row c makes M[c][:] = G[c][:] D in registers (every entry of the symmetric D is read once)
+    double m[NS];
+    int mcc = -1;
+    // P_k(r, c) of this chunk's columns for the role's rows: requested now, used behind the two barriers
+    double pkv[NCOL][CH];
+    int po[NCOL][CH];
+#pragma unroll
+    for (int t = 0; t < NCOL; t++)
+#pragma unroll
+      for (int q = 0; q < CH; q++) {
+        po[t][q] = tab.col[w][t][(c0 + q < NS) ? c0 + q : NS - 1];
+        pkv[t][q] = cur[tb + po[t][q]];
+      }
+#pragma unroll
+    for (int t = 0; t < NCOL; t++) {
+      const int rel = cidx[t] - c0;
+      if (rel >= 0 && rel < CH && cidx[t] < NS) {
+        mcc = rel;
+#pragma unroll
+        for (int j = 0; j < NS; j++) m[j] = 0.0;
+#pragma unroll
+        for (int i = 0; i < NS; i++)
+#pragma unroll
+          for (int j = 0; j <= i; j++) {
+            const double d = S[pk(i, j) * 64];
+            m[j] = fma(z[t][i], d, m[j]);
+            if (i != j) m[i] = fma(z[t][j], d, m[i]);
+            if (j == i && (i & 1)) __builtin_amdgcn_sched_barrier(0);  // (keeps the reads of D from being hoisted: registers)
+          }
+      }
+    }
+    __syncthreads();  // the readers of the previous chunk (and of dx) are done
+    if (mcc >= 0) {
+#pragma unroll
+      for (int j = 0; j < NS; j++) S[(O_X + mcc * NS + j) * 64] = m[j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < CH; q++) {
+      const int c = c0 + q;
+      if (c < NS && c <= cidx[NCOL - 1]) {  // (wave-uniform) some row of this role is at or below the diagonal of column c
+        double mr[NS];
+#pragma unroll
+        for (int j = 0; j < NS; j++) mr[j] = S[(O_X + q * NS + j) * 64];
+#pragma unroll
+        for (int t = 0; t < NCOL; t++) {
+          const int r = cidx[t];
+          if (r < NS && c <= r) {
+            double acc = pkv[t][q];
+#pragma unroll
+            for (int j = 0; j < NS; j++) acc = fma(z[t][j], mr[j], acc);
+            if (active) out[tb + po[t][q]] = acc;
+          }
+        }
+      }
+    }
+  }
+}
+
+}  // namespace pb
