@@ -25,6 +25,12 @@
 
 #include "rbis_device.hpp"
 
+// attribution builds (scripts/smooth_attribution.sh lane...): parts compiled OUT, results are garbage, only the time means something
+#if !defined(PB_EXPERIMENTS) && (defined(SML_SKIP_FACT) || defined(SML_SKIP_RHS) || defined(SML_SKIP_SUBST) || defined(SML_SKIP_D) || \
+                                 defined(SML_SKIP_M) || defined(SML_SKIP_FINAL) || defined(SML_SKIP_CHUNKS))
+#error "the SML_* attribution flags need -DPB_EXPERIMENTS as well"
+#endif
+
 namespace pb {
 
 #ifndef SM_LANE_CH15
@@ -35,12 +41,21 @@ template <int NS>
 struct SmoothLaneCfg {
   using L = Lay<NS>;
   using SL = Slots<NS>;
-  static constexpr int NR = (NS <= 16) ? 4 : 8;          // role waves per tile
+#ifndef SM_LANE_PKEEP
+#define SM_LANE_PKEEP 0
+#endif
+#ifndef SM_LANE_FULLM15
+#define SM_LANE_FULLM15 1
+#endif
+  // 15 states: ALL rows of M = G D are exchanged at once (n x n doubles per lane fit beside nothing else: one workgroup per CU);
+  // 21 states: that is 226 KB -- the rows go round CH at a time, beside D
+  static constexpr bool FULLM = (NS <= 16) && SM_LANE_FULLM15;
+  static constexpr int NR = FULLM ? 8 : ((NS <= 16) ? 4 : 8);  // role waves per tile
   static constexpr int NCOL = (NS + NR - 1) / NR;        // columns / gain rows per role
   static constexpr int CH = (NS <= 16) ? SM_LANE_CH15 : 3;  // rows of M per exchange (<= NR: at most one per role)
   static constexpr int NP = L::NP;
-  static constexpr int O_X = NP;                         // exchange region: residual + dx first, then CH rows of M
-  static constexpr int PER = NP + CH * NS;               // doubles per lane
+  static constexpr int O_X = FULLM ? NS * NS : NP;       // exchange region: residual + dx first, then CH rows of M
+  static constexpr int PER = O_X + CH * NS;              // doubles per lane
   static constexpr int THREADS = 64 * NR;
   static constexpr int WAVES_PER_SIMD = 2;               // 8 waves per CU either way: 256 registers per lane
   static constexpr size_t LDS_BYTES = sizeof(double) * PER * 64;
@@ -70,11 +85,33 @@ struct SmoothLaneCfg {
 template <int NS>
 __constant__ const typename SmoothLaneCfg<NS>::Tab smooth_lane_tab = SmoothLaneCfg<NS>::make();
 
+// A pointer the optimiser knows nothing about from here on: loads through it stay behind this point.  (The checkpoints are read-only
+// and __restrict__, so every load of the kernel would otherwise be hoisted to its top -- 150 doubles per lane in flight and spilled.)
+__device__ __forceinline__ const double *launder(const double *p)
+{
+  asm volatile("" : "+s"(p));
+  return p;
+}
+
+// End of a group of LDS reads.  The backend gathers independent LDS reads at the top of a block whatever scheduling barriers sit
+// between them (all of D: 240 registers, spilled), so the NEXT group's reads are made to depend on this group's arithmetic: the
+// lane's LDS index passes through an empty asm that also names a result of the group.  The memory clobber makes a later read of
+// the same entry a real read instead of a value kept in registers since its first use (the backward substitution reads what the
+// forward one read).
+__device__ __forceinline__ void lane_fence(int &sb, double after)
+{
+  asm volatile("" : "+v"(sb) : "v"(after) : "memory");
+}
+
+// The value is COMPUTED here: without this the backend sinks arithmetic below the next barrier to its first use, and what it was
+// computed from (LDS reads that cannot follow it across the barrier) stays live or is spilled (rbis_coop.hpp, pb_pin).
+__device__ __forceinline__ void lane_pin(double &v) { asm volatile("" : "+v"(v)); }
+
 __device__ __forceinline__ int pk_s(int i, int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
 
 template <int NS>
 __global__ __launch_bounds__(SmoothLaneCfg<NS>::THREADS, SmoothLaneCfg<NS>::WAVES_PER_SIMD) void k_smooth_lane(
-    const double *__restrict__ next_pred, const double *__restrict__ next_sm, const double *cur, double *out, int B, double dt, Consts k)
+    const double *__restrict__ next_pred_, const double *__restrict__ next_sm_, const double *cur_, double *out, int B, double dt, Consts k)
 {
   using L = Lay<NS>;
   using SL = Slots<NS>;
@@ -86,15 +123,17 @@ __global__ __launch_bounds__(SmoothLaneCfg<NS>::THREADS, SmoothLaneCfg<NS>::WAVE
   const long tb = (long) blockIdx.x * SL::TILE_DOUBLES + lane * 2;
   const bool active = (long) blockIdx.x * 64 + lane < B;
   const auto &tab = smooth_lane_tab<NS>;
-  double *const S = lds + lane;  // entry e of this lane's filter: S[e * 64]
+  const double *next_pred = next_pred_, *next_sm = next_sm_;
+  int sb = lane;  // entry e of this lane's filter: lds[sb + e * 64] (sb passes through lane_fence)
+#define S (lds + sb)
   auto ldc = [&](const double *src, int comp) { return src[tb + C::off_of(comp)]; };  // compile-time component only
   // column t of this role from one of the checkpoints: the offsets come in with wide scalar loads, the n loads go out back to back
-  auto ld_col = [&](const double *src, int t, double (&v)[NS]) {
+  auto ld_col = [&](const double *src, int t, int i0, double (&v)[NS]) {  // rows i0 .. n-1 (the others: 0)
     int o[NS];
 #pragma unroll
     for (int i = 0; i < NS; i++) o[i] = tab.col[w][t][i];
 #pragma unroll
-    for (int i = 0; i < NS; i++) v[i] = src[tb + o[i]];
+    for (int i = 0; i < NS; i++) v[i] = (i >= i0) ? src[tb + o[i]] : 0.0;
   };
 
   int cidx[NCOL], cc[NCOL];  // this role's columns (gain rows); stand-ins mirror column n - 1
@@ -124,7 +163,7 @@ __global__ __launch_bounds__(SmoothLaneCfg<NS>::THREADS, SmoothLaneCfg<NS>::WAVE
   {
     double a[NCOL][NS];
 #pragma unroll
-    for (int t = 0; t < NCOL; t++) ld_col(next_pred, t, a[t]);
+    for (int t = 0; t < NCOL; t++) ld_col(next_pred, t, NR * t, a[t]);  // column w + NR t: rows above NR t are above its diagonal for every role
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (NS == 21) {  // rbis.cpp:244-251: a bias block whose variance is < 1e-11 is replaced by I in the factorised matrix
       bool fix_g = false, fix_a = false;
@@ -144,6 +183,10 @@ __global__ __launch_bounds__(SmoothLaneCfg<NS>::THREADS, SmoothLaneCfg<NS>::WAVE
     double inv_prev = 0.0;
     static_for<NS>([&](auto KK) {
       constexpr int kk = decltype(KK)::value;
+#ifdef SML_SKIP_FACT
+      if (kk == 0) S[0] = a[0][0] + a[NCOL - 1][NS - 1];
+      return;
+#endif
       if (w == kk % NR) {  // owner of column kk
         constexpr int t = kk / NR;
         const double d = a[t][kk];
@@ -159,14 +202,21 @@ __global__ __launch_bounds__(SmoothLaneCfg<NS>::THREADS, SmoothLaneCfg<NS>::WAVE
         if (w == (kk - 1) % NR) S[pk(kk - 1, kk - 1) * 64] = inv_prev;
       if constexpr (kk + 1 < NS) {
         const double dk = S[pk(kk, kk) * 64];
+        // column slot t holds a column c in [NR t, NR t + NR): it is finished once kk >= NR (t + 1) - 1, and its rows above NR t
+        // are above the diagonal -- neither is touched (compile-time bounds; what remains above the diagonal is never read)
         double tc[NCOL];
 #pragma unroll
-        for (int t = 0; t < NCOL; t++) tc[t] = S[pk_s(cc[t], kk) * 64] * dk;
+        for (int t = 0; t < NCOL; t++)
+          if (kk < NR * (t + 1) - 1) tc[t] = S[pk_s(cc[t], kk) * 64] * dk;
 #pragma unroll
         for (int i = kk + 1; i < NS; i++) {
           const double lik = S[pk(i, kk) * 64];
 #pragma unroll
-          for (int t = 0; t < NCOL; t++) a[t][i] = fma(-lik, tc[t], a[t][i]);
+          for (int t = 0; t < NCOL; t++)
+            if (kk < NR * (t + 1) - 1 && i >= NR * t) {
+              a[t][i] = fma(-lik, tc[t], a[t][i]);
+              lane_pin(a[t][i]);  // (downdated NOW, not when the column is published)
+            }
         }
       }
     });
@@ -174,7 +224,9 @@ __global__ __launch_bounds__(SmoothLaneCfg<NS>::THREADS, SmoothLaneCfg<NS>::WAVE
 
   // ---- 2. right-hand sides: columns cc[t] of Ad P_k, Ad = I + dt Ac about the filtered state (rbis.cpp:12-35, 236-239) ----
   double z[NCOL][NS];
+  double pkeep[C::FULLM ? NCOL : 1][NS];  // FULLM: this role's rows of P_k stay in registers for step 6
   {
+    const double *const cur = launder(cur_);
     double wv[3], v[3], q[4], R[9];
 #pragma unroll
     for (int i = 0; i < 3; i++) {
@@ -188,9 +240,13 @@ __global__ __launch_bounds__(SmoothLaneCfg<NS>::THREADS, SmoothLaneCfg<NS>::WAVE
 #pragma unroll
     for (int t = 0; t < NCOL; t++) {
       double p[NS];
-      ld_col(cur, t, p);
+      ld_col(cur, t, 0, p);
 #pragma unroll
       for (int i = 0; i < NS; i++) z[t][i] = p[i];
+      if constexpr (C::FULLM && SM_LANE_PKEEP) {
+#pragma unroll
+        for (int i = 0; i < NS; i++) pkeep[t][i] = p[i];
+      }
       const double pv[3] = { p[3], p[4], p[5] }, pc[3] = { p[6], p[7], p[8] };
       // v rows: -w x p_v + g_b x p_chi [- v x p_bg - p_ba];  chi rows: -w x p_chi [- p_bg];  Delta rows: R p_v - R (v x p_chi)
       const double wxpv[3] = { wv[1] * pv[2] - wv[2] * pv[1], wv[2] * pv[0] - wv[0] * pv[2], wv[0] * pv[1] - wv[1] * pv[0] };
@@ -216,6 +272,7 @@ __global__ __launch_bounds__(SmoothLaneCfg<NS>::THREADS, SmoothLaneCfg<NS>::WAVE
   __syncthreads();  // the factor is complete (the last reciprocal pivots were written behind the last barrier of step 1)
 
   // ---- 3. (P^-) X = Ad P_k out of the LDS factor: z[t][:] becomes row cidx[t] of G ----
+#ifndef SML_SKIP_SUBST
 #pragma unroll
   for (int i = 1; i < NS; i++)
 #pragma unroll
@@ -223,7 +280,7 @@ __global__ __launch_bounds__(SmoothLaneCfg<NS>::THREADS, SmoothLaneCfg<NS>::WAVE
       const double l = S[pk(i, m) * 64];
 #pragma unroll
       for (int t = 0; t < NCOL; t++) z[t][i] = fma(-l, z[t][m], z[t][i]);
-      if (m == i - 1 && (i & 1)) __builtin_amdgcn_sched_barrier(0);  // (the factor is read as it is used, not hoisted: registers)
+      if (m == i - 1 && (i & 1)) lane_fence(sb, z[0][i]);
     }
 #pragma unroll
   for (int i = 0; i < NS; i++) {
@@ -231,6 +288,7 @@ __global__ __launch_bounds__(SmoothLaneCfg<NS>::THREADS, SmoothLaneCfg<NS>::WAVE
 #pragma unroll
     for (int t = 0; t < NCOL; t++) z[t][i] *= inv;
   }
+  lane_fence(sb, z[0][NS - 1]);
 #pragma unroll
   for (int i = NS - 2; i >= 0; i--)
 #pragma unroll
@@ -238,8 +296,9 @@ __global__ __launch_bounds__(SmoothLaneCfg<NS>::THREADS, SmoothLaneCfg<NS>::WAVE
       const double l = S[pk(m, i) * 64];
 #pragma unroll
       for (int t = 0; t < NCOL; t++) z[t][i] = fma(-l, z[t][m], z[t][i]);
-      if (m == NS - 1 && (i & 1)) __builtin_amdgcn_sched_barrier(0);
+      if (m == NS - 1 && (i & 1)) lane_fence(sb, z[0][i]);
     }
+#endif
   // dx = G resid (rbis.cpp:263): this role's entries
   double dxv[NCOL];
 #pragma unroll
@@ -250,7 +309,16 @@ __global__ __launch_bounds__(SmoothLaneCfg<NS>::THREADS, SmoothLaneCfg<NS>::WAVE
 #pragma unroll
     for (int t = 0; t < NCOL; t++) dxv[t] = fma(z[t][i], r, dxv[t]);
   }
+#pragma unroll
+  for (int t = 0; t < NCOL; t++) {
+    lane_pin(dxv[t]);
+#pragma unroll
+    for (int i = 0; i < NS; i++) lane_pin(z[t][i]);
+  }
   __syncthreads();  // factor and residual are dead
+  next_sm = launder(next_sm_);
+  next_pred = launder(next_pred_);
+  const double *const cur = launder(cur_);
 
   // ---- 4. D = P^s - P^- (the uncorrected P^-, rbis.cpp:256) takes the factor's place; dx goes behind the residual ----
 #pragma unroll
@@ -301,24 +369,106 @@ __global__ __launch_bounds__(SmoothLaneCfg<NS>::THREADS, SmoothLaneCfg<NS>::WAVE
   }
 
   // ---- 6. P^s = P_k + G D G^T, CH rows of M = G D at a time ----
+#ifdef SML_SKIP_CHUNKS
+  if (B > 0) return;
+#endif
+  if constexpr (C::FULLM) {
+    // every role makes ITS rows of M = G D at once (D is read once per role, no barrier inside), the rows take D's place, and
+    // P^s(r, c) = P_k(r, c) + G[r] . M[c] for the role's rows r
+    double m[NCOL][NS];
+#pragma unroll
+    for (int t = 0; t < NCOL; t++)
+#pragma unroll
+      for (int j = 0; j < NS; j++) m[t][j] = 0.0;
+#pragma unroll
+    for (int i = 0; i < NS; i++) {
+#pragma unroll
+      for (int j = 0; j <= i; j++) {
+        const double d = S[pk(i, j) * 64];
+#pragma unroll
+        for (int t = 0; t < NCOL; t++) {
+          m[t][j] = fma(z[t][i], d, m[t][j]);
+          if (i != j) m[t][i] = fma(z[t][j], d, m[t][i]);
+        }
+      }
+      if (i & 1) lane_fence(sb, m[0][i]);
+    }
+#pragma unroll
+    for (int t = 0; t < NCOL; t++)
+#pragma unroll
+      for (int j = 0; j < NS; j++) lane_pin(m[t][j]);
+    __syncthreads();  // D is dead
+#pragma unroll
+    for (int t = 0; t < NCOL; t++)
+      if (cidx[t] < NS) {
+#pragma unroll
+        for (int j = 0; j < NS; j++) S[(cidx[t] * NS + j) * 64] = m[t][j];
+      }
+    __syncthreads();
+    int po[NCOL][NS];
+#pragma unroll
+    for (int t = 0; t < NCOL; t++)
+#pragma unroll
+      for (int c = 0; c < NS; c++) po[t][c] = tab.col[w][t][c];
+#pragma unroll
+    for (int c = 0; c < NS; c++) {
+      if (c <= cidx[NCOL - 1]) {
+        double mr[NS];
+#pragma unroll
+        for (int j = 0; j < NS; j++) mr[j] = S[(c * NS + j) * 64];
+#pragma unroll
+        for (int t = 0; t < NCOL; t++) {
+          const int r = cidx[t];
+          if (r < NS && c <= r) {
+            double acc = SM_LANE_PKEEP ? pkeep[t][c] : cur[tb + po[t][c]];
+#pragma unroll
+            for (int j = 0; j < NS; j++) acc = fma(z[t][j], mr[j], acc);
+            if (active) out[tb + po[t][c]] = acc;
+          }
+        }
+      }
+      lane_fence(sb, z[0][c]);  // (one row of M at a time: registers)
+    }
+    return;
+  }
+  double pkn[NCOL][CH];
+  int pon[NCOL][CH];
+#pragma unroll
+  for (int t = 0; t < NCOL; t++)
+#pragma unroll
+    for (int q = 0; q < CH; q++) {
+      pon[t][q] = tab.col[w][t][q];
+      pkn[t][q] = cur[tb + pon[t][q]];
+    }
 #pragma unroll 1
   for (int c0 = 0; c0 < NS; c0 += CH) {
     // the owner of row c makes M[c][:] = G[c][:] D in registers (every entry of the symmetric D is read once)
     double m[NS];
     int mcc = -1;
-    // P_k(r, c) of this chunk's columns for the role's rows: requested now, used behind the two barriers
+    // P_k(r, c) of the NEXT chunk's columns for the role's rows are requested now: a load waits for every older store as well
+    // (one counter, in-order return), so a load issued behind this chunk's stores would expose their latency in every iteration
     double pkv[NCOL][CH];
     int po[NCOL][CH];
 #pragma unroll
     for (int t = 0; t < NCOL; t++)
 #pragma unroll
       for (int q = 0; q < CH; q++) {
-        po[t][q] = tab.col[w][t][(c0 + q < NS) ? c0 + q : NS - 1];
-        pkv[t][q] = cur[tb + po[t][q]];
+        pkv[t][q] = pkn[t][q];
+        po[t][q] = pon[t][q];
+        pon[t][q] = tab.col[w][t][(c0 + CH + q < NS) ? c0 + CH + q : NS - 1];
+        pkn[t][q] = cur[tb + pon[t][q]];
       }
 #pragma unroll
     for (int t = 0; t < NCOL; t++) {
       const int rel = cidx[t] - c0;
+#ifdef SML_SKIP_M
+      if (rel >= 0 && rel < CH && cidx[t] < NS) {
+        mcc = rel;
+#pragma unroll
+        for (int j = 0; j < NS; j++) m[j] = z[t][j];
+      }
+      continue;
+#endif
       if (rel >= 0 && rel < CH && cidx[t] < NS) {
         mcc = rel;
 #pragma unroll
@@ -330,9 +480,17 @@ __global__ __launch_bounds__(SmoothLaneCfg<NS>::THREADS, SmoothLaneCfg<NS>::WAVE
             const double d = S[pk(i, j) * 64];
             m[j] = fma(z[t][i], d, m[j]);
             if (i != j) m[i] = fma(z[t][j], d, m[i]);
-            if (j == i && (i & 1)) __builtin_amdgcn_sched_barrier(0);  // (keeps the reads of D from being hoisted: registers)
+#ifndef SML_MFENCE
+#define SML_MFENCE 2
+#endif
+            if (SML_MFENCE > 0 && j == i && (i % (SML_MFENCE > 0 ? SML_MFENCE : 1)) == (SML_MFENCE > 0 ? SML_MFENCE : 1) - 1)
+              lane_fence(sb, m[i]);
           }
       }
+    }
+    if (mcc >= 0) {
+#pragma unroll
+      for (int j = 0; j < NS; j++) lane_pin(m[j]);
     }
     __syncthreads();  // the readers of the previous chunk (and of dx) are done
     if (mcc >= 0) {
@@ -361,5 +519,7 @@ __global__ __launch_bounds__(SmoothLaneCfg<NS>::THREADS, SmoothLaneCfg<NS>::WAVE
     }
   }
 }
+
+#undef S
 
 }  // namespace pb

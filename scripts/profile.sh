@@ -18,9 +18,12 @@ smoother_trace() {
 smoother_pmc() {
   rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU --output-format csv -d $OUT/smooth_pmc_a -- python3 scripts/smooth_rate.py > $OUT/smooth_pmc_a.txt 2>&1 || exit 24
   rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAVES SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL --output-format csv -d $OUT/smooth_pmc_b -- python3 scripts/smooth_rate.py > $OUT/smooth_pmc_b.txt 2>&1 || exit 25
+  # HBM traffic of the smoother step (one counter per pass, as for the hot step)
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/smooth_pmc_fetch -- python3 scripts/smooth_rate.py > $OUT/smooth_pmc_fetch.txt 2>&1 || exit 26
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/smooth_pmc_write -- python3 scripts/smooth_rate.py > $OUT/smooth_pmc_write.txt 2>&1 || exit 27
 }
 if [ "$ONLY" = smoother ]; then
-  mkdir -p $OUT; rm -rf $OUT/smoother $OUT/smooth_pmc_a $OUT/smooth_pmc_b
+  mkdir -p $OUT; rm -rf $OUT/smoother $OUT/smooth_pmc_a $OUT/smooth_pmc_b $OUT/smooth_pmc_fetch $OUT/smooth_pmc_write
   smoother_trace; smoother_pmc
   echo "smoother profile done"
   exit 0
