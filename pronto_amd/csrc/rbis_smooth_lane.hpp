@@ -27,7 +27,7 @@
 
 // attribution builds (scripts/smooth_attribution.sh lane...): parts compiled OUT, results are garbage, only the time means something
 #if !defined(PB_EXPERIMENTS) && (defined(SML_SKIP_FACT) || defined(SML_SKIP_RHS) || defined(SML_SKIP_SUBST) || defined(SML_SKIP_D) || \
-                                 defined(SML_SKIP_M) || defined(SML_SKIP_FINAL) || defined(SML_SKIP_CHUNKS))
+                                 defined(SML_SKIP_M) || defined(SML_SKIP_FINAL) || defined(SML_SKIP_CHUNKS) || defined(SML_NO_PKLOAD) || defined(SML_NO_PSTORE))
 #error "the SML_* attribution flags need -DPB_EXPERIMENTS as well"
 #endif
 
@@ -41,20 +41,14 @@ template <int NS>
 struct SmoothLaneCfg {
   using L = Lay<NS>;
   using SL = Slots<NS>;
-#ifndef SM_LANE_PKEEP
-#define SM_LANE_PKEEP 0
-#endif
-#ifndef SM_LANE_FULLM15
-#define SM_LANE_FULLM15 1
-#endif
-  // 15 states: ALL rows of M = G D are exchanged at once (n x n doubles per lane fit beside nothing else: one workgroup per CU);
-  // 21 states: that is 226 KB -- the rows go round CH at a time, beside D
-  static constexpr bool FULLM = (NS <= 16) && SM_LANE_FULLM15;
-  static constexpr int NR = FULLM ? 8 : ((NS <= 16) ? 4 : 8);  // role waves per tile
+  static constexpr int NR = (NS <= 16) ? 4 : 8;          // role waves per tile
   static constexpr int NCOL = (NS + NR - 1) / NR;        // columns / gain rows per role
-  static constexpr int CH = (NS <= 16) ? SM_LANE_CH15 : 3;  // rows of M per exchange (<= NR: at most one per role)
+#ifndef SM_LANE_CH21
+#define SM_LANE_CH21 3
+#endif
+  static constexpr int CH = (NS <= 16) ? SM_LANE_CH15 : SM_LANE_CH21;  // rows of M per exchange (<= NR: at most one per role)
   static constexpr int NP = L::NP;
-  static constexpr int O_X = FULLM ? NS * NS : NP;       // exchange region: residual + dx first, then CH rows of M
+  static constexpr int O_X = NP;                         // exchange region: residual + dx first, then CH rows of M
   static constexpr int PER = O_X + CH * NS;              // doubles per lane
   static constexpr int THREADS = 64 * NR;
   static constexpr int WAVES_PER_SIMD = 2;               // 8 waves per CU either way: 256 registers per lane
@@ -85,14 +79,6 @@ struct SmoothLaneCfg {
 template <int NS>
 __constant__ const typename SmoothLaneCfg<NS>::Tab smooth_lane_tab = SmoothLaneCfg<NS>::make();
 
-// A pointer the optimiser knows nothing about from here on: loads through it stay behind this point.  (The checkpoints are read-only
-// and __restrict__, so every load of the kernel would otherwise be hoisted to its top -- 150 doubles per lane in flight and spilled.)
-__device__ __forceinline__ const double *launder(const double *p)
-{
-  asm volatile("" : "+s"(p));
-  return p;
-}
-
 // End of a group of LDS reads.  The backend gathers independent LDS reads at the top of a block whatever scheduling barriers sit
 // between them (all of D: 240 registers, spilled), so the NEXT group's reads are made to depend on this group's arithmetic: the
 // lane's LDS index passes through an empty asm that also names a result of the group.  The memory clobber makes a later read of
@@ -111,7 +97,7 @@ __device__ __forceinline__ int pk_s(int i, int j) { return i >= j ? i * (i + 1) 
 
 template <int NS>
 __global__ __launch_bounds__(SmoothLaneCfg<NS>::THREADS, SmoothLaneCfg<NS>::WAVES_PER_SIMD) void k_smooth_lane(
-    const double *__restrict__ next_pred_, const double *__restrict__ next_sm_, const double *cur_, double *out, int B, double dt, Consts k)
+    const double *__restrict__ next_pred, const double *__restrict__ next_sm, const double *cur, double *out, int B, double dt, Consts k)
 {
   using L = Lay<NS>;
   using SL = Slots<NS>;
@@ -123,7 +109,6 @@ __global__ __launch_bounds__(SmoothLaneCfg<NS>::THREADS, SmoothLaneCfg<NS>::WAVE
   const long tb = (long) blockIdx.x * SL::TILE_DOUBLES + lane * 2;
   const bool active = (long) blockIdx.x * 64 + lane < B;
   const auto &tab = smooth_lane_tab<NS>;
-  const double *next_pred = next_pred_, *next_sm = next_sm_;
   int sb = lane;  // entry e of this lane's filter: lds[sb + e * 64] (sb passes through lane_fence)
 #define S (lds + sb)
   auto ldc = [&](const double *src, int comp) { return src[tb + C::off_of(comp)]; };  // compile-time component only
@@ -215,7 +200,9 @@ __global__ __launch_bounds__(SmoothLaneCfg<NS>::THREADS, SmoothLaneCfg<NS>::WAVE
           for (int t = 0; t < NCOL; t++)
             if (kk < NR * (t + 1) - 1 && i >= NR * t) {
               a[t][i] = fma(-lik, tc[t], a[t][i]);
+#ifndef SM_LANE_NOPIN_A
               lane_pin(a[t][i]);  // (downdated NOW, not when the column is published)
+#endif
             }
         }
       }
@@ -224,9 +211,7 @@ __global__ __launch_bounds__(SmoothLaneCfg<NS>::THREADS, SmoothLaneCfg<NS>::WAVE
 
   // ---- 2. right-hand sides: columns cc[t] of Ad P_k, Ad = I + dt Ac about the filtered state (rbis.cpp:12-35, 236-239) ----
   double z[NCOL][NS];
-  double pkeep[C::FULLM ? NCOL : 1][NS];  // FULLM: this role's rows of P_k stay in registers for step 6
   {
-    const double *const cur = launder(cur_);
     double wv[3], v[3], q[4], R[9];
 #pragma unroll
     for (int i = 0; i < 3; i++) {
@@ -243,10 +228,6 @@ __global__ __launch_bounds__(SmoothLaneCfg<NS>::THREADS, SmoothLaneCfg<NS>::WAVE
       ld_col(cur, t, 0, p);
 #pragma unroll
       for (int i = 0; i < NS; i++) z[t][i] = p[i];
-      if constexpr (C::FULLM && SM_LANE_PKEEP) {
-#pragma unroll
-        for (int i = 0; i < NS; i++) pkeep[t][i] = p[i];
-      }
       const double pv[3] = { p[3], p[4], p[5] }, pc[3] = { p[6], p[7], p[8] };
       // v rows: -w x p_v + g_b x p_chi [- v x p_bg - p_ba];  chi rows: -w x p_chi [- p_bg];  Delta rows: R p_v - R (v x p_chi)
       const double wxpv[3] = { wv[1] * pv[2] - wv[2] * pv[1], wv[2] * pv[0] - wv[0] * pv[2], wv[0] * pv[1] - wv[1] * pv[0] };
@@ -280,7 +261,7 @@ __global__ __launch_bounds__(SmoothLaneCfg<NS>::THREADS, SmoothLaneCfg<NS>::WAVE
       const double l = S[pk(i, m) * 64];
 #pragma unroll
       for (int t = 0; t < NCOL; t++) z[t][i] = fma(-l, z[t][m], z[t][i]);
-      if (m == i - 1 && (i & 1)) lane_fence(sb, z[0][i]);
+      if (m == i - 1 && (i & 1)) lane_fence(sb, z[0][i >= 2 ? i - 2 : 0]);  // (row i - 2: one group of reads may run ahead)
     }
 #pragma unroll
   for (int i = 0; i < NS; i++) {
@@ -296,7 +277,7 @@ __global__ __launch_bounds__(SmoothLaneCfg<NS>::THREADS, SmoothLaneCfg<NS>::WAVE
       const double l = S[pk(m, i) * 64];
 #pragma unroll
       for (int t = 0; t < NCOL; t++) z[t][i] = fma(-l, z[t][m], z[t][i]);
-      if (m == NS - 1 && (i & 1)) lane_fence(sb, z[0][i]);
+      if (m == NS - 1 && (i & 1)) lane_fence(sb, z[0][i + 2 < NS ? i + 2 : NS - 1]);
     }
 #endif
   // dx = G resid (rbis.cpp:263): this role's entries
@@ -311,14 +292,13 @@ __global__ __launch_bounds__(SmoothLaneCfg<NS>::THREADS, SmoothLaneCfg<NS>::WAVE
   }
 #pragma unroll
   for (int t = 0; t < NCOL; t++) {
+#ifndef SM_LANE_NOPIN_Z
     lane_pin(dxv[t]);
 #pragma unroll
     for (int i = 0; i < NS; i++) lane_pin(z[t][i]);
+#endif
   }
   __syncthreads();  // factor and residual are dead
-  next_sm = launder(next_sm_);
-  next_pred = launder(next_pred_);
-  const double *const cur = launder(cur_);
 
   // ---- 4. D = P^s - P^- (the uncorrected P^-, rbis.cpp:256) takes the factor's place; dx goes behind the residual ----
 #pragma unroll
@@ -372,65 +352,6 @@ __global__ __launch_bounds__(SmoothLaneCfg<NS>::THREADS, SmoothLaneCfg<NS>::WAVE
 #ifdef SML_SKIP_CHUNKS
   if (B > 0) return;
 #endif
-  if constexpr (C::FULLM) {
-    // every role makes ITS rows of M = G D at once (D is read once per role, no barrier inside), the rows take D's place, and
-    // P^s(r, c) = P_k(r, c) + G[r] . M[c] for the role's rows r
-    double m[NCOL][NS];
-#pragma unroll
-    for (int t = 0; t < NCOL; t++)
-#pragma unroll
-      for (int j = 0; j < NS; j++) m[t][j] = 0.0;
-#pragma unroll
-    for (int i = 0; i < NS; i++) {
-#pragma unroll
-      for (int j = 0; j <= i; j++) {
-        const double d = S[pk(i, j) * 64];
-#pragma unroll
-        for (int t = 0; t < NCOL; t++) {
-          m[t][j] = fma(z[t][i], d, m[t][j]);
-          if (i != j) m[t][i] = fma(z[t][j], d, m[t][i]);
-        }
-      }
-      if (i & 1) lane_fence(sb, m[0][i]);
-    }
-#pragma unroll
-    for (int t = 0; t < NCOL; t++)
-#pragma unroll
-      for (int j = 0; j < NS; j++) lane_pin(m[t][j]);
-    __syncthreads();  // D is dead
-#pragma unroll
-    for (int t = 0; t < NCOL; t++)
-      if (cidx[t] < NS) {
-#pragma unroll
-        for (int j = 0; j < NS; j++) S[(cidx[t] * NS + j) * 64] = m[t][j];
-      }
-    __syncthreads();
-    int po[NCOL][NS];
-#pragma unroll
-    for (int t = 0; t < NCOL; t++)
-#pragma unroll
-      for (int c = 0; c < NS; c++) po[t][c] = tab.col[w][t][c];
-#pragma unroll
-    for (int c = 0; c < NS; c++) {
-      if (c <= cidx[NCOL - 1]) {
-        double mr[NS];
-#pragma unroll
-        for (int j = 0; j < NS; j++) mr[j] = S[(c * NS + j) * 64];
-#pragma unroll
-        for (int t = 0; t < NCOL; t++) {
-          const int r = cidx[t];
-          if (r < NS && c <= r) {
-            double acc = SM_LANE_PKEEP ? pkeep[t][c] : cur[tb + po[t][c]];
-#pragma unroll
-            for (int j = 0; j < NS; j++) acc = fma(z[t][j], mr[j], acc);
-            if (active) out[tb + po[t][c]] = acc;
-          }
-        }
-      }
-      lane_fence(sb, z[0][c]);  // (one row of M at a time: registers)
-    }
-    return;
-  }
   double pkn[NCOL][CH];
   int pon[NCOL][CH];
 #pragma unroll
@@ -456,7 +377,11 @@ __global__ __launch_bounds__(SmoothLaneCfg<NS>::THREADS, SmoothLaneCfg<NS>::WAVE
         pkv[t][q] = pkn[t][q];
         po[t][q] = pon[t][q];
         pon[t][q] = tab.col[w][t][(c0 + CH + q < NS) ? c0 + CH + q : NS - 1];
+#ifdef SML_NO_PKLOAD
+        pkn[t][q] = 1.0;
+#else
         pkn[t][q] = cur[tb + pon[t][q]];
+#endif
       }
 #pragma unroll
     for (int t = 0; t < NCOL; t++) {
@@ -471,6 +396,7 @@ __global__ __launch_bounds__(SmoothLaneCfg<NS>::THREADS, SmoothLaneCfg<NS>::WAVE
 #endif
       if (rel >= 0 && rel < CH && cidx[t] < NS) {
         mcc = rel;
+        double hook = z[t][0];
 #pragma unroll
         for (int j = 0; j < NS; j++) m[j] = 0.0;
 #pragma unroll
@@ -484,20 +410,29 @@ __global__ __launch_bounds__(SmoothLaneCfg<NS>::THREADS, SmoothLaneCfg<NS>::WAVE
 #define SML_MFENCE 2
 #endif
             if (SML_MFENCE > 0 && j == i && (i % (SML_MFENCE > 0 ? SML_MFENCE : 1)) == (SML_MFENCE > 0 ? SML_MFENCE : 1) - 1)
-              lane_fence(sb, m[i]);
+            {
+              lane_fence(sb, hook);
+              hook = m[0];
+              lane_pin(hook);
+            }
           }
       }
     }
+#ifndef SM_LANE_NOPIN_M
     if (mcc >= 0) {
 #pragma unroll
       for (int j = 0; j < NS; j++) lane_pin(m[j]);
     }
+#endif
     __syncthreads();  // the readers of the previous chunk (and of dx) are done
     if (mcc >= 0) {
 #pragma unroll
       for (int j = 0; j < NS; j++) S[(O_X + mcc * NS + j) * 64] = m[j];
     }
     __syncthreads();
+#ifdef SML_SKIP_FINAL
+    continue;
+#endif
 #pragma unroll
     for (int q = 0; q < CH; q++) {
       const int c = c0 + q;
@@ -512,7 +447,11 @@ __global__ __launch_bounds__(SmoothLaneCfg<NS>::THREADS, SmoothLaneCfg<NS>::WAVE
             double acc = pkv[t][q];
 #pragma unroll
             for (int j = 0; j < NS; j++) acc = fma(z[t][j], mr[j], acc);
+#ifdef SML_NO_PSTORE
+            if (acc == 1.2345e300) out[tb + po[t][q]] = acc;
+#else
             if (active) out[tb + po[t][q]] = acc;
+#endif
           }
         }
       }

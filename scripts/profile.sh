@@ -14,6 +14,8 @@ ONLY=${2:-all}   # "smoother": refresh the smoother's trace and counters only (m
 cd $ROOT
 smoother_trace() {
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/smoother -- python3 scripts/smooth_rate.py > $OUT/smoother.txt 2> $OUT/smoother.err || exit 23
+  # the kernel it replaced (16 / 32 lanes per filter), same box, for the record
+  PRONTO_SMOOTH_KERNEL=reg python3 scripts/smooth_rate.py > $OUT/smoother_reg.txt 2>> $OUT/smoother.err || exit 23
 }
 smoother_pmc() {
   rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU --output-format csv -d $OUT/smooth_pmc_a -- python3 scripts/smooth_rate.py > $OUT/smooth_pmc_a.txt 2>&1 || exit 24

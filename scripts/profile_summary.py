@@ -55,7 +55,7 @@ for d, name in (("trace64k", "_kernel_stats.csv"), ("trace64k_n21", "_kernel_sta
         shutil.copy(ks[0], os.path.join(out, tag + name))
 for name in ("trace64k.json", "trace64k_n21.json", "trace1m.json", "leg_rates.txt", "bench1m.json", "calib_plain.txt", "copybench.txt", "batch_sweep.txt",
              "bench_default.json", "others.txt", "configs.txt", "smoother.txt", "n21_input_footprint.txt", "checkpoint_rate.txt",
-             "smoother_pivoted.txt", "leg_ab.txt", "segment_rate.txt"):
+             "smoother_pivoted.txt", "smoother_reg.txt", "leg_ab.txt", "segment_rate.txt"):
     p = os.path.join(src, name)
     if os.path.exists(p):
         shutil.copy(p, os.path.join(out, tag + "_" + name))
@@ -102,11 +102,19 @@ json.dump(res, open(os.path.join(out, tag + "_pmc.json"), "w"), indent=1)
 json.dump(traffic, open(os.path.join(out, "traffic.json"), "w"), indent=1)
 # the smoother's SQ / LDS counters (two passes), averaged per launch
 sm = {}
-for d in ("smooth_pmc_a", "smooth_pmc_b"):
+for d in ("smooth_pmc_a", "smooth_pmc_b", "smooth_pmc_fetch", "smooth_pmc_write"):
+    if not glob.glob(os.path.join(src, d, "*", "*counter_collection.csv")):
+        continue
     for (k, c), v in counters(d).items():
-        m = re.match(r"k_smooth_reg<(\d+)", k)   # k_smooth_reg<NS,PIVOT> since round 4
+        m = re.match(r"k_smooth_(?:lane|reg)<(\d+)", k)   # k_smooth_lane<NS> (default since round 4), k_smooth_reg<NS,PIVOT>
         if m:
             sm.setdefault("n" + m.group(1), {})[c] = sum(v) / len(v)
+            sm["n" + m.group(1)]["kernel"] = k.split("(")[0]
+for r in sm.values():  # HBM traffic with the calibration of the hot step's counters (same units, same corrections)
+    if "FETCH_SIZE" in r:
+        r["hbm_read_bytes"] = r["FETCH_SIZE"] * 1024 * fs
+    if "WRITE_SIZE" in r:
+        r["hbm_write_bytes"] = r["WRITE_SIZE"] * 1024 * ws
 txt = os.path.join(src, "smoother.txt")
 if sm:
     for line in open(txt) if os.path.exists(txt) else ():
@@ -123,7 +131,7 @@ if sm:
             r["valu_insts_per_wave"] = r.get("SQ_INSTS_VALU", 0) / r["SQ_WAVES"]
             r["lds_insts_per_wave"] = r.get("SQ_INSTS_LDS", 0) / r["SQ_WAVES"]
     json.dump({"what": "rocprofv3 --pmc of scripts/smooth_rate.py (64k filters), two passes (scripts/profile.sh); averages per launch",
-               "kernel": "k_smooth_reg<NS,false> (pb_smooth_step; no pivot search since round 4)", "runs": sm},
+               "kernel": "pb_smooth_step's default kernel (k_smooth_lane<NS> since the second half of round 4; PRONTO_SMOOTH_KERNEL=reg: k_smooth_reg<NS,false>)", "runs": sm},
               open(os.path.join(out, tag + "_smoother_pmc.json"), "w"), indent=1)
 
 for k, v in res["runs"].items():

@@ -147,10 +147,10 @@ def test_backward_pass_matches_golden_fixture(oracle, n):
 
 @pytest.mark.parametrize("n", [15, 21])
 def test_full_size_smooth_step_equals_its_shard(oracle, n):
-    """BASELINE's batch size (65 536 filters, 4 096 / 8 192 workgroups, the matrix-pipe products with four / two filters per
-    wave): the smoothed posterior of a window of filters must be bit-identical to the same filters smoothed alone in a
-    small batch (another position in the tile, the workgroup and the wave), stay finite everywhere, and never increase
-    the uncertainty.  (Parity with the oracle on small batches: the tests above.)"""
+    """BASELINE's batch size (65 536 filters = 1 024 tiles of 64 filters, one lane per filter, 4 / 8 role waves per tile): the
+    smoothed posterior of a window of filters must be bit-identical to the same filters smoothed alone in a small batch
+    (another lane, another tile), stay finite everywhere, and never increase the uncertainty.  (Parity with the oracle on
+    small batches: the tests above.)"""
     from pronto_amd.batch import BatchEstimator
     dt = 1e-3
 
