@@ -146,6 +146,44 @@ def test_backward_pass_matches_golden_fixture(oracle, n):
 
 
 @pytest.mark.parametrize("n", [15, 21])
+def test_smooth_step_in_place_equals_out_of_place(oracle, n):
+    """pb_smooth_step allows slot_out == slot_cur (pronto_batch.h).  k_smooth_lane reads the filtered checkpoint in three places (the
+    right-hand sides, the state, P_k(r, c) inside the products) while its role waves store P^s(r, c) as they go: every entry has to be
+    read by the thread that overwrites it, before it does.  In place == out of place, bit for bit, over a ragged batch."""
+    from pronto_amd.batch import BatchEstimator
+    B, dt = 200, 1e-3
+    w = Workload(B, n_states=n)
+    vec, quat, P0 = w.initial_state()
+    est = BatchEstimator(B, n_states=n)
+    est.set_constants(*oracle.constants())
+    est.reset(vec, quat, P0)
+    est.history_reserve(5)
+    q4 = w.process_noise()
+    for k in range(3):
+        lo, mask = w.legodo_block(k)
+        est.step_legodo(w.imu_block(k), lo, mask, q4)
+    est.state_save(0)
+    est.state_save(4)                       # a second copy of the filtered posterior: smoothed in place below
+    est.predict(w.imu_block(3), q4)
+    est.state_save(1)
+    lo, mask = w.legodo_block(3)
+    est.update_indexed([3, 4, 5], np.ascontiguousarray(lo[0:3]), np.ascontiguousarray(lo[3:6]), mask=mask)
+    est.state_save(2)
+    est.smooth_step(1, 2, 0, 3, dt)
+    est.smooth_step(1, 2, 4, 4, dt)
+    est.state_restore(3)
+    a = est.get_head()
+    est.state_restore(4)
+    b = est.get_head()
+    est.state_restore(0)
+    f = est.get_head()
+    for x, y in zip(a[:3], b[:3]):
+        assert np.array_equal(x, y)
+    assert not np.array_equal(a[2], f[2])   # (and the step did something)
+    est.close()
+
+
+@pytest.mark.parametrize("n", [15, 21])
 def test_full_size_smooth_step_equals_its_shard(oracle, n):
     """BASELINE's batch size (65 536 filters = 1 024 tiles of 64 filters, one lane per filter, 4 / 8 role waves per tile): the
     smoothed posterior of a window of filters must be bit-identical to the same filters smoothed alone in a small batch
