@@ -323,8 +323,9 @@ __global__ __launch_bounds__(SmoothLaneCfg<NS>::THREADS, SmoothLaneCfg<NS>::WAVE
   }
   __syncthreads();
 
-  // ---- 5. state: cur.addState(RBIS(dx)) (rbis.cpp:263-265), by role 0 ----
-  if (w == 0) {
+  // ---- 5. state: cur.addState(RBIS(dx)) (rbis.cpp:263-265), by the LAST role: the first CH roles make the first rows of M in step 6
+  //         meanwhile (with role 0 doing both, every other wave of the tile waited for two fold_chi at the first barrier of step 6) ----
+  if (w == NR - 1) {
     double dchi[3] = { S[(O_X + NS + 6) * 64], S[(O_X + NS + 7) * 64], S[(O_X + NS + 8) * 64] };
     double dq[4] = { 1.0, 0.0, 0.0, 0.0 };
     fold_chi(dchi, dq, k.chi_tol);  // RBIS(vec) constructor
