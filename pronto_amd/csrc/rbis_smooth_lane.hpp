@@ -128,20 +128,17 @@ __global__ __launch_bounds__(SmoothLaneCfg<NS>::THREADS, SmoothLaneCfg<NS>::WAVE
     cc[t] = cidx[t] < NS ? cidx[t] : NS - 1;
   }
 
-  // ---- 0. residual x^s (-) x^- (rbis.cpp:258-261), by role 0, into the exchange region ----
-  if (w == 0) {
-    double qs[4], qp[4], dchi[3];
+  // ---- 0. residual x^s (-) x^- (rbis.cpp:258-261), by the last role: its loads are requested here, the arithmetic (an atan2) and the
+  //         hand-over through the exchange region come behind the factorisation, whose first barrier would otherwise wait for them ----
+  double rqs[4], rqp[4], rv[NS];
+  if (w == NR - 1) {
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-      qs[i] = ldc(next_sm, L::OFF_QUAT + i);
-      qp[i] = ldc(next_pred, L::OFF_QUAT + i);
+      rqs[i] = ldc(next_sm, L::OFF_QUAT + i);
+      rqp[i] = ldc(next_pred, L::OFF_QUAT + i);
     }
-    subtract_quats(qs, qp, dchi);
 #pragma unroll
-    for (int i = 0; i < NS; i++) {
-      const double r = ldc(next_sm, L::OFF_VEC + i) - ldc(next_pred, L::OFF_VEC + i);
-      S[(O_X + i) * 64] = (i >= 6 && i <= 8) ? dchi[i - 6] : r;
-    }
+    for (int i = 0; i < NS; i++) rv[i] = ldc(next_sm, L::OFF_VEC + i) - ldc(next_pred, L::OFF_VEC + i);
   }
 
   // ---- 1. P^- = L diag(d) L^T ----
@@ -207,6 +204,13 @@ __global__ __launch_bounds__(SmoothLaneCfg<NS>::THREADS, SmoothLaneCfg<NS>::WAVE
         }
       }
     });
+  }
+
+  if (w == NR - 1) {
+    double dchi[3];
+    subtract_quats(rqs, rqp, dchi);
+#pragma unroll
+    for (int i = 0; i < NS; i++) S[(O_X + i) * 64] = (i >= 6 && i <= 8) ? dchi[i - 6] : rv[i];
   }
 
   // ---- 2. right-hand sides: columns cc[t] of Ad P_k, Ad = I + dt Ac about the filtered state (rbis.cpp:12-35, 236-239) ----
