@@ -371,7 +371,11 @@ int pb_state_restore(pb_ctx *ctx, int slot);   /* head posterior <- slot */
  * (mav_state_est.cpp:98-189), on checkpoint slots:
  *   slot_next_pred = posterior of the INS update at k+1 (prediction), slot_next = smoothed (or, for the last step,
  *   filtered) posterior at k+1, slot_cur = filtered posterior at k; slot_out <- smoothed posterior at k.
- * slot_out may be slot_cur (in place) but not one of the k+1 slots.  dt as passed to EKFSmoothBackwardsPass. */
+ * slot_out may be slot_cur (in place) but not one of the k+1 slots.  dt as passed to EKFSmoothBackwardsPass.
+ * P^-_{k+1} is factorised WITHOUT the reference's diagonal pivot search (it is SPD; results agree with Eigen's .ldlt() to rounding,
+ * tests: <= 1e-9 against the oracle).  Environment, read once per process: PRONTO_SMOOTH_KERNEL=reg selects the kernel of rounds
+ * 2-4 (16 / 32 lanes per filter) instead of the default (one lane per filter, rbis_smooth_lane.hpp); PRONTO_SMOOTH_PIVOT=1 that
+ * kernel with Eigen's pivoting. */
 int pb_smooth_step(pb_ctx *ctx, int slot_next_pred, int slot_next, int slot_cur, int slot_out, double dt);
 
 /* ---- estimator queries (mav_state_est.hpp:20-22) -------------------------------------------------------- */
