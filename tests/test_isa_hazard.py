@@ -10,28 +10,39 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "pronto_amd", "csrc")
 
 
-def test_no_write_to_a_16_byte_stores_data_registers_before_its_nop():
-    out = os.path.join(ROOT, "tests", "build", "pb_step.s")
-    os.makedirs(os.path.dirname(out), exist_ok=True)
+# every assembly dump this file looks at: name -> (source, defines).  They are made together, in parallel, the first time one is
+# asked for (four hipcc runs of 15-70 s each: one after the other they were half of the CPU tier's time)
+DUMPS = {"pb_step.s": ("pb_step.hip", ()), "pb_step_leg15.s": ("pb_step_leg.hip", ("-DPB_LEG_NS=15",)),
+         "pb_step_leg21.s": ("pb_step_leg.hip", ("-DPB_LEG_NS=21",)), "pb_smooth.s": ("pb_smooth.hip", ())}
+
+
+def _stale(out):
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".hip"))]
-    if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(d) for d in deps):
-        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "--cuda-device-only", "-S", "-o", out,
-                               os.path.join(CSRC, "pb_step.hip")], stderr=subprocess.DEVNULL)
+    return not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(d) for d in deps)
+
+
+def _asm(name, src=None, *defs):
+    bdir = os.path.join(ROOT, "tests", "build")
+    os.makedirs(bdir, exist_ok=True)
+    todo = {n: v for n, v in DUMPS.items() if _stale(os.path.join(bdir, n))}
+    if name not in DUMPS and _stale(os.path.join(bdir, name)):
+        todo[name] = (src, defs)
+    procs = [(n, subprocess.Popen(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "--cuda-device-only", "-S", "-o",
+                                   os.path.join(bdir, n + ".tmp"), *d, os.path.join(CSRC, f)], stderr=subprocess.DEVNULL))
+             for n, (f, d) in todo.items()]
+    for n, pr in procs:
+        assert pr.wait() == 0, n
+        os.replace(os.path.join(bdir, n + ".tmp"), os.path.join(bdir, n))
+    return os.path.join(bdir, name)
+
+
+def test_no_write_to_a_16_byte_stores_data_registers_before_its_nop():
+    out = _asm("pb_step.s")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "chk_store_hazard.py"), out], capture_output=True, text=True)
     last = r.stdout.strip().splitlines()[-1]
     assert r.returncode == 0, r.stdout[-3000:]
     n_stores = int(last.split()[1])
     assert n_stores > 1000, last     # the step kernels really were in that file
-
-
-def _asm(name, src, *defs):
-    out = os.path.join(ROOT, "tests", "build", name)
-    os.makedirs(os.path.dirname(out), exist_ok=True)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".hip"))]
-    if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(d) for d in deps):
-        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "--cuda-device-only", "-S", "-o", out, *defs,
-                               os.path.join(CSRC, src)], stderr=subprocess.DEVNULL)
-    return out
 
 
 def _kernel_metadata(path):
