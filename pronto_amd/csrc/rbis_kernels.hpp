@@ -1156,17 +1156,29 @@ static __global__ void k_notch(double *__restrict__ nst, long stride, int B, int
 #pragma unroll
     for (int t = 0; t < 4; t++) s[i][t] = nst[(long) ((ax * 3 + i) * 4 + t) * stride + b];
   double v = 0.0;
-  for (int p = 0; p < n_packets; p++) {
-    v = acc_in[((long) p * 3 + ax) * B + b];
+  // packets four at a time, all four requested before the first is filtered: with one load per trip of the loop every packet's
+  // memory latency came on top of the one before (three packets per message: three round trips in a kernel that is one)
+  for (int p0 = 0; p0 < n_packets; p0 += 4) {
+    double pk[4];
 #pragma unroll
-    for (int i = 0; i < 3; i++) {
-      const double in = v;
-      const double xb = in * k.b[i][0] + s[i][0] * k.b[i][1] + s[i][1] * k.b[i][2];
-      const double ya = s[i][2] * k.a[i][1] + s[i][3] * k.a[i][2];
-      const double out = xb - ya;
-      s[i][1] = s[i][0]; s[i][0] = in;
-      s[i][3] = s[i][2]; s[i][2] = out;
-      v = out;
+    for (int j = 0; j < 4; j++) {
+      const int p = (p0 + j < n_packets) ? p0 + j : n_packets - 1;
+      pk[j] = acc_in[((long) p * 3 + ax) * B + b];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      if (p0 + j >= n_packets) break;
+      v = pk[j];
+#pragma unroll
+      for (int i = 0; i < 3; i++) {
+        const double in = v;
+        const double xb = in * k.b[i][0] + s[i][0] * k.b[i][1] + s[i][1] * k.b[i][2];
+        const double ya = s[i][2] * k.a[i][1] + s[i][3] * k.a[i][2];
+        const double out = xb - ya;
+        s[i][1] = s[i][0]; s[i][0] = in;
+        s[i][3] = s[i][2]; s[i][2] = out;
+        v = out;
+      }
     }
   }
 #pragma unroll
