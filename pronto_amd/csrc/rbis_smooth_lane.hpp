@@ -197,9 +197,7 @@ __global__ __launch_bounds__(SmoothLaneCfg<NS>::THREADS, SmoothLaneCfg<NS>::WAVE
           for (int t = 0; t < NCOL; t++)
             if (kk < NR * (t + 1) - 1 && i >= NR * t) {
               a[t][i] = fma(-lik, tc[t], a[t][i]);
-#ifndef SM_LANE_NOPIN_A
               lane_pin(a[t][i]);  // (downdated NOW, not when the column is published)
-#endif
             }
         }
       }
@@ -296,11 +294,9 @@ __global__ __launch_bounds__(SmoothLaneCfg<NS>::THREADS, SmoothLaneCfg<NS>::WAVE
   }
 #pragma unroll
   for (int t = 0; t < NCOL; t++) {
-#ifndef SM_LANE_NOPIN_Z
     lane_pin(dxv[t]);
 #pragma unroll
     for (int i = 0; i < NS; i++) lane_pin(z[t][i]);
-#endif
   }
   __syncthreads();  // factor and residual are dead
 
@@ -411,11 +407,7 @@ __global__ __launch_bounds__(SmoothLaneCfg<NS>::THREADS, SmoothLaneCfg<NS>::WAVE
             const double d = S[pk(i, j) * 64];
             m[j] = fma(z[t][i], d, m[j]);
             if (i != j) m[i] = fma(z[t][j], d, m[i]);
-#ifndef SML_MFENCE
-#define SML_MFENCE 2
-#endif
-            if (SML_MFENCE > 0 && j == i && (i % (SML_MFENCE > 0 ? SML_MFENCE : 1)) == (SML_MFENCE > 0 ? SML_MFENCE : 1) - 1)
-            {
+            if (j == i && (i & 1)) {  // end of a group of two rows of D
               lane_fence(sb, hook);
               hook = m[0];
               lane_pin(hook);
@@ -423,12 +415,10 @@ __global__ __launch_bounds__(SmoothLaneCfg<NS>::THREADS, SmoothLaneCfg<NS>::WAVE
           }
       }
     }
-#ifndef SM_LANE_NOPIN_M
     if (mcc >= 0) {
 #pragma unroll
       for (int j = 0; j < NS; j++) lane_pin(m[j]);
     }
-#endif
     __syncthreads();  // the readers of the previous chunk (and of dx) are done
     if (mcc >= 0) {
 #pragma unroll
