@@ -87,3 +87,20 @@ def test_numbers_quoted_in_design_are_in_the_committed_profiles():
         assert hits, (path, key)
         got = float(hits[0].group(1))
         assert abs(got - want) <= 0.05 * want, (path, key, got, want)
+
+
+def test_smoother_trace_agrees_with_its_rate_line():
+    """The smoother's committed wall-clock rate (scripts/smooth_rate.py, back-to-back launches) and the rocprofv3 kernel trace of the same
+    run (scripts/profile.sh) must name the same kernel time: 8 % covers the tracer and the launch gaps."""
+    import re
+    tag = latest_round()
+    txt, stats = os.path.join(ROOT, "profiles", tag + "_smoother.txt"), os.path.join(ROOT, "profiles", tag + "_kernel_stats_smoother.csv")
+    if not (os.path.exists(txt) and os.path.exists(stats)):
+        pytest.skip("no smoother profile for " + tag)
+    rate = {int(m.group(1)): float(m.group(2)) for m in re.finditer(r"n=(\d+): \d+ filters, ([\d.]+) us/step", open(txt).read())}
+    with open(stats) as f:
+        rows = [r for r in csv.DictReader(f) if "k_smooth" in r["Name"]]
+    assert rate and rows
+    for r in rows:
+        n = int(re.search(r"k_smooth_\w+<(\d+)", r["Name"]).group(1))
+        assert abs(float(r["AverageNs"]) / 1e3 - rate[n]) / rate[n] < 0.08, (r["Name"], r["AverageNs"], rate[n])
