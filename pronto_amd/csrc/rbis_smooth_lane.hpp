@@ -57,11 +57,15 @@ struct SmoothLaneCfg {
   // component -> offset (doubles) of lane 0's copy inside a tile (rbis_device.hpp: slot s sits in row s / 2, half s % 2)
   static constexpr int off_of(int comp) { return (SL::T.slot_of[comp] / 2) * 128 + (SL::T.slot_of[comp] % 2); }
   // What depends on the role is read from constant memory with wide scalar loads, ONE table row per use: col[w][t][i] = offset of
-  // P(i, column w + NR t) -- by symmetry also of P(row w + NR t, i) --, dsrc[w][u] = offset of packed entry w + NR u.
-  static constexpr int DU = (NP + NR - 1) / NR, NSP = (NS + 3) & ~3;
+  // P(i, column w + NR t) -- by symmetry also of P(row w + NR t, i).
+  static constexpr int NSP = (NS + 3) & ~3;
+  // D = P^s - P^- is staged by whole 16-byte rows of the checkpoints (two components per lane and load, every byte of a line used):
+  // role w takes rows w, w + NR, ...; drow[w][u] = { packed entry of the row's first component, of its second } or -1 (state
+  // vector, quaternion, log-likelihood, padding: not part of D)
+  static constexpr int RU = (SL::NROW + NR - 1) / NR;
   struct Tab {
     int col[NR][NCOL][NSP];
-    int dsrc[NR][(DU + 3) & ~3];
+    int drow[NR][RU][2];
   };
   static constexpr Tab make()
   {
@@ -71,7 +75,12 @@ struct SmoothLaneCfg {
         const int j = (w + NR * c < NS) ? w + NR * c : NS - 1;
         for (int i = 0; i < NSP; i++) t.col[w][c][i] = off_of(L::OFF_P + pk(i < NS ? i : NS - 1, j));
       }
-      for (int u = 0; u < ((DU + 3) & ~3); u++) t.dsrc[w][u] = off_of(L::OFF_P + ((w + NR * u < NP) ? w + NR * u : NP - 1));
+      for (int u = 0; u < RU; u++)
+        for (int h = 0; h < 2; h++) {
+          const int r2 = w + NR * u;
+          const int comp = (r2 < SL::NROW) ? SL::T.comp_of[2 * r2 + h] : -1;
+          t.drow[w][u][h] = (comp >= L::OFF_P) ? comp - L::OFF_P : -1;
+        }
     }
     return t;
   }
@@ -305,20 +314,29 @@ __global__ __launch_bounds__(SmoothLaneCfg<NS>::THREADS, SmoothLaneCfg<NS>::WAVE
   for (int t = 0; t < NCOL; t++)
     if (cidx[t] < NS) S[(O_X + NS + cidx[t]) * 64] = dxv[t];
   {
-    double ds[C::DU], dp[C::DU];
-    int o[C::DU];
+    // in two passes: all rows of both checkpoints in flight at once are 68-72 doubles next to the 60 of G
+    constexpr int RH = (C::RU + 1) / 2;
 #pragma unroll
-    for (int u = 0; u < C::DU; u++) o[u] = tab.dsrc[w][u];
+    for (int pass = 0; pass < 2; pass++) {
+      d2_t ds[RH], dp[RH];
 #pragma unroll
-    for (int u = 0; u < C::DU; u++) {
-      ds[u] = next_sm[tb + o[u]];
-      dp[u] = next_pred[tb + o[u]];
-    }
-    __builtin_amdgcn_sched_barrier(0);
+      for (int v = 0; v < RH; v++) {
+        const int u = pass * RH + v;
+        const int r2 = (u < C::RU && w + NR * u < SL::NROW) ? w + NR * u : SL::NROW - 1;
+        ds[v] = *reinterpret_cast<const d2_t *>(next_sm + tb + r2 * 128);
+        dp[v] = *reinterpret_cast<const d2_t *>(next_pred + tb + r2 * 128);
+      }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int u = 0; u < C::DU; u++) {
-      const int e = w + NR * u;
-      if (e < NP) S[e * 64] = ds[u] - dp[u];
+      for (int v = 0; v < RH; v++) {
+        const int u = pass * RH + v;
+        if (u < C::RU) {
+          const int e0 = tab.drow[w][u][0], e1 = tab.drow[w][u][1];
+          if (e0 >= 0) S[e0 * 64] = ds[v].x - dp[v].x;
+          if (e1 >= 0) S[e1 * 64] = ds[v].y - dp[v].y;
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
   __syncthreads();
