@@ -48,5 +48,23 @@ int pbk_smooth_step(pb_ctx *c, const double *np_, const double *ns_, const doubl
     else k_smooth_reg<21, false><<<grid, S::THREADS, ldsb, c->stream>>>(np_, ns_, cu, out, c->B, dt, c->k);
   }
   LAUNCHCHK(c);
+#ifdef SML_TIMELINE  // attribution build: print the stamps of launch 60 (n = 15) and 310 (n = 21) of scripts/smooth_rate.py
+  {
+    static int calls = 0;
+    if (++calls == 60 || calls == 310) {
+      unsigned long long h[8][16];
+      (void) hipStreamSynchronize(c->stream);
+      (void) hipMemcpyFromSymbol(h, HIP_SYMBOL(sml_tl), sizeof(h));
+      const int nr = c->ns == 15 ? SmoothLaneCfg<15>::NR : SmoothLaneCfg<21>::NR;
+      for (int w = 0; w < nr; w++) {
+        const double t0 = (double) h[0][0];
+        fprintf(stderr, "timeline n=%d tile %d role %d [k cycles from role 0's start] first factor barrier %.1f, last %.1f, rhs done %.1f, subst done %.1f, "
+                        "D staged %.1f, first chunk barrier %.1f, end %.1f; in the chunks: publish phases %.1f, final+M phases %.1f\n", c->ns, SML_TIMELINE, w,
+                (h[w][1] - t0) / 1e3, (h[w][2] - t0) / 1e3, (h[w][3] - t0) / 1e3, (h[w][4] - t0) / 1e3, (h[w][5] - t0) / 1e3, (h[w][6] - t0) / 1e3,
+                (h[w][7] - t0) / 1e3, h[w][8] / 1e3, h[w][9] / 1e3);
+      }
+    }
+  }
+#endif
   return PB_OK;
 }

@@ -27,7 +27,7 @@
 
 // attribution builds (scripts/smooth_attribution.sh lane...): parts compiled OUT, results are garbage, only the time means something
 #if !defined(PB_EXPERIMENTS) && (defined(SML_SKIP_FACT) || defined(SML_SKIP_RHS) || defined(SML_SKIP_SUBST) || defined(SML_SKIP_D) || \
-                                 defined(SML_SKIP_M) || defined(SML_SKIP_FINAL) || defined(SML_SKIP_CHUNKS) || defined(SML_NO_PKLOAD) || defined(SML_NO_PSTORE))
+                                 defined(SML_SKIP_M) || defined(SML_SKIP_FINAL) || defined(SML_SKIP_CHUNKS) || defined(SML_NO_PKLOAD) || defined(SML_NO_PSTORE) || defined(SML_TIMELINE))
 #error "the SML_* attribution flags need -DPB_EXPERIMENTS as well"
 #endif
 
@@ -102,6 +102,14 @@ __device__ __forceinline__ void lane_fence(int &sb, double after)
 // computed from (LDS reads that cannot follow it across the barrier) stays live or is spilled (rbis_coop.hpp, pb_pin).
 __device__ __forceinline__ void lane_pin(double &v) { asm volatile("" : "+v"(v)); }
 
+#ifdef SML_TIMELINE  // attribution (-DPB_EXPERIMENTS -DSML_TIMELINE=<tile>): shader-clock stamps of one tile's roles, taken right behind
+                     // barriers (where the wave has just waited for its LDS traffic anyway), written out at the end; the kernel's time is unchanged
+__device__ unsigned long long sml_tl[8][16];
+#define SML_T(i) tl[i] = __builtin_amdgcn_s_memtime()
+#else
+#define SML_T(i) do { } while (0)
+#endif
+
 __device__ __forceinline__ int pk_s(int i, int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
 
 template <int NS>
@@ -111,7 +119,7 @@ __global__ __launch_bounds__(SmoothLaneCfg<NS>::THREADS, SmoothLaneCfg<NS>::WAVE
   using L = Lay<NS>;
   using SL = Slots<NS>;
   using C = SmoothLaneCfg<NS>;
-  constexpr int NR = C::NR, NCOL = C::NCOL, CH = C::CH, NP = C::NP, O_X = C::O_X;
+  constexpr int NR = C::NR, NCOL = C::NCOL, CH = C::CH, O_X = C::O_X;
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
@@ -137,6 +145,10 @@ __global__ __launch_bounds__(SmoothLaneCfg<NS>::THREADS, SmoothLaneCfg<NS>::WAVE
     cc[t] = cidx[t] < NS ? cidx[t] : NS - 1;
   }
 
+#ifdef SML_TIMELINE
+  unsigned long long tl[16] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }, ta = 0;
+#endif
+  SML_T(0);
   // ---- 0. residual x^s (-) x^- (rbis.cpp:258-261), by the last role: its loads are requested here, the arithmetic (an atan2) and the
   //         hand-over through the exchange region come behind the factorisation, whose first barrier would otherwise wait for them ----
   double rqs[4], rqp[4], rv[NS];
@@ -188,6 +200,8 @@ __global__ __launch_bounds__(SmoothLaneCfg<NS>::THREADS, SmoothLaneCfg<NS>::WAVE
         inv_prev = inv;
       }
       __syncthreads();
+      if constexpr (kk == 0) SML_T(1);
+      if constexpr (kk == NS - 1) SML_T(2);
       // the diagonal slot of column kk-1 held d for the downdates of step kk-1; every role is past them now: it becomes 1/d
       if constexpr (kk > 0)
         if (w == (kk - 1) % NR) S[pk(kk - 1, kk - 1) * 64] = inv_prev;
@@ -262,6 +276,7 @@ __global__ __launch_bounds__(SmoothLaneCfg<NS>::THREADS, SmoothLaneCfg<NS>::WAVE
     }
   }
   __syncthreads();  // the factor is complete (the last reciprocal pivots were written behind the last barrier of step 1)
+  SML_T(3);
 
   // ---- 3. (P^-) X = Ad P_k out of the LDS factor: z[t][:] becomes row cidx[t] of G ----
 #ifndef SML_SKIP_SUBST
@@ -308,6 +323,7 @@ __global__ __launch_bounds__(SmoothLaneCfg<NS>::THREADS, SmoothLaneCfg<NS>::WAVE
     for (int i = 0; i < NS; i++) lane_pin(z[t][i]);
   }
   __syncthreads();  // factor and residual are dead
+  SML_T(4);
 
   // ---- 4. D = P^s - P^- (the uncorrected P^-, rbis.cpp:256) takes the factor's place; dx goes behind the residual ----
 #pragma unroll
@@ -340,6 +356,7 @@ __global__ __launch_bounds__(SmoothLaneCfg<NS>::THREADS, SmoothLaneCfg<NS>::WAVE
     }
   }
   __syncthreads();
+  SML_T(5);
 
   // ---- 5. state: cur.addState(RBIS(dx)) (rbis.cpp:263-265), by the LAST role: the first CH roles make the first rows of M in step 6
   //         meanwhile (with role 0 doing both, every other wave of the tile waited for two fold_chi at the first barrier of step 6) ----
@@ -438,11 +455,19 @@ __global__ __launch_bounds__(SmoothLaneCfg<NS>::THREADS, SmoothLaneCfg<NS>::WAVE
       for (int j = 0; j < NS; j++) lane_pin(m[j]);
     }
     __syncthreads();  // the readers of the previous chunk (and of dx) are done
+#ifdef SML_TIMELINE
+    ta = __builtin_amdgcn_s_memtime();
+    if (c0 == 0) tl[6] = ta; else tl[9] += ta - tl[10];
+#endif
     if (mcc >= 0) {
 #pragma unroll
       for (int j = 0; j < NS; j++) S[(O_X + mcc * NS + j) * 64] = m[j];
     }
     __syncthreads();
+#ifdef SML_TIMELINE
+    tl[10] = __builtin_amdgcn_s_memtime();
+    tl[8] += tl[10] - ta;
+#endif
 #ifdef SML_SKIP_FINAL
     continue;
 #endif
@@ -470,6 +495,11 @@ __global__ __launch_bounds__(SmoothLaneCfg<NS>::THREADS, SmoothLaneCfg<NS>::WAVE
       }
     }
   }
+#ifdef SML_TIMELINE
+  tl[7] = __builtin_amdgcn_s_memtime();
+  if (blockIdx.x == SML_TIMELINE && lane == 0)
+    for (int i = 0; i < 16; i++) sml_tl[w][i] = tl[i];
+#endif
 }
 
 #undef S
