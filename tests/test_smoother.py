@@ -14,7 +14,7 @@ from util import rel
 from pronto_amd.synth import Workload
 
 pytestmark = pytest.mark.gpu
-TOL = 1e-7
+TOL = 1e-9   # observed: 2e-15 .. 4e-15 (block-relative) for all three kernels over 23 backward steps
 
 
 @pytest.mark.parametrize("n,zero_bias", [(15, False), (21, False), (21, True)])
@@ -40,6 +40,7 @@ def test_backward_pass_matches_oracle(oracle, n, zero_bias):
     S = [2 * T, 2 * T + 1]               # ping-pong slots for the smoothed posterior
     # backward recursion: next = filtered(T-1), next_pred = pred(T-1)
     nxt_slot, nxt_o = 2 * (T - 1) + 1, hist[T - 1][1]
+    worst = 0.0
     for k in range(T - 2, -1, -1):
         out_slot = S[k % 2]
         est.smooth_step(2 * (k + 1), nxt_slot, 2 * k + 1, out_slot, dt)
@@ -49,9 +50,12 @@ def test_backward_pass_matches_oracle(oracle, n, zero_bias):
         v, q, P, ll = est.get_head()
         assert rel(v, nxt_o[0][:n]) < TOL and rel(q, nxt_o[1]) < TOL, (k, rel(v, nxt_o[0][:n]))
         assert rel(P, nxt_o[2][:n, :n]) < TOL, (k, rel(P, nxt_o[2][:n, :n]))
+        worst = max(worst, rel(v, nxt_o[0][:n]), rel(q, nxt_o[1]), rel(P, nxt_o[2][:n, :n]))
         # smoothing never increases the uncertainty: P_filtered - P_smoothed is PSD
         d = hist[k][1][2][:n, :n, 0] - P[:, :, 0]
         assert np.linalg.eigvalsh(0.5 * (d + d.T)).min() > -1e-9 * np.abs(hist[k][1][2]).max()
+    print("smoother backward pass n=%d zero_bias=%s: worst relative error against the oracle over %d steps: %.2e" % (n, zero_bias, T - 1, worst))
+    est.close()
 
 
 @pytest.mark.parametrize("blk,tells", [(15, False), (18, True)])
