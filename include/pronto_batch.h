@@ -114,6 +114,13 @@ int pb_host_free(pb_ctx *ctx, void *host_ptr);
  * broadcast != 0, vec [n], quat [4], cov [n*n] applied to every filter (host memory only). */
 int pb_reset(pb_ctx *ctx, const double *vec, const double *quat, const double *cov, int broadcast, int mem);
 
+/* The posterior of an update computed OUTSIDE the library becomes the head: posterior_state / posterior_covariance /
+ * loglikelihood as an RBISUpdateInterface subclass fills them (rbis_update_interface.hpp:14-35; the estimator then reads them as
+ * the next prior, mav_state_est.cpp:55-62).  This is the slow path behind the shim's RBISHostUpdate -- user code written against
+ * the reference's updateFilter(const RBIS&, const RBIM&, double) runs on the host between a pb_get_head and this call.  Layout
+ * as pb_reset (not broadcast); loglik [B] or NULL (= 0).  Honours pb_set_output_slot like every update.  PB_HOST or PB_DEVICE. */
+int pb_set_head(pb_ctx *ctx, const double *vec, const double *quat, const double *cov, const double *loglik, int mem);
+
 /* RBISIMUProcessStep::updateFilter (rbis_update_interface.cpp:30-52 -> rbis.cpp:37-122).
  * imu_block [7][B] = gyro xyz, accelerometer xyz (body frame, as InsHandler hands them over,
  * sensor_handlers.cpp:226-251), dt.  q = {q_gyro, q_accel, q_gyro_bias, q_accel_bias} (host). */
@@ -177,7 +184,9 @@ int pb_replay_legodo_fused(pb_ctx *ctx, int n_steps, int steps_per_launch, const
  * (mav_state_est.cpp:50-70) and what EKFSmoothBackwardsPass reads (:98-189): the posterior of step t is also written into
  * checkpoint slot first_slot + t (pb_history_reserve; first_slot + n_steps <= slots), while the state stays in registers.
  * Per step one slot is written and nothing is read back (the per-message path with pb_set_output_slot reads the previous
- * slot and writes the next one).  Slots are bit-identical to what pb_set_output_slot + pb_step_legodo leave.  The head
+ * slot and writes the next one).  Slots are bit-identical to pb_replay_legodo_fused run ONE step per launch, and equal to
+ * rounding (1e-12 relative in the tests) to what pb_set_output_slot + pb_step_legodo leave -- another kernel, other FMA
+ * contractions: do not mix the two paths under a bit-exact replay checksum.  The head
  * afterwards is the context's own array (= the last slot's content).  Accounting: (S_x + S_P + 8) + 104 + 2 (S_x + S_P + 8) / T
  * bytes per filter-step -- its own, never the headline metric. */
 int pb_replay_legodo_checkpointed(pb_ctx *ctx, int n_steps, int steps_per_launch, const double *imu_stream,
@@ -246,7 +255,10 @@ int pb_legodo_set_contact_mode(pb_ctx *ctx, int standing, double total_force, do
  * odometry / pair call only: utimes [B] (int64, may be NULL = the call's scalar utime for every filter) is what
  * leg_estimate::updateOdometry takes as `utime` per filter (elapsed time of the increment, the 30 ms reset, the Schmitt-trigger
  * clocks, foot_contact_classify's black-out windows); valid [B] (uint8, may be NULL = all) marks the filters that HAVE a message --
- * the others keep their odometry state and get no measurement (mask 0).  mem: PB_HOST or PB_DEVICE.  (The joint Kalman filter of
+ * the others keep their odometry state and get no measurement (mask 0).  mem: PB_HOST (copied before the call returns) or
+ * PB_DEVICE (read IN PLACE by the consuming launch: the arrays stay the caller's until that launch has run).  The arrays are
+ * taken by the next pb_legodo_update* / pb_step_legodo_joints / _feet call whatever its outcome -- a call that fails its argument
+ * checks has still consumed them.  (The joint Kalman filter of
  * pb_joint_filter keeps one clock per context: with per-filter times use the low-pass filter or none.) */
 int pb_legodo_set_message_times(pb_ctx *ctx, const int64_t *utimes, const uint8_t *valid, int mem);
 /* Which of LegOdoCommon's measurements (state_estimator.legodo.mode, rbis_legodo_common.cpp:5-23,110-169) the odometry calls

@@ -59,6 +59,7 @@ _SIGS = {
     "pb_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
     "pb_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
     "pb_reset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    "pb_set_head": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "pb_predict": (C.c_int, [C.c_void_p, C.c_void_p, _dp, C.c_int]),
     "pb_update_indexed": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_void_p, C.c_void_p, C.c_int,
                                     C.c_void_p, C.c_int]),

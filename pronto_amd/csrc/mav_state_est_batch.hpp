@@ -380,6 +380,51 @@ public:
   }
 };
 
+// An update written against the REFERENCE's contract (rbis_update_interface.hpp:14-35):
+//     virtual void updateFilter(const RBIS & prior_state, const RBIM & prior_cov, double prior_loglikelihood) = 0;
+// "must fill posterior_state, posterior_covariance, loglikelihood".  This is what a third-party RBISUpdateInterface subclass looks
+// like (RBISOpticalFlowMeasurement, rbis_update_interface.hpp:128-154; RBISLaserGPFMeasurement::updateFilter,
+// gpf/rbis_gpf_update.cpp:28-76): user arithmetic on ONE filter's state.  It runs here on the SLOW path, documented as such: the
+// batch's head comes to the host (pb_get_head), the user's updateFilter is called once per filter with single-filter RBIS / RBIM
+// (B = 1 containers: prior_state(i, 0), prior_state.q(i, 0), prior_cov(r, c, 0)), and the posteriors go back (pb_set_head) --
+// two PCIe crossings of the whole state per update, 2 x 126 MB at 64k 15-state filters.  The built-in updates never take it.
+// apply[b] = false (optional mask, like a handler's NULL return for filter b) leaves filter b's head as it is.
+class RBISHostUpdate : public RBISUpdateInterface {
+public:
+  RBIS posterior_state;          // single-filter containers, filled by the user's updateFilter
+  RBIM posterior_covariance;
+  double loglikelihood = 0;
+  std::vector<uint8_t> apply;    // [B] or empty (= every filter)
+  RBISHostUpdate(sensor_enum sensor_id_, int64_t utime_) : RBISUpdateInterface(sensor_id_, utime_) {}
+  virtual void updateFilter(const RBIS &prior_state, const RBIM &prior_cov, double prior_loglikelihood) = 0;
+  int updateFilter(pb_ctx *ctx) final
+  {
+    const int n = pb_n_states(ctx), B = pb_batch(ctx);
+    std::vector<double> vec((size_t) n * B), quat((size_t) 4 * B), cov((size_t) n * n * B), ll((size_t) B);
+    int rc = pb_get_head(ctx, 0, B, vec.data(), quat.data(), cov.data(), ll.data(), PB_HOST);
+    if (rc != PB_OK) return rc;
+    RBIS prior(n, 1);
+    RBIM prior_cov(n, 1);
+    for (int b = 0; b < B; b++) {
+      if (!apply.empty() && !apply[(size_t) b]) continue;
+      for (int i = 0; i < n; i++) prior.vec[(size_t) i] = vec[(size_t) i * B + b];
+      for (int i = 0; i < 4; i++) prior.quat[(size_t) i] = quat[(size_t) i * B + b];
+      for (int i = 0; i < n * n; i++) prior_cov.m[(size_t) i] = cov[(size_t) i * B + b];
+      prior.utime = utime;
+      posterior_state = prior;               // (a subclass that forgets a member leaves the prior there, not garbage)
+      posterior_covariance = prior_cov;
+      loglikelihood = ll[(size_t) b];
+      updateFilter(prior, prior_cov, ll[(size_t) b]);
+      if (posterior_state.n != n || posterior_state.B != 1 || posterior_covariance.n != n || posterior_covariance.B != 1) return PB_ERR_ARG;
+      for (int i = 0; i < n; i++) vec[(size_t) i * B + b] = posterior_state.vec[(size_t) i];
+      for (int i = 0; i < 4; i++) quat[(size_t) i * B + b] = posterior_state.quat[(size_t) i];
+      for (int i = 0; i < n * n; i++) cov[(size_t) i * B + b] = posterior_covariance.m[(size_t) i];
+      ll[(size_t) b] = loglikelihood;
+    }
+    return pb_set_head(ctx, vec.data(), quat.data(), cov.data(), ll.data(), PB_HOST);
+  }
+};
+
 // Two updates with complementary per-filter masks that together are ONE update of the reference (each filter takes
 // exactly one branch): used where the reference changes the measurement dimension per message (LegOdoCommon's
 // pos_and_lin_rate -> lin_rate fallback, rbis_legodo_common.cpp:118-122).  If the first half wrote its posterior into a
@@ -543,24 +588,33 @@ public:
       dropped_updates++;
       return;
     }
+    const auto old_start = unprocessed_updates_start;
     auto added_it = map.insert(map.end(), updateHistory::historyPair(update->utime, update));
     if (unprocessed_updates_start == map.end() || added_it->first < unprocessed_updates_start->first)
       unprocessed_updates_start = added_it;                                   // mav_state_est.cpp:33-40
     if (!roll_forward) {
       // a measurement that is still to be made from the handler's inputs is made NOW (those inputs are the caller's and only
-      // valid until its next message): slaved to the state after the INS step in front of it when that is the one held back
-      if (auto *m = deferredMeasurement(update))
-        if (m->deferred()) {
-          RBISIMUProcessStep *ahead = nullptr;
-          if (holding_ == 1 && added_it != map.begin()) {
-            auto prev = std::prev(added_it);
-            if (prev == unprocessed_updates_start) ahead = dynamic_cast<RBISIMUProcessStep *>(prev->second);
-          }
-          if (ahead == nullptr) flushPending();
-          const int rc = m->resolve(ctx, ahead);
-          if (rc != PB_OK) last_status = rc;
+      // valid until its next message): slaved to the state after the INS step in front of it when that is the one held back.
+      // The update ITSELF stays unapplied (roll_forward = false).
+      auto *m = deferredMeasurement(update);
+      if (m == nullptr || !m->deferred()) return;
+      // a late arrival in front of an update that HAS been applied: the state its odometry reads is the one at its place in the
+      // history, so it takes the restore-checkpoint + replay path below like a rolled-forward update
+      auto after = std::next(added_it);
+      bool next_applied = after != map.end();
+      for (auto it = old_start; next_applied && it != map.end(); ++it)
+        if (it == after) next_applied = false;
+      if (!next_applied) {
+        RBISIMUProcessStep *ahead = nullptr;
+        if (holding_ == 1 && added_it != map.begin()) {
+          auto prev = std::prev(added_it);
+          if (prev == unprocessed_updates_start) ahead = dynamic_cast<RBISIMUProcessStep *>(prev->second);
         }
-      return;
+        if (ahead == nullptr) flushPendingBefore(added_it);   // (what is pending IN FRONT of it, never the new element)
+        const int rc = m->resolve(ctx, ahead);
+        if (rc != PB_OK) last_status = rc;
+        return;
+      }
     }
 
     // The prior of the first unprocessed update is the posterior of the update before it (:45-57).  If the device
@@ -700,6 +754,23 @@ public:
     holding_ = 0;
     pb_set_utime(ctx, head_utime);
     unprocessed_updates_start = map.end();
+  }
+
+  // the same for the pending updates IN FRONT of `stop` only; `stop` and what follows it stay unprocessed
+  void flushPendingBefore(updateHistory::historyMapIterator stop)
+  {
+    if (!fuse_ins_legodo || unprocessed_updates_start == history.updateMap.end() || unprocessed_updates_start == stop) return;
+    flushing_ = true;
+    for (auto it = unprocessed_updates_start; it != stop && it != history.updateMap.end(); ++it) {
+      int rc = it->second->updateFilter(ctx);
+      if (rc != PB_OK) last_status = rc;
+      device_head = it->second;
+      head_utime = it->second->utime;
+    }
+    flushing_ = false;
+    holding_ = 0;
+    pb_set_utime(ctx, head_utime);
+    unprocessed_updates_start = stop;
   }
 
   void getHeadState(RBIS &head_state, RBIM &head_cov)

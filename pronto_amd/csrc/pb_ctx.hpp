@@ -35,6 +35,8 @@ struct pb_ctx {
   int64_t *leg_ut = nullptr;      // per-filter message times / validity of the NEXT odometry call (pb_legodo_set_message_times),
   uint8_t *leg_valid = nullptr;   // device [B] each; consumed by that call
   bool leg_ut_on = false, leg_valid_on = false;
+  const int64_t *leg_ut_ext = nullptr;    // PB_DEVICE times / validity are read in place: the caller's arrays, not copies
+  const uint8_t *leg_valid_ext = nullptr;
   LegMeasPar leg_meas;            // pb_legodo_set_measurement_mode: which of LegOdoCommon's measurements the odometry calls write
   LegChain *leg_chain = nullptr;  // forward-kinematics chain table (pb_legodo_set_chain), device copy ...
   LegChain leg_chain_h;           // ... and the host copy (PB_HOST_BROADCAST joint states are reduced to chain angles on the host)

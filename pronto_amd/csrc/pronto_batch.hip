@@ -356,6 +356,31 @@ extern "C" int pb_reset(pb_ctx *c, const double *vec, const double *quat, const 
   return PB_OK;
 }
 
+// The posterior of an update that was computed OUTSIDE the library (the shim's RBISHostUpdate: user code written against the
+// reference's updateFilter(prior_state, prior_cov, prior_loglikelihood) contract, rbis_update_interface.hpp:14-35) becomes the head.
+extern "C" int pb_set_head(pb_ctx *c, const double *vec, const double *quat, const double *cov, const double *loglik, int mem)
+{
+  ENTER(c);
+  NEED_STATE(c);
+  if (!vec || !quat || !cov) return fail(c, PB_ERR_ARG, "pb_set_head: NULL input");
+  if (mem != PB_HOST && mem != PB_DEVICE) return fail(c, PB_ERR_ARG, "pb_set_head: mem must be PB_HOST or PB_DEVICE");
+  const int n = c->ns, B = c->B;
+  Part p[4] = { { vec, sizeof(double) * n * B, 0 }, { quat, sizeof(double) * 4 * B, 0 }, { cov, sizeof(double) * n * n * B, 0 },
+                { loglik, loglik ? sizeof(double) * B : 0, 0 } };
+  int rc = stage_in(c, mem, p, 4);
+  if (rc) return rc;
+  double *target = update_target(c);   // like every update: in place, or into the checkpoint slot named by pb_set_output_slot
+  if (n == 15)
+    k_reset<15><<<nblk(B), 64, 0, c->stream>>>(target, B, (const double *) p[0].dev, (const double *) p[1].dev, (const double *) p[2].dev,
+                                               (const double *) p[3].dev);
+  else
+    k_reset<21><<<nblk(B), 64, 0, c->stream>>>(target, B, (const double *) p[0].dev, (const double *) p[1].dev, (const double *) p[2].dev,
+                                               (const double *) p[3].dev);
+  LAUNCHCHK(c);
+  update_done(c, target);
+  return PB_OK;
+}
+
 extern "C" int pb_predict(pb_ctx *c, const double *imu_block, const double q[4], int mem)
 {
   ENTER(c);
@@ -927,27 +952,46 @@ extern "C" int pb_legodo_set_message_times(pb_ctx *c, const int64_t *utimes, con
   ENTER(c);
   if (!c->legd) return fail(c, PB_ERR_STATE, "pb_legodo_set_message_times before pb_legodo_init");
   if (mem != PB_HOST && mem != PB_DEVICE) return fail(c, PB_ERR_ARG, "pb_legodo_set_message_times: mem must be PB_HOST or PB_DEVICE");
-  const hipMemcpyKind kind = mem == PB_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
   c->leg_ut_on = c->leg_valid_on = false;
+  c->leg_ut_ext = nullptr;
+  c->leg_valid_ext = nullptr;
+  if (mem == PB_DEVICE) {   // read in place by the consuming launch (no copy): the arrays stay the caller's until that launch has run
+    c->leg_ut_ext = utimes;
+    c->leg_valid_ext = valid;
+    c->leg_ut_on = utimes != nullptr;
+    c->leg_valid_on = valid != nullptr;
+    return PB_OK;
+  }
   if (utimes) {
     if (!c->leg_ut) HIPCHK(c, hipMalloc((void **) &c->leg_ut, sizeof(int64_t) * (size_t) c->stride));
-    HIPCHK(c, hipMemcpyAsync(c->leg_ut, utimes, sizeof(int64_t) * (size_t) c->B, kind, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->leg_ut, utimes, sizeof(int64_t) * (size_t) c->B, hipMemcpyHostToDevice, c->stream));
     c->leg_ut_on = true;
   }
   if (valid) {
     if (!c->leg_valid) HIPCHK(c, hipMalloc((void **) &c->leg_valid, (size_t) c->stride));
-    HIPCHK(c, hipMemcpyAsync(c->leg_valid, valid, (size_t) c->B, kind, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->leg_valid, valid, (size_t) c->B, hipMemcpyHostToDevice, c->stream));
     c->leg_valid_on = true;
   }
-  if (mem == PB_HOST && (utimes || valid)) HIPCHK(c, hipStreamSynchronize(c->stream));  // the caller's arrays are free again
+  if (utimes || valid) HIPCHK(c, hipStreamSynchronize(c->stream));  // the caller's arrays are free again
   return PB_OK;
 }
-// hands the one-shot per-filter times / validity to the launch that consumes them
-static void leg_take_message_times(pb_ctx *c, LegIn &in)
+// The one-shot per-filter times / validity belong to the NEXT odometry or pair call, whatever becomes of it: every such entry point
+// takes them FIRST, before it validates anything, so that a call that fails early cannot leave them behind for an unrelated later
+// call.
+struct LegMsgTimes {
+  const int64_t *utimes = nullptr;
+  const uint8_t *valid = nullptr;
+};
+static LegMsgTimes leg_take_message_times(pb_ctx *c)
 {
-  if (c->leg_ut_on) in.utimes = c->leg_ut;
-  if (c->leg_valid_on) in.valid = c->leg_valid;
+  LegMsgTimes t;
+  if (c == nullptr) return t;
+  if (c->leg_ut_on) t.utimes = c->leg_ut_ext ? c->leg_ut_ext : c->leg_ut;
+  if (c->leg_valid_on) t.valid = c->leg_valid_ext ? c->leg_valid_ext : c->leg_valid;
   c->leg_ut_on = c->leg_valid_on = false;
+  c->leg_ut_ext = nullptr;
+  c->leg_valid_ext = nullptr;
+  return t;
 }
 
 extern "C" int pb_legodo_set_measurement_mode(pb_ctx *c, int mode, double r_xyz, double r_vang, double r_vang_uncertain)
@@ -1191,7 +1235,7 @@ static int leg_in_joints(pb_ctx *c, const char *who, int n_rows, const float *jp
   return PB_OK;
 }
 
-static int legodo_launch(pb_ctx *c, LegIn &in, const double *imu_block, int imu_mem, int64_t utime, int zero_delta, double r_vxyz,
+static int legodo_launch(pb_ctx *c, LegIn &in, const LegMsgTimes &mt, const double *imu_block, int imu_mem, int64_t utime, int zero_delta, double r_vxyz,
                          double r_vxyz_uncertain, double *delta_out, double *status_out, double *lo_out, uint8_t *mask_out,
                          double *pos_out = nullptr, uint8_t *pos_ok_out = nullptr)
 {
@@ -1211,7 +1255,8 @@ static int legodo_launch(pb_ctx *c, LegIn &in, const double *imu_block, int imu_
   if (c->leg_nc_dev) in.ncontacts = c->leg_nc;
   in.nc[0] = c->leg_nc_h[0];
   in.nc[1] = c->leg_nc_h[1];
-  leg_take_message_times(c, in);
+  in.utimes = mt.utimes;
+  in.valid = mt.valid;
   LegMeasPar mp = c->leg_meas;
   mp.r_v2 = r_vxyz * r_vxyz;                            // bot_sq (rbis_legodo_common.cpp:40-43)
   mp.r_v2_uncertain = r_vxyz_uncertain * r_vxyz_uncertain;
@@ -1235,6 +1280,7 @@ static int legodo_update_impl(pb_ctx *c, const double *imu_block, int imu_mem, b
                               const double *forces, int mem, int zero_delta, double r_vxyz, double r_vxyz_uncertain,
                               double *delta_out, double *status_out, double *lo_out, uint8_t *mask_out)
 {
+  const LegMsgTimes mt = leg_take_message_times(c);
   ENTER(c);
   NEED_STATE(c);
   if (!c->legd) return fail(c, PB_ERR_STATE, "pb_legodo_update before pb_legodo_init");
@@ -1254,7 +1300,7 @@ static int legodo_update_impl(pb_ctx *c, const double *imu_block, int imu_mem, b
     in.feet = (const double *) p[0].dev;
     in.forces = (const double *) p[1].dev;
   }
-  return legodo_launch(c, in, ahead ? imu_block : nullptr, imu_mem, utime, zero_delta, r_vxyz, r_vxyz_uncertain, delta_out, status_out,
+  return legodo_launch(c, in, mt, ahead ? imu_block : nullptr, imu_mem, utime, zero_delta, r_vxyz, r_vxyz_uncertain, delta_out, status_out,
                        lo_out, mask_out);
 }
 
@@ -1279,6 +1325,7 @@ extern "C" int pb_legodo_update_joints(pb_ctx *c, const double *imu_block, int i
                                        int zero_delta, double r_vxyz, double r_vxyz_uncertain, double *delta_out, double *status_out,
                                        double *lo_out, uint8_t *mask_out, double *position_out, uint8_t *position_status_out)
 {
+  const LegMsgTimes mt = leg_take_message_times(c);
   ENTER(c);
   NEED_STATE(c);
   if (!c->legd) return fail(c, PB_ERR_STATE, "pb_legodo_update_joints before pb_legodo_init");
@@ -1288,14 +1335,14 @@ extern "C" int pb_legodo_update_joints(pb_ctx *c, const double *imu_block, int i
   LegIn in;
   int rc = leg_in_joints(c, "pb_legodo_update_joints", n_rows, joint_position, joint_effort, forces, mem, in);
   if (rc) return rc;
-  return legodo_launch(c, in, imu_block, imu_mem, utime, zero_delta, r_vxyz, r_vxyz_uncertain, delta_out, status_out, lo_out, mask_out,
+  return legodo_launch(c, in, mt, imu_block, imu_mem, utime, zero_delta, r_vxyz, r_vxyz_uncertain, delta_out, status_out, lo_out, mask_out,
                        position_out, position_status_out);
 }
 
 // IMU step + leg odometry + its update (LegOdoCommon's mode, pb_legodo_set_measurement_mode) for one message pair: one kernel where
 // the context has it (pbk_step_leg), else the odometry kernel slaved to the state after the IMU step followed by the fused step
 // (lin_rate: two launches) or by the process step and the indexed update(s) (the six-row modes); same results to rounding
-static int step_leg_impl(pb_ctx *c, LegIn &in, const double *imu_block, int imu_mem, const double q[4], int64_t utime, double r_vxyz,
+static int step_leg_impl(pb_ctx *c, LegIn &in, const LegMsgTimes &mt, const double *imu_block, int imu_mem, const double q[4], int64_t utime, double r_vxyz,
                          double r_vxyz_uncertain, double *lo_out, uint8_t *mask_out)
 {
   StepBcast bc;
@@ -1312,7 +1359,8 @@ static int step_leg_impl(pb_ctx *c, LegIn &in, const double *imu_block, int imu_
   if (c->leg_nc_dev) in.ncontacts = c->leg_nc;
   in.nc[0] = c->leg_nc_h[0];
   in.nc[1] = c->leg_nc_h[1];
-  leg_take_message_times(c, in);
+  in.utimes = mt.utimes;
+  in.valid = mt.valid;
   LegMeasPar mp = c->leg_meas;
   mp.r_v2 = r_vxyz * r_vxyz;                            // bot_sq (rbis_legodo_common.cpp:40-43)
   mp.r_v2_uncertain = r_vxyz_uncertain * r_vxyz_uncertain;
@@ -1356,6 +1404,7 @@ extern "C" int pb_step_legodo_joints(pb_ctx *c, const double *imu_block, int imu
                                      const float *joint_position, const float *joint_effort, const float *forces, int mem,
                                      double r_vxyz, double r_vxyz_uncertain, double *lo_block_out, uint8_t *mask_out)
 {
+  const LegMsgTimes mt = leg_take_message_times(c);
   ENTER(c);
   NEED_STATE(c);
   if (!c->legd) return fail(c, PB_ERR_STATE, "pb_step_legodo_joints before pb_legodo_init");
@@ -1365,13 +1414,14 @@ extern "C" int pb_step_legodo_joints(pb_ctx *c, const double *imu_block, int imu
   LegIn in;
   int rc = leg_in_joints(c, "pb_step_legodo_joints", n_rows, joint_position, joint_effort, forces, mem, in);
   if (rc) return rc;
-  return step_leg_impl(c, in, imu_block, imu_mem, q, utime, r_vxyz, r_vxyz_uncertain, lo_block_out, mask_out);
+  return step_leg_impl(c, in, mt, imu_block, imu_mem, q, utime, r_vxyz, r_vxyz_uncertain, lo_block_out, mask_out);
 }
 
 extern "C" int pb_step_legodo_feet(pb_ctx *c, const double *imu_block, int imu_mem, const double q[4], int64_t utime, const double *feet,
                                    const double *forces, int mem, double r_vxyz, double r_vxyz_uncertain, double *lo_block_out,
                                    uint8_t *mask_out)
 {
+  const LegMsgTimes mt = leg_take_message_times(c);
   ENTER(c);
   NEED_STATE(c);
   if (!c->legd) return fail(c, PB_ERR_STATE, "pb_step_legodo_feet before pb_legodo_init");
@@ -1391,7 +1441,7 @@ extern "C" int pb_step_legodo_feet(pb_ctx *c, const double *imu_block, int imu_m
     in.feet = (const double *) p[0].dev;
     in.forces = (const double *) p[1].dev;
   }
-  return step_leg_impl(c, in, imu_block, imu_mem, q, utime, r_vxyz, r_vxyz_uncertain, lo_block_out, mask_out);
+  return step_leg_impl(c, in, mt, imu_block, imu_mem, q, utime, r_vxyz, r_vxyz_uncertain, lo_block_out, mask_out);
 }
 
 extern "C" int pb_legodo_fk(pb_ctx *c, int n_rows, const float *joint_position, const float *joint_effort, int mem, double *feet_out)

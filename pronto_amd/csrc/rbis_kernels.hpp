@@ -339,7 +339,7 @@ struct DiagArg {
 // RBISResetUpdate::updateFilter, per-filter inputs: vec [n][B], quat [4][B], cov [n*n][B] column-major
 template <int NS>
 __global__ void k_reset(double *__restrict__ st, int B, const double *__restrict__ vec,
-                        const double *__restrict__ quat, const double *__restrict__ cov)
+                        const double *__restrict__ quat, const double *__restrict__ cov, const double *__restrict__ ll = nullptr)
 {
   using L = Lay<NS>;
   using S = Slots<NS>;
@@ -347,7 +347,7 @@ __global__ void k_reset(double *__restrict__ st, int B, const double *__restrict
   if (b >= B) return;
   for (int i = 0; i < NS; i++) st[S::eidx(L::OFF_VEC + i, b)] = vec[(long) i * B + b];
   for (int i = 0; i < 4; i++) st[S::eidx(L::OFF_QUAT + i, b)] = quat[(long) i * B + b];
-  st[S::eidx(L::OFF_LL, b)] = 0.0;
+  st[S::eidx(L::OFF_LL, b)] = ll ? ll[b] : 0.0;
   for (int i = 0; i < NS; i++)
     for (int j = 0; j <= i; j++) st[S::eidx(L::OFF_P + pk(i, j), b)] = cov[(long) (j * NS + i) * B + b];
 }
@@ -619,7 +619,6 @@ __global__ __launch_bounds__(128, 1) void k_step_coop(const double *st, double *
                                                       const uint8_t *__restrict__ mask, double qg, double qa,
                                                       double qbg, double qba, Consts k, CorrArgs ca, StepBcast bc = StepBcast())
 {
-  using C = Coop<NS>;
   __shared__ double xch[(UPDATE || CORR::M > 0) ? CoopX<NS, CORR>::NXCH : 1][64];
   const int role = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
   const unsigned lane = threadIdx.x & 63u;

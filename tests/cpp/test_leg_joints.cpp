@@ -59,6 +59,20 @@ static const char *URDF = R"(<?xml version="1.0"?>
 int main(int argc, char **argv)
 {
   const int n = take_n_states(argc, argv);
+  // "late" anywhere: legodo.roll_forward_on_receive = false, posterior checkpoints on, the joint state stamped 300 us behind its IMU
+  // sample, and on every 10th tick a scan-match pose stamped 400 us behind it that is delivered -- and rolled forward -- BEFORE the
+  // joint state: the leg odometry then arrives in front of an update that has been applied, without roll_forward (the
+  // estimator must neither apply it on top of the pose nor apply the pose twice; it replays from the checkpoint).  On the other
+  // ticks the joint state is simply left unapplied until the next IMU message rolls forward.
+  bool late = false;
+  {
+    int w = 1;
+    for (int i = 1; i < argc; i++) {
+      if (std::string(argv[i]) == "late") late = true;
+      else argv[w++] = argv[i];
+    }
+    argc = w;
+  }
   const std::string lomode = argc > 1 ? argv[1] : "lin_rate";
   const std::string cmode = argc > 2 ? argv[2] : "alt";
   // "fuse3": fuse_ins_legodo + fuse_corrections -- the estimator holds the finished [INS, leg odometry] pair back until the next
@@ -75,7 +89,8 @@ int main(int argc, char **argv)
   po_get_constants(&g, nullptr);
   BotParam param;
   param.set("state_estimator.utime_history_span", "1000000");
-  param.set("state_estimator.history_slots", "0");
+  param.set("state_estimator.history_slots", late ? "12" : "0");
+  if (late) param.set("state_estimator.history_checkpoint_every", "1");
   param.set("state_estimator.fuse_ins_legodo", fuse ? "true" : "false");
   param.set("state_estimator.fuse_corrections", fuse3 ? "true" : "false");
   param.set("state_estimator.ins.channel", "IMU");
@@ -100,11 +115,13 @@ int main(int argc, char **argv)
                        "state_estimator.legodo.adjustment_gain=7000,10000,10000,0,5000");
   param.set("state_estimator.legodo.init_contact_mode", cmode == "standing" ? "standing" : "walking");
   param.set("state_estimator.legodo.use_controller_input", cmode == "ctrl" ? "true" : "false");
-  for (const char *s : { "ins", "legodo" }) {
+  for (const char *s : { "ins", "legodo", "scan_matcher" }) {
     param.set(std::string("state_estimator.") + s + ".downsample_factor", "1");
-    param.set(std::string("state_estimator.") + s + ".roll_forward_on_receive", "true");
+    param.set(std::string("state_estimator.") + s + ".roll_forward_on_receive", (late && std::string(s) == "legodo") ? "false" : "true");
     param.set(std::string("state_estimator.") + s + ".utime_offset", "0");
   }
+  param.applyOverrides("state_estimator.scan_matcher.mode=position_yaw|state_estimator.scan_matcher.r_pxy=0.05|"
+                       "state_estimator.scan_matcher.r_pz=0.05|state_estimator.scan_matcher.r_yaw=1.0");
   // the joint_state_t layout of the log: 12 leg joints among 4 others
   const std::vector<std::string> names = { "back_bkz", "l_leg_hpz", "l_leg_hpx", "l_leg_hpy", "neck_ay", "l_leg_kny", "l_leg_aky", "l_leg_akx",
                                            "l_arm_shz", "r_leg_hpz", "r_leg_hpx", "r_leg_hpy", "r_arm_shz", "r_leg_kny", "r_leg_aky", "r_leg_akx" };
@@ -165,8 +182,10 @@ int main(int argc, char **argv)
   }
   BotTrans ins_to_body;
   InsHandler ins_handler(&param, &ins_to_body);
+  ScanMatcherHandler sm_handler(&param);
   FrontEnd front_end(&param);
   auto on_ins = front_end.addSensor("ins", &InsHandler::processMessage, &ins_handler);
+  auto on_pose = front_end.addSensor("scan_matcher", &ScanMatcherHandler::processMessage, &sm_handler);
   MavStateEstimator est(new RBISResetUpdate(x0, P0, RBISUpdateInterface::reset, 0), &param, 0);
   front_end.setStateEstimator(&est);
   int n_status[3] = { 0, 0, 0 }, n_pos = 0, n_before_ft = 0;
@@ -220,8 +239,15 @@ int main(int argc, char **argv)
           jp[(size_t) (r1 + 2) * W + b] = (float) (-0.03 * sgn - 0.02 * sw);
         }
       }
+      const int64_t js_utime = late ? utime + 300 : utime;
+      const bool pose_tick = late && k % 10 == 9;
+      double ppos[3] = { 0, 0, 0 }, pquat[4] = { 1, 0, 0, 0 };
+      if (pose_tick) {
+        for (int i = 0; i < 3; i++) ppos[i] = 0.05 * nrand();
+        po_euler_to_quat(0.0, 0.0, 0.3 * (urand() - 0.5), pquat);
+      }
       msgs::joint_state_t js;
-      js.utime = utime;
+      js.utime = js_utime;
       js.joint_name = names;
       js.joint_position = jp.data();
       js.joint_effort = je.data();
@@ -253,6 +279,11 @@ int main(int argc, char **argv)
         msgs::controller_foot_contact_t cc{ utime, ncl, ncr };
         legodo_handler.controllerInputHandler(&cc);
       }
+      if (pose_tick) {   // delivered (and applied) ahead of the joint state it is stamped behind
+        const double zero3[3] = { 0, 0, 0 };
+        msgs::pose_t pm{ utime + 400, BatchArray(ppos, PB_HOST_BROADCAST), BatchArray(zero3, PB_HOST_BROADCAST), BatchArray(pquat, PB_HOST_BROADCAST) };
+        on_pose(&pm);
+      }
       on_joints(&js);
       if (device && fuse3) {  // the caller refills its blocks for the next message right away
         std::vector<float> junk((size_t) NJ * W, 1e9f);
@@ -271,7 +302,7 @@ int main(int argc, char **argv)
             const size_t at = (size_t) och[side].row[j] * W + s;
             pos[och[side].row[j]] = po_torque_adjust(jp[at], je[at], och[side].gain[j]);
           }
-        po_joint_filter(jmode, olp[b].data(), okf[b].data(), utime, NJ, pos, vel);
+        po_joint_filter(jmode, olp[b].data(), okf[b].data(), js_utime, NJ, pos, vel);
         for (int side = 0; side < 2; side++) {
           double ang[8];
           for (int j = 0; j < och[side].n; j++) ang[j] = (double) pos[och[side].row[j]];
@@ -280,19 +311,34 @@ int main(int argc, char **argv)
         double dt3[3], dq[4], cpos[3];
         long prev = 0;
         int cok = 0;
-        float status = po_leg_update_wc((po_leg *) legs[b].data(), utime, ft_[0], fq_[0], ft_[1], fq_[1], fabs(fz[s]), fabs(fz[W + s]), ncl, ncr,
+        float status = po_leg_update_wc((po_leg *) legs[b].data(), js_utime, ft_[0], fq_[0], ft_[1], fq_[1], fabs(fz[s]), fabs(fz[W + s]), ncl, ncr,
                                         &ox[b].vec[9], ox[b].quat, dt3, dq, &prev, cpos, &cok);
         n_status[status < 0 ? 0 : (status < 0.5 ? 1 : 2)]++;
-        if (status < 0) continue;                       // "return NULL" (:243-255)
-        zc[b]--;                                        // :264-268
-        if (zc[b] > 0) { dt3[0] = dt3[1] = dt3[2] = 0; dq[0] = 1; dq[1] = dq[2] = dq[3] = 0; cpos[0] = cpos[1] = cpos[2] = 0; }
-        int idx[6];
-        double z[6], Rd[6], R[36] = { 0 };
-        const int m = po_legodo_create_measurement(omode, r5, cpos, dt3, dq, utime, prev, cok, status, idx, z, Rd);
-        if (m == 6 && omode == 2) n_pos++;
-        for (int i = 0; i < m; i++) R[i * m + i] = Rd[i];
-        po_indexed_update(m, idx, z, R, &ox[b], &oP[b], oll[b], &ox[b], &oP[b], &oll[b]);
+        if (status >= 0) {                              // (else "return NULL", :243-255)
+          zc[b]--;                                      // :264-268
+          if (zc[b] > 0) { dt3[0] = dt3[1] = dt3[2] = 0; dq[0] = 1; dq[1] = dq[2] = dq[3] = 0; cpos[0] = cpos[1] = cpos[2] = 0; }
+          int idx[6];
+          double z[6], Rd[6], R[36] = { 0 };
+          const int m = po_legodo_create_measurement(omode, r5, cpos, dt3, dq, js_utime, prev, cok, status, idx, z, Rd);
+          if (m == 6 && omode == 2) n_pos++;
+          for (int i = 0; i < m; i++) R[i * m + i] = Rd[i];
+          po_indexed_update(m, idx, z, R, &ox[b], &oP[b], oll[b], &ox[b], &oP[b], &oll[b]);
+        }
+        if (pose_tick) {                                // in time order the pose FOLLOWS the leg odometry
+          const int pidx[4] = { 9, 10, 11, 8 };
+          double pz[4] = { ppos[0], ppos[1], ppos[2], 0.0 }, pR[16] = { 0 };
+          pR[0] = pR[5] = pR[10] = 0.05 * 0.05;
+          pR[15] = bot_sq(bot_to_radians(1.0));
+          po_indexed_orient_update(4, pidx, pz, pR, pquat, &ox[b], &oP[b], oll[b], &ox[b], &oP[b], &oll[b]);
+        }
       }
+    }
+    if (late) {   // one more IMU message rolls the last (unapplied) leg odometry forward
+      const int64_t utime = 1000000 + (int64_t) (T + 1) * 2000;
+      const double v[6] = { 0.01, 0.02, -0.01, 0.1, -0.1, g };
+      msgs::ins_t im{ utime, BatchArray(v, PB_HOST_BROADCAST), BatchArray(v + 3, PB_HOST_BROADCAST) };
+      on_ins(&im);
+      for (int b = 0; b < B; b++) po_imu_process_step(v, v + 3, 0.002, q4[0], q4[1], q4[2], q4[3], &ox[b], &oP[b], oll[b], &ox[b], &oP[b], &oll[b]);
     }
     if (device) {
       est.flushPending();  // (a pending pair still reads the blocks)
@@ -316,8 +362,17 @@ int main(int argc, char **argv)
   printf("n=%d mode %s / %s%s%s, joint filter %s: status skip/certain/uncertain %d/%d/%d, position updates %d: rel err vec %.2e quat %.2e cov %.2e ll %.2e (status %d, fused pairs %lld)\n",
          n, lomode.c_str(), cmode.c_str(), fuse ? " fused" : "", bcast ? " bcast" : (device ? " device blocks" : ""), jfilt.c_str(), n_status[0], n_status[1], n_status[2], n_pos, ev / sv, eq, eP / sP,
          el / sl, est.last_status, (long long) est.fused_pairs);
-  const bool fused_ok = !fuse || lomode != "lin_rate" || est.fused_pairs > T / 2;
+  // Every mode must have run its pairs as ONE kernel where the shim can: lin_rate always; the six-row modes whenever the joint block
+  // outlives the handler call (broadcast, device blocks, or the joint filters' device output) -- inside the pair kernel
+  // (leg_kernel_pairs).  The one exception: fuse_corrections holds the finished pair back, its measurement is made at once, and a
+  // six-row measurement made ahead of time is applied by the stand-alone update.
+  const bool six = lomode != "lin_rate";
+  const bool expect_fused = fuse && (!six || (!fuse3 && !late && (bcast || device || jmode != 0)));
+  const bool fused_ok = !expect_fused || (est.fused_pairs > T / 2 && (!six || est.leg_kernel_pairs > T / 2));
+  printf("fused pairs %lld, of them inside the pair kernel %lld (expected to fuse: %s)\n", (long long) est.fused_pairs, (long long) est.leg_kernel_pairs, expect_fused ? "yes" : "no");
   const bool pos_ok = lomode != "pos_and_lin_rate" || n_pos > B * T / 20;
+  if (late) printf("late mode: updates re-applied after late arrivals %lld, dropped %lld\n", (long long) est.replayed_updates, (long long) est.dropped_updates);
+  if (late && (est.replayed_updates < T / 10 || est.dropped_updates != 0)) { printf("FAIL: the late leg odometry did not take the replay path\n"); return 1; }
   const bool ok = n_before_ft == 0 /* no leg odometry before the first F/T message */ && fused_ok && pos_ok && est.last_status == PB_OK && n_status[0] > 100 &&
                   n_status[1] > 50 && n_status[2] > 100 && ev / sv < 1e-8 && eq < 1e-8 && eP / sP < 1e-8 && el / sl < 1e-8;
   printf(ok ? "PASS\n" : "FAIL\n");

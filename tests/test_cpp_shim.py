@@ -168,7 +168,7 @@ def test_legodo_modes_on_gpu(oracle, mode, slots, fuse, n):
 
 @pytest.mark.parametrize("name", ["test_shim", "test_history", "test_atlas_imu", "test_smooth_pass", "test_log_replay",
                                   "test_legodo_modes", "test_fovis_history", "test_fovis_replay",
-                                  "test_handler_modes", "test_leg_feet", "test_leg_joints", "test_segments"])
+                                  "test_handler_modes", "test_leg_feet", "test_leg_joints", "test_segments", "test_host_update"])
 def test_shim_compiles_and_links(oracle, name):
     exe = build_exe(oracle, name)
     out = subprocess.run(["ldd", exe], capture_output=True, text=True).stdout
@@ -278,7 +278,11 @@ def test_shim_sweep_rate_example_runs(n, slots):
                                   # the six-row modes inside the pair kernel (fuse_ins_legodo: SIX, rbis_legstep.hpp)
                                   ("lin_rot_rate", "alt", "fuse", "device", "none"), ("pos_and_lin_rate", "alt", "fuse", "device", "none"),
                                   ("lin_rot_rate", "ctrl", "fuse", "bcast"), ("pos_and_lin_rate", "alt", "fuse", "bcast"),
-                                  ("pos_and_lin_rate", "standing", "fuse", "blocks", "lowpass"), ("pos_and_lin_rate", "alt", "fuse3", "device", "none")])
+                                  ("pos_and_lin_rate", "standing", "fuse", "blocks", "lowpass"), ("pos_and_lin_rate", "alt", "fuse3", "device", "none"),
+                                  # "late": legodo.roll_forward_on_receive = false and every 10th joint state arrives BEHIND a pose that
+                                  # has been applied (replay from the checkpoint, neither applied early nor the pose twice)
+                                  ("lin_rate", "alt", "fuse", "device", "none", "late"), ("lin_rate", "alt", "nofuse", "device", "none", "late"),
+                                  ("pos_and_lin_rate", "alt", "fuse", "bcast", "none", "late")])
 @pytest.mark.parametrize("n", [15, 21])
 def test_joint_state_handler_on_gpu(oracle, args, n):
     """LegOdoHandler::processMessage(joint_state_t) -- the reference's handler signature -- from a synthetic 6-DoF-per-leg gait:
@@ -300,4 +304,19 @@ def test_independent_log_segments_as_one_batch_on_gpu(oracle, tmp_path, n, fuse)
     exe = build_exe(oracle, "test_segments")
     r = subprocess.run([exe, str(tmp_path)] + ([fuse] if fuse == "nofuse" else []) + NARG[n], capture_output=True, text=True, timeout=600)
     print(r.stdout[-3000:], r.stderr[-2000:])
+    assert r.returncode == 0 and "PASS" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [15, 21])
+@pytest.mark.parametrize("variant", [(), ("slots",), ("mask",), ("slots", "mask")])
+def test_user_defined_update_with_the_reference_signature_on_gpu(oracle, n, variant):
+    """RBISHostUpdate: a user-defined update written against the REFERENCE's contract -- updateFilter(const RBIS &prior_state,
+    const RBIM &prior_cov, double prior_loglikelihood), rbis_update_interface.hpp:14-35 -- handed to MavStateEstimator::addUpdate
+    between built-in updates (slow path: pb_get_head -> user code per filter -> pb_set_head).  The user's scalar altimeter update is
+    written from the textbook equations; the expected head is the oracle's po_indexed_update in the same place.  "slots": with
+    posterior checkpoints and one user update that arrives late and is replayed; "mask": applied to every other filter only."""
+    exe = build_exe(oracle, "test_host_update")
+    r = subprocess.run([exe, *variant] + NARG[n], capture_output=True, text=True, timeout=300)
+    print(r.stdout[-2000:], r.stderr[-2000:])
     assert r.returncode == 0 and "PASS" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]

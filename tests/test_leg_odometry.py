@@ -794,6 +794,114 @@ def test_pair_call_against_the_oracle_chain_on_gpu(oracle, n, kind):
 @pytest.mark.gpu
 @pytest.mark.parametrize("n", [15, 21])
 @pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("kind", ["joints_dev", "joints_bcast"])
+def test_pair_call_in_the_six_row_modes_against_the_oracle_chain_on_gpu(oracle, n, mode, kind):
+    """pb_step_legodo_joints in LegOdoCommon's six-row modes (pb_legodo_set_measurement_mode 1 = lin_rot_rate, 2 = pos_and_lin_rate:
+    k_step_leg / k_step_quad_leg<SIX>) DIRECTLY against the oracle chain -- not against the library's own call sequence: per tick
+    po_imu_process_step, then on the ORACLE filter's own pose after that step po_torque_adjust -> po_fk -> po_leg_update_wc (mode 2:
+    with its world constraint) -> po_legodo_create_measurement (rbis_legodo_common.cpp:110-169: six rows, or the three-row
+    fall-back while the constraint is not valid) -> po_indexed_update, the zero_initial_velocity counter per filter.  Masks
+    bit-identical every tick, the measurement block the kernel applied <= 1e-8, the posterior at the end <= 1e-9 (check)."""
+    import torch
+    import legs
+    from pronto_amd import batch as pa
+    from util import embed21
+    B, T, ZERO = 12, 260, 4
+    R_XYZ, R_VANG, R_VANG_U = 0.05, 0.4, 0.9
+    dev = torch.device("cuda:0")
+    L = oracle.lib()
+    chain = legs.chain_arrays(legs.ATLAS_LEFT, legs.ATLAS_RIGHT, legs.ATLAS_ROWS)
+    gain = np.array([7000, 10000, 10000, 10000, 10000, 10000] * 2, dtype=np.float32)
+    w = Workload(B, n_states=n, dt_us=2000)
+    vec, quat, P0 = w.initial_state()
+    v21, P21 = embed21(vec, P0)
+    ob = oracle.OracleBatch(v21, quat, P21)
+    est = pa.BatchEstimator(B, n_states=n)
+    est.set_constants(*oracle.constants())
+    est.reset(vec, quat, P0)
+    est.legodo_init(*SCHMITT, True)
+    est.legodo_set_chain(*chain, gain)
+    est.legodo_set_zero_initial_velocity(ZERO)
+    est.legodo_set_measurement_mode(mode, R_XYZ, R_VANG, R_VANG_U)
+    orc = OracleLegs(oracle, B, True)
+    zc = np.full(B, ZERO)
+    q4 = w.process_noise()
+    lo = torch.zeros((12, B), dtype=torch.float64, device=dev)
+    mk = torch.zeros((B,) if mode == 1 else (2, B), dtype=torch.uint8, device=dev)
+    r, ru = R_VXYZ
+    r5 = np.array([R_XYZ, r, R_VANG, ru, R_VANG_U])
+    bcast = kind.endswith("bcast")
+    W = 1 if bcast else B
+    n_six = n_three = 0
+    seen = set()
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    for k, msg in enumerate(legs.joint_gait(W, T, seed=29)):
+        imu = w.imu_block(k)
+        if bcast:
+            imu = np.ascontiguousarray(np.repeat(imu[:, :1], B, axis=1))
+        imu_in = np.ascontiguousarray(imu[:, 0]) if bcast else torch.from_numpy(imu).to(dev)
+        utime, jp, je, forces, _ = msg
+        a = (np.ascontiguousarray(jp[:, 0]), np.ascontiguousarray(je[:, 0]), np.ascontiguousarray(forces[:, 0])) if bcast else \
+            tuple(torch.from_numpy(x).to(dev) for x in (jp, je, forces))
+        est.step_legodo_joints(imu_in, q4, utime, *a, r, ru, lo, mk)
+        ofeet = legs.oracle_feet(L, chain, jp, je, gain)
+        if bcast:
+            ofeet, forces = np.repeat(ofeet, B, axis=1), np.repeat(forces, B, axis=1)
+        # the oracle chain on the oracle filter's OWN state after its own process step
+        ob.predict(imu, q4)
+        od, os_, op = orc.update(utime, np.ascontiguousarray(ofeet), forces.astype(np.float64), np.ascontiguousarray(ob.quat),
+                                 wpos=np.ascontiguousarray(ob.vec[9:12]))
+        valid = os_ >= 0
+        zc[valid] -= 1                                    # rbis_legodo_update.cpp:264-268, reached for a valid status only
+        zero = valid & (zc > 0)
+        z6, R6 = np.zeros((6, B)), np.ones((6, B))
+        m_of = np.zeros(B, dtype=int)
+        idx6 = None
+        for b in np.nonzero(valid)[0]:
+            dt3, dq, cpos = od[0:3, b].copy(), od[3:7, b].copy(), orc.pos[:, b].copy()
+            if zero[b]:                                   # odo_delta / odo_position set to identity, the status passed on as it is
+                dt3[:] = 0.0
+                dq[:] = (1.0, 0.0, 0.0, 0.0)
+                cpos[:] = 0.0
+            idx = np.zeros(6, dtype=np.int32)
+            z, Rd = np.zeros(6), np.zeros(6)
+            m = L.po_legodo_create_measurement(mode, dp(r5), dp(cpos), dp(dt3), dp(dq), int(utime), int(op[b]), int(orc.pos_ok[b]),
+                                               float(os_[b]), idx.ctypes.data_as(C.POINTER(C.c_int)), dp(z), dp(Rd))
+            m_of[b] = m
+            if m == 6:
+                assert idx6 is None or list(idx) == idx6
+                idx6 = list(idx)
+                z6[:, b], R6[:, b] = z, Rd
+            else:
+                assert mode == 2 and m == 3 and list(idx[:3]) == [3, 4, 5]
+                z6[3:6, b], R6[3:6, b] = z[:3], Rd[:3]
+        six, three = m_of == 6, m_of == 3
+        g_mask, g_lo = mk.cpu().numpy().reshape(-1, B), lo.cpu().numpy()
+        assert np.array_equal(g_mask[0], six.astype(np.uint8)), (k, g_mask[0], six)
+        if mode == 2:
+            assert np.array_equal(g_mask[1], three.astype(np.uint8)), (k, g_mask[1], three)
+        assert np.max(np.abs(g_lo[0:6][:, six] - z6[:, six]), initial=0.0) < 1e-8, k
+        assert np.allclose(g_lo[6:12][:, six], R6[:, six], rtol=1e-13, atol=0), k
+        assert np.max(np.abs(g_lo[3:6][:, three] - z6[3:6][:, three]), initial=0.0) < 1e-8, k
+        assert np.allclose(g_lo[9:12][:, three], R6[3:6][:, three], rtol=1e-13, atol=0), k
+        if six.any():
+            assert idx6 == ([3, 4, 5, 0, 1, 2] if mode == 1 else [9, 10, 11, 3, 4, 5])
+            ob.update_indexed(idx6, np.ascontiguousarray(z6), np.ascontiguousarray(R6), mask=six.astype(np.uint8))
+        if three.any():
+            ob.update_indexed([3, 4, 5], np.ascontiguousarray(z6[3:6]), np.ascontiguousarray(R6[3:6]), mask=three.astype(np.uint8))
+        n_six += int(six.sum())
+        n_three += int(three.sum())
+        seen.update(np.unique(os_).tolist())
+    assert n_six > B * T // 10 and seen == {-1.0, 0.0, 1.0}
+    assert mode == 1 or n_three > 0      # (the world constraint is not valid from the first tick: the fall-back was taken)
+    from test_gpu_parity import check
+    check(est, ob)
+    est.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [15, 21])
+@pytest.mark.parametrize("mode", [1, 2])
 @pytest.mark.parametrize("kind,B", [("joints_dev", 1000), ("joints_bcast", 1000), ("feet_dev", 130), ("joints_dev", 65)])
 def test_one_call_pair_in_the_six_row_modes_on_gpu(n, mode, kind, B):
     """LegOdoCommon's lin_rot_rate / pos_and_lin_rate (pb_legodo_set_measurement_mode 1 / 2) through the pair calls: the IMU step,

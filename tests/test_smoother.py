@@ -1,8 +1,10 @@
 """RTS smoother (rbis.cpp:234-266 + the backward pass of mav_state_est.cpp:98-189): the device
-kernel k_smooth_step on posterior checkpoints against the oracle's dense restatement po_ekf_smoothing_step.
+kernels behind pb_smooth_step -- k_smooth_lane (default: one lane per filter, role waves, unpivoted LDL^T), k_smooth_reg
+(PRONTO_SMOOTH_KERNEL=reg) and its pivoted variant (PRONTO_SMOOTH_PIVOT=1, Eigen's diagonal pivoting like the reference's
+.ldlt()) -- on posterior checkpoints against the oracle's dense restatement po_ekf_smoothing_step.
 
-Tolerance: the step inverts P^-_{k+1} (condition number up to ~1e7 here: variances from 1e-8 to 0.25); both sides use
-LDL^T with the same diagonal pivoting, so they differ by summation order only -- 1e-7 relative is the bound used."""
+Tolerance: TOL = 1e-9 relative (block-wise).  The step inverts P^-_{k+1} (condition number up to ~1e7 here: variances from
+1e-8 to 0.25); observed over 23 backward steps: 2e-15 .. 4e-15 for all three kernels, the worst error is printed."""
 import os
 
 import numpy as np
