@@ -107,6 +107,24 @@ int pb_memcpy_d2h(pb_ctx *ctx, void *host_dst, const void *dev_src, uint64_t byt
 int pb_host_alloc(pb_ctx *ctx, uint64_t bytes, void **host_ptr);
 int pb_host_free(pb_ctx *ctx, void *host_ptr);
 
+/* ---- chunked uploads (bulk replays of recorded logs, segment_stream.hpp) ------------------------------------------------
+ * The reference's LCMFrontEnd::run hands one message at a time to the handlers (lcm_front_end.cpp:223-229); a replay of N recorded
+ * logs as one batch instead moves CHUNKS of pre-decoded messages ([slot][rows][B] blocks in page-locked memory) to HBM on the
+ * context's copy stream while the kernels of the previous chunk run, and the handlers are then given PB_DEVICE messages.
+ *   pb_fence_create / pb_fence_record   a marker on the main stream: "every kernel enqueued so far" (at most 16 per context)
+ *   pb_fence_wait                       the host waits until the marked work has run
+ *   pb_upload_async                     host (pb_host_alloc) -> device on the copy stream; it starts once fence `after_fence` has
+ *                                       been reached (-1: at once) -- the fence recorded behind the last kernel that READ dev_dst
+ *   pb_upload_join                      the main stream waits for every upload issued so far (call it before the first kernel
+ *                                       that reads the uploaded block)
+ *   pb_upload_sync                      the HOST waits for every upload issued so far (the page-locked source may be refilled) */
+int pb_fence_create(pb_ctx *ctx, int *fence_out);
+int pb_fence_record(pb_ctx *ctx, int fence);
+int pb_fence_wait(pb_ctx *ctx, int fence);
+int pb_upload_async(pb_ctx *ctx, void *dev_dst, const void *host_src, uint64_t bytes, int after_fence);
+int pb_upload_join(pb_ctx *ctx);
+int pb_upload_sync(pb_ctx *ctx);
+
 /* ---- update objects (rbis_update_interface.hpp) ----------------------------------------------------- */
 
 /* RBISResetUpdate::updateFilter (rbis_update_interface.cpp:23-28): posterior <- (state, cov), loglik <- 0.
@@ -357,6 +375,29 @@ int pb_imu_notch_init(pb_ctx *ctx, double notch_freq, double fs);
  * the newest filtered sample (what processMessageAtlas feeds to the process step, sensor_handlers.cpp:191-196).
  * accel_out must be device memory when mem == PB_DEVICE, host memory when PB_HOST. */
 int pb_imu_notch(pb_ctx *ctx, int n_packets, const double *accel_packets, double *accel_out, int mem);
+/* The same with a PER-FILTER packet count -- independent log segments: every filter has its own KVH stream and its own
+ * IMUStream de-duplication (imu_stream.cpp:62-98), so a batched message carries a different number of NEW packets per filter.
+ * counts [B] (int32): filter b runs its first min(counts[b], max_packets) packets of accel_packets [max_packets][3][B] (oldest
+ * first) through its cascade; a filter with no new packet keeps its filter state and its accel_out entries are not written
+ * (PB_HOST: they come back as 0) -- the reference returns NULL for such a message (sensor_handlers.cpp:181-187). */
+int pb_imu_notch_counts(pb_ctx *ctx, int max_packets, const int32_t *counts, const double *accel_packets, double *accel_out, int mem);
+
+/* InsHandler's per-message arithmetic for B robots at once, on the device: one robot's IMU sample -> the [7][B] block that
+ * pb_predict / pb_step_legodo* take (gyro xyz | accelerometer xyz | dt, body frame), written to imu_block_out (DEVICE memory).
+ *   Microstrain (InsHandler::processMessage, sensor_handlers.cpp:96-131): gyro [3][B] and accel [3][B] rotated by rot_quat
+ *     (bot_quat_rotate_to), dt = dt_default.  raw_dt = NULL, trans_vec = NULL, dt_from_utimes = 0.
+ *   Atlas KVH (processMessageAtlas, :199-252): gyro holds delta_rotation and is divided by raw_dt [B] (:207-210); accel goes through
+ *     the whole ins_to_body transform (rotation + trans_vec, bot_trans_apply_vec :227); dt_from_utimes = 1: dt = (utime - this
+ *     filter's previous utime) * 1E-6, dt_default on its first message (:239-249).  utimes [B] = every robot's own message time,
+ *     or NULL = `utime` for all.
+ *   valid [B] (or NULL = all): 0 = this filter has NO message (its log segment has ended, or its KVH batch carried no new packet:
+ *     the reference's handler returns NULL) -- its block is its own last sample with dt = 0, a step that leaves state and
+ *     covariance where they are; its previous-utime is not advanced.
+ * mem (of the input arrays): PB_HOST or PB_DEVICE.  pb_ins_body_reset forgets the last samples / previous utimes. */
+int pb_ins_body_block(pb_ctx *ctx, const double *gyro, const double *accel, const double *raw_dt, const int64_t *utimes, int64_t utime,
+                      const uint8_t *valid, const double rot_quat[4], const double trans_vec[3], double dt_default, int dt_from_utimes,
+                      int mem, double *imu_block_out);
+int pb_ins_body_reset(pb_ctx *ctx);
 
 /* ---- posterior checkpoints for roll-forward replay (mav_state_est.cpp:28-80, update_history.cpp) ------------ */
 

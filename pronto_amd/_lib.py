@@ -21,7 +21,7 @@ PB_CORR_POS_ORIENT, PB_CORR_POS_YAW = 0, 1
 
 def sources():
     return [os.path.join(CSRC, f) for f in ("pronto_batch.hip", "pb_step.hip", "pb_update.hip", "pb_update_rt21.hip", "pb_update_ct.hip", "pb_smooth.hip", "pb_ctx.hpp",
-                                            "rbis_kernels.hpp", "rbis_legodo.hpp", "rbis_legstep.hpp", "rbis_jointfilt.hpp", "rbis_coop.hpp", "rbis_quad.hpp", "rbis_quad_rt.hpp", "rbis_smooth.hpp",
+                                            "rbis_kernels.hpp", "rbis_frontend.hpp", "rbis_legodo.hpp", "rbis_legstep.hpp", "rbis_jointfilt.hpp", "rbis_coop.hpp", "rbis_quad.hpp", "rbis_quad_rt.hpp", "rbis_smooth.hpp",
                                             "rbis_device.hpp", "Makefile")] + [HEADER]
 
 
@@ -59,6 +59,16 @@ _SIGS = {
     "pb_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
     "pb_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
     "pb_reset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    "pb_fence_create": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
+    "pb_fence_record": (C.c_int, [C.c_void_p, C.c_int]),
+    "pb_fence_wait": (C.c_int, [C.c_void_p, C.c_int]),
+    "pb_upload_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int]),
+    "pb_upload_join": (C.c_int, [C.c_void_p]),
+    "pb_upload_sync": (C.c_int, [C.c_void_p]),
+    "pb_imu_notch_counts": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "pb_ins_body_block": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, _dp, _dp,
+                                    C.c_double, C.c_int, C.c_int, C.c_void_p]),
+    "pb_ins_body_reset": (C.c_int, [C.c_void_p]),
     "pb_set_head": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "pb_predict": (C.c_int, [C.c_void_p, C.c_void_p, _dp, C.c_int]),
     "pb_update_indexed": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_void_p, C.c_void_p, C.c_int,

@@ -222,6 +222,92 @@ public:
       std::vector<uint8_t> expect;
       void clear() { valid = false; cmps.clear(); ops.clear(); expect.clear(); }
     };
+    // The streaming decoders' entry (segment_stream.hpp): true = `sh` IS the layout of this message -- the cached one, verified
+    // (length, length members, string lengths, wanted strings: a handful of memcmp), or rebuilt the long way (*rebuilt; `out` then
+    // holds the decoded members incl. the wanted strings).  The wanted numbers are then read in place with gather_f64 / _f32 /
+    // _i64 from sh.ops: no value vectors, no conversions through double for float members.
+    bool layout(const void *data, size_t len, Shape &sh, std::vector<Extracted> &out, bool *rebuilt) const
+    {
+      if (rebuilt) *rebuilt = false;
+      if (root_ < 0) return false;
+      if (sh.valid && len == sh.len) {
+        const uint8_t *p = (const uint8_t *) data;
+        bool same = true;
+        for (const Shape::Cmp &c : sh.cmps)
+          if (memcmp(p + c.off, sh.expect.data() + c.at, c.n) != 0) { same = false; break; }
+        if (same) return true;
+      }
+      sh.valid = false;
+      bool same_strings = false;
+      if (!run(data, len, out, sh, &same_strings)) return false;
+      if (rebuilt) *rebuilt = true;
+      return true;
+    }
+    // the numbers of wanted member `slot` of a message whose layout is `sh`, in encoding order; returns how many (at most cap)
+    static size_t gather_f64(const Shape &sh, const void *data, int slot, double *out, size_t cap)
+    {
+      const uint8_t *p = (const uint8_t *) data;
+      size_t n = 0;
+      for (const Shape::Op &o : sh.ops) {
+        if (o.slot != slot) continue;
+        const uint8_t *q = p + o.off;
+        for (uint32_t k = 0; k < o.count && n < cap; k++, n++) {
+          switch ((Kind) o.kind) {
+          case I8: out[n] = (double) (int8_t) q[k]; break;
+          case U8: out[n] = (double) q[k]; break;
+          case I16: out[n] = (double) (int16_t) ((q[2 * k] << 8) | q[2 * k + 1]); break;
+          case I32: { uint32_t u; memcpy(&u, q + 4 * k, 4); out[n] = (double) (int32_t) __builtin_bswap32(u); break; }
+          case I64: { uint64_t u; memcpy(&u, q + 8 * k, 8); out[n] = (double) (int64_t) __builtin_bswap64(u); break; }
+          case F32: { uint32_t u; memcpy(&u, q + 4 * k, 4); u = __builtin_bswap32(u); float x; memcpy(&x, &u, 4); out[n] = x; break; }
+          default: { uint64_t u; memcpy(&u, q + 8 * k, 8); u = __builtin_bswap64(u); memcpy(&out[n], &u, 8); break; }
+          }
+        }
+      }
+      return n;
+    }
+    static size_t gather_f32(const Shape &sh, const void *data, int slot, float *out, size_t cap)
+    {
+      const uint8_t *p = (const uint8_t *) data;
+      size_t n = 0;
+      for (const Shape::Op &o : sh.ops) {
+        if (o.slot != slot) continue;
+        const uint8_t *q = p + o.off;
+        if ((Kind) o.kind == F32) {
+          for (uint32_t k = 0; k < o.count && n < cap; k++, n++) { uint32_t u; memcpy(&u, q + 4 * k, 4); u = __builtin_bswap32(u); memcpy(&out[n], &u, 4); }
+        } else {
+          double v;
+          Shape one = Shape();
+          one.ops.push_back(o);
+          for (uint32_t k = 0; k < o.count && n < cap; k++, n++) {
+            one.ops[0].off = o.off + k * (uint32_t) prim_size((Kind) o.kind);
+            one.ops[0].count = 1;
+            gather_f64(one, data, slot, &v, 1);
+            out[n] = (float) v;
+          }
+        }
+      }
+      return n;
+    }
+    static size_t gather_i64(const Shape &sh, const void *data, int slot, int64_t *out, size_t cap)
+    {
+      const uint8_t *p = (const uint8_t *) data;
+      size_t n = 0;
+      for (const Shape::Op &o : sh.ops) {
+        if (o.slot != slot) continue;
+        const uint8_t *q = p + o.off;
+        for (uint32_t k = 0; k < o.count && n < cap; k++, n++) {
+          switch ((Kind) o.kind) {
+          case I8: out[n] = (int8_t) q[k]; break;
+          case U8: out[n] = q[k]; break;
+          case I16: out[n] = (int16_t) ((q[2 * k] << 8) | q[2 * k + 1]); break;
+          case I32: { uint32_t u; memcpy(&u, q + 4 * k, 4); out[n] = (int32_t) __builtin_bswap32(u); break; }
+          case I64: { uint64_t u; memcpy(&u, q + 8 * k, 8); out[n] = (int64_t) __builtin_bswap64(u); break; }
+          default: { double v; Shape one = Shape(); one.ops.push_back(o); one.ops[0].off = o.off + k * (uint32_t) prim_size((Kind) o.kind); one.ops[0].count = 1; gather_f64(one, data, slot, &v, 1); out[n] = (int64_t) v; break; }
+          }
+        }
+      }
+      return n;
+    }
     // as run(); *same_strings (may be NULL) = the message had the cached shape: out[k].str is then left EMPTY -- the strings are
     // the ones the call that made the shape returned
     bool run(const void *data, size_t len, std::vector<Extracted> &out, Shape &sh, bool *same_strings) const

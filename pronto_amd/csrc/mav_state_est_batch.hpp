@@ -277,6 +277,7 @@ class RBISIMUProcessStep : public RBISUpdateInterface {
 public:
   // gyro xyz | accelerometer xyz | dt as ONE block [7][B] (body frame), owned when built on the host
   std::vector<double> owned;
+  std::shared_ptr<DeviceBlock> owned_dev;  // a block made on the device (InsHandler's device path: pb_ins_body_block)
   BatchArray imu_block;
   double q_gyro, q_accel, q_gyro_bias, q_accel_bias;
   RBISIMUProcessStep(BatchArray imu_block_, double q_gyro_, double q_accel_, double q_gyro_bias_, double q_accel_bias_,
@@ -1066,8 +1067,9 @@ struct ins_t {               // bot_core::ins_t
   int64_t utime;
   BatchArray gyro, accel;    // [3][B] each, sensor frame
   BatchArray mag;            // [3][B] magnetometer, sensor frame; optional (p == NULL: zeros, like the Atlas path :274)
-  const uint8_t *valid = nullptr;  // [B] HOST, PB_HOST messages only (independent log segments, SegmentBatcher): 0 = this filter has
-                                   // no message -- its segment has ended -- and idles: its step is taken with dt = 0
+  const uint8_t *valid = nullptr;  // [B], in the memory space of gyro / accel (independent log segments, SegmentBatcher /
+                                   // SegmentStreamer): 0 = this filter has no message -- its segment has ended -- and idles: its
+                                   // step is taken with dt = 0
 };
 struct kvh_raw_imu_t {       // the newest packet of bot_core::kvh_raw_imu_batch_t (atlas_filter == false path)
   int64_t utime;
@@ -1099,6 +1101,7 @@ struct joint_state_t {       // bot_core::joint_state_t: the arrays are float on
   // segment has ended has no message at all: valid [B], HOST, 0 = none.  NULL = one time for all / all valid.
   const int64_t *utimes = nullptr;
   const uint8_t *valid = nullptr;
+  int times_mem = PB_HOST;                  // where utimes / valid live: PB_HOST, or PB_DEVICE (chunked replays: read in place)
 };
 struct six_axis_force_torque_array_t {   // bot_core::six_axis_force_torque_array_t: what the leg odometry reads of it
   int64_t utime;
@@ -1141,6 +1144,20 @@ struct kvh_raw_imu_batch_t {   // bot_core::kvh_raw_imu_batch_t: raw_imu[0] is t
   int64_t utime;
   std::vector<kvh_raw_imu_packet_t> raw_imu;
   int mem = PB_HOST;           // PB_HOST_BROADCAST: the packets' arrays are [3], one robot's IMU for every filter
+};
+// B DIFFERENT robots' kvh_raw_imu_batch_t messages as one batched message (independent log segments): every robot's message has
+// been through ITS OWN IMUStream::convertFromLCMBatch (imu_stream.cpp:62-98) where it was decoded, and what is left of it is
+// what InsHandler::processMessageAtlas reads (sensor_handlers.cpp:173-204).  All arrays live in `mem` (PB_HOST or PB_DEVICE).
+struct kvh_raw_imu_segments_t {
+  int64_t utime;                 // batch-level time (orders the update in the history)
+  int max_new = 0;               // rows of new_accel: the most new packets any filter can have in one message
+  const int32_t *n_new = nullptr;         // [B] new packets of filter b; 0 = "no new IMU packets": no update for it (:181-187)
+  const uint8_t *valid = nullptr;         // [B] n_new[b] > 0 and the filter has a message at all
+  const double *new_accel = nullptr;      // [max_new][3][B] linear_acceleration of the new packets, oldest first
+  const double *delta_rotation = nullptr; // [3][B] of the newest new packet
+  const double *raw_dt = nullptr;         // [B] that packet's utime_delta * 1E-6 (atlas_filter), or (raw_imu[0].utime - raw_imu[1].utime) * 1E-6
+  const int64_t *utimes = nullptr;        // [B] every robot's own message utime
+  int mem = PB_HOST;
 };
 }  // namespace msgs
 
@@ -1356,7 +1373,53 @@ public:
   // Microstrain path (sensor_handlers.cpp:96-131): rotate accel and gyro into the body frame, dt = param
   RBISUpdateInterface *processMessage(const msgs::ins_t *msg, MavStateEstimator *est)
   {
+    if (msg->gyro.mem == PB_DEVICE && msg->accel.mem == PB_DEVICE)   // per-filter samples already in HBM: the frame rotation runs there
+      return buildOnDevice(est, msg->gyro.p, msg->accel.p, nullptr, nullptr, msg->utime, msg->valid, false, PB_DEVICE);
     return build(msg->gyro, msg->accel, 1.0, false, dt, msg->utime, est->B, msg->valid);
+  }
+  // Atlas KVH path for B DIFFERENT robots (independent log segments): the de-duplication ran per robot where the messages were
+  // decoded (msgs::kvh_raw_imu_segments_t); here the notch cascade of every filter takes ITS new packets (pb_imu_notch_counts), and
+  // the newest filtered packet becomes the process step with the filter's own raw_dt and its own message-time dt
+  // (sensor_handlers.cpp:173-252).  A filter without a new packet -- the reference returns NULL for its message -- idles (dt = 0).
+  // Returns NULL when the message carries nothing at all (max_new == 0).
+  RBISUpdateInterface *processMessageAtlasSegments(const msgs::kvh_raw_imu_segments_t *msg, MavStateEstimator *est)
+  {
+    if ((msg->mem != PB_HOST && msg->mem != PB_DEVICE) || msg->max_new < 1 || !msg->new_accel || !msg->delta_rotation || !msg->raw_dt) return nullptr;
+    const size_t B = (size_t) est->B;
+    const double *accel = msg->new_accel;   // atlas_filter == false: row 0 is the newest packet, unfiltered (:199-204)
+    if (atlas_filter) {
+      if (!notch_initialised) {
+        if (pb_imu_notch_init(est->ctx, notch_freq, 1000) != PB_OK) {  // fs = 1000 (:32)
+          fprintf(stderr, "InsHandler: %s\n", pb_last_error(est->ctx));
+          exit(1);
+        }
+        notch_initialised = true;
+      }
+      if (msg->n_new == nullptr) return nullptr;
+      if (msg->mem == PB_DEVICE) {
+        if (notch_out_dev_ == nullptr) {
+          void *d = nullptr;
+          if (pb_malloc(est->ctx, sizeof(double) * 3 * B, &d) != PB_OK) {
+            fprintf(stderr, "InsHandler: %s\n", pb_last_error(est->ctx));
+            exit(1);
+          }
+          notch_out_dev_ = std::make_shared<DeviceBlock>(std::make_shared<DevicePool>(est->ctx, est->ctx_alive, sizeof(double) * 3 * B), d);
+        }
+        accel = (const double *) notch_out_dev_->p;
+        if (pb_imu_notch_counts(est->ctx, msg->max_new, msg->n_new, msg->new_accel, (double *) notch_out_dev_->p, PB_DEVICE) != PB_OK) {
+          fprintf(stderr, "InsHandler: %s\n", pb_last_error(est->ctx));
+          return nullptr;
+        }
+      } else {
+        notch_out_host_.resize(3 * B);
+        if (pb_imu_notch_counts(est->ctx, msg->max_new, msg->n_new, msg->new_accel, notch_out_host_.data(), PB_HOST) != PB_OK) {
+          fprintf(stderr, "InsHandler: %s\n", pb_last_error(est->ctx));
+          return nullptr;
+        }
+        accel = notch_out_host_.data();
+      }
+    }
+    return buildOnDevice(est, msg->delta_rotation, accel, msg->raw_dt, msg->utimes, msg->utime, msg->valid, true, msg->mem);
   }
   // Atlas KVH path without the notch (sensor_handlers.cpp:199-252): gyro = delta_rotation/raw_dt, accel through the
   // full ins_to_body transform (rotation + translation, :227), dt from message timestamps (:239-249)
@@ -1493,6 +1556,29 @@ public:
 private:
   BotParam *param_ = nullptr;
   bool init_params_read_ = false;
+  std::shared_ptr<DevicePool> ins_pool_;         // [7][B] process-step blocks made on the device
+  std::shared_ptr<DeviceBlock> notch_out_dev_;   // [3][B] newest filtered packet (stream order: read by the step made from it)
+  std::vector<double> notch_out_host_;
+  // The per-sample arithmetic of processMessage / processMessageAtlas for B robots on the device (pb_ins_body_block): the update
+  // owns the [7][B] block it is given.  atlas: gyro holds delta_rotation (divided by raw_dt), the acceleration is translated too,
+  // dt comes from every filter's own message times.
+  RBISUpdateInterface *buildOnDevice(MavStateEstimator *est, const double *gyro, const double *accel, const double *raw_dt, const int64_t *utimes,
+                                     int64_t utime, const uint8_t *valid, bool atlas, int mem)
+  {
+    if (!ins_pool_) ins_pool_ = std::make_shared<DevicePool>(est->ctx, est->ctx_alive, sizeof(double) * 7 * (size_t) est->B);
+    bool fresh = false;
+    void *blk = ins_pool_->get(fresh);
+    if (blk == nullptr ||
+        pb_ins_body_block(est->ctx, gyro, accel, raw_dt, utimes, utime, valid, ins_to_body.rot_quat, atlas ? ins_to_body.trans_vec : nullptr, dt,
+                          atlas ? 1 : 0, mem, (double *) blk) != PB_OK) {
+      fprintf(stderr, "InsHandler: %s\n", pb_last_error(est->ctx));
+      if (blk) ins_pool_->free_.push_back(blk);
+      return nullptr;
+    }
+    auto *u = new RBISIMUProcessStep(BatchArray((const double *) blk, PB_DEVICE), cov_gyro, cov_accel, cov_gyro_bias, cov_accel_bias, utime);
+    u->owned_dev = std::make_shared<DeviceBlock>(ins_pool_, blk);
+    return u;
+  }
   // valid [B] (per-filter host messages only): a filter without a message takes its step with dt = 0 -- with the sample it was
   // handed (its own last one) that leaves its state and covariance where they are
   RBISUpdateInterface *build(BatchArray gyro, BatchArray accel, double gyro_scale, bool accel_translate, double dt_,
@@ -1525,7 +1611,7 @@ private:
         blk[(size_t) i * B + b] = gb[i];
         blk[(size_t) (3 + i) * B + b] = ab[i];
       }
-      blk[(size_t) 6 * B + b] = (valid != nullptr && mem == PB_HOST && !valid[b]) ? 0.0 : dt_;
+      blk[(size_t) 6 * B + b] = (valid != nullptr && mem == PB_HOST && !valid[b]) ? -0.0 : dt_;   // negative zero: "no message", a no-op
     }
     return new RBISIMUProcessStep(std::move(blk), cov_gyro, cov_accel, cov_gyro_bias, cov_accel_bias, utime, mem);
   }
@@ -1959,9 +2045,12 @@ public:
     std::shared_ptr<DeviceBlock> forces_dev; // the foot forces of a host force/torque message uploaded next to a device joint block
     std::vector<int64_t> own_ut;             // per-filter message times / validity (independent log segments), copied: the odometry
     std::vector<uint8_t> own_valid;          // may run after the handler has returned
+    const int64_t *dev_ut = nullptr;         // ... or device arrays, referenced like every PB_DEVICE input (valid until the update
+    const uint8_t *dev_valid = nullptr;      // made from this message has been applied)
     double r = 0, ru = 0;
     int times(pb_ctx *ctx) const
     {
+      if (dev_ut != nullptr || dev_valid != nullptr) return pb_legodo_set_message_times(ctx, dev_ut, dev_valid, PB_DEVICE);
       if (own_ut.empty() && own_valid.empty()) return PB_OK;
       return pb_legodo_set_message_times(ctx, own_ut.empty() ? nullptr : own_ut.data(), own_valid.empty() ? nullptr : own_valid.data(), PB_HOST);
     }
@@ -2120,8 +2209,13 @@ public:
     lm->mem = msg->mem;
     lm->rows = (int) msg->joint_name.size();
     lm->utime = msg->utime;
-    if (msg->utimes != nullptr) lm->own_ut.assign(msg->utimes, msg->utimes + est->B);
-    if (msg->valid != nullptr) lm->own_valid.assign(msg->valid, msg->valid + est->B);
+    if (msg->times_mem == PB_DEVICE) {
+      lm->dev_ut = msg->utimes;
+      lm->dev_valid = msg->valid;
+    } else {
+      if (msg->utimes != nullptr) lm->own_ut.assign(msg->utimes, msg->utimes + est->B);
+      if (msg->valid != nullptr) lm->own_valid.assign(msg->valid, msg->valid + est->B);
+    }
     if (msg->utimes != nullptr && filter_joint_positions_ == 2) {
       fprintf(stderr, "LegOdoHandler: per-filter message times with filter_joint_positions = kalman are not supported (the joint Kalman filters keep one clock per batch)\n");
       return nullptr;

@@ -18,6 +18,8 @@
 
 using namespace pb;
 
+#define PB_MAX_FENCES 16
+
 struct pb_ctx {
   int ns = 0, B = 0, dev = 0, nsnap = 0, nc = 0;  // nc: canonical components (Lay<NS>::NC)
   long stride = 0;      // batch rounded up to whole 64-filter tiles
@@ -58,6 +60,13 @@ struct pb_ctx {
   double *notch = nullptr;  // IMU notch cascade state [36][stride] (pb_imu_notch_init)
   NotchCoef notch_coef;
   bool notch_ready = false;
+  // IMU front end per filter (pb_ins_body_block, rbis_frontend.hpp): last body-frame sample [6][stride], previous message time [stride]
+  double *ins_last = nullptr;
+  int64_t *ins_prev_ut = nullptr;
+  // chunked uploads (pb_upload_async): fences recorded on the main stream, one event for "the uploads issued so far"
+  hipEvent_t fence[PB_MAX_FENCES] = {};
+  int n_fences = 0;
+  hipEvent_t ev_upload = nullptr;
   void *stage = nullptr;
   size_t stage_bytes = 0;
   // PB_HOST inputs: two staging buffers filled on a copy stream, so that the copy of message k+1 overlaps the kernels

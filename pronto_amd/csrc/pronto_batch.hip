@@ -4,6 +4,7 @@
 #include <new>
 
 #include "pb_ctx.hpp"
+#include "rbis_frontend.hpp"
 
 #define PB_VERSION_STR "pronto_batch 0.3 gfx950"
 
@@ -114,6 +115,11 @@ extern "C" int pb_destroy(pb_ctx *c)
   if (c->snaps) (void) hipFree(c->snaps);
   if (c->hist) (void) hipFree(c->hist);
   if (c->notch) (void) hipFree(c->notch);
+  if (c->ins_last) (void) hipFree(c->ins_last);
+  if (c->ins_prev_ut) (void) hipFree(c->ins_prev_ut);
+  for (int i = 0; i < c->n_fences; i++)
+    if (c->fence[i]) (void) hipEventDestroy(c->fence[i]);
+  if (c->ev_upload) (void) hipEventDestroy(c->ev_upload);
   if (c->legd) (void) hipFree(c->legd);
   if (c->legi) (void) hipFree(c->legi);
   if (c->leg_chain) (void) hipFree(c->leg_chain);
@@ -228,6 +234,59 @@ extern "C" int pb_host_free(pb_ctx *c, void *host_ptr)
 {
   if (!c) return PB_ERR_ARG;
   if (host_ptr) HIPCHK(c, hipHostFree(host_ptr));
+  return PB_OK;
+}
+
+// ---- chunked uploads: a block of pre-staged inputs goes to HBM on the copy stream while the kernels of the previous block run ----
+extern "C" int pb_fence_create(pb_ctx *c, int *fence_out)
+{
+  if (!c || !fence_out) return PB_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->dev));
+  if (c->n_fences >= PB_MAX_FENCES) return fail(c, PB_ERR_STATE, "pb_fence_create: at most %d fences per context", PB_MAX_FENCES);
+  HIPCHK(c, hipEventCreateWithFlags(&c->fence[c->n_fences], hipEventDisableTiming));
+  HIPCHK(c, hipEventRecord(c->fence[c->n_fences], c->stream));   // (a fence that was never recorded would not be waitable)
+  *fence_out = c->n_fences++;
+  return PB_OK;
+}
+extern "C" int pb_fence_record(pb_ctx *c, int fence)
+{
+  if (!c) return PB_ERR_ARG;
+  if (fence < 0 || fence >= c->n_fences) return fail(c, PB_ERR_ARG, "pb_fence_record: no fence %d", fence);
+  HIPCHK(c, hipSetDevice(c->dev));
+  HIPCHK(c, hipEventRecord(c->fence[fence], c->stream));
+  return PB_OK;
+}
+extern "C" int pb_fence_wait(pb_ctx *c, int fence)
+{
+  if (!c) return PB_ERR_ARG;
+  if (fence < 0 || fence >= c->n_fences) return fail(c, PB_ERR_ARG, "pb_fence_wait: no fence %d", fence);
+  HIPCHK(c, hipSetDevice(c->dev));
+  HIPCHK(c, hipEventSynchronize(c->fence[fence]));
+  return PB_OK;
+}
+extern "C" int pb_upload_async(pb_ctx *c, void *d, const void *h, uint64_t bytes, int after_fence)
+{
+  if (!c || (!d && bytes) || (!h && bytes)) return PB_ERR_ARG;
+  if (after_fence >= c->n_fences) return fail(c, PB_ERR_ARG, "pb_upload_async: no fence %d", after_fence);
+  HIPCHK(c, hipSetDevice(c->dev));
+  if (after_fence >= 0) HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->fence[after_fence], 0));
+  if (bytes) HIPCHK(c, hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, c->copy_stream));
+  return PB_OK;
+}
+extern "C" int pb_upload_join(pb_ctx *c)
+{
+  if (!c) return PB_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->dev));
+  if (!c->ev_upload) HIPCHK(c, hipEventCreateWithFlags(&c->ev_upload, hipEventDisableTiming));
+  HIPCHK(c, hipEventRecord(c->ev_upload, c->copy_stream));
+  HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_upload, 0));
+  return PB_OK;
+}
+extern "C" int pb_upload_sync(pb_ctx *c)
+{
+  if (!c) return PB_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->dev));
+  HIPCHK(c, hipStreamSynchronize(c->copy_stream));
   return PB_OK;
 }
 
@@ -1501,32 +1560,90 @@ extern "C" int pb_imu_notch_init(pb_ctx *c, double notch_freq, double fs)
   return PB_OK;
 }
 
-extern "C" int pb_imu_notch(pb_ctx *c, int n_packets, const double *accel_packets, double *accel_out, int mem)
+static int imu_notch_impl(pb_ctx *c, const char *who, int n_packets, const int32_t *counts, const double *accel_packets, double *accel_out, int mem)
 {
   ENTER(c);
-  if (!c->notch_ready) return fail(c, PB_ERR_STATE, "pb_imu_notch before pb_imu_notch_init");
-  if (n_packets < 0 || (n_packets > 0 && (!accel_packets || !accel_out))) return fail(c, PB_ERR_ARG, "pb_imu_notch: bad argument");
+  if (!c->notch_ready) return fail(c, PB_ERR_STATE, "%s before pb_imu_notch_init", who);
+  if (n_packets < 0 || (n_packets > 0 && (!accel_packets || !accel_out))) return fail(c, PB_ERR_ARG, "%s: bad argument", who);
   if (n_packets == 0) return PB_OK;
   const size_t B = (size_t) c->B;
-  Part p[2] = { { accel_packets, sizeof(double) * 3 * B * n_packets, 0 }, { nullptr, sizeof(double) * 3 * B, 0 } };
+  const size_t pk_bytes = sizeof(double) * 3 * B * n_packets, pk_pad = (pk_bytes + 255) / 256 * 256;
+  const size_t cn_bytes = counts ? sizeof(int32_t) * B : 0, cn_pad = (cn_bytes + 255) / 256 * 256;
+  const double *d_in = accel_packets;
+  const int32_t *d_counts = counts;
   double *d_out = accel_out;
   if (mem == PB_HOST) {
-    int rc = stage_reserve(c, (p[0].bytes + 255) / 256 * 256 + p[1].bytes);
+    int rc = stage_reserve(c, pk_pad + cn_pad + sizeof(double) * 3 * B);
     if (rc) return rc;
-    HIPCHK(c, hipMemcpyAsync(c->stage, accel_packets, p[0].bytes, hipMemcpyHostToDevice, c->stream));
-    p[0].dev = c->stage;
-    d_out = (double *) ((char *) c->stage + (p[0].bytes + 255) / 256 * 256);
-  } else if (mem == PB_DEVICE) {
-    p[0].dev = accel_packets;
-  } else {
+    HIPCHK(c, hipMemcpyAsync(c->stage, accel_packets, pk_bytes, hipMemcpyHostToDevice, c->stream));
+    d_in = (const double *) c->stage;
+    if (counts) {
+      HIPCHK(c, hipMemcpyAsync((char *) c->stage + pk_pad, counts, cn_bytes, hipMemcpyHostToDevice, c->stream));
+      d_counts = (const int32_t *) ((char *) c->stage + pk_pad);
+    }
+    d_out = (double *) ((char *) c->stage + pk_pad + cn_pad);
+    if (counts) HIPCHK(c, hipMemsetAsync(d_out, 0, sizeof(double) * 3 * B, c->stream));   // (filters without a packet: a defined 0 comes back)
+  } else if (mem != PB_DEVICE) {
     return fail(c, PB_ERR_ARG, "mem must be PB_HOST or PB_DEVICE");
   }
-  k_notch<<<dim3((unsigned) nblk(c->B), 3u), 64, 0, c->stream>>>(c->notch, c->stride, c->B, n_packets, (const double *) p[0].dev, d_out, c->notch_coef);
+  k_notch_counts<<<dim3((unsigned) nblk(c->B), 3u), 64, 0, c->stream>>>(c->notch, c->stride, c->B, n_packets, d_counts, d_in, d_out, c->notch_coef);
   LAUNCHCHK(c);
   if (mem == PB_HOST) {
     HIPCHK(c, hipMemcpyAsync(accel_out, d_out, sizeof(double) * 3 * B, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
   }
+  return PB_OK;
+}
+
+extern "C" int pb_imu_notch(pb_ctx *c, int n_packets, const double *accel_packets, double *accel_out, int mem)
+{
+  return imu_notch_impl(c, "pb_imu_notch", n_packets, nullptr, accel_packets, accel_out, mem);
+}
+
+extern "C" int pb_imu_notch_counts(pb_ctx *c, int max_packets, const int32_t *counts, const double *accel_packets, double *accel_out, int mem)
+{
+  if (c && !counts) return fail(c, PB_ERR_ARG, "pb_imu_notch_counts: NULL counts");
+  return imu_notch_impl(c, "pb_imu_notch_counts", max_packets, counts, accel_packets, accel_out, mem);
+}
+
+extern "C" int pb_ins_body_reset(pb_ctx *c)
+{
+  ENTER(c);
+  if (!c->ins_last) {
+    HIPCHK(c, hipMalloc((void **) &c->ins_last, sizeof(double) * 6 * (size_t) c->stride));
+    HIPCHK(c, hipMalloc((void **) &c->ins_prev_ut, sizeof(int64_t) * (size_t) c->stride));
+  }
+  HIPCHK(c, hipMemsetAsync(c->ins_last, 0, sizeof(double) * 6 * (size_t) c->stride, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->ins_prev_ut, 0, sizeof(int64_t) * (size_t) c->stride, c->stream));
+  return PB_OK;
+}
+
+extern "C" int pb_ins_body_block(pb_ctx *c, const double *gyro, const double *accel, const double *raw_dt, const int64_t *utimes, int64_t utime,
+                                 const uint8_t *valid, const double rot_quat[4], const double trans_vec[3], double dt_default, int dt_from_utimes,
+                                 int mem, double *imu_block_out)
+{
+  ENTER(c);
+  if (!gyro || !accel || !rot_quat || !imu_block_out) return fail(c, PB_ERR_ARG, "pb_ins_body_block: NULL argument");
+  if (mem != PB_HOST && mem != PB_DEVICE) return fail(c, PB_ERR_ARG, "pb_ins_body_block: mem must be PB_HOST or PB_DEVICE");
+  if (!c->ins_last) {
+    int rc = pb_ins_body_reset(c);
+    if (rc) return rc;
+  }
+  const size_t B = (size_t) c->B;
+  Part p[5] = { { gyro, sizeof(double) * 3 * B, 0 }, { accel, sizeof(double) * 3 * B, 0 }, { raw_dt, raw_dt ? sizeof(double) * B : 0, 0 },
+                { utimes, utimes ? sizeof(int64_t) * B : 0, 0 }, { valid, valid ? B : 0, 0 } };
+  int rc = stage_in(c, mem, p, 5);
+  if (rc) return rc;
+  InsFrame f;
+  for (int i = 0; i < 4; i++) f.rot[i] = rot_quat[i];
+  for (int i = 0; i < 3; i++) f.trans[i] = trans_vec ? trans_vec[i] : 0.0;
+  f.translate = trans_vec != nullptr;
+  f.dt_from_utimes = dt_from_utimes ? 1 : 0;
+  f.dt_default = dt_default;
+  k_ins_body<<<(unsigned) ((c->B + 255) / 256), 256, 0, c->stream>>>(c->B, c->stride, (const double *) p[0].dev, (const double *) p[1].dev,
+                                                                      (const double *) p[2].dev, (const int64_t *) p[3].dev, utime,
+                                                                      (const uint8_t *) p[4].dev, f, c->ins_last, c->ins_prev_ut, imu_block_out);
+  LAUNCHCHK(c);
   return PB_OK;
 }
 

@@ -1141,51 +1141,7 @@ __global__ void k_window_nll(const double *__restrict__ st, int B, IdxArg<M> idx
 struct NotchCoef {
   double b[3][3], a[3][3];  // [stage][tap]
 };
-// One lane per (filter, axis): blockIdx.y is the axis -- three times the waves of a lane-per-filter mapping, which this
-// short, latency-bound kernel needs (rocprof: 14.6 us -> see DESIGN.md 6 for the lane-per-filter version it replaced).
-static __global__ void k_notch(double *__restrict__ nst, long stride, int B, int n_packets, const double *__restrict__ acc_in,
-                        double *__restrict__ acc_out, NotchCoef k)
-{
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  const int ax = blockIdx.y;
-  if (b >= B) return;
-  double s[3][4];
-#pragma unroll
-  for (int i = 0; i < 3; i++)
-#pragma unroll
-    for (int t = 0; t < 4; t++) s[i][t] = nst[(long) ((ax * 3 + i) * 4 + t) * stride + b];
-  double v = 0.0;
-  // packets four at a time, all four requested before the first is filtered: with one load per trip of the loop every packet's
-  // memory latency came on top of the one before (three packets per message: three round trips in a kernel that is one)
-  for (int p0 = 0; p0 < n_packets; p0 += 4) {
-    double pk[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const int p = (p0 + j < n_packets) ? p0 + j : n_packets - 1;
-      pk[j] = acc_in[((long) p * 3 + ax) * B + b];
-    }
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      if (p0 + j >= n_packets) break;
-      v = pk[j];
-#pragma unroll
-      for (int i = 0; i < 3; i++) {
-        const double in = v;
-        const double xb = in * k.b[i][0] + s[i][0] * k.b[i][1] + s[i][1] * k.b[i][2];
-        const double ya = s[i][2] * k.a[i][1] + s[i][3] * k.a[i][2];
-        const double out = xb - ya;
-        s[i][1] = s[i][0]; s[i][0] = in;
-        s[i][3] = s[i][2]; s[i][2] = out;
-        v = out;
-      }
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < 3; i++)
-#pragma unroll
-    for (int t = 0; t < 4; t++) nst[(long) ((ax * 3 + i) * 4 + t) * stride + b] = s[i][t];
-  if (n_packets > 0) acc_out[(long) ax * B + b] = v;
-}
+// (the cascade kernel itself is k_notch_counts, rbis_frontend.hpp: one lane per (filter, axis), an optional per-filter packet count)
 
 // Counter calibration: a plain copy with EXACTLY the access pattern of the step kernels (buffer_load/store_dwordx4,
 // 16 bytes per lane, one tile per wave, all loads of a chunk before its stores), so that rocprofv3's FETCH_SIZE /

@@ -40,24 +40,38 @@ public:
     posterior_covariance = prior_cov;
     for (int a = 0; a < n; a++)
       for (int b = 0; b < n; b++) posterior_covariance(a, b, 0) = prior_cov(a, b, 0) - K[(size_t) a] * prior_cov(i, b, 0);
-    double chi[3] = { 0, 0, 0 };
-    for (int a = 0; a < n; a++) {
-      const double dx = K[(size_t) a] * r;
-      if (a >= RBIS::chi_ind && a < RBIS::chi_ind + 3) chi[a - RBIS::chi_ind] = dx;   // the attitude part of the delta is a rotation vector
-      else posterior_state(a, 0) += dx;
+    // dstate = RBIS(K * residual): a state whose attitude part is folded into its OWN quaternion when it exceeds the tolerance
+    // (RigidBodyState(vec) -> chiToQuat); posterior = prior.addState(dstate): vec += dstate.vec, chiToQuat() on what is in chi then
+    // (normally nothing), quat *= dstate.quat  (rbis.cpp:219-227, rbis.hpp's constructors)
+    auto expq = [](const double c[3], double d[4]) {
+      const double ang = sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]), sn = sin(0.5 * ang) / ang;
+      d[0] = cos(0.5 * ang); d[1] = sn * c[0]; d[2] = sn * c[1]; d[3] = sn * c[2];
+    };
+    auto mulq = [](const double q[4], const double d[4], double o[4]) {
+      o[0] = q[0] * d[0] - q[1] * d[1] - q[2] * d[2] - q[3] * d[3];
+      o[1] = q[0] * d[1] + q[1] * d[0] + q[2] * d[3] - q[3] * d[2];
+      o[2] = q[0] * d[2] - q[1] * d[3] + q[2] * d[0] + q[3] * d[1];
+      o[3] = q[0] * d[3] + q[1] * d[2] - q[2] * d[1] + q[3] * d[0];
+    };
+    std::vector<double> d((size_t) n);
+    for (int a = 0; a < n; a++) d[(size_t) a] = K[(size_t) a] * r;
+    double dq[4] = { 1, 0, 0, 0 }, dchi[3] = { d[6], d[7], d[8] };
+    if (sqrt(dchi[0] * dchi[0] + dchi[1] * dchi[1] + dchi[2] * dchi[2]) > 1e-6) {
+      expq(dchi, dq);
+      d[6] = d[7] = d[8] = 0.0;
     }
-    const double ang = sqrt(chi[0] * chi[0] + chi[1] * chi[1] + chi[2] * chi[2]);
-    if (ang > 1e-6) {   // quat <- quat * exp(chi)   (RigidBodyState::chiToQuat)
-      const double s = sin(0.5 * ang) / ang, c = cos(0.5 * ang);
-      const double d[4] = { c, s * chi[0], s * chi[1], s * chi[2] };
-      const double q[4] = { prior_state.q(0, 0), prior_state.q(1, 0), prior_state.q(2, 0), prior_state.q(3, 0) };
-      posterior_state.q(0, 0) = q[0] * d[0] - q[1] * d[1] - q[2] * d[2] - q[3] * d[3];
-      posterior_state.q(1, 0) = q[0] * d[1] + q[1] * d[0] + q[2] * d[3] - q[3] * d[2];
-      posterior_state.q(2, 0) = q[0] * d[2] - q[1] * d[3] + q[2] * d[0] + q[3] * d[1];
-      posterior_state.q(3, 0) = q[0] * d[3] + q[1] * d[2] - q[2] * d[1] + q[3] * d[0];
-    } else {
-      for (int k = 0; k < 3; k++) posterior_state(RBIS::chi_ind + k, 0) += chi[k];
+    for (int a = 0; a < n; a++) posterior_state(a, 0) += d[(size_t) a];
+    double q[4] = { prior_state.q(0, 0), prior_state.q(1, 0), prior_state.q(2, 0), prior_state.q(3, 0) }, o[4];
+    double chi[3] = { posterior_state(6, 0), posterior_state(7, 0), posterior_state(8, 0) };
+    if (sqrt(chi[0] * chi[0] + chi[1] * chi[1] + chi[2] * chi[2]) > 1e-6) {
+      double e[4];
+      expq(chi, e);
+      mulq(q, e, o);
+      memcpy(q, o, sizeof q);
+      for (int k = 0; k < 3; k++) posterior_state(RBIS::chi_ind + k, 0) = 0.0;
     }
+    mulq(q, dq, o);
+    for (int k = 0; k < 4; k++) posterior_state.q(k, 0) = o[k];
     loglikelihood = prior_loglikelihood - log(S) - r * r / S;
   }
 };

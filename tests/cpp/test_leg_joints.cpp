@@ -59,11 +59,14 @@ static const char *URDF = R"(<?xml version="1.0"?>
 int main(int argc, char **argv)
 {
   const int n = take_n_states(argc, argv);
-  // "late" anywhere: legodo.roll_forward_on_receive = false, posterior checkpoints on, the joint state stamped 300 us behind its IMU
-  // sample, and on every 10th tick a scan-match pose stamped 400 us behind it that is delivered -- and rolled forward -- BEFORE the
-  // joint state: the leg odometry then arrives in front of an update that has been applied, without roll_forward (the
-  // estimator must neither apply it on top of the pose nor apply the pose twice; it replays from the checkpoint).  On the other
-  // ticks the joint state is simply left unapplied until the next IMU message rolls forward.
+  // "late" anywhere: legodo.roll_forward_on_receive = false and posterior checkpoints on.  On ordinary ticks the joint state is
+  // stamped 300 us behind its IMU sample and simply stays unapplied until the next IMU message rolls forward.  On every 10th tick
+  // the messages arrive OUT OF ORDER: a scan-match pose stamped 200 us BEFORE the IMU sample is delivered and applied first, then
+  // the IMU sample (held back by fuse_ins_legodo), then the joint state, stamped 300 us before the IMU sample -- older than the
+  // held INS step AND older than an update that has been applied, without roll_forward, and (with device / broadcast joint blocks
+  // under "fuse") with its odometry still deferred.  ADVICE r04: the estimator must neither apply it on top of the head nor apply
+  // the pose twice; it restores the checkpoint in front of it, makes the odometry from THAT state and replays.  The oracle runs the
+  // same messages in time order.
   bool late = false;
   {
     int w = 1;
@@ -213,8 +216,14 @@ int main(int argc, char **argv)
       const double t = (k + 1) * 0.002;
       const double v[6] = { 0.2 * sin(0.05 * k), 0.05, -0.1 * cos(0.03 * k), 0.3 * nrand(), 0.3 * nrand(), g + 0.3 * nrand() };
       msgs::ins_t im{ utime, BatchArray(v, PB_HOST_BROADCAST), BatchArray(v + 3, PB_HOST_BROADCAST) };
-      on_ins(&im);
-      for (int b = 0; b < B; b++) po_imu_process_step(v, v + 3, 0.002, q4[0], q4[1], q4[2], q4[3], &ox[b], &oP[b], oll[b], &ox[b], &oP[b], &oll[b]);
+      const bool late_tick = late && k % 10 == 9;
+      auto oracle_imu = [&]() {
+        for (int b = 0; b < B; b++) po_imu_process_step(v, v + 3, 0.002, q4[0], q4[1], q4[2], q4[3], &ox[b], &oP[b], oll[b], &ox[b], &oP[b], &oll[b]);
+      };
+      if (!late_tick) {
+        on_ins(&im);
+        oracle_imu();
+      }
       for (int b = 0; b < W; b++) {
         double ph = t / period[b] + phase[b];
         ph -= floor(ph);
@@ -239,8 +248,8 @@ int main(int argc, char **argv)
           jp[(size_t) (r1 + 2) * W + b] = (float) (-0.03 * sgn - 0.02 * sw);
         }
       }
-      const int64_t js_utime = late ? utime + 300 : utime;
-      const bool pose_tick = late && k % 10 == 9;
+      const int64_t js_utime = late_tick ? utime - 300 : (late ? utime + 300 : utime);
+      const bool pose_tick = late_tick;
       double ppos[3] = { 0, 0, 0 }, pquat[4] = { 1, 0, 0, 0 };
       if (pose_tick) {
         for (int i = 0; i < 3; i++) ppos[i] = 0.05 * nrand();
@@ -279,10 +288,11 @@ int main(int argc, char **argv)
         msgs::controller_foot_contact_t cc{ utime, ncl, ncr };
         legodo_handler.controllerInputHandler(&cc);
       }
-      if (pose_tick) {   // delivered (and applied) ahead of the joint state it is stamped behind
+      if (late_tick) {   // the pose first (applied), then the IMU sample (held back), then the joint state that is older than both
         const double zero3[3] = { 0, 0, 0 };
-        msgs::pose_t pm{ utime + 400, BatchArray(ppos, PB_HOST_BROADCAST), BatchArray(zero3, PB_HOST_BROADCAST), BatchArray(pquat, PB_HOST_BROADCAST) };
+        msgs::pose_t pm{ utime - 200, BatchArray(ppos, PB_HOST_BROADCAST), BatchArray(zero3, PB_HOST_BROADCAST), BatchArray(pquat, PB_HOST_BROADCAST) };
         on_pose(&pm);
+        on_ins(&im);
       }
       on_joints(&js);
       if (device && fuse3) {  // the caller refills its blocks for the next message right away
@@ -324,7 +334,7 @@ int main(int argc, char **argv)
           for (int i = 0; i < m; i++) R[i * m + i] = Rd[i];
           po_indexed_update(m, idx, z, R, &ox[b], &oP[b], oll[b], &ox[b], &oP[b], &oll[b]);
         }
-        if (pose_tick) {                                // in time order the pose FOLLOWS the leg odometry
+        if (pose_tick) {                                // in time order the pose FOLLOWS the leg odometry ...
           const int pidx[4] = { 9, 10, 11, 8 };
           double pz[4] = { ppos[0], ppos[1], ppos[2], 0.0 }, pR[16] = { 0 };
           pR[0] = pR[5] = pR[10] = 0.05 * 0.05;
@@ -332,6 +342,7 @@ int main(int argc, char **argv)
           po_indexed_orient_update(4, pidx, pz, pR, pquat, &ox[b], &oP[b], oll[b], &ox[b], &oP[b], &oll[b]);
         }
       }
+      if (late_tick) oracle_imu();                      // ... and the IMU sample follows the pose
     }
     if (late) {   // one more IMU message rolls the last (unapplied) leg odometry forward
       const int64_t utime = 1000000 + (int64_t) (T + 1) * 2000;

@@ -10,7 +10,15 @@
 //     IMU + joint-state pair) and ScanMatcherHandler::processMessage (position_yaw);
 //   * every filter must equal the ORACLE run of ITS OWN log alone (po_imu_process_step, po_torque_adjust -> po_fk ->
 //     po_leg_update_wc on the oracle filter's own pose with the log's own time stamps -> po_indexed_update), <= 1e-9.
-// argv: "n21" = 21 states, "nofuse" = without fuse_ins_legodo, a directory for the logs.  Exit code 0 + "PASS".  Needs a GPU.
+// argv: "n21" = 21 states, "nofuse" = without fuse_ins_legodo, a directory for the logs;
+//   "stream"  the same replay through SegmentStreamer (segment_stream.hpp): memory-mapped logs decoded ahead in chunks, one upload per
+//             chunk, the handlers called with PB_DEVICE messages;  "chunk7": chunks of 7 batched messages (every chunk boundary case);
+//   "kvh"     (with "stream") the IMU arrives as the reference's Atlas channel -- bot_core::kvh_raw_imu_batch_t on ATLAS_IMU_BATCH
+//             (fusion.cpp:161-163): every message repeats packets of the one before, some carry NO new packet, the first ones are
+//             shorter; InsHandler::processMessageAtlasSegments with atlas_filter = true (one IMUStream state per segment, the notch
+//             cascade on the device with per-filter packet counts, raw_dt and message-time dt per filter); the oracle runs
+//             imu_stream.cpp:62-98 + the notch cascade + sensor_handlers.cpp:199-252 per segment.
+// Exit code 0 + "PASS".  Needs a GPU.
 #include <chrono>
 #include <cinttypes>
 #include <cstdio>
@@ -19,6 +27,7 @@
 
 #include "test_n.hpp"
 #include "../../pronto_amd/csrc/segment_batcher.hpp"
+#include "../../pronto_amd/csrc/segment_stream.hpp"
 
 using namespace MavStateEst;
 
@@ -54,9 +63,13 @@ struct joint_state_t { int64_t utime; int16_t num_joints; string joint_name[num_
 struct six_axis_force_torque_t { int64_t utime; double force[3]; double moment[3]; }
 struct six_axis_force_torque_array_t { int64_t utime; int32_t num_sensors; string names[num_sensors]; six_axis_force_torque_t sensors[num_sensors]; }
 struct pose_t { int64_t utime; double pos[3]; double vel[3]; double orientation[4]; double rotation_rate[3]; double accel[3]; }
+struct kvh_raw_imu_t { int64_t utime; int64_t packet_count; double delta_rotation[3]; double linear_acceleration[3]; }
+struct kvh_raw_imu_batch_t { int64_t utime; int32_t num_packets; kvh_raw_imu_t raw_imu[num_packets]; }
 )";
 
+struct Packet { int64_t utime, count; double drot[3], lacc[3]; };
 struct Tick {   // one tick of one segment, as the oracle replays it
+  int n_new = 0, pk_hi = -1;   // "kvh": new packets in this tick's batch message, index of its newest packet
   int64_t imu_utime, js_utime;
   double gyro[3], accel[3], fz[2];
   float jp[16], je[16];
@@ -67,12 +80,16 @@ struct Tick {   // one tick of one segment, as the oracle replays it
 int main(int argc, char **argv)
 {
   const int n = take_n_states(argc, argv);
-  bool fuse = true;
+  bool fuse = true, stream = false, kvh = false, chunk7 = false;
   std::string dir = "/tmp";
   for (int i = 1; i < argc; i++) {
     if (std::string(argv[i]) == "nofuse") fuse = false;
+    else if (std::string(argv[i]) == "stream") stream = true;
+    else if (std::string(argv[i]) == "kvh") kvh = stream = true;
+    else if (std::string(argv[i]) == "chunk7") chunk7 = true;
     else if (argv[i][0] == '/') dir = argv[i];
   }
+  const int KVH_PACKETS = 5;
   // "rate <segments> <ticks>": no oracle, time the replay (segments x messages per second, PCIe and log decoding included)
   int rate_B = 0, rate_T = 0;
   for (int i = 1; i + 2 < argc; i++)
@@ -91,23 +108,39 @@ int main(int argc, char **argv)
                                            "l_arm_shz", "r_leg_hpz", "r_leg_hpx", "r_leg_hpy", "r_arm_shz", "r_leg_kny", "r_leg_aky", "r_leg_akx" };
 
   // ---- write B different logs ----
-  std::vector<std::vector<Tick>> ticks((size_t) B);
-  std::vector<int64_t> start_ts((size_t) B, 0);
-  std::vector<std::string> paths((size_t) B);
-  for (int s = 0; s < B; s++) {
-    const int Ts = rate ? T : T - (s % 5) * 17;            // ragged ends
+  // Rate runs of the streamer ("rate ... stream"): 16 long recordings and every segment its own WINDOW of T ticks of one of them
+  // (a start_timestamp found by bisection and an end_timestamp) -- N runs over parts of a few long logs, the shape a batch of
+  // se-fusion runs over recorded sessions has; 16 384 separate files of that length would not fit the box.
+  const bool windows = rate && stream;
+  const int n_logs = windows ? std::min(B, 16) : B;
+  const int per_log = (B + n_logs - 1) / n_logs;
+  std::vector<std::vector<Tick>> ticks((size_t) n_logs);
+  std::vector<std::vector<Packet>> packets((size_t) n_logs);
+  std::vector<int64_t> start_ts((size_t) B, 0), end_ts((size_t) B, 0), log_base((size_t) n_logs, 0);
+  std::vector<std::string> paths((size_t) B), log_paths((size_t) n_logs);
+  for (int s = 0; s < n_logs; s++) {
+    const int Ts = windows ? T + per_log : (rate ? T : T - (s % 5) * 17);            // ragged ends
     const int64_t base = 1000000000LL * (s + 1) + 12345 * s;   // another absolute time base per recording
+    log_base[(size_t) s] = base;
     const double period = 0.9 + 0.4 * urand(), phase = urand(), swing = 0.15 + 0.2 * urand();
-    paths[(size_t) s] = dir + "/segment_" + std::to_string(s) + ".lcmlog";
-    pronto_wire::LogWriter log(paths[(size_t) s]);
-    if (!log.good()) { printf("cannot write %s\nFAIL\n", paths[(size_t) s].c_str()); return 1; }
-    if (s % 4 == 1) {   // events in front of the start_timestamp this segment is opened with: they must not be replayed
+    log_paths[(size_t) s] = dir + "/segment_" + std::to_string(s) + ".lcmlog";
+    if (!windows) paths[(size_t) s] = log_paths[(size_t) s];
+    pronto_wire::LogWriter log(log_paths[(size_t) s]);
+    if (!log.good()) { printf("cannot write %s\nFAIL\n", log_paths[(size_t) s].c_str()); return 1; }
+    if (!windows && s % 4 == 1) {   // events in front of the start_timestamp this segment is opened with: they must not be replayed
       for (int k = 0; k < 9; k++) {
         pronto_wire::Writer w;
-        w.u64(schema.fingerprint("bot_core.ins_t"));
-        w.i64(base - 50000 + 2000 * k); w.i64(0);
-        for (int i = 0; i < 16; i++) w.f64(100.0);   // nonsense that would wreck the filter
-        log.write(base - 50000 + 2000 * k, "IMU", w.buf);
+        if (kvh) {
+          w.u64(schema.fingerprint("bot_core.kvh_raw_imu_batch_t"));
+          w.i64(base - 50000 + 2000 * k); w.i32(1);
+          w.i64(base - 50000 + 2000 * k); w.i64(9000000 + k);   // (a packet count that would also freeze the de-duplication)
+          for (int i = 0; i < 6; i++) w.f64(100.0);
+        } else {
+          w.u64(schema.fingerprint("bot_core.ins_t"));
+          w.i64(base - 50000 + 2000 * k); w.i64(0);
+          for (int i = 0; i < 16; i++) w.f64(100.0);   // nonsense that would wreck the filter
+        }
+        log.write(base - 50000 + 2000 * k, kvh ? "ATLAS_IMU_BATCH" : "IMU", w.buf);
       }
       start_ts[(size_t) s] = base - 1000;
     }
@@ -142,15 +175,40 @@ int main(int argc, char **argv)
       for (int i = 0; i < 3; i++) tk.pos[i] = 0.05 * nrand();
       po_euler_to_quat(0.0, 0.0, 0.3 * (urand() - 0.5), tk.quat);
       // the events of this tick, in the order every recording of this robot has them: IMU, force/torque, joint state, [pose]
-      pronto_wire::Writer w;
-      w.u64(schema.fingerprint("bot_core.ins_t"));
-      w.i64(tk.imu_utime); w.i64(tk.imu_utime + 17);
-      w.f64s(tk.gyro, 3);
-      for (int i = 0; i < 3; i++) w.f64(0.1 * i);
-      w.f64s(tk.accel, 3);
-      for (int i = 0; i < 4; i++) w.f64(i == 0);
-      w.f64(1013.0); w.f64(0.0);
-      log.write(tk.imu_utime, "IMU", w.buf);
+      if (kvh) {
+        // 1 kHz packets in 500 Hz batch messages: normally two new packets, sometimes one or three, one message in ten none at all
+        // (imu_stream.cpp: "happens all the time"); each message repeats the packets in front, newest first
+        const double u = urand();
+        tk.n_new = k == 0 ? 2 : (u < 0.1 ? 0 : (u < 0.25 ? 1 : (u < 0.9 ? 2 : 3)));
+        std::vector<Packet> &pk = packets[(size_t) s];
+        for (int j = 0; j < tk.n_new; j++) {
+          Packet p;
+          p.count = 5000 + 3 * s + (int64_t) pk.size();
+          p.utime = base + (int64_t) pk.size() * 1000 + (int64_t) (40 * (urand() - 0.5));
+          for (int i = 0; i < 3; i++) { p.drot[i] = 0.001 * (0.2 * sin(0.025 * (double) pk.size() + s + i) + 0.01 * nrand()); p.lacc[i] = 0.3 * nrand() + (i == 2 ? g : 0.0); }
+          pk.push_back(p);
+        }
+        tk.pk_hi = (int) pk.size() - 1;
+        const int np = std::min(KVH_PACKETS, tk.pk_hi + 1);
+        pronto_wire::Writer w;
+        w.u64(schema.fingerprint("bot_core.kvh_raw_imu_batch_t"));
+        w.i64(tk.imu_utime); w.i32(np);
+        for (int j = 0; j < np; j++) {
+          const Packet &p = pk[(size_t) (tk.pk_hi - j)];
+          w.i64(p.utime); w.i64(p.count); w.f64s(p.drot, 3); w.f64s(p.lacc, 3);
+        }
+        log.write(tk.imu_utime, "ATLAS_IMU_BATCH", w.buf);
+      } else {
+        pronto_wire::Writer w;
+        w.u64(schema.fingerprint("bot_core.ins_t"));
+        w.i64(tk.imu_utime); w.i64(tk.imu_utime + 17);
+        w.f64s(tk.gyro, 3);
+        for (int i = 0; i < 3; i++) w.f64(0.1 * i);
+        w.f64s(tk.accel, 3);
+        for (int i = 0; i < 4; i++) w.f64(i == 0);
+        w.f64(1013.0); w.f64(0.0);
+        log.write(tk.imu_utime, "IMU", w.buf);
+      }
       if (k % 11 == 3) log.write(tk.imu_utime + 50, "SOMETHING_ELSE", std::vector<uint8_t>(13, 0x5A));
       pronto_wire::Writer f;
       f.u64(schema.fingerprint("bot_core.six_axis_force_torque_array_t"));
@@ -182,6 +240,14 @@ int main(int argc, char **argv)
     }
   }
 
+  if (windows)
+    for (int s = 0; s < B; s++) {
+      const int l = s % n_logs, o = s / n_logs;
+      paths[(size_t) s] = log_paths[(size_t) l];
+      start_ts[(size_t) s] = log_base[(size_t) l] + (int64_t) o * 2000 + 1000;   // between two ticks: the window opens with an IMU message
+      end_ts[(size_t) s] = start_ts[(size_t) s] + (int64_t) T * 2000;
+    }
+
   // ---- the estimator and the handlers, configured with the reference's keys ----
   BotParam param;
   param.set("state_estimator.utime_history_span", "1000000");
@@ -191,7 +257,8 @@ int main(int argc, char **argv)
   param.set("state_estimator.ins.q_gyro", 0.5);
   param.set("state_estimator.ins.q_accel", 0.1);
   param.set("state_estimator.ins.timestep_dt", 0.002);
-  param.set("state_estimator.ins.atlas_filter", "false");
+  param.set("state_estimator.ins.atlas_filter", kvh ? "true" : "false");
+  param.set("state_estimator.ins.atlas_filter_freq", 87.0);
   set_ins_bias_keys(param, n);
   param.applyOverrides("state_estimator.legodo.mode=lin_rate|state_estimator.legodo.r_xyz=2.0|state_estimator.legodo.r_vxyz=5|"
                        "state_estimator.legodo.r_vang=3|state_estimator.legodo.r_vxyz_uncertain=10|state_estimator.legodo.r_vang_uncertain=9|"
@@ -244,61 +311,150 @@ int main(int argc, char **argv)
   }
   BotTrans ins_to_body;   // a mounted IMU: 90 degrees about z
   ins_to_body.rot_quat[0] = sqrt(0.5); ins_to_body.rot_quat[3] = sqrt(0.5);
+  if (kvh) { ins_to_body.trans_vec[0] = 0.01; ins_to_body.trans_vec[1] = -0.02; ins_to_body.trans_vec[2] = 0.03; }   // (the Atlas path applies the whole transform to the acceleration, :227)
   InsHandler ins_handler(&param, &ins_to_body);
   ScanMatcherHandler sm_handler(&param);
   FrontEnd front_end(&param);
   MavStateEstimator est(new RBISResetUpdate(x0, P0, RBISUpdateInterface::reset, 0), &param, 0);
   front_end.setStateEstimator(&est);
-  SegmentBatcher::Stats st;
+  struct Totals {   // what both replayers count
+    int64_t batches = 0, segment_messages = 0, ragged = 0, order_violations = 0, undecodable = 0, max_skew_us = 0;
+    std::map<std::string, int64_t> per_channel;
+  } st;
   RBIS head;
   RBIM cov;
   std::vector<double> ll;
+  const char *imu_channel = kvh ? "ATLAS_IMU_BATCH" : "IMU";
   {
     LegOdoHandler legodo_handler(&param, &model);
-    SegmentBatcher batch(&est);
-    for (int s = 0; s < B; s++)
-      if (!batch.addSegment(paths[(size_t) s], start_ts[(size_t) s])) { printf("FAIL: cannot open segment %d\n", s); return 1; }
-    if (batch.addSegment(paths[0])) { printf("FAIL: a 65th segment was accepted by a 64-filter batch\n"); return 1; }
-    batch.subscribeIns("IMU", &schema, "bot_core.ins_t", front_end.addSensor("ins", &InsHandler::processMessage, &ins_handler));
-    batch.subscribeForceTorque("FORCE_TORQUE", &schema, "bot_core.six_axis_force_torque_array_t",
-                               [&](const msgs::six_axis_force_torque_array_t *m) { legodo_handler.forceTorqueHandler(m, B); });
-    batch.subscribeJointState("JOINT_STATE", &schema, "bot_core.joint_state_t", front_end.addSensor("legodo", &LegOdoHandler::processMessage, &legodo_handler));
-    batch.subscribePose("POSE_SCAN", &schema, "bot_core.pose_t", front_end.addSensor("scan_matcher", &ScanMatcherHandler::processMessage, &sm_handler));
-    const auto t0 = std::chrono::steady_clock::now();
-    const int64_t nb = batch.run();
-    pb_sync(est.ctx);
-    const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    st = batch.stats;
+    auto t0 = std::chrono::steady_clock::now();
+    double sec = 0;
+    int64_t nb = 0;
+    if (stream) {
+      SegmentStreamer batch(&est);
+      if (chunk7) batch.max_slots = 7;
+      if (getenv("SEGMENT_CHUNK_MB")) batch.chunk_budget_bytes = (uint64_t) atoi(getenv("SEGMENT_CHUNK_MB")) << 20;
+      if (getenv("SEGMENT_MAX_SLOTS")) batch.max_slots = atoi(getenv("SEGMENT_MAX_SLOTS"));
+      for (int s = 0; s < B; s++)
+        if (!batch.addSegment(paths[(size_t) s], start_ts[(size_t) s], end_ts[(size_t) s])) { printf("FAIL: cannot open segment %d\n", s); return 1; }
+      if (batch.addSegment(paths[0])) { printf("FAIL: a segment too many was accepted by a %d-filter batch\n", B); return 1; }
+      if (kvh)
+        batch.subscribeKvhBatch(imu_channel, &schema, "bot_core.kvh_raw_imu_batch_t", ins_handler.atlas_filter, KVH_PACKETS,
+                                front_end.addSensor("ins", &InsHandler::processMessageAtlasSegments, &ins_handler));
+      else
+        batch.subscribeIns(imu_channel, &schema, "bot_core.ins_t", front_end.addSensor("ins", &InsHandler::processMessage, &ins_handler));
+      batch.subscribeForceTorque("FORCE_TORQUE", &schema, "bot_core.six_axis_force_torque_array_t", [&](const float *abs_fz) { legodo_handler.forceTorqueDevice(abs_fz); });
+      batch.subscribeJointState("JOINT_STATE", &schema, "bot_core.joint_state_t", front_end.addSensor("legodo", &LegOdoHandler::processMessage, &legodo_handler));
+      batch.subscribePose("POSE_SCAN", &schema, "bot_core.pose_t", front_end.addSensor("scan_matcher", &ScanMatcherHandler::processMessage, &sm_handler));
+      t0 = std::chrono::steady_clock::now();
+      nb = batch.run();
+      est.flushPending();
+      pb_sync(est.ctx);
+      sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      const SegmentStreamer::Stats &ss = batch.stats;
+      st.batches = ss.batches; st.segment_messages = ss.segment_messages; st.ragged = ss.ragged; st.order_violations = ss.order_violations;
+      st.undecodable = ss.undecodable; st.max_skew_us = ss.max_skew_us; st.per_channel = ss.per_channel;
+      if (rate) {
+        const double steps = (double) B * T;
+        printf("segment stream rate: %d segments x %d ticks (%s + force/torque + joint state per tick, pose every 20th; %d logs, every segment its own "
+               "window), n=%d, %s: %.2f s -> %.3g segment-messages/s, %.3g filter-steps/s (memory-mapped logs decoded through the run-time schema, "
+               "page-locked chunks, PCIe and kernels all inside), %lld batched messages in %lld chunks of <= %.1f MB, fused pairs %lld, status %d\n",
+               B, T, kvh ? "KVH batch IMU" : "IMU", n_logs, n, fuse ? "fused pairs" : "unfused", sec, ss.segment_messages / sec, steps / sec, (long long) ss.batches,
+               (long long) ss.chunks, ss.chunk_bytes / 1048576.0, (long long) est.fused_pairs, est.last_status);
+        printf("  decode-ahead thread [s]: lead pass %.3f | parallel decode + assembly %.3f | waiting for a free ring slot %.3f\n", ss.t_lead, ss.t_decode, ss.t_wait_free);
+        printf("  dispatching thread [s]: waiting for a chunk %.3f | uploads (issue + host wait) %.3f | handlers (enqueues) %.3f | heads of finished runs %.3f\n",
+               ss.t_wait_chunk, ss.t_upload, ss.t_handlers, ss.t_final);
+        printf("  bytes: %.1f MB uploaded = %.1f B per segment-tick; ragged columns %lld, order violations %lld, undecodable %lld, read-ahead capped %lld, max skew %lld us\n",
+               ss.uploaded_bytes / 1048576.0, ss.uploaded_bytes / steps, (long long) ss.ragged, (long long) ss.order_violations, (long long) ss.undecodable,
+               (long long) ss.readahead_capped, (long long) ss.max_skew_us);
+      }
+      batch.finalState(head, cov);           // every run's result: its filter's head at the end of ITS log
+      ll = batch.finalLogLikelihood();
+    } else {
+      SegmentBatcher batch(&est);
+      for (int s = 0; s < B; s++)
+        if (!batch.addSegment(paths[(size_t) s], start_ts[(size_t) s])) { printf("FAIL: cannot open segment %d\n", s); return 1; }
+      if (batch.addSegment(paths[0])) { printf("FAIL: a 65th segment was accepted by a 64-filter batch\n"); return 1; }
+      batch.subscribeIns("IMU", &schema, "bot_core.ins_t", front_end.addSensor("ins", &InsHandler::processMessage, &ins_handler));
+      batch.subscribeForceTorque("FORCE_TORQUE", &schema, "bot_core.six_axis_force_torque_array_t",
+                                 [&](const msgs::six_axis_force_torque_array_t *m) { legodo_handler.forceTorqueHandler(m, B); });
+      batch.subscribeJointState("JOINT_STATE", &schema, "bot_core.joint_state_t", front_end.addSensor("legodo", &LegOdoHandler::processMessage, &legodo_handler));
+      batch.subscribePose("POSE_SCAN", &schema, "bot_core.pose_t", front_end.addSensor("scan_matcher", &ScanMatcherHandler::processMessage, &sm_handler));
+      t0 = std::chrono::steady_clock::now();
+      nb = batch.run();
+      pb_sync(est.ctx);
+      sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      const SegmentBatcher::Stats &bs = batch.stats;
+      st.batches = bs.batches; st.segment_messages = bs.segment_messages; st.ragged = bs.ragged; st.order_violations = bs.order_violations;
+      st.undecodable = bs.undecodable; st.max_skew_us = bs.max_skew_us; st.per_channel = bs.per_channel;
+      if (rate) {
+        printf("segment batch rate: %d segments x %d ticks (IMU + force/torque + joint state per tick, pose every 20th), n=%d, %s: %.2f s -> "
+               "%.3g segment-messages/s, %.3g filter-steps/s (log decoding through the run-time schema, page-locked assembly, PCIe and "
+               "kernels all inside), %lld batched messages, fused pairs %lld, status %d\n",
+               B, T, n, fuse ? "fused pairs" : "unfused", sec, bs.segment_messages / sec, (double) B * T / sec, (long long) bs.batches,
+               (long long) est.fused_pairs, est.last_status);
+        printf("  where the time went [s]: lead %.3f | read + decode %.3f | book-keeping %.3f | assembly + handlers %.3f | read-ahead %.3f | heads %.3f\n",
+               bs.t_lead, bs.t_pull, bs.t_book, bs.t_dispatch, bs.t_fill, bs.t_final);
+        printf("  of assembly + handlers: inside the handlers' callbacks %.3f, joint blocks to HBM %.3f\n", bs.t_handler, bs.t_upload);
+      }
+      batch.finalState(head, cov);
+      ll = batch.finalLogLikelihood();
+    }
     if (rate) {
-      printf("segment batch rate: %d segments x %d ticks (IMU + force/torque + joint state per tick, pose every 20th), n=%d, %s: %.2f s -> "
-             "%.3g segment-messages/s, %.3g filter-steps/s (log decoding through the run-time schema, page-locked assembly, PCIe and "
-             "kernels all inside), %lld batched messages, fused pairs %lld, status %d\n",
-             B, T, n, fuse ? "fused pairs" : "unfused", sec, st.segment_messages / sec, (double) B * T / sec, (long long) st.batches,
-             (long long) est.fused_pairs, est.last_status);
-      printf("  where the time went [s]: lead %.3f | read + decode %.3f | book-keeping %.3f | assembly + handlers %.3f | read-ahead %.3f | heads %.3f\n",
-             st.t_lead, st.t_pull, st.t_book, st.t_dispatch, st.t_fill, st.t_final);
-      printf("  of assembly + handlers: inside the handlers' callbacks %.3f, joint blocks to HBM %.3f\n", st.t_handler, st.t_upload);
-      for (int s2 = 0; s2 < B; s2++) remove(paths[(size_t) s2].c_str());
+      for (int s2 = 0; s2 < n_logs; s2++) remove(log_paths[(size_t) s2].c_str());
       return est.last_status == PB_OK ? 0 : 1;
     }
     if (nb != st.batches) { printf("FAIL: run() returned %lld\n", (long long) nb); return 1; }
-    batch.finalState(head, cov);           // every run's result: its filter's head at the end of ITS log
-    ll = batch.finalLogLikelihood();
   }
 
   // ---- the oracle: every segment ALONE, from its own log ----
   const double q4[4] = { ins_handler.cov_gyro, ins_handler.cov_accel, ins_handler.cov_gyro_bias, ins_handler.cov_accel_bias };
   const double r5[5] = { 2.0, 5.0, 3.0, 10.0, 9.0 };
-  int n_status[3] = { 0, 0, 0 };
+  int n_status[3] = { 0, 0, 0 }, n_kvh_new[4] = { 0, 0, 0, 0 };
   for (int b = 0; b < B; b++) {
     std::vector<char> leg(po_leg_sizeof());
     po_leg_init((po_leg *) leg.data(), 475, 525, 7000, 7000, 1);
     int zc = 3;
+    // "kvh": this segment's IMUStream + notch cascade + processMessageAtlas state (imu_stream.hpp:10-37, sensor_handlers.hpp)
+    std::vector<po_notch> notch(9);
+    po_notch_cascade_init(notch.data(), 87.0, 1000);
+    int64_t last_packet = -1, last_packet_utime = 0, prev_utime_atlas = 0;
     for (const Tick &tk : ticks[(size_t) b]) {
       double gb[3], ab[3];
-      bot_quat_rotate_to(ins_to_body.rot_quat, tk.gyro, gb);
-      bot_quat_rotate_to(ins_to_body.rot_quat, tk.accel, ab);
-      po_imu_process_step(gb, ab, 0.002, q4[0], q4[1], q4[2], q4[3], &ox[(size_t) b], &oP[(size_t) b], oll[(size_t) b], &ox[(size_t) b], &oP[(size_t) b], &oll[(size_t) b]);
+      if (kvh) {
+        // IMUStream::convertFromLCMBatch on the message as it was written (newest first, at most KVH_PACKETS packets): the new ones,
+        // oldest first, through the cascade; the newest filtered one drives the step (sensor_handlers.cpp:173-197)
+        const std::vector<Packet> &pk = packets[(size_t) b];
+        const int np = std::min(KVH_PACKETS, tk.pk_hi + 1);
+        int n_new = 0;
+        double filt[3] = { 0, 0, 0 }, drot[3] = { 0, 0, 0 };
+        int64_t utime_delta = 0;
+        for (int j = np - 1; j >= 0; j--) {
+          const Packet &p = pk[(size_t) (tk.pk_hi - j)];
+          if (p.count <= last_packet) continue;
+          utime_delta = p.utime - last_packet_utime;
+          last_packet = p.count;
+          last_packet_utime = p.utime;
+          for (int i = 0; i < 3; i++) { filt[i] = p.lacc[i]; drot[i] = p.drot[i]; }
+          po_notch_cascade(notch.data(), filt);
+          n_new++;
+        }
+        if (n_new != tk.n_new) { printf("FAIL: the test's own packet bookkeeping (%d new, expected %d)\n", n_new, tk.n_new); return 1; }
+        n_kvh_new[std::min(n_new, 3)]++;
+        if (n_new > 0) {   // (else: "No new IMU packets detected ... Skipping iteration", return NULL)
+          const double raw_dt = utime_delta * 1E-6;
+          const double sg[3] = { drot[0] / raw_dt, drot[1] / raw_dt, drot[2] / raw_dt };
+          bot_trans_apply_vec(&ins_to_body, filt, ab);            // :227
+          bot_quat_rotate_to(ins_to_body.rot_quat, sg, gb);      // :235
+          const double integration_dt = prev_utime_atlas == 0 ? 0.002 : (tk.imu_utime - prev_utime_atlas) * 1E-6;   // :239-249
+          prev_utime_atlas = tk.imu_utime;
+          po_imu_process_step(gb, ab, integration_dt, q4[0], q4[1], q4[2], q4[3], &ox[(size_t) b], &oP[(size_t) b], oll[(size_t) b], &ox[(size_t) b], &oP[(size_t) b], &oll[(size_t) b]);
+        }
+      } else {
+        bot_quat_rotate_to(ins_to_body.rot_quat, tk.gyro, gb);
+        bot_quat_rotate_to(ins_to_body.rot_quat, tk.accel, ab);
+        po_imu_process_step(gb, ab, 0.002, q4[0], q4[1], q4[2], q4[3], &ox[(size_t) b], &oP[(size_t) b], oll[(size_t) b], &ox[(size_t) b], &oP[(size_t) b], &oll[(size_t) b]);
+      }
       double ft_[2][3], fq_[2][4];
       for (int side = 0; side < 2; side++) {
         double ang[8];
@@ -344,14 +500,16 @@ int main(int argc, char **argv)
   long long want_msgs = 0;
   for (int s = 0; s < B; s++)
     for (const Tick &tk : ticks[(size_t) s]) want_msgs += 3 + (tk.pose ? 1 : 0);
-  printf("n=%d %s: %d segments, %lld batched messages carrying %lld segment messages (IMU %lld, joint %lld, force/torque %lld, pose %lld), ragged columns %lld, "
+  if (kvh) printf("KVH batch messages with 0 / 1 / 2 / 3 new packets: %d / %d / %d / %d\n", n_kvh_new[0], n_kvh_new[1], n_kvh_new[2], n_kvh_new[3]);
+  printf("n=%d %s%s: %d segments, %lld batched messages carrying %lld segment messages (IMU %lld, joint %lld, force/torque %lld, pose %lld), ragged columns %lld, "
          "order violations %lld, undecodable %lld, max skew %lld us, fused pairs %lld; status skip/certain/uncertain %d/%d/%d; "
          "rel err vs %d single-segment oracle runs: vec %.2e quat %.2e cov %.2e ll %.2e (status %d)\n",
-         n, fuse ? "fused" : "unfused", B, (long long) st.batches, (long long) st.segment_messages, (long long) st.per_channel["IMU"],
+         n, fuse ? "fused" : "unfused", stream ? (kvh ? ", streamed, KVH batch IMU" : ", streamed") : "", B, (long long) st.batches, (long long) st.segment_messages, (long long) st.per_channel[imu_channel],
          (long long) st.per_channel["JOINT_STATE"], (long long) st.per_channel["FORCE_TORQUE"], (long long) st.per_channel["POSE_SCAN"], (long long) st.ragged,
          (long long) st.order_violations, (long long) st.undecodable, (long long) st.max_skew_us, (long long) est.fused_pairs, n_status[0], n_status[1], n_status[2], B,
          ev / sv, eq, eP / sP, el / sl, est.last_status);
-  const bool ok = est.last_status == PB_OK && st.segment_messages == want_msgs && st.per_channel["IMU"] == T && st.per_channel["JOINT_STATE"] == T &&
+  const bool kvh_ok = !kvh || (n_kvh_new[0] > B * T / 40 && n_kvh_new[1] > B * T / 40 && n_kvh_new[3] > B * T / 40);
+  const bool ok = kvh_ok && est.last_status == PB_OK && st.segment_messages == want_msgs && st.per_channel[imu_channel] == T && st.per_channel["JOINT_STATE"] == T &&
                   st.order_violations == 0 && st.undecodable == 0 && st.ragged > 0 && st.max_skew_us > 20 && st.max_skew_us < 200 &&
                   (!fuse || est.fused_pairs > T / 2) && n_status[0] > 100 && n_status[1] > 100 && n_status[2] > 100 && ev / sv < 1e-9 && eq < 1e-9 &&
                   eP / sP < 1e-9 && el / sl < 1e-9;
