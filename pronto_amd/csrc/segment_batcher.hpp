@@ -45,6 +45,7 @@ public:
     int64_t segment_messages = 0;   // per-segment messages they carried
     int64_t ragged = 0;             // columns without a message (segment ended)
     int64_t order_violations = 0, undecodable = 0, max_skew_us = 0;
+    int64_t readahead_capped = 0;   // ticks in which a segment read `readahead_cap` events ahead without finding the channel's next message
     std::map<std::string, int64_t> per_channel;
     // where run() spent its wall-clock time, seconds: finding the lead (serial; includes its read-ahead), the segments' reads +
     // decodes (parallel), book-keeping (serial), assembling the batched arrays + the handler call (parallel loop + one enqueue),
@@ -54,6 +55,7 @@ public:
 
   };
   Stats stats;
+  size_t readahead_cap = 4096;
 
   explicit SegmentBatcher(MavStateEstimator *est)
       : est_(est), B_(est->B), final_vec_((size_t) est->n * est->B, 0.0), final_quat_((size_t) 4 * est->B, 0.0),
@@ -404,7 +406,8 @@ public:
     for (const auto &sg : segs_) {
       stats.undecodable += sg->undecodable;
       stats.order_violations += sg->order_violations;
-      sg->undecodable = sg->order_violations = 0;
+      stats.readahead_capped += sg->capped;
+      sg->undecodable = sg->order_violations = sg->capped = 0;
     }
     return stats.batches;
   }
@@ -456,7 +459,7 @@ private:
     std::deque<int> order;                              // channels (index) of the decoded, not yet consumed events, in file order
     std::vector<std::deque<Rec>> queue;                 // ... and the events themselves, per channel
     std::vector<Stream> stream;
-    int64_t undecodable = 0, order_violations = 0;      // (per segment: the segments are read by different host threads)
+    int64_t undecodable = 0, order_violations = 0, capped = 0;      // (per segment: the segments are read by different host threads)
     Seg(const std::string &path, int64_t start) : rd(path), start_timestamp(start) {}
   };
 
@@ -489,8 +492,15 @@ private:
   bool pull(Seg &sg, int channel, Rec &out)
   {
     std::deque<Rec> &q = sg.queue[(size_t) channel];
-    while (q.empty() && !sg.eof) read_one(sg);
-    if (q.empty()) return false;
+    // (bounded: a live segment whose channel has stopped while its other channels go on would otherwise decode the whole rest of
+    // its log into its queues in one tick -- the channel then simply has no message for this tick; SegmentStreamer keeps offsets
+    // instead of decoded events and has the same bound)
+    size_t ahead = 0;
+    while (q.empty() && !sg.eof && ahead < readahead_cap) { read_one(sg); ahead++; }
+    if (q.empty()) {
+      if (!sg.eof) sg.capped++;
+      return false;
+    }
     out = std::move(q.front());
     q.pop_front();
     auto it = std::find(sg.order.begin(), sg.order.end(), channel);

@@ -556,7 +556,7 @@ private:
   };
   struct Chan {
     std::vector<Plane> planes;        // record layout: the planes back to back, 8-byte members first (natural alignment)
-    size_t rec_bytes = 0;
+    size_t rec_bytes = 0, rec_stride = 0;   // exact size (a chunk block is rec_bytes * B), and rounded up to 8 for the host-side copies
     bool carry = true, configured = false;
     std::function<bool(const MappedLog::Event &, Chan &)> configure;   // sizes that only the first message knows (joint count)
     std::function<bool(const MappedLog::Event &, SegChan &, uint8_t *, int64_t &)> decode;
@@ -633,6 +633,7 @@ private:
       for (int k = 0; k < p.count; k++) c.elems.push_back({ (uint32_t) (c.rec_bytes + (size_t) k * p.elem), (uint8_t) p.elem });
       c.rec_bytes += (size_t) p.elem * p.count;
     }
+    c.rec_stride = (c.rec_bytes + 7) / 8 * 8;
     c.configured = true;
   }
 
@@ -676,10 +677,10 @@ private:
           break;
         }
         const size_t at = lead_recs.size();
-        lead_recs.resize(at + ch.rec_bytes);
+        lead_recs.resize(at + ch.rec_stride);
         int64_t utime = 0;
         SegChan &sc = lead.chan[(size_t) c];
-        if (sc.last.size() != ch.rec_bytes) sc.last.assign(ch.rec_bytes, 0);
+        if (sc.last.size() != ch.rec_stride) sc.last.assign(ch.rec_stride, 0);
         memcpy(lead_recs.data() + at, sc.last.data(), ch.rec_bytes);   // (members the decoder leaves alone keep their last value)
         if (!ch.decode(ev, sc, lead_recs.data() + at, utime)) {
           lead_recs.resize(at);
@@ -760,14 +761,14 @@ private:
         size_t tot = 0;
         for (int k = 0; k < n_slots; k++) {
           slot_at[(size_t) k] = tot;
-          tot += chan_list_[(size_t) ckp->slots[(size_t) k].chan]->rec_bytes * (size_t) G;
+          tot += chan_list_[(size_t) ckp->slots[(size_t) k].chan]->rec_stride * (size_t) G;
         }
         local.resize(tot);
         for (int i = 0; i < ns; i++) {
           const int s = s0 + i;
           Seg &sg = *segs_[(size_t) s];
           filled.assign((size_t) n_slots, 0);
-          auto rec_of = [&](int k) { return local.data() + slot_at[(size_t) k] + (size_t) i * chan_list_[(size_t) ckp->slots[(size_t) k].chan]->rec_bytes; };
+          auto rec_of = [&](int k) { return local.data() + slot_at[(size_t) k] + (size_t) i * chan_list_[(size_t) ckp->slots[(size_t) k].chan]->rec_stride; };
           if (s == lead_s) {
             for (int k = 0; k < n_slots; k++) {
               memcpy(rec_of(k), lead_recs.data() + lead_rec_at[(size_t) k], chan_list_[(size_t) ckp->slots[(size_t) k].chan]->rec_bytes);
@@ -790,7 +791,7 @@ private:
               const int k = slot_of[(size_t) c][(size_t) taken[(size_t) c]];
               Chan &ch = *chan_list_[(size_t) c];
               SegChan &sc = sg.chan[(size_t) c];
-              if (sc.last.size() != ch.rec_bytes) sc.last.assign(ch.rec_bytes, 0);
+              if (sc.last.size() != ch.rec_stride) sc.last.assign(ch.rec_stride, 0);
               uint8_t *rec = rec_of(k);
               memcpy(rec, sc.last.data(), ch.rec_bytes);
               int64_t utime = 0;
@@ -819,7 +820,7 @@ private:
             if (filled[(size_t) k]) continue;
             Chan &ch = *chan_list_[(size_t) ckp->slots[(size_t) k].chan];
             SegChan &sc = sg.chan[(size_t) ch.id];
-            if (sc.last.size() != ch.rec_bytes) sc.last.assign(ch.rec_bytes, 0);
+            if (sc.last.size() != ch.rec_stride) sc.last.assign(ch.rec_stride, 0);
             uint8_t *rec = rec_of(k);
             memcpy(rec, sc.last.data(), ch.rec_bytes);
             if (!ch.carry) memset(rec, 0, ch.rec_bytes);
@@ -832,7 +833,7 @@ private:
           const Chan &ch = *chan_list_[(size_t) ckp->slots[(size_t) k].chan];
           uint8_t *blk = host + ckp->slots[(size_t) k].off;
           const uint8_t *src = local.data() + slot_at[(size_t) k];
-          const size_t rb = ch.rec_bytes;
+          const size_t rb = ch.rec_stride;
           for (const auto &el : ch.elems) {
             uint8_t *dst = blk + (size_t) el.first * (size_t) B_ + (size_t) s0 * el.second;
             const uint8_t *sp = src + el.first;

@@ -119,7 +119,7 @@ int main(int argc, char **argv)
   std::vector<int64_t> start_ts((size_t) B, 0), end_ts((size_t) B, 0), log_base((size_t) n_logs, 0);
   std::vector<std::string> paths((size_t) B), log_paths((size_t) n_logs);
   for (int s = 0; s < n_logs; s++) {
-    const int Ts = windows ? T + per_log : (rate ? T : T - (s % 5) * 17);            // ragged ends
+    const int Ts = windows ? T + 20 * per_log : (rate ? T : T - (s % 5) * 17);            // ragged ends
     const int64_t base = 1000000000LL * (s + 1) + 12345 * s;   // another absolute time base per recording
     log_base[(size_t) s] = base;
     const double period = 0.9 + 0.4 * urand(), phase = urand(), swing = 0.15 + 0.2 * urand();
@@ -244,7 +244,9 @@ int main(int argc, char **argv)
     for (int s = 0; s < B; s++) {
       const int l = s % n_logs, o = s / n_logs;
       paths[(size_t) s] = log_paths[(size_t) l];
-      start_ts[(size_t) s] = log_base[(size_t) l] + (int64_t) o * 2000 + 1000;   // between two ticks: the window opens with an IMU message
+      // between two ticks, a whole number of pose periods in: the window opens with an IMU message and every run sees its sparse
+      // channel at the same place (messages are aligned by index per channel)
+      start_ts[(size_t) s] = log_base[(size_t) l] + (int64_t) o * 20 * 2000 + 1000;
       end_ts[(size_t) s] = start_ts[(size_t) s] + (int64_t) T * 2000;
     }
 
