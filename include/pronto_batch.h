@@ -93,6 +93,8 @@ int pb_sync(pb_ctx *ctx);
  * "k_step_coop<21,true,H>" (21 states with PRONTO_BATCH_QUAD21=0); H = 0/1/2 is the cache policy of the state round trip
  * the library picked from the state size (default / sc1 stores / non-temporal) */
 const char *pb_hot_kernel(const pb_ctx *ctx);
+/* filters per block of pb_run_legodo's cache-blocked order (0: the whole batch per launch; see pb_run_legodo) */
+int pb_run_block(const pb_ctx *ctx);
 int pb_batch(const pb_ctx *ctx);
 int pb_n_states(const pb_ctx *ctx);
 
@@ -185,7 +187,14 @@ int pb_step_legodo_correct(pb_ctx *ctx, const double *imu_block, const double *l
  * lo_stream [n_steps][6][B], mask_stream [n_steps][B] or NULL (device pointers).  One launch per step (the
  * posterior is materialised in HBM after every message, as MavStateEstimator::addUpdate does,
  * mav_state_est.cpp:50-70).  If elapsed_ms != NULL the call brackets the launches with HIP events on the
- * context's stream, synchronises, and returns the device time. */
+ * context's stream, synchronises, and returns the device time.
+ * Launch ORDER: for a state that fits the memory-side cache, step by step over the whole batch.  Beyond it (pb_create: more than
+ * 256 MB of state and a batch of whole tiles; pb_run_block() > 0) the call runs filter range OUTER, time INNER: a block of
+ * pb_run_block() filters takes all n_steps steps -- its posteriors stay cache-resident from step to step -- before the next block
+ * starts.  The filters are independent, so the results are those of the step-by-step order: bit for bit when the same step kernel
+ * runs (PRONTO_BATCH_COOP15 forced, or any batch up to 393 216 filters), to rounding where the blocks run the two-wave 15-state
+ * kernel that their size wants and the whole batch would run the one-lane kernel.  Same accounting as ever: one launch per step
+ * and block, every posterior loaded and stored once per step.  PRONTO_BATCH_BLOCKED=0 keeps the step-by-step order. */
 int pb_run_legodo(pb_ctx *ctx, int n_steps, const double *imu_stream, const double *lo_stream,
                   const uint8_t *mask_stream, const double q[4], float *elapsed_ms);
 

@@ -53,6 +53,7 @@ _SIGS = {
     "pb_sync": (C.c_int, [C.c_void_p]),
     "pb_hot_kernel": (C.c_char_p, [C.c_void_p]),
     "pb_batch": (C.c_int, [C.c_void_p]),
+    "pb_run_block": (C.c_int, [C.c_void_p]),
     "pb_n_states": (C.c_int, [C.c_void_p]),
     "pb_malloc": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]),
     "pb_free": (C.c_int, [C.c_void_p, C.c_void_p]),

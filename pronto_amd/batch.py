@@ -107,6 +107,10 @@ class BatchEstimator:
     def hot_kernel(self):
         return self._L.pb_hot_kernel(self._h).decode()
 
+    def run_block(self):
+        """filters per block of run_legodo's cache-blocked order (0: the whole batch per launch)"""
+        return self._L.pb_run_block(self._h)
+
     # --- posterior checkpoints, RTS smoother ---
     def history_reserve(self, n_slots):
         self._chk(self._L.pb_history_reserve(self._h, n_slots))

@@ -81,6 +81,10 @@ struct pb_ctx {
   bool have_state = false;
   bool coop15 = false;  // PRONTO_BATCH_COOP15=1: run the 15-state step on the two-wave cooperative kernel (A/B switch)
   int mem_hint = 0;     // MH_* cache policy of the step kernels' state round trip (PRONTO_BATCH_MEMHINT=0/1/2 forces it)
+  // pb_run_legodo's cache-blocked order (filter range outer, time inner) for states beyond the memory-side cache: filters per block
+  // (whole tiles; 0 = the whole batch per launch), and the kernel / cache policy that block size wants
+  int run_block = 0, run_block_hint = 0;
+  bool run_block_coop15 = false;
   bool quad21 = true;   // PRONTO_BATCH_QUAD21=0: run the 21-state step on the two-wave kernel instead of the four-wave one (A/B)
   bool generic_update = false;  // PRONTO_BATCH_GENERIC_UPDATE=1: every stand-alone update on the run-time-index kernel (A/B, tests)
   bool smooth_attr = false;  // dynamic-LDS limit of the smoother kernels raised on this device
@@ -132,6 +136,8 @@ inline void update_done(pb_ctx *c, double *target)
 // pb_step.hip: predict (update = false) or predict + leg-odometry update on the kernel pb_create picked
 int pbk_step(pb_ctx *c, bool update, const double *imu, const double *lo, const uint8_t *mask, const double q[4],
              const StepBcast *bcast = nullptr);  // bcast: one message for every filter, as kernel arguments
+// the fused step on the filters [b0, b0 + nb) only (whole tiles, in place; pb_run_legodo's cache-blocked order)
+int pbk_step_range(pb_ctx *c, const double *imu, const double *lo, const uint8_t *mask, const double q[4], long b0, int nb, bool coop15, int mem_hint);
 // IMU step + leg odometry (from `lin`) + its lin_rate update in ONE kernel; -1 = this context has no such kernel (run
 // pb_legodo_update* ahead of pbk_step instead)
 // mp.mode 1 / 2: LegOdoCommon's six-row measurements instead (lo_out [12][B], mask_out [2][B] as pb_legodo_set_measurement_mode)

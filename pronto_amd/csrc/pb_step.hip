@@ -35,6 +35,36 @@ static int launch_step(pb_ctx *c, const double *imu, const double *lo, const uin
 }
 
 
+// The fused step on the filters [b0, b0 + nb) only -- b0 and the batch multiples of 64 (whole tiles), the posterior in place, the inputs
+// still blocks [rows][B] of the WHOLE batch (the kernels take B as the row stride; the block is addressed by shifting every pointer).
+// coop15 / mem_hint are the caller's: a block that fits the memory-side cache wants the kernel and the cache policy of ITS size.
+template <int MH>
+static void launch_range_mh(pb_ctx *c, double *st, const double *imu, const double *lo, const uint8_t *mask, const double q[4], int nb, bool coop15)
+{
+  const int B = c->B;
+  const StepBcast bc = StepBcast();
+  if (c->ns == 15 && coop15) k_step_coop<15, true, MH><<<nblk(nb), 128, 0, c->stream>>>(st, st, B, imu, lo, mask, q[0], q[1], q[2], q[3], c->k, CorrArgs(), bc);
+  else if (c->ns == 15) k_step<15, true, MH><<<(nb + PB_STEP_BLOCK - 1) / PB_STEP_BLOCK, PB_STEP_BLOCK, 0, c->stream>>>(st, st, B, imu, lo, mask, q[0], q[1], q[2], q[3], c->k, bc);
+  else if (c->quad21) k_step_quad<true, MH><<<nblk(nb), 256, 0, c->stream>>>(st, st, B, imu, lo, mask, q[0], q[1], q[2], q[3], c->k, bc);
+  else k_step_coop<21, true, MH><<<nblk(nb), 128, 0, c->stream>>>(st, st, B, imu, lo, mask, q[0], q[1], q[2], q[3], c->k, CorrArgs(), bc);
+}
+int pbk_step_range(pb_ctx *c, const double *imu, const double *lo, const uint8_t *mask, const double q[4], long b0, int nb, bool coop15, int mem_hint)
+{
+  if (c->st != c->st_base || c->out_slot >= 0 || (c->B & 63) || (b0 & 63) || (nb & 63) || b0 + nb > c->B)
+    return fail(c, PB_ERR_STATE, "pbk_step_range: whole tiles of a head that lives in the context's own array");
+  const size_t tile_doubles = c->state_doubles / (size_t) (c->stride / 64);
+  double *st = c->st + (size_t) (b0 / 64) * tile_doubles;
+  const double *imu_b = imu + b0, *lo_b = lo + b0;
+  const uint8_t *mask_b = mask ? mask + b0 : nullptr;
+  switch (mem_hint) {
+  case MH_STORE_SC1: launch_range_mh<MH_STORE_SC1>(c, st, imu_b, lo_b, mask_b, q, nb, coop15); break;
+  case MH_STREAM_NT: launch_range_mh<MH_STREAM_NT>(c, st, imu_b, lo_b, mask_b, q, nb, coop15); break;
+  default: launch_range_mh<MH_DEFAULT>(c, st, imu_b, lo_b, mask_b, q, nb, coop15); break;
+  }
+  LAUNCHCHK(c);
+  return PB_OK;
+}
+
 int pbk_step(pb_ctx *c, bool update, const double *imu, const double *lo, const uint8_t *mask, const double q[4],
              const StepBcast *bcast)
 {

@@ -18,9 +18,17 @@ ns = [int(a) for a in sys.argv[1:]] or [15, 21]
 sizes = [int(a) for a in os.environ.get("SWEEP_SIZES", "32768,65536,131072,196608,262144,524288,1048576").split(",")]
 VARIANTS = {"default": {}, "coop0": {"PRONTO_BATCH_COOP15": "0"}, "coop1": {"PRONTO_BATCH_COOP15": "1"},
             "xcd0": {"PRONTO_BATCH_XCD": "0"}, "xcd1": {"PRONTO_BATCH_XCD": "1"},
-            "quad0": {"PRONTO_BATCH_QUAD21": "0"}, "mh0": {"PRONTO_BATCH_MEMHINT": "0"}, "mh1": {"PRONTO_BATCH_MEMHINT": "1"}, "mh2": {"PRONTO_BATCH_MEMHINT": "2"}}
+            "quad0": {"PRONTO_BATCH_QUAD21": "0"}, "mh0": {"PRONTO_BATCH_MEMHINT": "0"}, "mh1": {"PRONTO_BATCH_MEMHINT": "1"}, "mh2": {"PRONTO_BATCH_MEMHINT": "2"},
+            # launch order of run_legodo beyond the memory-side cache: "default" is the library's choice (blocked there), "unblocked"
+            # the step-by-step order over the whole batch, "blk<N>k" a named block size
+            "unblocked": {"PRONTO_BATCH_BLOCKED": "0"}, "blocked": {"PRONTO_BATCH_BLOCKED": "1"}}
+for _kb in (48, 64, 80, 96, 112, 128, 160, 192, 224, 256):
+    VARIANTS["blk%dk" % _kb] = {"PRONTO_BATCH_BLOCKED": "1", "PRONTO_BATCH_BLOCK_FILTERS": str(_kb * 1024)}
 variants = os.environ.get("SWEEP_VARIANTS", "default").split(",")
-K, B0 = 16, 4096
+# SWEEP_STEPS: steps per run_legodo call (distinct input blocks cycled).  The cache-blocked order runs a block of filters through ALL of
+# them before the next block starts, so its rate depends on the stream length: per block one cold read and one write-back of the
+# block's state are shared by K steps (K = 16: +10-16 % on top of K warm steps; a real replay has thousands of steps per call).
+K, B0 = int(os.environ.get("SWEEP_STEPS", "16")), 4096
 for n in ns:
     w = Workload(B0, n_states=n)
     vec, quat, P0 = w.initial_state()
@@ -48,7 +56,9 @@ for n in ns:
             reps = max(2, int(3e-2 / (K * B * bps / 5e12)))
             ms = min(sum(est.run_legodo(d_imu, d_lo, d_mask, q4, timed=True) for _ in range(reps)) / reps for _ in range(3))
             us = ms / K * 1e3
-            print("n=%d B=%8d %-8s %-24s %8.2f us  %6.0f GB/s  frac %.3f" % (n, B, v, est.hot_kernel(), us, bps * B / us / 1e3,
-                                                                         bps * B / us / 1e3 / 8000), flush=True)
+            rb = est.run_block()
+            print("n=%d B=%8d K=%3d %-9s %-24s %8.2f us  %6.0f GB/s  frac %.3f  %s" % (n, B, K, v, est.hot_kernel(), us, bps * B / us / 1e3,
+                                                                             bps * B / us / 1e3 / 8000,
+                                                                             ("blocked: %d filters per block" % rb) if rb else "step by step"), flush=True)
             est.close()
         del d_imu, d_lo, d_mask, tv, tq, tP

@@ -6,7 +6,7 @@
 #     the cache-busting 1M-filter run, the n=21 run, and the calibration copy (known bytes, same access pattern)
 #  3. the adjacent kernels, whole configurations and the smoother (trace + SQ/LDS counters); copy ceilings and sweeps
 set -o pipefail
-TAG=${1:-r04}
+TAG=${1:-r05}
 export TMPDIR=/tmp
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/prof_$TAG
@@ -58,7 +58,13 @@ smoother_pmc
 echo "smoother counters done"
 # ceilings and sweeps, not under the profiler
 hipcc -O3 --offload-arch=gfx950 -o /tmp/copybench scripts/copybench.hip && /tmp/copybench > $OUT/copybench.txt 2>&1
-python3 scripts/batch_sweep.py 15 21 > $OUT/batch_sweep.txt 2>&1
+# step by step over the whole batch (the rate a single launch gets at each size), then the launch ORDER of bulk replays beyond the
+# memory-side cache: the library's default (blocked) against step by step, with 64- and 256-step streams
+SWEEP_VARIANTS=unblocked python3 scripts/batch_sweep.py 15 21 > $OUT/batch_sweep.txt 2>&1
+for K in 64 256; do
+  SWEEP_STEPS=$K SWEEP_SIZES=524288,1048576 SWEEP_VARIANTS=unblocked,default python3 scripts/batch_sweep.py 15 >> $OUT/batch_sweep.txt 2>&1
+  SWEEP_STEPS=$K SWEEP_SIZES=262144,524288 SWEEP_VARIANTS=unblocked,default python3 scripts/batch_sweep.py 21 >> $OUT/batch_sweep.txt 2>&1
+done
 bash scripts/input_footprint.sh > $OUT/n21_input_footprint.txt 2>&1
 python3 bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
 # round 4: forward passes that keep every posterior (per-message into slots vs the write-through replay), the smoother with

@@ -640,6 +640,44 @@ def test_every_kernel_variant_is_bit_identical(pa, oracle, n, B, kern, monkeypat
             est.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,kern", [(15, "coop"), (15, "lane"), (21, "quad"), (21, "coop")])
+def test_cache_blocked_replay_is_bit_identical_to_the_step_by_step_order(pa, oracle, n, kern, monkeypatch):
+    """pb_run_legodo beyond the memory-side cache runs filter range outer / time inner over blocks of whole tiles (pb_create;
+    forced here on 1 024 filters in four blocks of 256 with PRONTO_BATCH_BLOCKED / _BLOCK_FILTERS).  The filters are independent:
+    with the same step kernel the blocked order must give the step-by-step order's head BIT FOR BIT, whatever the cache policy, and
+    both are the oracle's."""
+    import torch
+    B, T = 1024, 12
+    dev = torch.device("cuda:0")
+    w = Workload(B, n_states=n)
+    q4 = w.process_noise()
+    imu, lo, mask = w.streams(0, T)
+    d = [torch.from_numpy(a).to(dev) for a in (imu, lo, mask)]
+    monkeypatch.setenv("PRONTO_BATCH_COOP15", "1" if kern == "coop" else "0")
+    monkeypatch.setenv("PRONTO_BATCH_QUAD21", "1" if kern == "quad" else "0")
+    heads = {}
+    for blocked in ("0", "1"):
+        for hint in (("0", "1", "2") if blocked == "1" else ("0",)):
+            monkeypatch.setenv("PRONTO_BATCH_BLOCKED", blocked)
+            monkeypatch.setenv("PRONTO_BATCH_BLOCK_FILTERS", "320")
+            monkeypatch.setenv("PRONTO_BATCH_MEMHINT", hint)
+            est, ob = make_pair(pa, oracle, w, dense_p0=5)
+            assert est.run_block() == (256 if blocked == "1" else 0)
+            est.run_legodo(*d, q4)
+            est.run_legodo(*d, q4)          # (twice: the second call starts from a head the blocked order left)
+            heads[(blocked, hint)] = est.get_head()
+            if blocked == "0":
+                for _ in range(2):
+                    ob.run_legodo(imu, lo, mask, q4)
+                check(est, ob)
+            est.close()
+    ref = heads[("0", "0")]
+    for key, head in heads.items():
+        for a, b in zip(head, ref):
+            assert np.array_equal(a, b), key
+
+
 @pytest.mark.parametrize("n,default_kernels", [(15, True), (21, True), (15, False), (21, False)])
 def test_broadcast_inputs_equal_replicated_blocks(pa, oracle, n, default_kernels, monkeypatch):
     """PB_HOST_BROADCAST: one message for every filter of the batch (a parameter sweep replaying one robot's log) passed
