@@ -440,6 +440,23 @@ int pb_state_restore(pb_ctx *ctx, int slot);   /* head posterior <- slot */
  * kernel with Eigen's pivoting. */
 int pb_smooth_step(pb_ctx *ctx, int slot_next_pred, int slot_next, int slot_cur, int slot_out, double dt);
 
+/* EKFSmoothBackwardsPass over a WHOLE log with bounded memory (mav_state_est.cpp:98-189, lcm_front_end.cpp:168-203: the reference's
+ * "-S" smooths the entire log; it keeps three posteriors per step by value, which for a batch is 2 T slots of the whole state).
+ * Checkpoint and recompute: the forward pass filters the n_steps steps of the streams (as pb_run_legodo takes them; per step the
+ * process step, then the velocity update -- the per-message kernels of pb_predict / pb_update_indexed) from the current head and
+ * keeps only the posterior in front of every `stride`-th step; the backward pass re-runs the log stretch by stretch, newest
+ * first, into a window of 2 * stride slots and applies pb_smooth_step to every step but the newest.  It uses the checkpoint slots
+ * [first_slot, first_slot + pb_smooth_log_slots(n_steps, stride)) = n_steps / stride + 2 * stride + 4 slots instead of 2 * n_steps
+ * (stride near sqrt(n_steps / 2) is the minimum).  sink(user, step, slot) is called, newest step first, once the smoother step
+ * of `step` has been ENQUEUED: `slot` holds the smoothed posterior of that step until the NEXT call of the sink returns; read it with
+ * stream-ordered calls that leave the head alone (pb_get_slot, pb_snapshot_from_slot).  The smoothed posteriors are, bit for bit,
+ * those of the all-checkpoints pass (pb_set_output_slot per update + pb_smooth_step).  Afterwards the head is the newest filtered
+ * posterior.  dt as pb_smooth_step.  elapsed_ms != NULL: device time of the whole call (forward + backward). */
+typedef void (*pb_smooth_sink)(void *user, int step, int slot);
+int pb_smooth_log_slots(int n_steps, int stride);
+int pb_smooth_log(pb_ctx *ctx, int n_steps, int stride, const double *imu_stream, const double *lo_stream, const uint8_t *mask_stream,
+                  const double q[4], double dt, int first_slot, pb_smooth_sink sink, void *user, float *elapsed_ms);
+
 /* ---- estimator queries (mav_state_est.hpp:20-22) -------------------------------------------------------- */
 
 /* MavStateEstimator::getHeadState + getMeasurementsLogLikelihood for filters [first, first+count):
@@ -448,6 +465,9 @@ int pb_smooth_step(pb_ctx *ctx, int slot_next_pred, int slot_next, int slot_cur,
 int pb_get_head(pb_ctx *ctx, int first, int count, double *vec_out, double *quat_out, double *cov_out,
                 double *ll_out, int mem);
 /* rbisCreateFilterStateMessageCPP (rbis.cpp:287-304) for one filter: quat[4], state[21], cov[441] (host). */
+/* the same read of a posterior that lives in checkpoint slot `slot` (the head stays what it is) */
+int pb_get_slot(pb_ctx *ctx, int slot, int first, int count, double *vec_out, double *quat_out, double *cov_out, double *loglik_out,
+                int mem);
 int pb_get_filter_state(pb_ctx *ctx, int filter, double quat[4], double state[21], double cov[441]);
 /* per-shard run summary for the end-of-run all-reduce:
  * out[0] = sum loglik, out[1] = sum |vec| + |quat| (checksum), out[2] = max | |quat|^2 - 1 |,

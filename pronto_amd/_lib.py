@@ -70,6 +70,10 @@ _SIGS = {
     "pb_ins_body_block": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, _dp, _dp,
                                     C.c_double, C.c_int, C.c_int, C.c_void_p]),
     "pb_ins_body_reset": (C.c_int, [C.c_void_p]),
+    "pb_get_slot": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "pb_smooth_log_slots": (C.c_int, [C.c_int, C.c_int]),
+    "pb_smooth_log": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, _dp, C.c_double, C.c_int, C.c_void_p, C.c_void_p,
+                                C.POINTER(C.c_float)]),
     "pb_set_head": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "pb_predict": (C.c_int, [C.c_void_p, C.c_void_p, _dp, C.c_int]),
     "pb_update_indexed": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_void_p, C.c_void_p, C.c_int,

@@ -139,6 +139,40 @@ class BatchEstimator:
     def smooth_step(self, slot_next_pred, slot_next, slot_cur, slot_out, dt):
         self._chk(self._L.pb_smooth_step(self._h, slot_next_pred, slot_next, slot_cur, slot_out, dt))
 
+    def smooth_log_slots(self, n_steps, stride):
+        return self._L.pb_smooth_log_slots(n_steps, stride)
+
+    def smooth_log(self, imu_stream, lo_stream, mask_stream, q4, dt, stride, first_slot=0, sink=None, timed=False):
+        """Whole-log RTS smoothing with bounded memory (checkpoint and recompute): sink(step, slot) is called newest step first; read the
+        slot with get_slot before returning from the sink.  Returns device ms if timed."""
+        T = imu_stream.shape[0]
+        pi, m1 = _ptr(imu_stream, shape=(T, 7, self.B))
+        pl, m2 = _ptr(lo_stream, shape=(T, 6, self.B))
+        pm, m3 = _ptr(mask_stream, np.uint8, shape=(T, self.B))
+        if _same_mem(m1, m2, m3) != PB_DEVICE:
+            raise ValueError("smooth_log needs device-resident streams")
+        q = (C.c_double * 4)(*q4)
+        ms = C.c_float(0)
+        SINK = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int)
+        cb = SINK((lambda user, step, slot: sink(step, slot))) if sink is not None else None
+        self._chk(self._L.pb_smooth_log(self._h, T, stride, pi, pl, pm, q, dt, first_slot, C.cast(cb, C.c_void_p) if cb else None, None,
+                                        C.byref(ms) if timed else None))
+        return ms.value if timed else None
+
+    def get_slot(self, slot, first=0, count=None, want_cov=True):
+        """get_head for a posterior that lives in a checkpoint slot."""
+        count = self.B - first if count is None else count
+        n = self.n
+        vec = np.empty((n, count))
+        quat = np.empty((4, count))
+        ll = np.empty(count)
+        cov = np.empty((n, n, count)) if want_cov else None
+        self._chk(self._L.pb_get_slot(self._h, slot, first, count, C.c_void_p(vec.ctypes.data), C.c_void_p(quat.ctypes.data),
+                                      C.c_void_p(cov.ctypes.data) if want_cov else None, C.c_void_p(ll.ctypes.data), PB_HOST))
+        if want_cov:
+            cov = np.swapaxes(cov, 0, 1)
+        return vec, quat, cov, ll
+
     # --- noise identification ---
     def set_process_noise_block(self, q_block):
         """q_block: torch CUDA tensor [4,B] (kept alive by the caller) or None."""

@@ -838,10 +838,17 @@ public:
   // EKFSmoothBackwardsPass (mav_state_est.cpp:98-189): walk the history backwards; at every INS update k apply
   // ekfSmoothingStep with  next_pred = posterior of INS_{k+1},  next = smoothed posterior of step k+1 (for the newest
   // step: its last measurement's posterior),  cur = posterior of the last measurement that followed INS_k (or INS_k's
-  // own when none did).  Needs a checkpoint on every update of the window (history_checkpoint_every = 1) and two
-  // spare checkpoint slots.  The reference overwrites the updates' posteriors with the smoothed ones for later
-  // republishing; here on_smoothed(utime of INS_k, slot) is called newest-first with a slot that holds the smoothed
-  // posterior until the next call (pb_state_restore(slot) + getHeadState reads it).  Returns the number of steps.
+  // own when none did).  The reference reads these posteriors out of its update objects, which keep them by value; here a
+  // posterior exists where an update has a CHECKPOINT slot.  With a checkpoint on every update of the window
+  // (history_checkpoint_every = 1) the pass only reads; with sparser checkpoints -- the only way a long window of a big batch
+  // fits the device: 64k 21-state filters are 135 MB per posterior -- it re-derives what is missing, stretch by stretch from the
+  // newest: the updates between two checkpoints are re-applied from the older one into a window of free slots (checkpoint and
+  // recompute: history_slots >= window / every + every + 3 instead of one per update; pb_smooth_log is the same idea for device
+  // streams).  The smoothed posteriors are bit for bit those of the all-checkpoints pass.
+  // The reference overwrites the updates' posteriors with the smoothed ones for later republishing; here
+  // on_smoothed(utime of INS_k, slot) is called newest-first with a slot that holds the smoothed posterior until the next call
+  // (pb_get_slot reads it; pb_state_restore(slot) + getHeadState too).  Returns the number of steps, -1 on an error.
+  int64_t smoother_reapplied_updates = 0;   // statistics: updates re-applied to re-derive posteriors that had no checkpoint
   int EKFSmoothBackwardsPass(double dt, const std::function<void(int64_t, int)> &on_smoothed)
   {
     auto &map = history.updateMap;
@@ -849,44 +856,82 @@ public:
       fprintf(stderr, "EKFSmoothBackwardsPass: needs the posterior of every INS update; run with state_estimator.fuse_ins_legodo = false\n");
       return -1;
     }
-    if (free_slots.size() < 2) {
-      fprintf(stderr, "EKFSmoothBackwardsPass: needs 2 free checkpoint slots (state_estimator.history_slots)\n");
+    flushPending();
+    // time-ordered list of (update, slot or -1)
+    std::vector<std::pair<RBISUpdateInterface *, int>> seq;
+    for (auto u = map.begin(); u != unprocessed_updates_start; ++u) {
+      auto it = checkpoint_of.find(u->second);
+      seq.push_back({ u->second, it == checkpoint_of.end() ? -1 : it->second });
+    }
+    const int N = (int) seq.size();
+    if (N == 0 || seq[0].second < 0) {
+      fprintf(stderr, "EKFSmoothBackwardsPass: the oldest update of the history has no checkpoint (state_estimator.history_slots = 0?)\n");
       return -1;
     }
-    const int spare[2] = { free_slots[free_slots.size() - 1], free_slots[free_slots.size() - 2] };
-    // time-ordered list of (update, slot); every update must be checkpointed
-    std::vector<std::pair<RBISUpdateInterface *, int>> seq;
-    for (auto &kv : map) {
-      auto it = checkpoint_of.find(kv.second);
-      if (it == checkpoint_of.end()) {
-        fprintf(stderr, "EKFSmoothBackwardsPass: update at %jd has no checkpoint (set history_checkpoint_every = 1)\n",
-                (intmax_t) kv.first);
-        return -1;
-      }
-      seq.push_back({ kv.second, it->second });
+    std::vector<int> ins, cks;
+    for (int i = 0; i < N; i++) {
+      if (seq[(size_t) i].first->sensor_id == RBISUpdateInterface::ins) ins.push_back(i);
+      if (seq[(size_t) i].second >= 0) cks.push_back(i);
     }
-    // indices of INS updates, and for each the slot of the filtered posterior of its step
-    std::vector<int> ins;
-    for (int i = 0; i < (int) seq.size(); i++)
-      if (seq[i].first->sensor_id == RBISUpdateInterface::ins) ins.push_back(i);
     if (ins.size() < 2) return 0;
-    auto filt_slot = [&](int j) {  // last update before the next INS (or the end)
-      const int stop = (j + 1 < (int) ins.size()) ? ins[j + 1] : (int) seq.size();
-      return seq[stop - 1].second;
+    // the longest run of updates without a checkpoint decides the window
+    int maxgap = N - 1 - cks.back();
+    for (size_t m = 0; m + 1 < cks.size(); m++) maxgap = std::max(maxgap, cks[m + 1] - cks[m] - 1);
+    const bool head_loose = seq.back().second < 0;   // the newest posterior exists only as the device head
+    const int need = maxgap + 2 + ((maxgap > 0 || head_loose) ? 1 : 0);
+    if ((int) free_slots.size() < need) {
+      fprintf(stderr, "EKFSmoothBackwardsPass: needs %d free checkpoint slots (two for the smoothed posteriors%s), %zu are free: raise "
+                      "state_estimator.history_slots or lower history_checkpoint_every\n",
+              need, maxgap > 0 ? ", the longest run of updates without a checkpoint and one for the head" : "", free_slots.size());
+      return -1;
+    }
+    const size_t nf = free_slots.size();
+    const int spare[2] = { free_slots[nf - 1], free_slots[nf - 2] };
+    const int head_keep = (maxgap > 0 || head_loose) ? free_slots[nf - 3] : -1;
+    auto W = [&](int i) { return free_slots[nf - 4 - (size_t) i]; };   // window slots
+    int rc = PB_OK;
+    auto bail = [&](const char *what) {
+      last_status = rc;
+      fprintf(stderr, "EKFSmoothBackwardsPass: %s: %s\n", what, pb_last_error(ctx));
+      return -1;
     };
-    int next_pred = seq[ins.back()].second, next = filt_slot((int) ins.size() - 1), steps = 0;
-    for (int j = (int) ins.size() - 2; j >= 0; j--) {
-      const int out = spare[steps & 1];
-      int rc = pb_smooth_step(ctx, next_pred, next, filt_slot(j), out, dt);
-      if (rc != PB_OK) {
-        last_status = rc;
-        fprintf(stderr, "EKFSmoothBackwardsPass: %s\n", pb_last_error(ctx));
+    if (head_keep >= 0) {
+      if (device_head != seq.back().first) {
+        fprintf(stderr, "EKFSmoothBackwardsPass: the device does not hold the newest posterior (call it right after addUpdate)\n");
         return -1;
       }
-      if (on_smoothed) on_smoothed(seq[ins[j]].first->utime, out);
-      next = out;
-      next_pred = seq[ins[j]].second;
-      steps++;
+      if ((rc = pb_state_save(ctx, head_keep)) != PB_OK) return bail("saving the head");
+    }
+    int next = head_loose ? head_keep : seq.back().second, steps = 0, toggle = 0;
+    int j = (int) ins.size() - 2;   // the step being smoothed: needs the posteriors of updates ins[j+1] - 1 and ins[j+1]
+    // stretches (a, e]: a = a checkpointed update, e = the next checkpointed update (or the newest update)
+    for (int m = (int) cks.size() - 1; m >= 0 && j >= 0; m--) {
+      const int a = cks[(size_t) m], e = (m + 1 < (int) cks.size()) ? cks[(size_t) m + 1] : N - 1;
+      if (ins[(size_t) j + 1] <= a) continue;          // (no INS update in this stretch)
+      const int last_missing = (seq[(size_t) e].second >= 0) ? e - 1 : e;
+      if (last_missing > a) {                          // re-derive the posteriors of a+1 .. last_missing into the window
+        if ((rc = pb_state_restore(ctx, seq[(size_t) a].second)) != PB_OK) return bail("restoring a checkpoint");
+        for (int i = a + 1; i <= last_missing; i++) {
+          pb_set_output_slot(ctx, W(i - a - 1));
+          if ((rc = seq[(size_t) i].first->updateFilter(ctx)) != PB_OK) return bail("re-applying an update");
+          smoother_reapplied_updates++;
+        }
+      }
+      auto slot_at = [&](int i) { return seq[(size_t) i].second >= 0 ? seq[(size_t) i].second : W(i - a - 1); };
+      while (j >= 0 && ins[(size_t) j + 1] > a) {
+        const int ip = ins[(size_t) j + 1];
+        const int out = spare[toggle];
+        if ((rc = pb_smooth_step(ctx, slot_at(ip), next, slot_at(ip - 1), out, dt)) != PB_OK) return bail("smoother step");
+        if (on_smoothed) on_smoothed(seq[(size_t) ins[(size_t) j]].first->utime, out);
+        next = out;
+        toggle ^= 1;
+        steps++;
+        j--;
+      }
+    }
+    if (head_keep >= 0) {
+      if ((rc = pb_state_restore(ctx, head_keep)) != PB_OK) return bail("putting the head back");   // the newest posterior again
+      pb_set_utime(ctx, head_utime);
     }
     device_head = nullptr;  // callers may have restored slots into the head: force a restore on the next replay
     return steps;

@@ -801,11 +801,26 @@ extern "C" int pb_compose_delta(pb_ctx *c, int slot, const double *t, const doub
   return PB_OK;
 }
 
+static int get_state_impl(pb_ctx *c, const double *st, int first, int count, double *vec_out, double *quat_out, double *cov_out, double *ll_out, int mem);
+
 extern "C" int pb_get_head(pb_ctx *c, int first, int count, double *vec_out, double *quat_out, double *cov_out,
                            double *ll_out, int mem)
 {
   ENTER(c);
   NEED_STATE(c);
+  return get_state_impl(c, c->st, first, count, vec_out, quat_out, cov_out, ll_out, mem);
+}
+
+// the same read of a posterior that lives in a checkpoint slot (the head is not touched)
+extern "C" int pb_get_slot(pb_ctx *c, int slot, int first, int count, double *vec_out, double *quat_out, double *cov_out, double *ll_out, int mem)
+{
+  ENTER(c);
+  if (slot < 0 || slot >= c->nhist) return fail(c, PB_ERR_STATE, "pb_get_slot: checkpoint slot %d of %d", slot, c->nhist);
+  return get_state_impl(c, c->hist + (size_t) slot * c->state_doubles, first, count, vec_out, quat_out, cov_out, ll_out, mem);
+}
+
+static int get_state_impl(pb_ctx *c, const double *st, int first, int count, double *vec_out, double *quat_out, double *cov_out, double *ll_out, int mem)
+{
   if (first < 0 || count < 0 || (long) first + count > c->B) return fail(c, PB_ERR_ARG, "pb_get_head: range [%d,+%d) outside batch %d", first, count, c->B);
   if (count == 0) return PB_OK;
   const int n = c->ns;
@@ -827,8 +842,8 @@ extern "C" int pb_get_head(pb_ctx *c, int first, int count, double *vec_out, dou
   } else if (mem != PB_DEVICE) {
     return fail(c, PB_ERR_ARG, "mem must be PB_HOST or PB_DEVICE");
   }
-  if (n == 15) k_get_head<15><<<nblk(count), 64, 0, c->stream>>>(c->st, first, count, dv, dq, dc, dl);
-  else k_get_head<21><<<nblk(count), 64, 0, c->stream>>>(c->st, first, count, dv, dq, dc, dl);
+  if (n == 15) k_get_head<15><<<nblk(count), 64, 0, c->stream>>>(st, first, count, dv, dq, dc, dl);
+  else k_get_head<21><<<nblk(count), 64, 0, c->stream>>>(st, first, count, dv, dq, dc, dl);
   LAUNCHCHK(c);
   if (mem == PB_HOST) {
     if (vec_out) HIPCHK(c, hipMemcpyAsync(vec_out, dv, sizeof(double) * n * count, hipMemcpyDeviceToHost, c->stream));
@@ -1771,6 +1786,89 @@ extern "C" int pb_smooth_step(pb_ctx *c, int slot_next_pred, int slot_next, int 
   const double *cu = c->hist + (size_t) slot_cur * n;
   double *out = c->hist + (size_t) slot_out * n;
   return pbk_smooth_step(c, np_, ns_, cu, out, dt);
+}
+
+// ---- whole-log RTS smoothing with bounded memory: checkpoint and recompute ----
+// EKFSmoothBackwardsPass (mav_state_est.cpp:98-189) walks the WHOLE history backwards and reads, at every INS update, three
+// posteriors the reference keeps by value in its update objects.  For a batch that is 2 T slots of the whole state (64k 21-state
+// filters: 135 MB each -- one second of a 1 kHz log fills 288 GB).  Here the forward pass keeps only every `stride`-th posterior;
+// the backward pass takes the log stretch by stretch, newest first: it re-runs the stretch's steps from its checkpoint into a
+// window of 2 * stride slots (the posterior of every process step AND of the update behind it, with the very kernels the
+// per-message path runs: pb_predict, pb_update_indexed) and smooths it with the smoother step.  Slots: T / stride + 2 stride + 4.
+extern "C" int pb_smooth_log_slots(int n_steps, int stride)
+{
+  if (n_steps < 1 || stride < 1) return -1;
+  return (n_steps + stride - 1) / stride + 2 * stride + 4;
+}
+
+extern "C" int pb_smooth_log(pb_ctx *c, int n_steps, int stride, const double *imu_stream, const double *lo_stream, const uint8_t *mask_stream,
+                             const double q[4], double dt, int first_slot, pb_smooth_sink sink, void *user, float *elapsed_ms)
+{
+  ENTER(c);
+  NEED_STATE(c);
+  if (n_steps < 1 || stride < 1 || !imu_stream || !lo_stream || !q) return fail(c, PB_ERR_ARG, "pb_smooth_log: bad argument");
+  const int K = stride, T = n_steps, M = (T + K - 1) / K, need = pb_smooth_log_slots(T, K);
+  if (first_slot < 0 || first_slot + need > c->nhist)
+    return fail(c, PB_ERR_STATE, "pb_smooth_log: needs checkpoint slots [%d, %d), %d are reserved (pb_history_reserve)", first_slot, first_slot + need, c->nhist);
+  const size_t B = (size_t) c->B, n = c->state_doubles;
+  const int CK = first_slot, WP = CK + M, WF = WP + K, PC = WF + K, FIN = PC + 1, SP = FIN + 1;   // checkpoints | window | carry | final | ping-pong
+  auto slot_ptr = [&](int sl) { return c->hist + (size_t) sl * n; };
+  static const int idx_v[3] = { 3, 4, 5 };
+  // one step of the log exactly as the per-message path applies it: the process step, then LegOdoCommon's lin_rate update
+  // (pred_slot / filt_slot < 0: in place)
+  auto step = [&](int j, int pred_slot, int filt_slot) -> int {
+    c->out_slot = pred_slot;
+    int rc = pbk_step(c, false, imu_stream + (size_t) j * 7 * B, nullptr, nullptr, q);
+    if (rc) return rc;
+    c->out_slot = filt_slot;
+    return update_common(c, 3, idx_v, lo_stream + (size_t) j * 6 * B, lo_stream + (size_t) j * 6 * B + 3 * B, PB_R_DIAG, nullptr, false,
+                         mask_stream ? mask_stream + (size_t) j * B : nullptr, PB_DEVICE);
+  };
+  if (elapsed_ms) HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+  int rc = detach_head(c, true);
+  if (rc) return rc;
+  // ---- forward: the filter, a checkpoint in front of every stretch ----
+  for (int j = 0; j < T; j++) {
+    if (j % K == 0) {
+      rc = pb_state_save(c, CK + j / K);
+      if (rc) return rc;
+    }
+    rc = step(j, -1, -1);
+    if (rc) return rc;
+  }
+  rc = pb_state_save(c, FIN);   // the newest posterior: its own smoothed value (and the head again when the pass is over)
+  if (rc) return rc;
+  // ---- backward: stretch by stretch ----
+  int next_sm = FIN, toggle = 0;
+  for (int m = M - 1; m >= 0; m--) {
+    const int s0 = m * K, s1 = std::min(T, s0 + K) - 1;
+    c->st = slot_ptr(CK + m);   // the head lives in the checkpoint: the first process step reads it there and writes into the window
+    c->out_slot = -1;
+    for (int j = s0; j <= s1; j++) {
+      rc = step(j, WP + (j - s0), WF + (j - s0));
+      if (rc) return rc;
+    }
+    for (int j = s1; j >= s0; j--) {
+      if (j == T - 1) continue;   // (the newest step is not smoothed: mav_state_est.cpp:120-131 starts one step behind it)
+      const int np = (j == s1) ? PC : WP + (j + 1 - s0);
+      const int out = SP + toggle;
+      rc = pbk_smooth_step(c, slot_ptr(np), slot_ptr(next_sm), slot_ptr(WF + (j - s0)), slot_ptr(out), dt);
+      if (rc) return rc;
+      if (sink) sink(user, j, out);
+      next_sm = out;
+      toggle ^= 1;
+    }
+    // the earlier stretch's last step needs the process-step posterior of THIS stretch's first step
+    HIPCHK(c, hipMemcpyAsync(slot_ptr(PC), slot_ptr(WP), sizeof(double) * n, hipMemcpyDeviceToDevice, c->stream));
+  }
+  rc = pb_state_restore(c, FIN);
+  if (rc) return rc;
+  if (elapsed_ms) {
+    HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+    HIPCHK(c, hipEventSynchronize(c->ev1));
+    HIPCHK(c, hipEventElapsedTime(elapsed_ms, c->ev0, c->ev1));
+  }
+  return PB_OK;
 }
 
 static int calib_copy_impl(pb_ctx *c, int reps, float *elapsed_ms, uint64_t *checksum)

@@ -53,6 +53,8 @@ smoother_trace
 # leg kinematic odometry: per-filter inputs (kernel rates), then the handler API end to end (one log for every filter)
 python3 scripts/leg_rates.py > $OUT/leg_rates.txt 2> $OUT/leg_rates.err
 bash scripts/shim_rate.sh $OUT/shim > $OUT/shim.log 2>&1
+python3 scripts/smooth_log_rate.py > $OUT/smooth_log.txt 2>&1
+bash scripts/segment_rate.sh $OUT/segment_rate.txt > $OUT/segment_rate.log 2>&1
 echo "adjacent kernels done"
 smoother_pmc
 echo "smoother counters done"

@@ -68,6 +68,20 @@ def test_smooth_backwards_pass_on_gpu(oracle, n, kernel):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("n", [15, 21])
+@pytest.mark.parametrize("every", [3, 7])
+def test_smooth_backwards_pass_with_sparse_checkpoints_on_gpu(oracle, n, every):
+    """EKFSmoothBackwardsPass when the history does not fit a posterior per update (what the reference keeps by value): with
+    state_estimator.history_checkpoint_every = K only every K-th update has a checkpoint and the pass re-derives the others stretch
+    by stretch, newest first, by re-applying the updates between two checkpoints into a window of free slots (checkpoint and
+    recompute).  60 steps (100 updates) in 2 T / K + K + 8 slots; every smoothed step against the oracle's recursion."""
+    exe = build_exe(oracle, "test_smooth_pass")
+    r = subprocess.run([exe, str(n), str(every)], capture_output=True, text=True, timeout=300)
+    print(r.stdout, r.stderr)
+    assert r.returncode == 0 and "PASS" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [15, 21])
 def test_lcm_log_replay_and_filter_state_publishing_on_gpu(oracle, tmp_path, n):
     """A recorded LCM event log (pronto::indexed_measurement_t, pronto::update_t, raw IMU ticks, foreign channels)
     replayed into the batch through LogPlayer + the reference's handlers vs the oracle; the head published as

@@ -245,3 +245,121 @@ def test_mfma_f64_lane_maps(tmp_path):
                     os.path.join(root, "scripts", "mfma_f64_probe.hip"), "-o", exe], check=True, timeout=300)
     out = subprocess.run([exe], check=True, timeout=120, capture_output=True, text=True).stdout
     assert "lane maps" in out and "(OK)" in out, out
+
+
+@pytest.mark.parametrize("n", [15, 21])
+def test_smooth_log_equals_the_all_checkpoints_pass_bit_for_bit(oracle, n):
+    """pb_smooth_log -- EKFSmoothBackwardsPass over a whole log with bounded memory (checkpoint and recompute: the forward pass keeps
+    the posterior in front of every 7th step, the backward pass re-runs the log stretch by stretch into a window of 14 slots) --
+    against the all-checkpoints pass (a slot per update, 2 T slots): the same smoothed posterior at every step, BIT FOR BIT, and the
+    oracle's backward recursion within TOL.  50 steps in stretches of 7: a last stretch of one step, boundaries inside the log."""
+    import torch
+    from pronto_amd.batch import BatchEstimator
+    B, T, K, dt = 37, 50, 7, 1e-3
+    dev = torch.device("cuda:0")
+    w = Workload(B, n_states=n)
+    vec, quat, P0, q4 = start_of(w)
+    imu, lo, mask = w.streams(0, T)
+    # the all-checkpoints pass: every process-step posterior and every update posterior in a slot of its own
+    ref = BatchEstimator(B, n_states=n)
+    ref.set_constants(*oracle.constants())
+    ref.reset(vec, quat, P0)
+    ref.history_reserve(2 * T + 2)
+    for k in range(T):
+        ref.set_output_slot(2 * k)
+        ref.predict(imu[k], q4)
+        ref.set_output_slot(2 * k + 1)
+        ref.update_indexed([3, 4, 5], np.ascontiguousarray(lo[k][0:3]), np.ascontiguousarray(lo[k][3:6]), mask=mask[k])
+    want = {}
+    nxt = 2 * (T - 1) + 1
+    for k in range(T - 2, -1, -1):
+        out = 2 * T + (k % 2)
+        ref.smooth_step(2 * (k + 1), nxt, 2 * k + 1, out, dt)
+        want[k] = ref.get_slot(out)
+        nxt = out
+    final = ref.get_slot(2 * (T - 1) + 1)
+    ref.close()
+    # checkpoint and recompute
+    est = BatchEstimator(B, n_states=n)
+    est.set_constants(*oracle.constants())
+    est.reset(vec, quat, P0)
+    need = est.smooth_log_slots(T, K)
+    assert need == (T + K - 1) // K + 2 * K + 4 and need < 2 * T
+    est.history_reserve(need + 1)
+    got, order = {}, []
+
+    def sink(step, slot):
+        order.append(step)
+        got[step] = est.get_slot(slot)
+    est.smooth_log(*(torch.from_numpy(a).to(dev) for a in (imu, lo, mask)), q4, dt, K, first_slot=1, sink=sink)
+    assert order == list(range(T - 2, -1, -1))
+    for k in range(T - 1):
+        for a, b in zip(got[k], want[k]):
+            assert np.array_equal(a, b), k
+    for a, b in zip(est.get_head(), final):      # the head afterwards: the newest filtered posterior
+        assert np.array_equal(a, b)
+    # ... and the oracle's recursion
+    keep = {0, 1, K - 1, K, 3 * K, T - 3, T - 2}
+    ora = oracle_backward_pass(oracle, w, n, T, B, dt, keep)
+    worst = 0.0
+    for k in keep:
+        v, q, P, _ = got[k]
+        worst = max(worst, rel(v, ora[k][0][:n]), rel(q, ora[k][1]), rel(P, ora[k][2][:n, :n]))
+    assert worst < TOL, worst
+    est.close()
+
+
+def test_whole_log_smoothing_of_10000_steps_with_bounded_memory(oracle):
+    """The reference's "-S" smooths the ENTIRE log (fusion.cpp:268-269, lcm_front_end.cpp:168-203).  10 000 steps x 4 096 15-state
+    filters would need 20 000 posterior slots (92 GB) with a slot per update; pb_smooth_log runs it in 157 + 128 + 4 = 289 slots
+    (1.3 GB).  Sampled filters at sampled steps -- the ends of the log, both sides of stretch boundaries -- against the oracle's
+    forward + backward recursion over the same 10 000 steps of the same inputs (copied back from the device streams)."""
+    import torch
+    from pronto_amd.batch import BatchEstimator
+    from pronto_amd.synth_device import DeviceWorkload
+    from util import embed21
+    n, B, T, K, dt = 15, 4096, 10000, 64, 1e-3
+    dw = DeviceWorkload(B, n_states=n, device="cuda:0")
+    w = dw.host
+    vec, quat, P0 = w.initial_state()
+    q4 = w.process_noise()
+    d_imu, d_lo, d_mask = dw.streams(0, T)
+    est = BatchEstimator(B, n_states=n)
+    est.set_constants(*oracle.constants())
+    est.reset(vec, quat, P0)
+    need = est.smooth_log_slots(T, K)
+    assert need == 289
+    est.history_reserve(need)
+    filters = [0, 2049, B - 1]
+    steps = {0, 1, K - 1, K, K + 1, 5000, T - K - 1, T - K, T - 3, T - 2}
+    got = {}
+
+    def sink(step, slot):
+        if step in steps:
+            got[step] = [est.get_slot(slot, first=b, count=1) for b in filters]
+    ms = est.smooth_log(d_imu, d_lo, d_mask, q4, dt, K, sink=sink, timed=True)
+    print("pb_smooth_log: %d steps x %d filters, stride %d, %d slots: %.0f ms = %.3f us per smoothed filter-step (forward + recompute + smoother)"
+          % (T, B, K, need, ms, ms * 1e3 / (T * B)))
+    assert sorted(got) == sorted(steps)
+    # the oracle on the sampled filters: forward pass keeping (pred, filtered), then the backward recursion
+    sel = torch.tensor(filters, device=d_imu.device)
+    imu, lo, mask = (t.index_select(t.dim() - 1, sel).cpu().numpy() for t in (d_imu, d_lo, d_mask))
+    v21, P21 = embed21(np.ascontiguousarray(vec[:, filters]), np.ascontiguousarray(P0[:, :, filters]))
+    ob = oracle.OracleBatch(v21, np.ascontiguousarray(quat[:, filters]), P21)
+    hist = []
+    for k in range(T):
+        ob.predict(np.ascontiguousarray(imu[k]), q4)
+        pred = (ob.vec.copy(), ob.quat.copy(), ob.cov.copy())
+        ob.update_indexed([3, 4, 5], np.ascontiguousarray(lo[k][0:3]), np.ascontiguousarray(lo[k][3:6]), mask=np.ascontiguousarray(mask[k]))
+        hist.append((pred, (ob.vec.copy(), ob.quat.copy(), ob.cov.copy())))
+    nxt = hist[T - 1][1]
+    worst = 0.0
+    for k in range(T - 2, -1, -1):
+        nxt = oracle_smooth_step(oracle, hist[k + 1][0], nxt, hist[k][1], dt)
+        if k in steps:
+            for i in range(len(filters)):
+                v, q, P, _ = got[k][i]
+                worst = max(worst, rel(v[:, 0], nxt[0][:n, i]), rel(q[:, 0], nxt[1][:, i]), rel(P[:, :, 0], nxt[2][:n, :n, i]))
+    print("worst relative error against the oracle at %d sampled (step, filter) pairs: %.2e" % (len(steps) * len(filters), worst))
+    assert worst < TOL, worst
+    est.close()
