@@ -27,7 +27,8 @@
 
 // attribution builds (scripts/smooth_attribution.sh lane...): parts compiled OUT, results are garbage, only the time means something
 #if !defined(PB_EXPERIMENTS) && (defined(SML_SKIP_FACT) || defined(SML_SKIP_RHS) || defined(SML_SKIP_SUBST) || defined(SML_SKIP_D) || \
-                                 defined(SML_SKIP_M) || defined(SML_SKIP_FINAL) || defined(SML_SKIP_CHUNKS) || defined(SML_NO_PKLOAD) || defined(SML_NO_PSTORE) || defined(SML_TIMELINE))
+                                 defined(SML_SKIP_M) || defined(SML_SKIP_FINAL) || defined(SML_SKIP_CHUNKS) || defined(SML_NO_PKLOAD) || defined(SML_NO_PSTORE) || defined(SML_TIMELINE) || \
+                                 defined(SML_WIDE))
 #error "the SML_* attribution flags need -DPB_EXPERIMENTS as well"
 #endif
 
@@ -134,8 +135,21 @@ __global__ __launch_bounds__(SmoothLaneCfg<NS>::THREADS, SmoothLaneCfg<NS>::WAVE
     int o[NS];
 #pragma unroll
     for (int i = 0; i < NS; i++) o[i] = tab.col[w][t][i];
+#ifdef SML_WIDE   // attribution (round 5): the SAME loads as whole 16-byte rows -- every byte of every 128-byte line the instruction touches is
+                  // fetched by it, where the 8-byte access at a 16-byte stride uses half of each.  Results are garbage.
+#pragma unroll
+    for (int i = 0; i < NS; i++) {
+      if (i >= i0) {
+        const d2_t r = *reinterpret_cast<const d2_t *>(src + tb + (o[i] & ~1));
+        v[i] = r.x + r.y;
+      } else {
+        v[i] = 0.0;
+      }
+    }
+#else
 #pragma unroll
     for (int i = 0; i < NS; i++) v[i] = (i >= i0) ? src[tb + o[i]] : 0.0;
+#endif
   };
 
   int cidx[NCOL], cc[NCOL];  // this role's columns (gain rows); stand-ins mirror column n - 1
@@ -415,6 +429,11 @@ __global__ __launch_bounds__(SmoothLaneCfg<NS>::THREADS, SmoothLaneCfg<NS>::WAVE
         pon[t][q] = tab.col[w][t][(c0 + CH + q < NS) ? c0 + CH + q : NS - 1];
 #ifdef SML_NO_PKLOAD
         pkn[t][q] = 1.0;
+#elif defined(SML_WIDE)
+        {
+          const d2_t r = *reinterpret_cast<const d2_t *>(cur + tb + (pon[t][q] & ~1));
+          pkn[t][q] = r.x + r.y;
+        }
 #else
         pkn[t][q] = cur[tb + pon[t][q]];
 #endif
@@ -487,6 +506,8 @@ __global__ __launch_bounds__(SmoothLaneCfg<NS>::THREADS, SmoothLaneCfg<NS>::WAVE
             for (int j = 0; j < NS; j++) acc = fma(z[t][j], mr[j], acc);
 #ifdef SML_NO_PSTORE
             if (acc == 1.2345e300) out[tb + po[t][q]] = acc;
+#elif defined(SML_WIDE)
+            if (active) *reinterpret_cast<d2_t *>(out + tb + (po[t][q] & ~1)) = d2_t{ acc, acc };
 #else
             if (active) out[tb + po[t][q]] = acc;
 #endif

@@ -70,13 +70,8 @@ done
 bash scripts/input_footprint.sh > $OUT/n21_input_footprint.txt 2>&1
 python3 bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
 # round 4: forward passes that keep every posterior (per-message into slots vs the write-through replay), the smoother with
-# Eigen's pivoting for comparison, the pair kernels A/B (min of 3), independent log segments as one batch
+# Eigen's pivoting for comparison, the pair kernels A/B (min of 3)  (independent log segments: scripts/segment_rate.sh, above)
 python3 scripts/checkpoint_rate.py 2>/dev/null | grep "n=" > $OUT/checkpoint_rate.txt
 PRONTO_SMOOTH_PIVOT=1 python3 scripts/smooth_rate.py 2>/dev/null | grep smoother | sed "s/^/PRONTO_SMOOTH_PIVOT=1 /" > $OUT/smoother_pivoted.txt
 bash scripts/leg_ab.sh 3 - PRONTO_BATCH_LEG21_TWO=1 > $OUT/leg_ab.txt 2>&1
-if [ -x tests/build/test_segments ]; then
-  export OMP_WAIT_POLICY=passive
-  for a in "rate 1024 200" "rate 4096 100" "rate 16384 40" "rate 4096 100 n21"; do tests/build/test_segments $a /tmp 2>&1 | grep -A1 "segment batch rate"; done > $OUT/segment_rate.txt
-  PRONTO_SHIM_THREADS=1 tests/build/test_segments rate 4096 100 /tmp 2>&1 | grep -A1 "segment batch rate" | sed "s/^/PRONTO_SHIM_THREADS=1 /" >> $OUT/segment_rate.txt
-fi
 echo "profile done"
