@@ -79,6 +79,7 @@ struct pb_ctx {
   Consts k{ 9.80665, 1e-6 };
   int64_t utime = 0;
   bool have_state = false;
+  bool half15 = false;  // the 15-state fused step with two workgroups per tile (pb_create: batches that leave half the workgroup slots empty; PRONTO_BATCH_HALF=0/1)
   bool coop15 = false;  // PRONTO_BATCH_COOP15=1: run the 15-state step on the two-wave cooperative kernel (A/B switch)
   int mem_hint = 0;     // MH_* cache policy of the step kernels' state round trip (PRONTO_BATCH_MEMHINT=0/1/2 forces it)
   // pb_run_legodo's cache-blocked order (filter range outer, time inner) for states beyond the memory-side cache: filters per block

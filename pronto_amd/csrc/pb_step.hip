@@ -7,7 +7,9 @@ static void launch_step_mh(pb_ctx *c, double *out, const double *imu, const doub
 {
   const int B = c->B;
   if (c->ns == 15 && c->coop15) {
-    k_step_coop<15, UPDATE, MH><<<nblk(B), 128, 0, c->stream>>>(c->st, out, B, imu, lo, mask, q[0], q[1], q[2], q[3], c->k, CorrArgs(), bc);
+    Consts kk = c->k;
+    kk.half_tiles = c->half15 ? 1 : 0;   // (this launch only: every other kernel that takes c->k keeps whole tiles)
+    k_step_coop<15, UPDATE, MH><<<nblk(B) * (c->half15 ? 2 : 1), 128, 0, c->stream>>>(c->st, out, B, imu, lo, mask, q[0], q[1], q[2], q[3], kk, CorrArgs(), bc);
   } else if (c->ns == 15) {
     k_step<15, UPDATE, MH><<<(B + PB_STEP_BLOCK - 1) / PB_STEP_BLOCK, PB_STEP_BLOCK, 0, c->stream>>>(c->st, out, B, imu, lo, mask, q[0], q[1], q[2], q[3], c->k, bc);
   } else if (c->quad21) {

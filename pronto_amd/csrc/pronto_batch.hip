@@ -40,6 +40,13 @@ extern "C" int pb_create(pb_ctx **out, int n_states, int batch, int device, int 
     // PRONTO_BATCH_COOP15=0/1 forces one of them (A/B runs and tests).
     const char *e = getenv("PRONTO_BATCH_COOP15");
     c->coop15 = e ? (e[0] == '1') : (batch <= 393216);
+    // Below ~48k filters the two-wave kernel's 64-filter tiles leave workgroup slots empty (1 024 slots: 256 CUs x 4 workgroups of two
+    // waves at two waves per SIMD; 32 768 filters = 512 tiles).  Two workgroups per tile, 32 filters each, fill them -- and change
+    // nothing: 13.12 against 13.14 us at 32 768 filters, slower everywhere else (profiles/r05_half_tile.txt).  The step time is
+    // ~5 us of one tile's dependent chain + bytes / 9.4 TB/s at every size; more workgroups do not shorten the chain.  Kept as an A/B
+    // switch (PRONTO_BATCH_HALF=1), off by default.
+    const char *eh = getenv("PRONTO_BATCH_HALF");
+    c->half15 = c->coop15 && n_states == 15 && eh && eh[0] == '1';
   }
   c->stride = ((long) batch + 63) / 64 * 64;
   c->nc = (n_states == 15) ? Lay<15>::NC : Lay<21>::NC;

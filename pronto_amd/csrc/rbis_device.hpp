@@ -197,6 +197,9 @@ struct Consts {
   const double *qblk = nullptr;
   // k_step_coop: 1 = give each of the 8 XCDs one contiguous filter range (workgroups are dealt round-robin to XCDs)
   int xcd_remap = 0;
+  // k_step_coop: 1 = TWO workgroups per 64-filter tile, each with its 64 lanes on one half of it (lane l and lane l + 32 carry the
+  // same filter: the same addresses, the same values) -- twice the workgroups in flight for batches that do not fill the chip
+  int half_tiles = 0;
 };
 
 // ------------------------------------------------------------------------------------------------------------

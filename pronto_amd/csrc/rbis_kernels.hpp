@@ -621,8 +621,11 @@ __global__ __launch_bounds__(128, 1) void k_step_coop(const double *st, double *
 {
   __shared__ double xch[(UPDATE || CORR::M > 0) ? CoopX<NS, CORR>::NXCH : 1][64];
   const int role = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
-  const unsigned lane = threadIdx.x & 63u;
-  const unsigned tile = xcd_workgroup(k);
+  // half tiles (Consts::half_tiles, batches that leave workgroup slots empty): workgroup 2 t takes filters 0-31 of tile t, 2 t + 1
+  // filters 32-63; lanes l and l + 32 mirror each other, so nothing else in the kernel knows
+  const unsigned wgi = xcd_workgroup(k);
+  const unsigned tile = k.half_tiles ? (wgi >> 1) : wgi;
+  const unsigned lane = k.half_tiles ? ((threadIdx.x & 31u) | ((wgi & 1u) << 5)) : (threadIdx.x & 63u);
   const unsigned b = tile * 64u + lane;
   const unsigned bo = b * 8u, B8 = (unsigned) B * 8u;
   TileIO<NS, MemHint<MH>::LA, MemHint<MH>::SA, true> io(st, sto, tile, lane);

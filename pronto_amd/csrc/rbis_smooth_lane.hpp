@@ -98,6 +98,10 @@ __device__ __forceinline__ void lane_fence(int &sb, double after)
 {
   asm volatile("" : "+v"(sb) : "v"(after) : "memory");
 }
+__device__ __forceinline__ void lane_fence3(int &sb, int &sb1, int &sb2, double after)   // the same for all three bases of SE()
+{
+  asm volatile("" : "+v"(sb), "+v"(sb1), "+v"(sb2) : "v"(after) : "memory");
+}
 
 // The value is COMPUTED here: without this the backend sinks arithmetic below the next barrier to its first use, and what it was
 // computed from (LDS reads that cannot follow it across the barrier) stays live or is spilled (rbis_coop.hpp, pb_pin).
@@ -129,6 +133,14 @@ __global__ __launch_bounds__(SmoothLaneCfg<NS>::THREADS, SmoothLaneCfg<NS>::WAVE
   const auto &tab = smooth_lane_tab<NS>;
   int sb = lane;  // entry e of this lane's filter: lds[sb + e * 64] (sb passes through lane_fence)
 #define S (lds + sb)
+  // An LDS instruction's immediate offset reaches 64 KB = 128 entries of this [entry][lane] layout, and a paired read
+  // (ds_read2st64_b64) 256: beyond, the backend made an address for every single access (n = 21: 870 v_add_u32 and 897 unpaired
+  // ds_read_b64 among 10 083 instructions).  Two more bases, 128 and 256 entries in, opaque to the optimiser like sb itself:
+  // SE(e) with a compile-time e picks the base that leaves an immediate offset.
+  int sb1 = lane + 128 * 64, sb2 = lane + 256 * 64;
+  asm volatile("" : "+v"(sb1), "+v"(sb2));
+#define SE(e) (*(((e) < 128) ? (lds + sb + (e) * 64) : ((e) < 256) ? (lds + sb1 + ((e) - 128) * 64) : (lds + sb2 + ((e) - 256) * 64)))
+#define LANE_FENCE(after) lane_fence3(sb, sb1, sb2, after)
   auto ldc = [&](const double *src, int comp) { return src[tb + C::off_of(comp)]; };  // compile-time component only
   // column t of this role from one of the checkpoints: the offsets come in with wide scalar loads, the n loads go out back to back
   auto ld_col = [&](const double *src, int t, int i0, double (&v)[NS]) {  // rows i0 .. n-1 (the others: 0)
@@ -208,9 +220,9 @@ __global__ __launch_bounds__(SmoothLaneCfg<NS>::THREADS, SmoothLaneCfg<NS>::WAVE
         constexpr int t = kk / NR;
         const double d = a[t][kk];
         const double inv = (fabs(d) > 5.562684646268003e-309) ? 1.0 / d : 0.0;
-        S[pk(kk, kk) * 64] = (kk == NS - 1) ? inv : d;
+        SE(pk(kk, kk)) = (kk == NS - 1) ? inv : d;
 #pragma unroll
-        for (int i = kk + 1; i < NS; i++) S[pk(i, kk) * 64] = a[t][i] * inv;
+        for (int i = kk + 1; i < NS; i++) SE(pk(i, kk)) = a[t][i] * inv;
         inv_prev = inv;
       }
       __syncthreads();
@@ -218,9 +230,9 @@ __global__ __launch_bounds__(SmoothLaneCfg<NS>::THREADS, SmoothLaneCfg<NS>::WAVE
       if constexpr (kk == NS - 1) SML_T(2);
       // the diagonal slot of column kk-1 held d for the downdates of step kk-1; every role is past them now: it becomes 1/d
       if constexpr (kk > 0)
-        if (w == (kk - 1) % NR) S[pk(kk - 1, kk - 1) * 64] = inv_prev;
+        if (w == (kk - 1) % NR) SE(pk(kk - 1, kk - 1)) = inv_prev;
       if constexpr (kk + 1 < NS) {
-        const double dk = S[pk(kk, kk) * 64];
+        const double dk = SE(pk(kk, kk));
         // column slot t holds a column c in [NR t, NR t + NR): it is finished once kk >= NR (t + 1) - 1, and its rows above NR t
         // are above the diagonal -- neither is touched (compile-time bounds; what remains above the diagonal is never read)
         double tc[NCOL];
@@ -229,7 +241,7 @@ __global__ __launch_bounds__(SmoothLaneCfg<NS>::THREADS, SmoothLaneCfg<NS>::WAVE
           if (kk < NR * (t + 1) - 1) tc[t] = S[pk_s(cc[t], kk) * 64] * dk;
 #pragma unroll
         for (int i = kk + 1; i < NS; i++) {
-          const double lik = S[pk(i, kk) * 64];
+          const double lik = SE(pk(i, kk));
 #pragma unroll
           for (int t = 0; t < NCOL; t++)
             if (kk < NR * (t + 1) - 1 && i >= NR * t) {
@@ -245,7 +257,7 @@ __global__ __launch_bounds__(SmoothLaneCfg<NS>::THREADS, SmoothLaneCfg<NS>::WAVE
     double dchi[3];
     subtract_quats(rqs, rqp, dchi);
 #pragma unroll
-    for (int i = 0; i < NS; i++) S[(O_X + i) * 64] = (i >= 6 && i <= 8) ? dchi[i - 6] : rv[i];
+    for (int i = 0; i < NS; i++) SE(O_X + i) = (i >= 6 && i <= 8) ? dchi[i - 6] : rv[i];
   }
 
   // ---- 2. right-hand sides: columns cc[t] of Ad P_k, Ad = I + dt Ac about the filtered state (rbis.cpp:12-35, 236-239) ----
@@ -298,26 +310,26 @@ __global__ __launch_bounds__(SmoothLaneCfg<NS>::THREADS, SmoothLaneCfg<NS>::WAVE
   for (int i = 1; i < NS; i++)
 #pragma unroll
     for (int m = 0; m < i; m++) {
-      const double l = S[pk(i, m) * 64];
+      const double l = SE(pk(i, m));
 #pragma unroll
       for (int t = 0; t < NCOL; t++) z[t][i] = fma(-l, z[t][m], z[t][i]);
-      if (m == i - 1 && (i & 1)) lane_fence(sb, z[0][i >= 2 ? i - 2 : 0]);  // (row i - 2: one group of reads may run ahead)
+      if (m == i - 1 && (i & 1)) LANE_FENCE(z[0][i >= 2 ? i - 2 : 0]);  // (row i - 2: one group of reads may run ahead)
     }
 #pragma unroll
   for (int i = 0; i < NS; i++) {
-    const double inv = S[pk(i, i) * 64];
+    const double inv = SE(pk(i, i));
 #pragma unroll
     for (int t = 0; t < NCOL; t++) z[t][i] *= inv;
   }
-  lane_fence(sb, z[0][NS - 1]);
+  LANE_FENCE(z[0][NS - 1]);
 #pragma unroll
   for (int i = NS - 2; i >= 0; i--)
 #pragma unroll
     for (int m = i + 1; m < NS; m++) {
-      const double l = S[pk(m, i) * 64];
+      const double l = SE(pk(m, i));
 #pragma unroll
       for (int t = 0; t < NCOL; t++) z[t][i] = fma(-l, z[t][m], z[t][i]);
-      if (m == NS - 1 && (i & 1)) lane_fence(sb, z[0][i + 2 < NS ? i + 2 : NS - 1]);
+      if (m == NS - 1 && (i & 1)) LANE_FENCE(z[0][i + 2 < NS ? i + 2 : NS - 1]);
     }
 #endif
   // dx = G resid (rbis.cpp:263): this role's entries
@@ -326,7 +338,7 @@ __global__ __launch_bounds__(SmoothLaneCfg<NS>::THREADS, SmoothLaneCfg<NS>::WAVE
   for (int t = 0; t < NCOL; t++) dxv[t] = 0.0;
 #pragma unroll
   for (int i = 0; i < NS; i++) {
-    const double r = S[(O_X + i) * 64];
+    const double r = SE(O_X + i);
 #pragma unroll
     for (int t = 0; t < NCOL; t++) dxv[t] = fma(z[t][i], r, dxv[t]);
   }
@@ -375,7 +387,7 @@ __global__ __launch_bounds__(SmoothLaneCfg<NS>::THREADS, SmoothLaneCfg<NS>::WAVE
   // ---- 5. state: cur.addState(RBIS(dx)) (rbis.cpp:263-265), by the LAST role: the first CH roles make the first rows of M in step 6
   //         meanwhile (with role 0 doing both, every other wave of the tile waited for two fold_chi at the first barrier of step 6) ----
   if (w == NR - 1) {
-    double dchi[3] = { S[(O_X + NS + 6) * 64], S[(O_X + NS + 7) * 64], S[(O_X + NS + 8) * 64] };
+    double dchi[3] = { SE(O_X + NS + 6), SE(O_X + NS + 7), SE(O_X + NS + 8) };
     double dq[4] = { 1.0, 0.0, 0.0, 0.0 };
     fold_chi(dchi, dq, k.chi_tol);  // RBIS(vec) constructor
     double chi[3], qq[4], o[4];
@@ -388,7 +400,7 @@ __global__ __launch_bounds__(SmoothLaneCfg<NS>::THREADS, SmoothLaneCfg<NS>::WAVE
     const double ll = ldc(cur, L::OFF_LL);
     double xo[NS];
 #pragma unroll
-    for (int i = 0; i < NS; i++) xo[i] = (i >= 6 && i <= 8) ? chi[i - 6] : ldc(cur, L::OFF_VEC + i) + S[(O_X + NS + i) * 64];
+    for (int i = 0; i < NS; i++) xo[i] = (i >= 6 && i <= 8) ? chi[i - 6] : ldc(cur, L::OFF_VEC + i) + SE(O_X + NS + i);
     if (active) {
 #pragma unroll
       for (int i = 0; i < NS; i++) out[tb + C::off_of(L::OFF_VEC + i)] = xo[i];
@@ -458,11 +470,11 @@ __global__ __launch_bounds__(SmoothLaneCfg<NS>::THREADS, SmoothLaneCfg<NS>::WAVE
         for (int i = 0; i < NS; i++)
 #pragma unroll
           for (int j = 0; j <= i; j++) {
-            const double d = S[pk(i, j) * 64];
+            const double d = SE(pk(i, j));
             m[j] = fma(z[t][i], d, m[j]);
             if (i != j) m[i] = fma(z[t][j], d, m[i]);
             if (j == i && (i & 1)) {  // end of a group of two rows of D
-              lane_fence(sb, hook);
+              LANE_FENCE(hook);
               hook = m[0];
               lane_pin(hook);
             }
@@ -496,7 +508,7 @@ __global__ __launch_bounds__(SmoothLaneCfg<NS>::THREADS, SmoothLaneCfg<NS>::WAVE
       if (c < NS && c <= cidx[NCOL - 1]) {  // (wave-uniform) some row of this role is at or below the diagonal of column c
         double mr[NS];
 #pragma unroll
-        for (int j = 0; j < NS; j++) mr[j] = S[(O_X + q * NS + j) * 64];
+        for (int j = 0; j < NS; j++) mr[j] = SE(O_X + q * NS + j);
 #pragma unroll
         for (int t = 0; t < NCOL; t++) {
           const int r = cidx[t];
@@ -524,5 +536,7 @@ __global__ __launch_bounds__(SmoothLaneCfg<NS>::THREADS, SmoothLaneCfg<NS>::WAVE
 }
 
 #undef S
+#undef SE
+#undef LANE_FENCE
 
 }  // namespace pb

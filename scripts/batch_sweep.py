@@ -21,7 +21,9 @@ VARIANTS = {"default": {}, "coop0": {"PRONTO_BATCH_COOP15": "0"}, "coop1": {"PRO
             "quad0": {"PRONTO_BATCH_QUAD21": "0"}, "mh0": {"PRONTO_BATCH_MEMHINT": "0"}, "mh1": {"PRONTO_BATCH_MEMHINT": "1"}, "mh2": {"PRONTO_BATCH_MEMHINT": "2"},
             # launch order of run_legodo beyond the memory-side cache: "default" is the library's choice (blocked there), "unblocked"
             # the step-by-step order over the whole batch, "blk<N>k" a named block size
-            "unblocked": {"PRONTO_BATCH_BLOCKED": "0"}, "blocked": {"PRONTO_BATCH_BLOCKED": "1"}}
+            "unblocked": {"PRONTO_BATCH_BLOCKED": "0"}, "blocked": {"PRONTO_BATCH_BLOCKED": "1"},
+            # two workgroups per 64-filter tile (15 states, small batches): off / on
+            "half0": {"PRONTO_BATCH_HALF": "0"}, "half1": {"PRONTO_BATCH_HALF": "1"}}
 for _kb in (48, 64, 80, 96, 112, 128, 160, 192, 224, 256):
     VARIANTS["blk%dk" % _kb] = {"PRONTO_BATCH_BLOCKED": "1", "PRONTO_BATCH_BLOCK_FILTERS": str(_kb * 1024)}
 variants = os.environ.get("SWEEP_VARIANTS", "default").split(",")
