@@ -123,6 +123,91 @@ public:
     };
     chans_[channel] = std::move(c);
   }
+  // bot_core::kvh_raw_imu_batch_t (utime, raw_imu[]{utime, packet_count, delta_rotation[3], linear_acceleration[3]}; raw_imu[0] is the
+  // NEWEST packet): the reference's Atlas IMU channel (fusion.cpp:161-163 -> InsHandler::processMessageAtlas, sensor_handlers.cpp:165-252)
+  // for N independent logs -> InsHandler::processMessageAtlasSegments.  Every segment has its OWN IMUStream de-duplication state
+  // (imu_stream.cpp:62-98); atlas_filter = the handler's (true: the new packets go to the device notch cascade with per-filter
+  // counts; false: newest packet, raw_dt from the two newest); max_packets = the most packets a message can carry.
+  // (SegmentStreamer has the same subscription with the blocks already in HBM.)
+  void subscribeKvhBatch(const std::string &channel, const pronto_wire::Schema *schema, const std::string &type, bool atlas_filter, int max_packets,
+                         std::function<void(const msgs::kvh_raw_imu_segments_t *)> cb)
+  {
+    Chan c;
+    auto plan = std::make_shared<pronto_wire::Schema::Plan>(
+        schema->compile(type, { "utime", "raw_imu.utime", "raw_imu.packet_count", "raw_imu.delta_rotation", "raw_imu.linear_acceleration" }));
+    if (!plan->ok()) fprintf(stderr, "SegmentBatcher: %s is not a kvh_raw_imu_batch_t\n", type.c_str());
+    const int MP = max_packets < 1 ? 1 : max_packets;
+    // Rec: utime; aux = number of new packets; d = new accelerations [3 * n_new] (oldest first, at most MP), delta_rotation [3], raw_dt
+    c.decode = [plan, MP, atlas_filter](const pronto_wire::LogEvent &ev, Rec &r, Stream &st) {
+      static thread_local std::vector<pronto_wire::Schema::Extracted> x;
+      if (!plan->run(ev.data.data(), ev.data.size(), x, st.shape, nullptr) || x[0].num.size() != 1) return false;
+      const size_t np = x[1].num.size();
+      if (np < 1 || x[2].num.size() != np || x[3].num.size() != 3 * np || x[4].num.size() != 3 * np) return false;
+      r.utime = (int64_t) x[0].num[0];
+      r.d.clear();
+      double drot[3] = { 0, 0, 0 }, raw_dt = 0;
+      int n_new = 0;
+      if (!atlas_filter) {   // sensor_handlers.cpp:199-204
+        if (np < 2) return false;
+        for (int i = 0; i < 3; i++) { r.d.push_back(x[4].num[(size_t) i]); drot[i] = x[3].num[(size_t) i]; }
+        raw_dt = (double) ((int64_t) x[1].num[0] - (int64_t) x[1].num[1]) * 1E-6;
+        n_new = 1;
+      } else {               // IMUStream::convertFromLCMBatch, this segment's own state
+        if ((int64_t) x[2].num[0] < st.last_packet) { st.last_packet = -1; st.last_packet_utime = 0; }
+        for (size_t i = np; i-- > 0;) {
+          const int64_t cnt = (int64_t) x[2].num[i], put = (int64_t) x[1].num[i];
+          if (cnt <= st.last_packet) continue;
+          if (n_new < MP)
+            for (int a = 0; a < 3; a++) r.d.push_back(x[4].num[3 * i + (size_t) a]);
+          n_new++;
+          for (int a = 0; a < 3; a++) drot[a] = x[3].num[3 * i + (size_t) a];
+          raw_dt = (double) (put - st.last_packet_utime) * 1E-6;
+          st.last_packet = cnt;
+          st.last_packet_utime = put;
+        }
+        if (n_new > MP) n_new = MP;
+      }
+      r.aux = n_new;
+      r.d.resize((size_t) 3 * n_new);
+      r.d.insert(r.d.end(), drot, drot + 3);
+      r.d.push_back(raw_dt);
+      return true;
+    };
+    double *acc = pinned<double>((size_t) 3 * MP * B_), *drot = pinned<double>((size_t) 3 * B_), *raw_dt = pinned<double>((size_t) B_);
+    int64_t *ut = pinned<int64_t>((size_t) B_);
+    int32_t *n_new = pinned<int32_t>((size_t) B_);
+    uint8_t *valid = pinned<uint8_t>((size_t) B_);
+    std::fill_n(acc, (size_t) 3 * MP * B_, 0.0);
+    std::fill_n(drot, (size_t) 3 * B_, 0.0);
+    std::fill_n(raw_dt, (size_t) B_, 1.0);
+    c.dispatch = [this, cb, MP, acc, drot, raw_dt, ut, n_new, valid](const std::vector<const Rec *> &col, int64_t utime) {
+      PB_SHIM_PARALLEL_FOR
+      for (int s = 0; s < B_; s++) {
+        const Rec *r = col[(size_t) s];
+        const int nn = r ? (int) r->aux : 0;
+        n_new[s] = nn;
+        valid[s] = nn > 0;
+        ut[s] = r ? r->utime : 0;
+        if (nn <= 0) continue;   // (no message, or no new packet: the filter idles; its arrays keep their last values)
+        for (int p = 0; p < nn; p++)
+          for (int a = 0; a < 3; a++) acc[((size_t) p * 3 + (size_t) a) * B_ + s] = r->d[(size_t) 3 * p + (size_t) a];
+        for (int a = 0; a < 3; a++) drot[(size_t) a * B_ + s] = r->d[(size_t) 3 * nn + (size_t) a];
+        raw_dt[s] = r->d[(size_t) 3 * nn + 3];
+      }
+      msgs::kvh_raw_imu_segments_t m;
+      m.utime = utime;
+      m.max_new = MP;
+      m.n_new = n_new;
+      m.valid = valid;
+      m.new_accel = acc;
+      m.delta_rotation = drot;
+      m.raw_dt = raw_dt;
+      m.utimes = ut;
+      m.mem = PB_HOST;
+      timed(stats.t_handler, [&]() { cb(&m); });
+    };
+    chans_[channel] = std::move(c);
+  }
   // bot_core::joint_state_t (utime, joint_name[], joint_position[], joint_velocity[], joint_effort[]): LegOdoHandler::processMessage
   void subscribeJointState(const std::string &channel, const pronto_wire::Schema *schema, const std::string &type,
                            std::function<void(const msgs::joint_state_t *)> cb)
@@ -440,6 +525,7 @@ private:
     pronto_wire::Schema::Plan::Shape shape;
     std::shared_ptr<const std::vector<std::string>> names;
     uint64_t names_hash = 0;
+    int64_t last_packet = -1, last_packet_utime = 0;   // IMUStream (imu_stream.hpp:10-37), one per segment
   };
   struct Chan {
     std::function<bool(const pronto_wire::LogEvent &, Rec &, Stream &)> decode;

@@ -55,7 +55,7 @@ for d, name in (("trace64k", "_kernel_stats.csv"), ("trace64k_n21", "_kernel_sta
         shutil.copy(ks[0], os.path.join(out, tag + name))
 for name in ("trace64k.json", "trace64k_n21.json", "trace1m.json", "leg_rates.txt", "bench1m.json", "calib_plain.txt", "copybench.txt", "batch_sweep.txt",
              "bench_default.json", "others.txt", "configs.txt", "smoother.txt", "n21_input_footprint.txt", "checkpoint_rate.txt",
-             "smoother_pivoted.txt", "smoother_reg.txt", "leg_ab.txt", "segment_rate.txt"):
+             "smoother_pivoted.txt", "smoother_reg.txt", "leg_ab.txt", "segment_rate.txt", "smooth_log.txt"):
     p = os.path.join(src, name)
     if os.path.exists(p):
         shutil.copy(p, os.path.join(out, tag + "_" + name))

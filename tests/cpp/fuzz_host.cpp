@@ -316,7 +316,13 @@ int main(int argc, char **argv)
         batch.addSegment(bad_path);
         batch.addSegment(good_path, 1000000000LL + 20000);
         batch.addSegment(bad2_path);
-        batch.subscribeIns("IMU", &schema, "bot_core.ins_t", [&](const msgs::ins_t *m) { touch(m->gyro.p, 3, B); touch(m->accel.p, 3, B); touch(m->valid, 1, B); });
+        if (it % 2)
+          batch.subscribeIns("IMU", &schema, "bot_core.ins_t", [&](const msgs::ins_t *m) { touch(m->gyro.p, 3, B); touch(m->accel.p, 3, B); touch(m->valid, 1, B); });
+        else
+          batch.subscribeKvhBatch("ATLAS_IMU_BATCH", &schema, "bot_core.kvh_raw_imu_batch_t", it % 4 == 0, 3, [&](const msgs::kvh_raw_imu_segments_t *m) {
+            touch(m->new_accel, 3 * (size_t) m->max_new, B); touch(m->delta_rotation, 3, B); touch(m->raw_dt, 1, B); touch(m->utimes, 1, B);
+            touch(m->n_new, 1, B); touch(m->valid, 1, B);
+          });
         batch.subscribeForceTorque("FORCE_TORQUE", &schema, "bot_core.six_axis_force_torque_array_t",
                                    [&](const msgs::six_axis_force_torque_array_t *m) { touch(m->force_z.p, 2, B); });
         batch.subscribeJointState("JOINT_STATE", &schema, "bot_core.joint_state_t", [&](const msgs::joint_state_t *m) {

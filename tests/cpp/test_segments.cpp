@@ -18,6 +18,7 @@
 //             shorter; InsHandler::processMessageAtlasSegments with atlas_filter = true (one IMUStream state per segment, the notch
 //             cascade on the device with per-filter packet counts, raw_dt and message-time dt per filter); the oracle runs
 //             imu_stream.cpp:62-98 + the notch cascade + sensor_handlers.cpp:199-252 per segment.
+//   "kvhbatch" the same KVH logs through the per-message SegmentBatcher (page-locked host blocks, staged by the handler).
 // Exit code 0 + "PASS".  Needs a GPU.
 #include <chrono>
 #include <cinttypes>
@@ -86,6 +87,7 @@ int main(int argc, char **argv)
     if (std::string(argv[i]) == "nofuse") fuse = false;
     else if (std::string(argv[i]) == "stream") stream = true;
     else if (std::string(argv[i]) == "kvh") kvh = stream = true;
+    else if (std::string(argv[i]) == "kvhbatch") kvh = true;      // the KVH channel through the per-message SegmentBatcher
     else if (std::string(argv[i]) == "chunk7") chunk7 = true;
     else if (argv[i][0] == '/') dir = argv[i];
   }
@@ -377,7 +379,11 @@ int main(int argc, char **argv)
       for (int s = 0; s < B; s++)
         if (!batch.addSegment(paths[(size_t) s], start_ts[(size_t) s])) { printf("FAIL: cannot open segment %d\n", s); return 1; }
       if (batch.addSegment(paths[0])) { printf("FAIL: a 65th segment was accepted by a 64-filter batch\n"); return 1; }
-      batch.subscribeIns("IMU", &schema, "bot_core.ins_t", front_end.addSensor("ins", &InsHandler::processMessage, &ins_handler));
+      if (kvh)
+        batch.subscribeKvhBatch(imu_channel, &schema, "bot_core.kvh_raw_imu_batch_t", ins_handler.atlas_filter, KVH_PACKETS,
+                                front_end.addSensor("ins", &InsHandler::processMessageAtlasSegments, &ins_handler));
+      else
+        batch.subscribeIns("IMU", &schema, "bot_core.ins_t", front_end.addSensor("ins", &InsHandler::processMessage, &ins_handler));
       batch.subscribeForceTorque("FORCE_TORQUE", &schema, "bot_core.six_axis_force_torque_array_t",
                                  [&](const msgs::six_axis_force_torque_array_t *m) { legodo_handler.forceTorqueHandler(m, B); });
       batch.subscribeJointState("JOINT_STATE", &schema, "bot_core.joint_state_t", front_end.addSensor("legodo", &LegOdoHandler::processMessage, &legodo_handler));

@@ -339,7 +339,7 @@ def test_user_defined_update_with_the_reference_signature_on_gpu(oracle, n, vari
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("n", [15, 21])
-@pytest.mark.parametrize("variant", [("stream",), ("stream", "chunk7"), ("stream", "nofuse"), ("kvh",), ("kvh", "chunk7")])
+@pytest.mark.parametrize("variant", [("stream",), ("stream", "chunk7"), ("stream", "nofuse"), ("kvh",), ("kvh", "chunk7"), ("kvhbatch",)])
 def test_independent_log_segments_streamed_on_gpu(oracle, tmp_path, n, variant):
     """SegmentStreamer (segment_stream.hpp): the same 64 DIFFERENT recorded segments as test_independent_log_segments_as_one_batch_on_gpu,
     replayed as a pipeline -- memory-mapped logs decoded ahead in chunks, one upload per chunk on the copy stream, the handlers called
@@ -348,7 +348,8 @@ def test_independent_log_segments_streamed_on_gpu(oracle, tmp_path, n, variant):
     "kvh": the IMU arrives as the reference's own Atlas channel, bot_core::kvh_raw_imu_batch_t on ATLAS_IMU_BATCH (fusion.cpp:161-163
     -> InsHandler::processMessageAtlas, sensor_handlers.cpp:165-252): 64 different KVH logs with repeated packets, shorter first
     messages and messages with NO new packet; one IMUStream de-duplication per segment (imu_stream.cpp:62-98), the notch cascade on
-    the device with per-filter packet counts, raw_dt and message-time dt per filter."""
+    the device with per-filter packet counts, raw_dt and message-time dt per filter.  "kvhbatch": the same 64 KVH logs through the
+    per-message SegmentBatcher::subscribeKvhBatch (host blocks, staged by the handler)."""
     exe = build_exe(oracle, "test_segments")
     r = subprocess.run([exe, str(tmp_path), *variant] + NARG[n], capture_output=True, text=True, timeout=600)
     print(r.stdout[-3000:], r.stderr[-2000:])
