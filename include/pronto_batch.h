@@ -400,13 +400,23 @@ int pb_imu_notch_counts(pb_ctx *ctx, int max_packets, const int32_t *counts, con
  *     filter's previous utime) * 1E-6, dt_default on its first message (:239-249).  utimes [B] = every robot's own message time,
  *     or NULL = `utime` for all.
  *   valid [B] (or NULL = all): 0 = this filter has NO message (its log segment has ended, or its KVH batch carried no new packet:
- *     the reference's handler returns NULL) -- its block is its own last sample with dt = 0, a step that leaves state and
- *     covariance where they are; its previous-utime is not advanced.
+ *     the reference's handler returns NULL) -- its block entry is its own last sample with dt = 0; its previous-utime is not
+ *     advanced.  valid_out (DEVICE, [B], or NULL) receives the mask: hand it to pb_set_imu_valid in front of the call that takes the
+ *     step, which makes that step a no-op for these filters.
  * mem (of the input arrays): PB_HOST or PB_DEVICE.  pb_ins_body_reset forgets the last samples / previous utimes. */
 int pb_ins_body_block(pb_ctx *ctx, const double *gyro, const double *accel, const double *raw_dt, const int64_t *utimes, int64_t utime,
                       const uint8_t *valid, const double rot_quat[4], const double trans_vec[3], double dt_default, int dt_from_utimes,
-                      int mem, double *imu_block_out);
+                      int mem, double *imu_block_out, uint8_t *valid_out);
 int pb_ins_body_reset(pb_ctx *ctx);
+/* Filters WITHOUT an IMU message in the next IMU step (independent log segments: the reference's handler returned NULL for them, so
+ * its estimator did nothing at all).  valid_dev [B] (DEVICE; 0 = no message) applies to the NEXT call that takes an IMU step
+ * (pb_predict, pb_step_legodo, _split, _correct, pb_step_legodo_joints / _feet) and is consumed by it whatever its outcome.  A
+ * step with dt = 0 already leaves pose, velocity, biases and covariance alone whatever the sample; with the mask the library
+ * replaces, right in front of the step kernel, the sample of such a filter by the one that reproduces its angular-velocity and
+ * acceleration entries too (omega + gyro bias, a + accel bias of the prior), and sets its dt to 0: the step is a no-op for it --
+ * exactly for 15 states, to the last bit of those sums for 21 -- and a measurement update in the same kernel sees the state the
+ * reference's would.  The step kernels themselves know nothing of it.  The array must stay valid until the step has run. */
+int pb_set_imu_valid(pb_ctx *ctx, const uint8_t *valid_dev);
 
 /* ---- posterior checkpoints for roll-forward replay (mav_state_est.cpp:28-80, update_history.cpp) ------------ */
 

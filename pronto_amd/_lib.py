@@ -68,7 +68,8 @@ _SIGS = {
     "pb_upload_sync": (C.c_int, [C.c_void_p]),
     "pb_imu_notch_counts": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "pb_ins_body_block": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, _dp, _dp,
-                                    C.c_double, C.c_int, C.c_int, C.c_void_p]),
+                                    C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "pb_set_imu_valid": (C.c_int, [C.c_void_p, C.c_void_p]),
     "pb_ins_body_reset": (C.c_int, [C.c_void_p]),
     "pb_get_slot": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "pb_smooth_log_slots": (C.c_int, [C.c_int, C.c_int]),

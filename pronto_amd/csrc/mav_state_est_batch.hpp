@@ -278,6 +278,10 @@ public:
   // gyro xyz | accelerometer xyz | dt as ONE block [7][B] (body frame), owned when built on the host
   std::vector<double> owned;
   std::shared_ptr<DeviceBlock> owned_dev;  // a block made on the device (InsHandler's device path: pb_ins_body_block)
+  // [B] DEVICE or NULL: 0 = this filter has NO IMU message in this step (independent log segments; the reference's handler returned
+  // NULL for it).  Whoever takes this step hands the mask to the library first (announce): the step is then a no-op for it.
+  const uint8_t *valid_dev = nullptr;
+  void announce(pb_ctx *ctx) const { if (valid_dev) pb_set_imu_valid(ctx, valid_dev); }
   BatchArray imu_block;
   double q_gyro, q_accel, q_gyro_bias, q_accel_bias;
   RBISIMUProcessStep(BatchArray imu_block_, double q_gyro_, double q_accel_, double q_gyro_bias_, double q_accel_bias_,
@@ -291,6 +295,7 @@ public:
   int updateFilter(pb_ctx *ctx) override
   {
     const double q[4] = { q_gyro, q_accel, q_gyro_bias, q_accel_bias };
+    announce(ctx);
     return pb_predict(ctx, imu_block.p, q, imu_block.mem);
   }
 };
@@ -994,6 +999,7 @@ private:
       mask1 = m->mask;
       mem1 = PB_HOST;
     }
+    imu->announce(ctx);
     rc = pb_step_legodo_correct(ctx, imu->imu_block.p, lo, mask1, q, mem1, kind, o->measurement.p, o->measurement_cov,
                                 o->r_kind, o->orientation.p, o->mask, o->measurement.mem);
     return true;
@@ -1019,6 +1025,7 @@ private:
     auto *m = dynamic_cast<RBISIndexedMeasurement *>(next);
     if (m == nullptr || m->index != RBIS::velocityInds()) return false;
     const double q[4] = { imu->q_gyro, imu->q_accel, imu->q_gyro_bias, imu->q_accel_bias };
+    imu->announce(ctx);   // (taken by whichever step call follows)
     if (device_lo_block(m)) {  // IMU block from the host (broadcast or per filter), measurement on the device
       rc = pb_step_legodo_split(ctx, imu->imu_block.p, imu->imu_block.mem, m->measurement.p, m->mask, PB_DEVICE, q);
       return true;
@@ -1610,18 +1617,22 @@ private:
   RBISUpdateInterface *buildOnDevice(MavStateEstimator *est, const double *gyro, const double *accel, const double *raw_dt, const int64_t *utimes,
                                      int64_t utime, const uint8_t *valid, bool atlas, int mem)
   {
-    if (!ins_pool_) ins_pool_ = std::make_shared<DevicePool>(est->ctx, est->ctx_alive, sizeof(double) * 7 * (size_t) est->B);
+    if (!ins_pool_) ins_pool_ = std::make_shared<DevicePool>(est->ctx, est->ctx_alive, sizeof(double) * 7 * (size_t) est->B + (size_t) est->B);
     bool fresh = false;
     void *blk = ins_pool_->get(fresh);
+    // (the block is [7][B] doubles + a [B] mask behind it: the update OWNS its copy of the mask -- a host mask is gone when the handler
+    // returns, and a device mask inside a replayer's chunk buffer may be overwritten before a held-back step has run)
+    uint8_t *mask_out = (blk != nullptr && valid != nullptr) ? (uint8_t *) ((double *) blk + (size_t) 7 * est->B) : nullptr;
     if (blk == nullptr ||
         pb_ins_body_block(est->ctx, gyro, accel, raw_dt, utimes, utime, valid, ins_to_body.rot_quat, atlas ? ins_to_body.trans_vec : nullptr, dt,
-                          atlas ? 1 : 0, mem, (double *) blk) != PB_OK) {
+                          atlas ? 1 : 0, mem, (double *) blk, mask_out) != PB_OK) {
       fprintf(stderr, "InsHandler: %s\n", pb_last_error(est->ctx));
       if (blk) ins_pool_->free_.push_back(blk);
       return nullptr;
     }
     auto *u = new RBISIMUProcessStep(BatchArray((const double *) blk, PB_DEVICE), cov_gyro, cov_accel, cov_gyro_bias, cov_accel_bias, utime);
     u->owned_dev = std::make_shared<DeviceBlock>(ins_pool_, blk);
+    u->valid_dev = mask_out;
     return u;
   }
   // valid [B] (per-filter host messages only): a filter without a message takes its step with dt = 0 -- with the sample it was
@@ -1656,7 +1667,7 @@ private:
         blk[(size_t) i * B + b] = gb[i];
         blk[(size_t) (3 + i) * B + b] = ab[i];
       }
-      blk[(size_t) 6 * B + b] = (valid != nullptr && mem == PB_HOST && !valid[b]) ? -0.0 : dt_;   // negative zero: "no message", a no-op
+      blk[(size_t) 6 * B + b] = (valid != nullptr && mem == PB_HOST && !valid[b]) ? 0.0 : dt_;
     }
     return new RBISIMUProcessStep(std::move(blk), cov_gyro, cov_accel, cov_gyro_bias, cov_accel_bias, utime, mem);
   }
@@ -2117,6 +2128,7 @@ public:
       const double q[4] = { imu->q_gyro, imu->q_accel, imu->q_gyro_bias, imu->q_accel_bias };
       const int trc = times(ctx);
       if (trc != PB_OK) return trc;
+      imu->announce(ctx);
       if (kind == 1)
         return pb_step_legodo_joints(ctx, imu->imu_block.p, imu->imu_block.mem, q, utime, rows, jp, je, ff, mem, r, ru, d_lo, d_mask);
       return pb_step_legodo_feet(ctx, imu->imu_block.p, imu->imu_block.mem, q, utime, feet, forces, mem, r, ru, d_lo, d_mask);

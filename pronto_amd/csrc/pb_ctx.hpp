@@ -63,6 +63,9 @@ struct pb_ctx {
   // IMU front end per filter (pb_ins_body_block, rbis_frontend.hpp): last body-frame sample [6][stride], previous message time [stride]
   double *ins_last = nullptr;
   int64_t *ins_prev_ut = nullptr;
+  const uint8_t *imu_valid_next = nullptr;   // pb_set_imu_valid: one-shot, taken by the next call that takes an IMU step ...
+  const uint8_t *imu_valid_cur = nullptr;    // ... and held here for the duration of that call
+  double *imu_keep = nullptr;                // [7][stride]: the IMU block that call's step kernel reads instead (pbk_idle_prepare)
   // chunked uploads (pb_upload_async): fences recorded on the main stream, one event for "the uploads issued so far"
   hipEvent_t fence[PB_MAX_FENCES] = {};
   int n_fences = 0;
@@ -132,6 +135,11 @@ inline void update_done(pb_ctx *c, double *target)
 
 
 #define LAUNCHCHK(c) HIPCHK((c), hipGetLastError())
+
+// in front of the ONE step launch of a call that was given a mask (pb_set_imu_valid): the IMU block with the samples of the filters
+// WITHOUT a message replaced by what reproduces their angular-velocity / acceleration entries (pronto_batch.hip); the block itself
+// when there is no mask
+const double *pbk_idle_prepare(pb_ctx *c, const double *imu_dev, int *rc_out);
 
 // ---- launchers defined in the other translation units ----
 // pb_step.hip: predict (update = false) or predict + leg-odometry update on the kernel pb_create picked

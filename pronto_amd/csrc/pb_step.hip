@@ -26,6 +26,9 @@ template <bool UPDATE>
 static int launch_step(pb_ctx *c, const double *imu, const double *lo, const uint8_t *mask, const double q[4], const StepBcast &bc)
 {
   double *out = update_target(c);
+  int rc = PB_OK;
+  imu = pbk_idle_prepare(c, imu, &rc);
+  if (rc) return rc;
   switch (c->mem_hint) {  // cache policy of the state round trip, chosen in pb_create from the state size
   case MH_STORE_SC1: launch_step_mh<UPDATE, MH_STORE_SC1>(c, out, imu, lo, mask, q, bc); break;
   case MH_STREAM_NT: launch_step_mh<UPDATE, MH_STREAM_NT>(c, out, imu, lo, mask, q, bc); break;
@@ -86,6 +89,9 @@ int pbk_step_leg(pb_ctx *c, const double *imu, const StepBcast *bcast, const dou
   const StepBcast bc = bcast ? *bcast : StepBcast();
   LegStepArgs la{ c->legd, c->legi, c->stride, utime, mp.r_v2, mp.r_v2_uncertain, lo_out, mask_out, mp };
   double *out = update_target(c);
+  int rc = PB_OK;
+  imu = pbk_idle_prepare(c, imu, &rc);
+  if (rc) return rc;
   if (c->ns == 15) pbk_step_leg15(c, out, imu, q, bc, lin, la);
   else pbk_step_leg21(c, out, imu, q, bc, lin, la);
   LAUNCHCHK(c);
@@ -166,6 +172,9 @@ int pbk_step_correct(pb_ctx *c, int corr_kind, const double *imu, const double *
   }
   const StepBcast bc = bcast ? *bcast : StepBcast();
   double *out = update_target(c);
+  int rc = PB_OK;
+  imu = pbk_idle_prepare(c, imu, &rc);
+  if (rc) return rc;
   if (corr_kind == PB_CORR_POS_ORIENT) launch_corr_mh<15, CorrPosOrient>(c, out, imu, lo, mask, q, ca, bc);
   else launch_corr_mh<15, CorrPosYaw>(c, out, imu, lo, mask, q, ca, bc);
   LAUNCHCHK(c);

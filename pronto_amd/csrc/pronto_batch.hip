@@ -149,6 +149,7 @@ extern "C" int pb_destroy(pb_ctx *c)
   if (c->notch) (void) hipFree(c->notch);
   if (c->ins_last) (void) hipFree(c->ins_last);
   if (c->ins_prev_ut) (void) hipFree(c->ins_prev_ut);
+  if (c->imu_keep) (void) hipFree(c->imu_keep);
   for (int i = 0; i < c->n_fences; i++)
     if (c->fence[i]) (void) hipEventDestroy(c->fence[i]);
   if (c->ev_upload) (void) hipEventDestroy(c->ev_upload);
@@ -474,8 +475,53 @@ extern "C" int pb_set_head(pb_ctx *c, const double *vec, const double *quat, con
   return PB_OK;
 }
 
+// ---- filters without an IMU message in a batched message (independent log segments) ----
+extern "C" int pb_set_imu_valid(pb_ctx *c, const uint8_t *valid_dev)
+{
+  if (!c) return PB_ERR_ARG;
+  c->imu_valid_next = valid_dev;
+  return PB_OK;
+}
+// The mask belongs to the NEXT call that takes an IMU step, whatever becomes of it: such an entry point moves it from imu_valid_next to
+// imu_valid_cur first thing (ImuIdleTake) and forgets it when it returns; the launchers of the step kernels (pb_step.hip) pass
+// their IMU block through pbk_idle_prepare right in front of their ONE launch (rbis_frontend.hpp, k_imu_idle_prepare).
+struct ImuIdleTake {
+  pb_ctx *c;
+  explicit ImuIdleTake(pb_ctx *ctx) : c(ctx)
+  {
+    if (c) {
+      c->imu_valid_cur = c->imu_valid_next;
+      c->imu_valid_next = nullptr;
+    }
+  }
+  ~ImuIdleTake()
+  {
+    if (c) c->imu_valid_cur = nullptr;
+  }
+};
+const double *pbk_idle_prepare(pb_ctx *c, const double *imu_dev, int *rc_out)
+{
+  *rc_out = PB_OK;
+  const uint8_t *valid = c->imu_valid_cur;
+  if (!valid || !imu_dev) return imu_dev;
+  c->imu_valid_cur = nullptr;   // (one step launch per call)
+  if (!c->imu_keep) {
+    hipError_t e = hipMalloc((void **) &c->imu_keep, sizeof(double) * 7 * (size_t) c->stride);
+    if (e != hipSuccess) {
+      *rc_out = fail(c, PB_ERR_HIP, "hipMalloc failed: %s", hipGetErrorString(e));
+      return imu_dev;
+    }
+  }
+  if (c->ns == 15) k_imu_idle_prepare<15><<<(c->B + 255) / 256, 256, 0, c->stream>>>(c->st, valid, imu_dev, c->imu_keep, c->B);
+  else k_imu_idle_prepare<21><<<(c->B + 255) / 256, 256, 0, c->stream>>>(c->st, valid, imu_dev, c->imu_keep, c->B);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) *rc_out = fail(c, PB_ERR_HIP, "k_imu_idle_prepare: %s", hipGetErrorString(e));
+  return c->imu_keep;
+}
+
 extern "C" int pb_predict(pb_ctx *c, const double *imu_block, const double q[4], int mem)
 {
+  ImuIdleTake idle(c);
   ENTER(c);
   NEED_STATE(c);
   if (!imu_block || !q) return fail(c, PB_ERR_ARG, "pb_predict: NULL input");
@@ -494,6 +540,7 @@ extern "C" int pb_predict(pb_ctx *c, const double *imu_block, const double q[4],
 extern "C" int pb_step_legodo(pb_ctx *c, const double *imu_block, const double *lo_block, const uint8_t *mask,
                               const double q[4], int mem)
 {
+  ImuIdleTake idle(c);
   ENTER(c);
   NEED_STATE(c);
   if (!imu_block || !lo_block || !q) return fail(c, PB_ERR_ARG, "pb_step_legodo: NULL input");
@@ -517,6 +564,7 @@ extern "C" int pb_step_legodo(pb_ctx *c, const double *imu_block, const double *
 extern "C" int pb_step_legodo_split(pb_ctx *c, const double *imu_block, int imu_mem, const double *lo_block,
                                     const uint8_t *mask, int lo_mem, const double q[4])
 {
+  ImuIdleTake idle(c);
   if (imu_mem == lo_mem) return pb_step_legodo(c, imu_block, lo_block, mask, q, imu_mem);
   ENTER(c);
   NEED_STATE(c);
@@ -554,6 +602,7 @@ extern "C" int pb_step_legodo_correct(pb_ctx *c, const double *imu_block, const 
                                       const double q[4], int mem, int corr_kind, const double *z2, const double *R2,
                                       int r_kind2, const double *quat_meas2, const uint8_t *mask2, int mem2)
 {
+  ImuIdleTake idle(c);
   ENTER(c);
   NEED_STATE(c);
   if (!imu_block || !lo_block || !q || !z2 || !R2 || !quat_meas2) return fail(c, PB_ERR_ARG, "pb_step_legodo_correct: NULL input");
@@ -1524,6 +1573,7 @@ extern "C" int pb_step_legodo_joints(pb_ctx *c, const double *imu_block, int imu
                                      const float *joint_position, const float *joint_effort, const float *forces, int mem,
                                      double r_vxyz, double r_vxyz_uncertain, double *lo_block_out, uint8_t *mask_out)
 {
+  ImuIdleTake idle(c);
   const LegMsgTimes mt = leg_take_message_times(c);
   ENTER(c);
   NEED_STATE(c);
@@ -1541,6 +1591,7 @@ extern "C" int pb_step_legodo_feet(pb_ctx *c, const double *imu_block, int imu_m
                                    const double *forces, int mem, double r_vxyz, double r_vxyz_uncertain, double *lo_block_out,
                                    uint8_t *mask_out)
 {
+  ImuIdleTake idle(c);
   const LegMsgTimes mt = leg_take_message_times(c);
   ENTER(c);
   NEED_STATE(c);
@@ -1681,7 +1732,7 @@ extern "C" int pb_ins_body_reset(pb_ctx *c)
 
 extern "C" int pb_ins_body_block(pb_ctx *c, const double *gyro, const double *accel, const double *raw_dt, const int64_t *utimes, int64_t utime,
                                  const uint8_t *valid, const double rot_quat[4], const double trans_vec[3], double dt_default, int dt_from_utimes,
-                                 int mem, double *imu_block_out)
+                                 int mem, double *imu_block_out, uint8_t *valid_out)
 {
   ENTER(c);
   if (!gyro || !accel || !rot_quat || !imu_block_out) return fail(c, PB_ERR_ARG, "pb_ins_body_block: NULL argument");
@@ -1703,7 +1754,7 @@ extern "C" int pb_ins_body_block(pb_ctx *c, const double *gyro, const double *ac
   f.dt_default = dt_default;
   k_ins_body<<<(unsigned) ((c->B + 255) / 256), 256, 0, c->stream>>>(c->B, c->stride, (const double *) p[0].dev, (const double *) p[1].dev,
                                                                       (const double *) p[2].dev, (const int64_t *) p[3].dev, utime,
-                                                                      (const uint8_t *) p[4].dev, f, c->ins_last, c->ins_prev_ut, imu_block_out);
+                                                                      (const uint8_t *) p[4].dev, f, c->ins_last, c->ins_prev_ut, imu_block_out, valid_out);
   LAUNCHCHK(c);
   return PB_OK;
 }

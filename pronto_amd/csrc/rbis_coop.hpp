@@ -596,8 +596,8 @@ PB_HD void coop_role_passive_x(LD ld, ST st, XW xw, XR xr, SYNC sync, const Step
   // rbis.cpp:50-51
 #pragma unroll
   for (int i = 0; i < 3; i++) {
-    xp[i] = imu_idle(in.dt) ? x[i] : in.gyro[i] - (C::HB ? x[15 + i] : 0.0);
-    xp[3 + i] = imu_idle(in.dt) ? x[12 + i] : in.accel[i] - (C::HB ? x[18 + i] : 0.0);
+    xp[i] = in.gyro[i] - (C::HB ? x[15 + i] : 0.0);
+    xp[3 + i] = in.accel[i] - (C::HB ? x[18 + i] : 0.0);
   }
   }  // PREDICT
 

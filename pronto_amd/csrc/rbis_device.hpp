@@ -318,12 +318,6 @@ PB_HD void subtract_quats(const double (&q1)[4], const double (&q2)[4], double (
 // predict
 // ------------------------------------------------------------------------------------------------------------
 
-// dt = -0.0 (NEGATIVE zero) marks a filter that has NO IMU message in this step -- the reference's handler returned NULL for it (a
-// KVH batch without a new packet, sensor_handlers.cpp:181-187) or its log segment has ended: a true no-op.  Every product with dt
-// vanishes as for +0.0 (pose, velocity, biases and the covariance stay), and the angular-velocity / acceleration entries,
-// which a real message with dt = +0.0 re-derives from its sample, are kept as well (the roles that own them ask imu_idle too).
-PB_HD bool imu_idle(double dt) { return dt == 0.0 && __builtin_signbit(dt); }
-
 // rbis.cpp:37-75.  x is updated in place; uses the PRE-update v and quat on every right-hand side.
 template <int NS>
 PB_HD void ins_update_state(double (&x)[NS], double (&q)[4], const double (&gyro)[3], const double (&accel)[3],
@@ -331,12 +325,11 @@ PB_HD void ins_update_state(double (&x)[NS], double (&q)[4], const double (&gyro
 {
   double R[9];
   quat_to_rot(q, R);
-  const bool idle = imu_idle(dt);
   double w[3], a[3];
 #pragma unroll
   for (int i = 0; i < 3; i++) {
-    w[i] = idle ? x[i] : gyro[i] - (NS == 21 ? x[15 + i] : 0.0);        // :50
-    a[i] = idle ? x[12 + i] : accel[i] - (NS == 21 ? x[18 + i] : 0.0);  // :51
+    w[i] = gyro[i] - (NS == 21 ? x[15 + i] : 0.0);   // :50
+    a[i] = accel[i] - (NS == 21 ? x[18 + i] : 0.0);  // :51
   }
   const double v[3] = { x[3], x[4], x[5] };
   // -w x v + R^T g + a   (:55-56); R^T g = -g * (third row of R)

@@ -90,17 +90,18 @@ PB_HD void ins_rotate(const double rot[4], const double v[3], double r[3])
 // One robot's IMU message -> the [7][B] block of RBISIMUProcessStep (gyro xyz | accel xyz | dt, body frame), one lane per filter.
 //   gyro [3][B]: angular rate, or delta_rotation when raw_dt != NULL (then divided by raw_dt[b], :207-210);  accel [3][B];
 //   utimes [B] or NULL (= utime for every filter);  valid [B] or NULL (= all): a filter WITHOUT a message -- its segment has ended,
-//   or its KVH message carried no new packet (:181-187: the reference returns NULL) -- gets dt = -0.0 (negative zero) on its own last
-//   sample: the step kernels leave every entry of its state and covariance where it is.
+//   or its KVH message carried no new packet (:181-187: the reference returns NULL) -- gets dt = 0 on its own last sample; valid_out
+//   [B] (optional) receives the mask for pb_set_imu_valid, which makes the step that consumes the block a true no-op for it.
 // State per filter: the last body-frame sample `last` [6][stride] and the previous message time `prev_ut` [stride].
 static __global__ void k_ins_body(int B, long stride, const double *__restrict__ gyro, const double *__restrict__ accel,
                                   const double *__restrict__ raw_dt, const int64_t *__restrict__ utimes, int64_t utime,
                                   const uint8_t *__restrict__ valid, InsFrame f, double *__restrict__ last, int64_t *__restrict__ prev_ut,
-                                  double *__restrict__ out)
+                                  double *__restrict__ out, uint8_t *__restrict__ valid_out)
 {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   const bool on = valid ? valid[b] != 0 : true;
+  if (valid_out) valid_out[b] = on ? 1 : 0;
   double blk[7];
   if (on) {
     double g[3] = { gyro[b], gyro[(long) B + b], gyro[2L * B + b] };
@@ -124,9 +125,42 @@ static __global__ void k_ins_body(int B, long stride, const double *__restrict__
     for (int i = 0; i < 6; i++) last[(long) i * stride + b] = blk[i];
   } else {
     for (int i = 0; i < 6; i++) blk[i] = last[(long) i * stride + b];
-    blk[6] = -0.0;   // NEGATIVE zero: "no message" (ins_update_state, rbis_device.hpp) -- nothing of this filter changes
+    blk[6] = 0.0;   // dt = 0 on its own last sample: pose, velocity, biases and covariance stay (the step call that consumes the block
+                    // keeps the angular-velocity / acceleration entries too when it is given the mask: pb_set_imu_valid)
   }
   for (int i = 0; i < 7; i++) out[(long) i * B + b] = blk[i];
 }
 
+// A filter WITHOUT an IMU message in a batched message: the reference does nothing at all for it (its handler returned NULL).  Its
+// block entry says dt = 0 -- pose, velocity, biases and covariance stay whatever the sample -- but the step also writes the
+// angular-velocity and acceleration entries, omega = gyro - gyro_bias, a = accel - accel_bias, with the biases of NOW.  Right in
+// front of the step kernel, for the filters whose mask is 0, the sample becomes (omega + gyro_bias, a + accel_bias) of the PRIOR the
+// step is about to read: the step then re-derives what is there (exactly for 15 states, to the last bit of the sum for 21) and the
+// update that shares the kernel sees the same state the reference's would.  One small launch and a 56-byte copy per filter in
+// front of the hot kernel instead of selects inside it -- measured: the selects cost k_step_quad 6-7 % (39.7 vs 37.0-37.9 us at
+// 64k filters, same box); this costs the hot kernels nothing, and nothing at all when no mask is given.
+template <int NS>
+static __global__ void k_imu_idle_prepare(const double *__restrict__ st, const uint8_t *__restrict__ valid, const double *__restrict__ imu,
+                                          double *__restrict__ imu_out, int B)
+{
+  using L = Lay<NS>;
+  using S = Slots<NS>;
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  double v[7];
+#pragma unroll
+  for (int i = 0; i < 7; i++) v[i] = imu[(long) i * B + b];
+  if (valid[b] == 0) {
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      v[i] = st[S::eidx(L::OFF_VEC + i, b)] + (NS == 21 ? st[S::eidx(L::OFF_VEC + (NS == 21 ? 15 : 0) + i, b)] : 0.0);
+      v[3 + i] = st[S::eidx(L::OFF_VEC + 12 + i, b)] + (NS == 21 ? st[S::eidx(L::OFF_VEC + (NS == 21 ? 18 : 0) + i, b)] : 0.0);
+    }
+    v[6] = 0.0;
+  }
+#pragma unroll
+  for (int i = 0; i < 7; i++) imu_out[(long) i * B + b] = v[i];
+}
+
 }  // namespace pb
+

@@ -367,7 +367,7 @@ PB_HD void quad_role_cb(LD ld, ST st, XW xw, XR xr, SYNC sync, const StepInputs 
 #pragma unroll
   for (int i = 0; i < 6; i++) xb[i] = x[15 + i];
 #pragma unroll
-  for (int i = 0; i < 3; i++) xw_[i] = imu_idle(in.dt) ? x[i] : in.gyro[i] - x[15 + i];  // rbis.cpp:50
+  for (int i = 0; i < 3; i++) xw_[i] = in.gyro[i] - x[15 + i];  // rbis.cpp:50
 
   ProcBlocks f;
   make_proc_blocks<NS>(x, q, in.dt, k, f);
@@ -625,7 +625,7 @@ PB_HD void quad_role_passive(LD ld, ST st, XW xw, XR xr, SYNC sync, const StepIn
     for (int c = 0; c <= r; c++) Pjj[pk(r, c)] = (r == c) ? (J == 0 ? in.qg : in.qa) : 0.0;
   double xp[3];  // J == 1: rbis.cpp:51
 #pragma unroll
-  for (int i = 0; i < 3; i++) xp[i] = imu_idle(in.dt) ? x[12 + i] : in.accel[i] - x[18 + i];
+  for (int i = 0; i < 3; i++) xp[i] = in.accel[i] - x[18 + i];
   double dx1[9];    // SIX == 1, role PW: the omega block's correction of x[v chi Delta]
   double dsum[9];   // SIX == 2, role PW: the velocity block's correction, applied together with the position block's
 #pragma unroll

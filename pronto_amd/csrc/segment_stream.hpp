@@ -448,7 +448,7 @@ public:
     const size_t NC = chan_list_.size();
     for (auto &sg : segs_)
       if (sg->chan.size() != NC) sg->chan.resize(NC);
-    if (ring < 2) ring = 2;
+    if (ring < 3) ring = 3;   // (a block is read by its own chunk's kernels and by the first ones of the next)
     if (ring > 8) ring = 8;
     if (group < 1) group = 1;
     if (max_slots < 1) max_slots = 1;
@@ -499,9 +499,13 @@ public:
         stats.t_handlers += since(t0);
         finalize_after(*ck, k);
       }
-      // everything that reads this chunk's device block has been enqueued -- except what the estimator still holds back: that is
-      // applied (at the latest) by the first message of the next chunk, `ring` - 1 uploads before this block is written again
+      // Everything that reads this chunk's device block has been enqueued -- except what crosses into the NEXT chunk: a force/torque
+      // block kept by the handler for the joint state that follows it, an update the estimator holds back.  So the marker of the
+      // PREVIOUS chunk's block is set (again) here, behind this chunk's kernels: the block of chunk i is written again by the upload
+      // of chunk i + ring, issued after chunk i + ring - 1 >= i + 2 has been dispatched.
       pb_fence_record(est_->ctx, fences_[(size_t) ck->buf]);
+      if (prev_buf_ >= 0 && prev_buf_ != ck->buf) pb_fence_record(est_->ctx, fences_[(size_t) prev_buf_]);
+      prev_buf_ = ck->buf;
       t0 = now();
       pb_upload_sync(est_->ctx);   // the page-locked block may be refilled (the sparse channels' PB_HOST blocks were copied by their handlers)
       stats.t_upload += since(t0);
@@ -946,6 +950,7 @@ private:
   int first_alive_ = 0;
   std::vector<Buf> bufs_;
   std::vector<int> fences_;
+  int prev_buf_ = -1;
   std::mutex mu_;
   std::condition_variable cv_ready_, cv_free_;
   std::deque<Chunk *> ready_;
