@@ -92,6 +92,7 @@ struct pb_ctx {
   bool quad21 = true;   // PRONTO_BATCH_QUAD21=0: run the 21-state step on the two-wave kernel instead of the four-wave one (A/B)
   bool generic_update = false;  // PRONTO_BATCH_GENERIC_UPDATE=1: every stand-alone update on the run-time-index kernel (A/B, tests)
   bool smooth_attr = false;  // dynamic-LDS limit of the smoother kernels raised on this device
+  int n_cu = 256;            // compute units of the device (grid of the persistent smoother kernel)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   char err[512] = { 0 };
 };

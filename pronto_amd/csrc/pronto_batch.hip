@@ -34,6 +34,7 @@ extern "C" int pb_create(pb_ctx **out, int n_states, int batch, int device, int 
   c->B = batch;
   c->dev = device;
   c->nsnap = n_snapshots;
+  c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   {
     // 15-state hot kernel: the two-wave cooperative mapping (2 waves/SIMD, reads and writes interleave) measured
     // 3-20 % faster up to 256k filters, the one-lane-per-filter k_step 3-5 % faster beyond (profiles/).

@@ -34,6 +34,9 @@
 
 namespace pb {
 
+#ifndef SM_LANE_NR15
+#define SM_LANE_NR15 4
+#endif
 #ifndef SM_LANE_CH15
 #define SM_LANE_CH15 2
 #endif
@@ -42,7 +45,7 @@ template <int NS>
 struct SmoothLaneCfg {
   using L = Lay<NS>;
   using SL = Slots<NS>;
-  static constexpr int NR = (NS <= 16) ? 4 : 8;          // role waves per tile
+  static constexpr int NR = (NS <= 16) ? SM_LANE_NR15 : 8;   // role waves per tile
   static constexpr int NCOL = (NS + NR - 1) / NR;        // columns / gain rows per role
 #ifndef SM_LANE_CH21
 #define SM_LANE_CH21 3
@@ -101,6 +104,18 @@ __device__ __forceinline__ void lane_fence(int &sb, double after)
 __device__ __forceinline__ void lane_fence3(int &sb, int &sb1, int &sb2, double after)   // the same for all three bases of SE()
 {
   asm volatile("" : "+v"(sb), "+v"(sb1), "+v"(sb2) : "v"(after) : "memory");
+}
+
+// Workgroup barrier that orders LDS traffic ONLY.  __syncthreads() is a fence over every address space: the backend puts
+// `s_waitcnt vmcnt(0)` in front of every s_barrier, so each of the kernel's 20-30 barriers also waited for every global load in flight
+// (checkpoints requested ahead of their use) and every global store behind it (the posterior's entries: a full round trip to memory per
+// exchange of rows).  Global memory needs no ordering between the waves of a tile here: every wave reads its checkpoints' entries
+// itself and stores entries nobody reads in this launch.
+__device__ __forceinline__ void lds_barrier()
+{
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
 // The value is COMPUTED here: without this the backend sinks arithmetic below the next barrier to its first use, and what it was

@@ -10,7 +10,7 @@ from pronto_amd.batch import BatchEstimator  # noqa: E402
 from pronto_amd.synth import Workload  # noqa: E402
 
 for n in (15, 21):
-    B = 65536
+    B = int(os.environ.get("SMOOTH_B", "65536"))
     w = Workload(B, n_states=n)
     vec, quat, P0 = w.initial_state()
     est = BatchEstimator(B, n_states=n)
