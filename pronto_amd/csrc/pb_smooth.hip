@@ -75,8 +75,9 @@ int pbk_smooth_step(pb_ctx *c, const double *np_, const double *ns_, const doubl
                 (h[w][1] - t0) / 1e3, (h[w][2] - t0) / 1e3, (h[w][3] - t0) / 1e3, (h[w][4] - t0) / 1e3, (h[w][5] - t0) / 1e3, (h[w][6] - t0) / 1e3,
                 (h[w][7] - t0) / 1e3, h[w][8] / 1e3, h[w][9] / 1e3);
         if (c->ns == 15 && !lane15)   // k_smooth_wide: 6 = M made, 8 = first half published, 9 = its products done, 10 = second half published
-          fprintf(stderr, "  wide: prefetched columns taken %.1f, loads issued %.1f, M made %.1f, first half published %.1f, its products done %.1f, second half published %.1f\n",
-                  (h[w][11] - t0) / 1e3, (h[w][12] - t0) / 1e3, (h[w][6] - t0) / 1e3, (h[w][8] - t0) / 1e3, (h[w][9] - t0) / 1e3, (h[w][10] - t0) / 1e3);
+          fprintf(stderr, "  wide: P^- rows in LDS %.1f, barrier behind them %.1f, M made %.1f, first half published %.1f, its products done %.1f, second half published %.1f, "
+                          "posterior staged %.1f\n",
+                  (h[w][11] - t0) / 1e3, (h[w][12] - t0) / 1e3, (h[w][6] - t0) / 1e3, (h[w][8] - t0) / 1e3, (h[w][9] - t0) / 1e3, (h[w][10] - t0) / 1e3, (h[w][13] - t0) / 1e3);
       }
     }
   }

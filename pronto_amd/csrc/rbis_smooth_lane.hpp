@@ -249,7 +249,7 @@ __global__ __launch_bounds__(SmoothLaneCfg<NS>::THREADS, SmoothLaneCfg<NS>::WAVE
         for (int i = kk + 1; i < NS; i++) SE(pk(i, kk)) = a[t][i] * inv;
         inv_prev = inv;
       }
-      __syncthreads();
+      lds_barrier();
       if constexpr (kk == 0) SML_T(1);
       if constexpr (kk == NS - 1) SML_T(2);
       // the diagonal slot of column kk-1 held d for the downdates of step kk-1; every role is past them now: it becomes 1/d
@@ -325,7 +325,7 @@ __global__ __launch_bounds__(SmoothLaneCfg<NS>::THREADS, SmoothLaneCfg<NS>::WAVE
       }
     }
   }
-  __syncthreads();  // the factor is complete (the last reciprocal pivots were written behind the last barrier of step 1)
+  lds_barrier();  // the factor is complete (the last reciprocal pivots were written behind the last barrier of step 1)
   SML_T(3);
 
   // ---- 3. (P^-) X = Ad P_k out of the LDS factor: z[t][:] becomes row cidx[t] of G ----
@@ -372,7 +372,7 @@ __global__ __launch_bounds__(SmoothLaneCfg<NS>::THREADS, SmoothLaneCfg<NS>::WAVE
 #pragma unroll
     for (int i = 0; i < NS; i++) lane_pin(z[t][i]);
   }
-  __syncthreads();  // factor and residual are dead
+  lds_barrier();  // factor and residual are dead
   SML_T(4);
 
   // ---- 4. D = P^s - P^- (the uncorrected P^-, rbis.cpp:256) takes the factor's place; dx goes behind the residual ----
@@ -405,7 +405,7 @@ __global__ __launch_bounds__(SmoothLaneCfg<NS>::THREADS, SmoothLaneCfg<NS>::WAVE
       __builtin_amdgcn_sched_barrier(0);
     }
   }
-  __syncthreads();
+  lds_barrier();
   SML_T(5);
 
   // ---- 5. state: cur.addState(RBIS(dx)) (rbis.cpp:263-265), by the LAST role: the first CH roles make the first rows of M in step 6
@@ -509,7 +509,7 @@ __global__ __launch_bounds__(SmoothLaneCfg<NS>::THREADS, SmoothLaneCfg<NS>::WAVE
 #pragma unroll
       for (int j = 0; j < NS; j++) lane_pin(m[j]);
     }
-    __syncthreads();  // the readers of the previous chunk (and of dx) are done
+    lds_barrier();  // the readers of the previous chunk (and of dx) are done
 #ifdef SML_TIMELINE
     ta = __builtin_amdgcn_s_memtime();
     if (c0 == 0) tl[6] = ta; else tl[9] += ta - tl[10];
@@ -518,7 +518,7 @@ __global__ __launch_bounds__(SmoothLaneCfg<NS>::THREADS, SmoothLaneCfg<NS>::WAVE
 #pragma unroll
       for (int j = 0; j < NS; j++) S[(O_X + mcc * NS + j) * 64] = m[j];
     }
-    __syncthreads();
+    lds_barrier();
 #ifdef SML_TIMELINE
     tl[10] = __builtin_amdgcn_s_memtime();
     tl[8] += tl[10] - ta;

@@ -1,5 +1,6 @@
 // rbis_smooth_wide.hpp -- the RTS smoother step for 15 states (ekfSmoothingStep, state-estimator/src/mav_state_est/rbis.cpp:234-266) with
-// ONE LANE PER FILTER, four role waves per 64-filter tile and ONE wave per SIMD: 512 registers per lane (round 5).
+// ONE LANE PER FILTER, four role waves per 64-filter tile, ONE wave per SIMD (512 registers per lane) and a PERSISTENT workgroup per CU
+// that walks the tiles (round 5).
 //
 //   G      = P_k Ad^T (P^-_{k+1})^-1      P^s_k = P_k + G (P^s_{k+1} - P^-_{k+1}) G^T      x^s_k = x_k (+) G (x^s_{k+1} (-) x^-_{k+1})
 //
@@ -7,15 +8,18 @@
 // idle GPU takes 73 k cycles, half of them in the loop that hands the rows of M = G D round two at a time -- two of four roles make a
 // row while the others wait, 16 barriers -- and every checkpoint is asked for when it is needed, four exposed round trips to memory).
 // With 256 registers a role cannot hold its rows of G AND of M; with 512 it can, and the chain becomes:
-//   0. every global load of the tile is issued at the top: the role's columns of P^-, of P^s_{k+1} and of P_k (each checkpoint is read
-//      ONCE; D = P^s - P^- is formed column by column in registers as soon as both are there);
-//   1. P^- = L diag(d) L^T, right-looking, unpivoted, published column by column into LDS [packed entry][lane] (as k_smooth_lane);
+//   0. data movement by whole 16-byte ROWS of the tile (role w moves rows w, w + 4, ...: 18 loads per checkpoint and role instead of 40-60
+//      8-byte ones -- a wave may have 64 memory instructions in flight, and the texture path handles a half-used line as slowly as a full
+//      one), redistributed through LDS [entry][lane]; each checkpoint is read ONCE, the posterior is stored by whole rows;
+//      the rows of P^- of the NEXT tile are requested while this one computes (the factorisation can start at once), P_k and P^s_{k+1}
+//      of this tile arrive behind the factorisation;
+//   1. P^- = L diag(d) L^T, right-looking, unpivoted, published column by column into LDS in place (as k_smooth_lane);
 //   2. right-hand sides Ad P_k in registers, both substitutions out of the LDS factor: the role's rows of G;
-//   3. D takes the factor's place; every role makes ALL its rows of M = G D in one sweep over D (8 multiply-adds per LDS read);
+//   3. D = P^s - P^- takes the factor's place; every role makes ALL its rows of M = G D (two sweeps of two rows over D);
 //   4. the rows of M are published in two halves into the same LDS (8 rows x 15 = 120 entries = the factor's place) and
-//      P^s[r][c] = P_k[r][c] + G[r] . M[c] is finished from the role's registers: P_k(r, c) is the copy loaded in step 0.
-// 20 + 6 barriers; LDS (n (n + 1) / 2 + 3 n + 1) doubles per lane = 85 KB per tile; one tile per CU (the registers decide).
-// Role ownership, the LDS layout, the read fences and the stand-in column are k_smooth_lane's; so is the arithmetic of steps 1-2.
+//      P^s[r][c] = P_k[r][c] + G[r] . M[c] is finished from the role's registers into the output staging area.
+// LDS reads of the long phases are an explicit pipeline (lds_stream).  LDS per tile: 307 entries of 512 bytes = 154 KB; barriers order
+// LDS only (lds_barrier).  Role ownership, the [entry][lane] layout and the stand-in column are k_smooth_lane's, so is the arithmetic.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -64,8 +68,9 @@ __device__ __forceinline__ void lds_wait8(double (&b)[8])
                : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7])
                : "n"(CNT));
 }
+struct LdsBases { int b0, b1, b2; };   // byte addresses of this lane's entries 0, 128, 256 ([entry][lane] layout: 512 bytes per entry)
 template <int N, class EntryOf, class Use, class Pin>
-__device__ __forceinline__ void lds_stream(int byte_base0, int byte_base1, Use &&use, Pin &&pin)
+__device__ __forceinline__ void lds_stream(LdsBases bb, Use &&use, Pin &&pin)
 {
   constexpr int G = 8, NG = (N + G - 1) / G;
   double buf[2][G];
@@ -77,8 +82,9 @@ __device__ __forceinline__ void lds_stream(int byte_base0, int byte_base1, Use &
       constexpr int j = decltype(JJ)::value, kq = g * G + j;
       if constexpr (kq < N) {
         constexpr int e = EntryOf::at(kq);
-        if constexpr (e < 128) lds_rd_b64<e * 512>(buf[g & 1][j], byte_base0);
-        else lds_rd_b64<(e - 128) * 512>(buf[g & 1][j], byte_base1);
+        if constexpr (e < 128) lds_rd_b64<e * 512>(buf[g & 1][j], bb.b0);
+        else if constexpr (e < 256) lds_rd_b64<(e - 128) * 512>(buf[g & 1][j], bb.b1);
+        else lds_rd_b64<(e - 256) * 512>(buf[g & 1][j], bb.b2);
       }
     });
   };
@@ -125,30 +131,50 @@ template <int NS>
 struct SmoothWideCfg {
   using L = Lay<NS>;
   using SL = Slots<NS>;
-  static constexpr int NR = SMW_NR;                  // role waves per tile
+  static constexpr int NR = 4;                       // role waves per tile, one per SIMD
   static constexpr int NCOL = (NS + NR - 1) / NR;    // columns / gain rows per role
   static constexpr int NP = L::NP;
   static constexpr int HALF = NP / NS;               // rows of M per publish (n = 15: 8)
-  static constexpr int O_X = NP;                     // behind the factor / D / M: residual [n], dx [n]
-  static constexpr int O_S = NP + 2 * NS;            // the filtered state vector [n] and log-likelihood, parked by the last role until the end
-  static constexpr int PER = NP + 3 * NS + 1;        // doubles per lane
+  // LDS entries (64 doubles each):
+  static constexpr int O_A = 0;                      // P^- -> its factor -> D -> half of M
+  static constexpr int O_B = NP;                     // [covariance entries | vec, quat, ll] of the filtered checkpoint, then of the posterior
+  static constexpr int NST = NS + 5;                 // vec, quat, ll of one checkpoint, canonical order
+  static constexpr int NB = NP + NST;
+  static constexpr int O_SN = O_B + NB;              // vec, quat of x^s_{k+1}; the residual takes the place of its vec
+  static constexpr int O_SP = O_SN + NST;            // vec, quat of x^-_{k+1}; dx takes its place
+  static constexpr int O_X = O_SN;                   // residual [n]
+  static constexpr int O_DX = O_SP;                  // dx [n]
+  static constexpr int DUMMY = O_SP + NST;           // where the halves of a row that nobody wants go
+  static constexpr int PER = DUMMY + 1;
   static constexpr int THREADS = 64 * NR;
   static constexpr size_t LDS_BYTES = sizeof(double) * PER * 64;
-  static_assert(NS == 15, "15 states only: 21 states need 231 entries for D and have no room for half of M (rbis_smooth_lane.hpp stays)");
+  static_assert(NS == 15, "15 states only: 21 states need 231 entries for D alone (rbis_smooth_lane.hpp stays)");
   static_assert(2 * HALF >= NS && HALF * NS <= NP && HALF % NR == 0, "two publishes cover every row of M inside the factor's place");
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS of a CU");
   static constexpr int off_of(int comp) { return (SL::T.slot_of[comp] / 2) * 128 + (SL::T.slot_of[comp] % 2); }
-  static constexpr int NSP = (NS + 3) & ~3;
+  static constexpr int RU = (SL::NROW + NR - 1) / NR;   // rows per role
+  // Where the two halves of row w + NR u go in LDS, for each use of a row (ONE table row per use and role: 36 neighbouring words,
+  // fetched with a few wide scalar loads):
+  enum { PUT_NP = 0, PUT_CUR = 1, PUT_NS_STATE = 2, PUT_D = 3, GET_OUT = 4, NPUT = 5 };
   struct Tab {
-    int col[NR][NCOL][NSP];   // col[w][t][i] = offset of P(i, column w + NR t) -- by symmetry also of P(row w + NR t, i)
+    int put[NPUT][NR][RU][2];
   };
   static constexpr Tab make()
   {
     Tab t{};
     for (int w = 0; w < NR; w++)
-      for (int c = 0; c < NCOL; c++) {
-        const int j = (w + NR * c < NS) ? w + NR * c : NS - 1;
-        for (int i = 0; i < NSP; i++) t.col[w][c][i] = off_of(L::OFF_P + pk(i < NS ? i : NS - 1, j));
-      }
+      for (int u = 0; u < RU; u++)
+        for (int h = 0; h < 2; h++) {
+          const int r2 = w + NR * u;
+          const int comp = (r2 < SL::NROW) ? SL::T.comp_of[2 * r2 + h] : -1;
+          const int ep = (comp >= L::OFF_P) ? comp - L::OFF_P : -1;           // packed covariance entry
+          const int es = (comp >= 0 && comp < L::OFF_P) ? comp : -1;          // canonical state component (vec i: i; quat j: n + j; ll: n + 4)
+          t.put[PUT_NP][w][u][h] = ep >= 0 ? O_A + ep : es >= 0 ? O_SP + es : DUMMY;        // P^- into the factor's place, x^- beside it
+          t.put[PUT_CUR][w][u][h] = ep >= 0 ? O_B + ep : es >= 0 ? O_B + NP + es : DUMMY;    // the filtered checkpoint
+          t.put[PUT_NS_STATE][w][u][h] = es >= 0 ? O_SN + es : DUMMY;                        // x^s_{k+1}
+          t.put[PUT_D][w][u][h] = ep >= 0 ? O_A + ep : DUMMY;                                // D = P^s - P^-
+          t.put[GET_OUT][w][u][h] = ep >= 0 ? O_B + ep : es >= 0 ? O_B + NP + es : DUMMY;    // the posterior, from the staging area
+        }
     return t;
   }
 };
@@ -162,20 +188,21 @@ __constant__ const typename SmoothWideCfg<NS>::Tab smooth_wide_tab = SmoothWideC
 #endif
 
 template <int NS>
-__global__ __launch_bounds__(SmoothWideCfg<NS>::THREADS, SmoothWideCfg<NS>::NR / 4) void k_smooth_wide(const double *__restrict__ next_pred, const double *__restrict__ next_sm,
+__global__ __launch_bounds__(SmoothWideCfg<NS>::THREADS, 1) void k_smooth_wide(const double *__restrict__ next_pred, const double *__restrict__ next_sm,
                                                                              const double *cur, double *out, int B, int ntiles, double dt, Consts k)
 {
   using L = Lay<NS>;
   using SL = Slots<NS>;
   using C = SmoothWideCfg<NS>;
-  constexpr int NR = C::NR, NCOL = C::NCOL, O_X = C::O_X, HALF = C::HALF;
+  constexpr int NR = C::NR, NCOL = C::NCOL, O_X = C::O_X, O_DX = C::O_DX, O_B = C::O_B, HALF = C::HALF, RU = C::RU, NP = C::NP;
+  static_assert(L::OFF_VEC == 0 && L::OFF_QUAT == NS && L::OFF_LL == NS + 4, "the staging area keeps vec, quat, ll in canonical order");
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int lane = threadIdx.x & 63;
   const int w0 = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
   int w = w0;   // (made opaque again at the top of every tile: see the loop)
-  // Global accesses are buffer instructions: a descriptor per checkpoint AND TILE (scalar registers), the component's offset in the
-  // scalar offset, the lane's 16-byte column in ONE vector register for every access -- no address registers and no vector arithmetic
-  // per access (with 64-bit per-lane addresses the 200 loads at the top of a tile held two registers each just for their addresses).
+  // Global accesses are buffer instructions: a descriptor per checkpoint AND TILE (scalar registers), the row / component in the scalar
+  // offset, the lane's 16-byte column in ONE vector register for every access -- no address registers, no vector arithmetic per access.
+  // A row past the tile's last (role 2 / 3, u = 17) is outside the descriptor: it loads zeros and its store is dropped.
   const unsigned lane_b = (unsigned) lane * 16u;
   struct TileBufs { rsrc_t np, ns, cu, out; };
   auto bufs_of = [&](int tile) {
@@ -184,22 +211,29 @@ __global__ __launch_bounds__(SmoothWideCfg<NS>::THREADS, SmoothWideCfg<NS>::NR /
                      mkbuf(out + off, SL::TILE_BYTES) };
   };
   TileBufs tbuf = bufs_of((int) blockIdx.x);
-  const auto &tab = smooth_wide_tab<NS>;
-  // entry e of this lane's filter: lds[sb + e * 64]; two bases so that every access keeps an immediate offset (rbis_smooth_lane.hpp)
-  int sb = lane, sb1 = lane + 128 * 64;
-  asm volatile("" : "+v"(sb), "+v"(sb1));
-  // the same two bases as LDS byte addresses, for lds_stream (dynamic LDS starts at 0: no static LDS in this kernel)
-  const int bb0 = lane * 8, bb1 = lane * 8 + 128 * 512;
+  // entry e of this lane's filter: lds[sb + e * 64]; three bases so that every access keeps an immediate offset (rbis_smooth_lane.hpp)
+  int sb = lane, sb1 = lane + 128 * 64, sb2 = lane + 256 * 64;
+  asm volatile("" : "+v"(sb), "+v"(sb1), "+v"(sb2));
+  const LdsBases bb{ lane * 8, lane * 8 + 128 * 512, lane * 8 + 256 * 512 };   // (dynamic LDS starts at 0: no static LDS in this kernel)
 #define WS (lds + sb)
-#define WE(e) (*(((e) < 128) ? (lds + sb + (e) * 64) : (lds + sb1 + ((e) - 128) * 64)))
-#define WFENCE(after) asm volatile("" : "+v"(sb), "+v"(sb1) : "v"(after) : "memory")
+#define WE(e) (*(((e) < 128) ? (lds + sb + (e) * 64) : ((e) < 256) ? (lds + sb1 + ((e) - 128) * 64) : (lds + sb2 + ((e) - 256) * 64)))
   auto ldc = [&](rsrc_t src, int comp) { return ldg(src, (unsigned) C::off_of(comp) * 8u, lane_b); };
-  auto ld_col = [&](rsrc_t src, int t, int i0, double (&v)[NS]) {  // rows i0 .. n-1 of column t of this role (the others: 0)
-    int o[NS];
+  auto ld_rows = [&](rsrc_t src, d2_t (&r)[RU]) {   // this role's rows of one checkpoint
 #pragma unroll
-    for (int i = 0; i < NS; i++) o[i] = tab.col[w][t][i];
+    for (int u = 0; u < RU; u++) r[u] = ldg2(src, (unsigned) (w + NR * u) * 1024u, lane_b);
+  };
+  // ... into LDS [entry][lane] by one of the table's uses
+  auto put_rows = [&](const d2_t (&r)[RU], int use) {
+    int e[RU][2];
 #pragma unroll
-    for (int i = 0; i < NS; i++) v[i] = (i >= i0) ? ldg(src, (unsigned) o[i] * 8u, lane_b) : 0.0;
+    for (int u = 0; u < RU; u++)
+#pragma unroll
+      for (int h = 0; h < 2; h++) e[u][h] = smooth_wide_tab<NS>.put[use][w][u][h];
+#pragma unroll
+    for (int u = 0; u < RU; u++) {
+      WS[e[u][0] * 64] = r[u].x;
+      WS[e[u][1] * 64] = r[u].y;
+    }
   };
 
 #ifdef SML_TIMELINE
@@ -207,18 +241,16 @@ __global__ __launch_bounds__(SmoothWideCfg<NS>::THREADS, SmoothWideCfg<NS>::NR /
 #endif
 
   // The workgroup is PERSISTENT: tiles blockIdx.x, + gridDim.x, ... (one workgroup per CU fills the registers anyway).  What the
-  // factorisation starts from -- the role's columns of P^- -- is requested one tile AHEAD (behind step 4, when the registers of D are
-  // free), so a tile begins to compute at once; its other two checkpoints are requested at its top and arrive behind the
-  // factorisation.  Without this every CU asks for its whole tile at the same moment and then computes with the memory idle.
-  double a[NCOL][NS];
-#pragma unroll
-  for (int t = 0; t < NCOL; t++) ld_col(tbuf.np, t, NR * t, a[t]);
+  // factorisation starts from -- the rows of P^- -- is requested one tile AHEAD (behind step 4), so a tile begins to compute at once; its
+  // other two checkpoints are requested at its top and arrive behind the factorisation.  Without this every CU asks for its whole
+  // tile at the same moment and then computes with the memory idle.
+  d2_t ar[RU];
+  ld_rows(tbuf.np, ar);
 #pragma unroll 1
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
   tbuf = bufs_of(tile);
-  // The role index is made opaque per tile: what depends on it (table offsets, LDS indices of the role's columns, ~300 scalars) would
-  // otherwise be computed ONCE in front of the loop and kept -- in scalar registers the kernel does not have (spilled to vector lanes
-  // and from there to scratch).
+  // The role index is made opaque per tile: what depends on it (table entries, LDS indices of the role's columns, ~300 scalars) would
+  // otherwise be computed ONCE in front of the loop and kept -- in scalar registers the kernel does not have.
   w = w0;
   asm volatile("" : "+s"(w));
   int cidx[NCOL], cc[NCOL];  // this role's columns (gain rows); the stand-in mirrors column n - 1
@@ -229,71 +261,31 @@ __global__ __launch_bounds__(SmoothWideCfg<NS>::THREADS, SmoothWideCfg<NS>::NR /
   }
   const bool has_last = cidx[NCOL - 1] < NS;  // (wave-uniform) the role's last column slot is a real column
   const bool active = (long) tile * 64 + lane < B;
-  lds_barrier();  // the previous tile's readers of the LDS are done
 #ifdef SML_TIMELINE
   const bool stamp = tile == SML_TIMELINE;
 #endif
+  lds_barrier();  // the previous tile's readers of the LDS are done
   SMW_T(0);
 
-  // The prefetched columns are TAKEN here, in front of this tile's loads: the counter of outstanding memory operations has 6 bits, and
-  // a wait for these (old) loads placed behind 100 younger ones can only be written as "at most 62 outstanding" -- it then waits for
-  // half of the tile's fresh loads as well (measured: 12 k cycles at the top of every tile).
-#pragma unroll
-  for (int t = 0; t < NCOL; t++)
-#pragma unroll
-    for (int i = NR * t; i < NS; i++) lane_pin(a[t][i]);
+  // ---- 0. P^- (prefetched rows) into the factor's place, x^- beside it; this tile's rows of P_k and P^s_{k+1} are requested ----
+  put_rows(ar, C::PUT_NP);
   SMW_T(11);
-
-  // ---- 0. the loads of the tile that the factorisation can hide: what the last role needs for the residual and the state update
-  //         (FIRST: loads return in order, and it is the one that consumes early), the filtered state for Ad and the role's columns of
-  //         P_k (whole: the right-hand side needs the column, step 7 its part left of the diagonal).  The columns of P^s_{k+1} are asked
-  //         for behind the factorisation, when the registers of `a` are free ----
-  double dcol[NCOL][NS], p[NCOL][NS], a0[NCOL][NS];
-  // (the state vectors are shared out: role w asks for components w, w + NR, ... of the three checkpoints -- all of them on one role
-  //  were 54 loads in flight on top of its columns, which the backend serialised into 15 round trips to memory for want of registers)
-  double rqs[4], rqp[4], rvs[NCOL], rvp[NCOL], xc[NCOL], llc = 0.0;   // (raw: consumed behind the factorisation, nothing waits here)
-  static_for<NR>([&](auto WW) {
-    constexpr int ww = decltype(WW)::value;
-    if (w == ww) {
-#pragma unroll
-      for (int t = 0; t < NCOL; t++) {
-        const int i = ww + NR * t;   // (compile-time inside this branch)
-        if (i < NS) {
-          rvs[t] = ldc(tbuf.ns, L::OFF_VEC + i);
-          rvp[t] = ldc(tbuf.np, L::OFF_VEC + i);
-          xc[t] = ldc(tbuf.cu, L::OFF_VEC + i);
-        } else {
-          rvs[t] = rvp[t] = xc[t] = 0.0;
-        }
-      }
-    }
-  });
-  if (w == NR - 1) {
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      rqs[i] = ldc(tbuf.ns, L::OFF_QUAT + i);
-      rqp[i] = ldc(tbuf.np, L::OFF_QUAT + i);
-    }
-    llc = ldc(tbuf.cu, L::OFF_LL);
-  }
-  double wv[3], vv[3], q[4];
-#pragma unroll
-  for (int i = 0; i < 3; i++) {
-    wv[i] = ldc(tbuf.cu, L::OFF_VEC + i);
-    vv[i] = ldc(tbuf.cu, L::OFF_VEC + 3 + i);
-  }
-#pragma unroll
-  for (int i = 0; i < 4; i++) q[i] = ldc(tbuf.cu, L::OFF_QUAT + i);
-#pragma unroll
-  for (int t = 0; t < NCOL; t++) ld_col(tbuf.cu, t, 0, p[t]);
-  // the uncorrected P^- for D = P^s - P^- (rbis.cpp:256): a copy, the factorisation works on `a`
+  d2_t cr[RU], nr[RU];
+  ld_rows(tbuf.cu, cr);
+  ld_rows(tbuf.ns, nr);
+  lds_barrier();  // P^- is in LDS
+  SMW_T(12);
+  // the role's columns of P^-, rows at or below NR t (what is above the column's own diagonal is never used: those entries belong to
+  // another role's column and may already hold its factor)
+  double a[NCOL][NS];
 #pragma unroll
   for (int t = 0; t < NCOL; t++)
 #pragma unroll
-    for (int i = 0; i < NS; i++) a0[t][i] = a[t][i];
+    for (int i = 0; i < NS; i++) a[t][i] = (i >= NR * t) ? WS[pk_s(i, cc[t]) * 64] : 0.0;
 
-  SMW_T(12);
-  // ---- 1. P^- = L diag(d) L^T (k_smooth_lane's step 1) ----
+  // ---- 1. P^- = L diag(d) L^T (k_smooth_lane's step 1).  In front of its ninth barrier (the other two checkpoints have arrived by
+  //         then): P_k and x_k into LDS, x^s_{k+1} beside x^-, and D = P^s - P^- (the uncorrected P^-, rbis.cpp:256) row by row in
+  //         registers -- the rows of the three checkpoints are the same rows ----
   {
     double inv_prev = 0.0;
     static_for<NS>([&](auto KK) {
@@ -306,6 +298,12 @@ __global__ __launch_bounds__(SmoothWideCfg<NS>::THREADS, SmoothWideCfg<NS>::NR /
 #pragma unroll
         for (int i = kk + 1; i < NS; i++) WE(pk(i, kk)) = a[t][i] * inv;
         inv_prev = inv;
+      }
+      if constexpr (kk == 8) {
+        put_rows(cr, C::PUT_CUR);
+        put_rows(nr, C::PUT_NS_STATE);
+#pragma unroll
+        for (int u = 0; u < RU; u++) ar[u] = nr[u] - ar[u];
       }
       lds_barrier();
       if constexpr (kk == 0) SMW_T(1);
@@ -333,25 +331,37 @@ __global__ __launch_bounds__(SmoothWideCfg<NS>::THREADS, SmoothWideCfg<NS>::NR /
     });
   }
 
-  // residual x^s (-) x^- (rbis.cpp:258-261) for step 3 and the filtered state for step 8, parked in LDS (registers are scarce from here on)
+  // residual x^s (-) x^- (rbis.cpp:258-261) for step 3, in the place of x^s: role w its components w, w + NR, ..., the last role the
+  // attitude part
 #pragma unroll
   for (int t = 0; t < NCOL; t++)
-    if (cidx[t] < NS) {
-      if (cidx[t] < 6 || cidx[t] > 8) WS[(O_X + cidx[t]) * 64] = rvs[t] - rvp[t];
-      WS[(C::O_S + cidx[t]) * 64] = xc[t];
-    }
+    if (cidx[t] < NS && (cidx[t] < 6 || cidx[t] > 8)) WS[(O_X + cidx[t]) * 64] = WS[(C::O_SN + cidx[t]) * 64] - WS[(C::O_SP + cidx[t]) * 64];
   if (w == NR - 1) {
-    double dchi[3];
+    double rqs[4], rqp[4], dchi[3];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      rqs[i] = WE(C::O_SN + NS + i);
+      rqp[i] = WE(C::O_SP + NS + i);
+    }
     subtract_quats(rqs, rqp, dchi);
 #pragma unroll
     for (int i = 0; i < 3; i++) WE(O_X + 6 + i) = dchi[i];
-    WE(C::O_S + NS) = llc;
   }
-#pragma unroll
-  for (int t = 0; t < NCOL; t++) ld_col(tbuf.ns, t, NR * t, dcol[t]);
 
   // ---- 2. right-hand sides: columns cc[t] of Ad P_k, Ad = I + dt Ac about the filtered state (rbis.cpp:12-35, 236-239) ----
-  double z[NCOL][NS];
+  double z[NCOL][NS], p[NCOL][NS];
+#pragma unroll
+  for (int t = 0; t < NCOL; t++)
+#pragma unroll
+    for (int i = 0; i < NS; i++) p[t][i] = WS[(O_B + pk_s(i, cc[t])) * 64];
+  double wv[3], vv[3], q[4];
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    wv[i] = WE(O_B + NP + i);
+    vv[i] = WE(O_B + NP + 3 + i);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; i++) q[i] = WE(O_B + NP + NS + i);
   {
     double R[9];
     quat_to_rot(q, R);
@@ -385,17 +395,17 @@ __global__ __launch_bounds__(SmoothWideCfg<NS>::THREADS, SmoothWideCfg<NS>::NR /
 #pragma unroll
       for (int i = 0; i < NS; i++) lane_pin(z[t][i]);
   };
-  lds_stream<NS *(NS - 1) / 2, SmwLowerStrict>(bb0, bb1, [&](auto KQ, double l) {
+  lds_stream<NS *(NS - 1) / 2, SmwLowerStrict>(bb, [&](auto KQ, double l) {
     constexpr int kq = decltype(KQ)::value, i = SmwLowerStrict::row(kq), mm = SmwLowerStrict::col(kq);
 #pragma unroll
     for (int t = 0; t < NCOL; t++) z[t][i] = fma(-l, z[t][mm], z[t][i]);
   }, pin_z);
-  lds_stream<NS, SmwDiag>(bb0, bb1, [&](auto KQ, double inv) {
+  lds_stream<NS, SmwDiag>(bb, [&](auto KQ, double inv) {
     constexpr int i = decltype(KQ)::value;
 #pragma unroll
     for (int t = 0; t < NCOL; t++) z[t][i] *= inv;
   }, pin_z);
-  lds_stream<NS *(NS - 1) / 2, SmwBackward<NS>>(bb0, bb1, [&](auto KQ, double l) {
+  lds_stream<NS *(NS - 1) / 2, SmwBackward<NS>>(bb, [&](auto KQ, double l) {
     constexpr int kq = decltype(KQ)::value, i = SmwBackward<NS>::ci(kq), mm = SmwBackward<NS>::cm(kq);
 #pragma unroll
     for (int t = 0; t < NCOL; t++) z[t][i] = fma(-l, z[t][mm], z[t][i]);
@@ -404,7 +414,7 @@ __global__ __launch_bounds__(SmoothWideCfg<NS>::THREADS, SmoothWideCfg<NS>::NR /
   double dxv[NCOL];
 #pragma unroll
   for (int t = 0; t < NCOL; t++) dxv[t] = 0.0;
-  lds_stream<NS, SmwRun<O_X>>(bb0, bb1, [&](auto KQ, double r) {
+  lds_stream<NS, SmwRun<O_X>>(bb, [&](auto KQ, double r) {
     constexpr int i = decltype(KQ)::value;
 #pragma unroll
     for (int t = 0; t < NCOL; t++) dxv[t] = fma(z[t][i], r, dxv[t]);
@@ -421,33 +431,28 @@ __global__ __launch_bounds__(SmoothWideCfg<NS>::THREADS, SmoothWideCfg<NS>::NR /
   lds_barrier();  // factor and residual are dead
   SMW_T(4);
 
-  // ---- 4. D = P^s - P^- (the uncorrected P^-, rbis.cpp:256) takes the factor's place, column by column from the registers of step 0
-  //         (an entry above the role's diagonal is the mirror image of another role's entry: the same bits, written twice) ----
+  // ---- 4. D = P^s - P^- takes the factor's place (its rows are in registers since step 1); dx takes the place of x^- ----
+  put_rows(ar, C::PUT_D);
 #pragma unroll
-  for (int t = 0; t < NCOL; t++) {
-    if (cidx[t] < NS) WS[(O_X + NS + cidx[t]) * 64] = dxv[t];
-#pragma unroll
-    for (int i = NR * t; i < NS; i++) WS[pk_s(i, cc[t]) * 64] = dcol[t][i] - a0[t][i];
-  }
-  {  // the NEXT tile's columns of P^- (the last tile asks for its own again: the same instruction stream for every tile)
+  for (int t = 0; t < NCOL; t++)
+    if (cidx[t] < NS) WS[(O_DX + cidx[t]) * 64] = dxv[t];
+  {  // the NEXT tile's rows of P^- (the last tile asks for its own again: the same instruction stream for every tile)
     const int ntile = (tile + (int) gridDim.x < ntiles) ? tile + (int) gridDim.x : tile;
-    const rsrc_t npn = mkbuf(next_pred + (long) ntile * SL::TILE_DOUBLES, SL::TILE_BYTES);
-#pragma unroll
-    for (int t = 0; t < NCOL; t++) ld_col(npn, t, NR * t, a[t]);
+    ld_rows(mkbuf(next_pred + (long) ntile * SL::TILE_DOUBLES, SL::TILE_BYTES), ar);
   }
   lds_barrier();
   SMW_T(5);
 
-  // ---- 6. M = G D: ALL rows of the role in one sweep over the symmetric D (every entry read once, 2 NCOL multiply-adds each) ----
+  // ---- 6. M = G D: ALL rows of the role, in passes of two rows over the symmetric D (with all four the accumulators and G fill the
+  //         architectural registers and nothing is left to read ahead into) ----
   double m[NCOL][NS];
 #pragma unroll
   for (int t = 0; t < NCOL; t++)
 #pragma unroll
     for (int j = 0; j < NS; j++) m[t][j] = 0.0;
-  // in passes of two rows: with all four the accumulators and G fill the architectural registers and nothing is left to read ahead into
   auto sweep = [&](auto T0, auto NT) {
     constexpr int t0 = decltype(T0)::value, nt = decltype(NT)::value;
-    lds_stream<C::NP, SmwPacked>(bb0, bb1, [&](auto KQ, double d) {
+    lds_stream<NP, SmwPacked>(bb, [&](auto KQ, double d) {
       constexpr int kq = decltype(KQ)::value, i = pk_row(kq), j = pk_col(kq);
 #pragma unroll
       for (int t = t0; t < t0 + nt; t++) {
@@ -470,7 +475,11 @@ __global__ __launch_bounds__(SmoothWideCfg<NS>::THREADS, SmoothWideCfg<NS>::NR /
 #pragma unroll
     for (int j = 0; j < NS; j++) lane_pin(m[t][j]);
 
-  // ---- 7. P^s[r][c] = P_k[r][c] + G[r] . M[c] for c <= r: the rows of M in two halves through the place of D ----
+  // ---- 7. P^s[r][c] = P_k[r][c] + G[r] . M[c] for c <= r: the rows of M in two halves through the place of D, the results into the
+  //         staging area (the place of P^s_{k+1}, read for the last time in step 4) ----
+  int rbase[NCOL];   // packed index of (row cidx[t], column 0)
+#pragma unroll
+  for (int t = 0; t < NCOL; t++) rbase[t] = cidx[t] * (cidx[t] + 1) / 2;
   static_for<2>([&](auto HH) {
     constexpr int h = decltype(HH)::value;
     lds_barrier();  // D (h = 0) / the first half of M (h = 1) is dead
@@ -485,20 +494,9 @@ __global__ __launch_bounds__(SmoothWideCfg<NS>::THREADS, SmoothWideCfg<NS>::NR /
     }
     lds_barrier();
     if constexpr (h == 0) SMW_T(8); else SMW_T(10);
-    // the offsets of this half's stores, fetched HERE (a scalar load in the middle of lds_stream's pipeline would stall it: one counter)
-    int so[HALF][NCOL];
-#pragma unroll
-    for (int t = 0; t < NCOL; t++)
-#pragma unroll
-      for (int cq = 0; cq < HALF; cq++) so[cq][t] = smooth_wide_tab<NS>.col[w][t][HALF * h + cq];   // (8 neighbours: wide loads)
-#pragma unroll
-    for (int t = 0; t < NCOL; t++)
-#pragma unroll
-      for (int cq = 0; cq < HALF; cq++)
-        if (HALF * h + cq < NS && t >= (HALF * h + cq) / NR) asm volatile("" : "+s"(so[cq][t]));   // (all in flight together, THEN pinned)
     // ONE stream over the half: columns two at a time, their rows of M interleaved entry by entry (2 x up to NCOL sums in flight: a
     // multiply-add that waits for its predecessor costs twice its issue slot); the role's rows r = w + NR t at or below the column.
-    // Compile time: t >= c / NR; run time: c <= r.  A pair's sums are stored as soon as its last entry is in.
+    // Compile time: t >= c / NR; run time: c <= r.  A pair's sums go to the staging area as soon as its last entry is in.
     constexpr int rows_h = (HALF * (h + 1) <= NS) ? HALF : NS - HALF * h;
     using FE = SmwFinal<NS, rows_h>;
     double acc[HALF][NCOL];
@@ -506,7 +504,7 @@ __global__ __launch_bounds__(SmoothWideCfg<NS>::THREADS, SmoothWideCfg<NS>::NR /
     for (int cq = 0; cq < HALF; cq++)
 #pragma unroll
       for (int t = 0; t < NCOL; t++) acc[cq][t] = (cq < rows_h) ? p[t][HALF * h + cq < NS ? HALF * h + cq : 0] : 0.0;
-    lds_stream<rows_h * NS, FE>(bb0, bb1, [&](auto KQ, double mv) {
+    lds_stream<rows_h * NS, FE>(bb, [&](auto KQ, double mv) {
       constexpr int kq = decltype(KQ)::value, cq = FE::row(kq), j = FE::col(kq), c = HALF * h + cq;
 #pragma unroll
       for (int t = 0; t < NCOL; t++)
@@ -518,7 +516,7 @@ __global__ __launch_bounds__(SmoothWideCfg<NS>::THREADS, SmoothWideCfg<NS>::NR /
           for (int t = 0; t < NCOL; t++)
             if (t >= (HALF * h + cs) / NR) {
               lane_pin(acc[cs][t]);
-              if (active && cidx[t] < NS && HALF * h + cs <= cidx[t]) stg(tbuf.out, (unsigned) so[cs][t] * 8u, lane_b, acc[cs][t]);
+              if (cidx[t] < NS && HALF * h + cs <= cidx[t]) WS[(O_B + rbase[t] + HALF * h + cs) * 64] = acc[cs][t];
             }
       }
     }, [&]() {
@@ -529,28 +527,38 @@ __global__ __launch_bounds__(SmoothWideCfg<NS>::THREADS, SmoothWideCfg<NS>::NR /
           if (t >= (HALF * h + cq) / NR) lane_pin(acc[cq][t]);
     });
   });
-  // ---- 5. state: cur.addState(RBIS(dx)) (rbis.cpp:263-265), by the LAST role, at the end (nobody waits for it at a barrier) ----
+  // ---- 8. state: cur.addState(RBIS(dx)) (rbis.cpp:263-265), by the LAST role (it has a stand-in instead of a fourth row), into the
+  //         staging area behind the covariance ----
   if (w == NR - 1) {
-    double dchi[3] = { WE(O_X + NS + 6), WE(O_X + NS + 7), WE(O_X + NS + 8) };
+    double dchi[3] = { WE(O_DX + 6), WE(O_DX + 7), WE(O_DX + 8) };
     double dq[4] = { 1.0, 0.0, 0.0, 0.0 };
     fold_chi(dchi, dq, k.chi_tol);  // RBIS(vec) constructor
     double chi[3], qq[4], qo[4];
 #pragma unroll
-    for (int i = 0; i < 3; i++) chi[i] = WE(C::O_S + 6 + i) + dchi[i];
+    for (int i = 0; i < 3; i++) chi[i] = WE(O_B + NP + 6 + i) + dchi[i];
 #pragma unroll
-    for (int i = 0; i < 4; i++) qq[i] = q[i];
+    for (int i = 0; i < 4; i++) qq[i] = WE(O_B + NP + NS + i);
     fold_chi(chi, qq, k.chi_tol);
     quat_mul(qq, dq, qo);
-    double xo[NS];
 #pragma unroll
-    for (int i = 0; i < NS; i++) xo[i] = (i >= 6 && i <= 8) ? chi[i - 6] : WE(C::O_S + i) + WE(O_X + NS + i);
-    const double ll = WE(C::O_S + NS);
-    if (active) {
+    for (int i = 0; i < NS; i++) WE(O_B + NP + i) = (i >= 6 && i <= 8) ? chi[i - 6] : WE(O_B + NP + i) + WE(O_DX + i);
 #pragma unroll
-      for (int i = 0; i < NS; i++) stg(tbuf.out, (unsigned) C::off_of(L::OFF_VEC + i) * 8u, lane_b, xo[i]);
+    for (int i = 0; i < 4; i++) WE(O_B + NP + NS + i) = qo[i];
+    // (the log-likelihood stays where the filtered checkpoint's row put it)
+  }
+  lds_barrier();
+  SMW_T(13);
+  // ---- 9. the posterior by whole rows ----
+  {
+    int e[RU][2];
 #pragma unroll
-      for (int i = 0; i < 4; i++) stg(tbuf.out, (unsigned) C::off_of(L::OFF_QUAT + i) * 8u, lane_b, qo[i]);
-      stg(tbuf.out, (unsigned) C::off_of(L::OFF_LL) * 8u, lane_b, ll);
+    for (int u = 0; u < RU; u++)
+#pragma unroll
+      for (int h = 0; h < 2; h++) e[u][h] = smooth_wide_tab<NS>.put[C::GET_OUT][w][u][h];
+#pragma unroll
+    for (int u = 0; u < RU; u++) {
+      const d2_t v = { WS[e[u][0] * 64], WS[e[u][1] * 64] };
+      if (active) stg2(tbuf.out, (unsigned) (w + NR * u) * 1024u, lane_b, v);
     }
   }
 
@@ -565,6 +573,5 @@ __global__ __launch_bounds__(SmoothWideCfg<NS>::THREADS, SmoothWideCfg<NS>::NR /
 #undef SMW_T
 #undef WS
 #undef WE
-#undef WFENCE
 
 }  // namespace pb
