@@ -52,7 +52,7 @@ namespace pb {
 // entries G at a time into two buffers with ds_read_b64 of its own (single reads: the LDS serves two of them in half the time of the
 // paired ds_read2st64_b64 the backend prefers), the reads of group g + 1 issued BEFORE the wait for group g (a counted s_waitcnt: LDS
 // operations of a wave return in order; a scalar load the backend may have in flight can only make the wait longer, never shorter).
-// `use(k, value)` is called for k = 0 .. N-1 in order with k a compile-time constant; `pin()` after every group: it names what the
+// `use(k, value)` is called for k = 0 .. N-1 in order with k a compile-time constant; `pin(g)` after every group g: it names what the
 // group's arithmetic wrote (lane_pin), which keeps that arithmetic in front of the next group's reads -- the backend would otherwise
 // let all the reads of the list go first and park their values in accumulation registers.
 template <int OFF>
@@ -98,7 +98,7 @@ __device__ __forceinline__ void lds_stream(LdsBases bb, Use &&use, Pin &&pin)
       constexpr int j = decltype(JJ)::value, kq = g * G + j;
       if constexpr (kq < N) use(std::integral_constant<int, kq>{}, buf[g & 1][j]);
     });
-    pin();
+    pin(std::integral_constant<int, g>{});
   });
 }
 // entry lists
@@ -240,15 +240,19 @@ __global__ __launch_bounds__(SmoothWideCfg<NS>::THREADS, 1) void k_smooth_wide(c
   unsigned long long tl[16] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
 #endif
 
-  // The workgroup is PERSISTENT: tiles blockIdx.x, + gridDim.x, ... (one workgroup per CU fills the registers anyway).  What the
-  // factorisation starts from -- the rows of P^- -- is requested one tile AHEAD (behind step 4), so a tile begins to compute at once; its
-  // other two checkpoints are requested at its top and arrive behind the factorisation.  Without this every CU asks for its whole
-  // tile at the same moment and then computes with the memory idle.
-  d2_t ar[RU];
+  // The workgroup is PERSISTENT: tiles blockIdx.x, + gridDim.x, ... (one workgroup per CU fills the registers anyway).  A burst of
+  // row loads BLOCKS the wave that issues it until the CU's memory path has taken them (36 loads of 1 KB per wave: 12 k cycles), so the
+  // loads are spread: the rows of P^- and of the filtered checkpoint of the NEXT tile are requested while this one multiplies (steps 6
+  // and 7), the rows of P^s_{k+1} of THIS tile during its first factorisation steps (first needed in its ninth).
+  d2_t ar[RU], cr[RU], nr[RU];
   ld_rows(tbuf.np, ar);
+  ld_rows(tbuf.cu, cr);
+  auto ld_row1 = [&](rsrc_t src, d2_t (&r)[RU], int u) { r[u] = ldg2(src, (unsigned) (w + NR * u) * 1024u, lane_b); };
 #pragma unroll 1
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
   tbuf = bufs_of(tile);
+  const int ntile = (tile + (int) gridDim.x < ntiles) ? tile + (int) gridDim.x : tile;   // (the last tile asks for its own rows again)
+  const rsrc_t npn = mkbuf(next_pred + (long) ntile * SL::TILE_DOUBLES, SL::TILE_BYTES), cun = mkbuf(cur + (long) ntile * SL::TILE_DOUBLES, SL::TILE_BYTES);
   // The role index is made opaque per tile: what depends on it (table entries, LDS indices of the role's columns, ~300 scalars) would
   // otherwise be computed ONCE in front of the loop and kept -- in scalar registers the kernel does not have.
   w = w0;
@@ -267,12 +271,10 @@ __global__ __launch_bounds__(SmoothWideCfg<NS>::THREADS, 1) void k_smooth_wide(c
   lds_barrier();  // the previous tile's readers of the LDS are done
   SMW_T(0);
 
-  // ---- 0. P^- (prefetched rows) into the factor's place, x^- beside it; this tile's rows of P_k and P^s_{k+1} are requested ----
+  // ---- 0. the two prefetched checkpoints into LDS: P^- into the factor's place, x^- beside it; P_k and x_k ----
   put_rows(ar, C::PUT_NP);
+  put_rows(cr, C::PUT_CUR);
   SMW_T(11);
-  d2_t cr[RU], nr[RU];
-  ld_rows(tbuf.cu, cr);
-  ld_rows(tbuf.ns, nr);
   lds_barrier();  // P^- is in LDS
   SMW_T(12);
   // the role's columns of P^-, rows at or below NR t (what is above the column's own diagonal is never used: those entries belong to
@@ -283,9 +285,9 @@ __global__ __launch_bounds__(SmoothWideCfg<NS>::THREADS, 1) void k_smooth_wide(c
 #pragma unroll
     for (int i = 0; i < NS; i++) a[t][i] = (i >= NR * t) ? WS[pk_s(i, cc[t]) * 64] : 0.0;
 
-  // ---- 1. P^- = L diag(d) L^T (k_smooth_lane's step 1).  In front of its ninth barrier (the other two checkpoints have arrived by
-  //         then): P_k and x_k into LDS, x^s_{k+1} beside x^-, and D = P^s - P^- (the uncorrected P^-, rbis.cpp:256) row by row in
-  //         registers -- the rows of the three checkpoints are the same rows ----
+  // ---- 1. P^- = L diag(d) L^T (k_smooth_lane's step 1).  The rows of P^s_{k+1} are requested in front of its first six barriers; in
+  //         front of its eleventh (they have arrived): x^s_{k+1} beside x^-, and D = P^s - P^- (the uncorrected P^-, rbis.cpp:256) row
+  //         by row in registers -- the rows of the three checkpoints are the same rows ----
   {
     double inv_prev = 0.0;
     static_for<NS>([&](auto KK) {
@@ -299,11 +301,14 @@ __global__ __launch_bounds__(SmoothWideCfg<NS>::THREADS, 1) void k_smooth_wide(c
         for (int i = kk + 1; i < NS; i++) WE(pk(i, kk)) = a[t][i] * inv;
         inv_prev = inv;
       }
-      if constexpr (kk == 8) {
-        put_rows(cr, C::PUT_CUR);
+      if constexpr (kk < 6) {   // three rows of P^s_{k+1} in front of each of the first six barriers
+#pragma unroll
+        for (int u = 3 * kk; u < 3 * kk + 3; u++) ld_row1(tbuf.ns, nr, u);
+      }
+      if constexpr (kk == 10) {  // (they have arrived)
         put_rows(nr, C::PUT_NS_STATE);
 #pragma unroll
-        for (int u = 0; u < RU; u++) ar[u] = nr[u] - ar[u];
+        for (int u = 0; u < RU; u++) nr[u] = nr[u] - ar[u];
       }
       lds_barrier();
       if constexpr (kk == 0) SMW_T(1);
@@ -389,7 +394,7 @@ __global__ __launch_bounds__(SmoothWideCfg<NS>::THREADS, 1) void k_smooth_wide(c
   SMW_T(3);
 
   // ---- 3. (P^-) X = Ad P_k out of the LDS factor: z[t][:] becomes row cidx[t] of G ----
-  auto pin_z = [&]() {
+  auto pin_z = [&](auto) {
 #pragma unroll
     for (int t = 0; t < NCOL; t++)
 #pragma unroll
@@ -418,7 +423,7 @@ __global__ __launch_bounds__(SmoothWideCfg<NS>::THREADS, 1) void k_smooth_wide(c
     constexpr int i = decltype(KQ)::value;
 #pragma unroll
     for (int t = 0; t < NCOL; t++) dxv[t] = fma(z[t][i], r, dxv[t]);
-  }, [&]() {
+  }, [&](auto) {
 #pragma unroll
     for (int t = 0; t < NCOL; t++) lane_pin(dxv[t]);
   });
@@ -432,14 +437,10 @@ __global__ __launch_bounds__(SmoothWideCfg<NS>::THREADS, 1) void k_smooth_wide(c
   SMW_T(4);
 
   // ---- 4. D = P^s - P^- takes the factor's place (its rows are in registers since step 1); dx takes the place of x^- ----
-  put_rows(ar, C::PUT_D);
+  put_rows(nr, C::PUT_D);
 #pragma unroll
   for (int t = 0; t < NCOL; t++)
     if (cidx[t] < NS) WS[(O_DX + cidx[t]) * 64] = dxv[t];
-  {  // the NEXT tile's rows of P^- (the last tile asks for its own again: the same instruction stream for every tile)
-    const int ntile = (tile + (int) gridDim.x < ntiles) ? tile + (int) gridDim.x : tile;
-    ld_rows(mkbuf(next_pred + (long) ntile * SL::TILE_DOUBLES, SL::TILE_BYTES), ar);
-  }
   lds_barrier();
   SMW_T(5);
 
@@ -459,11 +460,14 @@ __global__ __launch_bounds__(SmoothWideCfg<NS>::THREADS, 1) void k_smooth_wide(c
         m[t][j] = fma(z[t][i], d, m[t][j]);
         if (i != j) m[t][i] = fma(z[t][j], d, m[t][i]);
       }
-    }, [&]() {
+    }, [&](auto GG) {
 #pragma unroll
       for (int t = t0; t < t0 + nt; t++)
 #pragma unroll
         for (int j = 0; j < NS; j++) lane_pin(m[t][j]);
+      // one row of the NEXT tile's P^- per group of the first pass (15 groups), the last three in the second
+      constexpr int g = decltype(GG)::value, u = (t0 == 0) ? g : 15 + g;
+      if constexpr (u < RU && (t0 == 0 || g < 3)) ld_row1(npn, ar, u);
     });
   };
   static_assert(NCOL == 4, "two passes of two rows");
@@ -503,7 +507,7 @@ __global__ __launch_bounds__(SmoothWideCfg<NS>::THREADS, 1) void k_smooth_wide(c
 #pragma unroll
     for (int cq = 0; cq < HALF; cq++)
 #pragma unroll
-      for (int t = 0; t < NCOL; t++) acc[cq][t] = (cq < rows_h) ? p[t][HALF * h + cq < NS ? HALF * h + cq : 0] : 0.0;
+      for (int t = 0; t < NCOL; t++) acc[cq][t] = (cq < rows_h && t >= (HALF * h + cq) / NR) ? WS[(O_B + rbase[t] + HALF * h + cq) * 64] : 0.0;   // P_k(r, c): its owner's own entry
     lds_stream<rows_h * NS, FE>(bb, [&](auto KQ, double mv) {
       constexpr int kq = decltype(KQ)::value, cq = FE::row(kq), j = FE::col(kq), c = HALF * h + cq;
 #pragma unroll
@@ -519,12 +523,15 @@ __global__ __launch_bounds__(SmoothWideCfg<NS>::THREADS, 1) void k_smooth_wide(c
               if (cidx[t] < NS && HALF * h + cs <= cidx[t]) WS[(O_B + rbase[t] + HALF * h + cs) * 64] = acc[cs][t];
             }
       }
-    }, [&]() {
+    }, [&](auto GG) {
 #pragma unroll
       for (int cq = 0; cq < rows_h; cq++)
 #pragma unroll
         for (int t = 0; t < NCOL; t++)
           if (t >= (HALF * h + cq) / NR) lane_pin(acc[cq][t]);
+      // one row of the NEXT tile's filtered checkpoint per group of the first half (15 groups), the last three in the second
+      constexpr int g = decltype(GG)::value, u = (h == 0) ? g : 15 + g;
+      if constexpr (u < RU && (h == 0 || g < 3)) ld_row1(cun, cr, u);
     });
   });
   // ---- 8. state: cur.addState(RBIS(dx)) (rbis.cpp:263-265), by the LAST role (it has a stand-in instead of a fourth row), into the
