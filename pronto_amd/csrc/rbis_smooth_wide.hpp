@@ -153,6 +153,9 @@ struct SmoothWideCfg {
   static_assert(LDS_BYTES <= 160 * 1024, "LDS of a CU");
   static constexpr int off_of(int comp) { return (SL::T.slot_of[comp] / 2) * 128 + (SL::T.slot_of[comp] % 2); }
   static constexpr int RU = (SL::NROW + NR - 1) / NR;   // rows per role
+  // the order in which a role asks for its rows of P^s_{k+1}: the four that carry the state vector first (the residual is made during
+  // the factorisation), then the rest
+  static constexpr int ns_order(int k) { return k == 0 ? 0 : k == 1 ? 1 : k == 2 ? RU - 2 : k == 3 ? RU - 1 : k - 2; }
   // Where the two halves of row w + NR u go in LDS, for each use of a row (ONE table row per use and role: 36 neighbouring words,
   // fetched with a few wide scalar loads):
   enum { PUT_NP = 0, PUT_CUR = 1, PUT_NS_STATE = 2, PUT_D = 3, GET_OUT = 4, NPUT = 5 };
@@ -236,6 +239,20 @@ __global__ __launch_bounds__(SmoothWideCfg<NS>::THREADS, 1) void k_smooth_wide(c
     }
   };
 
+  auto put_state_rows = [&](const d2_t (&r)[RU], int use) {   // ... of the four rows that carry state components
+    constexpr int us[4] = { 0, 1, RU - 2, RU - 1 };
+    int e[4][2];
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+#pragma unroll
+      for (int h = 0; h < 2; h++) e[q][h] = smooth_wide_tab<NS>.put[use][w][us[q]][h];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      WS[e[q][0] * 64] = r[us[q]].x;
+      WS[e[q][1] * 64] = r[us[q]].y;
+    }
+  };
+
 #ifdef SML_TIMELINE
   unsigned long long tl[16] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
 #endif
@@ -253,6 +270,19 @@ __global__ __launch_bounds__(SmoothWideCfg<NS>::THREADS, 1) void k_smooth_wide(c
   tbuf = bufs_of(tile);
   const int ntile = (tile + (int) gridDim.x < ntiles) ? tile + (int) gridDim.x : tile;   // (the last tile asks for its own rows again)
   const rsrc_t npn = mkbuf(next_pred + (long) ntile * SL::TILE_DOUBLES, SL::TILE_BYTES), cun = mkbuf(cur + (long) ntile * SL::TILE_DOUBLES, SL::TILE_BYTES);
+  // The tile's 3 RU row loads, ONE at a time at points spread over the whole tile (the CU's memory path takes ~10 bytes per cycle: a load
+  // issued into a full queue blocks its wave): 0 .. RU-1 the rows of P^s_{k+1} of this tile (factorisation, start of the substitution),
+  // then the NEXT tile's rows of P^- and of its filtered checkpoint (steps 6 and 7, two per three groups of LDS reads)
+  auto mem_tick = [&](auto KT) {
+    constexpr int kt = decltype(KT)::value;
+    if constexpr (kt >= 0 && kt < RU) ld_row1(tbuf.ns, nr, C::ns_order(kt));
+    else if constexpr (kt >= RU && kt < 2 * RU) ld_row1(npn, ar, kt - RU);
+    else if constexpr (kt >= 2 * RU && kt < 3 * RU) ld_row1(cun, cr, kt - 2 * RU);
+  };
+  auto tick23 = [&](auto BASE, auto GG) {   // group g of a stream: an operation for g % 3 != 2, numbered from BASE
+    constexpr int g = decltype(GG)::value, base = decltype(BASE)::value;
+    if constexpr (g % 3 != 2) mem_tick(std::integral_constant<int, base + g - g / 3>{});
+  };
   // The role index is made opaque per tile: what depends on it (table entries, LDS indices of the role's columns, ~300 scalars) would
   // otherwise be computed ONCE in front of the loop and kept -- in scalar registers the kernel does not have.
   w = w0;
@@ -271,9 +301,8 @@ __global__ __launch_bounds__(SmoothWideCfg<NS>::THREADS, 1) void k_smooth_wide(c
   lds_barrier();  // the previous tile's readers of the LDS are done
   SMW_T(0);
 
-  // ---- 0. the two prefetched checkpoints into LDS: P^- into the factor's place, x^- beside it; P_k and x_k ----
+  // ---- 0. the prefetched P^- into the factor's place, x^- beside it (the filtered checkpoint follows in step 1) ----
   put_rows(ar, C::PUT_NP);
-  put_rows(cr, C::PUT_CUR);
   SMW_T(11);
   lds_barrier();  // P^- is in LDS
   SMW_T(12);
@@ -285,30 +314,43 @@ __global__ __launch_bounds__(SmoothWideCfg<NS>::THREADS, 1) void k_smooth_wide(c
 #pragma unroll
     for (int i = 0; i < NS; i++) a[t][i] = (i >= NR * t) ? WS[pk_s(i, cc[t]) * 64] : 0.0;
 
-  // ---- 1. P^- = L diag(d) L^T (k_smooth_lane's step 1).  The rows of P^s_{k+1} are requested in front of its first six barriers; in
-  //         front of its eleventh (they have arrived): x^s_{k+1} beside x^-, and D = P^s - P^- (the uncorrected P^-, rbis.cpp:256) row
-  //         by row in registers -- the rows of the three checkpoints are the same rows ----
+  // ---- 1. P^- = L diag(d) L^T (k_smooth_lane's step 1); a row of P^s_{k+1} is requested in front of every barrier, the filtered
+  //         checkpoint goes into LDS in front of the ninth ----
   {
     double inv_prev = 0.0;
+    auto publish = [&](auto CK) {   // column ck by its owner: d (1 / d for the last) on the diagonal, l_i,ck = a_i,ck / d below
+      constexpr int ck = decltype(CK)::value, t = ck / NR;
+      const double d = a[t][ck];
+      const double inv = (fabs(d) > 5.562684646268003e-309) ? 1.0 / d : 0.0;
+      WE(pk(ck, ck)) = (ck == NS - 1) ? inv : d;
+#pragma unroll
+      for (int i = ck + 1; i < NS; i++) WE(pk(i, ck)) = a[t][i] * inv;
+      inv_prev = inv;
+    };
+    if (w == 0) publish(std::integral_constant<int, 0>{});
     static_for<NS>([&](auto KK) {
       constexpr int kk = decltype(KK)::value;
-      if (w == kk % NR) {  // owner of column kk
-        constexpr int t = kk / NR;
-        const double d = a[t][kk];
-        const double inv = (fabs(d) > 5.562684646268003e-309) ? 1.0 / d : 0.0;
-        WE(pk(kk, kk)) = (kk == NS - 1) ? inv : d;
-#pragma unroll
-        for (int i = kk + 1; i < NS; i++) WE(pk(i, kk)) = a[t][i] * inv;
-        inv_prev = inv;
-      }
-      if constexpr (kk < 6) {   // three rows of P^s_{k+1} in front of each of the first six barriers
-#pragma unroll
-        for (int u = 3 * kk; u < 3 * kk + 3; u++) ld_row1(tbuf.ns, nr, u);
-      }
-      if constexpr (kk == 10) {  // (they have arrived)
-        put_rows(nr, C::PUT_NS_STATE);
-#pragma unroll
-        for (int u = 0; u < RU; u++) nr[u] = nr[u] - ar[u];
+      // (column kk was published by its owner during step kk - 1 -- column 0 in front of the loop)
+      mem_tick(std::integral_constant<int, kk>{});   // a row of P^s_{k+1}
+      if constexpr (kk == 8) put_rows(cr, C::PUT_CUR);   // P_k and x_k (prefetched; the last rows were asked for at the end of the previous tile)
+      if constexpr (kk == 9) put_state_rows(nr, C::PUT_NS_STATE);   // x^s_{k+1} beside x^- (its rows were the first four asked for)
+      if constexpr (kk == 11) {
+        // residual x^s (-) x^- (rbis.cpp:258-261) for step 3, in the place of x^s: role w its components w, w + NR, ..., the last role the
+        // attitude part
+      #pragma unroll
+        for (int t = 0; t < NCOL; t++)
+          if (cidx[t] < NS && (cidx[t] < 6 || cidx[t] > 8)) WS[(O_X + cidx[t]) * 64] = WS[(C::O_SN + cidx[t]) * 64] - WS[(C::O_SP + cidx[t]) * 64];
+        if (w == NR - 1) {
+          double rqs[4], rqp[4], dchi[3];
+      #pragma unroll
+          for (int i = 0; i < 4; i++) {
+            rqs[i] = WE(C::O_SN + NS + i);
+            rqp[i] = WE(C::O_SP + NS + i);
+          }
+          subtract_quats(rqs, rqp, dchi);
+      #pragma unroll
+          for (int i = 0; i < 3; i++) WE(O_X + 6 + i) = dchi[i];
+        }
       }
       lds_barrier();
       if constexpr (kk == 0) SMW_T(1);
@@ -317,40 +359,39 @@ __global__ __launch_bounds__(SmoothWideCfg<NS>::THREADS, 1) void k_smooth_wide(c
       if constexpr (kk > 0)
         if (w == (kk - 1) % NR) WE(pk(kk - 1, kk - 1)) = inv_prev;
       if constexpr (kk + 1 < NS) {
+        // LOOK-AHEAD: the owner of column kk + 1 downdates THAT column first and publishes it at once, so that its reciprocal, scaling
+        // and LDS writes run while the other roles (and then itself) downdate the rest; the barrier of step kk + 1 finds the column there
+        constexpr int t1 = (kk + 1) / NR;
+        const bool nxt = (w == (kk + 1) % NR);
         const double dk = WE(pk(kk, kk));
-        double tc[NCOL];
+        double tc[NCOL], lik[NS];
 #pragma unroll
         for (int t = 0; t < NCOL; t++)
           if (kk < NR * (t + 1) - 1) tc[t] = WS[pk_s(cc[t], kk) * 64] * dk;
 #pragma unroll
-        for (int i = kk + 1; i < NS; i++) {
-          const double lik = WE(pk(i, kk));
+        for (int i = kk + 1; i < NS; i++) lik[i] = WE(pk(i, kk));
+        if (nxt) {
 #pragma unroll
-          for (int t = 0; t < NCOL; t++)
-            if (kk < NR * (t + 1) - 1 && i >= NR * t) {
-              a[t][i] = fma(-lik, tc[t], a[t][i]);
-              lane_pin(a[t][i]);  // (downdated NOW, not when the column is published)
-            }
+          for (int i = kk + 1; i < NS; i++) {
+            a[t1][i] = fma(-lik[i], tc[t1], a[t1][i]);
+            lane_pin(a[t1][i]);
+          }
+          publish(std::integral_constant<int, kk + 1>{});
         }
+#pragma unroll
+        for (int t = 0; t < NCOL; t++)
+          if (kk < NR * (t + 1) - 1) {
+            if (t != t1 || !nxt) {
+#pragma unroll
+              for (int i = kk + 1; i < NS; i++)
+                if (i >= NR * t) {
+                  a[t][i] = fma(-lik[i], tc[t], a[t][i]);
+                  lane_pin(a[t][i]);  // (downdated NOW, not when the column is published)
+                }
+            }
+          }
       }
     });
-  }
-
-  // residual x^s (-) x^- (rbis.cpp:258-261) for step 3, in the place of x^s: role w its components w, w + NR, ..., the last role the
-  // attitude part
-#pragma unroll
-  for (int t = 0; t < NCOL; t++)
-    if (cidx[t] < NS && (cidx[t] < 6 || cidx[t] > 8)) WS[(O_X + cidx[t]) * 64] = WS[(C::O_SN + cidx[t]) * 64] - WS[(C::O_SP + cidx[t]) * 64];
-  if (w == NR - 1) {
-    double rqs[4], rqp[4], dchi[3];
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      rqs[i] = WE(C::O_SN + NS + i);
-      rqp[i] = WE(C::O_SP + NS + i);
-    }
-    subtract_quats(rqs, rqp, dchi);
-#pragma unroll
-    for (int i = 0; i < 3; i++) WE(O_X + 6 + i) = dchi[i];
   }
 
   // ---- 2. right-hand sides: columns cc[t] of Ad P_k, Ad = I + dt Ac about the filtered state (rbis.cpp:12-35, 236-239) ----
@@ -404,7 +445,11 @@ __global__ __launch_bounds__(SmoothWideCfg<NS>::THREADS, 1) void k_smooth_wide(c
     constexpr int kq = decltype(KQ)::value, i = SmwLowerStrict::row(kq), mm = SmwLowerStrict::col(kq);
 #pragma unroll
     for (int t = 0; t < NCOL; t++) z[t][i] = fma(-l, z[t][mm], z[t][i]);
-  }, pin_z);
+  }, [&](auto GG) {
+    pin_z(GG);
+    constexpr int g = decltype(GG)::value;
+    if constexpr (NS + g < RU) mem_tick(std::integral_constant<int, NS + g>{});   // the last rows of P^s_{k+1}
+  });
   lds_stream<NS, SmwDiag>(bb, [&](auto KQ, double inv) {
     constexpr int i = decltype(KQ)::value;
 #pragma unroll
@@ -415,35 +460,37 @@ __global__ __launch_bounds__(SmoothWideCfg<NS>::THREADS, 1) void k_smooth_wide(c
 #pragma unroll
     for (int t = 0; t < NCOL; t++) z[t][i] = fma(-l, z[t][mm], z[t][i]);
   }, pin_z);
-  // dx = G resid (rbis.cpp:263): this role's entries
-  double dxv[NCOL];
-#pragma unroll
-  for (int t = 0; t < NCOL; t++) dxv[t] = 0.0;
-  lds_stream<NS, SmwRun<O_X>>(bb, [&](auto KQ, double r) {
-    constexpr int i = decltype(KQ)::value;
-#pragma unroll
-    for (int t = 0; t < NCOL; t++) dxv[t] = fma(z[t][i], r, dxv[t]);
-  }, [&](auto) {
-#pragma unroll
-    for (int t = 0; t < NCOL; t++) lane_pin(dxv[t]);
-  });
-#pragma unroll
-  for (int t = 0; t < NCOL; t++) {
-    lane_pin(dxv[t]);
-#pragma unroll
-    for (int i = 0; i < NS; i++) lane_pin(z[t][i]);
-  }
-  lds_barrier();  // factor and residual are dead
-  SMW_T(4);
-
-  // ---- 4. D = P^s - P^- takes the factor's place (its rows are in registers since step 1); dx takes the place of x^- ----
-  put_rows(nr, C::PUT_D);
 #pragma unroll
   for (int t = 0; t < NCOL; t++)
-    if (cidx[t] < NS) WS[(O_DX + cidx[t]) * 64] = dxv[t];
-  lds_barrier();
-  SMW_T(5);
+#pragma unroll
+    for (int i = 0; i < NS; i++) lane_pin(z[t][i]);
+  lds_barrier();  // the factor is dead
+  SMW_T(4);
 
+  // ---- 4. D = P^s - P^- (the uncorrected P^-, rbis.cpp:256) takes the factor's place, row by row: the rows of the checkpoints are the
+  //         same rows ----
+#pragma unroll
+  for (int u = 0; u < RU; u++) nr[u] = nr[u] - ar[u];
+  put_rows(nr, C::PUT_D);
+  // dx = G resid (rbis.cpp:263): this role's entries, into the place of x^- (read for the last time by the residual, in step 1)
+  {
+    double dxv[NCOL];
+#pragma unroll
+    for (int t = 0; t < NCOL; t++) dxv[t] = 0.0;
+    lds_stream<NS, SmwRun<O_X>>(bb, [&](auto KQ, double r) {
+      constexpr int i = decltype(KQ)::value;
+#pragma unroll
+      for (int t = 0; t < NCOL; t++) dxv[t] = fma(z[t][i], r, dxv[t]);
+    }, [&](auto) {
+#pragma unroll
+      for (int t = 0; t < NCOL; t++) lane_pin(dxv[t]);
+    });
+#pragma unroll
+    for (int t = 0; t < NCOL; t++)
+      if (cidx[t] < NS) WS[(O_DX + cidx[t]) * 64] = dxv[t];   // (x^- is read by the residual only, and every role is past it)
+  }
+  lds_barrier();  // D and dx are in LDS
+  SMW_T(5);
   // ---- 6. M = G D: ALL rows of the role, in passes of two rows over the symmetric D (with all four the accumulators and G fill the
   //         architectural registers and nothing is left to read ahead into) ----
   double m[NCOL][NS];
@@ -465,9 +512,7 @@ __global__ __launch_bounds__(SmoothWideCfg<NS>::THREADS, 1) void k_smooth_wide(c
       for (int t = t0; t < t0 + nt; t++)
 #pragma unroll
         for (int j = 0; j < NS; j++) lane_pin(m[t][j]);
-      // one row of the NEXT tile's P^- per group of the first pass (15 groups), the last three in the second
-      constexpr int g = decltype(GG)::value, u = (t0 == 0) ? g : 15 + g;
-      if constexpr (u < RU && (t0 == 0 || g < 3)) ld_row1(npn, ar, u);
+      tick23(std::integral_constant<int, RU + (t0 == 0 ? 0 : 10)>{}, GG);   // (15 groups per pass: 10 operations each)
     });
   };
   static_assert(NCOL == 4, "two passes of two rows");
@@ -529,13 +574,11 @@ __global__ __launch_bounds__(SmoothWideCfg<NS>::THREADS, 1) void k_smooth_wide(c
 #pragma unroll
         for (int t = 0; t < NCOL; t++)
           if (t >= (HALF * h + cq) / NR) lane_pin(acc[cq][t]);
-      // one row of the NEXT tile's filtered checkpoint per group of the first half (15 groups), the last three in the second
-      constexpr int g = decltype(GG)::value, u = (h == 0) ? g : 15 + g;
-      if constexpr (u < RU && (h == 0 || g < 3)) ld_row1(cun, cr, u);
+      tick23(std::integral_constant<int, RU + 20 + (h == 0 ? 0 : 10)>{}, GG);   // (15 / 14 groups: 10 operations each; 54 in all)
     });
   });
-  // ---- 8. state: cur.addState(RBIS(dx)) (rbis.cpp:263-265), by the LAST role (it has a stand-in instead of a fourth row), into the
-  //         staging area behind the covariance ----
+  // ---- 8. state: cur.addState(RBIS(dx)) (rbis.cpp:263-265), by the LAST role (it has a stand-in instead of a fourth row of M to make), in
+  //         place behind P_k: that is where the staging area keeps the state ----
   if (w == NR - 1) {
     double dchi[3] = { WE(O_DX + 6), WE(O_DX + 7), WE(O_DX + 8) };
     double dq[4] = { 1.0, 0.0, 0.0, 0.0 };
@@ -553,6 +596,8 @@ __global__ __launch_bounds__(SmoothWideCfg<NS>::THREADS, 1) void k_smooth_wide(c
     for (int i = 0; i < 4; i++) WE(O_B + NP + NS + i) = qo[i];
     // (the log-likelihood stays where the filtered checkpoint's row put it)
   }
+
+
   lds_barrier();
   SMW_T(13);
   // ---- 9. the posterior by whole rows ----
