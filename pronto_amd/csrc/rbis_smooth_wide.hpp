@@ -270,18 +270,19 @@ __global__ __launch_bounds__(SmoothWideCfg<NS>::THREADS, 1) void k_smooth_wide(c
   tbuf = bufs_of(tile);
   const int ntile = (tile + (int) gridDim.x < ntiles) ? tile + (int) gridDim.x : tile;   // (the last tile asks for its own rows again)
   const rsrc_t npn = mkbuf(next_pred + (long) ntile * SL::TILE_DOUBLES, SL::TILE_BYTES), cun = mkbuf(cur + (long) ntile * SL::TILE_DOUBLES, SL::TILE_BYTES);
-  // The tile's 3 RU row loads, ONE at a time at points spread over the whole tile (the CU's memory path takes ~10 bytes per cycle: a load
-  // issued into a full queue blocks its wave): 0 .. RU-1 the rows of P^s_{k+1} of this tile (factorisation, start of the substitution),
-  // then the NEXT tile's rows of P^- and of its filtered checkpoint (steps 6 and 7, two per three groups of LDS reads)
+  // The tile's 3 RU row loads, one or two at a time at points spread over the whole tile (the CU's memory path takes ~10 bytes per cycle:
+  // a load issued into a full queue blocks its wave): 0 .. RU-1 the rows of P^s_{k+1} of THIS tile (two in front of each of the first nine
+  // barriers of the factorisation), then the NEXT tile's rows of P^- (end of the factorisation, every other group of the substitutions)
+  // and of its filtered checkpoint (every third group of steps 6 and 7)
   auto mem_tick = [&](auto KT) {
     constexpr int kt = decltype(KT)::value;
     if constexpr (kt >= 0 && kt < RU) ld_row1(tbuf.ns, nr, C::ns_order(kt));
     else if constexpr (kt >= RU && kt < 2 * RU) ld_row1(npn, ar, kt - RU);
     else if constexpr (kt >= 2 * RU && kt < 3 * RU) ld_row1(cun, cr, kt - 2 * RU);
   };
-  auto tick23 = [&](auto BASE, auto GG) {   // group g of a stream: an operation for g % 3 != 2, numbered from BASE
-    constexpr int g = decltype(GG)::value, base = decltype(BASE)::value;
-    if constexpr (g % 3 != 2) mem_tick(std::integral_constant<int, base + g - g / 3>{});
+  auto tick_every = [&](auto EVERY, auto BASE, auto GG) {   // group g of a stream: an operation when g % EVERY == 0, numbered from BASE
+    constexpr int g = decltype(GG)::value, base = decltype(BASE)::value, ev = decltype(EVERY)::value;
+    if constexpr (g % ev == 0) mem_tick(std::integral_constant<int, base + g / ev>{});
   };
   // The role index is made opaque per tile: what depends on it (table entries, LDS indices of the role's columns, ~300 scalars) would
   // otherwise be computed ONCE in front of the loop and kept -- in scalar registers the kernel does not have.
@@ -331,10 +332,18 @@ __global__ __launch_bounds__(SmoothWideCfg<NS>::THREADS, 1) void k_smooth_wide(c
     static_for<NS>([&](auto KK) {
       constexpr int kk = decltype(KK)::value;
       // (column kk was published by its owner during step kk - 1 -- column 0 in front of the loop)
-      mem_tick(std::integral_constant<int, kk>{});   // a row of P^s_{k+1}
+      if constexpr (kk < 9) {   // two rows of P^s_{k+1}
+        mem_tick(std::integral_constant<int, 2 * kk>{});
+        mem_tick(std::integral_constant<int, 2 * kk + 1>{});
+      }
+      if constexpr (kk == 11) {   // D = P^s - P^- (the uncorrected P^-, rbis.cpp:256) row by row in registers: the rows of the checkpoints are the same rows
+#pragma unroll
+        for (int u = 0; u < RU; u++) nr[u] = nr[u] - ar[u];
+      }
+      if constexpr (kk >= 12) mem_tick(std::integral_constant<int, RU + kk - 12>{});   // the next tile's P^- (this tile's rows are used up)
       if constexpr (kk == 8) put_rows(cr, C::PUT_CUR);   // P_k and x_k (prefetched; the last rows were asked for at the end of the previous tile)
-      if constexpr (kk == 9) put_state_rows(nr, C::PUT_NS_STATE);   // x^s_{k+1} beside x^- (its rows were the first four asked for)
-      if constexpr (kk == 11) {
+      if constexpr (kk == 7) put_state_rows(nr, C::PUT_NS_STATE);   // x^s_{k+1} beside x^- (its rows were the first four asked for)
+      if constexpr (kk == 9) {
         // residual x^s (-) x^- (rbis.cpp:258-261) for step 3, in the place of x^s: role w its components w, w + NR, ..., the last role the
         // attitude part
       #pragma unroll
@@ -447,8 +456,7 @@ __global__ __launch_bounds__(SmoothWideCfg<NS>::THREADS, 1) void k_smooth_wide(c
     for (int t = 0; t < NCOL; t++) z[t][i] = fma(-l, z[t][mm], z[t][i]);
   }, [&](auto GG) {
     pin_z(GG);
-    constexpr int g = decltype(GG)::value;
-    if constexpr (NS + g < RU) mem_tick(std::integral_constant<int, NS + g>{});   // the last rows of P^s_{k+1}
+    tick_every(std::integral_constant<int, 2>{}, std::integral_constant<int, RU + 3>{}, GG);   // 14 groups: 7 rows
   });
   lds_stream<NS, SmwDiag>(bb, [&](auto KQ, double inv) {
     constexpr int i = decltype(KQ)::value;
@@ -459,7 +467,10 @@ __global__ __launch_bounds__(SmoothWideCfg<NS>::THREADS, 1) void k_smooth_wide(c
     constexpr int kq = decltype(KQ)::value, i = SmwBackward<NS>::ci(kq), mm = SmwBackward<NS>::cm(kq);
 #pragma unroll
     for (int t = 0; t < NCOL; t++) z[t][i] = fma(-l, z[t][mm], z[t][i]);
-  }, pin_z);
+  }, [&](auto GG) {
+    pin_z(GG);
+    tick_every(std::integral_constant<int, 2>{}, std::integral_constant<int, RU + 10>{}, GG);   // 14 groups: 7 rows
+  });
 #pragma unroll
   for (int t = 0; t < NCOL; t++)
 #pragma unroll
@@ -469,8 +480,6 @@ __global__ __launch_bounds__(SmoothWideCfg<NS>::THREADS, 1) void k_smooth_wide(c
 
   // ---- 4. D = P^s - P^- (the uncorrected P^-, rbis.cpp:256) takes the factor's place, row by row: the rows of the checkpoints are the
   //         same rows ----
-#pragma unroll
-  for (int u = 0; u < RU; u++) nr[u] = nr[u] - ar[u];
   put_rows(nr, C::PUT_D);
   // dx = G resid (rbis.cpp:263): this role's entries, into the place of x^- (read for the last time by the residual, in step 1)
   {
@@ -512,7 +521,7 @@ __global__ __launch_bounds__(SmoothWideCfg<NS>::THREADS, 1) void k_smooth_wide(c
       for (int t = t0; t < t0 + nt; t++)
 #pragma unroll
         for (int j = 0; j < NS; j++) lane_pin(m[t][j]);
-      tick23(std::integral_constant<int, RU + (t0 == 0 ? 0 : 10)>{}, GG);   // (15 groups per pass: 10 operations each)
+      tick_every(std::integral_constant<int, 3>{}, std::integral_constant<int, RU + 17 + (t0 == 0 ? 0 : 5)>{}, GG);   // (15 groups per pass: 5 rows each)
     });
   };
   static_assert(NCOL == 4, "two passes of two rows");
@@ -574,7 +583,7 @@ __global__ __launch_bounds__(SmoothWideCfg<NS>::THREADS, 1) void k_smooth_wide(c
 #pragma unroll
         for (int t = 0; t < NCOL; t++)
           if (t >= (HALF * h + cq) / NR) lane_pin(acc[cq][t]);
-      tick23(std::integral_constant<int, RU + 20 + (h == 0 ? 0 : 10)>{}, GG);   // (15 / 14 groups: 10 operations each; 54 in all)
+      tick_every(std::integral_constant<int, 3>{}, std::integral_constant<int, RU + 27 + (h == 0 ? 0 : 5)>{}, GG);   // (15 / 14 groups: 5 rows each; 3 RU = 54 in all)
     });
   });
   // ---- 8. state: cur.addState(RBIS(dx)) (rbis.cpp:263-265), by the LAST role (it has a stand-in instead of a fourth row of M to make), in
