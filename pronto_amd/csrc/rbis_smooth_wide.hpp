@@ -115,6 +115,27 @@ struct SmwBackward {  // k-th (m, i), i = n-2 .. 0, m = i+1 .. n-1: the backward
 };
 struct SmwDiag { static constexpr int at(int k) { return pk(k, k); } };
 struct SmwPacked { static constexpr int at(int k) { return k; } };
+// Orders in which CONSECUTIVE entries touch different accumulators (a multiply-add that waits for its predecessor's result costs twice
+// its issue slot, and one wave per SIMD has nothing else to issue meanwhile):
+template <int NS>
+struct SmwByDiagonal {  // the lower triangle diagonal by diagonal: (d, 0), (d + 1, 1), ... for d = 0 .. n-1
+  static constexpr int dg(int k) { int d = 0; while (k >= NS - d) { k -= NS - d; d++; } return d; }
+  static constexpr int col(int k) { int d = 0; while (k >= NS - d) { k -= NS - d; d++; } return k; }
+  static constexpr int row(int k) { return col(k) + dg(k); }
+  static constexpr int at(int k) { return pk(row(k), col(k)); }
+};
+template <int NS>
+struct SmwLowerByColumn {  // k-th (i, m), m < i, column by column: z_i -= l_im z_m for i = m+1 .. n-1, m = 0 .. n-2
+  static constexpr int col(int k) { int m = 0; while (k >= NS - 1 - m) { k -= NS - 1 - m; m++; } return m; }
+  static constexpr int row(int k) { int m = 0; while (k >= NS - 1 - m) { k -= NS - 1 - m; m++; } return m + 1 + k; }
+  static constexpr int at(int k) { return pk(row(k), col(k)); }
+};
+template <int NS>
+struct SmwUpperByColumn {  // k-th (m, i), i < m: z_i -= l_mi z_m for i = m-1 .. 0, m = n-1 .. 1
+  static constexpr int cm(int k) { int m = NS - 1; while (k >= m) { k -= m; m--; } return m; }
+  static constexpr int ci(int k) { int m = NS - 1; while (k >= m) { k -= m; m--; } return m - 1 - k; }
+  static constexpr int at(int k) { return pk(cm(k), ci(k)); }
+};
 template <int BASE>
 struct SmwRun { static constexpr int at(int k) { return BASE + k; } };
 template <int NS, int ROWS>
@@ -450,8 +471,8 @@ __global__ __launch_bounds__(SmoothWideCfg<NS>::THREADS, 1) void k_smooth_wide(c
 #pragma unroll
       for (int i = 0; i < NS; i++) lane_pin(z[t][i]);
   };
-  lds_stream<NS *(NS - 1) / 2, SmwLowerStrict>(bb, [&](auto KQ, double l) {
-    constexpr int kq = decltype(KQ)::value, i = SmwLowerStrict::row(kq), mm = SmwLowerStrict::col(kq);
+  lds_stream<NS *(NS - 1) / 2, SmwLowerByColumn<NS>>(bb, [&](auto KQ, double l) {
+    constexpr int kq = decltype(KQ)::value, i = SmwLowerByColumn<NS>::row(kq), mm = SmwLowerByColumn<NS>::col(kq);
 #pragma unroll
     for (int t = 0; t < NCOL; t++) z[t][i] = fma(-l, z[t][mm], z[t][i]);
   }, [&](auto GG) {
@@ -463,8 +484,8 @@ __global__ __launch_bounds__(SmoothWideCfg<NS>::THREADS, 1) void k_smooth_wide(c
 #pragma unroll
     for (int t = 0; t < NCOL; t++) z[t][i] *= inv;
   }, pin_z);
-  lds_stream<NS *(NS - 1) / 2, SmwBackward<NS>>(bb, [&](auto KQ, double l) {
-    constexpr int kq = decltype(KQ)::value, i = SmwBackward<NS>::ci(kq), mm = SmwBackward<NS>::cm(kq);
+  lds_stream<NS *(NS - 1) / 2, SmwUpperByColumn<NS>>(bb, [&](auto KQ, double l) {
+    constexpr int kq = decltype(KQ)::value, i = SmwUpperByColumn<NS>::ci(kq), mm = SmwUpperByColumn<NS>::cm(kq);
 #pragma unroll
     for (int t = 0; t < NCOL; t++) z[t][i] = fma(-l, z[t][mm], z[t][i]);
   }, [&](auto GG) {
@@ -509,8 +530,8 @@ __global__ __launch_bounds__(SmoothWideCfg<NS>::THREADS, 1) void k_smooth_wide(c
     for (int j = 0; j < NS; j++) m[t][j] = 0.0;
   auto sweep = [&](auto T0, auto NT) {
     constexpr int t0 = decltype(T0)::value, nt = decltype(NT)::value;
-    lds_stream<NP, SmwPacked>(bb, [&](auto KQ, double d) {
-      constexpr int kq = decltype(KQ)::value, i = pk_row(kq), j = pk_col(kq);
+    lds_stream<NP, SmwByDiagonal<NS>>(bb, [&](auto KQ, double d) {
+      constexpr int kq = decltype(KQ)::value, i = SmwByDiagonal<NS>::row(kq), j = SmwByDiagonal<NS>::col(kq);
 #pragma unroll
       for (int t = t0; t < t0 + nt; t++) {
         m[t][j] = fma(z[t][i], d, m[t][j]);
