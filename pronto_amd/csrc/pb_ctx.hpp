@@ -92,6 +92,7 @@ struct pb_ctx {
   bool quad21 = true;   // PRONTO_BATCH_QUAD21=0: run the 21-state step on the two-wave kernel instead of the four-wave one (A/B)
   bool generic_update = false;  // PRONTO_BATCH_GENERIC_UPDATE=1: every stand-alone update on the run-time-index kernel (A/B, tests)
   bool smooth_attr = false;  // dynamic-LDS limit of the smoother kernels raised on this device
+  bool smooth_wide_attr = false;
   int n_cu = 256;            // compute units of the device (grid of the persistent smoother kernel)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   char err[512] = { 0 };
@@ -181,3 +182,4 @@ int pbk_update_ct(pb_ctx *c, int m, const int *idx, const double *z, const doubl
                   const uint8_t *mask, const double *zb = nullptr, const double *qb = nullptr, const double *rfull = nullptr);
 // pb_smooth.hip
 int pbk_smooth_step(pb_ctx *c, const double *next_pred, const double *next_sm, const double *cur, double *out, double dt);
+int pbk_smooth_wide(pb_ctx *c, const double *next_pred, const double *next_sm, const double *cur, double *out, double dt);   // 15 states (pb_smooth_wide.hip)

@@ -2,7 +2,6 @@
 #include "pb_ctx.hpp"
 #include "rbis_smooth.hpp"
 #include "rbis_smooth_lane.hpp"
-#include "rbis_smooth_wide.hpp"
 
 int pbk_smooth_step(pb_ctx *c, const double *np_, const double *ns_, const double *cu, double *out, double dt)
 {
@@ -21,11 +20,11 @@ int pbk_smooth_step(pb_ctx *c, const double *np_, const double *ns_, const doubl
   // PRONTO_SMOOTH_KERNEL=reg: the 16 / 32-lanes-per-filter kernel of rounds 2-4 (rbis_smooth.hpp); default: one lane per filter,
   // the dense work split over role waves (rbis_smooth_lane.hpp)
   static const bool reg_kernel = pivot || (getenv("PRONTO_SMOOTH_KERNEL") && !strcmp(getenv("PRONTO_SMOOTH_KERNEL"), "reg"));
-  // PRONTO_SMOOTH_KERNEL=wide: k_smooth_wide for 15 states (rbis_smooth_wide.hpp: persistent, one wave per SIMD, 512 registers; work in
-  // progress); default: k_smooth_lane (two tiles per CU, 256 registers)
-  static const bool lane15 = !(getenv("PRONTO_SMOOTH_KERNEL") && !strcmp(getenv("PRONTO_SMOOTH_KERNEL"), "wide"));
+  // 15 states: k_smooth_wide (rbis_smooth_wide.hpp, pb_smooth_wide.hip: persistent workgroups, one wave per SIMD with 512 registers, data
+  // movement by whole rows) unless PRONTO_SMOOTH_KERNEL=lane asks for k_smooth_lane (two tiles per CU, 256 registers: the default until
+  // the second half of round 5, and still the kernel for 21 states)
+  static const bool lane15 = getenv("PRONTO_SMOOTH_KERNEL") && !strcmp(getenv("PRONTO_SMOOTH_KERNEL"), "lane");
   if (!c->smooth_attr) {  // more than the default 64 KB of dynamic LDS per workgroup
-    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_smooth_wide<15>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) SmoothWideCfg<15>::LDS_BYTES));
     HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_smooth_lane<15>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) (SmoothLaneCfg<15>::LDS_BYTES + pad)));
     HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_smooth_lane<21>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) SmoothLaneCfg<21>::LDS_BYTES));
     const int l15 = (int) (pad + sizeof(double) * SmoothRegCfg<15>::LDS_DOUBLES), l21 = (int) (pad + sizeof(double) * SmoothRegCfg<21>::LDS_DOUBLES);
@@ -38,13 +37,8 @@ int pbk_smooth_step(pb_ctx *c, const double *np_, const double *ns_, const doubl
   if (!reg_kernel) {
     const dim3 grid((unsigned) ((c->B + 63) / 64));
     // (the pad of the attribution builds: past the kernel's own LDS, never touched -- it only keeps a second workgroup off the CU)
-    if (c->ns == 15 && !lane15) {  // persistent: one workgroup per CU walks the tiles (PRONTO_SMOOTH_GRID: workgroups, for experiments)
-      static const int grid_env = getenv("PRONTO_SMOOTH_GRID") ? atoi(getenv("PRONTO_SMOOTH_GRID")) : 0;
-      const int ntiles = (int) grid.x, nwg = grid_env > 0 ? grid_env : c->n_cu;
-      k_smooth_wide<15><<<dim3((unsigned) (ntiles < nwg ? ntiles : nwg)), SmoothWideCfg<15>::THREADS, SmoothWideCfg<15>::LDS_BYTES, c->stream>>>(np_, ns_, cu, out, c->B,
-                                                                                                                                           ntiles, dt, c->k);
-    }
-    else if (c->ns == 15) k_smooth_lane<15><<<grid, SmoothLaneCfg<15>::THREADS, SmoothLaneCfg<15>::LDS_BYTES + pad, c->stream>>>(np_, ns_, cu, out, c->B, dt, c->k);
+    if (c->ns == 15 && !lane15) return pbk_smooth_wide(c, np_, ns_, cu, out, dt);
+    if (c->ns == 15) k_smooth_lane<15><<<grid, SmoothLaneCfg<15>::THREADS, SmoothLaneCfg<15>::LDS_BYTES + pad, c->stream>>>(np_, ns_, cu, out, c->B, dt, c->k);
     else k_smooth_lane<21><<<grid, SmoothLaneCfg<21>::THREADS, SmoothLaneCfg<21>::LDS_BYTES, c->stream>>>(np_, ns_, cu, out, c->B, dt, c->k);
   } else if (c->ns == 15) {
     using S = SmoothRegCfg<15>;
@@ -74,10 +68,7 @@ int pbk_smooth_step(pb_ctx *c, const double *np_, const double *ns_, const doubl
                         "D staged %.1f, first chunk barrier %.1f, end %.1f; in the chunks: publish phases %.1f, final+M phases %.1f\n", c->ns, SML_TIMELINE, w,
                 (h[w][1] - t0) / 1e3, (h[w][2] - t0) / 1e3, (h[w][3] - t0) / 1e3, (h[w][4] - t0) / 1e3, (h[w][5] - t0) / 1e3, (h[w][6] - t0) / 1e3,
                 (h[w][7] - t0) / 1e3, h[w][8] / 1e3, h[w][9] / 1e3);
-        if (c->ns == 15 && !lane15)   // k_smooth_wide: 6 = M made, 8 = first half published, 9 = its products done, 10 = second half published
-          fprintf(stderr, "  wide: P^- rows in LDS %.1f, barrier behind them %.1f, M made %.1f, first half published %.1f, its products done %.1f, second half published %.1f, "
-                          "posterior staged %.1f\n",
-                  (h[w][11] - t0) / 1e3, (h[w][12] - t0) / 1e3, (h[w][6] - t0) / 1e3, (h[w][8] - t0) / 1e3, (h[w][9] - t0) / 1e3, (h[w][10] - t0) / 1e3, (h[w][13] - t0) / 1e3);
+
       }
     }
   }

@@ -30,22 +30,6 @@
 
 namespace pb {
 
-// rows of the factor / of D per group of LDS reads (the next group's reads wait for this group's arithmetic: WFENCE), columns of the
-// final product per group
-#ifndef SMW_NR
-#define SMW_NR 4   // role waves per tile: 4 (one per SIMD, 512 registers) or 8 (two per SIMD, 256 registers)
-#endif
-#ifndef SMW_SUB_G
-#define SMW_SUB_G 2
-#endif
-#ifndef SMW_M_G
-#define SMW_M_G 2
-#endif
-#ifndef SMW_FIN_G
-#define SMW_FIN_G 1
-#endif
-
-
 // ---- LDS reads as an explicit pipeline -------------------------------------------------------------------------------------------
 // One wave per SIMD has nobody to hide an LDS round trip behind, and the backend schedules `read, wait, use, read, wait, use` once the
 // accumulators fill the 256 architectural registers (the M sweep: 60 exposed round trips).  lds_stream reads a compile-time list of
@@ -102,19 +86,7 @@ __device__ __forceinline__ void lds_stream(LdsBases bb, Use &&use, Pin &&pin)
   });
 }
 // entry lists
-struct SmwLowerStrict {  // k-th (i, m), m < i, row by row: the forward substitution's order
-  static constexpr int row(int k) { return pk_row(k) + 1; }
-  static constexpr int col(int k) { return pk_col(k); }
-  static constexpr int at(int k) { return pk(row(k), col(k)); }
-};
-template <int NS>
-struct SmwBackward {  // k-th (m, i), i = n-2 .. 0, m = i+1 .. n-1: the backward substitution's order
-  static constexpr int ci(int k) { int i = NS - 2; while (k >= NS - 1 - i) { k -= NS - 1 - i; i--; } return i; }
-  static constexpr int cm(int k) { int i = NS - 2; while (k >= NS - 1 - i) { k -= NS - 1 - i; i--; } return i + 1 + k; }
-  static constexpr int at(int k) { return pk(cm(k), ci(k)); }
-};
 struct SmwDiag { static constexpr int at(int k) { return pk(k, k); } };
-struct SmwPacked { static constexpr int at(int k) { return k; } };
 // Orders in which CONSECUTIVE entries touch different accumulators (a multiply-add that waits for its predecessor's result costs twice
 // its issue slot, and one wave per SIMD has nothing else to issue meanwhile):
 template <int NS>
@@ -241,7 +213,6 @@ __global__ __launch_bounds__(SmoothWideCfg<NS>::THREADS, 1) void k_smooth_wide(c
   const LdsBases bb{ lane * 8, lane * 8 + 128 * 512, lane * 8 + 256 * 512 };   // (dynamic LDS starts at 0: no static LDS in this kernel)
 #define WS (lds + sb)
 #define WE(e) (*(((e) < 128) ? (lds + sb + (e) * 64) : ((e) < 256) ? (lds + sb1 + ((e) - 128) * 64) : (lds + sb2 + ((e) - 256) * 64)))
-  auto ldc = [&](rsrc_t src, int comp) { return ldg(src, (unsigned) C::off_of(comp) * 8u, lane_b); };
   auto ld_rows = [&](rsrc_t src, d2_t (&r)[RU]) {   // this role's rows of one checkpoint
 #pragma unroll
     for (int u = 0; u < RU; u++) r[u] = ldg2(src, (unsigned) (w + NR * u) * 1024u, lane_b);

@@ -18,9 +18,10 @@ if [ "${1:-}" = build ]; then
   for v in $V; do
     n=${v%%:*}; fl=$(echo ${v#*:} | tr ',' ' ')
     /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -DPB_EXPERIMENTS -Ipronto_amd/csrc $fl -c -o $D/pb_smooth_$n.o pronto_amd/csrc/pb_smooth.hip || exit 1
+    /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -DPB_EXPERIMENTS -mllvm -disable-machine-licm -Ipronto_amd/csrc $fl -c -o $D/pb_smooth_wide_$n.o pronto_amd/csrc/pb_smooth_wide.hip || exit 1
     /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -shared -o $D/lib_$n.so $O/pronto_batch.o $O/pb_step.o $O/pb_step_leg15.o $O/pb_step_leg21.o $O/pb_update15.o \
-      $O/pb_update21_0.o $O/pb_update21_1.o $O/pb_update21_2.o $O/pb_update_ct.o $D/pb_smooth_$n.o || exit 1
-    rm -f $D/pb_smooth_$n.o
+      $O/pb_update21_0.o $O/pb_update21_1.o $O/pb_update21_2.o $O/pb_update_ct.o $D/pb_smooth_$n.o $D/pb_smooth_wide_$n.o || exit 1
+    rm -f $D/pb_smooth_$n.o $D/pb_smooth_wide_$n.o
   done
   ls $D
   exit 0
