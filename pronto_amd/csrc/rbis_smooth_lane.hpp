@@ -28,7 +28,7 @@
 // attribution builds (scripts/smooth_attribution.sh lane...): parts compiled OUT, results are garbage, only the time means something
 #if !defined(PB_EXPERIMENTS) && (defined(SML_SKIP_FACT) || defined(SML_SKIP_RHS) || defined(SML_SKIP_SUBST) || defined(SML_SKIP_D) || \
                                  defined(SML_SKIP_M) || defined(SML_SKIP_FINAL) || defined(SML_SKIP_CHUNKS) || defined(SML_NO_PKLOAD) || defined(SML_NO_PSTORE) || defined(SML_TIMELINE) || \
-                                 defined(SML_WIDE) || defined(SML_SINGLE_READS))
+                                 defined(SML_WIDE) || defined(SML_SINGLE_READS) || defined(SML_FINAL_SPLIT))
 #error "the SML_* attribution flags need -DPB_EXPERIMENTS as well"
 #endif
 
@@ -537,9 +537,20 @@ __global__ __launch_bounds__(SmoothLaneCfg<NS>::THREADS, SmoothLaneCfg<NS>::WAVE
         for (int t = 0; t < NCOL; t++) {
           const int r = cidx[t];
           if (r < NS && c <= r) {
+#ifdef SML_FINAL_SPLIT   // attribution (round 5): the sum in three interleaved parts -- a multiply-add that waits for its predecessor costs twice its slot
+            double acc = pkv[t][q], acc1 = 0.0, acc2 = 0.0;
+#pragma unroll
+            for (int j = 0; j < NS; j += 3) {
+              acc = fma(z[t][j], mr[j], acc);
+              if (j + 1 < NS) acc1 = fma(z[t][j + 1], mr[j + 1], acc1);
+              if (j + 2 < NS) acc2 = fma(z[t][j + 2], mr[j + 2], acc2);
+            }
+            acc += acc1 + acc2;
+#else
             double acc = pkv[t][q];
 #pragma unroll
             for (int j = 0; j < NS; j++) acc = fma(z[t][j], mr[j], acc);
+#endif
 #ifdef SML_NO_PSTORE
             if (acc == 1.2345e300) out[tb + po[t][q]] = acc;
 #elif defined(SML_WIDE)

@@ -14,7 +14,9 @@ ONLY=${2:-all}   # "smoother": refresh the smoother's trace and counters only (m
 cd $ROOT
 smoother_trace() {
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/smoother -- python3 scripts/smooth_rate.py > $OUT/smoother.txt 2> $OUT/smoother.err || exit 23
-  # the kernel it replaced (16 / 32 lanes per filter), same box, for the record
+  # the kernels it replaced, same box, for the record: k_smooth_lane for 15 states as well (the default until the second half of round 5),
+  # k_smooth_reg (16 / 32 lanes per filter)
+  PRONTO_SMOOTH_KERNEL=lane python3 scripts/smooth_rate.py > $OUT/smoother_lane.txt 2>> $OUT/smoother.err || exit 23
   PRONTO_SMOOTH_KERNEL=reg python3 scripts/smooth_rate.py > $OUT/smoother_reg.txt 2>> $OUT/smoother.err || exit 23
 }
 smoother_pmc() {

@@ -55,7 +55,7 @@ for d, name in (("trace64k", "_kernel_stats.csv"), ("trace64k_n21", "_kernel_sta
         shutil.copy(ks[0], os.path.join(out, tag + name))
 for name in ("trace64k.json", "trace64k_n21.json", "trace1m.json", "leg_rates.txt", "bench1m.json", "calib_plain.txt", "copybench.txt", "batch_sweep.txt",
              "bench_default.json", "others.txt", "configs.txt", "smoother.txt", "n21_input_footprint.txt", "checkpoint_rate.txt",
-             "smoother_pivoted.txt", "smoother_reg.txt", "leg_ab.txt", "segment_rate.txt", "smooth_log.txt"):
+             "smoother_pivoted.txt", "smoother_reg.txt", "smoother_lane.txt", "leg_ab.txt", "segment_rate.txt", "smooth_log.txt"):
     p = os.path.join(src, name)
     if os.path.exists(p):
         shutil.copy(p, os.path.join(out, tag + "_" + name))
@@ -106,7 +106,7 @@ for d in ("smooth_pmc_a", "smooth_pmc_b", "smooth_pmc_fetch", "smooth_pmc_write"
     if not glob.glob(os.path.join(src, d, "*", "*counter_collection.csv")):
         continue
     for (k, c), v in counters(d).items():
-        m = re.match(r"k_smooth_(?:lane|reg)<(\d+)", k)   # k_smooth_lane<NS> (default since round 4), k_smooth_reg<NS,PIVOT>
+        m = re.match(r"k_smooth_(?:wide|lane|reg)<(\d+)", k)   # k_smooth_wide<15> (default for 15 states since round 5), k_smooth_lane<NS>, k_smooth_reg<NS,PIVOT>
         if m:
             sm.setdefault("n" + m.group(1), {})[c] = sum(v) / len(v)
             sm["n" + m.group(1)]["kernel"] = k.split("(")[0]
@@ -131,7 +131,7 @@ if sm:
             r["valu_insts_per_wave"] = r.get("SQ_INSTS_VALU", 0) / r["SQ_WAVES"]
             r["lds_insts_per_wave"] = r.get("SQ_INSTS_LDS", 0) / r["SQ_WAVES"]
     json.dump({"what": "rocprofv3 --pmc of scripts/smooth_rate.py (64k filters), two passes (scripts/profile.sh); averages per launch",
-               "kernel": "pb_smooth_step's default kernel (k_smooth_lane<NS> since the second half of round 4; PRONTO_SMOOTH_KERNEL=reg: k_smooth_reg<NS,false>)", "runs": sm},
+               "kernel": "pb_smooth_step's default kernel (15 states: k_smooth_wide<15> since the second half of round 5; 21 states: k_smooth_lane<21>; PRONTO_SMOOTH_KERNEL=lane / reg: the older kernels)", "runs": sm},
               open(os.path.join(out, tag + "_smoother_pmc.json"), "w"), indent=1)
 
 for k, v in res["runs"].items():

@@ -46,19 +46,19 @@ def test_atlas_imu_front_end_on_gpu(oracle, tmp_path, n):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("n", [15, 21])
-@pytest.mark.parametrize("kernel", ["lane", "reg", "reg_pivoted"])
+@pytest.mark.parametrize("kernel", ["default", "lane", "reg", "reg_pivoted"])
 def test_smooth_backwards_pass_on_gpu(oracle, n, kernel):
     """EKFSmoothBackwardsPass (mav_state_est.cpp:98-189) through the shim vs the oracle's backward recursion, steps with
-    and without a measurement after the INS update.  `kernel`: the default k_smooth_lane (one lane per filter, role waves;
-    rbis_smooth_lane.hpp), and the two kernels it replaced, which stay selectable (PRONTO_SMOOTH_KERNEL=reg: 16 / 32 lanes per
-    filter without the pivot search; PRONTO_SMOOTH_PIVOT=1: with Eigen's diagonal pivoting) -- the switch is read once per
-    process, hence the executable."""
+    and without a measurement after the INS update.  `kernel`: the default (15 states: k_smooth_wide, rbis_smooth_wide.hpp; 21 states:
+    k_smooth_lane, rbis_smooth_lane.hpp), k_smooth_lane for 15 states as well (PRONTO_SMOOTH_KERNEL=lane), and the two kernels they
+    replaced, which stay selectable (PRONTO_SMOOTH_KERNEL=reg: 16 / 32 lanes per filter without the pivot search; PRONTO_SMOOTH_PIVOT=1:
+    with Eigen's diagonal pivoting) -- the switch is read once per process, hence the executable."""
     exe = build_exe(oracle, "test_smooth_pass")
     env = dict(os.environ)
     env.pop("PRONTO_SMOOTH_KERNEL", None)
     env.pop("PRONTO_SMOOTH_PIVOT", None)
-    if kernel == "reg":
-        env["PRONTO_SMOOTH_KERNEL"] = "reg"
+    if kernel in ("reg", "lane"):
+        env["PRONTO_SMOOTH_KERNEL"] = kernel
     elif kernel == "reg_pivoted":
         env["PRONTO_SMOOTH_PIVOT"] = "1"
     r = subprocess.run([exe, str(n)], capture_output=True, text=True, timeout=300, env=env)

@@ -13,7 +13,8 @@ CSRC = os.path.join(ROOT, "pronto_amd", "csrc")
 # every assembly dump this file looks at: name -> (source, defines).  They are made together, in parallel, the first time one is
 # asked for (four hipcc runs of 15-70 s each: one after the other they were half of the CPU tier's time)
 DUMPS = {"pb_step.s": ("pb_step.hip", ()), "pb_step_leg15.s": ("pb_step_leg.hip", ("-DPB_LEG_NS=15",)),
-         "pb_step_leg21.s": ("pb_step_leg.hip", ("-DPB_LEG_NS=21",)), "pb_smooth.s": ("pb_smooth.hip", ())}
+         "pb_step_leg21.s": ("pb_step_leg.hip", ("-DPB_LEG_NS=21",)), "pb_smooth.s": ("pb_smooth.hip", ()),
+         "pb_smooth_wide.s": ("pb_smooth_wide.hip", ("-mllvm", "-disable-machine-licm"))}   # (the Makefile's flags for that object)
 
 
 def _stale(out):
@@ -117,3 +118,20 @@ def test_smoother_lane_kernel_keeps_its_values_in_front_of_the_barriers():
     assert len(lane) == 2, sorted(meta)
     for name, (vgpr, agpr, scratch) in lane.items():
         assert vgpr <= 256 and agpr == 0 and scratch <= (0 if "ILi15E" in name else 16), (name, vgpr, agpr, scratch)
+
+
+def test_smoother_wide_kernel_has_no_scratch_and_guards_its_row_stores():
+    """k_smooth_wide<15> (rbis_smooth_wide.hpp): one wave per SIMD, architectural + accumulation registers, NO scratch -- with the
+    backend's loop-invariant code motion left on, ~60 constants of the attitude arithmetic are lifted in front of the loop over the tiles
+    and spilled (372 bytes per lane, 162 instead of 139 us per step when that was measured), hence the object's own flags (Makefile).
+    Its posterior leaves by 16-byte rows: the store hazard workaround of stg2 must hold here as well."""
+    path = _asm("pb_smooth_wide.s")
+    meta = _kernel_metadata(path)
+    wide = {k: v for k, v in meta.items() if k.startswith("_ZN2pb13k_smooth_wideILi15E")}
+    assert len(wide) == 1, sorted(meta)
+    for name, (vgpr, agpr, scratch) in wide.items():
+        assert vgpr <= 512 and 0 < agpr <= 256 and scratch == 0, (name, vgpr, agpr, scratch)   # (.vgpr_count is the unified total here)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "chk_store_hazard.py"), path], capture_output=True, text=True)
+    last = r.stdout.strip().splitlines()[-1]
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert int(last.split()[1]) >= 18, last     # the role's rows

@@ -1,5 +1,6 @@
 """RTS smoother (rbis.cpp:234-266 + the backward pass of mav_state_est.cpp:98-189): the device
-kernels behind pb_smooth_step -- k_smooth_lane (default: one lane per filter, role waves, unpivoted LDL^T), k_smooth_reg
+kernels behind pb_smooth_step -- k_smooth_wide (default for 15 states: persistent workgroups, one wave per SIMD, rows through LDS),
+k_smooth_lane (default for 21 states; PRONTO_SMOOTH_KERNEL=lane for 15: one lane per filter, role waves, unpivoted LDL^T), k_smooth_reg
 (PRONTO_SMOOTH_KERNEL=reg) and its pivoted variant (PRONTO_SMOOTH_PIVOT=1, Eigen's diagonal pivoting like the reference's
 .ldlt()) -- on posterior checkpoints against the oracle's dense restatement po_ekf_smoothing_step.
 
@@ -363,3 +364,63 @@ def test_whole_log_smoothing_of_10000_steps_with_bounded_memory(oracle):
     print("worst relative error against the oracle at %d sampled (step, filter) pairs: %.2e" % (len(steps) * len(filters), worst))
     assert worst < TOL, worst
     est.close()
+
+
+_SNIPPET = r"""
+import sys, numpy as np
+sys.path.insert(0, %(root)r)
+from pronto_amd.batch import BatchEstimator
+from pronto_amd.synth import Workload
+B = %(B)d
+w = Workload(B, n_states=15)
+est = BatchEstimator(B, n_states=15)
+vec, quat, P0 = w.initial_state()
+est.reset(vec, quat, P0)
+est.history_reserve(6)
+q4 = w.process_noise()
+for k in range(2):
+    est.predict(w.imu_block(k), q4)
+    est.state_save(2 * k)
+    lo, mask = w.legodo_block(k)
+    est.update_indexed([3, 4, 5], np.ascontiguousarray(lo[0:3]), np.ascontiguousarray(lo[3:6]), mask=mask)
+    est.state_save(2 * k + 1)
+est.smooth_step(2, 3, 1, 4, 1e-3)
+est.smooth_step(2, 3, 1, 1, 1e-3)     # in place: slot_out == slot_cur
+out = []
+for slot in (4, 1):
+    est.state_restore(slot)
+    v, q, P, ll = est.get_head()
+    out += [v, q, P, ll]
+np.savez(%(path)r, *out)
+est.close()
+"""
+
+
+@pytest.mark.parametrize("B", [1, 100, 16384 + 64 * 3 + 5, 65536 + 37])
+def test_wide_and_lane_kernels_agree_at_ragged_batch_sizes(tmp_path, B):
+    """k_smooth_wide<15> is persistent (a workgroup walks tiles blockIdx.x, + gridDim.x, ...) and moves whole rows of a tile: partly filled
+    last tiles, fewer tiles than CUs, workgroups with an uneven number of tiles, and the in-place call (slot_out == slot_cur) must give what
+    k_smooth_lane<15> gives (PRONTO_SMOOTH_KERNEL=lane; the switch is read once per process, hence the child processes).  The two kernels
+    round differently (orders of the sums): 1e-10 block-relative, observed ~1e-14."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for kern in ("wide", "lane"):
+        env = dict(os.environ)
+        env.pop("PRONTO_SMOOTH_KERNEL", None)
+        if kern == "lane":
+            env["PRONTO_SMOOTH_KERNEL"] = "lane"
+        path = str(tmp_path / (kern + ".npz"))
+        r = subprocess.run([sys.executable, "-c", _SNIPPET % {"root": root, "B": B, "path": path}], capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stdout + r.stderr
+        d = np.load(path)
+        res[kern] = [d["arr_%d" % i] for i in range(8)]
+    worst = 0.0
+    for a, b in zip(res["wide"], res["lane"]):
+        assert np.all(np.isfinite(a)) and a.shape == b.shape
+        worst = max(worst, rel(a, b))
+    print("wide vs lane, B = %d: worst block-relative difference %.2e" % (B, worst))
+    assert worst < 1e-10
+    for i in range(4):   # the in-place call gives the same bits as the call into a free slot
+        assert np.array_equal(res["wide"][i], res["wide"][4 + i])
