@@ -96,6 +96,30 @@ __device__ __forceinline__ void leg_blocks(const Pose &delta, double status, con
 // SIX: LegOdoCommon's six-row modes in the same kernel (rbis_coop.hpp, coop_role_core): 1 lin_rot_rate, 2 pos_and_lin_rate (with
 // leg_estimate's world constraint: the pelvis position is measured, so the odometry wave needs the head POSITION after the IMU
 // step too -- the whole state propagate instead of the quaternion's).
+// PB_LEG_PRIO (experiment, round 5): the kernel starts with ~3 us of kinematics per tile, and at 64k filters every tile of the GPU starts
+// at the same moment (one dispatch round: 4 workgroups per CU) -- the memory sits idle while all of them compute, then all of them load.
+// With a raised priority for HALF of the waves that share a SIMD, those finish their kinematics in half the time and start loading
+// while the others compute.  1: odd workgroups; 2: bit 8 of the workgroup index; 3: the odd hardware wave slots.
+#ifndef PB_LEG_PRIO
+#define PB_LEG_PRIO 0
+#endif
+__device__ __forceinline__ void leg_prio_raise()
+{
+#if PB_LEG_PRIO == 1
+  if (blockIdx.x & 1) __builtin_amdgcn_s_setprio(3);
+#elif PB_LEG_PRIO == 2
+  if ((blockIdx.x >> 8) & 1) __builtin_amdgcn_s_setprio(3);
+#elif PB_LEG_PRIO == 3
+  if (__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1) __builtin_amdgcn_s_setprio(3);   // HW_REG_HW_ID, WAVE_ID
+#endif
+}
+__device__ __forceinline__ void leg_prio_drop()
+{
+#if PB_LEG_PRIO != 0
+  __builtin_amdgcn_s_setprio(0);
+#endif
+}
+
 template <int NS, int MH, int PLAN = 0, int EARLY = 12, int SIX = 0>
 __global__ __launch_bounds__(128, 2) void k_step_leg(const double *st, double *sto, int B, const double *__restrict__ imu, double qg,
                                                      double qa, double qbg, double qba, Consts k, StepBcast bc, LegPar par, LegIn lin,
@@ -142,6 +166,7 @@ __global__ __launch_bounds__(128, 2) void k_step_leg(const double *st, double *s
   // the right leg's is role P's; one more barrier (F) hands the left foot over.  (A broadcast joint state arrives as foot poses.)
   const bool split_fk = lin.kind == 1;  // wave-uniform
   const long bl_ = b < (unsigned) B ? (long) b : (long) B - 1;  // lanes past the batch read the last robot's inputs, store nothing
+  leg_prio_raise();
   if (role == 0) {
     io.template need<0, Slots<NS>::ROW_SPLIT>();
     if (split_fk) {
@@ -156,6 +181,7 @@ __global__ __launch_bounds__(128, 2) void k_step_leg(const double *st, double *s
       }
       __syncthreads();  // barrier F
     }
+    leg_prio_drop();
     coop_role_core<NS, true, CORR, true, true, SIX>(ld, stf, [lane](int s, double v) { xch[s][lane] = v; }, xrd, sync, in, k);
   } else {
     // ---- the odometry, on the prior state this role reads anyway ----
@@ -233,6 +259,7 @@ __global__ __launch_bounds__(128, 2) void k_step_leg(const double *st, double *s
       xch[CX::XCH_LEG + 8][lane] = m.r2;
       xch[CX::XCH_LEG + 9][lane] = m.on2 ? 1.0 : 0.0;
     }
+    leg_prio_drop();
     if constexpr (SIX != 1) __syncthreads();  // barrier L (SIX == 1: inside the passive role, behind its omega stage)
     else reload_fence();                       // (keeps the panel loads below the odometry, as the barrier does)
     CorrInputs cin2;
