@@ -254,8 +254,8 @@ __global__ __launch_bounds__(SmoothWideCfg<NS>::THREADS, 1) void k_smooth_wide(c
   // loads are spread: the rows of P^- and of the filtered checkpoint of the NEXT tile are requested while this one multiplies (steps 6
   // and 7), the rows of P^s_{k+1} of THIS tile during its first factorisation steps (first needed in its ninth).
   d2_t ar[RU], cr[RU], nr[RU];
-  ld_rows(tbuf.np, ar);
-  ld_rows(tbuf.cu, cr);
+  ld_rows(tbuf.np, ar);   // (the first tile's filtered checkpoint follows during its factorisation: a burst of 36 row loads here would hold the wave for 12 k cycles)
+  bool first = true;
   auto ld_row1 = [&](rsrc_t src, d2_t (&r)[RU], int u) { r[u] = ldg2(src, (unsigned) (w + NR * u) * 1024u, lane_b); };
 #pragma unroll 1
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -324,6 +324,12 @@ __global__ __launch_bounds__(SmoothWideCfg<NS>::THREADS, 1) void k_smooth_wide(c
     static_for<NS>([&](auto KK) {
       constexpr int kk = decltype(KK)::value;
       // (column kk was published by its owner during step kk - 1 -- column 0 in front of the loop)
+      if constexpr (kk < 6) {   // the workgroup's first tile has no predecessor that asked for its filtered checkpoint: three rows per step
+        if (first) {
+#pragma unroll
+          for (int u = 3 * kk; u < 3 * kk + 3; u++) ld_row1(tbuf.cu, cr, u);
+        }
+      }
       if constexpr (kk < 9) {   // two rows of P^s_{k+1}
         mem_tick(std::integral_constant<int, 2 * kk>{});
         mem_tick(std::integral_constant<int, 2 * kk + 1>{});
@@ -620,6 +626,7 @@ __global__ __launch_bounds__(SmoothWideCfg<NS>::THREADS, 1) void k_smooth_wide(c
   if (stamp && lane == 0)
     for (int i = 0; i < 16; i++) sml_tl[w][i] = tl[i];
 #endif
+  first = false;
   }  // tiles
 }
 
