@@ -424,3 +424,90 @@ def test_wide_and_lane_kernels_agree_at_ragged_batch_sizes(tmp_path, B):
     assert worst < 1e-10
     for i in range(4):   # the in-place call gives the same bits as the call into a free slot
         assert np.array_equal(res["wide"][i], res["wide"][4 + i])
+
+
+def _exact_smoothed_cov(Ad, Pc, Pp, Ps):
+    """P_k + G (P^s - P^-) G^T, G = P_k Ad^T (P^-)^-1 in exact rational arithmetic on the float inputs (one filter)."""
+    from fractions import Fraction
+    n = Pc.shape[0]
+    F = lambda M: [[Fraction(float(M[i, j])) for j in range(M.shape[1])] for i in range(M.shape[0])]
+    A, C, P, S = F(Ad), F(Pc), F(Pp), F(Ps)
+    # X = (P^-)^-1 (Ad P_k): Gaussian elimination with partial pivoting on [P | Ad P_k] (exact: the pivoting only avoids zero pivots)
+    rhs = [[sum(A[i][k] * C[k][j] for k in range(n)) for j in range(n)] for i in range(n)]
+    M = [P[i][:] + rhs[i][:] for i in range(n)]
+    for c in range(n):
+        piv = max(range(c, n), key=lambda r: abs(M[r][c]))
+        M[c], M[piv] = M[piv], M[c]
+        inv = 1 / M[c][c]
+        M[c] = [v * inv for v in M[c]]
+        for r in range(n):
+            if r != c and M[r][c] != 0:
+                f = M[r][c]
+                M[r] = [a - f * b for a, b in zip(M[r], M[c])]
+    X = [row[n:] for row in M]                       # X = (P^-)^-1 Ad P_k, G = X^T
+    D = [[S[i][j] - P[i][j] for j in range(n)] for i in range(n)]
+    GD = [[sum(X[k][i] * D[k][j] for k in range(n)) for j in range(n)] for i in range(n)]
+    out = np.zeros((n, n))
+    for i in range(n):
+        for j in range(n):
+            out[i, j] = float(C[i][j] + sum(GD[i][k] * X[k][j] for k in range(n)))
+    return out
+
+
+@pytest.mark.parametrize("n", [15, 21])
+def test_unpivoted_factorisation_is_as_accurate_as_the_pivoted_one_on_ill_conditioned_covariances(oracle, n):
+    """the default kernels factorise P^-_{k+1} WITHOUT the reference's diagonal pivoting (.ldlt()).  For an SPD matrix the
+    two differ by rounding; the question is what happens as P^- approaches a positive-SEMI-definite matrix.  One smoother step on crafted
+    checkpoints whose P^- = Q diag(lambda) Q^T has condition numbers 1e6 .. 1e10 (dense Q), judged against the EXACT smoothed covariance
+    (rational arithmetic on the same float inputs): the GPU's unpivoted result must be finite and no further from the truth than a small
+    multiple of the oracle's pivoted result -- the step itself loses digits like cond^2 (G is as large as cond), pivoting does not buy
+    them back.  An exactly singular P^- is outside what either factorisation defines (the reference divides by whatever rounding leaves
+    of the zero pivot as well: Eigen's solve zeroes only |d| <= DBL_MIN)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import numpy_restatement as nr
+    from pronto_amd.batch import BatchEstimator
+    from util import embed21
+    B = 64
+    NX = 3          # filters checked against exact arithmetic (seconds each)
+    w = Workload(B, n_states=n)
+    vec, quat, P0 = w.initial_state()
+    rng = np.random.default_rng(1234 + n)
+    dt = 1e-3
+    for cond in (1e6, 1e8, 1e10):
+        Pp = np.zeros((n, n, B))
+        for b in range(B):
+            Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+            lam = 1e-2 * np.logspace(0.0, -np.log10(cond), n)
+            Pp[:, :, b] = (Q * lam) @ Q.T
+            Pp[:, :, b] = 0.5 * (Pp[:, :, b] + Pp[:, :, b].T)
+        Ps = 0.7 * Pp
+        Pc = P0.copy()
+        for i in range(n):
+            Pc[i, i] += 1e-4     # (every state has some variance in the filtered checkpoint)
+        vp = vec + 1e-3 * rng.standard_normal(vec.shape)
+        vs = vp + 1e-4 * rng.standard_normal(vec.shape)
+        est = BatchEstimator(B, n_states=n)
+        est.set_constants(*oracle.constants())
+        est.history_reserve(4)
+        for slot, (v, P) in enumerate(((vec, Pc), (vp, Pp), (vs, Ps))):
+            est.reset(v, quat, P)
+            est.state_save(slot)
+        est.smooth_step(1, 2, 0, 3, dt)
+        est.state_restore(3)
+        gv, gq, gP, _ = est.get_head()
+        est.close()
+        e = lambda v, P: (embed21(v, P)[0], quat, embed21(v, P)[1])
+        ov, oq, oP = oracle_smooth_step(oracle, e(vp, Pp), e(vs, Ps), e(vec, Pc), dt)
+        assert np.all(np.isfinite(gv)) and np.all(np.isfinite(gq)) and np.all(np.isfinite(gP))
+        v21 = embed21(vec, Pc)[0]
+        Ad = nr.process_matrices(np.ascontiguousarray(v21.T), np.ascontiguousarray(quat.T), np.full(B, dt))
+        eg = eo = 0.0
+        for b in range(NX):
+            truth = _exact_smoothed_cov(Ad[b][:n, :n], Pc[:, :, b], Pp[:, :, b], Ps[:, :, b])
+            sc = np.abs(truth).max()
+            eg = max(eg, np.abs(gP[:, :, b] - truth).max() / sc)
+            eo = max(eo, np.abs(oP[:n, :n, b] - truth).max() / sc)
+        print("n=%d cond %.0e: error against exact arithmetic: GPU (unpivoted) %.2e, oracle (pivoted) %.2e; GPU against oracle %.2e"
+              % (n, cond, eg, eo, rel(gP, oP[:n, :n])))
+        assert eg < 10.0 * eo + 1e-12, (cond, eg, eo)
