@@ -30,11 +30,15 @@
 
 namespace pb {
 
+#ifndef SMW_DEPTH
+#define SMW_DEPTH 2   // groups of LDS reads in flight in the long phases (lds_stream)
+#endif
+
 // ---- LDS reads as an explicit pipeline -------------------------------------------------------------------------------------------
 // One wave per SIMD has nobody to hide an LDS round trip behind, and the backend schedules `read, wait, use, read, wait, use` once the
 // accumulators fill the 256 architectural registers (the M sweep: 60 exposed round trips).  lds_stream reads a compile-time list of
-// entries G at a time into two buffers with ds_read_b64 of its own (single reads: the LDS serves two of them in half the time of the
-// paired ds_read2st64_b64 the backend prefers), the reads of group g + 1 issued BEFORE the wait for group g (a counted s_waitcnt: LDS
+// entries G at a time into D + 1 buffers with ds_read_b64 of its own (single reads: the LDS serves two of them in half the time of the
+// paired ds_read2st64_b64 the backend prefers), the reads of groups g + 1 .. g + D issued BEFORE the wait for group g (a counted s_waitcnt: LDS
 // operations of a wave return in order; a scalar load the backend may have in flight can only make the wait longer, never shorter).
 // `use(k, value)` is called for k = 0 .. N-1 in order with k a compile-time constant; `pin(g)` after every group g: it names what the
 // group's arithmetic wrote (lane_pin), which keeps that arithmetic in front of the next group's reads -- the backend would otherwise
@@ -53,34 +57,41 @@ __device__ __forceinline__ void lds_wait8(double (&b)[8])
                : "n"(CNT));
 }
 struct LdsBases { int b0, b1, b2; };   // byte addresses of this lane's entries 0, 128, 256 ([entry][lane] layout: 512 bytes per entry)
-template <int N, class EntryOf, class Use, class Pin>
+template <int N, class EntryOf, int D = 1, class Use, class Pin>
 __device__ __forceinline__ void lds_stream(LdsBases bb, Use &&use, Pin &&pin)
 {
+  // D groups are in flight while one is consumed (D = 2 where a group's arithmetic is shorter than an LDS round trip)
   constexpr int G = 8, NG = (N + G - 1) / G;
-  double buf[2][G];
+  double buf[D + 1][G];
 #pragma unroll
-  for (int j = 0; j < G; j++) buf[0][j] = buf[1][j] = 0.0;
+  for (int q = 0; q <= D; q++)
+#pragma unroll
+    for (int j = 0; j < G; j++) buf[q][j] = 0.0;
+  auto size_of = [](int g) constexpr { return g < NG ? ((N - g * G < G) ? N - g * G : G) : 0; };
   auto issue = [&](auto GG) {
     constexpr int g = decltype(GG)::value;
     static_for<G>([&](auto JJ) {
       constexpr int j = decltype(JJ)::value, kq = g * G + j;
       if constexpr (kq < N) {
         constexpr int e = EntryOf::at(kq);
-        if constexpr (e < 128) lds_rd_b64<e * 512>(buf[g & 1][j], bb.b0);
-        else if constexpr (e < 256) lds_rd_b64<(e - 128) * 512>(buf[g & 1][j], bb.b1);
-        else lds_rd_b64<(e - 256) * 512>(buf[g & 1][j], bb.b2);
+        if constexpr (e < 128) lds_rd_b64<e * 512>(buf[g % (D + 1)][j], bb.b0);
+        else if constexpr (e < 256) lds_rd_b64<(e - 128) * 512>(buf[g % (D + 1)][j], bb.b1);
+        else lds_rd_b64<(e - 256) * 512>(buf[g % (D + 1)][j], bb.b2);
       }
     });
   };
-  issue(std::integral_constant<int, 0>{});
+  static_for<D>([&](auto GG) {
+    if constexpr (decltype(GG)::value < NG) issue(GG);
+  });
   static_for<NG>([&](auto GG) {
     constexpr int g = decltype(GG)::value;
-    constexpr int next = (g + 1 < NG) ? ((N - (g + 1) * G < G) ? N - (g + 1) * G : G) : 0;
-    if constexpr (g + 1 < NG) issue(std::integral_constant<int, g + 1>{});
-    lds_wait8<next>(buf[g & 1]);
+    if constexpr (g + D < NG) issue(std::integral_constant<int, g + D>{});
+    constexpr int younger_all = size_of(g + 1) + (D >= 2 ? size_of(g + 2) : 0) + (D >= 3 ? size_of(g + 3) : 0);
+    constexpr int younger = younger_all > 15 ? 15 : younger_all;   // (the counter's field has 4 bits: waiting for one read more is harmless)
+    lds_wait8<younger>(buf[g % (D + 1)]);
     static_for<G>([&](auto JJ) {
       constexpr int j = decltype(JJ)::value, kq = g * G + j;
-      if constexpr (kq < N) use(std::integral_constant<int, kq>{}, buf[g & 1][j]);
+      if constexpr (kq < N) use(std::integral_constant<int, kq>{}, buf[g % (D + 1)][j]);
     });
     pin(std::integral_constant<int, g>{});
   });
@@ -448,7 +459,7 @@ __global__ __launch_bounds__(SmoothWideCfg<NS>::THREADS, 1) void k_smooth_wide(c
 #pragma unroll
       for (int i = 0; i < NS; i++) lane_pin(z[t][i]);
   };
-  lds_stream<NS *(NS - 1) / 2, SmwLowerByColumn<NS>>(bb, [&](auto KQ, double l) {
+  lds_stream<NS *(NS - 1) / 2, SmwLowerByColumn<NS>, SMW_DEPTH>(bb, [&](auto KQ, double l) {
     constexpr int kq = decltype(KQ)::value, i = SmwLowerByColumn<NS>::row(kq), mm = SmwLowerByColumn<NS>::col(kq);
 #pragma unroll
     for (int t = 0; t < NCOL; t++) z[t][i] = fma(-l, z[t][mm], z[t][i]);
@@ -461,7 +472,7 @@ __global__ __launch_bounds__(SmoothWideCfg<NS>::THREADS, 1) void k_smooth_wide(c
 #pragma unroll
     for (int t = 0; t < NCOL; t++) z[t][i] *= inv;
   }, pin_z);
-  lds_stream<NS *(NS - 1) / 2, SmwUpperByColumn<NS>>(bb, [&](auto KQ, double l) {
+  lds_stream<NS *(NS - 1) / 2, SmwUpperByColumn<NS>, SMW_DEPTH>(bb, [&](auto KQ, double l) {
     constexpr int kq = decltype(KQ)::value, i = SmwUpperByColumn<NS>::ci(kq), mm = SmwUpperByColumn<NS>::cm(kq);
 #pragma unroll
     for (int t = 0; t < NCOL; t++) z[t][i] = fma(-l, z[t][mm], z[t][i]);
@@ -507,7 +518,7 @@ __global__ __launch_bounds__(SmoothWideCfg<NS>::THREADS, 1) void k_smooth_wide(c
     for (int j = 0; j < NS; j++) m[t][j] = 0.0;
   auto sweep = [&](auto T0, auto NT) {
     constexpr int t0 = decltype(T0)::value, nt = decltype(NT)::value;
-    lds_stream<NP, SmwByDiagonal<NS>>(bb, [&](auto KQ, double d) {
+    lds_stream<NP, SmwByDiagonal<NS>, SMW_DEPTH>(bb, [&](auto KQ, double d) {
       constexpr int kq = decltype(KQ)::value, i = SmwByDiagonal<NS>::row(kq), j = SmwByDiagonal<NS>::col(kq);
 #pragma unroll
       for (int t = t0; t < t0 + nt; t++) {
@@ -560,7 +571,7 @@ __global__ __launch_bounds__(SmoothWideCfg<NS>::THREADS, 1) void k_smooth_wide(c
     for (int cq = 0; cq < HALF; cq++)
 #pragma unroll
       for (int t = 0; t < NCOL; t++) acc[cq][t] = (cq < rows_h && t >= (HALF * h + cq) / NR) ? WS[(O_B + rbase[t] + HALF * h + cq) * 64] : 0.0;   // P_k(r, c): its owner's own entry
-    lds_stream<rows_h * NS, FE>(bb, [&](auto KQ, double mv) {
+    lds_stream<rows_h * NS, FE, SMW_DEPTH>(bb, [&](auto KQ, double mv) {
       constexpr int kq = decltype(KQ)::value, cq = FE::row(kq), j = FE::col(kq), c = HALF * h + cq;
 #pragma unroll
       for (int t = 0; t < NCOL; t++)
