@@ -212,11 +212,29 @@ __global__ __launch_bounds__(SmoothLaneCfg<NS>::THREADS, SmoothLaneCfg<NS>::WAVE
     for (int i = 0; i < NS; i++) rv[i] = ldc(next_sm, L::OFF_VEC + i) - ldc(next_pred, L::OFF_VEC + i);
   }
 
+  // (round 5 experiment, OFF) the role's columns of P_k and the filtered state for step 2 asked for HERE, so that they arrive behind the
+  // factorisation (the barriers order LDS only, nothing waits for them on the way): SML_EARLY_PK = how many of the role's 3 columns
+  // (21 states only).  Measured at 64k filters: 0: 291.6 us, 1: 303.2 (20 B of scratch), 2: 311.3 (60 B), 3: 339.4 (276 B) -- the
+  // kernel has no registers left for them.
+#ifndef SML_EARLY_PK
+#define SML_EARLY_PK 0
+#endif
+  constexpr int NEARLY = (NS == 21) ? SML_EARLY_PK : 0;
+  constexpr bool EARLY_PK = NEARLY > 0;
+  double pke[EARLY_PK ? NEARLY : 1][EARLY_PK ? NS : 1], ske[10];
   // ---- 1. P^- = L diag(d) L^T ----
   {
     double a[NCOL][NS];
 #pragma unroll
     for (int t = 0; t < NCOL; t++) ld_col(next_pred, t, NR * t, a[t]);  // column w + NR t: rows above NR t are above its diagonal for every role
+    if constexpr (EARLY_PK) {
+#pragma unroll
+      for (int i = 0; i < 6; i++) ske[i] = ldc(cur, L::OFF_VEC + i);
+#pragma unroll
+      for (int i = 0; i < 4; i++) ske[6 + i] = ldc(cur, L::OFF_QUAT + i);
+#pragma unroll
+      for (int t = 0; t < NEARLY; t++) ld_col(cur, t, 0, pke[t]);
+    }
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (NS == 21) {  // rbis.cpp:244-251: a bias block whose variance is < 1e-11 is replaced by I in the factorised matrix
       bool fix_g = false, fix_a = false;
@@ -290,17 +308,22 @@ __global__ __launch_bounds__(SmoothLaneCfg<NS>::THREADS, SmoothLaneCfg<NS>::WAVE
     double wv[3], v[3], q[4], R[9];
 #pragma unroll
     for (int i = 0; i < 3; i++) {
-      wv[i] = ldc(cur, L::OFF_VEC + i);
-      v[i] = ldc(cur, L::OFF_VEC + 3 + i);
+      wv[i] = EARLY_PK ? ske[i] : ldc(cur, L::OFF_VEC + i);
+      v[i] = EARLY_PK ? ske[3 + i] : ldc(cur, L::OFF_VEC + 3 + i);
     }
 #pragma unroll
-    for (int i = 0; i < 4; i++) q[i] = ldc(cur, L::OFF_QUAT + i);
+    for (int i = 0; i < 4; i++) q[i] = EARLY_PK ? ske[6 + i] : ldc(cur, L::OFF_QUAT + i);
     quat_to_rot(q, R);
     const double gb[3] = { -k.g * R[6], -k.g * R[7], -k.g * R[8] };
 #pragma unroll
     for (int t = 0; t < NCOL; t++) {
       double p[NS];
-      ld_col(cur, t, 0, p);
+      if (t < NEARLY) {   // (compile-time inside the unrolled loop)
+#pragma unroll
+        for (int i = 0; i < NS; i++) p[i] = pke[t < NEARLY ? t : 0][i];
+      } else {
+        ld_col(cur, t, 0, p);
+      }
 #pragma unroll
       for (int i = 0; i < NS; i++) z[t][i] = p[i];
       const double pv[3] = { p[3], p[4], p[5] }, pc[3] = { p[6], p[7], p[8] };
