@@ -184,6 +184,33 @@ struct SmoothWideCfg {
         }
     return t;
   }
+  // every covariance entry and every state component of a checkpoint has exactly one place in each use of the rows (compile-time check
+  // of the table against the tile layout of rbis_device.hpp)
+  static constexpr bool tab_ok()
+  {
+    const Tab t = make();
+    for (int use = 0; use < NPUT; use++) {
+      int hits[PER] = {};
+      for (int w = 0; w < NR; w++)
+        for (int u = 0; u < RU; u++)
+          for (int h = 0; h < 2; h++) {
+            const int e = t.put[use][w][u][h];
+            if (e < 0 || e >= PER) return false;
+            hits[e]++;
+          }
+      const int pbase = (use == PUT_NP || use == PUT_D) ? O_A : O_B;
+      const int sbase = (use == PUT_NP) ? O_SP : (use == PUT_NS_STATE) ? O_SN : O_B + NP;
+      if (use != PUT_NS_STATE)
+        for (int e = 0; e < NP; e++)
+          if (hits[pbase + e] != 1) return false;
+      if (use != PUT_D)
+        for (int c = 0; c < NST; c++)
+          if (hits[sbase + c] != 1) return false;
+      if (hits[DUMMY] != 2 * NR * RU - (use != PUT_NS_STATE ? NP : 0) - (use != PUT_D ? NST : 0)) return false;
+    }
+    return true;
+  }
+  static_assert(tab_ok(), "row tables of the smoother do not match the tile layout");
 };
 template <int NS>
 __constant__ const typename SmoothWideCfg<NS>::Tab smooth_wide_tab = SmoothWideCfg<NS>::make();
