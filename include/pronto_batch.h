@@ -445,9 +445,10 @@ int pb_state_restore(pb_ctx *ctx, int slot);   /* head posterior <- slot */
  *   filtered) posterior at k+1, slot_cur = filtered posterior at k; slot_out <- smoothed posterior at k.
  * slot_out may be slot_cur (in place) but not one of the k+1 slots.  dt as passed to EKFSmoothBackwardsPass.
  * P^-_{k+1} is factorised WITHOUT the reference's diagonal pivot search (it is SPD; results agree with Eigen's .ldlt() to rounding,
- * tests: <= 1e-9 against the oracle).  Environment, read once per process: PRONTO_SMOOTH_KERNEL=reg selects the kernel of rounds
- * 2-4 (16 / 32 lanes per filter) instead of the default (one lane per filter, rbis_smooth_lane.hpp); PRONTO_SMOOTH_PIVOT=1 that
- * kernel with Eigen's pivoting. */
+ * tests: <= 1e-9 against the oracle, and as close to exact arithmetic as the pivoted oracle up to a condition number of 1e10).
+ * Default kernels: 15 states k_smooth_wide (rbis_smooth_wide.hpp: persistent workgroups, rows through LDS), 21 states k_smooth_lane
+ * (rbis_smooth_lane.hpp).  Environment, read once per process: PRONTO_SMOOTH_KERNEL=lane selects k_smooth_lane for 15 states as well,
+ * =reg the kernel of rounds 2-4 (16 / 32 lanes per filter); PRONTO_SMOOTH_PIVOT=1 that kernel with Eigen's pivoting. */
 int pb_smooth_step(pb_ctx *ctx, int slot_next_pred, int slot_next, int slot_cur, int slot_out, double dt);
 
 /* EKFSmoothBackwardsPass over a WHOLE log with bounded memory (mav_state_est.cpp:98-189, lcm_front_end.cpp:168-203: the reference's
