@@ -165,7 +165,12 @@ __global__ __launch_bounds__(SmoothLaneCfg<NS>::THREADS, SmoothLaneCfg<NS>::WAVE
 #else
 #define SER(e) SE(e)
 #endif
-  auto ldc = [&](const double *src, int comp) { return src[tb + C::off_of(comp)]; };  // compile-time component only
+#ifndef SML_NT
+#define SML_NT 0   // (round 5 experiment) non-temporal global loads and stores
+#endif
+  auto gld = [&](const double *pp) { return SML_NT ? __builtin_nontemporal_load(pp) : *pp; };
+  auto gst = [&](double *pp, double v) { if (SML_NT) __builtin_nontemporal_store(v, pp); else *pp = v; };
+  auto ldc = [&](const double *src, int comp) { return gld(src + tb + C::off_of(comp)); };  // compile-time component only
   // column t of this role from one of the checkpoints: the offsets come in with wide scalar loads, the n loads go out back to back
   auto ld_col = [&](const double *src, int t, int i0, double (&v)[NS]) {  // rows i0 .. n-1 (the others: 0)
     int o[NS];
@@ -184,7 +189,7 @@ __global__ __launch_bounds__(SmoothLaneCfg<NS>::THREADS, SmoothLaneCfg<NS>::WAVE
     }
 #else
 #pragma unroll
-    for (int i = 0; i < NS; i++) v[i] = (i >= i0) ? src[tb + o[i]] : 0.0;
+    for (int i = 0; i < NS; i++) v[i] = (i >= i0) ? gld(src + tb + o[i]) : 0.0;
 #endif
   };
 
@@ -515,7 +520,7 @@ __global__ __launch_bounds__(SmoothLaneCfg<NS>::THREADS, SmoothLaneCfg<NS>::WAVE
           pkn[t][q] = r.x + r.y;
         }
 #else
-        pkn[t][q] = cur[tb + pon[t][q]];
+        pkn[t][q] = gld(cur + tb + pon[t][q]);
 #endif
       }
 #pragma unroll
@@ -600,7 +605,7 @@ __global__ __launch_bounds__(SmoothLaneCfg<NS>::THREADS, SmoothLaneCfg<NS>::WAVE
 #elif defined(SML_WIDE)
             if (active) *reinterpret_cast<d2_t *>(out + tb + (po[t][q] & ~1)) = d2_t{ acc, acc };
 #else
-            if (active) out[tb + po[t][q]] = acc;
+            if (active) gst(out + tb + po[t][q], acc);
 #endif
           }
         }

@@ -30,6 +30,15 @@
 
 namespace pb {
 
+// cache-policy bits of the row loads / stores (rbis_kernels.hpp: 1 = sc0, 2 = nt, 16 = sc1).  Every checkpoint is read once and the
+// posterior written once: non-temporal both ways, 85.7 us against 87.4-88.5 at 64k filters (loads only: 90.4, stores only: 86.7,
+// nt loads + sc1 stores: 87.9), no worse at 4k-128k filters and in pb_smooth_log
+#ifndef SMW_LOAD_AUX
+#define SMW_LOAD_AUX 2
+#endif
+#ifndef SMW_STORE_AUX
+#define SMW_STORE_AUX 2
+#endif
 #ifndef SMW_DEPTH
 #define SMW_DEPTH 1   // groups of LDS reads in flight beside the one consumed, in the long phases (2: 91.0 us against 88.1, 3: 91.4 -- registers)
 #endif
@@ -253,7 +262,7 @@ __global__ __launch_bounds__(SmoothWideCfg<NS>::THREADS, 1) void k_smooth_wide(c
 #define WE(e) (*(((e) < 128) ? (lds + sb + (e) * 64) : ((e) < 256) ? (lds + sb1 + ((e) - 128) * 64) : (lds + sb2 + ((e) - 256) * 64)))
   auto ld_rows = [&](rsrc_t src, d2_t (&r)[RU]) {   // this role's rows of one checkpoint
 #pragma unroll
-    for (int u = 0; u < RU; u++) r[u] = ldg2(src, (unsigned) (w + NR * u) * 1024u, lane_b);
+    for (int u = 0; u < RU; u++) r[u] = ldg2<SMW_LOAD_AUX>(src, (unsigned) (w + NR * u) * 1024u, lane_b);
   };
   // ... into LDS [entry][lane] by one of the table's uses
   auto put_rows = [&](const d2_t (&r)[RU], int use) {
@@ -294,7 +303,7 @@ __global__ __launch_bounds__(SmoothWideCfg<NS>::THREADS, 1) void k_smooth_wide(c
   d2_t ar[RU], cr[RU], nr[RU];
   ld_rows(tbuf.np, ar);   // (the first tile's filtered checkpoint follows during its factorisation: a burst of 36 row loads here would hold the wave for 12 k cycles)
   bool first = true;
-  auto ld_row1 = [&](rsrc_t src, d2_t (&r)[RU], int u) { r[u] = ldg2(src, (unsigned) (w + NR * u) * 1024u, lane_b); };
+  auto ld_row1 = [&](rsrc_t src, d2_t (&r)[RU], int u) { r[u] = ldg2<SMW_LOAD_AUX>(src, (unsigned) (w + NR * u) * 1024u, lane_b); };
 #pragma unroll 1
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
   tbuf = bufs_of(tile);
@@ -655,7 +664,7 @@ __global__ __launch_bounds__(SmoothWideCfg<NS>::THREADS, 1) void k_smooth_wide(c
 #pragma unroll
     for (int u = 0; u < RU; u++) {
       const d2_t v = { WS[e[u][0] * 64], WS[e[u][1] * 64] };
-      if (active) stg2(tbuf.out, (unsigned) (w + NR * u) * 1024u, lane_b, v);
+      if (active) stg2<SMW_STORE_AUX>(tbuf.out, (unsigned) (w + NR * u) * 1024u, lane_b, v);
     }
   }
 
