@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 
 #include "rbis_device.hpp"
+#include "rbis_lds_stream.hpp"
 
 // attribution builds (scripts/smooth_attribution.sh lane...): parts compiled OUT, results are garbage, only the time means something
 #if !defined(PB_EXPERIMENTS) && (defined(SML_SKIP_FACT) || defined(SML_SKIP_RHS) || defined(SML_SKIP_SUBST) || defined(SML_SKIP_D) || \
@@ -373,7 +374,39 @@ __global__ __launch_bounds__(SmoothLaneCfg<NS>::THREADS, SmoothLaneCfg<NS>::WAVE
     }
   }
   // ---- 3. (P^-) X = Ad P_k out of the LDS factor: z[t][:] becomes row cidx[t] of G ----
+  // SML_STREAM (21 states): the reads as lds_stream's explicit pipeline of SINGLE ds_read_b64 (rbis_lds_stream.hpp) -- with 8 roles every
+  // entry of the factor is read 8 times, and the paired ds_read2st64_b64 the backend makes of neighbouring reads moves the same bytes in
+  // twice the LDS time (8 x 462 reads x 8 cycles per pair = 15 k of the substitutions' 17 k cycles).  Measured: the substitutions take
+  // 15.1 k instead of 17.2 k cycles and step 4 waits 2 k longer for its rows: 290.7 against 291.1 us per step.  Off.
+#ifndef SML_STREAM
+#define SML_STREAM 0
+#endif
+  constexpr bool STREAM = (NS == 21) && SML_STREAM;
+  const LdsBases lbb{ lane * 8, lane * 8 + 128 * 512, lane * 8 + 256 * 512 };   // (dynamic LDS starts at 0: no static LDS in this kernel)
 #ifndef SML_SKIP_SUBST
+  if constexpr (STREAM) {
+    auto pin_z = [&](auto) {
+#pragma unroll
+      for (int t = 0; t < NCOL; t++)
+#pragma unroll
+        for (int i = 0; i < NS; i++) lane_pin(z[t][i]);
+    };
+    lds_stream<NS *(NS - 1) / 2, SmwLowerByColumn<NS>>(lbb, [&](auto KQ, double l) {
+      constexpr int kq = decltype(KQ)::value, i = SmwLowerByColumn<NS>::row(kq), mm = SmwLowerByColumn<NS>::col(kq);
+#pragma unroll
+      for (int t = 0; t < NCOL; t++) z[t][i] = fma(-l, z[t][mm], z[t][i]);
+    }, pin_z);
+    lds_stream<NS, SmwDiag>(lbb, [&](auto KQ, double inv) {
+      constexpr int i = decltype(KQ)::value;
+#pragma unroll
+      for (int t = 0; t < NCOL; t++) z[t][i] *= inv;
+    }, pin_z);
+    lds_stream<NS *(NS - 1) / 2, SmwUpperByColumn<NS>>(lbb, [&](auto KQ, double l) {
+      constexpr int kq = decltype(KQ)::value, i = SmwUpperByColumn<NS>::ci(kq), mm = SmwUpperByColumn<NS>::cm(kq);
+#pragma unroll
+      for (int t = 0; t < NCOL; t++) z[t][i] = fma(-l, z[t][mm], z[t][i]);
+    }, pin_z);
+  } else {
 #pragma unroll
   for (int i = 1; i < NS; i++)
 #pragma unroll
@@ -399,6 +432,7 @@ __global__ __launch_bounds__(SmoothLaneCfg<NS>::THREADS, SmoothLaneCfg<NS>::WAVE
       for (int t = 0; t < NCOL; t++) z[t][i] = fma(-l, z[t][m], z[t][i]);
       if (m == NS - 1 && (i & 1)) LANE_FENCE(z[0][i + 2 < NS ? i + 2 : NS - 1]);
     }
+  }
 #endif
   // dx = G resid (rbis.cpp:263): this role's entries
   double dxv[NCOL];
