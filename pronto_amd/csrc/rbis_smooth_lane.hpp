@@ -231,8 +231,38 @@ __global__ __launch_bounds__(SmoothLaneCfg<NS>::THREADS, SmoothLaneCfg<NS>::WAVE
   // ---- 1. P^- = L diag(d) L^T ----
   {
     double a[NCOL][NS];
+    // SML_ROWTOP (21 states): P^- comes in by whole 16-byte rows (role w: rows w, w + NR, ...; the table of step 4) into the factor's place,
+    // and every role takes its columns from there -- 17 full-line loads per role instead of 39 eight-byte ones that use half of every
+    // line they touch.  Measured: 292.1 against 291.1 us, the tile's first barrier still comes 14 k cycles in -- every CU asks for its
+    // tile's 129 KB at the same moment (four dispatch rounds in lockstep): the burst is bound by the memory, not by the form of the loads,
+    // and this kernel has neither registers nor LDS to ask earlier.  Off.
+#ifndef SML_ROWTOP
+#define SML_ROWTOP 0
+#endif
+    constexpr bool ROWTOP = (NS == 21) && SML_ROWTOP;
+    if constexpr (ROWTOP) {
+      d2_t rr[C::RU];
 #pragma unroll
-    for (int t = 0; t < NCOL; t++) ld_col(next_pred, t, NR * t, a[t]);  // column w + NR t: rows above NR t are above its diagonal for every role
+      for (int u = 0; u < C::RU; u++) {
+        const int r2 = (w + NR * u < SL::NROW) ? w + NR * u : SL::NROW - 1;
+        rr[u] = *reinterpret_cast<const d2_t *>(next_pred + tb + r2 * 128);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < C::RU; u++) {
+        const int e0 = tab.drow[w][u][0], e1 = tab.drow[w][u][1];
+        if (e0 >= 0) S[e0 * 64] = rr[u].x;
+        if (e1 >= 0) S[e1 * 64] = rr[u].y;
+      }
+      lds_barrier();
+#pragma unroll
+      for (int t = 0; t < NCOL; t++)
+#pragma unroll
+        for (int i = 0; i < NS; i++) a[t][i] = (i >= NR * t) ? S[pk_s(i, cc[t]) * 64] : 0.0;   // (above the column's diagonal: never used)
+    } else {
+#pragma unroll
+      for (int t = 0; t < NCOL; t++) ld_col(next_pred, t, NR * t, a[t]);  // column w + NR t: rows above NR t are above its diagonal for every role
+    }
     if constexpr (EARLY_PK) {
 #pragma unroll
       for (int i = 0; i < 6; i++) ske[i] = ldc(cur, L::OFF_VEC + i);
@@ -246,8 +276,8 @@ __global__ __launch_bounds__(SmoothLaneCfg<NS>::THREADS, SmoothLaneCfg<NS>::WAVE
       bool fix_g = false, fix_a = false;
 #pragma unroll
       for (int i = 0; i < 3; i++) {
-        fix_g = fix_g | (ldc(next_pred, L::OFF_P + pk(15 + i, 15 + i)) < .00000000001);
-        fix_a = fix_a | (ldc(next_pred, L::OFF_P + pk(18 + i, 18 + i)) < .00000000001);
+        fix_g = fix_g | ((ROWTOP ? SE(pk(15 + i, 15 + i)) : ldc(next_pred, L::OFF_P + pk(15 + i, 15 + i))) < .00000000001);
+        fix_a = fix_a | ((ROWTOP ? SE(pk(18 + i, 18 + i)) : ldc(next_pred, L::OFF_P + pk(18 + i, 18 + i))) < .00000000001);
       }
 #pragma unroll
       for (int t = 0; t < NCOL; t++)
